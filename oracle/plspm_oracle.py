@@ -1,0 +1,335 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the PLS-PM metric hot path.
+
+A plain-NumPy, data-level restatement of the reference algorithm (GoogleCloudPlatform/plspm-python
+v0.5.6).  It exists to CHECK the HIP path; only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  The product package (plspm-python_amd/plspm) never does.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
+  (a) the reference's own golden CSVs for this path (tests/golden/ref_data/satisfaction*.csv,
+      originally reference tests/data/, R `plspm` output), and
+  (b) tests/golden/*.npz, produced by importing the real reference in the build container
+      (tests/golden/make_golden.py, interpreter /opt/conda/bin/python3.9 + oracle/refshim.py).
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+The arithmetic works on the N x P observation matrix exactly like the reference does (no
+second-moment shortcut), so that the GPU's Gram formulation is checked against an independent
+formulation.
+
+Conventions: X is the filtered raw data, N x P float64, columns in "data order" (the order of
+Config.add_lv calls, reference config.py:269).  `blocks[l]` lists the columns of LV l, LVs in path
+order.  `C[i, j] = 1` iff LV j -> LV i (reference config.py:95).
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+CENTROID, FACTORIAL, PATH = "centroid", "factorial", "path"
+
+
+@dataclass
+class Model:
+    blocks: List[np.ndarray]          # per LV (path order): column indices into X
+    C: np.ndarray                     # L x L 0/1 lower-triangular path matrix
+    modes: Sequence[str]              # "A" / "B" per LV
+    scheme: str = CENTROID
+    scaled: bool = True
+    max_iter: int = 100
+    tol: float = 1e-6
+
+    def __post_init__(self):
+        self.blocks = [np.asarray(b, dtype=np.int64) for b in self.blocks]
+        self.C = np.asarray(self.C, dtype=np.int64)
+        self.L = len(self.blocks)
+        self.P = int(sum(len(b) for b in self.blocks))
+        # MVs in path-LV order == row order of the reference's `weights` frame (weights.py:31,69)
+        self.mv_order = np.concatenate(self.blocks)
+
+
+class NotConverged(Exception):
+    pass
+
+
+# ----------------------------------------------------------------------------- pre-treatment
+def treat_metric(X: np.ndarray, scaled: bool) -> np.ndarray:
+    """Config.treat metric branch (config.py:299-305) + util.treat (util.py:33-39).
+
+    scaled=True divides the centred data by ONE scalar: std(ddof=1) over all N*P raw values times
+    sqrt((N-1)/N) (config.py:302-303); scaled=False only centres (config.py:305).
+    """
+    n = X.shape[0]
+    Xc = X - X.mean(axis=0)
+    if scaled:
+        g = np.std(X.reshape(-1), ddof=1) * math.sqrt((n - 1) / n)
+        Xc = Xc / g
+    return Xc
+
+
+def correction(n: int) -> float:
+    """plspm.py:65."""
+    return math.sqrt(n / (n - 1))
+
+
+# ----------------------------------------------------------------------------- inner weights
+def scheme_centroid(C, Y):
+    """scheme.py:27-28."""
+    return np.sign(np.corrcoef(Y, rowvar=False) * (C + C.T))
+
+
+def scheme_factorial(C, Y):
+    """scheme.py:36-37 (np.cov default ddof=1)."""
+    return np.cov(Y, rowvar=False) * (C + C.T)
+
+
+def scheme_path(C, Y):
+    """scheme.py:45-54.  OLS without intercept via pinv (statsmodels OLS.fit default method)."""
+    E = C.astype(np.float64)
+    L = C.shape[0]
+    for i in range(L):
+        follow = C[i, :] == 1
+        if C[i, :].sum() > 0:
+            E[follow, i] = np.linalg.pinv(Y[:, follow]) @ Y[:, i]
+        predec = C[:, i] == 1
+        if C[:, i].sum() > 0:
+            E[predec, i] = np.corrcoef(np.column_stack((Y[:, predec], Y[:, i])), rowvar=False)[:, -1][:-1]
+    return E
+
+
+_SCHEMES = {CENTROID: scheme_centroid, FACTORIAL: scheme_factorial, PATH: scheme_path}
+
+
+# ----------------------------------------------------------------------------- outer weights
+def mode_a(Xk, z):
+    """mode.py:28-29: (1/N) X_k' z."""
+    return (Xk.T @ z) / Xk.shape[0]
+
+
+def mode_b(Xk, z):
+    """mode.py:50-52: least squares of z on X_k (LAPACK gelsd, like scipy.linalg.lstsq)."""
+    return np.linalg.lstsq(Xk, z, rcond=None)[0]
+
+
+# ----------------------------------------------------------------------------- the solver
+def init_weights(Xt, model: Model, corr: float) -> np.ndarray:
+    """_MetricWeights.__init__ (weights.py:28-39): W = odm * diag(corr / std1(X odm))."""
+    W = np.zeros((Xt.shape[1], model.L))
+    for l, b in enumerate(model.blocks):
+        W[b, l] = corr / np.std(Xt[:, b].sum(axis=1), ddof=1)
+    return W
+
+
+def iterate(Xt, W, model: Model, corr: float):
+    """_MetricWeights.iterate (weights.py:41-54).  Returns (W_new, convergence)."""
+    w_old = W.sum(axis=1)
+    Y = Xt @ W                                                    # weights.py:43
+    Y = (Y - Y.mean(axis=0)) / np.std(Y, axis=0, ddof=1) / corr   # weights.py:44 (util.treat)
+    E = _SCHEMES[model.scheme](model.C, Y)                        # weights.py:45
+    Z = Y @ E                                                     # weights.py:46
+    Wn = W.copy()
+    for l, b in enumerate(model.blocks):                          # weights.py:47-50
+        Xk = Xt[:, b]
+        Wn[b, l] = mode_a(Xk, Z[:, l]) if model.modes[l] == "A" else mode_b(Xk, Z[:, l])
+    w_new = Wn.sum(axis=1)
+    conv = float(np.sum((np.abs(w_old) - np.abs(w_new)) ** 2))    # weights.py:51-52
+    return Wn, conv
+
+
+def finalize(Xt, W, model: Model, corr: float):
+    """_MetricWeights.calculate (weights.py:56-70).
+
+    Returns (scores N x L, weights P [data-column order], cor P x L, sign L).  The sign rule counts
+    the sign of the correlation of EVERY MV with the LV (the `cor * odm` product yields -0.0 off
+    block and copysign(1, -0.0) = -1, weights.py:62-64); scores are flipped, weights are not.
+    """
+    wf = 1.0 / (np.std(Xt @ W, axis=0, ddof=1) / corr)            # weights.py:57
+    W = W * wf                                                    # weights.py:58-59
+    scores = Xt @ W                                               # weights.py:60
+    xs = np.std(Xt, axis=0, ddof=1)
+    ss = np.std(scores, axis=0, ddof=1)
+    n = Xt.shape[0]
+    cov = (Xt - Xt.mean(axis=0)).T @ (scores - scores.mean(axis=0)) / (n - 1)
+    cor = cov / np.outer(xs, ss)                                  # weights.py:61
+    odm = (W != 0).astype(int)                                    # weights.py:62
+    prod = cor * odm                                              # -0.0 where cor<0 and odm==0
+    sgn_mv = np.copysign(1.0, prod)
+    sign = np.copysign(1.0, sgn_mv.sum(axis=0))                   # weights.py:64
+    if -1 in sign:                                                # weights.py:65-68
+        scores = scores * sign
+    return scores, W.sum(axis=1), cor, sign
+
+
+def solve(Xt, model: Model, corr: float):
+    """WeightsCalculatorFactory.calculate (weights.py:172-187), metric branch.
+
+    Returns dict(scores, weights, iterations, cor, sign).  Raises NotConverged exactly where the
+    reference raises (iteration counter exceeds max_iter, weights.py:183-186).
+    """
+    W = init_weights(Xt, model, corr)
+    iteration = 0
+    while True:
+        iteration += 1
+        W, conv = iterate(Xt, W, model, corr)
+        if conv < model.tol or iteration > model.max_iter:
+            break
+    if iteration > model.max_iter:
+        raise NotConverged("Could not converge after %d iterations" % iteration)
+    scores, weights, cor, sign = finalize(Xt, W, model, corr)
+    return dict(scores=scores, weights=weights, iterations=iteration, cor=cor, sign=sign)
+
+
+# ----------------------------------------------------------------------------- inner model
+def inner_model(C, scores):
+    """InnerModel.__init__ (inner_model.py:58-75): OLS with intercept per endogenous LV.
+
+    Returns (B L x L path coefficients, r2 L, r2_adj L).
+    """
+    L = C.shape[0]
+    n = scores.shape[0]
+    B = np.zeros((L, L))
+    r2 = np.zeros(L)
+    r2_adj = np.zeros(L)
+    for i in range(L):
+        if C[i, :].sum() == 0:
+            continue
+        ivs = np.where(C[i, :] == 1)[0]
+        A = np.column_stack((np.ones(n), scores[:, ivs]))
+        y = scores[:, i]
+        params = np.linalg.pinv(A) @ y
+        resid = y - A @ params
+        yc = y - y.mean()
+        r2[i] = 1.0 - (resid @ resid) / (yc @ yc)
+        B[i, ivs] = params[1:]
+        r2_adj[i] = 1 - (1 - r2[i]) * (n - 1) / (n - C[i, :].sum() - 1)
+    return B, r2, r2_adj
+
+
+def effects(B):
+    """_effects (inner_model.py:33-53).  Returns (pairs [(from, to)], direct, indirect, total)."""
+    L = B.shape[0]
+    indirect = np.zeros_like(B)
+    if L == 2:
+        total = B.copy()
+    else:
+        power = B.copy()
+        for _ in range(1, L):
+            power = power @ B
+            indirect = indirect + power
+        total = B + indirect
+    pairs, d, ind, tot = [], [], [], []
+    for f in range(L):
+        for t in range(L):
+            if f != t and total[t, f] != 0:
+                pairs.append((f, t)); d.append(B[t, f]); ind.append(indirect[t, f]); tot.append(total[t, f])
+    return pairs, np.array(d), np.array(ind), np.array(tot)
+
+
+def crossloadings(Xt, scores):
+    """OuterModel.__init__ (outer_model.py:26): Pearson correlation of every MV with every LV score."""
+    n = Xt.shape[0]
+    Xc = Xt - Xt.mean(axis=0)
+    Sc = scores - scores.mean(axis=0)
+    cov = Xc.T @ Sc / (n - 1)
+    return cov / np.outer(np.std(Xt, axis=0, ddof=1), np.std(scores, axis=0, ddof=1))
+
+
+def loadings(Xt, scores, model: Model):
+    """bootstrap.py:63-64 / outer_model.py:27: own-block crossloading per MV (data-column order)."""
+    cl = crossloadings(Xt, scores)
+    out = np.zeros(Xt.shape[1])
+    for l, b in enumerate(model.blocks):
+        out[b] = cl[b, l]
+    return out
+
+
+# ----------------------------------------------------------------------------- whole fit / bootstrap
+def fit(X, model: Model, corr: Optional[float] = None):
+    """Estimator.estimate + the statistics the hot path feeds (estimator.py:29-55, plspm.py:63-72).
+
+    `corr` defaults to sqrt(N/(N-1)) of X; the bootstrap passes the ORIGINAL fit's value
+    (the calculator is built once, plspm.py:65-67, and cloned per replicate).
+    """
+    n = X.shape[0]
+    if corr is None:
+        corr = correction(n)
+    Xt = treat_metric(X, model.scaled)                            # estimator.py:33
+    s = solve(Xt, model, corr)                                    # estimator.py:39 (== :52, no HOC)
+    B, r2, r2_adj = inner_model(model.C, s["scores"])             # plspm.py:71
+    pairs, d, ind, tot = effects(B)
+    cl = crossloadings(Xt, s["scores"])
+    ld = np.zeros(X.shape[1])
+    for l, b in enumerate(model.blocks):
+        ld[b] = cl[b, l]
+    return dict(treated=Xt, scores=s["scores"], weights=s["weights"], iterations=s["iterations"],
+                sign=s["sign"], path_coef=B, r2=r2, r2_adj=r2_adj, effect_pairs=pairs, direct=d,
+                indirect=ind, total=tot, crossloadings=cl, loadings=ld)
+
+
+def bootstrap_replicate(X, model: Model, idx, corr: float):
+    """One pass of BootstrapProcess.run's loop body (bootstrap.py:54-66) on explicit indices.
+
+    Returns the row [weights (P, data order) | r2 (L) | total (n_eff) | direct (n_eff) |
+    loadings (P)] plus the iteration count; raises NotConverged where the reference would drop
+    the replicate (bare except, bootstrap.py:65-66).
+    """
+    r = fit(X[np.asarray(idx), :], model, corr)
+    row = np.concatenate((r["weights"], r["r2"], r["total"], r["direct"], r["loadings"]))
+    return row, r["iterations"]
+
+
+def summary(samples, original):
+    """_create_summary (bootstrap.py:24-32): columns original, mean, std.error, perc.025, perc.975,
+    t stat.  pandas std = ddof 1; pandas quantile = linear interpolation."""
+    samples = np.asarray(samples, dtype=np.float64)
+    mean = samples.mean(axis=0)
+    sd = samples.std(axis=0, ddof=1)
+    lo = np.quantile(samples, 0.025, axis=0)
+    hi = np.quantile(samples, 0.975, axis=0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.asarray(original, dtype=np.float64) / sd
+    return np.column_stack((original, mean, sd, lo, hi, t))
+
+
+# ----------------------------------------------------------------------------- synthetic data
+SAT_LVS = ["IMAG", "EXPE", "QUAL", "VAL", "SAT", "LOY"]
+SAT_EDGES = [("IMAG", "EXPE"), ("IMAG", "SAT"), ("IMAG", "LOY"), ("EXPE", "QUAL"), ("EXPE", "VAL"),
+             ("EXPE", "SAT"), ("QUAL", "VAL"), ("QUAL", "SAT"), ("VAL", "SAT"), ("SAT", "LOY")]
+
+
+def satisfaction_C():
+    """Path matrix of the 6-LV satisfaction structure (tests/test_regression_metric.py:23-30) in the
+    topological order Structure.path() yields: IMAG, EXPE, QUAL, VAL, SAT, LOY."""
+    C = np.zeros((6, 6), dtype=np.int64)
+    for s, t in SAT_EDGES:
+        C[SAT_LVS.index(t), SAT_LVS.index(s)] = 1
+    return C
+
+
+def chain_C(L):
+    """C5 structure: edges j-1 -> j and j-3 -> j."""
+    C = np.zeros((L, L), dtype=np.int64)
+    for j in range(L):
+        if j - 1 >= 0:
+            C[j, j - 1] = 1
+        if j - 3 >= 0:
+            C[j, j - 3] = 1
+    return C
+
+
+def synth(n, C, mvs_per_lv=10, seed=0, dtype=np.float64):
+    """Synthetic generator of SURVEY.md 8(d): eta_j = sum_i 0.4 C[j,i] eta_i + eps; x_jk = lambda_k
+    eta_j + delta, lambda = linspace(0.5, 0.9, k), delta ~ N(0, 0.6^2).  Draw order: all eta noise
+    first, then MV noise block by block."""
+    rng = np.random.default_rng(seed)
+    L = C.shape[0]
+    eps = rng.standard_normal((n, L))
+    eta = np.zeros((n, L))
+    for j in range(L):
+        eta[:, j] = eps[:, j] + 0.4 * (eta[:, C[j, :] == 1]).sum(axis=1)
+    lam = np.linspace(0.5, 0.9, mvs_per_lv)
+    X = np.empty((n, L * mvs_per_lv), dtype=dtype)
+    for j in range(L):
+        delta = 0.6 * rng.standard_normal((n, mvs_per_lv))
+        X[:, j * mvs_per_lv:(j + 1) * mvs_per_lv] = eta[:, [j]] * lam[None, :] + delta
+    blocks = [np.arange(j * mvs_per_lv, (j + 1) * mvs_per_lv) for j in range(L)]
+    return X, blocks

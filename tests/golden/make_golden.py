@@ -1,0 +1,248 @@
+#!/opt/conda/bin/python3.9
+"""Golden-vector generator (build container only; the reference never travels to the GPU box).
+
+Run:   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+Imports the REAL reference from /root/reference (through oracle/refshim.py, plumbing shims only),
+drives it through its public API / the same internal calls its bootstrap worker makes
+(bootstrap.py:56-64), and stores inputs + outputs as small .npz fixtures in tests/golden/.
+Fixtures are data only.  Iteration counts are observed by wrapping _MetricWeights.iterate with a
+call counter (the reference does not expose them); the solver runs twice per estimate()
+(estimator.py:39,52) so the count is halved.
+"""
+import hashlib
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import refshim  # noqa: E402
+
+refshim.load_reference()
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+import plspm.config as c  # noqa: E402
+import plspm.weights as refw  # noqa: E402
+import plspm.inner_model as refim  # noqa: E402
+import plspm.bootstrap as refboot  # noqa: E402
+from plspm.estimator import Estimator  # noqa: E402
+from plspm.plspm import Plspm  # noqa: E402
+from plspm.mode import Mode  # noqa: E402
+from plspm.scheme import Scheme  # noqa: E402
+
+import plspm_oracle as orc  # noqa: E402  (only for the synthetic generator + structures)
+
+_calls = {"n": 0}
+_orig_iterate = refw._MetricWeights.iterate
+
+
+def _counting_iterate(self, scheme):
+    _calls["n"] += 1
+    return _orig_iterate(self, scheme)
+
+
+refw._MetricWeights.iterate = _counting_iterate
+
+SCHEMES = {"centroid": Scheme.CENTROID, "factorial": Scheme.FACTORIAL, "path": Scheme.PATH}
+
+
+def path_frame(C, lvs):
+    return pd.DataFrame(np.asarray(C, dtype=int), index=lvs, columns=lvs)
+
+
+def build_config(C, lvs, blocks_names, modes, scaled, add_order=None):
+    cfg = c.Config(path_frame(C, lvs), scaled=scaled)
+    for lv in (add_order or lvs):
+        i = lvs.index(lv)
+        cfg.add_lv(lv, Mode.A if modes[i] == "A" else Mode.B, *[c.MV(n) for n in blocks_names[i]])
+    return cfg
+
+
+def run_fit(df, cfg, scheme, lvs, want_scores=True):
+    _calls["n"] = 0
+    m = Plspm(df, cfg, SCHEMES[scheme])
+    iters = _calls["n"] // 2
+    data_cols = [mv for lv in cfg._Config__mvs for mv in cfg._Config__mvs[lv]]  # add_lv order == filtered column order
+    om = m.outer_model()
+    eff = m.effects()
+    out = dict(
+        mv_names=np.array(data_cols),
+        weights=om.loc[data_cols, "weight"].values.astype(float),
+        loadings=om.loc[data_cols, "loading"].values.astype(float),
+        crossloadings=m.crossloadings().loc[data_cols, lvs].values.astype(float),
+        path_coef=m.path_coefficients().loc[lvs, lvs].values.astype(float),
+        r2=m.inner_summary().loc[lvs, "r_squared"].values.astype(float),
+        eff_from=np.array([lvs.index(x) for x in eff["from"]]),
+        eff_to=np.array([lvs.index(x) for x in eff["to"]]),
+        eff_direct=eff["direct"].values.astype(float),
+        eff_indirect=eff["indirect"].values.astype(float),
+        eff_total=eff["total"].values.astype(float),
+        iters=np.array(iters),
+    )
+    if want_scores:
+        out["scores"] = m.scores().loc[:, lvs].values.astype(float)
+    return m, out
+
+
+def boot_rows(df, cfg, scheme, lvs, idx_list, effects_index):
+    """Per-replicate rows exactly as BootstrapProcess.run builds them (bootstrap.py:56-64)."""
+    filtered = cfg.filter(df)
+    n = filtered.shape[0]
+    corr = np.sqrt(n / (n - 1))
+    calc = refw.WeightsCalculatorFactory(cfg, 100, 1e-6, corr, SCHEMES[scheme])
+    est = Estimator(cfg)
+    cols = list(filtered.columns)
+    rows, iters = [], []
+    for idx in idx_list:
+        _calls["n"] = 0
+        fd, sc, w = est.estimate(calc, filtered.iloc[idx, :])
+        iters.append(_calls["n"] // 2)
+        im = refim.InnerModel(cfg.path(), sc)
+        r2 = im.r_squared().loc[lvs].values.astype(float)
+        eff = im.effects()
+        tot = eff.loc[effects_index, "total"].values.astype(float)
+        dire = eff.loc[effects_index, "direct"].values.astype(float)
+        ld = (sc.apply(lambda s: fd.corrwith(s)) * cfg.odm(cfg.path())).sum(axis=1).loc[cols].values.astype(float)
+        wv = w.loc[cols, "weight"].values.astype(float)
+        rows.append(np.concatenate((wv, r2, tot, dire, ld)))
+    return np.array(rows), np.array(iters)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+def save(name, **arrays):
+    p = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(p, **arrays)
+    print("wrote %-40s %7.1f KB" % (name + ".npz", os.path.getsize(p) / 1024))
+
+
+def main():
+    t0 = time.time()
+    sat = pd.read_csv(os.path.join(HERE, "ref_data", "satisfaction.csv"), index_col=0)
+    lvs = orc.SAT_LVS
+    Csat = orc.satisfaction_C()
+    prefixes = dict(IMAG="imag", EXPE="expe", QUAL="qual", VAL="val", SAT="sat", LOY="loy")
+    sat_blocks = [[col for col in sat.columns if col.startswith(prefixes[lv])] for lv in lvs]
+
+    # ---- G1: satisfaction x {A,B,mixed} x {C,F,P} x scaled {F,T}; add_lv order as the reference test (VAL before QUAL)
+    add_order = ["IMAG", "EXPE", "VAL", "QUAL", "SAT", "LOY"]
+    g1 = {}
+    for modes_name, modes in (("A", "AAAAAA"), ("B", "BBBBBB"), ("M", "ABABAB")):
+        for scheme in SCHEMES:
+            for scaled in (False, True):
+                cfg = build_config(Csat, lvs, sat_blocks, modes, scaled, add_order)
+                _, out = run_fit(sat, cfg, scheme, lvs)
+                key = "%s_%s_%d" % (modes_name, scheme, int(scaled))
+                for k, v in out.items():
+                    g1[key + "/" + k] = v
+    save("g1_satisfaction", **g1)
+
+    # ---- G2: synthetic N=2000 x 60 x 6 (matrix regenerated from seed; SHA-256 recorded)
+    X2, blocks2 = orc.synth(2000, Csat, 10, seed=7)
+    names2 = ["x%d" % i for i in range(X2.shape[1])]
+    df2 = pd.DataFrame(X2, columns=names2)
+    bn2 = [[names2[i] for i in b] for b in blocks2]
+    g2 = {"sha256": np.array(sha(X2)), "seed": np.array(7), "n": np.array(2000)}
+    for modes_name, modes in (("A", "AAAAAA"), ("B", "BBBBBB"), ("M", "BABABA")):
+        for scheme in SCHEMES:
+            for scaled in (False, True):
+                cfg = build_config(Csat, lvs, bn2, modes, scaled)
+                _, out = run_fit(df2, cfg, scheme, lvs, want_scores=False)
+                key = "%s_%s_%d" % (modes_name, scheme, int(scaled))
+                for k, v in out.items():
+                    if k != "mv_names":
+                        g2[key + "/" + k] = v
+    save("g2_synth2000", **g2)
+
+    # ---- G3: synthetic 10k x 60 x 6, Mode A, PATH, scaled (BASELINE.json config 2) + score checksums
+    X3, blocks3 = orc.synth(10000, Csat, 10, seed=0)
+    names3 = ["x%d" % i for i in range(X3.shape[1])]
+    df3 = pd.DataFrame(X3, columns=names3)
+    bn3 = [[names3[i] for i in b] for b in blocks3]
+    cfg3 = build_config(Csat, lvs, bn3, "AAAAAA", True)
+    m3, out3 = run_fit(df3, cfg3, "path", lvs)
+    sc3 = out3.pop("scores")
+    out3.pop("mv_names")
+    g3 = dict(out3)
+    g3.update(sha256=np.array(sha(X3)), seed=np.array(0), n=np.array(10000),
+              scores_head=sc3[:64], scores_colsum=sc3.sum(axis=0), scores_gram=sc3.T @ sc3,
+              scores_rows=np.arange(0, 10000, 97), scores_sample=sc3[::97])
+    # G4b: bootstrap rows for 4 seeded index vectors on the 10k data
+    eff_index = list(m3.effects().index)
+    seeds = [11, 12, 13, 14]
+    idx_list = [np.random.RandomState(s).randint(10000, size=10000) for s in seeds]
+    rows, its = boot_rows(df3, cfg3, "path", lvs, idx_list, eff_index)
+    g3.update(boot_seeds=np.array(seeds), boot_rows=rows, boot_iters=its)
+    save("g3_synth10k_path", **g3)
+
+    # ---- G4a: satisfaction bootstrap-by-index (8 explicit index vectors), Mode A centroid unscaled + Mode B path scaled
+    rs = np.random.RandomState(2024)
+    idx8 = rs.randint(250, size=(8, 250)).astype(np.int32)
+    g4 = {"idx": idx8}
+    for tag, modes, scheme, scaled in (("A_centroid_0", "AAAAAA", "centroid", False), ("B_path_1", "BBBBBB", "path", True),
+                                       ("M_factorial_1", "ABABAB", "factorial", True)):
+        cfg = build_config(Csat, lvs, sat_blocks, modes, scaled, add_order)
+        m, _ = run_fit(sat, cfg, scheme, lvs)
+        rows, its = boot_rows(sat, cfg, scheme, lvs, list(idx8), list(m.effects().index))
+        g4[tag + "/rows"] = rows
+        g4[tag + "/iters"] = its
+    save("g4_satisfaction_boot", **g4)
+
+    # ---- G5: sign-rule stress: LV "a" (2 MVs) negatively related to LV "b" (5 MVs) and "c" (4 MVs)
+    rs = np.random.RandomState(5)
+    n5 = 300
+    ea = rs.standard_normal(n5)
+    eb = -0.8 * ea + 0.6 * rs.standard_normal(n5)
+    ec = -0.5 * ea + 0.4 * eb + 0.7 * rs.standard_normal(n5)
+    X5 = np.column_stack([ea[:, None] * np.array([0.8, 0.7]) + 0.5 * rs.standard_normal((n5, 2)),
+                          eb[:, None] * np.array([0.9, 0.8, 0.7, 0.6, 0.8]) + 0.5 * rs.standard_normal((n5, 5)),
+                          ec[:, None] * np.array([0.9, 0.8, 0.7, 0.6]) + 0.5 * rs.standard_normal((n5, 4))])
+    lv5 = ["a", "b", "c"]
+    C5 = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+    names5 = ["m%d" % i for i in range(11)]
+    bn5 = [names5[0:2], names5[2:7], names5[7:11]]
+    df5 = pd.DataFrame(X5, columns=names5)
+    g5 = {"X": X5, "C": C5}
+    for scheme in SCHEMES:
+        for modes in ("AAA", "BBB"):
+            cfg = build_config(C5, lv5, bn5, modes, True)
+            _, out = run_fit(df5, cfg, scheme, lv5)
+            out.pop("mv_names")
+            for k, v in out.items():
+                g5["%s_%s/%s" % (modes, scheme, k)] = v
+    save("g5_sign_rule", **g5)
+
+    # ---- G6: summary statistics (reference _create_summary on a fixed sample matrix)
+    rs = np.random.RandomState(6)
+    samp = rs.standard_normal((37, 5)) * np.array([1, 2, 0.5, 3, 1]) + np.array([0, 1, -1, 2, 0.3])
+    orig = pd.Series(np.array([0.1, 1.2, -0.9, 2.5, 0.2]), index=list("abcde"))
+    summ = refboot._create_summary(pd.DataFrame(samp, columns=list("abcde")), orig)
+    save("g6_summary", samples=samp, original=orig.values, summary=summ.values.astype(float),
+         columns=np.array(list(summ.columns)))
+
+    # ---- G7: reduced BASELINE config 5: N=4000 x 200 x 20, Mode B, FACTORIAL (+ Mode A path), chain structure
+    L7 = 20
+    C7 = orc.chain_C(L7)
+    X7, blocks7 = orc.synth(4000, C7, 10, seed=3)
+    lv7 = ["L%02d" % i for i in range(L7)]
+    names7 = ["x%d" % i for i in range(X7.shape[1])]
+    df7 = pd.DataFrame(X7, columns=names7)
+    bn7 = [[names7[i] for i in b] for b in blocks7]
+    g7 = {"sha256": np.array(sha(X7)), "seed": np.array(3), "n": np.array(4000)}
+    for tag, modes, scheme in (("B_factorial_1", "B" * L7, "factorial"), ("A_path_1", "A" * L7, "path"),
+                               ("B_centroid_1", "B" * L7, "centroid")):
+        cfg = build_config(C7, lv7, bn7, modes, True)
+        _, out = run_fit(df7, cfg, scheme, lv7, want_scores=False)
+        out.pop("mv_names")
+        for k, v in out.items():
+            g7[tag + "/" + k] = v
+    save("g7_chain20", **g7)
+    print("done in %.1f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

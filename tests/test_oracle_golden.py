@@ -1,0 +1,178 @@
+"""Pins oracle/plspm_oracle.py (the CPU restatement) against
+  * golden vectors produced by the REAL reference (tests/golden/make_golden.py), and
+  * the reference's own R-generated golden CSVs (tests/golden/ref_data/, reference tests/data/).
+CPU only.  Tolerance 1e-9 relative: both sides are fp64 NumPy; differences are summation order only.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import plspm_oracle as orc
+from helpers import GOLDEN, assert_close, case_modes, load, satisfaction_oracle_inputs, sha
+
+RTOL = 1e-9
+SCHEMES = ["centroid", "factorial", "path"]
+
+
+def _check_fit(r, g, key, with_scores=True):
+    assert r["iterations"] == int(g[key + "/iters"]), key
+    assert_close(r["weights"], g[key + "/weights"], RTOL, what=key + " weights")
+    assert_close(r["loadings"], g[key + "/loadings"], RTOL, what=key + " loadings")
+    assert_close(r["crossloadings"], g[key + "/crossloadings"], RTOL, 1e-13, what=key + " crossloadings")
+    assert_close(r["path_coef"], g[key + "/path_coef"], RTOL, 1e-13, what=key + " path")
+    assert_close(r["r2"], g[key + "/r2"], RTOL, 1e-13, what=key + " r2")
+    assert [p[0] for p in r["effect_pairs"]] == list(g[key + "/eff_from"])
+    assert [p[1] for p in r["effect_pairs"]] == list(g[key + "/eff_to"])
+    assert_close(r["direct"], g[key + "/eff_direct"], RTOL, 1e-13)
+    assert_close(r["indirect"], g[key + "/eff_indirect"], RTOL, 1e-13)
+    assert_close(r["total"], g[key + "/eff_total"], RTOL, 1e-13)
+    if with_scores:
+        assert_close(r["scores"], g[key + "/scores"], 1e-8, 1e-11, what=key + " scores")
+
+
+@pytest.mark.parametrize("modes", ["A", "B", "M"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("scaled", [0, 1])
+def test_g1_satisfaction(modes, scheme, scaled):
+    g = load("g1_satisfaction")
+    X, blocks, cols = satisfaction_oracle_inputs()
+    key = "%s_%s_%d" % (modes, scheme, scaled)
+    assert list(g[key + "/mv_names"]) == cols
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, bool(scaled))
+    _check_fit(orc.fit(X, model), g, key)
+
+
+@pytest.mark.parametrize("modes", ["A", "B", "M"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("scaled", [0, 1])
+def test_g2_synth2000(modes, scheme, scaled):
+    g = load("g2_synth2000")
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    assert sha(X) == str(g["sha256"]), "synthetic generator stream differs from the one the goldens were made with"
+    key = "%s_%s_%d" % (modes, scheme, scaled)
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes, mixed="BABABA"), scheme, bool(scaled))
+    _check_fit(orc.fit(X, model), g, key, with_scores=False)
+
+
+def test_g3_synth10k_and_bootstrap_rows():
+    g = load("g3_synth10k_path")
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    assert sha(X) == str(g["sha256"])
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    r = orc.fit(X, model)
+    assert r["iterations"] == int(g["iters"]) == 3
+    assert_close(r["weights"], g["weights"], RTOL)
+    assert_close(r["path_coef"], g["path_coef"], RTOL, 1e-13)
+    assert_close(r["r2"], g["r2"], RTOL, 1e-13)
+    assert_close(r["loadings"], g["loadings"], RTOL)
+    assert_close(r["scores"][:64], g["scores_head"], 1e-8, 1e-11)
+    assert_close(r["scores"][::97], g["scores_sample"], 1e-8, 1e-11)
+    assert_close(r["scores"].T @ r["scores"], g["scores_gram"], 1e-8, 1e-8)
+    corr = orc.correction(10000)
+    for s, row, it in zip(g["boot_seeds"], g["boot_rows"], g["boot_iters"]):
+        idx = np.random.RandomState(int(s)).randint(10000, size=10000)
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-13, what="boot seed %d" % s)
+
+
+@pytest.mark.parametrize("tag", ["A_centroid_0", "B_path_1", "M_factorial_1"])
+def test_g4_satisfaction_bootstrap_rows(tag):
+    g = load("g4_satisfaction_boot")
+    X, blocks, _ = satisfaction_oracle_inputs()
+    m, scheme, scaled = tag.split("_")
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(m), scheme, bool(int(scaled)))
+    corr = orc.correction(250)
+    for idx, row, it in zip(g["idx"], g[tag + "/rows"], g[tag + "/iters"]):
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-12, what=tag)
+
+
+@pytest.mark.parametrize("modes", ["AAA", "BBB"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_g5_sign_rule(modes, scheme):
+    g = load("g5_sign_rule")
+    X = g["X"]
+    blocks = [np.arange(0, 2), np.arange(2, 7), np.arange(7, 11)]
+    model = orc.Model(blocks, g["C"], modes, scheme, True)
+    r = orc.fit(X, model)
+    key = "%s_%s" % (modes, scheme)
+    _check_fit(r, g, key)
+    if modes == "AAA":
+        # the stress case does flip LV 0: in-block correlations positive, all-MV vote negative
+        assert r["sign"][0] == -1 and np.all(r["crossloadings"][0:2, 0] < 0) and np.all(r["weights"][0:2] > 0)
+
+
+def test_g6_summary():
+    g = load("g6_summary")
+    assert list(g["columns"]) == ["original", "mean", "std.error", "perc.025", "perc.975", "t stat."]
+    assert_close(orc.summary(g["samples"], g["original"]), g["summary"], 1e-12)
+
+
+@pytest.mark.parametrize("tag", ["B_factorial_1", "A_path_1", "B_centroid_1"])
+def test_g7_chain20(tag):
+    g = load("g7_chain20")
+    C = orc.chain_C(20)
+    X, blocks = orc.synth(4000, C, 10, seed=3)
+    assert sha(X) == str(g["sha256"])
+    m, scheme, scaled = tag.split("_")
+    model = orc.Model(blocks, C, m * 20, scheme, True)
+    _check_fit(orc.fit(X, model), g, tag, with_scores=False)
+
+
+# ------------------------------------------------------------------ the reference's own golden CSVs (R plspm output)
+def _sat_model(scheme, modes="AAAAAA", scaled=False):
+    X, blocks, cols = satisfaction_oracle_inputs()
+    return X, cols, orc.Model(blocks, orc.satisfaction_C(), modes, scheme, scaled)
+
+
+def test_reference_csv_scores_and_outer_model():
+    """reference tests/test_regression_metric.py:44-60 (rtol 1e-7 there)."""
+    X, cols, model = _sat_model("centroid")
+    r = orc.fit(X, model)
+    exp_scores = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.scores.csv"))
+    assert_close(r["scores"], exp_scores[orc.SAT_LVS].values, 1e-7)
+    om = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.outer-model.csv"), index_col=0)
+    assert_close(r["weights"], om.loc[cols, "weight"].values, 1e-7)
+    assert_close(r["loadings"], om.loc[cols, "loading"].values, 1e-7)
+    cl = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.crossloadings.csv"), index_col=0)
+    assert_close(r["crossloadings"], cl.loc[cols, orc.SAT_LVS].values, 1e-7)
+
+
+@pytest.mark.parametrize("scheme,fname", [("path", "satisfaction.outer-model-path.csv"),
+                                          ("factorial", "satisfaction.outer-model-factorial.csv")])
+def test_reference_csv_outer_model_schemes(scheme, fname):
+    """reference tests/test_regression_metric.py:82-94."""
+    X, cols, model = _sat_model(scheme)
+    r = orc.fit(X, model)
+    om = pd.read_csv(os.path.join(GOLDEN, "ref_data", fname), index_col=0)
+    assert_close(r["weights"], om.loc[cols, "weight"].values, 1e-7)
+    assert_close(r["loadings"], om.loc[cols, "loading"].values, 1e-7)
+
+
+def test_reference_csv_inner_model_effects_r2():
+    """reference tests/test_regression_metric.py:47-51, 62-74."""
+    X, cols, model = _sat_model("centroid")
+    r = orc.fit(X, model)
+    lv = orc.SAT_LVS
+    inner = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.inner-model.csv"), index_col=0)
+    for frm in inner.index:
+        assert abs(r["path_coef"][lv.index("SAT"), lv.index(frm)] - inner.loc[frm, "estimate"]) < 1e-7
+    summ = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.inner-summary.csv"), index_col=0)
+    assert_close(r["r2"], summ.loc[lv, "r_squared"].values, 1e-7, 1e-12)
+    eff = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.effects.csv"), index_col=0)
+    mine = {(lv[f], lv[t]): (d, i, tt) for (f, t), d, i, tt in zip(r["effect_pairs"], r["direct"], r["indirect"], r["total"])}
+    assert len(mine) == len(eff) == 15
+    for _, row in eff.iterrows():
+        assert_close(mine[(row["from"], row["to"])], [row["direct"], row["indirect"], row["total"]], 1e-7, 1e-9)
+
+
+def test_reference_csv_mode_b_r2():
+    """reference tests/test_regression_metric.py:96-111."""
+    X, cols, model = _sat_model("centroid", "BBBBBB")
+    r = orc.fit(X, model)
+    summ = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.modeb.inner-summary.csv"), index_col=0)
+    assert_close(r["r2"], summ.loc[orc.SAT_LVS, "r_squared"].values, 1e-7, 1e-12)
