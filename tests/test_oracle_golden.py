@@ -160,7 +160,7 @@ def test_reference_csv_inner_model_effects_r2():
     lv = orc.SAT_LVS
     inner = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.inner-model.csv"), index_col=0)
     for frm in inner.index:
-        assert abs(r["path_coef"][lv.index("SAT"), lv.index(frm)] - inner.loc[frm, "estimate"]) < 1e-7
+        assert abs(r["path_coef"][lv.index("SAT"), lv.index(frm)] - inner.loc[frm, "Estimate"]) < 1e-7
     summ = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.inner-summary.csv"), index_col=0)
     assert_close(r["r2"], summ.loc[lv, "r_squared"].values, 1e-7, 1e-12)
     eff = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.effects.csv"), index_col=0)
