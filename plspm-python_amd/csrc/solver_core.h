@@ -1,0 +1,417 @@
+// PLS-PM iterative weight solver on second moments -- the LDS-resident per-problem stage.
+//
+// One cooperating thread group (a HIP workgroup; std::threads in the CPU emulation build used by
+// tests/test_solver_hostemu.py) solves ONE problem: it turns the augmented raw scatter matrix
+//     M = sum_i c_i [x'_i, 1] [x'_i, 1]^T          (x' = x - shift, shift = full-sample column means)
+// produced by the Gram kernels into everything the reference computes per fit / per bootstrap
+// replicate.  Reference call sites restated here (paths relative to the reference repo):
+//   Config.treat            plspm/config.py:299-305  + util.treat plspm/util.py:33-39   -> moments_to_cov
+//   _MetricWeights.__init__ plspm/weights.py:28-39                                        -> init_weights
+//   _MetricWeights.iterate  plspm/weights.py:41-54                                        -> iterate
+//   Scheme.*.calculate      plspm/scheme.py:27-28, 36-37, 45-54                           -> inner_weights
+//   Mode.*.outer_weights_metric plspm/mode.py:28-29, 50-52                                -> outer step
+//   WeightsCalculatorFactory.calculate plspm/weights.py:172-187                           -> solve loop
+//   _MetricWeights.calculate plspm/weights.py:56-70                                       -> finalize
+//   InnerModel.__init__ / _effects plspm/inner_model.py:58-75, 33-53                      -> inner_model, effects
+//   bootstrap row           plspm/bootstrap.py:58-64                                      -> emit_row
+// The algebra: with S = X^T X / N of the treated data,
+//   var1(Xw) = w'Sw N/(N-1);  cov0(Yhat) = Wn' S Wn;  X'Z/N = S Wn E;  Mode B w = S_bb^-1 (S Wn E)_b;
+//   PATH OLS beta = G_ff^-1 G_fi;  cor(x_p, score_l) = (S W)_pl / sqrt(S_pp).
+//
+// Execution model: every thread of the group runs solve_problem(); `ex.par(n, f)` distributes
+// indices over the group and ends with a group barrier, `ex.one(f)` runs f on thread 0 and
+// barriers.  Every value that crosses threads lives in the workspace (never in a local).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PLSPM_HD __host__ __device__ __forceinline__
+#else
+#define PLSPM_HD inline
+#endif
+
+namespace plspm {
+
+enum { SCHEME_CENTROID = 0, SCHEME_FACTORIAL = 1, SCHEME_PATH = 2 };
+enum { MODE_A = 0, MODE_B = 1 };
+enum { ST_OK = 0, ST_NOT_CONVERGED = 1, ST_SINGULAR = 2, ST_NONFINITE = 3 };
+
+// Tile-packed layout of the symmetric (PA x PA) scatter matrix written by the MFMA Gram kernels:
+// columns are split into T = PA/16 tiles, tile t holds columns 32*(t/2) + 2*i + (t&1), i = 0..15;
+// only tiles (t,u) with t <= u are stored, 256 doubles each, in v_mfma_f64_16x16x4_f64 C/D register
+// order: element (row, col) of a tile sits at ((reg = row/4) * 64 + lane), lane = (row%4)*16 + col.
+PLSPM_HD int packed_tile_of(int p) { return 2 * (p >> 5) + (p & 1); }
+PLSPM_HD int packed_pos_of(int p) { return (p & 31) >> 1; }
+PLSPM_HD long packed_index(int T, int p, int q) {
+    int tp = packed_tile_of(p), tq = packed_tile_of(q), ip = packed_pos_of(p), iq = packed_pos_of(q);
+    int t, u, r, c;
+    if (tp < tq || (tp == tq && ip <= iq)) { t = tp; u = tq; r = ip; c = iq; } else { t = tq; u = tp; r = iq; c = ip; }
+    long tile = (long)t * T - (long)t * (t - 1) / 2 + (u - t);
+    return (tile * 4 + (r >> 2)) * 64 + (r & 3) * 16 + c;
+}
+PLSPM_HD long packed_size(int T) { return (long)T * (T + 1) / 2 * 256; }
+
+struct ModelDesc {
+    int P, L, PA, T;            // MVs, LVs, padded augmented width (multiple of 32), tiles per side
+    int scheme, scaled, max_iter, kmax, n_eff, n_chol;
+    double tol;
+    const int* boff;            // [L+1] first device column of every block (device columns are in path-LV order)
+    const int* lvof;            // [P]   LV of every device column
+    const unsigned char* C;     // [L*L] C[i*L+j] = 1 iff LV j -> LV i
+    const int* mode;            // [L]
+    const int* chol_off;        // [L]   offset of the Mode-B Cholesky factor of block l inside ws.chol (-1 for Mode A)
+    const int* eff_from;        // [n_eff]
+    const int* eff_to;          // [n_eff]
+    const double* shift;        // [P]   column shift applied at upload
+};
+
+struct Workspace {
+    double* S;                  // [P*PS] treated population covariance, S[q*PS+p]
+    int PS;
+    double *w, *wn, *cv, *dv, *sd, *mu;         // [P] each
+    double* V;                  // [P*L]
+    double *Q, *G, *E, *Bm, *Pw, *Pw2, *Ind, *Cs;   // [L*L] each
+    double *a, *wf, *sgn, *r2;  // [L] each
+    double* scr;                // [L*(kmax*kmax+kmax)]
+    double* chol;               // [n_chol]
+    double* scal;               // [8]  0 conv, 1 n, 2 1/(n g^2) or 1/n, 3 status, 4 nonzero-flag
+};
+
+PLSPM_HD long workspace_small_doubles(int P, int L, int kmax, int n_chol) {
+    return 6L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * (kmax * kmax + kmax) + n_chol + 8;
+}
+PLSPM_HD int cov_ld(int P) { return P | 1; }
+
+PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, int n_chol) {
+    double* p = base;
+    ws.w = p; p += P; ws.wn = p; p += P; ws.cv = p; p += P; ws.dv = p; p += P; ws.sd = p; p += P; ws.mu = p; p += P;
+    ws.V = p; p += (long)P * L;
+    ws.Q = p; p += L * L; ws.G = p; p += L * L; ws.E = p; p += L * L; ws.Bm = p; p += L * L;
+    ws.Pw = p; p += L * L; ws.Pw2 = p; p += L * L; ws.Ind = p; p += L * L; ws.Cs = p; p += L * L;
+    ws.a = p; p += L; ws.wf = p; p += L; ws.sgn = p; p += L; ws.r2 = p; p += L;
+    ws.scr = p; p += (long)L * (kmax * kmax + kmax);
+    ws.chol = p; p += n_chol;
+    ws.scal = p;
+}
+
+// In-place Cholesky A = R^T R of a k x k SPD matrix (row-major, ld k, upper part used/overwritten).
+// Returns false when a pivot is not positive (rank-deficient: the reference's pinv/gelsd would return
+// a minimum-norm solution there; the caller flags ST_SINGULAR instead).
+PLSPM_HD bool chol_factor(double* A, int k) {
+    for (int j = 0; j < k; ++j) {
+        double d = A[j * k + j];
+        for (int r = 0; r < j; ++r) d -= A[r * k + j] * A[r * k + j];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[j * k + j] = d;
+        for (int c = j + 1; c < k; ++c) {
+            double s = A[j * k + c];
+            for (int r = 0; r < j; ++r) s -= A[r * k + j] * A[r * k + c];
+            A[j * k + c] = s / d;
+        }
+    }
+    return true;
+}
+// Solve R^T R x = b in place (b -> x).
+PLSPM_HD void chol_solve(const double* R, int k, double* b) {
+    for (int i = 0; i < k; ++i) {
+        double s = b[i];
+        for (int r = 0; r < i; ++r) s -= R[r * k + i] * b[r];
+        b[i] = s / R[i * k + i];
+    }
+    for (int i = k - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int c = i + 1; c < k; ++c) s -= R[i * k + c] * b[c];
+        b[i] = s / R[i * k + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1: packed raw scatter -> treated population covariance S (config.py:299-305, util.py:33-39)
+template <class Ex>
+PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Mp) {
+    const int P = md.P, PS = ws.PS, T = md.T;
+    ex.par(P, [&](int p) { ws.mu[p] = Mp[packed_index(T, md.P, p)]; });   // column sums of the shifted data
+    ex.one([&]() {
+        const double n = Mp[packed_index(T, md.P, md.P)];
+        double fac = 1.0 / n;
+        if (md.scaled) {
+            // g = std1(all N*P raw values) * sqrt((N-1)/N)   (config.py:302), evaluated around the grand mean
+            double tot = 0.0;
+            for (int p = 0; p < P; ++p) tot += ws.mu[p] + n * md.shift[p];
+            const double np_ = n * (double)P, grand = tot / np_;
+            double ss = 0.0;
+            for (int p = 0; p < P; ++p) {
+                const double d = md.shift[p] - grand;
+                ss += Mp[packed_index(T, p, p)] + 2.0 * d * ws.mu[p] + n * d * d;
+            }
+            const double g2 = ss / (np_ - 1.0) * ((n - 1.0) / n);
+            fac = 1.0 / (n * g2);
+        }
+        ws.scal[1] = n;
+        ws.scal[2] = fac;
+        ws.scal[3] = (double)ST_OK;
+    });
+    ex.par(P * P, [&](int e) {
+        const int q = e / P, p = e - q * P;
+        if (p <= q) {
+            const double n = ws.scal[1];
+            const double v = (Mp[packed_index(T, p, q)] - ws.mu[p] * ws.mu[q] / n) * ws.scal[2];
+            ws.S[q * PS + p] = v;
+            ws.S[p * PS + q] = v;
+        }
+    });
+    ex.par(P, [&](int p) { ws.sd[p] = sqrt(ws.S[p * PS + p]); });
+}
+
+// V[p,m] = sum_{q in block m} S[p,q] w[q];   Q[l,m] = sum_{p in block l} w[p] V[p,m]
+template <class Ex>
+PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {
+    const int P = md.P, L = md.L, PS = ws.PS;
+    ex.par(P, [&](int p) {
+        for (int m = 0; m < L; ++m) {
+            double s = 0.0;
+            for (int q = md.boff[m]; q < md.boff[m + 1]; ++q) s += ws.S[q * PS + p] * ws.w[q];
+            ws.V[p * L + m] = s;
+        }
+    });
+    ex.par(L * L, [&](int e) {
+        const int l = e / L, m = e - l * L;
+        double s = 0.0;
+        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += ws.w[p] * ws.V[p * L + m];
+        ws.Q[e] = s;
+    });
+}
+
+// Inner weights E from G = cov0(Yhat) (scheme.py:27-28 / 36-37 / 45-54)
+template <class Ex>
+PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) {
+    const int L = md.L;
+    if (md.scheme == SCHEME_PATH) {
+        ex.par(L, [&](int i) {
+            for (int j = 0; j < L; ++j) ws.E[j * L + i] = 0.0;
+            const int km = md.kmax;
+            double* A = ws.scr + (long)i * (km * km + km);
+            double* rhs = A + km * km;
+            int f[64];
+            int k = 0;
+            for (int j = 0; j < L; ++j) if (md.C[i * L + j]) f[k++] = j;      // predecessors of i ("follow", scheme.py:47)
+            if (k > 0) {
+                for (int r = 0; r < k; ++r) {
+                    for (int c = 0; c < k; ++c) A[r * k + c] = ws.G[f[r] * L + f[c]];
+                    rhs[r] = ws.G[f[r] * L + i];
+                }
+                if (!chol_factor(A, k)) ws.scal[3] = (double)ST_SINGULAR;
+                chol_solve(A, k, rhs);
+                for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = rhs[r];
+            }
+            for (int s = 0; s < L; ++s)                                        // successors of i ("predec", scheme.py:51)
+                if (md.C[s * L + i]) ws.E[s * L + i] = ws.G[s * L + i] / sqrt(ws.G[s * L + s] * ws.G[i * L + i]);
+        });
+    } else {
+        ex.par(L * L, [&](int e) {
+            const int l = e / L, m = e - l * L;
+            const int d = (int)md.C[l * L + m] + (int)md.C[m * L + l];
+            double v = 0.0;
+            if (d) {
+                if (md.scheme == SCHEME_CENTROID) {
+                    const double g = ws.G[e];
+                    v = (g > 0.0) ? 1.0 : ((g < 0.0) ? -1.0 : 0.0);
+                } else {
+                    v = ws.G[e] * corr2 * (double)d;                           // cov1 = cov0 * N/(N-1)
+                }
+            }
+            ws.E[e] = v;
+        });
+    }
+}
+
+// One PLS iteration (weights.py:41-54).  Leaves the convergence measure in ws.scal[0].
+template <class Ex>
+PLSPM_HD void iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) {
+    const int P = md.P, L = md.L;
+    apply_cov(ex, md, ws);
+    ex.par(L, [&](int l) { ws.a[l] = 1.0 / (corr2 * sqrt(ws.Q[l * L + l])); });   // Yhat_l = Y_l / std1 / corr
+    ex.par(L * L, [&](int e) { ws.G[e] = ws.a[e / L] * ws.a[e % L] * ws.Q[e]; });
+    inner_weights(ex, md, ws, corr2);
+    ex.par(P, [&](int p) {                                                         // (S Wn E)[p, lv(p)]  == X'Z/N  (mode.py:29)
+        const int l = md.lvof[p];
+        double s = 0.0;
+        for (int m = 0; m < L; ++m) s += ws.a[m] * ws.V[p * L + m] * ws.E[m * L + l];
+        ws.cv[p] = s;
+        ws.wn[p] = s;
+    });
+    if (md.n_chol > 0) {
+        ex.par(L, [&](int l) {                                                     // Mode B: S_bb w = c_b  (mode.py:51)
+            if (md.mode[l] == MODE_B) {
+                const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
+                chol_solve(ws.chol + md.chol_off[l], k, ws.wn + b0);
+            }
+        });
+    }
+    ex.par(P, [&](int p) { const double d = fabs(ws.w[p]) - fabs(ws.wn[p]); ws.dv[p] = d * d; });
+    ex.one([&]() { double s = 0.0; for (int p = 0; p < P; ++p) s += ws.dv[p]; ws.scal[0] = s; });
+    ex.par(P, [&](int p) { ws.w[p] = ws.wn[p]; });
+}
+
+struct FitOutputs {             // any pointer may be null
+    double* row;                // [2P + L + 2 n_eff]  weights | r2 | total | direct | loadings   (device column order)
+    double* weights;            // [P]
+    double* loadings;           // [P]
+    double* crossloadings;      // [P*L]
+    double* path_coef;          // [L*L]
+    double* r2;                 // [L]
+    double* lv_cov;             // [L*L] population covariance of the (sign-corrected) scores
+    double* indirect;           // [n_eff]
+    double* score_w;            // [P]  sgn_l * w_p / g-free factor: scores = (x' - mu') * score_w summed per block
+    double* score_c;            // [L]  constant term of the score map
+    double* cov;                // [P*P] treated covariance S (row-major)
+    double* mean;               // [P]   column means of the raw data of this problem
+    int8_t* sign;               // [L]
+    int* iters;
+    int* status;
+};
+
+template <class Ex>
+PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Mp, const FitOutputs& out) {
+    const int P = md.P, L = md.L, PS = ws.PS;
+    moments_to_cov(ex, md, ws, Mp);
+    const double n = ws.scal[1];
+    const double corr2 = n / (n - 1.0);
+
+    if (md.n_chol > 0) {
+        ex.par(L, [&](int l) {
+            if (md.mode[l] == MODE_B) {
+                const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
+                double* R = ws.chol + md.chol_off[l];
+                for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) R[r * k + c] = ws.S[(b0 + r) * PS + b0 + c];
+                if (!chol_factor(R, k)) ws.scal[3] = (double)ST_SINGULAR;
+            }
+        });
+    }
+    // init (weights.py:28-39): w_p = corr / std1(sum of the block's MVs) = 1 / sqrt(sum(S_bb))
+    ex.par(L, [&](int l) {
+        double s = 0.0;
+        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) for (int q = md.boff[l]; q < md.boff[l + 1]; ++q) s += ws.S[q * PS + p];
+        ws.wf[l] = 1.0 / sqrt(s);
+    });
+    ex.par(P, [&](int p) { ws.w[p] = ws.wf[md.lvof[p]]; });
+
+    // weights.py:179-186: iteration counter, stop on conv < tol or counter > max_iter, fail if counter > max_iter
+    int iteration = 0;
+    while (true) {
+        ++iteration;
+        iterate(ex, md, ws, corr2);
+        const double conv = ws.scal[0];
+        if (conv < md.tol || iteration > md.max_iter) break;
+    }
+    ex.one([&]() { if (iteration > md.max_iter && ws.scal[3] == (double)ST_OK) ws.scal[3] = (double)ST_NOT_CONVERGED; });
+
+    // finalize (weights.py:56-70)
+    apply_cov(ex, md, ws);
+    ex.par(L, [&](int l) { ws.wf[l] = 1.0 / sqrt(ws.Q[l * L + l]); });        // 1 / (std1(X w_l) / corr)
+    ex.par(P, [&](int p) { ws.w[p] *= ws.wf[md.lvof[p]]; });                  // returned weights: never sign-flipped
+    ex.par(L, [&](int l) {                                                    // sign rule: EVERY MV votes (weights.py:62-64)
+        int vote = 0;
+        for (int p = 0; p < P; ++p) {
+            const double cor = ws.V[p * L + l] * ws.wf[l] / ws.sd[p];
+            vote += (cor < 0.0) ? -1 : 1;
+        }
+        ws.sgn[l] = (vote < 0) ? -1.0 : 1.0;
+    });
+    ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.Cs[e] = ws.sgn[l] * ws.sgn[m] * ws.wf[l] * ws.wf[m] * ws.Q[e]; });
+
+    // inner model (inner_model.py:58-75): OLS with intercept == centred normal equations on the score covariance
+    ex.par(L, [&](int i) {
+        for (int j = 0; j < L; ++j) ws.Bm[i * L + j] = 0.0;
+        ws.r2[i] = 0.0;
+        const int km = md.kmax;
+        double* A = ws.scr + (long)i * (km * km + km);
+        double* rhs = A + km * km;
+        int f[64];
+        int k = 0;
+        for (int j = 0; j < L; ++j) if (md.C[i * L + j]) f[k++] = j;
+        if (k > 0) {
+            for (int r = 0; r < k; ++r) {
+                for (int c = 0; c < k; ++c) A[r * k + c] = ws.Cs[f[r] * L + f[c]];
+                rhs[r] = ws.Cs[f[r] * L + i];
+            }
+            if (!chol_factor(A, k)) ws.scal[3] = (double)ST_SINGULAR;
+            chol_solve(A, k, rhs);
+            double expl = 0.0;
+            for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = rhs[r]; expl += rhs[r] * ws.Cs[f[r] * L + i]; }
+            ws.r2[i] = expl / ws.Cs[i * L + i];
+        }
+    });
+    // effects (inner_model.py:33-53): indirect = sum_{k=2..L} B^k (none when L == 2), total = B + indirect
+    ex.par(L * L, [&](int e) { ws.Ind[e] = 0.0; ws.Pw[e] = ws.Bm[e]; });
+    if (L != 2) {
+        double* cur = ws.Pw;
+        double* nxt = ws.Pw2;
+        for (int k = 2; k <= L; ++k) {
+            ex.par(L * L, [&](int e) {
+                const int r = e / L, c = e - r * L;
+                double s = 0.0;
+                for (int t = 0; t < L; ++t) s += cur[r * L + t] * ws.Bm[t * L + c];
+                nxt[e] = s;
+                ws.Ind[e] += s;
+            });
+            ex.one([&]() {
+                double any = 0.0;
+                for (int e = 0; e < L * L; ++e) if (nxt[e] != 0.0) any = 1.0;
+                ws.scal[4] = any;
+            });
+            if (ws.scal[4] == 0.0) break;             // B is nilpotent: all further powers vanish exactly
+            double* t = cur; cur = nxt; nxt = t;
+        }
+    }
+
+    // outputs
+    ex.par(P, [&](int p) {
+        const int l = md.lvof[p];
+        const double ld = ws.sgn[l] * ws.V[p * L + l] * ws.wf[l] / ws.sd[p];
+        if (out.row) { out.row[p] = ws.w[p]; out.row[P + L + 2 * md.n_eff + p] = ld; }
+        if (out.weights) out.weights[p] = ws.w[p];
+        if (out.loadings) out.loadings[p] = ld;
+        if (out.crossloadings) for (int m = 0; m < L; ++m) out.crossloadings[p * L + m] = ws.sgn[m] * ws.V[p * L + m] * ws.wf[m] / ws.sd[p];
+        // scores_l = sgn_l * sum_p ((x'_p - mu'_p) * sqrt(fac*n)) w_p ; sqrt(fac*n) = 1/g (scaled) or 1
+        const double n_ = ws.scal[1];
+        if (out.score_w) out.score_w[p] = ws.sgn[l] * ws.w[p] * sqrt(ws.scal[2] * n_);
+        if (out.mean) out.mean[p] = ws.mu[p] / n_ + md.shift[p];
+        if (out.cov) for (int q = 0; q < P; ++q) out.cov[p * P + q] = ws.S[q * PS + p];
+    });
+    ex.par(L, [&](int l) {
+        if (out.row) out.row[P + l] = ws.r2[l];
+        if (out.r2) out.r2[l] = ws.r2[l];
+        if (out.sign) out.sign[l] = (int8_t)ws.sgn[l];
+        if (out.score_c) {
+            const double n_ = ws.scal[1];
+            double s = 0.0;
+            for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += (ws.mu[p] / n_) * ws.sgn[l] * ws.w[p] * sqrt(ws.scal[2] * n_);
+            out.score_c[l] = -s;
+        }
+    });
+    ex.par(L * L, [&](int e) {
+        if (out.path_coef) out.path_coef[e] = ws.Bm[e];
+        if (out.lv_cov) out.lv_cov[e] = ws.Cs[e];
+    });
+    ex.par(md.n_eff, [&](int e) {
+        const int idx = md.eff_to[e] * L + md.eff_from[e];
+        if (out.row) { out.row[P + L + e] = ws.Bm[idx] + ws.Ind[idx]; out.row[P + L + md.n_eff + e] = ws.Bm[idx]; }
+        if (out.indirect) out.indirect[e] = ws.Ind[idx];
+    });
+    ex.one([&]() {
+        int st = (int)ws.scal[3];
+        if (st == ST_OK) {
+            bool ok = true;
+            for (int p = 0; p < P; ++p) ok = ok && isfinite(ws.w[p]) && isfinite(ws.sd[p]) && ws.sd[p] > 0.0;
+            for (int l = 0; l < L; ++l) ok = ok && isfinite(ws.r2[l]);
+            if (!ok) st = ST_NONFINITE;
+        }
+        if (out.status) *out.status = st;
+        if (out.iters) *out.iters = iteration;
+    });
+}
+
+}  // namespace plspm

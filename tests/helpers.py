@@ -51,3 +51,47 @@ def rel_err(a, b):
 def assert_close(a, b, rtol, atol=0.0, what=""):
     np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol,
                                err_msg=what)
+
+
+# ----------------------------------------------------------------------------------------------
+# NumPy restatement of the device data layouts (independent of the C++ in csrc/solver_core.h)
+def packed_index_np(T, p, q):
+    p = np.asarray(p); q = np.asarray(q)
+    tp, tq = 2 * (p >> 5) + (p & 1), 2 * (q >> 5) + (q & 1)
+    ip, iq = (p & 31) >> 1, (q & 31) >> 1
+    swap = ~((tp < tq) | ((tp == tq) & (ip <= iq)))
+    t = np.where(swap, tq, tp); u = np.where(swap, tp, tq)
+    r = np.where(swap, iq, ip); c = np.where(swap, ip, iq)
+    tile = t * T - t * (t - 1) // 2 + (u - t)
+    return (tile * 4 + (r >> 2)) * 64 + (r & 3) * 16 + c
+
+
+def padded_width(P):
+    return ((P + 1 + 31) // 32) * 32
+
+
+def packed_scatter(Xdev, counts=None, shift=None):
+    """Augmented raw scatter sum_i c_i [x'_i,1][x'_i,1]^T of the shifted data in the tile-packed layout."""
+    n, P = Xdev.shape
+    PA = padded_width(P)
+    T = PA // 16
+    if shift is None:
+        shift = Xdev.mean(axis=0)
+    Xa = np.zeros((n, PA))
+    Xa[:, :P] = Xdev - shift
+    Xa[:, P] = 1.0
+    c = np.ones(n) if counts is None else np.asarray(counts, dtype=np.float64)
+    M = (Xa * c[:, None]).T @ Xa
+    out = np.zeros(T * (T + 1) // 2 * 256)
+    pp, qq = np.meshgrid(np.arange(PA), np.arange(PA), indexing="ij")
+    out[packed_index_np(T, pp.ravel(), qq.ravel())] = M.ravel()
+    return out, shift, PA
+
+
+def effect_pairs(C):
+    """(from, to) pairs with a directed path from -> to, from-major (the rows of the reference's effects frame)."""
+    L = C.shape[0]
+    reach = (np.asarray(C) != 0)
+    for _ in range(L):
+        reach = reach | ((reach.astype(int) @ reach.astype(int)) > 0)
+    return [(f, t) for f in range(L) for t in range(L) if f != t and reach[t, f]]

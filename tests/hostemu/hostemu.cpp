@@ -1,0 +1,62 @@
+// TEST INFRASTRUCTURE ONLY.  CPU emulation build of the device-side solver (csrc/solver_core.h):
+// the same source the HIP kernel compiles, executed by NT std::threads with a std::barrier playing
+// __syncthreads().  Lets the CPU test-suite (and ThreadSanitizer) check the solver's algebra and its
+// barrier discipline against the oracle without a GPU.  Never loaded by the product package.
+#include <barrier>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../plspm-python_amd/csrc/solver_core.h"
+
+using namespace plspm;
+
+struct HostExec {
+    int tid, nt;
+    std::barrier<>* bar;
+    template <class F> void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); bar->arrive_and_wait(); }
+    template <class F> void one(F f) { if (tid == 0) f(); bar->arrive_and_wait(); }
+};
+
+extern "C" {
+
+// Mp: packed scatter (see packed_index); everything else mirrors ModelDesc / FitOutputs.
+int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                  const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Mp,
+                  int nthreads, double* row, double* crossloadings, double* path_coef, double* lv_cov, double* indirect,
+                  double* score_w, double* score_c, double* cov, double* mean, int8_t* sign, int* iters, int* status) {
+    std::vector<int> lvof(P), chol_off(L, -1);
+    int kmax = 0, n_chol = 0;
+    for (int l = 0; l < L; ++l) {
+        for (int p = boff[l]; p < boff[l + 1]; ++p) lvof[p] = l;
+        int k = 0;
+        for (int j = 0; j < L; ++j) k += C[l * L + j] ? 1 : 0;
+        kmax = k > kmax ? k : kmax;
+        if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += kb * kb; }
+    }
+    ModelDesc md{};
+    md.P = P; md.L = L; md.PA = PA; md.T = PA / 16; md.scheme = scheme; md.scaled = scaled; md.max_iter = max_iter;
+    md.kmax = kmax; md.n_eff = n_eff; md.n_chol = n_chol; md.tol = tol; md.boff = boff; md.lvof = lvof.data(); md.C = C;
+    md.mode = mode; md.chol_off = chol_off.data(); md.eff_from = eff_from; md.eff_to = eff_to; md.shift = shift;
+    const int PS = cov_ld(P);
+    std::vector<double> S((size_t)P * PS), small(workspace_small_doubles(P, L, kmax, n_chol));
+    FitOutputs out{};
+    out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.lv_cov = lv_cov; out.indirect = indirect;
+    out.score_w = score_w; out.score_c = score_c; out.cov = cov; out.mean = mean; out.sign = sign; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            Workspace ws{};
+            ws.S = S.data(); ws.PS = PS;
+            carve_small(ws, small.data(), P, L, kmax, n_chol);
+            HostExec ex{t, nthreads, &bar};
+            solve_problem(ex, md, ws, Mp, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+long hostemu_packed_index(int T, int p, int q) { return packed_index(T, p, q); }
+long hostemu_packed_size(int T) { return packed_size(T); }
+}

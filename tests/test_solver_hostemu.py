@@ -1,0 +1,177 @@
+"""CPU check of the device solver source (csrc/solver_core.h) through the std::thread emulation build in
+tests/hostemu/: second-moment formulation vs the data-level oracle, all Mode x Scheme x scaled cases,
+plus weighted (bootstrap-count) problems, thread-count invariance and a ThreadSanitizer run.
+Tolerance: 1e-9 relative (fp64 both sides; the formulations differ, SURVEY.md A.7 measured <= 6e-13)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import plspm_oracle as orc
+from helpers import (assert_close, case_modes, effect_pairs, packed_index_np, packed_scatter, satisfaction_oracle_inputs)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "hostemu")
+SCHEME_ID = {"centroid": 0, "factorial": 1, "path": 2}
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", EMU, "libplspm_hostemu.so"])
+    return ctypes.CDLL(os.path.join(EMU, "libplspm_hostemu.so"))
+
+
+def _ptr(a, t=ctypes.c_double):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def run_emu(lib, X, model, counts=None, shift=None, nthreads=4):
+    order = model.mv_order
+    Xdev = np.ascontiguousarray(X[:, order])
+    P, L = Xdev.shape[1], model.L
+    Mp, shift, PA = packed_scatter(Xdev, counts, shift)
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
+    C = np.ascontiguousarray(model.C.astype(np.uint8))
+    mode = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    pairs = effect_pairs(model.C)
+    ef = np.array([p[0] for p in pairs], dtype=np.int32)
+    et = np.array([p[1] for p in pairs], dtype=np.int32)
+    ne = len(pairs)
+    row = np.zeros(2 * P + L + 2 * ne); cl = np.zeros((P, L)); pc = np.zeros((L, L)); lc = np.zeros((L, L))
+    ind = np.zeros(max(ne, 1)); sw = np.zeros(P); sc = np.zeros(L); cov = np.zeros((P, P)); mean = np.zeros(P)
+    sign = np.zeros(L, dtype=np.int8); iters = ctypes.c_int(0); status = ctypes.c_int(-1)
+    shift = np.ascontiguousarray(shift, dtype=np.float64)
+    lib.hostemu_solve(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
+                      _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte), _ptr(mode, ctypes.c_int), _ptr(shift), ne,
+                      _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Mp), nthreads, _ptr(row), _ptr(cl), _ptr(pc),
+                      _ptr(lc), _ptr(ind), _ptr(sw), _ptr(sc), _ptr(cov), _ptr(mean), _ptr(sign, ctypes.c_int8),
+                      ctypes.byref(iters), ctypes.byref(status))
+    inv = np.empty(P, dtype=np.int64); inv[order] = np.arange(P)          # data column -> device column
+    w = row[:P][inv]; ld = row[P + L + 2 * ne:][inv]
+    scores = ((Xdev - shift) * sw) @ np.equal.outer(np.repeat(np.arange(L), np.diff(boff)), np.arange(L)).astype(float) + sc
+    return dict(weights=w, r2=row[P:P + L], total=row[P + L:P + L + ne], direct=row[P + L + ne:P + L + 2 * ne], loadings=ld,
+                crossloadings=cl[inv], path_coef=pc, lv_cov=lc, indirect=ind[:ne], sign=sign, iterations=iters.value,
+                status=status.value, pairs=pairs, scores=scores, cov=cov, mean=mean, row=row, inv=inv)
+
+
+def check(e, r, tag=""):
+    assert e["status"] == 0, tag
+    assert e["iterations"] == r["iterations"], tag
+    assert_close(e["weights"], r["weights"], RTOL, what=tag + " weights")
+    assert_close(e["loadings"], r["loadings"], RTOL, what=tag + " loadings")
+    assert_close(e["crossloadings"], r["crossloadings"], RTOL, 1e-13, what=tag + " crossloadings")
+    assert_close(e["path_coef"], r["path_coef"], RTOL, 1e-13, what=tag + " path")
+    assert_close(e["r2"], r["r2"], RTOL, 1e-13, what=tag + " r2")
+    assert e["pairs"] == r["effect_pairs"], tag
+    assert_close(e["total"], r["total"], RTOL, 1e-13)
+    assert_close(e["direct"], r["direct"], RTOL, 1e-13)
+    assert_close(e["indirect"], r["indirect"], RTOL, 1e-13)
+    assert_close(e["scores"], r["scores"], 1e-8, 1e-10, what=tag + " scores")
+    assert np.array_equal(e["sign"], r["sign"].astype(np.int8)), tag
+
+
+def test_packed_index_matches_numpy(emu):
+    emu.hostemu_packed_index.restype = ctypes.c_long
+    for T in (2, 4, 14):
+        PA = 16 * T
+        seen = set()
+        for p in range(PA):
+            for q in range(PA):
+                a = emu.hostemu_packed_index(T, p, q)
+                assert a == int(packed_index_np(T, np.array(p), np.array(q)))
+                assert a == emu.hostemu_packed_index(T, q, p)
+                seen.add(a)
+        assert len(seen) <= T * (T + 1) // 2 * 256 and max(seen) < T * (T + 1) // 2 * 256
+
+
+@pytest.mark.parametrize("modes", ["A", "B", "M"])
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_satisfaction_all_cases(emu, modes, scheme, scaled):
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, scaled)
+    check(run_emu(emu, X, model), orc.fit(X, model), "%s/%s/%d" % (modes, scheme, scaled))
+
+
+@pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
+def test_synth_2000(emu, modes, scheme):
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, True)
+    check(run_emu(emu, X, model), orc.fit(X, model))
+
+
+@pytest.mark.parametrize("modes,scheme", [("B", "factorial"), ("A", "path"), ("B", "path")])
+def test_chain20(emu, modes, scheme):
+    C = orc.chain_C(20)
+    X, blocks = orc.synth(3000, C, 10, seed=3)
+    model = orc.Model(blocks, C, modes * 20, scheme, True)
+    check(run_emu(emu, X, model, nthreads=8), orc.fit(X, model))
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "path"])
+def test_sign_rule_case(emu, scheme):
+    from helpers import load
+    g = load("g5_sign_rule")
+    model = orc.Model([np.arange(0, 2), np.arange(2, 7), np.arange(7, 11)], g["C"], "AAA", scheme, True)
+    e = run_emu(emu, g["X"], model)
+    check(e, orc.fit(g["X"], model))
+    assert e["sign"][0] == -1
+
+
+@pytest.mark.parametrize("tag", ["A_centroid_0", "B_path_1", "M_factorial_1"])
+def test_bootstrap_counts_vs_oracle_and_reference_rows(emu, tag):
+    """Weighted scatter (multiplicities) == the reference run on data.iloc[idx] (bootstrap.py:56-64)."""
+    from helpers import load
+    g = load("g4_satisfaction_boot")
+    X, blocks, _ = satisfaction_oracle_inputs()
+    m, scheme, scaled = tag.split("_")
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(m), scheme, bool(int(scaled)))
+    shift = X[:, model.mv_order].mean(axis=0)
+    for idx, ref_row, it in zip(g["idx"], g[tag + "/rows"], g[tag + "/iters"]):
+        counts = np.bincount(idx, minlength=X.shape[0])
+        e = run_emu(emu, X, model, counts=counts, shift=shift)
+        assert e["status"] == 0 and e["iterations"] == int(it)
+        mine = np.concatenate((e["weights"], e["r2"], e["total"], e["direct"], e["loadings"]))
+        assert_close(mine, ref_row, RTOL, 1e-12, what=tag)
+
+
+def test_thread_count_invariance(emu):
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "path", True)
+    base = run_emu(emu, X, model, nthreads=1)["row"]
+    for nt in (2, 3, 7, 16):
+        assert np.array_equal(base, run_emu(emu, X, model, nthreads=nt)["row"])     # bitwise: no order-dependent reductions
+
+
+def test_not_converged_status(emu):
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=2, tol=1e-30)
+    e = run_emu(emu, X, model)
+    assert e["status"] == 1 and e["iterations"] == 3      # counter runs to max_iter+1 before giving up (weights.py:181-186)
+    with pytest.raises(orc.NotConverged):
+        orc.fit(X, model)
+
+
+def test_singular_block_flagged(emu):
+    X, blocks, _ = satisfaction_oracle_inputs()
+    X = X.copy(); X[:, blocks[2][1]] = X[:, blocks[2][0]]            # duplicate MV inside a Mode-B block
+    model = orc.Model(blocks, orc.satisfaction_C(), "BBBBBB", "centroid", True)
+    assert run_emu(emu, X, model)["status"] == 2
+
+
+def test_thread_sanitizer_clean():
+    subprocess.check_call(["make", "-s", "-C", EMU, "libplspm_hostemu_tsan.so"])
+    code = ("import sys; sys.path[:0]=[%r,%r]; import ctypes, numpy as np; import plspm_oracle as orc; import test_solver_hostemu as t;"
+            "from helpers import satisfaction_oracle_inputs;"
+            "lib=ctypes.CDLL(%r); X,b,_=satisfaction_oracle_inputs();"
+            "[t.run_emu(lib, X, orc.Model(b, orc.satisfaction_C(), m, s, True), nthreads=6) for m in ('AAAAAA','BBBBBB') for s in ('centroid','path')];"
+            "print('tsan-run-done')") % (HERE, os.path.join(os.path.dirname(HERE), "oracle"), os.path.join(EMU, "libplspm_hostemu_tsan.so"))
+    tsan = subprocess.run(["bash", "-c", "ls /usr/lib/gcc/x86_64-linux-gnu/*/libtsan.so | head -1"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "tsan-run-done" in r.stdout, r.stderr[-2000:]
+    assert "data race" not in r.stderr, r.stderr[-4000:]
