@@ -1,0 +1,149 @@
+/*
+ * plspm_hip.h -- C-ABI of libplspm_hip.so, the MI355X (gfx950) estimator backend for the PLS-PM
+ * weight-solver + bootstrap hot path of GoogleCloudPlatform/plspm-python.
+ *
+ * The reference is pure Python and has no FFI of its own; this ABI is the seam a maintainer would bind
+ * with ctypes in place of two internal call sites (paths relative to the reference repository):
+ *
+ *   (i)  WeightsCalculatorFactory.calculate(data, path)      plspm/weights.py:172-187
+ *        called from Estimator.estimate                      plspm/estimator.py:39,52
+ *        -> plspm_model_create + plspm_upload + plspm_fit
+ *   (ii) Bootstrap.__init__ / BootstrapProcess.run           plspm/bootstrap.py:81-117, 45-73
+ *        called from Plspm.__init__                          plspm/plspm.py:78-82
+ *        -> plspm_bootstrap (replicates in [rep_offset, rep_offset + B) of one logical stream, so the
+ *           result does not depend on how replicates are sharded over GPUs / processes)
+ *
+ * Conventions
+ *   - plain C types only; all host buffers caller-allocated, row-major, IEEE fp64 unless noted.
+ *   - "device column order": MVs grouped by LV in path-matrix order, blocks contiguous
+ *     (block_offset[l] .. block_offset[l+1]); the caller supplies the map from its own columns.
+ *   - every function returns 0 on success, > 0 for a numerical/argument condition, < 0 for a
+ *     HIP runtime error; plspm_last_error() returns the text.  Nothing throws across the boundary.
+ *   - one opaque handle per (model, device); handles are independent and may be used from different
+ *     threads; a single handle is not re-entrant.
+ *   - there is NO CPU fallback: without a usable HIP device plspm_model_create fails.
+ */
+#ifndef PLSPM_HIP_H
+#define PLSPM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plspm_model plspm_model_t;
+
+/* Scheme ids (reference plspm/scheme.py:57-63) and Mode ids (plspm/mode.py:64-69). */
+enum { PLSPM_SCHEME_CENTROID = 0, PLSPM_SCHEME_FACTORIAL = 1, PLSPM_SCHEME_PATH = 2 };
+enum { PLSPM_MODE_A = 0, PLSPM_MODE_B = 1 };
+/* Per-problem status written by plspm_fit / plspm_bootstrap. */
+enum {
+    PLSPM_OK = 0,
+    PLSPM_NOT_CONVERGED = 1, /* reference raises Exception("Could not converge ...") weights.py:185-186 */
+    PLSPM_SINGULAR = 2,      /* a Mode-B block / inner regression is rank deficient                        */
+    PLSPM_NONFINITE = 3      /* zero-variance MV or NaN input                                            */
+};
+/* Argument errors returned by the API functions themselves. */
+enum { PLSPM_E_ARG = 100, PLSPM_E_STATE = 101, PLSPM_E_LIMIT = 102 };
+
+/* ABI version of this header; plspm_abi_version() of the loaded library must match. */
+#define PLSPM_ABI_VERSION 1
+int plspm_abi_version(void);
+
+/* Number of HIP devices visible to the process (0 when there is none; never negative). */
+int plspm_device_count(void);
+
+/* Text of the last error on this handle (or of the last failed plspm_model_create when NULL). */
+const char* plspm_last_error(const plspm_model_t* m);
+
+/*
+ * Compile a model specification (reference Config + path matrix + Plspm kwargs, plspm/config.py:89-160,
+ * plspm/plspm.py:35-67) into device descriptors.
+ *   P, L           manifest / latent variable counts (1 <= L <= 64, L <= P <= 254)
+ *   block_offset   [L+1] device-column ranges of the LV blocks
+ *   path           [L*L] row-major 0/1, path[i*L+j] = 1 iff LV j -> LV i; must be strictly lower triangular
+ *   mode           [L]   PLSPM_MODE_A / PLSPM_MODE_B per LV
+ *   scheme         PLSPM_SCHEME_*
+ *   scaled         Config(scaled=...) : divide the centred data by ONE global scalar (config.py:302-303)
+ *   max_iter, tol  already clamped by the caller the way Plspm.__init__ does (plspm.py:54-56)
+ *   device_id      HIP device ordinal
+ * Returns NULL on failure (see plspm_last_error(NULL)).
+ */
+plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_offset, const uint8_t* path, const int32_t* mode,
+                                  int32_t scheme, int32_t scaled, int32_t max_iter, double tol, int32_t device_id);
+void plspm_model_destroy(plspm_model_t* m);
+
+/*
+ * Upload the filtered raw observation matrix (what Config.filter returns, config.py:247-285; no NaNs).
+ *   X          host pointer, dense fp64, src_cols columns x N rows
+ *   layout     0: row-major (element (i,c) at X[i*src_cols + c]);  1: column-major (X[c*N + i])
+ *   col_index  [P] source column of every device column, or NULL for the identity
+ * The matrix stays resident in HBM (shifted by its column means, padded, with a ones column) until the
+ * next upload / destroy.
+ */
+int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols, int32_t layout, const int32_t* col_index);
+
+/* Number of (from,to) effect rows = ordered LV pairs joined by a directed path; from-major order
+ * (reference inner_model.py:46-52).  from/to may be NULL. */
+int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to);
+
+/* Width R = 2P + L + 2*n_eff of one bootstrap row:  weights[P] | r2[L] | total[n_eff] | direct[n_eff] | loadings[P]
+ * (device column order; the reference collects the same five vectors per replicate, bootstrap.py:58-64). */
+int32_t plspm_row_width(const plspm_model_t* m);
+
+/* Outputs of one fit; every pointer may be NULL. */
+typedef struct plspm_fit_result {
+    double* weights;       /* [P]    outer weights, never sign-flipped (weights.py:69)                      */
+    double* loadings;      /* [P]    cor(x_p, score of own LV) after the sign rule (outer_model.py:27)      */
+    double* crossloadings; /* [P*L]  cor(x_p, score_l)                    (outer_model.py:26)               */
+    double* path_coef;     /* [L*L]  inner-model slopes, [i*L+j] = j -> i (inner_model.py:70)               */
+    double* r2;            /* [L]    R^2 per LV, 0 for exogenous          (inner_model.py:71-72)            */
+    double* lv_cov;        /* [L*L]  population covariance of the LV scores                                */
+    double* total;         /* [n_eff] total effects                       (inner_model.py:45-52)            */
+    double* direct;        /* [n_eff]                                                                       */
+    double* indirect;      /* [n_eff]                                                                       */
+    double* scores;        /* [N*L]  LV scores, row-major, sign-corrected (weights.py:60-68)               */
+    double* cov;           /* [P*P]  population covariance of the treated data (device column order)       */
+    double* mean;          /* [P]    raw column means                                                      */
+    int8_t* sign;          /* [L]    the sign vector of weights.py:62-64                                   */
+    int32_t* iterations;   /* [1]    value of the reference's iteration counter when the loop stopped      */
+    int32_t* status;       /* [1]    PLSPM_OK / PLSPM_NOT_CONVERGED / ...                                  */
+} plspm_fit_result_t;
+
+/* One estimate on the uploaded data (Estimator.estimate, estimator.py:29-55, without higher-order constructs). */
+int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out);
+
+/*
+ * B bootstrap replicates (the loop of BootstrapProcess.run, bootstrap.py:54-66).
+ *   rep_offset  global id of the first replicate; replicate r draws its N row indices from a counter-based
+ *               Philox4x32-10 stream keyed by (seed, r), so any sharding reproduces the same rows
+ *   idx         NULL -> on-device RNG;  else [B*N] int32 explicit resample indices in [0, N) (parity testing:
+ *               the reference draws np.random.randint(N, size=N), bootstrap.py:56)
+ *   out         [B*R] host buffer, R = plspm_row_width();  status/iters [B] (may be NULL)
+ * Replicates whose status != PLSPM_OK are the ones the reference silently drops (bootstrap.py:65-66).
+ */
+int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out,
+                    int32_t* status, int32_t* iters);
+
+/* Same, leaving the results in device memory owned by the handle (valid until the next call on it):
+ * *d_out -> [B*R] fp64, *d_status / *d_iters -> [B] int32.  Work is enqueued on the handle's stream;
+ * plspm_sync() waits for it.  Lets a caller hand the buffers to RCCL without a host round trip. */
+int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out,
+                           void** d_status, void** d_iters);
+int plspm_sync(plspm_model_t* m);
+
+/* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
+int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);
+
+/* Kernel timing with HIP events on the handle's own stream (for the roofline figures in bench.py).
+ * kernel ids: 0 resample/compact, 1 gram (MFMA), 2 solver, 3 scores, 4 upload/pack, 5 gram reduce. */
+enum { PLSPM_K_RESAMPLE = 0, PLSPM_K_GRAM = 1, PLSPM_K_SOLVER = 2, PLSPM_K_SCORES = 3, PLSPM_K_PACK = 4, PLSPM_K_REDUCE = 5, PLSPM_K_COUNT = 6 };
+int plspm_profile_enable(plspm_model_t* m, int32_t on);
+int plspm_profile_read(plspm_model_t* m, int32_t kernel_id, double* total_ms, int64_t* launches);
+int plspm_profile_reset(plspm_model_t* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSPM_HIP_H */

@@ -1,0 +1,887 @@
+// libplspm_hip.so -- MI355X (gfx950 / CDNA4) backend for the PLS-PM weight solver + bootstrap hot path.
+// C-ABI: include/plspm_hip.h.  Design, data layout and per-kernel rooflines: DESIGN.md.
+//
+// Pipeline (all fp64, one HIP stream per handle):
+//   upload   : raw X -> column means (two-stage reduce) -> Xa = [X - mean | 1 | 0-pad], N x PA, PA % 32 == 0
+//   bootstrap: resample_kernel  (Philox indices or explicit idx -> LDS histogram -> ordered (row,count) list)
+//              gram_rows/_wide  (fp64 MFMA 16x16x4 weighted Gram  sum_i c_i xa_i xa_i^T, upper tiles, tile-packed)
+//              solver_kernel    (csrc/solver_core.h, LDS-resident PLS iteration + inner model + effects + loadings)
+//   fit      : gram (dense rows, split over workgroups) -> reduce -> solver -> scores (LDS-staged X tile . W)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/plspm_hip.h"
+#include "solver_core.h"
+
+using namespace plspm;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10
+struct u32x4 { uint32_t v[4]; };
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u32x4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+// Resample index i (0 <= i < N) of replicate `rep`: word (i & 3) of Philox(counter = (i >> 2, 0, rep), key = seed),
+// mapped to [0, N) by the 32x32 -> high-word multiply (bias <= N / 2^32).
+__host__ __device__ __forceinline__ u32x4 resample_quad(uint64_t seed, uint64_t rep, uint32_t q) {
+    return philox4x32_10(q, 0u, (uint32_t)rep, (uint32_t)(rep >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__host__ __device__ __forceinline__ int32_t to_index(uint32_t u, uint32_t n) { return (int32_t)mulhi32(u, n); }
+
+// ------------------------------------------------------------------------------------------------ upload kernels
+// Column sums, row-major source: block = 64 columns x 4 row lanes; partial[blockIdx.x][p].
+__global__ void __launch_bounds__(256) colsum_rowmajor_kernel(const double* __restrict__ X, long N, int src_cols, const int* __restrict__ colidx,
+                                                               int P, double* __restrict__ partial) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = lmin(N, r0 + rows_per_block);
+    for (int pbase = 0; pbase < P; pbase += 64) {
+        const int p = pbase + tx;
+        double s = 0.0;
+        if (p < P) {
+            const int c = colidx[p];
+            for (long i = r0 + ty; i < r1; i += 4) s += X[i * src_cols + c];
+        }
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && p < P) partial[(long)blockIdx.x * P + p] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        __syncthreads();
+    }
+}
+// Column sums, column-major source: grid (chunks, P); threads run along the rows.
+__global__ void __launch_bounds__(256) colsum_colmajor_kernel(const double* __restrict__ X, long N, const int* __restrict__ colidx, int P,
+                                                               double* __restrict__ partial) {
+    __shared__ double red[256];
+    const int p = blockIdx.y;
+    const double* col = X + (long)colidx[p] * N;
+    const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = lmin(N, r0 + rows_per_block);
+    double s = 0.0;
+    for (long i = r0 + threadIdx.x; i < r1; i += 256) s += col[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[(long)blockIdx.x * P + p] = red[0];
+}
+__global__ void colmean_kernel(const double* __restrict__ partial, int nblk, int P, long N, double* __restrict__ shift) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * P + p];
+    shift[p] = s / (double)N;
+}
+// Xa[i][p] = X[i][colidx[p]] - shift[p] (p < P), 1 (p == P), 0 (p > P).  Row-major source: one thread per output element.
+__global__ void __launch_bounds__(256) pack_rowmajor_kernel(const double* __restrict__ X, long N, int src_cols, const int* __restrict__ colidx,
+                                                             int P, int PA, const double* __restrict__ shift, double* __restrict__ Xa) {
+    const long total = N * PA;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e / PA;
+        const int p = (int)(e - i * PA);
+        double v = 0.0;
+        if (p < P) v = X[i * src_cols + colidx[p]] - shift[p];
+        else if (p == P) v = 1.0;
+        Xa[e] = v;
+    }
+}
+// Column-major source: 64-row x 32-column LDS transpose tile (reads run along rows, writes along columns).
+__global__ void __launch_bounds__(256) pack_colmajor_kernel(const double* __restrict__ X, long N, const int* __restrict__ colidx, int P, int PA,
+                                                             const double* __restrict__ shift, double* __restrict__ Xa) {
+    __shared__ double tile[32][65];
+    const long i0 = (long)blockIdx.x * 64;
+    const int p0 = blockIdx.y * 32;
+    {
+        const int r = threadIdx.x & 63;
+        for (int c = threadIdx.x >> 6; c < 32; c += 4) {
+            const int p = p0 + c;
+            const long i = i0 + r;
+            double v = 0.0;
+            if (i < N) {
+                if (p < P) v = X[(long)colidx[p] * N + i] - shift[p];
+                else if (p == P) v = 1.0;
+            }
+            tile[c][r] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x & 31;
+        for (int r = threadIdx.x >> 5; r < 64; r += 8) {
+            const long i = i0 + r;
+            if (i < N && p0 + c < PA) Xa[i * PA + p0 + c] = tile[c][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resample + compact
+// One workgroup per replicate: LDS histogram of the N drawn row indices, then an ordered compaction into
+// (row, multiplicity) pairs -- ~63 % of the rows survive, so the Gram kernel issues 37 % fewer MFMAs than a
+// gather of all N draws.  The list is zero-padded to a multiple of 4 entries (one MFMA k-group).
+__global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restrict__ idx, uint64_t seed, int64_t rep0, int2* __restrict__ ent,
+                                                        int* __restrict__ nent, long ent_stride, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);
+    __shared__ int wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long b = blockIdx.x;
+    for (int i = tid; i < N; i += 256) hist[i] = 0u;
+    __syncthreads();
+    if (idx) {
+        const int* my = idx + b * (long)N;
+        for (int i = tid; i < N; i += 256) {
+            const int r = my[i];
+            if ((unsigned)r < (unsigned)N) atomicAdd(&hist[r], 1u);
+            else atomicOr(err, 1);
+        }
+    } else {
+        const uint64_t rep = (uint64_t)(rep0 + b);
+        const int nq = (N + 3) >> 2;
+        for (int q = tid; q < nq; q += 256) {
+            const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < N) atomicAdd(&hist[to_index(u.v[j], (uint32_t)N)], 1u);
+        }
+    }
+    __syncthreads();
+    int2* my_ent = ent + b * ent_stride;
+    int base = 0;
+    for (int c0 = 0; c0 < N; c0 += 256) {
+        const int row = c0 + tid;
+        const int cnt = (row < N) ? (int)hist[row] : 0;
+        const unsigned long long bal = __ballot(cnt > 0);
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        off += __popcll(bal & ((1ull << lane) - 1ull));
+        if (cnt > 0) my_ent[off] = make_int2(row, cnt);
+        base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    const int padded = (base + 3) & ~3;
+    if (tid < padded - base) my_ent[base + tid] = make_int2(0, 0);
+    if (tid == 0) nent[b] = base;
+}
+
+// ------------------------------------------------------------------------------------------------ Gram (fp64 MFMA)
+// v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; for the
+// Gram both are the SAME element xa[row_k][col_t(l&15)] (A additionally times the multiplicity), so one 16-byte
+// load per 32 columns feeds two tiles: lane (k, i) reads columns 32*g + 2i, 2i+1 of row k -> tile 2g holds the even
+// columns of group g, tile 2g+1 the odd ones (packed_tile_of / packed_pos_of in solver_core.h).
+// Lane l ends up with D[(l>>4) + 4*reg][l&15] in acc[reg].
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+template <int T>
+struct TileIdx {
+    static constexpr int NTILE = T * (T + 1) / 2;
+    __host__ __device__ static constexpr int of(int t, int u) { return t * T - t * (t - 1) / 2 + (u - t); }
+};
+
+// Rows-split variant (T <= 4): every wave of the 256-thread workgroup keeps ALL upper tiles and takes every 4th
+// k-group of the (row,count) list; a two-level LDS tree adds the four partial accumulators at the end.
+template <int T, bool DENSE>
+__global__ void __launch_bounds__(256) gram_rows_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
+                                                         const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
+    constexpr int NT = TileIdx<T>::NTILE, G = T / 2, PA = 16 * T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* red = reinterpret_cast<double*>(smem_raw);      // [2][NT*256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane >> 4, i = lane & 15;
+    const long problem = blockIdx.y;
+    const int nchunks = gridDim.x, chunk = blockIdx.x;
+    const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
+    const long ng = DENSE ? ((N + 3) >> 2) : (long)((nent[problem] + 3) >> 2);
+    const long gstride = (long)nchunks * 4;
+
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    long g = (long)chunk * 4 + wave;
+    long row = 0; double cnt = 0.0;
+    double2 v[G];
+    auto fetch = [&](long gg) {
+        if (DENSE) { const long r = 4 * gg + k; cnt = (r < N) ? 1.0 : 0.0; row = (r < N) ? r : (N - 1); }
+        else { const int2 en = e[4 * gg + k]; row = en.x; cnt = (double)en.y; }
+        const double2* xr = reinterpret_cast<const double2*>(Xa + row * PA);
+#pragma unroll
+        for (int q = 0; q < G; ++q) v[q] = xr[q * 16 + i];
+    };
+    if (g < ng) fetch(g);
+    while (g < ng) {
+        double x[T], a[T];
+#pragma unroll
+        for (int q = 0; q < G; ++q) { x[2 * q] = v[q].x; x[2 * q + 1] = v[q].y; }
+#pragma unroll
+        for (int t = 0; t < T; ++t) a[t] = DENSE ? ((cnt != 0.0) ? x[t] : 0.0) : cnt * x[t];
+        const long gn = g + gstride;
+        if (gn < ng) fetch(gn);                 // software prefetch of the next k-group under the MFMAs below
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int u = t; u < T; ++u) acc[TileIdx<T>::of(t, u)] = MFMA_F64(a[t], x[u], acc[TileIdx<T>::of(t, u)]);
+        g = gn;
+    }
+    // tree reduce: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores.
+    if (wave >= 2) {
+        double* dst = red + (long)(wave - 2) * NT * 256;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const double* src = red + (long)wave * NT * 256;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += src[(t * 4 + r) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double* dst = out + (problem * nchunks + chunk) * (long)(NT * 256);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64 + lane] = acc[t][r] + red[(t * 4 + r) * 64 + lane];
+    }
+}
+
+// Tile-split variant (6 <= T <= 16): the NW waves of a workgroup walk the SAME k-groups; wave W owns the upper tiles
+// whose linear index == W (mod NW), so no reduction is needed and the accumulators stay within the register file.
+template <int T, int NW, int W, bool DENSE>
+__device__ __forceinline__ void gram_wide_body(const double* __restrict__ Xa, long N, const int2* __restrict__ e, long ng, int chunk, int nchunks,
+                                                double* __restrict__ dst, int lane) {
+    constexpr int NT = TileIdx<T>::NTILE, G = T / 2, PA = 16 * T, MINE = (NT - W + NW - 1) / NW;
+    const int k = lane >> 4, i = lane & 15;
+    d4 acc[MINE];
+#pragma unroll
+    for (int t = 0; t < MINE; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    long row = 0; double cnt = 0.0;
+    double2 v[G];
+    auto fetch = [&](long gg) {
+        if (DENSE) { const long r = 4 * gg + k; cnt = (r < N) ? 1.0 : 0.0; row = (r < N) ? r : (N - 1); }
+        else { const int2 en = e[4 * gg + k]; row = en.x; cnt = (double)en.y; }
+        const double2* xr = reinterpret_cast<const double2*>(Xa + row * PA);
+#pragma unroll
+        for (int q = 0; q < G; ++q) v[q] = xr[q * 16 + i];
+    };
+    long g = chunk;
+    if (g < ng) fetch(g);
+    while (g < ng) {
+        double x[T], a[T];
+#pragma unroll
+        for (int q = 0; q < G; ++q) { x[2 * q] = v[q].x; x[2 * q + 1] = v[q].y; }
+#pragma unroll
+        for (int t = 0; t < T; ++t) a[t] = DENSE ? ((cnt != 0.0) ? x[t] : 0.0) : cnt * x[t];
+        const long gn = g + nchunks;
+        if (gn < ng) fetch(gn);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int u = t; u < T; ++u) {
+                const int li = TileIdx<T>::of(t, u);
+                if (li % NW == W) acc[li / NW] = MFMA_F64(a[t], x[u], acc[li / NW]);
+            }
+        g = gn;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int u = t; u < T; ++u) {
+            const int li = TileIdx<T>::of(t, u);
+            if (li % NW == W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(li * 4 + r) * 64 + lane] = acc[li / NW][r];
+            }
+        }
+}
+template <int T, int NW, int W, bool DENSE>
+struct WideDispatch {
+    __device__ static void run(int wave, const double* Xa, long N, const int2* e, long ng, int chunk, int nchunks, double* dst, int lane) {
+        if (wave == W) gram_wide_body<T, NW, W, DENSE>(Xa, N, e, ng, chunk, nchunks, dst, lane);
+        else WideDispatch<T, NW, W + 1, DENSE>::run(wave, Xa, N, e, ng, chunk, nchunks, dst, lane);
+    }
+};
+template <int T, int NW, bool DENSE>
+struct WideDispatch<T, NW, NW, DENSE> {
+    __device__ static void run(int, const double*, long, const int2*, long, int, int, double*, int) {}
+};
+template <int T, int NW, bool DENSE>
+__global__ void __launch_bounds__(NW * 64) gram_wide_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
+                                                             const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long problem = blockIdx.y;
+    const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
+    const long ng = DENSE ? ((N + 3) >> 2) : (long)((nent[problem] + 3) >> 2);
+    double* dst = out + (problem * gridDim.x + blockIdx.x) * (long)(TileIdx<T>::NTILE * 256);
+    WideDispatch<T, NW, 0, DENSE>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
+}
+
+// out[e] = sum over chunks of partial[chunk][e]  (fixed order: deterministic)
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const double* __restrict__ partial, int nchunks, long size, double* __restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= size) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(long)c * size + e];
+    out[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ solver kernel
+struct DevExec {
+    int tid, nt;
+    template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
+    template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
+};
+struct SolverOut {      // per-problem strides; null base pointers are skipped
+    double* row; long row_stride;
+    int* status; int* iters;
+    FitOutputs fit;     // single-fit extras (problem 0 only)
+};
+// LDS: [S (if s_in_lds)] [small workspace (if small_in_lds)]; otherwise the global scratch areas are used.
+__global__ void solver_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, int s_in_lds, int small_in_lds,
+                              double* gS, double* gsmall) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    const int PS = cov_ld(md.P);
+    const long s_doubles = (long)md.P * PS, small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    Workspace ws;
+    ws.PS = PS;
+    double* lp = lds;
+    if (s_in_lds) { ws.S = lp; lp += s_doubles; } else ws.S = gS + b * s_doubles;
+    carve_small(ws, small_in_lds ? lp : gsmall + b * small_doubles, md.P, md.L, md.kmax, md.n_chol);
+    FitOutputs out = so.fit;
+    if (b != 0) out = FitOutputs{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x};
+    solve_problem(ex, md, ws, Mp + b * mp_stride, out);
+}
+
+// ------------------------------------------------------------------------------------------------ scores kernel
+// scores[i][l] = sum_{p in block l} xa[i][p] * score_w[p] + score_c[l]   (weights.py:60, sign rule folded into score_w)
+// A 64-row tile of Xa is staged in LDS with coalesced 16-byte loads (row stride PA+1 doubles: conflict-free column
+// walks); thread (row, l-group) then forms the short per-block dot products and the tile's scores leave through LDS
+// as one contiguous 64*L block.
+__global__ void __launch_bounds__(256) scores_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, const int* __restrict__ boff,
+                                                      const double* __restrict__ score_w, const double* __restrict__ score_c,
+                                                      double* __restrict__ scores, int stage_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);     // [64][PA+1]
+    double* wsh = tile + 64 * (PA + 1);                     // [P]
+    double* osh = wsh + P;                                  // [64*L]
+    const int tid = threadIdx.x;
+    for (int p = tid; p < P; p += 256) wsh[p] = score_w[p];
+    const long ntiles = (N + 63) / 64;
+    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long i0 = tl * 64;
+        const int rows = (int)lmin(64, N - i0);
+        __syncthreads();
+        const double2* src = reinterpret_cast<const double2*>(Xa + i0 * PA);
+        const int n2 = rows * PA / 2;
+        for (int e = tid; e < n2; e += 256) {
+            const double2 v = src[e];
+            const int r = (2 * e) / PA, c = (2 * e) - r * PA;
+            tile[r * (PA + 1) + c] = v.x;
+            tile[r * (PA + 1) + c + 1] = v.y;
+        }
+        __syncthreads();
+        const int r = tid & 63;
+        for (int l = tid >> 6; l < L; l += 4) {
+            double s = 0.0;
+            for (int p = boff[l]; p < boff[l + 1]; ++p) s += tile[r * (PA + 1) + p] * wsh[p];
+            if (stage_out) osh[r * L + l] = s + score_c[l];
+            else if (r < rows) scores[(i0 + r) * L + l] = s + score_c[l];
+        }
+        __syncthreads();
+        double* dst = scores + i0 * L;
+        if (stage_out) for (int e = tid; e < rows * L; e += 256) dst[e] = osh[e];
+    }
+}
+
+// ================================================================================================ host side
+static thread_local std::string g_create_error;
+
+struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double total_ms = 0.0; int64_t launches = 0; };
+
+struct plspm_model {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int P = 0, L = 0, PA = 0, T = 0, scheme = 0, scaled = 1, max_iter = 100, kmax = 0, n_eff = 0, n_chol = 0;
+    double tol = 1e-6;
+    std::vector<int> boff, lvof, mode, chol_off, eff_from, eff_to;
+    std::vector<uint8_t> C;
+    int *d_boff = nullptr, *d_lvof = nullptr, *d_mode = nullptr, *d_chol_off = nullptr, *d_eff_from = nullptr, *d_eff_to = nullptr;
+    uint8_t* d_C = nullptr;
+    double* d_shift = nullptr;
+    int64_t N = 0;
+    double* d_Xa = nullptr;
+    // grow-only device scratch
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err;
+    bool profiling = false;
+    ProfSlot prof[PLSPM_K_COUNT];
+    std::string error;
+};
+
+static int fail(plspm_model* m, int code, const std::string& msg) {
+    if (m) m->error = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(m, call)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e__ = (call);                                                                                \
+        if (e__ != hipSuccess) return fail((m), -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+static int ensure(plspm_model* m, plspm_model::Buf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIPCHK(m, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    HIPCHK(m, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+static const size_t kMaxLds = 160 * 1024;
+// Dynamic LDS beyond the 64 KiB default needs an explicit opt-in per kernel.
+static int allow_lds(plspm_model* m, const void* fn, size_t bytes) {
+    if (bytes > kMaxLds) return fail(m, PLSPM_E_LIMIT, "kernel needs more than 160 KiB of LDS");
+    if (bytes > 48 * 1024) HIPCHK(m, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+struct ProfScope {
+    plspm_model* m; int id; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(plspm_model* m_, int id_) : m(m_), id(id_) {
+        if (m->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, m->stream); }
+    }
+    ~ProfScope() {
+        if (m->profiling) { hipEventRecord(b, m->stream); m->prof[id].ev.emplace_back(a, b); }
+    }
+};
+static void prof_collect(plspm_model* m) {
+    for (int k = 0; k < PLSPM_K_COUNT; ++k) {
+        for (auto& pr : m->prof[k].ev) {
+            float ms = 0.f;
+            hipEventSynchronize(pr.second);
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            m->prof[k].total_ms += ms; m->prof[k].launches += 1;
+            hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+        }
+        m->prof[k].ev.clear();
+    }
+}
+
+static ModelDesc make_desc(const plspm_model* m) {
+    ModelDesc md{};
+    md.P = m->P; md.L = m->L; md.PA = m->PA; md.T = m->T; md.scheme = m->scheme; md.scaled = m->scaled; md.max_iter = m->max_iter;
+    md.kmax = m->kmax; md.n_eff = m->n_eff; md.n_chol = m->n_chol; md.tol = m->tol;
+    md.boff = m->d_boff; md.lvof = m->d_lvof; md.C = m->d_C; md.mode = m->d_mode; md.chol_off = m->d_chol_off;
+    md.eff_from = m->d_eff_from; md.eff_to = m->d_eff_to; md.shift = m->d_shift;
+    return md;
+}
+
+template <class Tv>
+static int upload_vec(plspm_model* m, Tv** dst, const std::vector<Tv>& v) {
+    const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(Tv);
+    HIPCHK(m, hipMalloc((void**)dst, bytes));
+    if (!v.empty()) HIPCHK(m, hipMemcpy(*dst, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+int plspm_abi_version(void) { return PLSPM_ABI_VERSION; }
+
+int plspm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* plspm_last_error(const plspm_model_t* m) { return m ? m->error.c_str() : g_create_error.c_str(); }
+
+plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_offset, const uint8_t* path, const int32_t* mode, int32_t scheme,
+                                  int32_t scaled, int32_t max_iter, double tol, int32_t device_id) {
+    g_create_error.clear();
+    if (!block_offset || !path || !mode) { fail(nullptr, PLSPM_E_ARG, "null argument"); return nullptr; }
+    if (L < 1 || L > 64 || P < L || P > 254) { fail(nullptr, PLSPM_E_LIMIT, "limits: 1 <= L <= 64, L <= P <= 254"); return nullptr; }
+    if (scheme < 0 || scheme > 2 || !(tol > 0.0) || max_iter < 1) { fail(nullptr, PLSPM_E_ARG, "bad scheme / tolerance / max_iter"); return nullptr; }
+    if (block_offset[0] != 0 || block_offset[L] != P) { fail(nullptr, PLSPM_E_ARG, "block_offset must run from 0 to P"); return nullptr; }
+    for (int l = 0; l < L; ++l) {
+        if (block_offset[l + 1] <= block_offset[l]) { fail(nullptr, PLSPM_E_ARG, "every LV needs at least one MV"); return nullptr; }
+        if (mode[l] != PLSPM_MODE_A && mode[l] != PLSPM_MODE_B) { fail(nullptr, PLSPM_E_ARG, "mode must be A(0) or B(1)"); return nullptr; }
+        for (int j = 0; j < L; ++j) {
+            if (path[l * L + j] > 1) { fail(nullptr, PLSPM_E_ARG, "path entries must be 0/1"); return nullptr; }
+            if (j >= l && path[l * L + j]) { fail(nullptr, PLSPM_E_ARG, "path matrix must be strictly lower triangular"); return nullptr; }
+        }
+    }
+    int ndev = plspm_device_count();
+    if (ndev <= 0) { fail(nullptr, PLSPM_E_STATE, "no HIP device visible: libplspm_hip has no CPU fallback"); return nullptr; }
+    if (device_id < 0 || device_id >= ndev) { fail(nullptr, PLSPM_E_ARG, "device_id out of range"); return nullptr; }
+    plspm_model* m = new (std::nothrow) plspm_model();
+    if (!m) { fail(nullptr, PLSPM_E_STATE, "out of host memory"); return nullptr; }
+    m->device = device_id; m->P = P; m->L = L; m->scheme = scheme; m->scaled = scaled ? 1 : 0; m->max_iter = max_iter; m->tol = tol;
+    m->PA = ((P + 1 + 31) / 32) * 32; m->T = m->PA / 16;
+    m->boff.assign(block_offset, block_offset + L + 1);
+    m->mode.assign(mode, mode + L);
+    m->C.assign(path, path + (size_t)L * L);
+    m->lvof.resize(P); m->chol_off.assign(L, -1);
+    for (int l = 0; l < L; ++l) {
+        for (int p = m->boff[l]; p < m->boff[l + 1]; ++p) m->lvof[p] = l;
+        int k = 0;
+        for (int j = 0; j < L; ++j) k += m->C[l * L + j] ? 1 : 0;
+        m->kmax = std::max(m->kmax, k);
+        if (mode[l] == PLSPM_MODE_B) { const int kb = m->boff[l + 1] - m->boff[l]; m->chol_off[l] = m->n_chol; m->n_chol += kb * kb; }
+    }
+    // transitive closure -> effect rows (from-major), inner_model.py:46-52
+    std::vector<uint8_t> reach(m->C);
+    for (int k = 0; k < L; ++k) for (int i = 0; i < L; ++i) for (int j = 0; j < L; ++j)
+        if (reach[i * L + k] && reach[k * L + j]) reach[i * L + j] = 1;
+    for (int f = 0; f < L; ++f) for (int t = 0; t < L; ++t)
+        if (f != t && reach[t * L + f]) { m->eff_from.push_back(f); m->eff_to.push_back(t); }
+    m->n_eff = (int)m->eff_from.size();
+
+    auto bail = [&](const std::string& why) { g_create_error = why + (m->error.empty() ? "" : (": " + m->error)); plspm_model_destroy(m); return (plspm_model_t*)nullptr; };
+    if (hipSetDevice(device_id) != hipSuccess) return bail("hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+    if (upload_vec(m, &m->d_boff, m->boff) || upload_vec(m, &m->d_lvof, m->lvof) || upload_vec(m, &m->d_mode, m->mode) ||
+        upload_vec(m, &m->d_chol_off, m->chol_off) || upload_vec(m, &m->d_eff_from, m->eff_from) || upload_vec(m, &m->d_eff_to, m->eff_to) ||
+        upload_vec(m, &m->d_C, m->C))
+        return bail("descriptor upload failed");
+    if (hipMalloc((void**)&m->d_shift, sizeof(double) * P) != hipSuccess) return bail("hipMalloc failed");
+    return m;
+}
+
+void plspm_model_destroy(plspm_model_t* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    prof_collect(m);
+    void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
+                    m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
+                    m->fitout.p, m->idx.p, m->err.p};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to) {
+    if (!m) return 0;
+    for (int e = 0; e < m->n_eff; ++e) { if (from) from[e] = m->eff_from[e]; if (to) to[e] = m->eff_to[e]; }
+    return m->n_eff;
+}
+int32_t plspm_row_width(const plspm_model_t* m) { return m ? 2 * m->P + m->L + 2 * m->n_eff : 0; }
+
+int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols, int32_t layout, const int32_t* col_index) {
+    if (!m) return PLSPM_E_ARG;
+    if (!X || N < 2 || src_cols < 1 || (layout != 0 && layout != 1)) return fail(m, PLSPM_E_ARG, "plspm_upload: bad arguments");
+    if (N > 0x7fffffffLL - 64) return fail(m, PLSPM_E_LIMIT, "plspm_upload: N must fit in int32");
+    std::vector<int> ci(m->P);
+    for (int p = 0; p < m->P; ++p) {
+        ci[p] = col_index ? col_index[p] : p;
+        if (ci[p] < 0 || ci[p] >= src_cols) return fail(m, PLSPM_E_ARG, "plspm_upload: col_index out of range");
+    }
+    HIPCHK(m, hipSetDevice(m->device));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (m->d_Xa) { HIPCHK(m, hipFree(m->d_Xa)); m->d_Xa = nullptr; }
+    m->N = 0;
+    double* d_raw = nullptr; int* d_ci = nullptr; double* d_partial = nullptr;
+    const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
+    auto cleanup = [&]() { if (d_raw) hipFree(d_raw); if (d_ci) hipFree(d_ci); if (d_partial) hipFree(d_partial); };
+#define UPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(m, -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+    UPCHK(hipMalloc((void**)&d_raw, raw_bytes));
+    UPCHK(hipMalloc((void**)&d_ci, sizeof(int) * m->P));
+    UPCHK(hipMalloc((void**)&m->d_Xa, (size_t)N * m->PA * sizeof(double)));
+    UPCHK(hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
+    UPCHK(hipMemcpyAsync(d_ci, ci.data(), sizeof(int) * m->P, hipMemcpyHostToDevice, m->stream));
+    const int nblk = (int)std::min<int64_t>(1024, (N + 255) / 256);
+    UPCHK(hipMalloc((void**)&d_partial, sizeof(double) * (size_t)nblk * m->P));
+    {
+        ProfScope ps(m, PLSPM_K_PACK);
+        if (layout == 0) {
+            hipLaunchKernelGGL(colsum_rowmajor_kernel, dim3(nblk), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, m->P, d_partial);
+        } else {
+            hipLaunchKernelGGL(colsum_colmajor_kernel, dim3(nblk, m->P), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, m->P, d_partial);
+        }
+        hipLaunchKernelGGL(colmean_kernel, dim3((m->P + 63) / 64), dim3(64), 0, m->stream, d_partial, nblk, m->P, (long)N, m->d_shift);
+        if (layout == 0) {
+            const long total = (long)N * m->PA;
+            const int grid = (int)std::min<long>(4096, (total + 255) / 256);
+            hipLaunchKernelGGL(pack_rowmajor_kernel, dim3(grid), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, m->P, m->PA, m->d_shift, m->d_Xa);
+        } else {
+            hipLaunchKernelGGL(pack_colmajor_kernel, dim3((unsigned)((N + 63) / 64), m->PA / 32), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, m->P, m->PA,
+                               m->d_shift, m->d_Xa);
+        }
+    }
+    UPCHK(hipGetLastError());
+    UPCHK(hipStreamSynchronize(m->stream));
+#undef UPCHK
+    cleanup();
+    m->N = N;
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+template <bool DENSE>
+static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* ent, const int* nent, long ent_stride, double* out) {
+    const dim3 grid(nchunks, (unsigned)nproblems);
+    const long N = m->N;
+    hipStream_t s = m->stream;
+#define ROWS(TT)                                                                                                         \
+    {                                                                                                                    \
+        const size_t lds = 2 * (size_t)TileIdx<TT>::NTILE * 256 * sizeof(double);                                        \
+        hipLaunchKernelGGL((gram_rows_kernel<TT, DENSE>), grid, dim3(256), lds, s, m->d_Xa, N, ent, nent, ent_stride, out); \
+    }
+#define WIDE(TT, NW) hipLaunchKernelGGL((gram_wide_kernel<TT, NW, DENSE>), grid, dim3(NW * 64), 0, s, m->d_Xa, N, ent, nent, ent_stride, out);
+    switch (m->T) {
+        case 2: ROWS(2) break;
+        case 4: ROWS(4) break;
+        case 6: WIDE(6, 4) break;
+        case 8: WIDE(8, 4) break;
+        case 10: WIDE(10, 4) break;
+        case 12: WIDE(12, 4) break;
+        case 14: WIDE(14, 8) break;
+        case 16: WIDE(16, 8) break;
+        default: return fail(m, PLSPM_E_LIMIT, "unsupported tile count");
+    }
+#undef ROWS
+#undef WIDE
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
+
+static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, int threads) {
+    const int P = m->P, L = m->L;
+    const size_t s_bytes = (size_t)P * cov_ld(P) * sizeof(double);
+    const size_t small_bytes = (size_t)workspace_small_doubles(P, L, m->kmax, m->n_chol) * sizeof(double);
+    const size_t lds_budget = (nproblems == 1) ? kMaxLds : 64 * 1024;   // batched: keep >= 2 workgroups per CU
+    int s_in_lds = 0, small_in_lds = 0;
+    size_t lds = 0;
+    if (small_bytes <= lds_budget) { small_in_lds = 1; lds += small_bytes; }
+    if (small_in_lds && lds + s_bytes <= lds_budget) { s_in_lds = 1; lds += s_bytes; }
+    if (!s_in_lds) { int rc = ensure(m, m->gS, (size_t)nproblems * s_bytes); if (rc) return rc; }
+    if (!small_in_lds) { int rc = ensure(m, m->gsmall, (size_t)nproblems * small_bytes); if (rc) return rc; }
+    { int rc = allow_lds(m, (const void*)solver_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(solver_kernel, dim3((unsigned)nproblems), dim3(threads), lds, m->stream, make_desc(m), Mp, mp_stride, so, s_in_lds, small_in_lds,
+                       (double*)m->gS.p, (double*)m->gsmall.p);
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int plspm_sync(plspm_model_t* m) {
+    if (!m) return PLSPM_E_ARG;
+    HIPCHK(m, hipSetDevice(m->device));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
+    if (!m || !out) return PLSPM_E_ARG;
+    if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_fit: no data uploaded");
+    HIPCHK(m, hipSetDevice(m->device));
+    const int P = m->P, L = m->L, ne = m->n_eff;
+    const long N = m->N;
+    const long psize = packed_size(m->T);
+    const long ng = (N + 3) / 4;
+    const int waves_per_wg = (m->T <= 4) ? 4 : 1;
+    const int nchunks = (int)std::max<long>(1, std::min<long>(m->T <= 4 ? 512 : 1024, (ng + waves_per_wg * 4 - 1) / (waves_per_wg * 4)));
+    int rc;
+    if ((rc = ensure(m, m->gram_partial, (size_t)nchunks * psize * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
+    // device-side result block
+    const long o_w = 0, o_ld = o_w + P, o_cl = o_ld + P, o_pc = o_cl + (long)P * L, o_r2 = o_pc + (long)L * L, o_lc = o_r2 + L,
+               o_row = o_lc + (long)L * L, o_ind = o_row + (2L * P + L + 2L * ne), o_sw = o_ind + std::max(ne, 1), o_sc = o_sw + P, o_cov = o_sc + L,
+               o_mean = o_cov + (long)P * P, o_end = o_mean + P;
+    const size_t fit_bytes = (size_t)o_end * sizeof(double) + 64 + (size_t)L + 16;
+    if ((rc = ensure(m, m->fitout, fit_bytes))) return rc;
+    double* d = (double*)m->fitout.p;
+    int* d_int = (int*)(d + o_end);           // [0] iters, [1] status
+    int8_t* d_sign = (int8_t*)(d_int + 4);
+    {
+        ProfScope ps(m, PLSPM_K_GRAM);
+        if ((rc = launch_gram<true>(m, 1, nchunks, nullptr, nullptr, 0, (double*)m->gram_partial.p))) return rc;
+    }
+    {
+        ProfScope ps(m, PLSPM_K_REDUCE);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((psize + 255) / 256)), dim3(256), 0, m->stream, (const double*)m->gram_partial.p, nchunks, psize,
+                           (double*)m->gram.p);
+    }
+    SolverOut so{};
+    so.row = d + o_row; so.row_stride = 0; so.status = d_int + 1; so.iters = d_int;
+    so.fit.weights = d + o_w; so.fit.loadings = d + o_ld; so.fit.crossloadings = d + o_cl; so.fit.path_coef = d + o_pc; so.fit.r2 = d + o_r2;
+    so.fit.lv_cov = d + o_lc; so.fit.indirect = d + o_ind; so.fit.score_w = d + o_sw; so.fit.score_c = d + o_sc;
+    so.fit.cov = out->cov ? d + o_cov : nullptr; so.fit.mean = d + o_mean; so.fit.sign = d_sign;
+    {
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        if ((rc = launch_solver(m, 1, (const double*)m->gram.p, psize, so, 256))) return rc;
+    }
+    if (out->scores) {
+        if ((rc = ensure(m, m->rows, (size_t)N * L * sizeof(double)))) return rc;
+        size_t lds = ((size_t)64 * (m->PA + 1) + P + 64 * (size_t)L) * sizeof(double);
+        int stage_out = 1;
+        if (lds > kMaxLds) { stage_out = 0; lds -= 64 * (size_t)L * sizeof(double); }
+        if ((rc = allow_lds(m, (const void*)scores_kernel, lds))) return rc;
+        const int grid = (int)std::min<long>(2048, (N + 63) / 64);
+        ProfScope ps(m, PLSPM_K_SCORES);
+        hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->rows.p,
+                           stage_out);
+    }
+    HIPCHK(m, hipGetLastError());
+    auto get = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream) : hipSuccess;
+    };
+    HIPCHK(m, get(out->weights, d + o_w, sizeof(double) * P));
+    HIPCHK(m, get(out->loadings, d + o_ld, sizeof(double) * P));
+    HIPCHK(m, get(out->crossloadings, d + o_cl, sizeof(double) * P * L));
+    HIPCHK(m, get(out->path_coef, d + o_pc, sizeof(double) * L * L));
+    HIPCHK(m, get(out->r2, d + o_r2, sizeof(double) * L));
+    HIPCHK(m, get(out->lv_cov, d + o_lc, sizeof(double) * L * L));
+    HIPCHK(m, get(out->total, d + o_row + P + L, sizeof(double) * ne));
+    HIPCHK(m, get(out->direct, d + o_row + P + L + ne, sizeof(double) * ne));
+    HIPCHK(m, get(out->indirect, d + o_ind, sizeof(double) * ne));
+    HIPCHK(m, get(out->cov, d + o_cov, sizeof(double) * P * P));
+    HIPCHK(m, get(out->mean, d + o_mean, sizeof(double) * P));
+    HIPCHK(m, get(out->sign, d_sign, (size_t)L));
+    HIPCHK(m, get(out->iterations, d_int, sizeof(int)));
+    HIPCHK(m, get(out->status, d_int + 1, sizeof(int)));
+    HIPCHK(m, get(out->scores, m->rows.p, sizeof(double) * (size_t)N * L));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out, void** d_status,
+                           void** d_iters) {
+    if (!m || B < 1 || rep_offset < 0) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
+    if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
+    const long N = m->N;
+    if (N > 36000) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: N > 36000 needs the global-histogram resampler (not built yet)");
+    HIPCHK(m, hipSetDevice(m->device));
+    const int R = plspm_row_width(m);
+    const long psize = packed_size(m->T);
+    const long ent_stride = ((N + 3) & ~3L) + 4;
+    // replicates per pass: bound the (row,count) + Gram scratch to ~2 GiB
+    const size_t per_rep = (size_t)ent_stride * sizeof(int2) + (size_t)psize * sizeof(double);
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
+    int rc;
+    if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
+    if ((rc = ensure(m, m->nent, (size_t)chunk * sizeof(int)))) return rc;
+    if ((rc = ensure(m, m->gram, (size_t)chunk * psize * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->rows, (size_t)B * R * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->status, (size_t)B * sizeof(int)))) return rc;
+    if ((rc = ensure(m, m->iters, (size_t)B * sizeof(int)))) return rc;
+    if ((rc = ensure(m, m->err, sizeof(int)))) return rc;
+    HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = std::min<int64_t>(chunk, B - b0);
+        if ((rc = allow_lds(m, (const void*)resample_kernel, (size_t)N * sizeof(unsigned)))) return rc;
+        {
+            ProfScope ps(m, PLSPM_K_RESAMPLE);
+            hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), (size_t)N * sizeof(unsigned), m->stream, (int)N,
+                               d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
+        }
+        {
+            ProfScope ps(m, PLSPM_K_GRAM);
+            if ((rc = launch_gram<false>(m, nb, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
+        }
+        SolverOut so{};
+        so.row = (double*)m->rows.p + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
+        {
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, 64))) return rc;
+        }
+    }
+    HIPCHK(m, hipGetLastError());
+    if (d_out) *d_out = m->rows.p;
+    if (d_status) *d_status = m->status.p;
+    if (d_iters) *d_iters = m->iters.p;
+    return 0;
+}
+
+int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out, int32_t* status, int32_t* iters) {
+    if (!m || !out || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
+    if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
+    HIPCHK(m, hipSetDevice(m->device));
+    const int32_t* d_idx = nullptr;
+    if (idx) {
+        int rc = ensure(m, m->idx, (size_t)B * m->N * sizeof(int32_t));
+        if (rc) return rc;
+        HIPCHK(m, hipMemcpyAsync(m->idx.p, idx, (size_t)B * m->N * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+        d_idx = (const int32_t*)m->idx.p;
+    }
+    void *d_out = nullptr, *d_st = nullptr, *d_it = nullptr;
+    int rc = plspm_bootstrap_device(m, B, seed, rep_offset, d_idx, &d_out, &d_st, &d_it);
+    if (rc) return rc;
+    const int R = plspm_row_width(m);
+    int h_err = 0;
+    HIPCHK(m, hipMemcpyAsync(out, d_out, (size_t)B * R * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    if (status) HIPCHK(m, hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (iters) HIPCHK(m, hipMemcpyAsync(iters, d_it, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(&h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    return 0;
+}
+
+int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx) {
+    if (!idx || N < 1 || N > 0x7fffffffLL || rep < 0) return PLSPM_E_ARG;
+    for (int64_t q = 0; q < (N + 3) / 4; ++q) {
+        const u32x4 u = resample_quad(seed, (uint64_t)rep, (uint32_t)q);
+        for (int j = 0; j < 4; ++j) if (4 * q + j < N) idx[4 * q + j] = to_index(u.v[j], (uint32_t)N);
+    }
+    return 0;
+}
+
+int plspm_profile_enable(plspm_model_t* m, int32_t on) { if (!m) return PLSPM_E_ARG; m->profiling = on != 0; return 0; }
+int plspm_profile_reset(plspm_model_t* m) {
+    if (!m) return PLSPM_E_ARG;
+    hipSetDevice(m->device);
+    hipStreamSynchronize(m->stream);
+    prof_collect(m);
+    for (int k = 0; k < PLSPM_K_COUNT; ++k) { m->prof[k].total_ms = 0.0; m->prof[k].launches = 0; }
+    return 0;
+}
+int plspm_profile_read(plspm_model_t* m, int32_t kernel_id, double* total_ms, int64_t* launches) {
+    if (!m || kernel_id < 0 || kernel_id >= PLSPM_K_COUNT) return PLSPM_E_ARG;
+    hipSetDevice(m->device);
+    hipStreamSynchronize(m->stream);
+    prof_collect(m);
+    if (total_ms) *total_ms = m->prof[kernel_id].total_ms;
+    if (launches) *launches = m->prof[kernel_id].launches;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""Bootstrap validation (reference plspm/bootstrap.py:76-137) on the GPU.
+
+The reference forks ``processes`` workers that each loop over resample -> estimate -> inner model -> loadings
+(bootstrap.py:54-66) and merges five DataFrames through a Queue.  Here all replicates of this process run as
+three batched kernels on the data already resident in HBM (resample/compact, fp64-MFMA Gram, LDS solver);
+with several processes (one per GPU) the replicate range is sharded and merged by ``plspm.parallel``.
+Replicates whose status is not OK are dropped, as the reference's bare ``except`` drops them
+(bootstrap.py:65-66).  Summaries follow ``_create_summary`` (bootstrap.py:24-32).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+
+from plspm import parallel
+
+SUMMARY_COLUMNS = ["original", "mean", "std.error", "perc.025", "perc.975", "t stat."]
+
+
+def _create_summary(samples: pd.DataFrame, original) -> pd.DataFrame:
+    """original / mean / std (ddof 1) / 2.5 % and 97.5 % quantiles (linear interpolation) / t = original / std."""
+    v = samples.values.astype(np.float64)
+    summary = pd.DataFrame(0.0, index=samples.columns, columns=SUMMARY_COLUMNS)
+    summary["original"] = original
+    if v.shape[0]:
+        sd = v.std(axis=0, ddof=1) if v.shape[0] > 1 else np.full(v.shape[1], np.nan)
+        summary["mean"] = v.mean(axis=0)
+        summary["std.error"] = sd
+        summary["perc.025"] = np.quantile(v, 0.025, axis=0)
+        summary["perc.975"] = np.quantile(v, 0.975, axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            summary["t stat."] = summary["original"].values / sd
+    return summary
+
+
+class Bootstrap:
+    """Bootstrap results; constructed by :class:`plspm.plspm.Plspm` when ``bootstrap=True``."""
+
+    def __init__(self, config, data: pd.DataFrame, inner_model, outer_model, calculator, iterations: int, num_processes: int,
+                 result=None, seed=None, group=None):
+        if result is None:
+            from plspm.estimator import Estimator
+            result = Estimator(config).run(calculator, data, want_scores=False)
+        native, cm = result.native, result.compiled
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")      # the reference is unseeded as well (bootstrap.py:56)
+        self._seed = seed
+        P, L, ne = cm.P, cm.L, native.n_eff
+        rows, status, iters = parallel.sharded_bootstrap(lambda count, first: native.bootstrap(count, seed, first), iterations,
+                                                         native.row_width, group=group)
+        self._status, self._iterations = status, iters
+        ok = rows[status == 0]
+        self._replicates = ok
+        cols = list(data.columns)
+        eff_index = list(inner_model.effects().index)
+        w = pd.DataFrame(ok[:, :P][:, cm.inv_index], columns=cols)
+        r2 = pd.DataFrame(ok[:, P:P + L], columns=cm.lvs)
+        tot = pd.DataFrame(ok[:, P + L:P + L + ne], columns=eff_index)
+        direct = pd.DataFrame(ok[:, P + L + ne:P + L + 2 * ne], columns=eff_index)
+        ld = pd.DataFrame(ok[:, P + L + 2 * ne:][:, cm.inv_index], columns=cols)
+        om = outer_model.model()
+        self._weights = _create_summary(w, om.loc[cols, "weight"])
+        self._r_squared = _create_summary(r2, inner_model.r_squared()).loc[inner_model.endogenous(), :]
+        self._total_effects = _create_summary(tot, inner_model.effects().loc[:, "total"])
+        self._paths = _create_summary(direct, inner_model.effects().loc[:, "direct"])
+        self._loading = _create_summary(ld, om.loc[cols, "loading"])
+
+    def weights(self) -> pd.DataFrame:
+        """Outer weights calculated from bootstrap validation."""
+        return self._weights
+
+    def r_squared(self) -> pd.DataFrame:
+        """R squared for the endogenous latent variables."""
+        return self._r_squared
+
+    def total_effects(self) -> pd.DataFrame:
+        return self._total_effects
+
+    def paths(self) -> pd.DataFrame:
+        """Direct effects; rows whose bootstrap mean is exactly zero (indirect-only pairs) are hidden (bootstrap.py:133)."""
+        return self._paths[self._paths["mean"] != 0]
+
+    def loading(self) -> pd.DataFrame:
+        return self._loading
+
+    # --- extensions (not in the reference) -----------------------------------------------------------
+    def seed(self):
+        return self._seed
+
+    def status(self):
+        """Per-replicate status codes (0 = used; others were dropped like the reference's failed replicates)."""
+        return self._status
+
+    def replicate_iterations(self):
+        return self._iterations

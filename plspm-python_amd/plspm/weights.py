@@ -1,0 +1,89 @@
+"""The weight-solver seam (reference plspm/weights.py:157-187), backed by libplspm_hip.so.
+
+``WeightsCalculatorFactory(config, iterations, tolerance, correction, scheme)`` keeps the reference's
+constructor, ``clone()``, ``config()`` and ``calculate(data, path) -> (final_data, scores, weights)``.
+``calculate`` receives *treated* data exactly like the reference's (estimator.py:33,39) and therefore runs
+the device solver with centring only.  ``Estimator`` uses ``run()`` instead, which uploads the raw filtered
+data once and lets the device moments stage apply the treatment (config.py:299-305) itself -- that handle
+then also serves the bootstrap.
+"""
+import numpy as np
+import pandas as pd
+
+from plspm import _native
+from plspm._compile import compile_model
+from plspm.scheme import Scheme
+
+
+class ConvergenceError(Exception):
+    pass
+
+
+class SolverResult:
+    """Everything one device fit produced, still in device column order, plus the labels to unpack it."""
+
+    def __init__(self, compiled, native, raw, index):
+        self.compiled = compiled
+        self.native = native
+        self.raw = raw
+        self.index = index
+
+    # frames with the reference's labels / ordering contracts
+    def scores(self) -> pd.DataFrame:
+        return pd.DataFrame(self.raw["scores"], index=self.index, columns=self.compiled.lvs)
+
+    def weights(self) -> pd.DataFrame:
+        return pd.DataFrame({"weight": self.raw["weights"]}, index=self.compiled.dev_mvs)
+
+    def by_data_column(self, key):
+        """A per-MV device vector / matrix re-ordered to the filtered data's column order."""
+        return self.raw[key][self.compiled.inv_index]
+
+
+class WeightsCalculatorFactory:
+    """Calculates weights and scores from the data using the model, on the GPU."""
+
+    def __init__(self, config, iterations: int, tolerance: float, correction: float, scheme: Scheme, device_id: int = 0):
+        self._config = config
+        self._iterations = iterations
+        self._tolerance = tolerance
+        self._correction = correction
+        self._scheme = scheme
+        self._device_id = device_id
+
+    def clone(self):
+        return WeightsCalculatorFactory(self._config.clone(), self._iterations, self._tolerance, self._correction, self._scheme,
+                                        self._device_id)
+
+    def config(self):
+        return self._config
+
+    def scheme(self):
+        return self._scheme
+
+    def _check_supported(self):
+        if not self._config.metric():
+            raise NotImplementedError("non-metric data (Scale.*) is not part of the MI355X hot path yet; see SURVEY.md 8(f)")
+
+    def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False) -> SolverResult:
+        """Compile, upload ``data`` (raw or treated) and run one device fit.  Raises the reference's
+        ``Exception("Could not converge ...")`` (weights.py:185-186) on non-convergence."""
+        self._check_supported()
+        n = data.shape[0]
+        expected = np.sqrt(n / (n - 1))
+        if abs(self._correction - expected) > 1e-12 * expected:
+            raise ValueError("correction must be sqrt(N / (N - 1)) of the data handed to the solver")
+        compiled = compile_model(self._config, path, list(data.columns))
+        native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
+                                     self._iterations, self._tolerance, self._device_id)
+        values = data.values
+        native.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled.col_index)
+        raw = native.fit(want_scores=want_scores, want_cov=want_cov)
+        if raw["status"] == _native.STATUS_NOT_CONVERGED:
+            raise ConvergenceError("Could not converge after " + str(raw["iterations"]) + " iterations")
+        return SolverResult(compiled, native, raw, data.index)
+
+    def calculate(self, data: pd.DataFrame, path: pd.DataFrame):
+        """Reference seam: ``data`` is already treated; returns (final_data, scores, weights)."""
+        result = self.run(data, path, scaled=False)
+        return data, result.scores(), result.weights()

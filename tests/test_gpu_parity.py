@@ -1,0 +1,316 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the oracle,
+the golden vectors made from the real reference, and the reference's own R-output CSVs.
+
+Tolerances: north_star demands 1e-6 relative (fp64) on outer weights, LV scores and path coefficients.  The tests
+hold the HIP path to 1e-8 relative (+ a 1e-11 absolute floor for quantities that are structurally ~0), i.e. two orders
+tighter, and require IDENTICAL iteration counts."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import plspm_oracle as orc
+from helpers import (GOLDEN, assert_close, case_modes, load, satisfaction_frame, satisfaction_oracle_inputs, SAT_ADD_ORDER,
+                     SAT_PREFIX)
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-8, 1e-11
+SCHEME_ID = {"centroid": 0, "factorial": 1, "path": 2}
+
+
+def native_model(model, device_id=0):
+    from plspm import _native
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    return _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], model.scaled, model.max_iter, model.tol,
+                               device_id)
+
+
+def gpu_fit(X, model, layout="C"):
+    nm = native_model(model)
+    Xs = np.asfortranarray(X) if layout == "F" else np.ascontiguousarray(X)
+    nm.upload(Xs, model.mv_order.astype(np.int32))
+    out = nm.fit(want_scores=True, want_cov=True)
+    P = X.shape[1]
+    inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
+    out["weights_d"] = out["weights"][inv]; out["loadings_d"] = out["loadings"][inv]; out["crossloadings_d"] = out["crossloadings"][inv]
+    out["pairs"] = list(zip(nm.eff_from.tolist(), nm.eff_to.tolist()))
+    out["inv"] = inv
+    return nm, out
+
+
+def check_fit(g, r, tag=""):
+    assert g["status"] == 0, tag
+    assert g["iterations"] == r["iterations"], "%s: iterations %d vs oracle %d" % (tag, g["iterations"], r["iterations"])
+    assert_close(g["weights_d"], r["weights"], RTOL, what=tag + " weights")
+    assert_close(g["loadings_d"], r["loadings"], RTOL, what=tag + " loadings")
+    assert_close(g["crossloadings_d"], r["crossloadings"], RTOL, ATOL, what=tag + " crossloadings")
+    assert_close(g["path_coef"], r["path_coef"], RTOL, ATOL, what=tag + " path coefficients")
+    assert_close(g["r2"], r["r2"], RTOL, ATOL, what=tag + " r2")
+    assert g["pairs"] == r["effect_pairs"], tag
+    assert_close(g["total"], r["total"], RTOL, ATOL); assert_close(g["direct"], r["direct"], RTOL, ATOL)
+    assert_close(g["indirect"], r["indirect"], RTOL, ATOL)
+    assert_close(g["scores"], r["scores"], 1e-7, 1e-9, what=tag + " scores")
+    assert np.array_equal(g["sign"], r["sign"].astype(np.int8)), tag
+
+
+@pytest.mark.parametrize("modes", ["A", "B", "M"])
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_satisfaction_fit_vs_oracle_and_reference_golden(modes, scheme, scaled):
+    X, blocks, cols = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, scaled)
+    _, g = gpu_fit(X, model)
+    check_fit(g, orc.fit(X, model), "%s/%s/%d" % (modes, scheme, scaled))
+    gold = load("g1_satisfaction")
+    key = "%s_%s_%d" % (modes, scheme, int(scaled))
+    assert g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights_d"], gold[key + "/weights"], RTOL)
+    assert_close(g["path_coef"], gold[key + "/path_coef"], RTOL, ATOL)
+    assert_close(g["scores"], gold[key + "/scores"], 1e-7, 1e-9)
+
+
+def test_column_major_upload_gives_identical_results():
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    _, a = gpu_fit(X, model, "C")
+    _, b = gpu_fit(X, model, "F")
+    for k in ("weights", "path_coef", "r2", "scores", "loadings"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
+def test_synth2000_vs_golden(modes, scheme):
+    gold = load("g2_synth2000")
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes, mixed="BABABA"), scheme, True)
+    _, g = gpu_fit(X, model)
+    key = "%s_%s_1" % (modes, scheme)
+    assert g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights_d"], gold[key + "/weights"], RTOL)
+    assert_close(g["path_coef"], gold[key + "/path_coef"], RTOL, ATOL)
+    assert_close(g["r2"], gold[key + "/r2"], RTOL, ATOL)
+    assert_close(g["loadings_d"], gold[key + "/loadings"], RTOL)
+
+
+def test_config2_synth10k_path_single_fit():
+    """BASELINE.json configs[1]: 10,000 x 60 x 6, Mode A, Scheme.PATH, single fit."""
+    gold = load("g3_synth10k_path")
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    _, g = gpu_fit(X, model)
+    assert g["iterations"] == int(gold["iters"]) == 3
+    assert_close(g["weights_d"], gold["weights"], RTOL)
+    assert_close(g["path_coef"], gold["path_coef"], RTOL, ATOL)
+    assert_close(g["r2"], gold["r2"], RTOL, ATOL)
+    assert_close(g["loadings_d"], gold["loadings"], RTOL)
+    assert_close(g["scores"][:64], gold["scores_head"], 1e-7, 1e-9)
+    assert_close(g["scores"][::97], gold["scores_sample"], 1e-7, 1e-9)
+    assert_close(g["scores"].T @ g["scores"], gold["scores_gram"], 1e-7, 1e-7)
+
+
+@pytest.mark.parametrize("tag", ["B_factorial_1", "A_path_1", "B_centroid_1"])
+def test_chain20_wide_gram_vs_golden(tag):
+    """Reduced BASELINE.json configs[4] (P=200, L=20; tile-split MFMA Gram, solver with S in global memory)."""
+    gold = load("g7_chain20")
+    C = orc.chain_C(20)
+    X, blocks = orc.synth(4000, C, 10, seed=3)
+    m, scheme, _ = tag.split("_")
+    model = orc.Model(blocks, C, m * 20, scheme, True)
+    _, g = gpu_fit(X, model)
+    assert g["status"] == 0 and g["iterations"] == int(gold[tag + "/iters"])
+    assert_close(g["weights_d"], gold[tag + "/weights"], RTOL)
+    assert_close(g["path_coef"], gold[tag + "/path_coef"], RTOL, ATOL)
+    assert_close(g["r2"], gold[tag + "/r2"], RTOL, ATOL)
+    assert_close(g["crossloadings_d"], gold[tag + "/crossloadings"], RTOL, ATOL)
+
+
+@pytest.mark.parametrize("P_per,L", [(3, 2), (5, 7), (9, 11), (13, 9), (12, 14), (13, 17)])
+def test_every_gram_tile_count(P_per, L):
+    """T = 2,4,6,...,16 tile configurations of the MFMA Gram (P+1 padded to 32..256 columns)."""
+    C = orc.chain_C(L)
+    X, blocks = orc.synth(1501, C, P_per, seed=L)
+    model = orc.Model(blocks, C, "A" * L, "factorial", True)
+    _, g = gpu_fit(X, model)
+    check_fit(g, orc.fit(X, model), "P=%d" % (P_per * L))
+    Xt = orc.treat_metric(X[:, model.mv_order], True)
+    assert_close(g["cov"], Xt.T @ Xt / X.shape[0], 1e-10, 1e-13, what="treated covariance")
+    assert_close(g["mean"], X[:, model.mv_order].mean(axis=0), 1e-12, 1e-13)
+
+
+@pytest.mark.parametrize("tag", ["A_centroid_0", "B_path_1", "M_factorial_1"])
+def test_bootstrap_explicit_indices_vs_reference_rows(tag):
+    """Identical resample indices -> identical replicate rows (reference bootstrap.py:56-64)."""
+    gold = load("g4_satisfaction_boot")
+    X, blocks, _ = satisfaction_oracle_inputs()
+    m, scheme, scaled = tag.split("_")
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(m), scheme, bool(int(scaled)))
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    rows, status, iters = nm.bootstrap(8, idx=gold["idx"])
+    assert np.all(status == 0)
+    assert np.array_equal(iters, gold[tag + "/iters"])
+    P, L, ne = 27, 6, nm.n_eff
+    inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
+    mine = np.concatenate((rows[:, :P][:, inv], rows[:, P:P + L + 2 * ne], rows[:, P + L + 2 * ne:][:, inv]), axis=1)
+    assert_close(mine, gold[tag + "/rows"], RTOL, ATOL, what=tag)
+
+
+def test_bootstrap_10k_seeded_indices_vs_reference_rows():
+    gold = load("g3_synth10k_path")
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    idx = np.stack([np.random.RandomState(int(s)).randint(10000, size=10000) for s in gold["boot_seeds"]]).astype(np.int32)
+    rows, status, iters = nm.bootstrap(len(idx), idx=idx)
+    assert np.all(status == 0) and np.array_equal(iters, gold["boot_iters"])
+    assert_close(rows, gold["boot_rows"], RTOL, ATOL)
+
+
+def test_device_rng_matches_host_mirror_and_sharding_is_invariant():
+    from plspm import _native
+    X, blocks = orc.synth(3000, orc.satisfaction_C(), 10, seed=1)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True)
+    nm = native_model(model)
+    nm.upload(X)
+    B, seed = 24, 0xC0FFEE
+    rows, status, iters = nm.bootstrap(B, seed=seed)
+    idx = np.stack([_native.bootstrap_indices(seed, r, 3000) for r in range(B)])
+    assert idx.min() >= 0 and idx.max() < 3000
+    rows2, _, iters2 = nm.bootstrap(B, idx=idx)
+    assert np.array_equal(rows, rows2) and np.array_equal(iters, iters2)          # bit-identical: same list, same kernels
+    a, _, _ = nm.bootstrap(10, seed=seed, rep_offset=0)
+    b, _, _ = nm.bootstrap(14, seed=seed, rep_offset=10)
+    assert np.array_equal(np.concatenate((a, b)), rows)                            # any sharding reproduces the stream
+    corr = orc.correction(3000)
+    for r in (0, 7, 23):
+        mine, its = orc.bootstrap_replicate(X, model, idx[r], corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+
+
+def test_bootstrap_rejects_out_of_range_index():
+    from plspm import _native
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    idx = np.zeros((2, 250), dtype=np.int32); idx[1, 5] = 250
+    with pytest.raises(_native.NativeBackendError):
+        nm.bootstrap(2, idx=idx)
+
+
+def test_sign_rule_and_status_codes():
+    g5 = load("g5_sign_rule")
+    model = orc.Model([np.arange(0, 2), np.arange(2, 7), np.arange(7, 11)], g5["C"], "AAA", "centroid", True)
+    _, g = gpu_fit(g5["X"], model)
+    check_fit(g, orc.fit(g5["X"], model))
+    assert g["sign"][0] == -1 and np.all(g["weights"][:2] > 0)
+    X, blocks, _ = satisfaction_oracle_inputs()
+    hard = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=2, tol=1e-30)
+    _, g = gpu_fit(X, hard)
+    assert g["status"] == 1 and g["iterations"] == 3
+    Xd = X.copy(); Xd[:, blocks[2][1]] = Xd[:, blocks[2][0]]
+    _, g = gpu_fit(Xd, orc.Model(blocks, orc.satisfaction_C(), "BBBBBB", "centroid", True))
+    assert g["status"] == 2
+
+
+def test_bootstrap_full_size_properties():
+    """BASELINE.json configs[2] at full size (5,000 replicates of 10k x 60 x 6): size-independent properties."""
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(5000, seed=1)
+    assert np.all(status == 0) and iters.min() >= 2 and iters.max() <= 6
+    P, L, ne = 60, 6, nm.n_eff
+    w, r2, tot, direct, ld = rows[:, :P], rows[:, P:P + L], rows[:, P + L:P + L + ne], rows[:, P + L + ne:P + L + 2 * ne], rows[:, -P:]
+    assert np.all(np.isfinite(rows))
+    assert np.all(r2[:, 0] == 0) and np.all((r2[:, 1:] > 0) & (r2[:, 1:] < 1))
+    assert np.all(np.abs(ld) <= 1 + 1e-12) and np.all(ld > 0) and np.all(w > 0)
+    base = orc.fit(X, model)
+    # bootstrap means sit on the full-sample estimates (bias << spread), spread ~ 1/sqrt(N)
+    assert np.max(np.abs(w.mean(axis=0) - base["weights"])) < 5e-4
+    assert np.max(np.abs(direct.mean(axis=0) - base["direct"])) < 3e-3
+    assert 0.002 < w.std(axis=0).max() < 0.02
+    # total = direct + indirect >= structure: pairs without a direct edge have direct == 0 exactly
+    pairs = list(zip(nm.eff_from.tolist(), nm.eff_to.tolist()))
+    Cm = orc.satisfaction_C()
+    for e, (f, t) in enumerate(pairs):
+        if Cm[t, f] == 0:
+            assert np.all(direct[:, e] == 0) and np.all(tot[:, e] != 0)
+    # idempotence: the same seed reproduces the batch bit for bit
+    again, _, _ = nm.bootstrap(5000, seed=1)
+    assert np.array_equal(rows, again)
+
+
+def test_plspm_api_reproduces_reference_test_satisfaction():
+    """Mirror of reference tests/test_regression_metric.py:32-94 through the drop-in API."""
+    import math
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    import plspm.util as util
+    import os
+    sat = satisfaction_frame()
+    structure = c.Structure()
+    structure.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); structure.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    structure.add_path(["QUAL"], ["VAL", "SAT"]); structure.add_path(["VAL"], ["SAT"]); structure.add_path(["SAT"], ["LOY"])
+    config = c.Config(structure.path(), scaled=False)
+    for lv in SAT_ADD_ORDER:
+        config.add_lv_with_columns_named(lv, Mode.A, sat, SAT_PREFIX[lv])
+    ref = os.path.join(GOLDEN, "ref_data")
+    calc = Plspm(sat, config)
+    expected_scores = pd.read_csv(os.path.join(ref, "satisfaction.scores.csv"))
+    np.testing.assert_allclose(util.sort_cols(expected_scores), util.sort_cols(calc.scores()))
+    inner = pd.read_csv(os.path.join(ref, "satisfaction.inner-model.csv"), index_col=0)
+    actual = calc.inner_model()
+    actual = actual[actual["to"].isin(["SAT"])].drop(["to"], axis=1)
+    np.testing.assert_allclose(util.sort_cols(inner).sort_index(), util.sort_cols(actual.set_index(["from"], drop=True)).sort_index())
+    outer = pd.read_csv(os.path.join(ref, "satisfaction.outer-model.csv"), index_col=0).drop(["block"], axis=1)
+    pd.testing.assert_index_equal(outer.columns, calc.outer_model().columns)
+    np.testing.assert_allclose(util.sort_cols(outer.sort_index()), util.sort_cols(calc.outer_model()).sort_index())
+    cl = pd.read_csv(os.path.join(ref, "satisfaction.crossloadings.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(cl.drop(["block"], axis=1)).sort_index(), util.sort_cols(calc.crossloadings()).sort_index())
+    summ = pd.read_csv(os.path.join(ref, "satisfaction.inner-summary.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(summ.drop(["type"], axis=1)).sort_index(),
+                               util.sort_cols(calc.inner_summary().drop(["type", "r_squared_adj"], axis=1)).sort_index())
+    pd.testing.assert_series_equal(summ.loc[:, "type"].sort_index(), calc.inner_summary().loc[:, "type"].sort_index())
+    eff = pd.read_csv(os.path.join(ref, "satisfaction.effects.csv"), index_col=0)
+    pd.testing.assert_frame_equal(eff.loc[:, ["from", "to"]].sort_index(), calc.effects().loc[:, ["from", "to"]].sort_index())
+    np.testing.assert_allclose(eff.drop(["from", "to"], axis=1).sort_index(), calc.effects().drop(["from", "to"], axis=1).sort_index(),
+                               atol=1e-12)
+    unidim = pd.read_csv(os.path.join(ref, "satisfaction_unidim.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(unidim.drop(["mode"], axis=1)).sort_index(),
+                               util.sort_cols(calc.unidimensionality().drop(["mode"], axis=1)).sort_index().astype(float))
+    assert math.isclose(0.609741624338411, calc.goodness_of_fit())
+    for scheme, fname in ((Scheme.PATH, "satisfaction.outer-model-path.csv"), (Scheme.FACTORIAL, "satisfaction.outer-model-factorial.csv")):
+        exp = util.sort_cols(pd.read_csv(os.path.join(ref, fname), index_col=0).drop(["block"], axis=1)).sort_index()
+        np.testing.assert_allclose(exp, util.sort_cols(Plspm(sat, config, scheme).outer_model()).sort_index())
+
+
+def test_plspm_api_bootstrap_matches_reference_statistical_test():
+    """Mirror of reference tests/test_regression_bootstrap.py:20-48 (absolute tolerances 0.05-0.15 as there)."""
+    import os
+    import plspm.config as c
+    import plspm.util as util
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    sat = satisfaction_frame()
+    structure = c.Structure()
+    structure.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); structure.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    structure.add_path(["QUAL"], ["VAL", "SAT"]); structure.add_path(["VAL"], ["SAT"]); structure.add_path(["SAT"], ["LOY"])
+    config = c.Config(structure.path(), scaled=False)
+    for lv in ["IMAG", "EXPE", "QUAL", "VAL", "SAT", "LOY"]:
+        config.add_lv_with_columns_named(lv, Mode.A, sat, SAT_PREFIX[lv])
+    calc = Plspm(sat, config, bootstrap=True, processes=4, seed=7)
+    ref = os.path.join(GOLDEN, "ref_data")
+    drop = ["t stat."]
+    for fname, frame, atol in (("satisfaction_boot_weights.csv", calc.bootstrap().weights(), 0.05),
+                               ("satisfaction_boot_rsquared.csv", calc.bootstrap().r_squared(), 0.1),
+                               ("satisfaction_boot_total_effects.csv", calc.bootstrap().total_effects(), 0.1),
+                               ("satisfaction_boot_paths.csv", calc.bootstrap().paths(), 0.1),
+                               ("satisfaction_boot_loadings.csv", calc.bootstrap().loading(), 0.15)):
+        expected = pd.read_csv(os.path.join(ref, fname), index_col=0)
+        np.testing.assert_allclose(util.sort_cols(expected), util.sort_cols(frame.drop(columns=drop)), atol=atol, err_msg=fname)
