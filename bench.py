@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: bootstrap replicates / second, 6-LV satisfaction model, N = 10,000 obs x 60 MVs
+(BASELINE.json configs[2]: Mode A, Scheme.PATH, scaled, 5,000 replicates per GPU -- weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: every rank resamples + solves its shard of the replicate
+range on its own GPU (inputs already resident in HBM), then ONE all_gather (RCCL over xGMI) merges the
+B x 156 result rows -- the whole job, gather included, is inside the timed region.  Rank 0 prints one JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel (fp64-MFMA weighted Gram), duration measured with HIP events on the library's own
+                stream during the timed steps; algorithmic work per replicate per SURVEY.md 8(d)
+  cpu_baseline  the NumPy oracle (oracle/plspm_oracle.py, a port of the reference arithmetic) timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd"))
+
+import numpy as np  # noqa: E402
+
+N_OBS, MVS_PER_LV, N_LV = 10000, 10, 6
+REPS_PER_GPU = 5000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet fp64 matrix; 77.9 TF measured with v_mfma_f64_16x16x4_f64 (tools/ubench)
+
+
+def synth_inputs():
+    """Synthetic generator of SURVEY.md 8(d) (own code; the oracle module only supplies the generator + structure)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import plspm_oracle as orc
+    X, blocks = orc.synth(N_OBS, orc.satisfaction_C(), MVS_PER_LV, seed=0)
+    return orc, X, blocks
+
+
+def cpu_worker(args):
+    seed, count = args
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    orc, X, blocks = synth_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "A" * N_LV, "path", True)
+    corr = orc.correction(N_OBS)
+    rs = np.random.RandomState(seed)
+    t0 = time.perf_counter()
+    for _ in range(count):
+        orc.bootstrap_replicate(X, model, rs.randint(N_OBS, size=N_OBS), corr)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle replicates/s on the host cores: a process pool of min(cpu_count, 32) single-threaded workers."""
+    import multiprocessing as mp
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    per_rep = cpu_worker((1, 8)) / 8                # single-core seconds per replicate (loop only; data synthesis excluded)
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    count = min(64, max(4, int(budget_s / max(per_rep, 1e-3))))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        t0 = time.perf_counter()
+        busy = pool.map(cpu_worker, [(100 + i, count) for i in range(cores)])
+        wall = time.perf_counter() - t0
+    # throughput of the replicate loops themselves (workers time only their loop; data synthesis excluded)
+    value = cores * count / max(busy)
+    return {"value": round(value, 2), "unit": "replicates/s", "cores": cores, "kind": "port",
+            "sample": "%d oracle replicates per core on %d cores (10k x 60 x 6, Mode A, PATH), single-core %.2f rep/s, pool wall %.1f s"
+                      % (count, cores, 1.0 / per_rep, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps-per-gpu", type=int, default=REPS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+
+    from plspm import _native, parallel
+    dist = None
+    use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also exercises RCCL at N = 1)
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device_id = local_rank if use_dist else 0
+
+    orc, X, blocks = synth_inputs()
+    C = orc.satisfaction_C()
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+    model = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, device_id)
+    model.upload(X)                                            # X resident in HBM before the timed region
+    B_total = args.reps_per_gpu * world
+    width = model.row_width
+
+    def run_shard(count, first):
+        d_rows, d_st, d_it = model.bootstrap_device(count, seed=1, rep_offset=first)
+        return d_rows, d_st, d_it, model.sync
+
+    def step():
+        if not use_dist:
+            model.bootstrap_device(B_total, seed=1, rep_offset=0)
+            model.sync()
+            return None
+        return parallel.sharded_bootstrap(run_shard, B_total, width, on_device=True)
+
+    def fence():
+        model.sync()
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.profile(True)
+    model.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    model.profile(False)
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness guard on what was timed: every replicate converged, row 0 of the stream equals the oracle
+    rows, status, iters = model.bootstrap(8, seed=1, rep_offset=0)
+    assert np.all(status == 0), status
+    idx0 = _native.bootstrap_indices(1, 0, N_OBS)
+    omodel = orc.Model(blocks, C, "A" * N_LV, "path", True)
+    ref_row, ref_it = orc.bootstrap_replicate(X, omodel, idx0, orc.correction(N_OBS))
+    assert ref_it == iters[0] and np.allclose(rows[0], ref_row, rtol=1e-8, atol=1e-11), "timed path disagrees with the oracle"
+
+    if rank == 0:
+        gram_ms, gram_n = model.profile_read("gram")
+        res_ms, res_n = model.profile_read("resample")
+        sol_ms, sol_n = model.profile_read("solver")
+        reps_per_launch = args.reps_per_gpu
+        a_rep = 8.0 * N_OBS * 60 + 4.0 * N_OBS                 # one gathered read of X + the index vector
+        f_rep = float(N_OBS) * 60 * 61                         # symmetric Gram flops
+        gram_avg_ms = gram_ms / max(gram_n, 1)
+        hbm_achieved = a_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e9
+        mfma_achieved = f_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
+        traffic = None
+        prof_json = os.path.join(ROOT, "profiles", "r01_gram_traffic.json")
+        if os.path.exists(prof_json):
+            try:
+                traffic = json.load(open(prof_json)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "bootstrap replicates/sec (6-LV satisfaction model, N=10k)",
+            "value": round(B_total * args.steps / elapsed, 1),
+            "unit": "replicates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic 10,000 obs x 60 MVs x 6 LVs, Mode A, Scheme.PATH, scaled, %d bootstrap replicates per GPU "
+                                   "(BASELINE.json configs[2]); on-device Philox resampling; X resident in HBM" % args.reps_per_gpu,
+                       "replicates_per_step": B_total, "iterations_per_replicate": [int(iters.min()), int(iters.max())],
+                       "parallelism": "replicate-sharded x%d, one all_gather per step" % world},
+            "roofline": {"bound": "mfma", "achieved": round(mfma_achieved, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(mfma_achieved / FP64_MFMA_PEAK_TF, 4), "traffic": traffic,
+                         "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n,
+                         "algorithmic_flops_per_replicate": f_rep, "algorithmic_bytes_per_replicate": a_rep,
+                         "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}},
+            "kernels_ms_per_step": {"resample": round(res_ms / max(res_n, 1), 4), "gram": round(gram_avg_ms, 4),
+                                    "solver": round(sol_ms / max(sol_n, 1), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

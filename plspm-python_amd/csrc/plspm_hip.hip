@@ -188,58 +188,150 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
 // load per 32 columns feeds two tiles: lane (k, i) reads columns 32*g + 2i, 2i+1 of row k -> tile 2g holds the even
 // columns of group g, tile 2g+1 the odd ones (packed_tile_of / packed_pos_of in solver_core.h).
 // Lane l ends up with D[(l>>4) + 4*reg][l&15] in acc[reg].
+//
+// Software pipeline.  hipcc de-pipelines a C++ prefetch here (it re-issues the loop-carried loads next to their
+// use, exposing the full (list entry -> row address -> row data) latency every k-group -- measured 42 % MFMA
+// utilisation), so the loads are issued with inline asm the compiler does not count, in a two-stage ping-pong:
+//     stage s:  s_waitcnt vmcnt(0)                      rows(s) and entry(s+1) have landed
+//               issue rows(s+1) <- Xa[entry(s+1).row]   } in flight under the MFMAs of stage s
+//               issue entry(s+2)                        }
+//               NT x v_mfma_f64_16x16x4_f64 on rows(s)
+// Rules followed (cdna_hip_programming.md 5.7): destinations are tied "+v" operands (no compiler copy of an
+// in-flight register), every destination is named by the wait statement before its first consumer, the
+// accumulators are pinned "+a" at stage boundaries so no MFMA drifts across a wait, and a final vmcnt(0)
+// precedes any other use of those registers.  Audit with tools/kernel_resources.py + -save-temps: the loop
+// must show no v_accvgpr_* and no v_mov of a load destination.
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+typedef double dv2 __attribute__((ext_vector_type(2)));
+typedef int iv2 __attribute__((ext_vector_type(2)));
 
 template <int T>
 struct TileIdx {
     static constexpr int NTILE = T * (T + 1) / 2;
     __host__ __device__ static constexpr int of(int t, int u) { return t * T - t * (t - 1) / 2 + (u - t); }
 };
+// Tiles owned by wave W of NW when the upper tiles are dealt round-robin (NW = 1: one wave owns all).
+template <int T, int NW, int W>
+struct Own {
+    static constexpr int COUNT = (TileIdx<T>::NTILE - W + NW - 1) / NW;
+    __host__ __device__ static constexpr bool mine(int li) { return li % NW == W; }
+    __host__ __device__ static constexpr int slot(int li) { return li / NW; }
+};
+
+template <int T, int NW, int W>
+using AccArr = d4[Own<T, NW, W>::COUNT];
+template <int T>
+using RowArr = dv2[T / 2];
+
+template <int Q, int G>
+struct RowLoader {
+    static __device__ __forceinline__ void issue(dv2 (&v)[G], const double* p) {
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(v[Q]) : "v"(p), "i"(Q * 256) : "memory");
+        RowLoader<Q + 1, G>::issue(v, p);
+    }
+    static __device__ __forceinline__ void pin(dv2 (&v)[G]) { asm volatile("" : "+v"(v[Q])); RowLoader<Q + 1, G>::pin(v); }
+};
+template <int G>
+struct RowLoader<G, G> {
+    static __device__ __forceinline__ void issue(dv2 (&)[G], const double*) {}
+    static __device__ __forceinline__ void pin(dv2 (&)[G]) {}
+};
+__device__ __forceinline__ void issue_entry(iv2& e, const int2* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(e) : "v"(p) : "memory"); }
+
+// One pipeline stage (see above).  DENSE: rows are consecutive (single fit), no (row,count) list.
+template <int T, int NW, int W, bool DENSE>
+__device__ __forceinline__ void gram_stage(AccArr<T, NW, W>& acc, RowArr<T>& Vcur, RowArr<T>& Vnext, iv2& Enext, iv2& Eafter, double cnt,
+                                           const double* xbase, const int2* eptr_after, long dense_row_next) {
+    constexpr int G = T / 2, PA = 16 * T;
+#pragma unroll
+    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
+    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Enext)::"memory");
+    RowLoader<0, G>::pin(Vcur);
+    double x[T];
+#pragma unroll
+    for (int q = 0; q < G; ++q) { x[2 * q] = Vcur[q].x; x[2 * q + 1] = Vcur[q].y; }
+    const long rnext = DENSE ? dense_row_next : (long)Enext.x;
+    RowLoader<0, G>::issue(Vnext, xbase + rnext * PA);
+    if (!DENSE) issue_entry(Eafter, eptr_after);
+    asm volatile("" : "+v"(cnt));          // every MFMA operand below depends on cnt: none is scheduled above the loads
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const double a = cnt * x[t];
+#pragma unroll
+        for (int u = t; u < T; ++u) {
+            const int li = TileIdx<T>::of(t, u);
+            const int sl = Own<T, NW, W>::slot(li);
+            if (Own<T, NW, W>::mine(li)) acc[sl] = MFMA_F64(a, x[u], acc[sl]);
+        }
+    }
+}
+
+// The k-group walk of one wave: groups g0, g0 + gs, ... < ng; accumulates its owned tiles.
+template <int T, int NW, int W, bool DENSE>
+__device__ __forceinline__ void gram_walk(AccArr<T, NW, W>& acc, const double* __restrict__ Xa, long N, const int2* __restrict__ e, int ng, int g0,
+                                          int gs, int lane) {
+    constexpr int G = T / 2, PA = 16 * T;
+    const int k = lane >> 4, i = lane & 15;
+    const double* xbase = Xa + 2 * i;
+    const int2* ek = e + k;
+    const int niter = (g0 < ng) ? (ng - g0 + gs - 1) / gs : 0;
+    const int last = ng - 1;
+    auto gof = [&](int it) { const int g = g0 + it * gs; return g < last ? g : last; };
+    auto eaddr = [&](int it) { return ek + 4 * (long)gof(it); };
+    auto drow = [&](int it) { const long r = 4 * (long)gof(it) + k; return r < N ? r : N - 1; };
+    auto dcnt = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? 1 : 0; };
+#pragma unroll
+    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }
+    iv2 EA = {0, 0}, EB = {0, 0};
+    dv2 VA[G], VB[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) { VA[q] = (dv2){0.0, 0.0}; VB[q] = (dv2){0.0, 0.0}; }
+    int cA;
+    if (DENSE) {
+        RowLoader<0, G>::issue(VA, xbase + drow(0) * PA);
+        cA = dcnt(0);
+    } else {
+        issue_entry(EA, eaddr(0));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA)::"memory");
+        RowLoader<0, G>::issue(VA, xbase + (long)EA.x * PA);
+        cA = (niter > 0) ? EA.y : 0;
+        issue_entry(EB, eaddr(1));
+    }
+    for (int it = 0; it < niter; it += 2) {
+        // stage A: consume VA; prefetch VB <- rows(it+1), EA <- entry(it+2)
+        gram_stage<T, NW, W, DENSE>(acc, VA, VB, EB, EA, (double)cA, xbase, DENSE ? nullptr : eaddr(it + 2), DENSE ? drow(it + 1) : 0);
+        const int cB = DENSE ? dcnt(it + 1) : ((it + 1 < niter) ? EB.y : 0);
+        // stage B: consume VB; prefetch VA <- rows(it+2), EB <- entry(it+3)
+        gram_stage<T, NW, W, DENSE>(acc, VB, VA, EA, EB, (double)cB, xbase, DENSE ? nullptr : eaddr(it + 3), DENSE ? drow(it + 2) : 0);
+        cA = DENSE ? dcnt(it + 2) : EA.y;
+    }
+    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA), "+v"(EB)::"memory");
+    RowLoader<0, G>::pin(VA);
+    RowLoader<0, G>::pin(VB);
+#pragma unroll
+    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
+}
 
 // Rows-split variant (T <= 4): every wave of the 256-thread workgroup keeps ALL upper tiles and takes every 4th
 // k-group of the (row,count) list; a two-level LDS tree adds the four partial accumulators at the end.
 template <int T, bool DENSE>
 __global__ void __launch_bounds__(256) gram_rows_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
                                                          const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
-    constexpr int NT = TileIdx<T>::NTILE, G = T / 2, PA = 16 * T;
+    constexpr int NT = TileIdx<T>::NTILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* red = reinterpret_cast<double*>(smem_raw);      // [2][NT*256]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane >> 4, i = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long problem = blockIdx.y;
     const int nchunks = gridDim.x, chunk = blockIdx.x;
     const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
-    const long ng = DENSE ? ((N + 3) >> 2) : (long)((nent[problem] + 3) >> 2);
-    const long gstride = (long)nchunks * 4;
+    const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
 
     d4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    gram_walk<T, 1, 0, DENSE>(acc, Xa, N, e, ng, chunk * 4 + wave, nchunks * 4, lane);
 
-    long g = (long)chunk * 4 + wave;
-    long row = 0; double cnt = 0.0;
-    double2 v[G];
-    auto fetch = [&](long gg) {
-        if (DENSE) { const long r = 4 * gg + k; cnt = (r < N) ? 1.0 : 0.0; row = (r < N) ? r : (N - 1); }
-        else { const int2 en = e[4 * gg + k]; row = en.x; cnt = (double)en.y; }
-        const double2* xr = reinterpret_cast<const double2*>(Xa + row * PA);
-#pragma unroll
-        for (int q = 0; q < G; ++q) v[q] = xr[q * 16 + i];
-    };
-    if (g < ng) fetch(g);
-    while (g < ng) {
-        double x[T], a[T];
-#pragma unroll
-        for (int q = 0; q < G; ++q) { x[2 * q] = v[q].x; x[2 * q + 1] = v[q].y; }
-#pragma unroll
-        for (int t = 0; t < T; ++t) a[t] = DENSE ? ((cnt != 0.0) ? x[t] : 0.0) : cnt * x[t];
-        const long gn = g + gstride;
-        if (gn < ng) fetch(gn);                 // software prefetch of the next k-group under the MFMAs below
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int u = t; u < T; ++u) acc[TileIdx<T>::of(t, u)] = MFMA_F64(a[t], x[u], acc[TileIdx<T>::of(t, u)]);
-        g = gn;
-    }
     // tree reduce: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores.
     if (wave >= 2) {
         double* dst = red + (long)(wave - 2) * NT * 256;
@@ -276,72 +368,44 @@ __global__ void __launch_bounds__(256) gram_rows_kernel(const double* __restrict
 // Tile-split variant (6 <= T <= 16): the NW waves of a workgroup walk the SAME k-groups; wave W owns the upper tiles
 // whose linear index == W (mod NW), so no reduction is needed and the accumulators stay within the register file.
 template <int T, int NW, int W, bool DENSE>
-__device__ __forceinline__ void gram_wide_body(const double* __restrict__ Xa, long N, const int2* __restrict__ e, long ng, int chunk, int nchunks,
+__device__ __forceinline__ void gram_wide_body(const double* __restrict__ Xa, long N, const int2* __restrict__ e, int ng, int chunk, int nchunks,
                                                 double* __restrict__ dst, int lane) {
-    constexpr int NT = TileIdx<T>::NTILE, G = T / 2, PA = 16 * T, MINE = (NT - W + NW - 1) / NW;
-    const int k = lane >> 4, i = lane & 15;
-    d4 acc[MINE];
-#pragma unroll
-    for (int t = 0; t < MINE; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    long row = 0; double cnt = 0.0;
-    double2 v[G];
-    auto fetch = [&](long gg) {
-        if (DENSE) { const long r = 4 * gg + k; cnt = (r < N) ? 1.0 : 0.0; row = (r < N) ? r : (N - 1); }
-        else { const int2 en = e[4 * gg + k]; row = en.x; cnt = (double)en.y; }
-        const double2* xr = reinterpret_cast<const double2*>(Xa + row * PA);
-#pragma unroll
-        for (int q = 0; q < G; ++q) v[q] = xr[q * 16 + i];
-    };
-    long g = chunk;
-    if (g < ng) fetch(g);
-    while (g < ng) {
-        double x[T], a[T];
-#pragma unroll
-        for (int q = 0; q < G; ++q) { x[2 * q] = v[q].x; x[2 * q + 1] = v[q].y; }
-#pragma unroll
-        for (int t = 0; t < T; ++t) a[t] = DENSE ? ((cnt != 0.0) ? x[t] : 0.0) : cnt * x[t];
-        const long gn = g + nchunks;
-        if (gn < ng) fetch(gn);
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int u = t; u < T; ++u) {
-                const int li = TileIdx<T>::of(t, u);
-                if (li % NW == W) acc[li / NW] = MFMA_F64(a[t], x[u], acc[li / NW]);
-            }
-        g = gn;
-    }
+    d4 acc[Own<T, NW, W>::COUNT];
+    gram_walk<T, NW, W, DENSE>(acc, Xa, N, e, ng, chunk, nchunks, lane);
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int u = t; u < T; ++u) {
             const int li = TileIdx<T>::of(t, u);
-            if (li % NW == W) {
+            if (Own<T, NW, W>::mine(li)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(li * 4 + r) * 64 + lane] = acc[li / NW][r];
+                for (int r = 0; r < 4; ++r) dst[(li * 4 + r) * 64 + lane] = acc[Own<T, NW, W>::slot(li)][r];
             }
         }
 }
 template <int T, int NW, int W, bool DENSE>
 struct WideDispatch {
-    __device__ static void run(int wave, const double* Xa, long N, const int2* e, long ng, int chunk, int nchunks, double* dst, int lane) {
+    __device__ static __forceinline__ void run(int wave, const double* Xa, long N, const int2* e, int ng, int chunk, int nchunks, double* dst, int lane) {
         if (wave == W) gram_wide_body<T, NW, W, DENSE>(Xa, N, e, ng, chunk, nchunks, dst, lane);
         else WideDispatch<T, NW, W + 1, DENSE>::run(wave, Xa, N, e, ng, chunk, nchunks, dst, lane);
     }
 };
 template <int T, int NW, bool DENSE>
 struct WideDispatch<T, NW, NW, DENSE> {
-    __device__ static void run(int, const double*, long, const int2*, long, int, int, double*, int) {}
+    __device__ static __forceinline__ void run(int, const double*, long, const int2*, int, int, int, double*, int) {}
 };
-template <int T, int NW, bool DENSE>
-__global__ void __launch_bounds__(NW * 64) gram_wide_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
-                                                             const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// NWV "virtual" waves share the tiles; a workgroup carries NWP of them and blockIdx.z selects which slice
+// (NWV == NWP: one workgroup per k-group walk; NWV == 2*NWP: two workgroups walk the same rows, disjoint tiles).
+template <int T, int NWV, int NWP, bool DENSE>
+__global__ void __launch_bounds__(NWP * 64) gram_wide_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
+                                                              const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + NWP * (int)blockIdx.z;
     const long problem = blockIdx.y;
     const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
-    const long ng = DENSE ? ((N + 3) >> 2) : (long)((nent[problem] + 3) >> 2);
+    const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
     double* dst = out + (problem * gridDim.x + blockIdx.x) * (long)(TileIdx<T>::NTILE * 256);
-    WideDispatch<T, NW, 0, DENSE>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
+    WideDispatch<T, NWV, 0, DENSE>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
 }
 
 // out[e] = sum over chunks of partial[chunk][e]  (fixed order: deterministic)
@@ -664,16 +728,18 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
         const size_t lds = 2 * (size_t)TileIdx<TT>::NTILE * 256 * sizeof(double);                                        \
         hipLaunchKernelGGL((gram_rows_kernel<TT, DENSE>), grid, dim3(256), lds, s, m->d_Xa, N, ent, nent, ent_stride, out); \
     }
-#define WIDE(TT, NW) hipLaunchKernelGGL((gram_wide_kernel<TT, NW, DENSE>), grid, dim3(NW * 64), 0, s, m->d_Xa, N, ent, nent, ent_stride, out);
+#define WIDE(TT, NWV, NWP)                                                                                                     \
+    hipLaunchKernelGGL((gram_wide_kernel<TT, NWV, NWP, DENSE>), dim3(nchunks, (unsigned)nproblems, NWV / NWP), dim3(NWP * 64), 0, s, m->d_Xa, N, ent, \
+                       nent, ent_stride, out);
     switch (m->T) {
         case 2: ROWS(2) break;
         case 4: ROWS(4) break;
-        case 6: WIDE(6, 4) break;
-        case 8: WIDE(8, 4) break;
-        case 10: WIDE(10, 4) break;
-        case 12: WIDE(12, 4) break;
-        case 14: WIDE(14, 8) break;
-        case 16: WIDE(16, 8) break;
+        case 6: WIDE(6, 4, 4) break;
+        case 8: WIDE(8, 4, 4) break;
+        case 10: WIDE(10, 4, 4) break;
+        case 12: WIDE(12, 4, 4) break;
+        case 14: WIDE(14, 8, 8) break;
+        case 16: WIDE(16, 16, 8) break;
         default: return fail(m, PLSPM_E_LIMIT, "unsupported tile count");
     }
 #undef ROWS

@@ -47,7 +47,7 @@ def sharded_bootstrap(run_shard, total, width, group=None, on_device=False):
     start, stop = shard_range(total, rank, world)
     mine = stop - start
     res = run_shard(mine, start) if mine > 0 else None
-    if world == 1:
+    if dist is None:
         if on_device:
             import torch
             rows_ptr, st_ptr, it_ptr, sync = res
