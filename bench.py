@@ -109,15 +109,15 @@ def main():
     width = model.row_width
 
     def run_shard(count, first):
-        d_rows, d_st, d_it = model.bootstrap_device(count, seed=1, rep_offset=first)
-        return d_rows, d_st, d_it, model.sync
+        d_rows, _, _ = model.bootstrap_device(count, seed=1, rep_offset=first)
+        return d_rows, model.sync
 
     def step():
         if not use_dist:
             model.bootstrap_device(B_total, seed=1, rep_offset=0)
             model.sync()
             return None
-        return parallel.sharded_bootstrap(run_shard, B_total, width, on_device=True)
+        return parallel.sharded_bootstrap(run_shard, B_total, width, on_device=True, to_host=False)   # merged rows stay in HBM
 
     def fence():
         model.sync()
@@ -141,6 +141,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if use_dist:
+        # the gathered records of the last timed step: complete, in replicate-id order, identical on every rank
+        rec = step().cpu().numpy()
+        assert rec.shape == (B_total, width + 2) and np.all(rec[:, width] == 0), "gather lost replicates"
+        probe = min(B_total - 1, (B_total // world) * (world - 1) + 3)          # a row owned by the last rank
+        one, _, _ = model.bootstrap(1, seed=1, rep_offset=probe)
+        assert np.array_equal(rec[probe, :width], one[0]), "sharded stream differs from the single-GPU stream"
 
     # correctness guard on what was timed: every replicate converged, row 0 of the stream equals the oracle
     rows, status, iters = model.bootstrap(8, seed=1, rep_offset=0)

@@ -92,6 +92,10 @@ int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to);
  * (device column order; the reference collects the same five vectors per replicate, bootstrap.py:58-64). */
 int32_t plspm_row_width(const plspm_model_t* m);
 
+/* Row pitch (in doubles) of the DEVICE result buffer of plspm_bootstrap_device: R + 2.  Columns R and R+1 of every
+ * device row hold that replicate's status and iteration count as doubles, so that one collective moves everything. */
+int32_t plspm_row_stride(const plspm_model_t* m);
+
 /* Outputs of one fit; every pointer may be NULL. */
 typedef struct plspm_fit_result {
     double* weights;       /* [P]    outer weights, never sign-flipped (weights.py:69)                      */
@@ -127,7 +131,7 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
                     int32_t* status, int32_t* iters);
 
 /* Same, leaving the results in device memory owned by the handle (valid until the next call on it):
- * *d_out -> [B*R] fp64, *d_status / *d_iters -> [B] int32.  Work is enqueued on the handle's stream;
+ * *d_out -> [B * plspm_row_stride()] fp64, *d_status / *d_iters -> [B] int32.  Work is enqueued on the handle's stream;
  * plspm_sync() waits for it.  Lets a caller hand the buffers to RCCL without a host round trip. */
 int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out,
                            void** d_status, void** d_iters);

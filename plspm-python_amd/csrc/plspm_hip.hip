@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -420,12 +421,15 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const double* __restri
 // ------------------------------------------------------------------------------------------------ solver kernel
 struct DevExec {
     int tid, nt;
+    long long* marks;      // debug: phase timestamps of problem 0 (PLSPM_DEBUG_MARKS)
+    __device__ __forceinline__ void mark(int id) { if (marks && tid == 0) marks[id] = clock64(); }
     template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
     template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
 };
 struct SolverOut {      // per-problem strides; null base pointers are skipped
     double* row; long row_stride;
     int* status; int* iters;
+    long long* marks;
     FitOutputs fit;     // single-fit extras (problem 0 only)
 };
 // LDS: [S (if s_in_lds)] [small workspace (if small_in_lds)]; otherwise the global scratch areas are used.
@@ -446,7 +450,7 @@ __global__ void solver_kernel(ModelDesc md, const double* __restrict__ Mp, long 
     out.row = so.row ? so.row + b * so.row_stride : nullptr;
     out.status = so.status ? so.status + b : nullptr;
     out.iters = so.iters ? so.iters + b : nullptr;
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x};
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, (b == 0) ? so.marks : nullptr};
     solve_problem(ex, md, ws, Mp + b * mp_stride, out);
 }
 
@@ -665,6 +669,7 @@ int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to) {
     return m->n_eff;
 }
 int32_t plspm_row_width(const plspm_model_t* m) { return m ? 2 * m->P + m->L + 2 * m->n_eff : 0; }
+int32_t plspm_row_stride(const plspm_model_t* m) { return m ? plspm_row_width(m) + 2 : 0; }
 
 int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols, int32_t layout, const int32_t* col_index) {
     if (!m) return PLSPM_E_ARG;
@@ -790,7 +795,7 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
     // device-side result block
     const long o_w = 0, o_ld = o_w + P, o_cl = o_ld + P, o_pc = o_cl + (long)P * L, o_r2 = o_pc + (long)L * L, o_lc = o_r2 + L,
-               o_row = o_lc + (long)L * L, o_ind = o_row + (2L * P + L + 2L * ne), o_sw = o_ind + std::max(ne, 1), o_sc = o_sw + P, o_cov = o_sc + L,
+               o_row = o_lc + (long)L * L, o_ind = o_row + (2L * P + L + 2L * ne + 2), o_sw = o_ind + std::max(ne, 1), o_sc = o_sw + P, o_cov = o_sc + L,
                o_mean = o_cov + (long)P * P, o_end = o_mean + P;
     const size_t fit_bytes = (size_t)o_end * sizeof(double) + 64 + (size_t)L + 16;
     if ((rc = ensure(m, m->fitout, fit_bytes))) return rc;
@@ -856,7 +861,7 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     const long N = m->N;
     if (N > 36000) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: N > 36000 needs the global-histogram resampler (not built yet)");
     HIPCHK(m, hipSetDevice(m->device));
-    const int R = plspm_row_width(m);
+    const int R = plspm_row_stride(m);
     const long psize = packed_size(m->T);
     const long ent_stride = ((N + 3) & ~3L) + 4;
     // replicates per pass: bound the (row,count) + Gram scratch to ~2 GiB
@@ -885,9 +890,18 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         }
         SolverOut so{};
         so.row = (double*)m->rows.p + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
+        long long* d_marks = nullptr;
+        if (getenv("PLSPM_DEBUG_MARKS")) { HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks; }
         {
             ProfScope ps(m, PLSPM_K_SOLVER);
             if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, 64))) return rc;
+        }
+        if (d_marks) {
+            long long h[16];
+            HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+            HIPCHK(m, hipFree(d_marks));
         }
     }
     HIPCHK(m, hipGetLastError());
@@ -911,9 +925,10 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     void *d_out = nullptr, *d_st = nullptr, *d_it = nullptr;
     int rc = plspm_bootstrap_device(m, B, seed, rep_offset, d_idx, &d_out, &d_st, &d_it);
     if (rc) return rc;
-    const int R = plspm_row_width(m);
+    const int R = plspm_row_width(m), RS = plspm_row_stride(m);
     int h_err = 0;
-    HIPCHK(m, hipMemcpyAsync(out, d_out, (size_t)B * R * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpy2DAsync(out, (size_t)R * sizeof(double), d_out, (size_t)RS * sizeof(double), (size_t)R * sizeof(double), (size_t)B,
+                               hipMemcpyDeviceToHost, m->stream));
     if (status) HIPCHK(m, hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     if (iters) HIPCHK(m, hipMemcpyAsync(iters, d_it, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipMemcpyAsync(&h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));

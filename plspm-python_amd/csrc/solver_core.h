@@ -256,7 +256,8 @@ PLSPM_HD void iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) 
 }
 
 struct FitOutputs {             // any pointer may be null
-    double* row;                // [2P + L + 2 n_eff]  weights | r2 | total | direct | loadings   (device column order)
+    double* row;                // [2P + L + 2 n_eff + 2]  weights | r2 | total | direct | loadings | status | iterations
+                                //                         (device column order; the last two as doubles, for the one-collective gather)
     double* weights;            // [P]
     double* loadings;           // [P]
     double* crossloadings;      // [P*L]
@@ -276,7 +277,9 @@ struct FitOutputs {             // any pointer may be null
 template <class Ex>
 PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Mp, const FitOutputs& out) {
     const int P = md.P, L = md.L, PS = ws.PS;
+    ex.mark(0);
     moments_to_cov(ex, md, ws, Mp);
+    ex.mark(1);
     const double n = ws.scal[1];
     const double corr2 = n / (n - 1.0);
 
@@ -297,6 +300,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         ws.wf[l] = 1.0 / sqrt(s);
     });
     ex.par(P, [&](int p) { ws.w[p] = ws.wf[md.lvof[p]]; });
+    ex.mark(2);
 
     // weights.py:179-186: iteration counter, stop on conv < tol or counter > max_iter, fail if counter > max_iter
     int iteration = 0;
@@ -307,6 +311,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         if (conv < md.tol || iteration > md.max_iter) break;
     }
     ex.one([&]() { if (iteration > md.max_iter && ws.scal[3] == (double)ST_OK) ws.scal[3] = (double)ST_NOT_CONVERGED; });
+    ex.mark(3);
 
     // finalize (weights.py:56-70)
     apply_cov(ex, md, ws);
@@ -322,6 +327,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
     });
     ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.Cs[e] = ws.sgn[l] * ws.sgn[m] * ws.wf[l] * ws.wf[m] * ws.Q[e]; });
 
+    ex.mark(4);
     // inner model (inner_model.py:58-75): OLS with intercept == centred normal equations on the score covariance
     ex.par(L, [&](int i) {
         for (int j = 0; j < L; ++j) ws.Bm[i * L + j] = 0.0;
@@ -344,6 +350,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
             ws.r2[i] = expl / ws.Cs[i * L + i];
         }
     });
+    ex.mark(5);
     // effects (inner_model.py:33-53): indirect = sum_{k=2..L} B^k (none when L == 2), total = B + indirect
     ex.par(L * L, [&](int e) { ws.Ind[e] = 0.0; ws.Pw[e] = ws.Bm[e]; });
     if (L != 2) {
@@ -367,6 +374,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         }
     }
 
+    ex.mark(6);
     // outputs
     ex.par(P, [&](int p) {
         const int l = md.lvof[p];
@@ -411,7 +419,9 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         }
         if (out.status) *out.status = st;
         if (out.iters) *out.iters = iteration;
+        if (out.row) { out.row[2 * P + L + 2 * md.n_eff] = (double)st; out.row[2 * P + L + 2 * md.n_eff + 1] = (double)iteration; }
     });
+    ex.mark(7);
 }
 
 }  // namespace plspm

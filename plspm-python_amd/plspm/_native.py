@@ -16,7 +16,7 @@ ABI_VERSION = 1
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
 EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy",
-           "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device",
+           "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device",
            "plspm_sync", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
 
@@ -55,6 +55,8 @@ def load():
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
     lib.plspm_row_width.restype = i32
     lib.plspm_row_width.argtypes = [vp]
+    lib.plspm_row_stride.restype = i32
+    lib.plspm_row_stride.argtypes = [vp]
     lib.plspm_fit.argtypes = [vp, ctypes.POINTER(_FitResult)]
     lib.plspm_bootstrap.argtypes = [vp, i64, u64, i64, vp, vp, vp, vp]
     lib.plspm_bootstrap_device.argtypes = [vp, i64, u64, i64, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
@@ -109,6 +111,7 @@ class NativeModel:
         lib.plspm_effect_pairs(self._h, _ptr(ef), _ptr(et))
         self.eff_from, self.eff_to = ef[:self.n_eff], et[:self.n_eff]
         self.row_width = lib.plspm_row_width(self._h)
+        self.row_stride = lib.plspm_row_stride(self._h)     # device rows: [row | status | iterations]
         self.N = 0
 
     def _check(self, rc, what):

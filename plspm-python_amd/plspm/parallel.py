@@ -5,7 +5,8 @@ them over ``multiprocessing`` workers, bootstrap.py:91-94, and merges through a 
 Here rank g runs the contiguous replicate-id range ``shard_range(B, g, G)`` of one logical Philox stream keyed
 by (seed, replicate id), so the merged result is identical for every G, and the Queue becomes a single
 ``all_gather`` (RCCL over xGMI when the process group's backend is "nccl", gloo in the CPU tests).
-torch.distributed is used for rendezvous + the collective only.
+torch.distributed is used for rendezvous + the collective only; the device buffer that libplspm_hip filled is
+handed to RCCL in place (CUDA-array-interface view, no staging copy when the shards are equal).
 """
 import numpy as np
 
@@ -24,6 +25,23 @@ class _DeviceView:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
 
 
+_view_cache = {}
+_recv_cache = {}
+
+
+def device_rows(ptr, count, stride):
+    """torch view [count, stride] float64 of the result rows libplspm_hip left in HBM (cached per buffer)."""
+    import torch
+    key = (int(ptr), int(count), int(stride), torch.cuda.current_device())
+    t = _view_cache.get(key)
+    if t is None:
+        if len(_view_cache) > 64:
+            _view_cache.clear()
+        t = torch.as_tensor(_DeviceView(ptr, (count, stride), "<f8"), device=torch.device("cuda", torch.cuda.current_device()))
+        _view_cache[key] = t
+    return t
+
+
 def _world(group=None):
     try:
         import torch.distributed as dist
@@ -34,49 +52,71 @@ def _world(group=None):
     return dist, dist.get_rank(group), dist.get_world_size(group)
 
 
-def sharded_bootstrap(run_shard, total, width, group=None, on_device=False):
-    """Run ``total`` replicates split over the process group and return the merged
-    (rows [total, width] float64, status [total] int32, iters [total] int32) on every rank, in replicate-id order.
+def split_records(records, width):
+    """[row | status | iterations] records -> (rows, status int32, iters int32)."""
+    records = np.asarray(records)
+    return np.ascontiguousarray(records[:, :width]), records[:, width].astype(np.int32), records[:, width + 1].astype(np.int32)
+
+
+def gather_records(send, total, group=None):
+    """all_gather of per-rank record blocks (a torch tensor [mine, width+2] on the group's device) into one
+    [total, width+2] tensor in replicate-id order, on every rank.  This is the single collective of a bootstrap."""
+    import torch
+    dist, rank, world = _world(group)
+    if dist is None:
+        return send
+    stride = send.shape[1]
+    cap = shard_range(total, 0, world)[1]                 # rank 0 always holds the largest shard
+    equal = (total % world == 0)
+    if not equal:
+        padded = torch.zeros((cap, stride), dtype=send.dtype, device=send.device)
+        padded[:send.shape[0]] = send
+        send = padded
+    key = (world, cap, stride, str(send.device))
+    recv = _recv_cache.get(key)
+    if recv is None:
+        recv = torch.empty((world * cap, stride), dtype=send.dtype, device=send.device)
+        _recv_cache[key] = recv
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if equal:
+        return recv
+    parts = []
+    for r in range(world):
+        a, b = shard_range(total, r, world)
+        parts.append(recv[r * cap:r * cap + (b - a)])
+    return torch.cat(parts, dim=0)
+
+
+def sharded_bootstrap(run_shard, total, width, group=None, on_device=False, to_host=True):
+    """Run ``total`` replicates split over the process group; every rank gets all of them back, in replicate-id order.
 
     run_shard(count, first_id) executes one shard and returns
-      * host arrays (rows, status, iters)                       when on_device is False, or
-      * device pointers (rows_ptr, status_ptr, iters_ptr) + a ``sync`` callable  when on_device is True
-        (buffers stay on the GPU and go straight into RCCL).
+      * host arrays (rows [count, width], status, iters)                        when on_device is False, or
+      * (device pointer of [count, width+2] records, sync callable)             when on_device is True
+        (the buffer stays in HBM and goes straight into RCCL).
+    Returns (rows, status, iters) as NumPy arrays, or the merged record tensor when to_host is False.
     """
+    import torch
     dist, rank, world = _world(group)
     start, stop = shard_range(total, rank, world)
     mine = stop - start
-    res = run_shard(mine, start) if mine > 0 else None
-    if dist is None:
-        if on_device:
-            import torch
-            rows_ptr, st_ptr, it_ptr, sync = res
+    if on_device:
+        if mine > 0:
+            ptr, sync = run_shard(mine, start)
             sync()
-            rows = torch.as_tensor(_DeviceView(rows_ptr, (mine, width), "<f8"), device="cuda").cpu().numpy()
-            status = torch.as_tensor(_DeviceView(st_ptr, (mine,), "<i4"), device="cuda").cpu().numpy()
-            iters = torch.as_tensor(_DeviceView(it_ptr, (mine,), "<i4"), device="cuda").cpu().numpy()
-            return rows, status, iters
-        return res
-    import torch
-    cap = shard_range(total, 0, world)[1]            # rank 0 always holds the largest shard
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
-    # one packed record per replicate: [row | status | iters] as float64 so a single collective moves everything
-    send = torch.zeros((cap, width + 2), dtype=torch.float64, device=dev)
-    if mine > 0:
-        if on_device:
-            rows_ptr, st_ptr, it_ptr, sync = res
-            sync()
-            send[:mine, :width] = torch.as_tensor(_DeviceView(rows_ptr, (mine, width), "<f8"), device=dev)
-            send[:mine, width] = torch.as_tensor(_DeviceView(st_ptr, (mine,), "<i4"), device=dev).to(torch.float64)
-            send[:mine, width + 1] = torch.as_tensor(_DeviceView(it_ptr, (mine,), "<i4"), device=dev).to(torch.float64)
+            send = device_rows(ptr, mine, width + 2)
         else:
-            rows, status, iters = res
-            send[:mine, :width] = torch.from_numpy(np.ascontiguousarray(rows))
-            send[:mine, width] = torch.from_numpy(status.astype(np.float64))
-            send[:mine, width + 1] = torch.from_numpy(iters.astype(np.float64))
-    recv = torch.empty((world * cap, width + 2), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)             # the single collective of the job
-    merged = recv.cpu().numpy().reshape(world, cap, width + 2)
-    parts = [merged[r, :shard_range(total, r, world)[1] - shard_range(total, r, world)[0]] for r in range(world)]
-    flat = np.concatenate(parts, axis=0)
-    return np.ascontiguousarray(flat[:, :width]), flat[:, width].astype(np.int32), flat[:, width + 1].astype(np.int32)
+            send = torch.zeros((0, width + 2), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        if mine > 0:
+            rows, status, iters = run_shard(mine, start)
+            rec = np.concatenate((rows, status[:, None].astype(np.float64), iters[:, None].astype(np.float64)), axis=1)
+        else:
+            rec = np.zeros((0, width + 2))
+        if dist is None:
+            return split_records(rec, width) if to_host else rec
+        send = torch.from_numpy(np.ascontiguousarray(rec))
+    merged = gather_records(send, total, group)
+    if not to_host:
+        return merged
+    return split_records(merged.cpu().numpy(), width)

@@ -16,6 +16,7 @@ struct HostExec {
     std::barrier<>* bar;
     template <class F> void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); bar->arrive_and_wait(); }
     template <class F> void one(F f) { if (tid == 0) f(); bar->arrive_and_wait(); }
+    void mark(int) {}
 };
 
 extern "C" {

@@ -1,0 +1,233 @@
+"""CPU tests of the host side: the drop-in model-specification API (mirrors reference tests/test_config.py and
+tests/test_estimator-free parts), the model compiler, the C-ABI surface of libplspm_hip.so (loads, exports every symbol
+include/plspm_hip.h declares -- no compute calls without a GPU), and that the product fails loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pandas.testing as pdt
+import pytest
+
+import plspm.config as c
+from plspm import _native
+from plspm._compile import compile_model
+from plspm.bootstrap import _create_summary
+from plspm.mode import Mode
+from plspm.scale import Scale
+from plspm.scheme import Scheme
+from helpers import GOLDEN, load, satisfaction_frame, SAT_PREFIX
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def russa():
+    return pd.read_csv(os.path.join(GOLDEN, "ref_data", "russa.csv"), index_col=0)
+
+
+def russa_path():
+    lvs = ["AGRI", "IND", "POLINS"]
+    return pd.DataFrame([[0, 0, 0], [0, 0, 0], [1, 1, 0]], index=lvs, columns=lvs)
+
+
+# ------------------------------------------------------------------ Config / Structure (reference tests/test_config.py)
+def test_config_rejects_bad_path_matrix():
+    with pytest.raises(TypeError):
+        c.Config("hello")
+    with pytest.raises(ValueError):
+        c.Config(pd.DataFrame([[0, 0, 0]]))
+    with pytest.raises(ValueError):
+        c.Config(pd.DataFrame([[1, 1], [1, 1]]))
+    with pytest.raises(ValueError):
+        c.Config(pd.DataFrame([[1, 0], [2, 1]]))
+    with pytest.raises(ValueError):
+        c.Config(pd.DataFrame([[1, 0], [1, 1]], index=["A", "B"], columns=["C", "D"]))
+
+
+def test_config_lv_and_mv_consistency():
+    config = c.Config(russa_path())
+    with pytest.raises(ValueError):
+        config.add_lv("POO", Mode.A, c.MV("test"))
+    config.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("farm"), c.MV("rent"))
+    assert config.mode("AGRI") == Mode.A and config.mvs("AGRI") == ["gini", "farm", "rent"]
+    config.add_lv("IND", Mode.A, c.MV("gnpr"))
+    with pytest.raises(ValueError):                      # POLINS missing
+        config.filter(russa())
+    bad = c.Config(russa_path())
+    bad.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("farm"), c.MV("poo"))
+    bad.add_lv("IND", Mode.A, c.MV("gnpr")); bad.add_lv("POLINS", Mode.A, c.MV("ecks"))
+    with pytest.raises(ValueError):                      # column not in the data
+        bad.filter(russa())
+
+
+def test_config_filters_columns_in_add_lv_order_and_rejects_non_numeric():
+    config = c.Config(russa_path())
+    config.add_lv("POLINS", Mode.A)
+    config.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("farm"), c.MV("rent"))
+    config.add_lv("IND", Mode.A)
+    assert list(config.filter(russa())) == ["gini", "farm", "rent"]
+    data = russa(); data["gini"] = data["gini"].astype(str)
+    with pytest.raises(ValueError):
+        config.filter(data)
+
+
+def test_scale_promotion_rules():
+    def full(default, **kw):
+        cfg = c.Config(russa_path(), default_scale=default, **kw)
+        return cfg
+    cfg = full(None)
+    cfg.add_lv("POLINS", Mode.A, c.MV("ecks"), c.MV("death"), c.MV("demo"), c.MV("inst"))
+    cfg.add_lv("AGRI", Mode.A, c.MV("gini", Scale.NUM), c.MV("farm"), c.MV("rent"))
+    cfg.add_lv("IND", Mode.A, c.MV("gnpr"), c.MV("labo"))
+    with pytest.raises(TypeError):
+        cfg.treat(cfg.filter(russa()))
+    cfg = full(Scale.RAW)
+    cfg.add_lv("POLINS", Mode.A, c.MV("ecks"), c.MV("death"), c.MV("demo"), c.MV("inst"))
+    cfg.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("farm"), c.MV("rent"))
+    cfg.add_lv("IND", Mode.A, c.MV("gnpr"), c.MV("labo"))
+    cfg.treat(cfg.filter(russa()))
+    assert not cfg.scaled()
+    cfg = full(Scale.RAW)
+    cfg.add_lv("POLINS", Mode.A, c.MV("ecks", Scale.NUM), c.MV("death"), c.MV("demo"), c.MV("inst"))
+    cfg.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("farm"), c.MV("rent"))
+    cfg.add_lv("IND", Mode.A, c.MV("gnpr"), c.MV("labo"))
+    cfg.treat(cfg.filter(russa()))
+    assert cfg.scaled() and all(cfg.scale(mv) == Scale.NUM for mv in ["gini", "farm", "rent"])
+    cfg = full(Scale.RAW, scaled=False)
+    cfg.add_lv("AGRI", Mode.A, c.MV("gini", Scale.NUM), c.MV("farm", Scale.ORD), c.MV("rent"))
+    cfg.add_lv("IND", Mode.A, c.MV("gnpr"), c.MV("labo"))
+    cfg.add_lv("POLINS", Mode.A, c.MV("ecks"), c.MV("death"), c.MV("demo"), c.MV("inst"))
+    cfg.filter(russa())
+    assert not cfg.scaled() and cfg.scale("farm") == Scale.ORD and not cfg.metric()
+
+
+def test_structure_topological_order_matches_reference():
+    lvs = ["MANDRILL", "BONOBO", "APE", "GOAT", "CATFISH"]
+    expected = pd.DataFrame([[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [1, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 1, 0, 0]], index=lvs, columns=lvs)
+    s = c.Structure()
+    s.add_path(source=["BONOBO", "MANDRILL"], target=["APE"])
+    s.add_path(source=["APE"], target=["CATFISH", "GOAT"])
+    pdt.assert_frame_equal(expected, s.path())
+    pdt.assert_frame_equal(expected, s.path())                  # repeatable (the reference's second call raises)
+    rebuilt = c.Structure(expected).path()                      # same edges; order follows the row-major edge list
+    assert sorted(rebuilt.index) == sorted(lvs)
+    pdt.assert_frame_equal(rebuilt.loc[lvs, lvs], expected)
+    with pytest.raises(ValueError):
+        c.Structure().add_path(["A", "B"], ["C", "D"])
+    cyc = c.Structure(); cyc.add_path(["A"], ["B"]); cyc.add_path(["B"], ["A"])
+    with pytest.raises(ValueError):
+        cyc.path()
+
+
+def test_satisfaction_structure_order():
+    s = c.Structure()
+    s.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); s.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    s.add_path(["QUAL"], ["VAL", "SAT"]); s.add_path(["VAL"], ["SAT"]); s.add_path(["SAT"], ["LOY"])
+    import plspm_oracle as orc
+    p = s.path()
+    assert list(p) == orc.SAT_LVS and np.array_equal(p.values, orc.satisfaction_C())
+
+
+def test_duplicate_names_rejected():
+    s = c.Structure(); s.add_path(source=["BONOBO"], target=["APE"])
+    cfg = c.Config(s.path())
+    cfg.add_lv("BONOBO", Mode.A, c.MV("a"), c.MV("b"))
+    with pytest.raises(ValueError):
+        cfg.add_lv("APE", Mode.A, c.MV("a"), c.MV("b"))
+    with pytest.raises(ValueError):
+        c.Config(s.path()).add_lv("BONOBO", Mode.A, c.MV("BONOBO"))
+
+
+def test_metric_treat_is_one_global_scalar():
+    sat = satisfaction_frame()
+    s = c.Structure(); s.add_path(["IMAG"], ["EXPE"])
+    cfg = c.Config(s.path(), scaled=True)
+    cfg.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); cfg.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
+    f = cfg.filter(sat)
+    t = cfg.treat(f)
+    n = f.shape[0]
+    g = np.std(f.values.reshape(-1), ddof=1) * np.sqrt((n - 1) / n)
+    np.testing.assert_allclose(t.values, (f.values - f.values.mean(axis=0)) / g, rtol=1e-13)
+    assert t.std().nunique() > 1                                   # columns keep different spreads
+
+
+# ------------------------------------------------------------------ model compiler
+def test_compile_model_orders_and_maps():
+    sat = satisfaction_frame()
+    s = c.Structure()
+    s.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); s.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    s.add_path(["QUAL"], ["VAL", "SAT"]); s.add_path(["VAL"], ["SAT"]); s.add_path(["SAT"], ["LOY"])
+    cfg = c.Config(s.path(), scaled=False)
+    for lv, mode in (("IMAG", Mode.A), ("EXPE", Mode.B), ("VAL", Mode.A), ("QUAL", Mode.B), ("SAT", Mode.A), ("LOY", Mode.A)):
+        cfg.add_lv_with_columns_named(lv, mode, sat, SAT_PREFIX[lv])
+    f = cfg.filter(sat)
+    cm = compile_model(cfg, cfg.path(), list(f.columns))
+    assert cm.lvs == ["IMAG", "EXPE", "QUAL", "VAL", "SAT", "LOY"]
+    assert cm.dev_mvs[:5] == ["imag%d" % i for i in range(1, 6)] and cm.dev_mvs[10:15] == ["qual%d" % i for i in range(1, 6)]
+    assert list(f.columns)[10:14] == ["val%d" % i for i in range(1, 5)]            # data order is add_lv order (VAL before QUAL)
+    assert [list(f.columns)[i] for i in cm.col_index] == cm.dev_mvs
+    assert [cm.dev_mvs[i] for i in cm.inv_index] == list(f.columns)
+    assert cm.block_offset.tolist() == [0, 5, 10, 15, 19, 23, 27] and cm.modes.tolist() == [0, 1, 1, 0, 0, 0]
+    assert cm.endogenous() == ["EXPE", "QUAL", "VAL", "SAT", "LOY"]
+    assert Scheme.CENTROID.value.code == 0 and Scheme.FACTORIAL.value.code == 1 and Scheme.PATH.value.code == 2
+
+
+# ------------------------------------------------------------------ summaries (host side of the bootstrap)
+def test_create_summary_matches_reference_golden():
+    g = load("g6_summary")
+    frame = _create_summary(pd.DataFrame(g["samples"], columns=list("abcde")), pd.Series(g["original"], index=list("abcde")))
+    assert list(frame.columns) == list(g["columns"])
+    np.testing.assert_allclose(frame.values, g["summary"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    header = open(os.path.join(ROOT, "include", "plspm_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(plspm_[a-z_]+)\s*\(", header)) - {"plspm_model", "plspm_fit_result"})
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(lib, name), "libplspm_hip.so does not export " + name
+    assert sorted(_native.EXPORTS) == declared
+    assert lib.plspm_abi_version() == 1
+
+
+def test_host_rng_mirror_properties():
+    a = _native.bootstrap_indices(7, 0, 1000)
+    b = _native.bootstrap_indices(7, 0, 1000)
+    c2 = _native.bootstrap_indices(7, 1, 1000)
+    d = _native.bootstrap_indices(8, 0, 1000)
+    assert np.array_equal(a, b) and not np.array_equal(a, c2) and not np.array_equal(a, d)
+    assert a.min() >= 0 and a.max() < 1000
+    big = _native.bootstrap_indices(1, 5, 200000)
+    frac_unique = len(np.unique(big)) / 200000.0
+    assert abs(frac_unique - (1 - np.exp(-1))) < 0.01                 # ~63.2 % distinct rows per resample
+    assert abs(big.mean() / 200000.0 - 0.5) < 0.01
+
+
+@pytest.mark.skipif(_native.device_count() > 0, reason="needs a box WITHOUT a GPU")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    assert _native.device_count() == 0
+    with pytest.raises(_native.NativeBackendError):
+        _native.NativeModel(np.array([0, 2, 4]), np.array([[0, 0], [1, 0]]), np.array([0, 0]), 0, True, 100, 1e-6)
+    from plspm.plspm import Plspm
+    sat = satisfaction_frame()
+    s = c.Structure(); s.add_path(["IMAG"], ["EXPE"])
+    cfg = c.Config(s.path())
+    cfg.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); cfg.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
+    with pytest.raises(_native.NativeBackendError):
+        Plspm(sat, cfg)
+
+
+def test_unsupported_paths_raise_not_implemented():
+    from plspm.plspm import Plspm
+    sat = satisfaction_frame()
+    s = c.Structure(); s.add_path(["IMAG"], ["EXPE"])
+    cfg = c.Config(s.path(), default_scale=Scale.NUM)
+    cfg.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); cfg.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
+    with pytest.raises(NotImplementedError):
+        Plspm(sat, cfg)
+    with pytest.raises(AssertionError):
+        Plspm(sat, cfg, tolerance=0)
+    with pytest.raises(AssertionError):
+        Plspm(sat, cfg, bootstrap_iterations=100, processes=3)

@@ -41,7 +41,7 @@ def run_emu(lib, X, model, counts=None, shift=None, nthreads=4):
     ef = np.array([p[0] for p in pairs], dtype=np.int32)
     et = np.array([p[1] for p in pairs], dtype=np.int32)
     ne = len(pairs)
-    row = np.zeros(2 * P + L + 2 * ne); cl = np.zeros((P, L)); pc = np.zeros((L, L)); lc = np.zeros((L, L))
+    row = np.zeros(2 * P + L + 2 * ne + 2); cl = np.zeros((P, L)); pc = np.zeros((L, L)); lc = np.zeros((L, L))
     ind = np.zeros(max(ne, 1)); sw = np.zeros(P); sc = np.zeros(L); cov = np.zeros((P, P)); mean = np.zeros(P)
     sign = np.zeros(L, dtype=np.int8); iters = ctypes.c_int(0); status = ctypes.c_int(-1)
     shift = np.ascontiguousarray(shift, dtype=np.float64)
@@ -51,7 +51,7 @@ def run_emu(lib, X, model, counts=None, shift=None, nthreads=4):
                       _ptr(lc), _ptr(ind), _ptr(sw), _ptr(sc), _ptr(cov), _ptr(mean), _ptr(sign, ctypes.c_int8),
                       ctypes.byref(iters), ctypes.byref(status))
     inv = np.empty(P, dtype=np.int64); inv[order] = np.arange(P)          # data column -> device column
-    w = row[:P][inv]; ld = row[P + L + 2 * ne:][inv]
+    w = row[:P][inv]; ld = row[P + L + 2 * ne:2 * P + L + 2 * ne][inv]
     scores = ((Xdev - shift) * sw) @ np.equal.outer(np.repeat(np.arange(L), np.diff(boff)), np.arange(L)).astype(float) + sc
     return dict(weights=w, r2=row[P:P + L], total=row[P + L:P + L + ne], direct=row[P + L + ne:P + L + 2 * ne], loadings=ld,
                 crossloadings=cl[inv], path_coef=pc, lv_cov=lc, indirect=ind[:ne], sign=sign, iterations=iters.value,
