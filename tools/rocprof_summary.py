@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd (.db) outputs into profiles/: kernel time table (--kernel-trace --stats run) and per-kernel
+HBM counters (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs).
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
+read, so fetched bytes = 2 * FETCH_SIZE KiB; checked here on colsum_rowmajor_kernel, which reads a known N*P*8 bytes once.
+WRITE_SIZE is used as reported.
+usage: rocprof_summary.py <round-tag> <stats.db> [<fetch.db> <write.db>]"""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def main():
+    tag, stats = sys.argv[1], sys.argv[2]
+    out = {"round": tag, "kernels": [], "counters": {}}
+    cur = sqlite3.connect(stats).cursor()
+    lines = ["# rocprofv3 --kernel-trace --stats  (%s)" % tag, "", "| kernel | calls | total us | avg us | % |", "|---|---:|---:|---:|---:|"]
+    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        out["kernels"].append({"kernel": short(name), "calls": calls, "total_us": round(total, 3), "avg_us": round(avg, 3), "pct": round(pct, 2)})
+        lines.append("| %s | %d | %.1f | %.2f | %.2f |" % (short(name), calls, total, avg, pct))
+    if len(sys.argv) >= 5:
+        for key, db in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+            c2 = sqlite3.connect(db).cursor()
+            q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
+            for name, n, avg in c2.execute(q, (key,)):
+                out["counters"].setdefault(short(name), {})[key + "_KiB_avg"] = round(avg, 2)
+                out["counters"][short(name)]["dispatches_" + key] = n
+        lines += ["", "# HBM counters per dispatch (separate --pmc passes)", "",
+                  "| kernel | FETCH_SIZE KiB (raw) | fetched MB (x2 gfx950 correction) | WRITE_SIZE KiB | HBM MB / dispatch |", "|---|---:|---:|---:|---:|"]
+        for k, v in out["counters"].items():
+            f, w = v.get("FETCH_SIZE_KiB_avg", 0.0), v.get("WRITE_SIZE_KiB_avg", 0.0)
+            v["hbm_bytes_per_dispatch"] = int((2 * f + w) * 1024)
+            lines.append("| %s | %.1f | %.3f | %.1f | %.3f |" % (k, f, 2 * f * 1024 / 1e6, w, v["hbm_bytes_per_dispatch"] / 1e6))
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.md" % tag), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.json" % tag), "w") as fh:
+        json.dump(out, fh, indent=1)
+    gram = [k for k in out["counters"] if k.startswith("gram_")]
+    if gram:
+        with open(os.path.join(ROOT, "profiles", "%s_gram_traffic.json" % tag), "w") as fh:
+            json.dump({"kernel": gram[0], "hbm_bytes_per_launch": out["counters"][gram[0]]["hbm_bytes_per_dispatch"],
+                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md"}, fh, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
