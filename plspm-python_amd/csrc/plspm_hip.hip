@@ -421,10 +421,47 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const double* __restri
 // ------------------------------------------------------------------------------------------------ solver kernel
 struct DevExec {
     int tid, nt;
+    double* red;           // LDS scratch, one slot per wave
     long long* marks;      // debug: phase timestamps of problem 0 (PLSPM_DEBUG_MARKS)
     __device__ __forceinline__ void mark(int id) { if (marks && tid == 0) marks[id] = clock64(); }
     template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
     template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
+    // src is a sequence of 64-double chunks (one 512-byte coalesced row each); wave w takes chunks w, w + nw, ... with
+    // NB global loads issued before any is consumed.  The chunk index is wave-uniform (scalar decode).
+    template <class F> __device__ __forceinline__ void par_chunks64(int nchunks, const double* __restrict__ src, F f) {
+        const int lane = tid & 63, nw = nt >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        constexpr int NB = 20;                  // loads in flight per lane: the sweep is latency/queue bound (10 KB per wave outstanding)
+        for (int base = wave; base < nchunks; base += NB * nw) {
+            double v[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int c = base + j * nw; v[j] = (c < nchunks) ? src[c * 64 + lane] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int c = base + j * nw; if (c < nchunks) f(c, lane, v[j]); }
+        }
+        __syncthreads();
+    }
+    // group-wide sum: per-thread strided partials -> 64-lane shuffle tree -> (several waves) LDS; fixed order, every thread gets it
+    template <class F> __device__ __forceinline__ double sum(int n, F f) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += nt) s += f(i);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        s = __shfl(s, 0, 64);
+        if (nt > 64) {
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            s = 0.0;
+            for (int w = 0; w < (nt >> 6); ++w) s += red[w];
+        }
+        __syncthreads();
+        return s;
+    }
+    template <class F> __device__ __forceinline__ bool any(int n, F f) {
+        int hit = 0;
+        for (int i = tid; i < n; i += nt) hit |= f(i) ? 1 : 0;
+        return __syncthreads_or(hit) != 0;
+    }
 };
 struct SolverOut {      // per-problem strides; null base pointers are skipped
     double* row; long row_stride;
@@ -433,24 +470,62 @@ struct SolverOut {      // per-problem strides; null base pointers are skipped
     FitOutputs fit;     // single-fit extras (problem 0 only)
 };
 // LDS: [S (if s_in_lds)] [small workspace (if small_in_lds)]; otherwise the global scratch areas are used.
-__global__ void solver_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, int s_in_lds, int small_in_lds,
-                              double* gS, double* gsmall) {
+// The placement is a template parameter so that every workspace pointer has ONE provenance: the compiler then proves the
+// LDS ones to be address-space-3 (ds_read / ds_write) instead of falling back to flat_load / flat_store.
+template <bool S_IN_LDS, bool SMALL_IN_LDS>
+__global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gsmall) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
     const int PS = cov_ld(md.P);
-    const long s_doubles = (long)md.P * PS, small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    const long s_doubles = cov_doubles(md.P), small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
     Workspace ws;
     ws.PS = PS;
     double* lp = lds;
-    if (s_in_lds) { ws.S = lp; lp += s_doubles; } else ws.S = gS + b * s_doubles;
-    carve_small(ws, small_in_lds ? lp : gsmall + b * small_doubles, md.P, md.L, md.kmax, md.n_chol);
+    if (S_IN_LDS) { ws.S = lp; lp += s_doubles; } else ws.S = gS + b * s_doubles;
+    if (SMALL_IN_LDS) { carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol); lp += small_doubles; }
+    else carve_small(ws, gsmall + b * small_doubles, md.P, md.L, md.kmax, md.n_chol);
+    // stage the model descriptors in LDS: the solver consults them in every phase
+    {
+        const int P = md.P, L = md.L, ne = md.n_eff, tid = threadIdx.x, nt = blockDim.x;
+        double* sh = lp; lp += P;
+        int* ip = reinterpret_cast<int*>(lp);
+        int* boff = ip; ip += L + 1;
+        int* lvof = ip; ip += P;
+        int* mode = ip; ip += L;
+        int* choff = ip; ip += L;
+        int* ef = ip; ip += ne;
+        int* et = ip; ip += ne;
+        const int nedge = md.n_edges;
+        int* poff = ip; ip += L + 1;
+        int* soff = ip; ip += L + 1;
+        int* pidx = ip; ip += nedge;
+        int* sidx = ip; ip += nedge;
+        const int ntile = md.T * (md.T + 1) / 2;
+        unsigned short* ttu = reinterpret_cast<unsigned short*>(ip); ip += (ntile + 1) / 2;
+        unsigned char* Cb = reinterpret_cast<unsigned char*>(ip);
+        for (int i = tid; i < ntile; i += nt) {
+            int t = 0, rem = i;
+            while (rem >= md.T - t) { rem -= md.T - t; ++t; }
+            ttu[i] = (unsigned short)(t | ((t + rem) << 8));
+        }
+        for (int i = tid; i <= L; i += nt) { poff[i] = md.pred_off[i]; soff[i] = md.succ_off[i]; }
+        for (int i = tid; i < nedge; i += nt) { pidx[i] = md.pred_idx[i]; sidx[i] = md.succ_idx[i]; }
+        for (int i = tid; i < P; i += nt) { sh[i] = md.shift[i]; lvof[i] = md.lvof[i]; }
+        for (int i = tid; i <= L; i += nt) boff[i] = md.boff[i];
+        for (int i = tid; i < L; i += nt) { mode[i] = md.mode[i]; choff[i] = md.chol_off[i]; }
+        for (int i = tid; i < ne; i += nt) { ef[i] = md.eff_from[i]; et[i] = md.eff_to[i]; }
+        for (int i = tid; i < L * L; i += nt) Cb[i] = md.C[i];
+        md.shift = sh; md.boff = boff; md.lvof = lvof; md.mode = mode; md.chol_off = choff; md.eff_from = ef; md.eff_to = et; md.C = Cb;
+        md.pred_off = poff; md.succ_off = soff; md.pred_idx = pidx; md.succ_idx = sidx; md.tile_tu = ttu;
+        __syncthreads();
+    }
     FitOutputs out = so.fit;
     if (b != 0) out = FitOutputs{};
     out.row = so.row ? so.row + b * so.row_stride : nullptr;
     out.status = so.status ? so.status + b : nullptr;
     out.iters = so.iters ? so.iters + b : nullptr;
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, (b == 0) ? so.marks : nullptr};
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
     solve_problem(ex, md, ws, Mp + b * mp_stride, out);
 }
 
@@ -505,9 +580,10 @@ struct plspm_model {
     hipStream_t stream = nullptr;
     int P = 0, L = 0, PA = 0, T = 0, scheme = 0, scaled = 1, max_iter = 100, kmax = 0, n_eff = 0, n_chol = 0;
     double tol = 1e-6;
-    std::vector<int> boff, lvof, mode, chol_off, eff_from, eff_to;
+    std::vector<int> boff, lvof, mode, chol_off, eff_from, eff_to, pred_off, pred_idx, succ_off, succ_idx;
     std::vector<uint8_t> C;
     int *d_boff = nullptr, *d_lvof = nullptr, *d_mode = nullptr, *d_chol_off = nullptr, *d_eff_from = nullptr, *d_eff_to = nullptr;
+    int *d_pred_off = nullptr, *d_pred_idx = nullptr, *d_succ_off = nullptr, *d_succ_idx = nullptr;
     uint8_t* d_C = nullptr;
     double* d_shift = nullptr;
     int64_t N = 0;
@@ -575,6 +651,9 @@ static ModelDesc make_desc(const plspm_model* m) {
     md.kmax = m->kmax; md.n_eff = m->n_eff; md.n_chol = m->n_chol; md.tol = m->tol;
     md.boff = m->d_boff; md.lvof = m->d_lvof; md.C = m->d_C; md.mode = m->d_mode; md.chol_off = m->d_chol_off;
     md.eff_from = m->d_eff_from; md.eff_to = m->d_eff_to; md.shift = m->d_shift;
+    md.pred_off = m->d_pred_off; md.pred_idx = m->d_pred_idx; md.succ_off = m->d_succ_off; md.succ_idx = m->d_succ_idx;
+    md.n_edges = (int)m->pred_idx.size();
+    md.tile_tu = nullptr;
     return md;
 }
 
@@ -631,6 +710,13 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
         m->kmax = std::max(m->kmax, k);
         if (mode[l] == PLSPM_MODE_B) { const int kb = m->boff[l + 1] - m->boff[l]; m->chol_off[l] = m->n_chol; m->n_chol += kb * kb; }
     }
+    m->pred_off.assign(L + 1, 0); m->succ_off.assign(L + 1, 0);
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < L; ++j) if (m->C[i * L + j]) m->pred_idx.push_back(j);
+        m->pred_off[i + 1] = (int)m->pred_idx.size();
+        for (int s2 = 0; s2 < L; ++s2) if (m->C[s2 * L + i]) m->succ_idx.push_back(s2);
+        m->succ_off[i + 1] = (int)m->succ_idx.size();
+    }
     // transitive closure -> effect rows (from-major), inner_model.py:46-52
     std::vector<uint8_t> reach(m->C);
     for (int k = 0; k < L; ++k) for (int i = 0; i < L; ++i) for (int j = 0; j < L; ++j)
@@ -644,7 +730,8 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
     if (upload_vec(m, &m->d_boff, m->boff) || upload_vec(m, &m->d_lvof, m->lvof) || upload_vec(m, &m->d_mode, m->mode) ||
         upload_vec(m, &m->d_chol_off, m->chol_off) || upload_vec(m, &m->d_eff_from, m->eff_from) || upload_vec(m, &m->d_eff_to, m->eff_to) ||
-        upload_vec(m, &m->d_C, m->C))
+        upload_vec(m, &m->d_C, m->C) || upload_vec(m, &m->d_pred_off, m->pred_off) || upload_vec(m, &m->d_pred_idx, m->pred_idx) ||
+        upload_vec(m, &m->d_succ_off, m->succ_off) || upload_vec(m, &m->d_succ_idx, m->succ_idx))
         return bail("descriptor upload failed");
     if (hipMalloc((void**)&m->d_shift, sizeof(double) * P) != hipSuccess) return bail("hipMalloc failed");
     return m;
@@ -656,6 +743,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -753,20 +841,32 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
     return 0;
 }
 
+static size_t desc_lds_bytes(int P, int L, int ne, int nedge) {
+    return (size_t)P * 8 + (3 * (size_t)(L + 1) + P + 2 * (size_t)L + 2 * (size_t)ne + 2 * (size_t)nedge + 72) * 4 + (((size_t)L * L + 15) & ~(size_t)15) + 16;
+}
+
 static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, int threads) {
     const int P = m->P, L = m->L;
-    const size_t s_bytes = (size_t)P * cov_ld(P) * sizeof(double);
+    const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
     const size_t small_bytes = (size_t)workspace_small_doubles(P, L, m->kmax, m->n_chol) * sizeof(double);
     const size_t lds_budget = (nproblems == 1) ? kMaxLds : 64 * 1024;   // batched: keep >= 2 workgroups per CU
     int s_in_lds = 0, small_in_lds = 0;
-    size_t lds = 0;
-    if (small_bytes <= lds_budget) { small_in_lds = 1; lds += small_bytes; }
+    size_t lds = desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
+    if (lds + small_bytes <= lds_budget) { small_in_lds = 1; lds += small_bytes; }
     if (small_in_lds && lds + s_bytes <= lds_budget) { s_in_lds = 1; lds += s_bytes; }
     if (!s_in_lds) { int rc = ensure(m, m->gS, (size_t)nproblems * s_bytes); if (rc) return rc; }
     if (!small_in_lds) { int rc = ensure(m, m->gsmall, (size_t)nproblems * small_bytes); if (rc) return rc; }
-    { int rc = allow_lds(m, (const void*)solver_kernel, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(solver_kernel, dim3((unsigned)nproblems), dim3(threads), lds, m->stream, make_desc(m), Mp, mp_stride, so, s_in_lds, small_in_lds,
-                       (double*)m->gS.p, (double*)m->gsmall.p);
+#define SOLVER_LAUNCH(A, B)                                                                                                        \
+    {                                                                                                                              \
+        int rc = allow_lds(m, (const void*)solver_kernel<A, B>, lds);                                                               \
+        if (rc) return rc;                                                                                                         \
+        hipLaunchKernelGGL((solver_kernel<A, B>), dim3((unsigned)nproblems), dim3(threads), lds, m->stream, make_desc(m), Mp, mp_stride, so, \
+                           (double*)m->gS.p, (double*)m->gsmall.p);                                                                \
+    }
+    if (s_in_lds && small_in_lds) SOLVER_LAUNCH(true, true)
+    else if (small_in_lds) SOLVER_LAUNCH(false, true)
+    else SOLVER_LAUNCH(false, false)
+#undef SOLVER_LAUNCH
     HIPCHK(m, hipGetLastError());
     return 0;
 }
@@ -894,13 +994,16 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         if (getenv("PLSPM_DEBUG_MARKS")) { HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks; }
         {
             ProfScope ps(m, PLSPM_K_SOLVER);
-            if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, 64))) return rc;
+            if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 64))) return rc;
         }
         if (d_marks) {
             long long h[16];
             HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+            fprintf(stderr, "[plspm cov] sweep %lld  scale-factor %lld  centre+sd %lld\n", h[14] - h[0], h[15] - h[14], h[1] - h[15]);
+            fprintf(stderr, "[plspm last iterate] apply_cov %lld  a+G %lld  inner_weights %lld  outer %lld  conv+copy %lld\n", h[9] - h[8], h[10] - h[9],
+                    h[11] - h[10], h[12] - h[11], h[13] - h[12]);
             HIPCHK(m, hipFree(d_marks));
         }
     }

@@ -20,7 +20,9 @@
 //
 // Execution model: every thread of the group runs solve_problem(); `ex.par(n, f)` distributes
 // indices over the group and ends with a group barrier, `ex.one(f)` runs f on thread 0 and
-// barriers.  Every value that crosses threads lives in the workspace (never in a local).
+// barriers, `ex.sum(n, f)` / `ex.any(n, f)` are group-wide reductions whose result every thread
+// receives (wave shuffles + LDS on the GPU).  Every other value that crosses threads lives in the
+// workspace (never in a local).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -61,13 +63,19 @@ struct ModelDesc {
     const unsigned char* C;     // [L*L] C[i*L+j] = 1 iff LV j -> LV i
     const int* mode;            // [L]
     const int* chol_off;        // [L]   offset of the Mode-B Cholesky factor of block l inside ws.chol (-1 for Mode A)
+    const int* pred_off;        // [L+1] CSR of predecessors: pred_idx[pred_off[i] .. pred_off[i+1]) = { j : C[i,j] = 1 }, ascending
+    const int* pred_idx;        // [n_edges]
+    const int* succ_off;        // [L+1] CSR of successors:   succ_idx[succ_off[i] .. ) = { s : C[s,i] = 1 }, ascending
+    const int* succ_idx;        // [n_edges]
+    int n_edges;
     const int* eff_from;        // [n_eff]
     const int* eff_to;          // [n_eff]
     const double* shift;        // [P]   column shift applied at upload
+    const unsigned short* tile_tu;   // [T(T+1)/2] (t | u << 8) of every stored tile, or null (decode on the fly)
 };
 
 struct Workspace {
-    double* S;                  // [P*PS] treated population covariance, S[q*PS+p]
+    double* S;                  // [(P+1)*PS] treated population covariance S[q*PS+p], p,q < P; row/column P: raw column sums and n
     int PS;
     double *w, *wn, *cv, *dv, *sd, *mu;         // [P] each
     double* V;                  // [P*L]
@@ -75,13 +83,15 @@ struct Workspace {
     double *a, *wf, *sgn, *r2;  // [L] each
     double* scr;                // [L*(kmax*kmax+kmax)]
     double* chol;               // [n_chol]
-    double* scal;               // [8]  0 conv, 1 n, 2 1/(n g^2) or 1/n, 3 status, 4 nonzero-flag
+    double* scal;               // [8]  1 n, 2 1/(n g^2) or 1/n, 3 status
+    double* red;                // [16] scratch of the group reductions (Ex::sum / Ex::any), one slot per wave
 };
 
 PLSPM_HD long workspace_small_doubles(int P, int L, int kmax, int n_chol) {
-    return 6L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * (kmax * kmax + kmax) + n_chol + 8;
+    return 6L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * (kmax * kmax + kmax) + n_chol + 8 + 16;
 }
-PLSPM_HD int cov_ld(int P) { return P | 1; }
+PLSPM_HD int cov_ld(int P) { return (P + 1) | 1; }      // S carries the ones row/column P as well (column sums, n)
+PLSPM_HD long cov_doubles(int P) { return (long)(P + 1) * cov_ld(P); }
 
 PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, int n_chol) {
     double* p = base;
@@ -92,7 +102,8 @@ PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, i
     ws.a = p; p += L; ws.wf = p; p += L; ws.sgn = p; p += L; ws.r2 = p; p += L;
     ws.scr = p; p += (long)L * (kmax * kmax + kmax);
     ws.chol = p; p += n_chol;
-    ws.scal = p;
+    ws.scal = p; p += 8;
+    ws.red = p;
 }
 
 // In-place Cholesky A = R^T R of a k x k SPD matrix (row-major, ld k, upper part used/overwritten).
@@ -127,40 +138,141 @@ PLSPM_HD void chol_solve(const double* R, int k, double* b) {
     }
 }
 
+// Normal equations  M[idx, idx] x = M[idx, col]  for a short index list (the <= kmax predecessors of an LV), M an
+// L x L covariance matrix in the workspace.  k <= 8 runs entirely in registers (fully unrolled, predicated
+// Cholesky: the workspace accesses are the k*k + k independent gathers only); larger k uses `scratch`.
+template <int K>
+PLSPM_HD bool spd_solve_fixed(const double* M, int L, const int* idx, int k, int col, double* x) {
+    double A[K][K], b[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const int ir = (r < k) ? idx[r] : 0;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const int ic = (c < k) ? idx[c] : 0;
+            A[r][c] = (r < k && c < k) ? M[ir * L + ic] : ((r == c) ? 1.0 : 0.0);   // identity padding keeps the factorisation well defined
+        }
+        b[r] = (r < k) ? M[ir * L + col] : 0.0;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int r = 0; r < j; ++r) d -= A[r][j] * A[r][j];
+        ok = ok && (d > 0.0);
+        d = sqrt(d);
+        A[j][j] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int c = j + 1; c < K; ++c) {
+            double t = A[j][c];
+#pragma unroll
+            for (int r = 0; r < j; ++r) t -= A[r][j] * A[r][c];
+            A[j][c] = t * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        double t = b[i];
+#pragma unroll
+        for (int r = 0; r < i; ++r) t -= A[r][i] * b[r];
+        b[i] = t / A[i][i];
+    }
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        double t = b[i];
+#pragma unroll
+        for (int c = i + 1; c < K; ++c) t -= A[i][c] * b[c];
+        b[i] = t / A[i][i];
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) if (r < k) x[r] = b[r];
+    return ok;
+}
+PLSPM_HD bool spd_solve(const double* M, int L, const int* idx, int k, int col, double* x, double* scratch) {
+    if (k <= 2) return spd_solve_fixed<2>(M, L, idx, k, col, x);
+    if (k <= 4) return spd_solve_fixed<4>(M, L, idx, k, col, x);
+    if (k <= 8) return spd_solve_fixed<8>(M, L, idx, k, col, x);
+    double* A = scratch;
+    for (int r = 0; r < k; ++r) {
+        for (int c = 0; c < k; ++c) A[r * k + c] = M[idx[r] * L + idx[c]];
+        x[r] = M[idx[r] * L + col];
+    }
+    const bool ok = chol_factor(A, k);
+    chol_solve(A, k, x);
+    return ok;
+}
+// sum_{q in [a, b)} S[q*PS + p] * w[q]  with four independent accumulators (the LDS reads of one step overlap)
+PLSPM_HD double dot_col(const double* S, int PS, int p, const double* w, int a, int b) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = a;
+    for (; q + 3 < b; q += 4) {
+        s0 += S[q * PS + p] * w[q];
+        s1 += S[(q + 1) * PS + p] * w[q + 1];
+        s2 += S[(q + 2) * PS + p] * w[q + 2];
+        s3 += S[(q + 3) * PS + p] * w[q + 3];
+    }
+    for (; q < b; ++q) s0 += S[q * PS + p] * w[q];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage 1: packed raw scatter -> treated population covariance S (config.py:299-305, util.py:33-39)
+// Inverse of packed_index for one stored element: tile (t,u), register r, lane -> (p, q) with p the row column.
+PLSPM_HD void packed_coords(int t, int u, int r, int lane, int& p, int& q) {
+    const int row = (lane >> 4) + 4 * r, col = lane & 15;
+    p = 32 * (t >> 1) + 2 * row + (t & 1);
+    q = 32 * (u >> 1) + 2 * col + (u & 1);
+}
+
 template <class Ex>
 PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Mp) {
     const int P = md.P, PS = ws.PS, T = md.T;
-    ex.par(P, [&](int p) { ws.mu[p] = Mp[packed_index(T, md.P, p)]; });   // column sums of the shifted data
-    ex.one([&]() {
-        const double n = Mp[packed_index(T, md.P, md.P)];
-        double fac = 1.0 / n;
-        if (md.scaled) {
-            // g = std1(all N*P raw values) * sqrt((N-1)/N)   (config.py:302), evaluated around the grand mean
-            double tot = 0.0;
-            for (int p = 0; p < P; ++p) tot += ws.mu[p] + n * md.shift[p];
-            const double np_ = n * (double)P, grand = tot / np_;
-            double ss = 0.0;
-            for (int p = 0; p < P; ++p) {
-                const double d = md.shift[p] - grand;
-                ss += Mp[packed_index(T, p, p)] + 2.0 * d * ws.mu[p] + n * d * d;
-            }
-            const double g2 = ss / (np_ - 1.0) * ((n - 1.0) / n);
-            fac = 1.0 / (n * g2);
-        }
-        ws.scal[1] = n;
-        ws.scal[2] = fac;
-        ws.scal[3] = (double)ST_OK;
+    // 1. sweep the stored tiles in memory order (coalesced 512-byte rows, loads batched): raw second moments -> S,
+    //    the ones-column entries -> column sums mu and the row count n.  Diagonal tiles hold both triangles: only
+    //    their row <= col half is used so that S is exactly symmetric.
+    const int ntile = T * (T + 1) / 2;
+    ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
+        const int tile = chunk >> 2, r = chunk & 3;
+        int t, u;
+        if (md.tile_tu) { const int tu = md.tile_tu[tile]; t = tu & 255; u = tu >> 8; }
+        else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
+        const int p = 32 * (t >> 1) + (t & 1) + 8 * r + 2 * (lane >> 4);      // packed_coords, chunk part hoisted
+        const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
+        if ((t != u || p <= q) && p <= P && q <= P) { ws.S[q * PS + p] = m; ws.S[p * PS + q] = m; }
     });
-    ex.par(P * P, [&](int e) {
-        const int q = e / P, p = e - q * P;
-        if (p <= q) {
-            const double n = ws.scal[1];
-            const double v = (Mp[packed_index(T, p, q)] - ws.mu[p] * ws.mu[q] / n) * ws.scal[2];
-            ws.S[q * PS + p] = v;
-            ws.S[p * PS + q] = v;
+    ex.par(P, [&](int p) { ws.mu[p] = ws.S[P * PS + p]; });
+    ex.one([&]() { ws.scal[1] = ws.S[P * PS + P]; });
+    ex.mark(14);
+    const double n = ws.scal[1], inv_n = 1.0 / n;
+    double fac = inv_n;
+    if (md.scaled) {
+        // g = std1(all N*P raw values) * sqrt((N-1)/N)   (config.py:302), evaluated around the grand mean
+        const double tot = ex.sum(P, [&](int p) { return ws.mu[p] + n * md.shift[p]; });
+        const double np_ = n * (double)P, grand = tot / np_;
+        const double ss = ex.sum(P, [&](int p) {
+            const double d = md.shift[p] - grand;
+            return ws.S[p * PS + p] + 2.0 * d * ws.mu[p] + n * d * d;
+        });
+        const double g2 = ss / (np_ - 1.0) * ((n - 1.0) / n);
+        fac = 1.0 / (n * g2);
+    }
+    ex.one([&]() { ws.scal[2] = fac; ws.scal[3] = (double)ST_OK; });
+    ex.mark(15);
+    // 2. centre and scale in place: S <- (M - mu mu' / n) * fac   (thread p owns column p: conflict-free LDS walk)
+    ex.par(P, [&](int p) {
+        const double mp = ws.mu[p];
+        int q = 0;
+        for (; q + 3 < P; q += 4) {
+            const double a0 = ws.S[q * PS + p], a1 = ws.S[(q + 1) * PS + p], a2 = ws.S[(q + 2) * PS + p], a3 = ws.S[(q + 3) * PS + p];
+            const double m0 = ws.mu[q], m1 = ws.mu[q + 1], m2 = ws.mu[q + 2], m3 = ws.mu[q + 3];
+            ws.S[q * PS + p] = (a0 - (mp * m0) * inv_n) * fac;           // (mu_p mu_q) first: bitwise symmetric in (p, q)
+            ws.S[(q + 1) * PS + p] = (a1 - (mp * m1) * inv_n) * fac;
+            ws.S[(q + 2) * PS + p] = (a2 - (mp * m2) * inv_n) * fac;
+            ws.S[(q + 3) * PS + p] = (a3 - (mp * m3) * inv_n) * fac;
         }
+        for (; q < P; ++q) ws.S[q * PS + p] = (ws.S[q * PS + p] - (mp * ws.mu[q]) * inv_n) * fac;
     });
     ex.par(P, [&](int p) { ws.sd[p] = sqrt(ws.S[p * PS + p]); });
 }
@@ -170,11 +282,7 @@ template <class Ex>
 PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {
     const int P = md.P, L = md.L, PS = ws.PS;
     ex.par(P, [&](int p) {
-        for (int m = 0; m < L; ++m) {
-            double s = 0.0;
-            for (int q = md.boff[m]; q < md.boff[m + 1]; ++q) s += ws.S[q * PS + p] * ws.w[q];
-            ws.V[p * L + m] = s;
-        }
+        for (int m = 0; m < L; ++m) ws.V[p * L + m] = dot_col(ws.S, PS, p, ws.w, md.boff[m], md.boff[m + 1]);
     });
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;
@@ -192,22 +300,19 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
         ex.par(L, [&](int i) {
             for (int j = 0; j < L; ++j) ws.E[j * L + i] = 0.0;
             const int km = md.kmax;
-            double* A = ws.scr + (long)i * (km * km + km);
-            double* rhs = A + km * km;
-            int f[64];
-            int k = 0;
-            for (int j = 0; j < L; ++j) if (md.C[i * L + j]) f[k++] = j;      // predecessors of i ("follow", scheme.py:47)
+            double* scratch = ws.scr + (long)i * (km * km + km);
+            const int* f = md.pred_idx + md.pred_off[i];                    // predecessors of i ("follow", scheme.py:47)
+            const int k = md.pred_off[i + 1] - md.pred_off[i];
             if (k > 0) {
-                for (int r = 0; r < k; ++r) {
-                    for (int c = 0; c < k; ++c) A[r * k + c] = ws.G[f[r] * L + f[c]];
-                    rhs[r] = ws.G[f[r] * L + i];
-                }
-                if (!chol_factor(A, k)) ws.scal[3] = (double)ST_SINGULAR;
-                chol_solve(A, k, rhs);
-                for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = rhs[r];
+                double* x = scratch + km * km;
+                if (!spd_solve(ws.G, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
+                for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = x[r];
             }
-            for (int s = 0; s < L; ++s)                                        // successors of i ("predec", scheme.py:51)
-                if (md.C[s * L + i]) ws.E[s * L + i] = ws.G[s * L + i] / sqrt(ws.G[s * L + s] * ws.G[i * L + i]);
+            const double gii = ws.G[i * L + i];
+            for (int e2 = md.succ_off[i]; e2 < md.succ_off[i + 1]; ++e2) {  // successors of i ("predec", scheme.py:51)
+                const int s2 = md.succ_idx[e2];
+                ws.E[s2 * L + i] = ws.G[s2 * L + i] / sqrt(ws.G[s2 * L + s2] * gii);
+            }
         });
     } else {
         ex.par(L * L, [&](int e) {
@@ -227,14 +332,18 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
     }
 }
 
-// One PLS iteration (weights.py:41-54).  Leaves the convergence measure in ws.scal[0].
+// One PLS iteration (weights.py:41-54).  Returns the convergence measure (identical on every thread).
 template <class Ex>
-PLSPM_HD void iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) {
+PLSPM_HD double iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) {
     const int P = md.P, L = md.L;
+    ex.mark(8);
     apply_cov(ex, md, ws);
+    ex.mark(9);
     ex.par(L, [&](int l) { ws.a[l] = 1.0 / (corr2 * sqrt(ws.Q[l * L + l])); });   // Yhat_l = Y_l / std1 / corr
     ex.par(L * L, [&](int e) { ws.G[e] = ws.a[e / L] * ws.a[e % L] * ws.Q[e]; });
+    ex.mark(10);
     inner_weights(ex, md, ws, corr2);
+    ex.mark(11);
     ex.par(P, [&](int p) {                                                         // (S Wn E)[p, lv(p)]  == X'Z/N  (mode.py:29)
         const int l = md.lvof[p];
         double s = 0.0;
@@ -250,9 +359,11 @@ PLSPM_HD void iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) 
             }
         });
     }
-    ex.par(P, [&](int p) { const double d = fabs(ws.w[p]) - fabs(ws.wn[p]); ws.dv[p] = d * d; });
-    ex.one([&]() { double s = 0.0; for (int p = 0; p < P; ++p) s += ws.dv[p]; ws.scal[0] = s; });
+    ex.mark(12);
+    const double conv = ex.sum(P, [&](int p) { const double d = fabs(ws.w[p]) - fabs(ws.wn[p]); return d * d; });
     ex.par(P, [&](int p) { ws.w[p] = ws.wn[p]; });
+    ex.mark(13);
+    return conv;
 }
 
 struct FitOutputs {             // any pointer may be null
@@ -294,9 +405,11 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         });
     }
     // init (weights.py:28-39): w_p = corr / std1(sum of the block's MVs) = 1 / sqrt(sum(S_bb))
+    ex.par(P, [&](int p) { const int l = md.lvof[p]; ws.w[p] = 1.0; ws.dv[p] = 0.0; (void)l; });
+    ex.par(P, [&](int p) { const int l = md.lvof[p]; ws.dv[p] = dot_col(ws.S, PS, p, ws.w, md.boff[l], md.boff[l + 1]); });   // block row sums
     ex.par(L, [&](int l) {
         double s = 0.0;
-        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) for (int q = md.boff[l]; q < md.boff[l + 1]; ++q) s += ws.S[q * PS + p];
+        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += ws.dv[p];
         ws.wf[l] = 1.0 / sqrt(s);
     });
     ex.par(P, [&](int p) { ws.w[p] = ws.wf[md.lvof[p]]; });
@@ -306,8 +419,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
     int iteration = 0;
     while (true) {
         ++iteration;
-        iterate(ex, md, ws, corr2);
-        const double conv = ws.scal[0];
+        const double conv = iterate(ex, md, ws, corr2);
         if (conv < md.tol || iteration > md.max_iter) break;
     }
     ex.one([&]() { if (iteration > md.max_iter && ws.scal[3] == (double)ST_OK) ws.scal[3] = (double)ST_NOT_CONVERGED; });
@@ -318,11 +430,14 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
     ex.par(L, [&](int l) { ws.wf[l] = 1.0 / sqrt(ws.Q[l * L + l]); });        // 1 / (std1(X w_l) / corr)
     ex.par(P, [&](int p) { ws.w[p] *= ws.wf[md.lvof[p]]; });                  // returned weights: never sign-flipped
     ex.par(L, [&](int l) {                                                    // sign rule: EVERY MV votes (weights.py:62-64)
+        // sign(cor[p,l]) == sign(V[p,l]): cor = V * wf / sd with wf, sd > 0
         int vote = 0;
-        for (int p = 0; p < P; ++p) {
-            const double cor = ws.V[p * L + l] * ws.wf[l] / ws.sd[p];
-            vote += (cor < 0.0) ? -1 : 1;
+        int p = 0;
+        for (; p + 3 < P; p += 4) {
+            const double v0 = ws.V[p * L + l], v1 = ws.V[(p + 1) * L + l], v2 = ws.V[(p + 2) * L + l], v3 = ws.V[(p + 3) * L + l];
+            vote += ((v0 < 0.0) ? -1 : 1) + ((v1 < 0.0) ? -1 : 1) + ((v2 < 0.0) ? -1 : 1) + ((v3 < 0.0) ? -1 : 1);
         }
+        for (; p < P; ++p) vote += (ws.V[p * L + l] < 0.0) ? -1 : 1;
         ws.sgn[l] = (vote < 0) ? -1.0 : 1.0;
     });
     ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.Cs[e] = ws.sgn[l] * ws.sgn[m] * ws.wf[l] * ws.wf[m] * ws.Q[e]; });
@@ -333,20 +448,14 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         for (int j = 0; j < L; ++j) ws.Bm[i * L + j] = 0.0;
         ws.r2[i] = 0.0;
         const int km = md.kmax;
-        double* A = ws.scr + (long)i * (km * km + km);
-        double* rhs = A + km * km;
-        int f[64];
-        int k = 0;
-        for (int j = 0; j < L; ++j) if (md.C[i * L + j]) f[k++] = j;
+        double* scratch = ws.scr + (long)i * (km * km + km);
+        const int* f = md.pred_idx + md.pred_off[i];
+        const int k = md.pred_off[i + 1] - md.pred_off[i];
         if (k > 0) {
-            for (int r = 0; r < k; ++r) {
-                for (int c = 0; c < k; ++c) A[r * k + c] = ws.Cs[f[r] * L + f[c]];
-                rhs[r] = ws.Cs[f[r] * L + i];
-            }
-            if (!chol_factor(A, k)) ws.scal[3] = (double)ST_SINGULAR;
-            chol_solve(A, k, rhs);
+            double* x = scratch + km * km;
+            if (!spd_solve(ws.Cs, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
             double expl = 0.0;
-            for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = rhs[r]; expl += rhs[r] * ws.Cs[f[r] * L + i]; }
+            for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = x[r]; expl += x[r] * ws.Cs[f[r] * L + i]; }
             ws.r2[i] = expl / ws.Cs[i * L + i];
         }
     });
@@ -364,12 +473,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
                 nxt[e] = s;
                 ws.Ind[e] += s;
             });
-            ex.one([&]() {
-                double any = 0.0;
-                for (int e = 0; e < L * L; ++e) if (nxt[e] != 0.0) any = 1.0;
-                ws.scal[4] = any;
-            });
-            if (ws.scal[4] == 0.0) break;             // B is nilpotent: all further powers vanish exactly
+            if (!ex.any(L * L, [&](int e) { return nxt[e] != 0.0; })) break;   // B is nilpotent: further powers vanish exactly
             double* t = cur; cur = nxt; nxt = t;
         }
     }
@@ -409,14 +513,13 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         if (out.row) { out.row[P + L + e] = ws.Bm[idx] + ws.Ind[idx]; out.row[P + L + md.n_eff + e] = ws.Bm[idx]; }
         if (out.indirect) out.indirect[e] = ws.Ind[idx];
     });
+    const bool bad = ex.any(P + L, [&](int e) {
+        if (e < P) return !(isfinite(ws.w[e]) && isfinite(ws.sd[e]) && ws.sd[e] > 0.0);
+        return !isfinite(ws.r2[e - P]);
+    });
     ex.one([&]() {
         int st = (int)ws.scal[3];
-        if (st == ST_OK) {
-            bool ok = true;
-            for (int p = 0; p < P; ++p) ok = ok && isfinite(ws.w[p]) && isfinite(ws.sd[p]) && ws.sd[p] > 0.0;
-            for (int l = 0; l < L; ++l) ok = ok && isfinite(ws.r2[l]);
-            if (!ok) st = ST_NONFINITE;
-        }
+        if (st == ST_OK && bad) st = ST_NONFINITE;
         if (out.status) *out.status = st;
         if (out.iters) *out.iters = iteration;
         if (out.row) { out.row[2 * P + L + 2 * md.n_eff] = (double)st; out.row[2 * P + L + 2 * md.n_eff + 1] = (double)iteration; }

@@ -17,6 +17,31 @@ struct HostExec {
     template <class F> void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); bar->arrive_and_wait(); }
     template <class F> void one(F f) { if (tid == 0) f(); bar->arrive_and_wait(); }
     void mark(int) {}
+    template <class F> void par_chunks64(int nchunks, const double* src, F f) {
+        for (int c = tid; c < nchunks; c += nt) for (int lane = 0; lane < 64; ++lane) f(c, lane, src[c * 64 + lane]);
+        bar->arrive_and_wait();
+    }
+    double* red;
+    template <class F> double sum(int n, F f) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += nt) s += f(i);
+        red[tid] = s;
+        bar->arrive_and_wait();
+        double t = 0.0;
+        for (int k = 0; k < nt; ++k) t += red[k];
+        bar->arrive_and_wait();
+        return t;
+    }
+    template <class F> bool any(int n, F f) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += nt) if (f(i)) s = 1.0;
+        red[tid] = s;
+        bar->arrive_and_wait();
+        bool t = false;
+        for (int k = 0; k < nt; ++k) t = t || (red[k] != 0.0);
+        bar->arrive_and_wait();
+        return t;
+    }
 };
 
 extern "C" {
@@ -24,8 +49,9 @@ extern "C" {
 // Mp: packed scatter (see packed_index); everything else mirrors ModelDesc / FitOutputs.
 int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
                   const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Mp,
-                  int nthreads, double* row, double* crossloadings, double* path_coef, double* lv_cov, double* indirect,
+                  int nthreads_in, double* row, double* crossloadings, double* path_coef, double* lv_cov, double* indirect,
                   double* score_w, double* score_c, double* cov, double* mean, int8_t* sign, int* iters, int* status) {
+    const int nthreads = nthreads_in > 16 ? 16 : nthreads_in;
     std::vector<int> lvof(P), chol_off(L, -1);
     int kmax = 0, n_chol = 0;
     for (int l = 0; l < L; ++l) {
@@ -35,12 +61,22 @@ int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, do
         kmax = k > kmax ? k : kmax;
         if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += kb * kb; }
     }
+    std::vector<int> pred_off(L + 1, 0), pred_idx, succ_off(L + 1, 0), succ_idx;
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < L; ++j) if (C[i * L + j]) pred_idx.push_back(j);
+        pred_off[i + 1] = (int)pred_idx.size();
+        for (int s2 = 0; s2 < L; ++s2) if (C[s2 * L + i]) succ_idx.push_back(s2);
+        succ_off[i + 1] = (int)succ_idx.size();
+    }
+    pred_idx.push_back(0); succ_idx.push_back(0);
     ModelDesc md{};
+    md.pred_off = pred_off.data(); md.pred_idx = pred_idx.data(); md.succ_off = succ_off.data(); md.succ_idx = succ_idx.data();
+    md.n_edges = pred_off[L];
     md.P = P; md.L = L; md.PA = PA; md.T = PA / 16; md.scheme = scheme; md.scaled = scaled; md.max_iter = max_iter;
     md.kmax = kmax; md.n_eff = n_eff; md.n_chol = n_chol; md.tol = tol; md.boff = boff; md.lvof = lvof.data(); md.C = C;
     md.mode = mode; md.chol_off = chol_off.data(); md.eff_from = eff_from; md.eff_to = eff_to; md.shift = shift;
     const int PS = cov_ld(P);
-    std::vector<double> S((size_t)P * PS), small(workspace_small_doubles(P, L, kmax, n_chol));
+    std::vector<double> S((size_t)cov_doubles(P)), small(workspace_small_doubles(P, L, kmax, n_chol));
     FitOutputs out{};
     out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.lv_cov = lv_cov; out.indirect = indirect;
     out.score_w = score_w; out.score_c = score_c; out.cov = cov; out.mean = mean; out.sign = sign; out.iters = iters; out.status = status;
@@ -51,7 +87,7 @@ int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, do
             Workspace ws{};
             ws.S = S.data(); ws.PS = PS;
             carve_small(ws, small.data(), P, L, kmax, n_chol);
-            HostExec ex{t, nthreads, &bar};
+            HostExec ex{t, nthreads, &bar, ws.red};
             solve_problem(ex, md, ws, Mp, out);
         });
     for (auto& x : th) x.join();

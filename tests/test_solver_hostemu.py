@@ -144,7 +144,9 @@ def test_thread_count_invariance(emu):
     model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "path", True)
     base = run_emu(emu, X, model, nthreads=1)["row"]
     for nt in (2, 3, 7, 16):
-        assert np.array_equal(base, run_emu(emu, X, model, nthreads=nt)["row"])     # bitwise: no order-dependent reductions
+        other = run_emu(emu, X, model, nthreads=nt)["row"]
+        assert_close(other, base, 1e-12, 1e-14)                # group reductions sum per-thread partials: order depends on the group size
+        assert np.array_equal(other, run_emu(emu, X, model, nthreads=nt)["row"])    # but a fixed group size is bit-reproducible
 
 
 def test_not_converged_status(emu):
