@@ -42,7 +42,11 @@ def synth_inputs():
 
 def cpu_worker(args):
     seed, count = args
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)                      # one BLAS thread per worker: the pool, not BLAS, spreads over the cores
+    except ImportError:
+        pass
     orc, X, blocks = synth_inputs()
     model = orc.Model(blocks, orc.satisfaction_C(), "A" * N_LV, "path", True)
     corr = orc.correction(N_OBS)
@@ -158,6 +162,15 @@ def main():
     ref_row, ref_it = orc.bootstrap_replicate(X, omodel, idx0, orc.correction(N_OBS))
     assert ref_it == iters[0] and np.allclose(rows[0], ref_row, rtol=1e-8, atol=1e-11), "timed path disagrees with the oracle"
 
+    pcie = None
+    if world == 1 and not use_dist:
+        # the same batch through the host-buffer entry point (results copied back over PCIe every step); never `value`
+        model.bootstrap(B_total, seed=1)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            model.bootstrap(B_total, seed=1)
+        pcie = B_total * 5 / (time.perf_counter() - t1)
+
     if rank == 0:
         gram_ms, gram_n = model.profile_read("gram")
         res_ms, res_n = model.profile_read("resample")
@@ -196,6 +209,9 @@ def main():
             "kernels_ms_per_step": {"resample": round(res_ms / max(res_n, 1), 4), "gram": round(gram_avg_ms, 4),
                                     "solver": round(sol_ms / max(sol_n, 1), 4)},
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = {"value": round(pcie, 1), "unit": "replicates/s",
+                                      "note": "plspm_bootstrap(): device -> pageable host copy of the B x 156 rows every step"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
