@@ -413,9 +413,16 @@ __global__ void __launch_bounds__(NWP * 64) gram_wide_kernel(const double* __res
 __global__ void __launch_bounds__(256) gram_reduce_kernel(const double* __restrict__ partial, int nchunks, long size, double* __restrict__ out) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= size) return;
-    double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += partial[(long)c * size + e];
-    out[e] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 3 < nchunks; c += 4) {
+        s0 += partial[(long)c * size + e];
+        s1 += partial[(long)(c + 1) * size + e];
+        s2 += partial[(long)(c + 2) * size + e];
+        s3 += partial[(long)(c + 3) * size + e];
+    }
+    for (; c < nchunks; ++c) s0 += partial[(long)c * size + e];
+    out[e] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------------ solver kernel
@@ -531,42 +538,50 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
 
 // ------------------------------------------------------------------------------------------------ scores kernel
 // scores[i][l] = sum_{p in block l} xa[i][p] * score_w[p] + score_c[l]   (weights.py:60, sign rule folded into score_w)
-// A 64-row tile of Xa is staged in LDS with coalesced 16-byte loads (row stride PA+1 doubles: conflict-free column
-// walks); thread (row, l-group) then forms the short per-block dot products and the tile's scores leave through LDS
-// as one contiguous 64*L block.
+// A 16-row tile of Xa (16*PA*8 contiguous bytes) is staged in LDS with coalesced 16-byte loads (row stride PA+1 doubles:
+// conflict-free column walks); thread (row, l-group) forms the short per-block dot products; the tile's scores leave
+// through LDS as one contiguous 16*L block.  Small tiles keep several workgroups per CU resident so that one
+// workgroup's HBM loads overlap another's LDS phase (HBM-bound: 8*N*(PA+L) bytes).
+#define SCORE_ROWS 16
 __global__ void __launch_bounds__(256) scores_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, const int* __restrict__ boff,
                                                       const double* __restrict__ score_w, const double* __restrict__ score_c,
-                                                      double* __restrict__ scores, int stage_out) {
+                                                      double* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* tile = reinterpret_cast<double*>(smem_raw);     // [64][PA+1]
-    double* wsh = tile + 64 * (PA + 1);                     // [P]
-    double* osh = wsh + P;                                  // [64*L]
+    double* tile = reinterpret_cast<double*>(smem_raw);     // [16][PA+1]
+    double* wsh = tile + SCORE_ROWS * (PA + 1);             // [P]
+    double* osh = wsh + P;                                  // [16*L]
+    int* bsh = reinterpret_cast<int*>(osh + SCORE_ROWS * L); // [L+1]
     const int tid = threadIdx.x;
     for (int p = tid; p < P; p += 256) wsh[p] = score_w[p];
-    const long ntiles = (N + 63) / 64;
+    for (int l = tid; l <= L; l += 256) bsh[l] = boff[l];
+    const long ntiles = (N + SCORE_ROWS - 1) / SCORE_ROWS;
+    const int half = PA >> 1;
+    const int r_c = tid & 15, lg = tid >> 4;
     for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const long i0 = tl * 64;
-        const int rows = (int)lmin(64, N - i0);
+        const long i0 = tl * SCORE_ROWS;
+        const int rows = (int)lmin(SCORE_ROWS, N - i0);
         __syncthreads();
         const double2* src = reinterpret_cast<const double2*>(Xa + i0 * PA);
-        const int n2 = rows * PA / 2;
+        const int n2 = rows * half;
         for (int e = tid; e < n2; e += 256) {
             const double2 v = src[e];
-            const int r = (2 * e) / PA, c = (2 * e) - r * PA;
+            const int r = e / half, c = 2 * (e - r * half);
             tile[r * (PA + 1) + c] = v.x;
             tile[r * (PA + 1) + c + 1] = v.y;
         }
         __syncthreads();
-        const int r = tid & 63;
-        for (int l = tid >> 6; l < L; l += 4) {
-            double s = 0.0;
-            for (int p = boff[l]; p < boff[l + 1]; ++p) s += tile[r * (PA + 1) + p] * wsh[p];
-            if (stage_out) osh[r * L + l] = s + score_c[l];
-            else if (r < rows) scores[(i0 + r) * L + l] = s + score_c[l];
+        for (int l = lg; l < L; l += 16) {
+            const double* row = tile + r_c * (PA + 1);
+            double s0 = 0.0, s1 = 0.0;
+            int p = bsh[l];
+            const int pe = bsh[l + 1];
+            for (; p + 1 < pe; p += 2) { s0 += row[p] * wsh[p]; s1 += row[p + 1] * wsh[p + 1]; }
+            if (p < pe) s0 += row[p] * wsh[p];
+            osh[r_c * L + l] = (s0 + s1) + score_c[l];
         }
         __syncthreads();
         double* dst = scores + i0 * L;
-        if (stage_out) for (int e = tid; e < rows * L; e += 256) dst[e] = osh[e];
+        for (int e = tid; e < rows * L; e += 256) dst[e] = osh[e];
     }
 }
 
@@ -831,7 +846,11 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
         case 8: WIDE(8, 4, 4) break;
         case 10: WIDE(10, 4, 4) break;
         case 12: WIDE(12, 4, 4) break;
-        case 14: WIDE(14, 8, 8) break;
+        case 14: {
+            const char* nw = getenv("PLSPM_WIDE_NW");
+            const int sel = nw ? atoi(nw) : 4;      // measured on 1M x 200: NW=4 0.99 ms, 8: 1.12 ms, 16 (two workgroups per walk): 1.37 ms
+            if (sel == 4) WIDE(14, 4, 4) else if (sel == 16) WIDE(14, 16, 8) else WIDE(14, 8, 8)
+        } break;
         case 16: WIDE(16, 16, 8) break;
         default: return fail(m, PLSPM_E_LIMIT, "unsupported tile count");
     }
@@ -888,8 +907,12 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     const long N = m->N;
     const long psize = packed_size(m->T);
     const long ng = (N + 3) / 4;
+    // row chunks (workgroups) of the dense Gram: enough k-groups per wave to amortise the pipeline prologue, and at most
+    // ~2 workgroups per CU so the fixed-order reduce stays small
     const int waves_per_wg = (m->T <= 4) ? 4 : 1;
-    const int nchunks = (int)std::max<long>(1, std::min<long>(m->T <= 4 ? 512 : 1024, (ng + waves_per_wg * 4 - 1) / (waves_per_wg * 4)));
+    const long per_wave = 16;
+    const char* nc_env = getenv("PLSPM_FIT_CHUNKS");
+    const int nchunks = nc_env ? atoi(nc_env) : (int)std::max<long>(1, std::min<long>(512, (ng + waves_per_wg * per_wave - 1) / (waves_per_wg * per_wave)));
     int rc;
     if ((rc = ensure(m, m->gram_partial, (size_t)nchunks * psize * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
@@ -922,14 +945,11 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     }
     if (out->scores) {
         if ((rc = ensure(m, m->rows, (size_t)N * L * sizeof(double)))) return rc;
-        size_t lds = ((size_t)64 * (m->PA + 1) + P + 64 * (size_t)L) * sizeof(double);
-        int stage_out = 1;
-        if (lds > kMaxLds) { stage_out = 0; lds -= 64 * (size_t)L * sizeof(double); }
+        const size_t lds = ((size_t)SCORE_ROWS * (m->PA + 1) + P + SCORE_ROWS * (size_t)L) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
         if ((rc = allow_lds(m, (const void*)scores_kernel, lds))) return rc;
-        const int grid = (int)std::min<long>(2048, (N + 63) / 64);
+        const int grid = (int)std::min<long>(256 * 8, (N + SCORE_ROWS - 1) / SCORE_ROWS);
         ProfScope ps(m, PLSPM_K_SCORES);
-        hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->rows.p,
-                           stage_out);
+        hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->rows.p);
     }
     HIPCHK(m, hipGetLastError());
     auto get = [&](void* dst, const void* src, size_t bytes) -> hipError_t {

@@ -314,3 +314,36 @@ def test_plspm_api_bootstrap_matches_reference_statistical_test():
                                ("satisfaction_boot_loadings.csv", calc.bootstrap().loading(), 0.15)):
         expected = pd.read_csv(os.path.join(ref, fname), index_col=0)
         np.testing.assert_allclose(util.sort_cols(expected), util.sort_cols(frame.drop(columns=drop)), atol=atol, err_msg=fname)
+
+
+def test_config5_full_size_1m_rows_properties():
+    """BASELINE.json configs[4] at full size (1,000,000 x 200 x 20, Mode B, FACTORIAL): size-independent properties.
+    The N x L scores come from the streaming scores kernel, lv_cov / path coefficients from the Gram + LDS solver:
+    two independent device paths that must agree; a 50k-row prefix is checked against the oracle outright."""
+    C = orc.chain_C(20)
+    X, blocks = orc.synth(1000000, C, 10, seed=0)
+    model = orc.Model(blocks, C, "B" * 20, "factorial", True)
+    nm, g = gpu_fit(X, model)
+    n = X.shape[0]
+    assert g["status"] == 0 and 2 <= g["iterations"] <= 4
+    s = g["scores"]
+    assert np.all(np.isfinite(s))
+    assert np.max(np.abs(s.mean(axis=0))) < 1e-9                       # scores are centred
+    cov = s.T @ s / n
+    assert_close(np.diag(cov), np.ones(20), 1e-9)                      # ... and have unit population variance (weights.py:57-60)
+    assert_close(cov, g["lv_cov"], 1e-8, 1e-10, what="streamed scores vs Gram-side LV covariance")
+    # inner-model normal equations hold on the streamed scores
+    for i in range(20):
+        f = np.flatnonzero(C[i])
+        if f.size:
+            beta = np.linalg.solve(cov[np.ix_(f, f)], cov[f, i])
+            assert_close(g["path_coef"][i, f], beta, 1e-7, 1e-10)
+    # Mode B optimality: X_b' (z_l - X_b w_l) = 0  <=>  within a block, cov(x_p, score_l) is proportional to (S_bb w)_p
+    Xt = X[::20, :]                                                    # 50k-row slice for a cheap loadings check
+    sub = s[::20, :]
+    ld = np.array([np.corrcoef(Xt[:, p], sub[:, p // 10])[0, 1] for p in range(0, 200, 7)])
+    assert_close(g["loadings"][0:200:7], ld, 0, 0.02)                  # statistical: slice vs full sample
+    # prefix vs oracle (exact parity on the same 50k rows)
+    Xs = np.ascontiguousarray(X[:50000])
+    _, gs = gpu_fit(Xs, model)
+    check_fit(gs, orc.fit(Xs, model), "50k prefix")

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Single-fit latency on BASELINE.json configs[1] (10k x 60 x 6, Mode A, PATH) and configs[4] (1M x 200 x 20, Mode B, FACTORIAL):
+per-kernel HIP-event times through the C-ABI profile hooks + wall time of plspm_fit; algorithmic roofline per SURVEY.md 8(d):
+A_fit = 16 N P + 8 N L bytes, F_fit = N P (P+1) + 2 N P L flops.  Usage: python tools/fit_bench.py [c2] [c5]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+import plspm_oracle as orc  # noqa: E402
+from plspm import _native  # noqa: E402
+
+
+def run(tag, n, C, per, modes, scheme, reps=5):
+    L = C.shape[0]
+    t0 = time.time()
+    X, blocks = orc.synth(n, C, per, seed=0)
+    t_gen = time.time() - t0
+    P = X.shape[1]
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+    m = _native.NativeModel(boff, C.astype(np.uint8), np.array(modes, dtype=np.int32), scheme, True, 100, 1e-6, 0)
+    t0 = time.time(); m.upload(X); t_up = time.time() - t0
+    out = m.fit(want_scores=True)                      # warm-up
+    m.profile(True); m.profile_reset()
+    t0 = time.time()
+    for _ in range(reps):
+        out = m.fit(want_scores=True)
+    wall = (time.time() - t0) / reps
+    t0 = time.time()
+    for _ in range(reps):
+        m.fit(want_scores=False)
+    wall_noscores = (time.time() - t0) / reps
+    k = {name: m.profile_read(name) for name in ("gram", "reduce", "solver", "scores")}
+    ms = {name: (v[0] / max(v[1], 1)) for name, v in k.items()}
+    a_fit = 16.0 * n * P + 8.0 * n * L
+    f_fit = float(n) * P * (P + 1) + 2.0 * n * P * L
+    dev_ms = ms["gram"] + ms["reduce"] + ms["solver"] + ms["scores"]
+    line = {"config": tag, "N": n, "P": P, "L": L, "iterations": out["iterations"], "status": out["status"],
+            "kernel_ms": {a: round(b, 4) for a, b in ms.items()}, "device_ms_total": round(dev_ms, 4),
+            "fit_wall_ms_incl_scores_download": round(wall * 1e3, 3), "fit_wall_ms_no_scores": round(wall_noscores * 1e3, 3),
+            "upload_ms": round(t_up * 1e3, 1), "synth_s": round(t_gen, 1),
+            "algorithmic": {"bytes": a_fit, "flops": f_fit, "GBps_on_device_time": round(a_fit / dev_ms / 1e6, 1),
+                            "TFLOPs_on_gram_time": round(float(n) * P * (P + 1) / ms["gram"] / 1e9, 2),
+                            "scores_GBps": round((8.0 * n * m.P + 8.0 * n * L) / ms["scores"] / 1e6, 1) if ms["scores"] > 0 else None}}
+    print(json.dumps(line), flush=True)
+    return m, out, X, blocks
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c5"]
+    if "c2" in which:
+        run("configs[1] 10k x 60 x 6 Mode A PATH", 10000, orc.satisfaction_C(), 10, [0] * 6, 2, reps=20)
+    if "c5" in which:
+        run("configs[4] 1M x 200 x 20 Mode B FACTORIAL", 1000000, orc.chain_C(20), 10, [1] * 20, 1, reps=3)
