@@ -163,24 +163,32 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
         }
     }
     __syncthreads();
+    // ordered compaction with two barriers: wave w owns the contiguous row range [w*Q, (w+1)*Q); pass 1 counts its
+    // non-empty rows, pass 2 writes them behind the preceding waves' totals (ballot + popcount prefix inside a wave).
     int2* my_ent = ent + b * ent_stride;
-    int base = 0;
-    for (int c0 = 0; c0 < N; c0 += 256) {
-        const int row = c0 + tid;
-        const int cnt = (row < N) ? (int)hist[row] : 0;
-        const unsigned long long bal = __ballot(cnt > 0);
-        if (lane == 0) wave_tot[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_tot[w];
-        off += __popcll(bal & ((1ull << lane) - 1ull));
-        if (cnt > 0) my_ent[off] = make_int2(row, cnt);
-        base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        __syncthreads();
+    const int Q = (((N + 3) >> 2) + 63) & ~63;
+    const int r0 = wave * Q, r1 = min(N, r0 + Q);
+    int mine = 0;
+    for (int c0 = r0; c0 < r1; c0 += 64) {
+        const int row = c0 + lane;
+        const int cnt = (row < r1) ? (int)hist[row] : 0;
+        mine += __popcll(__ballot(cnt > 0));
     }
-    const int padded = (base + 3) & ~3;
-    if (tid < padded - base) my_ent[base + tid] = make_int2(0, 0);
-    if (tid == 0) nent[b] = base;
+    if (lane == 0) wave_tot[wave] = mine;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    for (int c0 = r0; c0 < r1; c0 += 64) {
+        const int row = c0 + lane;
+        const int cnt = (row < r1) ? (int)hist[row] : 0;
+        const unsigned long long bal = __ballot(cnt > 0);
+        if (cnt > 0) my_ent[off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(row, cnt);
+        off += __popcll(bal);
+    }
+    const int padded = (total + 3) & ~3;
+    if (tid < padded - total) my_ent[total + tid] = make_int2(0, 0);
+    if (tid == 0) nent[b] = total;
 }
 
 // ------------------------------------------------------------------------------------------------ Gram (fp64 MFMA)
@@ -333,37 +341,48 @@ __global__ void __launch_bounds__(256) gram_rows_kernel(const double* __restrict
     d4 acc[NT];
     gram_walk<T, 1, 0, DENSE>(acc, Xa, N, e, ng, chunk * 4 + wave, nchunks * 4, lane);
 
-    // tree reduce: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores.
+    // tree reduce: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores.  One tile at a time
+    // (compiler fence per tile) so the epilogue does not inflate the kernel's VGPR budget past the main loop's.
+#define TILE_FENCE() asm volatile("" ::: "memory")
     if (wave >= 2) {
         double* dst = red + (long)(wave - 2) * NT * 256;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64 + lane] = acc[t][r];
+            TILE_FENCE();
+        }
     }
     __syncthreads();
     if (wave < 2) {
         const double* src = red + (long)wave * NT * 256;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][r] += src[(t * 4 + r) * 64 + lane];
+            TILE_FENCE();
+        }
     }
     __syncthreads();
     if (wave == 1) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(t * 4 + r) * 64 + lane] = acc[t][r];
+            TILE_FENCE();
+        }
     }
     __syncthreads();
     if (wave == 0) {
         double* dst = out + (problem * nchunks + chunk) * (long)(NT * 256);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64 + lane] = acc[t][r] + red[(t * 4 + r) * 64 + lane];
+            TILE_FENCE();
+        }
     }
+#undef TILE_FENCE
 }
 
 // Tile-split variant (6 <= T <= 16): the NW waves of a workgroup walk the SAME k-groups; wave W owns the upper tiles
@@ -433,6 +452,17 @@ struct DevExec {
     __device__ __forceinline__ void mark(int id) { if (marks && tid == 0) marks[id] = clock64(); }
     template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
     template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
+    // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
+    template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
+        int i0 = tid, i1 = 0;
+        while (i0 >= n0) { i0 -= n0; ++i1; }
+        while (i1 < n1) {
+            f(i0, i1);
+            i0 += nt;
+            while (i0 >= n0) { i0 -= n0; ++i1; }
+        }
+        __syncthreads();
+    }
     // src is a sequence of 64-double chunks (one 512-byte coalesced row each); wave w takes chunks w, w + nw, ... with
     // NB global loads issued before any is consumed.  The chunk index is wave-uniform (scalar decode).
     template <class F> __device__ __forceinline__ void par_chunks64(int nchunks, const double* __restrict__ src, F f) {
@@ -1014,7 +1044,7 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         if (getenv("PLSPM_DEBUG_MARKS")) { HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks; }
         {
             ProfScope ps(m, PLSPM_K_SOLVER);
-            if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 64))) return rc;
+            if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 128))) return rc;
         }
         if (d_marks) {
             long long h[16];

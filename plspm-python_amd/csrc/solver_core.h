@@ -20,7 +20,8 @@
 //
 // Execution model: every thread of the group runs solve_problem(); `ex.par(n, f)` distributes
 // indices over the group and ends with a group barrier, `ex.one(f)` runs f on thread 0 and
-// barriers, `ex.sum(n, f)` / `ex.any(n, f)` are group-wide reductions whose result every thread
+// barriers, `ex.par2(n0, n1, f)` is par over the n0 x n1 index grid (first index fastest, no integer division),
+// `ex.sum(n, f)` / `ex.any(n, f)` are group-wide reductions whose result every thread
 // receives (wave shuffles + LDS on the GPU).  Every other value that crosses threads lives in the
 // workspace (never in a local).
 #pragma once
@@ -281,9 +282,7 @@ PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const d
 template <class Ex>
 PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {
     const int P = md.P, L = md.L, PS = ws.PS;
-    ex.par(P, [&](int p) {
-        for (int m = 0; m < L; ++m) ws.V[p * L + m] = dot_col(ws.S, PS, p, ws.w, md.boff[m], md.boff[m + 1]);
-    });
+    ex.par2(P, L, [&](int p, int m) { ws.V[p * L + m] = dot_col(ws.S, PS, p, ws.w, md.boff[m], md.boff[m + 1]); });
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;
         double s = 0.0;

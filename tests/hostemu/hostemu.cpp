@@ -17,6 +17,10 @@ struct HostExec {
     template <class F> void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); bar->arrive_and_wait(); }
     template <class F> void one(F f) { if (tid == 0) f(); bar->arrive_and_wait(); }
     void mark(int) {}
+    template <class F> void par2(int n0, int n1, F f) {
+        for (int e = tid; e < n0 * n1; e += nt) f(e % n0, e / n0);
+        bar->arrive_and_wait();
+    }
     template <class F> void par_chunks64(int nchunks, const double* src, F f) {
         for (int c = tid; c < nchunks; c += nt) for (int lane = 0; lane < 64; ++lane) f(c, lane, src[c * 64 + lane]);
         bar->arrive_and_wait();
