@@ -107,40 +107,67 @@ def main():
     orc, X, blocks = synth_inputs()
     C = orc.satisfaction_C()
     boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
-    model = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, device_id)
-    model.upload(X)                                            # X resident in HBM before the timed region
+
+    def make_model():
+        mdl = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, device_id)
+        mdl.upload(X)                                          # X resident in HBM before the timed region
+        return mdl
+
+    model = make_model()
     B_total = args.reps_per_gpu * world
     width = model.row_width
-
-    def run_shard(count, first):
-        d_rows, _, _ = model.bootstrap_device(count, seed=1, rep_offset=first)
-        return d_rows, model.sync
+    # N > 1: two handles (each with its own result buffer) alternate, so the all_gather of step k runs on RCCL's stream
+    # under the kernels of step k+1; every step still does all of its work (shard compute + one collective) and the
+    # closing fence waits for the last collective.
+    models = [model, make_model()] if use_dist else [model]
+    pending = [None, None]
+    state = {"k": 0, "last": None}
 
     def step():
         if not use_dist:
             model.bootstrap_device(B_total, seed=1, rep_offset=0)
             model.sync()
             return None
-        return parallel.sharded_bootstrap(run_shard, B_total, width, on_device=True, to_host=False)   # merged rows stay in HBM
+        k = state["k"] % 2
+        state["k"] += 1
+        if pending[k] is not None:
+            pending[k][1].wait()                               # the buffer of this handle is free again
+        mdl = models[k]
+        start, stop = parallel.shard_range(B_total, rank, world)
+        d_rows, _, _ = mdl.bootstrap_device(stop - start, seed=1, rep_offset=start)
+        mdl.sync()
+        send = parallel.device_rows(d_rows, stop - start, width + 2)
+        pending[k] = parallel.gather_records(send, B_total, async_op=True, slot=k)
+        state["last"] = pending[k]
+        return pending[k]
+
+    def drain():
+        for pk in pending:
+            if pk is not None:
+                pk[1].wait()
 
     def fence():
-        model.sync()
+        for mdl in models:
+            mdl.sync()
         if use_dist:
+            drain()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    model.profile(True)
-    model.profile_reset()
+    for mdl in models:
+        mdl.profile(True)
+        mdl.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    model.profile(False)
+    for mdl in models:
+        mdl.profile(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -148,7 +175,10 @@ def main():
 
     if use_dist:
         # the gathered records of the last timed step: complete, in replicate-id order, identical on every rank
-        rec = step().cpu().numpy()
+        rec, work = step()
+        work.wait()
+        torch.cuda.synchronize()
+        rec = rec.cpu().numpy()
         assert rec.shape == (B_total, width + 2) and np.all(rec[:, width] == 0), "gather lost replicates"
         probe = min(B_total - 1, (B_total // world) * (world - 1) + 3)          # a row owned by the last rank
         one, _, _ = model.bootstrap(1, seed=1, rep_offset=probe)
@@ -172,9 +202,12 @@ def main():
         pcie = B_total * 5 / (time.perf_counter() - t1)
 
     if rank == 0:
-        gram_ms, gram_n = model.profile_read("gram")
-        res_ms, res_n = model.profile_read("resample")
-        sol_ms, sol_n = model.profile_read("solver")
+        def prof(name):
+            parts = [mdl.profile_read(name) for mdl in models]
+            return sum(p[0] for p in parts), sum(p[1] for p in parts)
+        gram_ms, gram_n = prof("gram")
+        res_ms, res_n = prof("resample")
+        sol_ms, sol_n = prof("solver")
         reps_per_launch = args.reps_per_gpu
         a_rep = 8.0 * N_OBS * 60 + 4.0 * N_OBS                 # one gathered read of X + the index vector
         f_rep = float(N_OBS) * 60 * 61                         # symmetric Gram flops
@@ -199,7 +232,7 @@ def main():
             "config": {"workload": "synthetic 10,000 obs x 60 MVs x 6 LVs, Mode A, Scheme.PATH, scaled, %d bootstrap replicates per GPU "
                                    "(BASELINE.json configs[2]); on-device Philox resampling; X resident in HBM" % args.reps_per_gpu,
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters.min()), int(iters.max())],
-                       "parallelism": "replicate-sharded x%d, one all_gather per step" % world},
+                       "parallelism": "replicate-sharded x%d, one all_gather per step%s" % (world, " (overlapped with the next step's kernels)" if use_dist else "")},
             "roofline": {"bound": "mfma", "achieved": round(mfma_achieved, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(mfma_achieved / FP64_MFMA_PEAK_TF, 4), "traffic": traffic,
                          "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n,

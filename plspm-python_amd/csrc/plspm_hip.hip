@@ -191,6 +191,61 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
     if (tid == 0) nent[b] = total;
 }
 
+// Large-N variant (N * 4 bytes no longer fits LDS): the histogram lives in a per-replicate slice of a global scratch
+// buffer.  Counting uses L2 atomics; the compaction passes read the slice with agent-scope relaxed loads, which bypass
+// this CU's L1 (the zero-fill went through L1, the atomics did not).
+__global__ void __launch_bounds__(256) resample_global_kernel(int N, const int* __restrict__ idx, uint64_t seed, int64_t rep0, unsigned* __restrict__ ghist,
+                                                               int2* __restrict__ ent, int* __restrict__ nent, long ent_stride, int* __restrict__ err) {
+    __shared__ int wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long b = blockIdx.x;
+    unsigned* hist = ghist + b * (long)N;
+    for (int i = tid; i < N; i += 256) __hip_atomic_store(&hist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (idx) {
+        const int* my = idx + b * (long)N;
+        for (int i = tid; i < N; i += 256) {
+            const int r = my[i];
+            if ((unsigned)r < (unsigned)N) __hip_atomic_fetch_add(&hist[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else atomicOr(err, 1);
+        }
+    } else {
+        const uint64_t rep = (uint64_t)(rep0 + b);
+        const int nq = (N + 3) >> 2;
+        for (int q = tid; q < nq; q += 256) {
+            const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < N) __hip_atomic_fetch_add(&hist[to_index(u.v[j], (uint32_t)N)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    int2* my_ent = ent + b * ent_stride;
+    const int Q = (((N + 3) >> 2) + 63) & ~63;
+    const int r0 = wave * Q, r1 = min(N, r0 + Q);
+    int mine = 0;
+    for (int c0 = r0; c0 < r1; c0 += 64) {
+        const int row = c0 + lane;
+        const int cnt = (row < r1) ? (int)__hip_atomic_load(&hist[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        mine += __popcll(__ballot(cnt > 0));
+    }
+    if (lane == 0) wave_tot[wave] = mine;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    for (int c0 = r0; c0 < r1; c0 += 64) {
+        const int row = c0 + lane;
+        const int cnt = (row < r1) ? (int)__hip_atomic_load(&hist[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const unsigned long long bal = __ballot(cnt > 0);
+        if (cnt > 0) my_ent[off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(row, cnt);
+        off += __popcll(bal);
+    }
+    const int padded = (total + 3) & ~3;
+    if (tid < padded - total) my_ent[total + tid] = make_int2(0, 0);
+    if (tid == 0) nent[b] = total;
+}
+
 // ------------------------------------------------------------------------------------------------ Gram (fp64 MFMA)
 // v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; for the
 // Gram both are the SAME element xa[row_k][col_t(l&15)] (A additionally times the multiplicity), so one 16-byte
@@ -635,7 +690,7 @@ struct plspm_model {
     double* d_Xa = nullptr;
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err;
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist;
     bool profiling = false;
     ProfSlot prof[PLSPM_K_COUNT];
     std::string error;
@@ -790,7 +845,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
-                    m->fitout.p, m->idx.p, m->err.p};
+                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p};
     for (void* p : ptrs) if (p) hipFree(p);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
@@ -1009,13 +1064,13 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     if (!m || B < 1 || rep_offset < 0) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
     if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
     const long N = m->N;
-    if (N > 36000) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: N > 36000 needs the global-histogram resampler (not built yet)");
+    const bool lds_hist = (N <= 36000);        // N * 4 bytes of LDS histogram (<= 144 KB); beyond that a global scratch slice per replicate
     HIPCHK(m, hipSetDevice(m->device));
     const int R = plspm_row_stride(m);
     const long psize = packed_size(m->T);
     const long ent_stride = ((N + 3) & ~3L) + 4;
     // replicates per pass: bound the (row,count) + Gram scratch to ~2 GiB
-    const size_t per_rep = (size_t)ent_stride * sizeof(int2) + (size_t)psize * sizeof(double);
+    const size_t per_rep = (size_t)ent_stride * sizeof(int2) + (size_t)psize * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned));
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
     int rc;
     if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
@@ -1025,14 +1080,19 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     if ((rc = ensure(m, m->status, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->iters, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->err, sizeof(int)))) return rc;
+    if (!lds_hist && (rc = ensure(m, m->ghist, (size_t)chunk * N * sizeof(unsigned)))) return rc;
     HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
-        if ((rc = allow_lds(m, (const void*)resample_kernel, (size_t)N * sizeof(unsigned)))) return rc;
-        {
+        if (lds_hist) {
+            if ((rc = allow_lds(m, (const void*)resample_kernel, (size_t)N * sizeof(unsigned)))) return rc;
             ProfScope ps(m, PLSPM_K_RESAMPLE);
             hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), (size_t)N * sizeof(unsigned), m->stream, (int)N,
                                d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
+        } else {
+            ProfScope ps(m, PLSPM_K_RESAMPLE);
+            hipLaunchKernelGGL(resample_global_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (int)N, d_idx ? d_idx + b0 * N : nullptr, seed,
+                               rep_offset + b0, (unsigned*)m->ghist.p, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
         }
         {
             ProfScope ps(m, PLSPM_K_GRAM);

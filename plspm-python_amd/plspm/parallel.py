@@ -58,9 +58,12 @@ def split_records(records, width):
     return np.ascontiguousarray(records[:, :width]), records[:, width].astype(np.int32), records[:, width + 1].astype(np.int32)
 
 
-def gather_records(send, total, group=None):
+def gather_records(send, total, group=None, async_op=False, slot=0):
     """all_gather of per-rank record blocks (a torch tensor [mine, width+2] on the group's device) into one
-    [total, width+2] tensor in replicate-id order, on every rank.  This is the single collective of a bootstrap."""
+    [total, width+2] tensor in replicate-id order, on every rank.  This is the single collective of a bootstrap.
+    async_op=True (equal shards only) returns (recv, work): the collective runs on RCCL's own stream and the caller
+    overlaps it with other work, calling work.wait() before touching ``recv`` or re-using ``send``; ``slot`` selects
+    one of several receive buffers so that consecutive jobs do not share one."""
     import torch
     dist, rank, world = _world(group)
     if dist is None:
@@ -72,11 +75,16 @@ def gather_records(send, total, group=None):
         padded = torch.zeros((cap, stride), dtype=send.dtype, device=send.device)
         padded[:send.shape[0]] = send
         send = padded
-    key = (world, cap, stride, str(send.device))
+    key = (world, cap, stride, str(send.device), slot)
     recv = _recv_cache.get(key)
     if recv is None:
         recv = torch.empty((world * cap, stride), dtype=send.dtype, device=send.device)
         _recv_cache[key] = recv
+    if async_op:
+        if not equal:
+            raise ValueError("async gather needs equal shards")
+        work = dist.all_gather_into_tensor(recv, send.contiguous(), group=group, async_op=True)
+        return recv, work
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     if equal:
         return recv

@@ -347,3 +347,28 @@ def test_config5_full_size_1m_rows_properties():
     Xs = np.ascontiguousarray(X[:50000])
     _, gs = gpu_fit(Xs, model)
     check_fit(gs, orc.fit(Xs, model), "50k prefix")
+
+
+def test_bootstrap_large_n_global_histogram_path():
+    """N = 50,000 > the LDS-histogram limit: the global-scratch resampler must give the same rows as the oracle run on the
+    same indices (device RNG mirrored on the host), and explicit indices must reproduce the RNG path bit for bit."""
+    from plspm import _native
+    C = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+    n = 50000
+    X, blocks = orc.synth(n, C, 4, seed=11)
+    model = orc.Model(blocks, C, "ABA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(6, seed=99, rep_offset=3)
+    assert np.all(status == 0)
+    idx = np.stack([_native.bootstrap_indices(99, 3 + r, n) for r in range(6)])
+    rows2, _, iters2 = nm.bootstrap(6, idx=idx)
+    assert np.array_equal(rows, rows2) and np.array_equal(iters, iters2)
+    corr = orc.correction(n)
+    for r in (0, 5):
+        mine, its = orc.bootstrap_replicate(X, model, idx[r], corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+    worst = np.zeros((1, n), dtype=np.int32)              # every draw hits the same row: multiplicity N, zero variance
+    _, st, _ = nm.bootstrap(1, idx=worst)
+    assert st[0] != 0
