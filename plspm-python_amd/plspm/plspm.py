@@ -18,74 +18,93 @@ from plspm.scheme import Scheme
 from plspm.unidimensionality import Unidimensionality
 
 
+def _normalise_arguments(scheme, iterations, tolerance, bootstrap_iterations, processes):
+    """The argument clamps and assertions of reference plspm/plspm.py:54-61, in one place."""
+    assert tolerance > 0
+    assert scheme in Scheme
+    assert processes > 0
+    iterations = max(iterations, 100)                   # "default and minimum 100"
+    if bootstrap_iterations < 10:                       # plspm.py:58-59: anything below 10 silently becomes 100
+        bootstrap_iterations = 100
+    assert bootstrap_iterations % processes == 0
+    return iterations, bootstrap_iterations
+
+
 class Plspm:
-    """Estimates path models with latent variables using the partial least squares algorithm."""
+    """PLS path model estimator.
+
+    ``Plspm(data, config, scheme=Scheme.CENTROID, iterations=100, tolerance=1e-6, bootstrap=False,
+    bootstrap_iterations=100, processes=2)`` -- argument meaning as in the reference; additionally ``seed`` makes the
+    bootstrap reproducible (the reference is unseeded) and ``device_id`` picks the GPU.  Raises ``Exception`` when the
+    solver does not converge, ``NotImplementedError`` for model features outside the MI355X hot path, and
+    ``plspm._native.NativeBackendError`` when no GPU / library is available.
+    """
 
     def __init__(self, data: pd.DataFrame, config: c.Config, scheme: Scheme = Scheme.CENTROID, iterations: int = 100,
                  tolerance: float = 0.000001, bootstrap: bool = False, bootstrap_iterations: int = 100, processes: int = 2,
                  seed: int = None, device_id: int = 0):
-        if iterations < 100:
-            iterations = 100
-        assert tolerance > 0
-        assert scheme in Scheme
-        if bootstrap_iterations < 10:
-            bootstrap_iterations = 100
-        assert processes > 0
-        assert bootstrap_iterations % processes == 0
-
+        iterations, bootstrap_iterations = _normalise_arguments(scheme, iterations, tolerance, bootstrap_iterations, processes)
         estimator = Estimator(config)
-        filtered = config.filter(data)
-        n = filtered.shape[0]
-        correction = np.sqrt(n / (n - 1))
-        calculator = w.WeightsCalculatorFactory(config, iterations, tolerance, correction, scheme, device_id)
-        result = estimator.run(calculator, filtered, want_scores=True, want_cov=True)
-        config = estimator.config()
+        observations = config.filter(data)
+        n_obs = observations.shape[0]
+        calculator = w.WeightsCalculatorFactory(config, iterations, tolerance, np.sqrt(n_obs / (n_obs - 1)), scheme, device_id)
 
-        self._result = result
-        self._scores = result.scores()
-        self._inner_model = im.InnerModel.from_device(config.path(), result)
-        self._outer_model = om.OuterModel(result, self._inner_model.r_squared())
-        self._inner_summary = pis.InnerSummary(config, self._inner_model.r_squared(), self._inner_model.r_squared_adj(),
-                                               self._outer_model.model())
-        self._unidimensionality = Unidimensionality(config, result)
+        # one device fit: Gram -> LDS solver -> scores; everything below only re-labels / post-processes its outputs
+        fit = estimator.run(calculator, observations, want_scores=True, want_cov=True)
+        model_spec = estimator.config()
+        self._result = fit
+        self._scores = fit.scores()
+        self._inner_model = im.InnerModel.from_device(model_spec.path(), fit)
+        r2 = self._inner_model.r_squared()
+        self._outer_model = om.OuterModel(fit, r2)
+        self._inner_summary = pis.InnerSummary(model_spec, r2, self._inner_model.r_squared_adj(), self._outer_model.model())
+        self._unidimensionality = Unidimensionality(model_spec, fit)
         self._bootstrap = None
         if bootstrap:
-            if n < 10:
+            if n_obs < 10:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
-            self._bootstrap = Bootstrap(config, filtered, self._inner_model, self._outer_model, calculator, bootstrap_iterations,
-                                        processes, result=result, seed=seed)
+            # the handle of the fit already holds the data in HBM: the replicates run on it
+            self._bootstrap = Bootstrap(model_spec, observations, self._inner_model, self._outer_model, calculator,
+                                        bootstrap_iterations, processes, result=fit, seed=seed)
 
+    # ---- accessors (names and return shapes of reference plspm/plspm.py:84-169) -------------------------------
     def scores(self) -> pd.DataFrame:
-        """Latent variable scores: one column per latent variable, index = the data's index."""
+        """LV scores, N x L: index = the input data's index, columns = LVs in path-matrix order."""
         return self._scores
 
     def outer_model(self) -> pd.DataFrame:
-        """weight, loading, communality and redundancy for each manifest variable."""
+        """Per MV (alphabetical index): weight, loading, communality, redundancy."""
         return self._outer_model.model()
 
     def inner_model(self) -> pd.DataFrame:
-        """estimate, std error, t and p>|t| for every structural path."""
+        """Per structural path "A -> B": from, to, estimate, std error, t, p>|t|."""
         return self._inner_model.inner_model()
 
     def path_coefficients(self) -> pd.DataFrame:
+        """L x L matrix shaped like the path matrix given to Config, holding the estimated coefficients."""
         return self._inner_model.path_coefficients()
 
     def crossloadings(self) -> pd.DataFrame:
+        """Correlation of every MV (rows, data-column order) with every LV score (columns)."""
         return self._outer_model.crossloadings()
 
     def inner_summary(self) -> pd.DataFrame:
+        """Per LV: type, r_squared, r_squared_adj, block_communality, mean_redundancy, ave."""
         return self._inner_summary.summary()
 
     def goodness_of_fit(self) -> float:
         return self._inner_summary.goodness_of_fit()
 
     def effects(self) -> pd.DataFrame:
+        """Per connected LV pair: from, to, direct, indirect, total."""
         return self._inner_model.effects()
 
     def unidimensionality(self) -> pd.DataFrame:
+        """Per block: mode, mvs, cronbach_alpha, dillon_goldstein_rho, eig_1st, eig_2nd."""
         return self._unidimensionality.summary()
 
     def bootstrap(self) -> Bootstrap:
+        """The :class:`plspm.bootstrap.Bootstrap` results; raises when bootstrap=True was not requested."""
         if self._bootstrap is None:
             raise Exception("To perform bootstrap validation, set the parameter bootstrap to True when calling Plspm")
         return self._bootstrap
