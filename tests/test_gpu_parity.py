@@ -372,3 +372,146 @@ def test_bootstrap_large_n_global_histogram_path():
     worst = np.zeros((1, n), dtype=np.int32)              # every draw hits the same row: multiplicity N, zero variance
     _, st, _ = nm.bootstrap(1, idx=worst)
     assert st[0] != 0
+
+
+# ------------------------------------------------------------------ edge cases (ragged blocks, limits, tiny inputs)
+def _random_dag(L, rng, density=0.5):
+    C = np.zeros((L, L), dtype=np.int64)
+    for i in range(1, L):
+        for j in range(i):
+            if rng.random() < density:
+                C[i, j] = 1
+        if C[i].sum() == 0 and C[:, i].sum() == 0:
+            C[i, rng.integers(0, i)] = 1
+    return C
+
+
+def _ragged(n, C, sizes, seed):
+    rng = np.random.default_rng(seed)
+    L = C.shape[0]
+    eta = np.zeros((n, L))
+    for j in range(L):
+        eta[:, j] = rng.standard_normal(n) + 0.4 * eta[:, C[j] == 1].sum(axis=1)
+    cols, blocks, at = [], [], 0
+    for j, k in enumerate(sizes):
+        lam = np.linspace(0.6, 0.9, k)
+        cols.append(eta[:, [j]] * lam[None, :] + 0.6 * rng.standard_normal((n, k)) + 3.0 * (j + 1))     # non-zero means on purpose
+        blocks.append(np.arange(at, at + k)); at += k
+    return np.column_stack(cols), blocks
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+def test_ragged_blocks_including_single_item_constructs(scheme):
+    rng = np.random.default_rng(4)
+    C = _random_dag(7, rng)
+    X, blocks = _ragged(400, C, [1, 3, 1, 7, 2, 12, 1], seed=8)
+    for modes in ("AAAAAAA", "ABBABBA"):
+        model = orc.Model(blocks, C, modes, scheme, True)
+        _, g = gpu_fit(X, model)
+        check_fit(g, orc.fit(X, model), "ragged %s %s" % (modes, scheme))
+
+
+def test_two_lv_model_effects_special_case_and_tiny_n():
+    """L == 2 takes the `total = path` branch of inner_model.py:37-38; N = 10 is the reference's bootstrap minimum."""
+    C = np.array([[0, 0], [1, 0]])
+    X, blocks = _ragged(10, C, [3, 2], seed=2)
+    model = orc.Model(blocks, C, "AB", "path", False)
+    nm, g = gpu_fit(X, model)
+    r = orc.fit(X, model)
+    check_fit(g, r, "L=2 N=10")
+    assert g["pairs"] == [(0, 1)] and g["indirect"][0] == 0.0
+    rng = np.random.RandomState(3)
+    idx = rng.randint(10, size=(16, 10)).astype(np.int32)
+    rows, status, iters = nm.bootstrap(16, idx=idx)
+    corr = orc.correction(10)
+    for b in range(16):
+        try:
+            mine, its = orc.bootstrap_replicate(X, model, idx[b], corr)
+        except Exception:
+            assert status[b] != 0
+            continue
+        if status[b] == 0 and np.all(np.isfinite(mine)):
+            assert its == iters[b]
+            assert_close(rows[b], mine, 1e-7, 1e-9)
+
+
+def test_limits_p254_and_l64():
+    """Largest supported shapes: P = 254 (T = 16 tiles, two workgroups per k-group walk) and L = 64 single-digit blocks."""
+    rng = np.random.default_rng(5)
+    C = orc.chain_C(64)
+    sizes = [4] * 62 + [3, 3]                     # P = 254
+    X, blocks = _ragged(1200, C, sizes, seed=6)
+    model = orc.Model(blocks, C, "A" * 64, "factorial", True)
+    _, g = gpu_fit(X, model)
+    check_fit(g, orc.fit(X, model), "P=254 L=64")
+    Cd = _random_dag(12, rng, density=0.9)         # dense DAG: up to 11 predecessors -> LDS-scratch Cholesky path (k > 8)
+    X2, b2 = _ragged(600, Cd, [3] * 12, seed=7)
+    for scheme in ("path", "centroid"):
+        m2 = orc.Model(b2, Cd, "ABABABABABAB", scheme, True)
+        _, g2 = gpu_fit(X2, m2)
+        check_fit(g2, orc.fit(X2, m2), "dense DAG " + scheme)
+
+
+def test_handle_reuse_and_reupload():
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    a = nm.fit()
+    rows1, _, _ = nm.bootstrap(5, seed=2)
+    Xh = np.ascontiguousarray(X[:125])
+    nm.upload(Xh, model.mv_order.astype(np.int32))                  # new data on the same handle
+    b = nm.fit()
+    assert b["scores"].shape == (125, 6) and not np.allclose(a["weights"], b["weights"])
+    assert_close(b["weights"][np.argsort(np.argsort(model.mv_order))] if False else b["weights"], native_fit_weights(Xh, model), 1e-12)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    c2 = nm.fit()
+    rows2, _, _ = nm.bootstrap(5, seed=2)
+    assert np.array_equal(a["weights"], c2["weights"]) and np.array_equal(rows1, rows2)
+
+
+def native_fit_weights(X, model):
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    return nm.fit()["weights"]
+
+
+def test_api_single_item_constructs_gof_raises():
+    """reference tests/test_regression_metric.py:113-125."""
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    sat = satisfaction_frame()
+    structure = c.Structure()
+    structure.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); structure.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    structure.add_path(["QUAL"], ["VAL", "SAT"]); structure.add_path(["VAL"], ["SAT"]); structure.add_path(["SAT"], ["LOY"])
+    config = c.Config(structure.path())
+    for lv in ["QUAL", "VAL", "SAT", "LOY", "IMAG", "EXPE"]:
+        config.add_lv(lv, Mode.A, c.MV(SAT_PREFIX[lv] + "1"))
+    calc = Plspm(sat, config, Scheme.CENTROID)
+    with pytest.raises(ValueError):
+        calc.goodness_of_fit()
+    assert calc.scores().shape == (250, 6)
+
+
+def test_api_mode_b_inner_summary_matches_reference_csv():
+    """reference tests/test_regression_metric.py:96-111."""
+    import os
+    import plspm.config as c
+    import plspm.util as util
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    sat = satisfaction_frame()
+    structure = c.Structure()
+    structure.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); structure.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    structure.add_path(["QUAL"], ["VAL", "SAT"]); structure.add_path(["VAL"], ["SAT"]); structure.add_path(["SAT"], ["LOY"])
+    config = c.Config(structure.path(), scaled=False)
+    for lv in ["QUAL", "VAL", "SAT", "LOY", "IMAG", "EXPE"]:
+        config.add_lv_with_columns_named(lv, Mode.B, sat, SAT_PREFIX[lv])
+    calc = Plspm(sat, config, Scheme.CENTROID)
+    exp = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.modeb.inner-summary.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(exp.drop(["type"], axis=1)).sort_index(),
+                               util.sort_cols(calc.inner_summary().drop(["type", "r_squared_adj"], axis=1)).sort_index().astype(float))
+    pd.testing.assert_series_equal(exp.loc[:, "type"].sort_index(), calc.inner_summary().loc[:, "type"].sort_index())
