@@ -691,6 +691,8 @@ struct plspm_model {
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist;
+    void* h_stage = nullptr;      // pinned host staging for plspm_fit results
+    size_t h_stage_cap = 0;
     bool profiling = false;
     ProfSlot prof[PLSPM_K_COUNT];
     std::string error;
@@ -847,6 +849,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (m->h_stage) hipHostFree(m->h_stage);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
 }
@@ -1003,8 +1006,8 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
     // device-side result block
     const long o_w = 0, o_ld = o_w + P, o_cl = o_ld + P, o_pc = o_cl + (long)P * L, o_r2 = o_pc + (long)L * L, o_lc = o_r2 + L,
-               o_row = o_lc + (long)L * L, o_ind = o_row + (2L * P + L + 2L * ne + 2), o_sw = o_ind + std::max(ne, 1), o_sc = o_sw + P, o_cov = o_sc + L,
-               o_mean = o_cov + (long)P * P, o_end = o_mean + P;
+               o_row = o_lc + (long)L * L, o_ind = o_row + (2L * P + L + 2L * ne + 2), o_sw = o_ind + std::max(ne, 1), o_sc = o_sw + P, o_mean = o_sc + L,
+               o_cov = o_mean + P, o_end = o_cov + (long)P * P;
     const size_t fit_bytes = (size_t)o_end * sizeof(double) + 64 + (size_t)L + 16;
     if ((rc = ensure(m, m->fitout, fit_bytes))) return rc;
     double* d = (double*)m->fitout.p;
@@ -1037,25 +1040,43 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
         hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->rows.p);
     }
     HIPCHK(m, hipGetLastError());
-    auto get = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-        return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream) : hipSuccess;
-    };
-    HIPCHK(m, get(out->weights, d + o_w, sizeof(double) * P));
-    HIPCHK(m, get(out->loadings, d + o_ld, sizeof(double) * P));
-    HIPCHK(m, get(out->crossloadings, d + o_cl, sizeof(double) * P * L));
-    HIPCHK(m, get(out->path_coef, d + o_pc, sizeof(double) * L * L));
-    HIPCHK(m, get(out->r2, d + o_r2, sizeof(double) * L));
-    HIPCHK(m, get(out->lv_cov, d + o_lc, sizeof(double) * L * L));
-    HIPCHK(m, get(out->total, d + o_row + P + L, sizeof(double) * ne));
-    HIPCHK(m, get(out->direct, d + o_row + P + L + ne, sizeof(double) * ne));
-    HIPCHK(m, get(out->indirect, d + o_ind, sizeof(double) * ne));
-    HIPCHK(m, get(out->cov, d + o_cov, sizeof(double) * P * P));
-    HIPCHK(m, get(out->mean, d + o_mean, sizeof(double) * P));
-    HIPCHK(m, get(out->sign, d_sign, (size_t)L));
-    HIPCHK(m, get(out->iterations, d_int, sizeof(int)));
-    HIPCHK(m, get(out->status, d_int + 1, sizeof(int)));
-    HIPCHK(m, get(out->scores, m->rows.p, sizeof(double) * (size_t)N * L));
+    // ONE device->host copy of the whole result block into a pinned staging buffer, then scatter on the host
+    // (15 separate small copies cost more than the four kernels of a 10k x 60 fit).
+    const size_t block_bytes = (size_t)(out->cov ? o_end : o_cov) * sizeof(double);
+    const size_t tail_bytes = 64 + (size_t)L + 16;
+    const size_t score_bytes = out->scores ? sizeof(double) * (size_t)N * L : 0;
+    const bool stage_scores = score_bytes > 0 && score_bytes <= ((size_t)8 << 20);      // small score matrices ride the pinned buffer too
+    const size_t stage_need = fit_bytes + (stage_scores ? score_bytes : 0);
+    if (m->h_stage_cap < stage_need) {
+        if (m->h_stage) HIPCHK(m, hipHostFree(m->h_stage));
+        m->h_stage = nullptr; m->h_stage_cap = 0;
+        HIPCHK(m, hipHostMalloc(&m->h_stage, stage_need, hipHostMallocDefault));
+        m->h_stage_cap = stage_need;
+    }
+    char* hs = (char*)m->h_stage;
+    HIPCHK(m, hipMemcpyAsync(hs, d, block_bytes, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(hs + (size_t)o_end * sizeof(double), d + o_end, tail_bytes, hipMemcpyDeviceToHost, m->stream));
+    if (stage_scores) HIPCHK(m, hipMemcpyAsync(hs + fit_bytes, m->rows.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
+    else if (out->scores) HIPCHK(m, hipMemcpyAsync(out->scores, m->rows.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (stage_scores) memcpy(out->scores, hs + fit_bytes, score_bytes);
+    const double* h = (const double*)hs;
+    const int* h_int = (const int*)(h + o_end);
+    auto put = [&](void* dst, const void* src, size_t bytes) { if (dst) memcpy(dst, src, bytes); };
+    put(out->weights, h + o_w, sizeof(double) * P);
+    put(out->loadings, h + o_ld, sizeof(double) * P);
+    put(out->crossloadings, h + o_cl, sizeof(double) * P * L);
+    put(out->path_coef, h + o_pc, sizeof(double) * L * L);
+    put(out->r2, h + o_r2, sizeof(double) * L);
+    put(out->lv_cov, h + o_lc, sizeof(double) * L * L);
+    put(out->total, h + o_row + P + L, sizeof(double) * ne);
+    put(out->direct, h + o_row + P + L + ne, sizeof(double) * ne);
+    put(out->indirect, h + o_ind, sizeof(double) * ne);
+    put(out->cov, h + o_cov, sizeof(double) * P * P);
+    put(out->mean, h + o_mean, sizeof(double) * P);
+    put(out->sign, h_int + 4, (size_t)L);
+    put(out->iterations, h_int, sizeof(int));
+    put(out->status, h_int + 1, sizeof(int));
     return 0;
 }
 
