@@ -23,13 +23,20 @@ def main():
     out = {"round": tag, "kernels": [], "counters": {}}
     cur = sqlite3.connect(stats).cursor()
     lines = ["# rocprofv3 --kernel-trace --stats  (%s)" % tag, "", "| kernel | calls | total us | avg us | % |", "|---|---:|---:|---:|---:|"]
-    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+    # full-size launches only: bench.py ends with a few tiny validation launches of the same kernels
+    q = ("select name, count(*), sum(duration)/1e3, avg(duration)/1e3 from kernels k where grid_x*grid_y*grid_z = "
+         "(select max(grid_x*grid_y*grid_z) from kernels k2 where k2.name = k.name) group by name order by 3 desc")
+    rows = list(cur.execute(q))
+    tot_all = sum(r[2] for r in rows) or 1.0
+    for name, calls, total, avg in rows:
+        pct = 100.0 * total / tot_all
         out["kernels"].append({"kernel": short(name), "calls": calls, "total_us": round(total, 3), "avg_us": round(avg, 3), "pct": round(pct, 2)})
         lines.append("| %s | %d | %.1f | %.2f | %.2f |" % (short(name), calls, total, avg, pct))
     if len(sys.argv) >= 5:
         for key, db in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
             c2 = sqlite3.connect(db).cursor()
-            q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
+            q = ("select kernel_name, count(*), avg(value) from counters_collection c where counter_name=? and grid_size = "
+                 "(select max(grid_size) from counters_collection c2 where c2.kernel_name = c.kernel_name) group by kernel_name")
             for name, n, avg in c2.execute(q, (key,)):
                 out["counters"].setdefault(short(name), {})[key + "_KiB_avg"] = round(avg, 2)
                 out["counters"][short(name)]["dispatches_" + key] = n
