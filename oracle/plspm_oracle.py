@@ -37,6 +37,7 @@ class Model:
     scaled: bool = True
     max_iter: int = 100
     tol: float = 1e-6
+    scales: Optional[Sequence[str]] = None   # non-metric data: "NUM" / "RAW" per data column (None = metric)
 
     def __post_init__(self):
         self.blocks = [np.asarray(b, dtype=np.int64) for b in self.blocks]
@@ -178,6 +179,74 @@ def solve(Xt, model: Model, corr: float):
     return dict(scores=scores, weights=weights, iterations=iteration, cor=cor, sign=sign)
 
 
+# ----------------------------------------------------------------------------- non-metric (NUM / RAW) solver
+def treat_numpy(v):
+    """util.treat_numpy (util.py:43-53)."""
+    v = v - np.nanmean(v)
+    return v / np.nanstd(v, axis=0, ddof=1)
+
+
+def treat_nonmetric(X):
+    """Config.treat non-metric branch (config.py:314): util.treat(data) / sqrt((N-1)/N), i.e. population-standardised."""
+    n = X.shape[0]
+    return (X - X.mean(axis=0)) / np.std(X, axis=0, ddof=1) / math.sqrt((n - 1) / n)
+
+
+def nm_quantify(X0, scales):
+    """Scale.NUM (scale.py:27-30): treat_numpy(initial) * sqrt(n/(n-1)) every iteration -- constant;  Scale.RAW (scale.py:38-39): unchanged."""
+    n = X0.shape[0]
+    Xq = X0.copy()
+    for p, kind in enumerate(scales):
+        if kind == "NUM":
+            Xq[:, p] = treat_numpy(X0[:, p]) * math.sqrt(n / (n - 1))
+        elif kind != "RAW":
+            raise NotImplementedError("oracle: scale " + str(kind))
+    return Xq
+
+
+def nm_init_scores(X0, model: Model):
+    """_NonmetricWeights.__init__ (weights.py:82-98, no missing data): equal weights 1/sqrt(k) per block."""
+    Y = np.zeros((X0.shape[0], model.L))
+    for l, b in enumerate(model.blocks):
+        Y[:, l] = X0[:, b] @ (np.ones(len(b)) / math.sqrt(len(b)))
+    return Y
+
+
+def nm_iterate(Xq, Y, model: Model, corr: float):
+    """_NonmetricWeights.iterate (weights.py:107-120) with mode.py:31-42 (A) / 54-61 (B).  Returns (W, Y_new, convergence)."""
+    E = _SCHEMES[model.scheme](model.C, Y)
+    Z = Y @ E
+    W = np.zeros((Xq.shape[1], model.L))
+    Yn = Y.copy()
+    for l, b in enumerate(model.blocks):
+        Xk = Xq[:, b]
+        if model.modes[l] == "A":
+            w = (Xk.T @ Z[:, l]) / np.sum(Z[:, l] ** 2)
+        else:
+            w = np.linalg.lstsq(Xk, Z[:, l], rcond=None)[0]
+        W[b, l] = w
+        Yn[:, l] = treat_numpy(Xk @ w) * corr
+    conv = float(np.sum((np.abs(Y) - np.abs(Yn)) ** 2))           # weights.py:120 -- on the SCORES, not the weights
+    return W, Yn, conv
+
+
+def solve_nonmetric(X0, model: Model, corr: float):
+    """WeightsCalculatorFactory.calculate, non-metric branch (weights.py:172-187 + 122-133).  No sign rule here."""
+    Xq = nm_quantify(X0, model.scales)
+    Y = nm_init_scores(X0, model)
+    iteration = 0
+    while True:
+        iteration += 1
+        W, Y, conv = nm_iterate(Xq, Y, model, corr)
+        if conv < model.tol or iteration > model.max_iter:
+            break
+    if iteration > model.max_iter:
+        raise NotConverged("Could not converge after %d iterations" % iteration)
+    wf = 1.0 / (np.std(Xq @ W, axis=0, ddof=1) / corr)            # weights.py:130
+    weights = (W * wf).sum(axis=1)                                # weights.py:131-132
+    return dict(scores=Y, weights=weights, iterations=iteration, data=Xq)
+
+
 # ----------------------------------------------------------------------------- inner model
 def inner_model(C, scores):
     """InnerModel.__init__ (inner_model.py:58-75): OLS with intercept per endogenous LV.
@@ -252,8 +321,13 @@ def fit(X, model: Model, corr: Optional[float] = None):
     n = X.shape[0]
     if corr is None:
         corr = correction(n)
-    Xt = treat_metric(X, model.scaled)                            # estimator.py:33
-    s = solve(Xt, model, corr)                                    # estimator.py:39 (== :52, no HOC)
+    if model.scales is not None:
+        s = solve_nonmetric(treat_nonmetric(X), model, corr)      # estimator.py:33,39 non-metric
+        Xt = s["data"]
+        s["sign"] = np.ones(model.L)
+    else:
+        Xt = treat_metric(X, model.scaled)                        # estimator.py:33
+        s = solve(Xt, model, corr)                                # estimator.py:39 (== :52, no HOC)
     B, r2, r2_adj = inner_model(model.C, s["scores"])             # plspm.py:71
     pairs, d, ind, tot = effects(B)
     cl = crossloadings(Xt, s["scores"])

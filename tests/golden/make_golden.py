@@ -44,6 +44,16 @@ def _counting_iterate(self, scheme):
 
 
 refw._MetricWeights.iterate = _counting_iterate
+_orig_nm_iterate = refw._NonmetricWeights.iterate
+
+
+def _counting_nm_iterate(self, scheme):
+    _calls["n"] += 1
+    return _orig_nm_iterate(self, scheme)
+
+
+refw._NonmetricWeights.iterate = _counting_nm_iterate
+from plspm.scale import Scale  # noqa: E402
 
 SCHEMES = {"centroid": Scheme.CENTROID, "factorial": Scheme.FACTORIAL, "path": Scheme.PATH}
 
@@ -52,17 +62,17 @@ def path_frame(C, lvs):
     return pd.DataFrame(np.asarray(C, dtype=int), index=lvs, columns=lvs)
 
 
-def build_config(C, lvs, blocks_names, modes, scaled, add_order=None):
-    cfg = c.Config(path_frame(C, lvs), scaled=scaled)
+def build_config(C, lvs, blocks_names, modes, scaled, add_order=None, default_scale=None, mv_scales=None):
+    cfg = c.Config(path_frame(C, lvs), scaled=scaled, default_scale=default_scale)
     for lv in (add_order or lvs):
         i = lvs.index(lv)
-        cfg.add_lv(lv, Mode.A if modes[i] == "A" else Mode.B, *[c.MV(n) for n in blocks_names[i]])
+        cfg.add_lv(lv, Mode.A if modes[i] == "A" else Mode.B, *[c.MV(n, (mv_scales or {}).get(n)) for n in blocks_names[i]])
     return cfg
 
 
-def run_fit(df, cfg, scheme, lvs, want_scores=True):
+def run_fit(df, cfg, scheme, lvs, want_scores=True, tol=1e-6):
     _calls["n"] = 0
-    m = Plspm(df, cfg, SCHEMES[scheme])
+    m = Plspm(df, cfg, SCHEMES[scheme], 100, tol)
     iters = _calls["n"] // 2
     data_cols = [mv for lv in cfg._Config__mvs for mv in cfg._Config__mvs[lv]]  # add_lv order == filtered column order
     om = m.outer_model()
@@ -86,12 +96,12 @@ def run_fit(df, cfg, scheme, lvs, want_scores=True):
     return m, out
 
 
-def boot_rows(df, cfg, scheme, lvs, idx_list, effects_index):
+def boot_rows(df, cfg, scheme, lvs, idx_list, effects_index, tol=1e-6):
     """Per-replicate rows exactly as BootstrapProcess.run builds them (bootstrap.py:56-64)."""
     filtered = cfg.filter(df)
     n = filtered.shape[0]
     corr = np.sqrt(n / (n - 1))
-    calc = refw.WeightsCalculatorFactory(cfg, 100, 1e-6, corr, SCHEMES[scheme])
+    calc = refw.WeightsCalculatorFactory(cfg, 100, tol, corr, SCHEMES[scheme])
     est = Estimator(cfg)
     cols = list(filtered.columns)
     rows, iters = [], []
@@ -241,6 +251,41 @@ def main():
         for k, v in out.items():
             g7[tag + "/" + k] = v
     save("g7_chain20", **g7)
+    # ---- G8: non-metric NUM / RAW: russa (reference tests/test_regression_nonmetric.py), mobi (seminr), synthetic
+    russa = pd.read_csv(os.path.join(HERE, "ref_data", "russa.csv"), index_col=0)
+    lv8 = ["AGRI", "IND", "POLINS"]
+    C8 = np.array([[0, 0, 0], [0, 0, 0], [1, 1, 0]])
+    bn8 = [["gini", "farm", "rent"], ["gnpr", "labo"], ["ecks", "death", "demo", "inst"]]
+    g8 = {}
+    for modes in ("AAA", "BBB", "ABA"):
+        for scheme in SCHEMES:
+            for kind, dflt, mvs in (("NUM", Scale.NUM, None), ("RAW", Scale.RAW, None), ("MIX", Scale.RAW, {"gini": Scale.NUM, "ecks": Scale.NUM})):
+                cfg = build_config(C8, lv8, bn8, modes, True, add_order=["POLINS", "AGRI", "IND"], default_scale=dflt, mv_scales=mvs)
+                m, out = run_fit(russa, cfg, scheme, lv8, tol=1e-7)
+                key = "%s_%s_%s" % (modes, scheme, kind)
+                for k, v in out.items():
+                    g8[key + "/" + k] = v
+    rs = np.random.RandomState(88)
+    idx47 = rs.randint(47, size=(6, 47)).astype(np.int32)
+    g8["idx"] = idx47
+    for tag, modes, scheme in (("AAA_centroid_NUM", "AAA", "centroid"), ("ABA_path_NUM", "ABA", "path")):
+        cfg = build_config(C8, lv8, bn8, modes, True, add_order=["POLINS", "AGRI", "IND"], default_scale=Scale.NUM)
+        m, _ = run_fit(russa, cfg, scheme, lv8, tol=1e-7)
+        rows, its = boot_rows(russa, cfg, scheme, lv8, list(idx47), list(m.effects().index), tol=1e-7)
+        g8[tag + "/boot_rows"] = rows
+        g8[tag + "/boot_iters"] = its
+    save("g8_nonmetric_russa", **g8)
+
+    g9 = {"sha256": np.array(sha(X2)), "seed": np.array(7), "n": np.array(2000)}
+    for modes_name, modes in (("A", "AAAAAA"), ("B", "BBBBBB"), ("M", "BABABA")):
+        for scheme in SCHEMES:
+            cfg = build_config(Csat, lvs, bn2, modes, True, default_scale=Scale.NUM)
+            _, out = run_fit(df2, cfg, scheme, lvs, want_scores=False, tol=1e-7)
+            key = "%s_%s" % (modes_name, scheme)
+            for k, v in out.items():
+                if k != "mv_names":
+                    g9[key + "/" + k] = v
+    save("g9_nonmetric_synth2000", **g9)
     print("done in %.1f s" % (time.time() - t0))
 
 

@@ -176,3 +176,84 @@ def test_reference_csv_mode_b_r2():
     r = orc.fit(X, model)
     summ = pd.read_csv(os.path.join(GOLDEN, "ref_data", "satisfaction.modeb.inner-summary.csv"), index_col=0)
     assert_close(r["r2"], summ.loc[orc.SAT_LVS, "r_squared"].values, 1e-7, 1e-12)
+
+
+# ------------------------------------------------------------------ non-metric NUM / RAW
+RUSSA_COLS = ["ecks", "death", "demo", "inst", "gini", "farm", "rent", "gnpr", "labo"]       # add_lv order POLINS, AGRI, IND
+RUSSA_BLOCKS = [np.array([4, 5, 6]), np.array([7, 8]), np.array([0, 1, 2, 3])]                # path order AGRI, IND, POLINS
+RUSSA_C = np.array([[0, 0, 0], [0, 0, 0], [1, 1, 0]])
+
+
+def russa_inputs():
+    russa = pd.read_csv(os.path.join(GOLDEN, "ref_data", "russa.csv"), index_col=0)
+    return russa[RUSSA_COLS].values.astype(np.float64)
+
+
+def russa_scales(kind):
+    if kind == "NUM":
+        return ["NUM"] * 9
+    if kind == "RAW":
+        return ["RAW"] * 9
+    return ["NUM"] * 9          # RAW + NUM mix is promoted to all-NUM (config.py:311-313)
+
+
+@pytest.mark.parametrize("modes", ["AAA", "BBB", "ABA"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("kind", ["NUM", "RAW", "MIX"])
+def test_g8_nonmetric_russa(modes, scheme, kind):
+    g = load("g8_nonmetric_russa")
+    X = russa_inputs()
+    key = "%s_%s_%s" % (modes, scheme, kind)
+    assert list(g[key + "/mv_names"]) == RUSSA_COLS
+    model = orc.Model(RUSSA_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=russa_scales(kind))
+    _check_fit(orc.fit(X, model), g, key)
+
+
+@pytest.mark.parametrize("tag", ["AAA_centroid_NUM", "ABA_path_NUM"])
+def test_g8_nonmetric_bootstrap_rows(tag):
+    g = load("g8_nonmetric_russa")
+    X = russa_inputs()
+    modes, scheme, _ = tag.split("_")
+    model = orc.Model(RUSSA_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=["NUM"] * 9)
+    corr = orc.correction(47)
+    for idx, row, it in zip(g["idx"], g[tag + "/boot_rows"], g[tag + "/boot_iters"]):
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-12, what=tag)
+
+
+@pytest.mark.parametrize("modes", ["A", "B", "M"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_g9_nonmetric_synth2000(modes, scheme):
+    g = load("g9_nonmetric_synth2000")
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    assert sha(X) == str(g["sha256"])
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes, mixed="BABABA"), scheme, True, tol=1e-7, scales=["NUM"] * 60)
+    _check_fit(orc.fit(X, model), g, "%s_%s" % (modes, scheme), with_scores=False)
+
+
+def test_reference_csv_russa_nonmetric():
+    """reference tests/test_regression_nonmetric.py:18-63 (R plspm output, default rtol 1e-7)."""
+    X = russa_inputs()
+    lv = ["AGRI", "IND", "POLINS"]
+    ref = os.path.join(GOLDEN, "ref_data")
+    model = orc.Model(RUSSA_BLOCKS, RUSSA_C, "AAA", "centroid", True, tol=1e-7, scales=["NUM"] * 9)
+    r = orc.fit(X, model)
+    scores = pd.read_csv(os.path.join(ref, "russa.scores.csv"), index_col=0)
+    assert_close(r["scores"], scores[lv].values, 1e-7)
+    om = pd.read_csv(os.path.join(ref, "russa.outer_model.csv"), index_col=0)
+    assert_close(r["weights"], om.loc[RUSSA_COLS, "weight"].values, 1e-7)
+    assert_close(r["loadings"], om.loc[RUSSA_COLS, "loading"].values, 1e-7)
+    cl = pd.read_csv(os.path.join(ref, "russa.crossloadings.csv"), index_col=0)
+    assert_close(r["crossloadings"], cl.loc[RUSSA_COLS, lv].values, 1e-7)
+    summ = pd.read_csv(os.path.join(ref, "russa.inner_summary.csv"), index_col=0)
+    assert_close(r["r2"], summ.loc[lv, "r_squared"].values, 1e-7, 1e-12)
+    for scheme, fname in (("path", "russa.outer_model_path.csv"), ("factorial", "russa.outer_model_factorial.csv")):
+        model = orc.Model(RUSSA_BLOCKS, RUSSA_C, "AAA", scheme, True, tol=1e-7, scales=["NUM"] * 9)
+        om = pd.read_csv(os.path.join(ref, fname), index_col=0)
+        rr = orc.fit(X, model)
+        assert_close(rr["weights"], om.loc[RUSSA_COLS, "weight"].values, 1e-7)
+        assert_close(rr["loadings"], om.loc[RUSSA_COLS, "loading"].values, 1e-7)
+    model = orc.Model(RUSSA_BLOCKS, RUSSA_C, "BBB", "centroid", True, tol=1e-7, scales=["NUM"] * 9)
+    summ_b = pd.read_csv(os.path.join(ref, "russa.mode_b_inner_summary.csv"), index_col=0)
+    assert_close(orc.fit(X, model)["r2"], summ_b.loc[lv, "r_squared"].values, 1e-7, 1e-12)
