@@ -78,7 +78,7 @@ struct ModelDesc {
 struct Workspace {
     double* S;                  // [(P+1)*PS] treated population covariance S[q*PS+p], p,q < P; row/column P: raw column sums and n
     int PS;
-    double *w, *wn, *cv, *dv, *sd, *mu;         // [P] each
+    double *w, *wn, *cv, *dv, *sd, *mu, *cs;    // [P] each (cs: factor from an uploaded column to its treated value)
     double* V;                  // [P*L]
     double *Q, *G, *E, *Bm, *Pw, *Pw2, *Ind, *Cs;   // [L*L] each
     double *a, *wf, *sgn, *r2;  // [L] each
@@ -89,14 +89,14 @@ struct Workspace {
 };
 
 PLSPM_HD long workspace_small_doubles(int P, int L, int kmax, int n_chol) {
-    return 6L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * (kmax * kmax + kmax) + n_chol + 8 + 16;
+    return 7L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * (kmax * kmax + kmax) + n_chol + 8 + 16;
 }
 PLSPM_HD int cov_ld(int P) { return (P + 1) | 1; }      // S carries the ones row/column P as well (column sums, n)
 PLSPM_HD long cov_doubles(int P) { return (long)(P + 1) * cov_ld(P); }
 
 PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, int n_chol) {
     double* p = base;
-    ws.w = p; p += P; ws.wn = p; p += P; ws.cv = p; p += P; ws.dv = p; p += P; ws.sd = p; p += P; ws.mu = p; p += P;
+    ws.w = p; p += P; ws.wn = p; p += P; ws.cv = p; p += P; ws.dv = p; p += P; ws.sd = p; p += P; ws.mu = p; p += P; ws.cs = p; p += P;
     ws.V = p; p += (long)P * L;
     ws.Q = p; p += L * L; ws.G = p; p += L * L; ws.E = p; p += L * L; ws.Bm = p; p += L * L;
     ws.Pw = p; p += L * L; ws.Pw2 = p; p += L * L; ws.Ind = p; p += L * L; ws.Cs = p; p += L * L;
@@ -275,7 +275,7 @@ PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const d
         }
         for (; q < P; ++q) ws.S[q * PS + p] = (ws.S[q * PS + p] - (mp * ws.mu[q]) * inv_n) * fac;
     });
-    ex.par(P, [&](int p) { ws.sd[p] = sqrt(ws.S[p * PS + p]); });
+    ex.par(P, [&](int p) { ws.sd[p] = sqrt(ws.S[p * PS + p]); ws.cs[p] = sqrt(fac * n); });   // cs = 1/g (scaled) or 1
 }
 
 // V[p,m] = sum_{q in block m} S[p,q] w[q];   Q[l,m] = sum_{p in block l} w[p] V[p,m]
@@ -385,6 +385,9 @@ struct FitOutputs {             // any pointer may be null
 };
 
 template <class Ex>
+PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule);
+
+template <class Ex>
 PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Mp, const FitOutputs& out) {
     const int P = md.P, L = md.L, PS = ws.PS;
     ex.mark(0);
@@ -423,8 +426,15 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
     }
     ex.one([&]() { if (iteration > md.max_iter && ws.scal[3] == (double)ST_OK) ws.scal[3] = (double)ST_NOT_CONVERGED; });
     ex.mark(3);
+    finish_problem(ex, md, ws, out, iteration, true);
+}
 
-    // finalize (weights.py:56-70)
+// Everything after the iteration (shared by the metric and the non-metric solver): final normalisation, the metric sign
+// rule, inner model, effects, loadings, outputs.  Expects the last weights in ws.w and the treated covariance in ws.S.
+template <class Ex>
+PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule) {
+    const int P = md.P, L = md.L, PS = ws.PS;
+    // finalize (weights.py:56-70; non-metric: weights.py:130-132, no sign rule)
     apply_cov(ex, md, ws);
     ex.par(L, [&](int l) { ws.wf[l] = 1.0 / sqrt(ws.Q[l * L + l]); });        // 1 / (std1(X w_l) / corr)
     ex.par(P, [&](int p) { ws.w[p] *= ws.wf[md.lvof[p]]; });                  // returned weights: never sign-flipped
@@ -437,7 +447,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
             vote += ((v0 < 0.0) ? -1 : 1) + ((v1 < 0.0) ? -1 : 1) + ((v2 < 0.0) ? -1 : 1) + ((v3 < 0.0) ? -1 : 1);
         }
         for (; p < P; ++p) vote += (ws.V[p * L + l] < 0.0) ? -1 : 1;
-        ws.sgn[l] = (vote < 0) ? -1.0 : 1.0;
+        ws.sgn[l] = (sign_rule && vote < 0) ? -1.0 : 1.0;
     });
     ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.Cs[e] = ws.sgn[l] * ws.sgn[m] * ws.wf[l] * ws.wf[m] * ws.Q[e]; });
 
@@ -486,9 +496,9 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         if (out.weights) out.weights[p] = ws.w[p];
         if (out.loadings) out.loadings[p] = ld;
         if (out.crossloadings) for (int m = 0; m < L; ++m) out.crossloadings[p * L + m] = ws.sgn[m] * ws.V[p * L + m] * ws.wf[m] / ws.sd[p];
-        // scores_l = sgn_l * sum_p ((x'_p - mu'_p) * sqrt(fac*n)) w_p ; sqrt(fac*n) = 1/g (scaled) or 1
+        // scores_l = sgn_l * sum_p (x'_p - mu'_p) * cs_p * w_p
         const double n_ = ws.scal[1];
-        if (out.score_w) out.score_w[p] = ws.sgn[l] * ws.w[p] * sqrt(ws.scal[2] * n_);
+        if (out.score_w) out.score_w[p] = ws.sgn[l] * ws.w[p] * ws.cs[p];
         if (out.mean) out.mean[p] = ws.mu[p] / n_ + md.shift[p];
         if (out.cov) for (int q = 0; q < P; ++q) out.cov[p * P + q] = ws.S[q * PS + p];
     });
@@ -499,7 +509,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         if (out.score_c) {
             const double n_ = ws.scal[1];
             double s = 0.0;
-            for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += (ws.mu[p] / n_) * ws.sgn[l] * ws.w[p] * sqrt(ws.scal[2] * n_);
+            for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += (ws.mu[p] / n_) * ws.sgn[l] * ws.w[p] * ws.cs[p];
             out.score_c[l] = -s;
         }
     });
@@ -524,6 +534,148 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         if (out.row) { out.row[2 * P + L + 2 * md.n_eff] = (double)st; out.row[2 * P + L + 2 * md.n_eff + 1] = (double)iteration; }
     });
     ex.mark(7);
+}
+
+
+// =============================================================================================================
+// Non-metric data with Scale.NUM / Scale.RAW (reference _NonmetricWeights, plspm/weights.py:73-133; mode.py:31-42, 54-61;
+// scale.py:22-39; Config.treat config.py:306-318).  Every MV is population-standardised, so the iteration lives on the
+// correlation matrix R; scores are y_l = Xs a_l with a_l supported on block l.  One step:
+//     Cy = A' R A;  E = scheme(Cy);  u_l = (R A E)_l;  Mode A  w_l = u_l / (E' Cy E)_ll,  Mode B  w_l = R_bb^-1 u_l;
+//     a_l <- w_l / sqrt(w_l' R_bb w_l)                                   (treat_numpy(X w) * correction, mode.py:41,60)
+// The stop rule is on the SCORES, sum_il (|y_old| - |y_new|)^2 (weights.py:120): the absolute values do not reduce to
+// second moments, so after every step a streaming pass over the observations (nm_conv kernels) evaluates it exactly
+// from the two coefficient sets; nm_step() of the next launch reads that sum and decides.
+// Persistent per-problem state (global memory, nm_state_doubles()):
+//     [0..8) scal: 0 n, 1 status, 2 iteration, 3 active, 4 last convergence value
+//     a_old[P] a_new[P]   coefficients on the standardised MVs        c_old[P] c_new[P]  the same per uploaded column (a / sigma)
+//     k_old[L] k_new[L]   constant terms of the score maps             sd[P] sigma_p      mu[P] column sums      chol[n_chol]
+struct NmState {
+    double *scal, *a_old, *a_new, *c_old, *c_new, *k_old, *k_new, *sd, *mu, *chol;
+};
+PLSPM_HD long nm_state_doubles(int P, int L, int n_chol) { return 8 + 6L * P + 2L * L + n_chol; }
+PLSPM_HD void nm_carve(NmState& st, double* base, int P, int L) {
+    double* p = base;
+    st.scal = p; p += 8; st.a_old = p; p += P; st.a_new = p; p += P; st.c_old = p; p += P; st.c_new = p; p += P;
+    st.k_old = p; p += L; st.k_new = p; p += L; st.sd = p; p += P; st.mu = p; p += P; st.chol = p;
+}
+
+// score-map coefficients of a coefficient vector a on the standardised MVs: y = sum_p x'_p c_p + k_l
+template <class Ex>
+PLSPM_HD void nm_score_map(Ex& ex, const ModelDesc& md, const NmState& st, const double* a, double* c, double* k) {
+    const double n = st.scal[0];
+    ex.par(md.P, [&](int p) { c[p] = a[p] / st.sd[p]; });
+    ex.par(md.L, [&](int l) {
+        double s = 0.0;
+        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += (st.mu[p] / n) * c[p];
+        k[l] = -s;
+    });
+}
+
+// packed raw scatter -> correlation matrix R (ws.S, global memory), sigma, mu; initial coefficients 1/sqrt(k_l) (weights.py:82-98)
+template <class Ex>
+PLSPM_HD void nm_prepare(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, const double* Mp) {
+    const int P = md.P, L = md.L, PS = ws.PS, T = md.T;
+    const int ntile = T * (T + 1) / 2;
+    ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
+        const int tile = chunk >> 2, r = chunk & 3;
+        int t, u;
+        if (md.tile_tu) { const int tu = md.tile_tu[tile]; t = tu & 255; u = tu >> 8; }
+        else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
+        const int p = 32 * (t >> 1) + (t & 1) + 8 * r + 2 * (lane >> 4);
+        const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
+        if ((t != u || p <= q) && p <= P && q <= P) { ws.S[q * PS + p] = m; ws.S[p * PS + q] = m; }
+    });
+    const double n = ws.S[P * PS + P], inv_n = 1.0 / n;
+    ex.par(P, [&](int p) {
+        const double mu = ws.S[P * PS + p];
+        st.mu[p] = mu;
+        st.sd[p] = sqrt(ws.S[p * PS + p] * inv_n - (mu * inv_n) * (mu * inv_n));       // population std (config.py:314)
+    });
+    ex.one([&]() { st.scal[0] = n; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
+    ex.par(P, [&](int p) {
+        const double mp = st.mu[p], sp = st.sd[p];
+        for (int q = 0; q < P; ++q) ws.S[q * PS + p] = ((ws.S[q * PS + p] - (mp * st.mu[q]) * inv_n) * inv_n) / (sp * st.sd[q]);
+    });
+    if (md.n_chol > 0) {
+        ex.par(L, [&](int l) {
+            if (md.mode[l] == MODE_B) {
+                const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
+                double* R = st.chol + md.chol_off[l];
+                for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) R[r * k + c] = ws.S[(b0 + r) * PS + b0 + c];
+                if (!chol_factor(R, k)) st.scal[1] = (double)ST_SINGULAR;
+            }
+        });
+    }
+    ex.par(P, [&](int p) { const int l = md.lvof[p]; st.a_old[p] = 1.0 / sqrt((double)(md.boff[l + 1] - md.boff[l])); st.a_new[p] = st.a_old[p]; });
+    nm_score_map(ex, md, st, st.a_old, st.c_old, st.k_old);
+    nm_score_map(ex, md, st, st.a_new, st.c_new, st.k_new);
+}
+
+// Decide on the previous step's convergence value (sum of `nparts` partial sums, fixed order), then -- if the problem is
+// still active -- run one more iteration.  Returns true when the problem is still active after this call.
+template <class Ex>
+PLSPM_HD bool nm_step(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, const double* partial, int nparts) {
+    const int P = md.P, L = md.L, PS = ws.PS;
+    if (st.scal[3] == 0.0) return false;
+    const int iteration = (int)st.scal[2];
+    if (iteration > 0) {
+        const double conv = ex.sum(nparts, [&](int c) { return partial[c]; });
+        const bool stop = (conv < md.tol) || (iteration > md.max_iter);            // weights.py:183
+        ex.one([&]() {
+            st.scal[4] = conv;
+            if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+        });
+        if (stop) return false;
+        ex.par(P, [&](int p) { st.a_old[p] = st.a_new[p]; st.c_old[p] = st.c_new[p]; });
+        ex.par(L, [&](int l) { st.k_old[l] = st.k_new[l]; });
+    }
+    const double n = st.scal[0], corr2 = n / (n - 1.0);
+    ex.par(P, [&](int p) { ws.w[p] = st.a_old[p]; });
+    apply_cov(ex, md, ws);                                                        // V = R A, Q = Cy = A' R A
+    ex.par(L * L, [&](int e) { ws.G[e] = ws.Q[e]; });
+    inner_weights(ex, md, ws, corr2);                                             // scheme on the (un-normalised) score covariance
+    ex.par(L, [&](int l) {                                                        // zeta_l = (E' Cy E)_ll = sum z_l^2 / n
+        double s = 0.0;
+        for (int m = 0; m < L; ++m) {
+            const double em = ws.E[m * L + l];
+            if (em == 0.0) continue;
+            double t = 0.0;
+            for (int m2 = 0; m2 < L; ++m2) t += ws.Q[m * L + m2] * ws.E[m2 * L + l];
+            s += em * t;
+        }
+        ws.a[l] = s;
+    });
+    ex.par(P, [&](int p) {                                                        // u_l = (R A E)[p, lv(p)] = X' z_l / n
+        const int l = md.lvof[p];
+        double s = 0.0;
+        for (int m = 0; m < L; ++m) s += ws.V[p * L + m] * ws.E[m * L + l];
+        ws.wn[p] = (md.mode[l] == MODE_A) ? s / ws.a[l] : s;                      // Mode A: X_b' z / sum z^2 (mode.py:38)
+    });
+    if (md.n_chol > 0) {
+        ex.par(L, [&](int l) {                                                    // Mode B: lstsq(X_b, z) = R_bb^-1 u_b (mode.py:58)
+            if (md.mode[l] == MODE_B) { const int b0 = md.boff[l]; chol_solve(st.chol + md.chol_off[l], md.boff[l + 1] - b0, ws.wn + b0); }
+        });
+    }
+    ex.par(P, [&](int p) { const int l = md.lvof[p]; ws.dv[p] = ws.wn[p] * dot_col(ws.S, PS, p, ws.wn, md.boff[l], md.boff[l + 1]); });
+    ex.par(L, [&](int l) {                                                        // std0(X_b w_l)
+        double s = 0.0;
+        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += ws.dv[p];
+        ws.wf[l] = 1.0 / sqrt(s);
+    });
+    ex.par(P, [&](int p) { st.a_new[p] = ws.wn[p] * ws.wf[md.lvof[p]]; });
+    nm_score_map(ex, md, st, st.a_new, st.c_new, st.k_new);
+    ex.one([&]() { st.scal[2] = (double)(iteration + 1); });
+    return true;
+}
+
+// After the loop: weights = a_new (already normalised, weights.py:130-132), scores = X a_new (no sign rule), the rest as metric.
+template <class Ex>
+PLSPM_HD void nm_finish(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, const FitOutputs& out) {
+    const int P = md.P, PS = ws.PS;
+    ex.par(P, [&](int p) { ws.w[p] = st.a_new[p]; ws.mu[p] = st.mu[p]; ws.cs[p] = 1.0 / st.sd[p]; ws.sd[p] = sqrt(ws.S[p * PS + p]); });
+    ex.one([&]() { ws.scal[1] = st.scal[0]; ws.scal[2] = 1.0 / st.scal[0]; ws.scal[3] = st.scal[1]; });
+    finish_problem(ex, md, ws, out, (int)st.scal[2], false);
 }
 
 }  // namespace plspm

@@ -48,7 +48,95 @@ struct HostExec {
     }
 };
 
+// Host-side model descriptors shared by the entry points below.
+struct EmuModel {
+    std::vector<int> lvof, chol_off, pred_off, pred_idx, succ_off, succ_idx;
+    ModelDesc md{};
+    EmuModel(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode,
+             const double* shift, int n_eff, const int* eff_from, const int* eff_to)
+        : lvof(P), chol_off(L, -1), pred_off(L + 1, 0), succ_off(L + 1, 0) {
+        int kmax = 0, n_chol = 0;
+        for (int l = 0; l < L; ++l) {
+            for (int p = boff[l]; p < boff[l + 1]; ++p) lvof[p] = l;
+            int k = 0;
+            for (int j = 0; j < L; ++j) k += C[l * L + j] ? 1 : 0;
+            kmax = k > kmax ? k : kmax;
+            if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += kb * kb; }
+        }
+        for (int i = 0; i < L; ++i) {
+            for (int j = 0; j < L; ++j) if (C[i * L + j]) pred_idx.push_back(j);
+            pred_off[i + 1] = (int)pred_idx.size();
+            for (int s2 = 0; s2 < L; ++s2) if (C[s2 * L + i]) succ_idx.push_back(s2);
+            succ_off[i + 1] = (int)succ_idx.size();
+        }
+        md.n_edges = pred_off[L];
+        pred_idx.push_back(0); succ_idx.push_back(0);
+        md.P = P; md.L = L; md.PA = PA; md.T = PA / 16; md.scheme = scheme; md.scaled = scaled; md.max_iter = max_iter;
+        md.kmax = kmax; md.n_eff = n_eff; md.n_chol = n_chol; md.tol = tol; md.boff = boff; md.lvof = lvof.data(); md.C = C;
+        md.mode = mode; md.chol_off = chol_off.data(); md.eff_from = eff_from; md.eff_to = eff_to; md.shift = shift;
+        md.pred_off = pred_off.data(); md.pred_idx = pred_idx.data(); md.succ_off = succ_off.data(); md.succ_idx = succ_idx.data();
+        md.tile_tu = nullptr;
+    }
+};
+
+template <class Body>
+static void run_group(int nthreads_in, int P, int L, const ModelDesc& md, double* S, Body body) {
+    const int nthreads = nthreads_in > 16 ? 16 : nthreads_in;
+    std::vector<double> small(workspace_small_doubles(P, L, md.kmax, md.n_chol));
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            Workspace ws{};
+            ws.S = S; ws.PS = cov_ld(P);
+            carve_small(ws, small.data(), P, L, md.kmax, md.n_chol);
+            HostExec ex{t, nthreads, &bar, ws.red};
+            body(ex, ws);
+        });
+    for (auto& x : th) x.join();
+}
+
 extern "C" {
+
+// ---- non-metric (NUM / RAW) entry points: S (R matrix, cov_doubles(P)) and state (nm_state_doubles) persist in caller memory
+long hostemu_cov_doubles(int P) { return cov_doubles(P); }
+long hostemu_nm_state_doubles(int P, int L, int n_chol) { return nm_state_doubles(P, L, n_chol); }
+
+int hostemu_nm_prepare(int P, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode,
+                       const double* shift, const double* Mp, int nthreads, double* S, double* state) {
+    EmuModel em(P, L, PA, scheme, 1, max_iter, tol, boff, C, mode, shift, 0, nullptr, nullptr);
+    run_group(nthreads, P, L, em.md, S, [&](HostExec& ex, Workspace& ws) {
+        NmState st; nm_carve(st, state, P, L);
+        nm_prepare(ex, em.md, ws, st, Mp);
+    });
+    return em.md.n_chol;
+}
+// returns 1 when the problem is still active after the call
+int hostemu_nm_step(int P, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode,
+                    const double* shift, int nthreads, double* S, double* state, const double* partial, int nparts) {
+    EmuModel em(P, L, PA, scheme, 1, max_iter, tol, boff, C, mode, shift, 0, nullptr, nullptr);
+    int active = 0;
+    run_group(nthreads, P, L, em.md, S, [&](HostExec& ex, Workspace& ws) {
+        NmState st; nm_carve(st, state, P, L);
+        const bool a = nm_step(ex, em.md, ws, st, partial, nparts);
+        if (ex.tid == 0) active = a ? 1 : 0;
+    });
+    return active;
+}
+int hostemu_nm_finish(int P, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode,
+                      const double* shift, int n_eff, const int* eff_from, const int* eff_to, int nthreads, double* S, double* state, double* row,
+                      double* crossloadings, double* path_coef, double* lv_cov, double* indirect, double* score_w, double* score_c, double* cov,
+                      double* mean, int* iters, int* status) {
+    EmuModel em(P, L, PA, scheme, 1, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    FitOutputs out{};
+    out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.lv_cov = lv_cov; out.indirect = indirect;
+    out.score_w = score_w; out.score_c = score_c; out.cov = cov; out.mean = mean; out.iters = iters; out.status = status;
+    run_group(nthreads, P, L, em.md, S, [&](HostExec& ex, Workspace& ws) {
+        NmState st; nm_carve(st, state, P, L);
+        nm_finish(ex, em.md, ws, st, out);
+    });
+    return 0;
+}
 
 // Mp: packed scatter (see packed_index); everything else mirrors ModelDesc / FitOutputs.
 int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
