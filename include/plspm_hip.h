@@ -75,6 +75,15 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
 void plspm_model_destroy(plspm_model_t* m);
 
 /*
+ * Non-metric data with Scale.NUM / Scale.RAW on every MV (reference _NonmetricWeights, plspm/weights.py:73-133 with
+ * scale.py:22-39; `Config(default_scale=Scale.NUM)`): every MV is population-standardised (config.py:314), the stop rule is
+ * sum (|Y_old| - |Y_new|)^2 over the LV scores (weights.py:120, evaluated by a streaming pass over the observations after
+ * every iteration), weights are rescaled as weights.py:130-132 and there is no sign rule.  `scaled` of plspm_model_create is
+ * ignored in this mode.  Scale.ORD / Scale.NOM are not supported.
+ */
+int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on);
+
+/*
  * Upload the filtered raw observation matrix (what Config.filter returns, config.py:247-285; no NaNs).
  *   X          host pointer, dense fp64, src_cols columns x N rows
  *   layout     0: row-major (element (i,c) at X[i*src_cols + c]);  1: column-major (X[c*N + i])

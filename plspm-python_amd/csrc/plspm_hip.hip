@@ -561,6 +561,42 @@ struct SolverOut {      // per-problem strides; null base pointers are skipped
     long long* marks;
     FitOutputs fit;     // single-fit extras (problem 0 only)
 };
+// Stage the model descriptors in LDS (the solver consults them in every phase) and repoint md at the copies.
+__device__ __forceinline__ void stage_descriptors(ModelDesc& md, double* lp) {
+    const int P = md.P, L = md.L, ne = md.n_eff, tid = threadIdx.x, nt = blockDim.x;
+    double* sh = lp; lp += P;
+    int* ip = reinterpret_cast<int*>(lp);
+    int* boff = ip; ip += L + 1;
+    int* lvof = ip; ip += P;
+    int* mode = ip; ip += L;
+    int* choff = ip; ip += L;
+    int* ef = ip; ip += ne;
+    int* et = ip; ip += ne;
+    const int nedge = md.n_edges;
+    int* poff = ip; ip += L + 1;
+    int* soff = ip; ip += L + 1;
+    int* pidx = ip; ip += nedge;
+    int* sidx = ip; ip += nedge;
+    const int ntile = md.T * (md.T + 1) / 2;
+    unsigned short* ttu = reinterpret_cast<unsigned short*>(ip); ip += (ntile + 1) / 2;
+    unsigned char* Cb = reinterpret_cast<unsigned char*>(ip);
+    for (int i = tid; i < ntile; i += nt) {
+        int t = 0, rem = i;
+        while (rem >= md.T - t) { rem -= md.T - t; ++t; }
+        ttu[i] = (unsigned short)(t | ((t + rem) << 8));
+    }
+    for (int i = tid; i <= L; i += nt) { poff[i] = md.pred_off[i]; soff[i] = md.succ_off[i]; }
+    for (int i = tid; i < nedge; i += nt) { pidx[i] = md.pred_idx[i]; sidx[i] = md.succ_idx[i]; }
+    for (int i = tid; i < P; i += nt) { sh[i] = md.shift[i]; lvof[i] = md.lvof[i]; }
+    for (int i = tid; i <= L; i += nt) boff[i] = md.boff[i];
+    for (int i = tid; i < L; i += nt) { mode[i] = md.mode[i]; choff[i] = md.chol_off[i]; }
+    for (int i = tid; i < ne; i += nt) { ef[i] = md.eff_from[i]; et[i] = md.eff_to[i]; }
+    for (int i = tid; i < L * L; i += nt) Cb[i] = md.C[i];
+    md.shift = sh; md.boff = boff; md.lvof = lvof; md.mode = mode; md.chol_off = choff; md.eff_from = ef; md.eff_to = et; md.C = Cb;
+    md.pred_off = poff; md.succ_off = soff; md.pred_idx = pidx; md.succ_idx = sidx; md.tile_tu = ttu;
+    __syncthreads();
+}
+
 // LDS: [S (if s_in_lds)] [small workspace (if small_in_lds)]; otherwise the global scratch areas are used.
 // The placement is a template parameter so that every workspace pointer has ONE provenance: the compiler then proves the
 // LDS ones to be address-space-3 (ds_read / ds_write) instead of falling back to flat_load / flat_store.
@@ -577,41 +613,7 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
     if (S_IN_LDS) { ws.S = lp; lp += s_doubles; } else ws.S = gS + b * s_doubles;
     if (SMALL_IN_LDS) { carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol); lp += small_doubles; }
     else carve_small(ws, gsmall + b * small_doubles, md.P, md.L, md.kmax, md.n_chol);
-    // stage the model descriptors in LDS: the solver consults them in every phase
-    {
-        const int P = md.P, L = md.L, ne = md.n_eff, tid = threadIdx.x, nt = blockDim.x;
-        double* sh = lp; lp += P;
-        int* ip = reinterpret_cast<int*>(lp);
-        int* boff = ip; ip += L + 1;
-        int* lvof = ip; ip += P;
-        int* mode = ip; ip += L;
-        int* choff = ip; ip += L;
-        int* ef = ip; ip += ne;
-        int* et = ip; ip += ne;
-        const int nedge = md.n_edges;
-        int* poff = ip; ip += L + 1;
-        int* soff = ip; ip += L + 1;
-        int* pidx = ip; ip += nedge;
-        int* sidx = ip; ip += nedge;
-        const int ntile = md.T * (md.T + 1) / 2;
-        unsigned short* ttu = reinterpret_cast<unsigned short*>(ip); ip += (ntile + 1) / 2;
-        unsigned char* Cb = reinterpret_cast<unsigned char*>(ip);
-        for (int i = tid; i < ntile; i += nt) {
-            int t = 0, rem = i;
-            while (rem >= md.T - t) { rem -= md.T - t; ++t; }
-            ttu[i] = (unsigned short)(t | ((t + rem) << 8));
-        }
-        for (int i = tid; i <= L; i += nt) { poff[i] = md.pred_off[i]; soff[i] = md.succ_off[i]; }
-        for (int i = tid; i < nedge; i += nt) { pidx[i] = md.pred_idx[i]; sidx[i] = md.succ_idx[i]; }
-        for (int i = tid; i < P; i += nt) { sh[i] = md.shift[i]; lvof[i] = md.lvof[i]; }
-        for (int i = tid; i <= L; i += nt) boff[i] = md.boff[i];
-        for (int i = tid; i < L; i += nt) { mode[i] = md.mode[i]; choff[i] = md.chol_off[i]; }
-        for (int i = tid; i < ne; i += nt) { ef[i] = md.eff_from[i]; et[i] = md.eff_to[i]; }
-        for (int i = tid; i < L * L; i += nt) Cb[i] = md.C[i];
-        md.shift = sh; md.boff = boff; md.lvof = lvof; md.mode = mode; md.chol_off = choff; md.eff_from = ef; md.eff_to = et; md.C = Cb;
-        md.pred_off = poff; md.succ_off = soff; md.pred_idx = pidx; md.succ_idx = sidx; md.tile_tu = ttu;
-        __syncthreads();
-    }
+    stage_descriptors(md, lp);
     FitOutputs out = so.fit;
     if (b != 0) out = FitOutputs{};
     out.row = so.row ? so.row + b * so.row_stride : nullptr;
@@ -621,13 +623,108 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
     solve_problem(ex, md, ws, Mp + b * mp_stride, out);
 }
 
+
+#define SCORE_ROWS 16
+// ------------------------------------------------------------------------------------------------ non-metric (NUM / RAW) kernels
+// The correlation matrix R and the iteration state of every problem live in global memory between launches (gS / gstate); the
+// small workspace and the descriptors are LDS-resident.  MODE 0 prepare, 1 step, 2 finish (solver_core.h nm_*).
+template <int MODE>
+__global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gstate,
+                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = gS + b * cov_doubles(md.P);
+    const long small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += small_doubles;
+    NmState st;
+    nm_carve(st, gstate + b * nm_state_doubles(md.P, md.L, md.n_chol), md.P, md.L);
+    if (MODE == 1 && st.scal[3] == 0.0) return;                 // finished problems cost nothing more
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    if (MODE == 0) {
+        nm_prepare(ex, md, ws, st, Mp + b * mp_stride);
+    } else if (MODE == 1) {
+        const bool active = nm_step(ex, md, ws, st, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
+    } else {
+        FitOutputs out = so.fit;
+        if (b != 0) out = FitOutputs{};
+        out.row = so.row ? so.row + b * so.row_stride : nullptr;
+        out.status = so.status ? so.status + b : nullptr;
+        out.iters = so.iters ? so.iters + b : nullptr;
+        nm_finish(ex, md, ws, st, out);
+    }
+}
+
+// Streaming convergence pass (reference weights.py:120): for every still-active problem, sum over its observations (all rows,
+// or the (row,count) list of a bootstrap replicate) of count * sum_l (|y_old| - |y_new|)^2, with y = xa . c + k for the two
+// score maps in the state.  16-row tiles of Xa are staged in LDS like scores_kernel; blockIdx.x = part, blockIdx.y = problem.
+__global__ void __launch_bounds__(256) nm_conv_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, int n_chol, const int* __restrict__ boff,
+                                                       const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride,
+                                                       const double* __restrict__ gstate, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);     // [16][PA+1]
+    double* co = tile + SCORE_ROWS * (PA + 1);              // [P] c_old
+    double* cn = co + P;                                    // [P] c_new
+    double* ko = cn + P;                                    // [L]
+    double* kn = ko + L;                                    // [L]
+    double* cnt = kn + L;                                   // [16]
+    double* red = cnt + SCORE_ROWS;                         // [256]
+    int* bsh = reinterpret_cast<int*>(red + 256);           // [L+1]
+    const long b = blockIdx.y;
+    const int part = blockIdx.x, nparts = gridDim.x, tid = threadIdx.x;
+    const double* st = gstate + b * nm_state_doubles(P, L, n_chol);
+    if (st[3] == 0.0) return;
+    for (int p = tid; p < P; p += 256) { co[p] = st[8 + 2 * P + p]; cn[p] = st[8 + 3 * P + p]; }
+    for (int l = tid; l < L; l += 256) { ko[l] = st[8 + 4 * P + l]; kn[l] = st[8 + 4 * P + L + l]; }
+    for (int l = tid; l <= L; l += 256) bsh[l] = boff[l];
+    const int2* e = ent ? ent + b * ent_stride : nullptr;
+    const long nrows = ent ? (long)nent[b] : N;
+    const long ntiles = (nrows + SCORE_ROWS - 1) / SCORE_ROWS;
+    const int half = PA >> 1;
+    const int r_c = tid & 15, lg = tid >> 4;
+    double acc = 0.0;
+    for (long tl = part; tl < ntiles; tl += nparts) {
+        const long i0 = tl * SCORE_ROWS;
+        const int rows = (int)lmin(SCORE_ROWS, nrows - i0);
+        __syncthreads();
+        if (tid < SCORE_ROWS) cnt[tid] = (tid < rows) ? (e ? (double)e[i0 + tid].y : 1.0) : 0.0;
+        for (int el = tid; el < rows * half; el += 256) {
+            const int r = el / half, c = 2 * (el - r * half);
+            const long src_row = e ? (long)e[i0 + r].x : i0 + r;
+            const double2 v = reinterpret_cast<const double2*>(Xa + src_row * PA)[c >> 1];
+            tile[r * (PA + 1) + c] = v.x;
+            tile[r * (PA + 1) + c + 1] = v.y;
+        }
+        __syncthreads();
+        if (r_c < rows) {
+            const double* row = tile + r_c * (PA + 1);
+            double s = 0.0;
+            for (int l = lg; l < L; l += 16) {
+                double yo = ko[l], yn = kn[l];
+                for (int p = bsh[l]; p < bsh[l + 1]; ++p) { const double x = row[p]; yo += x * co[p]; yn += x * cn[p]; }
+                const double d = fabs(yo) - fabs(yn);
+                s += d * d;
+            }
+            acc += cnt[r_c] * s;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
+    if (tid == 0) partial[b * nparts + part] = red[0];
+}
+
 // ------------------------------------------------------------------------------------------------ scores kernel
 // scores[i][l] = sum_{p in block l} xa[i][p] * score_w[p] + score_c[l]   (weights.py:60, sign rule folded into score_w)
 // A 16-row tile of Xa (16*PA*8 contiguous bytes) is staged in LDS with coalesced 16-byte loads (row stride PA+1 doubles:
 // conflict-free column walks); thread (row, l-group) forms the short per-block dot products; the tile's scores leave
 // through LDS as one contiguous 16*L block.  Small tiles keep several workgroups per CU resident so that one
 // workgroup's HBM loads overlap another's LDS phase (HBM-bound: 8*N*(PA+L) bytes).
-#define SCORE_ROWS 16
 __global__ void __launch_bounds__(256) scores_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, const int* __restrict__ boff,
                                                       const double* __restrict__ score_w, const double* __restrict__ score_c,
                                                       double* __restrict__ scores) {
@@ -690,7 +787,8 @@ struct plspm_model {
     double* d_Xa = nullptr;
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist;
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive;
+    int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
     bool profiling = false;
@@ -847,7 +945,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
-                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p};
+                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p};
     for (void* p : ptrs) if (p) hipFree(p);
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->stream) hipStreamDestroy(m->stream);
@@ -978,7 +1076,69 @@ static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long 
     return 0;
 }
 
+
+// Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
+// finish.  The host only reads one counter per iteration (how many problems are still active).
+static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, const int2* ent, const int* nent,
+                         long ent_stride, int threads) {
+    const int P = m->P, L = m->L;
+    const long N = m->N;
+    int rc;
+    const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
+    const size_t st_doubles = (size_t)nm_state_doubles(P, L, m->n_chol);
+    const long rows_per_problem = ent ? N : N;                      // upper bound for the list length
+    const int nparts = (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (rows_per_problem + 1023) / 1024));
+    if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
+    if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
+    const size_t lds = (size_t)workspace_small_doubles(P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
+    if (lds > kMaxLds) return fail(m, PLSPM_E_LIMIT, "non-metric solver: workspace exceeds LDS");
+    if ((rc = allow_lds(m, (const void*)nm_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<2>, lds)))
+        return rc;
+    const size_t conv_lds = ((size_t)SCORE_ROWS * (m->PA + 1) + 2 * (size_t)P + 2 * (size_t)L + SCORE_ROWS + 256) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
+    if ((rc = allow_lds(m, (const void*)nm_conv_kernel, conv_lds))) return rc;
+    const ModelDesc md = make_desc(m);
+    double* gS = (double*)m->gS.p;
+    double* gst = (double*)m->nmstate.p;
+    double* part = (double*)m->nmpartial.p;
+    int* nact = (int*)m->nmactive.p;
+    const dim3 grid((unsigned)nproblems);
+    {
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        hipLaunchKernelGGL((nm_kernel<0>), grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
+    }
+    for (int it = 0; it <= m->max_iter + 1; ++it) {
+        HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
+        {
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipLaunchKernelGGL((nm_kernel<1>), grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
+        }
+        int h_active = 0;
+        HIPCHK(m, hipMemcpyAsync(&h_active, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (h_active == 0) break;
+        {
+            ProfScope ps(m, PLSPM_K_SCORES);
+            hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, m->d_Xa, N, m->PA, P, L, m->n_chol, m->d_boff, ent,
+                               nent, ent_stride, (const double*)gst, part);
+        }
+    }
+    {
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        hipLaunchKernelGGL((nm_kernel<2>), grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
+    }
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
+
 extern "C" {
+
+int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on) {
+    if (!m) return PLSPM_E_ARG;
+    m->nonmetric = on ? 1 : 0;
+    return 0;
+}
 
 int plspm_sync(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
@@ -1027,7 +1187,9 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     so.fit.weights = d + o_w; so.fit.loadings = d + o_ld; so.fit.crossloadings = d + o_cl; so.fit.path_coef = d + o_pc; so.fit.r2 = d + o_r2;
     so.fit.lv_cov = d + o_lc; so.fit.indirect = d + o_ind; so.fit.score_w = d + o_sw; so.fit.score_c = d + o_sc;
     so.fit.cov = out->cov ? d + o_cov : nullptr; so.fit.mean = d + o_mean; so.fit.sign = d_sign;
-    {
+    if (m->nonmetric) {
+        if ((rc = run_nonmetric(m, 1, (const double*)m->gram.p, psize, so, nullptr, nullptr, 0, 256))) return rc;
+    } else {
         ProfScope ps(m, PLSPM_K_SOLVER);
         if ((rc = launch_solver(m, 1, (const double*)m->gram.p, psize, so, 256))) return rc;
     }
@@ -1121,6 +1283,10 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         }
         SolverOut so{};
         so.row = (double*)m->rows.p + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
+        if (m->nonmetric) {
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128))) return rc;
+            continue;
+        }
         long long* d_marks = nullptr;
         if (getenv("PLSPM_DEBUG_MARKS")) { HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks; }
         {

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
-EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy",
+EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device",
            "plspm_sync", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
@@ -50,6 +50,7 @@ def load():
     lib.plspm_model_create.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32, dbl, i32]
     lib.plspm_model_destroy.restype = None
     lib.plspm_model_destroy.argtypes = [vp]
+    lib.plspm_model_set_nonmetric.argtypes = [vp, i32]
     lib.plspm_upload.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.plspm_effect_pairs.restype = i32
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
@@ -91,7 +92,7 @@ def bootstrap_indices(seed, rep, n):
 class NativeModel:
     """One compiled model on one GPU (an opaque ``plspm_model_t*``)."""
 
-    def __init__(self, block_offset, path, modes, scheme, scaled, max_iter, tol, device_id=0):
+    def __init__(self, block_offset, path, modes, scheme, scaled, max_iter, tol, device_id=0, nonmetric=False):
         lib = load()
         if lib.plspm_device_count() <= 0:
             raise NativeBackendError("no HIP device visible: the MI355X backend has no CPU fallback")
@@ -105,6 +106,8 @@ class NativeModel:
                                          int(max_iter), float(tol), int(device_id))
         if not self._h:
             raise NativeBackendError("plspm_model_create: " + lib.plspm_last_error(None).decode())
+        if nonmetric:
+            self._check(lib.plspm_model_set_nonmetric(self._h, 1), "plspm_model_set_nonmetric")
         self.n_eff = lib.plspm_effect_pairs(self._h, None, None)
         ef = np.zeros(max(self.n_eff, 1), dtype=np.int32)
         et = np.zeros(max(self.n_eff, 1), dtype=np.int32)

@@ -181,6 +181,20 @@ class Config:
     def dummies(self, mv: str):
         return self._dummies[mv]
 
+    def promote_scales(self):
+        """The scale bookkeeping the reference performs inside treat() (config.py:309-313): RAW-only models are unscaled,
+        a RAW + NUM mix becomes all-NUM.  Raises TypeError when some MV has no scale (config.py:307-308)."""
+        if self._metric:
+            return
+        if None in self._mv_scales.values():
+            raise TypeError("If you supply a scale for any MV, you must either supply a scale for all of them or specify a default scale.")
+        kinds = set(self._mv_scales.values())
+        if kinds == {Scale.RAW}:
+            self._scaled = False
+        if kinds == {Scale.RAW, Scale.NUM}:
+            self._scaled = True
+            self._mv_scales = dict.fromkeys(self._mv_scales, Scale.NUM)
+
     # ------------------------------------------------------------------ data preparation
     def filter(self, data: pd.DataFrame) -> pd.DataFrame:
         """Keep only the configured MV columns (in add_lv order) and validate them (reference config.py:247-285)."""
@@ -212,14 +226,7 @@ class Config:
         standardise by the population std, rank ORD/NOM columns and build their dummy matrices.  The estimator does
         not call this -- the metric treatment is folded into the device moments stage -- it exists for API parity."""
         if not self._metric:
-            if None in self._mv_scales.values():
-                raise TypeError("If you supply a scale for any MV, you must either supply a scale for all of them or specify a default scale.")
-            kinds = set(self._mv_scales.values())
-            if kinds == {Scale.RAW}:
-                self._scaled = False
-            if kinds == {Scale.RAW, Scale.NUM}:
-                self._scaled = True
-                self._mv_scales = dict.fromkeys(self._mv_scales, Scale.NUM)
+            self.promote_scales()
             n = data.shape[0]
             out = ((data - data.mean()) / data.std()) / np.sqrt((n - 1) / n)
             for mv, kind in self._mv_scales.items():

@@ -12,6 +12,7 @@ import pandas as pd
 
 from plspm import _native
 from plspm._compile import compile_model
+from plspm.scale import Scale
 from plspm.scheme import Scheme
 
 
@@ -61,21 +62,27 @@ class WeightsCalculatorFactory:
     def scheme(self):
         return self._scheme
 
-    def _check_supported(self):
-        if not self._config.metric():
-            raise NotImplementedError("non-metric data (Scale.*) is not part of the MI355X hot path yet; see SURVEY.md 8(f)")
+    def _nonmetric(self):
+        """True for Scale.NUM / Scale.RAW models (device non-metric solver); ORD / NOM are not built yet."""
+        if self._config.metric():
+            return False
+        self._config.promote_scales()
+        kinds = set(self._config.scale(mv) for lv in list(self._config.path()) for mv in self._config.mvs(lv))
+        if not kinds.issubset({Scale.NUM, Scale.RAW}):
+            raise NotImplementedError("Scale.ORD / Scale.NOM (optimal scaling) are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
+        return True
 
     def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False) -> SolverResult:
         """Compile, upload ``data`` (raw or treated) and run one device fit.  Raises the reference's
         ``Exception("Could not converge ...")`` (weights.py:185-186) on non-convergence."""
-        self._check_supported()
+        nonmetric = self._nonmetric()
         n = data.shape[0]
         expected = np.sqrt(n / (n - 1))
         if abs(self._correction - expected) > 1e-12 * expected:
             raise ValueError("correction must be sqrt(N / (N - 1)) of the data handed to the solver")
         compiled = compile_model(self._config, path, list(data.columns))
         native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
-                                     self._iterations, self._tolerance, self._device_id)
+                                     self._iterations, self._tolerance, self._device_id, nonmetric=nonmetric)
         values = data.values
         native.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled.col_index)
         raw = native.fit(want_scores=want_scores, want_cov=want_cov)
@@ -84,6 +91,7 @@ class WeightsCalculatorFactory:
         return SolverResult(compiled, native, raw, data.index)
 
     def calculate(self, data: pd.DataFrame, path: pd.DataFrame):
-        """Reference seam: ``data`` is already treated; returns (final_data, scores, weights)."""
+        """Reference seam: ``data`` is already treated; returns (final_data, scores, weights).  (Treating is idempotent for
+        both branches: centring a centred matrix / standardising a standardised one changes nothing.)"""
         result = self.run(data, path, scaled=False)
         return data, result.scores(), result.weights()

@@ -515,3 +515,145 @@ def test_api_mode_b_inner_summary_matches_reference_csv():
     np.testing.assert_allclose(util.sort_cols(exp.drop(["type"], axis=1)).sort_index(),
                                util.sort_cols(calc.inner_summary().drop(["type", "r_squared_adj"], axis=1)).sort_index().astype(float))
     pd.testing.assert_series_equal(exp.loc[:, "type"].sort_index(), calc.inner_summary().loc[:, "type"].sort_index())
+
+
+# ------------------------------------------------------------------ non-metric NUM / RAW
+from test_oracle_golden import RUSSA_BLOCKS, RUSSA_C, RUSSA_COLS, russa_inputs     # noqa: E402
+
+
+def gpu_fit_nm(X, model):
+    from plspm import _native
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], True, model.max_iter, model.tol, 0, nonmetric=True)
+    nm.upload(np.ascontiguousarray(X), model.mv_order.astype(np.int32))
+    out = nm.fit(want_scores=True, want_cov=True)
+    P = X.shape[1]
+    inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
+    out["weights_d"] = out["weights"][inv]; out["loadings_d"] = out["loadings"][inv]; out["crossloadings_d"] = out["crossloadings"][inv]
+    out["pairs"] = list(zip(nm.eff_from.tolist(), nm.eff_to.tolist()))
+    return nm, out
+
+
+def check_fit_nm(g, r, tag=""):
+    assert g["status"] == 0, tag
+    assert g["iterations"] == r["iterations"], "%s: iterations %d vs oracle %d" % (tag, g["iterations"], r["iterations"])
+    assert_close(g["weights_d"], r["weights"], RTOL, what=tag + " weights")
+    assert_close(g["loadings_d"], r["loadings"], RTOL, what=tag + " loadings")
+    assert_close(g["crossloadings_d"], r["crossloadings"], RTOL, ATOL)
+    assert_close(g["path_coef"], r["path_coef"], RTOL, ATOL)
+    assert_close(g["r2"], r["r2"], RTOL, ATOL)
+    assert g["pairs"] == r["effect_pairs"]
+    assert_close(g["total"], r["total"], RTOL, ATOL)
+    assert_close(g["scores"], r["scores"], 1e-7, 1e-9, what=tag + " scores")
+    assert np.all(g["sign"] == 1)
+
+
+@pytest.mark.parametrize("modes", ["AAA", "BBB", "ABA"])
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+def test_nonmetric_russa_vs_oracle_and_reference_golden(modes, scheme):
+    X = russa_inputs()
+    model = orc.Model(RUSSA_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=["NUM"] * 9)
+    _, g = gpu_fit_nm(X, model)
+    check_fit_nm(g, orc.fit(X, model), modes + "/" + scheme)
+    gold = load("g8_nonmetric_russa")
+    for kind in ("NUM", "RAW", "MIX"):                              # RAW / mixed configurations give the same numbers
+        key = "%s_%s_%s" % (modes, scheme, kind)
+        assert g["iterations"] == int(gold[key + "/iters"])
+        assert_close(g["weights_d"], gold[key + "/weights"], RTOL)
+        assert_close(g["scores"], gold[key + "/scores"], 1e-7, 1e-9)
+
+
+@pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
+def test_nonmetric_synth2000_vs_golden(modes, scheme):
+    gold = load("g9_nonmetric_synth2000")
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes, mixed="BABABA"), scheme, True, tol=1e-7, scales=["NUM"] * 60)
+    _, g = gpu_fit_nm(X, model)
+    key = "%s_%s" % (modes, scheme)
+    assert g["status"] == 0 and g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights_d"], gold[key + "/weights"], RTOL)
+    assert_close(g["path_coef"], gold[key + "/path_coef"], RTOL, ATOL)
+    assert_close(g["loadings_d"], gold[key + "/loadings"], RTOL)
+
+
+@pytest.mark.parametrize("tag", ["AAA_centroid_NUM", "ABA_path_NUM"])
+def test_nonmetric_bootstrap_explicit_indices_vs_reference_rows(tag):
+    gold = load("g8_nonmetric_russa")
+    X = russa_inputs()
+    modes, scheme, _ = tag.split("_")
+    model = orc.Model(RUSSA_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=["NUM"] * 9)
+    nm, _ = gpu_fit_nm(X, model)
+    rows, status, iters = nm.bootstrap(6, idx=gold["idx"])
+    assert np.all(status == 0) and np.array_equal(iters, gold[tag + "/boot_iters"])
+    P, L, ne = 9, 3, nm.n_eff
+    inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
+    mine = np.concatenate((rows[:, :P][:, inv], rows[:, P:P + L + 2 * ne], rows[:, P + L + 2 * ne:][:, inv]), axis=1)
+    assert_close(mine, gold[tag + "/boot_rows"], RTOL, ATOL)
+
+
+def test_nonmetric_bootstrap_10k_vs_oracle_spot_checks():
+    from plspm import _native
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True, tol=1e-7, scales=["NUM"] * 60)
+    nm, g = gpu_fit_nm(X, model)
+    check_fit_nm(g, orc.fit(X, model), "10k nonmetric")
+    rows, status, iters = nm.bootstrap(300, seed=5)
+    assert np.all(status == 0)
+    corr = orc.correction(10000)
+    for r in (0, 151, 299):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(5, r, 10000), corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+
+
+def test_api_nonmetric_reproduces_reference_russa_and_seminr_tests():
+    """Mirrors reference tests/test_regression_nonmetric.py:18-63 (russa, Scale.NUM) and tests/test_regression_seminr.py:10-33."""
+    import math
+    import os
+    import plspm.config as c
+    import plspm.util as util
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    ref = os.path.join(GOLDEN, "ref_data")
+    russa = pd.read_csv(os.path.join(ref, "russa.csv"), index_col=0)
+    s = c.Structure(); s.add_path(["AGRI", "IND"], ["POLINS"])
+    config = c.Config(s.path(), default_scale=Scale.NUM)
+    config.add_lv("POLINS", Mode.A, c.MV("ecks"), c.MV("death"), c.MV("demo"), c.MV("inst"))
+    config.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("rent"), c.MV("farm"))
+    config.add_lv("IND", Mode.A, c.MV("gnpr"), c.MV("labo"))
+    calc = Plspm(russa, config, Scheme.CENTROID, 100, 0.0000001)
+    np.testing.assert_allclose(util.sort_cols(pd.read_csv(os.path.join(ref, "russa.scores.csv"), index_col=0)), util.sort_cols(calc.scores()))
+    inner = pd.read_csv(os.path.join(ref, "russa.inner_model.csv"), index_col=0)
+    actual = calc.inner_model()
+    actual = actual[actual["to"].isin(["POLINS"])].drop(["to"], axis=1)
+    np.testing.assert_allclose(util.sort_cols(inner).sort_index(), util.sort_cols(actual.set_index(["from"], drop=True)).sort_index())
+    om = pd.read_csv(os.path.join(ref, "russa.outer_model.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(om.filter(["weight", "loading", "communality", "redundancy"])).sort_index(),
+                               util.sort_cols(calc.outer_model()).sort_index())
+    cl = pd.read_csv(os.path.join(ref, "russa.crossloadings.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(cl.filter(["AGRI", "IND", "POLINS"])).sort_index(), util.sort_cols(calc.crossloadings()).sort_index())
+    summ = pd.read_csv(os.path.join(ref, "russa.inner_summary.csv"), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(summ.drop(["type"], axis=1)).sort_index(),
+                               util.sort_cols(calc.inner_summary().drop(["type", "r_squared_adj"], axis=1)).sort_index().astype(float))
+    assert math.isclose(0.643594505232204, calc.goodness_of_fit())
+    for scheme, fname in ((Scheme.PATH, "russa.outer_model_path.csv"), (Scheme.FACTORIAL, "russa.outer_model_factorial.csv")):
+        exp = util.sort_cols(pd.read_csv(os.path.join(ref, fname), index_col=0).filter(["weight", "loading", "communality", "redundancy"])).sort_index()
+        np.testing.assert_allclose(exp, util.sort_cols(Plspm(russa, config, scheme, 100, 0.0000001).outer_model()).sort_index())
+    # seminr / mobi: PATH scheme, mixed Mode A / B, tolerance 1e-8
+    mobi = pd.read_csv(os.path.join(ref, "mobi.csv"), index_col=0)
+    st = c.Structure()
+    st.add_path(["Expectation", "Quality"], ["Loyalty"]); st.add_path(["Image"], ["Expectation"]); st.add_path(["Complaints"], ["Loyalty"])
+    cfg = c.Config(st.path(), default_scale=Scale.NUM)
+    cfg.add_lv_with_columns_named("Expectation", Mode.A, mobi, "CUEX")
+    cfg.add_lv_with_columns_named("Quality", Mode.B, mobi, "PERQ")
+    cfg.add_lv_with_columns_named("Loyalty", Mode.A, mobi, "CUSL")
+    cfg.add_lv_with_columns_named("Image", Mode.A, mobi, "IMAG")
+    cfg.add_lv_with_columns_named("Complaints", Mode.A, mobi, "CUSCO")
+    pls = Plspm(mobi, cfg, Scheme.PATH, 100, 0.00000001)
+    exp_om = pd.read_csv(os.path.join(ref, "seminr-mobi-basic-outer-model.csv"), index_col=0)
+    np.testing.assert_allclose(exp_om.sort_index(), pls.outer_model().drop(["communality", "redundancy"], axis=1).sort_index(), rtol=1e-5)
+    exp_paths = pd.read_csv(os.path.join(ref, "seminr-mobi-basic-paths.csv"), index_col=0)
+    np.testing.assert_allclose(exp_paths.sort_index().sort_index(axis=1), pls.path_coefficients().transpose().sort_index().sort_index(axis=1), rtol=1e-6)

@@ -223,10 +223,14 @@ def test_unsupported_paths_raise_not_implemented():
     from plspm.plspm import Plspm
     sat = satisfaction_frame()
     s = c.Structure(); s.add_path(["IMAG"], ["EXPE"])
-    cfg = c.Config(s.path(), default_scale=Scale.NUM)
+    cfg = c.Config(s.path(), default_scale=Scale.ORD)                 # optimal scaling (ORD / NOM) is not built
     cfg.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); cfg.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
     with pytest.raises(NotImplementedError):
         Plspm(sat, cfg)
+    hoc = c.Config(s.path())
+    hoc.add_higher_order("EXPE", Mode.A, ["A", "B"])
+    with pytest.raises(NotImplementedError):
+        Plspm(sat, hoc)
     with pytest.raises(AssertionError):
         Plspm(sat, cfg, tolerance=0)
     with pytest.raises(AssertionError):
