@@ -34,6 +34,10 @@ class CompiledModel:
     def L(self):
         return len(self.lvs)
 
+    def used_data_cols(self):
+        """Data columns that belong to an LV of the compiled path (others, e.g. the MVs of HOC constituents in stage 2, are ignored)."""
+        return [col for col, dev in zip(self.data_cols, self.inv_index) if dev >= 0]
+
     def endogenous(self):
         return [lv for lv, row in zip(self.lvs, self.path) if row.sum() > 0]
 

@@ -178,6 +178,10 @@ class Config:
     def scale(self, mv: str):
         return self._mv_scales[mv]
 
+    def all_scales(self):
+        """Scales of every configured MV (including the MVs of HOC constituents that are not in the path matrix)."""
+        return list(self._mv_scales.values())
+
     def dummies(self, mv: str):
         return self._dummies[mv]
 

@@ -1,14 +1,22 @@
 """Estimation orchestration (reference plspm/estimator.py:24-74) for the MI355X backend.
 
-The reference treats the data on the host and runs the solver twice (estimator.py:39,52 -- the second run
-is only different when higher-order constructs exist).  Here the raw filtered data are uploaded once, the
-treatment is part of the device moments stage, and the solver runs once.  Higher-order constructs
-(two-stage approach) are not built yet: SURVEY.md 8(f) rank 2.
+The reference treats the data on the host and runs the solver twice (estimator.py:39,52 -- the second run is only
+different when higher-order constructs exist).  Here the raw filtered data are uploaded once, the treatment is part of
+the device moments stage, and the solver runs once.
+
+Higher-order constructs (two-stage approach, estimator.py:43-52): stage 1 fits the model in which every HOC is replaced
+by its constituent LVs (``hoc_path_first_stage``); the constituents' device scores are appended to the data as the
+HOC's manifest variables and stage 2 fits the user's path matrix on that -- two device fits, host orchestration only.
+As in the reference this works for non-metric (Scale.NUM / RAW) models; its metric branch cannot run a HOC model
+(``data.dot(odm)`` misaligns, weights.py:30), so that combination raises here too.  A bootstrap of a HOC model is not
+built yet.
 """
 from typing import Tuple
 
 import pandas as pd
 
+import plspm.config as c
+from plspm.scale import Scale
 from plspm.weights import SolverResult, WeightsCalculatorFactory
 
 
@@ -16,23 +24,53 @@ class Estimator:
     """Estimates the model.  Thread-safe the same way the reference is: it works on a cloned calculator."""
 
     def __init__(self, config):
-        if config.hoc():
-            raise NotImplementedError("higher order constructs are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
         self._config = config
+        self._first_stage_path = self.hoc_path_first_stage(config)
+
+    def hoc_path_first_stage(self, config) -> pd.DataFrame:
+        """Path matrix of stage 1: every exogenous LV of a HOC points at each of its constituent LVs, each constituent
+        points at the HOC's endogenous LVs, and the HOC itself is removed (reference estimator.py:60-74)."""
+        path = config.path()
+        for hoc, members in config.hoc().items():
+            structure = c.Structure(path)
+            incoming = path.loc[hoc]
+            outgoing = path.loc[:, hoc]
+            for lv in list(incoming[incoming == 1].index):
+                structure.add_path([lv], members)
+            for lv in list(outgoing[outgoing == 1].index):
+                structure.add_path(members, [lv])
+            path = structure.path().drop(hoc).drop(hoc, axis=1)
+        return path
 
     def run(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame, want_scores=True, want_cov=False) -> SolverResult:
         calculator = calculator.clone()
         config = calculator.config()
         if config.missing():
             raise NotImplementedError("missing values (mean imputation) are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
+        hocs = config.hoc()
+        if not hocs:
+            self._config = config
+            return calculator.run(data, config.path(), scaled=config.scaled(), want_scores=want_scores, want_cov=want_cov)
+        if config.metric():
+            raise NotImplementedError("higher order constructs need Scale.NUM / Scale.RAW data (the reference's metric solver cannot run them either)")
+        first = calculator.run(data, self._first_stage_path, scaled=config.scaled(), want_scores=True)
+        stage1_scores = first.scores()
+        first.native.close()
+        extended = data.copy()
+        for hoc, members in hocs.items():
+            for lv in members:
+                extended[lv] = stage1_scores[lv]                              # the constituent's scores become an MV of the HOC
+            config.add_lv(hoc, config.mode(hoc), *[c.MV(lv, Scale.NUM) for lv in members])
         self._config = config
-        return calculator.run(data, config.path(), scaled=config.scaled(), want_scores=want_scores, want_cov=want_cov)
+        return calculator.run(extended, config.path(), scaled=config.scaled(), want_scores=want_scores, want_cov=want_cov)
 
     def estimate(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame) -> Tuple[pd.DataFrame, pd.DataFrame, pd.DataFrame]:
-        """API parity with the reference: (final_data, scores, weights).  ``final_data`` (the treated frame) is
-        rebuilt on the host for callers that want it; nothing in the estimator consumes it."""
+        """API parity with the reference: (final_data, scores, weights)."""
         result = self.run(calculator, data)
-        return self._config.treat(data), result.scores(), result.weights()
+        used = list(result.compiled.dev_mvs)
+        frame = data if all(col in data.columns for col in used) else None
+        final = self._config.treat(frame[used]) if frame is not None and self._config.metric() else None
+        return final, result.scores(), result.weights()
 
     def config(self):
         return self._config

@@ -10,7 +10,7 @@ import pandas as pd
 class OuterModel:
     def __init__(self, result, r_squared: pd.Series):
         cm = result.compiled
-        self._crossloadings = pd.DataFrame(result.by_data_column("crossloadings"), index=cm.data_cols, columns=cm.lvs)
+        self._crossloadings = pd.DataFrame(result.by_data_column("crossloadings"), index=cm.used_data_cols(), columns=cm.lvs)
         weights = result.weights()["weight"]
         loading = pd.Series(result.raw["loadings"], index=cm.dev_mvs, name="loading")
         communality = (loading ** 2).rename("communality")

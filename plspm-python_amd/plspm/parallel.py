@@ -68,6 +68,8 @@ def gather_records(send, total, group=None, async_op=False, slot=0):
     dist, rank, world = _world(group)
     if dist is None:
         return send
+    if dist.get_backend(group) == "nccl" and not send.is_cuda:
+        send = send.cuda()                               # RCCL moves device buffers only
     stride = send.shape[1]
     cap = shard_range(total, 0, world)[1]                 # rank 0 always holds the largest shard
     equal = (total % world == 0)

@@ -61,6 +61,8 @@ class Plspm:
         self._unidimensionality = Unidimensionality(model_spec, fit)
         self._bootstrap = None
         if bootstrap:
+            if model_spec.hoc():
+                raise NotImplementedError("bootstrapping a model with higher order constructs is not built yet (two device stages per replicate)")
             if n_obs < 10:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
             # the handle of the fit already holds the data in HBM: the replicates run on it

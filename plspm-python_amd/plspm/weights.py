@@ -37,8 +37,9 @@ class SolverResult:
         return pd.DataFrame({"weight": self.raw["weights"]}, index=self.compiled.dev_mvs)
 
     def by_data_column(self, key):
-        """A per-MV device vector / matrix re-ordered to the filtered data's column order."""
-        return self.raw[key][self.compiled.inv_index]
+        """A per-MV device vector / matrix re-ordered to the (used) data columns' order."""
+        inv = self.compiled.inv_index
+        return self.raw[key][inv[inv >= 0]]
 
 
 class WeightsCalculatorFactory:
@@ -67,7 +68,7 @@ class WeightsCalculatorFactory:
         if self._config.metric():
             return False
         self._config.promote_scales()
-        kinds = set(self._config.scale(mv) for lv in list(self._config.path()) for mv in self._config.mvs(lv))
+        kinds = set(self._config.all_scales())
         if not kinds.issubset({Scale.NUM, Scale.RAW}):
             raise NotImplementedError("Scale.ORD / Scale.NOM (optimal scaling) are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
         return True

