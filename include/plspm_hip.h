@@ -146,6 +146,17 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
                            void** d_status, void** d_iters);
 int plspm_sync(plspm_model_t* m);
 
+/*
+ * Summary statistics of a bootstrap on the device (reference _create_summary, plspm/bootstrap.py:24-32): for every result
+ * column c: summary[c*6 + 0..5] = original, mean, std.error (ddof 1), perc.025, perc.975 (linear interpolation), t stat. --
+ * over the replicates whose status is PLSPM_OK.
+ *   d_rows   NULL: the rows of the last plspm_bootstrap(_device) call on this handle (stride = plspm_row_stride());
+ *            else a device buffer [B * stride] in the same record layout (e.g. the all-gathered records of all GPUs)
+ *   original [R] host: the full-sample estimates;  summary [R*6] host;  n_used: number of OK replicates (may be NULL)
+ */
+int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int32_t stride, const double* original, double* summary,
+                            int64_t* n_used);
+
 /* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);
 

@@ -767,6 +767,82 @@ __global__ void __launch_bounds__(256) scores_kernel(const double* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bootstrap summaries
+// reference _create_summary (plspm/bootstrap.py:24-32): per result column mean, std (ddof 1), 2.5 % / 97.5 % quantiles with
+// linear interpolation, t = original / std -- over the replicates whose status is OK.  One workgroup per column: gather the
+// column into `buf` (LDS when it fits, else a global scratch slice), bitonic sort, tree reductions.
+// out[c*6 + {0..5}] = original, mean, std.error, perc.025, perc.975, t stat.
+__device__ __forceinline__ double quantile_linear(const double* sorted, int m, double q) {
+    const double pos = q * (double)(m - 1);
+    const int lo = (int)floor(pos);
+    const int hi = (lo + 1 < m) ? lo + 1 : lo;
+    const double t = pos - (double)lo, a = sorted[lo], b = sorted[hi], d = b - a;
+    return (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;             // numpy's _lerp (monotone form)
+}
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) summary_kernel(const double* __restrict__ rows, long B, int stride, int R, const double* __restrict__ original,
+                                                       double* __restrict__ gbuf, int npad, double* __restrict__ out, int* __restrict__ n_used) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[256];
+    __shared__ int cnt_s;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double* buf = IN_LDS ? reinterpret_cast<double*>(smem_raw) : gbuf + (long)c * npad;
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+    // gather the OK replicates' values (order is irrelevant: they get sorted)
+    for (long b0 = 0; b0 < B; b0 += 256) {
+        const long b = b0 + tid;
+        const bool ok = (b < B) && rows[b * stride + R] == 0.0;
+        const unsigned long long bal = __ballot(ok);
+        __shared__ int wbase[4];
+        if ((tid & 63) == 0) wbase[tid >> 6] = atomicAdd(&cnt_s, __popcll(bal));
+        __syncthreads();
+        if (ok) buf[wbase[tid >> 6] + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = rows[b * stride + c];
+        __syncthreads();
+    }
+    const int m = cnt_s;
+    if (tid == 0 && c == 0) *n_used = m;
+    int n2 = 1;
+    while (n2 < m) n2 <<= 1;
+    for (int i = m + tid; i < n2; i += 256) buf[i] = 1.0e308 * 10.0;            // +inf padding sorts to the end
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const double a = buf[i], b = buf[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { buf[i] = b; buf[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    double s = 0.0;
+    for (int i = tid; i < m; i += 256) s += buf[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
+    const double mean = (m > 0) ? red[0] / (double)m : 0.0;
+    __syncthreads();
+    double v = 0.0;
+    for (int i = tid; i < m; i += 256) { const double d = buf[i] - mean; v += d * d; }
+    red[tid] = v;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
+    if (tid == 0) {
+        const double nan = __builtin_nan("");
+        const double sd = (m > 1) ? sqrt(red[0] / (double)(m - 1)) : nan;
+        double* o = out + (long)c * 6;
+        o[0] = original[c];
+        o[1] = (m > 0) ? mean : nan;
+        o[2] = sd;
+        o[3] = (m > 0) ? quantile_linear(buf, m, 0.025) : nan;
+        o[4] = (m > 0) ? quantile_linear(buf, m, 0.975) : nan;
+        o[5] = original[c] / sd;
+    }
+}
+
 // ================================================================================================ host side
 static thread_local std::string g_create_error;
 
@@ -787,7 +863,7 @@ struct plspm_model {
     double* d_Xa = nullptr;
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive;
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_io, sum_buf;
     int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
@@ -945,7 +1021,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
-                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p};
+                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->stream) hipStreamDestroy(m->stream);
@@ -1334,6 +1410,41 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     HIPCHK(m, hipMemcpyAsync(&h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    return 0;
+}
+
+int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int32_t stride, const double* original, double* summary, int64_t* n_used) {
+    if (!m || !original || !summary || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: bad arguments");
+    HIPCHK(m, hipSetDevice(m->device));
+    const int R = plspm_row_width(m);
+    const double* rows = d_rows ? (const double*)d_rows : (const double*)m->rows.p;
+    if (!rows) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_summary: no bootstrap result on this handle");
+    if (!d_rows) stride = plspm_row_stride(m);
+    if (stride < R + 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: stride must cover the status column");
+    int npad = 1;
+    while (npad < B) npad <<= 1;
+    const bool in_lds = (size_t)npad * sizeof(double) <= (size_t)128 * 1024;
+    int rc;
+    if ((rc = ensure(m, m->sum_io, ((size_t)R * 7 + 2) * sizeof(double)))) return rc;
+    if (!in_lds && (rc = ensure(m, m->sum_buf, (size_t)R * npad * sizeof(double)))) return rc;
+    double* d_orig = (double*)m->sum_io.p;
+    double* d_out = d_orig + R;
+    int* d_used = (int*)(d_out + (size_t)R * 6);
+    HIPCHK(m, hipMemcpyAsync(d_orig, original, sizeof(double) * R, hipMemcpyHostToDevice, m->stream));
+    if (in_lds) {
+        const size_t lds = (size_t)npad * sizeof(double);
+        if ((rc = allow_lds(m, (const void*)summary_kernel<true>, lds))) return rc;
+        hipLaunchKernelGGL((summary_kernel<true>), dim3(R), dim3(256), lds, m->stream, rows, (long)B, (int)stride, R, (const double*)d_orig, (double*)nullptr, npad, d_out, d_used);
+    } else {
+        hipLaunchKernelGGL((summary_kernel<false>), dim3(R), dim3(256), 0, m->stream, rows, (long)B, (int)stride, R, (const double*)d_orig, (double*)m->sum_buf.p, npad, d_out,
+                           d_used);
+    }
+    HIPCHK(m, hipGetLastError());
+    int h_used = 0;
+    HIPCHK(m, hipMemcpyAsync(summary, d_out, sizeof(double) * R * 6, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(&h_used, d_used, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (n_used) *n_used = h_used;
     return 0;
 }
 

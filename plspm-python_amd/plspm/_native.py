@@ -16,7 +16,7 @@ ABI_VERSION = 1
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
 EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric",
-           "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device",
+           "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
 
@@ -61,6 +61,7 @@ def load():
     lib.plspm_fit.argtypes = [vp, ctypes.POINTER(_FitResult)]
     lib.plspm_bootstrap.argtypes = [vp, i64, u64, i64, vp, vp, vp, vp]
     lib.plspm_bootstrap_device.argtypes = [vp, i64, u64, i64, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.plspm_bootstrap_summary.argtypes = [vp, vp, i64, i32, vp, vp, ctypes.POINTER(i64)]
     lib.plspm_sync.argtypes = [vp]
     lib.plspm_bootstrap_indices.argtypes = [u64, i64, i64, vp]
     lib.plspm_profile_enable.argtypes = [vp, i32]
@@ -177,6 +178,17 @@ class NativeModel:
         self._check(self._lib.plspm_bootstrap_device(self._h, B, seed, rep_offset, None, ctypes.byref(d_out), ctypes.byref(d_st), ctypes.byref(d_it)),
                     "plspm_bootstrap_device")
         return d_out.value, d_st.value, d_it.value
+
+    def summary(self, B, original, d_rows=None, stride=0):
+        """Device-side _create_summary of the last bootstrap on this handle (or of the device records at ``d_rows``).
+        Returns ([R, 6] array: original, mean, std.error, perc.025, perc.975, t stat.; number of OK replicates)."""
+        original = np.ascontiguousarray(original, dtype=np.float64)
+        if original.shape != (self.row_width,):
+            raise ValueError("original must have row_width entries")
+        out = np.empty((self.row_width, 6))
+        used = ctypes.c_int64(0)
+        self._check(self._lib.plspm_bootstrap_summary(self._h, d_rows, B, stride, _ptr(original), _ptr(out), ctypes.byref(used)), "plspm_bootstrap_summary")
+        return out, used.value
 
     def sync(self):
         self._check(self._lib.plspm_sync(self._h), "plspm_sync")

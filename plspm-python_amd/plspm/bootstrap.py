@@ -5,7 +5,9 @@ The reference forks ``processes`` workers that each loop over resample -> estima
 three batched kernels on the data already resident in HBM (resample/compact, fp64-MFMA Gram, LDS solver);
 with several processes (one per GPU) the replicate range is sharded and merged by ``plspm.parallel``.
 Replicates whose status is not OK are dropped, as the reference's bare ``except`` drops them
-(bootstrap.py:65-66).  Summaries follow ``_create_summary`` (bootstrap.py:24-32).
+(bootstrap.py:65-66).  The summaries of ``_create_summary`` (bootstrap.py:24-32) are computed on the device as well
+(``plspm_bootstrap_summary``: one workgroup per result column, LDS bitonic sort for the quantiles); the host
+``_create_summary`` below is the same statistic in NumPy, kept for API parity and as the checker of the kernel.
 """
 import os
 
@@ -45,25 +47,38 @@ class Bootstrap:
         if seed is None:
             seed = int.from_bytes(os.urandom(8), "little")      # the reference is unseeded as well (bootstrap.py:56)
         self._seed = seed
-        P, L, ne = cm.P, cm.L, native.n_eff
-        rows, status, iters = parallel.sharded_bootstrap(lambda count, first: native.bootstrap(count, seed, first), iterations,
-                                                         native.row_width, group=group)
-        self._status, self._iterations = status, iters
-        ok = rows[status == 0]
-        self._replicates = ok
+        P, L, ne, R = cm.P, cm.L, native.n_eff, native.row_width
         cols = list(data.columns)
         eff_index = list(inner_model.effects().index)
-        w = pd.DataFrame(ok[:, :P][:, cm.inv_index], columns=cols)
-        r2 = pd.DataFrame(ok[:, P:P + L], columns=cm.lvs)
-        tot = pd.DataFrame(ok[:, P + L:P + L + ne], columns=eff_index)
-        direct = pd.DataFrame(ok[:, P + L + ne:P + L + 2 * ne], columns=eff_index)
-        ld = pd.DataFrame(ok[:, P + L + 2 * ne:][:, cm.inv_index], columns=cols)
         om = outer_model.model()
-        self._weights = _create_summary(w, om.loc[cols, "weight"])
-        self._r_squared = _create_summary(r2, inner_model.r_squared()).loc[inner_model.endogenous(), :]
-        self._total_effects = _create_summary(tot, inner_model.effects().loc[:, "total"])
-        self._paths = _create_summary(direct, inner_model.effects().loc[:, "direct"])
-        self._loading = _create_summary(ld, om.loc[cols, "loading"])
+        # full-sample estimates in the device row layout: weights | r2 | total | direct | loadings (device column order)
+        original = np.concatenate((om.loc[cm.dev_mvs, "weight"].values, inner_model.r_squared().loc[cm.lvs].values,
+                                   inner_model.effects().loc[:, "total"].values, inner_model.effects().loc[:, "direct"].values,
+                                   om.loc[cm.dev_mvs, "loading"].values)).astype(np.float64)
+        dist, _, world = parallel._world(group)
+        if dist is None:
+            rows, status, iters = native.bootstrap(iterations, seed, 0)                 # resample + Gram + solver on this GPU
+            table, used = native.summary(iterations, original)                          # _create_summary, on the rows still in HBM
+        else:
+            def run_shard(count, first):
+                d_rows, _, _ = native.bootstrap_device(count, seed, first)
+                return d_rows, native.sync
+            records = parallel.sharded_bootstrap(run_shard, iterations, R, group=group, on_device=True, to_host=False)
+            import torch
+            torch.cuda.synchronize()
+            table, used = native.summary(iterations, original, d_rows=records.data_ptr(), stride=R + 2)
+            rows, status, iters = parallel.split_records(records.cpu().numpy(), R)
+        self._status, self._iterations, self._used = status, iters, used
+        self._replicates = rows[status == 0]
+        inv = cm.inv_index
+
+        def frame(block, index):
+            return pd.DataFrame(block, index=index, columns=SUMMARY_COLUMNS)
+        self._weights = frame(table[:P][inv], cols)                                      # data-column order (bootstrap.py:83)
+        self._r_squared = frame(table[P:P + L], cm.lvs).loc[inner_model.endogenous(), :]
+        self._total_effects = frame(table[P + L:P + L + ne], eff_index)
+        self._paths = frame(table[P + L + ne:P + L + 2 * ne], eff_index)
+        self._loading = frame(table[P + L + 2 * ne:][inv], cols)
 
     def weights(self) -> pd.DataFrame:
         """Outer weights calculated from bootstrap validation."""

@@ -689,3 +689,21 @@ def test_api_hoc_two_stage_reproduces_reference_seminr_test():
     paths = pd.read_csv(os.path.join(ref, "seminr-mobi-hoc-ts-paths.csv"), index_col=0).transpose()
     np.testing.assert_allclose(paths.sort_index().sort_index(axis=1), pls.path_coefficients().sort_index().sort_index(axis=1), rtol=1e-6)
     assert list(pls.scores().columns) == list(structure.path()) if False else pls.scores().shape == (250, 5)
+
+
+@pytest.mark.parametrize("B", [37, 5000, 20000])
+def test_device_bootstrap_summary_matches_host_statistics(B):
+    """plspm_bootstrap_summary (LDS sort up to 16k replicates, global scratch beyond) vs the NumPy / pandas definition."""
+    from plspm.bootstrap import _create_summary
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=100)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    rows, status, _ = nm.bootstrap(B, seed=3)
+    original = np.linspace(-1.0, 2.0, nm.row_width)
+    table, used = nm.summary(B, original)
+    ok = rows[status == 0]
+    assert used == ok.shape[0] and used >= B - 5
+    host = _create_summary(pd.DataFrame(ok), pd.Series(original)).values
+    assert_close(table, host, 1e-11, 1e-13)
+    assert_close(table, orc.summary(ok, original), 1e-11, 1e-13)
