@@ -67,6 +67,20 @@ def treat_metric(X: np.ndarray, scaled: bool) -> np.ndarray:
     return Xc
 
 
+def filter_missing(X: np.ndarray, model) -> np.ndarray:
+    """Config.filter (config.py:273-285): drop the rows in which ALL MVs of some LV are missing."""
+    drop = np.zeros(X.shape[0], dtype=bool)
+    for b in model.blocks:
+        drop |= np.isnan(X[:, b]).all(axis=1)
+    return X[~drop]
+
+
+def impute(X: np.ndarray) -> np.ndarray:
+    """util.impute (util.py:61-68): column-mean imputation of the remaining missing values (metric data only)."""
+    means = np.nanmean(X, axis=0)
+    return np.where(np.isnan(X), means[None, :], X)
+
+
 def correction(n: int) -> float:
     """plspm.py:65."""
     return math.sqrt(n / (n - 1))
@@ -326,6 +340,8 @@ def fit(X, model: Model, corr: Optional[float] = None):
         Xt = s["data"]
         s["sign"] = np.ones(model.L)
     else:
+        if np.isnan(X).any():
+            X = impute(X)                                         # config.py:300
         Xt = treat_metric(X, model.scaled)                        # estimator.py:33
         s = solve(Xt, model, corr)                                # estimator.py:39 (== :52, no HOC)
     B, r2, r2_adj = inner_model(model.C, s["scores"])             # plspm.py:71

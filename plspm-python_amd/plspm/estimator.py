@@ -1,5 +1,9 @@
 """Estimation orchestration (reference plspm/estimator.py:24-74) for the MI355X backend.
 
+Missing values in metric data are mean-imputed on the host before the upload (reference config.py:300, util.py:61-68;
+rows whose whole block is missing were already dropped by Config.filter); a bootstrap of such data would have to re-impute
+per replicate and is not built yet.
+
 The reference treats the data on the host and runs the solver twice (estimator.py:39,52 -- the second run is only
 different when higher-order constructs exist).  Here the raw filtered data are uploaded once, the treatment is part of
 the device moments stage, and the solver runs once.
@@ -46,7 +50,9 @@ class Estimator:
         calculator = calculator.clone()
         config = calculator.config()
         if config.missing():
-            raise NotImplementedError("missing values (mean imputation) are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
+            if not config.metric():
+                raise NotImplementedError("missing values in non-metric data are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
+            data = data.fillna(data.mean())                       # util.impute (reference util.py:61-68, config.py:300): column means
         hocs = config.hoc()
         if not hocs:
             self._config = config

@@ -58,9 +58,12 @@ class Plspm:
         r2 = self._inner_model.r_squared()
         self._outer_model = om.OuterModel(fit, r2)
         self._inner_summary = pis.InnerSummary(model_spec, r2, self._inner_model.r_squared_adj(), self._outer_model.model())
-        self._unidimensionality = Unidimensionality(model_spec, fit)
+        incomplete = [col for col in observations.columns if observations[col].isnull().any()]
+        self._unidimensionality = Unidimensionality(model_spec, fit, incomplete)
         self._bootstrap = None
         if bootstrap:
+            if model_spec.missing():
+                raise NotImplementedError("bootstrapping data with missing values is not built yet (the reference re-imputes every replicate)")
             if model_spec.hoc():
                 raise NotImplementedError("bootstrapping a model with higher order constructs is not built yet (two device stages per replicate)")
             if n_obs < 10:

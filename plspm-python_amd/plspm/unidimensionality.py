@@ -11,9 +11,10 @@ from plspm.mode import Mode
 
 
 class Unidimensionality:
-    def __init__(self, config, result):
+    def __init__(self, config, result, incomplete_mvs=()):
         self._config = config
         self._result = result
+        self._incomplete = set(incomplete_mvs)        # MVs with missing values: their blocks report NaN (unidimensionality.py:39)
 
     def summary(self) -> pd.DataFrame:
         cm = self._result.compiled
@@ -24,12 +25,14 @@ class Unidimensionality:
         for l, lv in enumerate(lvs):
             a, b = cm.block_offset[l], cm.block_offset[l + 1]
             k = b - a
+            out.loc[lv, "mode"] = self._config.mode(lv).name
+            out.loc[lv, "mvs"] = k
+            if self._incomplete.intersection(self._config.mvs(lv)):
+                continue
             block = cov[a:b, a:b]
             d = np.sqrt(np.diag(block))
             R = block / np.outer(d, d)
             evals, evecs = np.linalg.eigh(R)
-            out.loc[lv, "mode"] = self._config.mode(lv).name
-            out.loc[lv, "mvs"] = k
             out.loc[lv, "eig_1st"] = evals[-1]
             out.loc[lv, "eig_2nd"] = evals[-2] if k > 1 else np.nan
             if self._config.mode(lv) == Mode.A:

@@ -286,6 +286,22 @@ def main():
                 if k != "mv_names":
                     g9[key + "/" + k] = v
     save("g9_nonmetric_synth2000", **g9)
+    # ---- G10: metric data with missing values (mean imputation, config.py:300 + util.py:61-68; rows with an all-NaN block dropped, config.py:273-285)
+    satm = sat.copy()
+    rs = np.random.RandomState(10)
+    for _ in range(40):
+        satm.iloc[rs.randint(250), 1 + rs.randint(27)] = np.nan       # column 0 is gender
+    satm.loc[satm.index[7], [col for col in sat.columns if col.startswith("loy")]] = np.nan      # a whole LOY block missing -> row dropped
+    g10 = {"data": satm[[col for lv in add_order for col in sat.columns if col.startswith(prefixes[lv])]].values.astype(float)}
+    for modes_name, modes in (("A", "AAAAAA"), ("M", "ABABAB")):
+        for scheme in ("centroid", "path"):
+            for scaled in (False, True):
+                cfg = build_config(Csat, lvs, sat_blocks, modes, scaled, add_order)
+                _, out = run_fit(satm, cfg, scheme, lvs)
+                key = "%s_%s_%d" % (modes_name, scheme, int(scaled))
+                for k, v in out.items():
+                    g10[key + "/" + k] = v
+    save("g10_metric_missing", **g10)
     print("done in %.1f s" % (time.time() - t0))
 
 

@@ -707,3 +707,39 @@ def test_device_bootstrap_summary_matches_host_statistics(B):
     host = _create_summary(pd.DataFrame(ok), pd.Series(original)).values
     assert_close(table, host, 1e-11, 1e-13)
     assert_close(table, orc.summary(ok, original), 1e-11, 1e-13)
+
+
+def test_api_metric_missing_values_match_reference_golden():
+    """Mean imputation + all-block-missing row drop (reference config.py:273-285,300) through the drop-in API."""
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    g = load("g10_metric_missing")
+    _, blocks, cols = satisfaction_oracle_inputs()
+    frame = pd.DataFrame(g["data"], columns=cols)
+    structure = c.Structure()
+    structure.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); structure.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+    structure.add_path(["QUAL"], ["VAL", "SAT"]); structure.add_path(["VAL"], ["SAT"]); structure.add_path(["SAT"], ["LOY"])
+    for modes_name, modes in (("A", "AAAAAA"), ("M", "ABABAB")):
+        for scheme_name, scheme in (("centroid", Scheme.CENTROID), ("path", Scheme.PATH)):
+            for scaled in (False, True):
+                config = c.Config(structure.path(), scaled=scaled)
+                for lv in SAT_ADD_ORDER:
+                    mode = Mode.A if modes[orc.SAT_LVS.index(lv)] == "A" else Mode.B
+                    config.add_lv_with_columns_named(lv, mode, frame, SAT_PREFIX[lv])
+                calc = Plspm(frame, config, scheme)
+                key = "%s_%s_%d" % (modes_name, scheme_name, int(scaled))
+                assert calc.iterations() == int(g[key + "/iters"])
+                assert calc.scores().shape == (249, 6)
+                om = calc.outer_model()
+                assert_close(om.loc[cols, "weight"].values, g[key + "/weights"], RTOL)
+                assert_close(om.loc[cols, "loading"].values, g[key + "/loadings"], RTOL)
+                assert_close(calc.path_coefficients().loc[orc.SAT_LVS, orc.SAT_LVS].values, g[key + "/path_coef"], RTOL, ATOL)
+                assert_close(calc.scores().loc[:, orc.SAT_LVS].values, g[key + "/scores"], 1e-7, 1e-9)
+                uni = calc.unidimensionality()
+                for lv in orc.SAT_LVS:                      # blocks with a missing value report NaN (unidimensionality.py:39)
+                    has_nan = frame[[col for col in cols if col.startswith(SAT_PREFIX[lv])]].iloc[[i for i in range(250) if i != 7]].isnull().values.any()
+                    assert bool(np.isnan(uni.loc[lv, "eig_1st"])) == bool(has_nan)
+                with pytest.raises(NotImplementedError):
+                    Plspm(frame, config, scheme, bootstrap=True)

@@ -257,3 +257,18 @@ def test_reference_csv_russa_nonmetric():
     model = orc.Model(RUSSA_BLOCKS, RUSSA_C, "BBB", "centroid", True, tol=1e-7, scales=["NUM"] * 9)
     summ_b = pd.read_csv(os.path.join(ref, "russa.mode_b_inner_summary.csv"), index_col=0)
     assert_close(orc.fit(X, model)["r2"], summ_b.loc[lv, "r_squared"].values, 1e-7, 1e-12)
+
+
+# ------------------------------------------------------------------ metric data with missing values (config.py:273-285, 300)
+@pytest.mark.parametrize("modes", ["A", "M"])
+@pytest.mark.parametrize("scheme", ["centroid", "path"])
+@pytest.mark.parametrize("scaled", [0, 1])
+def test_g10_metric_missing(modes, scheme, scaled):
+    g = load("g10_metric_missing")
+    _, blocks, cols = satisfaction_oracle_inputs()
+    key = "%s_%s_%d" % (modes, scheme, scaled)
+    assert list(g[key + "/mv_names"]) == cols
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, bool(scaled))
+    X = orc.filter_missing(g["data"], model)
+    assert X.shape[0] == 249 and np.isnan(X).sum() >= 30
+    _check_fit(orc.fit(X, model), g, key)
