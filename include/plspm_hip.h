@@ -145,6 +145,9 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
 int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out,
                            void** d_status, void** d_iters);
 int plspm_sync(plspm_model_t* m);
+/* The handle's HIP stream (a hipStream_t), so that a caller can order its own work -- e.g. an RCCL collective -- behind the
+ * enqueued kernels with stream/event semantics instead of a host synchronisation. */
+void* plspm_stream(plspm_model_t* m);
 
 /*
  * Summary statistics of a bootstrap on the device (reference _create_summary, plspm/bootstrap.py:24-32): for every result

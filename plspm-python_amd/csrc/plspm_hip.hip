@@ -1216,6 +1216,8 @@ int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on) {
     return 0;
 }
 
+void* plspm_stream(plspm_model_t* m) { return m ? (void*)m->stream : nullptr; }
+
 int plspm_sync(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
     HIPCHK(m, hipSetDevice(m->device));

@@ -17,7 +17,7 @@ STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
 EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
-           "plspm_sync", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
+           "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
 
 class NativeBackendError(RuntimeError):
@@ -63,6 +63,8 @@ def load():
     lib.plspm_bootstrap_device.argtypes = [vp, i64, u64, i64, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     lib.plspm_bootstrap_summary.argtypes = [vp, vp, i64, i32, vp, vp, ctypes.POINTER(i64)]
     lib.plspm_sync.argtypes = [vp]
+    lib.plspm_stream.restype = vp
+    lib.plspm_stream.argtypes = [vp]
     lib.plspm_bootstrap_indices.argtypes = [u64, i64, i64, vp]
     lib.plspm_profile_enable.argtypes = [vp, i32]
     lib.plspm_profile_read.argtypes = [vp, i32, ctypes.POINTER(dbl), ctypes.POINTER(i64)]
@@ -189,6 +191,10 @@ class NativeModel:
         used = ctypes.c_int64(0)
         self._check(self._lib.plspm_bootstrap_summary(self._h, d_rows, B, stride, _ptr(original), _ptr(out), ctypes.byref(used)), "plspm_bootstrap_summary")
         return out, used.value
+
+    def stream_ptr(self):
+        """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        return int(self._lib.plspm_stream(self._h) or 0)
 
     def sync(self):
         self._check(self._lib.plspm_sync(self._h), "plspm_sync")

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python tools/fit_bench.py c2 c5 2>&1 | tail -2 | tee gpurun_out/fit_bench.txt | python -c "
-import sys,json
-for l in sys.stdin: d=json.loads(l); print(d['config'], d['kernel_ms'], d['device_ms_total'], d['algorithmic'])"
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for nw in 4 8; do
+echo "NW=$nw"; PLSPM_WIDE_NW=$nw timeout 900 python tools/fit_bench.py c5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernel_ms'], d['algorithmic']['TFLOPs_on_gram_time'])"
+done
+timeout 900 python -m pytest tests -m gpu -x -q -k "config5 or chain20 or tile_count or limits" 2>&1 | tail -2
