@@ -60,7 +60,7 @@ const char* plspm_last_error(const plspm_model_t* m);
 /*
  * Compile a model specification (reference Config + path matrix + Plspm kwargs, plspm/config.py:89-160,
  * plspm/plspm.py:35-67) into device descriptors.
- *   P, L           manifest / latent variable counts (1 <= L <= 64, L <= P <= 254)
+ *   P, L           manifest / latent variable counts (1 <= L <= 64, L <= P <= 1022)
  *   block_offset   [L+1] device-column ranges of the LV blocks
  *   path           [L*L] row-major 0/1, path[i*L+j] = 1 iff LV j -> LV i; must be strictly lower triangular
  *   mode           [L]   PLSPM_MODE_A / PLSPM_MODE_B per LV

@@ -483,6 +483,119 @@ __global__ void __launch_bounds__(NWP * 64) gram_wide_kernel(const double* __res
     WideDispatch<T, NWV, 0, DENSE>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
 }
 
+
+// Block variant (T > 16, i.e. 255 <= P <= 1022): the upper triangle of the T x T tile grid is cut into 4 x 4-tile super-blocks
+// (64 x 64 columns); every wave owns ONE super-block (16 accumulator tiles, 10 on the diagonal), the four waves of a workgroup
+// walk the same k-groups, and blockIdx.z enumerates groups of four super-blocks.  Tile coordinates are run-time values (wave-
+// uniform), so one instantiation serves every T; out-of-range tiles of the last super-block row/column are skipped.
+// two 16-byte loads: the first 32-column group of a super-block and (off doubles further) its second one
+__device__ __forceinline__ void issue_pair(dv2 (&v)[2], const double* p, int off) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v[0]) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v[1]) : "v"(p + off) : "memory");
+}
+template <bool DENSE>
+__device__ __forceinline__ void block_stage(d4 (&acc)[16], dv2 (&Rc)[2], dv2 (&Cc)[2], dv2 (&Rn)[2], dv2 (&Cn)[2], iv2& Enext, iv2& Eafter, double cnt,
+                                            const double* rbase, const double* cbase, int r1off, int c1off, int PA, const int2* eptr_after,
+                                            long dense_row_next, unsigned valid) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t]));
+    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Enext)::"memory");
+    RowLoader<0, 2>::pin(Rc);
+    RowLoader<0, 2>::pin(Cc);
+    const double xr[4] = {Rc[0].x, Rc[0].y, Rc[1].x, Rc[1].y};
+    const double xc[4] = {Cc[0].x, Cc[0].y, Cc[1].x, Cc[1].y};
+    const long rnext = DENSE ? dense_row_next : (long)Enext.x;
+    issue_pair(Rn, rbase + rnext * PA, r1off);
+    issue_pair(Cn, cbase + rnext * PA, c1off);
+    if (!DENSE) issue_entry(Eafter, eptr_after);
+    asm volatile("" : "+v"(cnt));
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        const double a = cnt * xr[ti];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+            if (valid & (1u << (ti * 4 + tj))) acc[ti * 4 + tj] = MFMA_F64(a, xc[tj], acc[ti * 4 + tj]);      // wave-uniform mask: scalar branch
+    }
+}
+template <bool DENSE>
+__global__ void __launch_bounds__(256) gram_block_kernel(const double* __restrict__ Xa, long N, int T, const int2* __restrict__ ent,
+                                                          const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, k = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long problem = blockIdx.y;
+    const int PA = 16 * T, TB = (T + 3) >> 2, nsb = TB * (TB + 1) / 2;
+    const int sb = (int)blockIdx.z * 4 + wave;
+    if (sb >= nsb) return;
+    int bi = 0, rem = sb;
+    while (rem >= TB - bi) { rem -= TB - bi; ++bi; }
+    const int bj = bi + rem;
+    unsigned valid = 0;
+    for (int ti = 0; ti < 4; ++ti)
+        for (int tj = 0; tj < 4; ++tj) {
+            const int t = 4 * bi + ti, u = 4 * bj + tj;
+            if (t < T && u < T && t <= u) valid |= 1u << (ti * 4 + tj);
+        }
+    const int2* e = DENSE ? nullptr : ent + problem * ent_stride + k;
+    const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
+    const int g0 = blockIdx.x, gs = gridDim.x;
+    const int niter = (g0 < ng) ? (ng - g0 + gs - 1) / gs : 0;
+    const int last = ng - 1;
+    // row / column fragments: 32-column groups 2*bi, 2*bi+1 and 2*bj, 2*bj+1; a partial last super-block has no second group:
+    // its load is pointed at the first group again (those tiles are masked out of `valid`)
+    const double* rbase = Xa + 32 * (2 * bi) + 2 * i;
+    const double* cbase = Xa + 32 * (2 * bj) + 2 * i;
+    const int r1off = ((2 * bi + 1) < T / 2) ? 32 : 0, c1off = ((2 * bj + 1) < T / 2) ? 32 : 0;
+    auto gof = [&](int it) { const int g = g0 + it * gs; return g < last ? g : last; };
+    auto eaddr = [&](int it) { return e + 4 * (long)gof(it); };
+    auto drow = [&](int it) { const long r = 4 * (long)gof(it) + k; return r < N ? r : N - 1; };
+    auto dcnt = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? 1 : 0; };
+    d4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }
+    iv2 EA = {0, 0}, EB = {0, 0};
+    dv2 RA[2], CA[2], RB[2], CB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { RA[q] = (dv2){0.0, 0.0}; CA[q] = RA[q]; RB[q] = RA[q]; CB[q] = RA[q]; }
+    const double* rb = rbase;
+    const double* cb = cbase;
+    int cA;
+    if (DENSE) {
+        issue_pair(RA, rb + drow(0) * PA, r1off);
+        issue_pair(CA, cb + drow(0) * PA, c1off);
+        cA = dcnt(0);
+    } else {
+        issue_entry(EA, eaddr(0));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA)::"memory");
+        issue_pair(RA, rb + (long)EA.x * PA, r1off);
+        issue_pair(CA, cb + (long)EA.x * PA, c1off);
+        cA = (niter > 0) ? EA.y : 0;
+        issue_entry(EB, eaddr(1));
+    }
+    for (int it = 0; it < niter; it += 2) {
+        block_stage<DENSE>(acc, RA, CA, RB, CB, EB, EA, (double)cA, rb, cb, r1off, c1off, PA, DENSE ? nullptr : eaddr(it + 2), DENSE ? drow(it + 1) : 0, valid);
+        const int cB = DENSE ? dcnt(it + 1) : ((it + 1 < niter) ? EB.y : 0);
+        block_stage<DENSE>(acc, RB, CB, RA, CA, EA, EB, (double)cB, rb, cb, r1off, c1off, PA, DENSE ? nullptr : eaddr(it + 3), DENSE ? drow(it + 2) : 0, valid);
+        cA = DENSE ? dcnt(it + 2) : EA.y;
+    }
+    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA), "+v"(EB)::"memory");
+    RowLoader<0, 2>::pin(RA); RowLoader<0, 2>::pin(CA); RowLoader<0, 2>::pin(RB); RowLoader<0, 2>::pin(CB);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t]));
+    double* dst = out + (problem * gridDim.x + blockIdx.x) * (long)(T * (T + 1) / 2) * 256;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+            if (valid & (1u << (ti * 4 + tj))) {
+                const int t = 4 * bi + ti, u = 4 * bj + tj;
+                const long li = (long)t * T - (long)t * (t - 1) / 2 + (u - t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(li * 4 + r) * 64 + lane] = acc[ti * 4 + tj][r];
+            }
+}
+
 // out[e] = sum over chunks of partial[chunk][e]  (fixed order: deterministic)
 __global__ void __launch_bounds__(256) gram_reduce_kernel(const double* __restrict__ partial, int nchunks, long size, double* __restrict__ out) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -957,7 +1070,7 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
                                   int32_t scaled, int32_t max_iter, double tol, int32_t device_id) {
     g_create_error.clear();
     if (!block_offset || !path || !mode) { fail(nullptr, PLSPM_E_ARG, "null argument"); return nullptr; }
-    if (L < 1 || L > 64 || P < L || P > 254) { fail(nullptr, PLSPM_E_LIMIT, "limits: 1 <= L <= 64, L <= P <= 254"); return nullptr; }
+    if (L < 1 || L > 64 || P < L || P > 1022) { fail(nullptr, PLSPM_E_LIMIT, "limits: 1 <= L <= 64, L <= P <= 1022"); return nullptr; }
     if (scheme < 0 || scheme > 2 || !(tol > 0.0) || max_iter < 1) { fail(nullptr, PLSPM_E_ARG, "bad scheme / tolerance / max_iter"); return nullptr; }
     if (block_offset[0] != 0 || block_offset[L] != P) { fail(nullptr, PLSPM_E_ARG, "block_offset must run from 0 to P"); return nullptr; }
     for (int l = 0; l < L; ++l) {
@@ -1114,7 +1227,11 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
             if (sel == 4) WIDE(14, 4, 4) else if (sel == 16) WIDE(14, 16, 8) else WIDE(14, 8, 8)
         } break;
         case 16: WIDE(16, 16, 8) break;
-        default: return fail(m, PLSPM_E_LIMIT, "unsupported tile count");
+        default: {
+            if (m->T < 18 || (m->T & 1)) return fail(m, PLSPM_E_LIMIT, "unsupported tile count");
+            const int TB = (m->T + 3) / 4, nsb = TB * (TB + 1) / 2;
+            hipLaunchKernelGGL((gram_block_kernel<DENSE>), dim3(nchunks, (unsigned)nproblems, (nsb + 3) / 4), dim3(256), 0, s, m->d_Xa, N, m->T, ent, nent, ent_stride, out);
+        } break;
     }
 #undef ROWS
 #undef WIDE
@@ -1123,7 +1240,8 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
 }
 
 static size_t desc_lds_bytes(int P, int L, int ne, int nedge) {
-    return (size_t)P * 8 + (3 * (size_t)(L + 1) + P + 2 * (size_t)L + 2 * (size_t)ne + 2 * (size_t)nedge + 72) * 4 + (((size_t)L * L + 15) & ~(size_t)15) + 16;
+    const size_t T = ((size_t)P + 1 + 31) / 32 * 2, ntile = T * (T + 1) / 2;
+    return (size_t)P * 8 + (3 * (size_t)(L + 1) + P + 2 * (size_t)L + 2 * (size_t)ne + 2 * (size_t)nedge + (ntile + 1) / 2 + 4) * 4 + (((size_t)L * L + 15) & ~(size_t)15) + 16;
 }
 
 static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, int threads) {

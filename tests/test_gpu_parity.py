@@ -743,3 +743,23 @@ def test_api_metric_missing_values_match_reference_golden():
                     assert bool(np.isnan(uni.loc[lv, "eig_1st"])) == bool(has_nan)
                 with pytest.raises(NotImplementedError):
                     Plspm(frame, config, scheme, bootstrap=True)
+
+
+@pytest.mark.parametrize("L,per,n", [(30, 9, 900), (64, 15, 1500)])
+def test_large_p_block_gram(L, per, n):
+    """P = 270 (T = 18, partial last super-block) and P = 960 (T = 62): run-time super-block Gram + global-memory solver
+    workspace, single fit vs the oracle and bootstrap rows vs the oracle on mirrored indices."""
+    from plspm import _native
+    C = orc.chain_C(L)
+    X, blocks = orc.synth(n, C, per, seed=L)
+    model = orc.Model(blocks, C, "A" * L, "centroid", True)
+    nm, g = gpu_fit(X, model)
+    r = orc.fit(X, model)
+    check_fit(g, r, "P=%d" % (L * per))
+    Xt = orc.treat_metric(X, True)
+    assert_close(g["cov"], Xt.T @ Xt / n, 1e-10, 1e-13)
+    rows, status, iters = nm.bootstrap(3, seed=4)
+    assert np.all(status == 0)
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(4, 2, n), orc.correction(n))
+    assert its == iters[2]
+    assert_close(rows[2], mine, RTOL, ATOL)
