@@ -206,59 +206,115 @@ def treat_nonmetric(X):
     return (X - X.mean(axis=0)) / np.std(X, axis=0, ddof=1) / math.sqrt((n - 1) / n)
 
 
-def nm_quantify(X0, scales):
-    """Scale.NUM (scale.py:27-30): treat_numpy(initial) * sqrt(n/(n-1)) every iteration -- constant;  Scale.RAW (scale.py:38-39): unchanged."""
-    n = X0.shape[0]
-    Xq = X0.copy()
+def rank_column(col):
+    """util.rank (util.py:80-86): every value replaced by the rank (1..C) of its unique value."""
+    uniq = np.unique(col)
+    return (np.searchsorted(uniq, col) + 1).astype(np.float64)
+
+
+def dummy_matrix(ranked):
+    """util.dummy (util.py:89-95): N x C indicator matrix of the rank codes 1..C."""
+    c = int(ranked.max())
+    return (ranked[:, None] == np.arange(1, c + 1)[None, :]).astype(np.float64)
+
+
+def _quantify(dummies, z):
+    """scale.py:47-52: mean of z inside every (possibly merged) category."""
+    return (dummies * z[:, None]).sum(axis=0) / dummies.sum(axis=0)
+
+
+def _ordinalize(scaling, dummies, z, sign):
+    """scale.py:54-66: pool adjacent categories until the category means are monotone (non-decreasing for sign=+1)."""
+    scaling = np.array(scaling, dtype=np.float64)
+    while True:
+        ncols = dummies.shape[1]
+        for n in range(ncols - 1):
+            if np.sign(scaling[n] - scaling[n + 1]) == sign:
+                dummies[:, n + 1] = dummies[:, n] + dummies[:, n + 1]
+                dummies = np.delete(dummies, n, axis=1)
+                scaling = _quantify(dummies, z)
+                break
+        if dummies.shape[1] == 1 or dummies.shape[1] == ncols:
+            break
+    x_new = dummies @ scaling
+    return x_new, np.var(x_new)
+
+
+def treat_nonmetric_full(X, scales):
+    """Config.treat non-metric branch (config.py:314-318): standardise; ORD / NOM columns become rank codes + dummy matrices."""
+    X0 = treat_nonmetric(X)
+    dummies = {}
     for p, kind in enumerate(scales):
-        if kind == "NUM":
-            Xq[:, p] = treat_numpy(X0[:, p]) * math.sqrt(n / (n - 1))
-        elif kind != "RAW":
-            raise NotImplementedError("oracle: scale " + str(kind))
-    return Xq
+        if kind in ("ORD", "NOM"):
+            X0[:, p] = rank_column(X0[:, p])
+            dummies[p] = dummy_matrix(X0[:, p])
+    return X0, dummies
 
 
 def nm_init_scores(X0, model: Model):
-    """_NonmetricWeights.__init__ (weights.py:82-98, no missing data): equal weights 1/sqrt(k) per block."""
+    """_NonmetricWeights.__init__ (weights.py:82-98, no missing data): equal weights 1/sqrt(k) per block, on the treated values."""
     Y = np.zeros((X0.shape[0], model.L))
     for l, b in enumerate(model.blocks):
         Y[:, l] = X0[:, b] @ (np.ones(len(b)) / math.sqrt(len(b)))
     return Y
 
 
-def nm_iterate(Xq, Y, model: Model, corr: float):
-    """_NonmetricWeights.iterate (weights.py:107-120) with mode.py:31-42 (A) / 54-61 (B).  Returns (W, Y_new, convergence)."""
-    E = _SCHEMES[model.scheme](model.C, Y)
-    Z = Y @ E
-    W = np.zeros((Xq.shape[1], model.L))
-    Yn = Y.copy()
-    for l, b in enumerate(model.blocks):
-        Xk = Xq[:, b]
-        if model.modes[l] == "A":
-            w = (Xk.T @ Z[:, l]) / np.sum(Z[:, l] ** 2)
-        else:
-            w = np.linalg.lstsq(Xk, Z[:, l], rcond=None)[0]
-        W[b, l] = w
-        Yn[:, l] = treat_numpy(Xk @ w) * corr
-    conv = float(np.sum((np.abs(Y) - np.abs(Yn)) ** 2))           # weights.py:120 -- on the SCORES, not the weights
-    return W, Yn, conv
-
-
-def solve_nonmetric(X0, model: Model, corr: float):
-    """WeightsCalculatorFactory.calculate, non-metric branch (weights.py:172-187 + 122-133).  No sign rule here."""
-    Xq = nm_quantify(X0, model.scales)
+def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
+    """WeightsCalculatorFactory.calculate, non-metric branch: _NonmetricWeights.__init__ / iterate / calculate
+    (weights.py:73-154) with the four Scale operators (scale.py) and the Mode-B correction get_Z_for_mode_b (weights.py:135-145).
+    X0 is the treated data (ranks in the ORD / NOM columns).  No sign rule here."""
+    n = X0.shape[0]
+    dummies = dummies or {}
+    cur = X0.copy()                                               # self.__mv_grouped_by_lv (updated column by column)
     Y = nm_init_scores(X0, model)
     iteration = 0
     while True:
         iteration += 1
-        W, Y, conv = nm_iterate(Xq, Y, model, corr)
+        Y_old = Y.copy()
+        E = _SCHEMES[model.scheme](model.C, Y)
+        Z = Y @ E
+        W = np.zeros((X0.shape[1], model.L))
+        for l, b in enumerate(model.blocks):
+            z = Z[:, l]
+            betas = None
+            for j, p in enumerate(b):
+                kind = model.scales[p]
+                if kind == "NUM":
+                    cur[:, p] = treat_numpy(X0[:, p]) * math.sqrt(n / (n - 1))          # scale.py:27-30
+                elif kind == "RAW":
+                    cur[:, p] = X0[:, p]                                                # scale.py:38-39
+                else:
+                    zc = z
+                    if model.modes[l] == "B" and len(b) > 1:                            # weights.py:135-145
+                        if betas is None:
+                            A = np.column_stack((np.ones(n), cur[:, b]))
+                            betas = (np.linalg.pinv(A) @ z)[1:]
+                        others = np.delete(np.arange(len(b)), j)
+                        zc = (1.0 / betas[j]) * (z - cur[:, b[others]] @ betas[others])
+                    d = dummies[p]
+                    means = _quantify(d, zc)                                            # util.groupby_mean on [codes; z] (scale.py:70-71, 85-86)
+                    if kind == "ORD":
+                        x_inc, v_inc = _ordinalize(means, d.copy(), zc, 1)
+                        x_dec, v_dec = _ordinalize(means, d.copy(), zc, -1)
+                        xq = -x_dec if v_inc < v_dec else x_inc                         # scale.py:74
+                    else:
+                        xq = d @ means                                                  # scale.py:87
+                    cur[:, p] = treat_numpy(xq) * corr
+            Xk = cur[:, b]
+            if model.modes[l] == "A":
+                w = (Xk.T @ z) / np.sum(z ** 2)
+            else:
+                w = np.linalg.lstsq(Xk, z, rcond=None)[0]
+            W[b, l] = w
+            Y[:, l] = treat_numpy(Xk @ w) * corr
+        conv = float(np.sum((np.abs(Y_old) - np.abs(Y)) ** 2))                          # weights.py:120
         if conv < model.tol or iteration > model.max_iter:
             break
     if iteration > model.max_iter:
         raise NotConverged("Could not converge after %d iterations" % iteration)
-    wf = 1.0 / (np.std(Xq @ W, axis=0, ddof=1) / corr)            # weights.py:130
+    wf = 1.0 / (np.std(cur @ W, axis=0, ddof=1) / corr)            # weights.py:130
     weights = (W * wf).sum(axis=1)                                # weights.py:131-132
-    return dict(scores=Y, weights=weights, iterations=iteration, data=Xq)
+    return dict(scores=Y, weights=weights, iterations=iteration, data=cur)
 
 
 # ----------------------------------------------------------------------------- inner model
@@ -336,7 +392,8 @@ def fit(X, model: Model, corr: Optional[float] = None):
     if corr is None:
         corr = correction(n)
     if model.scales is not None:
-        s = solve_nonmetric(treat_nonmetric(X), model, corr)      # estimator.py:33,39 non-metric
+        X0, dummies = treat_nonmetric_full(X, model.scales)       # estimator.py:33 (config.py:306-318)
+        s = solve_nonmetric(X0, model, corr, dummies)             # estimator.py:39 non-metric
         Xt = s["data"]
         s["sign"] = np.ones(model.L)
     else:

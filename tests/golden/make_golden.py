@@ -302,6 +302,33 @@ def main():
                 for k, v in out.items():
                     g10[key + "/" + k] = v
     save("g10_metric_missing", **g10)
+    # ---- G11: ORD / NOM optimal scaling (scale.py:42-89): russa categorical (reference tests/test_regression_nonmetric.py:94-120) + Likert-style synthetic
+    g11 = {}
+    cat = {"gnpr": Scale.ORD, "labo": Scale.ORD, "demo": Scale.NOM}
+    for modes in ("AAA", "BBB"):
+        for scheme in SCHEMES:
+            cfg = build_config(C8, lv8, bn8, modes, True, add_order=["IND", "POLINS", "AGRI"], default_scale=Scale.NUM, mv_scales=cat)
+            _, out = run_fit(russa, cfg, scheme, lv8, tol=1e-7)
+            for k, v in out.items():
+                g11["russa_%s_%s/%s" % (modes, scheme, k)] = v
+    rs = np.random.RandomState(111)
+    Cl = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 0, 0], [0, 1, 1, 0]])
+    lvl = ["L0", "L1", "L2", "L3"]
+    Xl, blocksl = orc.synth(400, Cl, 4, seed=21)
+    likert = np.clip(np.round(3 + 1.2 * Xl / Xl.std(axis=0)), 1, 5)                  # 5-point items
+    namesl = ["q%d" % i for i in range(16)]
+    dfl = pd.DataFrame(likert, columns=namesl)
+    bnl = [[namesl[i] for i in b] for b in blocksl]
+    g11["likert"] = likert
+    for tag, modes, mvs in (("ordA", "AAAA", {n: Scale.ORD for n in namesl}), ("ordB", "BBBB", {n: Scale.ORD for n in namesl}),
+                            ("mixM", "ABAB", {n: [Scale.ORD, Scale.NOM, Scale.NUM, Scale.RAW][i % 4] for i, n in enumerate(namesl)})):
+        for scheme in SCHEMES:
+            cfg = build_config(Cl, lvl, bnl, modes, True, default_scale=Scale.NUM, mv_scales=mvs)
+            _, out = run_fit(dfl, cfg, scheme, lvl, tol=1e-7)
+            for k, v in out.items():
+                if k != "mv_names":
+                    g11["likert_%s_%s/%s" % (tag, scheme, k)] = v
+    save("g11_ordnom", **g11)
     print("done in %.1f s" % (time.time() - t0))
 
 

@@ -272,3 +272,51 @@ def test_g10_metric_missing(modes, scheme, scaled):
     X = orc.filter_missing(g["data"], model)
     assert X.shape[0] == 249 and np.isnan(X).sum() >= 30
     _check_fit(orc.fit(X, model), g, key)
+
+
+# ------------------------------------------------------------------ ORD / NOM optimal scaling (scale.py:42-89)
+RUSSA_CAT_COLS = ["gnpr", "labo", "ecks", "death", "demo", "inst", "gini", "farm", "rent"]      # add_lv order IND, POLINS, AGRI
+RUSSA_CAT_BLOCKS = [np.array([6, 7, 8]), np.array([0, 1]), np.array([2, 3, 4, 5])]                # path order AGRI, IND, POLINS
+RUSSA_CAT_SCALES = ["ORD", "ORD", "NUM", "NUM", "NOM", "NUM", "NUM", "NUM", "NUM"]
+
+
+def russa_cat_inputs():
+    russa = pd.read_csv(os.path.join(GOLDEN, "ref_data", "russa.csv"), index_col=0)
+    return russa[RUSSA_CAT_COLS].values.astype(np.float64)
+
+
+@pytest.mark.parametrize("modes", ["AAA", "BBB"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_g11_russa_categorical(modes, scheme):
+    g = load("g11_ordnom")
+    key = "russa_%s_%s" % (modes, scheme)
+    assert list(g[key + "/mv_names"]) == RUSSA_CAT_COLS
+    model = orc.Model(RUSSA_CAT_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=RUSSA_CAT_SCALES)
+    _check_fit(orc.fit(russa_cat_inputs(), model), g, key)
+
+
+LIKERT_C = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 0, 0], [0, 1, 1, 0]])
+LIKERT_BLOCKS = [np.arange(4 * j, 4 * j + 4) for j in range(4)]
+LIKERT_CASES = {"ordA": ("AAAA", ["ORD"] * 16), "ordB": ("BBBB", ["ORD"] * 16),
+                "mixM": ("ABAB", [["ORD", "NOM", "NUM", "RAW"][i % 4] for i in range(16)])}
+
+
+@pytest.mark.parametrize("tag", ["ordA", "ordB", "mixM"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_g11_likert(tag, scheme):
+    g = load("g11_ordnom")
+    modes, scales = LIKERT_CASES[tag]
+    model = orc.Model(LIKERT_BLOCKS, LIKERT_C, modes, scheme, True, tol=1e-7, scales=scales)
+    _check_fit(orc.fit(g["likert"], model), g, "likert_%s_%s" % (tag, scheme))
+
+
+def test_reference_csv_russa_categorical():
+    """reference tests/test_regression_nonmetric.py:94-120 (R plspm output)."""
+    lv = ["AGRI", "IND", "POLINS"]
+    for modes, fname in (("AAA", "russa.categorical.inner_summary.csv"), ("BBB", "russa.categorical.mode_b.inner_summary.csv")):
+        model = orc.Model(RUSSA_CAT_BLOCKS, RUSSA_C, modes, "centroid", True, tol=1e-7, scales=RUSSA_CAT_SCALES)
+        r = orc.fit(russa_cat_inputs(), model)
+        summ = pd.read_csv(os.path.join(GOLDEN, "ref_data", fname), index_col=0)
+        assert_close(r["r2"], summ.loc[lv, "r_squared"].values, 1e-7, 1e-12)
+        comm = np.array([np.mean(r["loadings"][b] ** 2) for b in RUSSA_CAT_BLOCKS])
+        assert_close(comm, summ.loc[lv, "block_communality"].values, 1e-7)
