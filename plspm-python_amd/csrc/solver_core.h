@@ -292,9 +292,12 @@ PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {
 }
 
 // Inner weights E from G = cov0(Yhat) (scheme.py:27-28 / 36-37 / 45-54)
+// `Graw`: raw (uncentred) second moments of the scores for the PATH scheme's no-intercept OLS (scheme.py:50); null when the
+// scores are centred and the covariance ws.G serves both purposes.
 template <class Ex>
-PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) {
+PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2, const double* Graw = nullptr) {
     const int L = md.L;
+    const double* Gols = Graw ? Graw : ws.G;
     if (md.scheme == SCHEME_PATH) {
         ex.par(L, [&](int i) {
             for (int j = 0; j < L; ++j) ws.E[j * L + i] = 0.0;
@@ -304,7 +307,7 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
             const int k = md.pred_off[i + 1] - md.pred_off[i];
             if (k > 0) {
                 double* x = scratch + km * km;
-                if (!spd_solve(ws.G, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
+                if (!spd_solve(Gols, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
                 for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = x[r];
             }
             const double gii = ws.G[i * L + i];

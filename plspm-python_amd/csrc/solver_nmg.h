@@ -1,0 +1,339 @@
+// Non-metric solver with optimal scaling (Scale.ORD / Scale.NOM mixed with NUM / RAW) on second moments.
+//
+// Reference: _NonmetricWeights (plspm/weights.py:73-154), the Scale operators (plspm/scale.py:22-89: NUM, RAW, ORD with the
+// two-direction monotone pooling `_ordinalize`, NOM), the Mode-B correction get_Z_for_mode_b (weights.py:135-145), the
+// non-metric outer steps (mode.py:31-42, 54-61) and Config.treat's rank / dummy coding (config.py:314-318, util.py:80-95).
+//
+// Device columns ("aug columns", Q of them + a ones column): a NUM / RAW manifest variable is one column (its raw values);
+// an ORD / NOM manifest variable with C categories is C indicator columns (category codes in rank order).  Categorical
+// models are uploaded UNSHIFTED, so Mn = M / n holds raw second moments and Mn[.., Q] the column means.  Every quantified
+// manifest variable is an affine function of its own columns,  MV_p = sum_j tq_j col_j + tc_p,  every LV score an affine
+// function of its MVs,  y_l = sum_p a_p MV_p + kk_l;  group means of z by category, the pooled quantifications, the Mode-B
+// betas, outer weights and normalisations are all inner products through Mn.  As in the NUM / RAW solver (solver_core.h,
+// nm_*) only the score-based stop rule (weights.py:120) needs the observations: nm_conv_kernel evaluates it from the two
+// score maps over the aug columns that every step leaves in the NmState-compatible head of the state.
+//
+// State = [NmState layout for P := Q, n_chol := 0] ++ NmgExtra.  One cooperating group per problem; serial sections
+// (pooling over <= cmax categories, k x k block solves) run on thread 0.
+#pragma once
+#include "solver_core.h"
+
+namespace plspm {
+
+enum { KIND_NUM = 0, KIND_ORD = 1, KIND_NOM = 2 };
+
+struct CatDesc {
+    int Pm, cmax, kmv;          // logical MVs, max categories of an MV, max MVs of a block
+    const int* mv_off;          // [Pm+1] aug-column range of every MV
+    const int* mv_kind;         // [Pm]
+    const int* lmv_off;         // [L+1]  MV range of every LV (MVs are grouped by LV, path order)
+};
+
+struct NmgExtra {
+    double *tq, *tc;            // [Q], [Pm]   current quantification: MV_p = sum_j tq_j col_j + tc_p
+    double *akk;                // [L]         score constants kk_l of the CURRENT (old) scores
+    double *V, *MZ;             // [(Q+1)*L]   Mn . score-coefficients, Mn . z-coefficients (row Q: means)
+    double *YY;                 // [L*L]       raw second moments of the scores
+    double *mvm;                // [Pm*L + Pm] <MV_p, z_l> raw for the own LV (first Pm) + scratch
+    double *cm, *cf, *cs;       // [cmax] category means of z, category frequencies, chosen quantification
+    double *inc, *dec, *gsum, *gf;   // [cmax] pooled values of the two directions; pooling scratch (group sums / weights)
+    double *Bm, *Fm, *beta, *rhs;    // [kmv*kmv] block moment matrix and its Cholesky copy, [kmv], [kmv]
+    int* grp;                   // [cmax] (stored in a double-aligned slot)
+};
+PLSPM_HD long nmg_extra_doubles(int Q, int Pm, int L, int cmax, int kmv) {
+    return (long)Q + Pm + L + 2L * (Q + 1) * L + (long)L * L + ((long)Pm * L + Pm) + 7L * cmax + 2L * kmv * kmv + 2L * kmv + cmax + 8;
+}
+PLSPM_HD void nmg_carve(NmgExtra& x, double* base, int Q, int Pm, int L, int cmax, int kmv) {
+    double* p = base;
+    x.tq = p; p += Q; x.tc = p; p += Pm; x.akk = p; p += L;
+    x.V = p; p += (long)(Q + 1) * L; x.MZ = p; p += (long)(Q + 1) * L; x.YY = p; p += (long)L * L;
+    x.mvm = p; p += (long)Pm * L + Pm;
+    x.cm = p; p += cmax; x.cf = p; p += cmax; x.cs = p; p += cmax;
+    x.inc = p; p += cmax; x.dec = p; p += cmax; x.gsum = p; p += cmax; x.gf = p; p += cmax;
+    x.Bm = p; p += (long)kmv * kmv; x.Fm = p; p += (long)kmv * kmv; x.beta = p; p += kmv; x.rhs = p; p += kmv;
+    x.grp = reinterpret_cast<int*>(p);
+}
+PLSPM_HD long nmg_state_doubles(int Q, int Pm, int L, int cmax, int kmv) { return nm_state_doubles(Q, L, 0) + nmg_extra_doubles(Q, Pm, L, cmax, kmv); }
+
+// score map over the aug columns of coefficient set (a, kk) with the current quantification: c_j = a_mv(j) tq_j, k_l = kk_l + sum a_p tc_p
+template <class Ex>
+PLSPM_HD void nmg_score_map(Ex& ex, const ModelDesc& md, const CatDesc& cd, const NmgExtra& x, const double* a, const double* kk, double* c, double* k) {
+    ex.par(cd.Pm, [&](int p) { for (int j = cd.mv_off[p]; j < cd.mv_off[p + 1]; ++j) c[j] = a[p] * x.tq[j]; });
+    ex.par(md.L, [&](int l) {
+        double s = kk ? kk[l] : 0.0;
+        for (int p = cd.lmv_off[l]; p < cd.lmv_off[l + 1]; ++p) s += a[p] * x.tc[p];
+        k[l] = s;
+    });
+}
+
+// V[j,m] = <col_j, y_m> for j = 0..Q (row Q: mean of y_m), from the score map (c, k)
+template <class Ex>
+PLSPM_HD void nmg_apply(Ex& ex, const ModelDesc& md, const double* Mn, int LD, const double* c, const double* k, double* V) {
+    const int Q = md.P, L = md.L;
+    ex.par2(Q + 1, L, [&](int j, int m) {
+        double s = Mn[Q * LD + j] * k[m];                               // <col_j, 1> k_m   (Mn[Q][Q] = 1)
+        for (int q = md.boff[m]; q < md.boff[m + 1]; ++q) s += Mn[q * LD + j] * c[q];
+        V[j * L + m] = s;
+    });
+}
+
+// raw moment <MV_p, u> for a variable u given by its column moments Mu[j] = <col_j, u> and its mean
+PLSPM_HD double nmg_mv_moment(const CatDesc& cd, const NmgExtra& x, int p, const double* Mu, int stride, double mean_u) {
+    double s = x.tc[p] * mean_u;
+    for (int j = cd.mv_off[p]; j < cd.mv_off[p + 1]; ++j) s += x.tq[j] * Mu[j * stride];
+    return s;
+}
+// raw moment <MV_p, MV_q>
+PLSPM_HD double nmg_mv_mv(const CatDesc& cd, const NmgExtra& x, const double* Mn, int LD, int Q, int p, int q) {
+    double s = 0.0, mq = x.tc[q];
+    for (int j = cd.mv_off[q]; j < cd.mv_off[q + 1]; ++j) mq += x.tq[j] * Mn[Q * LD + j];          // mean of MV_q
+    for (int i = cd.mv_off[p]; i < cd.mv_off[p + 1]; ++i) {
+        double t = 0.0;
+        for (int j = cd.mv_off[q]; j < cd.mv_off[q + 1]; ++j) t += Mn[j * LD + i] * x.tq[j];
+        s += x.tq[i] * (t + Mn[Q * LD + i] * x.tc[q]);
+    }
+    return s + x.tc[p] * mq;
+}
+
+// scale.py:54-66 on (category mean, frequency) pairs: pool adjacent categories (first violation from the left, restart) until
+// the means are monotone for `sign`; out[c] = pooled value of category c; returns the population variance of the result.
+PLSPM_HD double nmg_ordinalize(const double* m, const double* f, int C, double sign, double* out, int* grp, double* gsum, double* gf) {
+    // groups are runs of categories; gsum / gf: weighted sum and weight per group (arrays of length C, in place of `out` scratch)
+    int ng = C;
+    for (int c = 0; c < C; ++c) { grp[c] = c; gsum[c] = m[c] * f[c]; gf[c] = f[c]; }
+    while (true) {
+        const int before = ng;
+        for (int g = 0; g + 1 < ng; ++g) {
+            const double a = gsum[g] / gf[g], b = gsum[g + 1] / gf[g + 1], d = a - b;
+            const double sg = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : 0.0);
+            if (sg == sign) {
+                gsum[g + 1] += gsum[g]; gf[g + 1] += gf[g];
+                for (int h = g; h + 1 < ng; ++h) { gsum[h] = gsum[h + 1]; gf[h] = gf[h + 1]; }
+                for (int c = 0; c < C; ++c) if (grp[c] > g) --grp[c];
+                --ng;
+                break;
+            }
+        }
+        if (ng == 1 || ng == before) break;
+    }
+    double mean = 0.0, ss = 0.0;
+    for (int c = 0; c < C; ++c) { const double v = gsum[grp[c]] / gf[grp[c]]; out[c] = v; mean += f[c] * v; ss += f[c] * v * v; }
+    return ss - mean * mean;
+}
+
+// packed scatter -> Mn (raw second moments / n, ones row/column = column means), initial quantification and scores (weights.py:82-98)
+template <class Ex>
+PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace& ws, NmState& st, NmgExtra& x, const double* Mp) {
+    const int Q = md.P, L = md.L, LD = ws.PS, T = md.T;
+    const int ntile = T * (T + 1) / 2;
+    ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
+        const int tile = chunk >> 2, r = chunk & 3;
+        int t, u;
+        if (md.tile_tu) { const int tu = md.tile_tu[tile]; t = tu & 255; u = tu >> 8; }
+        else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
+        const int p = 32 * (t >> 1) + (t & 1) + 8 * r + 2 * (lane >> 4);
+        const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
+        if ((t != u || p <= q) && p <= Q && q <= Q) { ws.S[q * LD + p] = m; ws.S[p * LD + q] = m; }
+    });
+    ex.one([&]() { st.scal[0] = ws.S[Q * LD + Q]; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
+    const double n = st.scal[0], inv_n = 1.0 / n;          // read through the state: the scaling below rewrites S[Q][Q]
+    ex.par(Q + 1, [&](int p) { for (int q = 0; q <= Q; ++q) ws.S[q * LD + p] *= inv_n; });
+    const double* Mn = ws.S;
+    // initial "treated" values (config.py:314-318): NUM / RAW population-standardised, ORD / NOM rank codes 1..C
+    ex.par(cd.Pm, [&](int p) {
+        const int j0 = cd.mv_off[p], C = cd.mv_off[p + 1] - j0;
+        if (cd.mv_kind[p] == KIND_NUM) {
+            const double mu = Mn[Q * LD + j0], sd = sqrt(Mn[j0 * LD + j0] - mu * mu);
+            x.tq[j0] = 1.0 / sd; x.tc[p] = -mu / sd;
+        } else {
+            for (int c = 0; c < C; ++c) x.tq[j0 + c] = (double)(c + 1);
+            x.tc[p] = 0.0;
+        }
+    });
+    ex.par(cd.Pm, [&](int p) {
+        int l = 0;
+        while (p >= cd.lmv_off[l + 1]) ++l;
+        st.a_old[p] = 1.0 / sqrt((double)(cd.lmv_off[l + 1] - cd.lmv_off[l]));
+        st.a_new[p] = st.a_old[p];
+    });
+    ex.par(L, [&](int l) { x.akk[l] = 0.0; });
+    nmg_score_map(ex, md, cd, x, st.a_old, x.akk, st.c_old, st.k_old);
+    nmg_score_map(ex, md, cd, x, st.a_new, x.akk, st.c_new, st.k_new);
+}
+
+// One iteration (weights.py:107-120).  Same protocol as nm_step: decide on the previous convergence value first.
+template <class Ex>
+PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace& ws, NmState& st, NmgExtra& x, const double* partial, int nparts) {
+    const int Q = md.P, L = md.L, LD = ws.PS, Pm = cd.Pm;
+    const double* Mn = ws.S;
+    if (st.scal[3] == 0.0) return false;
+    const int iteration = (int)st.scal[2];
+    if (iteration > 0) {
+        const double conv = ex.sum(nparts, [&](int c) { return partial[c]; });
+        const bool stop = (conv < md.tol) || (iteration > md.max_iter);
+        ex.one([&]() {
+            st.scal[4] = conv;
+            if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+        });
+        if (stop) return false;
+        ex.par(Pm, [&](int p) { st.a_old[p] = st.a_new[p]; });
+        ex.par(Q, [&](int j) { st.c_old[j] = st.c_new[j]; });
+        ex.par(L, [&](int l) { st.k_old[l] = st.k_new[l]; });
+    }
+    const double n = st.scal[0], corr2 = n / (n - 1.0);
+    // scores' moments: V = Mn . score maps, YY raw, means, covariance
+    nmg_apply(ex, md, Mn, LD, st.c_old, st.k_old, x.V);
+    ex.par(L * L, [&](int e) {
+        const int l = e / L, m = e - l * L;
+        double s = st.k_old[l] * x.V[Q * L + m];
+        for (int j = md.boff[l]; j < md.boff[l + 1]; ++j) s += st.c_old[j] * x.V[j * L + m];
+        x.YY[e] = s;
+    });
+    ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.G[e] = x.YY[e] - x.V[Q * L + l] * x.V[Q * L + m]; });
+    inner_weights(ex, md, ws, corr2, x.YY);
+    // MZ[j,l] = <col_j, z_l>, row Q = mean(z_l);  ws.a[l] = <z_l, z_l> raw
+    ex.par2(Q + 1, L, [&](int j, int l) {
+        double s = 0.0;
+        for (int m = 0; m < L; ++m) s += x.V[j * L + m] * ws.E[m * L + l];
+        x.MZ[j * L + l] = s;
+    });
+    ex.par(L, [&](int l) {
+        double s = 0.0;
+        for (int m = 0; m < L; ++m) {
+            const double em = ws.E[m * L + l];
+            if (em == 0.0) continue;
+            double t = 0.0;
+            for (int m2 = 0; m2 < L; ++m2) t += x.YY[m * L + m2] * ws.E[m2 * L + l];
+            s += em * t;
+        }
+        ws.a[l] = s;
+    });
+    // quantification, LV by LV, MV by MV (Gauss-Seidel inside a block, weights.py:112-115)
+    for (int l = 0; l < L; ++l) {
+        const int p0 = cd.lmv_off[l], p1 = cd.lmv_off[l + 1], k = p1 - p0;
+        const double mean_z = x.MZ[Q * L + l];
+        bool have_beta = false;
+        for (int p = p0; p < p1; ++p) {
+            const int kind = cd.mv_kind[p];
+            if (kind == KIND_NUM) continue;                                       // NUM / RAW: constant quantification
+            const int j0 = cd.mv_off[p], C = cd.mv_off[p + 1] - j0;
+            const bool modeb = (md.mode[l] == MODE_B) && (k > 1);
+            if (modeb && !have_beta) {
+                // betas of OLS(z ~ 1 + current block) = Cov_bb^-1 cov_bz, once per LV and iteration (weights.py:139-142)
+                ex.par(k * k, [&](int e) {
+                    const int r = e / k, c = e - r * k;
+                    if (r <= c) {
+                        const double v = nmg_mv_mv(cd, x, Mn, LD, Q, p0 + r, p0 + c);
+                        x.Bm[r * k + c] = v; x.Bm[c * k + r] = v;
+                    }
+                });
+                ex.par(k, [&](int r) { x.mvm[Pm * L + r] = nmg_mv_moment(cd, x, p0 + r, Mn + Q * LD, 1, 1.0); });       // means of the block MVs
+                ex.par(k, [&](int r) { x.rhs[r] = nmg_mv_moment(cd, x, p0 + r, x.MZ + l, L, mean_z) - x.mvm[Pm * L + r] * mean_z; });
+                ex.one([&]() {
+                    for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) x.Bm[r * k + c] -= x.mvm[Pm * L + r] * x.mvm[Pm * L + c];
+                    if (!chol_factor(x.Bm, k)) st.scal[1] = (double)ST_SINGULAR;
+                    for (int r = 0; r < k; ++r) x.beta[r] = x.rhs[r];
+                    chol_solve(x.Bm, k, x.beta);
+                });
+                have_beta = true;
+            }
+            // category means of (corrected) z: <D_c, zc> / <D_c, 1>
+            ex.par(C, [&](int c) {
+                const int j = j0 + c;
+                double s = x.MZ[j * L + l];
+                if (modeb) {
+                    for (int r = 0; r < k; ++r) {
+                        if (p0 + r == p) continue;
+                        // <D_c, MV_q> = sum_i tq_i Mn[j][i] + tc_q * mean(D_c)
+                        const int q = p0 + r;
+                        double t = x.tc[q] * Mn[Q * LD + j];
+                        for (int i = cd.mv_off[q]; i < cd.mv_off[q + 1]; ++i) t += x.tq[i] * Mn[i * LD + j];
+                        s -= x.beta[r] * t;
+                    }
+                    s /= x.beta[p - p0];
+                }
+                x.cf[c] = Mn[Q * LD + j];
+                x.cm[c] = s / x.cf[c];
+            });
+            ex.one([&]() {
+                double mean = 0.0, ss = 0.0;
+                if (kind == KIND_ORD) {
+                    const double v_inc = nmg_ordinalize(x.cm, x.cf, C, 1.0, x.inc, x.grp, x.gsum, x.gf);
+                    const double v_dec = nmg_ordinalize(x.cm, x.cf, C, -1.0, x.dec, x.grp, x.gsum, x.gf);
+                    if (v_inc < v_dec) { for (int c = 0; c < C; ++c) x.cs[c] = -x.dec[c]; }                       // -x_quant_decr (scale.py:74)
+                    else { for (int c = 0; c < C; ++c) x.cs[c] = x.inc[c]; }
+                } else {
+                    for (int c = 0; c < C; ++c) x.cs[c] = x.cm[c];                                                // NOM (scale.py:87)
+                }
+                for (int c = 0; c < C; ++c) { mean += x.cf[c] * x.cs[c]; ss += x.cf[c] * x.cs[c] * x.cs[c]; }
+                const double sd = sqrt(ss - mean * mean);                          // treat_numpy(.) * correction == population standardisation
+                for (int c = 0; c < C; ++c) x.tq[j0 + c] = (x.cs[c] - mean) / sd;
+                x.tc[p] = 0.0;
+            });
+        }
+        // outer weights of the block with the updated MVs (mode.py:38, 58), then Y = treat_numpy(X w) * correction (mode.py:41, 60)
+        ex.par(k, [&](int r) { x.mvm[p0 + r] = nmg_mv_moment(cd, x, p0 + r, x.MZ + l, L, mean_z); });
+        if (md.mode[l] == MODE_A) {
+            ex.par(k, [&](int r) { ws.wn[p0 + r] = x.mvm[p0 + r] / ws.a[l]; });
+            ex.par(k * k, [&](int e) {
+                const int r = e / k, c = e - r * k;
+                if (r <= c) { const double v = nmg_mv_mv(cd, x, Mn, LD, Q, p0 + r, p0 + c); x.Bm[r * k + c] = v; x.Bm[c * k + r] = v; }
+            });
+        } else {
+            ex.par(k * k, [&](int e) {
+                const int r = e / k, c = e - r * k;
+                if (r <= c) { const double v = nmg_mv_mv(cd, x, Mn, LD, Q, p0 + r, p0 + c); x.Bm[r * k + c] = v; x.Bm[c * k + r] = v; }
+            });
+            ex.one([&]() {
+                // lstsq(X_b, z) without intercept, on raw moments
+                for (int r = 0; r < k; ++r) x.rhs[r] = x.mvm[p0 + r];
+                for (int e = 0; e < k * k; ++e) x.Fm[e] = x.Bm[e];                 // Bm itself is needed for the normalisation below
+                if (!chol_factor(x.Fm, k)) st.scal[1] = (double)ST_SINGULAR;
+                chol_solve(x.Fm, k, x.rhs);
+                for (int r = 0; r < k; ++r) ws.wn[p0 + r] = x.rhs[r];
+            });
+        }
+        ex.one([&]() {
+            // variance of X_b w: w' Cov_b w (means of the block MVs removed: treat_numpy centres)
+            double q = 0.0, mw = 0.0;
+            for (int r = 0; r < k; ++r) {
+                double mr = x.tc[p0 + r];
+                for (int j = cd.mv_off[p0 + r]; j < cd.mv_off[p0 + r + 1]; ++j) mr += x.tq[j] * Mn[Q * LD + j];
+                mw += ws.wn[p0 + r] * mr;
+                for (int c = 0; c < k; ++c) q += ws.wn[p0 + r] * x.Bm[r * k + c] * ws.wn[p0 + c];
+            }
+            const double sd = sqrt(q - mw * mw);
+            for (int r = 0; r < k; ++r) st.a_new[p0 + r] = ws.wn[p0 + r] / sd;
+            x.akk[l] = -mw / sd;                                                   // constant of the NEW score (zero for centred MVs)
+        });
+    }
+    nmg_score_map(ex, md, cd, x, st.a_new, x.akk, st.c_new, st.k_new);
+    ex.one([&]() { st.scal[2] = (double)(iteration + 1); });
+    return true;
+}
+
+// Collapse to the MV level -- correlation matrix of the final quantified MVs, weights a_new -- and run the shared tail.
+// `mdm` is the MV-level descriptor (P = Pm, boff = lmv_off, ...); wsm its workspace (S: Pm x PSm).
+template <class Ex>
+PLSPM_HD void nmg_finish(Ex& ex, const ModelDesc& md, const CatDesc& cd, const ModelDesc& mdm, Workspace& ws, Workspace& wsm, NmState& st, NmgExtra& x,
+                         const FitOutputs& out) {
+    const int Q = md.P, LD = ws.PS, Pm = cd.Pm, PSm = wsm.PS;
+    const double* Mn = ws.S;
+    ex.par(Pm, [&](int p) { x.mvm[p] = nmg_mv_moment(cd, x, p, Mn + Q * LD, 1, 1.0); });                         // MV means
+    ex.par(Pm * Pm, [&](int e) {
+        const int p = e / Pm, q = e - p * Pm;
+        if (p <= q) {
+            const double v = nmg_mv_mv(cd, x, Mn, LD, Q, p, q) - x.mvm[p] * x.mvm[q];
+            wsm.S[q * PSm + p] = v; wsm.S[p * PSm + q] = v;
+        }
+    });
+    ex.par(Pm, [&](int p) { wsm.w[p] = st.a_new[p]; wsm.mu[p] = 0.0; wsm.cs[p] = 1.0; wsm.sd[p] = sqrt(wsm.S[p * PSm + p]); });
+    ex.one([&]() { wsm.scal[1] = st.scal[0]; wsm.scal[2] = 1.0 / st.scal[0]; wsm.scal[3] = st.scal[1]; });
+    FitOutputs o2 = out;
+    o2.score_w = nullptr; o2.score_c = nullptr; o2.mean = nullptr;          // the score map lives on the aug columns (below)
+    finish_problem(ex, mdm, wsm, o2, (int)st.scal[2], false);
+    if (out.score_w) ex.par(Q, [&](int j) { out.score_w[j] = st.c_new[j]; });
+    if (out.score_c) ex.par(md.L, [&](int l) { out.score_c[l] = st.k_new[l]; });
+}
+
+}  // namespace plspm

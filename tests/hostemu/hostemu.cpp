@@ -2,12 +2,14 @@
 // the same source the HIP kernel compiles, executed by NT std::threads with a std::barrier playing
 // __syncthreads().  Lets the CPU test-suite (and ThreadSanitizer) check the solver's algebra and its
 // barrier discipline against the oracle without a GPU.  Never loaded by the product package.
+#include <algorithm>
 #include <barrier>
 #include <cstring>
 #include <thread>
 #include <vector>
 
 #include "../../plspm-python_amd/csrc/solver_core.h"
+#include "../../plspm-python_amd/csrc/solver_nmg.h"
 
 using namespace plspm;
 
@@ -136,6 +138,52 @@ int hostemu_nm_finish(int P, int L, int PA, int scheme, int max_iter, double tol
         nm_finish(ex, em.md, ws, st, out);
     });
     return 0;
+}
+
+// ---- categorical (ORD / NOM) non-metric entry points.  boff: aug-column block offsets per LV; mv_off / mv_kind / lmv_off: CatDesc.
+struct EmuCat {
+    CatDesc cd{};
+    std::vector<int> mv_lv;
+    EmuCat(int Pm, int L, const int* mv_off, const int* mv_kind, const int* lmv_off) : mv_lv(Pm) {
+        cd.Pm = Pm; cd.mv_off = mv_off; cd.mv_kind = mv_kind; cd.lmv_off = lmv_off; cd.cmax = 1; cd.kmv = 1;
+        for (int p = 0; p < Pm; ++p) cd.cmax = std::max(cd.cmax, mv_off[p + 1] - mv_off[p]);
+        for (int l = 0; l < L; ++l) { cd.kmv = std::max(cd.kmv, lmv_off[l + 1] - lmv_off[l]); for (int p = lmv_off[l]; p < lmv_off[l + 1]; ++p) mv_lv[p] = l; }
+    }
+};
+long hostemu_nmg_state_doubles(int Q, int Pm, int L, const int* mv_off, const int* mv_kind, const int* lmv_off) {
+    EmuCat ec(Pm, L, mv_off, mv_kind, lmv_off);
+    return nmg_state_doubles(Q, Pm, L, ec.cd.cmax, ec.cd.kmv);
+}
+// mode: 0 prepare, 1 step (returns active), 2 finish
+int hostemu_nmg(int mode_op, int Q, int Pm, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode,
+                const int* mv_off, const int* mv_kind, const int* lmv_off, const double* Mp, int nthreads, double* S, double* state,
+                const double* partial, int nparts, int n_eff, const int* eff_from, const int* eff_to, double* row, double* crossloadings,
+                double* path_coef, double* score_w, double* score_c, double* cov, int* iters, int* status) {
+    std::vector<double> shift(Q, 0.0);
+    EmuModel em(Q, L, PA, scheme, 1, max_iter, tol, boff, C, mode, shift.data(), n_eff, eff_from, eff_to);
+    EmuCat ec(Pm, L, mv_off, mv_kind, lmv_off);
+    std::vector<double> shift_m(Pm, 0.0);
+    EmuModel emm(Pm, L, PA, scheme, 1, max_iter, tol, lmv_off, C, mode, shift_m.data(), n_eff, eff_from, eff_to);
+    emm.md.n_chol = 0;
+    std::vector<double> Sm((size_t)cov_doubles(Pm)), small_m(workspace_small_doubles(Pm, L, emm.md.kmax, 0));
+    int active = 0;
+    FitOutputs out{};
+    out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.score_w = score_w; out.score_c = score_c; out.cov = cov;
+    out.iters = iters; out.status = status;
+    em.md.n_chol = 0;
+    run_group(nthreads, Q, L, em.md, S, [&](HostExec& ex, Workspace& ws) {
+        NmState st; nm_carve(st, state, Q, L);
+        NmgExtra x; nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, Pm, L, ec.cd.cmax, ec.cd.kmv);
+        if (mode_op == 0) nmg_prepare(ex, em.md, ec.cd, ws, st, x, Mp);
+        else if (mode_op == 1) { const bool a = nmg_step(ex, em.md, ec.cd, ws, st, x, partial, nparts); if (ex.tid == 0) active = a ? 1 : 0; }
+        else {
+            Workspace wsm{};
+            wsm.S = Sm.data(); wsm.PS = cov_ld(Pm);
+            carve_small(wsm, small_m.data(), Pm, L, emm.md.kmax, 0);
+            nmg_finish(ex, em.md, ec.cd, emm.md, ws, wsm, st, x, out);
+        }
+    });
+    return active;
 }
 
 // Mp: packed scatter (see packed_index); everything else mirrors ModelDesc / FitOutputs.
