@@ -79,9 +79,26 @@ void plspm_model_destroy(plspm_model_t* m);
  * scale.py:22-39; `Config(default_scale=Scale.NUM)`): every MV is population-standardised (config.py:314), the stop rule is
  * sum (|Y_old| - |Y_new|)^2 over the LV scores (weights.py:120, evaluated by a streaming pass over the observations after
  * every iteration), weights are rescaled as weights.py:130-132 and there is no sign rule.  `scaled` of plspm_model_create is
- * ignored in this mode.  Scale.ORD / Scale.NOM are not supported.
+ * ignored in this mode.  Scale.ORD / Scale.NOM need plspm_model_set_categorical below.
  */
 int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on);
+
+/*
+ * Non-metric data with Scale.ORD / Scale.NOM MVs (optimal scaling: scale.py:41-56 with util.py rank / dummy / list_to_dummy,
+ * weights.py:96-118).  The handle's P device columns become AUGMENTED columns: a NUM / RAW MV keeps its one data column, an
+ * ORD / NOM MV is uploaded as its 0/1 indicator columns, one per category in ascending value order (what util.dummy builds
+ * per fit).  Pm logical MVs, grouped by LV in path order like the columns:
+ *   mv_off   [Pm+1] aug-column range of every MV (mv_off[0] = 0, mv_off[Pm] = P; a range never crosses an LV block)
+ *   mv_kind  [Pm]   PLSPM_MV_NUM (one column) / PLSPM_MV_ORD / PLSPM_MV_NOM
+ * Every per-MV output (weights, loadings, crossloadings, cov, bootstrap rows) then has Pm entries instead of P; the score
+ * map (scores = Xaug . score_w + score_c) stays on the aug columns.  `mean` is reported as zeros.  Implies set_nonmetric(1).
+ * Call before plspm_upload.  Bootstrap replicates that miss a category re-rank the present ones (rank of a resampled
+ * column, util.py rank).
+ */
+#define PLSPM_MV_NUM 0
+#define PLSPM_MV_ORD 1
+#define PLSPM_MV_NOM 2
+int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_off, const int32_t* mv_kind);
 
 /*
  * Upload the filtered raw observation matrix (what Config.filter returns, config.py:247-285; no NaNs).

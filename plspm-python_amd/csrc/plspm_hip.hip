@@ -19,6 +19,7 @@
 
 #include "../../include/plspm_hip.h"
 #include "solver_core.h"
+#include "solver_nmg.h"
 
 using namespace plspm;
 
@@ -773,12 +774,56 @@ __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __r
     }
 }
 
+
+// Categorical (Scale.ORD / NOM) non-metric problems (solver_nmg.h).  The aug-level moment matrix, the collapsed MV-level
+// correlation matrix and the iteration state live in global memory; both small workspaces and the aug-level descriptors in LDS.
+template <int MODE>
+__global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
+                                                  double* gS, double* gSm, double* gstate, long state_stride,
+                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    const int Q = md.P, L = md.L;
+    Workspace ws;
+    ws.PS = cov_ld(Q);
+    ws.S = gS + b * cov_doubles(Q);
+    carve_small(ws, lp, Q, L, md.kmax, 0);
+    lp += workspace_small_doubles(Q, L, md.kmax, 0);
+    Workspace wsm;
+    wsm.PS = cov_ld(cd.Pm);
+    wsm.S = gSm + b * cov_doubles(cd.Pm);
+    carve_small(wsm, lp, cd.Pm, L, md.kmax, 0);
+    lp += workspace_small_doubles(cd.Pm, L, md.kmax, 0);
+    double* state = gstate + b * state_stride;
+    NmState st;
+    nm_carve(st, state, Q, L);
+    NmgExtra x;
+    nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, cd.Pm, L, cd.cmax, cd.kmv);
+    if (MODE == 1 && st.scal[3] == 0.0) return;
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    if (MODE == 0) {
+        nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
+    } else if (MODE == 1) {
+        const bool active = nmg_step(ex, md, cd, ws, st, x, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
+    } else {
+        FitOutputs out = so.fit;
+        if (b != 0) out = FitOutputs{};
+        out.row = so.row ? so.row + b * so.row_stride : nullptr;
+        out.status = so.status ? so.status + b : nullptr;
+        out.iters = so.iters ? so.iters + b : nullptr;
+        nmg_finish(ex, md, cd, mdm, ws, wsm, st, x, out);
+    }
+}
+
 // Streaming convergence pass (reference weights.py:120): for every still-active problem, sum over its observations (all rows,
 // or the (row,count) list of a bootstrap replicate) of count * sum_l (|y_old| - |y_new|)^2, with y = xa . c + k for the two
 // score maps in the state.  16-row tiles of Xa are staged in LDS like scores_kernel; blockIdx.x = part, blockIdx.y = problem.
 __global__ void __launch_bounds__(256) nm_conv_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, int n_chol, const int* __restrict__ boff,
                                                        const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride,
-                                                       const double* __restrict__ gstate, double* __restrict__ partial) {
+                                                       const double* __restrict__ gstate, long state_stride, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* tile = reinterpret_cast<double*>(smem_raw);     // [16][PA+1]
     double* co = tile + SCORE_ROWS * (PA + 1);              // [P] c_old
@@ -790,7 +835,7 @@ __global__ void __launch_bounds__(256) nm_conv_kernel(const double* __restrict__
     int* bsh = reinterpret_cast<int*>(red + 256);           // [L+1]
     const long b = blockIdx.y;
     const int part = blockIdx.x, nparts = gridDim.x, tid = threadIdx.x;
-    const double* st = gstate + b * nm_state_doubles(P, L, n_chol);
+    const double* st = gstate + b * state_stride;       // NmState-compatible head: scal[8] a_old a_new c_old c_new k_old k_new
     if (st[3] == 0.0) return;
     for (int p = tid; p < P; p += 256) { co[p] = st[8 + 2 * P + p]; cn[p] = st[8 + 3 * P + p]; }
     for (int l = tid; l < L; l += 256) { ko[l] = st[8 + 4 * P + l]; kn[l] = st[8 + 4 * P + L + l]; }
@@ -978,6 +1023,11 @@ struct plspm_model {
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_io, sum_buf;
     int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
+    int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
+    int Pm = 0, cmax = 1, kmv = 1;
+    std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol;
+    int *d_mv_off = nullptr, *d_mv_kind = nullptr, *d_lmv_off = nullptr, *d_mv_lv = nullptr, *d_no_chol = nullptr;
+    Buf gSm;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
     bool profiling = false;
@@ -1132,7 +1182,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1146,7 +1196,7 @@ int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to) {
     for (int e = 0; e < m->n_eff; ++e) { if (from) from[e] = m->eff_from[e]; if (to) to[e] = m->eff_to[e]; }
     return m->n_eff;
 }
-int32_t plspm_row_width(const plspm_model_t* m) { return m ? 2 * m->P + m->L + 2 * m->n_eff : 0; }
+int32_t plspm_row_width(const plspm_model_t* m) { return m ? 2 * (m->categorical ? m->Pm : m->P) + m->L + 2 * m->n_eff : 0; }
 int32_t plspm_row_stride(const plspm_model_t* m) { return m ? plspm_row_width(m) + 2 : 0; }
 
 int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols, int32_t layout, const int32_t* col_index) {
@@ -1181,6 +1231,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
             hipLaunchKernelGGL(colsum_colmajor_kernel, dim3(nblk, m->P), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, m->P, d_partial);
         }
         hipLaunchKernelGGL(colmean_kernel, dim3((m->P + 63) / 64), dim3(64), 0, m->stream, d_partial, nblk, m->P, (long)N, m->d_shift);
+        if (m->categorical) hipMemsetAsync(m->d_shift, 0, sizeof(double) * m->P, m->stream);      // aug columns stay raw (solver_nmg.h)
         if (layout == 0) {
             const long total = (long)N * m->PA;
             const int grid = (int)std::min<long>(4096, (total + 255) / 256);
@@ -1277,37 +1328,53 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                          long ent_stride, int threads) {
     const int P = m->P, L = m->L;
     const long N = m->N;
+    const bool cat = m->categorical != 0;
     int rc;
     const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
-    const size_t st_doubles = (size_t)nm_state_doubles(P, L, m->n_chol);
-    const long rows_per_problem = ent ? N : N;                      // upper bound for the list length
-    const int nparts = (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (rows_per_problem + 1023) / 1024));
+    const size_t st_doubles = cat ? (size_t)nmg_state_doubles(P, m->Pm, L, m->cmax, m->kmv) : (size_t)nm_state_doubles(P, L, m->n_chol);
+    const int nparts = (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
+    if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
-    const size_t lds = (size_t)workspace_small_doubles(P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
+    size_t lds = (size_t)workspace_small_doubles(P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
+    if (cat) lds += (size_t)workspace_small_doubles(m->Pm, L, m->kmax, 0) * sizeof(double);
     if (lds > kMaxLds) return fail(m, PLSPM_E_LIMIT, "non-metric solver: workspace exceeds LDS");
-    if ((rc = allow_lds(m, (const void*)nm_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<2>, lds)))
+    if (cat) {
+        if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)))
+            return rc;
+    } else if ((rc = allow_lds(m, (const void*)nm_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<2>, lds)))
         return rc;
     const size_t conv_lds = ((size_t)SCORE_ROWS * (m->PA + 1) + 2 * (size_t)P + 2 * (size_t)L + SCORE_ROWS + 256) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
     if ((rc = allow_lds(m, (const void*)nm_conv_kernel, conv_lds))) return rc;
     const ModelDesc md = make_desc(m);
+    CatDesc cd{};
+    ModelDesc mdm = md;
+    if (cat) {
+        cd.Pm = m->Pm; cd.cmax = m->cmax; cd.kmv = m->kmv; cd.mv_off = m->d_mv_off; cd.mv_kind = m->d_mv_kind; cd.lmv_off = m->d_lmv_off;
+        mdm.P = m->Pm; mdm.boff = m->d_lmv_off; mdm.lvof = m->d_mv_lv; mdm.chol_off = m->d_no_chol; mdm.n_chol = 0;      // shift: zeros (upload)
+    }
     double* gS = (double*)m->gS.p;
+    double* gSm = (double*)m->gSm.p;
     double* gst = (double*)m->nmstate.p;
     double* part = (double*)m->nmpartial.p;
     int* nact = (int*)m->nmactive.p;
     const dim3 grid((unsigned)nproblems);
-    {
+    auto launch = [&](int mode_op) {
         ProfScope ps(m, PLSPM_K_SOLVER);
-        hipLaunchKernelGGL((nm_kernel<0>), grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
-    }
+        if (cat) {
+            auto k = mode_op == 0 ? nmg_kernel<0> : mode_op == 1 ? nmg_kernel<1> : nmg_kernel<2>;
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact);
+        } else {
+            auto k = mode_op == 0 ? nm_kernel<0> : mode_op == 1 ? nm_kernel<1> : nm_kernel<2>;
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
+        }
+    };
+    launch(0);
     for (int it = 0; it <= m->max_iter + 1; ++it) {
         HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
-        {
-            ProfScope ps(m, PLSPM_K_SOLVER);
-            hipLaunchKernelGGL((nm_kernel<1>), grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
-        }
+        launch(1);
         int h_active = 0;
         HIPCHK(m, hipMemcpyAsync(&h_active, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
         HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -1315,13 +1382,10 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
         {
             ProfScope ps(m, PLSPM_K_SCORES);
             hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, m->d_Xa, N, m->PA, P, L, m->n_chol, m->d_boff, ent,
-                               nent, ent_stride, (const double*)gst, part);
+                               nent, ent_stride, (const double*)gst, (long)st_doubles, part);
         }
     }
-    {
-        ProfScope ps(m, PLSPM_K_SOLVER);
-        hipLaunchKernelGGL((nm_kernel<2>), grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
-    }
+    launch(2);
     HIPCHK(m, hipGetLastError());
     return 0;
 }
@@ -1335,6 +1399,38 @@ int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on) {
 }
 
 void* plspm_stream(plspm_model_t* m) { return m ? (void*)m->stream : nullptr; }
+
+int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_off, const int32_t* mv_kind) {
+    if (!m || !mv_off || !mv_kind || Pm < m->L || Pm > m->P) return fail(m, PLSPM_E_ARG, "plspm_model_set_categorical: bad arguments");
+    if (m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_model_set_categorical: call before plspm_upload");
+    if (mv_off[0] != 0 || mv_off[Pm] != m->P) return fail(m, PLSPM_E_ARG, "mv_off must run from 0 to P");
+    m->mv_off.assign(mv_off, mv_off + Pm + 1);
+    m->mv_kind.assign(mv_kind, mv_kind + Pm);
+    m->lmv_off.assign(m->L + 1, 0);
+    m->mv_lv.assign(Pm, 0);
+    m->cmax = 1; m->kmv = 1;
+    int l = 0;
+    for (int p = 0; p < Pm; ++p) {
+        const int C = mv_off[p + 1] - mv_off[p];
+        if (C < 1 || mv_kind[p] < 0 || mv_kind[p] > 2 || (mv_kind[p] == 0 && C != 1)) return fail(m, PLSPM_E_ARG, "bad MV column range / kind");
+        while (l < m->L && mv_off[p] >= m->boff[l + 1]) ++l;
+        if (l >= m->L || mv_off[p + 1] > m->boff[l + 1]) return fail(m, PLSPM_E_ARG, "an MV's columns must lie inside one LV block");
+        m->mv_lv[p] = l;
+        m->lmv_off[l + 1] = p + 1;
+        m->cmax = std::max(m->cmax, C);
+    }
+    for (int k = 1; k <= m->L; ++k) { if (m->lmv_off[k] < m->lmv_off[k - 1]) m->lmv_off[k] = m->lmv_off[k - 1]; m->kmv = std::max(m->kmv, m->lmv_off[k] - m->lmv_off[k - 1]); }
+    for (int k = 0; k < m->L; ++k) if (m->lmv_off[k + 1] == m->lmv_off[k]) return fail(m, PLSPM_E_ARG, "every LV needs at least one MV");
+    m->no_chol.assign(m->L, -1);
+    HIPCHK(m, hipSetDevice(m->device));
+    if (upload_vec(m, &m->d_mv_off, m->mv_off) || upload_vec(m, &m->d_mv_kind, m->mv_kind) || upload_vec(m, &m->d_lmv_off, m->lmv_off) ||
+        upload_vec(m, &m->d_mv_lv, m->mv_lv) || upload_vec(m, &m->d_no_chol, m->no_chol))
+        return fail(m, PLSPM_E_STATE, "descriptor upload failed");
+    m->Pm = Pm; m->categorical = 1; m->nonmetric = 1; m->n_chol = 0;
+    for (auto& c : m->chol_off) c = -1;
+    HIPCHK(m, hipMemcpy(m->d_chol_off, m->chol_off.data(), sizeof(int) * m->L, hipMemcpyHostToDevice));
+    return 0;
+}
 
 int plspm_sync(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
@@ -1421,17 +1517,19 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     const double* h = (const double*)hs;
     const int* h_int = (const int*)(h + o_end);
     auto put = [&](void* dst, const void* src, size_t bytes) { if (dst) memcpy(dst, src, bytes); };
-    put(out->weights, h + o_w, sizeof(double) * P);
-    put(out->loadings, h + o_ld, sizeof(double) * P);
-    put(out->crossloadings, h + o_cl, sizeof(double) * P * L);
+    const int Po = m->categorical ? m->Pm : P;             // categorical handles report per logical MV, not per aug column
+    put(out->weights, h + o_w, sizeof(double) * Po);
+    put(out->loadings, h + o_ld, sizeof(double) * Po);
+    put(out->crossloadings, h + o_cl, sizeof(double) * Po * L);
     put(out->path_coef, h + o_pc, sizeof(double) * L * L);
     put(out->r2, h + o_r2, sizeof(double) * L);
     put(out->lv_cov, h + o_lc, sizeof(double) * L * L);
-    put(out->total, h + o_row + P + L, sizeof(double) * ne);
-    put(out->direct, h + o_row + P + L + ne, sizeof(double) * ne);
+    put(out->total, h + o_row + Po + L, sizeof(double) * ne);
+    put(out->direct, h + o_row + Po + L + ne, sizeof(double) * ne);
     put(out->indirect, h + o_ind, sizeof(double) * ne);
-    put(out->cov, h + o_cov, sizeof(double) * P * P);
-    put(out->mean, h + o_mean, sizeof(double) * P);
+    put(out->cov, h + o_cov, sizeof(double) * Po * Po);
+    if (m->categorical) { if (out->mean) memset(out->mean, 0, sizeof(double) * Po); }
+    else put(out->mean, h + o_mean, sizeof(double) * P);
     put(out->sign, h_int + 4, (size_t)L);
     put(out->iterations, h_int, sizeof(int));
     put(out->status, h_int + 1, sizeof(int));

@@ -146,7 +146,10 @@ PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Worksp
             const double mu = Mn[Q * LD + j0], sd = sqrt(Mn[j0 * LD + j0] - mu * mu);
             x.tq[j0] = 1.0 / sd; x.tc[p] = -mu / sd;
         } else {
-            for (int c = 0; c < C; ++c) x.tq[j0 + c] = (double)(c + 1);
+            // rank codes 1..C' over the categories PRESENT in this problem (a bootstrap replicate may miss some: util.rank ranks
+            // the values that occur, util.py:80-86); absent categories have an all-zero indicator column, any coefficient does
+            int code = 0;
+            for (int c = 0; c < C; ++c) { if (Mn[Q * LD + j0 + c] > 0.0) ++code; x.tq[j0 + c] = (double)code; }
             x.tc[p] = 0.0;
         }
     });
@@ -253,21 +256,28 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
                     s /= x.beta[p - p0];
                 }
                 x.cf[c] = Mn[Q * LD + j];
-                x.cm[c] = s / x.cf[c];
+                x.cm[c] = (x.cf[c] > 0.0) ? s / x.cf[c] : 0.0;
             });
             ex.one([&]() {
+                // compact to the categories present in this problem (frequency > 0), quantify, scatter back
+                int Cp = 0;
+                for (int c = 0; c < C; ++c) if (x.cf[c] > 0.0) { x.cm[Cp] = x.cm[c]; x.cf[Cp] = x.cf[c]; ++Cp; }
                 double mean = 0.0, ss = 0.0;
                 if (kind == KIND_ORD) {
-                    const double v_inc = nmg_ordinalize(x.cm, x.cf, C, 1.0, x.inc, x.grp, x.gsum, x.gf);
-                    const double v_dec = nmg_ordinalize(x.cm, x.cf, C, -1.0, x.dec, x.grp, x.gsum, x.gf);
-                    if (v_inc < v_dec) { for (int c = 0; c < C; ++c) x.cs[c] = -x.dec[c]; }                       // -x_quant_decr (scale.py:74)
-                    else { for (int c = 0; c < C; ++c) x.cs[c] = x.inc[c]; }
+                    const double v_inc = nmg_ordinalize(x.cm, x.cf, Cp, 1.0, x.inc, x.grp, x.gsum, x.gf);
+                    const double v_dec = nmg_ordinalize(x.cm, x.cf, Cp, -1.0, x.dec, x.grp, x.gsum, x.gf);
+                    if (v_inc < v_dec) { for (int c = 0; c < Cp; ++c) x.cs[c] = -x.dec[c]; }                      // -x_quant_decr (scale.py:74)
+                    else { for (int c = 0; c < Cp; ++c) x.cs[c] = x.inc[c]; }
                 } else {
-                    for (int c = 0; c < C; ++c) x.cs[c] = x.cm[c];                                                // NOM (scale.py:87)
+                    for (int c = 0; c < Cp; ++c) x.cs[c] = x.cm[c];                                               // NOM (scale.py:87)
                 }
-                for (int c = 0; c < C; ++c) { mean += x.cf[c] * x.cs[c]; ss += x.cf[c] * x.cs[c] * x.cs[c]; }
+                for (int c = 0; c < Cp; ++c) { mean += x.cf[c] * x.cs[c]; ss += x.cf[c] * x.cs[c] * x.cs[c]; }
                 const double sd = sqrt(ss - mean * mean);                          // treat_numpy(.) * correction == population standardisation
-                for (int c = 0; c < C; ++c) x.tq[j0 + c] = (x.cs[c] - mean) / sd;
+                int at = 0;
+                for (int c = 0; c < C; ++c) {
+                    if (Mn[Q * LD + j0 + c] > 0.0) { x.tq[j0 + c] = (x.cs[at] - mean) / sd; ++at; }
+                    else x.tq[j0 + c] = 0.0;
+                }
                 x.tc[p] = 0.0;
             });
         }

@@ -64,3 +64,34 @@ def compile_model(config, path: pd.DataFrame, data_cols) -> CompiledModel:
         raise ValueError("Path argument must be a strictly lower triangular matrix for the MI355X backend")
     modes = np.array([config.mode(lv).value.code for lv in lvs], dtype=np.int32)
     return CompiledModel(lvs, dev_mvs, data_cols, np.array(offsets, dtype=np.int32), col_index, inv, pmat, modes)
+
+
+KIND_NUM, KIND_ORD, KIND_NOM = 0, 1, 2
+
+
+def augment(compiled: CompiledModel, config, values: np.ndarray):
+    """Categorical (Scale.ORD / NOM) models: the device works on *augmented* columns (include/plspm_hip.h,
+    plspm_model_set_categorical).  A NUM / RAW MV keeps its data column; an ORD / NOM MV becomes one 0/1 indicator column per
+    distinct value in ascending order -- the dummy matrix of its rank codes, which the reference rebuilds inside every
+    quantification (scale.py:44,54 with util.py rank / dummy).  Returns (Xaug [N, Q] float64, aug block offsets [L+1],
+    mv_off [Pm+1], mv_kind [Pm])."""
+    from plspm.scale import Scale
+    kinds = {Scale.NUM: KIND_NUM, Scale.RAW: KIND_NUM, Scale.ORD: KIND_ORD, Scale.NOM: KIND_NOM}
+    n = values.shape[0]
+    cols, mv_off, mv_kind, boff = [], [0], [], [0]
+    for l, lv in enumerate(compiled.lvs):
+        for p in range(compiled.block_offset[l], compiled.block_offset[l + 1]):
+            kind = kinds[config.scale(compiled.dev_mvs[p])]
+            column = values[:, compiled.col_index[p]]
+            if kind == KIND_NUM:
+                cols.append(column.astype(np.float64)[:, None])
+            else:
+                _, codes = np.unique(column, return_inverse=True)
+                indicator = np.zeros((n, int(codes.max()) + 1))
+                indicator[np.arange(n), codes] = 1.0
+                cols.append(indicator)
+            mv_off.append(mv_off[-1] + cols[-1].shape[1])
+            mv_kind.append(kind)
+        boff.append(mv_off[-1])
+    return (np.ascontiguousarray(np.concatenate(cols, axis=1)), np.array(boff, dtype=np.int32), np.array(mv_off, dtype=np.int32),
+            np.array(mv_kind, dtype=np.int32))

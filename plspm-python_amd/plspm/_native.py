@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
-EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric",
+EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
@@ -51,6 +51,7 @@ def load():
     lib.plspm_model_destroy.restype = None
     lib.plspm_model_destroy.argtypes = [vp]
     lib.plspm_model_set_nonmetric.argtypes = [vp, i32]
+    lib.plspm_model_set_categorical.argtypes = [vp, i32, vp, vp]
     lib.plspm_upload.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.plspm_effect_pairs.restype = i32
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
@@ -95,7 +96,7 @@ def bootstrap_indices(seed, rep, n):
 class NativeModel:
     """One compiled model on one GPU (an opaque ``plspm_model_t*``)."""
 
-    def __init__(self, block_offset, path, modes, scheme, scaled, max_iter, tol, device_id=0, nonmetric=False):
+    def __init__(self, block_offset, path, modes, scheme, scaled, max_iter, tol, device_id=0, nonmetric=False, categorical=None):
         lib = load()
         if lib.plspm_device_count() <= 0:
             raise NativeBackendError("no HIP device visible: the MI355X backend has no CPU fallback")
@@ -111,6 +112,12 @@ class NativeModel:
             raise NativeBackendError("plspm_model_create: " + lib.plspm_last_error(None).decode())
         if nonmetric:
             self._check(lib.plspm_model_set_nonmetric(self._h, 1), "plspm_model_set_nonmetric")
+        self.P_out = self.P             # per-MV outputs: logical MVs (== device columns unless categorical)
+        if categorical is not None:     # (mv_off, mv_kind): device columns are indicator-augmented, see plspm_model_set_categorical
+            mv_off = np.ascontiguousarray(categorical[0], dtype=np.int32)
+            mv_kind = np.ascontiguousarray(categorical[1], dtype=np.int32)
+            self.P_out = len(mv_kind)
+            self._check(lib.plspm_model_set_categorical(self._h, self.P_out, _ptr(mv_off), _ptr(mv_kind)), "plspm_model_set_categorical")
         self.n_eff = lib.plspm_effect_pairs(self._h, None, None)
         ef = np.zeros(max(self.n_eff, 1), dtype=np.int32)
         et = np.zeros(max(self.n_eff, 1), dtype=np.int32)
@@ -151,7 +158,7 @@ class NativeModel:
         self.N = X.shape[0]
 
     def fit(self, want_scores=True, want_cov=False):
-        P, L, ne = self.P, self.L, self.n_eff
+        P, L, ne = self.P_out, self.L, self.n_eff
         out = dict(weights=np.empty(P), loadings=np.empty(P), crossloadings=np.empty((P, L)), path_coef=np.empty((L, L)), r2=np.empty(L),
                    lv_cov=np.empty((L, L)), total=np.empty(ne), direct=np.empty(ne), indirect=np.empty(ne),
                    scores=np.empty((self.N, L)) if want_scores else None, cov=np.empty((P, P)) if want_cov else None, mean=np.empty(P),

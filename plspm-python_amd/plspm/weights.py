@@ -11,7 +11,7 @@ import numpy as np
 import pandas as pd
 
 from plspm import _native
-from plspm._compile import compile_model
+from plspm._compile import augment, compile_model
 from plspm.scale import Scale
 from plspm.scheme import Scheme
 
@@ -64,14 +64,12 @@ class WeightsCalculatorFactory:
         return self._scheme
 
     def _nonmetric(self):
-        """True for Scale.NUM / Scale.RAW models (device non-metric solver); ORD / NOM are not built yet."""
+        """0 metric, 1 Scale.NUM / RAW only (correlation-matrix solver), 2 Scale.ORD / NOM present (categorical solver)."""
         if self._config.metric():
-            return False
+            return 0
         self._config.promote_scales()
         kinds = set(self._config.all_scales())
-        if not kinds.issubset({Scale.NUM, Scale.RAW}):
-            raise NotImplementedError("Scale.ORD / Scale.NOM (optimal scaling) are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
-        return True
+        return 1 if kinds.issubset({Scale.NUM, Scale.RAW}) else 2
 
     def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False) -> SolverResult:
         """Compile, upload ``data`` (raw or treated) and run one device fit.  Raises the reference's
@@ -82,10 +80,16 @@ class WeightsCalculatorFactory:
         if abs(self._correction - expected) > 1e-12 * expected:
             raise ValueError("correction must be sqrt(N / (N - 1)) of the data handed to the solver")
         compiled = compile_model(self._config, path, list(data.columns))
-        native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
-                                     self._iterations, self._tolerance, self._device_id, nonmetric=nonmetric)
         values = data.values
-        native.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled.col_index)
+        if nonmetric == 2:
+            xaug, aug_offset, mv_off, mv_kind = augment(compiled, self._config, values)
+            native = _native.NativeModel(aug_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled, self._iterations,
+                                         self._tolerance, self._device_id, nonmetric=True, categorical=(mv_off, mv_kind))
+            native.upload(xaug)
+        else:
+            native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
+                                         self._iterations, self._tolerance, self._device_id, nonmetric=bool(nonmetric))
+            native.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled.col_index)
         raw = native.fit(want_scores=want_scores, want_cov=want_cov)
         if raw["status"] == _native.STATUS_NOT_CONVERGED:
             raise ConvergenceError("Could not converge after " + str(raw["iterations"]) + " iterations")

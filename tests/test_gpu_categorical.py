@@ -1,0 +1,179 @@
+"""GPU parity of the categorical (Scale.ORD / NOM, optimal scaling) non-metric path -- SURVEY.md 8(f) rank 4 -- through the
+C-ABI (plspm_model_set_categorical) and through the host API, against the oracle (pinned on the reference, golden g11) and the
+reference's own expected CSVs (tests/test_regression_nonmetric.py:94-120).  Tolerance: 1e-6 relative (north_star), scores 1e-7."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import plspm_oracle as orc
+from helpers import GOLDEN, assert_close, load
+from test_oracle_golden import (LIKERT_BLOCKS, LIKERT_C, LIKERT_CASES, RUSSA_C, RUSSA_CAT_BLOCKS, RUSSA_CAT_COLS, RUSSA_CAT_SCALES,
+                                russa_cat_inputs)
+from test_solver_hostemu_ordnom import build_aug
+
+pytestmark = pytest.mark.gpu
+SCHEME_ID = {"centroid": 0, "factorial": 1, "path": 2}
+RTOL, ATOL = 1e-6, 1e-9
+
+
+def gpu_fit_cat(X, model):
+    from plspm import _native
+    Xaug, mv_off, mv_kind, lmv_off, boff, mv_data_col = build_aug(X, model)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], True, model.max_iter, model.tol, 0, nonmetric=True,
+                             categorical=(mv_off, mv_kind))
+    nm.upload(Xaug)
+    out = nm.fit(want_scores=True, want_cov=True)
+    Pm = len(mv_kind)
+    inv = np.empty(Pm, dtype=np.int64); inv[mv_data_col] = np.arange(Pm)
+    out["inv"] = inv
+    out["weights_d"] = out["weights"][inv]; out["loadings_d"] = out["loadings"][inv]; out["crossloadings_d"] = out["crossloadings"][inv]
+    out["pairs"] = list(zip(nm.eff_from.tolist(), nm.eff_to.tolist()))
+    return nm, out
+
+
+def check_fit(g, r, tag=""):
+    assert g["status"] == 0, tag
+    assert g["iterations"] == r["iterations"], "%s: iterations %d vs oracle %d" % (tag, g["iterations"], r["iterations"])
+    assert_close(g["weights_d"], r["weights"], RTOL, what=tag + " weights")
+    assert_close(g["loadings_d"], r["loadings"], RTOL, what=tag + " loadings")
+    assert_close(g["crossloadings_d"], r["crossloadings"], RTOL, ATOL)
+    assert_close(g["path_coef"], r["path_coef"], RTOL, ATOL)
+    assert_close(g["r2"], r["r2"], RTOL, ATOL)
+    assert g["pairs"] == r["effect_pairs"]
+    assert_close(g["total"], r["total"], RTOL, ATOL)
+    assert_close(g["direct"], r["direct"], RTOL, ATOL)
+    assert_close(g["scores"], r["scores"], 1e-7, 1e-9, what=tag + " scores")
+
+
+@pytest.mark.parametrize("modes", ["AAA", "BBB"])
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+def test_russa_categorical_vs_oracle_and_reference_golden(modes, scheme):
+    X = russa_cat_inputs()
+    model = orc.Model(RUSSA_CAT_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=RUSSA_CAT_SCALES)
+    _, g = gpu_fit_cat(X, model)
+    check_fit(g, orc.fit(X, model), modes + "/" + scheme)
+    gold = load("g11_ordnom")
+    key = "russa_%s_%s" % (modes, scheme)
+    assert g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights_d"], gold[key + "/weights"], RTOL)
+    assert_close(g["loadings_d"], gold[key + "/loadings"], RTOL)
+    assert_close(g["r2"], gold[key + "/r2"], RTOL, ATOL)
+    assert_close(g["scores"], gold[key + "/scores"], 1e-7, 1e-9)
+
+
+@pytest.mark.parametrize("tag", ["ordA", "ordB", "mixM"])
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+def test_likert_vs_oracle_and_reference_golden(tag, scheme):
+    gold = load("g11_ordnom")
+    modes, scales = LIKERT_CASES[tag]
+    model = orc.Model(LIKERT_BLOCKS, LIKERT_C, modes, scheme, True, tol=1e-7, scales=scales)
+    _, g = gpu_fit_cat(gold["likert"], model)
+    check_fit(g, orc.fit(gold["likert"], model), tag + "/" + scheme)
+    key = "likert_%s_%s" % (tag, scheme)
+    assert g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights_d"], gold[key + "/weights"], RTOL)
+    assert_close(g["path_coef"], gold[key + "/path_coef"], RTOL, ATOL)
+
+
+def _rows_in_data_order(rows, inv, Pm, L, ne):
+    return np.concatenate((rows[:, :Pm][:, inv], rows[:, Pm:Pm + L + 2 * ne], rows[:, Pm + L + 2 * ne:][:, inv]), axis=1)
+
+
+@pytest.mark.parametrize("modes,scheme", [("AAA", "centroid"), ("BBB", "path")])
+def test_bootstrap_explicit_indices_with_absent_categories(modes, scheme):
+    """N = 47 resamples regularly lose a category of `demo` / `gnpr`: the device re-ranks the present categories like util.rank
+    on the resampled column.  Replicates the oracle cannot finish (singular / not converged) must be flagged, not reported."""
+    X = russa_cat_inputs()
+    model = orc.Model(RUSSA_CAT_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=RUSSA_CAT_SCALES)
+    nm, g = gpu_fit_cat(X, model)
+    rs = np.random.RandomState(31)
+    idx = rs.randint(47, size=(24, 47)).astype(np.int32)
+    rows, status, iters = nm.bootstrap(24, idx=idx)
+    rows = _rows_in_data_order(rows, g["inv"], 9, 3, nm.n_eff)
+    corr = orc.correction(47)
+    compared = 0
+    for b in range(24):
+        try:
+            mine, its = orc.bootstrap_replicate(X, model, idx[b], corr)
+        except Exception:
+            assert status[b] != 0
+            continue
+        if not np.all(np.isfinite(mine)):
+            continue
+        assert status[b] == 0 and its == iters[b], "replicate %d: %d/%d vs %d" % (b, status[b], iters[b], its)
+        assert_close(rows[b], mine, RTOL, 1e-8, what="replicate %d" % b)
+        compared += 1
+    assert compared >= 12
+
+
+def test_bootstrap_device_resampling_likert_spot_checks():
+    from plspm import _native
+    gold = load("g11_ordnom")
+    modes, scales = LIKERT_CASES["mixM"]
+    model = orc.Model(LIKERT_BLOCKS, LIKERT_C, modes, "path", True, tol=1e-7, scales=scales)
+    X = gold["likert"]
+    nm, g = gpu_fit_cat(X, model)
+    rows, status, iters = nm.bootstrap(200, seed=9)
+    assert np.all(status == 0)
+    rows = _rows_in_data_order(rows, g["inv"], 16, 4, nm.n_eff)
+    corr = orc.correction(X.shape[0])
+    for r in (0, 77, 199):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(9, r, X.shape[0]), corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+    # sharding invariance: replicate ids, not call boundaries, key the streams
+    again, st2, _ = nm.bootstrap(50, seed=9, rep_offset=150)
+    assert np.array_equal(_rows_in_data_order(again, g["inv"], 16, 4, nm.n_eff), rows[150:])
+
+
+def _russa_config(mode):
+    import plspm.config as c
+    from plspm.scale import Scale
+    s = c.Structure(); s.add_path(["AGRI", "IND"], ["POLINS"])
+    config = c.Config(s.path(), default_scale=Scale.NUM)
+    config.add_lv("AGRI", mode, c.MV("gini"), c.MV("farm"), c.MV("rent"))
+    config.add_lv("IND", mode, c.MV("gnpr", Scale.ORD), c.MV("labo", Scale.ORD))
+    config.add_lv("POLINS", mode, c.MV("ecks"), c.MV("death"), c.MV("demo", Scale.NOM), c.MV("inst"))
+    return config
+
+
+@pytest.mark.parametrize("mode_name,fname", [("A", "russa.categorical.inner_summary.csv"), ("B", "russa.categorical.mode_b.inner_summary.csv")])
+def test_api_reproduces_reference_russa_categorical_tests(mode_name, fname):
+    """Mirrors reference tests/test_regression_nonmetric.py:94-120 (expected values: R plspm)."""
+    import plspm.util as util
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    ref = os.path.join(GOLDEN, "ref_data")
+    russa = pd.read_csv(os.path.join(ref, "russa.csv"), index_col=0)
+    calc = Plspm(russa, _russa_config(Mode.A if mode_name == "A" else Mode.B), Scheme.CENTROID, 100, 0.0000001)
+    expected = pd.read_csv(os.path.join(ref, fname), index_col=0)
+    np.testing.assert_allclose(util.sort_cols(expected.drop(["type"], axis=1)).sort_index(),
+                               util.sort_cols(calc.inner_summary().drop(["type", "r_squared_adj"], axis=1)).sort_index().astype(float))
+    pd.testing.assert_series_equal(expected.loc[:, "type"].sort_index(), calc.inner_summary().loc[:, "type"].sort_index())
+    # the frames carry the logical MVs (not the indicator columns)
+    assert sorted(calc.outer_model().index) == sorted(RUSSA_CAT_COLS)
+    assert calc.crossloadings().shape == (9, 3) and calc.scores().shape == (47, 3)
+    gold = load("g11_ordnom")
+    key = "russa_%s_centroid" % (mode_name * 3)
+    om = calc.outer_model().loc[RUSSA_CAT_COLS]
+    assert_close(om["weight"].values, gold[key + "/weights"], RTOL)
+    assert_close(om["loading"].values, gold[key + "/loadings"], RTOL)
+
+
+def test_api_bootstrap_categorical():
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    russa = pd.read_csv(os.path.join(GOLDEN, "ref_data", "russa.csv"), index_col=0)
+    calc = Plspm(russa, _russa_config(Mode.A), Scheme.CENTROID, 100, 0.0000001, bootstrap=True, bootstrap_iterations=200, seed=3)
+    boot = calc.bootstrap()
+    w = boot.weights()
+    assert sorted(w.index) == sorted(RUSSA_CAT_COLS)
+    assert np.all(np.isfinite(w[["original", "mean", "std.error"]].values))
+    om = calc.outer_model()
+    assert_close(w.loc[om.index, "original"].values, om["weight"].values, 1e-12)
+    assert boot.paths().shape[0] == 2 and boot.r_squared().shape[0] == 1

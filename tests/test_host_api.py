@@ -223,10 +223,14 @@ def test_unsupported_paths_raise_not_implemented():
     from plspm.plspm import Plspm
     sat = satisfaction_frame()
     s = c.Structure(); s.add_path(["IMAG"], ["EXPE"])
-    cfg = c.Config(s.path(), default_scale=Scale.ORD)                 # optimal scaling (ORD / NOM) is not built
+    cfg = c.Config(s.path(), default_scale=Scale.ORD)                 # optimal scaling runs on the device: no CPU fallback
     cfg.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); cfg.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
-    with pytest.raises(NotImplementedError):
+    from plspm._native import NativeBackendError
+    with pytest.raises(NativeBackendError):
         Plspm(sat, cfg)
+    miss = sat.copy(); miss.iloc[0, 0] = np.nan                       # NaN-aware non-metric products are not built
+    with pytest.raises(NotImplementedError):
+        Plspm(miss, cfg)
     hoc = c.Config(s.path())                                          # metric HOC: the reference cannot run it either
     hoc.add_higher_order("EXPE", Mode.A, ["A", "B"])
     hoc.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); hoc.add_lv_with_columns_named("A", Mode.A, sat, "expe")

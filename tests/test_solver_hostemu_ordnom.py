@@ -125,3 +125,30 @@ def test_all_numeric_model_agrees_with_the_num_solver_path(emu):
     X = russa_inputs()
     model = orc.Model(RUSSA_BLOCKS, RUSSA_C, "ABA", "path", True, tol=1e-7, scales=["NUM"] * 9)
     check(run_cat_emu(emu, X, model), orc.fit(X, model))
+
+
+@pytest.mark.parametrize("modes,scheme", [("AAA", "centroid"), ("BBB", "path")])
+def test_categorical_bootstrap_counts_with_absent_categories(emu, modes, scheme):
+    """A resample misses categories: their indicator columns are all-zero, rank codes are taken over the present ones
+    (util.rank on the resampled column) -- weighted moments must reproduce the oracle run on data[idx]."""
+    X = russa_cat_inputs()
+    model = orc.Model(RUSSA_CAT_BLOCKS, RUSSA_C, modes, scheme, True, tol=1e-7, scales=RUSSA_CAT_SCALES)
+    rs = np.random.RandomState(31)
+    corr = orc.correction(47)
+    done = 0
+    for _ in range(12):
+        idx = rs.randint(47, size=47)
+        try:
+            mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        except Exception:
+            continue
+        if not np.all(np.isfinite(mine)):
+            continue
+        e = run_cat_emu(emu, X, model, counts=np.bincount(idx, minlength=47))
+        assert e["status"] == 0 and e["iterations"] == its
+        got = np.concatenate((e["weights"], e["r2"], e["total"]))
+        ne = len(e["total"])
+        assert_close(got, np.concatenate((mine[:9], mine[9:12], mine[12:12 + ne])), 1e-8, 1e-11)
+        assert_close(e["loadings"], mine[-9:], 1e-8, 1e-11)
+        done += 1
+    assert done >= 6
