@@ -101,6 +101,18 @@ int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on);
 int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_off, const int32_t* mv_kind);
 
 /*
+ * Metric data with missing values (reference util.impute, plspm/util.py:61-68, applied by Config.treat, config.py:300 -- to
+ * the full data for the fit and to every RESAMPLED data set in the bootstrap, bootstrap.py:57): n_ind of the P data columns
+ * have NaNs.  The caller uploads P + n_ind columns: the data columns with every NaN replaced by that column's mean over its
+ * present values, then one 0/1 column per incomplete data column marking its NaN cells.
+ *   ind_of  [P]  upload column (in [P, P + n_ind)) of the indicator of data column p, or -1 when p is complete
+ * The fit then sees the mean-imputed data; every bootstrap replicate is re-imputed with its own column means, on the moments
+ * (solver_core.h impute_collapse) -- no per-replicate pass over the data.  A replicate in which some column lost all its
+ * present cells reports PLSPM_NONFINITE.  Metric handles only; call before plspm_upload.  Limit: P + n_ind <= 1022.
+ */
+int plspm_model_set_missing(plspm_model_t* m, int32_t n_ind, const int32_t* ind_of);
+
+/*
  * Upload the filtered raw observation matrix (what Config.filter returns, config.py:247-285; no NaNs).
  *   X          host pointer, dense fp64, src_cols columns x N rows
  *   layout     0: row-major (element (i,c) at X[i*src_cols + c]);  1: column-major (X[c*N + i])

@@ -738,6 +738,17 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
 }
 
 
+// Metric data with missing values: per problem, the Gram of [data | missing indicators | 1] -> mean-imputed moments of the P
+// data columns (solver_core.h impute_collapse).  One workgroup per problem.
+__global__ void __launch_bounds__(256) impute_kernel(int P, int Qa, int Ta, int Ts, const int* __restrict__ ind_of, const double* __restrict__ Min, long in_stride,
+                                                     double* __restrict__ Mout, long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* gam = reinterpret_cast<double*>(smem_raw);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    impute_collapse(ex, P, Qa, Ta, Ts, ind_of, Min + blockIdx.x * in_stride, Mout + blockIdx.x * out_stride, gam);
+}
+
+
 #define SCORE_ROWS 16
 // ------------------------------------------------------------------------------------------------ non-metric (NUM / RAW) kernels
 // The correlation matrix R and the iteration state of every problem live in global memory between launches (gS / gstate); the
@@ -1028,6 +1039,12 @@ struct plspm_model {
     std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol;
     int *d_mv_off = nullptr, *d_mv_kind = nullptr, *d_lmv_off = nullptr, *d_mv_lv = nullptr, *d_no_chol = nullptr;
     Buf gSm;
+    // metric data with missing values: Pg = P + n_ind device columns (data | missing indicators); PA / T describe the Gram of
+    // those, PAs / Ts the P-column moment matrix the solver reads (impute_collapse maps one to the other).  Pg == P otherwise.
+    int Pg = 0, PAs = 0, Ts = 0, n_ind = 0;
+    std::vector<int> ind_of;
+    int* d_ind_of = nullptr;
+    Buf gram2;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
     bool profiling = false;
@@ -1086,7 +1103,7 @@ static void prof_collect(plspm_model* m) {
 
 static ModelDesc make_desc(const plspm_model* m) {
     ModelDesc md{};
-    md.P = m->P; md.L = m->L; md.PA = m->PA; md.T = m->T; md.scheme = m->scheme; md.scaled = m->scaled; md.max_iter = m->max_iter;
+    md.P = m->P; md.L = m->L; md.PA = m->PAs; md.T = m->Ts; md.scheme = m->scheme; md.scaled = m->scaled; md.max_iter = m->max_iter;
     md.kmax = m->kmax; md.n_eff = m->n_eff; md.n_chol = m->n_chol; md.tol = m->tol;
     md.boff = m->d_boff; md.lvof = m->d_lvof; md.C = m->d_C; md.mode = m->d_mode; md.chol_off = m->d_chol_off;
     md.eff_from = m->d_eff_from; md.eff_to = m->d_eff_to; md.shift = m->d_shift;
@@ -1138,6 +1155,7 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
     if (!m) { fail(nullptr, PLSPM_E_STATE, "out of host memory"); return nullptr; }
     m->device = device_id; m->P = P; m->L = L; m->scheme = scheme; m->scaled = scaled ? 1 : 0; m->max_iter = max_iter; m->tol = tol;
     m->PA = ((P + 1 + 31) / 32) * 32; m->T = m->PA / 16;
+    m->Pg = P; m->PAs = m->PA; m->Ts = m->T;
     m->boff.assign(block_offset, block_offset + L + 1);
     m->mode.assign(mode, mode + L);
     m->C.assign(path, path + (size_t)L * L);
@@ -1182,7 +1200,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1203,8 +1221,9 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     if (!m) return PLSPM_E_ARG;
     if (!X || N < 2 || src_cols < 1 || (layout != 0 && layout != 1)) return fail(m, PLSPM_E_ARG, "plspm_upload: bad arguments");
     if (N > 0x7fffffffLL - 64) return fail(m, PLSPM_E_LIMIT, "plspm_upload: N must fit in int32");
-    std::vector<int> ci(m->P);
-    for (int p = 0; p < m->P; ++p) {
+    const int Pg = m->Pg;                  // data columns (+ missing-indicator columns, plspm_model_set_missing)
+    std::vector<int> ci(Pg);
+    for (int p = 0; p < Pg; ++p) {
         ci[p] = col_index ? col_index[p] : p;
         if (ci[p] < 0 || ci[p] >= src_cols) return fail(m, PLSPM_E_ARG, "plspm_upload: col_index out of range");
     }
@@ -1217,27 +1236,28 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     auto cleanup = [&]() { if (d_raw) hipFree(d_raw); if (d_ci) hipFree(d_ci); if (d_partial) hipFree(d_partial); };
 #define UPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(m, -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
     UPCHK(hipMalloc((void**)&d_raw, raw_bytes));
-    UPCHK(hipMalloc((void**)&d_ci, sizeof(int) * m->P));
+    UPCHK(hipMalloc((void**)&d_ci, sizeof(int) * Pg));
     UPCHK(hipMalloc((void**)&m->d_Xa, (size_t)N * m->PA * sizeof(double)));
     UPCHK(hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
-    UPCHK(hipMemcpyAsync(d_ci, ci.data(), sizeof(int) * m->P, hipMemcpyHostToDevice, m->stream));
+    UPCHK(hipMemcpyAsync(d_ci, ci.data(), sizeof(int) * Pg, hipMemcpyHostToDevice, m->stream));
     const int nblk = (int)std::min<int64_t>(1024, (N + 255) / 256);
-    UPCHK(hipMalloc((void**)&d_partial, sizeof(double) * (size_t)nblk * m->P));
+    UPCHK(hipMalloc((void**)&d_partial, sizeof(double) * (size_t)nblk * Pg));
     {
         ProfScope ps(m, PLSPM_K_PACK);
         if (layout == 0) {
-            hipLaunchKernelGGL(colsum_rowmajor_kernel, dim3(nblk), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, m->P, d_partial);
+            hipLaunchKernelGGL(colsum_rowmajor_kernel, dim3(nblk), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, Pg, d_partial);
         } else {
-            hipLaunchKernelGGL(colsum_colmajor_kernel, dim3(nblk, m->P), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, m->P, d_partial);
+            hipLaunchKernelGGL(colsum_colmajor_kernel, dim3(nblk, Pg), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, Pg, d_partial);
         }
-        hipLaunchKernelGGL(colmean_kernel, dim3((m->P + 63) / 64), dim3(64), 0, m->stream, d_partial, nblk, m->P, (long)N, m->d_shift);
-        if (m->categorical) hipMemsetAsync(m->d_shift, 0, sizeof(double) * m->P, m->stream);      // aug columns stay raw (solver_nmg.h)
+        hipLaunchKernelGGL(colmean_kernel, dim3((Pg + 63) / 64), dim3(64), 0, m->stream, d_partial, nblk, Pg, (long)N, m->d_shift);
+        if (m->categorical) hipMemsetAsync(m->d_shift, 0, sizeof(double) * Pg, m->stream);         // aug columns stay raw (solver_nmg.h)
+        if (m->n_ind) hipMemsetAsync(m->d_shift + m->P, 0, sizeof(double) * m->n_ind, m->stream);   // so do the 0/1 missing indicators
         if (layout == 0) {
             const long total = (long)N * m->PA;
             const int grid = (int)std::min<long>(4096, (total + 255) / 256);
-            hipLaunchKernelGGL(pack_rowmajor_kernel, dim3(grid), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, m->P, m->PA, m->d_shift, m->d_Xa);
+            hipLaunchKernelGGL(pack_rowmajor_kernel, dim3(grid), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, Pg, m->PA, m->d_shift, m->d_Xa);
         } else {
-            hipLaunchKernelGGL(pack_colmajor_kernel, dim3((unsigned)((N + 63) / 64), m->PA / 32), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, m->P, m->PA,
+            hipLaunchKernelGGL(pack_colmajor_kernel, dim3((unsigned)((N + 63) / 64), m->PA / 32), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, Pg, m->PA,
                                m->d_shift, m->d_Xa);
         }
     }
@@ -1293,6 +1313,20 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
 static size_t desc_lds_bytes(int P, int L, int ne, int nedge) {
     const size_t T = ((size_t)P + 1 + 31) / 32 * 2, ntile = T * (T + 1) / 2;
     return (size_t)P * 8 + (3 * (size_t)(L + 1) + P + 2 * (size_t)L + 2 * (size_t)ne + 2 * (size_t)nedge + (ntile + 1) / 2 + 4) * 4 + (((size_t)L * L + 15) & ~(size_t)15) + 16;
+}
+
+// Missing-data models: collapse the aug Gram(s) at `Min` into mean-imputed P-column moments; returns the matrix the solver reads.
+static int run_impute(plspm_model* m, long nproblems, const double* Min, const double** Mp, long* mp_stride) {
+    *Mp = Min; *mp_stride = packed_size(m->T);
+    if (!m->n_ind) return 0;
+    const long out_stride = packed_size(m->Ts);
+    int rc = ensure(m, m->gram2, (size_t)nproblems * out_stride * sizeof(double));
+    if (rc) return rc;
+    ProfScope ps(m, PLSPM_K_REDUCE);
+    hipLaunchKernelGGL(impute_kernel, dim3((unsigned)nproblems), dim3(256), (size_t)m->P * sizeof(double), m->stream, m->P, m->Pg, m->T, m->Ts, m->d_ind_of, Min,
+                       packed_size(m->T), (double*)m->gram2.p, out_stride);
+    *Mp = (const double*)m->gram2.p; *mp_stride = out_stride;
+    return 0;
 }
 
 static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, int threads) {
@@ -1432,6 +1466,30 @@ int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_
     return 0;
 }
 
+int plspm_model_set_missing(plspm_model_t* m, int32_t n_ind, const int32_t* ind_of) {
+    if (!m || !ind_of || n_ind < 1 || n_ind > m->P) return fail(m, PLSPM_E_ARG, "plspm_model_set_missing: bad arguments");
+    if (m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_model_set_missing: call before plspm_upload");
+    if (m->nonmetric) return fail(m, PLSPM_E_STATE, "plspm_model_set_missing: mean imputation is the METRIC treatment (config.py:300)");
+    if (m->P + n_ind > 1022) return fail(m, PLSPM_E_LIMIT, "limits: P + n_ind <= 1022");
+    std::vector<char> seen(n_ind, 0);
+    for (int p = 0; p < m->P; ++p) {
+        const int c = ind_of[p];
+        if (c == -1) continue;
+        if (c < m->P || c >= m->P + n_ind || seen[c - m->P]) return fail(m, PLSPM_E_ARG, "ind_of: -1 or a distinct column in [P, P + n_ind)");
+        seen[c - m->P] = 1;
+    }
+    for (char f : seen) if (!f) return fail(m, PLSPM_E_ARG, "ind_of: every indicator column needs a data column");
+    HIPCHK(m, hipSetDevice(m->device));
+    m->ind_of.assign(ind_of, ind_of + m->P);
+    if (upload_vec(m, &m->d_ind_of, m->ind_of)) return fail(m, PLSPM_E_STATE, "descriptor upload failed");
+    m->n_ind = n_ind; m->Pg = m->P + n_ind;
+    m->PA = ((m->Pg + 1 + 31) / 32) * 32; m->T = m->PA / 16;
+    HIPCHK(m, hipFree(m->d_shift));
+    m->d_shift = nullptr;
+    HIPCHK(m, hipMalloc((void**)&m->d_shift, sizeof(double) * m->Pg));
+    return 0;
+}
+
 int plspm_sync(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
     HIPCHK(m, hipSetDevice(m->device));
@@ -1482,8 +1540,10 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     if (m->nonmetric) {
         if ((rc = run_nonmetric(m, 1, (const double*)m->gram.p, psize, so, nullptr, nullptr, 0, 256))) return rc;
     } else {
+        const double* Mp; long mp_stride;
+        if ((rc = run_impute(m, 1, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
         ProfScope ps(m, PLSPM_K_SOLVER);
-        if ((rc = launch_solver(m, 1, (const double*)m->gram.p, psize, so, 256))) return rc;
+        if ((rc = launch_solver(m, 1, Mp, mp_stride, so, 256))) return rc;
     }
     if (out->scores) {
         if ((rc = ensure(m, m->rows, (size_t)N * L * sizeof(double)))) return rc;
@@ -1583,9 +1643,11 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         }
         long long* d_marks = nullptr;
         if (getenv("PLSPM_DEBUG_MARKS")) { HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks; }
+        const double* Mp; long mp_stride;
+        if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
         {
             ProfScope ps(m, PLSPM_K_SOLVER);
-            if ((rc = launch_solver(m, nb, (const double*)m->gram.p, psize, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 128))) return rc;
+            if ((rc = launch_solver(m, nb, Mp, mp_stride, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 128))) return rc;
         }
         if (d_marks) {
             long long h[16];

@@ -278,6 +278,52 @@ PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const d
     ex.par(P, [&](int p) { ws.sd[p] = sqrt(ws.S[p * PS + p]); ws.cs[p] = sqrt(fac * n); });   // cs = 1/g (scaled) or 1
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stage 0 (metric data with missing values): mean imputation on the moments.
+// The reference imputes every NaN with its column's mean over the present values -- of the data set handed to treat(), i.e.
+// per bootstrap replicate the mean of the *resampled* column (util.py:61-68 via config.py:300, bootstrap.py:57).  The device
+// matrix carries, after the P data columns, one 0/1 "missing" indicator column d_p for every column p that has NaNs
+// (ind_of[p] = its aug column, -1 if p is complete); the NaN cells of a data column hold one constant e_p (the caller's
+// full-data mean, minus the upload shift).  With g_p = (replicate mean of the present cells) - e_p the imputed column is
+// x_p + g_p d_p, hence
+//     M~(p,q) = M(p,q) + g_q M(p,d_q) + g_p M(d_p,q) + g_p g_q M(d_p,d_q),      M~(p,1) = M(p,1) + g_p M(d_p,1),
+// all entries of the SAME weighted Gram of the aug columns.  Reads the Ta-tile packed aug matrix, writes the Ts-tile packed
+// matrix of the P logical columns (+ ones) that moments_to_cov expects.  `gam`: P doubles of scratch.
+// A column that lost all its present cells (replicate mean undefined -> NaN in the reference) poisons its moments with NaN.
+template <class Ex>
+PLSPM_HD void impute_collapse(Ex& ex, int P, int Qa, int Ta, int Ts, const int* ind_of, const double* Min, double* Mout, double* gam) {
+    const double n = Min[packed_index(Ta, Qa, Qa)];
+    ex.par(P, [&](int p) {
+        const int c = ind_of[p];
+        double g = 0.0;
+        if (c >= 0) {
+            const double nd = Min[packed_index(Ta, c, Qa)], sp1 = Min[packed_index(Ta, p, Qa)], spd = Min[packed_index(Ta, p, c)];
+            const double present = n - nd;
+            if (nd > 0.0) g = (present > 0.0) ? (sp1 - spd) / present - spd / nd : NAN;
+        }
+        gam[p] = g;
+    });
+    const int ntile = Ts * (Ts + 1) / 2;
+    ex.par(ntile * 256, [&](int e) {
+        const int tile = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+        int t = 0, rem = tile;
+        while (rem >= Ts - t) { rem -= Ts - t; ++t; }
+        int p, q;
+        packed_coords(t, t + rem, r, lane, p, q);
+        double v = 0.0;
+        if (p <= P && q <= P) {
+            const int ap = p < P ? p : Qa, aq = q < P ? q : Qa;
+            const int cp = p < P ? ind_of[p] : -1, cq = q < P ? ind_of[q] : -1;
+            const double gp = cp >= 0 ? gam[p] : 0.0, gq = cq >= 0 ? gam[q] : 0.0;
+            v = Min[packed_index(Ta, ap, aq)];
+            if (cq >= 0 && gq != 0.0) v += gq * Min[packed_index(Ta, ap, cq)];
+            if (cp >= 0 && gp != 0.0) v += gp * Min[packed_index(Ta, cp, aq)];
+            if (cp >= 0 && cq >= 0 && gp != 0.0 && gq != 0.0) v += (gp * gq) * Min[packed_index(Ta, cp, cq)];
+        }
+        Mout[e] = v;
+    });
+}
+
 // V[p,m] = sum_{q in block m} S[p,q] w[q];   Q[l,m] = sum_{p in block l} w[p] V[p,m]
 template <class Ex>
 PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {

@@ -95,3 +95,19 @@ def augment(compiled: CompiledModel, config, values: np.ndarray):
         boff.append(mv_off[-1])
     return (np.ascontiguousarray(np.concatenate(cols, axis=1)), np.array(boff, dtype=np.int32), np.array(mv_off, dtype=np.int32),
             np.array(mv_kind, dtype=np.int32))
+
+
+def with_missing_indicators(compiled: CompiledModel, values: np.ndarray):
+    """Metric data with NaNs (include/plspm_hip.h, plspm_model_set_missing): every NaN becomes its column's mean over the present
+    cells (util.impute, reference util.py:61-68) and one 0/1 "missing" column per incomplete model column is appended, so that
+    the device can re-impute every bootstrap replicate with the replicate's own means.  Returns (matrix, col_index incl. the
+    indicator columns, ind_of [P])."""
+    missing = np.isnan(values)
+    means = np.nanmean(np.where(missing.all(axis=0), 0.0, values), axis=0)
+    filled = np.where(missing, means, values)
+    incomplete = [p for p in range(compiled.P) if missing[:, compiled.col_index[p]].any()]
+    ind_of = np.full(compiled.P, -1, dtype=np.int32)
+    ind_of[incomplete] = compiled.P + np.arange(len(incomplete))
+    indicators = missing[:, compiled.col_index[incomplete]].astype(np.float64)
+    col_index = np.concatenate([compiled.col_index, values.shape[1] + np.arange(len(incomplete))]).astype(np.int32)
+    return np.ascontiguousarray(np.concatenate([filled, indicators], axis=1)), col_index, ind_of

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
-EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical",
+EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
@@ -52,6 +52,7 @@ def load():
     lib.plspm_model_destroy.argtypes = [vp]
     lib.plspm_model_set_nonmetric.argtypes = [vp, i32]
     lib.plspm_model_set_categorical.argtypes = [vp, i32, vp, vp]
+    lib.plspm_model_set_missing.argtypes = [vp, i32, vp]
     lib.plspm_upload.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.plspm_effect_pairs.restype = i32
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
@@ -96,7 +97,7 @@ def bootstrap_indices(seed, rep, n):
 class NativeModel:
     """One compiled model on one GPU (an opaque ``plspm_model_t*``)."""
 
-    def __init__(self, block_offset, path, modes, scheme, scaled, max_iter, tol, device_id=0, nonmetric=False, categorical=None):
+    def __init__(self, block_offset, path, modes, scheme, scaled, max_iter, tol, device_id=0, nonmetric=False, categorical=None, missing=None):
         lib = load()
         if lib.plspm_device_count() <= 0:
             raise NativeBackendError("no HIP device visible: the MI355X backend has no CPU fallback")
@@ -118,6 +119,9 @@ class NativeModel:
             mv_kind = np.ascontiguousarray(categorical[1], dtype=np.int32)
             self.P_out = len(mv_kind)
             self._check(lib.plspm_model_set_categorical(self._h, self.P_out, _ptr(mv_off), _ptr(mv_kind)), "plspm_model_set_categorical")
+        if missing is not None:         # ind_of [P]: upload column of every incomplete data column's 0/1 missing indicator (else -1)
+            ind_of = np.ascontiguousarray(missing, dtype=np.int32)
+            self._check(lib.plspm_model_set_missing(self._h, int((ind_of >= 0).sum()), _ptr(ind_of)), "plspm_model_set_missing")
         self.n_eff = lib.plspm_effect_pairs(self._h, None, None)
         ef = np.zeros(max(self.n_eff, 1), dtype=np.int32)
         et = np.zeros(max(self.n_eff, 1), dtype=np.int32)

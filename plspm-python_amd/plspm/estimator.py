@@ -52,7 +52,7 @@ class Estimator:
         if config.missing():
             if not config.metric():
                 raise NotImplementedError("missing values in non-metric data are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
-            data = data.fillna(data.mean())                       # util.impute (reference util.py:61-68, config.py:300): column means
+            # metric: util.impute (reference util.py:61-68, config.py:300) happens in WeightsCalculatorFactory.run / on the device
         hocs = config.hoc()
         if not hocs:
             self._config = config

@@ -62,8 +62,6 @@ class Plspm:
         self._unidimensionality = Unidimensionality(model_spec, fit, incomplete)
         self._bootstrap = None
         if bootstrap:
-            if model_spec.missing():
-                raise NotImplementedError("bootstrapping data with missing values is not built yet (the reference re-imputes every replicate)")
             if model_spec.hoc():
                 raise NotImplementedError("bootstrapping a model with higher order constructs is not built yet (two device stages per replicate)")
             if n_obs < 10:

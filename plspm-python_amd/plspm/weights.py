@@ -11,7 +11,7 @@ import numpy as np
 import pandas as pd
 
 from plspm import _native
-from plspm._compile import augment, compile_model
+from plspm._compile import augment, compile_model, with_missing_indicators
 from plspm.scale import Scale
 from plspm.scheme import Scheme
 
@@ -87,9 +87,13 @@ class WeightsCalculatorFactory:
                                          self._tolerance, self._device_id, nonmetric=True, categorical=(mv_off, mv_kind))
             native.upload(xaug)
         else:
+            values = values if values.dtype == np.float64 else values.astype(np.float64)
+            col_index, ind_of = compiled.col_index, None
+            if not nonmetric and np.isnan(values).any():
+                values, col_index, ind_of = with_missing_indicators(compiled, values)
             native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
-                                         self._iterations, self._tolerance, self._device_id, nonmetric=bool(nonmetric))
-            native.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled.col_index)
+                                         self._iterations, self._tolerance, self._device_id, nonmetric=bool(nonmetric), missing=ind_of)
+            native.upload(values, col_index)
         raw = native.fit(want_scores=want_scores, want_cov=want_cov)
         if raw["status"] == _native.STATUS_NOT_CONVERGED:
             raise ConvergenceError("Could not converge after " + str(raw["iterations"]) + " iterations")

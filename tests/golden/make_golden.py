@@ -301,6 +301,15 @@ def main():
                 key = "%s_%s_%d" % (modes_name, scheme, int(scaled))
                 for k, v in out.items():
                     g10[key + "/" + k] = v
+    # bootstrap replicates on explicit indices: Config.treat re-imputes every resampled data set (bootstrap.py:57, config.py:300)
+    rs10 = np.random.RandomState(1010)
+    g10["idx"] = rs10.randint(249, size=(5, 249))
+    for tag, modes, scheme, scaled in (("A_centroid_1", "AAAAAA", "centroid", True), ("M_path_0", "ABABAB", "path", False)):
+        cfg = build_config(Csat, lvs, sat_blocks, modes, scaled, add_order)
+        m, _ = run_fit(satm, cfg, scheme, lvs)
+        rows, its = boot_rows(satm, cfg, scheme, lvs, list(g10["idx"]), list(m.effects().index))
+        g10[tag + "/boot_rows"] = rows
+        g10[tag + "/boot_iters"] = its
     save("g10_metric_missing", **g10)
     # ---- G11: ORD / NOM optimal scaling (scale.py:42-89): russa categorical (reference tests/test_regression_nonmetric.py:94-120) + Likert-style synthetic
     g11 = {}

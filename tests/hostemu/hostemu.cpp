@@ -234,6 +234,20 @@ int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, do
     return 0;
 }
 
+// Mean imputation on the moments (solver_core.h impute_collapse): aug packed Gram (Ta tiles) -> P-column packed moments (Ts tiles).
+void hostemu_impute_collapse(int P, int Qa, int Ta, int Ts, const int* ind_of, const double* Min, double* Mout, int nthreads_in) {
+    const int nthreads = nthreads_in > 16 ? 16 : nthreads_in;
+    std::vector<double> gam(P), red(nthreads);
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            HostExec ex{t, nthreads, &bar, red.data()};
+            impute_collapse(ex, P, Qa, Ta, Ts, ind_of, Min, Mout, gam.data());
+        });
+    for (auto& x : th) x.join();
+}
+
 long hostemu_packed_index(int T, int p, int q) { return packed_index(T, p, q); }
 long hostemu_packed_size(int T) { return packed_size(T); }
 }

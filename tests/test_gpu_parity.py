@@ -741,8 +741,6 @@ def test_api_metric_missing_values_match_reference_golden():
                 for lv in orc.SAT_LVS:                      # blocks with a missing value report NaN (unidimensionality.py:39)
                     has_nan = frame[[col for col in cols if col.startswith(SAT_PREFIX[lv])]].iloc[[i for i in range(250) if i != 7]].isnull().values.any()
                     assert bool(np.isnan(uni.loc[lv, "eig_1st"])) == bool(has_nan)
-                with pytest.raises(NotImplementedError):
-                    Plspm(frame, config, scheme, bootstrap=True)
 
 
 @pytest.mark.parametrize("L,per,n", [(30, 9, 900), (64, 15, 1500)])

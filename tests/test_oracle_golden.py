@@ -274,6 +274,20 @@ def test_g10_metric_missing(modes, scheme, scaled):
     _check_fit(orc.fit(X, model), g, key)
 
 
+@pytest.mark.parametrize("tag", ["A_centroid_1", "M_path_0"])
+def test_g10_metric_missing_bootstrap_rows_are_reimputed_per_replicate(tag):
+    g = load("g10_metric_missing")
+    _, blocks, _ = satisfaction_oracle_inputs()
+    m, scheme, scaled = tag.split("_")
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(m), scheme, bool(int(scaled)))
+    X = orc.filter_missing(g["data"], model)
+    corr = orc.correction(249)
+    for idx, row, it in zip(g["idx"], g[tag + "/boot_rows"], g[tag + "/boot_iters"]):
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-12, what=tag)
+
+
 # ------------------------------------------------------------------ ORD / NOM optimal scaling (scale.py:42-89)
 RUSSA_CAT_COLS = ["gnpr", "labo", "ecks", "death", "demo", "inst", "gini", "farm", "rent"]      # add_lv order IND, POLINS, AGRI
 RUSSA_CAT_BLOCKS = [np.array([6, 7, 8]), np.array([0, 1]), np.array([2, 3, 4, 5])]                # path order AGRI, IND, POLINS

@@ -29,11 +29,12 @@ def _ptr(a, t=ctypes.c_double):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def run_emu(lib, X, model, counts=None, shift=None, nthreads=4):
+def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None):
+    """`packed`: precomputed (Mp, shift, PA) of the DEVICE-ordered columns instead of the scatter of X (X then only feeds the score check)."""
     order = model.mv_order
     Xdev = np.ascontiguousarray(X[:, order])
     P, L = Xdev.shape[1], model.L
-    Mp, shift, PA = packed_scatter(Xdev, counts, shift)
+    Mp, shift, PA = packed if packed is not None else packed_scatter(Xdev, counts, shift)
     boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
     C = np.ascontiguousarray(model.C.astype(np.uint8))
     mode = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
