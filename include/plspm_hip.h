@@ -113,6 +113,21 @@ int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_
 int plspm_model_set_missing(plspm_model_t* m, int32_t n_ind, const int32_t* ind_of);
 
 /*
+ * Two-stage estimation of higher order constructs in the bootstrap (reference Estimator.estimate, plspm/estimator.py:29-55, run
+ * per resampled data set by bootstrap.py:57).  `first` is the stage-1 model (every HOC replaced by its constituent LVs,
+ * estimator.py:60-74) and holds the data; `second` is the original path model whose HOC blocks have ONE column per
+ * constituent LV -- that LV's stage-1 score (Scale.NUM, estimator.py:43-52) -- and takes no upload.  The stage-1 LV order
+ * must be the stage-2 order with every HOC expanded in place:
+ *   lv_first  [L2+1]  stage-2 LV l stands for the stage-1 LVs [lv_first[l], lv_first[l+1]): one LV with the same block
+ *                     (an ordinary LV) or its constituents (a HOC)
+ * After attaching, plspm_bootstrap* on `first` runs both stages per replicate -- the stage-2 moment matrix is a congruence of
+ * the replicate's stage-1 Gram with the stage-1 score maps (solver_hoc.h), no second pass over the data -- and reports the
+ * SECOND stage's rows (plspm_row_width(first) becomes the second stage's; effect pairs: plspm_effect_pairs(second)).
+ * plspm_fit(first) still fits stage 1 alone.  Both handles: plspm_model_set_nonmetric(.., 1), same device.  Destroy in any order.
+ */
+int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second, const int32_t* lv_first);
+
+/*
  * Upload the filtered raw observation matrix (what Config.filter returns, config.py:247-285; no NaNs).
  *   X          host pointer, dense fp64, src_cols columns x N rows
  *   layout     0: row-major (element (i,c) at X[i*src_cols + c]);  1: column-major (X[c*N + i])

@@ -412,6 +412,30 @@ def fit(X, model: Model, corr: Optional[float] = None):
                 indirect=ind, total=tot, crossloadings=cl, loadings=ld)
 
 
+def fit_two_stage(X, model1: Model, stage2, C2, modes2, corr: Optional[float] = None):
+    """Estimator.estimate with higher order constructs (estimator.py:29-55): stage 1 = `model1` (every HOC replaced by its
+    constituent LVs, estimator.py:60-74); stage 2 = the original path `C2` where LV l is `stage2[l]`: ("lv", j) -- stage-1
+    LV j with its own MVs -- or ("hoc", [j, ...]) -- a HOC whose MVs are the stage-1 SCORES of those LVs, Scale.NUM
+    (estimator.py:43-52).  Non-metric (NUM / RAW) models only, as in the reference.  Returns the stage-2 fit (its MV order:
+    stage-2 LV by LV) plus `iterations1`."""
+    if corr is None:
+        corr = correction(X.shape[0])
+    r1 = fit(X, model1, corr)
+    cols, blocks2 = [], []
+    for kind, ref in stage2:
+        start = len(cols)
+        if kind == "lv":
+            cols.extend(r1["treated"][:, p] for p in model1.blocks[ref])      # treated_data keeps the stage-1 treatment (estimator.py:33,47)
+        else:
+            cols.extend(r1["scores"][:, j] for j in ref)
+        blocks2.append(np.arange(start, len(cols)))
+    X2 = np.column_stack(cols)
+    model2 = Model(blocks2, np.asarray(C2), modes2, model1.scheme, model1.scaled, max_iter=model1.max_iter, tol=model1.tol, scales=["NUM"] * X2.shape[1])
+    r2 = fit(X2, model2, corr)
+    r2["iterations1"] = r1["iterations"]
+    return r2
+
+
 def bootstrap_replicate(X, model: Model, idx, corr: float):
     """One pass of BootstrapProcess.run's loop body (bootstrap.py:54-66) on explicit indices.
 

@@ -20,6 +20,7 @@
 #include "../../include/plspm_hip.h"
 #include "solver_core.h"
 #include "solver_nmg.h"
+#include "solver_hoc.h"
 
 using namespace plspm;
 
@@ -749,6 +750,30 @@ __global__ void __launch_bounds__(256) impute_kernel(int P, int Qa, int Ta, int 
 }
 
 
+// Two-stage HOC bootstrap (solver_hoc.h): stage-1 Gram + final stage-1 score maps -> stage-2 moment matrix, one workgroup per replicate.
+__global__ void __launch_bounds__(256) hoc_moments_kernel(HocDesc hd, const double* __restrict__ M1, long m1_stride, const double* __restrict__ state1, long st1_stride,
+                                                          double* __restrict__ M2, long m2_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* V = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    const double* st = state1 + b * st1_stride;
+    const double* c1 = st + 8 + 3 * hd.P1;                  // NmState: scal[8] a_old a_new c_old c_new k_old k_new
+    const double* k1 = st + 8 + 4 * hd.P1 + hd.L1;
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    hoc_second_stage_moments(ex, hd, M1 + b * m1_stride, c1, k1, st[1] == (double)ST_OK, M2 + b * m2_stride, V);
+}
+
+__global__ void __launch_bounds__(64) hoc_compose_kernel(HocDesc hd, const double* __restrict__ state1, long st1_stride, double* state2, long st2_stride, int n_chol2,
+                                                         double* pseudo, long ps_stride) {
+    const long b = blockIdx.x;
+    const double* st = state1 + b * st1_stride;
+    NmState st2;
+    nm_carve(st2, state2 + b * st2_stride, hd.P2, hd.L2);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    hoc_compose_score_maps(ex, hd, st + 8 + 3 * hd.P1, st + 8 + 4 * hd.P1 + hd.L1, st2, pseudo + b * ps_stride);
+}
+
+
 #define SCORE_ROWS 16
 // ------------------------------------------------------------------------------------------------ non-metric (NUM / RAW) kernels
 // The correlation matrix R and the iteration state of every problem live in global memory between launches (gS / gstate); the
@@ -1020,6 +1045,7 @@ struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double tota
 struct plspm_model {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;      // an attached second stage runs on its first stage's stream
     int P = 0, L = 0, PA = 0, T = 0, scheme = 0, scaled = 1, max_iter = 100, kmax = 0, n_eff = 0, n_chol = 0;
     double tol = 1e-6;
     std::vector<int> boff, lvof, mode, chol_off, eff_from, eff_to, pred_off, pred_idx, succ_off, succ_idx;
@@ -1045,6 +1071,14 @@ struct plspm_model {
     std::vector<int> ind_of;
     int* d_ind_of = nullptr;
     Buf gram2;
+    // two-stage higher order constructs (solver_hoc.h): `stage2` of a data-holding handle / `stage1` of its attached second stage
+    plspm_model* stage2 = nullptr;
+    plspm_model* stage1 = nullptr;
+    std::vector<int> lv_first, col2_lv1, col2_p1, hcol, hidx;
+    std::vector<int> lv_cols;
+    int* d_lv_cols = nullptr;
+    int *d_lv_first = nullptr, *d_col2_lv1 = nullptr, *d_col2_p1 = nullptr, *d_hcol = nullptr, *d_hidx = nullptr;
+    Buf pseudo;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
     bool profiling = false;
@@ -1111,6 +1145,15 @@ static ModelDesc make_desc(const plspm_model* m) {
     md.n_edges = (int)m->pred_idx.size();
     md.tile_tu = nullptr;
     return md;
+}
+
+static HocDesc make_hoc_desc(const plspm_model* m2) {
+    const plspm_model* m1 = m2->stage1;
+    HocDesc hd{};
+    hd.P1 = m1->P; hd.L1 = m1->L; hd.P2 = m2->P; hd.L2 = m2->L; hd.T1 = m1->T; hd.T2 = m2->Ts;
+    hd.boff1 = m1->d_boff; hd.boff2 = m2->d_boff; hd.lv_first = m2->d_lv_first; hd.col2_lv1 = m2->d_col2_lv1; hd.col2_p1 = m2->d_col2_p1;
+    hd.nh = (int)m2->hcol.size(); hd.hcol = m2->d_hcol; hd.hidx = m2->d_hidx;
+    return hd;
 }
 
 template <class Tv>
@@ -1196,16 +1239,18 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
 
 void plspm_model_destroy(plspm_model_t* m) {
     if (!m) return;
+    if (m->stage2) { m->stage2->stage1 = nullptr; m->stage2->stream = nullptr; }      // the pair is dissolved; the survivor is inert
+    if (m->stage1) m->stage1->stage2 = nullptr;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
     if (m->h_stage) hipHostFree(m->h_stage);
-    if (m->stream) hipStreamDestroy(m->stream);
+    if (m->stream && m->owns_stream) hipStreamDestroy(m->stream);
     delete m;
 }
 
@@ -1214,7 +1259,11 @@ int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to) {
     for (int e = 0; e < m->n_eff; ++e) { if (from) from[e] = m->eff_from[e]; if (to) to[e] = m->eff_to[e]; }
     return m->n_eff;
 }
-int32_t plspm_row_width(const plspm_model_t* m) { return m ? 2 * (m->categorical ? m->Pm : m->P) + m->L + 2 * m->n_eff : 0; }
+int32_t plspm_row_width(const plspm_model_t* m) {
+    if (!m) return 0;
+    if (m->stage2) m = m->stage2;               // two-stage handles report the second stage's rows
+    return 2 * (m->categorical ? m->Pm : m->P) + m->L + 2 * m->n_eff;
+}
 int32_t plspm_row_stride(const plspm_model_t* m) { return m ? plspm_row_width(m) + 2 : 0; }
 
 int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols, int32_t layout, const int32_t* col_index) {
@@ -1359,9 +1408,10 @@ static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long 
 // Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
 // finish.  The host only reads one counter per iteration (how many problems are still active).
 static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, const int2* ent, const int* nent,
-                         long ent_stride, int threads) {
+                         long ent_stride, int threads, bool finish = true) {
     const int P = m->P, L = m->L;
-    const long N = m->N;
+    const plspm_model* src = m->stage1 ? m->stage1 : m;          // an attached second stage streams its first stage's data (solver_hoc.h)
+    const long N = src->N;
     const bool cat = m->categorical != 0;
     int rc;
     const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
@@ -1380,7 +1430,9 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             return rc;
     } else if ((rc = allow_lds(m, (const void*)nm_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<2>, lds)))
         return rc;
-    const size_t conv_lds = ((size_t)SCORE_ROWS * (m->PA + 1) + 2 * (size_t)P + 2 * (size_t)L + SCORE_ROWS + 256) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
+    const size_t conv_lds = ((size_t)SCORE_ROWS * (src->PA + 1) + 2 * (size_t)src->P + 2 * (size_t)L + SCORE_ROWS + 256) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
+    const long ps_stride = 8 + 4L * src->P + 2L * L;
+    if (m->stage1 && (rc = ensure(m, m->pseudo, (size_t)nproblems * ps_stride * sizeof(double)))) return rc;
     if ((rc = allow_lds(m, (const void*)nm_conv_kernel, conv_lds))) return rc;
     const ModelDesc md = make_desc(m);
     CatDesc cd{};
@@ -1415,11 +1467,18 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
         if (h_active == 0) break;
         {
             ProfScope ps(m, PLSPM_K_SCORES);
-            hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, m->d_Xa, N, m->PA, P, L, m->n_chol, m->d_boff, ent,
-                               nent, ent_stride, (const double*)gst, (long)st_doubles, part);
+            if (m->stage1) {
+                hipLaunchKernelGGL(hoc_compose_kernel, grid, dim3(64), 0, m->stream, make_hoc_desc(m), (const double*)m->stage1->nmstate.p,
+                                   (long)nm_state_doubles(src->P, src->L, src->n_chol), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride);
+                hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, m->d_lv_cols, ent,
+                                   nent, ent_stride, (const double*)m->pseudo.p, ps_stride, part);
+            } else {
+                hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, m->d_Xa, N, m->PA, P, L, m->n_chol, m->d_boff, ent,
+                                   nent, ent_stride, (const double*)gst, (long)st_doubles, part);
+            }
         }
     }
-    launch(2);
+    if (finish) launch(2);
     HIPCHK(m, hipGetLastError());
     return 0;
 }
@@ -1487,6 +1546,41 @@ int plspm_model_set_missing(plspm_model_t* m, int32_t n_ind, const int32_t* ind_
     HIPCHK(m, hipFree(m->d_shift));
     m->d_shift = nullptr;
     HIPCHK(m, hipMalloc((void**)&m->d_shift, sizeof(double) * m->Pg));
+    return 0;
+}
+
+int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second, const int32_t* lv_first) {
+    if (!first || !second || !lv_first || first == second) return fail(first, PLSPM_E_ARG, "plspm_model_attach_second_stage: bad arguments");
+    plspm_model* m1 = first; plspm_model* m2 = second;
+    if (m1->stage1 || m1->stage2 || m2->stage1 || m2->stage2) return fail(m1, PLSPM_E_STATE, "a handle takes part in one two-stage pair only");
+    if (!m1->nonmetric || !m2->nonmetric || m1->categorical || m2->categorical || m1->n_ind || m2->n_ind)
+        return fail(m1, PLSPM_E_STATE, "two-stage estimation needs Scale.NUM / RAW handles (the reference's metric solver cannot run HOCs)");
+    if (m2->d_Xa) return fail(m1, PLSPM_E_STATE, "the second stage takes no data of its own");
+    if (m1->device != m2->device) return fail(m1, PLSPM_E_ARG, "both stages must live on one device");
+    const int L1 = m1->L, L2 = m2->L;
+    if (lv_first[0] != 0 || lv_first[L2] != L1) return fail(m1, PLSPM_E_ARG, "lv_first must run from 0 to the first stage's L");
+    std::vector<int> col2_lv1(m2->P, -1), col2_p1(m2->P, -1), hidx(m2->P, -1), hcol, lv_cols(L2 + 1, 0);
+    for (int l = 0; l < L2; ++l) {
+        const int j0 = lv_first[l], j1 = lv_first[l + 1], a0 = m2->boff[l], k2 = m2->boff[l + 1] - a0;
+        if (j1 <= j0) return fail(m1, PLSPM_E_ARG, "every second-stage LV stands for at least one first-stage LV");
+        lv_cols[l] = m1->boff[j0]; lv_cols[l + 1] = m1->boff[j1];
+        if (j1 - j0 == 1 && k2 == m1->boff[j1] - m1->boff[j0]) {            // plain LV: the same columns
+            for (int a = 0; a < k2; ++a) col2_p1[a0 + a] = m1->boff[j0] + a;
+        } else if (k2 == j1 - j0) {                                           // HOC: one MV per constituent, its stage-1 score
+            for (int a = 0; a < k2; ++a) { col2_lv1[a0 + a] = j0 + a; hidx[a0 + a] = (int)hcol.size(); hcol.push_back(a0 + a); }
+        } else return fail(m1, PLSPM_E_ARG, "a second-stage block is either the first-stage block itself or one column per constituent LV");
+    }
+    if (hcol.empty()) hcol.push_back(0), hcol.pop_back();
+    HIPCHK(m1, hipSetDevice(m1->device));
+    m2->lv_first.assign(lv_first, lv_first + L2 + 1); m2->col2_lv1 = col2_lv1; m2->col2_p1 = col2_p1; m2->hidx = hidx; m2->hcol = hcol; m2->lv_cols = lv_cols;
+    if (upload_vec(m2, &m2->d_lv_first, m2->lv_first) || upload_vec(m2, &m2->d_col2_lv1, m2->col2_lv1) || upload_vec(m2, &m2->d_col2_p1, m2->col2_p1) ||
+        upload_vec(m2, &m2->d_hidx, m2->hidx) || upload_vec(m2, &m2->d_hcol, m2->hcol) || upload_vec(m2, &m2->d_lv_cols, m2->lv_cols))
+        return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
+    HIPCHK(m1, hipMemset(m2->d_shift, 0, sizeof(double) * m2->P));
+    HIPCHK(m1, hipStreamSynchronize(m2->stream));
+    HIPCHK(m1, hipStreamDestroy(m2->stream));
+    m2->stream = m1->stream; m2->owns_stream = false;
+    m1->stage2 = m2; m2->stage1 = m1;
     return 0;
 }
 
@@ -1637,6 +1731,25 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         }
         SolverOut so{};
         so.row = (double*)m->rows.p + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
+        if (m->nonmetric && m->stage2) {
+            // two-stage HOC estimation per replicate (solver_hoc.h): stage 1 to convergence (no report), stage-2 moments by congruence,
+            // stage 2 on the second handle's descriptors with the convergence pass streaming THIS handle's data
+            plspm_model* m2 = m->stage2;
+            const long psize2 = packed_size(m2->Ts);
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, SolverOut{}, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128, false))) return rc;
+            if ((rc = ensure(m, m2->gram, (size_t)nb * psize2 * sizeof(double)))) return rc;
+            const HocDesc hd = make_hoc_desc(m2);
+            const size_t vlds = std::max<size_t>(1, (size_t)hd.nh * (hd.P1 + 1)) * sizeof(double);
+            if ((rc = allow_lds(m, (const void*)hoc_moments_kernel, vlds))) return rc;
+            {
+                ProfScope ps(m, PLSPM_K_REDUCE);
+                hipLaunchKernelGGL(hoc_moments_kernel, dim3((unsigned)nb), dim3(256), vlds, m->stream, hd, (const double*)m->gram.p, psize, (const double*)m->nmstate.p,
+                                   (long)nm_state_doubles(m->P, m->L, m->n_chol), (double*)m2->gram.p, psize2);
+            }
+            rc = run_nonmetric(m2, nb, (const double*)m2->gram.p, psize2, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128);
+            if (rc) return fail(m, rc, "second stage: " + m2->error);
+            continue;
+        }
         if (m->nonmetric) {
             if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128))) return rc;
             continue;

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
-EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing",
+EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing", "plspm_model_attach_second_stage",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
@@ -53,6 +53,7 @@ def load():
     lib.plspm_model_set_nonmetric.argtypes = [vp, i32]
     lib.plspm_model_set_categorical.argtypes = [vp, i32, vp, vp]
     lib.plspm_model_set_missing.argtypes = [vp, i32, vp]
+    lib.plspm_model_attach_second_stage.argtypes = [vp, vp, vp]
     lib.plspm_upload.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.plspm_effect_pairs.restype = i32
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
@@ -130,6 +131,16 @@ class NativeModel:
         self.row_width = lib.plspm_row_width(self._h)
         self.row_stride = lib.plspm_row_stride(self._h)     # device rows: [row | status | iterations]
         self.N = 0
+
+    def attach_second_stage(self, second, lv_first):
+        """Two-stage HOC bootstrap (plspm_model_attach_second_stage): ``second`` is the data-less stage-2 handle; afterwards
+        this handle's bootstrap rows / effect pairs / row width are the second stage's."""
+        lv_first = np.ascontiguousarray(lv_first, dtype=np.int32)
+        self._check(self._lib.plspm_model_attach_second_stage(self._h, second._h, _ptr(lv_first)), "plspm_model_attach_second_stage")
+        self._second = second                       # keeps the stage-2 handle alive as long as this one
+        self.n_eff, self.eff_from, self.eff_to = second.n_eff, second.eff_from, second.eff_to
+        self.row_width = self._lib.plspm_row_width(self._h)
+        self.row_stride = self._lib.plspm_row_stride(self._h)
 
     def _check(self, rc, what):
         if rc:

@@ -48,7 +48,7 @@ class Bootstrap:
             seed = int.from_bytes(os.urandom(8), "little")      # the reference is unseeded as well (bootstrap.py:56)
         self._seed = seed
         P, L, ne, R = cm.P, cm.L, native.n_eff, native.row_width
-        cols = list(data.columns)
+        cols = cm.used_data_cols()                  # == data.columns unless HOC constituents' MVs sit unused in stage 2
         eff_index = list(inner_model.effects().index)
         om = outer_model.model()
         # full-sample estimates in the device row layout: weights | r2 | total | direct | loadings (device column order)
@@ -70,7 +70,7 @@ class Bootstrap:
             rows, status, iters = parallel.split_records(records.cpu().numpy(), R)
         self._status, self._iterations, self._used = status, iters, used
         self._replicates = rows[status == 0]
-        inv = cm.inv_index
+        inv = cm.inv_index[cm.inv_index >= 0]
 
         def frame(block, index):
             return pd.DataFrame(block, index=index, columns=SUMMARY_COLUMNS)

@@ -17,6 +17,7 @@ built yet.
 """
 from typing import Tuple
 
+import numpy as np
 import pandas as pd
 
 import plspm.config as c
@@ -69,6 +70,49 @@ class Estimator:
             config.add_lv(hoc, config.mode(hoc), *[c.MV(lv, Scale.NUM) for lv in members])
         self._config = config
         return calculator.run(extended, config.path(), scaled=config.scaled(), want_scores=want_scores, want_cov=want_cov)
+
+    @staticmethod
+    def expanded_first_stage_path(config) -> pd.DataFrame:
+        """The first-stage path in the LV order the device's two-stage bootstrap needs: the original order with every HOC replaced
+        IN PLACE by its constituents (same edges as ``hoc_path_first_stage``; only the order differs, and no result depends on it)."""
+        path = config.path()
+        hocs = config.hoc() or {}
+        members = {lv: list(hocs.get(lv, [lv])) for lv in path.index}
+        order = [m for lv in path.index for m in members[lv]]
+        expanded = pd.DataFrame(0, index=order, columns=order, dtype=np.int64)
+        for to in path.index:
+            for frm in path.columns:
+                if path.loc[to, frm] == 1:
+                    expanded.loc[members[to], members[frm]] = 1
+        return expanded
+
+    def two_stage_bootstrap_handles(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame) -> SolverResult:
+        """Device handles for bootstrapping a HOC model: stage 1 (expanded path, holds the data) with the stage-2 model attached
+        (include/plspm_hip.h, plspm_model_attach_second_stage).  The returned result carries the stage-2 labels."""
+        from plspm import _native
+        from plspm._compile import compile_model
+        calculator = calculator.clone()
+        config = calculator.config()
+        hocs = config.hoc()
+        if config.metric() or calculator._nonmetric() != 1:
+            raise NotImplementedError("bootstrapping higher order constructs needs Scale.NUM / Scale.RAW data")
+        path1 = self.expanded_first_stage_path(config)
+        compiled1 = compile_model(config, path1, list(data.columns))
+        first = _native.NativeModel(compiled1.block_offset, compiled1.path, compiled1.modes, calculator.scheme().value.code, config.scaled(),
+                                    calculator._iterations, calculator._tolerance, calculator._device_id, nonmetric=True)
+        values = data.values
+        first.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled1.col_index)
+        lv_first, count = [0], 0
+        for lv in config.path().index:
+            count += len(hocs[lv]) if lv in hocs else 1
+            lv_first.append(count)
+        for hoc, parts in hocs.items():
+            config.add_lv(hoc, config.mode(hoc), *[c.MV(lv, Scale.NUM) for lv in parts])
+        compiled2 = compile_model(config, config.path(), list(data.columns) + [lv for parts in hocs.values() for lv in parts])
+        second = _native.NativeModel(compiled2.block_offset, compiled2.path, compiled2.modes, calculator.scheme().value.code, config.scaled(),
+                                     calculator._iterations, calculator._tolerance, calculator._device_id, nonmetric=True)
+        first.attach_second_stage(second, lv_first)
+        return SolverResult(compiled2, first, None, data.index)
 
     def estimate(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame) -> Tuple[pd.DataFrame, pd.DataFrame, pd.DataFrame]:
         """API parity with the reference: (final_data, scores, weights)."""

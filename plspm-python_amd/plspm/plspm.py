@@ -62,13 +62,12 @@ class Plspm:
         self._unidimensionality = Unidimensionality(model_spec, fit, incomplete)
         self._bootstrap = None
         if bootstrap:
-            if model_spec.hoc():
-                raise NotImplementedError("bootstrapping a model with higher order constructs is not built yet (two device stages per replicate)")
             if n_obs < 10:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
-            # the handle of the fit already holds the data in HBM: the replicates run on it
+            # the handle of the fit already holds the data in HBM: the replicates run on it (HOC models: a two-stage handle pair)
+            boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
             self._bootstrap = Bootstrap(model_spec, observations, self._inner_model, self._outer_model, calculator,
-                                        bootstrap_iterations, processes, result=fit, seed=seed)
+                                        bootstrap_iterations, processes, result=boot_on, seed=seed)
 
     # ---- accessors (names and return shapes of reference plspm/plspm.py:84-169) -------------------------------
     def scores(self) -> pd.DataFrame:

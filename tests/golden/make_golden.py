@@ -47,8 +47,14 @@ refw._MetricWeights.iterate = _counting_iterate
 _orig_nm_iterate = refw._NonmetricWeights.iterate
 
 
+_per_solver = []          # iterate() calls of every _NonmetricWeights instance, in creation order (two per HOC estimate)
+
+
 def _counting_nm_iterate(self, scheme):
     _calls["n"] += 1
+    if not _per_solver or _per_solver[-1][0] is not self:
+        _per_solver.append([self, 0])
+    _per_solver[-1][1] += 1
     return _orig_nm_iterate(self, scheme)
 
 
@@ -338,6 +344,48 @@ def main():
                 if k != "mv_names":
                     g11["likert_%s_%s/%s" % (tag, scheme, k)] = v
     save("g11_ordnom", **g11)
+    # ---- G12: higher order construct, two-stage approach (estimator.py:43-52; reference tests/test_regression_seminr.py:49-74), fit + bootstrap rows
+    mobi = pd.read_csv(os.path.join(HERE, "ref_data", "mobi.csv"), index_col=0)
+    g12 = {}
+    rs12 = np.random.RandomState(1212)
+    g12["idx"] = rs12.randint(250, size=(4, 250))
+    for tag, scheme, qmode in (("path_B", "path", Mode.B), ("centroid_A", "centroid", Mode.A)):
+        def hoc_config():
+            st = c.Structure()
+            st.add_path(["Expectation", "Quality"], ["Satisfaction"])
+            st.add_path(["Satisfaction"], ["Complaints", "Loyalty"])
+            cfg = c.Config(st.path(), default_scale=Scale.NUM)
+            cfg.add_higher_order("Satisfaction", Mode.A, ["Image", "Value"])
+            cfg.add_lv_with_columns_named("Expectation", Mode.A, mobi, "CUEX")
+            cfg.add_lv_with_columns_named("Quality", qmode, mobi, "PERQ")
+            cfg.add_lv_with_columns_named("Loyalty", Mode.A, mobi, "CUSL")
+            cfg.add_lv_with_columns_named("Image", Mode.A, mobi, "IMAG")
+            cfg.add_lv_with_columns_named("Complaints", Mode.A, mobi, "CUSCO")
+            cfg.add_lv_with_columns_named("Value", Mode.A, mobi, "PERV")
+            return cfg
+        cfg = hoc_config()
+        filtered = cfg.filter(mobi)
+        corr = np.sqrt(250 / 249)
+        calc = refw.WeightsCalculatorFactory(cfg, 100, 1e-8, corr, SCHEMES[scheme])
+        rows, its1, its2 = [], [], []
+        for idx in [np.arange(250)] + list(g12["idx"]):
+            est = Estimator(cfg)
+            del _per_solver[:]
+            fd, sc, w = est.estimate(calc, filtered.iloc[idx, :])
+            cfg2 = est.config()
+            its1.append(_per_solver[0][1]); its2.append(_per_solver[1][1])
+            lvs2 = list(cfg2.path())
+            mvs2 = [mv for lv in lvs2 for mv in cfg2.mvs(lv)]
+            im = refim.InnerModel(cfg2.path(), sc)
+            eff = im.effects()
+            ld = (sc.apply(lambda s: fd.corrwith(s)) * cfg2.odm(cfg2.path())).sum(axis=1).loc[mvs2].values.astype(float)
+            rows.append(np.concatenate((w.loc[mvs2, "weight"].values.astype(float), im.r_squared().loc[lvs2].values.astype(float),
+                                        eff.loc[:, "total"].values.astype(float), eff.loc[:, "direct"].values.astype(float), ld)))
+        g12[tag + "/lvs2"] = np.array(lvs2); g12[tag + "/mvs2"] = np.array(mvs2)
+        g12[tag + "/path2"] = cfg2.path().values.astype(int)
+        g12[tag + "/eff_from"] = np.array([lvs2.index(x) for x in eff["from"]]); g12[tag + "/eff_to"] = np.array([lvs2.index(x) for x in eff["to"]])
+        g12[tag + "/rows"] = np.array(rows); g12[tag + "/iters1"] = np.array(its1); g12[tag + "/iters2"] = np.array(its2)
+    save("g12_hoc_two_stage", **g12)
     print("done in %.1f s" % (time.time() - t0))
 
 

@@ -10,6 +10,7 @@
 
 #include "../../plspm-python_amd/csrc/solver_core.h"
 #include "../../plspm-python_amd/csrc/solver_nmg.h"
+#include "../../plspm-python_amd/csrc/solver_hoc.h"
 
 using namespace plspm;
 
@@ -95,6 +96,16 @@ static void run_group(int nthreads_in, int P, int L, const ModelDesc& md, double
             HostExec ex{t, nthreads, &bar, ws.red};
             body(ex, ws);
         });
+    for (auto& x : th) x.join();
+}
+
+template <class Body>
+static void run_plain(int nthreads_in, Body body) {
+    const int nthreads = nthreads_in > 16 ? 16 : nthreads_in;
+    std::vector<double> red(nthreads);
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { HostExec ex{t, nthreads, &bar, red.data()}; body(ex); });
     for (auto& x : th) x.join();
 }
 
@@ -246,6 +257,27 @@ void hostemu_impute_collapse(int P, int Qa, int Ta, int Ts, const int* ind_of, c
             impute_collapse(ex, P, Qa, Ta, Ts, ind_of, Min, Mout, gam.data());
         });
     for (auto& x : th) x.join();
+}
+
+// ---- two-stage higher order constructs (solver_hoc.h)
+static HocDesc emu_hoc_desc(int P1, int L1, int P2, int L2, int T1, int T2, const int* boff1, const int* boff2, const int* lv_first, const int* col2_lv1,
+                            const int* col2_p1, int nh, const int* hcol, const int* hidx) {
+    HocDesc hd{};
+    hd.P1 = P1; hd.L1 = L1; hd.P2 = P2; hd.L2 = L2; hd.T1 = T1; hd.T2 = T2; hd.boff1 = boff1; hd.boff2 = boff2; hd.lv_first = lv_first;
+    hd.col2_lv1 = col2_lv1; hd.col2_p1 = col2_p1; hd.nh = nh; hd.hcol = hcol; hd.hidx = hidx;
+    return hd;
+}
+void hostemu_hoc_moments(int P1, int L1, int P2, int L2, int T1, int T2, const int* boff1, const int* boff2, const int* lv_first, const int* col2_lv1,
+                         const int* col2_p1, int nh, const int* hcol, const int* hidx, const double* M1, const double* c1, const double* k1, int ok,
+                         double* M2, int nthreads) {
+    const HocDesc hd = emu_hoc_desc(P1, L1, P2, L2, T1, T2, boff1, boff2, lv_first, col2_lv1, col2_p1, nh, hcol, hidx);
+    std::vector<double> V((size_t)(nh > 0 ? nh : 1) * (P1 + 1));
+    run_plain(nthreads, [&](HostExec& ex) { hoc_second_stage_moments(ex, hd, M1, c1, k1, ok != 0, M2, V.data()); });
+}
+void hostemu_hoc_compose(int P1, int L1, int P2, int L2, const int* boff1, const int* boff2, const int* lv_first, const int* col2_lv1, const double* c1,
+                         const double* k1, double* state2, double* pseudo, int nthreads) {
+    const HocDesc hd = emu_hoc_desc(P1, L1, P2, L2, 0, 0, boff1, boff2, lv_first, col2_lv1, nullptr, 0, nullptr, nullptr);
+    run_plain(nthreads, [&](HostExec& ex) { NmState st2; nm_carve(st2, state2, P2, L2); hoc_compose_score_maps(ex, hd, c1, k1, st2, pseudo); });
 }
 
 long hostemu_packed_index(int T, int p, int q) { return packed_index(T, p, q); }

@@ -1,0 +1,118 @@
+"""GPU parity of the two-stage higher-order-construct bootstrap (plspm_model_attach_second_stage, csrc/solver_hoc.h) against the
+reference-generated golden g12 (mobi, seminr HOC model: fit and bootstrap replicates on explicit indices) and the oracle."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import plspm_oracle as orc
+from helpers import GOLDEN, assert_close, load
+from test_oracle_golden import MOBI_C1, MOBI_STAGE2, mobi_hoc_inputs, mobi_hoc_model
+
+pytestmark = pytest.mark.gpu
+SCHEME_ID = {"centroid": 0, "factorial": 1, "path": 2}
+RTOL, ATOL = 1e-6, 1e-9
+
+
+def handles(tag, max_iter=100):
+    from plspm import _native
+    g = load("g12_hoc_two_stage")
+    X, blocks, _ = mobi_hoc_inputs()
+    model1 = mobi_hoc_model(tag, blocks)
+    boff1 = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+    modes1 = np.array([0 if m == "A" else 1 for m in model1.modes], dtype=np.int32)
+    first = _native.NativeModel(boff1, MOBI_C1.astype(np.uint8), modes1, SCHEME_ID[model1.scheme], True, max_iter, 1e-8, 0, nonmetric=True)
+    first.upload(X)
+    boff2 = np.array([0, 7, 10, 12, 15, 16], dtype=np.int32)
+    modes2 = np.array([modes1[0], 0, 0, 0, 0], dtype=np.int32)
+    second = _native.NativeModel(boff2, g[tag + "/path2"].astype(np.uint8), modes2, SCHEME_ID[model1.scheme], True, max_iter, 1e-8, 0, nonmetric=True)
+    return first, second, X, model1, g
+
+
+@pytest.mark.parametrize("tag", ["path_B", "centroid_A"])
+def test_two_stage_bootstrap_rows_vs_reference_golden(tag):
+    first, second, X, model1, g = handles(tag)
+    first.attach_second_stage(second, [0, 1, 2, 4, 5, 6])
+    assert first.row_width == 2 * 16 + 5 + 2 * 8
+    assert list(first.eff_from) == list(g[tag + "/eff_from"]) and list(first.eff_to) == list(g[tag + "/eff_to"])
+    idx = np.vstack([np.arange(250), g["idx"]]).astype(np.int32)
+    rows, status, iters = first.bootstrap(5, idx=idx)
+    assert np.all(status == 0) and np.array_equal(iters, g[tag + "/iters2"])
+    assert_close(rows, g[tag + "/rows"], RTOL, ATOL)
+    # device-side resampling + sharding invariance, spot-checked against the oracle
+    from plspm import _native
+    rows, status, iters = first.bootstrap(96, seed=8)
+    assert np.all(status == 0)
+    corr = orc.correction(250)
+    for r in (0, 95):
+        o = orc.fit_two_stage(X[_native.bootstrap_indices(8, r, 250)], model1, MOBI_STAGE2, g[tag + "/path2"], model1.modes[0] + "AAAA", corr)
+        assert o["iterations"] == iters[r]
+        assert_close(rows[r], np.concatenate((o["weights"], o["r2"], o["total"], o["direct"], o["loadings"])), RTOL, ATOL)
+    tail, _, _ = first.bootstrap(16, seed=8, rep_offset=80)
+    assert np.array_equal(tail, rows[80:])
+    table, used = first.summary(96, rows[0])
+    assert used == 96 and table.shape == (first.row_width, 6)
+    assert_close(table[:, 1], rows.mean(axis=0), 1e-10, 1e-12)
+
+
+def test_failed_first_stage_drops_the_replicate():
+    first, second, X, model1, g = handles("path_B", max_iter=3)         # stage 1 needs 8+ iterations
+    first.attach_second_stage(second, [0, 1, 2, 4, 5, 6])
+    rows, status, iters = first.bootstrap(4, seed=1)
+    assert np.all(status != 0)
+
+
+def test_attach_rejects_inconsistent_pairs():
+    from plspm._native import NativeBackendError
+    first, second, *_ = handles("path_B")
+    with pytest.raises(NativeBackendError):
+        first.attach_second_stage(second, [0, 1, 2, 3, 5, 6])           # HOC block of 2 columns standing for one 5-column LV
+    with pytest.raises(NativeBackendError):
+        first.attach_second_stage(second, [0, 1, 2, 4, 5, 5])
+    first.attach_second_stage(second, [0, 1, 2, 4, 5, 6])
+    with pytest.raises(NativeBackendError):
+        first.attach_second_stage(second, [0, 1, 2, 4, 5, 6])           # already paired
+    second.close()                                                      # destroy order is free
+    first.close()
+
+
+def test_api_bootstrap_of_a_hoc_model():
+    """Plspm(..., bootstrap=True) on the reference's seminr HOC model (tests/test_regression_seminr.py:49-74)."""
+    import plspm.config as c
+    from plspm import _native
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    mobi = pd.read_csv(os.path.join(GOLDEN, "ref_data", "mobi.csv"), index_col=0)
+    structure = c.Structure()
+    structure.add_path(["Expectation", "Quality"], ["Satisfaction"])
+    structure.add_path(["Satisfaction"], ["Complaints", "Loyalty"])
+    config = c.Config(structure.path(), default_scale=Scale.NUM)
+    config.add_higher_order("Satisfaction", Mode.A, ["Image", "Value"])
+    config.add_lv_with_columns_named("Expectation", Mode.A, mobi, "CUEX")
+    config.add_lv_with_columns_named("Quality", Mode.B, mobi, "PERQ")
+    config.add_lv_with_columns_named("Loyalty", Mode.A, mobi, "CUSL")
+    config.add_lv_with_columns_named("Image", Mode.A, mobi, "IMAG")
+    config.add_lv_with_columns_named("Complaints", Mode.A, mobi, "CUSCO")
+    config.add_lv_with_columns_named("Value", Mode.A, mobi, "PERV")
+    pls = Plspm(mobi, config, Scheme.PATH, 100, 0.00000001, bootstrap=True, bootstrap_iterations=200, seed=6)
+    boot = pls.bootstrap()
+    w = boot.weights()
+    g = load("g12_hoc_two_stage")
+    assert sorted(w.index) == sorted(g["path_B/mvs2"])                  # stage-2 MVs: the constituents appear as MVs of the HOC
+    assert np.all(np.isfinite(w[["mean", "std.error", "perc.025", "perc.975"]].values))
+    om = pls.outer_model()
+    assert_close(w.loc[om.index, "original"].values, om["weight"].values, 1e-12)
+    assert_close(w.loc[list(g["path_B/mvs2"]), "original"].values, g["path_B/rows"][0][:16], 1e-6)
+    assert np.all(np.abs(w["mean"] - w["original"]) < 5 * w["std.error"] + 1e-3)
+    assert boot.r_squared().shape[0] == 3 and boot.total_effects().shape[0] == 8
+    assert int((boot.status() == 0).sum()) >= 190
+    # replicate 3 of the seeded stream against the oracle
+    X, blocks, _ = mobi_hoc_inputs()
+    model1 = mobi_hoc_model("path_B", blocks)
+    o = orc.fit_two_stage(X[_native.bootstrap_indices(6, 3, 250)], model1, MOBI_STAGE2, g["path_B/path2"], "BAAAA", orc.correction(250))
+    mine = boot._replicates                                             # noqa: SLF001 (rows in device order, failed ones dropped)
+    assert boot.status()[:4].tolist() == [0, 0, 0, 0]
+    assert_close(mine[3][16:16 + 5 + 16], np.concatenate((o["r2"], o["total"], o["direct"])), RTOL, ATOL)

@@ -334,3 +334,43 @@ def test_reference_csv_russa_categorical():
         assert_close(r["r2"], summ.loc[lv, "r_squared"].values, 1e-7, 1e-12)
         comm = np.array([np.mean(r["loadings"][b] ** 2) for b in RUSSA_CAT_BLOCKS])
         assert_close(comm, summ.loc[lv, "block_communality"].values, 1e-7)
+
+
+# ------------------------------------------------------------------ higher order constructs, two-stage (estimator.py:29-55)
+MOBI_STAGE2_LVS = ["Quality", "Expectation", "Satisfaction", "Loyalty", "Complaints"]
+MOBI_STAGE1_LVS = ["Quality", "Expectation", "Image", "Value", "Loyalty", "Complaints"]       # the HOC expanded in place
+MOBI_PREFIX = {"Quality": "PERQ", "Expectation": "CUEX", "Image": "IMAG", "Value": "PERV", "Loyalty": "CUSL", "Complaints": "CUSCO"}
+MOBI_C1 = np.array([[0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0]])
+MOBI_STAGE2 = [("lv", 0), ("lv", 1), ("hoc", [2, 3]), ("lv", 4), ("lv", 5)]
+
+
+def mobi_hoc_inputs():
+    mobi = pd.read_csv(os.path.join(GOLDEN, "ref_data", "mobi.csv"), index_col=0)
+    cols, blocks = [], []
+    for lv in MOBI_STAGE1_LVS:
+        names = [col for col in mobi.columns if col.startswith(MOBI_PREFIX[lv])]
+        blocks.append(np.arange(len(cols), len(cols) + len(names)))
+        cols.extend(names)
+    return mobi[cols].values.astype(np.float64), blocks, cols
+
+
+def mobi_hoc_model(tag, blocks):
+    scheme, qmode = tag.split("_")
+    return orc.Model(blocks, MOBI_C1, qmode + "AAAAA", scheme, True, tol=1e-8, scales=["NUM"] * 21)
+
+
+@pytest.mark.parametrize("tag", ["path_B", "centroid_A"])
+def test_g12_hoc_two_stage_fit_and_bootstrap_rows(tag):
+    g = load("g12_hoc_two_stage")
+    assert list(g[tag + "/lvs2"]) == MOBI_STAGE2_LVS
+    X, blocks, cols = mobi_hoc_inputs()
+    model1 = mobi_hoc_model(tag, blocks)
+    C2 = g[tag + "/path2"]
+    modes2 = model1.modes[0] + "AAAA"
+    corr = orc.correction(250)
+    for k, idx in enumerate([np.arange(250)] + list(g["idx"])):
+        r = orc.fit_two_stage(X[idx], model1, MOBI_STAGE2, C2, modes2, corr)
+        assert r["iterations1"] == int(g[tag + "/iters1"][k]) and r["iterations"] == int(g[tag + "/iters2"][k])
+        assert [p[0] for p in r["effect_pairs"]] == list(g[tag + "/eff_from"]) and [p[1] for p in r["effect_pairs"]] == list(g[tag + "/eff_to"])
+        row = np.concatenate((r["weights"], r["r2"], r["total"], r["direct"], r["loadings"]))
+        assert_close(row, g[tag + "/rows"][k], RTOL, 1e-12, what="%s replicate %d" % (tag, k))
