@@ -203,6 +203,8 @@ def treat_numpy(v):
 def treat_nonmetric(X):
     """Config.treat non-metric branch (config.py:314): util.treat(data) / sqrt((N-1)/N), i.e. population-standardised."""
     n = X.shape[0]
+    if np.isnan(X).any():                                         # pandas mean / std skip NaN; N stays the row count
+        return (X - np.nanmean(X, axis=0)) / np.nanstd(X, axis=0, ddof=1) / math.sqrt((n - 1) / n)
     return (X - X.mean(axis=0)) / np.std(X, axis=0, ddof=1) / math.sqrt((n - 1) / n)
 
 
@@ -255,7 +257,16 @@ def nm_init_scores(X0, model: Model):
     """_NonmetricWeights.__init__ (weights.py:82-98, no missing data): equal weights 1/sqrt(k) per block, on the treated values."""
     Y = np.zeros((X0.shape[0], model.L))
     for l, b in enumerate(model.blocks):
-        Y[:, l] = X0[:, b] @ (np.ones(len(b)) / math.sqrt(len(b)))
+        w = np.ones(len(b)) / math.sqrt(len(b))
+        Xb = X0[:, b]
+        if np.isnan(Xb).any():                                    # weights.py:88-96: NaN-aware, per-row normaliser
+            present = ~np.isnan(Xb)
+            den = ((w[None, :] * present) ** 2).sum(axis=1)
+            if np.any(den == 0):
+                raise ValueError("All mvs for an lv are NaN in some row")
+            Y[:, l] = np.nansum(Xb * w[None, :], axis=1) / den
+        else:
+            Y[:, l] = Xb @ w
     return Y
 
 
@@ -280,7 +291,8 @@ def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
             for j, p in enumerate(b):
                 kind = model.scales[p]
                 if kind == "NUM":
-                    cur[:, p] = treat_numpy(X0[:, p]) * math.sqrt(n / (n - 1))          # scale.py:27-30
+                    f = int(np.isfinite(X0[:, p]).sum())                                # scale.py:27-30 (finite cells only)
+                    cur[:, p] = treat_numpy(X0[:, p]) * math.sqrt(f / (f - 1))
                 elif kind == "RAW":
                     cur[:, p] = X0[:, p]                                                # scale.py:38-39
                 else:
@@ -301,18 +313,26 @@ def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
                         xq = d @ means                                                  # scale.py:87
                     cur[:, p] = treat_numpy(xq) * corr
             Xk = cur[:, b]
-            if model.modes[l] == "A":
-                w = (Xk.T @ z) / np.sum(z ** 2)
+            if np.isnan(X0[:, b]).any():                                                # "lv in mv_grouped_by_lv_missing" (weights.py:88-89)
+                if model.modes[l] != "A":
+                    raise Exception("Missing nonmetric data is not supported in mode B")  # mode.py:55-56
+                present = (~np.isnan(X0[:, b])).astype(np.float64)
+                w = np.nansum(Xk * z[:, None], axis=0) / ((present * z[:, None]) ** 2).sum(axis=0)      # mode.py:35-36
+                y = np.nansum(Xk * w[None, :], axis=1) / ((present * w[None, :]) ** 2).sum(axis=1)      # mode.py:37-38
             else:
-                w = np.linalg.lstsq(Xk, z, rcond=None)[0]
+                if model.modes[l] == "A":
+                    w = (Xk.T @ z) / np.sum(z ** 2)
+                else:
+                    w = np.linalg.lstsq(Xk, z, rcond=None)[0]
+                y = Xk @ w
             W[b, l] = w
-            Y[:, l] = treat_numpy(Xk @ w) * corr
+            Y[:, l] = treat_numpy(y) * corr
         conv = float(np.sum((np.abs(Y_old) - np.abs(Y)) ** 2))                          # weights.py:120
         if conv < model.tol or iteration > model.max_iter:
             break
     if iteration > model.max_iter:
         raise NotConverged("Could not converge after %d iterations" % iteration)
-    wf = 1.0 / (np.std(cur @ W, axis=0, ddof=1) / corr)            # weights.py:130
+    wf = 1.0 / (np.nanstd(cur @ W, axis=0, ddof=1) / corr)         # weights.py:130 (a NaN anywhere in a row drops the row: NaN * 0)
     weights = (W * wf).sum(axis=1)                                # weights.py:131-132
     return dict(scores=Y, weights=weights, iterations=iteration, data=cur)
 
@@ -365,6 +385,13 @@ def effects(B):
 
 def crossloadings(Xt, scores):
     """OuterModel.__init__ (outer_model.py:26): Pearson correlation of every MV with every LV score."""
+    if np.isnan(Xt).any():                                        # DataFrame.corrwith: pairwise-complete observations per MV
+        out = np.zeros((Xt.shape[1], scores.shape[1]))
+        for p in range(Xt.shape[1]):
+            ok = ~np.isnan(Xt[:, p])
+            for l in range(scores.shape[1]):
+                out[p, l] = np.corrcoef(Xt[ok, p], scores[ok, l])[0, 1]
+        return out
     n = Xt.shape[0]
     Xc = Xt - Xt.mean(axis=0)
     Sc = scores - scores.mean(axis=0)

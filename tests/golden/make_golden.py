@@ -386,6 +386,41 @@ def main():
         g12[tag + "/eff_from"] = np.array([lvs2.index(x) for x in eff["from"]]); g12[tag + "/eff_to"] = np.array([lvs2.index(x) for x in eff["to"]])
         g12[tag + "/rows"] = np.array(rows); g12[tag + "/iters1"] = np.array(its1); g12[tag + "/iters2"] = np.array(its2)
     save("g12_hoc_two_stage", **g12)
+    # ---- G13: non-metric data with missing values (weights.py:88-98, mode.py:35-39, scale.py:27-30; reference
+    #      tests/test_regression_nonmetric.py:122-138): russa with the test's three NaNs + a synthetic case, fits and bootstrap rows
+    g13 = {}
+    russam = russa.copy()
+    russam.iloc[0, 0] = np.nan; russam.iloc[3, 3] = np.nan; russam.iloc[5, 5] = np.nan
+    rs13 = np.random.RandomState(1313)
+    g13["idx47"] = rs13.randint(47, size=(6, 47))
+    for scheme in SCHEMES:
+        cfg = build_config(C8, lv8, bn8, "AAA", True, add_order=["AGRI", "IND", "POLINS"], default_scale=Scale.NUM)
+        m, out = run_fit(russam, cfg, scheme, lv8, tol=1e-7)
+        for k, v in out.items():
+            g13["russa_%s/%s" % (scheme, k)] = v
+        rows, its = boot_rows(russam, cfg, scheme, lv8, list(g13["idx47"]), list(m.effects().index), tol=1e-7)
+        g13["russa_%s/boot_rows" % scheme] = rows
+        g13["russa_%s/boot_iters" % scheme] = its
+    Cs = orc.satisfaction_C()
+    Xs, blocks_s = orc.synth(300, Cs, 4, seed=13)
+    Xm = Xs.copy()
+    for _ in range(45):
+        Xm[rs13.randint(300), rs13.randint(16)] = np.nan               # LVs 0-3 get holes, LVs 4-5 stay complete (Mode B allowed there)
+    names13 = ["v%d" % i for i in range(24)]
+    df13 = pd.DataFrame(Xm, columns=names13)
+    bn13 = [[names13[i] for i in b] for b in blocks_s]
+    g13["synth"] = Xm
+    g13["idx300"] = rs13.randint(300, size=(3, 300))
+    for tag, modes, scheme in (("A_path", "AAAAAA", "path"), ("M_centroid", "AAAABB", "centroid"), ("A_factorial", "AAAAAA", "factorial")):
+        cfg = build_config(Cs, orc.SAT_LVS, bn13, modes, True, default_scale=Scale.NUM)
+        m, out = run_fit(df13, cfg, scheme, orc.SAT_LVS, tol=1e-7)
+        for k, v in out.items():
+            if k != "mv_names":
+                g13["synth_%s/%s" % (tag, k)] = v
+        rows, its = boot_rows(df13, cfg, scheme, orc.SAT_LVS, list(g13["idx300"]), list(m.effects().index), tol=1e-7)
+        g13["synth_%s/boot_rows" % tag] = rows
+        g13["synth_%s/boot_iters" % tag] = its
+    save("g13_nonmetric_missing", **g13)
     print("done in %.1f s" % (time.time() - t0))
 
 

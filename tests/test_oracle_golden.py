@@ -374,3 +374,60 @@ def test_g12_hoc_two_stage_fit_and_bootstrap_rows(tag):
         assert [p[0] for p in r["effect_pairs"]] == list(g[tag + "/eff_from"]) and [p[1] for p in r["effect_pairs"]] == list(g[tag + "/eff_to"])
         row = np.concatenate((r["weights"], r["r2"], r["total"], r["direct"], r["loadings"]))
         assert_close(row, g[tag + "/rows"][k], RTOL, 1e-12, what="%s replicate %d" % (tag, k))
+
+
+# ------------------------------------------------------------------ non-metric data with missing values (weights.py:88-98, mode.py:35-39)
+RUSSA_M_COLS = ["gini", "farm", "rent", "gnpr", "labo", "ecks", "death", "demo", "inst"]
+RUSSA_M_BLOCKS = [np.array([0, 1, 2]), np.array([3, 4]), np.array([5, 6, 7, 8])]
+
+
+def russa_missing_matrix():
+    russa = pd.read_csv(os.path.join(GOLDEN, "ref_data", "russa.csv"), index_col=0)
+    russa.iloc[0, 0] = np.nan; russa.iloc[3, 3] = np.nan; russa.iloc[5, 5] = np.nan          # reference test_regression_nonmetric.py:124-126
+    return russa[RUSSA_M_COLS].values.astype(np.float64)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_g13_russa_nonmetric_missing(scheme):
+    g = load("g13_nonmetric_missing")
+    key = "russa_" + scheme
+    assert list(g[key + "/mv_names"]) == RUSSA_M_COLS
+    X = russa_missing_matrix()
+    assert np.isnan(X).sum() == 3
+    model = orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "AAA", scheme, True, tol=1e-7, scales=["NUM"] * 9)
+    _check_fit(orc.fit(X, model), g, key)
+    corr = orc.correction(47)
+    for idx, row, it in zip(g["idx47"], g[key + "/boot_rows"], g[key + "/boot_iters"]):
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-12, what=key)
+
+
+@pytest.mark.parametrize("tag", ["A_path", "M_centroid", "A_factorial"])
+def test_g13_synthetic_nonmetric_missing(tag):
+    g = load("g13_nonmetric_missing")
+    X = g["synth"]
+    modes, scheme = tag.split("_")
+    blocks = [np.arange(4 * j, 4 * j + 4) for j in range(6)]
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA" if modes == "A" else "AAAABB", scheme, True, tol=1e-7, scales=["NUM"] * 24)
+    key = "synth_" + tag
+    _check_fit(orc.fit(X, model), g, key)
+    corr = orc.correction(300)
+    for idx, row, it in zip(g["idx300"], g[key + "/boot_rows"], g[key + "/boot_iters"]):
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-12, what=key)
+
+
+def test_reference_csv_russa_missing():
+    """reference tests/test_regression_nonmetric.py:122-138 (R plspm output)."""
+    X = russa_missing_matrix()
+    model = orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "AAA", "centroid", True, tol=1e-7, scales=["NUM"] * 9)
+    r = orc.fit(X, model)
+    summ = pd.read_csv(os.path.join(GOLDEN, "ref_data", "russa.missing.inner_summary.csv"), index_col=0)
+    lv = ["AGRI", "IND", "POLINS"]
+    assert_close(r["r2"], summ.loc[lv, "r_squared"].values, 1e-7, 1e-12)
+    comm = np.array([np.mean(r["loadings"][b] ** 2) for b in RUSSA_M_BLOCKS])
+    assert_close(comm, summ.loc[lv, "block_communality"].values, 1e-7)
+    with pytest.raises(Exception):
+        orc.fit(X, orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "BAA", "centroid", True, tol=1e-7, scales=["NUM"] * 9))
