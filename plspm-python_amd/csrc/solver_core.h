@@ -478,6 +478,45 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
     finish_problem(ex, md, ws, out, iteration, true);
 }
 
+// Inner model (inner_model.py:58-75: OLS with intercept == centred normal equations on the score covariance ws.Cs) and the
+// effects (inner_model.py:33-53): indirect = sum_{k=2..L} B^k (none when L == 2), total = B + indirect.  -> ws.Bm, ws.r2, ws.Ind
+template <class Ex>
+PLSPM_HD void inner_model_effects(Ex& ex, const ModelDesc& md, Workspace& ws) {
+    const int L = md.L;
+    ex.par(L, [&](int i) {
+        for (int j = 0; j < L; ++j) ws.Bm[i * L + j] = 0.0;
+        ws.r2[i] = 0.0;
+        const int km = md.kmax;
+        double* scratch = ws.scr + (long)i * (km * km + km);
+        const int* f = md.pred_idx + md.pred_off[i];
+        const int k = md.pred_off[i + 1] - md.pred_off[i];
+        if (k > 0) {
+            double* x = scratch + km * km;
+            if (!spd_solve(ws.Cs, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
+            double expl = 0.0;
+            for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = x[r]; expl += x[r] * ws.Cs[f[r] * L + i]; }
+            ws.r2[i] = expl / ws.Cs[i * L + i];
+        }
+    });
+    ex.mark(5);
+    ex.par(L * L, [&](int e) { ws.Ind[e] = 0.0; ws.Pw[e] = ws.Bm[e]; });
+    if (L != 2) {
+        double* cur = ws.Pw;
+        double* nxt = ws.Pw2;
+        for (int k = 2; k <= L; ++k) {
+            ex.par(L * L, [&](int e) {
+                const int r = e / L, c = e - r * L;
+                double s = 0.0;
+                for (int t = 0; t < L; ++t) s += cur[r * L + t] * ws.Bm[t * L + c];
+                nxt[e] = s;
+                ws.Ind[e] += s;
+            });
+            if (!ex.any(L * L, [&](int e) { return nxt[e] != 0.0; })) break;   // B is nilpotent: further powers vanish exactly
+            double* t = cur; cur = nxt; nxt = t;
+        }
+    }
+}
+
 // Everything after the iteration (shared by the metric and the non-metric solver): final normalisation, the metric sign
 // rule, inner model, effects, loadings, outputs.  Expects the last weights in ws.w and the treated covariance in ws.S.
 template <class Ex>
@@ -501,40 +540,7 @@ PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const F
     ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.Cs[e] = ws.sgn[l] * ws.sgn[m] * ws.wf[l] * ws.wf[m] * ws.Q[e]; });
 
     ex.mark(4);
-    // inner model (inner_model.py:58-75): OLS with intercept == centred normal equations on the score covariance
-    ex.par(L, [&](int i) {
-        for (int j = 0; j < L; ++j) ws.Bm[i * L + j] = 0.0;
-        ws.r2[i] = 0.0;
-        const int km = md.kmax;
-        double* scratch = ws.scr + (long)i * (km * km + km);
-        const int* f = md.pred_idx + md.pred_off[i];
-        const int k = md.pred_off[i + 1] - md.pred_off[i];
-        if (k > 0) {
-            double* x = scratch + km * km;
-            if (!spd_solve(ws.Cs, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
-            double expl = 0.0;
-            for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = x[r]; expl += x[r] * ws.Cs[f[r] * L + i]; }
-            ws.r2[i] = expl / ws.Cs[i * L + i];
-        }
-    });
-    ex.mark(5);
-    // effects (inner_model.py:33-53): indirect = sum_{k=2..L} B^k (none when L == 2), total = B + indirect
-    ex.par(L * L, [&](int e) { ws.Ind[e] = 0.0; ws.Pw[e] = ws.Bm[e]; });
-    if (L != 2) {
-        double* cur = ws.Pw;
-        double* nxt = ws.Pw2;
-        for (int k = 2; k <= L; ++k) {
-            ex.par(L * L, [&](int e) {
-                const int r = e / L, c = e - r * L;
-                double s = 0.0;
-                for (int t = 0; t < L; ++t) s += cur[r * L + t] * ws.Bm[t * L + c];
-                nxt[e] = s;
-                ws.Ind[e] += s;
-            });
-            if (!ex.any(L * L, [&](int e) { return nxt[e] != 0.0; })) break;   // B is nilpotent: further powers vanish exactly
-            double* t = cur; cur = nxt; nxt = t;
-        }
-    }
+    inner_model_effects(ex, md, ws);
 
     ex.mark(6);
     // outputs

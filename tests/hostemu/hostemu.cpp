@@ -11,6 +11,7 @@
 #include "../../plspm-python_amd/csrc/solver_core.h"
 #include "../../plspm-python_amd/csrc/solver_nmg.h"
 #include "../../plspm-python_amd/csrc/solver_hoc.h"
+#include "../../plspm-python_amd/csrc/solver_nmx.h"
 
 using namespace plspm;
 
@@ -278,6 +279,30 @@ void hostemu_hoc_compose(int P1, int L1, int P2, int L2, const int* boff1, const
                          const double* k1, double* state2, double* pseudo, int nthreads) {
     const HocDesc hd = emu_hoc_desc(P1, L1, P2, L2, 0, 0, boff1, boff2, lv_first, col2_lv1, nullptr, 0, nullptr, nullptr);
     run_plain(nthreads, [&](HostExec& ex) { NmState st2; nm_carve(st2, state2, P2, L2); hoc_compose_score_maps(ex, hd, c1, k1, st2, pseudo); });
+}
+
+// ---- non-metric data with missing values (solver_nmx.h).  mode_op: 0 prepare, 1 step (returns active), 2 finish.  The caller
+// writes the incomplete rows' weights ck[K] at state[nm_state_doubles(P, L, n_chol)] before the prepare call.
+long hostemu_nmx_state_doubles(int P, int L, int n_chol, int K) { return nmx_state_doubles(P, L, n_chol, K); }
+int hostemu_nmx(int mode_op, int P, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode, int K,
+                const double* Xk, const double* Mk, const double* Mp, int nthreads, double* S, double* state, const double* partial, int nparts, int n_eff,
+                const int* eff_from, const int* eff_to, double* row, double* crossloadings, double* path_coef, double* score_w, double* score_c, double* cov,
+                int* iters, int* status) {
+    std::vector<double> shift(P, 0.0);
+    EmuModel em(P, L, PA, scheme, 1, max_iter, tol, boff, C, mode, shift.data(), n_eff, eff_from, eff_to);
+    MissDesc xd{K, Xk, Mk};
+    int active = 0;
+    FitOutputs out{};
+    out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.score_w = score_w; out.score_c = score_c; out.cov = cov;
+    out.iters = iters; out.status = status;
+    run_group(nthreads, P, L, em.md, S, [&](HostExec& ex, Workspace& ws) {
+        NmState st; nm_carve(st, state, P, L);
+        NmxExtra x; nmx_carve(x, state + nm_state_doubles(P, L, em.md.n_chol), P, L, K);
+        if (mode_op == 0) nmx_prepare(ex, em.md, xd, ws, st, x, Mp);
+        else if (mode_op == 1) { const bool a = nmx_step(ex, em.md, xd, ws, st, x, partial, nparts); if (ex.tid == 0) active = a ? 1 : 0; }
+        else nmx_finish(ex, em.md, xd, ws, st, x, out);
+    });
+    return active;
 }
 
 long hostemu_packed_index(int T, int p, int q) { return packed_index(T, p, q); }
