@@ -137,6 +137,19 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
  */
 int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols, int32_t layout, const int32_t* col_index);
 
+/*
+ * Non-metric (Scale.NUM) data with missing values (reference weights.py:88-98, mode.py:35-41, scale.py:27-30; pairwise-complete
+ * loadings outer_model.py:26).  Call AFTER plspm_upload: K rows of the uploaded matrix have missing cells (their NaNs replaced by
+ * any finite value before the upload); rows in which a whole LV block is missing must have been dropped (config.py:273-285).
+ *   row_index  [K]    ascending row numbers
+ *   present    [K*P]  1 = cell present, 0 = missing (device column order)
+ * The rows move into a side table and become all-zero rows of the resident matrix, so the Gram kernels see the complete rows only;
+ * the solver adds the incomplete rows explicitly in every sum (solver_nmx.h), weighted by their bootstrap counts.  Mode B blocks
+ * must be complete in the data set at hand (mode.py:55-56): otherwise the fit / replicate reports PLSPM_SINGULAR.
+ * plspm_model_set_nonmetric(.., 1) handles only; not combinable with set_categorical / set_missing / a two-stage pair.
+ */
+int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* row_index, const uint8_t* present);
+
 /* Number of (from,to) effect rows = ordered LV pairs joined by a directed path; from-major order
  * (reference inner_model.py:46-52).  from/to may be NULL. */
 int32_t plspm_effect_pairs(const plspm_model_t* m, int32_t* from, int32_t* to);

@@ -21,6 +21,7 @@
 #include "solver_core.h"
 #include "solver_nmg.h"
 #include "solver_hoc.h"
+#include "solver_nmx.h"
 
 using namespace plspm;
 
@@ -854,6 +855,78 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     }
 }
 
+
+// Non-metric data with missing values (solver_nmx.h).  MODE 0 also looks up the bootstrap weight of every incomplete row in the
+// replicate's ordered (row, count) list (1 for a plain fit).
+template <int MODE>
+__global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, const int* __restrict__ rowid, const double* __restrict__ Mp, long mp_stride, SolverOut so,
+                                                  double* gS, double* gstate, long state_stride, const double* __restrict__ partial, int nparts,
+                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = gS + b * cov_doubles(md.P);
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    double* state = gstate + b * state_stride;
+    NmState st;
+    nm_carve(st, state, md.P, md.L);
+    NmxExtra x;
+    nmx_carve(x, state + nm_state_doubles(md.P, md.L, md.n_chol), md.P, md.L, xd.K);
+    if (MODE == 1 && st.scal[3] == 0.0) return;
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    if (MODE == 0) {
+        const int2* e = ent ? ent + b * ent_stride : nullptr;
+        const int ne = ent ? nent[b] : 0;
+        for (int j = threadIdx.x; j < xd.K; j += blockDim.x) {
+            double c = 1.0;
+            if (e) {
+                const int row = rowid[j];
+                int lo = 0, hi = ne;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (e[mid].x < row) lo = mid + 1; else hi = mid; }
+                c = (lo < ne && e[lo].x == row) ? (double)e[lo].y : 0.0;
+            }
+            x.ck[j] = c;
+        }
+        __syncthreads();
+        nmx_prepare(ex, md, xd, ws, st, x, Mp + b * mp_stride);
+    } else if (MODE == 1) {
+        const bool active = nmx_step(ex, md, xd, ws, st, x, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
+    } else {
+        FitOutputs out = so.fit;
+        if (b != 0) out = FitOutputs{};
+        out.row = so.row ? so.row + b * so.row_stride : nullptr;
+        out.status = so.status ? so.status + b : nullptr;
+        out.iters = so.iters ? so.iters + b : nullptr;
+        nmx_finish(ex, md, xd, ws, st, x, out);
+    }
+}
+
+// plspm_model_set_incomplete_rows: copy the incomplete rows (masked) into the side tables and zero them in Xa (data + ones column)
+__global__ void __launch_bounds__(256) extract_rows_kernel(double* __restrict__ Xa, int PA, int P, const int* __restrict__ rowid, const unsigned char* __restrict__ mask,
+                                                           double* __restrict__ Xk, double* __restrict__ Mk) {
+    const long j = blockIdx.x;
+    double* row = Xa + (long)rowid[j] * PA;
+    for (int p = threadIdx.x; p < PA; p += blockDim.x) {
+        if (p < P) {
+            const double present = mask[j * P + p] ? 1.0 : 0.0;
+            Mk[j * P + p] = present;
+            Xk[j * P + p] = present * row[p];
+        }
+        row[p] = 0.0;
+    }
+}
+
+// scores of the incomplete rows come from the solver state, not from the score map (plspm_fit)
+__global__ void __launch_bounds__(64) patch_scores_kernel(double* __restrict__ scores, int L, const int* __restrict__ rowid, const double* __restrict__ Yn) {
+    const long j = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) scores[(long)rowid[j] * L + l] = Yn[j * L + l];
+}
+
 // Streaming convergence pass (reference weights.py:120): for every still-active problem, sum over its observations (all rows,
 // or the (row,count) list of a bootstrap replicate) of count * sum_l (|y_old| - |y_new|)^2, with y = xa . c + k for the two
 // score maps in the state.  16-row tiles of Xa are staged in LDS like scores_kernel; blockIdx.x = part, blockIdx.y = problem.
@@ -1079,6 +1152,10 @@ struct plspm_model {
     int* d_lv_cols = nullptr;
     int *d_lv_first = nullptr, *d_col2_lv1 = nullptr, *d_col2_p1 = nullptr, *d_hcol = nullptr, *d_hidx = nullptr;
     Buf pseudo;
+    // non-metric data with missing values (solver_nmx.h): K incomplete rows live in side tables, their rows of Xa are zero
+    int nmx_K = 0;
+    double *d_Xk = nullptr, *d_Mk = nullptr;
+    int* d_rowid = nullptr;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
     bool profiling = false;
@@ -1245,7 +1322,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1279,6 +1356,10 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     HIPCHK(m, hipSetDevice(m->device));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (m->d_Xa) { HIPCHK(m, hipFree(m->d_Xa)); m->d_Xa = nullptr; }
+    if (m->nmx_K) {
+        hipFree(m->d_Xk); hipFree(m->d_Mk); hipFree(m->d_rowid);
+        m->d_Xk = m->d_Mk = nullptr; m->d_rowid = nullptr; m->nmx_K = 0;
+    }
     m->N = 0;
     double* d_raw = nullptr; int* d_ci = nullptr; double* d_partial = nullptr;
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
@@ -1412,10 +1493,11 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     const int P = m->P, L = m->L;
     const plspm_model* src = m->stage1 ? m->stage1 : m;          // an attached second stage streams its first stage's data (solver_hoc.h)
     const long N = src->N;
-    const bool cat = m->categorical != 0;
+    const bool cat = m->categorical != 0, nmx = m->nmx_K > 0;
     int rc;
     const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
-    const size_t st_doubles = cat ? (size_t)nmg_state_doubles(P, m->Pm, L, m->cmax, m->kmv) : (size_t)nm_state_doubles(P, L, m->n_chol);
+    const size_t st_doubles = cat ? (size_t)nmg_state_doubles(P, m->Pm, L, m->cmax, m->kmv)
+                                  : nmx ? (size_t)nmx_state_doubles(P, L, m->n_chol, m->nmx_K) : (size_t)nm_state_doubles(P, L, m->n_chol);
     const int nparts = (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
@@ -1427,6 +1509,9 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     if (lds > kMaxLds) return fail(m, PLSPM_E_LIMIT, "non-metric solver: workspace exceeds LDS");
     if (cat) {
         if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)))
+            return rc;
+    } else if (nmx) {
+        if ((rc = allow_lds(m, (const void*)nmx_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<2>, lds)))
             return rc;
     } else if ((rc = allow_lds(m, (const void*)nm_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<2>, lds)))
         return rc;
@@ -1452,6 +1537,11 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
         if (cat) {
             auto k = mode_op == 0 ? nmg_kernel<0> : mode_op == 1 ? nmg_kernel<1> : nmg_kernel<2>;
             hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact);
+        } else if (nmx) {
+            auto k = mode_op == 0 ? nmx_kernel<0> : mode_op == 1 ? nmx_kernel<1> : nmx_kernel<2>;
+            const MissDesc xd{m->nmx_K, m->d_Xk, m->d_Mk};
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, xd, (const int*)m->d_rowid, Mp, mp_stride, so, gS, gst, (long)st_doubles, (const double*)part, nparts,
+                               nact, ent, nent, ent_stride);
         } else {
             auto k = mode_op == 0 ? nm_kernel<0> : mode_op == 1 ? nm_kernel<1> : nm_kernel<2>;
             hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
@@ -1553,7 +1643,7 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     if (!first || !second || !lv_first || first == second) return fail(first, PLSPM_E_ARG, "plspm_model_attach_second_stage: bad arguments");
     plspm_model* m1 = first; plspm_model* m2 = second;
     if (m1->stage1 || m1->stage2 || m2->stage1 || m2->stage2) return fail(m1, PLSPM_E_STATE, "a handle takes part in one two-stage pair only");
-    if (!m1->nonmetric || !m2->nonmetric || m1->categorical || m2->categorical || m1->n_ind || m2->n_ind)
+    if (!m1->nonmetric || !m2->nonmetric || m1->categorical || m2->categorical || m1->n_ind || m2->n_ind || m1->nmx_K)
         return fail(m1, PLSPM_E_STATE, "two-stage estimation needs Scale.NUM / RAW handles (the reference's metric solver cannot run HOCs)");
     if (m2->d_Xa) return fail(m1, PLSPM_E_STATE, "the second stage takes no data of its own");
     if (m1->device != m2->device) return fail(m1, PLSPM_E_ARG, "both stages must live on one device");
@@ -1581,6 +1671,40 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     HIPCHK(m1, hipStreamDestroy(m2->stream));
     m2->stream = m1->stream; m2->owns_stream = false;
     m1->stage2 = m2; m2->stage1 = m1;
+    return 0;
+}
+
+int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* row_index, const uint8_t* present) {
+    if (!m || K < 1 || !row_index || !present) return fail(m, PLSPM_E_ARG, "plspm_model_set_incomplete_rows: bad arguments");
+    if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_model_set_incomplete_rows: call after plspm_upload");
+    if (!m->nonmetric || m->categorical || m->n_ind || m->stage1 || m->stage2 || m->nmx_K)
+        return fail(m, PLSPM_E_STATE, "plspm_model_set_incomplete_rows: Scale.NUM handles only, once per upload, no two-stage pair");
+    for (int j = 0; j < K; ++j) {
+        if (row_index[j] < 0 || row_index[j] >= m->N || (j && row_index[j] <= row_index[j - 1])) return fail(m, PLSPM_E_ARG, "row_index must be ascending and inside [0, N)");
+        int cells = 0;
+        for (int l = 0; l < m->L; ++l) {
+            int in_block = 0;
+            for (int p = m->boff[l]; p < m->boff[l + 1]; ++p) in_block += present[(size_t)j * m->P + p] ? 1 : 0;
+            if (!in_block) return fail(m, PLSPM_E_ARG, "a row with an entirely missing LV block must be dropped before the upload (config.py:273-285)");
+            cells += in_block;
+        }
+        if (cells == m->P) return fail(m, PLSPM_E_ARG, "a listed row has no missing cell");
+    }
+    HIPCHK(m, hipSetDevice(m->device));
+    unsigned char* d_mask = nullptr;
+    const size_t cells = (size_t)K * m->P;
+    HIPCHK(m, hipMalloc((void**)&m->d_Xk, cells * sizeof(double)));
+    HIPCHK(m, hipMalloc((void**)&m->d_Mk, cells * sizeof(double)));
+    HIPCHK(m, hipMalloc((void**)&m->d_rowid, (size_t)K * sizeof(int)));
+    HIPCHK(m, hipMalloc((void**)&d_mask, cells));
+    HIPCHK(m, hipMemcpyAsync(m->d_rowid, row_index, (size_t)K * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(m, hipMemcpyAsync(d_mask, present, cells, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(extract_rows_kernel, dim3((unsigned)K), dim3(256), 0, m->stream, m->d_Xa, m->PA, m->P, (const int*)m->d_rowid, (const unsigned char*)d_mask, m->d_Xk,
+                       m->d_Mk);
+    HIPCHK(m, hipGetLastError());
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipFree(d_mask));
+    m->nmx_K = K;
     return 0;
 }
 
@@ -1646,6 +1770,10 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
         const int grid = (int)std::min<long>(256 * 8, (N + SCORE_ROWS - 1) / SCORE_ROWS);
         ProfScope ps(m, PLSPM_K_SCORES);
         hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->rows.p);
+        if (m->nmx_K) {                                     // the incomplete rows' scores are not affine in the columns: take them from the state
+            const double* Yn = (const double*)m->nmstate.p + nm_state_doubles(P, L, m->n_chol) + m->nmx_K + 2L * P + (long)m->nmx_K * P + (long)m->nmx_K * L;
+            hipLaunchKernelGGL(patch_scores_kernel, dim3((unsigned)m->nmx_K), dim3(64), 0, m->stream, (double*)m->rows.p, L, (const int*)m->d_rowid, Yn);
+        }
     }
     HIPCHK(m, hipGetLastError());
     // ONE device->host copy of the whole result block into a pinned staging buffer, then scatter on the host

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
-EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing", "plspm_model_attach_second_stage",
+EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing", "plspm_model_attach_second_stage", "plspm_model_set_incomplete_rows",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
 
@@ -54,6 +54,7 @@ def load():
     lib.plspm_model_set_categorical.argtypes = [vp, i32, vp, vp]
     lib.plspm_model_set_missing.argtypes = [vp, i32, vp]
     lib.plspm_model_attach_second_stage.argtypes = [vp, vp, vp]
+    lib.plspm_model_set_incomplete_rows.argtypes = [vp, i32, vp, vp]
     lib.plspm_upload.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.plspm_effect_pairs.restype = i32
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
@@ -131,6 +132,15 @@ class NativeModel:
         self.row_width = lib.plspm_row_width(self._h)
         self.row_stride = lib.plspm_row_stride(self._h)     # device rows: [row | status | iterations]
         self.N = 0
+
+    def set_incomplete_rows(self, rows, present):
+        """Non-metric data with missing values (plspm_model_set_incomplete_rows), after ``upload``: ``rows`` ascending row numbers,
+        ``present`` [K, P] booleans in device column order."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        present = np.ascontiguousarray(present, dtype=np.uint8)
+        if present.shape != (len(rows), self.P):
+            raise ValueError("present must have shape (K, P)")
+        self._check(self._lib.plspm_model_set_incomplete_rows(self._h, len(rows), _ptr(rows), _ptr(present)), "plspm_model_set_incomplete_rows")
 
     def attach_second_stage(self, second, lv_first):
         """Two-stage HOC bootstrap (plspm_model_attach_second_stage): ``second`` is the data-less stage-2 handle; afterwards

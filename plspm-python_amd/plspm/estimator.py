@@ -50,10 +50,10 @@ class Estimator:
     def run(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame, want_scores=True, want_cov=False) -> SolverResult:
         calculator = calculator.clone()
         config = calculator.config()
-        if config.missing():
-            if not config.metric():
-                raise NotImplementedError("missing values in non-metric data are not part of the MI355X hot path yet; see SURVEY.md 8(f)")
-            # metric: util.impute (reference util.py:61-68, config.py:300) happens in WeightsCalculatorFactory.run / on the device
+        if config.missing() and not config.metric() and calculator._nonmetric() == 2:
+            raise NotImplementedError("missing values together with Scale.ORD / NOM are not part of the MI355X hot path; see SURVEY.md 8(f)")
+        # NaNs otherwise travel to WeightsCalculatorFactory.run: metric -> mean imputation on the moments (util.py:61-68, config.py:300),
+        # Scale.NUM -> incomplete rows handled explicitly by the device solver (weights.py:88-98, mode.py:35-41)
         hocs = config.hoc()
         if not hocs:
             self._config = config
@@ -94,8 +94,8 @@ class Estimator:
         calculator = calculator.clone()
         config = calculator.config()
         hocs = config.hoc()
-        if config.metric() or calculator._nonmetric() != 1:
-            raise NotImplementedError("bootstrapping higher order constructs needs Scale.NUM / Scale.RAW data")
+        if config.metric() or calculator._nonmetric() != 1 or data.isnull().values.any():
+            raise NotImplementedError("bootstrapping higher order constructs needs complete Scale.NUM / Scale.RAW data")
         path1 = self.expanded_first_stage_path(config)
         compiled1 = compile_model(config, path1, list(data.columns))
         first = _native.NativeModel(compiled1.block_offset, compiled1.path, compiled1.modes, calculator.scheme().value.code, config.scaled(),

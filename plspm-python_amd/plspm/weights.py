@@ -71,6 +71,24 @@ class WeightsCalculatorFactory:
         kinds = set(self._config.all_scales())
         return 1 if kinds.issubset({Scale.NUM, Scale.RAW}) else 2
 
+    def _incomplete_rows(self, compiled, values):
+        """Non-metric (Scale.NUM) data with NaNs: the rows with missing cells and their masks in device column order; the NaNs
+        themselves become column means for the upload (their rows are taken out of the resident matrix, include/plspm_hip.h)."""
+        if set(self._config.all_scales()) == {Scale.RAW}:
+            raise NotImplementedError("missing values with Scale.RAW-only models are not part of the MI355X hot path (use Scale.NUM)")
+        missing = np.isnan(values[:, compiled.col_index])                  # device column order
+        for l, lv in enumerate(compiled.lvs):
+            block = missing[:, compiled.block_offset[l]:compiled.block_offset[l + 1]]
+            if block.any() and compiled.modes[l] == 1:
+                raise Exception("Missing nonmetric data is not supported in mode B. LV with missing data: " + lv)          # mode.py:55-56
+            if block.all(axis=1).any():
+                raise ValueError("All mvs for lv " + lv + " in row " + str(int(np.flatnonzero(block.all(axis=1))[0])) + " are NaN.")   # weights.py:94-95
+        rows = np.flatnonzero(missing.any(axis=1))
+        with np.errstate(invalid="ignore"):
+            means = np.nanmean(values, axis=0)
+        filled = np.where(np.isnan(values), np.where(np.isnan(means), 0.0, means), values)
+        return np.ascontiguousarray(filled), (rows, ~missing[rows])
+
     def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False) -> SolverResult:
         """Compile, upload ``data`` (raw or treated) and run one device fit.  Raises the reference's
         ``Exception("Could not converge ...")`` (weights.py:185-186) on non-convergence."""
@@ -89,11 +107,17 @@ class WeightsCalculatorFactory:
         else:
             values = values if values.dtype == np.float64 else values.astype(np.float64)
             col_index, ind_of = compiled.col_index, None
-            if not nonmetric and np.isnan(values).any():
-                values, col_index, ind_of = with_missing_indicators(compiled, values)
+            incomplete = None
+            if np.isnan(values).any():
+                if not nonmetric:
+                    values, col_index, ind_of = with_missing_indicators(compiled, values)
+                else:
+                    values, incomplete = self._incomplete_rows(compiled, values)
             native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
                                          self._iterations, self._tolerance, self._device_id, nonmetric=bool(nonmetric), missing=ind_of)
             native.upload(values, col_index)
+            if incomplete is not None:
+                native.set_incomplete_rows(*incomplete)
         raw = native.fit(want_scores=want_scores, want_cov=want_cov)
         if raw["status"] == _native.STATUS_NOT_CONVERGED:
             raise ConvergenceError("Could not converge after " + str(raw["iterations"]) + " iterations")
