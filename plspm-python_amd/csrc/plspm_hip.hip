@@ -139,8 +139,11 @@ __global__ void __launch_bounds__(256) pack_colmajor_kernel(const double* __rest
 // One workgroup per replicate: LDS histogram of the N drawn row indices, then an ordered compaction into
 // (row, multiplicity) pairs -- ~63 % of the rows survive, so the Gram kernel issues 37 % fewer MFMAs than a
 // gather of all N draws.  The list is zero-padded to a multiple of 4 entries (one MFMA k-group).
+// `dcnt` (optional): the histogram itself as [replicate][dcnt_stride] uint16, zero-padded -- the dense stop-rule pass of the
+// non-metric solvers reads it (nm_conv_dense_kernel); N <= 36000 here, so a count always fits.
 __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restrict__ idx, uint64_t seed, int64_t rep0, int2* __restrict__ ent,
-                                                        int* __restrict__ nent, long ent_stride, int* __restrict__ err) {
+                                                        int* __restrict__ nent, long ent_stride, int* __restrict__ err, unsigned short* __restrict__ dcnt,
+                                                        long dcnt_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);
     __shared__ int wave_tot[4];
@@ -166,6 +169,10 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
         }
     }
     __syncthreads();
+    if (dcnt) {
+        unsigned short* mine_cnt = dcnt + b * dcnt_stride;
+        for (int i = tid; i < (int)dcnt_stride; i += 256) mine_cnt[i] = (i < N) ? (unsigned short)hist[i] : (unsigned short)0;
+    }
     // ordered compaction with two barriers: wave w owns the contiguous row range [w*Q, (w+1)*Q); pass 1 counts its
     // non-empty rows, pass 2 writes them behind the preceding waves' totals (ballot + popcount prefix inside a wave).
     int2* my_ent = ent + b * ent_stride;
@@ -986,6 +993,94 @@ __global__ void __launch_bounds__(256) nm_conv_kernel(const double* __restrict__
     if (tid == 0) partial[b * nparts + part] = red[0];
 }
 
+
+// ------------------------------------------------------------------------------------------------ dense stop-rule pass (bootstrap)
+// nm_conv_kernel gathers every replicate's surviving rows (3.2 MB of L2 reads per replicate and iteration at 10k x 60).  With
+// thousands of replicates in flight it is cheaper to turn the loop inside out: a wave keeps a 16-ROW TILE of the data stationary
+// -- in scalar registers, the tile is stored column-major (Xt[tile][p][16]) so one s_load fetches a column of it -- and walks
+// over the replicates 64 at a time, one replicate per lane, their score-map coefficients staged through LDS from a table laid
+// out [group][coefficient][lane].  Per (row, replicate) it forms the L old / new scores with block-sparse FMAs (scalar x,
+// vector coefficient), accumulates (|y_old| - |y_new|)^2 and weights it with the row's count in that replicate (dense uint16
+// histogram written by resample_kernel).  One partial per (replicate, tile); nm_step adds them in a fixed order.
+__global__ void __launch_bounds__(256) tile_transpose_kernel(const double* __restrict__ Xa, long N, int PA, double* __restrict__ Xt) {
+    const long tile = blockIdx.x;
+    for (int e = threadIdx.x; e < 16 * PA; e += 256) {
+        const int p = e >> 4, r = e & 15;
+        const long i = tile * 16 + r;
+        Xt[tile * 16 * PA + e] = (i < N) ? Xa[i * PA + p] : 0.0;
+    }
+}
+
+// table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = 64 g + lane; row 2P + 2L: active flag
+__global__ void __launch_bounds__(256) coef_table_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, long nproblems, double* __restrict__ table) {
+    const long g = blockIdx.x;
+    const int rows = 2 * P + 2 * L + 1;
+    double* out = table + g * (long)rows * 64;
+    for (int e = threadIdx.x; e < rows * 64; e += 256) {
+        const int q = e >> 6, lane = e & 63;
+        const long b = g * 64 + lane;
+        double v = 0.0;
+        if (b < nproblems) { const double* st = gstate + b * state_stride; v = (q < rows - 1) ? st[8 + 2 * P + q] : st[3]; }
+        out[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
+                                                             const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
+                                                             long nproblems, double* __restrict__ partial, int nparts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long tile = (long)blockIdx.x * 4 + wave;              // wave-uniform
+    const bool have = tile < ntiles;
+    const double* __restrict__ xt = Xt + (have ? tile : 0) * 16 * PA;
+    const int rows = 2 * P + 2 * L + 1;
+    const double* cn = co + (long)P * 64;
+    const double* ko = co + 2L * P * 64;
+    const double* kn = ko + (long)L * 64;
+    const double* act = kn + (long)L * 64;
+    for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
+        __syncthreads();
+        const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
+        double2* dst = reinterpret_cast<double2*>(co);
+        for (int e = threadIdx.x; e < rows * 32; e += 256) dst[e] = src[e];
+        __syncthreads();
+        const long b = (long)g * 64 + lane;
+        if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;       // nothing to do for this wave (no barrier inside the body)
+        double s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0;
+        for (int l = 0; l < L; ++l) {
+            double ao[16], an[16];
+            const double k0 = ko[l * 64 + lane], k1 = kn[l * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
+            const int p1 = boff[l + 1];
+            for (int p = boff[l]; p < p1; ++p) {
+                const double c0 = co[p * 64 + lane], c1 = cn[p * 64 + lane];
+                const double* __restrict__ xp = xt + p * 16;                // one column of the tile: 16 consecutive doubles, wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const double x = xp[r]; ao[r] = fma(x, c0, ao[r]); an[r] = fma(x, c1, an[r]); }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const double d = fabs(ao[r]) - fabs(an[r]); s[r] = fma(d, d, s[r]); }
+        }
+        if (b < nproblems) {
+            const uint4* cp = reinterpret_cast<const uint4*>(dcnt + b * dcnt_stride + tile * 16);
+            const uint4 c01 = cp[0], c23 = cp[1];
+            const unsigned w[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
+            double acc = 0.0;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                acc = fma((double)(w[h] & 0xffffu), s[2 * h], acc);
+                acc = fma((double)(w[h] >> 16), s[2 * h + 1], acc);
+            }
+            partial[b * nparts + tile] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scores kernel
 // scores[i][l] = sum_{p in block l} xa[i][p] * score_w[p] + score_c[l]   (weights.py:60, sign rule folded into score_w)
 // A 16-row tile of Xa (16*PA*8 contiguous bytes) is staged in LDS with coalesced 16-byte loads (row stride PA+1 doubles:
@@ -1153,6 +1248,9 @@ struct plspm_model {
     int *d_lv_first = nullptr, *d_col2_lv1 = nullptr, *d_col2_p1 = nullptr, *d_hcol = nullptr, *d_hidx = nullptr;
     Buf pseudo;
     // non-metric data with missing values (solver_nmx.h): K incomplete rows live in side tables, their rows of Xa are zero
+    Buf dcnt, ctable, Xt;        // dense stop-rule pass of the non-metric bootstrap: uint16 histograms, coefficient table, tiled copy of Xa
+    long dcnt_stride = 0;
+    bool Xt_valid = false, dcnt_ready = false;
     int nmx_K = 0;
     double *d_Xk = nullptr, *d_Mk = nullptr;
     int* d_rowid = nullptr;
@@ -1322,7 +1420,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1360,7 +1458,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
         hipFree(m->d_Xk); hipFree(m->d_Mk); hipFree(m->d_rowid);
         m->d_Xk = m->d_Mk = nullptr; m->d_rowid = nullptr; m->nmx_K = 0;
     }
-    m->N = 0;
+    m->N = 0; m->Xt_valid = false;
     double* d_raw = nullptr; int* d_ci = nullptr; double* d_partial = nullptr;
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
     auto cleanup = [&]() { if (d_raw) hipFree(d_raw); if (d_ci) hipFree(d_ci); if (d_partial) hipFree(d_partial); };
@@ -1491,14 +1589,31 @@ static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long 
 static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, const int2* ent, const int* nent,
                          long ent_stride, int threads, bool finish = true) {
     const int P = m->P, L = m->L;
-    const plspm_model* src = m->stage1 ? m->stage1 : m;          // an attached second stage streams its first stage's data (solver_hoc.h)
+    plspm_model* src = m->stage1 ? m->stage1 : m;                // an attached second stage streams its first stage's data (solver_hoc.h)
     const long N = src->N;
     const bool cat = m->categorical != 0, nmx = m->nmx_K > 0;
     int rc;
     const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
     const size_t st_doubles = cat ? (size_t)nmg_state_doubles(P, m->Pm, L, m->cmax, m->kmv)
                                   : nmx ? (size_t)nmx_state_doubles(P, L, m->n_chol, m->nmx_K) : (size_t)nm_state_doubles(P, L, m->n_chol);
-    const int nparts = (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
+    // bootstrap: dense stop-rule pass (nm_conv_dense_kernel) when the replicates' uint16 histograms are at hand and the coefficient
+    // tile of 64 replicates fits LDS; otherwise (and for a single fit) the gathering pass
+    const long ntiles16 = (N + 15) / 16;
+    const int table_rows = 2 * src->P + 2 * L + 1;
+    const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
+    const char* dense_env = getenv("PLSPM_CONV_DENSE");
+    const bool dense = ent && src->dcnt_ready && dense_lds <= kMaxLds && !(dense_env && dense_env[0] == '0');
+    const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
+    const int ngroups = (int)((nproblems + 63) / 64);
+    if (dense) {
+        if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
+        if ((rc = allow_lds(m, (const void*)nm_conv_dense_kernel, dense_lds))) return rc;
+        if (!src->Xt_valid) {
+            hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, (double*)src->Xt.p);
+            src->Xt_valid = true;
+        }
+    }
     if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
@@ -1557,14 +1672,23 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
         if (h_active == 0) break;
         {
             ProfScope ps(m, PLSPM_K_SCORES);
+            const double* conv_state = gst;
+            long conv_stride = (long)st_doubles;
+            const int* conv_boff = m->d_boff;
             if (m->stage1) {
                 hipLaunchKernelGGL(hoc_compose_kernel, grid, dim3(64), 0, m->stream, make_hoc_desc(m), (const double*)m->stage1->nmstate.p,
                                    (long)nm_state_doubles(src->P, src->L, src->n_chol), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride);
-                hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, m->d_lv_cols, ent,
-                                   nent, ent_stride, (const double*)m->pseudo.p, ps_stride, part);
+                conv_state = (const double*)m->pseudo.p; conv_stride = ps_stride; conv_boff = m->d_lv_cols;
+            }
+            if (dense) {
+                hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L, nproblems, (double*)m->ctable.p);
+                const unsigned gx = (unsigned)((ntiles16 + 3) / 4);
+                const unsigned gy = (unsigned)std::max<long>(1, std::min<long>(ngroups, (1024 + gx - 1) / gx));
+                hipLaunchKernelGGL(nm_conv_dense_kernel, dim3(gx, gy), dim3(256), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L, conv_boff,
+                                   (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts);
             } else {
-                hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, m->d_Xa, N, m->PA, P, L, m->n_chol, m->d_boff, ent,
-                                   nent, ent_stride, (const double*)gst, (long)st_doubles, part);
+                hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
+                                   ent_stride, conv_state, conv_stride, part);
             }
         }
     }
@@ -1704,7 +1828,7 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
     HIPCHK(m, hipGetLastError());
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipFree(d_mask));
-    m->nmx_K = K;
+    m->nmx_K = K; m->Xt_valid = false;
     return 0;
 }
 
@@ -1829,7 +1953,11 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     const long psize = packed_size(m->T);
     const long ent_stride = ((N + 3) & ~3L) + 4;
     // replicates per pass: bound the (row,count) + Gram scratch to ~2 GiB
-    const size_t per_rep = (size_t)ent_stride * sizeof(int2) + (size_t)psize * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned));
+    // non-metric solvers: dense uint16 histograms for the dense stop-rule pass (LDS-histogram path only)
+    const bool want_dcnt = m->nonmetric && lds_hist;
+    const long dcnt_stride = ((N + 15) & ~15L);
+    const size_t per_rep = (size_t)ent_stride * sizeof(int2) + (size_t)psize * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
+                           (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0);
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
     int rc;
     if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
@@ -1840,6 +1968,8 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     if ((rc = ensure(m, m->iters, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->err, sizeof(int)))) return rc;
     if (!lds_hist && (rc = ensure(m, m->ghist, (size_t)chunk * N * sizeof(unsigned)))) return rc;
+    if (want_dcnt && (rc = ensure(m, m->dcnt, (size_t)chunk * dcnt_stride * sizeof(unsigned short)))) return rc;
+    m->dcnt_stride = dcnt_stride; m->dcnt_ready = want_dcnt;
     HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
@@ -1847,7 +1977,8 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
             if ((rc = allow_lds(m, (const void*)resample_kernel, (size_t)N * sizeof(unsigned)))) return rc;
             ProfScope ps(m, PLSPM_K_RESAMPLE);
             hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), (size_t)N * sizeof(unsigned), m->stream, (int)N,
-                               d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
+                               d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p,
+                               want_dcnt ? (unsigned short*)m->dcnt.p : (unsigned short*)nullptr, dcnt_stride);
         } else {
             ProfScope ps(m, PLSPM_K_RESAMPLE);
             hipLaunchKernelGGL(resample_global_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (int)N, d_idx ? d_idx + b0 * N : nullptr, seed,
