@@ -1025,14 +1025,17 @@ __global__ void __launch_bounds__(256) coef_table_kernel(const double* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
-                                                             const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
-                                                             long nproblems, double* __restrict__ partial, int nparts) {
+// One 16-row tile per wave, 8 waves per workgroup (two workgroups per CU -> 4 waves per SIMD): the x columns come through the
+// scalar cache with L2-like latency, and more resident waves hide it better than a deeper per-wave pipeline can (the SGPR file
+// holds two 16-double columns, not four; a 2-tile / 4-wave variant measured 2.05 ms against 1.56 ms for three passes).
+__global__ void __launch_bounds__(512) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
+                                                               const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
+                                                               long nproblems, double* __restrict__ partial, int nparts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long tile = (long)blockIdx.x * 4 + wave;              // wave-uniform
+    const long tile = (long)blockIdx.x * 8 + wave;              // wave-uniform: rows [16 tile, 16 tile + 16)
     const bool have = tile < ntiles;
     const double* __restrict__ xt = Xt + (have ? tile : 0) * 16 * PA;
     const int rows = 2 * P + 2 * L + 1;
@@ -1044,40 +1047,46 @@ __global__ void __launch_bounds__(256) nm_conv_dense_kernel(const double* __rest
         __syncthreads();
         const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
         double2* dst = reinterpret_cast<double2*>(co);
-        for (int e = threadIdx.x; e < rows * 32; e += 256) dst[e] = src[e];
+        for (int e = threadIdx.x; e < rows * 32; e += 512) dst[e] = src[e];
         __syncthreads();
         const long b = (long)g * 64 + lane;
-        if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;       // nothing to do for this wave (no barrier inside the body)
-        double s[16];
+        if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;
+        const bool live = b < nproblems;
+        const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (live ? b : 0) * dcnt_stride + tile * 16);
+        const uint4 c01 = live ? cp[0] : make_uint4(0, 0, 0, 0), c23 = live ? cp[1] : make_uint4(0, 0, 0, 0);
+        const unsigned wq[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
+        double acc = 0.0;
+        double c0 = co[lane], c1 = cn[lane];
+        double xa[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.0;
+        for (int r = 0; r < 16; ++r) xa[r] = xt[r];
+        int p = 0;
         for (int l = 0; l < L; ++l) {
             double ao[16], an[16];
             const double k0 = ko[l * 64 + lane], k1 = kn[l * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
-            const int p1 = boff[l + 1];
-            for (int p = boff[l]; p < p1; ++p) {
-                const double c0 = co[p * 64 + lane], c1 = cn[p * 64 + lane];
-                const double* __restrict__ xp = xt + p * 16;                // one column of the tile: 16 consecutive doubles, wave-uniform
+            const int pend = boff[l + 1];
+            for (; p < pend; ++p) {
+                const double d0 = c0, d1 = c1;
+                double xc[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const double x = xp[r]; ao[r] = fma(x, c0, ao[r]); an[r] = fma(x, c1, an[r]); }
+                for (int r = 0; r < 16; ++r) xc[r] = xa[r];
+                const int pn = (p + 1 < P) ? p + 1 : p;
+                c0 = co[pn * 64 + lane]; c1 = cn[pn * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xa[r] = xt[pn * 16 + r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ao[r] = fma(xc[r], d0, ao[r]); an[r] = fma(xc[r], d1, an[r]); }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const double d = fabs(ao[r]) - fabs(an[r]); s[r] = fma(d, d, s[r]); }
-        }
-        if (b < nproblems) {
-            const uint4* cp = reinterpret_cast<const uint4*>(dcnt + b * dcnt_stride + tile * 16);
-            const uint4 c01 = cp[0], c23 = cp[1];
-            const unsigned w[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
-            double acc = 0.0;
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                acc = fma((double)(w[h] & 0xffffu), s[2 * h], acc);
-                acc = fma((double)(w[h] >> 16), s[2 * h + 1], acc);
+            for (int r = 0; r < 16; ++r) {
+                const double d = fabs(ao[r]) - fabs(an[r]);
+                const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
+                acc = fma(w * d, d, acc);
             }
-            partial[b * nparts + tile] = acc;
         }
+        if (live) partial[b * nparts + tile] = acc;
     }
 }
 
@@ -1682,9 +1691,9 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             }
             if (dense) {
                 hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L, nproblems, (double*)m->ctable.p);
-                const unsigned gx = (unsigned)((ntiles16 + 3) / 4);
+                const unsigned gx = (unsigned)((ntiles16 + 7) / 8);
                 const unsigned gy = (unsigned)std::max<long>(1, std::min<long>(ngroups, (1024 + gx - 1) / gx));
-                hipLaunchKernelGGL(nm_conv_dense_kernel, dim3(gx, gy), dim3(256), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L, conv_boff,
+                hipLaunchKernelGGL(nm_conv_dense_kernel, dim3(gx, gy), dim3(512), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L, conv_boff,
                                    (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts);
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,

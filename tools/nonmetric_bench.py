@@ -15,7 +15,7 @@ import plspm_oracle as orc  # noqa: E402
 from plspm import _native  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-steps = 5
+steps = int(os.environ.get("NM_BENCH_STEPS", "20"))
 X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
 boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 m = _native.NativeModel(boff, orc.satisfaction_C().astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, nonmetric=True)
