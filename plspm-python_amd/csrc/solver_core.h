@@ -686,6 +686,7 @@ PLSPM_HD bool nm_step(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, c
         ex.par(L, [&](int l) { st.k_old[l] = st.k_new[l]; });
     }
     const double n = st.scal[0], corr2 = n / (n - 1.0);
+    ex.one([&]() { ws.scal[3] = (double)ST_OK; });                                // the small workspace does not survive between launches
     ex.par(P, [&](int p) { ws.w[p] = st.a_old[p]; });
     apply_cov(ex, md, ws);                                                        // V = R A, Q = Cy = A' R A
     ex.par(L * L, [&](int e) { ws.G[e] = ws.Q[e]; });
@@ -720,7 +721,7 @@ PLSPM_HD bool nm_step(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, c
     });
     ex.par(P, [&](int p) { st.a_new[p] = ws.wn[p] * ws.wf[md.lvof[p]]; });
     nm_score_map(ex, md, st, st.a_new, st.c_new, st.k_new);
-    ex.one([&]() { st.scal[2] = (double)(iteration + 1); });
+    ex.one([&]() { st.scal[2] = (double)(iteration + 1); if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3]; });
     return true;
 }
 

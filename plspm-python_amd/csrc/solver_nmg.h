@@ -184,6 +184,7 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
         ex.par(L, [&](int l) { st.k_old[l] = st.k_new[l]; });
     }
     const double n = st.scal[0], corr2 = n / (n - 1.0);
+    ex.one([&]() { ws.scal[3] = (double)ST_OK; });                                // the small workspace does not survive between launches
     // scores' moments: V = Mn . score maps, YY raw, means, covariance
     nmg_apply(ex, md, Mn, LD, st.c_old, st.k_old, x.V);
     ex.par(L * L, [&](int e) {
@@ -318,7 +319,7 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
         });
     }
     nmg_score_map(ex, md, cd, x, st.a_new, x.akk, st.c_new, st.k_new);
-    ex.one([&]() { st.scal[2] = (double)(iteration + 1); });
+    ex.one([&]() { st.scal[2] = (double)(iteration + 1); if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3]; });
     return true;
 }
 
