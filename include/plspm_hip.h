@@ -143,12 +143,14 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
  * any finite value before the upload); rows in which a whole LV block is missing must have been dropped (config.py:273-285).
  *   row_index  [K]    ascending row numbers
  *   present    [K*P]  1 = cell present, 0 = missing (device column order)
+ *   raw_scale  1 for a Scale.RAW-only model: the MVs then keep the treated values (scale.py:38-39), which are scaled by
+ *              sqrt((f-1)/f) / sqrt((N-1)/N) against Scale.NUM in a column with f < N present cells; 0 for Scale.NUM
  * The rows move into a side table and become all-zero rows of the resident matrix, so the Gram kernels see the complete rows only;
  * the solver adds the incomplete rows explicitly in every sum (solver_nmx.h), weighted by their bootstrap counts.  Mode B blocks
  * must be complete in the data set at hand (mode.py:55-56): otherwise the fit / replicate reports PLSPM_SINGULAR.
  * plspm_model_set_nonmetric(.., 1) handles only; not combinable with set_categorical / set_missing / a two-stage pair.
  */
-int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* row_index, const uint8_t* present);
+int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* row_index, const uint8_t* present, int32_t raw_scale);
 
 /* Number of (from,to) effect rows = ordered LV pairs joined by a directed path; from-major order
  * (reference inner_model.py:46-52).  from/to may be NULL. */

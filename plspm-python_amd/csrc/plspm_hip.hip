@@ -1260,7 +1260,7 @@ struct plspm_model {
     Buf dcnt, ctable, Xt;        // dense stop-rule pass of the non-metric bootstrap: uint16 histograms, coefficient table, tiled copy of Xa
     long dcnt_stride = 0;
     bool Xt_valid = false, dcnt_ready = false;
-    int nmx_K = 0;
+    int nmx_K = 0, nmx_raw = 0;
     double *d_Xk = nullptr, *d_Mk = nullptr;
     int* d_rowid = nullptr;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
@@ -1663,7 +1663,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact);
         } else if (nmx) {
             auto k = mode_op == 0 ? nmx_kernel<0> : mode_op == 1 ? nmx_kernel<1> : nmx_kernel<2>;
-            const MissDesc xd{m->nmx_K, m->d_Xk, m->d_Mk};
+            const MissDesc xd{m->nmx_raw, m->nmx_K, m->d_Xk, m->d_Mk};
             hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, xd, (const int*)m->d_rowid, Mp, mp_stride, so, gS, gst, (long)st_doubles, (const double*)part, nparts,
                                nact, ent, nent, ent_stride);
         } else {
@@ -1807,7 +1807,7 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     return 0;
 }
 
-int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* row_index, const uint8_t* present) {
+int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* row_index, const uint8_t* present, int32_t raw_scale) {
     if (!m || K < 1 || !row_index || !present) return fail(m, PLSPM_E_ARG, "plspm_model_set_incomplete_rows: bad arguments");
     if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_model_set_incomplete_rows: call after plspm_upload");
     if (!m->nonmetric || m->categorical || m->n_ind || m->stage1 || m->stage2 || m->nmx_K)
@@ -1837,7 +1837,7 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
     HIPCHK(m, hipGetLastError());
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipFree(d_mask));
-    m->nmx_K = K; m->Xt_valid = false;
+    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false;
     return 0;
 }
 

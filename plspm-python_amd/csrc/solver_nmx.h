@@ -24,6 +24,7 @@
 namespace plspm {
 
 struct MissDesc {
+    int raw;                // Scale.RAW-only model: the MVs keep the treated values (scale.py:38-39) = xh * kappa_p
     int K;                  // incomplete rows
     const double* Xk;       // [K*P] stored (upload-shifted) values, 0 in the missing cells
     const double* Mk;       // [K*P] 1 = present, 0 = missing
@@ -154,9 +155,11 @@ PLSPM_HD void nmx_prepare(Ex& ex, const ModelDesc& md, const MissDesc& xd, Works
         }
         const double mu = s1 / f, sd = sqrt(s2 / f - mu * mu);
         st.mu[p] = mu; st.sd[p] = sd;
-        x.alpha[p] = 1.0 / sd; x.beta[p] = -mu / sd;
+        const double kappa = sqrt((f - 1.0) / f) / sqrt((n - 1.0) / n);   // treated column (config.py:314) / xh; 1 for a complete column
+        const double unit = xd.raw ? kappa : 1.0;                       // Scale.RAW iterates on the treated values themselves
+        x.alpha[p] = unit / sd; x.beta[p] = -unit * mu / sd;
         x.t1[p] = ws.S[P * PS + p];                                   // raw column sums of the complete rows
-        x.t2[p] = sqrt((f - 1.0) / f) / sqrt((n - 1.0) / n);         // treated column / xh (1 for a complete column)
+        x.t2[p] = xd.raw ? 1.0 : kappa;                               // initial scores use the treated columns
         if (!(f > 1.0) || !(sd > 0.0) || !isfinite(sd)) st.scal[1] = (double)ST_NONFINITE;
     });
     ex.par(K * P, [&](int e) { const int p = e % P; x.Xh[e] = xd.Mk[e] * (x.alpha[p] * xd.Xk[e] + x.beta[p]); });

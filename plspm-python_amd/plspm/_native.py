@@ -54,7 +54,7 @@ def load():
     lib.plspm_model_set_categorical.argtypes = [vp, i32, vp, vp]
     lib.plspm_model_set_missing.argtypes = [vp, i32, vp]
     lib.plspm_model_attach_second_stage.argtypes = [vp, vp, vp]
-    lib.plspm_model_set_incomplete_rows.argtypes = [vp, i32, vp, vp]
+    lib.plspm_model_set_incomplete_rows.argtypes = [vp, i32, vp, vp, i32]
     lib.plspm_upload.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.plspm_effect_pairs.restype = i32
     lib.plspm_effect_pairs.argtypes = [vp, vp, vp]
@@ -133,14 +133,15 @@ class NativeModel:
         self.row_stride = lib.plspm_row_stride(self._h)     # device rows: [row | status | iterations]
         self.N = 0
 
-    def set_incomplete_rows(self, rows, present):
+    def set_incomplete_rows(self, rows, present, raw_scale=False):
         """Non-metric data with missing values (plspm_model_set_incomplete_rows), after ``upload``: ``rows`` ascending row numbers,
         ``present`` [K, P] booleans in device column order."""
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         present = np.ascontiguousarray(present, dtype=np.uint8)
         if present.shape != (len(rows), self.P):
             raise ValueError("present must have shape (K, P)")
-        self._check(self._lib.plspm_model_set_incomplete_rows(self._h, len(rows), _ptr(rows), _ptr(present)), "plspm_model_set_incomplete_rows")
+        self._check(self._lib.plspm_model_set_incomplete_rows(self._h, len(rows), _ptr(rows), _ptr(present), int(bool(raw_scale))),
+                    "plspm_model_set_incomplete_rows")
 
     def attach_second_stage(self, second, lv_first):
         """Two-stage HOC bootstrap (plspm_model_attach_second_stage): ``second`` is the data-less stage-2 handle; afterwards

@@ -74,8 +74,6 @@ class WeightsCalculatorFactory:
     def _incomplete_rows(self, compiled, values):
         """Non-metric (Scale.NUM) data with NaNs: the rows with missing cells and their masks in device column order; the NaNs
         themselves become column means for the upload (their rows are taken out of the resident matrix, include/plspm_hip.h)."""
-        if set(self._config.all_scales()) == {Scale.RAW}:
-            raise NotImplementedError("missing values with Scale.RAW-only models are not part of the MI355X hot path (use Scale.NUM)")
         missing = np.isnan(values[:, compiled.col_index])                  # device column order
         for l, lv in enumerate(compiled.lvs):
             block = missing[:, compiled.block_offset[l]:compiled.block_offset[l + 1]]
@@ -87,7 +85,7 @@ class WeightsCalculatorFactory:
         with np.errstate(invalid="ignore"):
             means = np.nanmean(values, axis=0)
         filled = np.where(np.isnan(values), np.where(np.isnan(means), 0.0, means), values)
-        return np.ascontiguousarray(filled), (rows, ~missing[rows])
+        return np.ascontiguousarray(filled), (rows, ~missing[rows], set(self._config.all_scales()) == {Scale.RAW})
 
     def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False) -> SolverResult:
         """Compile, upload ``data`` (raw or treated) and run one device fit.  Raises the reference's

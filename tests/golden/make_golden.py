@@ -401,6 +401,14 @@ def main():
         rows, its = boot_rows(russam, cfg, scheme, lv8, list(g13["idx47"]), list(m.effects().index), tol=1e-7)
         g13["russa_%s/boot_rows" % scheme] = rows
         g13["russa_%s/boot_iters" % scheme] = its
+    # Scale.RAW only: the MVs keep the treated values (scale.py:38-39), which differ from Scale.NUM where cells are missing
+    cfg = build_config(C8, lv8, bn8, "AAA", True, add_order=["AGRI", "IND", "POLINS"], default_scale=Scale.RAW)
+    m, out = run_fit(russam, cfg, "centroid", lv8, tol=1e-7)
+    for k, v in out.items():
+        g13["russa_raw_centroid/%s" % k] = v
+    rows, its = boot_rows(russam, cfg, "centroid", lv8, list(g13["idx47"][:3]), list(m.effects().index), tol=1e-7)
+    g13["russa_raw_centroid/boot_rows"] = rows
+    g13["russa_raw_centroid/boot_iters"] = its
     Cs = orc.satisfaction_C()
     Xs, blocks_s = orc.synth(300, Cs, 4, seed=13)
     Xm = Xs.copy()

@@ -284,13 +284,13 @@ void hostemu_hoc_compose(int P1, int L1, int P2, int L2, const int* boff1, const
 // ---- non-metric data with missing values (solver_nmx.h).  mode_op: 0 prepare, 1 step (returns active), 2 finish.  The caller
 // writes the incomplete rows' weights ck[K] at state[nm_state_doubles(P, L, n_chol)] before the prepare call.
 long hostemu_nmx_state_doubles(int P, int L, int n_chol, int K) { return nmx_state_doubles(P, L, n_chol, K); }
-int hostemu_nmx(int mode_op, int P, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode, int K,
+int hostemu_nmx(int mode_op, int raw, int P, int L, int PA, int scheme, int max_iter, double tol, const int* boff, const unsigned char* C, const int* mode, int K,
                 const double* Xk, const double* Mk, const double* Mp, int nthreads, double* S, double* state, const double* partial, int nparts, int n_eff,
                 const int* eff_from, const int* eff_to, double* row, double* crossloadings, double* path_coef, double* score_w, double* score_c, double* cov,
                 int* iters, int* status) {
     std::vector<double> shift(P, 0.0);
     EmuModel em(P, L, PA, scheme, 1, max_iter, tol, boff, C, mode, shift.data(), n_eff, eff_from, eff_to);
-    MissDesc xd{K, Xk, Mk};
+    MissDesc xd{raw, K, Xk, Mk};
     int active = 0;
     FitOutputs out{};
     out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.score_w = score_w; out.score_c = score_c; out.cov = cov;

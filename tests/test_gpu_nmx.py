@@ -27,7 +27,7 @@ def gpu_model(Xnan, model):
     nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], True, model.max_iter, model.tol, 0, nonmetric=True)
     nm.upload(filled)
     if len(rows):
-        nm.set_incomplete_rows(rows, Mk > 0)
+        nm.set_incomplete_rows(rows, Mk > 0, raw_scale=all(k == "RAW" for k in model.scales))
     inv = np.empty(P, dtype=np.int64); inv[order] = np.arange(P)
     return nm, inv
 
@@ -64,6 +64,36 @@ def test_russa_missing_fit_and_bootstrap_vs_reference_golden(scheme):
     rows, status, iters = nm.bootstrap(6, idx=gold["idx47"])
     assert np.all(status == 0) and np.array_equal(iters, gold[key + "/boot_iters"])
     assert_close(rows_in_data_order(rows, inv, 9, 3, nm.n_eff), gold[key + "/boot_rows"], RTOL, 1e-8)
+
+
+def test_russa_missing_raw_scale_vs_reference_golden():
+    gold = load("g13_nonmetric_missing")
+    X = russa_missing_matrix()
+    model = orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "AAA", "centroid", True, tol=1e-7, scales=["RAW"] * 9)
+    nm, inv = gpu_model(X, model)
+    g = nm.fit(want_scores=True)
+    check_fit(g, orc.fit(X, model), inv, "raw")
+    key = "russa_raw_centroid"
+    assert g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights"][inv], gold[key + "/weights"], RTOL)
+    assert_close(g["scores"], gold[key + "/scores"], 1e-7, 1e-9)
+    rows, status, iters = nm.bootstrap(3, idx=gold["idx47"][:3])
+    assert np.all(status == 0) and np.array_equal(iters, gold[key + "/boot_iters"])
+    assert_close(rows_in_data_order(rows, inv, 9, 3, nm.n_eff), gold[key + "/boot_rows"], RTOL, 1e-8)
+    # through the host API
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    russa = pd.DataFrame(X, columns=RUSSA_M_COLS)
+    s = c.Structure(); s.add_path(["AGRI", "IND"], ["POLINS"])
+    config = c.Config(s.path(), default_scale=Scale.RAW)
+    config.add_lv("AGRI", Mode.A, c.MV("gini"), c.MV("farm"), c.MV("rent"))
+    config.add_lv("IND", Mode.A, c.MV("gnpr"), c.MV("labo"))
+    config.add_lv("POLINS", Mode.A, c.MV("ecks"), c.MV("death"), c.MV("demo"), c.MV("inst"))
+    calc = Plspm(russa, config, Scheme.CENTROID, 100, 0.0000001)
+    assert_close(calc.outer_model().loc[RUSSA_M_COLS, "weight"].values, gold[key + "/weights"], RTOL)
 
 
 @pytest.mark.parametrize("tag", ["A_path", "M_centroid", "A_factorial"])

@@ -403,6 +403,17 @@ def test_g13_russa_nonmetric_missing(scheme):
         assert_close(mine, row, RTOL, 1e-12, what=key)
 
 
+def test_g13_russa_raw_scale_missing():
+    g = load("g13_nonmetric_missing")
+    X = russa_missing_matrix()
+    model = orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "AAA", "centroid", True, tol=1e-7, scales=["RAW"] * 9)
+    _check_fit(orc.fit(X, model), g, "russa_raw_centroid")
+    for idx, row, it in zip(g["idx47"][:3], g["russa_raw_centroid/boot_rows"], g["russa_raw_centroid/boot_iters"]):
+        mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(47))
+        assert its == int(it)
+        assert_close(mine, row, RTOL, 1e-12)
+
+
 @pytest.mark.parametrize("tag", ["A_path", "M_centroid", "A_factorial"])
 def test_g13_synthetic_nonmetric_missing(tag):
     g = load("g13_nonmetric_missing")

@@ -81,7 +81,7 @@ def run_nmx_emu(lib, Xnan, model, counts=None, nthreads=4, nparts=3):
         Xk_c, Mk_c = np.zeros(1), np.zeros(1)
 
     def call(op):
-        return lib.hostemu_nmx(op, P, L, PA, SCHEME_ID[model.scheme], model.max_iter, ctypes.c_double(model.tol), _ptr(boff, I32), _ptr(C, ctypes.c_ubyte),
+        return lib.hostemu_nmx(op, int(all(k == "RAW" for k in model.scales)), P, L, PA, SCHEME_ID[model.scheme], model.max_iter, ctypes.c_double(model.tol), _ptr(boff, I32), _ptr(C, ctypes.c_ubyte),
                                _ptr(mode, I32), K, _ptr(Xk_c), _ptr(Mk_c), _ptr(Mp), nthreads, _ptr(S), _ptr(state), _ptr(partial), nparts, ne,
                                _ptr(ef, I32), _ptr(et, I32), _ptr(row), _ptr(cl), _ptr(pc), _ptr(sw), _ptr(sc), _ptr(cov), ctypes.byref(iters), ctypes.byref(status))
     call(0)
@@ -133,6 +133,17 @@ def test_synthetic_missing(emu, tag):
     blocks = [np.arange(4 * j, 4 * j + 4) for j in range(6)]
     model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA" if modes == "A" else "AAAABB", scheme, True, tol=1e-7, scales=["NUM"] * 24)
     check(run_nmx_emu(emu, g["synth"], model, nthreads=7), orc.fit(g["synth"], model), tag)
+
+
+def test_russa_missing_raw_scale(emu):
+    """Scale.RAW only: the treated values are used as they are, so columns with holes are scaled differently from Scale.NUM."""
+    g = load("g13_nonmetric_missing")
+    X = russa_missing_matrix()
+    model = orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "AAA", "centroid", True, tol=1e-7, scales=["RAW"] * 9)
+    e = run_nmx_emu(emu, X, model)
+    check(e, orc.fit(X, model), "raw")
+    assert_close(e["weights"], g["russa_raw_centroid/weights"], 1e-8)
+    assert np.abs(e["weights"] - g["russa_centroid/weights"]).max() > 1e-5
 
 
 def test_bootstrap_weights_vs_oracle_replicates(emu):
