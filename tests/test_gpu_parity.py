@@ -592,6 +592,24 @@ def test_nonmetric_bootstrap_explicit_indices_vs_reference_rows(tag):
     assert_close(mine, gold[tag + "/boot_rows"], RTOL, ATOL)
 
 
+def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
+    """The bootstrap's dense stop-rule pass (nm_conv_dense_kernel) and the gathering pass it replaced (still used for N > 36,000
+    or very wide models; PLSPM_CONV_DENSE=0 forces it) must take the same decisions and give the same rows."""
+    import os
+    X, blocks = orc.synth(3000, orc.satisfaction_C(), 5, seed=17)
+    model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "factorial", True, tol=1e-7, scales=["NUM"] * 30)
+    nm, _ = gpu_fit_nm(X, model)
+    dense = nm.bootstrap(130, seed=2)
+    os.environ["PLSPM_CONV_DENSE"] = "0"
+    try:
+        gathered = nm.bootstrap(130, seed=2)
+    finally:
+        del os.environ["PLSPM_CONV_DENSE"]
+    assert np.array_equal(dense[1], gathered[1]) and np.array_equal(dense[2], gathered[2])
+    assert np.all(dense[1] == 0) and dense[2].min() >= 2
+    assert_close(dense[0], gathered[0], 1e-12, 1e-14)
+
+
 def test_nonmetric_bootstrap_10k_vs_oracle_spot_checks():
     from plspm import _native
     X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
