@@ -1,0 +1,310 @@
+// kernels_nonmetric.h -- Device kernels, part 4: non-metric solvers (NUM/RAW, categorical, missing data) and the stop-rule passes (gathering and dense).
+// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ non-metric (NUM / RAW) kernels
+// The correlation matrix R and the iteration state of every problem live in global memory between launches (gS / gstate); the
+// small workspace and the descriptors are LDS-resident.  MODE 0 prepare, 1 step, 2 finish (solver_core.h nm_*).
+template <int MODE>
+__global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gstate,
+                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = gS + b * cov_doubles(md.P);
+    const long small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += small_doubles;
+    NmState st;
+    nm_carve(st, gstate + b * nm_state_doubles(md.P, md.L, md.n_chol), md.P, md.L);
+    if (MODE == 1 && st.scal[3] == 0.0) return;                 // finished problems cost nothing more
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    if (MODE == 0) {
+        nm_prepare(ex, md, ws, st, Mp + b * mp_stride);
+    } else if (MODE == 1) {
+        const bool active = nm_step(ex, md, ws, st, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
+    } else {
+        FitOutputs out = so.fit;
+        if (b != 0) out = FitOutputs{};
+        out.row = so.row ? so.row + b * so.row_stride : nullptr;
+        out.status = so.status ? so.status + b : nullptr;
+        out.iters = so.iters ? so.iters + b : nullptr;
+        nm_finish(ex, md, ws, st, out);
+    }
+}
+
+
+// Categorical (Scale.ORD / NOM) non-metric problems (solver_nmg.h).  The aug-level moment matrix, the collapsed MV-level
+// correlation matrix and the iteration state live in global memory; both small workspaces and the aug-level descriptors in LDS.
+template <int MODE>
+__global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
+                                                  double* gS, double* gSm, double* gstate, long state_stride,
+                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    const int Q = md.P, L = md.L;
+    Workspace ws;
+    ws.PS = cov_ld(Q);
+    ws.S = gS + b * cov_doubles(Q);
+    carve_small(ws, lp, Q, L, md.kmax, 0);
+    lp += workspace_small_doubles(Q, L, md.kmax, 0);
+    Workspace wsm;
+    wsm.PS = cov_ld(cd.Pm);
+    wsm.S = gSm + b * cov_doubles(cd.Pm);
+    carve_small(wsm, lp, cd.Pm, L, md.kmax, 0);
+    lp += workspace_small_doubles(cd.Pm, L, md.kmax, 0);
+    double* state = gstate + b * state_stride;
+    NmState st;
+    nm_carve(st, state, Q, L);
+    NmgExtra x;
+    nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, cd.Pm, L, cd.cmax, cd.kmv);
+    if (MODE == 1 && st.scal[3] == 0.0) return;
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    if (MODE == 0) {
+        nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
+    } else if (MODE == 1) {
+        const bool active = nmg_step(ex, md, cd, ws, st, x, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
+    } else {
+        FitOutputs out = so.fit;
+        if (b != 0) out = FitOutputs{};
+        out.row = so.row ? so.row + b * so.row_stride : nullptr;
+        out.status = so.status ? so.status + b : nullptr;
+        out.iters = so.iters ? so.iters + b : nullptr;
+        nmg_finish(ex, md, cd, mdm, ws, wsm, st, x, out);
+    }
+}
+
+
+// Non-metric data with missing values (solver_nmx.h).  MODE 0 also looks up the bootstrap weight of every incomplete row in the
+// replicate's ordered (row, count) list (1 for a plain fit).
+template <int MODE>
+__global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, const int* __restrict__ rowid, const double* __restrict__ Mp, long mp_stride, SolverOut so,
+                                                  double* gS, double* gstate, long state_stride, const double* __restrict__ partial, int nparts,
+                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = gS + b * cov_doubles(md.P);
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    double* state = gstate + b * state_stride;
+    NmState st;
+    nm_carve(st, state, md.P, md.L);
+    NmxExtra x;
+    nmx_carve(x, state + nm_state_doubles(md.P, md.L, md.n_chol), md.P, md.L, xd.K);
+    if (MODE == 1 && st.scal[3] == 0.0) return;
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    if (MODE == 0) {
+        const int2* e = ent ? ent + b * ent_stride : nullptr;
+        const int ne = ent ? nent[b] : 0;
+        for (int j = threadIdx.x; j < xd.K; j += blockDim.x) {
+            double c = 1.0;
+            if (e) {
+                const int row = rowid[j];
+                int lo = 0, hi = ne;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (e[mid].x < row) lo = mid + 1; else hi = mid; }
+                c = (lo < ne && e[lo].x == row) ? (double)e[lo].y : 0.0;
+            }
+            x.ck[j] = c;
+        }
+        __syncthreads();
+        nmx_prepare(ex, md, xd, ws, st, x, Mp + b * mp_stride);
+    } else if (MODE == 1) {
+        const bool active = nmx_step(ex, md, xd, ws, st, x, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
+    } else {
+        FitOutputs out = so.fit;
+        if (b != 0) out = FitOutputs{};
+        out.row = so.row ? so.row + b * so.row_stride : nullptr;
+        out.status = so.status ? so.status + b : nullptr;
+        out.iters = so.iters ? so.iters + b : nullptr;
+        nmx_finish(ex, md, xd, ws, st, x, out);
+    }
+}
+
+// plspm_model_set_incomplete_rows: copy the incomplete rows (masked) into the side tables and zero them in Xa (data + ones column)
+__global__ void __launch_bounds__(256) extract_rows_kernel(double* __restrict__ Xa, int PA, int P, const int* __restrict__ rowid, const unsigned char* __restrict__ mask,
+                                                           double* __restrict__ Xk, double* __restrict__ Mk) {
+    const long j = blockIdx.x;
+    double* row = Xa + (long)rowid[j] * PA;
+    for (int p = threadIdx.x; p < PA; p += blockDim.x) {
+        if (p < P) {
+            const double present = mask[j * P + p] ? 1.0 : 0.0;
+            Mk[j * P + p] = present;
+            Xk[j * P + p] = present * row[p];
+        }
+        row[p] = 0.0;
+    }
+}
+
+// scores of the incomplete rows come from the solver state, not from the score map (plspm_fit)
+__global__ void __launch_bounds__(64) patch_scores_kernel(double* __restrict__ scores, int L, const int* __restrict__ rowid, const double* __restrict__ Yn) {
+    const long j = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) scores[(long)rowid[j] * L + l] = Yn[j * L + l];
+}
+
+// Streaming convergence pass (reference weights.py:120): for every still-active problem, sum over its observations (all rows,
+// or the (row,count) list of a bootstrap replicate) of count * sum_l (|y_old| - |y_new|)^2, with y = xa . c + k for the two
+// score maps in the state.  16-row tiles of Xa are staged in LDS like scores_kernel; blockIdx.x = part, blockIdx.y = problem.
+__global__ void __launch_bounds__(256) nm_conv_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, int n_chol, const int* __restrict__ boff,
+                                                       const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride,
+                                                       const double* __restrict__ gstate, long state_stride, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);     // [16][PA+1]
+    double* co = tile + SCORE_ROWS * (PA + 1);              // [P] c_old
+    double* cn = co + P;                                    // [P] c_new
+    double* ko = cn + P;                                    // [L]
+    double* kn = ko + L;                                    // [L]
+    double* cnt = kn + L;                                   // [16]
+    double* red = cnt + SCORE_ROWS;                         // [256]
+    int* bsh = reinterpret_cast<int*>(red + 256);           // [L+1]
+    const long b = blockIdx.y;
+    const int part = blockIdx.x, nparts = gridDim.x, tid = threadIdx.x;
+    const double* st = gstate + b * state_stride;       // NmState-compatible head: scal[8] a_old a_new c_old c_new k_old k_new
+    if (st[3] == 0.0) return;
+    for (int p = tid; p < P; p += 256) { co[p] = st[8 + 2 * P + p]; cn[p] = st[8 + 3 * P + p]; }
+    for (int l = tid; l < L; l += 256) { ko[l] = st[8 + 4 * P + l]; kn[l] = st[8 + 4 * P + L + l]; }
+    for (int l = tid; l <= L; l += 256) bsh[l] = boff[l];
+    const int2* e = ent ? ent + b * ent_stride : nullptr;
+    const long nrows = ent ? (long)nent[b] : N;
+    const long ntiles = (nrows + SCORE_ROWS - 1) / SCORE_ROWS;
+    const int half = PA >> 1;
+    const int r_c = tid & 15, lg = tid >> 4;
+    double acc = 0.0;
+    for (long tl = part; tl < ntiles; tl += nparts) {
+        const long i0 = tl * SCORE_ROWS;
+        const int rows = (int)lmin(SCORE_ROWS, nrows - i0);
+        __syncthreads();
+        if (tid < SCORE_ROWS) cnt[tid] = (tid < rows) ? (e ? (double)e[i0 + tid].y : 1.0) : 0.0;
+        for (int el = tid; el < rows * half; el += 256) {
+            const int r = el / half, c = 2 * (el - r * half);
+            const long src_row = e ? (long)e[i0 + r].x : i0 + r;
+            const double2 v = reinterpret_cast<const double2*>(Xa + src_row * PA)[c >> 1];
+            tile[r * (PA + 1) + c] = v.x;
+            tile[r * (PA + 1) + c + 1] = v.y;
+        }
+        __syncthreads();
+        if (r_c < rows) {
+            const double* row = tile + r_c * (PA + 1);
+            double s = 0.0;
+            for (int l = lg; l < L; l += 16) {
+                double yo = ko[l], yn = kn[l];
+                for (int p = bsh[l]; p < bsh[l + 1]; ++p) { const double x = row[p]; yo += x * co[p]; yn += x * cn[p]; }
+                const double d = fabs(yo) - fabs(yn);
+                s += d * d;
+            }
+            acc += cnt[r_c] * s;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
+    if (tid == 0) partial[b * nparts + part] = red[0];
+}
+
+
+// ------------------------------------------------------------------------------------------------ dense stop-rule pass (bootstrap)
+// nm_conv_kernel gathers every replicate's surviving rows (3.2 MB of L2 reads per replicate and iteration at 10k x 60).  With
+// thousands of replicates in flight it is cheaper to turn the loop inside out: a wave keeps a 16-ROW TILE of the data stationary
+// -- in scalar registers, the tile is stored column-major (Xt[tile][p][16]) so one s_load fetches a column of it -- and walks
+// over the replicates 64 at a time, one replicate per lane, their score-map coefficients staged through LDS from a table laid
+// out [group][coefficient][lane].  Per (row, replicate) it forms the L old / new scores with block-sparse FMAs (scalar x,
+// vector coefficient), accumulates (|y_old| - |y_new|)^2 and weights it with the row's count in that replicate (dense uint16
+// histogram written by resample_kernel).  One partial per (replicate, tile); nm_step adds them in a fixed order.
+__global__ void __launch_bounds__(256) tile_transpose_kernel(const double* __restrict__ Xa, long N, int PA, double* __restrict__ Xt) {
+    const long tile = blockIdx.x;
+    for (int e = threadIdx.x; e < 16 * PA; e += 256) {
+        const int p = e >> 4, r = e & 15;
+        const long i = tile * 16 + r;
+        Xt[tile * 16 * PA + e] = (i < N) ? Xa[i * PA + p] : 0.0;
+    }
+}
+
+// table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = 64 g + lane; row 2P + 2L: active flag
+__global__ void __launch_bounds__(256) coef_table_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, long nproblems, double* __restrict__ table) {
+    const long g = blockIdx.x;
+    const int rows = 2 * P + 2 * L + 1;
+    double* out = table + g * (long)rows * 64;
+    for (int e = threadIdx.x; e < rows * 64; e += 256) {
+        const int q = e >> 6, lane = e & 63;
+        const long b = g * 64 + lane;
+        double v = 0.0;
+        if (b < nproblems) { const double* st = gstate + b * state_stride; v = (q < rows - 1) ? st[8 + 2 * P + q] : st[3]; }
+        out[e] = v;
+    }
+}
+
+// One 16-row tile per wave, 8 waves per workgroup (two workgroups per CU -> 4 waves per SIMD): the x columns come through the
+// scalar cache with L2-like latency, and more resident waves hide it better than a deeper per-wave pipeline can (the SGPR file
+// holds two 16-double columns, not four; a 2-tile / 4-wave variant measured 2.05 ms against 1.56 ms for three passes).
+__global__ void __launch_bounds__(512) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
+                                                               const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
+                                                               long nproblems, double* __restrict__ partial, int nparts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long tile = (long)blockIdx.x * 8 + wave;              // wave-uniform: rows [16 tile, 16 tile + 16)
+    const bool have = tile < ntiles;
+    const double* __restrict__ xt = Xt + (have ? tile : 0) * 16 * PA;
+    const int rows = 2 * P + 2 * L + 1;
+    const double* cn = co + (long)P * 64;
+    const double* ko = co + 2L * P * 64;
+    const double* kn = ko + (long)L * 64;
+    const double* act = kn + (long)L * 64;
+    for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
+        __syncthreads();
+        const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
+        double2* dst = reinterpret_cast<double2*>(co);
+        for (int e = threadIdx.x; e < rows * 32; e += 512) dst[e] = src[e];
+        __syncthreads();
+        const long b = (long)g * 64 + lane;
+        if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;
+        const bool live = b < nproblems;
+        const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (live ? b : 0) * dcnt_stride + tile * 16);
+        const uint4 c01 = live ? cp[0] : make_uint4(0, 0, 0, 0), c23 = live ? cp[1] : make_uint4(0, 0, 0, 0);
+        const unsigned wq[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
+        double acc = 0.0;
+        double c0 = co[lane], c1 = cn[lane];
+        double xa[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xa[r] = xt[r];
+        int p = 0;
+        for (int l = 0; l < L; ++l) {
+            double ao[16], an[16];
+            const double k0 = ko[l * 64 + lane], k1 = kn[l * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
+            const int pend = boff[l + 1];
+            for (; p < pend; ++p) {
+                const double d0 = c0, d1 = c1;
+                double xc[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xc[r] = xa[r];
+                const int pn = (p + 1 < P) ? p + 1 : p;
+                c0 = co[pn * 64 + lane]; c1 = cn[pn * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xa[r] = xt[pn * 16 + r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ao[r] = fma(xc[r], d0, ao[r]); an[r] = fma(xc[r], d1, an[r]); }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double d = fabs(ao[r]) - fabs(an[r]);
+                const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
+                acc = fma(w * d, d, acc);
+            }
+        }
+        if (live) partial[b * nparts + tile] = acc;
+    }
+}

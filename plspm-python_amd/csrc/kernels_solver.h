@@ -1,0 +1,165 @@
+// kernels_solver.h -- Device kernels, part 3: the device executor, descriptor staging and the solver kernels (metric solver, mean-imputation collapse, two-stage HOC moments).
+// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------ solver kernel
+struct DevExec {
+    int tid, nt;
+    double* red;           // LDS scratch, one slot per wave
+    long long* marks;      // debug: phase timestamps of problem 0 (PLSPM_DEBUG_MARKS)
+    __device__ __forceinline__ void mark(int id) { if (marks && tid == 0) marks[id] = clock64(); }
+    template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
+    template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
+    // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
+    template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
+        int i0 = tid, i1 = 0;
+        while (i0 >= n0) { i0 -= n0; ++i1; }
+        while (i1 < n1) {
+            f(i0, i1);
+            i0 += nt;
+            while (i0 >= n0) { i0 -= n0; ++i1; }
+        }
+        __syncthreads();
+    }
+    // src is a sequence of 64-double chunks (one 512-byte coalesced row each); wave w takes chunks w, w + nw, ... with
+    // NB global loads issued before any is consumed.  The chunk index is wave-uniform (scalar decode).
+    template <class F> __device__ __forceinline__ void par_chunks64(int nchunks, const double* __restrict__ src, F f) {
+        const int lane = tid & 63, nw = nt >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        constexpr int NB = 20;                  // loads in flight per lane: the sweep is latency/queue bound (10 KB per wave outstanding)
+        for (int base = wave; base < nchunks; base += NB * nw) {
+            double v[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int c = base + j * nw; v[j] = (c < nchunks) ? src[c * 64 + lane] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int c = base + j * nw; if (c < nchunks) f(c, lane, v[j]); }
+        }
+        __syncthreads();
+    }
+    // group-wide sum: per-thread strided partials -> 64-lane shuffle tree -> (several waves) LDS; fixed order, every thread gets it
+    template <class F> __device__ __forceinline__ double sum(int n, F f) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += nt) s += f(i);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        s = __shfl(s, 0, 64);
+        if (nt > 64) {
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            s = 0.0;
+            for (int w = 0; w < (nt >> 6); ++w) s += red[w];
+        }
+        __syncthreads();
+        return s;
+    }
+    template <class F> __device__ __forceinline__ bool any(int n, F f) {
+        int hit = 0;
+        for (int i = tid; i < n; i += nt) hit |= f(i) ? 1 : 0;
+        return __syncthreads_or(hit) != 0;
+    }
+};
+struct SolverOut {      // per-problem strides; null base pointers are skipped
+    double* row; long row_stride;
+    int* status; int* iters;
+    long long* marks;
+    FitOutputs fit;     // single-fit extras (problem 0 only)
+};
+// Stage the model descriptors in LDS (the solver consults them in every phase) and repoint md at the copies.
+__device__ __forceinline__ void stage_descriptors(ModelDesc& md, double* lp) {
+    const int P = md.P, L = md.L, ne = md.n_eff, tid = threadIdx.x, nt = blockDim.x;
+    double* sh = lp; lp += P;
+    int* ip = reinterpret_cast<int*>(lp);
+    int* boff = ip; ip += L + 1;
+    int* lvof = ip; ip += P;
+    int* mode = ip; ip += L;
+    int* choff = ip; ip += L;
+    int* ef = ip; ip += ne;
+    int* et = ip; ip += ne;
+    const int nedge = md.n_edges;
+    int* poff = ip; ip += L + 1;
+    int* soff = ip; ip += L + 1;
+    int* pidx = ip; ip += nedge;
+    int* sidx = ip; ip += nedge;
+    const int ntile = md.T * (md.T + 1) / 2;
+    unsigned short* ttu = reinterpret_cast<unsigned short*>(ip); ip += (ntile + 1) / 2;
+    unsigned char* Cb = reinterpret_cast<unsigned char*>(ip);
+    for (int i = tid; i < ntile; i += nt) {
+        int t = 0, rem = i;
+        while (rem >= md.T - t) { rem -= md.T - t; ++t; }
+        ttu[i] = (unsigned short)(t | ((t + rem) << 8));
+    }
+    for (int i = tid; i <= L; i += nt) { poff[i] = md.pred_off[i]; soff[i] = md.succ_off[i]; }
+    for (int i = tid; i < nedge; i += nt) { pidx[i] = md.pred_idx[i]; sidx[i] = md.succ_idx[i]; }
+    for (int i = tid; i < P; i += nt) { sh[i] = md.shift[i]; lvof[i] = md.lvof[i]; }
+    for (int i = tid; i <= L; i += nt) boff[i] = md.boff[i];
+    for (int i = tid; i < L; i += nt) { mode[i] = md.mode[i]; choff[i] = md.chol_off[i]; }
+    for (int i = tid; i < ne; i += nt) { ef[i] = md.eff_from[i]; et[i] = md.eff_to[i]; }
+    for (int i = tid; i < L * L; i += nt) Cb[i] = md.C[i];
+    md.shift = sh; md.boff = boff; md.lvof = lvof; md.mode = mode; md.chol_off = choff; md.eff_from = ef; md.eff_to = et; md.C = Cb;
+    md.pred_off = poff; md.succ_off = soff; md.pred_idx = pidx; md.succ_idx = sidx; md.tile_tu = ttu;
+    __syncthreads();
+}
+
+// LDS: [S (if s_in_lds)] [small workspace (if small_in_lds)]; otherwise the global scratch areas are used.
+// The placement is a template parameter so that every workspace pointer has ONE provenance: the compiler then proves the
+// LDS ones to be address-space-3 (ds_read / ds_write) instead of falling back to flat_load / flat_store.
+template <bool S_IN_LDS, bool SMALL_IN_LDS>
+__global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gsmall) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    const int PS = cov_ld(md.P);
+    const long s_doubles = cov_doubles(md.P), small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    Workspace ws;
+    ws.PS = PS;
+    double* lp = lds;
+    if (S_IN_LDS) { ws.S = lp; lp += s_doubles; } else ws.S = gS + b * s_doubles;
+    if (SMALL_IN_LDS) { carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol); lp += small_doubles; }
+    else carve_small(ws, gsmall + b * small_doubles, md.P, md.L, md.kmax, md.n_chol);
+    stage_descriptors(md, lp);
+    FitOutputs out = so.fit;
+    if (b != 0) out = FitOutputs{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
+    solve_problem(ex, md, ws, Mp + b * mp_stride, out);
+}
+
+
+// Metric data with missing values: per problem, the Gram of [data | missing indicators | 1] -> mean-imputed moments of the P
+// data columns (solver_core.h impute_collapse).  One workgroup per problem.
+__global__ void __launch_bounds__(256) impute_kernel(int P, int Qa, int Ta, int Ts, const int* __restrict__ ind_of, const double* __restrict__ Min, long in_stride,
+                                                     double* __restrict__ Mout, long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* gam = reinterpret_cast<double*>(smem_raw);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    impute_collapse(ex, P, Qa, Ta, Ts, ind_of, Min + blockIdx.x * in_stride, Mout + blockIdx.x * out_stride, gam);
+}
+
+
+// Two-stage HOC bootstrap (solver_hoc.h): stage-1 Gram + final stage-1 score maps -> stage-2 moment matrix, one workgroup per replicate.
+__global__ void __launch_bounds__(256) hoc_moments_kernel(HocDesc hd, const double* __restrict__ M1, long m1_stride, const double* __restrict__ state1, long st1_stride,
+                                                          double* __restrict__ M2, long m2_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* V = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    const double* st = state1 + b * st1_stride;
+    const double* c1 = st + 8 + 3 * hd.P1;                  // NmState: scal[8] a_old a_new c_old c_new k_old k_new
+    const double* k1 = st + 8 + 4 * hd.P1 + hd.L1;
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    hoc_second_stage_moments(ex, hd, M1 + b * m1_stride, c1, k1, st[1] == (double)ST_OK, M2 + b * m2_stride, V);
+}
+
+__global__ void __launch_bounds__(64) hoc_compose_kernel(HocDesc hd, const double* __restrict__ state1, long st1_stride, double* state2, long st2_stride, int n_chol2,
+                                                         double* pseudo, long ps_stride) {
+    const long b = blockIdx.x;
+    const double* st = state1 + b * st1_stride;
+    NmState st2;
+    nm_carve(st2, state2 + b * st2_stride, hd.P2, hd.L2);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    hoc_compose_score_maps(ex, hd, st + 8 + 3 * hd.P1, st + 8 + 4 * hd.P1 + hd.L1, st2, pseudo + b * ps_stride);
+}
+
+
+#define SCORE_ROWS 16

@@ -28,1191 +28,11 @@ using namespace plspm;
 typedef double d4 __attribute__((ext_vector_type(4)));
 __host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a : b; }
 
-// ------------------------------------------------------------------------------------------------ Philox4x32-10
-struct u32x4 { uint32_t v[4]; };
-__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
-__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    u32x4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
-    return o;
-}
-// Resample index i (0 <= i < N) of replicate `rep`: word (i & 3) of Philox(counter = (i >> 2, 0, rep), key = seed),
-// mapped to [0, N) by the 32x32 -> high-word multiply (bias <= N / 2^32).
-__host__ __device__ __forceinline__ u32x4 resample_quad(uint64_t seed, uint64_t rep, uint32_t q) {
-    return philox4x32_10(q, 0u, (uint32_t)rep, (uint32_t)(rep >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-}
-__host__ __device__ __forceinline__ int32_t to_index(uint32_t u, uint32_t n) { return (int32_t)mulhi32(u, n); }
-
-// ------------------------------------------------------------------------------------------------ upload kernels
-// Column sums, row-major source: block = 64 columns x 4 row lanes; partial[blockIdx.x][p].
-__global__ void __launch_bounds__(256) colsum_rowmajor_kernel(const double* __restrict__ X, long N, int src_cols, const int* __restrict__ colidx,
-                                                               int P, double* __restrict__ partial) {
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = lmin(N, r0 + rows_per_block);
-    for (int pbase = 0; pbase < P; pbase += 64) {
-        const int p = pbase + tx;
-        double s = 0.0;
-        if (p < P) {
-            const int c = colidx[p];
-            for (long i = r0 + ty; i < r1; i += 4) s += X[i * src_cols + c];
-        }
-        red[ty][tx] = s;
-        __syncthreads();
-        if (ty == 0 && p < P) partial[(long)blockIdx.x * P + p] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-        __syncthreads();
-    }
-}
-// Column sums, column-major source: grid (chunks, P); threads run along the rows.
-__global__ void __launch_bounds__(256) colsum_colmajor_kernel(const double* __restrict__ X, long N, const int* __restrict__ colidx, int P,
-                                                               double* __restrict__ partial) {
-    __shared__ double red[256];
-    const int p = blockIdx.y;
-    const double* col = X + (long)colidx[p] * N;
-    const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = lmin(N, r0 + rows_per_block);
-    double s = 0.0;
-    for (long i = r0 + threadIdx.x; i < r1; i += 256) s += col[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h]; __syncthreads(); }
-    if (threadIdx.x == 0) partial[(long)blockIdx.x * P + p] = red[0];
-}
-__global__ void colmean_kernel(const double* __restrict__ partial, int nblk, int P, long N, double* __restrict__ shift) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * P + p];
-    shift[p] = s / (double)N;
-}
-// Xa[i][p] = X[i][colidx[p]] - shift[p] (p < P), 1 (p == P), 0 (p > P).  Row-major source: one thread per output element.
-__global__ void __launch_bounds__(256) pack_rowmajor_kernel(const double* __restrict__ X, long N, int src_cols, const int* __restrict__ colidx,
-                                                             int P, int PA, const double* __restrict__ shift, double* __restrict__ Xa) {
-    const long total = N * PA;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long i = e / PA;
-        const int p = (int)(e - i * PA);
-        double v = 0.0;
-        if (p < P) v = X[i * src_cols + colidx[p]] - shift[p];
-        else if (p == P) v = 1.0;
-        Xa[e] = v;
-    }
-}
-// Column-major source: 64-row x 32-column LDS transpose tile (reads run along rows, writes along columns).
-__global__ void __launch_bounds__(256) pack_colmajor_kernel(const double* __restrict__ X, long N, const int* __restrict__ colidx, int P, int PA,
-                                                             const double* __restrict__ shift, double* __restrict__ Xa) {
-    __shared__ double tile[32][65];
-    const long i0 = (long)blockIdx.x * 64;
-    const int p0 = blockIdx.y * 32;
-    {
-        const int r = threadIdx.x & 63;
-        for (int c = threadIdx.x >> 6; c < 32; c += 4) {
-            const int p = p0 + c;
-            const long i = i0 + r;
-            double v = 0.0;
-            if (i < N) {
-                if (p < P) v = X[(long)colidx[p] * N + i] - shift[p];
-                else if (p == P) v = 1.0;
-            }
-            tile[c][r] = v;
-        }
-    }
-    __syncthreads();
-    {
-        const int c = threadIdx.x & 31;
-        for (int r = threadIdx.x >> 5; r < 64; r += 8) {
-            const long i = i0 + r;
-            if (i < N && p0 + c < PA) Xa[i * PA + p0 + c] = tile[c][r];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ resample + compact
-// One workgroup per replicate: LDS histogram of the N drawn row indices, then an ordered compaction into
-// (row, multiplicity) pairs -- ~63 % of the rows survive, so the Gram kernel issues 37 % fewer MFMAs than a
-// gather of all N draws.  The list is zero-padded to a multiple of 4 entries (one MFMA k-group).
-// `dcnt` (optional): the histogram itself as [replicate][dcnt_stride] uint16, zero-padded -- the dense stop-rule pass of the
-// non-metric solvers reads it (nm_conv_dense_kernel); N <= 36000 here, so a count always fits.
-__global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restrict__ idx, uint64_t seed, int64_t rep0, int2* __restrict__ ent,
-                                                        int* __restrict__ nent, long ent_stride, int* __restrict__ err, unsigned short* __restrict__ dcnt,
-                                                        long dcnt_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);
-    __shared__ int wave_tot[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long b = blockIdx.x;
-    for (int i = tid; i < N; i += 256) hist[i] = 0u;
-    __syncthreads();
-    if (idx) {
-        const int* my = idx + b * (long)N;
-        for (int i = tid; i < N; i += 256) {
-            const int r = my[i];
-            if ((unsigned)r < (unsigned)N) atomicAdd(&hist[r], 1u);
-            else atomicOr(err, 1);
-        }
-    } else {
-        const uint64_t rep = (uint64_t)(rep0 + b);
-        const int nq = (N + 3) >> 2;
-        for (int q = tid; q < nq; q += 256) {
-            const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * q + j < N) atomicAdd(&hist[to_index(u.v[j], (uint32_t)N)], 1u);
-        }
-    }
-    __syncthreads();
-    if (dcnt) {
-        unsigned short* mine_cnt = dcnt + b * dcnt_stride;
-        for (int i = tid; i < (int)dcnt_stride; i += 256) mine_cnt[i] = (i < N) ? (unsigned short)hist[i] : (unsigned short)0;
-    }
-    // ordered compaction with two barriers: wave w owns the contiguous row range [w*Q, (w+1)*Q); pass 1 counts its
-    // non-empty rows, pass 2 writes them behind the preceding waves' totals (ballot + popcount prefix inside a wave).
-    int2* my_ent = ent + b * ent_stride;
-    const int Q = (((N + 3) >> 2) + 63) & ~63;
-    const int r0 = wave * Q, r1 = min(N, r0 + Q);
-    int mine = 0;
-    for (int c0 = r0; c0 < r1; c0 += 64) {
-        const int row = c0 + lane;
-        const int cnt = (row < r1) ? (int)hist[row] : 0;
-        mine += __popcll(__ballot(cnt > 0));
-    }
-    if (lane == 0) wave_tot[wave] = mine;
-    __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    for (int c0 = r0; c0 < r1; c0 += 64) {
-        const int row = c0 + lane;
-        const int cnt = (row < r1) ? (int)hist[row] : 0;
-        const unsigned long long bal = __ballot(cnt > 0);
-        if (cnt > 0) my_ent[off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(row, cnt);
-        off += __popcll(bal);
-    }
-    const int padded = (total + 3) & ~3;
-    if (tid < padded - total) my_ent[total + tid] = make_int2(0, 0);
-    if (tid == 0) nent[b] = total;
-}
-
-// Large-N variant (N * 4 bytes no longer fits LDS): the histogram lives in a per-replicate slice of a global scratch
-// buffer.  Counting uses L2 atomics; the compaction passes read the slice with agent-scope relaxed loads, which bypass
-// this CU's L1 (the zero-fill went through L1, the atomics did not).
-__global__ void __launch_bounds__(256) resample_global_kernel(int N, const int* __restrict__ idx, uint64_t seed, int64_t rep0, unsigned* __restrict__ ghist,
-                                                               int2* __restrict__ ent, int* __restrict__ nent, long ent_stride, int* __restrict__ err) {
-    __shared__ int wave_tot[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long b = blockIdx.x;
-    unsigned* hist = ghist + b * (long)N;
-    for (int i = tid; i < N; i += 256) __hip_atomic_store(&hist[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (idx) {
-        const int* my = idx + b * (long)N;
-        for (int i = tid; i < N; i += 256) {
-            const int r = my[i];
-            if ((unsigned)r < (unsigned)N) __hip_atomic_fetch_add(&hist[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else atomicOr(err, 1);
-        }
-    } else {
-        const uint64_t rep = (uint64_t)(rep0 + b);
-        const int nq = (N + 3) >> 2;
-        for (int q = tid; q < nq; q += 256) {
-            const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * q + j < N) __hip_atomic_fetch_add(&hist[to_index(u.v[j], (uint32_t)N)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    int2* my_ent = ent + b * ent_stride;
-    const int Q = (((N + 3) >> 2) + 63) & ~63;
-    const int r0 = wave * Q, r1 = min(N, r0 + Q);
-    int mine = 0;
-    for (int c0 = r0; c0 < r1; c0 += 64) {
-        const int row = c0 + lane;
-        const int cnt = (row < r1) ? (int)__hip_atomic_load(&hist[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        mine += __popcll(__ballot(cnt > 0));
-    }
-    if (lane == 0) wave_tot[wave] = mine;
-    __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    for (int c0 = r0; c0 < r1; c0 += 64) {
-        const int row = c0 + lane;
-        const int cnt = (row < r1) ? (int)__hip_atomic_load(&hist[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const unsigned long long bal = __ballot(cnt > 0);
-        if (cnt > 0) my_ent[off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(row, cnt);
-        off += __popcll(bal);
-    }
-    const int padded = (total + 3) & ~3;
-    if (tid < padded - total) my_ent[total + tid] = make_int2(0, 0);
-    if (tid == 0) nent[b] = total;
-}
-
-// ------------------------------------------------------------------------------------------------ Gram (fp64 MFMA)
-// v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; for the
-// Gram both are the SAME element xa[row_k][col_t(l&15)] (A additionally times the multiplicity), so one 16-byte
-// load per 32 columns feeds two tiles: lane (k, i) reads columns 32*g + 2i, 2i+1 of row k -> tile 2g holds the even
-// columns of group g, tile 2g+1 the odd ones (packed_tile_of / packed_pos_of in solver_core.h).
-// Lane l ends up with D[(l>>4) + 4*reg][l&15] in acc[reg].
-//
-// Software pipeline.  hipcc de-pipelines a C++ prefetch here (it re-issues the loop-carried loads next to their
-// use, exposing the full (list entry -> row address -> row data) latency every k-group -- measured 42 % MFMA
-// utilisation), so the loads are issued with inline asm the compiler does not count, in a two-stage ping-pong:
-//     stage s:  s_waitcnt vmcnt(0)                      rows(s) and entry(s+1) have landed
-//               issue rows(s+1) <- Xa[entry(s+1).row]   } in flight under the MFMAs of stage s
-//               issue entry(s+2)                        }
-//               NT x v_mfma_f64_16x16x4_f64 on rows(s)
-// Rules followed (cdna_hip_programming.md 5.7): destinations are tied "+v" operands (no compiler copy of an
-// in-flight register), every destination is named by the wait statement before its first consumer, the
-// accumulators are pinned "+a" at stage boundaries so no MFMA drifts across a wait, and a final vmcnt(0)
-// precedes any other use of those registers.  Audit with tools/kernel_resources.py + -save-temps: the loop
-// must show no v_accvgpr_* and no v_mov of a load destination.
-#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-typedef double dv2 __attribute__((ext_vector_type(2)));
-typedef int iv2 __attribute__((ext_vector_type(2)));
-
-template <int T>
-struct TileIdx {
-    static constexpr int NTILE = T * (T + 1) / 2;
-    __host__ __device__ static constexpr int of(int t, int u) { return t * T - t * (t - 1) / 2 + (u - t); }
-};
-// Tiles owned by wave W of NW when the upper tiles are dealt round-robin (NW = 1: one wave owns all).
-template <int T, int NW, int W>
-struct Own {
-    static constexpr int COUNT = (TileIdx<T>::NTILE - W + NW - 1) / NW;
-    __host__ __device__ static constexpr bool mine(int li) { return li % NW == W; }
-    __host__ __device__ static constexpr int slot(int li) { return li / NW; }
-};
-
-template <int T, int NW, int W>
-using AccArr = d4[Own<T, NW, W>::COUNT];
-template <int T>
-using RowArr = dv2[T / 2];
-
-template <int Q, int G>
-struct RowLoader {
-    static __device__ __forceinline__ void issue(dv2 (&v)[G], const double* p) {
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(v[Q]) : "v"(p), "i"(Q * 256) : "memory");
-        RowLoader<Q + 1, G>::issue(v, p);
-    }
-    static __device__ __forceinline__ void pin(dv2 (&v)[G]) { asm volatile("" : "+v"(v[Q])); RowLoader<Q + 1, G>::pin(v); }
-};
-template <int G>
-struct RowLoader<G, G> {
-    static __device__ __forceinline__ void issue(dv2 (&)[G], const double*) {}
-    static __device__ __forceinline__ void pin(dv2 (&)[G]) {}
-};
-__device__ __forceinline__ void issue_entry(iv2& e, const int2* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(e) : "v"(p) : "memory"); }
-
-// One pipeline stage (see above).  DENSE: rows are consecutive (single fit), no (row,count) list.
-template <int T, int NW, int W, bool DENSE>
-__device__ __forceinline__ void gram_stage(AccArr<T, NW, W>& acc, RowArr<T>& Vcur, RowArr<T>& Vnext, iv2& Enext, iv2& Eafter, double cnt,
-                                           const double* xbase, const int2* eptr_after, long dense_row_next) {
-    constexpr int G = T / 2, PA = 16 * T;
-#pragma unroll
-    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
-    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Enext)::"memory");
-    RowLoader<0, G>::pin(Vcur);
-    double x[T];
-#pragma unroll
-    for (int q = 0; q < G; ++q) { x[2 * q] = Vcur[q].x; x[2 * q + 1] = Vcur[q].y; }
-    const long rnext = DENSE ? dense_row_next : (long)Enext.x;
-    RowLoader<0, G>::issue(Vnext, xbase + rnext * PA);
-    if (!DENSE) issue_entry(Eafter, eptr_after);
-    asm volatile("" : "+v"(cnt));          // every MFMA operand below depends on cnt: none is scheduled above the loads
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const double a = cnt * x[t];
-#pragma unroll
-        for (int u = t; u < T; ++u) {
-            const int li = TileIdx<T>::of(t, u);
-            const int sl = Own<T, NW, W>::slot(li);
-            if (Own<T, NW, W>::mine(li)) acc[sl] = MFMA_F64(a, x[u], acc[sl]);
-        }
-    }
-}
-
-// The k-group walk of one wave: groups g0, g0 + gs, ... < ng; accumulates its owned tiles.
-template <int T, int NW, int W, bool DENSE>
-__device__ __forceinline__ void gram_walk(AccArr<T, NW, W>& acc, const double* __restrict__ Xa, long N, const int2* __restrict__ e, int ng, int g0,
-                                          int gs, int lane) {
-    constexpr int G = T / 2, PA = 16 * T;
-    const int k = lane >> 4, i = lane & 15;
-    const double* xbase = Xa + 2 * i;
-    const int2* ek = e + k;
-    const int niter = (g0 < ng) ? (ng - g0 + gs - 1) / gs : 0;
-    const int last = ng - 1;
-    auto gof = [&](int it) { const int g = g0 + it * gs; return g < last ? g : last; };
-    auto eaddr = [&](int it) { return ek + 4 * (long)gof(it); };
-    auto drow = [&](int it) { const long r = 4 * (long)gof(it) + k; return r < N ? r : N - 1; };
-    auto dcnt = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? 1 : 0; };
-#pragma unroll
-    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }
-    iv2 EA = {0, 0}, EB = {0, 0};
-    dv2 VA[G], VB[G];
-#pragma unroll
-    for (int q = 0; q < G; ++q) { VA[q] = (dv2){0.0, 0.0}; VB[q] = (dv2){0.0, 0.0}; }
-    int cA;
-    if (DENSE) {
-        RowLoader<0, G>::issue(VA, xbase + drow(0) * PA);
-        cA = dcnt(0);
-    } else {
-        issue_entry(EA, eaddr(0));
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA)::"memory");
-        RowLoader<0, G>::issue(VA, xbase + (long)EA.x * PA);
-        cA = (niter > 0) ? EA.y : 0;
-        issue_entry(EB, eaddr(1));
-    }
-    for (int it = 0; it < niter; it += 2) {
-        // stage A: consume VA; prefetch VB <- rows(it+1), EA <- entry(it+2)
-        gram_stage<T, NW, W, DENSE>(acc, VA, VB, EB, EA, (double)cA, xbase, DENSE ? nullptr : eaddr(it + 2), DENSE ? drow(it + 1) : 0);
-        const int cB = DENSE ? dcnt(it + 1) : ((it + 1 < niter) ? EB.y : 0);
-        // stage B: consume VB; prefetch VA <- rows(it+2), EB <- entry(it+3)
-        gram_stage<T, NW, W, DENSE>(acc, VB, VA, EA, EB, (double)cB, xbase, DENSE ? nullptr : eaddr(it + 3), DENSE ? drow(it + 2) : 0);
-        cA = DENSE ? dcnt(it + 2) : EA.y;
-    }
-    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA), "+v"(EB)::"memory");
-    RowLoader<0, G>::pin(VA);
-    RowLoader<0, G>::pin(VB);
-#pragma unroll
-    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
-}
-
-// Rows-split variant (T <= 4): every wave of the 256-thread workgroup keeps ALL upper tiles and takes every 4th
-// k-group of the (row,count) list; a two-level LDS tree adds the four partial accumulators at the end.
-template <int T, bool DENSE>
-__global__ void __launch_bounds__(256) gram_rows_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
-                                                         const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
-    constexpr int NT = TileIdx<T>::NTILE;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* red = reinterpret_cast<double*>(smem_raw);      // [2][NT*256]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long problem = blockIdx.y;
-    const int nchunks = gridDim.x, chunk = blockIdx.x;
-    const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
-    const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
-
-    d4 acc[NT];
-    gram_walk<T, 1, 0, DENSE>(acc, Xa, N, e, ng, chunk * 4 + wave, nchunks * 4, lane);
-
-    // tree reduce: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores.  One tile at a time
-    // (compiler fence per tile) so the epilogue does not inflate the kernel's VGPR budget past the main loop's.
-#define TILE_FENCE() asm volatile("" ::: "memory")
-    if (wave >= 2) {
-        double* dst = red + (long)(wave - 2) * NT * 256;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64 + lane] = acc[t][r];
-            TILE_FENCE();
-        }
-    }
-    __syncthreads();
-    if (wave < 2) {
-        const double* src = red + (long)wave * NT * 256;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] += src[(t * 4 + r) * 64 + lane];
-            TILE_FENCE();
-        }
-    }
-    __syncthreads();
-    if (wave == 1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(t * 4 + r) * 64 + lane] = acc[t][r];
-            TILE_FENCE();
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        double* dst = out + (problem * nchunks + chunk) * (long)(NT * 256);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64 + lane] = acc[t][r] + red[(t * 4 + r) * 64 + lane];
-            TILE_FENCE();
-        }
-    }
-#undef TILE_FENCE
-}
-
-// Tile-split variant (6 <= T <= 16): the NW waves of a workgroup walk the SAME k-groups; wave W owns the upper tiles
-// whose linear index == W (mod NW), so no reduction is needed and the accumulators stay within the register file.
-template <int T, int NW, int W, bool DENSE>
-__device__ __forceinline__ void gram_wide_body(const double* __restrict__ Xa, long N, const int2* __restrict__ e, int ng, int chunk, int nchunks,
-                                                double* __restrict__ dst, int lane) {
-    d4 acc[Own<T, NW, W>::COUNT];
-    gram_walk<T, NW, W, DENSE>(acc, Xa, N, e, ng, chunk, nchunks, lane);
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int u = t; u < T; ++u) {
-            const int li = TileIdx<T>::of(t, u);
-            if (Own<T, NW, W>::mine(li)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(li * 4 + r) * 64 + lane] = acc[Own<T, NW, W>::slot(li)][r];
-            }
-        }
-}
-template <int T, int NW, int W, bool DENSE>
-struct WideDispatch {
-    __device__ static __forceinline__ void run(int wave, const double* Xa, long N, const int2* e, int ng, int chunk, int nchunks, double* dst, int lane) {
-        if (wave == W) gram_wide_body<T, NW, W, DENSE>(Xa, N, e, ng, chunk, nchunks, dst, lane);
-        else WideDispatch<T, NW, W + 1, DENSE>::run(wave, Xa, N, e, ng, chunk, nchunks, dst, lane);
-    }
-};
-template <int T, int NW, bool DENSE>
-struct WideDispatch<T, NW, NW, DENSE> {
-    __device__ static __forceinline__ void run(int, const double*, long, const int2*, int, int, int, double*, int) {}
-};
-// NWV "virtual" waves share the tiles; a workgroup carries NWP of them and blockIdx.z selects which slice
-// (NWV == NWP: one workgroup per k-group walk; NWV == 2*NWP: two workgroups walk the same rows, disjoint tiles).
-template <int T, int NWV, int NWP, bool DENSE>
-__global__ void __launch_bounds__(NWP * 64) gram_wide_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
-                                                              const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + NWP * (int)blockIdx.z;
-    const long problem = blockIdx.y;
-    const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
-    const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
-    double* dst = out + (problem * gridDim.x + blockIdx.x) * (long)(TileIdx<T>::NTILE * 256);
-    WideDispatch<T, NWV, 0, DENSE>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
-}
-
-
-// Block variant (T > 16, i.e. 255 <= P <= 1022): the upper triangle of the T x T tile grid is cut into 4 x 4-tile super-blocks
-// (64 x 64 columns); every wave owns ONE super-block (16 accumulator tiles, 10 on the diagonal), the four waves of a workgroup
-// walk the same k-groups, and blockIdx.z enumerates groups of four super-blocks.  Tile coordinates are run-time values (wave-
-// uniform), so one instantiation serves every T; out-of-range tiles of the last super-block row/column are skipped.
-// two 16-byte loads: the first 32-column group of a super-block and (off doubles further) its second one
-__device__ __forceinline__ void issue_pair(dv2 (&v)[2], const double* p, int off) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v[0]) : "v"(p) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v[1]) : "v"(p + off) : "memory");
-}
-template <bool DENSE>
-__device__ __forceinline__ void block_stage(d4 (&acc)[16], dv2 (&Rc)[2], dv2 (&Cc)[2], dv2 (&Rn)[2], dv2 (&Cn)[2], iv2& Enext, iv2& Eafter, double cnt,
-                                            const double* rbase, const double* cbase, int r1off, int c1off, int PA, const int2* eptr_after,
-                                            long dense_row_next, unsigned valid) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t]));
-    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Enext)::"memory");
-    RowLoader<0, 2>::pin(Rc);
-    RowLoader<0, 2>::pin(Cc);
-    const double xr[4] = {Rc[0].x, Rc[0].y, Rc[1].x, Rc[1].y};
-    const double xc[4] = {Cc[0].x, Cc[0].y, Cc[1].x, Cc[1].y};
-    const long rnext = DENSE ? dense_row_next : (long)Enext.x;
-    issue_pair(Rn, rbase + rnext * PA, r1off);
-    issue_pair(Cn, cbase + rnext * PA, c1off);
-    if (!DENSE) issue_entry(Eafter, eptr_after);
-    asm volatile("" : "+v"(cnt));
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-        const double a = cnt * xr[ti];
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-            if (valid & (1u << (ti * 4 + tj))) acc[ti * 4 + tj] = MFMA_F64(a, xc[tj], acc[ti * 4 + tj]);      // wave-uniform mask: scalar branch
-    }
-}
-template <bool DENSE>
-__global__ void __launch_bounds__(256) gram_block_kernel(const double* __restrict__ Xa, long N, int T, const int2* __restrict__ ent,
-                                                          const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
-    const int lane = threadIdx.x & 63, k = lane >> 4, i = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long problem = blockIdx.y;
-    const int PA = 16 * T, TB = (T + 3) >> 2, nsb = TB * (TB + 1) / 2;
-    const int sb = (int)blockIdx.z * 4 + wave;
-    if (sb >= nsb) return;
-    int bi = 0, rem = sb;
-    while (rem >= TB - bi) { rem -= TB - bi; ++bi; }
-    const int bj = bi + rem;
-    unsigned valid = 0;
-    for (int ti = 0; ti < 4; ++ti)
-        for (int tj = 0; tj < 4; ++tj) {
-            const int t = 4 * bi + ti, u = 4 * bj + tj;
-            if (t < T && u < T && t <= u) valid |= 1u << (ti * 4 + tj);
-        }
-    const int2* e = DENSE ? nullptr : ent + problem * ent_stride + k;
-    const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
-    const int g0 = blockIdx.x, gs = gridDim.x;
-    const int niter = (g0 < ng) ? (ng - g0 + gs - 1) / gs : 0;
-    const int last = ng - 1;
-    // row / column fragments: 32-column groups 2*bi, 2*bi+1 and 2*bj, 2*bj+1; a partial last super-block has no second group:
-    // its load is pointed at the first group again (those tiles are masked out of `valid`)
-    const double* rbase = Xa + 32 * (2 * bi) + 2 * i;
-    const double* cbase = Xa + 32 * (2 * bj) + 2 * i;
-    const int r1off = ((2 * bi + 1) < T / 2) ? 32 : 0, c1off = ((2 * bj + 1) < T / 2) ? 32 : 0;
-    auto gof = [&](int it) { const int g = g0 + it * gs; return g < last ? g : last; };
-    auto eaddr = [&](int it) { return e + 4 * (long)gof(it); };
-    auto drow = [&](int it) { const long r = 4 * (long)gof(it) + k; return r < N ? r : N - 1; };
-    auto dcnt = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? 1 : 0; };
-    d4 acc[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }
-    iv2 EA = {0, 0}, EB = {0, 0};
-    dv2 RA[2], CA[2], RB[2], CB[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { RA[q] = (dv2){0.0, 0.0}; CA[q] = RA[q]; RB[q] = RA[q]; CB[q] = RA[q]; }
-    const double* rb = rbase;
-    const double* cb = cbase;
-    int cA;
-    if (DENSE) {
-        issue_pair(RA, rb + drow(0) * PA, r1off);
-        issue_pair(CA, cb + drow(0) * PA, c1off);
-        cA = dcnt(0);
-    } else {
-        issue_entry(EA, eaddr(0));
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA)::"memory");
-        issue_pair(RA, rb + (long)EA.x * PA, r1off);
-        issue_pair(CA, cb + (long)EA.x * PA, c1off);
-        cA = (niter > 0) ? EA.y : 0;
-        issue_entry(EB, eaddr(1));
-    }
-    for (int it = 0; it < niter; it += 2) {
-        block_stage<DENSE>(acc, RA, CA, RB, CB, EB, EA, (double)cA, rb, cb, r1off, c1off, PA, DENSE ? nullptr : eaddr(it + 2), DENSE ? drow(it + 1) : 0, valid);
-        const int cB = DENSE ? dcnt(it + 1) : ((it + 1 < niter) ? EB.y : 0);
-        block_stage<DENSE>(acc, RB, CB, RA, CA, EA, EB, (double)cB, rb, cb, r1off, c1off, PA, DENSE ? nullptr : eaddr(it + 3), DENSE ? drow(it + 2) : 0, valid);
-        cA = DENSE ? dcnt(it + 2) : EA.y;
-    }
-    if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA), "+v"(EB)::"memory");
-    RowLoader<0, 2>::pin(RA); RowLoader<0, 2>::pin(CA); RowLoader<0, 2>::pin(RB); RowLoader<0, 2>::pin(CB);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t]));
-    double* dst = out + (problem * gridDim.x + blockIdx.x) * (long)(T * (T + 1) / 2) * 256;
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-            if (valid & (1u << (ti * 4 + tj))) {
-                const int t = 4 * bi + ti, u = 4 * bj + tj;
-                const long li = (long)t * T - (long)t * (t - 1) / 2 + (u - t);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(li * 4 + r) * 64 + lane] = acc[ti * 4 + tj][r];
-            }
-}
-
-// out[e] = sum over chunks of partial[chunk][e]  (fixed order: deterministic)
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const double* __restrict__ partial, int nchunks, long size, double* __restrict__ out) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= size) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int c = 0;
-    for (; c + 3 < nchunks; c += 4) {
-        s0 += partial[(long)c * size + e];
-        s1 += partial[(long)(c + 1) * size + e];
-        s2 += partial[(long)(c + 2) * size + e];
-        s3 += partial[(long)(c + 3) * size + e];
-    }
-    for (; c < nchunks; ++c) s0 += partial[(long)c * size + e];
-    out[e] = (s0 + s1) + (s2 + s3);
-}
-
-// ------------------------------------------------------------------------------------------------ solver kernel
-struct DevExec {
-    int tid, nt;
-    double* red;           // LDS scratch, one slot per wave
-    long long* marks;      // debug: phase timestamps of problem 0 (PLSPM_DEBUG_MARKS)
-    __device__ __forceinline__ void mark(int id) { if (marks && tid == 0) marks[id] = clock64(); }
-    template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
-    template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
-    // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
-    template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
-        int i0 = tid, i1 = 0;
-        while (i0 >= n0) { i0 -= n0; ++i1; }
-        while (i1 < n1) {
-            f(i0, i1);
-            i0 += nt;
-            while (i0 >= n0) { i0 -= n0; ++i1; }
-        }
-        __syncthreads();
-    }
-    // src is a sequence of 64-double chunks (one 512-byte coalesced row each); wave w takes chunks w, w + nw, ... with
-    // NB global loads issued before any is consumed.  The chunk index is wave-uniform (scalar decode).
-    template <class F> __device__ __forceinline__ void par_chunks64(int nchunks, const double* __restrict__ src, F f) {
-        const int lane = tid & 63, nw = nt >> 6;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        constexpr int NB = 20;                  // loads in flight per lane: the sweep is latency/queue bound (10 KB per wave outstanding)
-        for (int base = wave; base < nchunks; base += NB * nw) {
-            double v[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { const int c = base + j * nw; v[j] = (c < nchunks) ? src[c * 64 + lane] : 0.0; }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { const int c = base + j * nw; if (c < nchunks) f(c, lane, v[j]); }
-        }
-        __syncthreads();
-    }
-    // group-wide sum: per-thread strided partials -> 64-lane shuffle tree -> (several waves) LDS; fixed order, every thread gets it
-    template <class F> __device__ __forceinline__ double sum(int n, F f) {
-        double s = 0.0;
-        for (int i = tid; i < n; i += nt) s += f(i);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        s = __shfl(s, 0, 64);
-        if (nt > 64) {
-            if ((tid & 63) == 0) red[tid >> 6] = s;
-            __syncthreads();
-            s = 0.0;
-            for (int w = 0; w < (nt >> 6); ++w) s += red[w];
-        }
-        __syncthreads();
-        return s;
-    }
-    template <class F> __device__ __forceinline__ bool any(int n, F f) {
-        int hit = 0;
-        for (int i = tid; i < n; i += nt) hit |= f(i) ? 1 : 0;
-        return __syncthreads_or(hit) != 0;
-    }
-};
-struct SolverOut {      // per-problem strides; null base pointers are skipped
-    double* row; long row_stride;
-    int* status; int* iters;
-    long long* marks;
-    FitOutputs fit;     // single-fit extras (problem 0 only)
-};
-// Stage the model descriptors in LDS (the solver consults them in every phase) and repoint md at the copies.
-__device__ __forceinline__ void stage_descriptors(ModelDesc& md, double* lp) {
-    const int P = md.P, L = md.L, ne = md.n_eff, tid = threadIdx.x, nt = blockDim.x;
-    double* sh = lp; lp += P;
-    int* ip = reinterpret_cast<int*>(lp);
-    int* boff = ip; ip += L + 1;
-    int* lvof = ip; ip += P;
-    int* mode = ip; ip += L;
-    int* choff = ip; ip += L;
-    int* ef = ip; ip += ne;
-    int* et = ip; ip += ne;
-    const int nedge = md.n_edges;
-    int* poff = ip; ip += L + 1;
-    int* soff = ip; ip += L + 1;
-    int* pidx = ip; ip += nedge;
-    int* sidx = ip; ip += nedge;
-    const int ntile = md.T * (md.T + 1) / 2;
-    unsigned short* ttu = reinterpret_cast<unsigned short*>(ip); ip += (ntile + 1) / 2;
-    unsigned char* Cb = reinterpret_cast<unsigned char*>(ip);
-    for (int i = tid; i < ntile; i += nt) {
-        int t = 0, rem = i;
-        while (rem >= md.T - t) { rem -= md.T - t; ++t; }
-        ttu[i] = (unsigned short)(t | ((t + rem) << 8));
-    }
-    for (int i = tid; i <= L; i += nt) { poff[i] = md.pred_off[i]; soff[i] = md.succ_off[i]; }
-    for (int i = tid; i < nedge; i += nt) { pidx[i] = md.pred_idx[i]; sidx[i] = md.succ_idx[i]; }
-    for (int i = tid; i < P; i += nt) { sh[i] = md.shift[i]; lvof[i] = md.lvof[i]; }
-    for (int i = tid; i <= L; i += nt) boff[i] = md.boff[i];
-    for (int i = tid; i < L; i += nt) { mode[i] = md.mode[i]; choff[i] = md.chol_off[i]; }
-    for (int i = tid; i < ne; i += nt) { ef[i] = md.eff_from[i]; et[i] = md.eff_to[i]; }
-    for (int i = tid; i < L * L; i += nt) Cb[i] = md.C[i];
-    md.shift = sh; md.boff = boff; md.lvof = lvof; md.mode = mode; md.chol_off = choff; md.eff_from = ef; md.eff_to = et; md.C = Cb;
-    md.pred_off = poff; md.succ_off = soff; md.pred_idx = pidx; md.succ_idx = sidx; md.tile_tu = ttu;
-    __syncthreads();
-}
-
-// LDS: [S (if s_in_lds)] [small workspace (if small_in_lds)]; otherwise the global scratch areas are used.
-// The placement is a template parameter so that every workspace pointer has ONE provenance: the compiler then proves the
-// LDS ones to be address-space-3 (ds_read / ds_write) instead of falling back to flat_load / flat_store.
-template <bool S_IN_LDS, bool SMALL_IN_LDS>
-__global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gsmall) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* lds = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
-    const int PS = cov_ld(md.P);
-    const long s_doubles = cov_doubles(md.P), small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
-    Workspace ws;
-    ws.PS = PS;
-    double* lp = lds;
-    if (S_IN_LDS) { ws.S = lp; lp += s_doubles; } else ws.S = gS + b * s_doubles;
-    if (SMALL_IN_LDS) { carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol); lp += small_doubles; }
-    else carve_small(ws, gsmall + b * small_doubles, md.P, md.L, md.kmax, md.n_chol);
-    stage_descriptors(md, lp);
-    FitOutputs out = so.fit;
-    if (b != 0) out = FitOutputs{};
-    out.row = so.row ? so.row + b * so.row_stride : nullptr;
-    out.status = so.status ? so.status + b : nullptr;
-    out.iters = so.iters ? so.iters + b : nullptr;
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
-    solve_problem(ex, md, ws, Mp + b * mp_stride, out);
-}
-
-
-// Metric data with missing values: per problem, the Gram of [data | missing indicators | 1] -> mean-imputed moments of the P
-// data columns (solver_core.h impute_collapse).  One workgroup per problem.
-__global__ void __launch_bounds__(256) impute_kernel(int P, int Qa, int Ta, int Ts, const int* __restrict__ ind_of, const double* __restrict__ Min, long in_stride,
-                                                     double* __restrict__ Mout, long out_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* gam = reinterpret_cast<double*>(smem_raw);
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
-    impute_collapse(ex, P, Qa, Ta, Ts, ind_of, Min + blockIdx.x * in_stride, Mout + blockIdx.x * out_stride, gam);
-}
-
-
-// Two-stage HOC bootstrap (solver_hoc.h): stage-1 Gram + final stage-1 score maps -> stage-2 moment matrix, one workgroup per replicate.
-__global__ void __launch_bounds__(256) hoc_moments_kernel(HocDesc hd, const double* __restrict__ M1, long m1_stride, const double* __restrict__ state1, long st1_stride,
-                                                          double* __restrict__ M2, long m2_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* V = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
-    const double* st = state1 + b * st1_stride;
-    const double* c1 = st + 8 + 3 * hd.P1;                  // NmState: scal[8] a_old a_new c_old c_new k_old k_new
-    const double* k1 = st + 8 + 4 * hd.P1 + hd.L1;
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
-    hoc_second_stage_moments(ex, hd, M1 + b * m1_stride, c1, k1, st[1] == (double)ST_OK, M2 + b * m2_stride, V);
-}
-
-__global__ void __launch_bounds__(64) hoc_compose_kernel(HocDesc hd, const double* __restrict__ state1, long st1_stride, double* state2, long st2_stride, int n_chol2,
-                                                         double* pseudo, long ps_stride) {
-    const long b = blockIdx.x;
-    const double* st = state1 + b * st1_stride;
-    NmState st2;
-    nm_carve(st2, state2 + b * st2_stride, hd.P2, hd.L2);
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
-    hoc_compose_score_maps(ex, hd, st + 8 + 3 * hd.P1, st + 8 + 4 * hd.P1 + hd.L1, st2, pseudo + b * ps_stride);
-}
-
-
-#define SCORE_ROWS 16
-// ------------------------------------------------------------------------------------------------ non-metric (NUM / RAW) kernels
-// The correlation matrix R and the iteration state of every problem live in global memory between launches (gS / gstate); the
-// small workspace and the descriptors are LDS-resident.  MODE 0 prepare, 1 step, 2 finish (solver_core.h nm_*).
-template <int MODE>
-__global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gstate,
-                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* lp = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
-    Workspace ws;
-    ws.PS = cov_ld(md.P);
-    ws.S = gS + b * cov_doubles(md.P);
-    const long small_doubles = workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
-    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
-    lp += small_doubles;
-    NmState st;
-    nm_carve(st, gstate + b * nm_state_doubles(md.P, md.L, md.n_chol), md.P, md.L);
-    if (MODE == 1 && st.scal[3] == 0.0) return;                 // finished problems cost nothing more
-    stage_descriptors(md, lp);
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
-    if (MODE == 0) {
-        nm_prepare(ex, md, ws, st, Mp + b * mp_stride);
-    } else if (MODE == 1) {
-        const bool active = nm_step(ex, md, ws, st, partial + b * nparts, nparts);
-        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
-    } else {
-        FitOutputs out = so.fit;
-        if (b != 0) out = FitOutputs{};
-        out.row = so.row ? so.row + b * so.row_stride : nullptr;
-        out.status = so.status ? so.status + b : nullptr;
-        out.iters = so.iters ? so.iters + b : nullptr;
-        nm_finish(ex, md, ws, st, out);
-    }
-}
-
-
-// Categorical (Scale.ORD / NOM) non-metric problems (solver_nmg.h).  The aug-level moment matrix, the collapsed MV-level
-// correlation matrix and the iteration state live in global memory; both small workspaces and the aug-level descriptors in LDS.
-template <int MODE>
-__global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
-                                                  double* gS, double* gSm, double* gstate, long state_stride,
-                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* lp = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
-    const int Q = md.P, L = md.L;
-    Workspace ws;
-    ws.PS = cov_ld(Q);
-    ws.S = gS + b * cov_doubles(Q);
-    carve_small(ws, lp, Q, L, md.kmax, 0);
-    lp += workspace_small_doubles(Q, L, md.kmax, 0);
-    Workspace wsm;
-    wsm.PS = cov_ld(cd.Pm);
-    wsm.S = gSm + b * cov_doubles(cd.Pm);
-    carve_small(wsm, lp, cd.Pm, L, md.kmax, 0);
-    lp += workspace_small_doubles(cd.Pm, L, md.kmax, 0);
-    double* state = gstate + b * state_stride;
-    NmState st;
-    nm_carve(st, state, Q, L);
-    NmgExtra x;
-    nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, cd.Pm, L, cd.cmax, cd.kmv);
-    if (MODE == 1 && st.scal[3] == 0.0) return;
-    stage_descriptors(md, lp);
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
-    if (MODE == 0) {
-        nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
-    } else if (MODE == 1) {
-        const bool active = nmg_step(ex, md, cd, ws, st, x, partial + b * nparts, nparts);
-        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
-    } else {
-        FitOutputs out = so.fit;
-        if (b != 0) out = FitOutputs{};
-        out.row = so.row ? so.row + b * so.row_stride : nullptr;
-        out.status = so.status ? so.status + b : nullptr;
-        out.iters = so.iters ? so.iters + b : nullptr;
-        nmg_finish(ex, md, cd, mdm, ws, wsm, st, x, out);
-    }
-}
-
-
-// Non-metric data with missing values (solver_nmx.h).  MODE 0 also looks up the bootstrap weight of every incomplete row in the
-// replicate's ordered (row, count) list (1 for a plain fit).
-template <int MODE>
-__global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, const int* __restrict__ rowid, const double* __restrict__ Mp, long mp_stride, SolverOut so,
-                                                  double* gS, double* gstate, long state_stride, const double* __restrict__ partial, int nparts,
-                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* lp = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
-    Workspace ws;
-    ws.PS = cov_ld(md.P);
-    ws.S = gS + b * cov_doubles(md.P);
-    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
-    lp += workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
-    double* state = gstate + b * state_stride;
-    NmState st;
-    nm_carve(st, state, md.P, md.L);
-    NmxExtra x;
-    nmx_carve(x, state + nm_state_doubles(md.P, md.L, md.n_chol), md.P, md.L, xd.K);
-    if (MODE == 1 && st.scal[3] == 0.0) return;
-    stage_descriptors(md, lp);
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
-    if (MODE == 0) {
-        const int2* e = ent ? ent + b * ent_stride : nullptr;
-        const int ne = ent ? nent[b] : 0;
-        for (int j = threadIdx.x; j < xd.K; j += blockDim.x) {
-            double c = 1.0;
-            if (e) {
-                const int row = rowid[j];
-                int lo = 0, hi = ne;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (e[mid].x < row) lo = mid + 1; else hi = mid; }
-                c = (lo < ne && e[lo].x == row) ? (double)e[lo].y : 0.0;
-            }
-            x.ck[j] = c;
-        }
-        __syncthreads();
-        nmx_prepare(ex, md, xd, ws, st, x, Mp + b * mp_stride);
-    } else if (MODE == 1) {
-        const bool active = nmx_step(ex, md, xd, ws, st, x, partial + b * nparts, nparts);
-        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
-    } else {
-        FitOutputs out = so.fit;
-        if (b != 0) out = FitOutputs{};
-        out.row = so.row ? so.row + b * so.row_stride : nullptr;
-        out.status = so.status ? so.status + b : nullptr;
-        out.iters = so.iters ? so.iters + b : nullptr;
-        nmx_finish(ex, md, xd, ws, st, x, out);
-    }
-}
-
-// plspm_model_set_incomplete_rows: copy the incomplete rows (masked) into the side tables and zero them in Xa (data + ones column)
-__global__ void __launch_bounds__(256) extract_rows_kernel(double* __restrict__ Xa, int PA, int P, const int* __restrict__ rowid, const unsigned char* __restrict__ mask,
-                                                           double* __restrict__ Xk, double* __restrict__ Mk) {
-    const long j = blockIdx.x;
-    double* row = Xa + (long)rowid[j] * PA;
-    for (int p = threadIdx.x; p < PA; p += blockDim.x) {
-        if (p < P) {
-            const double present = mask[j * P + p] ? 1.0 : 0.0;
-            Mk[j * P + p] = present;
-            Xk[j * P + p] = present * row[p];
-        }
-        row[p] = 0.0;
-    }
-}
-
-// scores of the incomplete rows come from the solver state, not from the score map (plspm_fit)
-__global__ void __launch_bounds__(64) patch_scores_kernel(double* __restrict__ scores, int L, const int* __restrict__ rowid, const double* __restrict__ Yn) {
-    const long j = blockIdx.x;
-    for (int l = threadIdx.x; l < L; l += blockDim.x) scores[(long)rowid[j] * L + l] = Yn[j * L + l];
-}
-
-// Streaming convergence pass (reference weights.py:120): for every still-active problem, sum over its observations (all rows,
-// or the (row,count) list of a bootstrap replicate) of count * sum_l (|y_old| - |y_new|)^2, with y = xa . c + k for the two
-// score maps in the state.  16-row tiles of Xa are staged in LDS like scores_kernel; blockIdx.x = part, blockIdx.y = problem.
-__global__ void __launch_bounds__(256) nm_conv_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, int n_chol, const int* __restrict__ boff,
-                                                       const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride,
-                                                       const double* __restrict__ gstate, long state_stride, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* tile = reinterpret_cast<double*>(smem_raw);     // [16][PA+1]
-    double* co = tile + SCORE_ROWS * (PA + 1);              // [P] c_old
-    double* cn = co + P;                                    // [P] c_new
-    double* ko = cn + P;                                    // [L]
-    double* kn = ko + L;                                    // [L]
-    double* cnt = kn + L;                                   // [16]
-    double* red = cnt + SCORE_ROWS;                         // [256]
-    int* bsh = reinterpret_cast<int*>(red + 256);           // [L+1]
-    const long b = blockIdx.y;
-    const int part = blockIdx.x, nparts = gridDim.x, tid = threadIdx.x;
-    const double* st = gstate + b * state_stride;       // NmState-compatible head: scal[8] a_old a_new c_old c_new k_old k_new
-    if (st[3] == 0.0) return;
-    for (int p = tid; p < P; p += 256) { co[p] = st[8 + 2 * P + p]; cn[p] = st[8 + 3 * P + p]; }
-    for (int l = tid; l < L; l += 256) { ko[l] = st[8 + 4 * P + l]; kn[l] = st[8 + 4 * P + L + l]; }
-    for (int l = tid; l <= L; l += 256) bsh[l] = boff[l];
-    const int2* e = ent ? ent + b * ent_stride : nullptr;
-    const long nrows = ent ? (long)nent[b] : N;
-    const long ntiles = (nrows + SCORE_ROWS - 1) / SCORE_ROWS;
-    const int half = PA >> 1;
-    const int r_c = tid & 15, lg = tid >> 4;
-    double acc = 0.0;
-    for (long tl = part; tl < ntiles; tl += nparts) {
-        const long i0 = tl * SCORE_ROWS;
-        const int rows = (int)lmin(SCORE_ROWS, nrows - i0);
-        __syncthreads();
-        if (tid < SCORE_ROWS) cnt[tid] = (tid < rows) ? (e ? (double)e[i0 + tid].y : 1.0) : 0.0;
-        for (int el = tid; el < rows * half; el += 256) {
-            const int r = el / half, c = 2 * (el - r * half);
-            const long src_row = e ? (long)e[i0 + r].x : i0 + r;
-            const double2 v = reinterpret_cast<const double2*>(Xa + src_row * PA)[c >> 1];
-            tile[r * (PA + 1) + c] = v.x;
-            tile[r * (PA + 1) + c + 1] = v.y;
-        }
-        __syncthreads();
-        if (r_c < rows) {
-            const double* row = tile + r_c * (PA + 1);
-            double s = 0.0;
-            for (int l = lg; l < L; l += 16) {
-                double yo = ko[l], yn = kn[l];
-                for (int p = bsh[l]; p < bsh[l + 1]; ++p) { const double x = row[p]; yo += x * co[p]; yn += x * cn[p]; }
-                const double d = fabs(yo) - fabs(yn);
-                s += d * d;
-            }
-            acc += cnt[r_c] * s;
-        }
-    }
-    red[tid] = acc;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
-    if (tid == 0) partial[b * nparts + part] = red[0];
-}
-
-
-// ------------------------------------------------------------------------------------------------ dense stop-rule pass (bootstrap)
-// nm_conv_kernel gathers every replicate's surviving rows (3.2 MB of L2 reads per replicate and iteration at 10k x 60).  With
-// thousands of replicates in flight it is cheaper to turn the loop inside out: a wave keeps a 16-ROW TILE of the data stationary
-// -- in scalar registers, the tile is stored column-major (Xt[tile][p][16]) so one s_load fetches a column of it -- and walks
-// over the replicates 64 at a time, one replicate per lane, their score-map coefficients staged through LDS from a table laid
-// out [group][coefficient][lane].  Per (row, replicate) it forms the L old / new scores with block-sparse FMAs (scalar x,
-// vector coefficient), accumulates (|y_old| - |y_new|)^2 and weights it with the row's count in that replicate (dense uint16
-// histogram written by resample_kernel).  One partial per (replicate, tile); nm_step adds them in a fixed order.
-__global__ void __launch_bounds__(256) tile_transpose_kernel(const double* __restrict__ Xa, long N, int PA, double* __restrict__ Xt) {
-    const long tile = blockIdx.x;
-    for (int e = threadIdx.x; e < 16 * PA; e += 256) {
-        const int p = e >> 4, r = e & 15;
-        const long i = tile * 16 + r;
-        Xt[tile * 16 * PA + e] = (i < N) ? Xa[i * PA + p] : 0.0;
-    }
-}
-
-// table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = 64 g + lane; row 2P + 2L: active flag
-__global__ void __launch_bounds__(256) coef_table_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, long nproblems, double* __restrict__ table) {
-    const long g = blockIdx.x;
-    const int rows = 2 * P + 2 * L + 1;
-    double* out = table + g * (long)rows * 64;
-    for (int e = threadIdx.x; e < rows * 64; e += 256) {
-        const int q = e >> 6, lane = e & 63;
-        const long b = g * 64 + lane;
-        double v = 0.0;
-        if (b < nproblems) { const double* st = gstate + b * state_stride; v = (q < rows - 1) ? st[8 + 2 * P + q] : st[3]; }
-        out[e] = v;
-    }
-}
-
-// One 16-row tile per wave, 8 waves per workgroup (two workgroups per CU -> 4 waves per SIMD): the x columns come through the
-// scalar cache with L2-like latency, and more resident waves hide it better than a deeper per-wave pipeline can (the SGPR file
-// holds two 16-double columns, not four; a 2-tile / 4-wave variant measured 2.05 ms against 1.56 ms for three passes).
-__global__ void __launch_bounds__(512) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
-                                                               const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
-                                                               long nproblems, double* __restrict__ partial, int nparts) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long tile = (long)blockIdx.x * 8 + wave;              // wave-uniform: rows [16 tile, 16 tile + 16)
-    const bool have = tile < ntiles;
-    const double* __restrict__ xt = Xt + (have ? tile : 0) * 16 * PA;
-    const int rows = 2 * P + 2 * L + 1;
-    const double* cn = co + (long)P * 64;
-    const double* ko = co + 2L * P * 64;
-    const double* kn = ko + (long)L * 64;
-    const double* act = kn + (long)L * 64;
-    for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
-        __syncthreads();
-        const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
-        double2* dst = reinterpret_cast<double2*>(co);
-        for (int e = threadIdx.x; e < rows * 32; e += 512) dst[e] = src[e];
-        __syncthreads();
-        const long b = (long)g * 64 + lane;
-        if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;
-        const bool live = b < nproblems;
-        const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (live ? b : 0) * dcnt_stride + tile * 16);
-        const uint4 c01 = live ? cp[0] : make_uint4(0, 0, 0, 0), c23 = live ? cp[1] : make_uint4(0, 0, 0, 0);
-        const unsigned wq[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
-        double acc = 0.0;
-        double c0 = co[lane], c1 = cn[lane];
-        double xa[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xa[r] = xt[r];
-        int p = 0;
-        for (int l = 0; l < L; ++l) {
-            double ao[16], an[16];
-            const double k0 = ko[l * 64 + lane], k1 = kn[l * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
-            const int pend = boff[l + 1];
-            for (; p < pend; ++p) {
-                const double d0 = c0, d1 = c1;
-                double xc[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xc[r] = xa[r];
-                const int pn = (p + 1 < P) ? p + 1 : p;
-                c0 = co[pn * 64 + lane]; c1 = cn[pn * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xa[r] = xt[pn * 16 + r];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ao[r] = fma(xc[r], d0, ao[r]); an[r] = fma(xc[r], d1, an[r]); }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const double d = fabs(ao[r]) - fabs(an[r]);
-                const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
-                acc = fma(w * d, d, acc);
-            }
-        }
-        if (live) partial[b * nparts + tile] = acc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ scores kernel
-// scores[i][l] = sum_{p in block l} xa[i][p] * score_w[p] + score_c[l]   (weights.py:60, sign rule folded into score_w)
-// A 16-row tile of Xa (16*PA*8 contiguous bytes) is staged in LDS with coalesced 16-byte loads (row stride PA+1 doubles:
-// conflict-free column walks); thread (row, l-group) forms the short per-block dot products; the tile's scores leave
-// through LDS as one contiguous 16*L block.  Small tiles keep several workgroups per CU resident so that one
-// workgroup's HBM loads overlap another's LDS phase (HBM-bound: 8*N*(PA+L) bytes).
-__global__ void __launch_bounds__(256) scores_kernel(const double* __restrict__ Xa, long N, int PA, int P, int L, const int* __restrict__ boff,
-                                                      const double* __restrict__ score_w, const double* __restrict__ score_c,
-                                                      double* __restrict__ scores) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* tile = reinterpret_cast<double*>(smem_raw);     // [16][PA+1]
-    double* wsh = tile + SCORE_ROWS * (PA + 1);             // [P]
-    double* osh = wsh + P;                                  // [16*L]
-    int* bsh = reinterpret_cast<int*>(osh + SCORE_ROWS * L); // [L+1]
-    const int tid = threadIdx.x;
-    for (int p = tid; p < P; p += 256) wsh[p] = score_w[p];
-    for (int l = tid; l <= L; l += 256) bsh[l] = boff[l];
-    const long ntiles = (N + SCORE_ROWS - 1) / SCORE_ROWS;
-    const int half = PA >> 1;
-    const int r_c = tid & 15, lg = tid >> 4;
-    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const long i0 = tl * SCORE_ROWS;
-        const int rows = (int)lmin(SCORE_ROWS, N - i0);
-        __syncthreads();
-        const double2* src = reinterpret_cast<const double2*>(Xa + i0 * PA);
-        const int n2 = rows * half;
-        for (int e = tid; e < n2; e += 256) {
-            const double2 v = src[e];
-            const int r = e / half, c = 2 * (e - r * half);
-            tile[r * (PA + 1) + c] = v.x;
-            tile[r * (PA + 1) + c + 1] = v.y;
-        }
-        __syncthreads();
-        for (int l = lg; l < L; l += 16) {
-            const double* row = tile + r_c * (PA + 1);
-            double s0 = 0.0, s1 = 0.0;
-            int p = bsh[l];
-            const int pe = bsh[l + 1];
-            for (; p + 1 < pe; p += 2) { s0 += row[p] * wsh[p]; s1 += row[p + 1] * wsh[p + 1]; }
-            if (p < pe) s0 += row[p] * wsh[p];
-            osh[r_c * L + l] = (s0 + s1) + score_c[l];
-        }
-        __syncthreads();
-        double* dst = scores + i0 * L;
-        for (int e = tid; e < rows * L; e += 256) dst[e] = osh[e];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ bootstrap summaries
-// reference _create_summary (plspm/bootstrap.py:24-32): per result column mean, std (ddof 1), 2.5 % / 97.5 % quantiles with
-// linear interpolation, t = original / std -- over the replicates whose status is OK.  One workgroup per column: gather the
-// column into `buf` (LDS when it fits, else a global scratch slice), bitonic sort, tree reductions.
-// out[c*6 + {0..5}] = original, mean, std.error, perc.025, perc.975, t stat.
-__device__ __forceinline__ double quantile_linear(const double* sorted, int m, double q) {
-    const double pos = q * (double)(m - 1);
-    const int lo = (int)floor(pos);
-    const int hi = (lo + 1 < m) ? lo + 1 : lo;
-    const double t = pos - (double)lo, a = sorted[lo], b = sorted[hi], d = b - a;
-    return (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;             // numpy's _lerp (monotone form)
-}
-template <bool IN_LDS>
-__global__ void __launch_bounds__(256) summary_kernel(const double* __restrict__ rows, long B, int stride, int R, const double* __restrict__ original,
-                                                       double* __restrict__ gbuf, int npad, double* __restrict__ out, int* __restrict__ n_used) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ double red[256];
-    __shared__ int cnt_s;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    double* buf = IN_LDS ? reinterpret_cast<double*>(smem_raw) : gbuf + (long)c * npad;
-    if (tid == 0) cnt_s = 0;
-    __syncthreads();
-    // gather the OK replicates' values (order is irrelevant: they get sorted)
-    for (long b0 = 0; b0 < B; b0 += 256) {
-        const long b = b0 + tid;
-        const bool ok = (b < B) && rows[b * stride + R] == 0.0;
-        const unsigned long long bal = __ballot(ok);
-        __shared__ int wbase[4];
-        if ((tid & 63) == 0) wbase[tid >> 6] = atomicAdd(&cnt_s, __popcll(bal));
-        __syncthreads();
-        if (ok) buf[wbase[tid >> 6] + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = rows[b * stride + c];
-        __syncthreads();
-    }
-    const int m = cnt_s;
-    if (tid == 0 && c == 0) *n_used = m;
-    int n2 = 1;
-    while (n2 < m) n2 <<= 1;
-    for (int i = m + tid; i < n2; i += 256) buf[i] = 1.0e308 * 10.0;            // +inf padding sorts to the end
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const double a = buf[i], b = buf[ixj];
-                    const bool up = ((i & k) == 0);
-                    if ((a > b) == up) { buf[i] = b; buf[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    double s = 0.0;
-    for (int i = tid; i < m; i += 256) s += buf[i];
-    red[tid] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
-    const double mean = (m > 0) ? red[0] / (double)m : 0.0;
-    __syncthreads();
-    double v = 0.0;
-    for (int i = tid; i < m; i += 256) { const double d = buf[i] - mean; v += d * d; }
-    red[tid] = v;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
-    if (tid == 0) {
-        const double nan = __builtin_nan("");
-        const double sd = (m > 1) ? sqrt(red[0] / (double)(m - 1)) : nan;
-        double* o = out + (long)c * 6;
-        o[0] = original[c];
-        o[1] = (m > 0) ? mean : nan;
-        o[2] = sd;
-        o[3] = (m > 0) ? quantile_linear(buf, m, 0.025) : nan;
-        o[4] = (m > 0) ? quantile_linear(buf, m, 0.975) : nan;
-        o[5] = original[c] / sd;
-    }
-}
+#include "kernels_input.h"
+#include "kernels_gram.h"
+#include "kernels_solver.h"
+#include "kernels_nonmetric.h"
+#include "kernels_post.h"
 
 // ================================================================================================ host side
 static thread_local std::string g_create_error;
