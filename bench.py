@@ -33,11 +33,11 @@ FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet fp64 matrix; 77.9 TF measured 
 
 
 def synth_inputs():
-    """Synthetic generator of SURVEY.md 8(d) (own code; the oracle module only supplies the generator + structure)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import plspm_oracle as orc
-    X, blocks = orc.synth(N_OBS, orc.satisfaction_C(), MVS_PER_LV, seed=0)
-    return orc, X, blocks
+    """The workload: synthetic generator of SURVEY.md 8(d) (tools/synthetic.py -- data only, no PLS arithmetic)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synthetic
+    X, blocks = synthetic.synth(N_OBS, synthetic.satisfaction_C(), MVS_PER_LV, seed=0)
+    return synthetic, X, blocks
 
 
 def cpu_worker(args):
@@ -47,8 +47,10 @@ def cpu_worker(args):
         threadpool_limits(1)                      # one BLAS thread per worker: the pool, not BLAS, spreads over the cores
     except ImportError:
         pass
-    orc, X, blocks = synth_inputs()
-    model = orc.Model(blocks, orc.satisfaction_C(), "A" * N_LV, "path", True)
+    synthetic, X, blocks = synth_inputs()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import plspm_oracle as orc                    # the cpu_baseline leg is the ONLY place bench.py touches the oracle
+    model = orc.Model(blocks, synthetic.satisfaction_C(), "A" * N_LV, "path", True)
     corr = orc.correction(N_OBS)
     rs = np.random.RandomState(seed)
     t0 = time.perf_counter()
@@ -104,8 +106,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     device_id = local_rank if use_dist else 0
 
-    orc, X, blocks = synth_inputs()
-    C = orc.satisfaction_C()
+    synthetic, X, blocks = synth_inputs()
+    C = synthetic.satisfaction_C()
     boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 
     def make_model():
@@ -186,13 +188,14 @@ def main():
         one, _, _ = model.bootstrap(1, seed=1, rep_offset=probe)
         assert np.array_equal(rec[probe, :width], one[0]), "sharded stream differs from the single-GPU stream"
 
-    # correctness guard on what was timed: every replicate converged, row 0 of the stream equals the oracle
+    # correctness guard on what was timed: every replicate converged, and replicate 0 of the seeded stream equals the committed
+    # reference-arithmetic row (tests/golden/bench_guard.npz, made by tests/golden/make_bench_guard.py with the oracle)
     rows, status, iters = model.bootstrap(8, seed=1, rep_offset=0)
     assert np.all(status == 0), status
+    guard = np.load(os.path.join(ROOT, "tests", "golden", "bench_guard.npz"))
     idx0 = _native.bootstrap_indices(1, 0, N_OBS)
-    omodel = orc.Model(blocks, C, "A" * N_LV, "path", True)
-    ref_row, ref_it = orc.bootstrap_replicate(X, omodel, idx0, orc.correction(N_OBS))
-    assert ref_it == iters[0] and np.allclose(rows[0], ref_row, rtol=1e-8, atol=1e-11), "timed path disagrees with the oracle"
+    assert int(idx0.astype(np.int64).sum()) == int(guard["idx_sum"]) and np.array_equal(idx0[:16], guard["idx_head"]), "resampling stream changed"
+    assert int(guard["iterations"]) == iters[0] and np.allclose(rows[0], guard["row"], rtol=1e-8, atol=1e-11), "timed path disagrees with the oracle"
 
     pcie = None
     if world == 1 and not use_dist:

@@ -259,3 +259,32 @@ def test_hoc_first_stage_path_matches_reference_construction():
     st.add_path(["GOUDA", "CHEDDAR"], ["GOAT"])
     expected = st.path().drop("APE").drop("APE", axis=1)
     pdt.assert_frame_equal(expected, estimator.hoc_path_first_stage(config))
+
+
+def test_workload_generator_matches_the_oracle_copy():
+    """bench.py / tools use tools/synthetic.py (so that they never import the test-only oracle for their workload); the oracle's own
+    generator, which made the goldens, must stay bit-identical."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synthetic
+    import plspm_oracle as orc
+    assert np.array_equal(synthetic.satisfaction_C(), orc.satisfaction_C()) and np.array_equal(synthetic.chain_C(20), orc.chain_C(20))
+    for n, C, k, seed in ((500, orc.satisfaction_C(), 10, 0), (300, orc.chain_C(7), 3, 5)):
+        Xa, ba = synthetic.synth(n, C, k, seed=seed)
+        Xb, bb = orc.synth(n, C, k, seed=seed)
+        assert np.array_equal(Xa, Xb) and all(np.array_equal(u, v) for u, v in zip(ba, bb))
+
+
+def test_bench_guard_fixture_is_current():
+    """tests/golden/bench_guard.npz (bench.py's correctness guard) == the oracle on replicate 0 of the seeded stream."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synthetic
+    import plspm_oracle as orc
+    g = np.load(os.path.join(GOLDEN, "bench_guard.npz"))
+    idx0 = _native.bootstrap_indices(1, 0, 10000)
+    assert int(idx0.astype(np.int64).sum()) == int(g["idx_sum"])
+    X, blocks = synthetic.synth(10000, synthetic.satisfaction_C(), 10, seed=0)
+    row, its = orc.bootstrap_replicate(X, orc.Model(blocks, synthetic.satisfaction_C(), "AAAAAA", "path", True), idx0, orc.correction(10000))
+    assert its == int(g["iterations"])
+    np.testing.assert_allclose(row, g["row"], rtol=1e-12)

@@ -6,8 +6,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, "oracle")
-import plspm_oracle as orc  # noqa: E402  (synthetic data generator only)
+sys.path.insert(0, "tools")
+import synthetic as orc  # noqa: E402  (workload generator: data only)
 
 vp, i32, i64, u64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
 C = orc.satisfaction_C()

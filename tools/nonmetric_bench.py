@@ -9,9 +9,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np  # noqa: E402
-import plspm_oracle as orc  # noqa: E402
+import synthetic as orc  # noqa: E402  (workload generator: data only)
 from plspm import _native  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 5000

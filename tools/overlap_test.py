@@ -4,9 +4,9 @@ the MFMA-bound Gram kernel of the other?  Compares 1 x 5000 replicates on one st
 concurrent streams."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
-import plspm_oracle as orc
+import synthetic as orc
 from plspm import _native
 
 X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
