@@ -244,67 +244,107 @@ __global__ void __launch_bounds__(256) coef_table_kernel(const double* __restric
     }
 }
 
-// One 16-row tile per wave, 8 waves per workgroup (two workgroups per CU -> 4 waves per SIMD): the x columns come through the
-// scalar cache with L2-like latency, and more resident waves hide it better than a deeper per-wave pipeline can (the SGPR file
-// holds two 16-double columns, not four; a 2-tile / 4-wave variant measured 2.05 ms against 1.56 ms for three passes).
-__global__ void __launch_bounds__(512) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
-                                                               const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
-                                                               long nproblems, double* __restrict__ partial, int nparts) {
+typedef double d8 __attribute__((ext_vector_type(8)));
+// acc += x * c with the wave-uniform x read straight from a scalar register (keeps the x columns out of the VGPR file)
+#define FMAC_SV(acc, xs, cv) asm("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc) : "s"(xs), "v"(cv))
+// keeps an accumulator array in VGPRs across a scheduling point (see nm_conv_dense_kernel)
+#define PIN_ACC(a)                                                                                                              \
+    do {                                                                                                                        \
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));         \
+        if (RW == 16) asm volatile("" : "+v"(a[RW - 8]), "+v"(a[RW - 7]), "+v"(a[RW - 6]), "+v"(a[RW - 5]), "+v"(a[RW - 4]), "+v"(a[RW - 3]), "+v"(a[RW - 2]), "+v"(a[RW - 1])); \
+    } while (0)
+
+// RW rows per wave (a 16-row tile or half of one), NW waves per workgroup, two workgroups per CU.  The x columns come through the
+// scalar cache with L2-like latency; resident waves hide it better than a deeper per-wave pipeline can (the SGPR file holds two
+// 16-double columns, not four): 16 rows x 8 waves beat 32 rows x 4 waves by 30 %, 8 rows x 16 waves is the default.
+template <int RW, int NW>
+__global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
+                                                                 const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
+                                                                 long nproblems, double* __restrict__ partial, int nparts, int rbx, int gy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]
+    constexpr int PER_TILE = 16 / RW;                           // row parts per 16-row tile of Xt
+    static_assert(RW == 8 || RW == 16, "a wave takes a 16-row tile or half of one");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long tile = (long)blockIdx.x * 8 + wave;              // wave-uniform: rows [16 tile, 16 tile + 16)
-    const bool have = tile < ntiles;
-    const double* __restrict__ xt = Xt + (have ? tile : 0) * 16 * PA;
+    // XCD-aware decomposition of the 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
+    // XCD k takes the row blocks k, k + 8, ... for every replicate slice -- its share of Xt (1/8 of 5 MB at 10k x 60) stays in
+    // its L2 while the coefficient table streams through.  rbx = row blocks per XCD, gy = replicate slices.
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int rb = (jj % rbx) * 8 + xcd, gy0 = jj / rbx;
+    const long nparts_all = ntiles * PER_TILE;
+    const long part = (long)rb * NW + wave;                     // wave-uniform: rows [RW part, RW part + RW)
+    if ((long)rb * NW >= nparts_all) return;                    // whole workgroup beyond the data (uniform: no barrier is skipped)
+    const bool have = part < nparts_all;
+    const double* __restrict__ xt = Xt + (have ? part / PER_TILE : 0) * 16 * PA + (part % PER_TILE) * RW;
     const int rows = 2 * P + 2 * L + 1;
     const double* cn = co + (long)P * 64;
     const double* ko = co + 2L * P * 64;
     const double* kn = ko + (long)L * 64;
     const double* act = kn + (long)L * 64;
-    for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
+    for (int g = gy0; g < ngroups; g += gy) {
         __syncthreads();
         const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
         double2* dst = reinterpret_cast<double2*>(co);
-        for (int e = threadIdx.x; e < rows * 32; e += 512) dst[e] = src[e];
+        for (int e = threadIdx.x; e < rows * 32; e += 64 * NW) dst[e] = src[e];
         __syncthreads();
         const long b = (long)g * 64 + lane;
         if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;
         const bool live = b < nproblems;
-        const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (live ? b : 0) * dcnt_stride + tile * 16);
-        const uint4 c01 = live ? cp[0] : make_uint4(0, 0, 0, 0), c23 = live ? cp[1] : make_uint4(0, 0, 0, 0);
-        const unsigned wq[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
-        double acc = 0.0;
-        double c0 = co[lane], c1 = cn[lane];
-        double xa[16];
+        unsigned wq[RW / 2];                                    // two uint16 counts per word
+        {
+            const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (live ? b : 0) * dcnt_stride + part * RW);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xa[r] = xt[r];
+            for (int h = 0; h < RW / 8; ++h) {
+                const uint4 c = live ? cp[h] : make_uint4(0, 0, 0, 0);
+                wq[4 * h] = c.x; wq[4 * h + 1] = c.y; wq[4 * h + 2] = c.z; wq[4 * h + 3] = c.w;
+            }
+        }
+        double acc = 0.0;
+        // Column loop, software-pipelined by hand (hipcc sinks a C++ prefetch below the FMAs and waits right after issuing it):
+        // the loads of column p + 1 -- one or two s_load_dwordx16 for the x values, two ds_read_b64 for the lane's coefficients --
+        // are ISSUED before the FMAs of column p and WAITED for after them.  The empty asm statements pin the accumulators on
+        // both sides of the FMA block so that the compiler cannot move the FMAs across the issue / wait points.
+        const unsigned lds_co = (unsigned)(size_t)(co + lane) & 0xffffffffu, lds_cn = (unsigned)(size_t)(cn + lane) & 0xffffffffu;
+        double c0 = co[lane], c1 = cn[lane];
+        d8 xa0, xa1 = {};                                       // column 0 (through the same scalar path: the loop-carried x stays in SGPRs)
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(xa0) : "s"(xt));
+        if (RW == 16) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(xa1) : "s"(xt));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xa0), "+s"(xa1));
         int p = 0;
         for (int l = 0; l < L; ++l) {
-            double ao[16], an[16];
+            double ao[RW], an[RW];
             const double k0 = ko[l * 64 + lane], k1 = kn[l * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
+            for (int r = 0; r < RW; ++r) { ao[r] = k0; an[r] = k1; }
             const int pend = boff[l + 1];
             for (; p < pend; ++p) {
-                const double d0 = c0, d1 = c1;
-                double xc[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xc[r] = xa[r];
                 const int pn = (p + 1 < P) ? p + 1 : p;
-                c0 = co[pn * 64 + lane]; c1 = cn[pn * 64 + lane];
+                const double* xn = xt + pn * 16;
+                d8 xn0, xn1 = {};
+                double c0n, c1n;
+                asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(xn0) : "s"(xn));
+                if (RW == 16) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(xn1) : "s"(xn));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(c0n) : "v"(lds_co + (unsigned)pn * 512u));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(c1n) : "v"(lds_cn + (unsigned)pn * 512u));
+                PIN_ACC(ao); PIN_ACC(an);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xa[r] = xt[pn * 16 + r];
+                for (int r = 0; r < 8; ++r) { FMAC_SV(ao[r], xa0[r], c0); FMAC_SV(an[r], xa0[r], c1); }
+                if (RW == 16) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { ao[r] = fma(xc[r], d0, ao[r]); an[r] = fma(xc[r], d1, an[r]); }
+                    for (int r = 0; r < 8; ++r) { FMAC_SV(ao[8 + r], xa1[r], c0); FMAC_SV(an[8 + r], xa1[r], c1); }
+                }
+                PIN_ACC(ao); PIN_ACC(an);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xn0), "+s"(xn1), "+v"(c0n), "+v"(c1n));
+                xa0 = xn0; xa1 = xn1; c0 = c0n; c1 = c1n;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < RW; ++r) {
                 const double d = fabs(ao[r]) - fabs(an[r]);
                 const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
                 acc = fma(w * d, d, acc);
             }
         }
-        if (live) partial[b * nparts + tile] = acc;
+        if (live) partial[b * nparts + part] = acc;
     }
 }

@@ -432,12 +432,14 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
     const char* dense_env = getenv("PLSPM_CONV_DENSE");
     const bool dense = ent && src->dcnt_ready && dense_lds <= kMaxLds && !(dense_env && dense_env[0] == '0');
-    const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
+    const char* conv_rw = getenv("PLSPM_CONV_ROWS");
+    const bool conv8 = conv_rw && atoi(conv_rw) == 8;              // rows per wave of nm_conv_dense_kernel: 16 (8 waves, default) or 8 (16 waves)
+    const int nparts = dense ? (int)(conv8 ? 2 * ntiles16 : ntiles16) : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     const int ngroups = (int)((nproblems + 63) / 64);
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
         if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
-        if ((rc = allow_lds(m, (const void*)nm_conv_dense_kernel, dense_lds))) return rc;
+        if ((rc = allow_lds(m, (const void*)nm_conv_dense_kernel<8, 16>, dense_lds)) || (rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8>, dense_lds))) return rc;
         if (!src->Xt_valid) {
             hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, (double*)src->Xt.p);
             src->Xt_valid = true;
@@ -511,10 +513,20 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             }
             if (dense) {
                 hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L, nproblems, (double*)m->ctable.p);
-                const unsigned gx = (unsigned)((ntiles16 + 7) / 8);
-                const unsigned gy = (unsigned)std::max<long>(1, std::min<long>(ngroups, (1024 + gx - 1) / gx));
-                hipLaunchKernelGGL(nm_conv_dense_kernel, dim3(gx, gy), dim3(512), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L, conv_boff,
-                                   (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts);
+                const int gx = (int)((ntiles16 + 7) / 8);                      // row blocks of 128 rows (8 tiles: 8 x 16-row or 16 x 8-row waves)
+                const int rbx = (gx + 7) / 8;                                  // row blocks per XCD
+                // replicate slices: one group of 64 replicates per workgroup measured best (1.06 ms for three passes against 1.17 / 1.21 /
+                // 1.28 with 12 / 6 / 13 slices): many small workgroups let the dispatcher balance the CUs
+                const char* gy_env = getenv("PLSPM_CONV_GY");
+                const int gy = gy_env ? std::max(1, atoi(gy_env)) : ngroups;
+                if (conv8)
+                    hipLaunchKernelGGL((nm_conv_dense_kernel<8, 16>), dim3((unsigned)(8 * rbx * gy)), dim3(1024), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA,
+                                       src->P, L, conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts,
+                                       rbx, gy);
+                else
+                    hipLaunchKernelGGL((nm_conv_dense_kernel<16, 8>), dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA,
+                                       src->P, L, conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts,
+                                       rbx, gy);
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
                                    ent_stride, conv_state, conv_stride, part);
