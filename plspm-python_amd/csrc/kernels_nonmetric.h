@@ -256,7 +256,7 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 
 // RW rows per wave (a 16-row tile or half of one), NW waves per workgroup, two workgroups per CU.  The x columns come through the
 // scalar cache with L2-like latency; resident waves hide it better than a deeper per-wave pipeline can (the SGPR file holds two
-// 16-double columns, not four): 16 rows x 8 waves beat 32 rows x 4 waves by 30 %, 8 rows x 16 waves is the default.
+// 16-double columns, not four): 16 rows x 8 waves (used) beat 32 rows x 4 waves by 30 % and 8 rows x 16 waves by 45 %.
 template <int RW, int NW>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
                                                                  const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
@@ -281,15 +281,17 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
     const double* cn = co + (long)P * 64;
     const double* ko = co + 2L * P * 64;
     const double* kn = ko + (long)L * 64;
-    const double* act = kn + (long)L * 64;
     for (int g = gy0; g < ngroups; g += gy) {
+        // nothing active in this group (e.g. the speculative pass after the last iteration): skip before staging; the decision is
+        // the same for every thread of the workgroup, so no barrier is skipped by part of it
+        if (__ballot(table[((long)g * rows + rows - 1) * 64 + lane] != 0.0) == 0ull) continue;
         __syncthreads();
         const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
         double2* dst = reinterpret_cast<double2*>(co);
         for (int e = threadIdx.x; e < rows * 32; e += 64 * NW) dst[e] = src[e];
         __syncthreads();
         const long b = (long)g * 64 + lane;
-        if (!have || __ballot(act[lane] != 0.0) == 0ull) continue;
+        if (!have) continue;
         const bool live = b < nproblems;
         unsigned wq[RW / 2];                                    // two uint16 counts per word
         {

@@ -83,6 +83,8 @@ struct plspm_model {
     int nmx_K = 0, nmx_raw = 0;
     double *d_Xk = nullptr, *d_Mk = nullptr;
     int* d_rowid = nullptr;
+    int* h_flag = nullptr;        // pinned: active-problem counter of the non-metric iteration
+    hipEvent_t ev_flag = nullptr;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
     size_t h_stage_cap = 0;
     bool profiling = false;
@@ -238,6 +240,8 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
         upload_vec(m, &m->d_succ_off, m->succ_off) || upload_vec(m, &m->d_succ_idx, m->succ_idx))
         return bail("descriptor upload failed");
     if (hipMalloc((void**)&m->d_shift, sizeof(double) * P) != hipSuccess) return bail("hipMalloc failed");
+    if (hipHostMalloc((void**)&m->h_flag, 64, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&m->ev_flag, hipEventDisableTiming) != hipSuccess)
+        return bail("pinned flag / event creation failed");
     return m;
 }
 
@@ -254,6 +258,8 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
     if (m->h_stage) hipHostFree(m->h_stage);
+    if (m->h_flag) hipHostFree(m->h_flag);
+    if (m->ev_flag) hipEventDestroy(m->ev_flag);
     if (m->stream && m->owns_stream) hipStreamDestroy(m->stream);
     delete m;
 }
@@ -432,14 +438,12 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
     const char* dense_env = getenv("PLSPM_CONV_DENSE");
     const bool dense = ent && src->dcnt_ready && dense_lds <= kMaxLds && !(dense_env && dense_env[0] == '0');
-    const char* conv_rw = getenv("PLSPM_CONV_ROWS");
-    const bool conv8 = conv_rw && atoi(conv_rw) == 8;              // rows per wave of nm_conv_dense_kernel: 16 (8 waves, default) or 8 (16 waves)
-    const int nparts = dense ? (int)(conv8 ? 2 * ntiles16 : ntiles16) : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
+    const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     const int ngroups = (int)((nproblems + 63) / 64);
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
         if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
-        if ((rc = allow_lds(m, (const void*)nm_conv_dense_kernel<8, 16>, dense_lds)) || (rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8>, dense_lds))) return rc;
+        if ((rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8>, dense_lds))) return rc;
         if (!src->Xt_valid) {
             hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, (double*)src->Xt.p);
             src->Xt_valid = true;
@@ -497,10 +501,11 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     for (int it = 0; it <= m->max_iter + 1; ++it) {
         HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
         launch(1);
-        int h_active = 0;
-        HIPCHK(m, hipMemcpyAsync(&h_active, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(m, hipStreamSynchronize(m->stream));
-        if (h_active == 0) break;
+        // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
+        // problems / replicate groups return at once on the device, and the 4-byte read-back of the counter overlaps with the pass
+        // instead of leaving the GPU idle for a host round trip per iteration.
+        HIPCHK(m, hipMemcpyAsync(m->h_flag, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
         {
             ProfScope ps(m, PLSPM_K_SCORES);
             const double* conv_state = gst;
@@ -519,12 +524,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 // 1.28 with 12 / 6 / 13 slices): many small workgroups let the dispatcher balance the CUs
                 const char* gy_env = getenv("PLSPM_CONV_GY");
                 const int gy = gy_env ? std::max(1, atoi(gy_env)) : ngroups;
-                if (conv8)
-                    hipLaunchKernelGGL((nm_conv_dense_kernel<8, 16>), dim3((unsigned)(8 * rbx * gy)), dim3(1024), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA,
-                                       src->P, L, conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts,
-                                       rbx, gy);
-                else
-                    hipLaunchKernelGGL((nm_conv_dense_kernel<16, 8>), dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA,
+                hipLaunchKernelGGL((nm_conv_dense_kernel<16, 8>), dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA,
                                        src->P, L, conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts,
                                        rbx, gy);
             } else {
@@ -532,6 +532,8 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                                    ent_stride, conv_state, conv_stride, part);
             }
         }
+        HIPCHK(m, hipEventSynchronize(m->ev_flag));
+        if (*m->h_flag == 0) break;
     }
     if (finish) launch(2);
     HIPCHK(m, hipGetLastError());
