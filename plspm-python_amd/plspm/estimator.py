@@ -1,19 +1,19 @@
 """Estimation orchestration (reference plspm/estimator.py:24-74) for the MI355X backend.
 
-Missing values in metric data are mean-imputed on the host before the upload (reference config.py:300, util.py:61-68;
-rows whose whole block is missing were already dropped by Config.filter); a bootstrap of such data would have to re-impute
-per replicate and is not built yet.
-
 The reference treats the data on the host and runs the solver twice (estimator.py:39,52 -- the second run is only
 different when higher-order constructs exist).  Here the raw filtered data are uploaded once, the treatment is part of
 the device moments stage, and the solver runs once.
+
+Missing values (rows whose whole block is missing were already dropped by Config.filter) travel to
+``WeightsCalculatorFactory.run``: metric data are mean-imputed on the moments (reference config.py:300, util.py:61-68;
+every bootstrap replicate with its own means), Scale.NUM / RAW data use the NaN-aware solver (weights.py:88-98).
 
 Higher-order constructs (two-stage approach, estimator.py:43-52): stage 1 fits the model in which every HOC is replaced
 by its constituent LVs (``hoc_path_first_stage``); the constituents' device scores are appended to the data as the
 HOC's manifest variables and stage 2 fits the user's path matrix on that -- two device fits, host orchestration only.
 As in the reference this works for non-metric (Scale.NUM / RAW) models; its metric branch cannot run a HOC model
-(``data.dot(odm)`` misaligns, weights.py:30), so that combination raises here too.  A bootstrap of a HOC model is not
-built yet.
+(``data.dot(odm)`` misaligns, weights.py:30), so that combination raises here too.  The bootstrap of a HOC model runs both
+stages per replicate on the device (``two_stage_bootstrap_handles``, include/plspm_hip.h plspm_model_attach_second_stage).
 """
 from typing import Tuple
 

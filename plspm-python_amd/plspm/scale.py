@@ -1,8 +1,8 @@
 """Measurement scales for non-metric data (reference plspm/scale.py:92-104).
 
-The enum is kept so that model specifications written for the reference still parse; the non-metric
-(optimal scaling) solver itself is not part of the MI355X hot path yet, so estimating a model that sets
-any scale raises ``NotImplementedError``."""
+Setting a scale on any MV (or a ``default_scale``) selects the non-metric solver, as in the reference: NUM / RAW run the
+correlation-matrix solver, ORD / NOM the optimal-scaling solver on indicator columns.  The per-scale
+arithmetic (scale.py:22-89 of the reference) lives in the device solver sources, not in this enum."""
 from enum import Enum
 
 from plspm.util import Value
