@@ -257,12 +257,14 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 // RW rows per wave (a 16-row tile or half of one), NW waves per workgroup, two workgroups per CU.  The x columns come through the
 // scalar cache with L2-like latency; resident waves hide it better than a deeper per-wave pipeline can (the SGPR file holds two
 // 16-double columns, not four): 16 rows x 8 waves (used) beat 32 rows x 4 waves by 30 % and 8 rows x 16 waves by 45 %.
-template <int RW, int NW>
+// BLOCKED: the coefficient tile of a 64-replicate group does not fit LDS as a whole (wide models, e.g. 300 indicator columns):
+// it is staged one LV block at a time ((2 kb + 2) x 64 doubles, kb = widest block), with two barriers per block.
+template <int RW, int NW, bool BLOCKED>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
                                                                  const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
-                                                                 long nproblems, double* __restrict__ partial, int nparts, int rbx, int gy) {
+                                                                 long nproblems, double* __restrict__ partial, int nparts, int rbx, int gy, int kb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]
+    double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]   (BLOCKED: [2 kb + 2][64])
     constexpr int PER_TILE = 16 / RW;                           // row parts per 16-row tile of Xt
     static_assert(RW == 8 || RW == 16, "a wave takes a 16-row tile or half of one");
     const int lane = threadIdx.x & 63;
@@ -285,6 +287,69 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
         // nothing active in this group (e.g. the speculative pass after the last iteration): skip before staging; the decision is
         // the same for every thread of the workgroup, so no barrier is skipped by part of it
         if (__ballot(table[((long)g * rows + rows - 1) * 64 + lane] != 0.0) == 0ull) continue;
+        if (BLOCKED) {
+            const long b = (long)g * 64 + lane;
+            const bool live = b < nproblems;
+            unsigned wq[RW / 2];
+            {
+                const uint4* cp = reinterpret_cast<const uint4*>(dcnt + ((live && have) ? b : 0) * dcnt_stride + (have ? part : 0) * RW);
+#pragma unroll
+                for (int h = 0; h < RW / 8; ++h) {
+                    const uint4 c = (live && have) ? cp[h] : make_uint4(0, 0, 0, 0);
+                    wq[4 * h] = c.x; wq[4 * h + 1] = c.y; wq[4 * h + 2] = c.z; wq[4 * h + 3] = c.w;
+                }
+            }
+            const double* tg = table + (long)g * rows * 64;
+            double* bcn = co + (long)kb * 64;                   // [kb][64] new coefficients, then k_old[64], k_new[64]
+            double* bk = bcn + (long)kb * 64;
+            const unsigned lds_co = (unsigned)(size_t)(co + lane) & 0xffffffffu, lds_cn = (unsigned)(size_t)(bcn + lane) & 0xffffffffu;
+            double acc = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const int p0 = boff[l], nb = boff[l + 1] - p0;
+                __syncthreads();                                // everybody is done with the previous block's coefficients
+                for (int e = threadIdx.x; e < nb * 64; e += 64 * NW) { co[e] = tg[(long)p0 * 64 + e]; bcn[e] = tg[((long)P + p0) * 64 + e]; }
+                if (threadIdx.x < 64) { bk[lane] = tg[(2L * P + l) * 64 + lane]; bk[64 + lane] = tg[(2L * P + L + l) * 64 + lane]; }
+                __syncthreads();
+                if (!have) continue;                            // (uniform per wave; the barriers above are reached by every wave)
+                double ao[RW], an[RW];
+                const double k0 = bk[lane], k1 = bk[64 + lane];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) { ao[r] = k0; an[r] = k1; }
+                double c0 = co[lane], c1 = bcn[lane];
+                d8 xa0, xa1 = {};
+                asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(xa0) : "s"(xt + p0 * 16));
+                if (RW == 16) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(xa1) : "s"(xt + p0 * 16));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xa0), "+s"(xa1));
+                for (int q = 0; q < nb; ++q) {
+                    const int qn = (q + 1 < nb) ? q + 1 : q;
+                    const double* xn = xt + (p0 + qn) * 16;
+                    d8 xn0, xn1 = {};
+                    double c0n, c1n;
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(xn0) : "s"(xn));
+                    if (RW == 16) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(xn1) : "s"(xn));
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(c0n) : "v"(lds_co + (unsigned)qn * 512u));
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(c1n) : "v"(lds_cn + (unsigned)qn * 512u));
+                    PIN_ACC(ao); PIN_ACC(an);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { FMAC_SV(ao[r], xa0[r], c0); FMAC_SV(an[r], xa0[r], c1); }
+                    if (RW == 16) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { FMAC_SV(ao[8 + r], xa1[r], c0); FMAC_SV(an[8 + r], xa1[r], c1); }
+                    }
+                    PIN_ACC(ao); PIN_ACC(an);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xn0), "+s"(xn1), "+v"(c0n), "+v"(c1n));
+                    xa0 = xn0; xa1 = xn1; c0 = c0n; c1 = c1n;
+                }
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const double d = fabs(ao[r]) - fabs(an[r]);
+                    const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
+                    acc = fma(w * d, d, acc);
+                }
+            }
+            if (live && have) partial[b * nparts + part] = acc;
+            continue;
+        }
         __syncthreads();
         const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
         double2* dst = reinterpret_cast<double2*>(co);

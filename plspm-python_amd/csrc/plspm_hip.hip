@@ -437,13 +437,21 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     const int table_rows = 2 * src->P + 2 * L + 1;
     const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
     const char* dense_env = getenv("PLSPM_CONV_DENSE");
-    const bool dense = ent && src->dcnt_ready && dense_lds <= kMaxLds && !(dense_env && dense_env[0] == '0');
+    // coefficient tile of 64 replicates: whole in LDS when it fits, else one LV block at a time (kb = widest block of the map the pass uses)
+    const std::vector<int>& conv_blocks = m->stage1 ? m->lv_cols : m->boff;
+    int kb = 1;
+    for (int l = 0; l < L; ++l) kb = std::max(kb, conv_blocks[l + 1] - conv_blocks[l]);
+    const bool dense_whole = dense_lds <= kMaxLds && !getenv("PLSPM_CONV_BLOCKED");      // (the variable forces the blocked variant: tests)
+    const size_t dense_blocked_lds = (size_t)(2 * kb + 2) * 64 * sizeof(double);
+    const size_t dense_use_lds = dense_whole ? dense_lds : dense_blocked_lds;
+    const bool dense = ent && src->dcnt_ready && dense_use_lds <= kMaxLds && !(dense_env && dense_env[0] == '0');
     const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     const int ngroups = (int)((nproblems + 63) / 64);
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
         if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
-        if ((rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8>, dense_lds))) return rc;
+        if (dense_whole ? (rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8, false>, dense_use_lds)) : (rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8, true>, dense_use_lds)))
+            return rc;
         if (!src->Xt_valid) {
             hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, (double*)src->Xt.p);
             src->Xt_valid = true;
@@ -524,9 +532,9 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 // 1.28 with 12 / 6 / 13 slices): many small workgroups let the dispatcher balance the CUs
                 const char* gy_env = getenv("PLSPM_CONV_GY");
                 const int gy = gy_env ? std::max(1, atoi(gy_env)) : ngroups;
-                hipLaunchKernelGGL((nm_conv_dense_kernel<16, 8>), dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA,
-                                       src->P, L, conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts,
-                                       rbx, gy);
+                auto conv_kernel = dense_whole ? nm_conv_dense_kernel<16, 8, false> : nm_conv_dense_kernel<16, 8, true>;
+                hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
+                                   conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts, rbx, gy, kb);
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
                                    ent_stride, conv_state, conv_stride, part);

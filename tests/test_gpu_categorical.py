@@ -177,3 +177,30 @@ def test_api_bootstrap_categorical():
     om = calc.outer_model()
     assert_close(w.loc[om.index, "original"].values, om["weight"].values, 1e-12)
     assert boot.paths().shape[0] == 2 and boot.r_squared().shape[0] == 1
+
+
+def test_wide_indicator_model_uses_the_block_staged_stop_rule_pass():
+    """60 five-point ORD items = 300 indicator columns: the coefficient tile of 64 replicates (300 KB) no longer fits LDS as a whole,
+    the dense pass stages it per LV block.  Must agree with the gathering pass and with the oracle."""
+    import os
+    from plspm import _native
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(1500, C, 10, seed=31)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+    model = orc.Model(blocks, C, "AAAAAA", "centroid", True, tol=1e-6, scales=["ORD"] * 60)
+    nm, g = gpu_fit_cat(likert, model)
+    check_fit(g, orc.fit(likert, model), "wide")
+    dense = nm.bootstrap(70, seed=4)
+    os.environ["PLSPM_CONV_DENSE"] = "0"
+    try:
+        gathered = nm.bootstrap(70, seed=4)
+    finally:
+        del os.environ["PLSPM_CONV_DENSE"]
+    assert np.all(dense[1] == 0)
+    assert np.array_equal(dense[1], gathered[1]) and np.array_equal(dense[2], gathered[2])
+    assert_close(dense[0], gathered[0], 1e-11, 1e-13)
+    rows = _rows_in_data_order(dense[0], g["inv"], 60, 6, nm.n_eff)
+    mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(4, 69, 1500), orc.correction(1500))
+    assert its == dense[2][69]
+    assert_close(rows[69], mine, RTOL, ATOL)

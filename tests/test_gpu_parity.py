@@ -605,9 +605,15 @@ def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
         gathered = nm.bootstrap(130, seed=2)
     finally:
         del os.environ["PLSPM_CONV_DENSE"]
-    assert np.array_equal(dense[1], gathered[1]) and np.array_equal(dense[2], gathered[2])
+    os.environ["PLSPM_CONV_BLOCKED"] = "1"                  # coefficient tile staged one LV block at a time (wide models)
+    try:
+        blocked = nm.bootstrap(130, seed=2)
+    finally:
+        del os.environ["PLSPM_CONV_BLOCKED"]
+    for other in (gathered, blocked):
+        assert np.array_equal(dense[1], other[1]) and np.array_equal(dense[2], other[2])
+        assert_close(dense[0], other[0], 1e-12, 1e-14)
     assert np.all(dense[1] == 0) and dense[2].min() >= 2
-    assert_close(dense[0], gathered[0], 1e-12, 1e-14)
 
 
 def test_nonmetric_bootstrap_10k_vs_oracle_spot_checks():

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Categorical (Scale.ORD, 5-point Likert) counterpart of the headline workload: 10k x 60 x 6, Mode A, PATH, B replicates per
+step -- 300 indicator columns on the device.  Prints one JSON line with replicates/s and per-kernel-class HIP-event times."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+import synthetic  # noqa: E402
+from plspm import _native  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+steps = int(os.environ.get("CAT_BENCH_STEPS", "3"))
+C = synthetic.satisfaction_C()
+X, blocks = synthetic.synth(10000, C, 10, seed=0)
+Z = (X - X.mean(axis=0)) / X.std(axis=0)
+likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+cols, mv_off, boff = [], [0], [0]
+for b in blocks:
+    for p in b:
+        codes = likert[:, p].astype(int) - 1
+        ind = np.zeros((10000, 5)); ind[np.arange(10000), codes] = 1.0
+        cols.append(ind); mv_off.append(mv_off[-1] + 5)
+    boff.append(mv_off[-1])
+Xaug = np.ascontiguousarray(np.concatenate(cols, axis=1))
+m = _native.NativeModel(np.array(boff, dtype=np.int32), C.astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, nonmetric=True,
+                        categorical=(np.array(mv_off, dtype=np.int32), np.ones(60, dtype=np.int32)))
+m.upload(Xaug)
+t0 = time.perf_counter(); fit = m.fit(want_scores=False); t_fit = time.perf_counter() - t0
+m.bootstrap_device(B, seed=1); m.sync()
+m.profile(True); m.profile_reset()
+t0 = time.perf_counter()
+for _ in range(steps):
+    m.bootstrap_device(B, seed=1)
+    m.sync()
+dt = (time.perf_counter() - t0) / steps
+rows, status, iters = m.bootstrap(32, seed=1)
+k = {n: m.profile_read(n) for n in ("resample", "gram", "solver", "scores")}
+print(json.dumps({"workload": "categorical (Scale.ORD, 5-point) 10k x 60 MVs (300 indicator columns) x 6, Mode A, PATH, %d replicates per step" % B,
+                  "replicates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "fit_iterations": fit["iterations"], "fit_status": fit["status"],
+                  "fit_wall_ms": round(t_fit * 1e3, 2), "replicate_iterations": [int(iters.min()), int(iters.max())], "all_ok": bool(np.all(status == 0)),
+                  "kernel_ms_per_step": {n: round(v[0] / steps, 3) for n, v in k.items()}}))
