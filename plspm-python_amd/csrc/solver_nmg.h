@@ -39,9 +39,10 @@ struct NmgExtra {
     double *inc, *dec, *gsum, *gf;   // [cmax] pooled values of the two directions; pooling scratch (group sums / weights)
     double *Bm, *Fm, *beta, *rhs;    // [kmv*kmv] block moment matrix and its Cholesky copy, [kmv], [kmv]
     int* grp;                   // [cmax] (stored in a double-aligned slot)
+    double* pq;                 // [Pm * 8 * cmax] per-MV scratch of the parallel quantification (Mode A blocks)
 };
 PLSPM_HD long nmg_extra_doubles(int Q, int Pm, int L, int cmax, int kmv) {
-    return (long)Q + Pm + L + 2L * (Q + 1) * L + (long)L * L + ((long)Pm * L + Pm) + 7L * cmax + 2L * kmv * kmv + 2L * kmv + cmax + 8;
+    return (long)Q + Pm + L + 2L * (Q + 1) * L + (long)L * L + ((long)Pm * L + Pm) + 7L * cmax + 2L * kmv * kmv + 2L * kmv + cmax + 8 + 8L * Pm * cmax;
 }
 PLSPM_HD void nmg_carve(NmgExtra& x, double* base, int Q, int Pm, int L, int cmax, int kmv) {
     double* p = base;
@@ -51,7 +52,8 @@ PLSPM_HD void nmg_carve(NmgExtra& x, double* base, int Q, int Pm, int L, int cma
     x.cm = p; p += cmax; x.cf = p; p += cmax; x.cs = p; p += cmax;
     x.inc = p; p += cmax; x.dec = p; p += cmax; x.gsum = p; p += cmax; x.gf = p; p += cmax;
     x.Bm = p; p += (long)kmv * kmv; x.Fm = p; p += (long)kmv * kmv; x.beta = p; p += kmv; x.rhs = p; p += kmv;
-    x.grp = reinterpret_cast<int*>(p);
+    x.grp = reinterpret_cast<int*>(p); p += cmax + 8;
+    x.pq = p;
 }
 PLSPM_HD long nmg_state_doubles(int Q, int Pm, int L, int cmax, int kmv) { return nm_state_doubles(Q, L, 0) + nmg_extra_doubles(Q, Pm, L, cmax, kmv); }
 
@@ -119,6 +121,32 @@ PLSPM_HD double nmg_ordinalize(const double* m, const double* f, int C, double s
     double mean = 0.0, ss = 0.0;
     for (int c = 0; c < C; ++c) { const double v = gsum[grp[c]] / gf[grp[c]]; out[c] = v; mean += f[c] * v; ss += f[c] * v * v; }
     return ss - mean * mean;
+}
+
+// Quantification of one ORD / NOM manifest variable from the category means of (corrected) z (scale.py:42-89): compact to the
+// categories present in this problem (frequency > 0), pool monotonically (ORD, both directions) or keep the means (NOM),
+// population-standardise, scatter back into tq.  cm / cf: [C] category means and frequencies (overwritten); scratch: 5 arrays of C
+// doubles + C ints.
+PLSPM_HD void nmg_quantify_mv(int kind, int C, const double* freq_all, double* cm, double* cf, double* cs, double* inc, double* dec, double* gsum, double* gf,
+                              int* grp, double* tq_out) {
+    int Cp = 0;
+    for (int c = 0; c < C; ++c) if (cf[c] > 0.0) { cm[Cp] = cm[c]; cf[Cp] = cf[c]; ++Cp; }
+    double mean = 0.0, ss = 0.0;
+    if (kind == KIND_ORD) {
+        const double v_inc = nmg_ordinalize(cm, cf, Cp, 1.0, inc, grp, gsum, gf);
+        const double v_dec = nmg_ordinalize(cm, cf, Cp, -1.0, dec, grp, gsum, gf);
+        if (v_inc < v_dec) { for (int c = 0; c < Cp; ++c) cs[c] = -dec[c]; }                      // -x_quant_decr (scale.py:74)
+        else { for (int c = 0; c < Cp; ++c) cs[c] = inc[c]; }
+    } else {
+        for (int c = 0; c < Cp; ++c) cs[c] = cm[c];                                               // NOM (scale.py:87)
+    }
+    for (int c = 0; c < Cp; ++c) { mean += cf[c] * cs[c]; ss += cf[c] * cs[c] * cs[c]; }
+    const double sd = sqrt(ss - mean * mean);                          // treat_numpy(.) * correction == population standardisation
+    int at = 0;
+    for (int c = 0; c < C; ++c) {
+        if (freq_all[c] > 0.0) { tq_out[c] = (cs[at] - mean) / sd; ++at; }
+        else tq_out[c] = 0.0;
+    }
 }
 
 // packed scatter -> Mn (raw second moments / n, ones row/column = column means), initial quantification and scores (weights.py:82-98)
@@ -212,16 +240,35 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
         }
         ws.a[l] = s;
     });
-    // quantification, LV by LV, MV by MV (Gauss-Seidel inside a block, weights.py:112-115)
+    // Quantification (weights.py:112-115).  Without the Mode-B correction (Mode A blocks, single-MV blocks) the MVs of a block
+    // only read z_l, so ALL of them are quantified at once, one thread per MV with its own scratch; Mode-B blocks go MV by MV
+    // below (Gauss-Seidel: the correction of MV j uses the block's MVs as updated so far, weights.py:143-145).
+    ex.par(Pm, [&](int p) {
+        const int kind = cd.mv_kind[p];
+        if (kind == KIND_NUM) return;
+        int l = 0;
+        while (p >= cd.lmv_off[l + 1]) ++l;
+        if (md.mode[l] == MODE_B && cd.lmv_off[l + 1] - cd.lmv_off[l] > 1) return;
+        const int j0 = cd.mv_off[p], C = cd.mv_off[p + 1] - j0, cm_ = cd.cmax;
+        double* w = x.pq + (long)p * 8 * cm_;
+        double *cm = w, *cf = w + cm_, *cs = w + 2 * cm_, *inc = w + 3 * cm_, *dec = w + 4 * cm_, *gsum = w + 5 * cm_, *gf = w + 6 * cm_;
+        int* grp = reinterpret_cast<int*>(w + 7 * cm_);
+        for (int c = 0; c < C; ++c) {
+            cf[c] = Mn[Q * LD + j0 + c];
+            cm[c] = (cf[c] > 0.0) ? x.MZ[(j0 + c) * L + l] / cf[c] : 0.0;
+        }
+        nmg_quantify_mv(kind, C, Mn + Q * LD + j0, cm, cf, cs, inc, dec, gsum, gf, grp, x.tq + j0);
+        x.tc[p] = 0.0;
+    });
     for (int l = 0; l < L; ++l) {
         const int p0 = cd.lmv_off[l], p1 = cd.lmv_off[l + 1], k = p1 - p0;
         const double mean_z = x.MZ[Q * L + l];
         bool have_beta = false;
-        for (int p = p0; p < p1; ++p) {
+        const bool modeb = (md.mode[l] == MODE_B) && (k > 1);
+        for (int p = p0; modeb && p < p1; ++p) {
             const int kind = cd.mv_kind[p];
             if (kind == KIND_NUM) continue;                                       // NUM / RAW: constant quantification
             const int j0 = cd.mv_off[p], C = cd.mv_off[p + 1] - j0;
-            const bool modeb = (md.mode[l] == MODE_B) && (k > 1);
             if (modeb && !have_beta) {
                 // betas of OLS(z ~ 1 + current block) = Cov_bb^-1 cov_bz, once per LV and iteration (weights.py:139-142)
                 ex.par(k * k, [&](int e) {
@@ -260,25 +307,7 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
                 x.cm[c] = (x.cf[c] > 0.0) ? s / x.cf[c] : 0.0;
             });
             ex.one([&]() {
-                // compact to the categories present in this problem (frequency > 0), quantify, scatter back
-                int Cp = 0;
-                for (int c = 0; c < C; ++c) if (x.cf[c] > 0.0) { x.cm[Cp] = x.cm[c]; x.cf[Cp] = x.cf[c]; ++Cp; }
-                double mean = 0.0, ss = 0.0;
-                if (kind == KIND_ORD) {
-                    const double v_inc = nmg_ordinalize(x.cm, x.cf, Cp, 1.0, x.inc, x.grp, x.gsum, x.gf);
-                    const double v_dec = nmg_ordinalize(x.cm, x.cf, Cp, -1.0, x.dec, x.grp, x.gsum, x.gf);
-                    if (v_inc < v_dec) { for (int c = 0; c < Cp; ++c) x.cs[c] = -x.dec[c]; }                      // -x_quant_decr (scale.py:74)
-                    else { for (int c = 0; c < Cp; ++c) x.cs[c] = x.inc[c]; }
-                } else {
-                    for (int c = 0; c < Cp; ++c) x.cs[c] = x.cm[c];                                               // NOM (scale.py:87)
-                }
-                for (int c = 0; c < Cp; ++c) { mean += x.cf[c] * x.cs[c]; ss += x.cf[c] * x.cs[c] * x.cs[c]; }
-                const double sd = sqrt(ss - mean * mean);                          // treat_numpy(.) * correction == population standardisation
-                int at = 0;
-                for (int c = 0; c < C; ++c) {
-                    if (Mn[Q * LD + j0 + c] > 0.0) { x.tq[j0 + c] = (x.cs[at] - mean) / sd; ++at; }
-                    else x.tq[j0 + c] = 0.0;
-                }
+                nmg_quantify_mv(kind, C, Mn + Q * LD + j0, x.cm, x.cf, x.cs, x.inc, x.dec, x.gsum, x.gf, x.grp, x.tq + j0);
                 x.tc[p] = 0.0;
             });
         }
