@@ -861,7 +861,11 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
             continue;
         }
         if (m->nonmetric) {
-            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128))) return rc;
+            // threads per problem by model width (measured: 60 columns 0.60 / 0.64 / 0.81 ms with 64 / 128 / 256 threads; 300 indicator
+            // columns 21.0 / 13.5 / 10.0 ms)
+            const char* nt_env = getenv("PLSPM_NM_THREADS");
+            const int nm_threads = nt_env ? atoi(nt_env) : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, nm_threads))) return rc;
             continue;
         }
         long long* d_marks = nullptr;
