@@ -155,37 +155,42 @@ PLSPM_HD bool spd_solve_fixed(const double* M, int L, const int* idx, int k, int
         }
         b[r] = (r < k) ? M[ir * L + col] : 0.0;
     }
+    // square-root-free factorisation A = U' D U (U unit upper triangular): K reciprocals are the only long-latency operations
+    // (fp64 sqrt and divide are ~150-cycle dependent chains on the device; the Cholesky form needed 4 sqrt + 12 divides for K = 4).
+    // T[r][c] = U[r][c] * D[r] is kept beside U so that the updates are plain multiply-adds.
     bool ok = true;
+    double T[K][K], invd[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         double d = A[j][j];
 #pragma unroll
-        for (int r = 0; r < j; ++r) d -= A[r][j] * A[r][j];
+        for (int r = 0; r < j; ++r) d -= A[r][j] * T[r][j];
         ok = ok && (d > 0.0);
-        d = sqrt(d);
-        A[j][j] = d;
-        const double inv = 1.0 / d;
+        invd[j] = 1.0 / d;
 #pragma unroll
         for (int c = j + 1; c < K; ++c) {
             double t = A[j][c];
 #pragma unroll
-            for (int r = 0; r < j; ++r) t -= A[r][j] * A[r][c];
-            A[j][c] = t * inv;
+            for (int r = 0; r < j; ++r) t -= A[r][j] * T[r][c];
+            T[j][c] = t;
+            A[j][c] = t * invd[j];                                  // U[j][c] overwrites the upper triangle of A
         }
     }
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
+    for (int i = 0; i < K; ++i) {                                   // U' z = b
         double t = b[i];
 #pragma unroll
         for (int r = 0; r < i; ++r) t -= A[r][i] * b[r];
-        b[i] = t / A[i][i];
+        b[i] = t;
     }
 #pragma unroll
-    for (int i = K - 1; i >= 0; --i) {
+    for (int i = 0; i < K; ++i) b[i] *= invd[i];                    // y = D^-1 z
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {                              // U x = y
         double t = b[i];
 #pragma unroll
         for (int c = i + 1; c < K; ++c) t -= A[i][c] * b[c];
-        b[i] = t / A[i][i];
+        b[i] = t;
     }
 #pragma unroll
     for (int r = 0; r < K; ++r) if (r < k) x[r] = b[r];
@@ -479,7 +484,7 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
 }
 
 // Inner model (inner_model.py:58-75: OLS with intercept == centred normal equations on the score covariance ws.Cs) and the
-// effects (inner_model.py:33-53): indirect = sum_{k=2..L} B^k (none when L == 2), total = B + indirect.  -> ws.Bm, ws.r2, ws.Ind
+// effects (inner_model.py:33-53): indirect = sum_{k>=2} B^k, total = B + indirect.  -> ws.Bm, ws.r2, ws.Ind
 template <class Ex>
 PLSPM_HD void inner_model_effects(Ex& ex, const ModelDesc& md, Workspace& ws) {
     const int L = md.L;
@@ -499,22 +504,17 @@ PLSPM_HD void inner_model_effects(Ex& ex, const ModelDesc& md, Workspace& ws) {
         }
     });
     ex.mark(5);
-    ex.par(L * L, [&](int e) { ws.Ind[e] = 0.0; ws.Pw[e] = ws.Bm[e]; });
-    if (L != 2) {
-        double* cur = ws.Pw;
-        double* nxt = ws.Pw2;
-        for (int k = 2; k <= L; ++k) {
-            ex.par(L * L, [&](int e) {
-                const int r = e / L, c = e - r * L;
-                double s = 0.0;
-                for (int t = 0; t < L; ++t) s += cur[r * L + t] * ws.Bm[t * L + c];
-                nxt[e] = s;
-                ws.Ind[e] += s;
-            });
-            if (!ex.any(L * L, [&](int e) { return nxt[e] != 0.0; })) break;   // B is nilpotent: further powers vanish exactly
-            double* t = cur; cur = nxt; nxt = t;
+    // indirect = B^2 + B^3 + ... (inner_model.py:37-44 sums the matrix powers) = (I - B)^-1 - I - B.  B is strictly lower triangular in
+    // path order, so column j of (I - B)^-1 follows by forward substitution: x_j = 1, x_i = B[i][j] + sum_{j < k < i} B[i][k] x_k.  One thread
+    // per column; ws.Pw holds the columns of (I - B)^-1 (row-major like B).
+    ex.par(L, [&](int j) {
+        for (int i = 0; i < L; ++i) {
+            double ind = 0.0;                                    // paths j -> ... -> i of length >= 2 (no cancellation: summed on its own)
+            for (int k = j + 1; k < i; ++k) ind += ws.Bm[i * L + k] * ws.Pw[k * L + j];
+            ws.Pw[i * L + j] = (i == j) ? 1.0 : ((i > j) ? ws.Bm[i * L + j] + ind : 0.0);
+            ws.Ind[i * L + j] = ind;
         }
-    }
+    });
 }
 
 // Everything after the iteration (shared by the metric and the non-metric solver): final normalisation, the metric sign
