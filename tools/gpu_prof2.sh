@@ -11,7 +11,7 @@ timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1 | tee gpurun_out/nonm
 timeout 900 python tools/fit_bench.py c2 c5 2>&1 | grep "^{" | tee gpurun_out/fit_bench.jsonl
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write $R/gpurun_out/prof_nm
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o stats -- python $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 > $R/gpurun_out/prof_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o stats -- python $R/bench.py --no-cpu-baseline --steps 50 --warmup 5 > $R/gpurun_out/prof_stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -o fetch -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/prof_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_write -o write -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/prof_write.log 2>&1
 NM_BENCH_STEPS=5 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_nm -o nm -- python $R/tools/nonmetric_bench.py > $R/gpurun_out/prof_nm.log 2>&1
