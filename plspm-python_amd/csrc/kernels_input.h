@@ -114,22 +114,25 @@ __global__ void __launch_bounds__(256) pack_colmajor_kernel(const double* __rest
 // (row, multiplicity) pairs -- ~63 % of the rows survive, so the Gram kernel issues 37 % fewer MFMAs than a
 // gather of all N draws.  The list is zero-padded to a multiple of 4 entries (one MFMA k-group).
 // `dcnt` (optional): the histogram itself as [replicate][dcnt_stride] uint16, zero-padded -- the dense stop-rule pass of the
-// non-metric solvers reads it (nm_conv_dense_kernel); N <= 36000 here, so a count always fits.
+// non-metric solvers reads it (nm_conv_dense_kernel); N <= 65535 here, so a count always fits.
 __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restrict__ idx, uint64_t seed, int64_t rep0, int2* __restrict__ ent,
                                                         int* __restrict__ nent, long ent_stride, int* __restrict__ err, unsigned short* __restrict__ dcnt,
                                                         long dcnt_stride) {
+    // 16-bit counters, two per LDS word (a count never exceeds N <= 65535 on this path): half the LDS of 32-bit counters, i.e.
+    // twice the resident workgroups.  Row r lives in the low (even r) or high (odd r) half of word r / 2.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);
     __shared__ int wave_tot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long b = blockIdx.x;
-    for (int i = tid; i < N; i += 256) hist[i] = 0u;
+    const int nwords = (N + 1) >> 1;
+    for (int i = tid; i < nwords; i += 256) hist[i] = 0u;
     __syncthreads();
     if (idx) {
         const int* my = idx + b * (long)N;
         for (int i = tid; i < N; i += 256) {
             const int r = my[i];
-            if ((unsigned)r < (unsigned)N) atomicAdd(&hist[r], 1u);
+            if ((unsigned)r < (unsigned)N) atomicAdd(&hist[r >> 1], (r & 1) ? 0x10000u : 1u);
             else atomicOr(err, 1);
         }
     } else {
@@ -139,14 +142,15 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
             const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * q + j < N) atomicAdd(&hist[to_index(u.v[j], (uint32_t)N)], 1u);
+                if (4 * q + j < N) { const unsigned r = to_index(u.v[j], (uint32_t)N); atomicAdd(&hist[r >> 1], (r & 1u) ? 0x10000u : 1u); }
         }
     }
     __syncthreads();
-    if (dcnt) {
-        unsigned short* mine_cnt = dcnt + b * dcnt_stride;
-        for (int i = tid; i < (int)dcnt_stride; i += 256) mine_cnt[i] = (i < N) ? (unsigned short)hist[i] : (unsigned short)0;
+    if (dcnt) {                                                  // the packed words ARE the little-endian uint16 row of the dense histogram
+        unsigned* mine_cnt = reinterpret_cast<unsigned*>(dcnt + b * dcnt_stride);
+        for (int i = tid; i < (int)(dcnt_stride >> 1); i += 256) mine_cnt[i] = (i < nwords) ? hist[i] : 0u;
     }
+    auto count_of = [&](int row) -> int { return (int)((hist[row >> 1] >> ((row & 1) << 4)) & 0xffffu); };
     // ordered compaction with two barriers: wave w owns the contiguous row range [w*Q, (w+1)*Q); pass 1 counts its
     // non-empty rows, pass 2 writes them behind the preceding waves' totals (ballot + popcount prefix inside a wave).
     int2* my_ent = ent + b * ent_stride;
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
     int mine = 0;
     for (int c0 = r0; c0 < r1; c0 += 64) {
         const int row = c0 + lane;
-        const int cnt = (row < r1) ? (int)hist[row] : 0;
+        const int cnt = (row < r1) ? count_of(row) : 0;
         mine += __popcll(__ballot(cnt > 0));
     }
     if (lane == 0) wave_tot[wave] = mine;
@@ -165,7 +169,7 @@ __global__ void __launch_bounds__(256) resample_kernel(int N, const int* __restr
     const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     for (int c0 = r0; c0 < r1; c0 += 64) {
         const int row = c0 + lane;
-        const int cnt = (row < r1) ? (int)hist[row] : 0;
+        const int cnt = (row < r1) ? count_of(row) : 0;
         const unsigned long long bal = __ballot(cnt > 0);
         if (cnt > 0) my_ent[off + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(row, cnt);
         off += __popcll(bal);

@@ -811,7 +811,7 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     if (!m || B < 1 || rep_offset < 0) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
     if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
     const long N = m->N;
-    const bool lds_hist = (N <= 36000);        // N * 4 bytes of LDS histogram (<= 144 KB); beyond that a global scratch slice per replicate
+    const bool lds_hist = (N <= 65535);        // N * 2 bytes of LDS histogram (16-bit counters, <= 128 KB); beyond that a global scratch slice per replicate
     HIPCHK(m, hipSetDevice(m->device));
     const int R = plspm_row_stride(m);
     const long psize = packed_size(m->T);
@@ -838,9 +838,10 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
         if (lds_hist) {
-            if ((rc = allow_lds(m, (const void*)resample_kernel, (size_t)N * sizeof(unsigned)))) return rc;
+            const size_t hist_bytes = (size_t)((N + 1) / 2) * sizeof(unsigned);
+            if ((rc = allow_lds(m, (const void*)resample_kernel, hist_bytes))) return rc;
             ProfScope ps(m, PLSPM_K_RESAMPLE);
-            hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), (size_t)N * sizeof(unsigned), m->stream, (int)N,
+            hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)N,
                                d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p,
                                want_dcnt ? (unsigned short*)m->dcnt.p : (unsigned short*)nullptr, dcnt_stride);
         } else {

@@ -349,12 +349,13 @@ def test_config5_full_size_1m_rows_properties():
     check_fit(gs, orc.fit(Xs, model), "50k prefix")
 
 
-def test_bootstrap_large_n_global_histogram_path():
-    """N = 50,000 > the LDS-histogram limit: the global-scratch resampler must give the same rows as the oracle run on the
-    same indices (device RNG mirrored on the host), and explicit indices must reproduce the RNG path bit for bit."""
+@pytest.mark.parametrize("n", [50000, 70000])
+def test_bootstrap_large_n_histogram_paths(n):
+    """N = 50,000: the largest LDS histograms (16-bit counters, 100 KB; a count of N must still fit); N = 70,000 > 65,535: the
+    global-scratch resampler.  Both must give the same rows as the oracle run on the same indices (device RNG mirrored on the
+    host), and explicit indices must reproduce the RNG path bit for bit."""
     from plspm import _native
     C = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0]])
-    n = 50000
     X, blocks = orc.synth(n, C, 4, seed=11)
     model = orc.Model(blocks, C, "ABA", "path", True)
     nm = native_model(model)
@@ -593,8 +594,8 @@ def test_nonmetric_bootstrap_explicit_indices_vs_reference_rows(tag):
 
 
 def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
-    """The bootstrap's dense stop-rule pass (nm_conv_dense_kernel) and the gathering pass it replaced (still used for N > 36,000
-    or very wide models; PLSPM_CONV_DENSE=0 forces it) must take the same decisions and give the same rows."""
+    """The bootstrap's dense stop-rule pass (nm_conv_dense_kernel) and the gathering pass it replaced (still used for N > 65,535
+    or models too wide even for block staging; PLSPM_CONV_DENSE=0 forces it) must take the same decisions and give the same rows."""
     import os
     X, blocks = orc.synth(3000, orc.satisfaction_C(), 5, seed=17)
     model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "factorial", True, tol=1e-7, scales=["NUM"] * 30)
