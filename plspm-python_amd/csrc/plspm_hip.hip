@@ -83,9 +83,6 @@ struct plspm_model {
     int nmx_K = 0, nmx_raw = 0;
     double *d_Xk = nullptr, *d_Mk = nullptr;
     int* d_rowid = nullptr;
-    hipStream_t side = nullptr;   // second stream: the solver of the full rounds runs under the Gram's last, partial round
-    hipEvent_t ev_a = nullptr, ev_s = nullptr;
-    int resident_slots = 0;       // Gram workgroups resident at once (2 per CU)
     int* h_flag = nullptr;        // pinned: active-problem counter of the non-metric iteration
     hipEvent_t ev_flag = nullptr;
     void* h_stage = nullptr;      // pinned host staging for plspm_fit results
@@ -263,9 +260,6 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->h_flag) hipHostFree(m->h_flag);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
-    if (m->ev_a) hipEventDestroy(m->ev_a);
-    if (m->ev_s) hipEventDestroy(m->ev_s);
-    if (m->side) hipStreamDestroy(m->side);
     if (m->stream && m->owns_stream) hipStreamDestroy(m->stream);
     delete m;
 }
@@ -396,13 +390,6 @@ static int run_impute(plspm_model* m, long nproblems, const double* Min, const d
                        packed_size(m->T), (double*)m->gram2.p, out_stride);
     *Mp = (const double*)m->gram2.p; *mp_stride = out_stride;
     return 0;
-}
-
-// true when a batched solver launch keeps S and its small workspace in LDS (no per-problem global scratch: two launches may overlap)
-static bool solver_all_in_lds(const plspm_model* m) {
-    const size_t need = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double) +
-                        (size_t)cov_doubles(m->P) * sizeof(double);
-    return need <= 64 * 1024;
 }
 
 static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, int threads) {
@@ -849,36 +836,9 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
             hipLaunchKernelGGL(resample_global_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (int)N, d_idx ? d_idx + b0 * N : nullptr, seed,
                                rep_offset + b0, (unsigned*)m->ghist.p, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
         }
-        // Tail overlap (metric models): nb workgroups fill the GPU in rounds of `slots`; the last round is partial (5,000 replicates on
-        // 512 slots: 9.77 rounds).  The Gram is launched as [full rounds | remainder]; the solver of the full rounds runs on a second
-        // stream under the remainder's Gram, on the CUs that round leaves idle.
-        long nA = 0;
-        {
-            const char* tail_env = getenv("PLSPM_TAIL_OVERLAP");
-            const bool plain_metric = !m->nonmetric && !m->n_ind && !getenv("PLSPM_DEBUG_MARKS") && !(tail_env && tail_env[0] == '0') && solver_all_in_lds(m);
-            if (plain_metric) {
-                if (!m->resident_slots) {
-                    int cus = 0;
-                    HIPCHK(m, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-                    m->resident_slots = 2 * std::max(cus, 1);
-                }
-                nA = (nb / m->resident_slots) * m->resident_slots;
-                if (nA == nb || nA == 0) nA = 0;
-                if (nA && !m->side) {
-                    HIPCHK(m, hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-                    HIPCHK(m, hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming));
-                    HIPCHK(m, hipEventCreateWithFlags(&m->ev_s, hipEventDisableTiming));
-                }
-            }
-        }
         {
             ProfScope ps(m, PLSPM_K_GRAM);
-            if (nA) {
-                if ((rc = launch_gram<false>(m, nA, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
-                HIPCHK(m, hipEventRecord(m->ev_a, m->stream));
-                if ((rc = launch_gram<false>(m, nb - nA, 1, (const int2*)m->ent.p + nA * ent_stride, (const int*)m->nent.p + nA, ent_stride, (double*)m->gram.p + nA * psize)))
-                    return rc;
-            } else if ((rc = launch_gram<false>(m, nb, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
+            if ((rc = launch_gram<false>(m, nb, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
         }
         SolverOut so{};
         so.row = (double*)m->rows.p + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
@@ -915,20 +875,7 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
         {
             ProfScope ps(m, PLSPM_K_SOLVER);
-            const int st = getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 128;
-            if (nA) {
-                hipStream_t main_stream = m->stream;
-                HIPCHK(m, hipStreamWaitEvent(m->side, m->ev_a, 0));
-                m->stream = m->side;                                  // launch_solver issues on m->stream
-                rc = launch_solver(m, nA, Mp, mp_stride, so, st);
-                m->stream = main_stream;
-                if (rc) return rc;
-                HIPCHK(m, hipEventRecord(m->ev_s, m->side));
-                SolverOut so_b = so;
-                so_b.row = so.row + nA * R; so_b.status = so.status + nA; so_b.iters = so.iters + nA;
-                if ((rc = launch_solver(m, nb - nA, Mp + nA * mp_stride, mp_stride, so_b, st))) return rc;
-                HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_s, 0));
-            } else if ((rc = launch_solver(m, nb, Mp, mp_stride, so, st))) return rc;
+            if ((rc = launch_solver(m, nb, Mp, mp_stride, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 128))) return rc;
         }
         if (d_marks) {
             long long h[16];
