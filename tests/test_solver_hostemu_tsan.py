@@ -42,3 +42,14 @@ def test_thread_sanitizer_clean(which):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert "tsan-run-done" in r.stdout, r.stderr[-3000:]
     assert "data race" not in r.stderr, r.stderr[-6000:]
+
+
+def test_address_sanitizer_clean():
+    """The same solver sources under AddressSanitizer (GPU ASan is not available on the pool: the CPU build is where out-of-bounds
+    accesses of the workspace / state carving would show)."""
+    subprocess.check_call(["make", "-s", "-C", EMU, "libplspm_hostemu_asan.so"])
+    asan = subprocess.run(["bash", "-c", "ls /usr/lib/gcc/x86_64-linux-gnu/*/libasan.so | head -1"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, os.path.join(EMU, "asan_run.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert "asan-run-done" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
