@@ -288,3 +288,23 @@ def test_bench_guard_fixture_is_current():
     row, its = orc.bootstrap_replicate(X, orc.Model(blocks, synthetic.satisfaction_C(), "AAAAAA", "path", True), idx0, orc.correction(10000))
     assert its == int(g["iterations"])
     np.testing.assert_allclose(row, g["row"], rtol=1e-12)
+
+
+def test_committed_bench_line_follows_the_driver_contract():
+    """profiles/r01_bench_n1.json is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions
+    (dtype = arithmetic type, vs_baseline null without a published number, config names the workload, roofline + cpu_baseline)."""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
+    for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], kind), key
+    assert line["vs_baseline"] is None and line["dtype"] == "f64" and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert line["metric"].split(" at ")[0] in baseline["metric"]
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and (roof["traffic"] is None or roof["traffic"] > 0)
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
+    assert abs(line["value"] - line["config"]["replicates_per_step"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
