@@ -6,12 +6,16 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch: every rank resamples + solves its shard of the replicate
-range on its own GPU (inputs already resident in HBM), then ONE all_gather (RCCL over xGMI) merges the
-B x 156 result rows -- the whole job, gather included, is inside the timed region.  Rank 0 prints one JSON line.
+range on its own GPU (inputs already resident in HBM), then ONE ncclAllGather (RCCL over xGMI, issued by
+libplspm_hip.so itself: plspm_group_bootstrap) merges the B x 156 result rows -- the whole job, gather included, is
+inside the timed region.  Rank 0 prints one JSON line.  No torch: under `python -m torch.distributed.run` the launcher
+only spawns the ranks (RANK / LOCAL_RANK / WORLD_SIZE); without a launcher `--gpus N` drives N GPUs from this process.
 
 Extra objects on the line:
   roofline      dominant kernel (fp64-MFMA weighted Gram), duration measured with HIP events on the library's own
                 stream during the timed steps; algorithmic work per replicate per SURVEY.md 8(d)
+  api_inclusive replicates/s a user of the drop-in API sees: wall of Plspm(data, config, Scheme.PATH, bootstrap=True,
+                bootstrap_iterations=5000) minus the wall of the same call without the bootstrap (N = 1 only)
   cpu_baseline  the NumPy oracle (oracle/plspm_oracle.py, a port of the reference arithmetic) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -79,6 +83,44 @@ def cpu_baseline(budget_s=20.0):
                       % (count, cores, 1.0 / per_rep, wall)}
 
 
+def api_inclusive(X, reps, pairs=7):
+    """Replicates/s through the drop-in API: Plspm(..., bootstrap=True) minus the same call with bootstrap=False (median of paired
+    runs).  The summaries are computed (on the device) inside the call; the reference-shaped frames are built on access."""
+    import pandas as pd
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    import synthetic
+    lvs = synthetic.SAT_LVS
+    cols = ["%s%d" % (lv.lower(), k) for lv in lvs for k in range(MVS_PER_LV)]
+    frame = pd.DataFrame(X, columns=cols)
+    structure = c.Structure()
+    for frm, to in synthetic.SAT_EDGES:
+        structure.add_path([frm], [to])
+
+    def config():
+        cfg = c.Config(structure.path(), scaled=True)
+        for lv in lvs:
+            cfg.add_lv_with_columns_named(lv, Mode.A, frame, lv.lower())
+        return cfg
+    diffs, fits, boots = [], [], []
+    for k in range(pairs + 1):
+        t0 = time.perf_counter()
+        Plspm(frame, config(), Scheme.PATH)
+        t1 = time.perf_counter()
+        m = Plspm(frame, config(), Scheme.PATH, bootstrap=True, bootstrap_iterations=reps, processes=1, seed=1)
+        t2 = time.perf_counter()
+        if k:                                        # the first pair warms the code objects
+            fits.append(t1 - t0); boots.append(t2 - t1); diffs.append((t2 - t1) - (t1 - t0))
+        used = m.bootstrap().used()
+    d = float(np.median(diffs))
+    return {"value": round(reps / d, 1), "unit": "replicates/s", "bootstrap_ms": round(d * 1e3, 3),
+            "plspm_fit_wall_ms": round(float(np.median(fits)) * 1e3, 3), "plspm_fit_plus_bootstrap_wall_ms": round(float(np.median(boots)) * 1e3, 3),
+            "replicates_used": int(used),
+            "note": "median over %d pairs of [Plspm(bootstrap=True, bootstrap_iterations=%d) wall] - [Plspm() wall], frames built lazily, rows left in HBM" % (pairs, reps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,110 +128,86 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reps-per-gpu", type=int, default=REPS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
-        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
-
     from plspm import _native, parallel
-    dist = None
-    use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also exercises RCCL at N = 1)
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    device_id = local_rank if use_dist else 0
+    launched = "RANK" in os.environ            # one process per GPU (a launcher set RANK / LOCAL_RANK / WORLD_SIZE)
+    if launched:
+        ctx = parallel.init_process_group()    # file rendezvous of the ncclUniqueId + ncclCommInitRank, inside libplspm_hip.so
+        rank, world, devices = ctx.rank, ctx.world, [ctx.local_rank]
+        if world != args.gpus:
+            raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+        comm = ctx.comm
+    else:
+        rank, world, devices = 0, args.gpus, list(range(args.gpus))
+        if args.gpus > _native.device_count():
+            raise SystemExit("--gpus %d but %d HIP devices are visible" % (args.gpus, _native.device_count()))
+        comm = parallel.local_comm(devices) if (world > 1 or args.group) else None
 
     synthetic, X, blocks = synth_inputs()
     C = synthetic.satisfaction_C()
     boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 
-    def make_model():
-        mdl = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, device_id)
+    def make_model(device):
+        mdl = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, device)
         mdl.upload(X)                                          # X resident in HBM before the timed region
         return mdl
 
-    model = make_model()
+    models = [make_model(d) for d in devices]
+    model = models[0]
+    group = _native.NativeGroup(comm, models) if comm is not None else None
     B_total = args.reps_per_gpu * world
     width = model.row_width
-    # N > 1: two handles (each with its own result buffer) alternate, so the all_gather of step k runs on RCCL's stream
-    # under the kernels of step k+1; every step still does all of its work (shard compute + one collective) and the
-    # closing fence waits for the last collective.
-    models = [model, make_model()] if use_dist else [model]
-    pending = [None, None]
-    state = {"k": 0, "last": None}
-
-    ext_streams = [torch.cuda.ExternalStream(mdl.stream_ptr()) for mdl in models] if use_dist else []
+    state = {"k": 0}
 
     def step():
-        if not use_dist:
-            model.bootstrap_device(B_total, seed=1, rep_offset=0)          # enqueue only: the closing fence synchronises
-            return None
-        k = state["k"] % 2
+        """One batch: a fresh replicate-id range every step (ids k*B .. (k+1)*B of the seeded stream).  Enqueue only -- with a
+        group the all-gather of step k runs on its own stream beside the kernels of step k+1 (double-buffered records)."""
+        offset = state["k"] * B_total
         state["k"] += 1
-        if pending[k] is not None:
-            with torch.cuda.stream(ext_streams[k]):
-                pending[k][1].wait()                           # stream-side wait: this handle's buffer is free again before its next kernels
-        mdl = models[k]
-        start, stop = parallel.shard_range(B_total, rank, world)
-        d_rows, _, _ = mdl.bootstrap_device(stop - start, seed=1, rep_offset=start)
-        send = parallel.device_rows(d_rows, stop - start, width + 2)
-        with torch.cuda.stream(ext_streams[k]):                # RCCL orders itself behind the handle's stream: no host sync
-            pending[k] = parallel.gather_records(send, B_total, async_op=True, slot=k)
-        state["last"] = pending[k]
-        return pending[k]
-
-    def drain():
-        for pk in pending:
-            if pk is not None:
-                pk[1].wait()
+        if group is None:
+            model.bootstrap_device(B_total, seed=1, rep_offset=offset)
+        else:
+            group.bootstrap(B_total, seed=1, rep_offset=offset)
 
     def fence():
-        for mdl in models:
-            mdl.sync()
-        if use_dist:
-            drain()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if group is None:
+            model.sync()
+        else:
+            group.sync()                                       # this process's kernel and gather streams
+            group.barrier()                                    # every rank of the job (all-reduce of one word over RCCL)
 
     for _ in range(args.warmup):
         step()
-    for mdl in models:
-        mdl.profile(True)
-        mdl.profile_reset()
     fence()
+    profiled = group is None                                   # single stream: the HIP events of the timed region see each kernel alone
+    if profiled:
+        model.profile(True)
+        model.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    for mdl in models:
-        mdl.profile(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if profiled:
+        model.profile(False)
+    if group is not None:
+        elapsed = group.max(elapsed)                           # max over ranks
 
-    if use_dist:
-        # the gathered records of the last timed step: complete, in replicate-id order, identical on every rank
-        rec, work = step()
-        work.wait()
-        torch.cuda.synchronize()
-        rec = rec.cpu().numpy()
-        assert rec.shape == (B_total, width + 2) and np.all(rec[:, width] == 0), "gather lost replicates"
-        probe = min(B_total - 1, (B_total // world) * (world - 1) + 3)          # a row owned by the last rank
-        one, _, _ = model.bootstrap(1, seed=1, rep_offset=probe)
-        assert np.array_equal(rec[probe, :width], one[0]), "sharded stream differs from the single-GPU stream"
-
-    # correctness guard on what was timed: every replicate converged, and replicate 0 of the seeded stream equals the committed
-    # reference-arithmetic row (tests/golden/bench_guard.npz, made by tests/golden/make_bench_guard.py with the oracle)
+    # what was timed is correct: every replicate of the last step converged, the gathered records are complete and in order
+    last_offset = (state["k"] - 1) * B_total
+    if group is not None:
+        rows_l, status_l, iters_l = group.rows()
+    else:
+        rows_l, status_l, iters_l = model.fetch(0, B_total)
+    assert rows_l.shape == (B_total, width) and np.all(status_l == 0), "a replicate of the timed batch failed"
+    probe = B_total - 3                                        # a row owned by the last rank
+    one, _, _ = model.bootstrap(1, seed=1, rep_offset=last_offset + probe)
+    assert np.array_equal(rows_l[probe], one[0]), "sharded stream differs from the single-GPU stream"
+    # ... and equals the reference arithmetic: replicate 0 of the seeded stream against the committed oracle row
+    # (tests/golden/bench_guard.npz, made by tests/golden/make_bench_guard.py with the oracle)
     rows, status, iters = model.bootstrap(8, seed=1, rep_offset=0)
     assert np.all(status == 0), status
     guard = np.load(os.path.join(ROOT, "tests", "golden", "bench_guard.npz"))
@@ -197,9 +215,20 @@ def main():
     assert int(idx0.astype(np.int64).sum()) == int(guard["idx_sum"]) and np.array_equal(idx0[:16], guard["idx_head"]), "resampling stream changed"
     assert int(guard["iterations"]) == iters[0] and np.allclose(rows[0], guard["row"], rtol=1e-8, atol=1e-11), "timed path disagrees with the oracle"
 
+    if not profiled:
+        # N > 1: the kernels of the timed region overlap the previous step's collective, so the dominant kernel is timed on a
+        # calibration pass of the same launches on the handle's stream alone (same B per GPU, same data)
+        model.sync()
+        model.profile(True)
+        model.profile_reset()
+        for k in range(min(args.steps, 10)):
+            model.bootstrap_device(args.reps_per_gpu, seed=1, rep_offset=k * args.reps_per_gpu)
+        model.sync()
+        model.profile(False)
+
     pcie = None
-    if world == 1 and not use_dist:
-        # the same batch through the host-buffer entry point (results copied back over PCIe every step); never `value`
+    if world == 1 and group is None:
+        # the same batch through the host-buffer entry point (records copied back over PCIe every step); never `value`
         model.bootstrap(B_total, seed=1)
         t1 = time.perf_counter()
         for _ in range(5):
@@ -207,25 +236,28 @@ def main():
         pcie = B_total * 5 / (time.perf_counter() - t1)
 
     if rank == 0:
-        def prof(name):
-            parts = [mdl.profile_read(name) for mdl in models]
-            return sum(p[0] for p in parts), sum(p[1] for p in parts)
-        gram_ms, gram_n = prof("gram")
-        res_ms, res_n = prof("resample")
-        sol_ms, sol_n = prof("solver")
+        gram_ms, gram_n = model.profile_read("gram")
+        res_ms, res_n = model.profile_read("resample")
+        sol_ms, sol_n = model.profile_read("solver")
         reps_per_launch = args.reps_per_gpu
         a_rep = 8.0 * N_OBS * 60 + 4.0 * N_OBS                 # one gathered read of X + the index vector
         f_rep = float(N_OBS) * 60 * 61                         # symmetric Gram flops
         gram_avg_ms = gram_ms / max(gram_n, 1)
         hbm_achieved = a_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e9
         mfma_achieved = f_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
-        traffic = None
-        prof_json = os.path.join(ROOT, "profiles", "r01_gram_traffic.json")
-        if os.path.exists(prof_json):
-            try:
-                traffic = json.load(open(prof_json)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = None, None
+        for name in ("r02_gram_traffic.json", "r01_gram_traffic.json"):
+            prof_json = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(prof_json):
+                try:
+                    traffic = json.load(open(prof_json)).get("hbm_bytes_per_launch")
+                    traffic_src = "static: profiles/%s (rocprofv3 --pmc passes of this command; PMC counters cannot be read from inside the bench)" % name
+                    break
+                except Exception:
+                    traffic = None
+        parallelism = ("one process, one GPU, no collective" if group is None else
+                       "replicate-sharded x%d (%s), ONE ncclAllGather per step issued by libplspm_hip.so on a gather stream "
+                       "(overlaps the next step's kernels; records double-buffered)" % (world, "one process per GPU" if launched else "one process, %d GPUs" % world))
         line = {
             "metric": "bootstrap replicates/sec (6-LV satisfaction model, N=10k)",
             "value": round(B_total * args.steps / elapsed, 1),
@@ -235,14 +267,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic 10,000 obs x 60 MVs x 6 LVs, Mode A, Scheme.PATH, scaled, %d bootstrap replicates per GPU "
-                                   "(BASELINE.json configs[2]); on-device Philox resampling; X resident in HBM" % args.reps_per_gpu,
-                       "replicates_per_step": B_total, "iterations_per_replicate": [int(iters.min()), int(iters.max())],
-                       "parallelism": "replicate-sharded x%d, one all_gather per step%s" % (world, " (overlapped with the next step's kernels)" if use_dist else "")},
+                                   "(BASELINE.json configs[2]; %d GPUs x %d = configs[3] at 8); on-device Philox resampling, a fresh replicate-id "
+                                   "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
+                       "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
+                       "parallelism": parallelism, "transport": ("rccl" if (comm is not None and comm.uses_rccl) else "none")},
             "roofline": {"bound": "mfma", "achieved": round(mfma_achieved, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(mfma_achieved / FP64_MFMA_PEAK_TF, 4), "traffic": traffic,
+                         "frac": round(mfma_achieved / FP64_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n,
-                         "note": ("two alternating handles: HIP-event durations include kernels co-scheduled from the other stream"
-                                  if use_dist else "single stream: HIP-event duration of the kernel alone"),
+                         "note": ("HIP events on the handle's stream over the timed region (single stream: the kernel alone)" if profiled else
+                                  "HIP events on the handle's stream over a calibration pass of the same launches without the overlapping collective"),
                          "algorithmic_flops_per_replicate": f_rep, "algorithmic_bytes_per_replicate": a_rep,
                          "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}},
@@ -251,13 +284,17 @@ def main():
         }
         if pcie is not None:
             line["pcie_inclusive"] = {"value": round(pcie, 1), "unit": "replicates/s",
-                                      "note": "plspm_bootstrap(): device -> pageable host copy of the B x 156 rows every step"}
+                                      "note": "plspm_bootstrap(): the B x 158 records copied to a pageable host buffer through pinned staging every step"}
+        if world == 1 and group is None and not args.no_api:
+            line["api_inclusive"] = api_inclusive(X, args.reps_per_gpu)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+        group.close()
+    if launched:
+        parallel.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -12,6 +12,8 @@
  *        called from Plspm.__init__                          plspm/plspm.py:78-82
  *        -> plspm_bootstrap (replicates in [rep_offset, rep_offset + B) of one logical stream, so the
  *           result does not depend on how replicates are sharded over GPUs / processes)
+ *        -> plspm_group_* : the fan-out over `processes` workers and the Queue merge (bootstrap.py:89-111)
+ *           as replicate shards on several MI355X with ONE RCCL all-gather over xGMI at the end
  *
  * Conventions
  *   - plain C types only; all host buffers caller-allocated, row-major, IEEE fp64 unless noted.
@@ -41,14 +43,14 @@ enum { PLSPM_MODE_A = 0, PLSPM_MODE_B = 1 };
 enum {
     PLSPM_OK = 0,
     PLSPM_NOT_CONVERGED = 1, /* reference raises Exception("Could not converge ...") weights.py:185-186 */
-    PLSPM_SINGULAR = 2,      /* a Mode-B block / inner regression is rank deficient                        */
+    PLSPM_SINGULAR = 2,      /* a regression the reference cannot solve either (e.g. Mode B on a block with missing cells, mode.py:55-56) */
     PLSPM_NONFINITE = 3      /* zero-variance MV or NaN input                                            */
 };
 /* Argument errors returned by the API functions themselves. */
 enum { PLSPM_E_ARG = 100, PLSPM_E_STATE = 101, PLSPM_E_LIMIT = 102 };
 
 /* ABI version of this header; plspm_abi_version() of the loaded library must match. */
-#define PLSPM_ABI_VERSION 1
+#define PLSPM_ABI_VERSION 2
 int plspm_abi_version(void);
 
 /* Number of HIP devices visible to the process (0 when there is none; never negative). */
@@ -56,6 +58,18 @@ int plspm_device_count(void);
 
 /* Text of the last error on this handle (or of the last failed plspm_model_create when NULL). */
 const char* plspm_last_error(const plspm_model_t* m);
+
+/*
+ * Launch-geometry options of a handle (defaults are the measured optima; tests use them to force a kernel variant).  The library
+ * reads NO environment variables.  Unknown keys / out-of-range values return PLSPM_E_ARG.
+ *   "solver_threads"  64 | 128 | 256      threads per problem of the batched metric solver (default 128)
+ *   "nm_threads"      0 (by model width) | 64 | 128 | 256   threads per problem of the non-metric solvers
+ *   "fit_chunks"      0 (auto) .. 65535   row chunks (workgroups) of the single-fit Gram
+ *   "wide_nw"         4 | 8 | 16          waves sharing one row walk in gram_wide_kernel<14>
+ *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
+ *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
+ */
+int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 
 /*
  * Compile a model specification (reference Config + path matrix + Plspm kwargs, plspm/config.py:89-160,
@@ -204,20 +218,94 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
 int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out,
                            void** d_status, void** d_iters);
 int plspm_sync(plspm_model_t* m);
+/* Host copy of replicates [first, first + count) of the LAST plspm_bootstrap(_device) call on this handle, whose records are still
+ * in HBM: out [count*R], status / iters [count] (each may be NULL).  Lets a caller keep the rows on the device (summaries:
+ * plspm_bootstrap_summary) and pay for the PCIe transfer only when individual replicates are asked for.  PLSPM_E_STATE when the
+ * handle holds no records (no bootstrap yet, or a later upload replaced the data). */
+int plspm_bootstrap_fetch(plspm_model_t* m, int64_t first, int64_t count, double* out, int32_t* status, int32_t* iters);
 /* The handle's HIP stream (a hipStream_t), so that a caller can order its own work -- e.g. an RCCL collective -- behind the
  * enqueued kernels with stream/event semantics instead of a host synchronisation. */
 void* plspm_stream(plspm_model_t* m);
+
+/* Replace the handle's records by B host records [B * plspm_row_stride()] in the device layout [row | status | iterations] -- for a
+ * caller that merged the shards of several processes with a transport of its own (MPI, gloo, files) and wants the device summary
+ * (plspm_bootstrap_summary with d_rows = NULL) of the merged set. */
+int plspm_bootstrap_store(plspm_model_t* m, const double* records, int64_t B);
 
 /*
  * Summary statistics of a bootstrap on the device (reference _create_summary, plspm/bootstrap.py:24-32): for every result
  * column c: summary[c*6 + 0..5] = original, mean, std.error (ddof 1), perc.025, perc.975 (linear interpolation), t stat. --
  * over the replicates whose status is PLSPM_OK.
- *   d_rows   NULL: the rows of the last plspm_bootstrap(_device) call on this handle (stride = plspm_row_stride());
- *            else a device buffer [B * stride] in the same record layout (e.g. the all-gathered records of all GPUs)
+ *   d_rows   NULL: the rows of the last plspm_bootstrap(_device) call on this handle (stride = plspm_row_stride(); B must be
+ *            that call's B, else PLSPM_E_ARG; PLSPM_E_STATE when the handle holds no records);
+ *            else a device buffer [B * stride] in the same record layout (e.g. the all-gathered records of all GPUs);
+ *            records whose status column is not exactly 0 (failed replicates, NaN-marked padding of ragged shards) are skipped
+ *   B        1 <= B <= 2^30
  *   original [R] host: the full-sample estimates;  summary [R*6] host;  n_used: number of OK replicates (may be NULL)
  */
 int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int32_t stride, const double* original, double* summary,
                             int64_t* n_used);
+
+/*
+ * ---- Multi-GPU: replicate shards + ONE RCCL all-gather --------------------------------------------------------------------------
+ * Reference: Bootstrap.__init__ forks `processes` workers, each running iterations / processes replicates, and merges their
+ * frames through a Queue (plspm/bootstrap.py:89-111; `processes` kwarg plspm/plspm.py:35-37,60-61).  Here a GROUP of handles --
+ * the same compiled model with the same data uploaded, one handle per MI355X -- runs the replicate ids
+ * [rep_offset, rep_offset + B) of one logical stream: rank r of nranks takes the contiguous shard plspm_group_shard(B, r), every
+ * rank's [row | status | iterations] records are written into its send buffer by the solver kernel, and ONE ncclAllGather over
+ * xGMI (librccl.so.1, loaded on first use) leaves all records on every rank.  Results are bit-identical for every nranks
+ * (Philox stream keyed by (seed, replicate id)).  Nothing here needs PyTorch.
+ *
+ * Two objects: a COMMUNICATOR (plspm_comm_t: the RCCL communicators of this process's ranks -- expensive, of the order of a
+ * second, create once per process) and a GROUP (plspm_group_t: binds one uploaded handle per local rank to the communicator --
+ * cheap: a gather stream, four events and the record buffers per handle).  Two ways to form a communicator:
+ *   single process   n_local == nranks ranks on DISTINCT devices (ncclCommInitAll); unique_id = NULL, first_rank = 0.
+ *                    Ranks that share a device (testing on a 1-GPU box; RCCL refuses duplicate devices) exchange their records
+ *                    with device-to-device copies instead of RCCL -- same buffers, same ordering, same results.
+ *   one process per GPU (torchrun / mpirun)   n_local == 1, first_rank = this process's rank, unique_id = the 128 bytes that
+ *                    rank 0 obtained from plspm_rccl_unique_id() and handed to every rank (ncclCommInitRank: collective call).
+ * A communicator serves one group at a time; a handle belongs to at most one group at a time and must outlive it.  Group calls
+ * are not re-entrant.
+ *
+ * Stream semantics: plspm_group_bootstrap only ENQUEUES (shard kernels on each handle's stream, the all-gather on a second
+ * stream per handle behind an event); records are double-buffered so that the collective of call k overlaps the kernels of call
+ * k+1.  plspm_group_summary / _rows / _sync wait for the last call's collective.
+ */
+typedef struct plspm_comm plspm_comm_t;
+typedef struct plspm_group plspm_group_t;
+#define PLSPM_UNIQUE_ID_BYTES 128
+int plspm_rccl_unique_id(uint8_t* id /* [PLSPM_UNIQUE_ID_BYTES] */);
+/* device_ids [n_local]: HIP device of every local rank; local rank i is global rank first_rank + i.  NULL on failure. */
+plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id);
+void plspm_comm_destroy(plspm_comm_t* c);                  /* also destroys the group still bound to it */
+int32_t plspm_comm_size(const plspm_comm_t* c);            /* nranks */
+int32_t plspm_comm_uses_rccl(const plspm_comm_t* c);       /* 1: records travel through RCCL; 0: the same-device copy route */
+/* models [n_local of the communicator]: handle i lives on the communicator's device i, data uploaded.  NULL on failure. */
+plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models);
+void plspm_group_destroy(plspm_group_t* g);
+/* Text of the last error on this group (or of the last failed plspm_comm_create / plspm_group_create / plspm_rccl_unique_id
+ * when NULL). */
+const char* plspm_group_last_error(const plspm_group_t* g);
+int32_t plspm_group_size(const plspm_group_t* g);          /* nranks */
+/* Shard of rank `rank`: balanced contiguous ranges, the first B % nranks ranks hold one replicate more. */
+int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* first, int64_t* count);
+/* Enqueue B replicates split over the group + the all-gather.  Returns without host synchronisation for metric models. */
+int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset);
+/* Wait for everything enqueued on the group's streams (every local handle). */
+int plspm_group_sync(plspm_group_t* g);
+/* Gathered records of the last plspm_group_bootstrap on local handle `local`: *d_records -> [*n_records * *stride] fp64 in HBM,
+ * n_records = nranks * ceil(B / nranks); rank r's shard starts at record r * ceil(B / nranks); the unused tail records of a ragged
+ * split carry NaN in the status column.  Valid until the next-but-one plspm_group_bootstrap. */
+int plspm_group_records(plspm_group_t* g, int32_t local, void** d_records, int64_t* n_records, int32_t* stride);
+/* _create_summary (bootstrap.py:24-32) of the last plspm_group_bootstrap, on local handle 0's copy of the gathered records:
+ * same outputs as plspm_bootstrap_summary. */
+int plspm_group_summary(plspm_group_t* g, const double* original, double* summary, int64_t* n_used);
+/* Host copy of the last plspm_group_bootstrap's replicates in replicate-id order: out [B*R], status / iters [B] (may be NULL). */
+int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* iters);
+/* Collective helpers for a caller's timing protocol (bench.py): barrier = all-reduce of one word on the gather stream + host
+ * wait; max = all-reduce(max) of one double over the ranks. */
+int plspm_group_barrier(plspm_group_t* g);
+int plspm_group_max(plspm_group_t* g, double* value);
 
 /* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);

@@ -7,7 +7,11 @@ struct DevExec {
     int tid, nt;
     double* red;           // LDS scratch, one slot per wave
     long long* marks;      // debug: phase timestamps of problem 0 (PLSPM_DEBUG_MARKS)
+#ifdef PLSPM_DEBUG_MARKS
     __device__ __forceinline__ void mark(int id) { if (marks && tid == 0) marks[id] = clock64(); }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
     template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
     template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
     // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)

@@ -1,0 +1,144 @@
+// Host-side state of one libplspm_hip handle (include/plspm_hip.h), shared by the translation units of the library:
+// plspm_hip.hip (kernels + single-device entry points) and plspm_group.cpp (multi-GPU groups over RCCL).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/plspm_hip.h"
+
+inline thread_local std::string g_create_error;
+
+// Kernel timing (plspm_profile_*): event pairs are recycled through `pool`, so a profiled launch costs two hipEventRecord only.
+struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev, pool; double total_ms = 0.0; int64_t launches = 0; };
+
+struct plspm_model {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = true;      // an attached second stage runs on its first stage's stream
+    int P = 0, L = 0, PA = 0, T = 0, scheme = 0, scaled = 1, max_iter = 100, kmax = 0, n_eff = 0, n_chol = 0;
+    double tol = 1e-6;
+    std::vector<int> boff, lvof, mode, chol_off, eff_from, eff_to, pred_off, pred_idx, succ_off, succ_idx;
+    std::vector<uint8_t> C;
+    int *d_boff = nullptr, *d_lvof = nullptr, *d_mode = nullptr, *d_chol_off = nullptr, *d_eff_from = nullptr, *d_eff_to = nullptr;
+    int *d_pred_off = nullptr, *d_pred_idx = nullptr, *d_succ_off = nullptr, *d_succ_idx = nullptr;
+    uint8_t* d_C = nullptr;
+    double* d_shift = nullptr;
+    int64_t N = 0;
+    double* d_Xa = nullptr;
+    // grow-only device scratch
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_io, sum_buf;
+    int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
+    int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
+    int Pm = 0, cmax = 1, kmv = 1;
+    std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol;
+    int *d_mv_off = nullptr, *d_mv_kind = nullptr, *d_lmv_off = nullptr, *d_mv_lv = nullptr, *d_no_chol = nullptr;
+    Buf gSm;
+    // metric data with missing values: Pg = P + n_ind device columns (data | missing indicators); PA / T describe the Gram of
+    // those, PAs / Ts the P-column moment matrix the solver reads (impute_collapse maps one to the other).  Pg == P otherwise.
+    int Pg = 0, PAs = 0, Ts = 0, n_ind = 0;
+    std::vector<int> ind_of;
+    int* d_ind_of = nullptr;
+    Buf gram2;
+    // two-stage higher order constructs (solver_hoc.h): `stage2` of a data-holding handle / `stage1` of its attached second stage
+    plspm_model* stage2 = nullptr;
+    plspm_model* stage1 = nullptr;
+    std::vector<int> lv_first, col2_lv1, col2_p1, hcol, hidx;
+    std::vector<int> lv_cols;
+    int* d_lv_cols = nullptr;
+    int *d_lv_first = nullptr, *d_col2_lv1 = nullptr, *d_col2_p1 = nullptr, *d_hcol = nullptr, *d_hidx = nullptr;
+    Buf pseudo;
+    // non-metric data with missing values (solver_nmx.h): K incomplete rows live in side tables, their rows of Xa are zero
+    Buf dcnt, ctable, Xt;        // dense stop-rule pass of the non-metric bootstrap: uint16 histograms, coefficient table, tiled copy of Xa
+    long dcnt_stride = 0;
+    bool Xt_valid = false, dcnt_ready = false;
+    int nmx_K = 0, nmx_raw = 0;
+    double *d_Xk = nullptr, *d_Mk = nullptr;
+    int* d_rowid = nullptr;
+    int* h_flag = nullptr;        // pinned: active-problem counter of the non-metric iteration
+    hipEvent_t ev_flag = nullptr;
+    void* h_stage = nullptr;      // pinned host staging for plspm_fit results
+    size_t h_stage_cap = 0;
+    // result bookkeeping: `rows` holds the records of the last plspm_bootstrap(_device) only (the fit's scores have their own buffer)
+    Buf scores;
+    Buf xa, up_raw, up_ci, up_partial;   // resident matrix (d_Xa points into `xa` while data are uploaded) and the upload staging
+    int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
+    // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
+    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128; } tune;
+    // grow-only pinned host staging for uploads / row downloads (two halves: copy-in of chunk k+1 overlaps the DMA of chunk k)
+    void* h_pin = nullptr;
+    size_t h_pin_cap = 0;
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    void* group = nullptr;        // the plspm_group this handle currently belongs to (plspm_group.cpp)
+    bool profiling = false;
+    ProfSlot prof[PLSPM_K_COUNT];
+    std::string error;
+};
+
+// Core of plspm_bootstrap_device (plspm_hip.hip): enqueue B replicates on the handle's stream, records written at `rows_out`
+// (pitch plspm_row_stride) or into the handle's own `rows` buffer when rows_out is NULL.  No host synchronisation for metric models.
+int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, double* rows_out);
+// Host -> device copy through the handle's pinned staging halves (chunked; returns when the source may be re-used).
+int plspm_detail_h2d(plspm_model* m, void* dst, const void* src, size_t bytes);
+// Summary statistics of device records (plspm_bootstrap_summary without the argument checks on `rows`).
+int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t stride, const double* original, double* summary, int64_t* n_used);
+// Host copy of device records [B x stride] -> rows [B x R], status, iters (any may be NULL), through the pinned staging buffer.
+int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t B, int32_t stride, double* out, int32_t* status, int32_t* iters);
+
+inline int fail(plspm_model* m, int code, const std::string& msg) {
+    if (m) m->error = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(m, call)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e__ = (call);                                                                                \
+        if (e__ != hipSuccess) return fail((m), -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+inline int ensure(plspm_model* m, plspm_model::Buf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIPCHK(m, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    HIPCHK(m, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+static constexpr size_t kMaxLds = 160 * 1024;
+// Dynamic LDS beyond the 64 KiB default needs an explicit opt-in per kernel.
+inline int allow_lds(plspm_model* m, const void* fn, size_t bytes) {
+    if (bytes > kMaxLds) return fail(m, PLSPM_E_LIMIT, "kernel needs more than 160 KiB of LDS");
+    if (bytes > 48 * 1024) HIPCHK(m, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+struct ProfScope {
+    plspm_model* m; int id; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(plspm_model* m_, int id_) : m(m_), id(id_) {
+        if (m->profiling) {
+            auto& pool = m->prof[id].pool;
+            if (pool.empty()) { hipEventCreate(&a); hipEventCreate(&b); }
+            else { a = pool.back().first; b = pool.back().second; pool.pop_back(); }
+            hipEventRecord(a, m->stream);
+        }
+    }
+    ~ProfScope() {
+        if (m->profiling) { hipEventRecord(b, m->stream); m->prof[id].ev.emplace_back(a, b); }
+    }
+};
+inline void prof_collect(plspm_model* m) {
+    for (int k = 0; k < PLSPM_K_COUNT; ++k) {
+        for (auto& pr : m->prof[k].ev) {
+            float ms = 0.f;
+            hipEventSynchronize(pr.second);
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            m->prof[k].total_ms += ms; m->prof[k].launches += 1;
+            m->prof[k].pool.push_back(pr);
+        }
+        m->prof[k].ev.clear();
+    }
+}

@@ -1,0 +1,429 @@
+// plspm_group.cpp -- multi-GPU bootstrap groups of libplspm_hip.so: replicate shards on several MI355X + ONE RCCL all-gather
+// over xGMI (include/plspm_hip.h, "Multi-GPU").  Host code only; the kernels live in plspm_hip.hip.
+//
+// Reference: Bootstrap.__init__ (plspm/bootstrap.py:89-111) forks `processes` workers that each run iterations / processes
+// replicates and merges their five DataFrames through a multiprocessing.Queue, polling once a second.  Replicates are
+// independent (bootstrap.py:54-66), so here rank r runs the contiguous replicate-id shard r of one logical Philox stream on its
+// own GPU (X is resident on every GPU), the solver kernel writes the [row | status | iterations] records straight into the
+// rank's send buffer, and a single ncclAllGather replaces the Queue.  There is no other data-path collective.
+//
+// RCCL is loaded with dlopen on the first group / unique-id call: a process that uses one GPU never maps the 570 MB library.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include "model.h"
+
+namespace {
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+thread_local std::string g_group_create_error;
+
+// Resolve librccl once per process.  Returns nullptr (and the reason) when the library or a symbol is missing: the caller fails
+// loudly -- there is no substitute transport for distinct devices.
+const Rccl* rccl(std::string& why) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.so) return &g_rccl;
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* so = nullptr;
+    for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+    if (!so) { why = std::string("librccl.so.1 not loadable: ") + dlerror(); return nullptr; }
+    Rccl r;
+    r.so = so;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(so, name); if (!p) { ok = false; why = std::string("librccl lacks ") + name; } return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(so); return nullptr; }
+    g_rccl = r;
+    return &g_rccl;
+}
+
+struct Local {
+    plspm_model* m = nullptr;
+    ncclComm_t comm = nullptr;                     // borrowed from the group's plspm_comm
+    hipStream_t cstream = nullptr;                 // the collective's stream: it runs beside the next call's kernels
+    plspm_model::Buf send[2], recv[2];
+    hipEvent_t computed[2] = {nullptr, nullptr};   // shard kernels of slot s done (recorded on the handle's stream)
+    hipEvent_t gathered[2] = {nullptr, nullptr};   // records of slot s complete in recv[s] (recorded on cstream)
+    double* d_word = nullptr;                      // barrier / max scratch
+    double* h_word = nullptr;                      // pinned mirror
+};
+
+}  // namespace
+
+// The communicator set of this process: every rank of a single-process job, or one rank of a one-process-per-GPU job.  Creating
+// it is the expensive part (librccl load + ncclCommInit*: of the order of a second), so it is an object of its own that a host
+// program creates once and binds to any number of groups, one after the other.
+struct plspm_comm {
+    int nranks = 1, first_rank = 0;
+    bool use_rccl = false;
+    std::vector<int> devices;                      // one per local rank
+    std::vector<ncclComm_t> comms;                 // empty when use_rccl is false
+    plspm_group* bound = nullptr;                  // the live group using it, if any
+};
+
+struct plspm_group {
+    plspm_comm* comm = nullptr;
+    int nranks = 1, first_rank = 0;
+    bool use_rccl = false;
+    std::vector<Local> loc;
+    int next_slot = 0, last_slot = -1;
+    bool pending[2] = {false, false};
+    int64_t last_B = 0, last_cap = 0;
+    std::string error;
+};
+
+namespace {
+
+int gfail(plspm_group* g, int code, const std::string& msg) {
+    if (g) g->error = msg; else g_group_create_error = msg;
+    return code;
+}
+#define GHIP(g, call)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess) return gfail((g), -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+#define GNCCL(g, r, call)                                                                                                  \
+    do {                                                                                                                   \
+        ncclResult_t n__ = (call);                                                                                         \
+        if (n__ != ncclSuccess) return gfail((g), -(1000 + (int)n__), std::string(#call) + ": " + (r)->GetErrorString(n__)); \
+    } while (0)
+
+void shard_of(int64_t B, int nranks, int rank, int64_t* first, int64_t* count) {
+    const int64_t base = B / nranks, extra = B % nranks;
+    *first = rank * base + std::min<int64_t>(rank, extra);
+    *count = base + (rank < extra ? 1 : 0);
+}
+
+int grow(plspm_group* g, Local& l, plspm_model::Buf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) GHIP(g, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    GHIP(g, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+int sync_all(plspm_group* g) {
+    for (auto& l : g->loc) {
+        GHIP(g, hipSetDevice(l.m->device));
+        GHIP(g, hipStreamSynchronize(l.m->stream));
+        GHIP(g, hipStreamSynchronize(l.cstream));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* plspm_group_last_error(const plspm_group_t* g) { return g ? g->error.c_str() : g_group_create_error.c_str(); }
+
+int plspm_rccl_unique_id(uint8_t* id) {
+    g_group_create_error.clear();
+    if (!id) return gfail(nullptr, PLSPM_E_ARG, "plspm_rccl_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == PLSPM_UNIQUE_ID_BYTES, "unique id size");
+    std::string why;
+    const Rccl* r = rccl(why);
+    if (!r) return gfail(nullptr, PLSPM_E_STATE, why);
+    ncclUniqueId uid;
+    GNCCL(nullptr, r, r->GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof(uid));
+    return 0;
+}
+
+void plspm_group_destroy(plspm_group_t* g) {
+    if (!g) return;
+    for (auto& l : g->loc) {
+        hipSetDevice(l.m->device);
+        if (l.m->stream) hipStreamSynchronize(l.m->stream);
+        if (l.cstream) hipStreamSynchronize(l.cstream);
+    }
+    for (auto& l : g->loc) {
+        hipSetDevice(l.m->device);
+        for (int s = 0; s < 2; ++s) {
+            if (l.send[s].p) hipFree(l.send[s].p);
+            if (l.recv[s].p) hipFree(l.recv[s].p);
+            if (l.computed[s]) hipEventDestroy(l.computed[s]);
+            if (l.gathered[s]) hipEventDestroy(l.gathered[s]);
+        }
+        if (l.d_word) hipFree(l.d_word);
+        if (l.h_word) hipHostFree(l.h_word);
+        if (l.cstream) hipStreamDestroy(l.cstream);
+        l.m->group = nullptr;
+    }
+    if (g->comm && g->comm->bound == g) g->comm->bound = nullptr;
+    delete g;
+}
+
+void plspm_comm_destroy(plspm_comm_t* c) {
+    if (!c) return;
+    if (c->bound) plspm_group_destroy(c->bound);
+    for (size_t i = 0; i < c->comms.size(); ++i)
+        if (c->comms[i] && g_rccl.so) { hipSetDevice(c->devices[i]); g_rccl.CommDestroy(c->comms[i]); }
+    delete c;
+}
+
+plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id) {
+    g_group_create_error.clear();
+    auto bad = [&](int code, const std::string& why) { gfail(nullptr, code, why); return (plspm_comm_t*)nullptr; };
+    if (!device_ids || n_local < 1 || nranks < n_local || first_rank < 0 || first_rank + n_local > nranks) return bad(PLSPM_E_ARG, "plspm_comm_create: bad arguments");
+    if (n_local != nranks && (n_local != 1 || !unique_id))
+        return bad(PLSPM_E_ARG, "plspm_comm_create: either all ranks in one process (unique_id NULL) or one rank per process with rank 0's unique id");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(PLSPM_E_STATE, "no HIP device visible");
+    bool distinct = true;
+    for (int i = 0; i < n_local; ++i) {
+        if (device_ids[i] < 0 || device_ids[i] >= ndev) return bad(PLSPM_E_ARG, "plspm_comm_create: device id out of range");
+        for (int j = 0; j < i; ++j) if (device_ids[i] == device_ids[j]) distinct = false;
+    }
+    plspm_comm* c = new (std::nothrow) plspm_comm();
+    if (!c) return bad(PLSPM_E_STATE, "out of host memory");
+    c->nranks = nranks; c->first_rank = first_rank;
+    c->devices.assign(device_ids, device_ids + n_local);
+    // ranks that share a device (a 1-GPU test box; RCCL refuses duplicate devices) exchange records with device-to-device copies
+    c->use_rccl = distinct;
+    if (!c->use_rccl) return c;
+    std::string why;
+    const Rccl* r = rccl(why);
+    if (!r) { delete c; return bad(PLSPM_E_STATE, why); }
+    c->comms.assign(n_local, nullptr);
+    ncclResult_t rc;
+    if (n_local == nranks) {
+        rc = r->CommInitAll(c->comms.data(), n_local, c->devices.data());
+        if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclCommInitAll: ") + r->GetErrorString(rc)); }
+    } else {
+        ncclUniqueId uid;
+        memcpy(&uid, unique_id, sizeof(uid));
+        if (hipSetDevice(c->devices[0]) != hipSuccess) { delete c; return bad(PLSPM_E_STATE, "hipSetDevice failed"); }
+        rc = r->CommInitRank(&c->comms[0], nranks, uid, first_rank);
+        if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclCommInitRank: ") + r->GetErrorString(rc)); }
+    }
+    return c;
+}
+
+int32_t plspm_comm_size(const plspm_comm_t* c) { return c ? c->nranks : 0; }
+int32_t plspm_comm_uses_rccl(const plspm_comm_t* c) { return (c && c->use_rccl) ? 1 : 0; }
+
+plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models) {
+    g_group_create_error.clear();
+    auto bad = [&](int code, const std::string& why) { gfail(nullptr, code, why); return (plspm_group_t*)nullptr; };
+    if (!c || !models) return bad(PLSPM_E_ARG, "plspm_group_create: bad arguments");
+    if (c->bound) return bad(PLSPM_E_STATE, "plspm_group_create: the communicator serves one group at a time");
+    const int n_local = (int)c->devices.size();
+    for (int i = 0; i < n_local; ++i) {
+        const plspm_model* m = models[i];
+        if (!m) return bad(PLSPM_E_ARG, "plspm_group_create: null handle");
+        if (m->group) return bad(PLSPM_E_STATE, "plspm_group_create: a handle belongs to one group at a time");
+        if (m->device != c->devices[i]) return bad(PLSPM_E_ARG, "plspm_group_create: handle i must live on the communicator's device i");
+        if (!m->d_Xa || m->N < 2) return bad(PLSPM_E_STATE, "plspm_group_create: every handle needs its data uploaded first");
+        if (m->stage1) return bad(PLSPM_E_ARG, "plspm_group_create: pass the data-holding first stage of a two-stage pair");
+        for (int j = 0; j < i; ++j) if (models[j] == m) return bad(PLSPM_E_ARG, "plspm_group_create: the same handle twice");
+        if (plspm_row_stride(m) != plspm_row_stride(models[0]) || m->N != models[0]->N || m->P != models[0]->P || m->L != models[0]->L)
+            return bad(PLSPM_E_ARG, "plspm_group_create: the handles must hold the same model and data");
+    }
+    plspm_group* g = new (std::nothrow) plspm_group();
+    if (!g) return bad(PLSPM_E_STATE, "out of host memory");
+    g->comm = c; g->nranks = c->nranks; g->first_rank = c->first_rank; g->use_rccl = c->use_rccl;
+    g->loc.resize(n_local);
+    for (int i = 0; i < n_local; ++i) { g->loc[i].m = models[i]; if (c->use_rccl) g->loc[i].comm = c->comms[i]; }
+    auto bail = [&](const std::string& why) { plspm_group_destroy(g); g_group_create_error = why; return (plspm_group_t*)nullptr; };
+    for (auto& l : g->loc) {
+        l.m->group = g;
+        if (hipSetDevice(l.m->device) != hipSuccess || hipStreamCreateWithFlags(&l.cstream, hipStreamNonBlocking) != hipSuccess) return bail("gather stream creation failed");
+        for (int s = 0; s < 2; ++s)
+            if (hipEventCreateWithFlags(&l.computed[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.gathered[s], hipEventDisableTiming) != hipSuccess)
+                return bail("event creation failed");
+        if (hipMalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || hipHostMalloc((void**)&l.h_word, 64, hipHostMallocDefault) != hipSuccess)
+            return bail("scratch allocation failed");
+    }
+    c->bound = g;
+    return g;
+}
+
+int32_t plspm_group_size(const plspm_group_t* g) { return g ? g->nranks : 0; }
+
+int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* first, int64_t* count) {
+    if (!g || B < 0 || rank < 0 || rank >= g->nranks || !first || !count) return PLSPM_E_ARG;
+    shard_of(B, g->nranks, rank, first, count);
+    return 0;
+}
+
+int plspm_group_sync(plspm_group_t* g) {
+    if (!g) return PLSPM_E_ARG;
+    return sync_all(g);
+}
+
+int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset) {
+    if (!g || B < 1 || rep_offset < 0 || B > ((int64_t)1 << 30)) return gfail(g, PLSPM_E_ARG, "plspm_group_bootstrap: bad arguments (1 <= B <= 2^30, rep_offset >= 0)");
+    const int nl = (int)g->loc.size();
+    const int RS = plspm_row_stride(g->loc[0].m);
+    const int64_t cap = (B + g->nranks - 1) / g->nranks;
+    const size_t send_bytes = (size_t)cap * RS * sizeof(double), recv_bytes = send_bytes * g->nranks;
+    const int s = g->next_slot;
+    int rc;
+    bool must_grow = false;
+    for (auto& l : g->loc) if (l.send[s].cap < send_bytes || l.recv[s].cap < recv_bytes) must_grow = true;
+    if (must_grow) {                                   // nothing may be in flight on a buffer that is about to be replaced
+        if ((rc = sync_all(g))) return rc;
+        g->pending[0] = g->pending[1] = false; g->last_slot = -1;
+        for (auto& l : g->loc) {
+            GHIP(g, hipSetDevice(l.m->device));
+            for (int k = 0; k < 2; ++k) if ((rc = grow(g, l, l.send[k], send_bytes)) || (rc = grow(g, l, l.recv[k], recv_bytes))) return rc;
+        }
+    }
+    // 1. shard kernels, one handle after the other (enqueue only); non-metric models iterate with host read-backs, so their
+    //    handles are driven by one host thread each
+    std::vector<int> shard_rc(nl, 0);
+    auto run_shard = [&](int i) {
+        Local& l = g->loc[i];
+        plspm_model* m = l.m;
+        if (hipSetDevice(m->device) != hipSuccess) { shard_rc[i] = fail(m, PLSPM_E_STATE, "hipSetDevice failed"); return; }
+        if (g->pending[s]) {
+            // slot s was last read / written by the collective of two calls ago
+            if (g->use_rccl) hipStreamWaitEvent(m->stream, l.gathered[s], 0);
+            else for (auto& peer : g->loc) hipStreamWaitEvent(m->stream, peer.gathered[s], 0);          // peers pull from this send buffer
+        }
+        int64_t first = 0, count = 0;
+        shard_of(B, g->nranks, g->first_rank + i, &first, &count);
+        double* send = (double*)l.send[s].p;
+        if (count > 0 && (shard_rc[i] = plspm_detail_bootstrap(m, count, seed, rep_offset + first, nullptr, send))) return;
+        if (count < cap && hipMemsetAsync(send + count * RS, 0xFF, (size_t)(cap - count) * RS * sizeof(double), m->stream) != hipSuccess) {   // NaN status: not a replicate
+            shard_rc[i] = fail(m, PLSPM_E_STATE, "hipMemsetAsync failed"); return;
+        }
+        if (hipEventRecord(l.computed[s], m->stream) != hipSuccess) shard_rc[i] = fail(m, PLSPM_E_STATE, "hipEventRecord failed");
+    };
+    if (nl > 1 && g->loc[0].m->nonmetric) {
+        std::vector<std::thread> workers;
+        for (int i = 0; i < nl; ++i) workers.emplace_back(run_shard, i);
+        for (auto& w : workers) w.join();
+    } else {
+        for (int i = 0; i < nl; ++i) run_shard(i);
+    }
+    for (int i = 0; i < nl; ++i) if (shard_rc[i]) return gfail(g, shard_rc[i], "shard of rank " + std::to_string(g->first_rank + i) + ": " + g->loc[i].m->error);
+    // 2. the ONE collective, on the gather streams behind the shard kernels
+    if (g->use_rccl) {
+        const Rccl* r = &g_rccl;
+        for (auto& l : g->loc) { GHIP(g, hipSetDevice(l.m->device)); GHIP(g, hipStreamWaitEvent(l.cstream, l.computed[s], 0)); }
+        GNCCL(g, r, r->GroupStart());
+        for (auto& l : g->loc) {
+            GHIP(g, hipSetDevice(l.m->device));
+            GNCCL(g, r, r->AllGather(l.send[s].p, l.recv[s].p, (size_t)cap * RS, ncclDouble, l.comm, l.cstream));
+        }
+        GNCCL(g, r, r->GroupEnd());
+        for (auto& l : g->loc) { GHIP(g, hipSetDevice(l.m->device)); GHIP(g, hipEventRecord(l.gathered[s], l.cstream)); }
+    } else {
+        for (auto& dst : g->loc) {
+            GHIP(g, hipSetDevice(dst.m->device));
+            for (int i = 0; i < nl; ++i) {
+                GHIP(g, hipStreamWaitEvent(dst.cstream, g->loc[i].computed[s], 0));
+                GHIP(g, hipMemcpyAsync((char*)dst.recv[s].p + (size_t)i * send_bytes, g->loc[i].send[s].p, send_bytes, hipMemcpyDeviceToDevice, dst.cstream));
+            }
+            GHIP(g, hipEventRecord(dst.gathered[s], dst.cstream));
+        }
+    }
+    g->pending[s] = true; g->last_slot = s; g->next_slot = s ^ 1; g->last_B = B; g->last_cap = cap;
+    return 0;
+}
+
+int plspm_group_records(plspm_group_t* g, int32_t local, void** d_records, int64_t* n_records, int32_t* stride) {
+    if (!g || local < 0 || local >= (int)g->loc.size()) return gfail(g, PLSPM_E_ARG, "plspm_group_records: bad arguments");
+    if (g->last_slot < 0) return gfail(g, PLSPM_E_STATE, "plspm_group_records: no bootstrap on this group yet");
+    Local& l = g->loc[local];
+    GHIP(g, hipSetDevice(l.m->device));
+    GHIP(g, hipEventSynchronize(l.gathered[g->last_slot]));
+    if (d_records) *d_records = l.recv[g->last_slot].p;
+    if (n_records) *n_records = g->last_cap * g->nranks;
+    if (stride) *stride = plspm_row_stride(l.m);
+    return 0;
+}
+
+int plspm_group_summary(plspm_group_t* g, const double* original, double* summary, int64_t* n_used) {
+    if (!g || !original || !summary) return gfail(g, PLSPM_E_ARG, "plspm_group_summary: bad arguments");
+    if (g->last_slot < 0) return gfail(g, PLSPM_E_STATE, "plspm_group_summary: no bootstrap on this group yet");
+    Local& l = g->loc[0];
+    GHIP(g, hipSetDevice(l.m->device));
+    GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
+    int rc = plspm_detail_summary(l.m, (const double*)l.recv[g->last_slot].p, g->last_cap * g->nranks, plspm_row_stride(l.m), original, summary, n_used);
+    if (rc) return gfail(g, rc, l.m->error);
+    return 0;
+}
+
+int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* iters) {
+    if (!g) return PLSPM_E_ARG;
+    if (g->last_slot < 0) return gfail(g, PLSPM_E_STATE, "plspm_group_rows: no bootstrap on this group yet");
+    Local& l = g->loc[0];
+    const int RS = plspm_row_stride(l.m), R = RS - 2;
+    GHIP(g, hipSetDevice(l.m->device));
+    GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
+    const double* rec = (const double*)l.recv[g->last_slot].p;
+    for (int r = 0; r < g->nranks; ++r) {
+        int64_t first = 0, count = 0;
+        shard_of(g->last_B, g->nranks, r, &first, &count);
+        if (!count) continue;
+        int rc = plspm_detail_fetch_records(l.m, rec + (size_t)r * g->last_cap * RS, count, RS, out ? out + first * R : nullptr, status ? status + first : nullptr,
+                                            iters ? iters + first : nullptr);
+        if (rc) return gfail(g, rc, l.m->error);
+    }
+    return 0;
+}
+
+int plspm_group_barrier(plspm_group_t* g) {
+    if (!g) return PLSPM_E_ARG;
+    int rc = sync_all(g);
+    if (rc || !g->use_rccl) return rc;
+    const Rccl* r = &g_rccl;
+    GNCCL(g, r, r->GroupStart());
+    for (auto& l : g->loc) {
+        GHIP(g, hipSetDevice(l.m->device));
+        GNCCL(g, r, r->AllReduce(l.d_word, l.d_word + 1, 1, ncclDouble, ncclMax, l.comm, l.cstream));
+    }
+    GNCCL(g, r, r->GroupEnd());
+    for (auto& l : g->loc) { GHIP(g, hipSetDevice(l.m->device)); GHIP(g, hipStreamSynchronize(l.cstream)); }
+    return 0;
+}
+
+int plspm_group_max(plspm_group_t* g, double* value) {
+    if (!g || !value) return PLSPM_E_ARG;
+    if (!g->use_rccl || (int)g->loc.size() == g->nranks) return 0;         // every rank lives in this process: the caller's value is the job's
+    const Rccl* r = &g_rccl;
+    Local& l = g->loc[0];
+    GHIP(g, hipSetDevice(l.m->device));
+    l.h_word[0] = *value;
+    GHIP(g, hipMemcpyAsync(l.d_word + 2, l.h_word, sizeof(double), hipMemcpyHostToDevice, l.cstream));
+    GNCCL(g, r, r->AllReduce(l.d_word + 2, l.d_word + 3, 1, ncclDouble, ncclMax, l.comm, l.cstream));
+    GHIP(g, hipMemcpyAsync(l.h_word + 1, l.d_word + 3, sizeof(double), hipMemcpyDeviceToHost, l.cstream));
+    GHIP(g, hipStreamSynchronize(l.cstream));
+    *value = l.h_word[1];
+    return 0;
+}
+
+}  // extern "C"

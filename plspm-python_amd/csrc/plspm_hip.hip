@@ -35,111 +35,7 @@ __host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a
 #include "kernels_post.h"
 
 // ================================================================================================ host side
-static thread_local std::string g_create_error;
-
-struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double total_ms = 0.0; int64_t launches = 0; };
-
-struct plspm_model {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = true;      // an attached second stage runs on its first stage's stream
-    int P = 0, L = 0, PA = 0, T = 0, scheme = 0, scaled = 1, max_iter = 100, kmax = 0, n_eff = 0, n_chol = 0;
-    double tol = 1e-6;
-    std::vector<int> boff, lvof, mode, chol_off, eff_from, eff_to, pred_off, pred_idx, succ_off, succ_idx;
-    std::vector<uint8_t> C;
-    int *d_boff = nullptr, *d_lvof = nullptr, *d_mode = nullptr, *d_chol_off = nullptr, *d_eff_from = nullptr, *d_eff_to = nullptr;
-    int *d_pred_off = nullptr, *d_pred_idx = nullptr, *d_succ_off = nullptr, *d_succ_idx = nullptr;
-    uint8_t* d_C = nullptr;
-    double* d_shift = nullptr;
-    int64_t N = 0;
-    double* d_Xa = nullptr;
-    // grow-only device scratch
-    struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_io, sum_buf;
-    int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
-    int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
-    int Pm = 0, cmax = 1, kmv = 1;
-    std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol;
-    int *d_mv_off = nullptr, *d_mv_kind = nullptr, *d_lmv_off = nullptr, *d_mv_lv = nullptr, *d_no_chol = nullptr;
-    Buf gSm;
-    // metric data with missing values: Pg = P + n_ind device columns (data | missing indicators); PA / T describe the Gram of
-    // those, PAs / Ts the P-column moment matrix the solver reads (impute_collapse maps one to the other).  Pg == P otherwise.
-    int Pg = 0, PAs = 0, Ts = 0, n_ind = 0;
-    std::vector<int> ind_of;
-    int* d_ind_of = nullptr;
-    Buf gram2;
-    // two-stage higher order constructs (solver_hoc.h): `stage2` of a data-holding handle / `stage1` of its attached second stage
-    plspm_model* stage2 = nullptr;
-    plspm_model* stage1 = nullptr;
-    std::vector<int> lv_first, col2_lv1, col2_p1, hcol, hidx;
-    std::vector<int> lv_cols;
-    int* d_lv_cols = nullptr;
-    int *d_lv_first = nullptr, *d_col2_lv1 = nullptr, *d_col2_p1 = nullptr, *d_hcol = nullptr, *d_hidx = nullptr;
-    Buf pseudo;
-    // non-metric data with missing values (solver_nmx.h): K incomplete rows live in side tables, their rows of Xa are zero
-    Buf dcnt, ctable, Xt;        // dense stop-rule pass of the non-metric bootstrap: uint16 histograms, coefficient table, tiled copy of Xa
-    long dcnt_stride = 0;
-    bool Xt_valid = false, dcnt_ready = false;
-    int nmx_K = 0, nmx_raw = 0;
-    double *d_Xk = nullptr, *d_Mk = nullptr;
-    int* d_rowid = nullptr;
-    int* h_flag = nullptr;        // pinned: active-problem counter of the non-metric iteration
-    hipEvent_t ev_flag = nullptr;
-    void* h_stage = nullptr;      // pinned host staging for plspm_fit results
-    size_t h_stage_cap = 0;
-    bool profiling = false;
-    ProfSlot prof[PLSPM_K_COUNT];
-    std::string error;
-};
-
-static int fail(plspm_model* m, int code, const std::string& msg) {
-    if (m) m->error = msg; else g_create_error = msg;
-    return code;
-}
-#define HIPCHK(m, call)                                                                                         \
-    do {                                                                                                        \
-        hipError_t e__ = (call);                                                                                \
-        if (e__ != hipSuccess) return fail((m), -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); \
-    } while (0)
-
-static int ensure(plspm_model* m, plspm_model::Buf& b, size_t bytes) {
-    if (bytes <= b.cap) return 0;
-    if (b.p) HIPCHK(m, hipFree(b.p));
-    b.p = nullptr; b.cap = 0;
-    HIPCHK(m, hipMalloc(&b.p, bytes));
-    b.cap = bytes;
-    return 0;
-}
-
-static const size_t kMaxLds = 160 * 1024;
-// Dynamic LDS beyond the 64 KiB default needs an explicit opt-in per kernel.
-static int allow_lds(plspm_model* m, const void* fn, size_t bytes) {
-    if (bytes > kMaxLds) return fail(m, PLSPM_E_LIMIT, "kernel needs more than 160 KiB of LDS");
-    if (bytes > 48 * 1024) HIPCHK(m, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
-}
-
-struct ProfScope {
-    plspm_model* m; int id; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(plspm_model* m_, int id_) : m(m_), id(id_) {
-        if (m->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, m->stream); }
-    }
-    ~ProfScope() {
-        if (m->profiling) { hipEventRecord(b, m->stream); m->prof[id].ev.emplace_back(a, b); }
-    }
-};
-static void prof_collect(plspm_model* m) {
-    for (int k = 0; k < PLSPM_K_COUNT; ++k) {
-        for (auto& pr : m->prof[k].ev) {
-            float ms = 0.f;
-            hipEventSynchronize(pr.second);
-            hipEventElapsedTime(&ms, pr.first, pr.second);
-            m->prof[k].total_ms += ms; m->prof[k].launches += 1;
-            hipEventDestroy(pr.first); hipEventDestroy(pr.second);
-        }
-        m->prof[k].ev.clear();
-    }
-}
+#include "model.h"
 
 static ModelDesc make_desc(const plspm_model* m) {
     ModelDesc md{};
@@ -160,6 +56,14 @@ static HocDesc make_hoc_desc(const plspm_model* m2) {
     hd.boff1 = m1->d_boff; hd.boff2 = m2->d_boff; hd.lv_first = m2->d_lv_first; hd.col2_lv1 = m2->d_col2_lv1; hd.col2_p1 = m2->d_col2_p1;
     hd.nh = (int)m2->hcol.size(); hd.hcol = m2->d_hcol; hd.hidx = m2->d_hidx;
     return hd;
+}
+
+// Side tables of plspm_model_set_incomplete_rows: freed (and nulled) on every re-upload and on a failed set call.
+static void drop_incomplete_rows(plspm_model* m) {
+    if (m->d_Xk) hipFree(m->d_Xk);
+    if (m->d_Mk) hipFree(m->d_Mk);
+    if (m->d_rowid) hipFree(m->d_rowid);
+    m->d_Xk = m->d_Mk = nullptr; m->d_rowid = nullptr; m->nmx_K = 0;
 }
 
 template <class Tv>
@@ -252,12 +156,15 @@ void plspm_model_destroy(plspm_model_t* m) {
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
-    void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->d_Xa,
+    void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
     for (void* p : ptrs) if (p) hipFree(p);
     if (m->h_stage) hipHostFree(m->h_stage);
+    if (m->h_pin) hipHostFree(m->h_pin);
+    for (int k = 0; k < 2; ++k) if (m->ev_pin[k]) hipEventDestroy(m->ev_pin[k]);
+    for (int k = 0; k < PLSPM_K_COUNT; ++k) for (auto& pr : m->prof[k].pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (m->h_flag) hipHostFree(m->h_flag);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
     if (m->stream && m->owns_stream) hipStreamDestroy(m->stream);
@@ -288,23 +195,26 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     }
     HIPCHK(m, hipSetDevice(m->device));
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    if (m->d_Xa) { HIPCHK(m, hipFree(m->d_Xa)); m->d_Xa = nullptr; }
-    if (m->nmx_K) {
-        hipFree(m->d_Xk); hipFree(m->d_Mk); hipFree(m->d_rowid);
-        m->d_Xk = m->d_Mk = nullptr; m->d_rowid = nullptr; m->nmx_K = 0;
-    }
-    m->N = 0; m->Xt_valid = false;
-    double* d_raw = nullptr; int* d_ci = nullptr; double* d_partial = nullptr;
+    // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
+    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->rows_B = 0; m->dcnt_ready = false;
+    drop_incomplete_rows(m);
+    // persistent grow-only buffers: a repeated upload of the same shape allocates nothing
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
-    auto cleanup = [&]() { if (d_raw) hipFree(d_raw); if (d_ci) hipFree(d_ci); if (d_partial) hipFree(d_partial); };
-#define UPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(m, -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
-    UPCHK(hipMalloc((void**)&d_raw, raw_bytes));
-    UPCHK(hipMalloc((void**)&d_ci, sizeof(int) * Pg));
-    UPCHK(hipMalloc((void**)&m->d_Xa, (size_t)N * m->PA * sizeof(double)));
-    UPCHK(hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
-    UPCHK(hipMemcpyAsync(d_ci, ci.data(), sizeof(int) * Pg, hipMemcpyHostToDevice, m->stream));
     const int nblk = (int)std::min<int64_t>(1024, (N + 255) / 256);
-    UPCHK(hipMalloc((void**)&d_partial, sizeof(double) * (size_t)nblk * Pg));
+    int rc;
+    if ((rc = ensure(m, m->up_raw, raw_bytes))) return rc;
+    if ((rc = ensure(m, m->up_ci, sizeof(int) * (size_t)Pg))) return rc;
+    if ((rc = ensure(m, m->up_partial, sizeof(double) * (size_t)nblk * Pg))) return rc;
+    if ((rc = ensure(m, m->xa, (size_t)N * m->PA * sizeof(double)))) return rc;
+    double* d_raw = (double*)m->up_raw.p;
+    int* d_ci = (int*)m->up_ci.p;
+    double* d_partial = (double*)m->up_partial.p;
+    double* d_Xa = (double*)m->xa.p;
+    // host -> device: small matrices go through the handle's pinned staging halves (no page pinning per call); large ones are
+    // handed to the runtime as they are (its pageable path pipelines page-locking and DMA: 52 GB/s measured on 1.6 GB)
+    if (raw_bytes <= ((size_t)64 << 20)) { if ((rc = plspm_detail_h2d(m, d_raw, X, raw_bytes))) return rc; }
+    else HIPCHK(m, hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
+    if ((rc = plspm_detail_h2d(m, d_ci, ci.data(), sizeof(int) * (size_t)Pg))) return rc;
     {
         ProfScope ps(m, PLSPM_K_PACK);
         if (layout == 0) {
@@ -318,16 +228,19 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
         if (layout == 0) {
             const long total = (long)N * m->PA;
             const int grid = (int)std::min<long>(4096, (total + 255) / 256);
-            hipLaunchKernelGGL(pack_rowmajor_kernel, dim3(grid), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, Pg, m->PA, m->d_shift, m->d_Xa);
+            hipLaunchKernelGGL(pack_rowmajor_kernel, dim3(grid), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, Pg, m->PA, m->d_shift, d_Xa);
         } else {
             hipLaunchKernelGGL(pack_colmajor_kernel, dim3((unsigned)((N + 63) / 64), m->PA / 32), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, Pg, m->PA,
-                               m->d_shift, m->d_Xa);
+                               m->d_shift, d_Xa);
         }
     }
-    UPCHK(hipGetLastError());
-    UPCHK(hipStreamSynchronize(m->stream));
-#undef UPCHK
-    cleanup();
+    HIPCHK(m, hipGetLastError());
+    HIPCHK(m, hipStreamSynchronize(m->stream));          // X may be released by the caller on return
+    if (raw_bytes > ((size_t)1 << 30)) {                 // do not keep a multi-GB staging copy alive next to the resident matrix
+        HIPCHK(m, hipFree(m->up_raw.p));
+        m->up_raw.p = nullptr; m->up_raw.cap = 0;
+    }
+    m->d_Xa = d_Xa;
     m->N = N;
     return 0;
 }
@@ -356,8 +269,7 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
         case 10: WIDE(10, 4, 4) break;
         case 12: WIDE(12, 4, 4) break;
         case 14: {
-            const char* nw = getenv("PLSPM_WIDE_NW");
-            const int sel = nw ? atoi(nw) : 4;      // measured on 1M x 200: NW=4 0.99 ms, 8: 1.12 ms, 16 (two workgroups per walk): 1.37 ms
+            const int sel = m->tune.wide_nw;        // measured on 1M x 200: NW=4 0.99 ms, 8: 1.12 ms, 16 (two workgroups per walk): 1.37 ms
             if (sel == 4) WIDE(14, 4, 4) else if (sel == 16) WIDE(14, 16, 8) else WIDE(14, 8, 8)
         } break;
         case 16: WIDE(16, 16, 8) break;
@@ -436,15 +348,14 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     const long ntiles16 = (N + 15) / 16;
     const int table_rows = 2 * src->P + 2 * L + 1;
     const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
-    const char* dense_env = getenv("PLSPM_CONV_DENSE");
     // coefficient tile of 64 replicates: whole in LDS when it fits, else one LV block at a time (kb = widest block of the map the pass uses)
     const std::vector<int>& conv_blocks = m->stage1 ? m->lv_cols : m->boff;
     int kb = 1;
     for (int l = 0; l < L; ++l) kb = std::max(kb, conv_blocks[l + 1] - conv_blocks[l]);
-    const bool dense_whole = dense_lds <= kMaxLds && !getenv("PLSPM_CONV_BLOCKED");      // (the variable forces the blocked variant: tests)
+    const bool dense_whole = dense_lds <= kMaxLds && m->tune.conv_pass != 2;            // (option conv_pass = 2 forces the blocked variant: tests)
     const size_t dense_blocked_lds = (size_t)(2 * kb + 2) * 64 * sizeof(double);
     const size_t dense_use_lds = dense_whole ? dense_lds : dense_blocked_lds;
-    const bool dense = ent && src->dcnt_ready && dense_use_lds <= kMaxLds && !(dense_env && dense_env[0] == '0');
+    const bool dense = ent && src->dcnt_ready && dense_use_lds <= kMaxLds && m->tune.conv_pass != 1;
     const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     const int ngroups = (int)((nproblems + 63) / 64);
     if (dense) {
@@ -530,8 +441,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 const int rbx = (gx + 7) / 8;                                  // row blocks per XCD
                 // replicate slices: one group of 64 replicates per workgroup measured best (1.06 ms for three passes against 1.17 / 1.21 /
                 // 1.28 with 12 / 6 / 13 slices): many small workgroups let the dispatcher balance the CUs
-                const char* gy_env = getenv("PLSPM_CONV_GY");
-                const int gy = gy_env ? std::max(1, atoi(gy_env)) : ngroups;
+                const int gy = m->tune.conv_gy > 0 ? m->tune.conv_gy : ngroups;
                 auto conv_kernel = dense_whole ? nm_conv_dense_kernel<16, 8, false> : nm_conv_dense_kernel<16, 8, true>;
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts, rbx, gy, kb);
@@ -557,6 +467,20 @@ int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on) {
 }
 
 void* plspm_stream(plspm_model_t* m) { return m ? (void*)m->stream : nullptr; }
+
+int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
+    if (!m || !key) return fail(m, PLSPM_E_ARG, "plspm_model_set_option: bad arguments");
+    const std::string k(key);
+    auto bad = [&]() { return fail(m, PLSPM_E_ARG, "plspm_model_set_option: value out of range for '" + k + "'"); };
+    if (k == "solver_threads") { if (value != 64 && value != 128 && value != 256) return bad(); m->tune.solver_threads = value; }
+    else if (k == "nm_threads") { if (value != 0 && value != 64 && value != 128 && value != 256) return bad(); m->tune.nm_threads = value; }
+    else if (k == "fit_chunks") { if (value < 0 || value > 65535) return bad(); m->tune.fit_chunks = value; }
+    else if (k == "wide_nw") { if (value != 4 && value != 8 && value != 16) return bad(); m->tune.wide_nw = value; }
+    else if (k == "conv_pass") { if (value < 0 || value > 2) return bad(); m->tune.conv_pass = value; }
+    else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
+    else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
+    return 0;
+}
 
 int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_off, const int32_t* mv_kind) {
     if (!m || !mv_off || !mv_kind || Pm < m->L || Pm > m->P) return fail(m, PLSPM_E_ARG, "plspm_model_set_categorical: bad arguments");
@@ -668,17 +592,21 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
     HIPCHK(m, hipSetDevice(m->device));
     unsigned char* d_mask = nullptr;
     const size_t cells = (size_t)K * m->P;
-    HIPCHK(m, hipMalloc((void**)&m->d_Xk, cells * sizeof(double)));
-    HIPCHK(m, hipMalloc((void**)&m->d_Mk, cells * sizeof(double)));
-    HIPCHK(m, hipMalloc((void**)&m->d_rowid, (size_t)K * sizeof(int)));
-    HIPCHK(m, hipMalloc((void**)&d_mask, cells));
-    HIPCHK(m, hipMemcpyAsync(m->d_rowid, row_index, (size_t)K * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    HIPCHK(m, hipMemcpyAsync(d_mask, present, cells, hipMemcpyHostToDevice, m->stream));
+    // any failure below leaves the handle as it was before the call: no side tables, nmx_K == 0
+#define NMXCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { if (d_mask) hipFree(d_mask); drop_incomplete_rows(m); \
+        return fail(m, -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+    NMXCHK(hipMalloc((void**)&m->d_Xk, cells * sizeof(double)));
+    NMXCHK(hipMalloc((void**)&m->d_Mk, cells * sizeof(double)));
+    NMXCHK(hipMalloc((void**)&m->d_rowid, (size_t)K * sizeof(int)));
+    NMXCHK(hipMalloc((void**)&d_mask, cells));
+    NMXCHK(hipMemcpyAsync(m->d_rowid, row_index, (size_t)K * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    NMXCHK(hipMemcpyAsync(d_mask, present, cells, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(extract_rows_kernel, dim3((unsigned)K), dim3(256), 0, m->stream, m->d_Xa, m->PA, m->P, (const int*)m->d_rowid, (const unsigned char*)d_mask, m->d_Xk,
                        m->d_Mk);
-    HIPCHK(m, hipGetLastError());
-    HIPCHK(m, hipStreamSynchronize(m->stream));
-    HIPCHK(m, hipFree(d_mask));
+    NMXCHK(hipGetLastError());
+    NMXCHK(hipStreamSynchronize(m->stream));
+#undef NMXCHK
+    hipFree(d_mask);
     m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false;
     return 0;
 }
@@ -702,8 +630,7 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     // ~2 workgroups per CU so the fixed-order reduce stays small
     const int waves_per_wg = (m->T <= 4) ? 4 : 1;
     const long per_wave = 16;
-    const char* nc_env = getenv("PLSPM_FIT_CHUNKS");
-    const int nchunks = nc_env ? atoi(nc_env) : (int)std::max<long>(1, std::min<long>(512, (ng + waves_per_wg * per_wave - 1) / (waves_per_wg * per_wave)));
+    const int nchunks = m->tune.fit_chunks > 0 ? m->tune.fit_chunks : (int)std::max<long>(1, std::min<long>(512, (ng + waves_per_wg * per_wave - 1) / (waves_per_wg * per_wave)));
     int rc;
     if ((rc = ensure(m, m->gram_partial, (size_t)nchunks * psize * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
@@ -739,15 +666,15 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
         if ((rc = launch_solver(m, 1, Mp, mp_stride, so, 256))) return rc;
     }
     if (out->scores) {
-        if ((rc = ensure(m, m->rows, (size_t)N * L * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->scores, (size_t)N * L * sizeof(double)))) return rc;
         const size_t lds = ((size_t)SCORE_ROWS * (m->PA + 1) + P + SCORE_ROWS * (size_t)L) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
         if ((rc = allow_lds(m, (const void*)scores_kernel, lds))) return rc;
         const int grid = (int)std::min<long>(256 * 8, (N + SCORE_ROWS - 1) / SCORE_ROWS);
         ProfScope ps(m, PLSPM_K_SCORES);
-        hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->rows.p);
+        hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->scores.p);
         if (m->nmx_K) {                                     // the incomplete rows' scores are not affine in the columns: take them from the state
             const double* Yn = (const double*)m->nmstate.p + nm_state_doubles(P, L, m->n_chol) + m->nmx_K + 2L * P + (long)m->nmx_K * P + (long)m->nmx_K * L;
-            hipLaunchKernelGGL(patch_scores_kernel, dim3((unsigned)m->nmx_K), dim3(64), 0, m->stream, (double*)m->rows.p, L, (const int*)m->d_rowid, Yn);
+            hipLaunchKernelGGL(patch_scores_kernel, dim3((unsigned)m->nmx_K), dim3(64), 0, m->stream, (double*)m->scores.p, L, (const int*)m->d_rowid, Yn);
         }
     }
     HIPCHK(m, hipGetLastError());
@@ -767,8 +694,8 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     char* hs = (char*)m->h_stage;
     HIPCHK(m, hipMemcpyAsync(hs, d, block_bytes, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipMemcpyAsync(hs + (size_t)o_end * sizeof(double), d + o_end, tail_bytes, hipMemcpyDeviceToHost, m->stream));
-    if (stage_scores) HIPCHK(m, hipMemcpyAsync(hs + fit_bytes, m->rows.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
-    else if (out->scores) HIPCHK(m, hipMemcpyAsync(out->scores, m->rows.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
+    if (stage_scores) HIPCHK(m, hipMemcpyAsync(hs + fit_bytes, m->scores.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
+    else if (out->scores) HIPCHK(m, hipMemcpyAsync(out->scores, m->scores.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (stage_scores) memcpy(out->scores, hs + fit_bytes, score_bytes);
     const double* h = (const double*)hs;
@@ -793,9 +720,10 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     return 0;
 }
 
-int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out, void** d_status,
-                           void** d_iters) {
-    if (!m || B < 1 || rep_offset < 0) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
+}  // extern "C"
+
+int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, double* rows_out) {
+    if (!m || B < 1 || rep_offset < 0 || B > ((int64_t)1 << 30)) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments (1 <= B <= 2^30, rep_offset >= 0)");
     if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
     const long N = m->N;
     const bool lds_hist = (N <= 65535);        // N * 2 bytes of LDS histogram (16-bit counters, <= 128 KB); beyond that a global scratch slice per replicate
@@ -814,7 +742,11 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
     if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
     if ((rc = ensure(m, m->nent, (size_t)chunk * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->gram, (size_t)chunk * psize * sizeof(double)))) return rc;
-    if ((rc = ensure(m, m->rows, (size_t)B * R * sizeof(double)))) return rc;
+    if (!rows_out) {
+        m->rows_B = 0;
+        if ((rc = ensure(m, m->rows, (size_t)B * R * sizeof(double)))) return rc;
+        rows_out = (double*)m->rows.p;
+    }
     if ((rc = ensure(m, m->status, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->iters, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->err, sizeof(int)))) return rc;
@@ -841,7 +773,7 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
             if ((rc = launch_gram<false>(m, nb, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
         }
         SolverOut so{};
-        so.row = (double*)m->rows.p + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
+        so.row = rows_out + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
         if (m->nonmetric && m->stage2) {
             // two-stage HOC estimation per replicate (solver_hoc.h): stage 1 to convergence (no report), stage-2 moments by congruence,
             // stage 2 on the second handle's descriptors with the convergence pass streaming THIS handle's data
@@ -864,20 +796,22 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
         if (m->nonmetric) {
             // threads per problem by model width (measured: 60 columns 0.60 / 0.64 / 0.81 ms with 64 / 128 / 256 threads; 300 indicator
             // columns 21.0 / 13.5 / 10.0 ms)
-            const char* nt_env = getenv("PLSPM_NM_THREADS");
-            const int nm_threads = nt_env ? atoi(nt_env) : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));
+            const int nm_threads = m->tune.nm_threads > 0 ? m->tune.nm_threads : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));
             if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, nm_threads))) return rc;
             continue;
         }
+#ifdef PLSPM_DEBUG_MARKS      // phase clocks of one solver problem (tools/gpu_marks.sh builds with -DPLSPM_DEBUG_MARKS); never in the release library
         long long* d_marks = nullptr;
-        if (getenv("PLSPM_DEBUG_MARKS")) { HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks; }
+        HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks;
+#endif
         const double* Mp; long mp_stride;
         if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
         {
             ProfScope ps(m, PLSPM_K_SOLVER);
-            if ((rc = launch_solver(m, nb, Mp, mp_stride, so, getenv("PLSPM_SOLVER_THREADS") ? atoi(getenv("PLSPM_SOLVER_THREADS")) : 128))) return rc;
+            if ((rc = launch_solver(m, nb, Mp, mp_stride, so, m->tune.solver_threads))) return rc;
         }
-        if (d_marks) {
+#ifdef PLSPM_DEBUG_MARKS
+        {
             long long h[16];
             HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
@@ -887,8 +821,19 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
                     h[11] - h[10], h[12] - h[11], h[13] - h[12]);
             HIPCHK(m, hipFree(d_marks));
         }
+#endif
     }
     HIPCHK(m, hipGetLastError());
+    if (rows_out == (double*)m->rows.p) m->rows_B = B;
+    return 0;
+}
+
+extern "C" {
+
+int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out, void** d_status,
+                           void** d_iters) {
+    int rc = plspm_detail_bootstrap(m, B, seed, rep_offset, d_idx, nullptr);
+    if (rc) return rc;
     if (d_out) *d_out = m->rows.p;
     if (d_status) *d_status = m->status.p;
     if (d_iters) *d_iters = m->iters.p;
@@ -900,45 +845,133 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
     HIPCHK(m, hipSetDevice(m->device));
     const int32_t* d_idx = nullptr;
+    int rc;
     if (idx) {
-        int rc = ensure(m, m->idx, (size_t)B * m->N * sizeof(int32_t));
-        if (rc) return rc;
-        HIPCHK(m, hipMemcpyAsync(m->idx.p, idx, (size_t)B * m->N * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+        const size_t bytes = (size_t)B * m->N * sizeof(int32_t);
+        if ((rc = ensure(m, m->idx, bytes))) return rc;
+        if ((rc = plspm_detail_h2d(m, m->idx.p, idx, bytes))) return rc;
         d_idx = (const int32_t*)m->idx.p;
     }
-    void *d_out = nullptr, *d_st = nullptr, *d_it = nullptr;
-    int rc = plspm_bootstrap_device(m, B, seed, rep_offset, d_idx, &d_out, &d_st, &d_it);
-    if (rc) return rc;
-    const int R = plspm_row_width(m), RS = plspm_row_stride(m);
-    int h_err = 0;
-    HIPCHK(m, hipMemcpy2DAsync(out, (size_t)R * sizeof(double), d_out, (size_t)RS * sizeof(double), (size_t)R * sizeof(double), (size_t)B,
-                               hipMemcpyDeviceToHost, m->stream));
-    if (status) HIPCHK(m, hipMemcpyAsync(status, d_st, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    if (iters) HIPCHK(m, hipMemcpyAsync(iters, d_it, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipMemcpyAsync(&h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if ((rc = plspm_detail_bootstrap(m, B, seed, rep_offset, d_idx, nullptr))) return rc;
+    if ((rc = plspm_detail_fetch_records(m, (const double*)m->rows.p, B, plspm_row_stride(m), out, status, iters))) return rc;
+    int* h_err = (int*)m->h_flag + 8;
+    HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    if (h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    if (*h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    return 0;
+}
+
+int plspm_bootstrap_fetch(plspm_model_t* m, int64_t first, int64_t count, double* out, int32_t* status, int32_t* iters) {
+    if (!m || first < 0 || count < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_fetch: bad arguments");
+    if (!m->rows_B || !m->rows.p) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_fetch: no bootstrap records on this handle (a later call replaced them)");
+    if (first + count > m->rows_B) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_fetch: range exceeds the last bootstrap's replicates");
+    HIPCHK(m, hipSetDevice(m->device));
+    const int RS = plspm_row_stride(m);
+    return plspm_detail_fetch_records(m, (const double*)m->rows.p + first * RS, count, RS, out, status, iters);
+}
+
+int plspm_bootstrap_store(plspm_model_t* m, const double* records, int64_t B) {
+    if (!m || !records || B < 1 || B > ((int64_t)1 << 30)) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_store: bad arguments");
+    HIPCHK(m, hipSetDevice(m->device));
+    const size_t bytes = (size_t)B * plspm_row_stride(m) * sizeof(double);
+    m->rows_B = 0;
+    int rc;
+    if ((rc = ensure(m, m->rows, bytes))) return rc;
+    if ((rc = plspm_detail_h2d(m, m->rows.p, records, bytes))) return rc;
+    m->rows_B = B;
     return 0;
 }
 
 int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int32_t stride, const double* original, double* summary, int64_t* n_used) {
-    if (!m || !original || !summary || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: bad arguments");
+    if (!m || !original || !summary || B < 1 || B > ((int64_t)1 << 30)) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: bad arguments (1 <= B <= 2^30)");
+    const double* rows = (const double*)d_rows;
+    if (!rows) {
+        // the handle's own records: exactly the replicates of the last plspm_bootstrap(_device) call (the buffer is never shared
+        // with another result, and a different B would read stale or foreign memory as records)
+        if (!m->rows_B || !m->rows.p) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_summary: no bootstrap result on this handle");
+        if (B != m->rows_B) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: B differs from the last bootstrap on this handle");
+        rows = (const double*)m->rows.p;
+        stride = plspm_row_stride(m);
+    }
+    return plspm_detail_summary(m, rows, B, stride, original, summary, n_used);
+}
+
+}  // extern "C"
+
+// ---- pinned staging: pageable host buffers never meet the DMA engines directly --------------------------------------------------
+static constexpr size_t kPinHalf = (size_t)8 << 20;       // two halves: the host copy of chunk k+1 overlaps the DMA of chunk k
+static int pin_ready(plspm_model* m) {
+    if (m->h_pin) return 0;
+    HIPCHK(m, hipHostMalloc(&m->h_pin, 2 * kPinHalf, hipHostMallocDefault));
+    m->h_pin_cap = 2 * kPinHalf;
+    for (int k = 0; k < 2; ++k) HIPCHK(m, hipEventCreateWithFlags(&m->ev_pin[k], hipEventDisableTiming));
+    return 0;
+}
+
+int plspm_detail_h2d(plspm_model* m, void* dst, const void* src, size_t bytes) {
+    int rc = pin_ready(m);
+    if (rc) return rc;
+    size_t done = 0;
+    for (int k = 0; done < bytes; ++k) {
+        const int h = k & 1;
+        const size_t n = std::min(kPinHalf, bytes - done);
+        char* stage = (char*)m->h_pin + h * kPinHalf;
+        if (k >= 2) HIPCHK(m, hipEventSynchronize(m->ev_pin[h]));            // the DMA that last read this half has finished
+        memcpy(stage, (const char*)src + done, n);
+        HIPCHK(m, hipMemcpyAsync((char*)dst + done, stage, n, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(m, hipEventRecord(m->ev_pin[h], m->stream));
+        done += n;
+    }
+    // the staging halves are re-used by the next call: wait for the (at most two) copies still in flight
+    HIPCHK(m, hipEventSynchronize(m->ev_pin[0]));
+    if (bytes > kPinHalf) HIPCHK(m, hipEventSynchronize(m->ev_pin[1]));
+    return 0;
+}
+
+int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t B, int32_t stride, double* out, int32_t* status, int32_t* iters) {
+    const int R = stride - 2;
+    int rc = pin_ready(m);
+    if (rc) return rc;
+    const int64_t per = std::max<int64_t>(1, (int64_t)(kPinHalf / ((size_t)stride * sizeof(double))));
+    auto unpack = [&](int h, int64_t b0, int64_t nb) {
+        const double* rec = (const double*)((const char*)m->h_pin + h * kPinHalf);
+        for (int64_t b = 0; b < nb; ++b, rec += stride) {
+            if (out) memcpy(out + (b0 + b) * R, rec, (size_t)R * sizeof(double));
+            if (status) status[b0 + b] = (rec[R] == rec[R]) ? (int32_t)rec[R] : -1;      // NaN marks the padding records of a ragged shard
+            if (iters) iters[b0 + b] = (rec[R + 1] == rec[R + 1]) ? (int32_t)rec[R + 1] : 0;
+        }
+    };
+    int64_t prev_b0 = 0, prev_nb = 0;
+    int k = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += per, ++k) {
+        const int h = k & 1;
+        const int64_t nb = std::min<int64_t>(per, B - b0);
+        HIPCHK(m, hipMemcpyAsync((char*)m->h_pin + h * kPinHalf, d_records + b0 * stride, (size_t)nb * stride * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipEventRecord(m->ev_pin[h], m->stream));
+        if (prev_nb) { HIPCHK(m, hipEventSynchronize(m->ev_pin[h ^ 1])); unpack(h ^ 1, prev_b0, prev_nb); }
+        prev_b0 = b0; prev_nb = nb;
+    }
+    if (prev_nb) { HIPCHK(m, hipEventSynchronize(m->ev_pin[(k - 1) & 1])); unpack((k - 1) & 1, prev_b0, prev_nb); }
+    return 0;
+}
+
+int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t stride, const double* original, double* summary, int64_t* n_used) {
     HIPCHK(m, hipSetDevice(m->device));
     const int R = plspm_row_width(m);
-    const double* rows = d_rows ? (const double*)d_rows : (const double*)m->rows.p;
-    if (!rows) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_summary: no bootstrap result on this handle");
-    if (!d_rows) stride = plspm_row_stride(m);
     if (stride < R + 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: stride must cover the status column");
     int npad = 1;
     while (npad < B) npad <<= 1;
     const bool in_lds = (size_t)npad * sizeof(double) <= (size_t)128 * 1024;
     int rc;
+    if ((rc = pin_ready(m))) return rc;
     if ((rc = ensure(m, m->sum_io, ((size_t)R * 7 + 2) * sizeof(double)))) return rc;
     if (!in_lds && (rc = ensure(m, m->sum_buf, (size_t)R * npad * sizeof(double)))) return rc;
     double* d_orig = (double*)m->sum_io.p;
     double* d_out = d_orig + R;
     int* d_used = (int*)(d_out + (size_t)R * 6);
-    HIPCHK(m, hipMemcpyAsync(d_orig, original, sizeof(double) * R, hipMemcpyHostToDevice, m->stream));
+    double* h_io = (double*)m->h_pin;                                   // [original R | summary 6R | n_used]: one small copy each way
+    memcpy(h_io, original, sizeof(double) * R);
+    HIPCHK(m, hipMemcpyAsync(d_orig, h_io, sizeof(double) * R, hipMemcpyHostToDevice, m->stream));
     if (in_lds) {
         const size_t lds = (size_t)npad * sizeof(double);
         if ((rc = allow_lds(m, (const void*)summary_kernel<true>, lds))) return rc;
@@ -948,13 +981,14 @@ int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int
                            d_used);
     }
     HIPCHK(m, hipGetLastError());
-    int h_used = 0;
-    HIPCHK(m, hipMemcpyAsync(summary, d_out, sizeof(double) * R * 6, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipMemcpyAsync(&h_used, d_used, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(h_io + R, d_out, sizeof(double) * ((size_t)R * 6 + 1), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    if (n_used) *n_used = h_used;
+    memcpy(summary, h_io + R, sizeof(double) * R * 6);
+    if (n_used) *n_used = *(const int*)(h_io + R + (size_t)R * 6);
     return 0;
 }
+
+extern "C" {
 
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx) {
     if (!idx || N < 1 || N > 0x7fffffffLL || rep < 0) return PLSPM_E_ARG;
@@ -965,7 +999,16 @@ int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx)
     return 0;
 }
 
-int plspm_profile_enable(plspm_model_t* m, int32_t on) { if (!m) return PLSPM_E_ARG; m->profiling = on != 0; return 0; }
+int plspm_profile_enable(plspm_model_t* m, int32_t on) {
+    if (!m) return PLSPM_E_ARG;
+    if (on) {                                              // event pairs are created here, not inside a profiled (timed) region
+        hipSetDevice(m->device);
+        for (int k = 0; k < PLSPM_K_COUNT; ++k)
+            while (m->prof[k].pool.size() < 128) { hipEvent_t a = nullptr, b = nullptr; hipEventCreate(&a); hipEventCreate(&b); m->prof[k].pool.emplace_back(a, b); }
+    }
+    m->profiling = on != 0;
+    return 0;
+}
 int plspm_profile_reset(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
     hipSetDevice(m->device);

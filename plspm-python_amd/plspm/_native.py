@@ -11,13 +11,18 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLSPM_HIP_LIB", os.path.join(_HERE, "_lib", "libplspm_hip.so"))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
 EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing", "plspm_model_attach_second_stage", "plspm_model_set_incomplete_rows",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
-           "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset"]
+           "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset",
+           "plspm_model_set_option", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
+           "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
+           "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows",
+           "plspm_group_barrier", "plspm_group_max"]
+UNIQUE_ID_BYTES = 128
 
 
 class NativeBackendError(RuntimeError):
@@ -73,6 +78,34 @@ def load():
     lib.plspm_profile_enable.argtypes = [vp, i32]
     lib.plspm_profile_read.argtypes = [vp, i32, ctypes.POINTER(dbl), ctypes.POINTER(i64)]
     lib.plspm_profile_reset.argtypes = [vp]
+    lib.plspm_model_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.plspm_bootstrap_fetch.argtypes = [vp, i64, i64, vp, vp, vp]
+    lib.plspm_bootstrap_store.argtypes = [vp, vp, i64]
+    lib.plspm_rccl_unique_id.argtypes = [vp]
+    lib.plspm_comm_create.restype = vp
+    lib.plspm_comm_create.argtypes = [vp, i32, i32, i32, vp]
+    lib.plspm_comm_destroy.restype = None
+    lib.plspm_comm_destroy.argtypes = [vp]
+    lib.plspm_comm_size.restype = i32
+    lib.plspm_comm_size.argtypes = [vp]
+    lib.plspm_comm_uses_rccl.restype = i32
+    lib.plspm_comm_uses_rccl.argtypes = [vp]
+    lib.plspm_group_create.restype = vp
+    lib.plspm_group_create.argtypes = [vp, vp]
+    lib.plspm_group_destroy.restype = None
+    lib.plspm_group_destroy.argtypes = [vp]
+    lib.plspm_group_last_error.restype = ctypes.c_char_p
+    lib.plspm_group_last_error.argtypes = [vp]
+    lib.plspm_group_size.restype = i32
+    lib.plspm_group_size.argtypes = [vp]
+    lib.plspm_group_shard.argtypes = [vp, i64, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.plspm_group_bootstrap.argtypes = [vp, i64, u64, i64]
+    lib.plspm_group_sync.argtypes = [vp]
+    lib.plspm_group_records.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32)]
+    lib.plspm_group_summary.argtypes = [vp, vp, vp, ctypes.POINTER(i64)]
+    lib.plspm_group_rows.argtypes = [vp, vp, vp, vp]
+    lib.plspm_group_barrier.argtypes = [vp]
+    lib.plspm_group_max.argtypes = [vp, ctypes.POINTER(dbl)]
     if lib.plspm_abi_version() != ABI_VERSION:
         raise NativeBackendError("libplspm_hip.so ABI %d != expected %d" % (lib.plspm_abi_version(), ABI_VERSION))
     _lib = lib
@@ -132,6 +165,8 @@ class NativeModel:
         self.row_width = lib.plspm_row_width(self._h)
         self.row_stride = lib.plspm_row_stride(self._h)     # device rows: [row | status | iterations]
         self.N = 0
+        self.last_B = 0
+        self.device_id = int(device_id)
 
     def set_incomplete_rows(self, rows, present, raw_scale=False):
         """Non-metric data with missing values (plspm_model_set_incomplete_rows), after ``upload``: ``rows`` ascending row numbers,
@@ -205,6 +240,7 @@ class NativeModel:
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
         self._check(self._lib.plspm_bootstrap(self._h, B, seed, rep_offset, _ptr(idx), _ptr(rows), _ptr(status), _ptr(iters)), "plspm_bootstrap")
+        self.last_B = B
         return rows, status, iters
 
     def bootstrap_device(self, B, seed=0, rep_offset=0):
@@ -212,6 +248,7 @@ class NativeModel:
         d_out, d_st, d_it = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         self._check(self._lib.plspm_bootstrap_device(self._h, B, seed, rep_offset, None, ctypes.byref(d_out), ctypes.byref(d_st), ctypes.byref(d_it)),
                     "plspm_bootstrap_device")
+        self.last_B = B
         return d_out.value, d_st.value, d_it.value
 
     def summary(self, B, original, d_rows=None, stride=0):
@@ -225,8 +262,32 @@ class NativeModel:
         self._check(self._lib.plspm_bootstrap_summary(self._h, d_rows, B, stride, _ptr(original), _ptr(out), ctypes.byref(used)), "plspm_bootstrap_summary")
         return out, used.value
 
+    def fetch(self, first=0, count=None):
+        """Host copy of replicates [first, first + count) of the LAST bootstrap / bootstrap_device / store on this handle (their
+        records are still in HBM): (rows [count, R], status, iters)."""
+        if count is None:
+            count = self.last_B - first
+        rows = np.empty((count, self.row_width))
+        status = np.empty(count, dtype=np.int32)
+        iters = np.empty(count, dtype=np.int32)
+        self._check(self._lib.plspm_bootstrap_fetch(self._h, first, count, _ptr(rows), _ptr(status), _ptr(iters)), "plspm_bootstrap_fetch")
+        return rows, status, iters
+
+    def store(self, records):
+        """Put merged host records [B, row_stride] (device layout: row | status | iterations) into the handle, e.g. shards that a
+        host-side transport gathered; ``summary`` / ``fetch`` then work on them."""
+        records = np.ascontiguousarray(records, dtype=np.float64)
+        if records.ndim != 2 or records.shape[1] != self.row_stride:
+            raise ValueError("records must have shape (B, row_stride)")
+        self._check(self._lib.plspm_bootstrap_store(self._h, _ptr(records), records.shape[0]), "plspm_bootstrap_store")
+        self.last_B = records.shape[0]
+
+    def set_option(self, key, value):
+        """Launch-geometry option of the handle (include/plspm_hip.h, plspm_model_set_option)."""
+        self._check(self._lib.plspm_model_set_option(self._h, key.encode(), int(value)), "plspm_model_set_option")
+
     def stream_ptr(self):
-        """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        """The handle's hipStream_t as an integer."""
         return int(self._lib.plspm_stream(self._h) or 0)
 
     def sync(self):
@@ -242,3 +303,126 @@ class NativeModel:
         ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
         self._check(self._lib.plspm_profile_read(self._h, KERNELS[kernel], ctypes.byref(ms), ctypes.byref(n)), "plspm_profile_read")
         return ms.value, n.value
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 of a one-process-per-GPU job hands them to every rank)."""
+    lib = load()
+    buf = (ctypes.c_uint8 * UNIQUE_ID_BYTES)()
+    rc = lib.plspm_rccl_unique_id(buf)
+    if rc:
+        raise NativeBackendError("plspm_rccl_unique_id failed (%d): %s" % (rc, lib.plspm_group_last_error(None).decode()))
+    return bytes(buf)
+
+
+class NativeComm:
+    """The RCCL communicators of this process's ranks (an opaque ``plspm_comm_t*``): every rank of a single-process multi-GPU job
+    (``NativeComm(devices)``) or one rank of a one-process-per-GPU job (``NativeComm([device], nranks, rank, unique_id)``).
+    Expensive to create (librccl load + ncclCommInit*); create once, bind to groups one after the other."""
+
+    def __init__(self, devices, nranks=None, first_rank=0, unique_id=None):
+        lib = load()
+        self._lib = lib
+        self.devices = [int(d) for d in devices]
+        self.nranks = len(self.devices) if nranks is None else int(nranks)
+        self.first_rank = int(first_rank)
+        dev = np.ascontiguousarray(self.devices, dtype=np.int32)
+        uid = None
+        if unique_id is not None:
+            if len(unique_id) != UNIQUE_ID_BYTES:
+                raise ValueError("unique_id must have %d bytes" % UNIQUE_ID_BYTES)
+            uid = (ctypes.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._h = lib.plspm_comm_create(_ptr(dev), len(self.devices), self.nranks, self.first_rank, uid)
+        if not self._h:
+            raise NativeBackendError("plspm_comm_create: " + lib.plspm_group_last_error(None).decode())
+        self.uses_rccl = bool(lib.plspm_comm_uses_rccl(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.plspm_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeGroup:
+    """Replicate shards over the handles of a communicator + ONE all-gather (an opaque ``plspm_group_t*``).  ``models[i]`` lives on
+    ``comm.devices[i]`` and holds the same model and data as every other handle of the job."""
+
+    def __init__(self, comm, models):
+        lib = load()
+        self._lib = lib
+        self.comm, self.models = comm, list(models)
+        if len(self.models) != len(comm.devices):
+            raise ValueError("one handle per local rank of the communicator")
+        arr = (ctypes.c_void_p * len(self.models))(*[m._h for m in self.models])
+        self._h = lib.plspm_group_create(comm._h, arr)
+        if not self._h:
+            raise NativeBackendError("plspm_group_create: " + lib.plspm_group_last_error(None).decode())
+        self.nranks = lib.plspm_group_size(self._h)
+        self.row_width, self.row_stride = self.models[0].row_width, self.models[0].row_stride
+        self.last_B = 0
+
+    def _check(self, rc, what):
+        if rc:
+            raise NativeBackendError("%s failed (%d): %s" % (what, rc, self._lib.plspm_group_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.comm, "_h", None):
+            self._lib.plspm_group_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, B, rank):
+        first, count = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.plspm_group_shard(self._h, B, rank, ctypes.byref(first), ctypes.byref(count)), "plspm_group_shard")
+        return first.value, count.value
+
+    def bootstrap(self, B, seed=0, rep_offset=0):
+        """Enqueue B replicates over the group + the all-gather (no host synchronisation for metric models)."""
+        self._check(self._lib.plspm_group_bootstrap(self._h, B, seed, rep_offset), "plspm_group_bootstrap")
+        self.last_B = B
+
+    def sync(self):
+        self._check(self._lib.plspm_group_sync(self._h), "plspm_group_sync")
+
+    def barrier(self):
+        self._check(self._lib.plspm_group_barrier(self._h), "plspm_group_barrier")
+
+    def max(self, value):
+        v = ctypes.c_double(float(value))
+        self._check(self._lib.plspm_group_max(self._h, ctypes.byref(v)), "plspm_group_max")
+        return v.value
+
+    def records(self, local=0):
+        """(device pointer, n_records, stride) of the gathered records of the last bootstrap on local handle ``local``."""
+        ptr, n, stride = ctypes.c_void_p(), ctypes.c_int64(0), ctypes.c_int32(0)
+        self._check(self._lib.plspm_group_records(self._h, local, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(stride)), "plspm_group_records")
+        return ptr.value, n.value, stride.value
+
+    def summary(self, original):
+        original = np.ascontiguousarray(original, dtype=np.float64)
+        if original.shape != (self.row_width,):
+            raise ValueError("original must have row_width entries")
+        out = np.empty((self.row_width, 6))
+        used = ctypes.c_int64(0)
+        self._check(self._lib.plspm_group_summary(self._h, _ptr(original), _ptr(out), ctypes.byref(used)), "plspm_group_summary")
+        return out, used.value
+
+    def rows(self):
+        """(rows [B, R], status, iters) of the last bootstrap in replicate-id order, on the host."""
+        B = self.last_B
+        rows = np.empty((B, self.row_width))
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        self._check(self._lib.plspm_group_rows(self._h, _ptr(rows), _ptr(status), _ptr(iters)), "plspm_group_rows")
+        return rows, status, iters

@@ -3,7 +3,8 @@
 The reference forks ``processes`` workers that each loop over resample -> estimate -> inner model -> loadings
 (bootstrap.py:54-66) and merges five DataFrames through a Queue.  Here all replicates of this process run as
 three batched kernels on the data already resident in HBM (resample/compact, fp64-MFMA Gram, LDS solver);
-with several processes (one per GPU) the replicate range is sharded and merged by ``plspm.parallel``.
+``processes`` maps to GPUs: the replicate range is sharded over them and merged by ONE RCCL all-gather inside
+libplspm_hip.so (``plspm_group_*``), in one process or with one process per GPU (``plspm.parallel``).
 Replicates whose status is not OK are dropped, as the reference's bare ``except`` drops them
 (bootstrap.py:65-66).  The summaries of ``_create_summary`` (bootstrap.py:24-32) are computed on the device as well
 (``plspm_bootstrap_summary``: one workgroup per result column, LDS bitonic sort for the quantiles); the host
@@ -36,10 +37,21 @@ def _create_summary(samples: pd.DataFrame, original) -> pd.DataFrame:
 
 
 class Bootstrap:
-    """Bootstrap results; constructed by :class:`plspm.plspm.Plspm` when ``bootstrap=True``."""
+    """Bootstrap results; constructed by :class:`plspm.plspm.Plspm` when ``bootstrap=True``.
+
+    Everything heavy stays in HBM: the constructor enqueues the replicates, runs the device summary and copies back the
+    ``R x 6`` table; the reference-shaped frames are built on first access and the per-replicate rows cross PCIe only when
+    ``replicates()`` / ``status()`` / ``replicate_iterations()`` are asked for.
+
+    Where the replicates run (results are bit-identical for every choice -- Philox stream keyed by (seed, replicate id)):
+      * ``comm`` given (any object with rank / world / all_gather): the caller's host-side transport (``parallel.sharded_bootstrap``);
+      * a one-process-per-GPU job (``parallel.init_process_group()`` was called): this rank's shard + ONE RCCL all-gather;
+      * otherwise ``num_processes`` (the reference's worker count) GPUs of this process, capped by the visible devices and by
+        ``parallel.MIN_REPLICATES_PER_GPU``: one handle per GPU + ONE RCCL all-gather; a single GPU needs no collective.
+    """
 
     def __init__(self, config, data: pd.DataFrame, inner_model, outer_model, calculator, iterations: int, num_processes: int,
-                 result=None, seed=None, group=None):
+                 result=None, seed=None, comm=None):
         if result is None:
             from plspm.estimator import Estimator
             result = Estimator(config).run(calculator, data, want_scores=False)
@@ -47,64 +59,114 @@ class Bootstrap:
         if seed is None:
             seed = int.from_bytes(os.urandom(8), "little")      # the reference is unseeded as well (bootstrap.py:56)
         self._seed = seed
-        P, L, ne, R = cm.P, cm.L, native.n_eff, native.row_width
-        cols = cm.used_data_cols()                  # == data.columns unless HOC constituents' MVs sit unused in stage 2
-        eff_index = list(inner_model.effects().index)
-        om = outer_model.model()
-        # full-sample estimates in the device row layout: weights | r2 | total | direct | loadings (device column order)
-        original = np.concatenate((om.loc[cm.dev_mvs, "weight"].values, inner_model.r_squared().loc[cm.lvs].values,
-                                   inner_model.effects().loc[:, "total"].values, inner_model.effects().loc[:, "direct"].values,
-                                   om.loc[cm.dev_mvs, "loading"].values)).astype(np.float64)
-        dist, _, world = parallel._world(group)
-        if dist is None:
-            rows, status, iters = native.bootstrap(iterations, seed, 0)                 # resample + Gram + solver on this GPU
-            table, used = native.summary(iterations, original)                          # _create_summary, on the rows still in HBM
+        self._cm, self._native, self._iterations_requested = cm, native, iterations
+        self._inner_model = inner_model
+        R = native.row_width
+        original = self._original(result, inner_model, outer_model)
+        self._group = self._helpers = None
+        ctx = parallel.context()
+        if comm is not None:
+            records = parallel.sharded_bootstrap(lambda count, first: native.bootstrap(count, seed, first), iterations, R, comm)
+            native.store(records)                                                       # merged records back to HBM for the summary
+            self._source = native
+        elif ctx is not None and ctx.world > 1:
+            from plspm import _native
+            if native.device_id != ctx.local_rank:
+                raise _native.NativeBackendError("the handle lives on device %d but this rank's GPU is %d: pass device_id=LOCAL_RANK"
+                                                 % (native.device_id, ctx.local_rank))
+            self._group = _native.NativeGroup(ctx.comm, [native])
+            self._group.bootstrap(iterations, seed, 0)
+            self._source = self._group
         else:
-            def run_shard(count, first):
-                d_rows, _, _ = native.bootstrap_device(count, seed, first)
-                return d_rows, native.sync
-            records = parallel.sharded_bootstrap(run_shard, iterations, R, group=group, on_device=True, to_host=False)
-            import torch
-            torch.cuda.synchronize()
-            table, used = native.summary(iterations, original, d_rows=records.data_ptr(), stride=R + 2)
-            rows, status, iters = parallel.split_records(records.cpu().numpy(), R)
-        self._status, self._iterations, self._used = status, iters, used
-        self._replicates = rows[status == 0]
-        inv = cm.inv_index[cm.inv_index >= 0]
+            devices = parallel.devices_for(num_processes, iterations, native.device_id)
+            if len(devices) > 1 and result.builder is not None:
+                from plspm import _native
+                self._helpers = [result.builder(dev) for dev in devices[1:]]            # the same model + data on the other GPUs
+                self._group = _native.NativeGroup(parallel.local_comm(devices), [native] + self._helpers)
+                self._group.bootstrap(iterations, seed, 0)
+                self._source = self._group
+            else:
+                native.bootstrap_device(iterations, seed, 0)                            # resample + Gram + solver, rows stay in HBM
+                self._source = native
+        # _create_summary (bootstrap.py:24-32) on the records still in HBM
+        if self._source is native:
+            self._table, self._used = native.summary(iterations, original)
+        else:
+            self._table, self._used = self._group.summary(original)
+        self._rows = None
+        self._frames = None
 
-        def frame(block, index):
-            return pd.DataFrame(block, index=index, columns=SUMMARY_COLUMNS)
-        self._weights = frame(table[:P][inv], cols)                                      # data-column order (bootstrap.py:83)
-        self._r_squared = frame(table[P:P + L], cm.lvs).loc[inner_model.endogenous(), :]
-        self._total_effects = frame(table[P + L:P + L + ne], eff_index)
-        self._paths = frame(table[P + L + ne:P + L + 2 * ne], eff_index)
-        self._loading = frame(table[P + L + 2 * ne:][inv], cols)
+    @staticmethod
+    def _original(result, inner_model, outer_model):
+        """Full-sample estimates in the device row layout: weights | r2 | total | direct | loadings (device column order)."""
+        cm, raw = result.compiled, result.raw
+        if raw is not None:
+            return np.concatenate((raw["weights"], raw["r2"], raw["total"], raw["direct"], raw["loadings"])).astype(np.float64)
+        om = outer_model.model()                    # two-stage handles carry no raw fit: take the estimates from the frames
+        return np.concatenate((om.loc[cm.dev_mvs, "weight"].values, inner_model.r_squared().loc[cm.lvs].values,
+                               inner_model.effects().loc[:, "total"].values, inner_model.effects().loc[:, "direct"].values,
+                               om.loc[cm.dev_mvs, "loading"].values)).astype(np.float64)
+
+    def _build_frames(self):
+        if self._frames is None:
+            cm, table, inner_model = self._cm, self._table, self._inner_model
+            P, L, ne = cm.P, cm.L, self._native.n_eff
+            cols = cm.used_data_cols()              # == data.columns unless HOC constituents' MVs sit unused in stage 2
+            eff_index = list(inner_model.effects().index)
+            inv = cm.inv_index[cm.inv_index >= 0]
+
+            def frame(block, index):
+                return pd.DataFrame(block, index=index, columns=SUMMARY_COLUMNS)
+            self._frames = {
+                "weights": frame(table[:P][inv], cols),                                  # data-column order (bootstrap.py:83)
+                "r_squared": frame(table[P:P + L], cm.lvs).loc[inner_model.endogenous(), :],
+                "total_effects": frame(table[P + L:P + L + ne], eff_index),
+                "paths": frame(table[P + L + ne:P + L + 2 * ne], eff_index),
+                "loading": frame(table[P + L + 2 * ne:][inv], cols),
+            }
+        return self._frames
+
+    def _fetch(self):
+        if self._rows is None:
+            self._rows = self._source.rows() if self._source is self._group else self._native.fetch(0, self._iterations_requested)
+        return self._rows
 
     def weights(self) -> pd.DataFrame:
         """Outer weights calculated from bootstrap validation."""
-        return self._weights
+        return self._build_frames()["weights"]
 
     def r_squared(self) -> pd.DataFrame:
         """R squared for the endogenous latent variables."""
-        return self._r_squared
+        return self._build_frames()["r_squared"]
 
     def total_effects(self) -> pd.DataFrame:
-        return self._total_effects
+        return self._build_frames()["total_effects"]
 
     def paths(self) -> pd.DataFrame:
         """Direct effects; rows whose bootstrap mean is exactly zero (indirect-only pairs) are hidden (bootstrap.py:133)."""
-        return self._paths[self._paths["mean"] != 0]
+        paths = self._build_frames()["paths"]
+        return paths[paths["mean"] != 0]
 
     def loading(self) -> pd.DataFrame:
-        return self._loading
+        return self._build_frames()["loading"]
 
     # --- extensions (not in the reference) -----------------------------------------------------------
     def seed(self):
         return self._seed
 
+    def used(self):
+        """Number of replicates that entered the summaries (the others failed and were dropped, bootstrap.py:65-66)."""
+        return self._used
+
     def status(self):
         """Per-replicate status codes (0 = used; others were dropped like the reference's failed replicates)."""
-        return self._status
+        return self._fetch()[1]
 
     def replicate_iterations(self):
-        return self._iterations
+        return self._fetch()[2]
+
+    def replicates(self):
+        """The OK replicates' result rows [n_used, R] in device layout (weights | r2 | total | direct | loadings), fetched from
+        HBM on first use."""
+        rows, status, _ = self._fetch()
+        return rows[status == 0]

@@ -98,10 +98,8 @@ class Estimator:
             raise NotImplementedError("bootstrapping higher order constructs needs complete Scale.NUM / Scale.RAW data")
         path1 = self.expanded_first_stage_path(config)
         compiled1 = compile_model(config, path1, list(data.columns))
-        first = _native.NativeModel(compiled1.block_offset, compiled1.path, compiled1.modes, calculator.scheme().value.code, config.scaled(),
-                                    calculator._iterations, calculator._tolerance, calculator._device_id, nonmetric=True)
         values = data.values
-        first.upload(values if values.dtype == np.float64 else values.astype(np.float64), compiled1.col_index)
+        values = values if values.dtype == np.float64 else values.astype(np.float64)
         lv_first, count = [0], 0
         for lv in config.path().index:
             count += len(hocs[lv]) if lv in hocs else 1
@@ -109,10 +107,19 @@ class Estimator:
         for hoc, parts in hocs.items():
             config.add_lv(hoc, config.mode(hoc), *[c.MV(lv, Scale.NUM) for lv in parts])
         compiled2 = compile_model(config, config.path(), list(data.columns) + [lv for parts in hocs.values() for lv in parts])
-        second = _native.NativeModel(compiled2.block_offset, compiled2.path, compiled2.modes, calculator.scheme().value.code, config.scaled(),
-                                     calculator._iterations, calculator._tolerance, calculator._device_id, nonmetric=True)
-        first.attach_second_stage(second, lv_first)
-        return SolverResult(compiled2, first, None, data.index)
+        scheme_code = calculator.scheme().value.code
+
+        def build(device_id):
+            """The handle pair on ``device_id``: the data-holding first stage with the second stage attached."""
+            first = _native.NativeModel(compiled1.block_offset, compiled1.path, compiled1.modes, scheme_code, config.scaled(),
+                                        calculator._iterations, calculator._tolerance, device_id, nonmetric=True)
+            first.upload(values, compiled1.col_index)
+            second = _native.NativeModel(compiled2.block_offset, compiled2.path, compiled2.modes, scheme_code, config.scaled(),
+                                         calculator._iterations, calculator._tolerance, device_id, nonmetric=True)
+            first.attach_second_stage(second, lv_first)
+            return first
+
+        return SolverResult(compiled2, build(calculator._device_id), None, data.index, builder=build)
 
     def estimate(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame) -> Tuple[pd.DataFrame, pd.DataFrame, pd.DataFrame]:
         """API parity with the reference: (final_data, scores, weights)."""

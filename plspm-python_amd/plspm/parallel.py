@@ -1,55 +1,34 @@
-"""Replicate sharding across GPUs: one process per GPU, no data-path collective, ONE gather at the end.
+"""Replicate sharding across GPUs: no data-path collective, ONE gather at the end.  No torch anywhere.
 
-Replicates are independent (reference bootstrap.py:54-66 has no cross-replicate state; the reference shards
-them over ``multiprocessing`` workers, bootstrap.py:91-94, and merges through a Queue, bootstrap.py:96-111).
-Here rank g runs the contiguous replicate-id range ``shard_range(B, g, G)`` of one logical Philox stream keyed
-by (seed, replicate id), so the merged result is identical for every G, and the Queue becomes a single
-``all_gather`` (RCCL over xGMI when the process group's backend is "nccl", gloo in the CPU tests).
-torch.distributed is used for rendezvous + the collective only; the device buffer that libplspm_hip filled is
-handed to RCCL in place (CUDA-array-interface view, no staging copy when the shards are equal).
+Replicates are independent (reference bootstrap.py:54-66 has no cross-replicate state; the reference shards them over
+``processes`` forked workers, bootstrap.py:89-94, and merges through a Queue, bootstrap.py:96-111).  Here rank g runs the
+contiguous replicate-id range ``shard_range(B, g, G)`` of one logical Philox stream keyed by (seed, replicate id), so the merged
+result is identical for every G, and the Queue becomes a single RCCL all-gather over xGMI inside libplspm_hip.so
+(``plspm_group_*``, include/plspm_hip.h).  Three ways to run more than one shard:
+
+* **one process, several GPUs** -- what ``Plspm(..., processes=k)`` does: ``local_comm(devices)`` (ncclCommInitAll, cached per
+  process) + one handle per device bound into a ``NativeGroup``;
+* **one process per GPU** (``python -m torch.distributed.run`` / mpirun; the launcher is only a process spawner, torch is not
+  imported): ``init_process_group()`` reads RANK / WORLD_SIZE / LOCAL_RANK, rank 0 publishes the ncclUniqueId through a
+  rendezvous file, every rank joins with ncclCommInitRank; ``Plspm`` then shards its bootstrap over the job automatically;
+* **a host-side transport of the caller's** (MPI, gloo, ...): ``sharded_bootstrap(run_shard, total, width, comm)`` with any
+  object offering ``rank``, ``world`` and ``all_gather(ndarray) -> ndarray``; the merged records go back to the device for the
+  summaries (``NativeModel.store``).  The CPU test-suite drives this with a gloo communicator.
 """
+import os
+import tempfile
+import time
+
 import numpy as np
+
+MIN_REPLICATES_PER_GPU = 1000      # below this a second GPU costs more (upload + launch) than it saves; results do not depend on G
 
 
 def shard_range(total, rank, world):
-    """Contiguous, balanced [start, stop) of replicate ids for ``rank``."""
+    """Contiguous, balanced [start, stop) of replicate ids for ``rank`` (same split as plspm_group_shard)."""
     base, extra = divmod(int(total), int(world))
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
-
-
-class _DeviceView:
-    """Zero-copy view of a device buffer owned by libplspm_hip for torch (CUDA array interface v2)."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
-
-
-_view_cache = {}
-_recv_cache = {}
-
-
-def device_rows(ptr, count, stride):
-    """torch view [count, stride] float64 of the result rows libplspm_hip left in HBM (cached per buffer)."""
-    import torch
-    key = (int(ptr), int(count), int(stride), torch.cuda.current_device())
-    t = _view_cache.get(key)
-    if t is None:
-        if len(_view_cache) > 64:
-            _view_cache.clear()
-        t = torch.as_tensor(_DeviceView(ptr, (count, stride), "<f8"), device=torch.device("cuda", torch.cuda.current_device()))
-        _view_cache[key] = t
-    return t
-
-
-def _world(group=None):
-    try:
-        import torch.distributed as dist
-    except ImportError:
-        return None, 0, 1
-    if not (dist.is_available() and dist.is_initialized()):
-        return None, 0, 1
-    return dist, dist.get_rank(group), dist.get_world_size(group)
 
 
 def split_records(records, width):
@@ -58,75 +37,143 @@ def split_records(records, width):
     return np.ascontiguousarray(records[:, :width]), records[:, width].astype(np.int32), records[:, width + 1].astype(np.int32)
 
 
-def gather_records(send, total, group=None, async_op=False, slot=0):
-    """all_gather of per-rank record blocks (a torch tensor [mine, width+2] on the group's device) into one
-    [total, width+2] tensor in replicate-id order, on every rank.  This is the single collective of a bootstrap.
-    async_op=True (equal shards only) returns (recv, work): the collective runs on RCCL's own stream and the caller
-    overlaps it with other work, calling work.wait() before touching ``recv`` or re-using ``send``; ``slot`` selects
-    one of several receive buffers so that consecutive jobs do not share one."""
-    import torch
-    dist, rank, world = _world(group)
-    if dist is None:
-        return send
-    if dist.get_backend(group) == "nccl" and not send.is_cuda:
-        send = send.cuda()                               # RCCL moves device buffers only
-    stride = send.shape[1]
-    cap = shard_range(total, 0, world)[1]                 # rank 0 always holds the largest shard
-    equal = (total % world == 0)
-    if not equal:
-        padded = torch.zeros((cap, stride), dtype=send.dtype, device=send.device)
-        padded[:send.shape[0]] = send
-        send = padded
-    key = (world, cap, stride, str(send.device), slot)
-    recv = _recv_cache.get(key)
-    if recv is None:
-        recv = torch.empty((world * cap, stride), dtype=send.dtype, device=send.device)
-        _recv_cache[key] = recv
-    if async_op:
-        if not equal:
-            raise ValueError("async gather needs equal shards")
-        work = dist.all_gather_into_tensor(recv, send.contiguous(), group=group, async_op=True)
-        return recv, work
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
-    if equal:
-        return recv
+def join_records(rows, status, iters):
+    return np.concatenate((rows, status[:, None].astype(np.float64), iters[:, None].astype(np.float64)), axis=1)
+
+
+# ------------------------------------------------------------------------------------------------ one process, several GPUs
+_local_comms = {}
+
+
+def local_comm(devices):
+    """The process-wide communicator over ``devices`` (created on first use: librccl load + ncclCommInitAll take of the order
+    of a second, every later bootstrap re-uses it)."""
+    from plspm import _native
+    key = tuple(int(d) for d in devices)
+    comm = _local_comms.get(key)
+    if comm is None or not comm._h:
+        comm = _native.NativeComm(key)
+        _local_comms[key] = comm
+    return comm
+
+
+def devices_for(processes, replicates, first_device=0):
+    """GPUs a single-process bootstrap uses: ``processes`` (the reference's worker count, plspm.py:35-37) capped by the visible
+    devices and by MIN_REPLICATES_PER_GPU.  Purely a performance decision -- the rows are the same for every answer."""
+    from plspm import _native
+    available = _native.device_count()
+    n = max(1, min(int(processes), available - int(first_device), int(replicates) // MIN_REPLICATES_PER_GPU))
+    return [int(first_device) + g for g in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------ one process per GPU
+class ProcessContext:
+    def __init__(self, rank, world, local_rank, comm):
+        self.rank, self.world, self.local_rank, self.comm = rank, world, local_rank, comm
+
+
+_context = None
+_rendezvous_seq = 0
+
+
+def _rendezvous_path(directory):
+    global _rendezvous_seq
+    _rendezvous_seq += 1
+    tag = "%s-%s-%d-%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"), os.getppid(), _rendezvous_seq)
+    return os.path.join(directory or os.environ.get("PLSPM_RDZV_DIR") or tempfile.gettempdir(), "plspm-rdzv-" + tag)
+
+
+def exchange_unique_id(rank, world, directory=None, timeout=300.0, make_id=None):
+    """Rank 0 draws the ncclUniqueId and publishes it through a file that the other ranks of the same launcher (same parent
+    process, same MASTER_ADDR/PORT) poll for: single-node rendezvous without a store service.  Every rank must call this the same
+    number of times (the file name carries a per-process sequence number).  ``make_id`` replaces ncclGetUniqueId (tests)."""
+    from plspm import _native
+    path = _rendezvous_path(directory)
+    deadline = time.time() + timeout
+    if rank == 0:
+        uid = (make_id or _native.rccl_unique_id)()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)                      # atomic: a reader never sees a partial id
+        acks = [path + ".ack%d" % r for r in range(1, world)]
+        try:
+            while not all(os.path.exists(a) for a in acks):          # every rank has the id: nothing of this exchange stays behind
+                if time.time() > deadline:
+                    raise _native.NativeBackendError("rendezvous: not every rank picked up %s within %.0f s" % (path, timeout))
+                time.sleep(0.002)
+        finally:
+            for name in [path] + acks:
+                try:
+                    os.remove(name)
+                except FileNotFoundError:
+                    pass
+        return uid
+    while True:
+        try:
+            with open(path, "rb") as fh:
+                uid = fh.read()
+            if len(uid) == _native.UNIQUE_ID_BYTES:
+                open(path + ".ack%d" % rank, "wb").close()
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.time() > deadline:
+            raise _native.NativeBackendError("rendezvous: rank 0 did not publish %s within %.0f s" % (path, timeout))
+        time.sleep(0.002)
+
+
+def init_process_group(rank=None, world_size=None, local_rank=None, rendezvous_dir=None, timeout=300.0):
+    """Join the one-process-per-GPU job described by RANK / WORLD_SIZE / LOCAL_RANK (or the arguments): collective, every rank
+    calls it once.  Afterwards ``Plspm(bootstrap=True)`` shards its replicates over the job.  Returns the context."""
+    global _context
+    from plspm import _native
+    if _context is not None:
+        return _context
+    rank = int(os.environ.get("RANK", "0") if rank is None else rank)
+    world = int(os.environ.get("WORLD_SIZE", "1") if world_size is None else world_size)
+    local = int(os.environ.get("LOCAL_RANK", str(rank)) if local_rank is None else local_rank)
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    if local >= _native.device_count():
+        raise _native.NativeBackendError("LOCAL_RANK %d but only %d HIP devices are visible" % (local, _native.device_count()))
+    uid = exchange_unique_id(rank, world, rendezvous_dir, timeout)
+    comm = _native.NativeComm([local], nranks=world, first_rank=rank, unique_id=uid)
+    _context = ProcessContext(rank, world, local, comm)
+    return _context
+
+
+def context():
+    """The process-group context, or None when this process runs on its own."""
+    return _context
+
+
+def destroy_process_group():
+    global _context
+    if _context is not None:
+        _context.comm.close()
+        _context = None
+
+
+# ------------------------------------------------------------------------------------------------ host-side transport
+def sharded_bootstrap(run_shard, total, width, comm=None):
+    """Run ``total`` replicates split over a host-side communicator; every rank gets all of them back in replicate-id order.
+
+    run_shard(count, first_id) -> (rows [count, width], status, iters) on the host (e.g. ``NativeModel.bootstrap``);
+    comm: None (this process alone) or an object with ``rank``, ``world`` and ``all_gather(block) -> stacked blocks`` where every
+    rank contributes a float64 array of identical shape.  Returns the merged [total, width + 2] records."""
+    rank, world = (0, 1) if comm is None else (int(comm.rank), int(comm.world))
+    start, stop = shard_range(total, rank, world)
+    mine = stop - start
+    cap = shard_range(total, 0, world)[1]              # rank 0 always holds the largest shard
+    block = np.full((cap, width + 2), np.nan)          # NaN status = padding of a ragged split (the device summary skips it too)
+    if mine > 0:
+        block[:mine] = join_records(*run_shard(mine, start))
+    if comm is None:
+        return block[:mine]
+    merged = np.asarray(comm.all_gather(block)).reshape(world, cap, width + 2)
     parts = []
     for r in range(world):
         a, b = shard_range(total, r, world)
-        parts.append(recv[r * cap:r * cap + (b - a)])
-    return torch.cat(parts, dim=0)
-
-
-def sharded_bootstrap(run_shard, total, width, group=None, on_device=False, to_host=True):
-    """Run ``total`` replicates split over the process group; every rank gets all of them back, in replicate-id order.
-
-    run_shard(count, first_id) executes one shard and returns
-      * host arrays (rows [count, width], status, iters)                        when on_device is False, or
-      * (device pointer of [count, width+2] records, sync callable)             when on_device is True
-        (the buffer stays in HBM and goes straight into RCCL).
-    Returns (rows, status, iters) as NumPy arrays, or the merged record tensor when to_host is False.
-    """
-    import torch
-    dist, rank, world = _world(group)
-    start, stop = shard_range(total, rank, world)
-    mine = stop - start
-    if on_device:
-        if mine > 0:
-            ptr, sync = run_shard(mine, start)
-            sync()
-            send = device_rows(ptr, mine, width + 2)
-        else:
-            send = torch.zeros((0, width + 2), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
-    else:
-        if mine > 0:
-            rows, status, iters = run_shard(mine, start)
-            rec = np.concatenate((rows, status[:, None].astype(np.float64), iters[:, None].astype(np.float64)), axis=1)
-        else:
-            rec = np.zeros((0, width + 2))
-        if dist is None:
-            return split_records(rec, width) if to_host else rec
-        send = torch.from_numpy(np.ascontiguousarray(rec))
-    merged = gather_records(send, total, group)
-    if not to_host:
-        return merged
-    return split_records(merged.cpu().numpy(), width)
+        parts.append(merged[r, :b - a])
+    return np.concatenate(parts, axis=0)

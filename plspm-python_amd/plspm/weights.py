@@ -20,14 +20,20 @@ class ConvergenceError(Exception):
     pass
 
 
+class NumericalConditionError(Exception):
+    """The device solver flagged the full-sample fit: a zero-variance / non-finite input (PLSPM_NONFINITE) or a regression that
+    the reference cannot solve either (PLSPM_SINGULAR).  Raised instead of returning frames built from meaningless numbers."""
+
+
 class SolverResult:
     """Everything one device fit produced, still in device column order, plus the labels to unpack it."""
 
-    def __init__(self, compiled, native, raw, index):
+    def __init__(self, compiled, native, raw, index, builder=None):
         self.compiled = compiled
         self.native = native
         self.raw = raw
         self.index = index
+        self.builder = builder          # builder(device_id) -> another uploaded handle of the same model + data (multi-GPU bootstrap)
 
     # frames with the reference's labels / ordering contracts (SURVEY.md section 7)
     def scores(self) -> pd.DataFrame:
@@ -97,29 +103,41 @@ class WeightsCalculatorFactory:
             raise ValueError("correction must be sqrt(N / (N - 1)) of the data handed to the solver")
         compiled = compile_model(self._config, path, list(data.columns))
         values = data.values
+        incomplete = None
         if nonmetric == 2:
             xaug, aug_offset, mv_off, mv_kind = augment(compiled, self._config, values)
-            native = _native.NativeModel(aug_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled, self._iterations,
-                                         self._tolerance, self._device_id, nonmetric=True, categorical=(mv_off, mv_kind))
-            native.upload(xaug)
         else:
             values = values if values.dtype == np.float64 else values.astype(np.float64)
             col_index, ind_of = compiled.col_index, None
-            incomplete = None
             if np.isnan(values).any():
                 if not nonmetric:
                     values, col_index, ind_of = with_missing_indicators(compiled, values)
                 else:
                     values, incomplete = self._incomplete_rows(compiled, values)
-            native = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
-                                         self._iterations, self._tolerance, self._device_id, nonmetric=bool(nonmetric), missing=ind_of)
-            native.upload(values, col_index)
+
+        def build(device_id):
+            """One handle of this model with the data resident on ``device_id``."""
+            if nonmetric == 2:
+                handle = _native.NativeModel(aug_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled, self._iterations,
+                                             self._tolerance, device_id, nonmetric=True, categorical=(mv_off, mv_kind))
+                handle.upload(xaug)
+                return handle
+            handle = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
+                                         self._iterations, self._tolerance, device_id, nonmetric=bool(nonmetric), missing=ind_of)
+            handle.upload(values, col_index)
             if incomplete is not None:
-                native.set_incomplete_rows(*incomplete)
+                handle.set_incomplete_rows(*incomplete)
+            return handle
+
+        native = build(self._device_id)
         raw = native.fit(want_scores=want_scores, want_cov=want_cov)
         if raw["status"] == _native.STATUS_NOT_CONVERGED:
             raise ConvergenceError("Could not converge after " + str(raw["iterations"]) + " iterations")
-        return SolverResult(compiled, native, raw, data.index)
+        if raw["status"] == _native.STATUS_NONFINITE:
+            raise NumericalConditionError("The solver met a zero-variance manifest variable or non-finite data (status PLSPM_NONFINITE)")
+        if raw["status"] == _native.STATUS_SINGULAR:
+            raise NumericalConditionError("The solver met a regression it cannot solve (status PLSPM_SINGULAR)")
+        return SolverResult(compiled, native, raw, data.index, builder=build)
 
     def calculate(self, data: pd.DataFrame, path: pd.DataFrame):
         """Reference seam: ``data`` is already treated; returns (final_data, scores, weights).  (Treating is idempotent for

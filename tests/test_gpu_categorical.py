@@ -192,11 +192,9 @@ def test_wide_indicator_model_uses_the_block_staged_stop_rule_pass():
     nm, g = gpu_fit_cat(likert, model)
     check_fit(g, orc.fit(likert, model), "wide")
     dense = nm.bootstrap(70, seed=4)
-    os.environ["PLSPM_CONV_DENSE"] = "0"
-    try:
-        gathered = nm.bootstrap(70, seed=4)
-    finally:
-        del os.environ["PLSPM_CONV_DENSE"]
+    nm.set_option("conv_pass", 1)                           # the gathering stop-rule pass
+    gathered = nm.bootstrap(70, seed=4)
+    nm.set_option("conv_pass", 0)
     assert np.all(dense[1] == 0)
     assert np.array_equal(dense[1], gathered[1]) and np.array_equal(dense[2], gathered[2])
     assert_close(dense[0], gathered[0], 1e-11, 1e-13)

@@ -1,5 +1,9 @@
-"""GPU: the drop-in API under torch.distributed (RCCL) gives the same bootstrap summaries as the single-process path
-(one rank on the one GPU of the test box: exercises rendezvous, the device-resident all_gather and the device summaries)."""
+"""GPU: the multi-GPU routes of the bootstrap, all through the C-ABI of libplspm_hip.so (plspm_comm_* / plspm_group_*).
+
+The test box has ONE MI355X, so more than one rank means several handles on device 0: RCCL refuses duplicate devices and the
+group then moves the records with device-to-device copies through exactly the same buffers, events and shard arithmetic; the
+RCCL transport itself (dlopen, ncclCommInit*, the all-gather ordered behind the handle's stream) runs with one rank.
+What must hold everywhere: the merged records are bit-identical to the single-handle stream for every number of ranks."""
 import json
 import os
 import subprocess
@@ -8,8 +12,11 @@ import sys
 import numpy as np
 import pytest
 
+import plspm_oracle as orc
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 
 
 def _run(cmd):
@@ -19,7 +26,18 @@ def _run(cmd):
     return json.loads(lines[-1][7:])
 
 
-def test_api_bootstrap_under_torchrun_equals_single_process():
+def _model(n=2000, mvs=10, seed=3, device=0, nonmetric=False, modes=None):
+    from plspm import _native
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(n, C, mvs, seed=seed)
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+    nm = _native.NativeModel(boff, C.astype(np.uint8), np.array(modes or [0] * 6, dtype=np.int32), 2, True, 100, 1e-6, device, nonmetric=nonmetric)
+    nm.upload(X)
+    return nm
+
+
+def test_api_bootstrap_one_process_per_gpu_rccl_equals_single_process():
+    """Plspm(bootstrap=True) in a launcher-spawned rank (RCCL, one rank) == the plain single-process result."""
     script = os.path.join(HERE, "dist_api_script.py")
     plain = _run([sys.executable, script])
     env_cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -27,3 +45,131 @@ def test_api_bootstrap_under_torchrun_equals_single_process():
     dist = _run(env_cmd)
     for key in plain:
         np.testing.assert_allclose(np.array(dist[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)
+
+
+@pytest.mark.parametrize("nranks,B", [(1, 64), (2, 64), (2, 65), (3, 100), (4, 3)])
+def test_group_records_bit_identical_to_single_handle(nranks, B):
+    """G handles (one device) = G ranks of the group: shards + one gather give the single-handle stream, bit for bit, for even,
+    ragged and more-ranks-than-replicates splits; the device summary of the gathered records equals the single-handle summary."""
+    from plspm import _native
+    models = [_model() for _ in range(nranks)]
+    ref_rows, ref_status, ref_iters = models[0].bootstrap(B, seed=5, rep_offset=7)
+    original = np.linspace(-1.0, 1.0, models[0].row_width)
+    ref_table, ref_used = models[0].summary(B, original)
+    comm = _native.NativeComm([0] * nranks)
+    assert comm.uses_rccl == (nranks == 1)                   # one rank: the real RCCL transport; several on one GPU: device copies
+    group = _native.NativeGroup(comm, models)
+    for _ in range(3):                                       # both buffer slots, and a slot re-used
+        group.bootstrap(B, seed=5, rep_offset=7)
+    rows, status, iters = group.rows()
+    assert np.array_equal(rows, ref_rows) and np.array_equal(status, ref_status) and np.array_equal(iters, ref_iters)
+    table, used = group.summary(original)
+    assert used == ref_used == B
+    assert np.array_equal(table, ref_table)
+    ptr, n_rec, stride = group.records(0)
+    assert n_rec == nranks * ((B + nranks - 1) // nranks) and stride == models[0].row_stride and ptr
+    starts = [group.shard(B, r) for r in range(nranks)]
+    assert starts[0][0] == 0 and sum(c for _, c in starts) == B
+    group.barrier()
+    assert group.max(1.25) == 1.25
+    group.close(); comm.close()
+
+
+def test_group_growing_and_shrinking_batches_and_a_second_group_on_the_same_comm():
+    from plspm import _native
+    models = [_model(800, 4, seed=8) for _ in range(2)]
+    comm = _native.NativeComm([0, 0])
+    group = _native.NativeGroup(comm, models)
+    for B in (10, 300, 31, 300):
+        group.bootstrap(B, seed=2)
+        rows, status, _ = group.rows()
+        ref = models[1].bootstrap(B, seed=2)
+        assert np.array_equal(rows, ref[0]) and np.array_equal(status, ref[1])
+    with pytest.raises(_native.NativeBackendError):          # a communicator serves one group at a time
+        _native.NativeGroup(comm, models)
+    group.close()
+    again = _native.NativeGroup(comm, models[::-1])
+    again.bootstrap(12, seed=2)
+    assert np.array_equal(again.rows()[0], models[0].bootstrap(12, seed=2)[0])
+    again.close(); comm.close()
+
+
+def test_group_nonmetric_two_ranks_threads():
+    """Non-metric models iterate with host read-backs: the group drives each handle from its own host thread."""
+    from plspm import _native
+    models = [_model(1500, 5, seed=4, nonmetric=True, modes=[0, 1, 0, 1, 0, 1]) for _ in range(2)]
+    ref = models[0].bootstrap(90, seed=13)
+    comm = _native.NativeComm([0, 0])
+    group = _native.NativeGroup(comm, models)
+    group.bootstrap(90, seed=13)
+    rows, status, iters = group.rows()
+    assert np.all(status == 0) and np.array_equal(iters, ref[2])
+    assert np.array_equal(rows, ref[0])
+    group.close(); comm.close()
+
+
+def _gloo_worker(rank, world, port, total, out_dir):
+    """Both ranks on GPU 0; the shard runner is the product's NativeModel.bootstrap, the transport a host-side gloo gather."""
+    from helpers_dist import GlooComm
+    from plspm import parallel
+    comm = GlooComm(rank, world, port)
+    try:
+        nm = _model(1200, 5, seed=6)
+        rec = parallel.sharded_bootstrap(lambda count, first: nm.bootstrap(count, 17, first), total, nm.row_width, comm)
+        nm.store(rec)
+        table, used = nm.summary(total, np.ones(nm.row_width))
+        np.savez(os.path.join(out_dir, "g%d.npz" % rank), rec=rec, table=table, used=used)
+    finally:
+        comm.close()
+
+
+def test_gloo_world2_real_cabi_shards_equal_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from helpers_dist import free_port
+    total = 77
+    mp.spawn(_gloo_worker, args=(2, free_port(), total, str(tmp_path)), nprocs=2, join=True)
+    nm = _model(1200, 5, seed=6)
+    rows, status, iters = nm.bootstrap(total, 17, 0)
+    table, used = nm.summary(total, np.ones(nm.row_width))
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "g%d.npz" % rank))
+        assert np.array_equal(got["rec"][:, :-2], rows) and np.array_equal(got["rec"][:, -2], status) and np.array_equal(got["rec"][:, -1], iters)
+        assert int(got["used"]) == used and np.array_equal(got["table"], table)
+
+
+def test_config4_40000_replicates_properties_and_sharding_invariance():
+    """BASELINE.json configs[3] on the one GPU of the box: 40,000 replicates of the 10k x 60 x 6 PATH model, as 8 shards of
+    5,000 (the 8-GPU split, here 2 handles x 4 sequential offsets and a 2-rank group) against ONE 40,000-replicate call.
+    Size-independent properties: every replicate converges in the same 3 iterations as the oracle's, shards are bit-identical to
+    the monolithic stream, summaries of the gathered records equal the single-call summaries, and spot rows match the oracle."""
+    from plspm import _native
+    a, b = _model(10000, 10, seed=0), _model(10000, 10, seed=0)
+    B, seed = 40000, 1
+    a.bootstrap_device(B, seed=seed)
+    original = np.zeros(a.row_width)
+    table, used = a.summary(B, original)
+    assert used == B
+    mono = a.fetch(0, B)
+    assert np.all(mono[1] == 0) and mono[2].min() == 3 and mono[2].max() <= 4
+    comm = _native.NativeComm([0, 0])
+    group = _native.NativeGroup(comm, [a, b])
+    group.bootstrap(B, seed=seed)                           # 2 ranks x 20,000
+    g_table, g_used = group.summary(original)
+    assert g_used == B and np.array_equal(g_table, table)
+    g_rows = group.rows()
+    assert np.array_equal(g_rows[0], mono[0]) and np.array_equal(g_rows[2], mono[2])
+    for shard in (0, 3, 7):                                 # the 8-GPU shards of 5,000 as separate calls
+        part = b.bootstrap(5000, seed=seed, rep_offset=5000 * shard)
+        assert np.array_equal(part[0], mono[0][5000 * shard:5000 * (shard + 1)])
+    group.close(); comm.close()
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    for r in (0, 19999, 20000, 39999):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(seed, r, 10000), orc.correction(10000))
+        assert its == mono[2][r]
+        np.testing.assert_allclose(mono[0][r], mine, rtol=1e-8, atol=1e-11)
+    # the summary statistic itself against NumPy on the fetched rows
+    np.testing.assert_allclose(table[:, 1], mono[0].mean(axis=0), rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(table[:, 2], mono[0].std(axis=0, ddof=1), rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(table[:, 3], np.quantile(mono[0], 0.025, axis=0), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(table[:, 4], np.quantile(mono[0], 0.975, axis=0), rtol=1e-12, atol=1e-15)

@@ -100,7 +100,7 @@ def test_random_variant_through_the_api(seed):
     assert its == boot.replicate_iterations()[0], tag
     dev = calc._result.compiled                              # rows are in device column order
     inv = dev.inv_index[dev.inv_index >= 0]
-    row = boot._replicates[0]
+    row = boot.replicates()[0]
     P, L = X.shape[1], model.L
     ne = (len(row) - 2 * P - L) // 2
     got = np.concatenate((row[:P][inv], row[P:P + L + 2 * ne], row[P + L + 2 * ne:][inv]))

@@ -113,6 +113,6 @@ def test_api_bootstrap_of_a_hoc_model():
     X, blocks, _ = mobi_hoc_inputs()
     model1 = mobi_hoc_model("path_B", blocks)
     o = orc.fit_two_stage(X[_native.bootstrap_indices(6, 3, 250)], model1, MOBI_STAGE2, g["path_B/path2"], "BAAAA", orc.correction(250))
-    mine = boot._replicates                                             # noqa: SLF001 (rows in device order, failed ones dropped)
+    mine = boot.replicates()                                             # noqa: SLF001 (rows in device order, failed ones dropped)
     assert boot.status()[:4].tolist() == [0, 0, 0, 0]
     assert_close(mine[3][16:16 + 5 + 16], np.concatenate((o["r2"], o["total"], o["direct"])), RTOL, ATOL)

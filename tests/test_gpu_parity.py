@@ -595,22 +595,16 @@ def test_nonmetric_bootstrap_explicit_indices_vs_reference_rows(tag):
 
 def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
     """The bootstrap's dense stop-rule pass (nm_conv_dense_kernel) and the gathering pass it replaced (still used for N > 65,535
-    or models too wide even for block staging; PLSPM_CONV_DENSE=0 forces it) must take the same decisions and give the same rows."""
-    import os
+    or models too wide even for block staging; option conv_pass = 1 forces it) must take the same decisions and give the same rows."""
     X, blocks = orc.synth(3000, orc.satisfaction_C(), 5, seed=17)
     model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "factorial", True, tol=1e-7, scales=["NUM"] * 30)
     nm, _ = gpu_fit_nm(X, model)
     dense = nm.bootstrap(130, seed=2)
-    os.environ["PLSPM_CONV_DENSE"] = "0"
-    try:
-        gathered = nm.bootstrap(130, seed=2)
-    finally:
-        del os.environ["PLSPM_CONV_DENSE"]
-    os.environ["PLSPM_CONV_BLOCKED"] = "1"                  # coefficient tile staged one LV block at a time (wide models)
-    try:
-        blocked = nm.bootstrap(130, seed=2)
-    finally:
-        del os.environ["PLSPM_CONV_BLOCKED"]
+    nm.set_option("conv_pass", 1)                           # the gathering pass
+    gathered = nm.bootstrap(130, seed=2)
+    nm.set_option("conv_pass", 2)                           # coefficient tile staged one LV block at a time (wide models)
+    blocked = nm.bootstrap(130, seed=2)
+    nm.set_option("conv_pass", 0)
     for other in (gathered, blocked):
         assert np.array_equal(dense[1], other[1]) and np.array_equal(dense[2], other[2])
         assert_close(dense[0], other[0], 1e-12, 1e-14)

@@ -1,9 +1,12 @@
-"""N > 1 path on CPU: two real processes, gloo backend, world_size 2 (rendezvous on 127.0.0.1).
-Checks the replicate sharding + the single all_gather of plspm.parallel against the single-process result,
-including ragged shards and more ranks than replicates.  A deterministic stand-in plays the GPU shard runner
-(no compute kernel is needed to test the exchange)."""
+"""N > 1 path on CPU: real processes, gloo backend, world_size 2 and 3 (rendezvous on 127.0.0.1).
+
+* replicate sharding + the single all_gather of plspm.parallel.sharded_bootstrap against the single-process result, including
+  ragged shards and more ranks than replicates (a deterministic stand-in plays the shard runner);
+* the same with the REAL solver source as shard runner: every rank draws its replicates' indices from the library's Philox
+  stream (plspm_bootstrap_indices -- host code of libplspm_hip.so) and solves them with the CPU emulation build of
+  csrc/solver_core.h; the merged rows must equal the single-process rows bit for bit and the oracle's to 1e-9;
+* the file rendezvous that hands rank 0's ncclUniqueId to the other ranks of a one-process-per-GPU job."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -11,6 +14,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from plspm import parallel  # noqa: E402
 
 WIDTH = 11
@@ -25,20 +29,16 @@ def fake_shard(count, first):
     return rows, status, iters
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
-
-
 def _worker(rank, world, port, totals, out_dir):
-    import torch.distributed as dist
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from helpers_dist import GlooComm
+    comm = GlooComm(rank, world, port)
     try:
         for total in totals:
-            rows, status, iters = parallel.sharded_bootstrap(fake_shard, total, WIDTH)
+            rec = parallel.sharded_bootstrap(fake_shard, total, WIDTH, comm)
+            rows, status, iters = parallel.split_records(rec, WIDTH)
             np.savez(os.path.join(out_dir, "r%d_t%d.npz" % (rank, total)), rows=rows, status=status, iters=iters)
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
 def test_shard_range_partitions_exactly():
@@ -52,7 +52,7 @@ def test_shard_range_partitions_exactly():
 
 
 def test_single_process_passthrough():
-    rows, status, iters = parallel.sharded_bootstrap(fake_shard, 9, WIDTH)
+    rows, status, iters = parallel.split_records(parallel.sharded_bootstrap(fake_shard, 9, WIDTH), WIDTH)
     ref = fake_shard(9, 0)
     assert np.array_equal(rows, ref[0]) and np.array_equal(status, ref[1]) and np.array_equal(iters, ref[2])
 
@@ -60,12 +60,90 @@ def test_single_process_passthrough():
 @pytest.mark.parametrize("world", [2, 3])
 def test_gloo_sharded_gather_matches_single_process(tmp_path, world):
     import torch.multiprocessing as mp
+    from helpers_dist import free_port
     totals = (8, 7, 1, 30)          # even, ragged, fewer replicates than ranks, larger
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, totals, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), totals, str(tmp_path)), nprocs=world, join=True)
     for total in totals:
         ref = fake_shard(total, 0)
         for rank in range(world):
             got = np.load(os.path.join(str(tmp_path), "r%d_t%d.npz" % (rank, total)))
             assert np.array_equal(got["rows"], ref[0]), (total, rank)        # bit-exact, replicate-id order, on every rank
             assert np.array_equal(got["status"], ref[1]) and np.array_equal(got["iters"], ref[2])
+
+
+# ---------------------------------------------------------------------------------------------- real solver source as the shard runner
+N_EMU, SEED_EMU, TOTAL_EMU = 400, 21, 7
+
+
+def _emu_inputs():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import plspm_oracle as orc
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(N_EMU, C, 3, seed=9)
+    return orc, X, orc.Model(blocks, C, "ABABAB", "path", True)
+
+
+def _emu_shard(count, first):
+    """Replicates [first, first + count) of the library's Philox stream, solved by the CPU build of csrc/solver_core.h."""
+    import ctypes
+    import subprocess
+    from plspm import _native
+    from test_solver_hostemu import EMU, run_emu
+    subprocess.check_call(["make", "-s", "-C", EMU, "libplspm_hostemu.so"])
+    lib = ctypes.CDLL(os.path.join(EMU, "libplspm_hostemu.so"))
+    _, X, model = _emu_inputs()
+    shift = X[:, model.mv_order].mean(axis=0)
+    rows, status, iters = [], [], []
+    for r in range(first, first + count):
+        idx = _native.bootstrap_indices(SEED_EMU, r, N_EMU)
+        out = run_emu(lib, X, model, counts=np.bincount(idx, minlength=N_EMU), shift=shift, nthreads=2)
+        rows.append(out["row"][:-2]); status.append(out["status"]); iters.append(out["iterations"])
+    return np.array(rows), np.array(status, dtype=np.int32), np.array(iters, dtype=np.int32)
+
+
+def _emu_worker(rank, world, port, out_dir):
+    from helpers_dist import GlooComm
+    comm = GlooComm(rank, world, port)
+    try:
+        width = _emu_shard(1, 0)[0].shape[1]
+        rec = parallel.sharded_bootstrap(_emu_shard, TOTAL_EMU, width, comm)
+        np.save(os.path.join(out_dir, "emu_r%d.npy" % rank), rec)
+    finally:
+        comm.close()
+
+
+def test_gloo_world2_real_solver_shards_equal_single_process_and_oracle(tmp_path):
+    import torch.multiprocessing as mp
+    from helpers_dist import free_port
+    mp.spawn(_emu_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = parallel.join_records(*_emu_shard(TOTAL_EMU, 0))
+    for rank in range(2):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "emu_r%d.npy" % rank)), single), rank
+    # and the stream itself is the reference arithmetic: replicate 5 against the data-level oracle
+    from plspm import _native
+    orc, X, model = _emu_inputs()
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(SEED_EMU, 5, N_EMU), orc.correction(N_EMU))
+    P, L = X.shape[1], model.L
+    ne = (single.shape[1] - 2 - 2 * P - L) // 2
+    inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
+    row = single[5]
+    got = np.concatenate((row[:P][inv], row[P:P + L + 2 * ne], row[P + L + 2 * ne:2 * P + L + 2 * ne][inv]))
+    assert its == int(row[-1]) and int(row[-2]) == 0
+    np.testing.assert_allclose(got, mine, rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------- ncclUniqueId rendezvous
+def _rdzv_worker(rank, world, directory, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29999"
+    got = []
+    for k in range(2):                                   # two exchanges in a row: the sequence number keeps them apart
+        got.append(parallel.exchange_unique_id(rank, world, directory, timeout=60.0, make_id=lambda k=k: bytes([k + 1]) * 128))
+    with open(os.path.join(out_dir, "uid_r%d" % rank), "wb") as fh:
+        fh.write(b"".join(got))
+
+
+def test_unique_id_rendezvous_file_world3(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_rdzv_worker, args=(3, str(tmp_path), str(tmp_path)), nprocs=3, join=True)
+    for rank in range(3):
+        assert open(os.path.join(str(tmp_path), "uid_r%d" % rank), "rb").read() == b"\x01" * 128 + b"\x02" * 128

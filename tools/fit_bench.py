@@ -23,7 +23,12 @@ def run(tag, n, C, per, modes, scheme, reps=5):
     P = X.shape[1]
     boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
     m = _native.NativeModel(boff, C.astype(np.uint8), np.array(modes, dtype=np.int32), scheme, True, 100, 1e-6, 0)
-    t0 = time.time(); m.upload(X); t_up = time.time() - t0
+    t0 = time.time(); m.upload(X); t_up = time.time() - t0            # first upload of the process: allocations + code-object load
+    ups = []
+    for _ in range(3 if n > 100000 else 10):
+        t0 = time.time(); m.upload(X); ups.append(time.time() - t0)      # steady state: persistent buffers, pinned staging
+    t_up2 = float(np.median(ups))
+    t0 = time.time(); m.upload(X); m.fit(want_scores=True); t_e2e = time.time() - t0     # what one Plspm() fit pays on the device side
     out = m.fit(want_scores=True)                      # warm-up
     m.profile(True); m.profile_reset()
     t0 = time.time()
@@ -42,7 +47,8 @@ def run(tag, n, C, per, modes, scheme, reps=5):
     line = {"config": tag, "N": n, "P": P, "L": L, "iterations": out["iterations"], "status": out["status"],
             "kernel_ms": {a: round(b, 4) for a, b in ms.items()}, "device_ms_total": round(dev_ms, 4),
             "fit_wall_ms_incl_scores_download": round(wall * 1e3, 3), "fit_wall_ms_no_scores": round(wall_noscores * 1e3, 3),
-            "upload_ms": round(t_up * 1e3, 1), "synth_s": round(t_gen, 1),
+            "upload_first_ms": round(t_up * 1e3, 2), "upload_ms": round(t_up2 * 1e3, 3), "upload_GBps": round(8.0 * n * P / t_up2 / 1e9, 2),
+            "upload_plus_fit_plus_scores_wall_ms": round(t_e2e * 1e3, 3), "synth_s": round(t_gen, 1),
             "algorithmic": {"bytes": a_fit, "flops": f_fit, "GBps_on_device_time": round(a_fit / dev_ms / 1e6, 1),
                             "TFLOPs_on_gram_time": round(float(n) * P * (P + 1) / ms["gram"] / 1e9, 2),
                             "scores_GBps": round((8.0 * n * m.P + 8.0 * n * L) / ms["scores"] / 1e6, 1) if ms["scores"] > 0 else None}}
