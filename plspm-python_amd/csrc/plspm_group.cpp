@@ -10,6 +10,7 @@
 // RCCL is loaded with dlopen on the first group / unique-id call: a process that uses one GPU never maps the 570 MB library.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstring>
@@ -64,6 +65,14 @@ const Rccl* rccl(std::string& why) {
     g_rccl = r;
     return &g_rccl;
 }
+
+// librccl prints an init banner (ROCm version / hostname / library path) on stdout; a host program's stdout is its own (bench.py
+// prints ONE JSON line there), so the banner is sent to stderr for the duration of the communicator set-up.
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+    ~StdoutToStderr() { if (saved >= 0) { fflush(stdout); dup2(saved, 1); close(saved); } }
+};
 
 struct Local {
     plspm_model* m = nullptr;
@@ -155,6 +164,7 @@ int plspm_rccl_unique_id(uint8_t* id) {
     const Rccl* r = rccl(why);
     if (!r) return gfail(nullptr, PLSPM_E_STATE, why);
     ncclUniqueId uid;
+    StdoutToStderr quiet;
     GNCCL(nullptr, r, r->GetUniqueId(&uid));
     memcpy(id, &uid, sizeof(uid));
     return 0;
@@ -217,6 +227,7 @@ plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int3
     if (!r) { delete c; return bad(PLSPM_E_STATE, why); }
     c->comms.assign(n_local, nullptr);
     ncclResult_t rc;
+    StdoutToStderr quiet;
     if (n_local == nranks) {
         rc = r->CommInitAll(c->comms.data(), n_local, c->devices.data());
         if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclCommInitAll: ") + r->GetErrorString(rc)); }

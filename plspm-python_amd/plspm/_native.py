@@ -4,8 +4,10 @@ The library is built in-tree by ``make -C plspm-python_amd/csrc`` (or ``__graft_
 ``plspm/_lib/libplspm_hip.so``.  If it is missing, or no HIP device is visible, the estimator raises
 ``NativeBackendError`` -- there is deliberately no NumPy path behind this module.
 """
+import atexit
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -35,6 +37,21 @@ class _FitResult(ctypes.Structure):
 
 
 _lib = None
+# live native objects, closed in dependency order (groups -> communicators -> handles) by an atexit hook: at interpreter shutdown
+# __del__ runs in arbitrary order and possibly after the HIP / RCCL runtimes have torn themselves down
+_live_models, _live_comms, _live_groups = weakref.WeakSet(), weakref.WeakSet(), weakref.WeakSet()
+
+
+def _shutdown():
+    for pool in (_live_groups, _live_comms, _live_models):
+        for obj in list(pool):
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
+atexit.register(_shutdown)
 
 
 def load():
@@ -167,6 +184,7 @@ class NativeModel:
         self.N = 0
         self.last_B = 0
         self.device_id = int(device_id)
+        _live_models.add(self)
 
     def set_incomplete_rows(self, rows, present, raw_scale=False):
         """Non-metric data with missing values (plspm_model_set_incomplete_rows), after ``upload``: ``rows`` ascending row numbers,
@@ -336,6 +354,7 @@ class NativeComm:
         if not self._h:
             raise NativeBackendError("plspm_comm_create: " + lib.plspm_group_last_error(None).decode())
         self.uses_rccl = bool(lib.plspm_comm_uses_rccl(self._h))
+        _live_comms.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -366,6 +385,7 @@ class NativeGroup:
         self.nranks = lib.plspm_group_size(self._h)
         self.row_width, self.row_stride = self.models[0].row_width, self.models[0].row_stride
         self.last_B = 0
+        _live_groups.add(self)
 
     def _check(self, rc, what):
         if rc:

@@ -69,7 +69,7 @@ class Bootstrap:
             records = parallel.sharded_bootstrap(lambda count, first: native.bootstrap(count, seed, first), iterations, R, comm)
             native.store(records)                                                       # merged records back to HBM for the summary
             self._source = native
-        elif ctx is not None and ctx.world > 1:
+        elif ctx is not None:
             from plspm import _native
             if native.device_id != ctx.local_rank:
                 raise _native.NativeBackendError("the handle lives on device %d but this rank's GPU is %d: pass device_id=LOCAL_RANK"

@@ -1,9 +1,12 @@
 """``Plspm`` -- the user-facing estimator (reference plspm/plspm.py:26-169), MI355X backend.
 
-Same constructor arguments, clamps, assertions and accessors as the reference.  ``processes`` is accepted for
-compatibility (bootstrap replicates run batched on the GPU of this process; with one process per GPU they are
-sharded by ``plspm.parallel``).  Two keyword extensions: ``seed`` (reproducible bootstrap) and ``device_id``.
+Same constructor arguments, clamps, assertions and accessors as the reference.  ``processes`` -- the reference's number of forked
+bootstrap workers (plspm.py:35-37, bootstrap.py:89-94) -- is the number of GPUs of this process the replicates are sharded
+over (capped by the visible devices and by ``parallel.MIN_REPLICATES_PER_GPU`` replicates per GPU; ONE RCCL all-gather merges
+the shards; the rows do not depend on it).  Two keyword extensions: ``seed`` (reproducible bootstrap) and ``device_id``.
 """
+import time
+
 import numpy as np
 import pandas as pd
 
@@ -44,6 +47,7 @@ class Plspm:
                  tolerance: float = 0.000001, bootstrap: bool = False, bootstrap_iterations: int = 100, processes: int = 2,
                  seed: int = None, device_id: int = 0):
         iterations, bootstrap_iterations = _normalise_arguments(scheme, iterations, tolerance, bootstrap_iterations, processes)
+        t_start = time.perf_counter()
         estimator = Estimator(config)
         observations = config.filter(data)
         n_obs = observations.shape[0]
@@ -61,6 +65,7 @@ class Plspm:
         incomplete = [col for col in observations.columns if observations[col].isnull().any()]
         self._unidimensionality = Unidimensionality(model_spec, fit, incomplete)
         self._bootstrap = None
+        t_fit = time.perf_counter()
         if bootstrap:
             if n_obs < 10:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
@@ -68,6 +73,7 @@ class Plspm:
             boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
             self._bootstrap = Bootstrap(model_spec, observations, self._inner_model, self._outer_model, calculator,
                                         bootstrap_iterations, processes, result=boot_on, seed=seed)
+        self._timings = {"fit_s": t_fit - t_start, "bootstrap_s": time.perf_counter() - t_fit}
 
     # ---- accessors (names and return shapes of reference plspm/plspm.py:84-169) -------------------------------
     def scores(self) -> pd.DataFrame:
@@ -112,6 +118,11 @@ class Plspm:
         return self._bootstrap
 
     # --- extension: solver diagnostics -------------------------------------------------------------------
+    def timings(self) -> dict:
+        """Wall seconds of the two phases of the constructor: ``fit_s`` (filter, upload, device fit, result frames) and
+        ``bootstrap_s`` (replicates + device summaries; 0 without bootstrap)."""
+        return dict(self._timings)
+
     def iterations(self) -> int:
         """Value of the reference's iteration counter when the solver stopped (weights.py:179-184)."""
         return self._result.raw["iterations"]
