@@ -118,7 +118,7 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
         int k = 0;
         for (int j = 0; j < L; ++j) k += m->C[l * L + j] ? 1 : 0;
         m->kmax = std::max(m->kmax, k);
-        if (mode[l] == PLSPM_MODE_B) { const int kb = m->boff[l + 1] - m->boff[l]; m->chol_off[l] = m->n_chol; m->n_chol += kb * kb; }
+        if (mode[l] == PLSPM_MODE_B) { const int kb = m->boff[l + 1] - m->boff[l]; m->chol_off[l] = m->n_chol; m->n_chol += (int)chol_block_doubles(kb); }
     }
     m->pred_off.assign(L + 1, 0); m->succ_off.assign(L + 1, 0);
     for (int i = 0; i < L; ++i) {

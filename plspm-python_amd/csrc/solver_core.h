@@ -82,14 +82,19 @@ struct Workspace {
     double* V;                  // [P*L]
     double *Q, *G, *E, *Bm, *Pw, *Pw2, *Ind, *Cs;   // [L*L] each
     double *a, *wf, *sgn, *r2;  // [L] each
-    double* scr;                // [L*(kmax*kmax+kmax)]
-    double* chol;               // [n_chol]
+    double* scr;                // [L*regression_scratch_doubles(kmax)]
+    double* chol;               // [n_chol] = sum over the Mode-B blocks of chol_block_doubles(k)
     double* scal;               // [8]  1 n, 2 1/(n g^2) or 1/n, 3 status
     double* red;                // [16] scratch of the group reductions (Ex::sum / Ex::any), one slot per wave
 };
 
+// per-LV scratch of the small regressions: the k x k normal matrix + k right-hand sides, and a second k x k matrix for the
+// eigenvectors of the minimum-norm fallback (jacobi_pinv)
+PLSPM_HD long regression_scratch_doubles(int kmax) { return 2L * kmax * kmax + kmax; }
+// cached factor of one Mode-B block of k MVs: the k x k factor (Cholesky, or the pseudo-inverse of a rank-deficient block) + k x k scratch
+PLSPM_HD long chol_block_doubles(int k) { return 2L * k * k; }
 PLSPM_HD long workspace_small_doubles(int P, int L, int kmax, int n_chol) {
-    return 7L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * (kmax * kmax + kmax) + n_chol + 8 + 16;
+    return 7L * P + (long)P * L + 8L * L * L + 4L * L + (long)L * regression_scratch_doubles(kmax) + n_chol + 8 + 16;
 }
 PLSPM_HD int cov_ld(int P) { return (P + 1) | 1; }      // S carries the ones row/column P as well (column sums, n)
 PLSPM_HD long cov_doubles(int P) { return (long)(P + 1) * cov_ld(P); }
@@ -101,20 +106,27 @@ PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, i
     ws.Q = p; p += L * L; ws.G = p; p += L * L; ws.E = p; p += L * L; ws.Bm = p; p += L * L;
     ws.Pw = p; p += L * L; ws.Pw2 = p; p += L * L; ws.Ind = p; p += L * L; ws.Cs = p; p += L * L;
     ws.a = p; p += L; ws.wf = p; p += L; ws.sgn = p; p += L; ws.r2 = p; p += L;
-    ws.scr = p; p += (long)L * (kmax * kmax + kmax);
+    ws.scr = p; p += (long)L * regression_scratch_doubles(kmax);
     ws.chol = p; p += n_chol;
     ws.scal = p; p += 8;
     ws.red = p;
 }
 
+// A pivot below PIVOT_RTOL * (its diagonal entry) means the column is a linear combination of the previous ones to working
+// precision: the matrix is treated as rank deficient and the caller switches to the minimum-norm solution, which is what the
+// reference's solvers return there (scipy.linalg.lstsq / gelsd in mode.py:51,58; statsmodels OLS.fit() = pinv in scheme.py:50,
+// inner_model.py:69).  Eigenvalues below EIG_RTOL * (largest eigenvalue) count as zero in that solution.
+#define PLSPM_PIVOT_RTOL 1e-13
+#define PLSPM_EIG_RTOL 1e-12
+
 // In-place Cholesky A = R^T R of a k x k SPD matrix (row-major, ld k, upper part used/overwritten).
-// Returns false when a pivot is not positive (rank-deficient: the reference's pinv/gelsd would return
-// a minimum-norm solution there; the caller flags ST_SINGULAR instead).
+// Returns false at the first pivot that is not safely positive (rank deficient to working precision).
 PLSPM_HD bool chol_factor(double* A, int k) {
     for (int j = 0; j < k; ++j) {
-        double d = A[j * k + j];
+        const double ajj = A[j * k + j];
+        double d = ajj;
         for (int r = 0; r < j; ++r) d -= A[r * k + j] * A[r * k + j];
-        if (!(d > 0.0)) return false;
+        if (!(d > PLSPM_PIVOT_RTOL * ajj)) return false;
         d = sqrt(d);
         A[j * k + j] = d;
         for (int c = j + 1; c < k; ++c) {
@@ -137,6 +149,96 @@ PLSPM_HD void chol_solve(const double* R, int k, double* b) {
         for (int c = i + 1; c < k; ++c) s -= R[i * k + c] * b[c];
         b[i] = s / R[i * k + i];
     }
+}
+
+// Moore-Penrose inverse of a symmetric positive SEMI-definite k x k matrix, in place: cyclic Jacobi eigendecomposition
+// A = V diag(lambda) V^T (V: k x k scratch), then A <- sum_{lambda_i > EIG_RTOL * lambda_max} v_i v_i^T / lambda_i.  A x = b then has
+// the minimum-norm least-squares solution x = A^+ b -- for the normal equations X'X w = X'z exactly the vector LAPACK gelsd /
+// numpy pinv return for min |X w - z| with a rank-deficient X.  One thread; the rare path (k is a block / predecessor count).
+// Returns false when the sweeps do not converge (never observed; the caller flags ST_SINGULAR).
+PLSPM_HD bool jacobi_pinv(double* A, int k, double* V) {
+    for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) V[i * k + j] = (i == j) ? 1.0 : 0.0;
+    bool converged = false;
+    for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < k; ++p) { diag += A[p * k + p] * A[p * k + p]; for (int q = p + 1; q < k; ++q) off += A[p * k + q] * A[p * k + q]; }
+        if (!(off > 1e-36 * diag)) { converged = true; break; }
+        for (int p = 0; p < k - 1; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                const double apq = A[p * k + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * k + q] - A[p * k + p]) / (2.0 * apq);
+                const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int r = 0; r < k; ++r) {                       // A <- A J  (columns p, q)
+                    const double arp = A[r * k + p], arq = A[r * k + q];
+                    A[r * k + p] = c * arp - sn * arq;
+                    A[r * k + q] = sn * arp + c * arq;
+                }
+                for (int r = 0; r < k; ++r) {                       // A <- J^T A (rows p, q)
+                    const double apr = A[p * k + r], aqr = A[q * k + r];
+                    A[p * k + r] = c * apr - sn * aqr;
+                    A[q * k + r] = sn * apr + c * aqr;
+                }
+                for (int r = 0; r < k; ++r) {                       // V <- V J
+                    const double vrp = V[r * k + p], vrq = V[r * k + q];
+                    V[r * k + p] = c * vrp - sn * vrq;
+                    V[r * k + q] = sn * vrp + c * vrq;
+                }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < k; ++i) lmax = (A[i * k + i] > lmax) ? A[i * k + i] : lmax;
+    for (int i = 0; i < k; ++i) {                                    // V[:, i] <- v_i / sqrt(lambda_i), or 0 for a null direction
+        const double l = A[i * k + i];
+        const double f = (l > PLSPM_EIG_RTOL * lmax) ? 1.0 / sqrt(l) : 0.0;
+        for (int r = 0; r < k; ++r) V[r * k + i] *= f;
+    }
+    for (int r = 0; r < k; ++r)                                      // A^+ = (V D^-1/2)(V D^-1/2)^T, both triangles
+        for (int c = r; c < k; ++c) {
+            double s2 = 0.0;
+            for (int i = 0; i < k; ++i) s2 += V[r * k + i] * V[c * k + i];
+            A[r * k + c] = s2;
+            A[c * k + r] = s2;
+        }
+    return converged;
+}
+
+// Cached factor of a Mode-B block (k x k at F, k x k scratch behind it): `fill(F)` writes the full symmetric matrix.  Afterwards
+// F holds either the Cholesky factor (upper triangle) or, for a rank-deficient block, the pseudo-inverse (upper triangle);
+// F[k] -- an entry of the unused strictly lower triangle -- says which (+1 / -1; k == 1 needs no tag).  psd_solve applies it.
+template <class Fill>
+PLSPM_HD bool psd_factor(double* F, int k, Fill fill) {
+    fill(F);
+    if (chol_factor(F, k)) { if (k > 1) F[k] = 1.0; return true; }
+    if (k == 1) return false;                                        // a zero-variance column: nothing to solve for
+    fill(F);
+    const bool ok = jacobi_pinv(F, k, F + (long)k * k);
+    F[k] = -1.0;
+    return ok;
+}
+PLSPM_HD void psd_solve(double* F, int k, double* b) {
+    if (k == 1 || F[k] > 0.0) { chol_solve(F, k, b); return; }
+    double* tmp = F + (long)k * k;                                   // the scratch half is free once the factor exists
+    for (int i = 0; i < k; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += ((i <= j) ? F[i * k + j] : F[j * k + i]) * b[j];
+        tmp[i] = s;
+    }
+    for (int i = 0; i < k; ++i) b[i] = tmp[i];
+}
+
+// One-off solve A x = b (b -> x) of a symmetric PSD k x k system that must stay intact: F is a k x k work copy, V k x k scratch.
+// Cholesky when A is safely positive definite, else the minimum-norm solution.
+PLSPM_HD bool psd_solve_once(const double* A, int k, double* F, double* V, double* b) {
+    for (int e = 0; e < k * k; ++e) F[e] = A[e];
+    if (chol_factor(F, k)) { chol_solve(F, k, b); return true; }
+    if (k == 1) return false;
+    for (int e = 0; e < k * k; ++e) F[e] = A[e];
+    const bool ok = jacobi_pinv(F, k, V);
+    for (int i = 0; i < k; ++i) { double s = 0.0; for (int j = 0; j < k; ++j) s += F[i * k + j] * b[j]; V[i] = s; }
+    for (int i = 0; i < k; ++i) b[i] = V[i];
+    return ok;
 }
 
 // Normal equations  M[idx, idx] x = M[idx, col]  for a short index list (the <= kmax predecessors of an LV), M an
@@ -165,7 +267,7 @@ PLSPM_HD bool spd_solve_fixed(const double* M, int L, const int* idx, int k, int
         double d = A[j][j];
 #pragma unroll
         for (int r = 0; r < j; ++r) d -= A[r][j] * T[r][j];
-        ok = ok && (d > 0.0);
+        ok = ok && (d > PLSPM_PIVOT_RTOL * A[j][j]);
         invd[j] = 1.0 / d;
 #pragma unroll
         for (int c = j + 1; c < K; ++c) {
@@ -196,18 +298,37 @@ PLSPM_HD bool spd_solve_fixed(const double* M, int L, const int* idx, int k, int
     for (int r = 0; r < K; ++r) if (r < k) x[r] = b[r];
     return ok;
 }
-PLSPM_HD bool spd_solve(const double* M, int L, const int* idx, int k, int col, double* x, double* scratch) {
-    if (k <= 2) return spd_solve_fixed<2>(M, L, idx, k, col, x);
-    if (k <= 4) return spd_solve_fixed<4>(M, L, idx, k, col, x);
-    if (k <= 8) return spd_solve_fixed<8>(M, L, idx, k, col, x);
+// Minimum-norm solution of the same normal equations when they are rank deficient (collinear predecessor scores): what
+// statsmodels' OLS.fit() (pinv) returns in scheme.py:50 / inner_model.py:69.  scratch: 2 k^2 doubles.
+PLSPM_HD bool pinv_solve(const double* M, int L, const int* idx, int k, int col, double* x, double* scratch) {
     double* A = scratch;
+    for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) A[r * k + c] = M[idx[r] * L + idx[c]];
+    const bool ok = jacobi_pinv(A, k, scratch + (long)k * k);
     for (int r = 0; r < k; ++r) {
-        for (int c = 0; c < k; ++c) A[r * k + c] = M[idx[r] * L + idx[c]];
-        x[r] = M[idx[r] * L + col];
+        double s = 0.0;
+        for (int c = 0; c < k; ++c) s += A[r * k + c] * M[idx[c] * L + col];
+        x[r] = s;
     }
-    const bool ok = chol_factor(A, k);
-    chol_solve(A, k, x);
     return ok;
+}
+// scratch: regression_scratch_doubles(kmax) doubles (x may be its last kmax entries).
+PLSPM_HD bool spd_solve(const double* M, int L, const int* idx, int k, int col, double* x, double* scratch) {
+    bool ok;
+    if (k <= 2) ok = spd_solve_fixed<2>(M, L, idx, k, col, x);
+    else if (k <= 4) ok = spd_solve_fixed<4>(M, L, idx, k, col, x);
+    else if (k <= 8) ok = spd_solve_fixed<8>(M, L, idx, k, col, x);
+    else {
+        double* A = scratch;
+        for (int r = 0; r < k; ++r) {
+            for (int c = 0; c < k; ++c) A[r * k + c] = M[idx[r] * L + idx[c]];
+            x[r] = M[idx[r] * L + col];
+        }
+        ok = chol_factor(A, k);
+        if (ok) chol_solve(A, k, x);
+    }
+    if (ok) return true;
+    if (k == 1) return false;
+    return pinv_solve(M, L, idx, k, col, x, scratch);
 }
 // sum_{q in [a, b)} S[q*PS + p] * w[q]  with four independent accumulators (the LDS reads of one step overlap)
 PLSPM_HD double dot_col(const double* S, int PS, int p, const double* w, int a, int b) {
@@ -353,11 +474,11 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
         ex.par(L, [&](int i) {
             for (int j = 0; j < L; ++j) ws.E[j * L + i] = 0.0;
             const int km = md.kmax;
-            double* scratch = ws.scr + (long)i * (km * km + km);
+            double* scratch = ws.scr + (long)i * regression_scratch_doubles(km);
             const int* f = md.pred_idx + md.pred_off[i];                    // predecessors of i ("follow", scheme.py:47)
             const int k = md.pred_off[i + 1] - md.pred_off[i];
             if (k > 0) {
-                double* x = scratch + km * km;
+                double* x = scratch + 2 * km * km;
                 if (!spd_solve(Gols, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
                 for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = x[r];
             }
@@ -408,7 +529,7 @@ PLSPM_HD double iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2
         ex.par(L, [&](int l) {                                                     // Mode B: S_bb w = c_b  (mode.py:51)
             if (md.mode[l] == MODE_B) {
                 const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
-                chol_solve(ws.chol + md.chol_off[l], k, ws.wn + b0);
+                psd_solve(ws.chol + md.chol_off[l], k, ws.wn + b0);
             }
         });
     }
@@ -454,9 +575,10 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
         ex.par(L, [&](int l) {
             if (md.mode[l] == MODE_B) {
                 const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
-                double* R = ws.chol + md.chol_off[l];
-                for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) R[r * k + c] = ws.S[(b0 + r) * PS + b0 + c];
-                if (!chol_factor(R, k)) ws.scal[3] = (double)ST_SINGULAR;
+                const bool ok = psd_factor(ws.chol + md.chol_off[l], k, [&](double* R) {
+                    for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) R[r * k + c] = ws.S[(b0 + r) * PS + b0 + c];
+                });
+                if (!ok) ws.scal[3] = (double)ST_SINGULAR;
             }
         });
     }
@@ -492,11 +614,11 @@ PLSPM_HD void inner_model_effects(Ex& ex, const ModelDesc& md, Workspace& ws) {
         for (int j = 0; j < L; ++j) ws.Bm[i * L + j] = 0.0;
         ws.r2[i] = 0.0;
         const int km = md.kmax;
-        double* scratch = ws.scr + (long)i * (km * km + km);
+        double* scratch = ws.scr + (long)i * regression_scratch_doubles(km);
         const int* f = md.pred_idx + md.pred_off[i];
         const int k = md.pred_off[i + 1] - md.pred_off[i];
         if (k > 0) {
-            double* x = scratch + km * km;
+            double* x = scratch + 2 * km * km;
             if (!spd_solve(ws.Cs, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
             double expl = 0.0;
             for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = x[r]; expl += x[r] * ws.Cs[f[r] * L + i]; }
@@ -656,9 +778,10 @@ PLSPM_HD void nm_prepare(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st
         ex.par(L, [&](int l) {
             if (md.mode[l] == MODE_B) {
                 const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
-                double* R = st.chol + md.chol_off[l];
-                for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) R[r * k + c] = ws.S[(b0 + r) * PS + b0 + c];
-                if (!chol_factor(R, k)) st.scal[1] = (double)ST_SINGULAR;
+                const bool ok = psd_factor(st.chol + md.chol_off[l], k, [&](double* R) {
+                    for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) R[r * k + c] = ws.S[(b0 + r) * PS + b0 + c];
+                });
+                if (!ok) st.scal[1] = (double)ST_SINGULAR;
             }
         });
     }
@@ -710,7 +833,7 @@ PLSPM_HD bool nm_step(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, c
     });
     if (md.n_chol > 0) {
         ex.par(L, [&](int l) {                                                    // Mode B: lstsq(X_b, z) = R_bb^-1 u_b (mode.py:58)
-            if (md.mode[l] == MODE_B) { const int b0 = md.boff[l]; chol_solve(st.chol + md.chol_off[l], md.boff[l + 1] - b0, ws.wn + b0); }
+            if (md.mode[l] == MODE_B) { const int b0 = md.boff[l]; psd_solve(st.chol + md.chol_off[l], md.boff[l + 1] - b0, ws.wn + b0); }
         });
     }
     ex.par(P, [&](int p) { const int l = md.lvof[p]; ws.dv[p] = ws.wn[p] * dot_col(ws.S, PS, p, ws.wn, md.boff[l], md.boff[l + 1]); });

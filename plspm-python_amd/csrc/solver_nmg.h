@@ -37,12 +37,12 @@ struct NmgExtra {
     double *mvm;                // [Pm*L + Pm] <MV_p, z_l> raw for the own LV (first Pm) + scratch
     double *cm, *cf, *cs;       // [cmax] category means of z, category frequencies, chosen quantification
     double *inc, *dec, *gsum, *gf;   // [cmax] pooled values of the two directions; pooling scratch (group sums / weights)
-    double *Bm, *Fm, *beta, *rhs;    // [kmv*kmv] block moment matrix and its Cholesky copy, [kmv], [kmv]
+    double *Bm, *Fm, *Vm, *beta, *rhs;   // [kmv*kmv] block moment matrix, its factor copy, eigenvector scratch of the minimum-norm fallback; [kmv], [kmv]
     int* grp;                   // [cmax] (stored in a double-aligned slot)
     double* pq;                 // [Pm * 8 * cmax] per-MV scratch of the parallel quantification (Mode A blocks)
 };
 PLSPM_HD long nmg_extra_doubles(int Q, int Pm, int L, int cmax, int kmv) {
-    return (long)Q + Pm + L + 2L * (Q + 1) * L + (long)L * L + ((long)Pm * L + Pm) + 7L * cmax + 2L * kmv * kmv + 2L * kmv + cmax + 8 + 8L * Pm * cmax;
+    return (long)Q + Pm + L + 2L * (Q + 1) * L + (long)L * L + ((long)Pm * L + Pm) + 7L * cmax + 3L * kmv * kmv + 2L * kmv + cmax + 8 + 8L * Pm * cmax;
 }
 PLSPM_HD void nmg_carve(NmgExtra& x, double* base, int Q, int Pm, int L, int cmax, int kmv) {
     double* p = base;
@@ -51,7 +51,7 @@ PLSPM_HD void nmg_carve(NmgExtra& x, double* base, int Q, int Pm, int L, int cma
     x.mvm = p; p += (long)Pm * L + Pm;
     x.cm = p; p += cmax; x.cf = p; p += cmax; x.cs = p; p += cmax;
     x.inc = p; p += cmax; x.dec = p; p += cmax; x.gsum = p; p += cmax; x.gf = p; p += cmax;
-    x.Bm = p; p += (long)kmv * kmv; x.Fm = p; p += (long)kmv * kmv; x.beta = p; p += kmv; x.rhs = p; p += kmv;
+    x.Bm = p; p += (long)kmv * kmv; x.Fm = p; p += (long)kmv * kmv; x.Vm = p; p += (long)kmv * kmv; x.beta = p; p += kmv; x.rhs = p; p += kmv;
     x.grp = reinterpret_cast<int*>(p); p += cmax + 8;
     x.pq = p;
 }
@@ -282,9 +282,8 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
                 ex.par(k, [&](int r) { x.rhs[r] = nmg_mv_moment(cd, x, p0 + r, x.MZ + l, L, mean_z) - x.mvm[Pm * L + r] * mean_z; });
                 ex.one([&]() {
                     for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) x.Bm[r * k + c] -= x.mvm[Pm * L + r] * x.mvm[Pm * L + c];
-                    if (!chol_factor(x.Bm, k)) st.scal[1] = (double)ST_SINGULAR;
                     for (int r = 0; r < k; ++r) x.beta[r] = x.rhs[r];
-                    chol_solve(x.Bm, k, x.beta);
+                    if (!psd_solve_once(x.Bm, k, x.Fm, x.Vm, x.beta)) st.scal[1] = (double)ST_SINGULAR;       // pinv like sm.OLS(...).fit() (weights.py:141)
                 });
                 have_beta = true;
             }
@@ -327,9 +326,7 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
             ex.one([&]() {
                 // lstsq(X_b, z) without intercept, on raw moments
                 for (int r = 0; r < k; ++r) x.rhs[r] = x.mvm[p0 + r];
-                for (int e = 0; e < k * k; ++e) x.Fm[e] = x.Bm[e];                 // Bm itself is needed for the normalisation below
-                if (!chol_factor(x.Fm, k)) st.scal[1] = (double)ST_SINGULAR;
-                chol_solve(x.Fm, k, x.rhs);
+                if (!psd_solve_once(x.Bm, k, x.Fm, x.Vm, x.rhs)) st.scal[1] = (double)ST_SINGULAR;   // Bm itself is needed for the normalisation below
                 for (int r = 0; r < k; ++r) ws.wn[p0 + r] = x.rhs[r];
             });
         }

@@ -185,13 +185,14 @@ PLSPM_HD void nmx_prepare(Ex& ex, const ModelDesc& md, const MissDesc& xd, Works
         ex.par(L, [&](int l) {
             if (md.mode[l] == MODE_B) {
                 const int b0 = md.boff[l], k = md.boff[l + 1] - b0;
-                double* R = st.chol + md.chol_off[l];
-                for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) {
-                    double s = ws.S[(b0 + r) * PS + b0 + c];
-                    for (int j = 0; j < K; ++j) s += x.ck[j] * inv_n * x.Xh[j * P + b0 + r] * x.Xh[j * P + b0 + c];
-                    R[r * k + c] = s;
-                }
-                if (!chol_factor(R, k)) st.scal[1] = (double)ST_SINGULAR;
+                const bool ok = psd_factor(st.chol + md.chol_off[l], k, [&](double* R) {
+                    for (int r = 0; r < k; ++r) for (int c = 0; c < k; ++c) {
+                        double s = ws.S[(b0 + r) * PS + b0 + c];
+                        for (int j = 0; j < K; ++j) s += x.ck[j] * inv_n * x.Xh[j * P + b0 + r] * x.Xh[j * P + b0 + c];
+                        R[r * k + c] = s;
+                    }
+                });
+                if (!ok) st.scal[1] = (double)ST_SINGULAR;
             }
         });
     }
@@ -269,7 +270,7 @@ PLSPM_HD bool nmx_step(Ex& ex, const ModelDesc& md, const MissDesc& xd, Workspac
     });
     if (md.n_chol > 0) {
         ex.par(L, [&](int l) {                                                     // Mode B: lstsq(X_b, z) on the all-row normal equations (mode.py:58)
-            if (md.mode[l] == MODE_B) { const int b0 = md.boff[l]; chol_solve(st.chol + md.chol_off[l], md.boff[l + 1] - b0, ws.wn + b0); }
+            if (md.mode[l] == MODE_B) { const int b0 = md.boff[l]; psd_solve(st.chol + md.chol_off[l], md.boff[l + 1] - b0, ws.wn + b0); }
         });
     }
     ex.par(P, [&](int p) { st.a_new[p] = ws.wn[p]; });

@@ -432,5 +432,80 @@ def main():
     print("done in %.1f s" % (time.time() - t0))
 
 
+def g14_rank_deficient():
+    """G14: rank-deficient least squares.  (a) Mode-B blocks with a duplicated MV and an MV that is a linear combination of three
+    others -- scipy.linalg.lstsq (gelsd) returns the minimum-norm weights (mode.py:51); (b) two LVs with identical blocks and
+    identical edges, i.e. exactly collinear predecessor scores -- statsmodels' pinv returns equal coefficients in the PATH scheme
+    (scheme.py:50) and in the inner model (inner_model.py:69).  Fits + bootstrap rows on explicit indices."""
+    sat = pd.read_csv(os.path.join(HERE, "ref_data", "satisfaction.csv"), index_col=0)
+    lvs = orc.SAT_LVS
+    Csat = orc.satisfaction_C()
+    prefixes = dict(IMAG="imag", EXPE="expe", QUAL="qual", VAL="val", SAT="sat", LOY="loy")
+    blocks = [[col for col in sat.columns if col.startswith(prefixes[lv])] for lv in lvs]
+    g = {}
+    df = sat.copy()
+    df["imag1dup"] = df["imag1"]
+    df["satlin"] = 0.5 * df["sat1"] - 2.0 * df["sat2"] + df["sat3"]
+    ba = [list(b) for b in blocks]
+    ba[0].append("imag1dup"); ba[4].append("satlin")
+    cols_a = [n for b in ba for n in b]
+    g["a/X"] = df[cols_a].values.astype(float)
+    g["a/block_sizes"] = np.array([len(b) for b in ba])
+    rs = np.random.RandomState(1414)
+    g["idx"] = rs.randint(250, size=(4, 250)).astype(np.int32)
+    for modes_name, modes in (("B", "BBBBBB"), ("M", "BABABA")):
+        for scheme in SCHEMES:
+            for scaled in (False, True):
+                cfg = build_config(Csat, lvs, ba, modes, scaled)
+                m, out = run_fit(df, cfg, scheme, lvs)
+                key = "a_%s_%s_%d" % (modes_name, scheme, int(scaled))
+                assert list(out.pop("mv_names")) == cols_a
+                for k, v in out.items():
+                    g[key + "/" + k] = v
+                if scheme == "path" or (modes_name == "B" and scheme == "centroid" and scaled):
+                    rows, its = boot_rows(df, cfg, scheme, lvs, list(g["idx"]), list(m.effects().index))
+                    g[key + "/boot_rows"] = rows
+                    g[key + "/boot_iters"] = its
+    # (b) EXPE2 = a clone of EXPE (same columns under new names, same edges)
+    lv7 = ["IMAG", "EXPE", "EXPE2", "QUAL", "VAL", "SAT", "LOY"]
+    edges = [("IMAG", "EXPE"), ("IMAG", "EXPE2"), ("IMAG", "SAT"), ("IMAG", "LOY"), ("EXPE", "QUAL"), ("EXPE", "VAL"), ("EXPE", "SAT"),
+             ("EXPE2", "QUAL"), ("EXPE2", "VAL"), ("EXPE2", "SAT"), ("QUAL", "VAL"), ("QUAL", "SAT"), ("VAL", "SAT"), ("SAT", "LOY")]
+    C7 = np.zeros((7, 7), dtype=int)
+    for frm, to in edges:
+        C7[lv7.index(to), lv7.index(frm)] = 1
+    dfb = sat.copy()
+    bb = []
+    for lv in lv7:
+        if lv == "EXPE2":
+            names = []
+            for col in blocks[1]:
+                dfb[col + "x"] = dfb[col]
+                names.append(col + "x")
+            bb.append(names)
+        else:
+            bb.append(list(blocks[lvs.index(lv)]))
+    cols_b = [n for b in bb for n in b]
+    g["b/X"] = dfb[cols_b].values.astype(float)
+    g["b/block_sizes"] = np.array([len(b) for b in bb])
+    g["b/C"] = C7
+    for modes_name, modes in (("A", "AAAAAAA"), ("B", "BBBBBBB")):
+        for scheme in SCHEMES:
+            cfg = build_config(C7, lv7, bb, modes, True)
+            m, out = run_fit(dfb, cfg, scheme, lv7)
+            key = "b_%s_%s" % (modes_name, scheme)
+            assert list(out.pop("mv_names")) == cols_b
+            for k, v in out.items():
+                g[key + "/" + k] = v
+            if scheme == "path":
+                rows, its = boot_rows(dfb, cfg, scheme, lv7, list(g["idx"][:2]), list(m.effects().index))
+                g[key + "/boot_rows"] = rows
+                g[key + "/boot_iters"] = its
+    save("g14_rank_deficient", **g)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14_rank_deficient()
+    else:
+        main()
+        g14_rank_deficient()

@@ -65,7 +65,7 @@ struct EmuModel {
             int k = 0;
             for (int j = 0; j < L; ++j) k += C[l * L + j] ? 1 : 0;
             kmax = k > kmax ? k : kmax;
-            if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += kb * kb; }
+            if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += (int)chol_block_doubles(kb); }
         }
         for (int i = 0; i < L; ++i) {
             for (int j = 0; j < L; ++j) if (C[i * L + j]) pred_idx.push_back(j);
@@ -211,7 +211,7 @@ int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, do
         int k = 0;
         for (int j = 0; j < L; ++j) k += C[l * L + j] ? 1 : 0;
         kmax = k > kmax ? k : kmax;
-        if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += kb * kb; }
+        if (mode[l] == MODE_B) { int kb = boff[l + 1] - boff[l]; chol_off[l] = n_chol; n_chol += (int)chol_block_doubles(kb); }
     }
     std::vector<int> pred_off(L + 1, 0), pred_idx, succ_off(L + 1, 0), succ_idx;
     for (int i = 0; i < L; ++i) {

@@ -210,9 +210,37 @@ def test_sign_rule_and_status_codes():
     hard = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=2, tol=1e-30)
     _, g = gpu_fit(X, hard)
     assert g["status"] == 1 and g["iterations"] == 3
-    Xd = X.copy(); Xd[:, blocks[2][1]] = Xd[:, blocks[2][0]]
-    _, g = gpu_fit(Xd, orc.Model(blocks, orc.satisfaction_C(), "BBBBBB", "centroid", True))
-    assert g["status"] == 2
+    Xd = X.copy(); Xd[:, blocks[2][1]] = 3.0                      # a constant MV: flagged, never silently returned
+    _, g = gpu_fit(Xd, orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True))
+    assert g["status"] in (2, 3)
+
+
+G14_CASES = [("a", "B", "centroid", 1), ("a", "B", "path", 0), ("a", "B", "path", 1), ("a", "M", "factorial", 1), ("a", "M", "path", 0),
+             ("b", "A", "path", 1), ("b", "B", "path", 1), ("b", "A", "centroid", 1), ("b", "B", "factorial", 1)]
+
+
+@pytest.mark.parametrize("which,modes,scheme,scaled", G14_CASES)
+def test_rank_deficient_least_squares_match_the_reference_minimum_norm(which, modes, scheme, scaled):
+    """Golden g14 (made from the real reference): Mode-B blocks with a duplicated / linearly dependent MV (scipy lstsq = gelsd,
+    mode.py:51) and exactly collinear predecessor scores (statsmodels pinv, scheme.py:50, inner_model.py:69).  The device falls
+    back from Cholesky to the eigen-truncated pseudo-inverse for the flagged regression only -- fit and bootstrap replicates."""
+    from test_oracle_golden import g14_case
+    gold = load("g14_rank_deficient")
+    X, blocks, C = g14_case(gold, which)
+    L = len(blocks)
+    model = orc.Model(blocks, C, case_modes(modes, L, mixed="BABABA"), scheme, bool(scaled))
+    nm, g = gpu_fit(X, model)
+    check_fit(g, orc.fit(X, model), "g14 " + which)
+    key = "a_%s_%s_%d" % (modes, scheme, scaled) if which == "a" else "b_%s_%s" % (modes, scheme)
+    assert g["iterations"] == int(gold[key + "/iters"])
+    assert_close(g["weights_d"], gold[key + "/weights"], RTOL, what=key)
+    assert_close(g["path_coef"], gold[key + "/path_coef"], RTOL, ATOL, what=key)
+    assert_close(g["scores"], gold[key + "/scores"], 1e-7, 1e-9, what=key)
+    if key + "/boot_rows" in gold.files:
+        n_idx = len(gold[key + "/boot_rows"])
+        rows, status, iters = nm.bootstrap(n_idx, idx=gold["idx"][:n_idx])
+        assert np.all(status == 0) and np.array_equal(iters, gold[key + "/boot_iters"])
+        assert_close(rows, gold[key + "/boot_rows"], RTOL, 1e-10, what=key + " bootstrap rows")
 
 
 def test_bootstrap_full_size_properties():

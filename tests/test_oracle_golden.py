@@ -442,3 +442,52 @@ def test_reference_csv_russa_missing():
     assert_close(comm, summ.loc[lv, "block_communality"].values, 1e-7)
     with pytest.raises(Exception):
         orc.fit(X, orc.Model(RUSSA_M_BLOCKS, RUSSA_C, "BAA", "centroid", True, tol=1e-7, scales=["NUM"] * 9))
+
+
+# ---------------------------------------------------------------------------------------------- rank-deficient least squares
+def g14_case(g, which):
+    """(X, blocks, C) of golden g14: 'a' = Mode-B blocks with a duplicated / linearly dependent MV, 'b' = a cloned LV."""
+    X = g[which + "/X"]
+    sizes = g[which + "/block_sizes"]
+    offs = np.concatenate(([0], np.cumsum(sizes)))
+    blocks = [np.arange(offs[i], offs[i + 1]) for i in range(len(sizes))]
+    C = orc.satisfaction_C() if which == "a" else g["b/C"]
+    return X, blocks, C
+
+
+G14_A = [("a_%s_%s_%d" % (m, s, sc), m, s, sc) for m in ("B", "M") for s in SCHEMES for sc in (0, 1)]
+G14_B = [("b_%s_%s" % (m, s), m, s) for m in ("A", "B") for s in SCHEMES]
+
+
+@pytest.mark.parametrize("key,modes,scheme,scaled", G14_A)
+def test_g14_rank_deficient_mode_b_blocks_minimum_norm(key, modes, scheme, scaled):
+    """scipy.linalg.lstsq (gelsd) gives the minimum-norm weights on a collinear Mode-B block (mode.py:51): the duplicated MV
+    shares its weight equally with its twin."""
+    g = load("g14_rank_deficient")
+    X, blocks, C = g14_case(g, "a")
+    model = orc.Model(blocks, C, case_modes(modes, mixed="BABABA"), scheme, bool(scaled))
+    r = orc.fit(X, model)
+    _check_fit(r, g, key)
+    assert abs(r["weights"][0] - r["weights"][5]) < 1e-12 * abs(r["weights"]).max()      # imag1 and its duplicate
+    if key + "/boot_rows" in g.files:
+        for idx, row, it in zip(g["idx"], g[key + "/boot_rows"], g[key + "/boot_iters"]):
+            mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(250))
+            assert its == int(it)
+            assert_close(mine, row, RTOL, 1e-12, what=key)
+
+
+@pytest.mark.parametrize("key,modes,scheme", G14_B)
+def test_g14_collinear_predecessor_scores_minimum_norm(key, modes, scheme):
+    """Two LVs with identical blocks and edges have identical scores: statsmodels' pinv gives both the same coefficient in the PATH
+    scheme's regression (scheme.py:50) and in the inner model (inner_model.py:69)."""
+    g = load("g14_rank_deficient")
+    X, blocks, C = g14_case(g, "b")
+    model = orc.Model(blocks, C, modes * 7, scheme, True)
+    r = orc.fit(X, model)
+    _check_fit(r, g, key)
+    assert abs(r["path_coef"][5, 1] - r["path_coef"][5, 2]) < 1e-10
+    if key + "/boot_rows" in g.files:
+        for idx, row, it in zip(g["idx"][:2], g[key + "/boot_rows"], g[key + "/boot_iters"]):
+            mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(250))
+            assert its == int(it)
+            assert_close(mine, row, RTOL, 1e-11, what=key)

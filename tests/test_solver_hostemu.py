@@ -159,11 +159,41 @@ def test_not_converged_status(emu):
         orc.fit(X, model)
 
 
-def test_singular_block_flagged(emu):
+@pytest.mark.parametrize("which,modes,scheme,scaled", [("a", "BBBBBB", "centroid", True), ("a", "BBBBBB", "path", False), ("a", "BABABA", "factorial", True),
+                                                       ("b", "AAAAAAA", "path", True), ("b", "BBBBBBB", "path", True), ("b", "AAAAAAA", "centroid", True)])
+def test_rank_deficient_least_squares_minimum_norm(emu, which, modes, scheme, scaled):
+    """Collinear Mode-B blocks (duplicated / linearly dependent MV) and exactly collinear predecessor scores (a cloned LV): the device
+    solver falls back from Cholesky to the eigen-truncated pseudo-inverse (solver_core.h jacobi_pinv) and lands on the minimum-norm
+    solution the reference's gelsd / pinv return (golden g14, made from the real reference) -- fit and weighted (bootstrap) problems."""
+    from helpers import load
+    from test_oracle_golden import g14_case
+    g = load("g14_rank_deficient")
+    X, blocks, C = g14_case(g, which)
+    model = orc.Model(blocks, C, modes, scheme, scaled)
+    e = run_emu(emu, X, model)
+    check(e, orc.fit(X, model), which + modes + scheme)
+    key = ("a_%s_%s_%d" % ("B" if modes == "BBBBBB" else "M", scheme, int(scaled))) if which == "a" else "b_%s_%s" % (modes[0], scheme)
+    assert e["iterations"] == int(g[key + "/iters"])
+    assert_close(e["weights"], g[key + "/weights"], RTOL, what=key)                     # straight against the reference's numbers
+    assert_close(e["path_coef"], g[key + "/path_coef"], RTOL, 1e-12, what=key)
+    if which == "a":
+        assert abs(e["weights"][0] - e["weights"][5]) < 1e-12                           # the duplicated MV shares its weight with its twin
+    else:
+        assert abs(e["path_coef"][5, 1] - e["path_coef"][5, 2]) < 1e-10                 # the clone shares its coefficient
+    if key + "/boot_rows" in g.files:
+        idx = g["idx"][0]
+        w = run_emu(emu, X, model, counts=np.bincount(idx, minlength=250), shift=X[:, model.mv_order].mean(axis=0))
+        assert w["status"] == 0 and w["iterations"] == int(g[key + "/boot_iters"][0])
+        P, L, ne = X.shape[1], model.L, len(w["pairs"])
+        mine = np.concatenate((w["weights"], w["r2"], w["total"], w["direct"], w["loadings"]))
+        assert_close(mine, g[key + "/boot_rows"][0], RTOL, 1e-11, what=key + " bootstrap row")
+
+
+def test_zero_variance_column_flagged(emu):
     X, blocks, _ = satisfaction_oracle_inputs()
-    X = X.copy(); X[:, blocks[2][1]] = X[:, blocks[2][0]]            # duplicate MV inside a Mode-B block
-    model = orc.Model(blocks, orc.satisfaction_C(), "BBBBBB", "centroid", True)
-    assert run_emu(emu, X, model)["status"] == 2
+    X = X.copy(); X[:, blocks[2][1]] = 3.0                            # a constant MV: nothing a least-squares solver can weigh
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True)
+    assert run_emu(emu, X, model)["status"] in (2, 3)
 
 
 def test_thread_sanitizer_clean():

@@ -47,7 +47,7 @@ class NmProblem:
         self.C = np.ascontiguousarray(np.asarray(C).astype(np.uint8))
         self.mode = np.array([0 if m == "A" else 1 for m in modes], dtype=np.int32)
         self.shift = np.zeros(P)
-        n_chol = int(sum((self.boff[l + 1] - self.boff[l]) ** 2 for l in range(self.L) if self.mode[l] == 1))
+        n_chol = int(sum(2 * (self.boff[l + 1] - self.boff[l]) ** 2 for l in range(self.L) if self.mode[l] == 1))
         self.S = np.zeros(lib.hostemu_cov_doubles(P))
         self.state = np.zeros(lib.hostemu_nm_state_doubles(P, self.L, n_chol))
         self.args = (P, self.L, padded_width(P), SCHEME_ID[scheme], max_iter, ctypes.c_double(tol), _ptr(self.boff, I32), _ptr(self.C, ctypes.c_ubyte),

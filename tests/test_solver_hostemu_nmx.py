@@ -65,7 +65,7 @@ def run_nmx_emu(lib, Xnan, model, counts=None, nthreads=4, nparts=3):
     boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
     C = np.ascontiguousarray(model.C.astype(np.uint8))
     mode = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
-    n_chol = int(sum((boff[l + 1] - boff[l]) ** 2 for l in range(L) if mode[l] == 1))
+    n_chol = int(sum(2 * (boff[l + 1] - boff[l]) ** 2 for l in range(L) if mode[l] == 1))
     S = np.zeros(lib.hostemu_cov_doubles(P))
     head = lib.hostemu_nm_state_doubles(P, L, n_chol)
     state = np.zeros(lib.hostemu_nmx_state_doubles(P, L, n_chol, K))

@@ -43,7 +43,7 @@ def run_nm_emu(lib, X, model, counts=None, shift=None, nthreads=4, nparts=5):
     boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
     C = np.ascontiguousarray(model.C.astype(np.uint8))
     mode = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
-    n_chol = int(sum((boff[l + 1] - boff[l]) ** 2 for l in range(L) if mode[l] == 1))
+    n_chol = int(sum(2 * (boff[l + 1] - boff[l]) ** 2 for l in range(L) if mode[l] == 1))
     S = np.zeros(lib.hostemu_cov_doubles(P))
     state = np.zeros(lib.hostemu_nm_state_doubles(P, L, n_chol))
     args = (P, L, PA, SCHEME_ID[model.scheme], model.max_iter, ctypes.c_double(model.tol), _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte),
