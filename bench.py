@@ -104,7 +104,7 @@ def api_inclusive(X, reps, pairs=7):
         for lv in lvs:
             cfg.add_lv_with_columns_named(lv, Mode.A, frame, lv.lower())
         return cfg
-    diffs, fits, boots, inner = [], [], [], []
+    diffs, fits, boots, inner, tails = [], [], [], [], []
     for k in range(pairs + 1):
         t0 = time.perf_counter()
         Plspm(frame, config(), Scheme.PATH)
@@ -112,16 +112,37 @@ def api_inclusive(X, reps, pairs=7):
         m = Plspm(frame, config(), Scheme.PATH, bootstrap=True, bootstrap_iterations=reps, processes=1, seed=1)
         t2 = time.perf_counter()
         if k:                                        # the first pair warms the code objects
-            fits.append(t1 - t0); boots.append(t2 - t1); diffs.append((t2 - t1) - (t1 - t0)); inner.append(m.timings()["bootstrap_s"])
+            fits.append(t1 - t0); boots.append(t2 - t1); diffs.append((t2 - t1) - (t1 - t0)); inner.append(m.timings()["bootstrap_latency_s"]); tails.append(m.timings()["bootstrap_s"])
         used = m.bootstrap().used()
-    d = float(np.median(inner))
-    return {"value": round(reps / d, 1), "unit": "replicates/s", "bootstrap_ms": round(d * 1e3, 3),
-            "paired_difference_ms": round(float(np.median(diffs)) * 1e3, 3),
+    # the same work with nothing to hide under: a fresh handle per call (create, upload, fit -- as Plspm does), then enqueue -> sync ->
+    # device summary, each host-synchronised
+    from plspm import _native
+    C = synthetic.satisfaction_C()
+    boff = np.arange(0, 61, 10).astype(np.int32)
+    alone, keep = [], None
+    for k in range(pairs + 2):
+        h = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, 0)
+        h.upload(X)
+        h.fit(want_scores=True, want_cov=True)
+        t0 = time.perf_counter()
+        h.bootstrap_device(reps, seed=1)
+        h.summary(reps, np.ones(h.row_width))
+        alone.append(time.perf_counter() - t0)
+        keep = h                                     # the previous handle stays alive while the next one is built, as in the loop above
+    standalone = float(np.median(alone[2:]))
+    diff = float(np.median(diffs))
+    bound = max(diff, standalone)
+    return {"value": round(reps / bound, 1), "unit": "replicates/s",
+            "standalone_ms": round(standalone * 1e3, 3), "paired_difference_ms": round(diff * 1e3, 3),
+            "bootstrap_tail_ms": round(float(np.median(tails)) * 1e3, 3), "bootstrap_latency_ms": round(float(np.median(inner)) * 1e3, 3),
             "plspm_fit_wall_ms": round(float(np.median(fits)) * 1e3, 3), "plspm_fit_plus_bootstrap_wall_ms": round(float(np.median(boots)) * 1e3, 3),
             "replicates_used": int(used),
-            "note": "bootstrap_ms = median wall of the bootstrap phase inside Plspm(bootstrap=True, bootstrap_iterations=%d) (Plspm.timings(): replicates + device "
-                    "summaries, host-synchronised); paired_difference_ms = median of [that call's wall] - [Plspm() wall] over %d pairs (two ~20 ms "
-                    "walls: noisy); frames built lazily, rows left in HBM" % (reps, pairs)}
+            "note": "Plspm(bootstrap=True, bootstrap_iterations=%d) enqueues the replicates before it builds its pandas result frames, so the call costs "
+                    "only paired_difference_ms more than Plspm() without bootstrap (median over %d pairs; bootstrap_tail_ms = what it still waits for "
+                    "after the frames, bootstrap_latency_ms = enqueue -> summaries on the host with the frame building in between).  value is NOT taken "
+                    "from that hidden figure: it is replicates / max(paired_difference_ms, standalone_ms), standalone_ms = the same bootstrap on a fresh "
+                    "handle with nothing to overlap (enqueue -> kernels -> device summaries -> %d x 6 table on the host); rows stay in HBM, frames are "
+                    "built on access" % (reps, pairs, 156)}
 
 
 def main():

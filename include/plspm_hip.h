@@ -56,6 +56,10 @@ int plspm_abi_version(void);
 /* Number of HIP devices visible to the process (0 when there is none; never negative). */
 int plspm_device_count(void);
 
+/* The library keeps freed device / pinned-host blocks for re-use (a Plspm() call creates, fills and destroys a handle; without the
+ * cache that is ~40 allocator round trips per call).  This hands every cached block back to the HIP runtime. */
+int plspm_release_cached_memory(void);
+
 /* Text of the last error on this handle (or of the last failed plspm_model_create when NULL). */
 const char* plspm_last_error(const plspm_model_t* m);
 
@@ -68,6 +72,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "wide_nw"         4 | 8 | 16          waves sharing one row walk in gram_wide_kernel<14>
  *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
  *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
+ *   "scores_tile"     0 (by LDS footprint) | 16 | 32   rows per tile of the scores kernel
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 
@@ -306,6 +311,21 @@ int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* it
  * wait; max = all-reduce(max) of one double over the ranks. */
 int plspm_group_barrier(plspm_group_t* g);
 int plspm_group_max(plspm_group_t* g, double* value);
+
+/*
+ * ---- Operator seam ------------------------------------------------------------------------------------------------------------
+ * The reference's strategy objects, callable on their own; each call uploads its operands, forms their moment
+ * matrix with the MFMA Gram kernel and finishes in one small kernel (csrc/solver_ops.h).  Errors: plspm_last_error(NULL).
+ *   plspm_op_inner_weights  Scheme.X.value.calculate(path, y)            plspm/scheme.py:27-28, 36-37, 45-54
+ *       scheme PLSPM_SCHEME_*; path [L*L] row-major 0/1 strictly lower triangular; y [N*L] row-major LV scores; E [L*L] row-major:
+ *       centroid sign(corrcoef(y) * (path + path')), factorial cov1(y) * (path + path'), path: OLS coefficients (no intercept,
+ *       minimum norm) of every LV on its predecessors / correlations with its successors, column i = LV i
+ *   plspm_op_outer_weights  Mode.X.value.outer_weights_metric(data, Z, lv, mvs)   plspm/mode.py:28-29, 50-52
+ *       Xk [N*k] row-major: the block's (treated) MVs; z [N]: the LV's inner estimate; w [k]:
+ *       Mode A  X_k' z / N;  Mode B  least squares of z on X_k (minimum norm when X_k is rank deficient, as scipy.linalg.lstsq)
+ */
+int plspm_op_inner_weights(int32_t device_id, int32_t scheme, int32_t L, const uint8_t* path, const double* y, int64_t N, double* E);
+int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, const double* z, int64_t N, int32_t k, double* w);
 
 /* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);

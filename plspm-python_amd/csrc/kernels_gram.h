@@ -6,7 +6,9 @@
 // v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; for the
 // Gram both are the SAME element xa[row_k][col_t(l&15)] (A additionally times the multiplicity), so one 16-byte
 // load per 32 columns feeds two tiles: lane (k, i) reads columns 32*g + 2i, 2i+1 of row k -> tile 2g holds the even
-// columns of group g, tile 2g+1 the odd ones (packed_tile_of / packed_pos_of in solver_core.h).
+// columns of group g, tile 2g+1 the odd ones (packed_tile_of / packed_pos_of in solver_core.h).  An odd tile count T (16-column
+// granularity of the padded width: 201 columns -> 13 tiles = 91 MFMAs per k-group instead of 14 tiles = 105) leaves the last
+// tile without a partner: lane (k, i) loads its single column 16(T-1) + i with an 8-byte load.
 // Lane l ends up with D[(l>>4) + 4*reg][l&15] in acc[reg].
 //
 // Software pipeline.  hipcc de-pipelines a C++ prefetch here (it re-issues the loop-carried loads next to their
@@ -56,28 +58,39 @@ struct RowLoader<G, G> {
     static __device__ __forceinline__ void issue(dv2 (&)[G], const double*) {}
     static __device__ __forceinline__ void pin(dv2 (&)[G]) {}
 };
+// Odd tile counts: the last tile has no partner; lane (k, i) loads its single column 16(T-1) + i of row k with an 8-byte load.
+__device__ __forceinline__ void issue_tail(double& t, const double* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(t) : "v"(p) : "memory"); }
 __device__ __forceinline__ void issue_entry(iv2& e, const int2* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(e) : "v"(p) : "memory"); }
 
 // One pipeline stage (see above).  DENSE: rows are consecutive (single fit), no (row,count) list.
 template <int T, int NW, int W, bool DENSE>
-__device__ __forceinline__ void gram_stage(AccArr<T, NW, W>& acc, RowArr<T>& Vcur, RowArr<T>& Vnext, iv2& Enext, iv2& Eafter, double cnt,
-                                           const double* xbase, const int2* eptr_after, long dense_row_next) {
+__device__ __forceinline__ void gram_stage(AccArr<T, NW, W>& acc, RowArr<T>& Vcur, RowArr<T>& Vnext, double& Tcur, double& Tnext, iv2& Enext, iv2& Eafter, double cnt,
+                                           const double* xbase, const double* tbase, const int2* eptr_after, long dense_row_next) {
     constexpr int G = T / 2, PA = 16 * T;
+    constexpr bool ODD = (T & 1) != 0;
 #pragma unroll
     for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
     if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Enext)::"memory");
     RowLoader<0, G>::pin(Vcur);
+    if (ODD) asm volatile("" : "+v"(Tcur));
     double x[T];
 #pragma unroll
     for (int q = 0; q < G; ++q) { x[2 * q] = Vcur[q].x; x[2 * q + 1] = Vcur[q].y; }
+    if (ODD) x[T - 1] = Tcur;
     const long rnext = DENSE ? dense_row_next : (long)Enext.x;
     RowLoader<0, G>::issue(Vnext, xbase + rnext * PA);
+    if (ODD) issue_tail(Tnext, tbase + rnext * PA);
     if (!DENSE) issue_entry(Eafter, eptr_after);
-    asm volatile("" : "+v"(cnt));          // every MFMA operand below depends on cnt: none is scheduled above the loads
+    // every MFMA operand below depends on a value pinned AFTER the loads were issued: none is scheduled above them.  DENSE rows
+    // need no multiplicity (rows past the end are redirected to the all-zero pad row behind the matrix): A and B are the same register.
+    if (DENSE) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) asm volatile("" : "+v"(x[t]));
+    } else asm volatile("" : "+v"(cnt));
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const double a = cnt * x[t];
+        const double a = DENSE ? x[t] : cnt * x[t];
 #pragma unroll
         for (int u = t; u < T; ++u) {
             const int li = TileIdx<T>::of(t, u);
@@ -94,42 +107,50 @@ __device__ __forceinline__ void gram_walk(AccArr<T, NW, W>& acc, const double* _
     constexpr int G = T / 2, PA = 16 * T;
     const int k = lane >> 4, i = lane & 15;
     const double* xbase = Xa + 2 * i;
+    const double* tbase = Xa + 32 * G + i;           // odd T: the partner-less last tile
+    constexpr bool ODD = (T & 1) != 0;
     const int2* ek = e + k;
     const int niter = (g0 < ng) ? (ng - g0 + gs - 1) / gs : 0;
     const int last = ng - 1;
     auto gof = [&](int it) { const int g = g0 + it * gs; return g < last ? g : last; };
     auto eaddr = [&](int it) { return ek + 4 * (long)gof(it); };
-    auto drow = [&](int it) { const long r = 4 * (long)gof(it) + k; return r < N ? r : N - 1; };
-    auto dcnt = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? 1 : 0; };
+    // dense walk: row N is the all-zero pad row plspm_upload keeps behind the matrix -- stages past the end and the rows >= N of the
+    // last k-group read it instead of being masked by a multiplicity
+    auto drow = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? r : N; };
+    auto dcnt = [&](int) { return 1; };
 #pragma unroll
     for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }
     iv2 EA = {0, 0}, EB = {0, 0};
     dv2 VA[G], VB[G];
+    double TA = 0.0, TB = 0.0;
 #pragma unroll
     for (int q = 0; q < G; ++q) { VA[q] = (dv2){0.0, 0.0}; VB[q] = (dv2){0.0, 0.0}; }
     int cA;
     if (DENSE) {
         RowLoader<0, G>::issue(VA, xbase + drow(0) * PA);
+        if (ODD) issue_tail(TA, tbase + drow(0) * PA);
         cA = dcnt(0);
     } else {
         issue_entry(EA, eaddr(0));
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA)::"memory");
         RowLoader<0, G>::issue(VA, xbase + (long)EA.x * PA);
+        if (ODD) issue_tail(TA, tbase + (long)EA.x * PA);
         cA = (niter > 0) ? EA.y : 0;
         issue_entry(EB, eaddr(1));
     }
     for (int it = 0; it < niter; it += 2) {
         // stage A: consume VA; prefetch VB <- rows(it+1), EA <- entry(it+2)
-        gram_stage<T, NW, W, DENSE>(acc, VA, VB, EB, EA, (double)cA, xbase, DENSE ? nullptr : eaddr(it + 2), DENSE ? drow(it + 1) : 0);
+        gram_stage<T, NW, W, DENSE>(acc, VA, VB, TA, TB, EB, EA, (double)cA, xbase, tbase, DENSE ? nullptr : eaddr(it + 2), DENSE ? drow(it + 1) : 0);
         const int cB = DENSE ? dcnt(it + 1) : ((it + 1 < niter) ? EB.y : 0);
         // stage B: consume VB; prefetch VA <- rows(it+2), EB <- entry(it+3)
-        gram_stage<T, NW, W, DENSE>(acc, VB, VA, EA, EB, (double)cB, xbase, DENSE ? nullptr : eaddr(it + 3), DENSE ? drow(it + 2) : 0);
+        gram_stage<T, NW, W, DENSE>(acc, VB, VA, TB, TA, EA, EB, (double)cB, xbase, tbase, DENSE ? nullptr : eaddr(it + 3), DENSE ? drow(it + 2) : 0);
         cA = DENSE ? dcnt(it + 2) : EA.y;
     }
     if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(EA), "+v"(EB)::"memory");
     RowLoader<0, G>::pin(VA);
     RowLoader<0, G>::pin(VB);
+    if (ODD) asm volatile("" : "+v"(TA), "+v"(TB));
 #pragma unroll
     for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
 }
@@ -265,10 +286,14 @@ __device__ __forceinline__ void block_stage(d4 (&acc)[16], dv2 (&Rc)[2], dv2 (&C
     issue_pair(Rn, rbase + rnext * PA, r1off);
     issue_pair(Cn, cbase + rnext * PA, c1off);
     if (!DENSE) issue_entry(Eafter, eptr_after);
-    asm volatile("" : "+v"(cnt));
+    double xa[4] = {xr[0], xr[1], xr[2], xr[3]};
+    if (DENSE) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) asm volatile("" : "+v"(xa[ti]));
+    } else asm volatile("" : "+v"(cnt));
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-        const double a = cnt * xr[ti];
+        const double a = DENSE ? xa[ti] : cnt * xr[ti];
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
             if (valid & (1u << (ti * 4 + tj))) acc[ti * 4 + tj] = MFMA_F64(a, xc[tj], acc[ti * 4 + tj]);      // wave-uniform mask: scalar branch
@@ -304,8 +329,8 @@ __global__ void __launch_bounds__(256) gram_block_kernel(const double* __restric
     const int r1off = ((2 * bi + 1) < T / 2) ? 32 : 0, c1off = ((2 * bj + 1) < T / 2) ? 32 : 0;
     auto gof = [&](int it) { const int g = g0 + it * gs; return g < last ? g : last; };
     auto eaddr = [&](int it) { return e + 4 * (long)gof(it); };
-    auto drow = [&](int it) { const long r = 4 * (long)gof(it) + k; return r < N ? r : N - 1; };
-    auto dcnt = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? 1 : 0; };
+    auto drow = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? r : N; };      // N: the all-zero pad row
+    auto dcnt = [&](int) { return 1; };
     d4 acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }

@@ -167,3 +167,27 @@ __global__ void __launch_bounds__(64) hoc_compose_kernel(HocDesc hd, const doubl
 
 
 #define SCORE_ROWS 16
+
+
+// ------------------------------------------------------------------------------------------------ operator seam (solver_ops.h)
+// One workgroup: descriptors + the small workspace in LDS (the handle's "MVs" are the L score columns).
+__global__ void __launch_bounds__(256) op_inner_kernel(ModelDesc md, const double* __restrict__ Mp, double* __restrict__ E_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = nullptr;
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    stage_descriptors(md, lp);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    op_inner_weights(ex, md, ws, Mp, E_out);
+}
+// scratch: [A k*k | F k*k | V k*k | flag] in global memory (a block may have up to 1020 MVs)
+__global__ void __launch_bounds__(256) op_outer_kernel(int mode, int k, int T, const double* __restrict__ Mp, const double* __restrict__ shift, double* scratch,
+                                                        double* __restrict__ w_out) {
+    __shared__ double red[16];
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, red, nullptr};
+    const long kk = (long)k * k;
+    op_outer_weights(ex, mode, k, T, Mp, shift, scratch, scratch + kk, scratch + 2 * kk, w_out, scratch + 3 * kk);
+}

@@ -12,6 +12,20 @@
 
 inline thread_local std::string g_create_error;
 
+// Caching allocator of the library (defined in plspm_hip.hip).  A Plspm() call creates a handle, uploads, fits and destroys it:
+// without a cache every call pays ~40 hipMalloc / hipHostMalloc / hipFree round trips (measured 12 of the 17 ms of a 10k x 60
+// Plspm() fit).  Freed blocks are kept per device (and for pinned host memory) and handed out again best-fit; a block is only
+// ever returned by an owner whose stream has been synchronised, so a cached block has no work in flight.
+// plspm_release_cached_memory() (C-ABI) gives everything back to the runtime.
+hipError_t plspm_dmalloc(void** p, size_t bytes);       // device memory on the CURRENT device
+void plspm_dfree(void* p);
+hipError_t plspm_hmalloc(void** p, size_t bytes);       // pinned host memory
+void plspm_hfree(void* p);
+// Streams are cached the same way (hipStreamCreate / hipStreamDestroy set up and tear down a hardware queue: ~1-2 ms each):
+// a stream goes back only after it has been synchronised.  Non-blocking streams of the CURRENT device.
+hipError_t plspm_stream_acquire(hipStream_t* s);
+void plspm_stream_release(hipStream_t s);
+
 // Kernel timing (plspm_profile_*): event pairs are recycled through `pool`, so a profiled launch costs two hipEventRecord only.
 struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev, pool; double total_ms = 0.0; int64_t launches = 0; };
 
@@ -68,7 +82,7 @@ struct plspm_model {
     Buf xa, up_raw, up_ci, up_partial;   // resident matrix (d_Xa points into `xa` while data are uploaded) and the upload staging
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
-    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128; } tune;
+    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0; } tune;
     // grow-only pinned host staging for uploads / row downloads (two halves: copy-in of chunk k+1 overlaps the DMA of chunk k)
     void* h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -101,9 +115,9 @@ inline int fail(plspm_model* m, int code, const std::string& msg) {
 
 inline int ensure(plspm_model* m, plspm_model::Buf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
-    if (b.p) HIPCHK(m, hipFree(b.p));
+    if (b.p) { HIPCHK(m, hipStreamSynchronize(m->stream)); plspm_dfree(b.p); }     // nothing of this handle may still be using the old block
     b.p = nullptr; b.cap = 0;
-    HIPCHK(m, hipMalloc(&b.p, bytes));
+    HIPCHK(m, plspm_dmalloc(&b.p, bytes));
     b.cap = bytes;
     return 0;
 }

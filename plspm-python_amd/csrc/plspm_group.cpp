@@ -134,9 +134,9 @@ void shard_of(int64_t B, int nranks, int rank, int64_t* first, int64_t* count) {
 
 int grow(plspm_group* g, Local& l, plspm_model::Buf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
-    if (b.p) GHIP(g, hipFree(b.p));
+    if (b.p) plspm_dfree(b.p);                     // (the caller synchronised every stream of the group)
     b.p = nullptr; b.cap = 0;
-    GHIP(g, hipMalloc(&b.p, bytes));
+    GHIP(g, plspm_dmalloc(&b.p, bytes));
     b.cap = bytes;
     return 0;
 }
@@ -180,14 +180,14 @@ void plspm_group_destroy(plspm_group_t* g) {
     for (auto& l : g->loc) {
         hipSetDevice(l.m->device);
         for (int s = 0; s < 2; ++s) {
-            if (l.send[s].p) hipFree(l.send[s].p);
-            if (l.recv[s].p) hipFree(l.recv[s].p);
+            if (l.send[s].p) plspm_dfree(l.send[s].p);
+            if (l.recv[s].p) plspm_dfree(l.recv[s].p);
             if (l.computed[s]) hipEventDestroy(l.computed[s]);
             if (l.gathered[s]) hipEventDestroy(l.gathered[s]);
         }
-        if (l.d_word) hipFree(l.d_word);
-        if (l.h_word) hipHostFree(l.h_word);
-        if (l.cstream) hipStreamDestroy(l.cstream);
+        if (l.d_word) plspm_dfree(l.d_word);
+        if (l.h_word) plspm_hfree(l.h_word);
+        if (l.cstream) plspm_stream_release(l.cstream);
         l.m->group = nullptr;
     }
     if (g->comm && g->comm->bound == g) g->comm->bound = nullptr;
@@ -269,11 +269,11 @@ plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models)
     auto bail = [&](const std::string& why) { plspm_group_destroy(g); g_group_create_error = why; return (plspm_group_t*)nullptr; };
     for (auto& l : g->loc) {
         l.m->group = g;
-        if (hipSetDevice(l.m->device) != hipSuccess || hipStreamCreateWithFlags(&l.cstream, hipStreamNonBlocking) != hipSuccess) return bail("gather stream creation failed");
+        if (hipSetDevice(l.m->device) != hipSuccess || plspm_stream_acquire(&l.cstream) != hipSuccess) return bail("gather stream creation failed");
         for (int s = 0; s < 2; ++s)
             if (hipEventCreateWithFlags(&l.computed[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.gathered[s], hipEventDisableTiming) != hipSuccess)
                 return bail("event creation failed");
-        if (hipMalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || hipHostMalloc((void**)&l.h_word, 64, hipHostMallocDefault) != hipSuccess)
+        if (plspm_dmalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || plspm_hmalloc((void**)&l.h_word, 64) != hipSuccess)
             return bail("scratch allocation failed");
     }
     c->bound = g;

@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +25,7 @@
 #include "solver_nmg.h"
 #include "solver_hoc.h"
 #include "solver_nmx.h"
+#include "solver_ops.h"
 
 using namespace plspm;
 
@@ -36,6 +40,124 @@ __host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a
 
 // ================================================================================================ host side
 #include "model.h"
+
+// ------------------------------------------------------------------------------------------------ caching allocator (model.h)
+namespace {
+struct MemPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> idle[17];                  // [device], 16 = pinned host
+    std::unordered_map<void*, std::pair<int, size_t>> live; // block -> (pool index, capacity)
+    size_t idle_bytes[17] = {};
+};
+MemPool& pool() { static MemPool* p = new MemPool(); return *p; }      // leaked on purpose: must outlive every static destructor
+constexpr size_t kPoolKeepPerDevice = (size_t)8 << 30, kPoolMaxBlock = (size_t)1 << 30, kPoolKeepHost = (size_t)1 << 30;
+// size classes of 12.5 % (a re-fit of a slightly larger data set still finds its blocks), 256-byte granularity below 2 KiB
+size_t size_class(size_t bytes) {
+    if (bytes <= 2048) return (bytes + 255) & ~(size_t)255;
+    int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (lg - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+hipError_t pool_get(int idx, size_t bytes, void** out) {
+    const size_t want = size_class(std::max<size_t>(bytes, 1));
+    MemPool& P = pool();
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        auto it = P.idle[idx].lower_bound(want);
+        if (it != P.idle[idx].end() && it->first <= want + want / 4) {
+            *out = it->second;
+            P.live[*out] = {idx, it->first};
+            P.idle_bytes[idx] -= it->first;
+            P.idle[idx].erase(it);
+            return hipSuccess;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = (idx == 16) ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (e != hipSuccess) {                                  // give the cache back to the runtime and try once more
+        plspm_release_cached_memory();
+        e = (idx == 16) ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.live[p] = {idx, want};
+    *out = p;
+    return hipSuccess;
+}
+void pool_put(void* p) {
+    if (!p) return;
+    MemPool& P = pool();
+    int idx; size_t cap;
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        auto it = P.live.find(p);
+        if (it == P.live.end()) return;                     // not ours
+        idx = it->second.first; cap = it->second.second;
+        P.live.erase(it);
+        const size_t keep = (idx == 16) ? kPoolKeepHost : kPoolKeepPerDevice;
+        if (cap <= kPoolMaxBlock && P.idle_bytes[idx] + cap <= keep) {
+            P.idle[idx].emplace(cap, p);
+            P.idle_bytes[idx] += cap;
+            return;
+        }
+    }
+    if (idx == 16) (void)hipHostFree(p); else (void)hipFree(p);          // hipFree works from any current device
+}
+}  // namespace
+
+hipError_t plspm_dmalloc(void** p, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipMalloc(p, bytes);
+    return pool_get(dev, bytes, p);
+}
+void plspm_dfree(void* p) { pool_put(p); }
+hipError_t plspm_hmalloc(void** p, size_t bytes) { return pool_get(16, bytes, p); }
+void plspm_hfree(void* p) { pool_put(p); }
+
+namespace {
+struct StreamPool { std::mutex mu; std::vector<hipStream_t> idle[16]; std::unordered_map<hipStream_t, int> live; };
+StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }
+}  // namespace
+hipError_t plspm_stream_acquire(hipStream_t* s) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    StreamPool& P = stream_pool();
+    if (dev >= 0 && dev < 16) {
+        std::lock_guard<std::mutex> lock(P.mu);
+        if (!P.idle[dev].empty()) { *s = P.idle[dev].back(); P.idle[dev].pop_back(); P.live[*s] = dev; return hipSuccess; }
+    }
+    e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (e == hipSuccess && dev >= 0 && dev < 16) { std::lock_guard<std::mutex> lock(P.mu); P.live[*s] = dev; }
+    return e;
+}
+void plspm_stream_release(hipStream_t s) {
+    if (!s) return;
+    StreamPool& P = stream_pool();
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        auto it = P.live.find(s);
+        if (it != P.live.end()) {
+            const int dev = it->second;
+            P.live.erase(it);
+            if (P.idle[dev].size() < 32) { P.idle[dev].push_back(s); return; }
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+
+extern "C" int plspm_release_cached_memory(void) {
+    MemPool& P = pool();
+    std::vector<std::pair<int, void*>> victims;
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        for (int i = 0; i < 17; ++i) { for (auto& kv : P.idle[i]) victims.emplace_back(i, kv.second); P.idle[i].clear(); P.idle_bytes[i] = 0; }
+    }
+    for (auto& v : victims) { if (v.first == 16) (void)hipHostFree(v.second); else (void)hipFree(v.second); }
+    return 0;
+}
 
 static ModelDesc make_desc(const plspm_model* m) {
     ModelDesc md{};
@@ -58,18 +180,33 @@ static HocDesc make_hoc_desc(const plspm_model* m2) {
     return hd;
 }
 
+// Padded width of the resident matrix [columns | 1 | 0-pad] and its tile count.  Pairs of 16-column tiles (32-column groups, one
+// 16-byte load per lane) by default; METRIC models whose width leaves the last group half empty run an odd tile count on the
+// gram_wide kernels (5 <= T <= 15): P + 1 = 201 columns -> 13 tiles instead of 14, i.e. 91 instead of 105 MFMAs per k-group and
+// 7 % fewer bytes per row for every streaming pass.  The non-metric kernels (tiled copies, stop-rule passes) keep whole groups.
+static int tiles_for(const plspm_model* m, int cols) {
+    const int t16 = (cols + 1 + 15) / 16;
+    const bool odd_ok = !m->nonmetric && (t16 & 1) && t16 >= 5 && t16 <= 15;
+    return odd_ok ? t16 : 2 * ((cols + 1 + 31) / 32);
+}
+// T / PA: the Gram of the uploaded columns (Pg = data + missing-indicator columns); Ts / PAs: the P-column matrix the solver reads.
+static void set_geometry(plspm_model* m) {
+    m->T = tiles_for(m, m->Pg); m->PA = 16 * m->T;
+    m->Ts = tiles_for(m, m->P); m->PAs = 16 * m->Ts;
+}
+
 // Side tables of plspm_model_set_incomplete_rows: freed (and nulled) on every re-upload and on a failed set call.
 static void drop_incomplete_rows(plspm_model* m) {
-    if (m->d_Xk) hipFree(m->d_Xk);
-    if (m->d_Mk) hipFree(m->d_Mk);
-    if (m->d_rowid) hipFree(m->d_rowid);
+    if (m->d_Xk) plspm_dfree(m->d_Xk);
+    if (m->d_Mk) plspm_dfree(m->d_Mk);
+    if (m->d_rowid) plspm_dfree(m->d_rowid);
     m->d_Xk = m->d_Mk = nullptr; m->d_rowid = nullptr; m->nmx_K = 0;
 }
 
 template <class Tv>
 static int upload_vec(plspm_model* m, Tv** dst, const std::vector<Tv>& v) {
     const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(Tv);
-    HIPCHK(m, hipMalloc((void**)dst, bytes));
+    HIPCHK(m, plspm_dmalloc((void**)dst, bytes));
     if (!v.empty()) HIPCHK(m, hipMemcpy(*dst, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice));
     return 0;
 }
@@ -107,8 +244,8 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
     plspm_model* m = new (std::nothrow) plspm_model();
     if (!m) { fail(nullptr, PLSPM_E_STATE, "out of host memory"); return nullptr; }
     m->device = device_id; m->P = P; m->L = L; m->scheme = scheme; m->scaled = scaled ? 1 : 0; m->max_iter = max_iter; m->tol = tol;
-    m->PA = ((P + 1 + 31) / 32) * 32; m->T = m->PA / 16;
-    m->Pg = P; m->PAs = m->PA; m->Ts = m->T;
+    m->Pg = P;
+    set_geometry(m);
     m->boff.assign(block_offset, block_offset + L + 1);
     m->mode.assign(mode, mode + L);
     m->C.assign(path, path + (size_t)L * L);
@@ -137,14 +274,14 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
 
     auto bail = [&](const std::string& why) { g_create_error = why + (m->error.empty() ? "" : (": " + m->error)); plspm_model_destroy(m); return (plspm_model_t*)nullptr; };
     if (hipSetDevice(device_id) != hipSuccess) return bail("hipSetDevice failed");
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate failed");
+    if (plspm_stream_acquire(&m->stream) != hipSuccess) return bail("hipStreamCreate failed");
     if (upload_vec(m, &m->d_boff, m->boff) || upload_vec(m, &m->d_lvof, m->lvof) || upload_vec(m, &m->d_mode, m->mode) ||
         upload_vec(m, &m->d_chol_off, m->chol_off) || upload_vec(m, &m->d_eff_from, m->eff_from) || upload_vec(m, &m->d_eff_to, m->eff_to) ||
         upload_vec(m, &m->d_C, m->C) || upload_vec(m, &m->d_pred_off, m->pred_off) || upload_vec(m, &m->d_pred_idx, m->pred_idx) ||
         upload_vec(m, &m->d_succ_off, m->succ_off) || upload_vec(m, &m->d_succ_idx, m->succ_idx))
         return bail("descriptor upload failed");
-    if (hipMalloc((void**)&m->d_shift, sizeof(double) * P) != hipSuccess) return bail("hipMalloc failed");
-    if (hipHostMalloc((void**)&m->h_flag, 64, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&m->ev_flag, hipEventDisableTiming) != hipSuccess)
+    if (plspm_dmalloc((void**)&m->d_shift, sizeof(double) * P) != hipSuccess) return bail("hipMalloc failed");
+    if (plspm_hmalloc((void**)&m->h_flag, 64) != hipSuccess || hipEventCreateWithFlags(&m->ev_flag, hipEventDisableTiming) != hipSuccess)
         return bail("pinned flag / event creation failed");
     return m;
 }
@@ -160,14 +297,14 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
-    for (void* p : ptrs) if (p) hipFree(p);
-    if (m->h_stage) hipHostFree(m->h_stage);
-    if (m->h_pin) hipHostFree(m->h_pin);
+    for (void* p : ptrs) if (p) plspm_dfree(p);
+    if (m->h_stage) plspm_hfree(m->h_stage);
+    if (m->h_pin) plspm_hfree(m->h_pin);
     for (int k = 0; k < 2; ++k) if (m->ev_pin[k]) hipEventDestroy(m->ev_pin[k]);
     for (int k = 0; k < PLSPM_K_COUNT; ++k) for (auto& pr : m->prof[k].pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    if (m->h_flag) hipHostFree(m->h_flag);
+    if (m->h_flag) plspm_hfree(m->h_flag);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
-    if (m->stream && m->owns_stream) hipStreamDestroy(m->stream);
+    if (m->stream && m->owns_stream) plspm_stream_release(m->stream);       // (synchronised above)
     delete m;
 }
 
@@ -205,7 +342,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     if ((rc = ensure(m, m->up_raw, raw_bytes))) return rc;
     if ((rc = ensure(m, m->up_ci, sizeof(int) * (size_t)Pg))) return rc;
     if ((rc = ensure(m, m->up_partial, sizeof(double) * (size_t)nblk * Pg))) return rc;
-    if ((rc = ensure(m, m->xa, (size_t)N * m->PA * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->xa, (size_t)(N + 1) * m->PA * sizeof(double)))) return rc;       // + one all-zero pad row (dense Gram walks read it past the end)
     double* d_raw = (double*)m->up_raw.p;
     int* d_ci = (int*)m->up_ci.p;
     double* d_partial = (double*)m->up_partial.p;
@@ -230,14 +367,15 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
             const int grid = (int)std::min<long>(4096, (total + 255) / 256);
             hipLaunchKernelGGL(pack_rowmajor_kernel, dim3(grid), dim3(256), 0, m->stream, d_raw, (long)N, (int)src_cols, d_ci, Pg, m->PA, m->d_shift, d_Xa);
         } else {
-            hipLaunchKernelGGL(pack_colmajor_kernel, dim3((unsigned)((N + 63) / 64), m->PA / 32), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, Pg, m->PA,
+            hipLaunchKernelGGL(pack_colmajor_kernel, dim3((unsigned)((N + 63) / 64), (m->PA + 31) / 32), dim3(256), 0, m->stream, d_raw, (long)N, d_ci, Pg, m->PA,
                                m->d_shift, d_Xa);
         }
     }
+    HIPCHK(m, hipMemsetAsync(d_Xa + (size_t)N * m->PA, 0, (size_t)m->PA * sizeof(double), m->stream));
     HIPCHK(m, hipGetLastError());
     HIPCHK(m, hipStreamSynchronize(m->stream));          // X may be released by the caller on return
     if (raw_bytes > ((size_t)1 << 30)) {                 // do not keep a multi-GB staging copy alive next to the resident matrix
-        HIPCHK(m, hipFree(m->up_raw.p));
+        plspm_dfree(m->up_raw.p);
         m->up_raw.p = nullptr; m->up_raw.cap = 0;
     }
     m->d_Xa = d_Xa;
@@ -264,7 +402,13 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
     switch (m->T) {
         case 2: ROWS(2) break;
         case 4: ROWS(4) break;
+        case 5: WIDE(5, 4, 4) break;
         case 6: WIDE(6, 4, 4) break;
+        case 7: WIDE(7, 4, 4) break;
+        case 9: WIDE(9, 4, 4) break;
+        case 11: WIDE(11, 4, 4) break;
+        case 13: WIDE(13, 4, 4) break;
+        case 15: WIDE(15, 4, 4) break;
         case 8: WIDE(8, 4, 4) break;
         case 10: WIDE(10, 4, 4) break;
         case 12: WIDE(12, 4, 4) break;
@@ -330,6 +474,35 @@ static int launch_solver(plspm_model* m, long nproblems, const double* Mp, long 
     return 0;
 }
 
+
+// Moment matrix of ALL uploaded rows (single fit, operator seam): the dense MFMA Gram split over row chunks + the fixed-order
+// reduce -> m->gram (tile-packed, of the shifted columns + ones).
+static int dense_moments(plspm_model* m) {
+    const long N = m->N;
+    const long psize = packed_size(m->T);
+    const long ng = (N + 3) / 4;
+    // row chunks (workgroups) of the dense Gram: enough k-groups per wave to amortise the pipeline prologue; at most two workgroups
+    // per CU for the rows kernel (every wave holds all tiles), ONE for the tile-split kernels (a wave per SIMD already fills the
+    // register file; measured on 1M x 200: 256 chunks 0.941 + reduce 0.027 ms, 512: 0.939 + 0.063, 1024: 0.954 + 0.132)
+    const int waves_per_wg = (m->T <= 4) ? 4 : 1;
+    const long per_wave = 16;
+    const long max_chunks = (m->T <= 4) ? 512 : 256;
+    const int nchunks = m->tune.fit_chunks > 0 ? m->tune.fit_chunks : (int)std::max<long>(1, std::min<long>(max_chunks, (ng + waves_per_wg * per_wave - 1) / (waves_per_wg * per_wave)));
+    int rc;
+    if ((rc = ensure(m, m->gram_partial, (size_t)nchunks * psize * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
+    {
+        ProfScope ps(m, PLSPM_K_GRAM);
+        if ((rc = launch_gram<true>(m, 1, nchunks, nullptr, nullptr, 0, (double*)m->gram_partial.p))) return rc;
+    }
+    {
+        ProfScope ps(m, PLSPM_K_REDUCE);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((psize + 255) / 256)), dim3(256), 0, m->stream, (const double*)m->gram_partial.p, nchunks, psize,
+                           (double*)m->gram.p);
+    }
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
 
 // Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
 // finish.  The host only reads one counter per iteration (how many problems are still active).
@@ -462,7 +635,9 @@ extern "C" {
 
 int plspm_model_set_nonmetric(plspm_model_t* m, int32_t on) {
     if (!m) return PLSPM_E_ARG;
+    if (m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_model_set_nonmetric: call before plspm_upload");
     m->nonmetric = on ? 1 : 0;
+    set_geometry(m);                       // the non-metric kernels keep whole 32-column groups
     return 0;
 }
 
@@ -477,6 +652,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "fit_chunks") { if (value < 0 || value > 65535) return bad(); m->tune.fit_chunks = value; }
     else if (k == "wide_nw") { if (value != 4 && value != 8 && value != 16) return bad(); m->tune.wide_nw = value; }
     else if (k == "conv_pass") { if (value < 0 || value > 2) return bad(); m->tune.conv_pass = value; }
+    else if (k == "scores_tile") { if (value != 0 && value != 16 && value != 32) return bad(); m->tune.scores_tile = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
@@ -509,6 +685,7 @@ int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_
         upload_vec(m, &m->d_mv_lv, m->mv_lv) || upload_vec(m, &m->d_no_chol, m->no_chol))
         return fail(m, PLSPM_E_STATE, "descriptor upload failed");
     m->Pm = Pm; m->categorical = 1; m->nonmetric = 1; m->n_chol = 0;
+    set_geometry(m);
     for (auto& c : m->chol_off) c = -1;
     HIPCHK(m, hipMemcpy(m->d_chol_off, m->chol_off.data(), sizeof(int) * m->L, hipMemcpyHostToDevice));
     return 0;
@@ -531,10 +708,10 @@ int plspm_model_set_missing(plspm_model_t* m, int32_t n_ind, const int32_t* ind_
     m->ind_of.assign(ind_of, ind_of + m->P);
     if (upload_vec(m, &m->d_ind_of, m->ind_of)) return fail(m, PLSPM_E_STATE, "descriptor upload failed");
     m->n_ind = n_ind; m->Pg = m->P + n_ind;
-    m->PA = ((m->Pg + 1 + 31) / 32) * 32; m->T = m->PA / 16;
-    HIPCHK(m, hipFree(m->d_shift));
+    set_geometry(m);
+    plspm_dfree(m->d_shift);
     m->d_shift = nullptr;
-    HIPCHK(m, hipMalloc((void**)&m->d_shift, sizeof(double) * m->Pg));
+    HIPCHK(m, plspm_dmalloc((void**)&m->d_shift, sizeof(double) * m->Pg));
     return 0;
 }
 
@@ -567,7 +744,7 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
         return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
     HIPCHK(m1, hipMemset(m2->d_shift, 0, sizeof(double) * m2->P));
     HIPCHK(m1, hipStreamSynchronize(m2->stream));
-    HIPCHK(m1, hipStreamDestroy(m2->stream));
+    plspm_stream_release(m2->stream);
     m2->stream = m1->stream; m2->owns_stream = false;
     m1->stage2 = m2; m2->stage1 = m1;
     return 0;
@@ -593,12 +770,12 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
     unsigned char* d_mask = nullptr;
     const size_t cells = (size_t)K * m->P;
     // any failure below leaves the handle as it was before the call: no side tables, nmx_K == 0
-#define NMXCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { if (d_mask) hipFree(d_mask); drop_incomplete_rows(m); \
+#define NMXCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { if (d_mask) plspm_dfree(d_mask); drop_incomplete_rows(m); \
         return fail(m, -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
-    NMXCHK(hipMalloc((void**)&m->d_Xk, cells * sizeof(double)));
-    NMXCHK(hipMalloc((void**)&m->d_Mk, cells * sizeof(double)));
-    NMXCHK(hipMalloc((void**)&m->d_rowid, (size_t)K * sizeof(int)));
-    NMXCHK(hipMalloc((void**)&d_mask, cells));
+    NMXCHK(plspm_dmalloc((void**)&m->d_Xk, cells * sizeof(double)));
+    NMXCHK(plspm_dmalloc((void**)&m->d_Mk, cells * sizeof(double)));
+    NMXCHK(plspm_dmalloc((void**)&m->d_rowid, (size_t)K * sizeof(int)));
+    NMXCHK(plspm_dmalloc((void**)&d_mask, cells));
     NMXCHK(hipMemcpyAsync(m->d_rowid, row_index, (size_t)K * sizeof(int), hipMemcpyHostToDevice, m->stream));
     NMXCHK(hipMemcpyAsync(d_mask, present, cells, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(extract_rows_kernel, dim3((unsigned)K), dim3(256), 0, m->stream, m->d_Xa, m->PA, m->P, (const int*)m->d_rowid, (const unsigned char*)d_mask, m->d_Xk,
@@ -606,7 +783,7 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
     NMXCHK(hipGetLastError());
     NMXCHK(hipStreamSynchronize(m->stream));
 #undef NMXCHK
-    hipFree(d_mask);
+    plspm_dfree(d_mask);
     m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false;
     return 0;
 }
@@ -625,15 +802,7 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     const int P = m->P, L = m->L, ne = m->n_eff;
     const long N = m->N;
     const long psize = packed_size(m->T);
-    const long ng = (N + 3) / 4;
-    // row chunks (workgroups) of the dense Gram: enough k-groups per wave to amortise the pipeline prologue, and at most
-    // ~2 workgroups per CU so the fixed-order reduce stays small
-    const int waves_per_wg = (m->T <= 4) ? 4 : 1;
-    const long per_wave = 16;
-    const int nchunks = m->tune.fit_chunks > 0 ? m->tune.fit_chunks : (int)std::max<long>(1, std::min<long>(512, (ng + waves_per_wg * per_wave - 1) / (waves_per_wg * per_wave)));
     int rc;
-    if ((rc = ensure(m, m->gram_partial, (size_t)nchunks * psize * sizeof(double)))) return rc;
-    if ((rc = ensure(m, m->gram, (size_t)psize * sizeof(double)))) return rc;
     // device-side result block
     const long o_w = 0, o_ld = o_w + P, o_cl = o_ld + P, o_pc = o_cl + (long)P * L, o_r2 = o_pc + (long)L * L, o_lc = o_r2 + L,
                o_row = o_lc + (long)L * L, o_ind = o_row + (2L * P + L + 2L * ne + 2), o_sw = o_ind + std::max(ne, 1), o_sc = o_sw + P, o_mean = o_sc + L,
@@ -643,15 +812,7 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     double* d = (double*)m->fitout.p;
     int* d_int = (int*)(d + o_end);           // [0] iters, [1] status
     int8_t* d_sign = (int8_t*)(d_int + 4);
-    {
-        ProfScope ps(m, PLSPM_K_GRAM);
-        if ((rc = launch_gram<true>(m, 1, nchunks, nullptr, nullptr, 0, (double*)m->gram_partial.p))) return rc;
-    }
-    {
-        ProfScope ps(m, PLSPM_K_REDUCE);
-        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((psize + 255) / 256)), dim3(256), 0, m->stream, (const double*)m->gram_partial.p, nchunks, psize,
-                           (double*)m->gram.p);
-    }
+    if ((rc = dense_moments(m))) return rc;
     SolverOut so{};
     so.row = d + o_row; so.row_stride = 0; so.status = d_int + 1; so.iters = d_int;
     so.fit.weights = d + o_w; so.fit.loadings = d + o_ld; so.fit.crossloadings = d + o_cl; so.fit.path_coef = d + o_pc; so.fit.r2 = d + o_r2;
@@ -667,11 +828,23 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     }
     if (out->scores) {
         if ((rc = ensure(m, m->scores, (size_t)N * L * sizeof(double)))) return rc;
-        const size_t lds = ((size_t)SCORE_ROWS * (m->PA + 1) + P + SCORE_ROWS * (size_t)L) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
-        if ((rc = allow_lds(m, (const void*)scores_kernel, lds))) return rc;
-        const int grid = (int)std::min<long>(256 * 8, (N + SCORE_ROWS - 1) / SCORE_ROWS);
+        // tile rows: 32 while two workgroups of them fit one CU's LDS, else 16 (wide models; option "scores_tile" overrides);
+        // chunk count per thread selects the prefetching instantiation (PA <= 256), wider matrices take the plain one
+        auto lds_of = [&](int tr) { return ((size_t)tr * (m->PA + 1) + P + L + (size_t)tr * L) * sizeof(double) + (size_t)(L + 2) * sizeof(int); };
+        const bool tr32 = m->tune.scores_tile ? (m->tune.scores_tile == 32) : (lds_of(32) <= 72 * 1024);
+        const int TRows = tr32 ? 32 : 16;
+        const size_t lds = lds_of(TRows);
+        const int nch = (m->PA / 2 + 15) / 16;
+        typedef void (*ScoresFn)(const double*, long, int, int, int, const int*, const double*, const double*, double*);
+        ScoresFn fn;
+        if (tr32) fn = nch <= 2 ? scores_kernel<32, 2> : nch <= 4 ? scores_kernel<32, 4> : nch <= 6 ? scores_kernel<32, 6> : nch <= 8 ? scores_kernel<32, 8> : scores_kernel<32, 0>;
+        else fn = nch <= 2 ? scores_kernel<16, 2> : nch <= 4 ? scores_kernel<16, 4> : nch <= 6 ? scores_kernel<16, 6> : nch <= 8 ? scores_kernel<16, 8> : scores_kernel<16, 0>;
+        if ((rc = allow_lds(m, (const void*)fn, lds))) return rc;
+        const long ntl = (N + TRows - 1) / TRows;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, kMaxLds / lds));
+        const int grid = (int)std::min<long>(256L * per_cu, ntl);         // resident workgroups only: each walks its tiles with the prefetch running
         ProfScope ps(m, PLSPM_K_SCORES);
-        hipLaunchKernelGGL(scores_kernel, dim3(grid), dim3(256), lds, m->stream, m->d_Xa, N, m->PA, P, L, m->d_boff, d + o_sw, d + o_sc, (double*)m->scores.p);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, m->stream, (const double*)m->d_Xa, N, m->PA, P, L, (const int*)m->d_boff, (const double*)(d + o_sw), (const double*)(d + o_sc), (double*)m->scores.p);
         if (m->nmx_K) {                                     // the incomplete rows' scores are not affine in the columns: take them from the state
             const double* Yn = (const double*)m->nmstate.p + nm_state_doubles(P, L, m->n_chol) + m->nmx_K + 2L * P + (long)m->nmx_K * P + (long)m->nmx_K * L;
             hipLaunchKernelGGL(patch_scores_kernel, dim3((unsigned)m->nmx_K), dim3(64), 0, m->stream, (double*)m->scores.p, L, (const int*)m->d_rowid, Yn);
@@ -686,9 +859,9 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     const bool stage_scores = score_bytes > 0 && score_bytes <= ((size_t)8 << 20);      // small score matrices ride the pinned buffer too
     const size_t stage_need = fit_bytes + (stage_scores ? score_bytes : 0);
     if (m->h_stage_cap < stage_need) {
-        if (m->h_stage) HIPCHK(m, hipHostFree(m->h_stage));
+        if (m->h_stage) plspm_hfree(m->h_stage);
         m->h_stage = nullptr; m->h_stage_cap = 0;
-        HIPCHK(m, hipHostMalloc(&m->h_stage, stage_need, hipHostMallocDefault));
+        HIPCHK(m, plspm_hmalloc(&m->h_stage, stage_need));
         m->h_stage_cap = stage_need;
     }
     char* hs = (char*)m->h_stage;
@@ -802,7 +975,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         }
 #ifdef PLSPM_DEBUG_MARKS      // phase clocks of one solver problem (tools/gpu_marks.sh builds with -DPLSPM_DEBUG_MARKS); never in the release library
         long long* d_marks = nullptr;
-        HIPCHK(m, hipMalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks;
+        HIPCHK(m, plspm_dmalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks;
 #endif
         const double* Mp; long mp_stride;
         if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
@@ -819,7 +992,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             fprintf(stderr, "[plspm cov] sweep %lld  scale-factor %lld  centre+sd %lld\n", h[14] - h[0], h[15] - h[14], h[1] - h[15]);
             fprintf(stderr, "[plspm last iterate] apply_cov %lld  a+G %lld  inner_weights %lld  outer %lld  conv+copy %lld\n", h[9] - h[8], h[10] - h[9],
                     h[11] - h[10], h[12] - h[11], h[13] - h[12]);
-            HIPCHK(m, hipFree(d_marks));
+            plspm_dfree(d_marks);
         }
 #endif
     }
@@ -902,7 +1075,7 @@ int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int
 static constexpr size_t kPinHalf = (size_t)8 << 20;       // two halves: the host copy of chunk k+1 overlaps the DMA of chunk k
 static int pin_ready(plspm_model* m) {
     if (m->h_pin) return 0;
-    HIPCHK(m, hipHostMalloc(&m->h_pin, 2 * kPinHalf, hipHostMallocDefault));
+    HIPCHK(m, plspm_hmalloc(&m->h_pin, 2 * kPinHalf));
     m->h_pin_cap = 2 * kPinHalf;
     for (int k = 0; k < 2; ++k) HIPCHK(m, hipEventCreateWithFlags(&m->ev_pin[k], hipEventDisableTiming));
     return 0;
@@ -959,8 +1132,7 @@ int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t 
     HIPCHK(m, hipSetDevice(m->device));
     const int R = plspm_row_width(m);
     if (stride < R + 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: stride must cover the status column");
-    int npad = 1;
-    while (npad < B) npad <<= 1;
+    const int npad = (int)((B + 1) & ~(int64_t)1);                   // values per column (no padding needed: nothing is sorted)
     const bool in_lds = (size_t)npad * sizeof(double) <= (size_t)128 * 1024;
     int rc;
     if ((rc = pin_ready(m))) return rc;
@@ -989,6 +1161,55 @@ int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t 
 }
 
 extern "C" {
+
+// ---- operator seam (solver_ops.h): the reference's Scheme / Mode plug-ins, one call = upload + MFMA Gram + one small kernel ----
+int plspm_op_inner_weights(int32_t device_id, int32_t scheme, int32_t L, const uint8_t* path, const double* y, int64_t N, double* E) {
+    g_create_error.clear();
+    if (!path || !y || !E || L < 1 || L > 64 || N < 2) return fail(nullptr, PLSPM_E_ARG, "plspm_op_inner_weights: bad arguments (1 <= L <= 64, N >= 2)");
+    std::vector<int32_t> boff(L + 1), mode(L, PLSPM_MODE_A);
+    for (int l = 0; l <= L; ++l) boff[l] = l;                       // every LV's "block" is its own score column
+    plspm_model* m = plspm_model_create(L, L, boff.data(), path, mode.data(), scheme, 0, 1, 1.0, device_id);
+    if (!m) return PLSPM_E_ARG;                                     // text in plspm_last_error(NULL)
+    auto done = [&](int rc) { if (rc) g_create_error = m->error; plspm_model_destroy(m); return rc; };
+    int rc;
+    if ((rc = plspm_upload(m, y, N, L, 0, nullptr)) || (rc = dense_moments(m))) return done(rc);
+    if ((rc = ensure(m, m->fitout, sizeof(double) * (size_t)L * L))) return done(rc);
+    const size_t lds = (size_t)workspace_small_doubles(L, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(L, L, m->n_eff, (int)m->pred_idx.size());
+    if ((rc = allow_lds(m, (const void*)op_inner_kernel, lds))) return done(rc);
+    hipLaunchKernelGGL(op_inner_kernel, dim3(1), dim3(256), lds, m->stream, make_desc(m), (const double*)m->gram.p, (double*)m->fitout.p);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(E, m->fitout.p, sizeof(double) * (size_t)L * L, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return done(fail(m, PLSPM_E_STATE, "plspm_op_inner_weights: launch / copy failed"));
+    return done(0);
+}
+
+int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, const double* z, int64_t N, int32_t k, double* w) {
+    g_create_error.clear();
+    if (!Xk || !z || !w || k < 1 || k > 1020 || N < 2 || (mode != PLSPM_MODE_A && mode != PLSPM_MODE_B))
+        return fail(nullptr, PLSPM_E_ARG, "plspm_op_outer_weights: bad arguments (1 <= k <= 1020, N >= 2)");
+    const int P = k + 1;                                            // [X_k | z]
+    const int32_t boff[2] = {0, P}, modes[1] = {PLSPM_MODE_A};
+    const uint8_t path[1] = {0};
+    plspm_model* m = plspm_model_create(P, 1, boff, path, modes, PLSPM_SCHEME_CENTROID, 0, 1, 1.0, device_id);
+    if (!m) return PLSPM_E_ARG;
+    auto done = [&](int rc) { if (rc) g_create_error = m->error; plspm_model_destroy(m); return rc; };
+    std::vector<double> both;                                       // the two host arrays side by side (one upload, one Gram)
+    try { both.resize((size_t)N * P); } catch (...) { return done(fail(m, PLSPM_E_STATE, "out of host memory")); }
+    for (int64_t i = 0; i < N; ++i) { memcpy(&both[(size_t)i * P], Xk + (size_t)i * k, sizeof(double) * k); both[(size_t)i * P + k] = z[i]; }
+    int rc;
+    if ((rc = plspm_upload(m, both.data(), N, P, 0, nullptr)) || (rc = dense_moments(m))) return done(rc);
+    const size_t kk = (size_t)k * k;
+    if ((rc = ensure(m, m->fitout, sizeof(double) * (3 * kk + 1 + k)))) return done(rc);
+    double* scratch = (double*)m->fitout.p;
+    double* d_w = scratch + 3 * kk + 1;
+    hipLaunchKernelGGL(op_outer_kernel, dim3(1), dim3(256), 0, m->stream, (int)mode, (int)k, m->T, (const double*)m->gram.p, (const double*)m->d_shift, scratch, d_w);
+    double flag = 0.0;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(w, d_w, sizeof(double) * k, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&flag, scratch + 3 * kk, sizeof(double), hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess)
+        return done(fail(m, PLSPM_E_STATE, "plspm_op_outer_weights: launch / copy failed"));
+    if (flag == 0.0) return done(fail(m, PLSPM_SINGULAR, "plspm_op_outer_weights: the Mode-B least squares did not converge"));
+    return done(0);
+}
 
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx) {
     if (!idx || N < 1 || N > 0x7fffffffLL || rep < 0) return PLSPM_E_ARG;

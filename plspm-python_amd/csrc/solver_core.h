@@ -44,10 +44,13 @@ enum { ST_OK = 0, ST_NOT_CONVERGED = 1, ST_SINGULAR = 2, ST_NONFINITE = 3 };
 // columns are split into T = PA/16 tiles, tile t holds columns 32*(t/2) + 2*i + (t&1), i = 0..15;
 // only tiles (t,u) with t <= u are stored, 256 doubles each, in v_mfma_f64_16x16x4_f64 C/D register
 // order: element (row, col) of a tile sits at ((reg = row/4) * 64 + lane), lane = (row%4)*16 + col.
-PLSPM_HD int packed_tile_of(int p) { return 2 * (p >> 5) + (p & 1); }
-PLSPM_HD int packed_pos_of(int p) { return (p & 31) >> 1; }
+// An ODD tile count (16-column granularity of the padded width: P + 1 = 201 columns take 13 tiles, not 14) leaves the last tile
+// without a partner: it holds the 16 consecutive columns 16(T-1) .. 16T-1.
+PLSPM_HD int packed_tile_of(int T, int p) { return ((T & 1) && p >= 16 * (T - 1)) ? T - 1 : 2 * (p >> 5) + (p & 1); }
+PLSPM_HD int packed_pos_of(int T, int p) { return ((T & 1) && p >= 16 * (T - 1)) ? p - 16 * (T - 1) : (p & 31) >> 1; }
+PLSPM_HD int packed_col_of(int T, int tile, int pos) { return ((T & 1) && tile == T - 1) ? 16 * (T - 1) + pos : 32 * (tile >> 1) + 2 * pos + (tile & 1); }
 PLSPM_HD long packed_index(int T, int p, int q) {
-    int tp = packed_tile_of(p), tq = packed_tile_of(q), ip = packed_pos_of(p), iq = packed_pos_of(q);
+    int tp = packed_tile_of(T, p), tq = packed_tile_of(T, q), ip = packed_pos_of(T, p), iq = packed_pos_of(T, q);
     int t, u, r, c;
     if (tp < tq || (tp == tq && ip <= iq)) { t = tp; u = tq; r = ip; c = iq; } else { t = tq; u = tp; r = iq; c = ip; }
     long tile = (long)t * T - (long)t * (t - 1) / 2 + (u - t);
@@ -347,10 +350,9 @@ PLSPM_HD double dot_col(const double* S, int PS, int p, const double* w, int a, 
 // ---------------------------------------------------------------------------------------------
 // Stage 1: packed raw scatter -> treated population covariance S (config.py:299-305, util.py:33-39)
 // Inverse of packed_index for one stored element: tile (t,u), register r, lane -> (p, q) with p the row column.
-PLSPM_HD void packed_coords(int t, int u, int r, int lane, int& p, int& q) {
-    const int row = (lane >> 4) + 4 * r, col = lane & 15;
-    p = 32 * (t >> 1) + 2 * row + (t & 1);
-    q = 32 * (u >> 1) + 2 * col + (u & 1);
+PLSPM_HD void packed_coords(int T, int t, int u, int r, int lane, int& p, int& q) {
+    p = packed_col_of(T, t, (lane >> 4) + 4 * r);
+    q = packed_col_of(T, u, lane & 15);
 }
 
 template <class Ex>
@@ -365,8 +367,8 @@ PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const d
         int t, u;
         if (md.tile_tu) { const int tu = md.tile_tu[tile]; t = tu & 255; u = tu >> 8; }
         else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
-        const int p = 32 * (t >> 1) + (t & 1) + 8 * r + 2 * (lane >> 4);      // packed_coords, chunk part hoisted
-        const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
+        const int p = packed_col_of(T, t, 4 * r + (lane >> 4));
+        const int q = packed_col_of(T, u, lane & 15);
         if ((t != u || p <= q) && p <= P && q <= P) { ws.S[q * PS + p] = m; ws.S[p * PS + q] = m; }
     });
     ex.par(P, [&](int p) { ws.mu[p] = ws.S[P * PS + p]; });
@@ -435,7 +437,7 @@ PLSPM_HD void impute_collapse(Ex& ex, int P, int Qa, int Ta, int Ts, const int* 
         int t = 0, rem = tile;
         while (rem >= Ts - t) { rem -= Ts - t; ++t; }
         int p, q;
-        packed_coords(t, t + rem, r, lane, p, q);
+        packed_coords(Ts, t, t + rem, r, lane, p, q);
         double v = 0.0;
         if (p <= P && q <= P) {
             const int ap = p < P ? p : Qa, aq = q < P ? q : Qa;
@@ -759,8 +761,8 @@ PLSPM_HD void nm_prepare(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st
         int t, u;
         if (md.tile_tu) { const int tu = md.tile_tu[tile]; t = tu & 255; u = tu >> 8; }
         else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
-        const int p = 32 * (t >> 1) + (t & 1) + 8 * r + 2 * (lane >> 4);
-        const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
+        const int p = packed_col_of(T, t, 4 * r + (lane >> 4));
+        const int q = packed_col_of(T, u, lane & 15);
         if ((t != u || p <= q) && p <= P && q <= P) { ws.S[q * PS + p] = m; ws.S[p * PS + q] = m; }
     });
     const double n = ws.S[P * PS + P], inv_n = 1.0 / n;

@@ -50,7 +50,7 @@ PLSPM_HD void hoc_second_stage_moments(Ex& ex, const HocDesc& hd, const double* 
         int t = 0, rem = tile;
         while (rem >= hd.T2 - t) { rem -= hd.T2 - t; ++t; }
         int a, b;
-        packed_coords(t, t + rem, r, lane, a, b);
+        packed_coords(hd.T2, t, t + rem, r, lane, a, b);
         double v = 0.0;
         if (a <= P2 && b <= P2) {
             if (!ok) v = NAN;

@@ -23,7 +23,8 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_model_set_option", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows",
-           "plspm_group_barrier", "plspm_group_max"]
+           "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
+           "plspm_op_inner_weights", "plspm_op_outer_weights"]
 UNIQUE_ID_BYTES = 128
 
 
@@ -123,6 +124,8 @@ def load():
     lib.plspm_group_rows.argtypes = [vp, vp, vp, vp]
     lib.plspm_group_barrier.argtypes = [vp]
     lib.plspm_group_max.argtypes = [vp, ctypes.POINTER(dbl)]
+    lib.plspm_op_inner_weights.argtypes = [i32, i32, i32, vp, vp, i64, vp]
+    lib.plspm_op_outer_weights.argtypes = [i32, i32, vp, vp, i64, i32, vp]
     if lib.plspm_abi_version() != ABI_VERSION:
         raise NativeBackendError("libplspm_hip.so ABI %d != expected %d" % (lib.plspm_abi_version(), ABI_VERSION))
     _lib = lib
@@ -321,6 +324,40 @@ class NativeModel:
         ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
         self._check(self._lib.plspm_profile_read(self._h, KERNELS[kernel], ctypes.byref(ms), ctypes.byref(n)), "plspm_profile_read")
         return ms.value, n.value
+
+
+def op_inner_weights(scheme_code, path, y, device_id=0):
+    """Scheme operator on the device (plspm_op_inner_weights): path [L, L] 0/1, y [N, L] scores -> E [L, L]."""
+    lib = load()
+    path = np.ascontiguousarray(path, dtype=np.uint8)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    L = path.shape[0]
+    if path.shape != (L, L) or y.ndim != 2 or y.shape[1] != L:
+        raise ValueError("path must be L x L and y N x L")
+    E = np.empty((L, L))
+    rc = lib.plspm_op_inner_weights(int(device_id), int(scheme_code), L, _ptr(path), _ptr(y), y.shape[0], _ptr(E))
+    if rc:
+        raise NativeBackendError("plspm_op_inner_weights failed (%d): %s" % (rc, lib.plspm_last_error(None).decode()))
+    return E
+
+
+def op_outer_weights(mode_code, Xk, z, device_id=0):
+    """Mode operator on the device (plspm_op_outer_weights): Xk [N, k], z [N] -> w [k]."""
+    lib = load()
+    Xk = np.ascontiguousarray(Xk, dtype=np.float64)
+    z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1)
+    if Xk.ndim != 2 or z.shape[0] != Xk.shape[0]:
+        raise ValueError("Xk must be N x k and z of length N")
+    w = np.empty(Xk.shape[1])
+    rc = lib.plspm_op_outer_weights(int(device_id), int(mode_code), _ptr(Xk), _ptr(z), Xk.shape[0], Xk.shape[1], _ptr(w))
+    if rc:
+        raise NativeBackendError("plspm_op_outer_weights failed (%d): %s" % (rc, lib.plspm_last_error(None).decode()))
+    return w
+
+
+def release_cached_memory():
+    """Hand the library's cached device / pinned-host blocks back to the HIP runtime."""
+    load().plspm_release_cached_memory()
 
 
 def rccl_unique_id():

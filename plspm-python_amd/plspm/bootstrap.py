@@ -11,6 +11,7 @@ Replicates whose status is not OK are dropped, as the reference's bare ``except`
 ``_create_summary`` below is the same statistic in NumPy, kept for API parity and as the checker of the kernel.
 """
 import os
+import time
 
 import numpy as np
 import pandas as pd
@@ -36,6 +37,51 @@ def _create_summary(samples: pd.DataFrame, original) -> pd.DataFrame:
     return summary
 
 
+class _Pending:
+    """Replicates enqueued on the device(s); ``Bootstrap`` turns them into summaries."""
+
+    def __init__(self, result, iterations, seed, source, group, helpers):
+        self.result, self.iterations, self.seed = result, iterations, seed
+        self.source, self.group, self.helpers = source, group, helpers
+        self.t_launch = time.perf_counter()
+
+
+def launch(result, iterations: int, num_processes: int, seed=None, comm=None) -> _Pending:
+    """Enqueue the bootstrap replicates of a fitted model (``result``: the SolverResult whose handle holds the data) and return at
+    once -- for metric models nothing here waits for the device, so the caller's host work (``Plspm`` builds its result frames)
+    runs while the GPU resamples and solves.  Where the replicates run: see :class:`Bootstrap`."""
+    native = result.native
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")      # the reference is unseeded as well (bootstrap.py:56)
+    R = native.row_width
+    group = helpers = None
+    ctx = parallel.context()
+    if comm is not None:
+        records = parallel.sharded_bootstrap(lambda count, first: native.bootstrap(count, seed, first), iterations, R, comm)
+        native.store(records)                                                       # merged records back to HBM for the summary
+        source = native
+    elif ctx is not None:
+        from plspm import _native
+        if native.device_id != ctx.local_rank:
+            raise _native.NativeBackendError("the handle lives on device %d but this rank's GPU is %d: pass device_id=LOCAL_RANK"
+                                             % (native.device_id, ctx.local_rank))
+        group = _native.NativeGroup(ctx.comm, [native])
+        group.bootstrap(iterations, seed, 0)
+        source = group
+    else:
+        devices = parallel.devices_for(num_processes, iterations, native.device_id)
+        if len(devices) > 1 and result.builder is not None:
+            from plspm import _native
+            helpers = [result.builder(dev) for dev in devices[1:]]                  # the same model + data on the other GPUs
+            group = _native.NativeGroup(parallel.local_comm(devices), [native] + helpers)
+            group.bootstrap(iterations, seed, 0)
+            source = group
+        else:
+            native.bootstrap_device(iterations, seed, 0)                            # resample + Gram + solver, rows stay in HBM
+            source = native
+    return _Pending(result, iterations, seed, source, group, helpers)
+
+
 class Bootstrap:
     """Bootstrap results; constructed by :class:`plspm.plspm.Plspm` when ``bootstrap=True``.
 
@@ -51,50 +97,27 @@ class Bootstrap:
     """
 
     def __init__(self, config, data: pd.DataFrame, inner_model, outer_model, calculator, iterations: int, num_processes: int,
-                 result=None, seed=None, comm=None):
-        if result is None:
-            from plspm.estimator import Estimator
-            result = Estimator(config).run(calculator, data, want_scores=False)
+                 result=None, seed=None, comm=None, pending=None):
+        if pending is None:
+            if result is None:
+                from plspm.estimator import Estimator
+                result = Estimator(config).run(calculator, data, want_scores=False)
+            pending = launch(result, iterations, num_processes, seed, comm)
+        result = pending.result
         native, cm = result.native, result.compiled
-        if seed is None:
-            seed = int.from_bytes(os.urandom(8), "little")      # the reference is unseeded as well (bootstrap.py:56)
-        self._seed = seed
-        self._cm, self._native, self._iterations_requested = cm, native, iterations
+        self._seed = pending.seed
+        self._cm, self._native, self._iterations_requested = cm, native, pending.iterations
         self._inner_model = inner_model
-        R = native.row_width
+        self._group, self._helpers, self._source = pending.group, pending.helpers, pending.source
         original = self._original(result, inner_model, outer_model)
-        self._group = self._helpers = None
-        ctx = parallel.context()
-        if comm is not None:
-            records = parallel.sharded_bootstrap(lambda count, first: native.bootstrap(count, seed, first), iterations, R, comm)
-            native.store(records)                                                       # merged records back to HBM for the summary
-            self._source = native
-        elif ctx is not None:
-            from plspm import _native
-            if native.device_id != ctx.local_rank:
-                raise _native.NativeBackendError("the handle lives on device %d but this rank's GPU is %d: pass device_id=LOCAL_RANK"
-                                                 % (native.device_id, ctx.local_rank))
-            self._group = _native.NativeGroup(ctx.comm, [native])
-            self._group.bootstrap(iterations, seed, 0)
-            self._source = self._group
-        else:
-            devices = parallel.devices_for(num_processes, iterations, native.device_id)
-            if len(devices) > 1 and result.builder is not None:
-                from plspm import _native
-                self._helpers = [result.builder(dev) for dev in devices[1:]]            # the same model + data on the other GPUs
-                self._group = _native.NativeGroup(parallel.local_comm(devices), [native] + self._helpers)
-                self._group.bootstrap(iterations, seed, 0)
-                self._source = self._group
-            else:
-                native.bootstrap_device(iterations, seed, 0)                            # resample + Gram + solver, rows stay in HBM
-                self._source = native
-        # _create_summary (bootstrap.py:24-32) on the records still in HBM
+        # _create_summary (bootstrap.py:24-32) on the records still in HBM (this is where the host waits for the replicates)
         if self._source is native:
-            self._table, self._used = native.summary(iterations, original)
+            self._table, self._used = native.summary(pending.iterations, original)
         else:
             self._table, self._used = self._group.summary(original)
         self._rows = None
         self._frames = None
+        self.latency_s = time.perf_counter() - pending.t_launch      # enqueue -> summaries on the host (host work in between overlaps)
 
     @staticmethod
     def _original(result, inner_model, outer_model):

@@ -124,9 +124,9 @@ class Estimator:
     def estimate(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame) -> Tuple[pd.DataFrame, pd.DataFrame, pd.DataFrame]:
         """API parity with the reference: (final_data, scores, weights)."""
         result = self.run(calculator, data)
-        used = list(result.compiled.dev_mvs)
-        frame = data if all(col in data.columns for col in used) else None
-        final = self._config.treat(frame[used]) if frame is not None and self._config.metric() else None
+        used = set(result.compiled.dev_mvs)
+        columns = [col for col in data.columns if col in used]           # the treated data keep the data's own column order (estimator.py:33)
+        final = self._config.treat(data[columns]) if len(columns) == len(used) and self._config.metric() else None
         return final, result.scores(), result.weights()
 
     def config(self):

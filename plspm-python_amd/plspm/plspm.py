@@ -16,6 +16,7 @@ import plspm.inner_summary as pis
 import plspm.outer_model as om
 import plspm.weights as w
 from plspm.bootstrap import Bootstrap
+from plspm.bootstrap import launch as launch_bootstrap
 from plspm.estimator import Estimator
 from plspm.scheme import Scheme
 from plspm.unidimensionality import Unidimensionality
@@ -56,24 +57,31 @@ class Plspm:
         # one device fit: Gram -> LDS solver -> scores; everything below only re-labels / post-processes its outputs
         fit = estimator.run(calculator, observations, want_scores=True, want_cov=True)
         model_spec = estimator.config()
+        pending = None
+        if bootstrap:
+            if n_obs < 10:
+                raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
+            # the handle of the fit already holds the data in HBM: the replicates are enqueued on it NOW (HOC models: on a two-stage
+            # handle pair), so that the GPU resamples and solves while the host builds the result frames below
+            boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
+            pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed)
         self._result = fit
         self._scores = fit.scores()
         self._inner_model = im.InnerModel.from_device(model_spec.path(), fit)
         r2 = self._inner_model.r_squared()
         self._outer_model = om.OuterModel(fit, r2)
         self._inner_summary = pis.InnerSummary(model_spec, r2, self._inner_model.r_squared_adj(), self._outer_model.model())
-        incomplete = [col for col in observations.columns if observations[col].isnull().any()]
+        incomplete = list(observations.columns[observations.isnull().values.any(axis=0)])        # one vectorised pass, not one per column
         self._unidimensionality = Unidimensionality(model_spec, fit, incomplete)
         self._bootstrap = None
         t_fit = time.perf_counter()
         if bootstrap:
-            if n_obs < 10:
-                raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
-            # the handle of the fit already holds the data in HBM: the replicates run on it (HOC models: a two-stage handle pair)
-            boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
             self._bootstrap = Bootstrap(model_spec, observations, self._inner_model, self._outer_model, calculator,
-                                        bootstrap_iterations, processes, result=boot_on, seed=seed)
-        self._timings = {"fit_s": t_fit - t_start, "bootstrap_s": time.perf_counter() - t_fit}
+                                        bootstrap_iterations, processes, pending=pending)
+        # fit_s: filter + upload + device fit + frames; bootstrap_s: what the bootstrap adds after the frames exist (mostly the device
+        # summaries: the replicates ran under the frame building); bootstrap_latency_s: enqueue of the replicates -> summaries on the host
+        self._timings = {"fit_s": t_fit - t_start, "bootstrap_s": time.perf_counter() - t_fit,
+                         "bootstrap_latency_s": self._bootstrap.latency_s if self._bootstrap is not None else 0.0}
 
     # ---- accessors (names and return shapes of reference plspm/plspm.py:84-169) -------------------------------
     def scores(self) -> pd.DataFrame:

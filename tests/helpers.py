@@ -56,9 +56,15 @@ def assert_close(a, b, rtol, atol=0.0, what=""):
 # ----------------------------------------------------------------------------------------------
 # NumPy restatement of the device data layouts (independent of the C++ in csrc/solver_core.h)
 def packed_index_np(T, p, q):
+    """csrc/solver_core.h packed_index in NumPy.  Odd T: the last tile holds the 16 consecutive columns 16(T-1) .. 16T-1."""
     p = np.asarray(p); q = np.asarray(q)
-    tp, tq = 2 * (p >> 5) + (p & 1), 2 * (q >> 5) + (q & 1)
-    ip, iq = (p & 31) >> 1, (q & 31) >> 1
+    last = 16 * (T - 1)
+
+    def tile_pos(c):
+        lone = (T % 2 == 1) & (c >= last)
+        return np.where(lone, T - 1, 2 * (c >> 5) + (c & 1)), np.where(lone, c - last, (c & 31) >> 1)
+    tp, ip = tile_pos(p)
+    tq, iq = tile_pos(q)
     swap = ~((tp < tq) | ((tp == tq) & (ip <= iq)))
     t = np.where(swap, tq, tp); u = np.where(swap, tp, tq)
     r = np.where(swap, iq, ip); c = np.where(swap, ip, iq)
@@ -66,14 +72,18 @@ def packed_index_np(T, p, q):
     return (tile * 4 + (r >> 2)) * 64 + (r & 3) * 16 + c
 
 
-def padded_width(P):
+def padded_width(P, odd_tiles=False):
+    """Device row pitch: whole 32-column groups; with odd_tiles the 16-column granularity metric handles use for 5 <= T <= 15."""
+    t16 = (P + 1 + 15) // 16
+    if odd_tiles and t16 % 2 == 1 and 5 <= t16 <= 15:
+        return 16 * t16
     return ((P + 1 + 31) // 32) * 32
 
 
-def packed_scatter(Xdev, counts=None, shift=None):
+def packed_scatter(Xdev, counts=None, shift=None, odd_tiles=False):
     """Augmented raw scatter sum_i c_i [x'_i,1][x'_i,1]^T of the shifted data in the tile-packed layout."""
     n, P = Xdev.shape
-    PA = padded_width(P)
+    PA = padded_width(P, odd_tiles)
     T = PA // 16
     if shift is None:
         shift = Xdev.mean(axis=0)

@@ -12,6 +12,7 @@
 #include "../../plspm-python_amd/csrc/solver_nmg.h"
 #include "../../plspm-python_amd/csrc/solver_hoc.h"
 #include "../../plspm-python_amd/csrc/solver_nmx.h"
+#include "../../plspm-python_amd/csrc/solver_ops.h"
 
 using namespace plspm;
 
@@ -111,6 +112,21 @@ static void run_plain(int nthreads_in, Body body) {
 }
 
 extern "C" {
+
+// ---- operator seam (csrc/solver_ops.h): Mp = tile-packed moment matrix of the SHIFTED columns + ones, shift = the column means
+void hostemu_op_inner_weights(int L, int PA, int scheme, const unsigned char* C, const double* shift, const double* Mp, int nthreads, double* E) {
+    std::vector<int> boff(L + 1), mode(L, MODE_A);
+    for (int l = 0; l <= L; ++l) boff[l] = l;
+    EmuModel em(L, L, PA, scheme, 0, 1, 1.0, boff.data(), C, mode.data(), shift, 0, nullptr, nullptr);
+    run_group(nthreads, L, L, em.md, nullptr, [&](HostExec& ex, Workspace& ws) { op_inner_weights(ex, em.md, ws, Mp, E); });
+}
+int hostemu_op_outer_weights(int mode, int k, int PA, const double* shift, const double* Mp, int nthreads, double* w) {
+    std::vector<double> scratch(3 * (size_t)k * k + 1);
+    run_plain(nthreads, [&](HostExec& ex) {
+        op_outer_weights(ex, mode, k, PA / 16, Mp, shift, scratch.data(), scratch.data() + (size_t)k * k, scratch.data() + 2 * (size_t)k * k, w, scratch.data() + 3 * (size_t)k * k);
+    });
+    return scratch[3 * (size_t)k * k] != 0.0 ? 0 : 2;
+}
 
 // ---- non-metric (NUM / RAW) entry points: S (R matrix, cov_doubles(P)) and state (nm_state_doubles) persist in caller memory
 long hostemu_cov_doubles(int P) { return cov_doubles(P); }

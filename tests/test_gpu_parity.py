@@ -124,9 +124,10 @@ def test_chain20_wide_gram_vs_golden(tag):
     assert_close(g["crossloadings_d"], gold[tag + "/crossloadings"], RTOL, ATOL)
 
 
-@pytest.mark.parametrize("P_per,L", [(3, 2), (5, 7), (9, 11), (13, 9), (12, 14), (13, 17)])
+@pytest.mark.parametrize("P_per,L", [(3, 2), (5, 7), (10, 7), (9, 11), (13, 9), (13, 10), (12, 14), (10, 20), (13, 17), (15, 15)])
 def test_every_gram_tile_count(P_per, L):
-    """T = 2,4,6,...,16 tile configurations of the MFMA Gram (P+1 padded to 32..256 columns)."""
+    """T = 2, 4, 5, 6, ..., 16 tile configurations of the MFMA Gram: whole 32-column groups (even T) and, for metric models with
+    5 <= T <= 15, the odd counts whose last tile has no partner (70 -> T 5, 99 -> 7, 130 -> 9, 117 -> 8, 168 -> 11, 200 -> 13, 225 -> 15)."""
     C = orc.chain_C(L)
     X, blocks = orc.synth(1501, C, P_per, seed=L)
     model = orc.Model(blocks, C, "A" * L, "factorial", True)
@@ -135,6 +136,23 @@ def test_every_gram_tile_count(P_per, L):
     Xt = orc.treat_metric(X[:, model.mv_order], True)
     assert_close(g["cov"], Xt.T @ Xt / X.shape[0], 1e-10, 1e-13, what="treated covariance")
     assert_close(g["mean"], X[:, model.mv_order].mean(axis=0), 1e-12, 1e-13)
+
+
+@pytest.mark.parametrize("P_per,L,modes", [(10, 7, "A"), (10, 20, "B")])
+def test_bootstrap_with_odd_tile_counts_vs_oracle(P_per, L, modes):
+    """The gathered (bootstrap) walk of gram_wide_kernel with a partner-less last tile (T = 5 and T = 13, the configs[4] geometry)."""
+    from plspm import _native
+    C = orc.chain_C(L)
+    X, blocks = orc.synth(900, C, P_per, seed=40 + L)
+    model = orc.Model(blocks, C, modes * L, "factorial", True)
+    nm, g = gpu_fit(X, model)
+    check_fit(g, orc.fit(X, model), "odd tiles")
+    rows, status, iters = nm.bootstrap(6, seed=9)
+    assert np.all(status == 0)
+    for r in (0, 5):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(9, r, 900), orc.correction(900))
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL, what="replicate %d" % r)
 
 
 @pytest.mark.parametrize("tag", ["A_centroid_0", "B_path_1", "M_factorial_1"])

@@ -95,3 +95,70 @@ def test_calculate_raises_the_reference_exception_when_not_converging():
     calculator = WeightsCalculatorFactory(cfg, 2, 1e-30, np.sqrt(n / (n - 1)), Scheme.CENTROID)
     with pytest.raises(Exception, match="Could not converge after 3 iterations"):                       # weights.py:185-186
         calculator.calculate(cfg.treat(filtered), cfg.path())
+
+
+# ---------------------------------------------------------------------------------------------- operator plug-ins
+def _reference_scheme(name, path, y):
+    """NumPy restatement of reference scheme.py:27-28 / 36-37 / 45-54 (test-side checker)."""
+    C = path.values
+    if name == "centroid":
+        return np.sign(np.corrcoef(y, rowvar=False) * (C + C.T))
+    if name == "factorial":
+        return np.cov(y, rowvar=False) * (C + C.T)
+    E = C.astype(np.float64)
+    for i in range(C.shape[0]):
+        follow = C[i, :] == 1
+        if follow.any():
+            E[follow, i] = np.linalg.pinv(y[:, follow]) @ y[:, i]
+        predec = C[:, i] == 1
+        if predec.any():
+            E[predec, i] = np.corrcoef(np.column_stack((y[:, predec], y[:, i])), rowvar=False)[:, -1][:-1]
+    return E
+
+
+@pytest.mark.parametrize("name", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("centred", [True, False])
+def test_scheme_operator_calculate(name, centred):
+    """Scheme.X.value.calculate(path, y) (reference scheme.py:27,36,45) as a device call, for standardised scores (how the solver
+    calls it, weights.py:45) and for arbitrary ones (uncentred: the no-intercept OLS of the path scheme sees the raw moments)."""
+    sat, cfg = sat_config("AAAAAA", 1)
+    path = cfg.path()
+    rs = np.random.RandomState(4)
+    eta = rs.standard_normal((500, 6)) @ (np.eye(6) + 0.5 * np.tril(rs.standard_normal((6, 6)), -1)).T
+    y = (eta - eta.mean(axis=0)) / eta.std(axis=0, ddof=1) if centred else eta * np.array([1, 2, 0.5, 3, 1, 0.1]) + np.array([0.3, -2, 5, 0, 1, -0.4])
+    got = SCHEME[name].value.calculate(path, y)
+    want = _reference_scheme(name, path, y)
+    if name == "path":
+        assert isinstance(got, np.ndarray)
+    else:
+        assert isinstance(got, pd.DataFrame) and list(got.index) == list(path.index) and list(got.columns) == list(path.columns)
+    assert_close(np.asarray(got), want, 1e-9, 1e-12, what=name)
+    assert_close(y @ np.asarray(got), y @ want, 1e-9, 1e-10)                            # Z = Y E (weights.py:46)
+
+
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_mode_operator_outer_weights_metric(mode):
+    """Mode.X.value.outer_weights_metric(data, Z, lv, mvs) (reference mode.py:28,50): k x 1 DataFrame, index = mvs, column = lv."""
+    sat, cfg = sat_config("AAAAAA", 1)
+    data = cfg.treat(cfg.filter(sat))
+    rs = np.random.RandomState(8)
+    Z = pd.DataFrame(rs.standard_normal((data.shape[0], 6)), index=data.index, columns=orc.SAT_LVS)
+    mvs = list(cfg.mvs("SAT"))
+    got = (Mode.A if mode == "A" else Mode.B).value.outer_weights_metric(data, Z, "SAT", mvs)
+    assert isinstance(got, pd.DataFrame) and list(got.index) == mvs and list(got.columns) == ["SAT"]
+    X = data.loc[:, mvs].values
+    z = Z.loc[:, "SAT"].values
+    want = X.T @ z / X.shape[0] if mode == "A" else np.linalg.lstsq(X, z, rcond=None)[0]
+    assert_close(got["SAT"].values, want, 1e-9, 1e-12, what="mode " + mode)
+
+
+def test_mode_b_operator_minimum_norm_on_a_collinear_block():
+    sat, cfg = sat_config("AAAAAA", 0)
+    data = cfg.treat(cfg.filter(sat))
+    data = data.assign(imag1dup=data["imag1"])
+    mvs = list(cfg.mvs("IMAG")) + ["imag1dup"]
+    Z = pd.DataFrame({"IMAG": np.random.RandomState(1).standard_normal(data.shape[0])}, index=data.index)
+    got = Mode.B.value.outer_weights_metric(data, Z, "IMAG", mvs)["IMAG"]
+    want = np.linalg.lstsq(data.loc[:, mvs].values, Z["IMAG"].values, rcond=None)[0]       # gelsd: minimum norm
+    assert_close(got.values, want, 1e-8, 1e-11)
+    assert abs(got["imag1"] - got["imag1dup"]) < 1e-12

@@ -77,7 +77,7 @@ def check(e, r, tag=""):
 
 def test_packed_index_matches_numpy(emu):
     emu.hostemu_packed_index.restype = ctypes.c_long
-    for T in (2, 4, 14):
+    for T in (2, 4, 5, 13, 14):                       # even: pairs of tiles per 32-column group; odd: a partner-less last tile
         PA = 16 * T
         seen = set()
         for p in range(PA):
@@ -150,6 +150,25 @@ def test_thread_count_invariance(emu):
         assert np.array_equal(other, run_emu(emu, X, model, nthreads=nt)["row"])    # but a fixed group size is bit-reproducible
 
 
+@pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial")])
+def test_odd_tile_count_layout(emu, modes, scheme):
+    """70 MVs + the ones column = 71 columns: 5 tiles of 16 (row pitch 80) instead of 6 -- the geometry metric handles use for
+    5 <= T <= 15 (configs[4]: 201 columns -> 13 tiles).  The solver must read the partner-less last tile correctly."""
+    C = orc.chain_C(7)
+    X, blocks = orc.synth(600, C, 10, seed=23)
+    model = orc.Model(blocks, C, modes * 7, scheme, True)
+    Xdev = np.ascontiguousarray(X[:, model.mv_order])
+    packed = packed_scatter(Xdev, odd_tiles=True)
+    assert packed[2] == 80
+    check(run_emu(emu, X, model, packed=packed), orc.fit(X, model), "odd tiles " + modes)
+    idx = np.random.RandomState(3).randint(600, size=600)
+    shift = Xdev.mean(axis=0)
+    w = run_emu(emu, X, model, packed=packed_scatter(Xdev, np.bincount(idx, minlength=600), shift, odd_tiles=True))
+    mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(600))
+    assert w["status"] == 0 and w["iterations"] == its
+    assert_close(np.concatenate((w["weights"], w["r2"], w["total"], w["direct"], w["loadings"])), mine, RTOL, 1e-12)
+
+
 def test_not_converged_status(emu):
     X, blocks, _ = satisfaction_oracle_inputs()
     model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=2, tol=1e-30)
@@ -208,3 +227,47 @@ def test_thread_sanitizer_clean():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "tsan-run-done" in r.stdout, r.stderr[-2000:]
     assert "data race" not in r.stderr, r.stderr[-4000:]
+
+
+# ---------------------------------------------------------------------------------------------- operator seam (csrc/solver_ops.h)
+def _scheme_np(name, C, y):
+    """reference scheme.py:27-28 / 36-37 / 45-54 in NumPy."""
+    if name == "centroid":
+        return np.sign(np.corrcoef(y, rowvar=False) * (C + C.T))
+    if name == "factorial":
+        return np.cov(y, rowvar=False) * (C + C.T)
+    E = C.astype(np.float64)
+    for i in range(C.shape[0]):
+        follow = C[i, :] == 1
+        if follow.any():
+            E[follow, i] = np.linalg.pinv(y[:, follow]) @ y[:, i]
+        predec = C[:, i] == 1
+        if predec.any():
+            E[predec, i] = np.corrcoef(np.column_stack((y[:, predec], y[:, i])), rowvar=False)[:, -1][:-1]
+    return E
+
+
+@pytest.mark.parametrize("name", ["centroid", "factorial", "path"])
+def test_operator_seam_scheme_on_moments(emu, name):
+    rs = np.random.RandomState(12)
+    C = orc.satisfaction_C()
+    y = rs.standard_normal((400, 6)) @ (np.eye(6) + 0.4 * np.tril(rs.standard_normal((6, 6)), -1)).T * np.array([1, 2, 0.5, 3, 1, 0.2]) + np.array([0.5, -1, 2, 0, 3, -0.2])
+    Mp, shift, PA = packed_scatter(y)
+    E = np.zeros((6, 6))
+    Cb = np.ascontiguousarray(C.astype(np.uint8))
+    emu.hostemu_op_inner_weights(6, PA, SCHEME_ID[name], _ptr(Cb, ctypes.c_ubyte), _ptr(np.ascontiguousarray(shift)), _ptr(Mp), 4, _ptr(E))
+    assert_close(E, _scheme_np(name, C, y), 1e-10, 1e-13, what=name)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_operator_seam_outer_weights_on_moments(emu, mode):
+    rs = np.random.RandomState(13)
+    X = rs.standard_normal((300, 7)) + np.array([1, 0, -2, 0.5, 0, 3, 1])
+    X[:, 6] = X[:, 0] - 2 * X[:, 3]                                  # rank deficient: Mode B must return the minimum-norm weights
+    z = rs.standard_normal(300) + 0.3 * X[:, 1]
+    Mp, shift, PA = packed_scatter(np.column_stack((X, z)))
+    w = np.zeros(7)
+    emu.hostemu_op_outer_weights.restype = ctypes.c_int
+    assert emu.hostemu_op_outer_weights(mode, 7, PA, _ptr(np.ascontiguousarray(shift)), _ptr(Mp), 3, _ptr(w)) == 0
+    want = X.T @ z / 300 if mode == 0 else np.linalg.lstsq(X, z, rcond=None)[0]
+    assert_close(w, want, 1e-9, 1e-12)
