@@ -82,7 +82,7 @@ struct plspm_model {
     Buf xa, up_raw, up_ci, up_partial;   // resident matrix (d_Xa points into `xa` while data are uploaded) and the upload staging
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
-    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0; } tune;
+    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0; } tune;
     // grow-only pinned host staging for uploads / row downloads (two halves: copy-in of chunk k+1 overlaps the DMA of chunk k)
     void* h_pin = nullptr;
     size_t h_pin_cap = 0;

@@ -393,7 +393,8 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
     hipStream_t s = m->stream;
 #define ROWS(TT)                                                                                                         \
     {                                                                                                                    \
-        const size_t lds = 2 * (size_t)TileIdx<TT>::NTILE * 256 * sizeof(double);                                        \
+        const size_t lds = std::max<size_t>(2 * (size_t)TileIdx<TT>::NTILE * 256 * sizeof(double), (size_t)m->tune.gram_lds_kb * 1024); \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)gram_rows_kernel<TT, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((gram_rows_kernel<TT, DENSE>), grid, dim3(256), lds, s, m->d_Xa, N, ent, nent, ent_stride, out); \
     }
 #define WIDE(TT, NWV, NWP)                                                                                                     \
@@ -653,6 +654,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "wide_nw") { if (value != 4 && value != 8 && value != 16) return bad(); m->tune.wide_nw = value; }
     else if (k == "conv_pass") { if (value < 0 || value > 2) return bad(); m->tune.conv_pass = value; }
     else if (k == "scores_tile") { if (value != 0 && value != 16 && value != 32) return bad(); m->tune.scores_tile = value; }
+    else if (k == "gram_lds_kb") { if (value < 0 || value > 160) return bad(); m->tune.gram_lds_kb = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
