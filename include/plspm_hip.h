@@ -79,7 +79,11 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 /*
  * Compile a model specification (reference Config + path matrix + Plspm kwargs, plspm/config.py:89-160,
  * plspm/plspm.py:35-67) into device descriptors.
- *   P, L           manifest / latent variable counts (1 <= L <= 64, L <= P <= 1022)
+ *   P, L           manifest / latent variable counts (1 <= L <= 64, L <= P <= 1022).  Metric handles fall back to global scratch
+ *                  when a problem's workspace exceeds LDS; the non-metric / categorical / incomplete-rows solvers keep their
+ *                  small workspace (about (7P + P L + 8 L^2 + L (2 k^2 + k) + 2 sum k_b^2) * 8 bytes, k = most predecessors of an
+ *                  LV, k_b = Mode-B block sizes) in the 160 KiB of LDS and return PLSPM_E_LIMIT from plspm_fit / plspm_bootstrap
+ *                  beyond that (P ~ 1000 with L = 6 still fits; L = 64 with P = 1022 does not)
  *   block_offset   [L+1] device-column ranges of the LV blocks
  *   path           [L*L] row-major 0/1, path[i*L+j] = 1 iff LV j -> LV i; must be strictly lower triangular
  *   mode           [L]   PLSPM_MODE_A / PLSPM_MODE_B per LV

@@ -7,7 +7,7 @@
 // small workspace and the descriptors are LDS-resident.  MODE 0 prepare, 1 step, 2 finish (solver_core.h nm_*).
 template <int MODE>
 __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gstate,
-                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
+                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
@@ -22,12 +22,20 @@ __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __r
     if (MODE == 1 && st.scal[3] == 0.0) return;                 // finished problems cost nothing more
     stage_descriptors(md, lp);
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    // Launch fusion: MODE 0 = prepare + the first step (nothing to decide before it); MODE 1 = decide + step, and -- with
+    // fuse_finish -- the finish of a problem right where its stop is decided (every problem stops inside a MODE 1 launch, so the
+    // separate finish launch and its reload of the correlation matrix disappear); MODE 2 = finish alone.
+    bool finish_now = (MODE == 2);
     if (MODE == 0) {
         nm_prepare(ex, md, ws, st, Mp + b * mp_stride);
+        const bool active = nm_step(ex, md, ws, st, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
     } else if (MODE == 1) {
         const bool active = nm_step(ex, md, ws, st, partial + b * nparts, nparts);
         if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
-    } else {
+        finish_now = !active && fuse_finish;
+    }
+    if (finish_now) {
         FitOutputs out = so.fit;
         if (b != 0) out = FitOutputs{};
         out.row = so.row ? so.row + b * so.row_stride : nullptr;
@@ -43,7 +51,7 @@ __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __r
 template <int MODE>
 __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
                                                   double* gS, double* gSm, double* gstate, long state_stride,
-                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive) {
+                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
@@ -66,12 +74,17 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     if (MODE == 1 && st.scal[3] == 0.0) return;
     stage_descriptors(md, lp);
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    bool finish_now = (MODE == 2);
     if (MODE == 0) {
         nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
+        const bool active = nmg_step(ex, md, cd, ws, st, x, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
     } else if (MODE == 1) {
         const bool active = nmg_step(ex, md, cd, ws, st, x, partial + b * nparts, nparts);
         if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
-    } else {
+        finish_now = !active && fuse_finish;
+    }
+    if (finish_now) {
         FitOutputs out = so.fit;
         if (b != 0) out = FitOutputs{};
         out.row = so.row ? so.row + b * so.row_stride : nullptr;
@@ -87,7 +100,7 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
 template <int MODE>
 __global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, const int* __restrict__ rowid, const double* __restrict__ Mp, long mp_stride, SolverOut so,
                                                   double* gS, double* gstate, long state_stride, const double* __restrict__ partial, int nparts,
-                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride) {
+                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride, int fuse_finish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
@@ -104,6 +117,7 @@ __global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, con
     if (MODE == 1 && st.scal[3] == 0.0) return;
     stage_descriptors(md, lp);
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    bool finish_now = (MODE == 2);
     if (MODE == 0) {
         const int2* e = ent ? ent + b * ent_stride : nullptr;
         const int ne = ent ? nent[b] : 0;
@@ -119,10 +133,14 @@ __global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, con
         }
         __syncthreads();
         nmx_prepare(ex, md, xd, ws, st, x, Mp + b * mp_stride);
+        const bool active = nmx_step(ex, md, xd, ws, st, x, partial + b * nparts, nparts);
+        if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
     } else if (MODE == 1) {
         const bool active = nmx_step(ex, md, xd, ws, st, x, partial + b * nparts, nparts);
         if (active && threadIdx.x == 0) atomicAdd(nactive, 1);
-    } else {
+        finish_now = !active && fuse_finish;
+    }
+    if (finish_now) {
         FitOutputs out = so.fit;
         if (b != 0) out = FitOutputs{};
         out.row = so.row ? so.row + b * so.row_stride : nullptr;

@@ -575,25 +575,25 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     double* part = (double*)m->nmpartial.p;
     int* nact = (int*)m->nmactive.p;
     const dim3 grid((unsigned)nproblems);
+    const int fuse = finish ? 1 : 0;           // the finish of a problem runs inside the step launch that decides its stop
     auto launch = [&](int mode_op) {
         ProfScope ps(m, PLSPM_K_SOLVER);
         if (cat) {
             auto k = mode_op == 0 ? nmg_kernel<0> : mode_op == 1 ? nmg_kernel<1> : nmg_kernel<2>;
-            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact);
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact, fuse);
         } else if (nmx) {
             auto k = mode_op == 0 ? nmx_kernel<0> : mode_op == 1 ? nmx_kernel<1> : nmx_kernel<2>;
             const MissDesc xd{m->nmx_raw, m->nmx_K, m->d_Xk, m->d_Mk};
             hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, xd, (const int*)m->d_rowid, Mp, mp_stride, so, gS, gst, (long)st_doubles, (const double*)part, nparts,
-                               nact, ent, nent, ent_stride);
+                               nact, ent, nent, ent_stride, fuse);
         } else {
             auto k = mode_op == 0 ? nm_kernel<0> : mode_op == 1 ? nm_kernel<1> : nm_kernel<2>;
-            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact);
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact, fuse);
         }
     };
-    launch(0);
     for (int it = 0; it <= m->max_iter + 1; ++it) {
         HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
-        launch(1);
+        launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
         // problems / replicate groups return at once on the device, and the 4-byte read-back of the counter overlaps with the pass
         // instead of leaving the GPU idle for a host round trip per iteration.
@@ -627,7 +627,6 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
         HIPCHK(m, hipEventSynchronize(m->ev_flag));
         if (*m->h_flag == 0) break;
     }
-    if (finish) launch(2);
     HIPCHK(m, hipGetLastError());
     return 0;
 }
