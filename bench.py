@@ -137,12 +137,10 @@ def api_inclusive(X, reps, pairs=7):
             "bootstrap_tail_ms": round(float(np.median(tails)) * 1e3, 3), "bootstrap_latency_ms": round(float(np.median(inner)) * 1e3, 3),
             "plspm_fit_wall_ms": round(float(np.median(fits)) * 1e3, 3), "plspm_fit_plus_bootstrap_wall_ms": round(float(np.median(boots)) * 1e3, 3),
             "replicates_used": int(used),
-            "note": "Plspm(bootstrap=True, bootstrap_iterations=%d) enqueues the replicates before it builds its pandas result frames, so the call costs "
-                    "only paired_difference_ms more than Plspm() without bootstrap (median over %d pairs; bootstrap_tail_ms = what it still waits for "
-                    "after the frames, bootstrap_latency_ms = enqueue -> summaries on the host with the frame building in between).  value is NOT taken "
-                    "from that hidden figure: it is replicates / max(paired_difference_ms, standalone_ms), standalone_ms = the same bootstrap on a fresh "
-                    "handle with nothing to overlap (enqueue -> kernels -> device summaries -> %d x 6 table on the host); rows stay in HBM, frames are "
-                    "built on access" % (reps, pairs, 156)}
+            "note": "paired_difference_ms = median over %d pairs of [wall of Plspm(bootstrap=True, bootstrap_iterations=%d)] - [wall of Plspm()] (the replicates "
+                    "are enqueued right after the fit; the pandas report frames are built on access); bootstrap_tail_ms / bootstrap_latency_ms = Plspm.timings(); "
+                    "standalone_ms = the same bootstrap on a fresh handle, nothing overlapped (enqueue -> kernels -> device summaries -> %d x 6 table on "
+                    "the host); value = replicates / max(paired_difference_ms, standalone_ms); rows stay in HBM" % (pairs, reps, 156)}
 
 
 def main():

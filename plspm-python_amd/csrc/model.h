@@ -96,6 +96,8 @@ struct plspm_model {
 // Core of plspm_bootstrap_device (plspm_hip.hip): enqueue B replicates on the handle's stream, records written at `rows_out`
 // (pitch plspm_row_stride) or into the handle's own `rows` buffer when rows_out is NULL.  No host synchronisation for metric models.
 int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, double* rows_out);
+// plspm_group.cpp: a handle that is destroyed while bound to a group takes the group's hold on every handle with it.
+extern "C" void plspm_detail_group_orphan(void* group);
 // Host -> device copy through the handle's pinned staging halves (chunked; returns when the source may be re-used).
 int plspm_detail_h2d(plspm_model* m, void* dst, const void* src, size_t bytes);
 // Summary statistics of device records (plspm_bootstrap_summary without the argument checks on `rows`).

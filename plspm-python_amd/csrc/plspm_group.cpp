@@ -170,8 +170,9 @@ int plspm_rccl_unique_id(uint8_t* id) {
     return 0;
 }
 
-void plspm_group_destroy(plspm_group_t* g) {
-    if (!g) return;
+// Release everything the group holds on its handles (streams, events, buffers) and unbind it; the struct itself stays (an owner may
+// still call plspm_group_destroy on it).  Idempotent.
+static void group_release(plspm_group* g) {
     for (auto& l : g->loc) {
         hipSetDevice(l.m->device);
         if (l.m->stream) hipStreamSynchronize(l.m->stream);
@@ -190,7 +191,19 @@ void plspm_group_destroy(plspm_group_t* g) {
         if (l.cstream) plspm_stream_release(l.cstream);
         l.m->group = nullptr;
     }
+    g->loc.clear();
+    g->last_slot = -1;
     if (g->comm && g->comm->bound == g) g->comm->bound = nullptr;
+    g->comm = nullptr;
+}
+
+// A handle is being destroyed while it still belongs to a group (host objects are collected in arbitrary order): the group lets go
+// of ALL its handles first, so that nothing dangles; later calls on the group report PLSPM_E_STATE.
+void plspm_detail_group_orphan(void* group) { if (group) group_release((plspm_group*)group); }
+
+void plspm_group_destroy(plspm_group_t* g) {
+    if (!g) return;
+    group_release(g);
     delete g;
 }
 
@@ -290,11 +303,13 @@ int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* 
 
 int plspm_group_sync(plspm_group_t* g) {
     if (!g) return PLSPM_E_ARG;
+    if (g->loc.empty()) return gfail(g, PLSPM_E_STATE, "the group's handles were destroyed");
     return sync_all(g);
 }
 
 int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset) {
     if (!g || B < 1 || rep_offset < 0 || B > ((int64_t)1 << 30)) return gfail(g, PLSPM_E_ARG, "plspm_group_bootstrap: bad arguments (1 <= B <= 2^30, rep_offset >= 0)");
+    if (g->loc.empty()) return gfail(g, PLSPM_E_STATE, "the group's handles were destroyed");
     const int nl = (int)g->loc.size();
     const int RS = plspm_row_stride(g->loc[0].m);
     const int64_t cap = (B + g->nranks - 1) / g->nranks;
@@ -409,6 +424,7 @@ int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* it
 
 int plspm_group_barrier(plspm_group_t* g) {
     if (!g) return PLSPM_E_ARG;
+    if (g->loc.empty()) return gfail(g, PLSPM_E_STATE, "the group's handles were destroyed");
     int rc = sync_all(g);
     if (rc || !g->use_rccl) return rc;
     const Rccl* r = &g_rccl;
@@ -424,6 +440,7 @@ int plspm_group_barrier(plspm_group_t* g) {
 
 int plspm_group_max(plspm_group_t* g, double* value) {
     if (!g || !value) return PLSPM_E_ARG;
+    if (g->loc.empty()) return gfail(g, PLSPM_E_STATE, "the group's handles were destroyed");
     if (!g->use_rccl || (int)g->loc.size() == g->nranks) return 0;         // every rank lives in this process: the caller's value is the job's
     const Rccl* r = &g_rccl;
     Local& l = g->loc[0];

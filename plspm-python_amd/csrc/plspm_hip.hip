@@ -288,6 +288,7 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
 
 void plspm_model_destroy(plspm_model_t* m) {
     if (!m) return;
+    if (m->group) plspm_detail_group_orphan(m->group);                                // host objects die in arbitrary order
     if (m->stage2) { m->stage2->stage1 = nullptr; m->stage2->stream = nullptr; }      // the pair is dissolved; the survivor is inert
     if (m->stage1) m->stage1->stage2 = nullptr;
     hipSetDevice(m->device);

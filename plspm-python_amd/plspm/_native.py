@@ -391,7 +391,13 @@ class NativeComm:
         if not self._h:
             raise NativeBackendError("plspm_comm_create: " + lib.plspm_group_last_error(None).decode())
         self.uses_rccl = bool(lib.plspm_comm_uses_rccl(self._h))
+        self._bound = None              # weak reference to the group this communicator currently serves (one at a time)
         _live_comms.add(self)
+
+    def busy(self):
+        """True while a live group is bound to this communicator (plspm_group_create refuses a second one)."""
+        g = self._bound() if self._bound is not None else None
+        return g is not None and bool(getattr(g, "_h", None))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -422,6 +428,7 @@ class NativeGroup:
         self.nranks = lib.plspm_group_size(self._h)
         self.row_width, self.row_stride = self.models[0].row_width, self.models[0].row_stride
         self.last_B = 0
+        comm._bound = weakref.ref(self)
         _live_groups.add(self)
 
     def _check(self, rc, what):

@@ -47,11 +47,12 @@ _local_comms = {}
 
 def local_comm(devices):
     """The process-wide communicator over ``devices`` (created on first use: librccl load + ncclCommInitAll take of the order
-    of a second, every later bootstrap re-uses it)."""
+    of a second, every later bootstrap re-uses it).  A communicator serves one group at a time: while the bootstrap of an earlier
+    ``Plspm`` object is still alive on the cached one, the caller gets a communicator of its own (which becomes the cached one)."""
     from plspm import _native
     key = tuple(int(d) for d in devices)
     comm = _local_comms.get(key)
-    if comm is None or not comm._h:
+    if comm is None or not comm._h or comm.busy():
         comm = _native.NativeComm(key)
         _local_comms[key] = comm
     return comm

@@ -34,6 +34,22 @@ def _normalise_arguments(scheme, iterations, tolerance, bootstrap_iterations, pr
     return iterations, bootstrap_iterations
 
 
+class _Lazy:
+    """Builds its object on first use and then stands in for it (attribute access is forwarded)."""
+
+    def __init__(self, build):
+        self._build, self._obj = build, None
+
+    def get(self):
+        if self._obj is None:
+            self._obj = self._build()
+            self._build = None
+        return self._obj
+
+    def __getattr__(self, name):
+        return getattr(self.get(), name)
+
+
 class Plspm:
     """PLS path model estimator.
 
@@ -62,31 +78,35 @@ class Plspm:
             if n_obs < 10:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
             # the handle of the fit already holds the data in HBM: the replicates are enqueued on it NOW (HOC models: on a two-stage
-            # handle pair), so that the GPU resamples and solves while the host builds the result frames below
+            # handle pair), so that the GPU resamples and solves while the host does whatever is left to do
             boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
             pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed)
         self._result = fit
-        self._scores = fit.scores()
-        self._inner_model = im.InnerModel.from_device(model_spec.path(), fit)
-        r2 = self._inner_model.r_squared()
-        self._outer_model = om.OuterModel(fit, r2)
-        self._inner_summary = pis.InnerSummary(model_spec, r2, self._inner_model.r_squared_adj(), self._outer_model.model())
+        # The report frames only re-label / post-process the device outputs already on the host (fit.raw); they are built on first
+        # access (the reference builds them eagerly, plspm.py:69-77 -- same objects, same values, ~4 ms of pandas work per call that a
+        # caller who wants two of the nine accessors does not pay).
+        path = model_spec.path()
         incomplete = list(observations.columns[observations.isnull().values.any(axis=0)])        # one vectorised pass, not one per column
-        self._unidimensionality = Unidimensionality(model_spec, fit, incomplete)
+        self._scores = _Lazy(fit.scores)
+        self._inner_model = _Lazy(lambda: im.InnerModel.from_device(path, fit))
+        self._outer_model = _Lazy(lambda: om.OuterModel(fit, self._inner_model.r_squared()))
+        self._inner_summary = _Lazy(lambda: pis.InnerSummary(model_spec, self._inner_model.r_squared(), self._inner_model.r_squared_adj(),
+                                                             self._outer_model.model()))
+        self._unidimensionality = _Lazy(lambda: Unidimensionality(model_spec, fit, incomplete))
         self._bootstrap = None
         t_fit = time.perf_counter()
         if bootstrap:
             self._bootstrap = Bootstrap(model_spec, observations, self._inner_model, self._outer_model, calculator,
                                         bootstrap_iterations, processes, pending=pending)
-        # fit_s: filter + upload + device fit + frames; bootstrap_s: what the bootstrap adds after the frames exist (mostly the device
-        # summaries: the replicates ran under the frame building); bootstrap_latency_s: enqueue of the replicates -> summaries on the host
+        # fit_s: filter + upload + device fit; bootstrap_s: what the bootstrap adds (the wait for the replicates + the device summaries);
+        # bootstrap_latency_s: enqueue of the replicates -> summaries on the host
         self._timings = {"fit_s": t_fit - t_start, "bootstrap_s": time.perf_counter() - t_fit,
                          "bootstrap_latency_s": self._bootstrap.latency_s if self._bootstrap is not None else 0.0}
 
     # ---- accessors (names and return shapes of reference plspm/plspm.py:84-169) -------------------------------
     def scores(self) -> pd.DataFrame:
         """LV scores, N x L: index = the input data's index, columns = LVs in path-matrix order."""
-        return self._scores
+        return self._scores.get()
 
     def outer_model(self) -> pd.DataFrame:
         """Per MV (alphabetical index): weight, loading, communality, redundancy."""

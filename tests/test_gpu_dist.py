@@ -173,3 +173,42 @@ def test_config4_40000_replicates_properties_and_sharding_invariance():
     np.testing.assert_allclose(table[:, 2], mono[0].std(axis=0, ddof=1), rtol=1e-9, atol=1e-14)
     np.testing.assert_allclose(table[:, 3], np.quantile(mono[0], 0.025, axis=0), rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(table[:, 4], np.quantile(mono[0], 0.975, axis=0), rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("kind", ["metric", "nonmetric"])
+def test_plspm_processes_shards_over_handles_with_identical_results(kind, monkeypatch):
+    """Plspm(..., processes=k) = k GPUs of this process (reference: k forked workers, plspm.py:35-37, bootstrap.py:89-94).  The box has
+    one GPU, so the device list is forced to [0, 0]: the fit's handle builder replicates model + data on the 'second GPU', the two
+    handles form a group, and every summary frame equals the single-handle result (same seed)."""
+    import pandas as pd
+    import plspm.config as c
+    from plspm import parallel
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    from helpers import satisfaction_frame
+    sat = satisfaction_frame()
+
+    def run(processes):
+        s = c.Structure()
+        s.add_path(["IMAG"], ["EXPE", "SAT", "LOY"]); s.add_path(["EXPE"], ["QUAL", "VAL", "SAT"])
+        s.add_path(["QUAL"], ["VAL", "SAT"]); s.add_path(["VAL"], ["SAT"]); s.add_path(["SAT"], ["LOY"])
+        cfg = c.Config(s.path(), scaled=True, default_scale=Scale.NUM if kind == "nonmetric" else None)
+        for lv in ["IMAG", "EXPE", "QUAL", "VAL", "SAT", "LOY"]:
+            cfg.add_lv_with_columns_named(lv, Mode.A, sat, lv.lower())
+        return Plspm(sat, cfg, Scheme.PATH, bootstrap=True, bootstrap_iterations=2400, processes=processes, seed=21).bootstrap()
+    single = run(1)
+    assert single._group is None
+    monkeypatch.setattr(parallel, "devices_for", lambda processes, replicates, first_device=0: [0] * min(int(processes), 2))
+    double = run(2)
+    assert double._group is not None and len(double._helpers) == 1 and double._group.nranks == 2
+    for name in ("weights", "r_squared", "total_effects", "paths", "loading"):
+        a, b = getattr(single, name)(), getattr(double, name)()
+        assert list(a.index) == list(b.index)
+        np.testing.assert_array_equal(a.values, b.values, err_msg=name)
+    assert np.array_equal(single.replicates(), double.replicates()) and single.used() == double.used() == 2400
+    # a second multi-GPU bootstrap while the first one's group still holds the cached communicator gets a communicator of its own
+    again = run(2)
+    assert again._group is not None and again._group.comm is not double._group.comm and double._group.comm.busy()
+    assert np.array_equal(again.replicates(), double.replicates())
