@@ -12,8 +12,11 @@ inside the timed region.  Rank 0 prints one JSON line.  No torch: under `python 
 only spawns the ranks (RANK / LOCAL_RANK / WORLD_SIZE); without a launcher `--gpus N` drives N GPUs from this process.
 
 Extra objects on the line:
-  roofline      dominant kernel (fp64-MFMA weighted Gram), duration measured with HIP events on the library's own
-                stream during the timed steps; algorithmic work per replicate per SURVEY.md 8(d)
+  roofline      dominant kernel, duration measured with HIP events on the library's own stream during the timed steps.  Default path:
+                gram_i8_kernel<7> -- the batch's moment matrices as ONE exact int8 MFMA product of the dense resample
+                multiplicities with the 7 base-256 digit planes of the pair products x_p x_q (csrc/kernels_gram_i8.h); its
+                algorithmic work is 2 N (P+1)(P+2)/2 7 int8 ops per replicate.  --gram-path 1: the fp64 MFMA Gram of round 1
+                (gram_rows_kernel<4,false>, SURVEY.md 8(d) flops).  `fp64_mfma_path` on the line = the same workload on that path.
   api_inclusive replicates/s a user of the drop-in API sees: wall of Plspm(data, config, Scheme.PATH, bootstrap=True,
                 bootstrap_iterations=5000) minus the wall of the same call without the bootstrap (N = 1 only)
   cpu_baseline  the NumPy oracle (oracle/plspm_oracle.py, a port of the reference arithmetic) timed on this box's
@@ -34,6 +37,9 @@ N_OBS, MVS_PER_LV, N_LV = 10000, 10, 6
 REPS_PER_GPU = 5000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet fp64 matrix; 77.9 TF measured with v_mfma_f64_16x16x4_f64 (tools/ubench)
+I8_MFMA_PEAK_TOPS = 5033.0     # dense int8 matrix peak: 1,024 SIMDs x 2,048 ops/clk x 2.4 GHz = 2 x the ~2.5 PF bf16 dense peak of
+                               # MI355X_MICROARCH.md (its table has no int8 spec entry; measured ceilings there: 3,944 TOP/s with
+                               # 16x16x64, 4,404 with 32x32x32)
 
 
 def synth_inputs():
@@ -152,6 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
+    ap.add_argument("--gram-path", type=int, default=0, choices=[0, 1, 2], help="0 library default (int8 digit planes), 1 fp64 MFMA Gram, 2 int8 digit planes")
     args = ap.parse_args()
 
     from plspm import _native, parallel
@@ -175,6 +182,8 @@ def main():
     def make_model(device):
         mdl = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, device)
         mdl.upload(X)                                          # X resident in HBM before the timed region
+        if args.gram_path:
+            mdl.set_option("gram_path", args.gram_path)
         return mdl
 
     models = [make_model(d) for d in devices]
@@ -261,22 +270,70 @@ def main():
         gram_ms, gram_n = model.profile_read("gram")
         res_ms, res_n = model.profile_read("resample")
         sol_ms, sol_n = model.profile_read("solver")
+        used_path = model.get_option("last_gram_path")
         reps_per_launch = args.reps_per_gpu
         a_rep = 8.0 * N_OBS * 60 + 4.0 * N_OBS                 # one gathered read of X + the index vector
         f_rep = float(N_OBS) * 60 * 61                         # symmetric Gram flops
         gram_avg_ms = gram_ms / max(gram_n, 1)
         hbm_achieved = a_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e9
-        mfma_achieved = f_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        for name in ("r02_gram_traffic.json", "r01_gram_traffic.json"):
-            prof_json = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(prof_json):
-                try:
-                    traffic = json.load(open(prof_json)).get("hbm_bytes_per_launch")
-                    traffic_src = "static: profiles/%s (rocprofv3 --pmc passes of this command; PMC counters cannot be read from inside the bench)" % name
-                    break
-                except Exception:
-                    traffic = None
+        f64_equiv = f_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
+
+        def static_traffic(names):
+            for name in names:
+                prof_json = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(prof_json):
+                    try:
+                        return (json.load(open(prof_json)).get("hbm_bytes_per_launch"),
+                                "static: profiles/%s (rocprofv3 --pmc passes of this command; PMC counters cannot be read from inside the bench)" % name)
+                    except Exception:
+                        pass
+            return None, None
+        timing_note = ("HIP events on the handle's stream over the timed region (single stream: the kernel alone)" if profiled else
+                       "HIP events on the handle's stream over a calibration pass of the same launches without the overlapping collective")
+        if used_path == 2:
+            slices = model.get_option("i8_slices")
+            npair = 61 * 62 // 2                               # unordered pairs of the 60 columns + the ones column
+            ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
+            achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
+            traffic, traffic_src = static_traffic(("r02_gram_i8_traffic.json",))
+            roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "kernel": "gram_i8_kernel<%d>" % slices, "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
+                        "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",
+                        "algorithmic_ops_per_replicate": ops_rep,
+                        "algorithmic_ops_derivation": "2 x N rows x %d pair columns x %d digit planes (SURVEY 8(d)'s N P (P+1) fp64 flops = %.4g per replicate, "
+                                                      "each fp64 multiply-add carried by %d exact int8 ones)" % (npair, slices, f_rep, slices),
+                        "fp64_equivalent": {"achieved": round(f64_equiv, 1), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(f64_equiv / FP64_MFMA_PEAK_TF, 3),
+                                            "note": "SURVEY 8(d) flops per replicate / the kernel's time, against the fp64 matrix peak the round-1 kernel ran at 0.95 of"},
+                        "algorithmic_bytes_per_replicate": a_rep,
+                        "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}}
+        else:
+            traffic, traffic_src = static_traffic(("r02_gram_traffic.json", "r01_gram_traffic.json"))
+            roofline = {"bound": "mfma", "achieved": round(f64_equiv, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(f64_equiv / FP64_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
+                        "algorithmic_flops_per_replicate": f_rep, "algorithmic_bytes_per_replicate": a_rep,
+                        "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}}
+        other = None
+        if world == 1 and group is None and used_path == 2:
+            # the same workload on the fp64 MFMA Gram (round 1's dominant kernel), for the record
+            alt = make_model(devices[0])
+            alt.set_option("gram_path", 1)
+            for k in range(3):
+                alt.bootstrap_device(B_total, seed=1, rep_offset=k * B_total)
+            alt.sync()
+            alt.profile(True); alt.profile_reset()
+            t1 = time.perf_counter()
+            for k in range(10):
+                alt.bootstrap_device(B_total, seed=1, rep_offset=(3 + k) * B_total)
+            alt.sync()
+            dt = (time.perf_counter() - t1) / 10
+            alt.profile(False)
+            g_ms, g_n = alt.profile_read("gram")
+            tf = f_rep * reps_per_launch / (g_ms / max(g_n, 1) * 1e-3) / 1e12
+            other = {"value": round(B_total / dt, 1), "unit": "replicates/s", "ms_per_step": round(dt * 1e3, 4), "kernel": "gram_rows_kernel<4,false>",
+                     "gram_avg_launch_ms": round(g_ms / max(g_n, 1), 4), "roofline_frac": round(tf / FP64_MFMA_PEAK_TF, 4),
+                     "note": "10 steps of the same batch with set_option('gram_path', 1): fp64 MFMA Gram over (row,count) lists; frac = SURVEY 8(d) flops / 78.6 TFLOP/s"}
         parallelism = ("one process, one GPU, no collective" if group is None else
                        "replicate-sharded x%d (%s), ONE ncclAllGather per step issued by libplspm_hip.so on a gather stream "
                        "(overlaps the next step's kernels; records double-buffered)" % (world, "one process per GPU" if launched else "one process, %d GPUs" % world))
@@ -288,22 +345,20 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "dtype_note": ("fp64 data, moments and solver; the batch Gram is evaluated as an exact int8 x int8 -> int32 product on the base-256 digit "
+                           "planes of the fp64 products (>= 53 bits of each column's largest product): results agree with the fp64 MFMA path to "
+                           "1e-10 and sit closer to the exactly rounded sums than it does (tests/test_gpu_gram_i8.py)") if used_path == 2 else "fp64 throughout",
             "config": {"workload": "synthetic 10,000 obs x 60 MVs x 6 LVs, Mode A, Scheme.PATH, scaled, %d bootstrap replicates per GPU "
                                    "(BASELINE.json configs[2]; %d GPUs x %d = configs[3] at 8); on-device Philox resampling, a fresh replicate-id "
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
                        "parallelism": parallelism, "transport": ("rccl" if (comm is not None and comm.uses_rccl) else "none")},
-            "roofline": {"bound": "mfma", "achieved": round(mfma_achieved, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(mfma_achieved / FP64_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n,
-                         "note": ("HIP events on the handle's stream over the timed region (single stream: the kernel alone)" if profiled else
-                                  "HIP events on the handle's stream over a calibration pass of the same launches without the overlapping collective"),
-                         "algorithmic_flops_per_replicate": f_rep, "algorithmic_bytes_per_replicate": a_rep,
-                         "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}},
+            "roofline": roofline,
             "kernels_ms_per_step": {"resample": round(res_ms / max(res_n, 1), 4), "gram": round(gram_avg_ms, 4),
                                     "solver": round(sol_ms / max(sol_n, 1), 4)},
         }
+        if other is not None:
+            line["fp64_mfma_path"] = other
         if pcie is not None:
             line["pcie_inclusive"] = {"value": round(pcie, 1), "unit": "replicates/s",
                                       "note": "plspm_bootstrap(): the B x 158 records copied to a pageable host buffer through pinned staging every step"}

@@ -73,8 +73,16 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
  *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
  *   "scores_tile"     0 (by LDS footprint) | 16 | 32   rows per tile of the scores kernel
+ *   "gram_path"       0 auto | 1 fp64 MFMA Gram over (row,count) lists | 2 int8 digit-plane Gram (exact integer product of the dense
+ *                     multiplicities with the base-256 digit planes of the pair products x_p x_q; bootstrap of metric models whose
+ *                     planes fit the memory budget, N <= 65,535; other models always take path 1)
+ *   "i8_slices"       5 .. 8   digit planes per pair product (default 7: >= 53 significant bits of the column maximum)
+ *   "i8_min_batch"    auto mode takes the int8 path from this many replicates per call (default 1: always -- the path must not
+ *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
+ * plspm_model_get_option reads a value back; the read-only key "last_gram_path" tells which Gram the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
+int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value);
 
 /*
  * Compile a model specification (reference Config + path matrix + Plspm kwargs, plspm/config.py:89-160,
@@ -330,6 +338,12 @@ int plspm_group_max(plspm_group_t* g, double* value);
  */
 int plspm_op_inner_weights(int32_t device_id, int32_t scheme, int32_t L, const uint8_t* path, const double* y, int64_t N, double* E);
 int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, const double* z, int64_t N, int32_t k, double* w);
+
+/* Test seam: only the resample + Gram stages of plspm_bootstrap (on the Gram path the handle's "gram_path" option selects).
+ *   idx   NULL (on-device Philox draws) or [B*N] explicit row indices;   out [B * C * C], C = device columns + 1 (after the data
+ *   columns the missing indicators of plspm_model_set_missing, last the ones column): the replicate's full symmetric matrix
+ *   sum_i c_i [x_i - shift, 1][x_i - shift, 1]' of the uploaded (mean-shifted) columns.  Metric handles only. */
+int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out);
 
 /* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);

@@ -1,0 +1,330 @@
+// kernels_gram_i8.h -- Device kernels, part 2b: the weighted Gram of a bootstrap BATCH as one exact int8 MFMA product.
+// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+//
+// Why.  Every replicate's moment matrix is M_b[p,q] = sum_i c_bi x_ip x_iq with the SAME data and small integer multiplicities
+// c_bi (how often row i was drawn).  Over a batch that is a matrix product  M[b, (p,q)] = C[b, i] . Z[i, (p,q)],  Z[i,(p,q)] =
+// x_ip x_iq (one column per unordered pair incl. the ones column, built once per data set).  C is EXACTLY int8.  Z is fp64 -- but
+// cut into S balanced base-256 digits relative to the largest |z| of its column,
+//     z_i 2^k = sum_s d_is 256^s,   d_is in [-128, 127],   k = 8S - 2 - exponent(max_i |z_i|),
+// every digit plane is int8 too, and  sum_i c_bi d_is  is an exact int32 dot product (|.| <= 128 N, N <= 2^24).  The fp64 matrix
+// pipe of MI355X peaks at 78.6 TFLOP/s, the int8 one at ~5,000 TOP/s: S = 7 digit planes (>= 53 significant bits of the column
+// maximum; the sum itself is exact, only the final int -> fp64 conversion rounds) cost 7 int8 MACs per fp64 MAC and still run several
+// times faster than v_mfma_f64.  The result is MORE accurate than the fp64 accumulation chain (which rounds after every one of
+// its ~6,300 additions); tools/experiments/slice_poc.py and tests/test_gpu_gram_i8.py compare both with exact rational sums.
+// This is the error-free-transformation (Ozaki-style) scheme with the simplification that one operand needs no splitting.
+//
+// Layout ("fragment-major", both operands).  v_mfma_i32_16x16x64_i8 takes, per lane l, 16 consecutive k of row (l & 15) for A and
+// of column (l & 15) for B, k-group l >> 4.  Both matrices are stored as 1 KB blocks [k-block of 64][16-row tile][g 0..3][r 0..15]
+// [16 B]: the block of (k-block kb, tile t) is exactly the 64 x 16 B a wave loads for one operand fragment, lane l reads its 16
+// bytes at offset 16 l (conflict-free ds_read_b128), and the blocks a workgroup needs for one k-step are contiguous in memory
+// (16 KB of counts, 2 S KB of digit planes), so global -> LDS is a linear copy.
+//   Cd: counts,  block index kb * MT + mt   (mt = replicate / 16, r = replicate % 16)
+//   Zs: digits,  block index kb * NT + nt   (nt = pair_group * S + s, r = pair % 16)
+#pragma once
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------- digit planes of the pair products
+// k_j and 2^-k_j of every pair column j = (p, q): one workgroup per pair.
+__global__ void __launch_bounds__(256) zs_scale_kernel(const double* __restrict__ Xa, long N, int PA, const int* __restrict__ pair_p, const int* __restrict__ pair_q,
+                                                        int S, int* __restrict__ pair_k, double* __restrict__ pair_scale) {
+    __shared__ double red[256];
+    const int j = blockIdx.x, p = pair_p[j], q = pair_q[j];
+    double mx = 0.0;
+    bool bad = false;
+    for (long i = threadIdx.x; i < N; i += 256) {
+        const double z = Xa[i * PA + p] * Xa[i * PA + q];
+        if (!(fabs(z) <= 1.7976931348623157e308)) bad = true;          // NaN or Inf
+        mx = fmax(mx, fabs(z));
+    }
+    red[threadIdx.x] = bad ? __builtin_inf() : mx;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + h]); __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double zmax = red[0];
+        int k = 0;
+        double sc = 0.0;
+        if (!(zmax <= 1.7976931348623157e308)) sc = __builtin_nan("");       // non-finite data: the fp64 path would report NaN moments as well
+        else if (zmax > 0.0) {
+            int e;
+            (void)frexp(zmax, &e);                                           // zmax = f 2^e, f in [0.5, 1)
+            k = 8 * S - 2 - e;                                               // |z| 2^k < 2^(8S-2): the top digit stays inside int8
+            sc = ldexp(1.0, -k);
+        }
+        pair_k[j] = k;
+        pair_scale[j] = sc;
+    }
+}
+
+// Digit planes in fragment-major layout.  Thread (pgl, g, r) of workgroup (kb, y): pair 16 (4y + pgl) + r, rows 64 kb + 16 g .. + 15;
+// the 64 threads of one pair group write one contiguous 1 KB block per digit plane.
+template <int S>
+__global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict__ Xa, long N, int PA, const int* __restrict__ pair_p, const int* __restrict__ pair_q,
+                                                        const int* __restrict__ pair_k, int npair, int npg, int NT, uint4* __restrict__ Zs) {
+    const int tid = threadIdx.x, r = tid & 15, g = (tid >> 4) & 3, pg = (int)blockIdx.y * 4 + (tid >> 6);
+    if (pg >= npg) return;
+    const int kb = blockIdx.x, j = pg * 16 + r;
+    unsigned char dig[S][16];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dig[s][t] = 0;
+    if (j < npair) {
+        const int p = pair_p[j], q = pair_q[j], k = pair_k[j];
+        const long i0 = (long)kb * 64 + g * 16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const long i = i0 + t;
+            double z = 0.0;
+            if (i < N) z = Xa[i * PA + p] * Xa[i * PA + q];
+            long long v = (z == z && fabs(z) <= 1.7976931348623157e308) ? __double2ll_rn(ldexp(z, k)) : 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int d = (int)((v + 128) & 255) - 128;                   // balanced digit in [-128, 127]
+                v = (v - d) >> 8;
+                dig[s][t] = (unsigned char)(d & 255);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        uint4 w;
+        unsigned u[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[c] = (unsigned)dig[s][4 * c] | ((unsigned)dig[s][4 * c + 1] << 8) | ((unsigned)dig[s][4 * c + 2] << 16) | ((unsigned)dig[s][4 * c + 3] << 24);
+        w.x = u[0]; w.y = u[1]; w.z = u[2]; w.w = u[3];
+        Zs[((long)kb * NT + (long)pg * S + s) * 64 + g * 16 + r] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- resample -> dense int8 counts
+// One workgroup per replicate, the same Philox draws / explicit indices and the same 16-bit LDS histogram as resample_kernel; the
+// histogram leaves as bytes in fragment-major layout (16 consecutive rows = one 16-byte piece).  err bit 0: index out of range,
+// bit 1: a multiplicity above 127 (only possible with explicit indices; the host then falls back to the fp64 Gram).
+__global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
+                                                           int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KB * 32 words: rows 2w, 2w+1 in the halves of word w (zero beyond N)
+    const int tid = threadIdx.x;
+    const long b = blockIdx.x;
+    const int nwords = KB * 32;
+    for (int i = tid; i < nwords; i += 256) hist[i] = 0u;
+    __syncthreads();
+    if (idx) {
+        const int* my = idx + b * (long)N;
+        for (int i = tid; i < N; i += 256) {
+            const int r = my[i];
+            if ((unsigned)r < (unsigned)N) atomicAdd(&hist[r >> 1], (r & 1) ? 0x10000u : 1u);
+            else atomicOr(err, 1);
+        }
+    } else {
+        const uint64_t rep = (uint64_t)(rep0 + b);
+        const int nq = (N + 3) >> 2;
+        for (int q = tid; q < nq; q += 256) {
+            const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < N) { const unsigned r = to_index(u.v[j], (uint32_t)N); atomicAdd(&hist[r >> 1], (r & 1u) ? 0x10000u : 1u); }
+        }
+    }
+    __syncthreads();
+    const int mt = (int)(b >> 4), r = (int)(b & 15);
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist);
+    bool over = false;
+    for (int c = tid; c < KB * 4; c += 256) {                      // piece c: rows 16c .. 16c+15 = hist words 8c .. 8c+7
+        const uint4 lo = h4[2 * c], hi = h4[2 * c + 1];
+        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = w[2 * k], bb = w[2 * k + 1];
+            over |= ((a | bb) & 0xff80ff80u) != 0u;
+            o[k] = (a & 0xffu) | ((a >> 8) & 0xff00u) | ((bb & 0xffu) << 16) | ((bb << 8) & 0xff000000u);
+        }
+        uint4 out;
+        out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
+        const int kb = c >> 2, g = c & 3;
+        Cd[((long)kb * MT + mt) * 64 + g * 16 + r] = out;
+    }
+    if (over) atomicOr(err, 2);
+}
+
+// ---------------------------------------------------------------------------------------------- the GEMM
+// Workgroup tile: 256 replicates x 2 pair groups (32 pairs x S digit planes); 4 waves as 2 (replicate halves) x 2 (pair groups);
+// a wave keeps 8 x S accumulator tiles (S = 7: 224 AGPRs) -- one wave per SIMD, latency hidden inside the wave.
+// k-step = one k-block of 64 rows = 16 + 2S contiguous 1 KB blocks, brought in by LDS-DMA (global_load_lds_dwordx4: one wave
+// instruction = one block, no staging registers, no ds_write pass) into a ring of three LDS stages:
+//     iteration kb:   issue DMA of k-step kb+2 -> stage (kb+2)%3        (its last readers finished before the previous barrier)
+//                     s_waitcnt vmcnt(own DMAs of kb+2 may stay in flight) lgkmcnt(0);  s_barrier     -> k-step kb+1 is complete
+//                     ds_read the fragments of kb+1 (second register set)  } overlap
+//                     8 S MFMAs of k-step kb on the first register set     }
+// so a DMA has two iterations (~1,800 cycles) to land and the matrix pipe only ever waits at the barrier.  The DMA statements are
+// inline asm (hipcc would drain vmcnt(0) at every barrier for a builtin LDS-DMA); their completion is counted by hand: every wave
+// issues exactly PER blocks per k-step (the 16 + 2S blocks dealt round-robin; the last wave repeats a few -- identical bytes to the
+// same place), hence the constant vmcnt(PER).
+// Tiles are enumerated XCD-aware: workgroup id mod 8 is the XCD, each XCD walks a contiguous range of an enumeration whose
+// consecutive 32 tiles form a 4 (replicate tiles) x 8 (pair tiles) block, so an XCD's L2 serves 4 count chunks + 8 digit chunks
+// per k-step to its 32 resident workgroups.
+// Epilogue: lane (l & 15) owns pair 16 pg + (l & 15) in all S planes -> digits recombined in the lane (fp64 fma chain over exact terms, ~one ulp
+// rounding chain), scaled by 2^-k_j and stored at the element's slot of the tile-packed moment matrix the solvers read.
+template <int S>
+struct GramI8 {
+    static constexpr int NBLK = 16 + 2 * S;         // 1 KB blocks per k-step: 16 count tiles + 2 pair groups x S planes
+    static constexpr int PER = (NBLK + 3) / 4;      // DMA instructions per wave and k-step
+    static constexpr int STAGE_BYTES = NBLK * 1024;
+    static constexpr size_t LDS_BYTES = (size_t)3 * STAGE_BYTES;
+};
+
+// one LDS-DMA block: 64 lanes x 16 B from `base + voff` to LDS byte address `lds_dst` (wave-uniform) + 16 lane
+__device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
+               const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
+    using G = GramI8<S>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile enumeration
+    const int total = ntx * nty, per = (total + 7) >> 3;
+    const int w = blockIdx.x, slot = w >> 3;
+    const int gidx = (w & 7) * per + slot;
+    if (slot >= per || gidx >= total) return;
+    const int srow = 4 * ntx;
+    const int sr = gidx / srow, rem = gidx - sr * srow;
+    const int nr = min(4, nty - 4 * sr);
+    const int tx = rem / nr, ty = 4 * sr + (rem - tx * nr);
+
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_raw);
+    const unsigned voff = (unsigned)lane * 16u;
+    // this wave's PER blocks of a k-step: block b < 16 = count tile b of the workgroup's 16, else digit block b - 16 of its 2 S
+    const char* src[G::PER];
+    long inc[G::PER];
+    unsigned dst[G::PER];
+#pragma unroll
+    for (int i = 0; i < G::PER; ++i) {
+        const int b = (wave * G::PER + i) % G::NBLK;
+        const bool isA = b < 16;
+        src[i] = isA ? (const char*)(Cd + ((long)ty * 16 + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - 16)) * 64);
+        inc[i] = (isA ? (long)MT : (long)NT) * 1024;
+        dst[i] = lds0 + (unsigned)b * 1024u;
+    }
+    int ahead = KB - 1;                               // k-steps the source pointers may still advance (they stop at the last one:
+    auto issue = [&](unsigned stage_off) {            // a DMA past the end re-reads it, never used)
+#pragma unroll
+        for (int i = 0; i < G::PER; ++i) glds_block(src[i], voff, dst[i] + stage_off);
+        const bool more = ahead > 0;
+        --ahead;
+#pragma unroll
+        for (int i = 0; i < G::PER; ++i) src[i] += more ? inc[i] : 0;
+    };
+    // Fragment reads and MFMAs are asm statements (fixed order, nothing counted by the compiler):
+    //  * accumulators constrained to AGPRs ("+a"): with the builtin hipcc kept a third of the 224 accumulator registers in VGPRs and
+    //    copied them to and fro at every step (1,250 v_accvgpr moves in the loop);
+    //  * ds_read_b128 of the NEXT k-step's fragments interleaved with the MFMAs of this one; their one wait is the lgkmcnt(0) in
+    //    front of the next barrier (~900 cycles later), which names the registers "+v" so that nothing the compiler does with them
+    //    can move above it -- compiler-issued LDS loads got an s_waitcnt lgkmcnt(0) in front of the first MFMA of every step;
+    //  * an accumulator is touched once per k-step, so no MFMA depends on a neighbour; the epilogue reads them after the nops below.
+    i32x4 acc[8][S];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[mt][s] = (i32x4){0, 0, 0, 0};
+    const unsigned fbaseA = voff + (unsigned)wm * 8192u, fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
+#define GI8_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(off))
+#define GI8_MFMA(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+    // one k-step: MFMAs on (fc, fd), fragment reads of the following k-step from LDS stage R into (fna, fnb)
+    auto step = [&](i32x4 (&fc)[8], i32x4 (&fd)[S], i32x4 (&fna)[8], i32x4 (&fnb)[S], unsigned Roff) {
+        const unsigned ra = fbaseA + Roff, rb = fbaseB + Roff;
+        int nread = 0;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                GI8_MFMA(acc[mt][s], fc[mt], fd[s]);
+                if ((mt * S + s) % 3 == 0 && nread < 8 + S) {
+                    if (nread < 8) GI8_DSREAD(fna[nread], ra, nread * 1024);
+                    else GI8_DSREAD(fnb[nread - 8], rb, (nread - 8) * 1024);
+                    ++nread;
+                }
+            }
+    };
+    // wait for this wave's DMAs of the k-step after next to be the only ones in flight and for the fragment reads of the set that
+    // is consumed next; then the workgroup barrier: every wave's share of the next k-step has landed
+    auto wait_barrier = [&](i32x4 (&fa)[8], i32x4 (&fb)[S]) {
+        if constexpr (S == 5)
+            asm volatile("s_waitcnt vmcnt(%13) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
+                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]) : "i"(G::PER) : "memory");
+        else if constexpr (S == 6)
+            asm volatile("s_waitcnt vmcnt(%14) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
+                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]) : "i"(G::PER) : "memory");
+        else if constexpr (S == 7)
+            asm volatile("s_waitcnt vmcnt(%15) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
+                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]) : "i"(G::PER) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%16) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
+                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7]) : "i"(G::PER) : "memory");
+    };
+
+    i32x4 fa0[8], fb0[S], fa1[8], fb1[S];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { fb0[i] = (i32x4){0, 0, 0, 0}; fb1[i] = fb0[i]; }
+    issue(0);
+    issue(G::STAGE_BYTES);
+    wait_barrier(fa1, fb1);                                   // k-step 0 has landed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
+#pragma unroll
+    for (int i = 0; i < S; ++i) GI8_DSREAD(fb0[i], fbaseB, i * 1024);
+    unsigned R = G::STAGE_BYTES, L = 2 * G::STAGE_BYTES;      // stage holding k-step kb+1 / stage receiving k-step kb+2
+    // KB is even (the host pads the rows to whole pairs of k-blocks): two steps per trip, the fragment sets swap roles
+    for (int kb = 0; kb < KB; kb += 2) {
+        issue(L);
+        wait_barrier(fa0, fb0);
+        step(fa0, fb0, fa1, fb1, R);
+        R = L;
+        L = (L == 2 * G::STAGE_BYTES) ? 0u : L + G::STAGE_BYTES;
+        issue(L);
+        wait_barrier(fa1, fb1);
+        step(fa1, fb1, fa0, fb0, R);
+        R = L;
+        L = (L == 2 * G::STAGE_BYTES) ? 0u : L + G::STAGE_BYTES;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> readable
+#undef GI8_DSREAD
+#undef GI8_MFMA
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // no DMA may land after the workgroup has gone
+#undef GI8_WAIT_BARRIER
+
+    const int j = (tx * 2 + wn) * 16 + (lane & 15);
+    if (j >= npair) return;
+    const long dstj = pair_dst[j];
+    const double sc = pair_scale[j];
+    const long rep0 = (long)ty * 256 + wm * 128 + (lane >> 4) * 4;
+    double* gp = gram + rep0 * psize + dstj;           // walks the replicates of this lane; opaque to the compiler so that it does not
+#pragma unroll                                         // precompute (and spill) 32 addresses
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (rep0 + mt * 16 + reg < nrep) {
+                // sum_s acc_s 256^s from the low planes up: every term is exact in fp64, the partial sums round only once they
+                // pass 2^53 (relative 2^-53 each): the recombination costs about one ulp
+                double v = (double)acc[mt][0][reg];
+#pragma unroll
+                for (int s = 1; s < S; ++s) v = fma((double)acc[mt][s][reg], (double)(1ll << (8 * s)), v);
+                *gp = v * sc;
+            }
+            gp += psize;
+            asm volatile("" : "+v"(gp)::"memory");
+        }
+        gp += 12 * psize;
+    }
+}

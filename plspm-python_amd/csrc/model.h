@@ -82,7 +82,15 @@ struct plspm_model {
     Buf xa, up_raw, up_ci, up_partial;   // resident matrix (d_Xa points into `xa` while data are uploaded) and the upload staging
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
-    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0; } tune;
+    struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
+                  int gram_path = 0, i8_slices = 7, i8_min_batch = 1; } tune;
+    // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
+    // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
+    Buf zs, cd, pair_tab, pair_scale;
+    bool zs_valid = false;
+    int zs_S = 0, zs_KB = 0, zs_NT = 0, zs_npair = 0, zs_npg = 0;
+    double* moments_out = nullptr; // plspm_bootstrap_moments: dense moment matrices go here and the solver is skipped
+    int last_gram_path = 0;       // 1 fp64 MFMA, 2 int8 digit planes: what the last bootstrap call used (plspm_model_get_info)
     // grow-only pinned host staging for uploads / row downloads (two halves: copy-in of chunk k+1 overlaps the DMA of chunk k)
     void* h_pin = nullptr;
     size_t h_pin_cap = 0;

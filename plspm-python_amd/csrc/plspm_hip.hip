@@ -34,6 +34,7 @@ __host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a
 
 #include "kernels_input.h"
 #include "kernels_gram.h"
+#include "kernels_gram_i8.h"
 #include "kernels_solver.h"
 #include "kernels_nonmetric.h"
 #include "kernels_post.h"
@@ -297,7 +298,8 @@ void plspm_model_destroy(plspm_model_t* m) {
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
-                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p};
+                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p,
+                    m->zs.p, m->cd.p, m->pair_tab.p, m->pair_scale.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -334,7 +336,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     HIPCHK(m, hipSetDevice(m->device));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
-    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->rows_B = 0; m->dcnt_ready = false;
+    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
     drop_incomplete_rows(m);
     // persistent grow-only buffers: a repeated upload of the same shape allocates nothing
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
@@ -655,8 +657,30 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "conv_pass") { if (value < 0 || value > 2) return bad(); m->tune.conv_pass = value; }
     else if (k == "scores_tile") { if (value != 0 && value != 16 && value != 32) return bad(); m->tune.scores_tile = value; }
     else if (k == "gram_lds_kb") { if (value < 0 || value > 160) return bad(); m->tune.gram_lds_kb = value; }
+    else if (k == "gram_path") { if (value < 0 || value > 2) return bad(); m->tune.gram_path = value; }
+    else if (k == "i8_slices") { if (value < 5 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
+    else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
+    return 0;
+}
+
+int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value) {
+    if (!m || !key || !value) return PLSPM_E_ARG;
+    const std::string k(key);
+    if (k == "solver_threads") *value = m->tune.solver_threads;
+    else if (k == "nm_threads") *value = m->tune.nm_threads;
+    else if (k == "fit_chunks") *value = m->tune.fit_chunks;
+    else if (k == "wide_nw") *value = m->tune.wide_nw;
+    else if (k == "conv_pass") *value = m->tune.conv_pass;
+    else if (k == "scores_tile") *value = m->tune.scores_tile;
+    else if (k == "gram_lds_kb") *value = m->tune.gram_lds_kb;
+    else if (k == "conv_gy") *value = m->tune.conv_gy;
+    else if (k == "gram_path") *value = m->tune.gram_path;
+    else if (k == "i8_slices") *value = m->tune.i8_slices;
+    else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
+    else if (k == "last_gram_path") *value = m->last_gram_path;
+    else return PLSPM_E_ARG;
     return 0;
 }
 
@@ -897,6 +921,100 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
 
 }  // extern "C"
 
+// dense [C x C] symmetric moment matrix of every replicate out of the tile-packed one (plspm_bootstrap_moments)
+__global__ void __launch_bounds__(256) moments_unpack_kernel(const double* __restrict__ gram, long psize, int T, int C, double* __restrict__ out) {
+    const double* g = gram + (long)blockIdx.x * psize;
+    double* o = out + (long)blockIdx.x * C * C;
+    for (int e = threadIdx.x; e < C * C; e += 256) { const int p = e / C, q = e - p * C; o[e] = g[packed_index(T, p, q)]; }
+}
+
+// ------------------------------------------------------------------------------------------------ int8 digit-plane Gram (kernels_gram_i8.h)
+static constexpr size_t kZsBudget = (size_t)24 << 30;       // digit planes of one data set: at most 24 GiB of the 288 GiB
+static inline int i8_kblocks(long N) { return (int)((N + 127) / 128) * 2; }      // k-blocks of 64 rows, an even number
+static inline long i8_pairs(const plspm_model* m) { const long C = m->Pg + 1; return C * (C + 1) / 2; }
+// Which Gram a bootstrap call of B replicates takes: 1 = fp64 MFMA on the (row,count) lists, 2 = int8 digit planes.
+static int choose_gram_path(const plspm_model* m, int64_t B) {
+    if (m->tune.gram_path == 1) return 1;
+    // plain metric models (complete or mean-imputed data): the solver needs nothing but the moment matrix.  The LDS histogram
+    // bounds N; int32 accumulators need 128 N < 2^31.
+    if (m->nonmetric || m->stage2 || m->stage1 || m->nmx_K || m->N > 65535 || m->N < 2) return 1;
+    const size_t zs_bytes = (size_t)i8_kblocks(m->N) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * m->tune.i8_slices) * 1024;
+    if (zs_bytes > kZsBudget) return 1;
+    if (m->tune.gram_path == 2) return 2;
+    return B >= m->tune.i8_min_batch ? 2 : 1;
+}
+
+// Digit planes + pair tables of the resident data (once per upload / digit count).
+static int prepare_zs(plspm_model* m) {
+    if (m->zs_valid) return 0;
+    const int S = m->tune.i8_slices, C = m->Pg + 1;
+    const long npair = i8_pairs(m);
+    const int npg = (int)((npair + 31) / 32) * 2;             // pair groups of 16, padded to whole workgroup tiles (two groups)
+    const int KB = i8_kblocks(m->N), NT = npg * S;
+    std::vector<int> tab(4 * (size_t)npair);
+    int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | slot]
+    long j = 0;
+    for (int p = 0; p < C; ++p)
+        for (int q = p; q < C; ++q, ++j) { hp[j] = p; hq[j] = q; hd[j] = (int)packed_index(m->T, p, q); }
+    int rc;
+    if ((rc = ensure(m, m->pair_tab, tab.size() * sizeof(int)))) return rc;
+    if ((rc = ensure(m, m->pair_scale, (size_t)npair * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->zs, (size_t)KB * NT * 1024))) return rc;
+    if ((rc = plspm_detail_h2d(m, m->pair_tab.p, tab.data(), tab.size() * sizeof(int)))) return rc;
+    int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
+    ProfScope ps(m, PLSPM_K_PACK);
+    hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)npair), dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, S, d_k, (double*)m->pair_scale.p);
+    const dim3 grid((unsigned)KB, (unsigned)((npg + 3) / 4));
+#define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, (uint4*)m->zs.p)
+    switch (S) { case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }
+#undef ZSB
+    HIPCHK(m, hipGetLastError());
+    m->zs_S = S; m->zs_KB = KB; m->zs_NT = NT; m->zs_npair = (int)npair; m->zs_npg = npg;
+    m->zs_valid = true;
+    return 0;
+}
+
+// Resample nb replicates into dense int8 counts and multiply with the digit planes: the nb moment matrices land at `out`.
+// Explicit indices can carry a multiplicity above 127 (Philox draws of N >= 128 rows cannot, P < 1e-200): the host looks at the
+// flag before the product and reports *fallback so that the caller takes the fp64 Gram for this chunk.
+static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool* fallback) {
+    *fallback = false;
+    const int S = m->zs_S, KB = m->zs_KB, NT = m->zs_NT;
+    const int nty = (int)((nb + 255) / 256), MT = nty * 16, ntx = m->zs_npg / 2;
+    const size_t hist_bytes = (size_t)KB * 32 * sizeof(unsigned);
+    int rc;
+    if ((rc = allow_lds(m, (const void*)resample_i8_kernel, hist_bytes))) return rc;
+    {
+        ProfScope ps(m, PLSPM_K_RESAMPLE);
+        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, d_idx, seed, rep0, (uint4*)m->cd.p, (int*)m->err.p);
+    }
+    if (d_idx) {
+        int* h_err = (int*)m->h_flag + 9;
+        HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (*h_err & 2) {
+            const int keep = *h_err & 1;
+            HIPCHK(m, hipMemcpyAsync(m->err.p, &keep, sizeof(int), hipMemcpyHostToDevice, m->stream));
+            HIPCHK(m, hipStreamSynchronize(m->stream));
+            *fallback = true;
+            return 0;
+        }
+    }
+    const int total = ntx * nty, per = (total + 7) / 8;
+    const int* d_dst = (const int*)m->pair_tab.p + 3 * (size_t)m->zs_npair;
+    ProfScope ps(m, PLSPM_K_GRAM);
+#define GI8(SS)                                                                                                                              \
+    {                                                                                                                                        \
+        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS>, GramI8<SS>::LDS_BYTES))) return rc;                                          \
+        hipLaunchKernelGGL((gram_i8_kernel<SS>), dim3((unsigned)(8 * per)), dim3(256), GramI8<SS>::LDS_BYTES, m->stream, (const uint4*)m->cd.p, \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, packed_size(m->T)); \
+    }
+    switch (S) { case 5: GI8(5) break; case 6: GI8(6) break; case 7: GI8(7) break; default: GI8(8) break; }
+#undef GI8
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
+
 int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, double* rows_out) {
     if (!m || B < 1 || rep_offset < 0 || B > ((int64_t)1 << 30)) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments (1 <= B <= 2^30, rep_offset >= 0)");
     if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
@@ -910,12 +1028,23 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // non-metric solvers: dense uint16 histograms for the dense stop-rule pass (LDS-histogram path only)
     const bool want_dcnt = m->nonmetric && lds_hist;
     const long dcnt_stride = ((N + 15) & ~15L);
-    const size_t per_rep = (size_t)ent_stride * sizeof(int2) + (size_t)psize * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
-                           (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0);
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
+    const int gpath = choose_gram_path(m, B);
+    m->last_gram_path = gpath;
+    const bool need_lists = gpath == 1 || d_idx != nullptr;           // the fp64 Gram walks (row,count) lists; explicit indices may fall back to it
+    const size_t kpad = (size_t)i8_kblocks(N) * 64;
+    const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)psize * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
+                           (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0);
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
+    if (gpath == 2 && chunk < B) chunk = std::max<int64_t>(256, chunk & ~(int64_t)255);      // whole 256-replicate tiles per pass
     int rc;
-    if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
-    if ((rc = ensure(m, m->nent, (size_t)chunk * sizeof(int)))) return rc;
+    if (gpath == 2) {
+        if ((rc = prepare_zs(m))) return rc;
+        if ((rc = ensure(m, m->cd, (size_t)((chunk + 255) / 256) * 256 * kpad))) return rc;
+    }
+    if (need_lists) {
+        if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
+        if ((rc = ensure(m, m->nent, (size_t)chunk * sizeof(int)))) return rc;
+    }
     if ((rc = ensure(m, m->gram, (size_t)chunk * psize * sizeof(double)))) return rc;
     if (!rows_out) {
         m->rows_B = 0;
@@ -931,21 +1060,32 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
-        if (lds_hist) {
-            const size_t hist_bytes = (size_t)((N + 1) / 2) * sizeof(unsigned);
-            if ((rc = allow_lds(m, (const void*)resample_kernel, hist_bytes))) return rc;
-            ProfScope ps(m, PLSPM_K_RESAMPLE);
-            hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)N,
-                               d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p,
-                               want_dcnt ? (unsigned short*)m->dcnt.p : (unsigned short*)nullptr, dcnt_stride);
-        } else {
-            ProfScope ps(m, PLSPM_K_RESAMPLE);
-            hipLaunchKernelGGL(resample_global_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (int)N, d_idx ? d_idx + b0 * N : nullptr, seed,
-                               rep_offset + b0, (unsigned*)m->ghist.p, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
+        bool f64_gram = gpath == 1;
+        if (gpath == 2) {
+            bool fallback = false;
+            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, (double*)m->gram.p, &fallback))) return rc;
+            f64_gram = fallback;
         }
-        {
+        if (f64_gram) {
+            if (lds_hist) {
+                const size_t hist_bytes = (size_t)((N + 1) / 2) * sizeof(unsigned);
+                if ((rc = allow_lds(m, (const void*)resample_kernel, hist_bytes))) return rc;
+                ProfScope ps(m, PLSPM_K_RESAMPLE);
+                hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)N,
+                                   d_idx ? d_idx + b0 * N : nullptr, seed, rep_offset + b0, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p,
+                                   want_dcnt ? (unsigned short*)m->dcnt.p : (unsigned short*)nullptr, dcnt_stride);
+            } else {
+                ProfScope ps(m, PLSPM_K_RESAMPLE);
+                hipLaunchKernelGGL(resample_global_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (int)N, d_idx ? d_idx + b0 * N : nullptr, seed,
+                                   rep_offset + b0, (unsigned*)m->ghist.p, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
+            }
             ProfScope ps(m, PLSPM_K_GRAM);
             if ((rc = launch_gram<false>(m, nb, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
+        }
+        if (m->moments_out) {                      // plspm_bootstrap_moments (test seam): the replicates' moment matrices, dense, no solver
+            const int C = m->Pg + 1;
+            hipLaunchKernelGGL(moments_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (const double*)m->gram.p, psize, m->T, C, m->moments_out + b0 * C * C);
+            continue;
         }
         SolverOut so{};
         so.row = rows_out + b0 * R; so.row_stride = R; so.status = (int*)m->status.p + b0; so.iters = (int*)m->iters.p + b0;
@@ -1211,6 +1351,35 @@ int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, co
         return done(fail(m, PLSPM_E_STATE, "plspm_op_outer_weights: launch / copy failed"));
     if (flag == 0.0) return done(fail(m, PLSPM_SINGULAR, "plspm_op_outer_weights: the Mode-B least squares did not converge"));
     return done(0);
+}
+
+int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out) {
+    if (!m || !out || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_moments: bad arguments");
+    if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_moments: no data uploaded");
+    if (m->nonmetric || m->stage1 || m->stage2) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_moments: metric handles only");
+    HIPCHK(m, hipSetDevice(m->device));
+    const int32_t* d_idx = nullptr;
+    int rc;
+    if (idx) {
+        const size_t bytes = (size_t)B * m->N * sizeof(int32_t);
+        if ((rc = ensure(m, m->idx, bytes))) return rc;
+        if ((rc = plspm_detail_h2d(m, m->idx.p, idx, bytes))) return rc;
+        d_idx = (const int32_t*)m->idx.p;
+    }
+    const size_t C = (size_t)m->Pg + 1, bytes = (size_t)B * C * C * sizeof(double);
+    double* d_out = nullptr;
+    HIPCHK(m, plspm_dmalloc((void**)&d_out, bytes));
+    m->moments_out = d_out;
+    rc = plspm_detail_bootstrap(m, B, seed, rep_offset, d_idx, nullptr);
+    m->moments_out = nullptr;
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, m->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+        if (e != hipSuccess) rc = fail(m, -(int)e, std::string("plspm_bootstrap_moments: ") + hipGetErrorString(e));
+    } else hipStreamSynchronize(m->stream);
+    plspm_dfree(d_out);
+    m->rows_B = 0;
+    return rc;
 }
 
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx) {

@@ -20,7 +20,7 @@ KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduc
 EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing", "plspm_model_attach_second_stage", "plspm_model_set_incomplete_rows",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset",
-           "plspm_model_set_option", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
+           "plspm_model_set_option", "plspm_model_get_option", "plspm_bootstrap_moments", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows",
            "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
@@ -97,7 +97,10 @@ def load():
     lib.plspm_profile_read.argtypes = [vp, i32, ctypes.POINTER(dbl), ctypes.POINTER(i64)]
     lib.plspm_profile_reset.argtypes = [vp]
     lib.plspm_model_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.plspm_model_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
+    lib.plspm_model_get_option.restype = ctypes.c_int
     lib.plspm_bootstrap_fetch.argtypes = [vp, i64, i64, vp, vp, vp]
+    lib.plspm_bootstrap_moments.argtypes = [vp, i64, u64, i64, vp, vp]
     lib.plspm_bootstrap_store.argtypes = [vp, vp, i64]
     lib.plspm_rccl_unique_id.argtypes = [vp]
     lib.plspm_comm_create.restype = vp
@@ -169,6 +172,7 @@ class NativeModel:
         if nonmetric:
             self._check(lib.plspm_model_set_nonmetric(self._h, 1), "plspm_model_set_nonmetric")
         self.P_out = self.P             # per-MV outputs: logical MVs (== device columns unless categorical)
+        self.n_upload_cols = self.P     # device columns of the resident matrix (+ missing indicators, set below)
         if categorical is not None:     # (mv_off, mv_kind): device columns are indicator-augmented, see plspm_model_set_categorical
             mv_off = np.ascontiguousarray(categorical[0], dtype=np.int32)
             mv_kind = np.ascontiguousarray(categorical[1], dtype=np.int32)
@@ -177,6 +181,7 @@ class NativeModel:
         if missing is not None:         # ind_of [P]: upload column of every incomplete data column's 0/1 missing indicator (else -1)
             ind_of = np.ascontiguousarray(missing, dtype=np.int32)
             self._check(lib.plspm_model_set_missing(self._h, int((ind_of >= 0).sum()), _ptr(ind_of)), "plspm_model_set_missing")
+            self.n_upload_cols = self.P + int((ind_of >= 0).sum())
         self.n_eff = lib.plspm_effect_pairs(self._h, None, None)
         ef = np.zeros(max(self.n_eff, 1), dtype=np.int32)
         et = np.zeros(max(self.n_eff, 1), dtype=np.int32)
@@ -264,6 +269,18 @@ class NativeModel:
         self.last_B = B
         return rows, status, iters
 
+    def bootstrap_moments(self, B, seed=0, rep_offset=0, idx=None):
+        """Test seam (plspm_bootstrap_moments): the replicates' moment matrices [B, C, C] of the uploaded columns + the ones column,
+        from the Gram path the ``gram_path`` option selects; no solver."""
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            if idx.shape != (B, self.N):
+                raise ValueError("idx must have shape (B, N)")
+        C = self.n_upload_cols + 1
+        out = np.empty((B, C, C))
+        self._check(self._lib.plspm_bootstrap_moments(self._h, B, seed, rep_offset, _ptr(idx), _ptr(out)), "plspm_bootstrap_moments")
+        return out
+
     def bootstrap_device(self, B, seed=0, rep_offset=0):
         """Enqueue B replicates; returns raw device pointers (rows, status, iters) owned by the handle."""
         d_out, d_st, d_it = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
@@ -306,6 +323,12 @@ class NativeModel:
     def set_option(self, key, value):
         """Launch-geometry option of the handle (include/plspm_hip.h, plspm_model_set_option)."""
         self._check(self._lib.plspm_model_set_option(self._h, key.encode(), int(value)), "plspm_model_set_option")
+
+    def get_option(self, key):
+        """Current value of an option; ``"last_gram_path"``: 1 = fp64 MFMA Gram, 2 = int8 digit-plane Gram (last bootstrap call)."""
+        v = ctypes.c_int32(0)
+        self._check(self._lib.plspm_model_get_option(self._h, key.encode(), ctypes.byref(v)), "plspm_model_get_option")
+        return v.value
 
     def stream_ptr(self):
         """The handle's hipStream_t as an integer."""

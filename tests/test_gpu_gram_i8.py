@@ -1,0 +1,172 @@
+"""GPU tests of the int8 digit-plane Gram (csrc/kernels_gram_i8.h) against the fp64 MFMA Gram, extended-precision sums and the
+oracle / reference goldens.  The bootstrap of a metric model takes this path by default; "gram_path" = 1 forces the fp64 one.
+
+Tolerances: the digit-plane product is an exact integer sum of the 7 x 8-bit fixed-point planes of x_p x_q (>= 53 bits of the
+column's largest product), so the moment matrices must sit within a few 1e-16 of the extended-precision sum -- closer than the fp64
+accumulation chain does -- and rows / iteration counts must agree with the fp64 path and with the reference's rows at the suite's 1e-8."""
+import numpy as np
+import pytest
+
+import plspm_oracle as orc
+from helpers import assert_close, case_modes, load, satisfaction_oracle_inputs
+from test_gpu_parity import ATOL, RTOL, native_model
+
+pytestmark = pytest.mark.gpu
+
+
+def exact_moments(Xdev, shift, idx):
+    """sum_i [x_i - shift, 1][x_i - shift, 1]' over the resampled rows, accumulated in 80-bit extended precision."""
+    Xa = np.concatenate((Xdev - shift[None, :], np.ones((Xdev.shape[0], 1))), axis=1)           # the device's fp64 mean-shifted columns
+    c = np.bincount(idx, minlength=Xdev.shape[0]).astype(np.longdouble)
+    Xl = Xa.astype(np.longdouble)
+    return (Xl * c[:, None]).T @ Xl
+
+
+def moment_errors(nm, X, order, idx, path, slices=None):
+    nm.set_option("gram_path", path)
+    if slices is not None:
+        nm.set_option("i8_slices", slices)
+    M = nm.bootstrap_moments(len(idx), idx=idx)
+    assert nm.get_option("last_gram_path") == path
+    shift = nm.fit(want_scores=False)["mean"]
+    worst = 0.0
+    for b in range(len(idx)):
+        ref = exact_moments(X[:, order], shift, idx[b])
+        scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))                # natural scale of entry (p, q)
+        worst = max(worst, float(np.max(np.abs(M[b].astype(np.longdouble) - ref) / scale)))
+        assert np.array_equal(M[b], M[b].T)
+    return worst, M
+
+
+@pytest.mark.parametrize("data", ["satisfaction", "synth2000"])
+def test_moment_matrices_vs_extended_precision(data):
+    if data == "satisfaction":
+        X, blocks, _ = satisfaction_oracle_inputs()
+        C = orc.satisfaction_C()
+    else:
+        C = orc.satisfaction_C()
+        X, blocks = orc.synth(2000, C, 10, seed=3)
+    model = orc.Model(blocks, C, "A" * 6, "path", True)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, X.shape[0], size=(5, X.shape[0])).astype(np.int32)
+    e64, M64 = moment_errors(nm, X, model.mv_order, idx, 1)
+    errs = {S: moment_errors(nm, X, model.mv_order, idx, 2, S)[0] for S in (5, 6, 7, 8)}
+    assert e64 < 2e-13, e64                      # fp64 MFMA accumulation chain
+    assert errs[7] < 1e-15 and errs[8] < 1e-15, errs   # exact sum of fp64-rounded products + one recombination rounding
+    assert errs[7] < e64
+    assert errs[6] < 5e-13 and errs[5] < 1e-10, errs   # 8 bits per plane
+    nm.set_option("i8_slices", 7)
+    _, M8 = moment_errors(nm, X, model.mv_order, idx, 2)
+    assert_close(M8, M64, 1e-12, 1e-9 * np.abs(M64).max())
+
+
+@pytest.mark.parametrize("tag", ["A_centroid_0", "B_path_1", "M_factorial_1"])
+@pytest.mark.parametrize("path", [1, 2])
+def test_reference_rows_on_both_gram_paths(tag, path):
+    """Golden g4 (rows of the real reference on explicit resample indices) through either Gram."""
+    gold = load("g4_satisfaction_boot")
+    X, blocks, _ = satisfaction_oracle_inputs()
+    m, scheme, scaled = tag.split("_")
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(m), scheme, bool(int(scaled)))
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    nm.set_option("gram_path", path)
+    rows, status, iters = nm.bootstrap(8, idx=gold["idx"])
+    assert nm.get_option("last_gram_path") == path
+    assert np.all(status == 0) and np.array_equal(iters, gold[tag + "/iters"])
+    P, L, ne = 27, 6, nm.n_eff
+    inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
+    mine = np.concatenate((rows[:, :P][:, inv], rows[:, P:P + L + 2 * ne], rows[:, P + L + 2 * ne:][:, inv]), axis=1)
+    assert_close(mine, gold[tag + "/rows"], RTOL, ATOL, what=tag)
+
+
+@pytest.mark.parametrize("B", [1, 255, 257, 700])
+def test_ragged_batches_and_sharding_bit_identity(B):
+    """Exact integer sums: a replicate's matrix does not depend on the batch it travels in -- rows are bit-identical for every split,
+    for device draws and for the same draws passed as explicit indices."""
+    from plspm import _native
+    C = orc.chain_C(7)
+    X, blocks = orc.synth(777, C, 5, seed=2)                       # 35 MVs: 36 columns -> 666 pairs = 41.6 pair groups; 777 rows: 13 k-blocks -> 14
+    model = orc.Model(blocks, C, "ABABABA", "factorial", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(B, seed=5)
+    assert nm.get_option("last_gram_path") == 2 and np.all(status == 0)
+    cut = B // 3
+    parts = [nm.bootstrap(n, seed=5, rep_offset=o)[0] for o, n in ((0, cut), (cut, B - cut)) if n > 0]
+    assert np.array_equal(np.concatenate(parts), rows)
+    k = min(B, 9)
+    idx = np.stack([_native.bootstrap_indices(5, r, 777) for r in range(k)])
+    assert np.array_equal(nm.bootstrap(k, idx=idx)[0], rows[:k])
+    nm.set_option("gram_path", 1)
+    rows64, status64, iters64 = nm.bootstrap(B, seed=5)
+    assert nm.get_option("last_gram_path") == 1 and np.array_equal(iters, iters64)
+    assert_close(rows, rows64, 1e-9, 1e-12)
+    corr = orc.correction(777)
+    for r in sorted({0, B - 1}):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(5, r, 777), corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+
+
+def test_multiplicity_above_127_falls_back_to_the_fp64_gram():
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "A" * 6, "centroid", True)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    rng = np.random.default_rng(4)
+    idx = rng.integers(0, 250, size=(3, 250)).astype(np.int32)
+    idx[1, :200] = 17                                             # row 17 drawn 200+ times
+    rows, status, iters = nm.bootstrap(3, idx=idx)
+    nm.set_option("gram_path", 1)
+    rows64, status64, iters64 = nm.bootstrap(3, idx=idx)
+    assert np.array_equal(rows, rows64) and np.array_equal(status, status64) and np.array_equal(iters, iters64)     # the whole chunk went the fp64 way
+    nm.set_option("gram_path", 2)
+    idx[1, :200] = rng.integers(0, 250, size=200)
+    rows2, _, _ = nm.bootstrap(3, idx=idx)
+    assert nm.get_option("last_gram_path") == 2 and not np.array_equal(rows2[0], rows64[0])
+    assert_close(rows2[[0, 2]], rows64[[0, 2]], 1e-9, 1e-12)
+
+
+def test_missing_data_model_on_the_digit_planes():
+    """Mean-imputed metric data: the Gram covers data + missing-indicator columns and impute_collapse reads the same packed matrix;
+    both Gram paths must agree (parity of the path itself with the reference: tests/test_gpu_missing.py, which now runs on the planes)."""
+    from plspm import _native
+    from test_solver_hostemu_missing import aug_matrix
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(600, C, 4, seed=8)
+    rng = np.random.default_rng(3)
+    X[rng.integers(0, 600, size=40), rng.integers(0, 24, size=40)] = np.nan
+    Xaug, ind_of = aug_matrix(X)
+    boff = np.arange(0, 25, 4).astype(np.int32)
+    out = {}
+    for path in (1, 2):
+        nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, missing=ind_of)
+        nm.upload(Xaug)
+        nm.set_option("gram_path", path)
+        out[path] = nm.bootstrap(300, seed=12)
+        assert nm.get_option("last_gram_path") == path
+    assert np.all(out[1][1] == 0) and np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2])
+    assert_close(out[2][0], out[1][0], 1e-9, 1e-12)
+
+
+def test_headline_workload_takes_the_digit_planes_and_matches_the_fp64_path():
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(5000, seed=1)
+    assert nm.get_option("last_gram_path") == 2 and np.all(status == 0)
+    nm.set_option("gram_path", 1)
+    rows64, status64, iters64 = nm.bootstrap(5000, seed=1)
+    assert nm.get_option("last_gram_path") == 1
+    assert np.array_equal(iters, iters64)
+    assert_close(rows, rows64, 1e-10, 1e-13)
+    gold = load("g3_synth10k_path")
+    nm.set_option("gram_path", 2)
+    idx = np.stack([np.random.RandomState(int(s)).randint(10000, size=10000) for s in gold["boot_seeds"]]).astype(np.int32)
+    r2, s2, i2 = nm.bootstrap(len(idx), idx=idx)
+    assert np.all(s2 == 0) and np.array_equal(i2, gold["boot_iters"])
+    assert_close(r2, gold["boot_rows"], RTOL, ATOL)
