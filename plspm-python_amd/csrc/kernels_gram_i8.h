@@ -23,6 +23,9 @@
 #pragma once
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+#ifndef I8_DEFAULT_VAR
+#define I8_DEFAULT_VAR 3
+#endif
 
 // ---------------------------------------------------------------------------------------------- digit planes of the pair products
 // k_j and 2^-k_j of every pair column j = (p, q): one workgroup per pair.
@@ -167,12 +170,21 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
 // per k-step to its 32 resident workgroups.
 // Epilogue: lane (l & 15) owns pair 16 pg + (l & 15) in all S planes -> digits recombined in the lane (fp64 fma chain over exact terms, ~one ulp
 // rounding chain), scaled by 2^-k_j and stored at the element's slot of the tile-packed moment matrix the solvers read.
-template <int S>
+// WM = wave rows of the workgroup (2: four waves, one per SIMD, 128 replicates x 16 pairs x S planes each; 4: eight waves, two per
+// SIMD, 64 replicates each -- an LDS-DMA instruction holds its wave's issue port for ~60 cycles, which a single wave per SIMD cannot
+// hide behind its own MFMAs: with two, the partner's MFMAs run meanwhile).
+// VAR (experiments, tools/i8_bench.py): ring depth NS = 3 + VAR % 3, a fragment read after every (1 + VAR / 3 % 3)-th MFMA, DMA issue
+// spread over the step (VAR / 9 == 0) or at its head (1).
+template <int S, int WM, int VAR = I8_DEFAULT_VAR>
 struct GramI8 {
+    static constexpr int NW = 2 * WM;               // waves per workgroup
+    static constexpr int MTW = 16 / WM;             // count tiles (16 replicates) per wave
     static constexpr int NBLK = 16 + 2 * S;         // 1 KB blocks per k-step: 16 count tiles + 2 pair groups x S planes
-    static constexpr int PER = (NBLK + 3) / 4;      // DMA instructions per wave and k-step
+    static constexpr int PER = (NBLK + NW - 1) / NW;   // DMA instructions per wave and k-step
     static constexpr int STAGE_BYTES = NBLK * 1024;
-    static constexpr size_t LDS_BYTES = (size_t)3 * STAGE_BYTES;
+    static constexpr int NS_WANT = 3 + VAR % 3, NS = NS_WANT * STAGE_BYTES <= 160 * 1024 ? NS_WANT : (160 * 1024) / STAGE_BYTES;      // LDS stages of the DMA ring
+    static constexpr int RSTEP = 1 + (VAR / 3) % 3, DMA_HEAD = VAR / 9;
+    static constexpr size_t LDS_BYTES = (size_t)NS * STAGE_BYTES;
 };
 
 // one LDS-DMA block: 64 lanes x 16 B from `base + voff` to LDS byte address `lds_dst` (wave-uniform) + 16 lane
@@ -182,11 +194,12 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
-template <int S>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <int S, int WM, int VAR = I8_DEFAULT_VAR>
+__global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2)))
 gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
                const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
-    using G = GramI8<S>;
+    using G = GramI8<S, WM, VAR>;
+    constexpr int MTW = G::MTW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,26 +216,30 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
 
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_raw);
     const unsigned voff = (unsigned)lane * 16u;
-    // this wave's PER blocks of a k-step: block b < 16 = count tile b of the workgroup's 16, else digit block b - 16 of its 2 S
+    // this wave's blocks of a k-step, dealt round-robin (wave, wave + NW, ...): block b < 16 = count tile b of the workgroup's 16, else
+    // digit block b - 16 of its 2 S.  NBLK is not always a multiple of NW: the last waves own one block less (`full` tells).
+    const int myper = (G::NBLK - wave + G::NW - 1) / G::NW;
+    const bool full = myper == G::PER;
     const char* src[G::PER];
     long inc[G::PER];
     unsigned dst[G::PER];
 #pragma unroll
     for (int i = 0; i < G::PER; ++i) {
-        const int b = (wave * G::PER + i) % G::NBLK;
+        const int b = min(wave + G::NW * i, G::NBLK - 1);
         const bool isA = b < 16;
         src[i] = isA ? (const char*)(Cd + ((long)ty * 16 + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - 16)) * 64);
         inc[i] = (isA ? (long)MT : (long)NT) * 1024;
         dst[i] = lds0 + (unsigned)b * 1024u;
     }
     int ahead = KB - 1;                               // k-steps the source pointers may still advance (they stop at the last one:
-    auto issue = [&](unsigned stage_off) {            // a DMA past the end re-reads it, never used)
-#pragma unroll
-        for (int i = 0; i < G::PER; ++i) glds_block(src[i], voff, dst[i] + stage_off);
+    auto advance = [&]() {                            // a DMA past the end re-reads it, never used)
         const bool more = ahead > 0;
         --ahead;
 #pragma unroll
         for (int i = 0; i < G::PER; ++i) src[i] += more ? inc[i] : 0;
+    };
+    auto issue_one = [&](int i, unsigned stage_off) {
+        if (i < G::PER - 1 || full) glds_block(src[i], voff, dst[i] + stage_off);
     };
     // Fragment reads and MFMAs are asm statements (fixed order, nothing counted by the compiler):
     //  * accumulators constrained to AGPRs ("+a"): with the builtin hipcc kept a third of the 224 accumulator registers in VGPRs and
@@ -231,87 +248,96 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     //    front of the next barrier (~900 cycles later), which names the registers "+v" so that nothing the compiler does with them
     //    can move above it -- compiler-issued LDS loads got an s_waitcnt lgkmcnt(0) in front of the first MFMA of every step;
     //  * an accumulator is touched once per k-step, so no MFMA depends on a neighbour; the epilogue reads them after the nops below.
-    i32x4 acc[8][S];
+    i32x4 acc[MTW][S];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int s = 0; s < S; ++s) acc[mt][s] = (i32x4){0, 0, 0, 0};
-    const unsigned fbaseA = voff + (unsigned)wm * 8192u, fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
+    const unsigned fbaseA = voff + (unsigned)wm * (unsigned)(MTW * 1024), fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
 #define GI8_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(off))
 #define GI8_MFMA(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
-    // one k-step: MFMAs on (fc, fd), fragment reads of the following k-step from LDS stage R into (fna, fnb)
-    auto step = [&](i32x4 (&fc)[8], i32x4 (&fd)[S], i32x4 (&fna)[8], i32x4 (&fnb)[S], unsigned Roff) {
+    // one k-step: MFMAs on (fc, fd); in their shadow the fragment reads of the following k-step from LDS stage R into (fna, fnb)
+    // and this wave's DMA instructions of the k-step three ahead into stage W (an LDS-DMA instruction occupies the wave's issue for
+    // ~60 cycles: eight of them back to back in front of the barrier left the matrix pipe idle a third of every step)
+    auto step = [&](i32x4 (&fc)[MTW], i32x4 (&fd)[S], i32x4 (&fna)[MTW], i32x4 (&fnb)[S], unsigned Roff, unsigned Woff) {
         const unsigned ra = fbaseA + Roff, rb = fbaseB + Roff;
-        int nread = 0;
+        constexpr int RSTEP = (MTW * S) / (MTW + S) >= G::RSTEP ? G::RSTEP : 1;          // a fragment read after every RSTEP-th MFMA
+        int nread = 0, ndma = 0;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
+                const int m = mt * S + s;
                 GI8_MFMA(acc[mt][s], fc[mt], fd[s]);
-                if ((mt * S + s) % 3 == 0 && nread < 8 + S) {
-                    if (nread < 8) GI8_DSREAD(fna[nread], ra, nread * 1024);
-                    else GI8_DSREAD(fnb[nread - 8], rb, (nread - 8) * 1024);
+                if (m % RSTEP == 0 && nread < MTW + S) {
+                    if (nread < MTW) GI8_DSREAD(fna[nread], ra, nread * 1024);
+                    else GI8_DSREAD(fnb[nread - MTW], rb, (nread - MTW) * 1024);
                     ++nread;
                 }
+                if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * MTW * S) / G::PER + 1)) { issue_one(ndma, Woff); ++ndma; }
             }
+        advance();
     };
-    // wait for this wave's DMAs of the k-step after next to be the only ones in flight and for the fragment reads of the set that
-    // is consumed next; then the workgroup barrier: every wave's share of the next k-step has landed
-    auto wait_barrier = [&](i32x4 (&fa)[8], i32x4 (&fb)[S]) {
-        if constexpr (S == 5)
-            asm volatile("s_waitcnt vmcnt(%13) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
-                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]) : "i"(G::PER) : "memory");
-        else if constexpr (S == 6)
-            asm volatile("s_waitcnt vmcnt(%14) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
-                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]) : "i"(G::PER) : "memory");
-        else if constexpr (S == 7)
-            asm volatile("s_waitcnt vmcnt(%15) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
-                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]) : "i"(G::PER) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%16) lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]),
-                         "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7]) : "i"(G::PER) : "memory");
+    // wait until this wave's DMAs of the k-step after next are the only ones in flight and the fragment reads of the set consumed
+    // next have returned (the registers are named so that nothing the compiler does with them moves above the wait); then the
+    // workgroup barrier: every wave's share of the next k-step has landed
+    auto wait_barrier = [&](i32x4 (&fa)[MTW], i32x4 (&fb)[S]) {
+        // (the count differs between waves; the branch holds no register operands -- with the pins inside it hipcc merged the two
+        // variants through copies of all the fragment registers every step)
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((G::NS - 2) * G::PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((G::NS - 2) * (G::PER - 1)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+        for (int i = 0; i < S; ++i) asm volatile("" : "+v"(fb[i]));
+        asm volatile("s_barrier" ::: "memory");
     };
 
-    i32x4 fa0[8], fb0[S], fa1[8], fb1[S];
+    i32x4 fa0[MTW], fb0[S], fa1[MTW], fb1[S];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
+    for (int i = 0; i < MTW; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
 #pragma unroll
     for (int i = 0; i < S; ++i) { fb0[i] = (i32x4){0, 0, 0, 0}; fb1[i] = fb0[i]; }
-    issue(0);
-    issue(G::STAGE_BYTES);
-    wait_barrier(fa1, fb1);                                   // k-step 0 has landed
+    const auto issue_all = [&](unsigned stage_off) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
+        for (int i = 0; i < G::PER; ++i) issue_one(i, stage_off);
+        advance();
+    };
+    issue_all(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // k-step 0 has landed
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
 #pragma unroll
     for (int i = 0; i < S; ++i) GI8_DSREAD(fb0[i], fbaseB, i * 1024);
-    unsigned R = G::STAGE_BYTES, L = 2 * G::STAGE_BYTES;      // stage holding k-step kb+1 / stage receiving k-step kb+2
+#pragma unroll
+    for (int st = 1; st < G::NS; ++st) issue_all(st * G::STAGE_BYTES);
+    // iteration kb: stage W = kb % NS (its fragments are in registers; it receives k-step kb+NS), stage R = (kb+1) % NS (read now)
+    unsigned W = 0, R = G::STAGE_BYTES;
     // KB is even (the host pads the rows to whole pairs of k-blocks): two steps per trip, the fragment sets swap roles
     for (int kb = 0; kb < KB; kb += 2) {
-        issue(L);
         wait_barrier(fa0, fb0);
-        step(fa0, fb0, fa1, fb1, R);
-        R = L;
-        L = (L == 2 * G::STAGE_BYTES) ? 0u : L + G::STAGE_BYTES;
-        issue(L);
+        step(fa0, fb0, fa1, fb1, R, W);
+        W = R;
+        R = (R == (G::NS - 1) * G::STAGE_BYTES) ? 0u : R + G::STAGE_BYTES;
         wait_barrier(fa1, fb1);
-        step(fa1, fb1, fa0, fb0, R);
-        R = L;
-        L = (L == 2 * G::STAGE_BYTES) ? 0u : L + G::STAGE_BYTES;
+        step(fa1, fb1, fa0, fb0, R, W);
+        W = R;
+        R = (R == (G::NS - 1) * G::STAGE_BYTES) ? 0u : R + G::STAGE_BYTES;
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> readable
 #undef GI8_DSREAD
 #undef GI8_MFMA
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // no DMA may land after the workgroup has gone
-#undef GI8_WAIT_BARRIER
 
     const int j = (tx * 2 + wn) * 16 + (lane & 15);
     if (j >= npair) return;
     const long dstj = pair_dst[j];
     const double sc = pair_scale[j];
-    const long rep0 = (long)ty * 256 + wm * 128 + (lane >> 4) * 4;
+    const long rep0 = (long)ty * 256 + wm * (MTW * 16) + (lane >> 4) * 4;
     double* gp = gram + rep0 * psize + dstj;           // walks the replicates of this lane; opaque to the compiler so that it does not
 #pragma unroll                                         // precompute (and spill) 32 addresses
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             if (rep0 + mt * 16 + reg < nrep) {

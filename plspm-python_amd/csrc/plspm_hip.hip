@@ -660,6 +660,8 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "gram_path") { if (value < 0 || value > 2) return bad(); m->tune.gram_path = value; }
     else if (k == "i8_slices") { if (value < 5 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
+    else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
+    else if (k == "i8_variant") { if (value < -1 || value > 17) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
@@ -679,6 +681,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "gram_path") *value = m->tune.gram_path;
     else if (k == "i8_slices") *value = m->tune.i8_slices;
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
+    else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else return PLSPM_E_ARG;
     return 0;
@@ -1003,13 +1006,24 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const int total = ntx * nty, per = (total + 7) / 8;
     const int* d_dst = (const int*)m->pair_tab.p + 3 * (size_t)m->zs_npair;
     ProfScope ps(m, PLSPM_K_GRAM);
-#define GI8(SS)                                                                                                                              \
+#define GI8V(SS, WW, VV)                                                                                                                     \
     {                                                                                                                                        \
-        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS>, GramI8<SS>::LDS_BYTES))) return rc;                                          \
-        hipLaunchKernelGGL((gram_i8_kernel<SS>), dim3((unsigned)(8 * per)), dim3(256), GramI8<SS>::LDS_BYTES, m->stream, (const uint4*)m->cd.p, \
+        const size_t lds_bytes = GramI8<SS, WW, VV>::LDS_BYTES;                                                                              \
+        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS, WW, VV>, lds_bytes))) return rc;                                              \
+        hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)m->cd.p, \
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, packed_size(m->T)); \
     }
-    switch (S) { case 5: GI8(5) break; case 6: GI8(6) break; case 7: GI8(7) break; default: GI8(8) break; }
+#define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
+#ifdef PLSPM_I8_EXPERIMENTS       // every schedule variant of the 7-plane kernel (tools/i8_bench.py --variants; not in the release library)
+#define GI8X(WW) switch (m->tune.i8_variant) { case 0: GI8V(7, WW, 0) break; case 1: GI8V(7, WW, 1) break; case 2: GI8V(7, WW, 2) break; case 3: GI8V(7, WW, 3) break; \
+        case 4: GI8V(7, WW, 4) break; case 5: GI8V(7, WW, 5) break; case 6: GI8V(7, WW, 6) break; case 7: GI8V(7, WW, 7) break; case 8: GI8V(7, WW, 8) break; \
+        case 9: GI8V(7, WW, 9) break; case 10: GI8V(7, WW, 10) break; case 11: GI8V(7, WW, 11) break; case 12: GI8V(7, WW, 12) break; case 13: GI8V(7, WW, 13) break; \
+        case 14: GI8V(7, WW, 14) break; case 15: GI8V(7, WW, 15) break; case 16: GI8V(7, WW, 16) break; default: GI8V(7, WW, 17) break; }
+    if (S == 7 && m->tune.i8_variant >= 0) { if (m->tune.i8_waves == 4) GI8X(2) else GI8X(4) } else
+#endif
+    if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8(5, 2) break; case 6: GI8(6, 2) break; case 7: GI8(7, 2) break; default: GI8(8, 2) break; } }
+    else { switch (S) { case 5: GI8(5, 4) break; case 6: GI8(6, 4) break; case 7: GI8(7, 4) break; default: GI8(8, 4) break; } }
+#undef GI8V
 #undef GI8
     HIPCHK(m, hipGetLastError());
     return 0;
@@ -1128,6 +1142,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
 #ifdef PLSPM_DEBUG_MARKS
         {
             long long h[16];
+            HIPCHK(m, hipStreamSynchronize(m->stream));
             HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);

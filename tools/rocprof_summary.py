@@ -51,11 +51,12 @@ def main():
         fh.write("\n".join(lines) + "\n")
     with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.json" % tag), "w") as fh:
         json.dump(out, fh, indent=1)
-    gram = [k for k in out["counters"] if k.startswith("gram_")]
-    if gram:
-        with open(os.path.join(ROOT, "profiles", "%s_gram_traffic.json" % tag), "w") as fh:
-            json.dump({"kernel": gram[0], "hbm_bytes_per_launch": out["counters"][gram[0]]["hbm_bytes_per_dispatch"],
-                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md"}, fh, indent=1)
+    for prefix, fname in (("gram_i8_kernel", "%s_gram_i8_traffic.json"), ("gram_rows_kernel", "%s_gram_traffic.json")):
+        gram = [k for k in out["counters"] if k.startswith(prefix)]
+        if gram:
+            with open(os.path.join(ROOT, "profiles", fname % tag), "w") as fh:
+                json.dump({"kernel": gram[0], "hbm_bytes_per_launch": out["counters"][gram[0]]["hbm_bytes_per_dispatch"],
+                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md"}, fh, indent=1)
     print("\n".join(lines))
 
 
