@@ -197,7 +197,7 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
 template <int S, int WM, int VAR = I8_DEFAULT_VAR>
 __global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2)))
 gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
-               const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
+               const int* __restrict__ pair_dst2, const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
     using G = GramI8<S, WM, VAR>;
     constexpr int MTW = G::MTW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
@@ -333,6 +333,7 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     const int j = (tx * 2 + wn) * 16 + (lane & 15);
     if (j >= npair) return;
     const long dstj = pair_dst[j];
+    const long dstj2 = pair_dst2 ? (long)pair_dst2[j] : -1;       // dense layout: the mirrored slot (q, p); -1 on the diagonal / packed layout
     const double sc = pair_scale[j];
     const long rep0 = (long)ty * 256 + wm * (MTW * 16) + (lane >> 4) * 4;
     double* gp = gram + rep0 * psize + dstj;           // walks the replicates of this lane; opaque to the compiler so that it does not
@@ -347,6 +348,7 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
 #pragma unroll
                 for (int s = 1; s < S; ++s) v = fma((double)acc[mt][s][reg], (double)(1ll << (8 * s)), v);
                 *gp = v * sc;
+                if (dstj2 >= 0) gp[dstj2 - dstj] = v * sc;
             }
             gp += psize;
             asm volatile("" : "+v"(gp)::"memory");

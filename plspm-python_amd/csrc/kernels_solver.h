@@ -3,7 +3,9 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ solver kernel
-struct DevExec {
+template <int KCAP>
+struct DevExecT {
+    static constexpr int kcap = KCAP;      // largest small regression solved in registers (solver_core.h spd_solve)
     int tid, nt;
     double* red;           // LDS scratch, one slot per wave
     long long* marks;      // debug: phase timestamps of problem 0 (PLSPM_DEBUG_MARKS)
@@ -14,6 +16,7 @@ struct DevExec {
 #endif
     template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
     template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
     // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
     template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
         int i0 = tid, i1 = 0;
@@ -62,6 +65,7 @@ struct DevExec {
         return __syncthreads_or(hit) != 0;
     }
 };
+using DevExec = DevExecT<8>;
 struct SolverOut {      // per-problem strides; null base pointers are skipped
     double* row; long row_stride;
     int* status; int* iters;
@@ -128,6 +132,28 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
     out.iters = so.iters ? so.iters + b : nullptr;
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
     solve_problem(ex, md, ws, Mp + b * mp_stride, out);
+}
+
+
+// Rows variant (solver_core.h solve_problem_rows): ONE wave per problem, column p of the covariance in the registers of lane p,
+// the small workspace + descriptors in LDS (~11 KB at P = 60, L = 6).  Bootstrap batches of metric models with P <= 64 whose
+// moment matrices arrive dense from the int8 digit-plane Gram.
+__global__ void __launch_bounds__(64) solver_rows_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = nullptr;
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    stage_descriptors(md, lp);
+    FitOutputs out{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevExecT<4> ex{(int)threadIdx.x, 64, ws.red, (b == 0) ? so.marks : nullptr};
+    solve_problem_rows<64>(ex, md, ws, Md + b * md_stride, out);
 }
 
 

@@ -661,6 +661,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_slices") { if (value < 5 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
+    else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 17) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
@@ -682,6 +683,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_slices") *value = m->tune.i8_slices;
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
+    else if (k == "solver_rows") *value = m->tune.solver_rows;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else return PLSPM_E_ARG;
     return 0;
@@ -954,11 +956,16 @@ static int prepare_zs(plspm_model* m) {
     const long npair = i8_pairs(m);
     const int npg = (int)((npair + 31) / 32) * 2;             // pair groups of 16, padded to whole workgroup tiles (two groups)
     const int KB = i8_kblocks(m->N), NT = npg * S;
-    std::vector<int> tab(4 * (size_t)npair);
-    int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | slot]
+    std::vector<int> tab(6 * (size_t)npair);
+    int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | packed slot | dense slot | mirrored dense slot]
+    int* hd1 = hd + npair; int* hd2 = hd1 + npair;
+    const int PSd = cov_ld(m->Pg);
     long j = 0;
     for (int p = 0; p < C; ++p)
-        for (int q = p; q < C; ++q, ++j) { hp[j] = p; hq[j] = q; hd[j] = (int)packed_index(m->T, p, q); }
+        for (int q = p; q < C; ++q, ++j) {
+            hp[j] = p; hq[j] = q; hd[j] = (int)packed_index(m->T, p, q);
+            hd1[j] = p * PSd + q; hd2[j] = (p == q) ? -1 : q * PSd + p;
+        }
     int rc;
     if ((rc = ensure(m, m->pair_tab, tab.size() * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->pair_scale, (size_t)npair * sizeof(double)))) return rc;
@@ -980,7 +987,7 @@ static int prepare_zs(plspm_model* m) {
 // Resample nb replicates into dense int8 counts and multiply with the digit planes: the nb moment matrices land at `out`.
 // Explicit indices can carry a multiplicity above 127 (Philox draws of N >= 128 rows cannot, P < 1e-200): the host looks at the
 // flag before the product and reports *fallback so that the caller takes the fp64 Gram for this chunk.
-static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool* fallback) {
+static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback) {
     *fallback = false;
     const int S = m->zs_S, KB = m->zs_KB, NT = m->zs_NT;
     const int nty = (int)((nb + 255) / 256), MT = nty * 16, ntx = m->zs_npg / 2;
@@ -1004,14 +1011,17 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         }
     }
     const int total = ntx * nty, per = (total + 7) / 8;
-    const int* d_dst = (const int*)m->pair_tab.p + 3 * (size_t)m->zs_npair;
+    // packed: the tile-packed slots the LDS solver / impute kernel read; dense: [(Pg+1) x cov_ld(Pg)] row-major, upper triangle (rows solver)
+    const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
+    const int* d_dst2 = nullptr;          // (a mirrored second store per element cost 0.08 ms per 5,000 replicates: the rows solver reads the triangle instead)
+    const long out_stride = dense ? cov_doubles(m->Pg) : packed_size(m->T);
     ProfScope ps(m, PLSPM_K_GRAM);
 #define GI8V(SS, WW, VV)                                                                                                                     \
     {                                                                                                                                        \
         const size_t lds_bytes = GramI8<SS, WW, VV>::LDS_BYTES;                                                                              \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS, WW, VV>, lds_bytes))) return rc;                                              \
         hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)m->cd.p, \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, packed_size(m->T)); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
     }
 #define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
 #ifdef PLSPM_I8_EXPERIMENTS       // every schedule variant of the 7-plane kernel (tools/i8_bench.py --variants; not in the release library)
@@ -1044,9 +1054,11 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const long dcnt_stride = ((N + 15) & ~15L);
     const int gpath = choose_gram_path(m, B);
     m->last_gram_path = gpath;
+    // one wave per problem on dense moment matrices (solver_rows_kernel): metric models of at most 64 MVs behind the int8 Gram
+    const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && m->P <= 64 && !m->n_ind && !m->moments_out;
     const bool need_lists = gpath == 1 || d_idx != nullptr;           // the fp64 Gram walks (row,count) lists; explicit indices may fall back to it
     const size_t kpad = (size_t)i8_kblocks(N) * 64;
-    const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)psize * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
+    const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)std::max<long>(psize, cov_doubles(m->Pg)) * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
                            (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0);
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
     if (gpath == 2 && chunk < B) chunk = std::max<int64_t>(256, chunk & ~(int64_t)255);      // whole 256-replicate tiles per pass
@@ -1059,7 +1071,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
         if ((rc = ensure(m, m->nent, (size_t)chunk * sizeof(int)))) return rc;
     }
-    if ((rc = ensure(m, m->gram, (size_t)chunk * psize * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->gram, (size_t)chunk * std::max<long>(psize, rows_solver ? cov_doubles(m->Pg) : 0) * sizeof(double)))) return rc;
     if (!rows_out) {
         m->rows_B = 0;
         if ((rc = ensure(m, m->rows, (size_t)B * R * sizeof(double)))) return rc;
@@ -1077,7 +1089,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         bool f64_gram = gpath == 1;
         if (gpath == 2) {
             bool fallback = false;
-            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, (double*)m->gram.p, &fallback))) return rc;
+            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, (double*)m->gram.p, rows_solver, &fallback))) return rc;
             f64_gram = fallback;
         }
         if (f64_gram) {
@@ -1133,9 +1145,14 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         long long* d_marks = nullptr;
         HIPCHK(m, plspm_dmalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks;
 #endif
-        const double* Mp; long mp_stride;
-        if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
-        {
+        if (rows_solver && !f64_gram) {
+            const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
+            if ((rc = allow_lds(m, (const void*)solver_rows_kernel, lds))) return rc;
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipLaunchKernelGGL(solver_rows_kernel, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), (const double*)m->gram.p, (long)cov_doubles(m->Pg), so);
+        } else {
+            const double* Mp; long mp_stride;
+            if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
             ProfScope ps(m, PLSPM_K_SOLVER);
             if ((rc = launch_solver(m, nb, Mp, mp_stride, so, m->tune.solver_threads))) return rc;
         }

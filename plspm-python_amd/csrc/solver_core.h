@@ -315,11 +315,14 @@ PLSPM_HD bool pinv_solve(const double* M, int L, const int* idx, int k, int col,
     return ok;
 }
 // scratch: regression_scratch_doubles(kmax) doubles (x may be its last kmax entries).
+// KCAP: largest k solved in registers (the 8 x 8 instance alone holds 128 doubles: executors whose threads carry other register
+// state -- the rows solver keeps a covariance column -- cap it at 4 and send 5 <= k <= 8 through `scratch` as well).
+template <int KCAP = 8>
 PLSPM_HD bool spd_solve(const double* M, int L, const int* idx, int k, int col, double* x, double* scratch) {
     bool ok;
     if (k <= 2) ok = spd_solve_fixed<2>(M, L, idx, k, col, x);
     else if (k <= 4) ok = spd_solve_fixed<4>(M, L, idx, k, col, x);
-    else if (k <= 8) ok = spd_solve_fixed<8>(M, L, idx, k, col, x);
+    else if (KCAP >= 8 && k <= 8) ok = spd_solve_fixed<(KCAP >= 8 ? 8 : 4)>(M, L, idx, k, col, x);
     else {
         double* A = scratch;
         for (int r = 0; r < k; ++r) {
@@ -452,11 +455,48 @@ PLSPM_HD void impute_collapse(Ex& ex, int P, int Qa, int Ta, int Ts, const int* 
     });
 }
 
+// Where the treated covariance S lives.  CovLds: the (P+1) x PS array ws.S (LDS or global scratch), any thread count.
+// CovRows<PMAX>: thread p keeps row p of S in registers (P <= PMAX, at least P threads: one wave per problem) -- the P x L product
+// S W, the only O(P^2) work of an iteration, then runs out of registers with w broadcast from the workspace.
+struct CovLds {
+    template <class Ex>
+    PLSPM_HD void block_products(Ex& ex, const ModelDesc& md, Workspace& ws) const {
+        const int L = md.L, PS = ws.PS;
+        ex.par2(md.P, L, [&](int p, int m) { ws.V[p * L + m] = dot_col(ws.S, PS, p, ws.w, md.boff[m], md.boff[m + 1]); });
+    }
+    PLSPM_HD void cov_row(const Workspace& ws, int p, int P, double* dst) const { for (int q = 0; q < P; ++q) dst[q] = ws.S[q * ws.PS + p]; }
+};
+template <int PMAX>
+struct CovRows {
+    double s[PMAX];             // s[q] = S[q][p] of the calling thread's column p = ex.tid (symmetric: its row as well)
+    template <class Ex>
+    PLSPM_HD void block_products(Ex& ex, const ModelDesc& md, Workspace& ws) const {
+        const int P = md.P, L = md.L, p = ex.tid;
+        if (p < P) {
+            int m = 0, bend = md.boff[1];
+            double r0 = 0.0, r1 = 0.0;                       // two chains per block (even / odd column): half the dependent latency
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                if (q < P) {                                  // (uniform across the threads)
+                    while (q == bend) { ws.V[p * L + m] = r0 + r1; r0 = 0.0; r1 = 0.0; ++m; bend = md.boff[m + 1]; }
+                    if (q & 1) r1 += s[q] * ws.w[q]; else r0 += s[q] * ws.w[q];
+                }
+            }
+            ws.V[p * L + m] = r0 + r1;
+        }
+        ex.sync();
+    }
+    PLSPM_HD void cov_row(const Workspace&, int, int P, double* dst) const {
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) if (q < P) dst[q] = s[q];
+    }
+};
+
 // V[p,m] = sum_{q in block m} S[p,q] w[q];   Q[l,m] = sum_{p in block l} w[p] V[p,m]
-template <class Ex>
-PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {
-    const int P = md.P, L = md.L, PS = ws.PS;
-    ex.par2(P, L, [&](int p, int m) { ws.V[p * L + m] = dot_col(ws.S, PS, p, ws.w, md.boff[m], md.boff[m + 1]); });
+template <class Ex, class Cov>
+PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const Cov& cov) {
+    const int L = md.L;
+    cov.block_products(ex, md, ws);
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;
         double s = 0.0;
@@ -464,6 +504,8 @@ PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) {
         ws.Q[e] = s;
     });
 }
+template <class Ex>
+PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) { apply_cov(ex, md, ws, CovLds{}); }
 
 // Inner weights E from G = cov0(Yhat) (scheme.py:27-28 / 36-37 / 45-54)
 // `Graw`: raw (uncentred) second moments of the scores for the PATH scheme's no-intercept OLS (scheme.py:50); null when the
@@ -481,7 +523,7 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
             const int k = md.pred_off[i + 1] - md.pred_off[i];
             if (k > 0) {
                 double* x = scratch + 2 * km * km;
-                if (!spd_solve(Gols, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
+                if (!spd_solve<Ex::kcap>(Gols, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
                 for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = x[r];
             }
             const double gii = ws.G[i * L + i];
@@ -509,11 +551,11 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
 }
 
 // One PLS iteration (weights.py:41-54).  Returns the convergence measure (identical on every thread).
-template <class Ex>
-PLSPM_HD double iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2) {
+template <class Ex, class Cov>
+PLSPM_HD double iterate(Ex& ex, const ModelDesc& md, Workspace& ws, double corr2, const Cov& cov) {
     const int P = md.P, L = md.L;
     ex.mark(8);
-    apply_cov(ex, md, ws);
+    apply_cov(ex, md, ws, cov);
     ex.mark(9);
     ex.par(L, [&](int l) { ws.a[l] = 1.0 / (corr2 * sqrt(ws.Q[l * L + l])); });   // Yhat_l = Y_l / std1 / corr
     ex.par(L * L, [&](int e) { ws.G[e] = ws.a[e / L] * ws.a[e % L] * ws.Q[e]; });
@@ -561,8 +603,12 @@ struct FitOutputs {             // any pointer may be null
     int* status;
 };
 
+template <class Ex, class Cov>
+PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule, const Cov& cov);
 template <class Ex>
-PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule);
+PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule) {
+    finish_problem(ex, md, ws, out, iteration, sign_rule, CovLds{});
+}
 
 template <class Ex>
 PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Mp, const FitOutputs& out) {
@@ -599,12 +645,110 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
     int iteration = 0;
     while (true) {
         ++iteration;
-        const double conv = iterate(ex, md, ws, corr2);
+        const double conv = iterate(ex, md, ws, corr2, CovLds{});
         if (conv < md.tol || iteration > md.max_iter) break;
     }
     ex.one([&]() { if (iteration > md.max_iter && ws.scal[3] == (double)ST_OK) ws.scal[3] = (double)ST_NOT_CONVERGED; });
     ex.mark(3);
     finish_problem(ex, md, ws, out, iteration, true);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Rows variant of solve_problem for narrow models (P <= PMAX, at least P threads -- one 64-lane wave per problem on the device):
+// thread p keeps column p of the treated covariance in registers (CovRows), so the workspace holds the small arrays only
+// (~10 KB instead of 40 KB at P = 60: twice the resident problems per CU, no cross-wave barriers) and the P x L product of every
+// iteration needs no loads of S.  `Md`: the DENSE moment matrix [(P+1) x PS] of the mean-shifted columns + ones (row / column P),
+// UPPER triangle only (entry (r, c), r <= c, at r * PS + c), as the int8 digit-plane Gram writes it (kernels_gram_i8.h, dense
+// slots: one store per element, 16 consecutive columns of a row per store group).  Same arithmetic as moments_to_cov /
+// solve_problem; sums over a block run in a different (fixed) order, so results agree to rounding, not bitwise.
+template <int PMAX, class Ex>
+PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Md, const FitOutputs& out) {
+    const int P = md.P, L = md.L, PS = cov_ld(P), p = ex.tid;
+    const bool mine = p < P;
+    CovRows<PMAX> cov;
+    ex.mark(0);
+    // 1. moments -> treated covariance (config.py:299-305, util.py:33-39).  Column p = entries (q, p) above the diagonal (one row of
+    //    Md across the threads: coalesced) + the thread's own row (p, q) behind it (a contiguous run per thread).
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) cov.s[q] = (q < P && mine) ? ((q <= p) ? Md[(long)q * PS + p] : Md[(long)p * PS + q]) : 0.0;
+    double dpp = 0.0, mup = 0.0;
+    if (mine) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; ws.mu[p] = mup; ws.dv[p] = dpp; }
+    if (p == 0) ws.scal[1] = Md[(long)P * PS + P];
+    ex.sync();
+    ex.mark(14);
+    const double n = ws.scal[1], inv_n = 1.0 / n;
+    double fac = inv_n;
+    if (md.scaled) {
+        const double tot = ex.sum(P, [&](int i) { return ws.mu[i] + n * md.shift[i]; });
+        const double np_ = n * (double)P, grand = tot / np_;
+        const double ss = ex.sum(P, [&](int i) {
+            const double d = md.shift[i] - grand;
+            return ws.dv[i] + 2.0 * d * ws.mu[i] + n * d * d;
+        });
+        const double g2 = ss / (np_ - 1.0) * ((n - 1.0) / n);
+        fac = 1.0 / (n * g2);
+    }
+    ex.one([&]() { ws.scal[2] = fac; ws.scal[3] = (double)ST_OK; });
+    ex.mark(15);
+    if (mine) {
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q)
+            if (q < P) cov.s[q] = (cov.s[q] - (mup * ws.mu[q]) * inv_n) * fac;          // (mu_p mu_q) first: bitwise symmetric in (p, q)
+        ws.sd[p] = sqrt((dpp - (mup * mup) * inv_n) * fac);
+        ws.cs[p] = sqrt(fac * n);
+    }
+    ex.sync();
+    ex.mark(1);
+    const double corr2 = n / (n - 1.0);
+
+    if (md.n_chol > 0) {
+        // every thread of a Mode-B block writes its row of S_bb into the block's factor slot and into the scratch half behind it
+        // (psd_factor restores from there for the minimum-norm fallback)
+        if (mine) {
+            const int l = md.lvof[p];
+            if (md.mode[l] == MODE_B) {
+                const int b0 = md.boff[l], b1 = md.boff[l + 1], k = b1 - b0;
+                double* F = ws.chol + md.chol_off[l];
+#pragma unroll
+                for (int q = 0; q < PMAX; ++q)
+                    if (q >= b0 && q < b1) { F[(p - b0) * k + (q - b0)] = cov.s[q]; F[(long)k * k + (p - b0) * k + (q - b0)] = cov.s[q]; }
+            }
+        }
+        ex.sync();
+        ex.par(L, [&](int l) {
+            if (md.mode[l] == MODE_B) {
+                const int k = md.boff[l + 1] - md.boff[l];
+                const bool ok = psd_factor(ws.chol + md.chol_off[l], k, [&](double* R) { for (int e = 0; e < k * k; ++e) R[e] = R[(long)k * k + e]; });
+                if (!ok) ws.scal[3] = (double)ST_SINGULAR;
+            }
+        });
+    }
+    // init (weights.py:28-39): w_p = 1 / sqrt(sum(S_bb)) of the MV's own block
+    if (mine) {
+        const int l = md.lvof[p], b0 = md.boff[l], b1 = md.boff[l + 1];
+        double r = 0.0;
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) if (q >= b0 && q < b1) r += cov.s[q];
+        ws.dv[p] = r;
+    }
+    ex.sync();
+    ex.par(L, [&](int l) {
+        double s = 0.0;
+        for (int q = md.boff[l]; q < md.boff[l + 1]; ++q) s += ws.dv[q];
+        ws.wf[l] = 1.0 / sqrt(s);
+    });
+    ex.par(P, [&](int i) { ws.w[i] = ws.wf[md.lvof[i]]; });
+    ex.mark(2);
+
+    int iteration = 0;
+    while (true) {
+        ++iteration;
+        const double conv = iterate(ex, md, ws, corr2, cov);
+        if (conv < md.tol || iteration > md.max_iter) break;
+    }
+    ex.one([&]() { if (iteration > md.max_iter && ws.scal[3] == (double)ST_OK) ws.scal[3] = (double)ST_NOT_CONVERGED; });
+    ex.mark(3);
+    finish_problem(ex, md, ws, out, iteration, true, cov);
 }
 
 // Inner model (inner_model.py:58-75: OLS with intercept == centred normal equations on the score covariance ws.Cs) and the
@@ -621,7 +765,7 @@ PLSPM_HD void inner_model_effects(Ex& ex, const ModelDesc& md, Workspace& ws) {
         const int k = md.pred_off[i + 1] - md.pred_off[i];
         if (k > 0) {
             double* x = scratch + 2 * km * km;
-            if (!spd_solve(ws.Cs, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
+            if (!spd_solve<Ex::kcap>(ws.Cs, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
             double expl = 0.0;
             for (int r = 0; r < k; ++r) { ws.Bm[i * L + f[r]] = x[r]; expl += x[r] * ws.Cs[f[r] * L + i]; }
             ws.r2[i] = expl / ws.Cs[i * L + i];
@@ -643,11 +787,11 @@ PLSPM_HD void inner_model_effects(Ex& ex, const ModelDesc& md, Workspace& ws) {
 
 // Everything after the iteration (shared by the metric and the non-metric solver): final normalisation, the metric sign
 // rule, inner model, effects, loadings, outputs.  Expects the last weights in ws.w and the treated covariance in ws.S.
-template <class Ex>
-PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule) {
-    const int P = md.P, L = md.L, PS = ws.PS;
+template <class Ex, class Cov>
+PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const FitOutputs& out, int iteration, bool sign_rule, const Cov& cov) {
+    const int P = md.P, L = md.L;
     // finalize (weights.py:56-70; non-metric: weights.py:130-132, no sign rule)
-    apply_cov(ex, md, ws);
+    apply_cov(ex, md, ws, cov);
     ex.par(L, [&](int l) { ws.wf[l] = 1.0 / sqrt(ws.Q[l * L + l]); });        // 1 / (std1(X w_l) / corr)
     ex.par(P, [&](int p) { ws.w[p] *= ws.wf[md.lvof[p]]; });                  // returned weights: never sign-flipped
     ex.par(L, [&](int l) {                                                    // sign rule: EVERY MV votes (weights.py:62-64)
@@ -679,7 +823,7 @@ PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const F
         const double n_ = ws.scal[1];
         if (out.score_w) out.score_w[p] = ws.sgn[l] * ws.w[p] * ws.cs[p];
         if (out.mean) out.mean[p] = ws.mu[p] / n_ + md.shift[p];
-        if (out.cov) for (int q = 0; q < P; ++q) out.cov[p * P + q] = ws.S[q * PS + p];
+        if (out.cov) cov.cov_row(ws, p, P, out.cov + (long)p * P);
     });
     ex.par(L, [&](int l) {
         if (out.row) out.row[P + l] = ws.r2[l];

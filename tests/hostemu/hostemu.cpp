@@ -17,11 +17,13 @@
 using namespace plspm;
 
 struct HostExec {
+    static constexpr int kcap = 8;
     int tid, nt;
     std::barrier<>* bar;
     template <class F> void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); bar->arrive_and_wait(); }
     template <class F> void one(F f) { if (tid == 0) f(); bar->arrive_and_wait(); }
     void mark(int) {}
+    void sync() { bar->arrive_and_wait(); }
     template <class F> void par2(int n0, int n1, F f) {
         for (int e = tid; e < n0 * n1; e += nt) f(e % n0, e / n0);
         bar->arrive_and_wait();
@@ -257,6 +259,32 @@ int hostemu_solve(int P, int L, int PA, int scheme, int scaled, int max_iter, do
             carve_small(ws, small.data(), P, L, kmax, n_chol);
             HostExec ex{t, nthreads, &bar, ws.red};
             solve_problem(ex, md, ws, Mp, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+// Rows variant (solve_problem_rows<64>): Md = dense symmetric moment matrix [(P+1) x cov_ld(P)] of the shifted columns + ones; one
+// emulated thread per lane of the device wave (at least P).
+int hostemu_solve_rows(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                       const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                       int nthreads, double* row, double* crossloadings, double* path_coef, double* lv_cov, double* indirect,
+                       double* score_w, double* score_c, double* cov, double* mean, int8_t* sign, int* iters, int* status) {
+    if (P > 64 || nthreads < P || nthreads > 64) return 1;
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    std::vector<double> small(workspace_small_doubles(P, L, em.md.kmax, em.md.n_chol)), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.crossloadings = crossloadings; out.path_coef = path_coef; out.lv_cov = lv_cov; out.indirect = indirect;
+    out.score_w = score_w; out.score_c = score_c; out.cov = cov; out.mean = mean; out.sign = sign; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            Workspace ws{};
+            ws.S = nullptr; ws.PS = cov_ld(P);
+            carve_small(ws, small.data(), P, L, em.md.kmax, em.md.n_chol);
+            HostExec ex{t, nthreads, &bar, red.data()};
+            solve_problem_rows<64>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

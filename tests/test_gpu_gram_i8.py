@@ -170,3 +170,25 @@ def test_headline_workload_takes_the_digit_planes_and_matches_the_fp64_path():
     r2, s2, i2 = nm.bootstrap(len(idx), idx=idx)
     assert np.all(s2 == 0) and np.array_equal(i2, gold["boot_iters"])
     assert_close(r2, gold["boot_rows"], RTOL, ATOL)
+
+
+@pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
+def test_rows_solver_equals_lds_solver_on_the_same_moments(modes, scheme):
+    """solver_rows_kernel (one wave per problem, covariance column in registers, dense upper-triangular moments) against solver_kernel
+    (workgroup per problem, covariance in LDS, tile-packed moments): same Gram, same iteration counts, rows equal to rounding."""
+    from plspm import _native
+    X, blocks = orc.synth(3000, orc.satisfaction_C(), 10, seed=9)
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, True)
+    nm = native_model(model)
+    nm.upload(X)
+    assert nm.get_option("solver_rows") == 1
+    rows, status, iters = nm.bootstrap(600, seed=3)
+    nm.set_option("solver_rows", 0)
+    rows0, status0, iters0 = nm.bootstrap(600, seed=3)
+    assert np.all(status == 0) and np.array_equal(status, status0) and np.array_equal(iters, iters0)
+    assert_close(rows, rows0, 1e-11, 1e-13)
+    corr = orc.correction(3000)
+    for r in (0, 599):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(3, r, 3000), corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)

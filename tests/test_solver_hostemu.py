@@ -29,8 +29,20 @@ def _ptr(a, t=ctypes.c_double):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None):
-    """`packed`: precomputed (Mp, shift, PA) of the DEVICE-ordered columns instead of the scatter of X (X then only feeds the score check)."""
+def dense_from_packed(Mp, PA, P):
+    """[(P+1) x cov_ld(P)] upper-triangular moment matrix (the layout the int8 Gram writes for the rows solver) out of the tile-packed one."""
+    PS = (P + 1) | 1
+    T = PA // 16
+    idx = np.arange(P + 1)
+    Md = np.zeros((P + 1, PS))
+    Md[:, :P + 1] = np.triu(Mp[packed_index_np(T, idx[:, None], idx[None, :])])      # upper triangle only, as the Gram writes it
+    Md[np.tril_indices(P + 1, -1)] = np.nan                                            # nothing may read below the diagonal
+    return Md
+
+
+def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None, rows=False):
+    """`packed`: precomputed (Mp, shift, PA) of the DEVICE-ordered columns instead of the scatter of X (X then only feeds the score check).
+    `rows`: the one-wave-per-problem variant (solve_problem_rows<64>) on the dense moment matrix, 64 emulated lanes."""
     order = model.mv_order
     Xdev = np.ascontiguousarray(X[:, order])
     P, L = Xdev.shape[1], model.L
@@ -46,11 +58,20 @@ def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None):
     ind = np.zeros(max(ne, 1)); sw = np.zeros(P); sc = np.zeros(L); cov = np.zeros((P, P)); mean = np.zeros(P)
     sign = np.zeros(L, dtype=np.int8); iters = ctypes.c_int(0); status = ctypes.c_int(-1)
     shift = np.ascontiguousarray(shift, dtype=np.float64)
-    lib.hostemu_solve(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
-                      _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte), _ptr(mode, ctypes.c_int), _ptr(shift), ne,
-                      _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Mp), nthreads, _ptr(row), _ptr(cl), _ptr(pc),
-                      _ptr(lc), _ptr(ind), _ptr(sw), _ptr(sc), _ptr(cov), _ptr(mean), _ptr(sign, ctypes.c_int8),
-                      ctypes.byref(iters), ctypes.byref(status))
+    if rows:
+        Md = np.ascontiguousarray(dense_from_packed(Mp, PA, P))
+        rc = lib.hostemu_solve_rows(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
+                                    _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte), _ptr(mode, ctypes.c_int), _ptr(shift), ne,
+                                    _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Md), 64, _ptr(row), _ptr(cl), _ptr(pc),
+                                    _ptr(lc), _ptr(ind), _ptr(sw), _ptr(sc), _ptr(cov), _ptr(mean), _ptr(sign, ctypes.c_int8),
+                                    ctypes.byref(iters), ctypes.byref(status))
+        assert rc == 0
+    else:
+        lib.hostemu_solve(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
+                          _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte), _ptr(mode, ctypes.c_int), _ptr(shift), ne,
+                          _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Mp), nthreads, _ptr(row), _ptr(cl), _ptr(pc),
+                          _ptr(lc), _ptr(ind), _ptr(sw), _ptr(sc), _ptr(cov), _ptr(mean), _ptr(sign, ctypes.c_int8),
+                          ctypes.byref(iters), ctypes.byref(status))
     inv = np.empty(P, dtype=np.int64); inv[order] = np.arange(P)          # data column -> device column
     w = row[:P][inv]; ld = row[P + L + 2 * ne:2 * P + L + 2 * ne][inv]
     scores = ((Xdev - shift) * sw) @ np.equal.outer(np.repeat(np.arange(L), np.diff(boff)), np.arange(L)).astype(float) + sc
@@ -96,6 +117,51 @@ def test_satisfaction_all_cases(emu, modes, scheme, scaled):
     X, blocks, _ = satisfaction_oracle_inputs()
     model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, scaled)
     check(run_emu(emu, X, model), orc.fit(X, model), "%s/%s/%d" % (modes, scheme, scaled))
+
+
+@pytest.mark.parametrize("modes", ["A", "B", "M"])
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_rows_variant_satisfaction_all_cases(emu, modes, scheme, scaled):
+    """solve_problem_rows<64> (one wave per problem, S rows in registers, dense moment matrix) against the oracle and the LDS variant."""
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, scaled)
+    e = run_emu(emu, X, model, rows=True)
+    check(e, orc.fit(X, model), "rows %s/%s/%d" % (modes, scheme, scaled))
+    base = run_emu(emu, X, model)
+    assert e["iterations"] == base["iterations"]
+    assert_close(e["row"], base["row"], 1e-11, 1e-13)
+    assert_close(e["cov"], base["cov"], 1e-13, 1e-15)
+
+
+@pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
+def test_rows_variant_synth_60_columns_and_weighted(emu, modes, scheme):
+    from helpers import load
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    model = orc.Model(blocks, orc.satisfaction_C(), case_modes(modes), scheme, True)
+    check(run_emu(emu, X, model, rows=True), orc.fit(X, model))
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, 2000, 2000)
+    counts = np.bincount(idx, minlength=2000)
+    shift = X[:, model.mv_order].mean(axis=0)
+    e = run_emu(emu, X, model, counts=counts, shift=shift, rows=True)
+    mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(2000))
+    assert e["status"] == 0 and e["iterations"] == its
+    assert_close(np.concatenate((e["weights"], e["r2"], e["total"], e["direct"], e["loadings"])), mine, RTOL, 1e-12)
+
+
+def test_rows_variant_rank_deficient_and_status(emu):
+    from helpers import load
+    X, blocks, _ = satisfaction_oracle_inputs()
+    Xd = X.copy()
+    Xd[:, blocks[1][1]] = Xd[:, blocks[1][0]]                       # duplicated MV in a Mode-B block: minimum-norm weights
+    model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "path", True)
+    e, base = run_emu(emu, Xd, model, rows=True), run_emu(emu, Xd, model)
+    assert e["status"] == base["status"] == 0 and e["iterations"] == base["iterations"]
+    assert_close(e["row"], base["row"], 1e-9, 1e-11)
+    tight = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True, max_iter=2, tol=1e-12)
+    e = run_emu(emu, X, tight, rows=True)
+    assert e["status"] == 1 and e["iterations"] == 3
 
 
 @pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
