@@ -17,6 +17,17 @@ struct DevExecT {
     template <class F> __device__ __forceinline__ void par(int n, F f) { for (int i = tid; i < n; i += nt) f(i); __syncthreads(); }
     template <class F> __device__ __forceinline__ void one(F f) { if (tid == 0) f(); __syncthreads(); }
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    // out[j] = the `v` of thread first + j, j < 8 (one wave: v_readlane, the results are scalar operands of the consumers)
+    template <int N> __device__ __forceinline__ void gather8(double v, int first, double (&out)[8]) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = __hiloint2double(__builtin_amdgcn_readlane(hi, first + j), __builtin_amdgcn_readlane(lo, first + j));
+    }
+    // a value every thread of the group holds identically, made provably uniform (scalar registers, scalar branches)
+    __device__ __forceinline__ unsigned long long uniform(unsigned long long v) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    }
     // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
     template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
         int i0 = tid, i1 = 0;
@@ -138,7 +149,7 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
 // Rows variant (solver_core.h solve_problem_rows): ONE wave per problem, column p of the covariance in the registers of lane p,
 // the small workspace + descriptors in LDS (~11 KB at P = 60, L = 6).  Bootstrap batches of metric models with P <= 64 whose
 // moment matrices arrive dense from the int8 digit-plane Gram.
-__global__ void __launch_bounds__(64) solver_rows_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_rows_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;

@@ -940,9 +940,10 @@ static inline long i8_pairs(const plspm_model* m) { const long C = m->Pg + 1; re
 // Which Gram a bootstrap call of B replicates takes: 1 = fp64 MFMA on the (row,count) lists, 2 = int8 digit planes.
 static int choose_gram_path(const plspm_model* m, int64_t B) {
     if (m->tune.gram_path == 1) return 1;
-    // plain metric models (complete or mean-imputed data): the solver needs nothing but the moment matrix.  The LDS histogram
-    // bounds N; int32 accumulators need 128 N < 2^31.
-    if (m->nonmetric || m->stage2 || m->stage1 || m->nmx_K || m->N > 65535 || m->N < 2) return 1;
+    // every model's replicates start from the moment matrix of the uploaded columns (metric, mean-imputed, non-metric, categorical
+    // indicator columns, incomplete rows zeroed, first stage of a HOC pair).  The LDS histogram bounds N; int32 accumulators need
+    // 128 N < 2^31.
+    if (m->stage1 || m->N > 65535 || m->N < 2) return 1;
     const size_t zs_bytes = (size_t)i8_kblocks(m->N) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * m->tune.i8_slices) * 1024;
     if (zs_bytes > kZsBudget) return 1;
     if (m->tune.gram_path == 2) return 2;
@@ -1055,8 +1056,9 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const int gpath = choose_gram_path(m, B);
     m->last_gram_path = gpath;
     // one wave per problem on dense moment matrices (solver_rows_kernel): metric models of at most 64 MVs behind the int8 Gram
-    const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && m->P <= 64 && !m->n_ind && !m->moments_out;
-    const bool need_lists = gpath == 1 || d_idx != nullptr;           // the fp64 Gram walks (row,count) lists; explicit indices may fall back to it
+    const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && m->P <= 64 && !m->n_ind && !m->nonmetric && !m->moments_out;
+    // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers
+    const bool need_lists = gpath == 1 || d_idx != nullptr || m->nonmetric;
     const size_t kpad = (size_t)i8_kblocks(N) * 64;
     const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)std::max<long>(psize, cov_doubles(m->Pg)) * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
                            (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0);
@@ -1092,7 +1094,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, (double*)m->gram.p, rows_solver, &fallback))) return rc;
             f64_gram = fallback;
         }
-        if (f64_gram) {
+        if (f64_gram || m->nonmetric) {            // (row,count) lists (+ dense uint16 histograms): the same draws as the int8 counts
             if (lds_hist) {
                 const size_t hist_bytes = (size_t)((N + 1) / 2) * sizeof(unsigned);
                 if ((rc = allow_lds(m, (const void*)resample_kernel, hist_bytes))) return rc;
@@ -1105,6 +1107,8 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
                 hipLaunchKernelGGL(resample_global_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, (int)N, d_idx ? d_idx + b0 * N : nullptr, seed,
                                    rep_offset + b0, (unsigned*)m->ghist.p, (int2*)m->ent.p, (int*)m->nent.p, ent_stride, (int*)m->err.p);
             }
+        }
+        if (f64_gram) {
             ProfScope ps(m, PLSPM_K_GRAM);
             if ((rc = launch_gram<false>(m, nb, 1, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, (double*)m->gram.p))) return rc;
         }
@@ -1143,7 +1147,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         }
 #ifdef PLSPM_DEBUG_MARKS      // phase clocks of one solver problem (tools/gpu_marks.sh builds with -DPLSPM_DEBUG_MARKS); never in the release library
         long long* d_marks = nullptr;
-        HIPCHK(m, plspm_dmalloc((void**)&d_marks, 16 * sizeof(long long))); so.marks = d_marks;
+        HIPCHK(m, plspm_dmalloc((void**)&d_marks, 32 * sizeof(long long))); so.marks = d_marks;
 #endif
         if (rows_solver && !f64_gram) {
             const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
@@ -1158,7 +1162,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         }
 #ifdef PLSPM_DEBUG_MARKS
         {
-            long long h[16];
+            long long h[32];
             HIPCHK(m, hipStreamSynchronize(m->stream));
             HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
@@ -1166,6 +1170,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             fprintf(stderr, "[plspm cov] sweep %lld  scale-factor %lld  centre+sd %lld\n", h[14] - h[0], h[15] - h[14], h[1] - h[15]);
             fprintf(stderr, "[plspm last iterate] apply_cov %lld  a+G %lld  inner_weights %lld  outer %lld  conv+copy %lld\n", h[9] - h[8], h[10] - h[9],
                     h[11] - h[10], h[12] - h[11], h[13] - h[12]);
+            fprintf(stderr, "[plspm last apply_cov] block products %lld  Q %lld\n", h[17] - h[16], h[18] - h[17]);
             plspm_dfree(d_marks);
         }
 #endif
@@ -1388,7 +1393,7 @@ int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, co
 int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out) {
     if (!m || !out || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_moments: bad arguments");
     if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_moments: no data uploaded");
-    if (m->nonmetric || m->stage1 || m->stage2) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_moments: metric handles only");
+    if (m->stage1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_moments: not on an attached second stage");
     HIPCHK(m, hipSetDevice(m->device));
     const int32_t* d_idx = nullptr;
     int rc;

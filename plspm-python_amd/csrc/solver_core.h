@@ -469,20 +469,33 @@ struct CovLds {
 template <int PMAX>
 struct CovRows {
     double s[PMAX];             // s[q] = S[q][p] of the calling thread's column p = ex.tid (symmetric: its row as well)
+    unsigned long long ends;    // bit q set: column q is the last one of its LV block (wave-uniform; PMAX <= 64)
+    // s[q] is 0 for q >= P, so the products run unguarded over whole chunks of 8 columns: the 8 broadcast reads of w are issued
+    // together (a per-column guard made every column its own basic block -- one exposed LDS round trip each, 11k cycles per call),
+    // only the block-boundary bookkeeping is conditional (uniform).
     template <class Ex>
     PLSPM_HD void block_products(Ex& ex, const ModelDesc& md, Workspace& ws) const {
         const int P = md.P, L = md.L, p = ex.tid;
-        if (p < P) {
-            int m = 0, bend = md.boff[1];
-            double r0 = 0.0, r1 = 0.0;                       // two chains per block (even / odd column): half the dependent latency
+        // thread q holds w[q] in a register; a chunk of 8 reaches every thread through the executor (device: v_readlane -> scalar
+        // operands of the FMAs, no LDS round trip per chunk; every thread of the group takes part)
+        const double wreg = ws.w[(p < P) ? p : P - 1];
+        // (a wave issues one instruction per 4 cycles whatever the number of busy lanes: what counts is instructions per column.  A
+        // uniform test + conditional store per column measured 5.4k cycles per call; storing the running sum after EVERY column with
+        // selects instead of the branch 6.5k; per-thread boundary tests with w read from LDS 7.3k)
+        int m = 0;
+        double r0 = 0.0, r1 = 0.0;                           // two chains per block (even / odd column): half the dependent latency
 #pragma unroll
-            for (int q = 0; q < PMAX; ++q) {
-                if (q < P) {                                  // (uniform across the threads)
-                    while (q == bend) { ws.V[p * L + m] = r0 + r1; r0 = 0.0; r1 = 0.0; ++m; bend = md.boff[m + 1]; }
-                    if (q & 1) r1 += s[q] * ws.w[q]; else r0 += s[q] * ws.w[q];
+        for (int q0 = 0; q0 < PMAX; q0 += 8) {
+            if (q0 < P) {                                     // (uniform across the threads)
+                double wq[8];
+                ex.template gather8<PMAX>(wreg, q0, wq);      // w of columns q0 .. q0+7, the same on every thread
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = q0 + j;
+                    if (j & 1) r1 += s[q] * wq[j]; else r0 += s[q] * wq[j];
+                    if ((ends >> q) & 1ull) { if (p < P) ws.V[p * L + m] = r0 + r1; r0 = 0.0; r1 = 0.0; ++m; }     // column q closes block m (uniform test)
                 }
             }
-            ws.V[p * L + m] = r0 + r1;
         }
         ex.sync();
     }
@@ -496,13 +509,16 @@ struct CovRows {
 template <class Ex, class Cov>
 PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const Cov& cov) {
     const int L = md.L;
+    ex.mark(16);
     cov.block_products(ex, md, ws);
+    ex.mark(17);
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;
         double s = 0.0;
         for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += ws.w[p] * ws.V[p * L + m];
         ws.Q[e] = s;
     });
+    ex.mark(18);
 }
 template <class Ex>
 PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws) { apply_cov(ex, md, ws, CovLds{}); }
@@ -515,21 +531,22 @@ PLSPM_HD void inner_weights(Ex& ex, const ModelDesc& md, Workspace& ws, double c
     const int L = md.L;
     const double* Gols = Graw ? Graw : ws.G;
     if (md.scheme == SCHEME_PATH) {
+        // column i of E: regression coefficients on the predecessors of i ("follow", scheme.py:47-50), correlations with its
+        // successors ("predec", scheme.py:51-53), zero elsewhere.  The L^2 entries first (one thread each: a sqrt + a divide),
+        // then the L regressions -- inside one per-LV loop the successor entries added up to three sqrt / divide chains per thread.
+        ex.par(L * L, [&](int e) {
+            const int s2 = e / L, i = e - s2 * L;
+            ws.E[e] = md.C[s2 * L + i] ? ws.G[e] / sqrt(ws.G[s2 * L + s2] * ws.G[i * L + i]) : 0.0;
+        });
         ex.par(L, [&](int i) {
-            for (int j = 0; j < L; ++j) ws.E[j * L + i] = 0.0;
             const int km = md.kmax;
             double* scratch = ws.scr + (long)i * regression_scratch_doubles(km);
-            const int* f = md.pred_idx + md.pred_off[i];                    // predecessors of i ("follow", scheme.py:47)
+            const int* f = md.pred_idx + md.pred_off[i];                    // predecessors of i
             const int k = md.pred_off[i + 1] - md.pred_off[i];
             if (k > 0) {
                 double* x = scratch + 2 * km * km;
                 if (!spd_solve<Ex::kcap>(Gols, L, f, k, i, x, scratch)) ws.scal[3] = (double)ST_SINGULAR;
                 for (int r = 0; r < k; ++r) ws.E[f[r] * L + i] = x[r];
-            }
-            const double gii = ws.G[i * L + i];
-            for (int e2 = md.succ_off[i]; e2 < md.succ_off[i + 1]; ++e2) {  // successors of i ("predec", scheme.py:51)
-                const int s2 = md.succ_idx[e2];
-                ws.E[s2 * L + i] = ws.G[s2 * L + i] / sqrt(ws.G[s2 * L + s2] * gii);
             }
         });
     } else {
@@ -666,11 +683,23 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
     const int P = md.P, L = md.L, PS = cov_ld(P), p = ex.tid;
     const bool mine = p < P;
     CovRows<PMAX> cov;
+    {
+        unsigned long long e = 0ull;
+        for (int l = 0; l < L; ++l) e |= 1ull << (md.boff[l + 1] - 1);
+        cov.ends = ex.uniform(e);                         // the same value on every thread: block boundaries become scalar tests
+    }
     ex.mark(0);
     // 1. moments -> treated covariance (config.py:299-305, util.py:33-39).  Column p = entries (q, p) above the diagonal (one row of
     //    Md across the threads: coalesced) + the thread's own row (p, q) behind it (a contiguous run per thread).
+    //    One load per column with a selected address (a select of two loads became two exec-masked branches per column); idle threads
+    //    and columns past P re-read valid entries, zeroed below.
+    const int pc = mine ? p : P - 1;
 #pragma unroll
-    for (int q = 0; q < PMAX; ++q) cov.s[q] = (q < P && mine) ? ((q <= p) ? Md[(long)q * PS + p] : Md[(long)p * PS + q]) : 0.0;
+    for (int q = 0; q < PMAX; ++q) {
+        const int qc = (q < P) ? q : P - 1;
+        const unsigned off = (unsigned)((qc <= pc) ? qc * PS + pc : pc * PS + qc) * 8u;      // 32-bit byte offset from one base: one
+        cov.s[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off); // address register per load, all in flight
+    }
     double dpp = 0.0, mup = 0.0;
     if (mine) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; ws.mu[p] = mup; ws.dv[p] = dpp; }
     if (p == 0) ws.scal[1] = Md[(long)P * PS + P];
@@ -690,10 +719,12 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
     }
     ex.one([&]() { ws.scal[2] = fac; ws.scal[3] = (double)ST_OK; });
     ex.mark(15);
-    if (mine) {
 #pragma unroll
-        for (int q = 0; q < PMAX; ++q)
-            if (q < P) cov.s[q] = (cov.s[q] - (mup * ws.mu[q]) * inv_n) * fac;          // (mu_p mu_q) first: bitwise symmetric in (p, q)
+    for (int q = 0; q < PMAX; ++q) {
+        const double v = (cov.s[q] - (mup * ws.mu[(q < P) ? q : P - 1]) * inv_n) * fac;          // (mu_p mu_q) first: bitwise symmetric in (p, q)
+        cov.s[q] = (q < P) ? v : 0.0;
+    }
+    if (mine) {
         ws.sd[p] = sqrt((dpp - (mup * mup) * inv_n) * fac);
         ws.cs[p] = sqrt(fac * n);
     }

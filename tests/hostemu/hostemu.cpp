@@ -24,6 +24,13 @@ struct HostExec {
     template <class F> void one(F f) { if (tid == 0) f(); bar->arrive_and_wait(); }
     void mark(int) {}
     void sync() { bar->arrive_and_wait(); }
+    unsigned long long uniform(unsigned long long v) { return v; }
+    template <int N> void gather8(double v, int first, double (&out)[8]) {      // `red` holds nt slots wherever this is used (rows variant)
+        red[tid] = v;
+        bar->arrive_and_wait();
+        for (int j = 0; j < 8; ++j) out[j] = (first + j < nt) ? red[first + j] : 0.0;
+        bar->arrive_and_wait();
+    }
     template <class F> void par2(int n0, int n1, F f) {
         for (int e = tid; e < n0 * n1; e += nt) f(e % n0, e / n0);
         bar->arrive_and_wait();

@@ -1,6 +1,8 @@
+"""Phase clocks of one solver problem (library built with EXTRA=-DPLSPM_DEBUG_MARKS) at different batch sizes: 256 replicates = one
+problem per CU (no co-resident waves), 2048 = eight per CU, 5000 = the headline batch."""
 import os, sys
 import numpy as np
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "plspm-python_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from plspm import _native
 from synthetic import satisfaction_C, synth
@@ -9,6 +11,10 @@ X, blocks = synth(10000, C, 10, seed=0)
 boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0)
 nm.upload(X)
-for k in range(4):
-    nm.bootstrap_device(5000, seed=1, rep_offset=k * 5000)
-nm.sync()
+for opt in sys.argv[1:]:
+    k, v = opt.split("=")
+    nm.set_option(k, int(v))
+for B in (256, 256, 2048, 5000, 5000):
+    sys.stderr.write("--- B = %d\n" % B); sys.stderr.flush()
+    nm.bootstrap_device(B, seed=1, rep_offset=0)
+    nm.sync()
