@@ -182,8 +182,13 @@ struct GramI8 {
     static constexpr int NBLK = 16 + 2 * S;         // 1 KB blocks per k-step: 16 count tiles + 2 pair groups x S planes
     static constexpr int PER = (NBLK + NW - 1) / NW;   // DMA instructions per wave and k-step
     static constexpr int STAGE_BYTES = NBLK * 1024;
-    static constexpr int NS_WANT = 3 + VAR % 3, NS = NS_WANT * STAGE_BYTES <= 160 * 1024 ? NS_WANT : (160 * 1024) / STAGE_BYTES;      // LDS stages of the DMA ring
-    static constexpr int RSTEP = 1 + (VAR / 3) % 3, DMA_HEAD = VAR / 9;
+    // VAR >= 18: ONE workgroup barrier per two k-steps on a ring of five stages (k-steps 2p+1 and 2p+2 have landed at the barrier of
+    // pair p, 2p+3 is in flight, 2p+4 / 2p+5 are issued during the pair into the stages of 2p-1 / 2p, whose fragments every wave
+    // read before that barrier) -- when five stages fit the 160 KB
+    static constexpr bool PAIRB = VAR >= 18 && 5 * STAGE_BYTES <= 160 * 1024;
+    static constexpr int NS_WANT = PAIRB ? 5 : 3 + VAR % 3, NS = NS_WANT * STAGE_BYTES <= 160 * 1024 ? NS_WANT : (160 * 1024) / STAGE_BYTES;      // LDS stages of the DMA ring
+    static constexpr int RSTEP = 1 + (VAR / 3) % 3, DMA_HEAD = (VAR % 18) / 9;
+    static constexpr int FLIGHT = PAIRB ? 1 : NS - 2;      // k-steps whose DMAs may still be in flight behind the barrier's wait
     static constexpr size_t LDS_BYTES = (size_t)NS * STAGE_BYTES;
 };
 
@@ -284,14 +289,21 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     auto wait_barrier = [&](i32x4 (&fa)[MTW], i32x4 (&fb)[S]) {
         // (the count differs between waves; the branch holds no register operands -- with the pins inside it hipcc merged the two
         // variants through copies of all the fragment registers every step)
-        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((G::NS - 2) * G::PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((G::NS - 2) * (G::PER - 1)) : "memory");
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * G::PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * (G::PER - 1)) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(fa[i]));
 #pragma unroll
         for (int i = 0; i < S; ++i) asm volatile("" : "+v"(fb[i]));
         asm volatile("s_barrier" ::: "memory");
+    };
+    auto wait_frags = [&](i32x4 (&fa)[MTW], i32x4 (&fb)[S]) {       // second k-step of a pair: only this wave's fragment reads
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+        for (int i = 0; i < S; ++i) asm volatile("" : "+v"(fb[i]));
     };
 
     i32x4 fa0[MTW], fb0[S], fa1[MTW], fb1[S];
@@ -310,20 +322,21 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     for (int i = 0; i < MTW; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
 #pragma unroll
     for (int i = 0; i < S; ++i) GI8_DSREAD(fb0[i], fbaseB, i * 1024);
+    constexpr int AHEAD = G::PAIRB ? G::NS - 1 : G::NS;        // the DMA issued during k-step kb carries k-step kb + AHEAD
 #pragma unroll
-    for (int st = 1; st < G::NS; ++st) issue_all(st * G::STAGE_BYTES);
-    // iteration kb: stage W = kb % NS (its fragments are in registers; it receives k-step kb+NS), stage R = (kb+1) % NS (read now)
-    unsigned W = 0, R = G::STAGE_BYTES;
+    for (int st = 1; st < AHEAD; ++st) issue_all(st * G::STAGE_BYTES);
+    // iteration kb: stage R = (kb+1) % NS is read now; stage W = (kb + AHEAD) % NS receives k-step kb + AHEAD (plain ring: the stage
+    // of k-step kb itself, whose fragments are in registers; pair barrier: the stage of k-step kb-1)
+    unsigned W = (AHEAD % G::NS) * G::STAGE_BYTES, R = G::STAGE_BYTES;
+    auto next = [](unsigned st) { return (st == (G::NS - 1) * G::STAGE_BYTES) ? 0u : st + G::STAGE_BYTES; };
     // KB is even (the host pads the rows to whole pairs of k-blocks): two steps per trip, the fragment sets swap roles
     for (int kb = 0; kb < KB; kb += 2) {
         wait_barrier(fa0, fb0);
         step(fa0, fb0, fa1, fb1, R, W);
-        W = R;
-        R = (R == (G::NS - 1) * G::STAGE_BYTES) ? 0u : R + G::STAGE_BYTES;
-        wait_barrier(fa1, fb1);
+        W = next(W); R = next(R);
+        if constexpr (G::PAIRB) wait_frags(fa1, fb1); else wait_barrier(fa1, fb1);
         step(fa1, fb1, fa0, fb0, R, W);
-        W = R;
-        R = (R == (G::NS - 1) * G::STAGE_BYTES) ? 0u : R + G::STAGE_BYTES;
+        W = next(W); R = next(R);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> readable
 #undef GI8_DSREAD

@@ -662,7 +662,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
-    else if (k == "i8_variant") { if (value < -1 || value > 17) return bad(); m->tune.i8_variant = value; }
+    else if (k == "i8_variant") { if (value < -1 || value > 35) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
@@ -1026,10 +1026,8 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     }
 #define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
 #ifdef PLSPM_I8_EXPERIMENTS       // every schedule variant of the 7-plane kernel (tools/i8_bench.py --variants; not in the release library)
-#define GI8X(WW) switch (m->tune.i8_variant) { case 0: GI8V(7, WW, 0) break; case 1: GI8V(7, WW, 1) break; case 2: GI8V(7, WW, 2) break; case 3: GI8V(7, WW, 3) break; \
-        case 4: GI8V(7, WW, 4) break; case 5: GI8V(7, WW, 5) break; case 6: GI8V(7, WW, 6) break; case 7: GI8V(7, WW, 7) break; case 8: GI8V(7, WW, 8) break; \
-        case 9: GI8V(7, WW, 9) break; case 10: GI8V(7, WW, 10) break; case 11: GI8V(7, WW, 11) break; case 12: GI8V(7, WW, 12) break; case 13: GI8V(7, WW, 13) break; \
-        case 14: GI8V(7, WW, 14) break; case 15: GI8V(7, WW, 15) break; case 16: GI8V(7, WW, 16) break; default: GI8V(7, WW, 17) break; }
+#define GI8X(WW) switch (m->tune.i8_variant) { case 0: GI8V(7, WW, 0) break; case 3: GI8V(7, WW, 3) break; case 6: GI8V(7, WW, 6) break; case 4: GI8V(7, WW, 4) break; \
+        case 12: GI8V(7, WW, 12) break; case 18: GI8V(7, WW, 18) break; case 21: GI8V(7, WW, 21) break; case 24: GI8V(7, WW, 24) break; case 30: GI8V(7, WW, 30) break; default: GI8V(7, WW, 33) break; }
     if (S == 7 && m->tune.i8_variant >= 0) { if (m->tune.i8_waves == 4) GI8X(2) else GI8X(4) } else
 #endif
     if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8(5, 2) break; case 6: GI8(6, 2) break; case 7: GI8(7, 2) break; default: GI8(8, 2) break; } }

@@ -13,7 +13,7 @@ nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(6, dtype=np.int32), 
 nm.upload(X)
 ref = None
 for waves in (4, 8):
-    for var in range(18):
+    for var in (0, 3, 6, 4, 12, 18, 21, 24, 30, 33):
         nm.set_option("i8_waves", waves); nm.set_option("i8_variant", var)
         rows = nm.bootstrap(64, seed=1)[0]
         if ref is None: ref = rows
@@ -23,4 +23,4 @@ for waves in (4, 8):
         for k in range(10): nm.bootstrap_device(B, seed=1, rep_offset=(2 + k) * B)
         nm.sync(); nm.profile(False)
         ms, n = nm.profile_read("gram")
-        print(json.dumps({"waves": waves, "variant": var, "NS": 3 + var % 3, "rstep": 1 + (var // 3) % 3, "dma_head": var // 9, "gram_ms": round(ms / n, 4), "identical_rows": ok}), flush=True)
+        print(json.dumps({"waves": waves, "variant": var, "pair_barrier": var >= 18, "NS": 5 if var >= 18 else 3 + var % 3, "rstep": 1 + (var // 3) % 3, "dma_head": (var % 18) // 9, "gram_ms": round(ms / n, 4), "identical_rows": ok}), flush=True)
