@@ -974,7 +974,16 @@ static int prepare_zs(plspm_model* m) {
     if ((rc = plspm_detail_h2d(m, m->pair_tab.p, tab.data(), tab.size() * sizeof(int)))) return rc;
     int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
     ProfScope ps(m, PLSPM_K_PACK);
-    hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)npair), dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, S, d_k, (double*)m->pair_scale.p);
+    {
+        // column maxima of the pair products: the digit buffer's head doubles as the npair x 8 B scratch (overwritten by zs_build below)
+        unsigned long long* d_max = (unsigned long long*)m->zs.p;
+        HIPCHK(m, hipMemsetAsync(d_max, 0, (size_t)npair * sizeof(unsigned long long), m->stream));
+        const int RB = (int)std::max<size_t>(1, std::min<size_t>(64, (kMaxLds - 1024) / ((size_t)(C | 1) * sizeof(double))));
+        const size_t lds = (size_t)RB * (C | 1) * sizeof(double);
+        if ((rc = allow_lds(m, (const void*)zs_max_kernel, lds))) return rc;
+        hipLaunchKernelGGL(zs_max_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB, d_max);
+        hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
+    }
     const dim3 grid((unsigned)KB, (unsigned)((npg + 3) / 4));
 #define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, (uint4*)m->zs.p)
     switch (S) { case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }
