@@ -23,6 +23,7 @@
 #pragma once
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define I8_SLACK_KB 6        // k-blocks of readable slack behind the counts and the digit planes (the DMA ring runs up to 5 k-steps ahead)
 #ifndef I8_DEFAULT_VAR
 #define I8_DEFAULT_VAR 3
 #endif
@@ -211,9 +212,11 @@ struct GramI8 {
 
 // one LDS-DMA block: 64 lanes x 16 B from `base + voff` to LDS byte address `lds_dst` (wave-uniform) + 16 lane
 __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+    // (M0 is written in the statement that uses it; nothing else in these kernels reads M0, so it is not saved / restored: two scalar
+    // moves less per DMA in a stream where every instruction between two MFMAs counts)
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ub), "s"(lds_dst) : "memory");
 }
 
 template <int S, int WM, int VAR = I8_DEFAULT_VAR>
@@ -253,12 +256,11 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
         inc[i] = (isA ? (long)MT : (long)NT) * 1024;
         dst[i] = lds0 + (unsigned)b * 1024u;
     }
-    int ahead = KB - 1;                               // k-steps the source pointers may still advance (they stop at the last one:
-    auto advance = [&]() {                            // a DMA past the end re-reads it, never used)
-        const bool more = ahead > 0;
-        --ahead;
+    // the source pointers simply run on: the DMAs of the k-steps past the end (never consumed) read the I8_SLACK_KB k-blocks of slack
+    // the host keeps behind both operands (a clamp cost a branch + 16 scalar selects per k-step)
+    auto advance = [&]() {
 #pragma unroll
-        for (int i = 0; i < G::PER; ++i) src[i] += more ? inc[i] : 0;
+        for (int i = 0; i < G::PER; ++i) src[i] += inc[i];
     };
     auto issue_one = [&](int i, unsigned stage_off) {
         if (i < G::PER - 1 || full) glds_block(src[i], voff, dst[i] + stage_off);

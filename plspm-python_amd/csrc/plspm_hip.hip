@@ -944,7 +944,7 @@ static int choose_gram_path(const plspm_model* m, int64_t B) {
     // indicator columns, incomplete rows zeroed, first stage of a HOC pair).  The LDS histogram bounds N; int32 accumulators need
     // 128 N < 2^31.
     if (m->stage1 || m->N > 65535 || m->N < 2) return 1;
-    const size_t zs_bytes = (size_t)i8_kblocks(m->N) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * m->tune.i8_slices) * 1024;
+    const size_t zs_bytes = (size_t)(i8_kblocks(m->N) + I8_SLACK_KB) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * m->tune.i8_slices) * 1024;
     if (zs_bytes > kZsBudget) return 1;
     if (m->tune.gram_path == 2) return 2;
     return B >= m->tune.i8_min_batch ? 2 : 1;
@@ -970,7 +970,7 @@ static int prepare_zs(plspm_model* m) {
     int rc;
     if ((rc = ensure(m, m->pair_tab, tab.size() * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->pair_scale, (size_t)npair * sizeof(double)))) return rc;
-    if ((rc = ensure(m, m->zs, (size_t)KB * NT * 1024))) return rc;
+    if ((rc = ensure(m, m->zs, (size_t)(KB + I8_SLACK_KB) * NT * 1024))) return rc;
     if ((rc = plspm_detail_h2d(m, m->pair_tab.p, tab.data(), tab.size() * sizeof(int)))) return rc;
     int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
     ProfScope ps(m, PLSPM_K_PACK);
@@ -1074,7 +1074,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     int rc;
     if (gpath == 2) {
         if ((rc = prepare_zs(m))) return rc;
-        if ((rc = ensure(m, m->cd, (size_t)((chunk + 255) / 256) * 256 * kpad))) return rc;
+        if ((rc = ensure(m, m->cd, (size_t)((chunk + 255) / 256) * 256 * (kpad + 64 * I8_SLACK_KB)))) return rc;
     }
     if (need_lists) {
         if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
