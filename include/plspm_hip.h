@@ -80,6 +80,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "i8_min_batch"    auto mode takes the int8 path from this many replicates per call (default 1: always -- the path must not
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
  *   "i8_waves"        4 | 8   waves per workgroup of the int8 Gram (default 4: one per SIMD, 128 replicates x 16 pairs each; 8: two per SIMD)
+ *   "i8_shape"        16 (default) | 32   MFMA shape / fragment-block layout of the int8 Gram (32: v_mfma_i32_32x32x32_i8, measured 16 % slower)
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
  * plspm_model_get_option reads a value back; the read-only key "last_gram_path" tells which Gram the last bootstrap call took.

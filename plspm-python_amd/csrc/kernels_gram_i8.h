@@ -21,6 +21,7 @@
 //   Cd: counts,  block index kb * MT + mt   (mt = replicate / 16, r = replicate % 16)
 //   Zs: digits,  block index kb * NT + nt   (nt = pair_group * S + s, r = pair % 16)
 #pragma once
+#include <type_traits>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define I8_SLACK_KB 6        // k-blocks of readable slack behind the counts and the digit planes (the DMA ring runs up to 5 k-steps ahead)
@@ -79,12 +80,17 @@ __global__ void __launch_bounds__(256) zs_scale_kernel(const unsigned long long*
 
 // Digit planes in fragment-major layout.  Thread (pgl, g, r) of workgroup (kb, y): pair 16 (4y + pgl) + r, rows 64 kb + 16 g .. + 15;
 // the 64 threads of one pair group write one contiguous 1 KB block per digit plane.
+// shape 16: thread (pgl, g, r) of workgroup (kb, y): pair 16 (4y + pgl) + r, rows 64 kb + 16 g .. + 15 -- block (kb, pair group * S + plane),
+// piece g * 16 + r.  shape 32: thread (pgl, sub, r): pair 32 (2y + pgl) + r, rows 64 kb + 16 sub .. -- block ((kb, group32 * S + plane), half
+// sub / 2), piece (sub % 2) * 32 + r.
 template <int S>
 __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict__ Xa, long N, int PA, const int* __restrict__ pair_p, const int* __restrict__ pair_q,
-                                                        const int* __restrict__ pair_k, int npair, int npg, int NT, uint4* __restrict__ Zs) {
-    const int tid = threadIdx.x, r = tid & 15, g = (tid >> 4) & 3, pg = (int)blockIdx.y * 4 + (tid >> 6);
-    if (pg >= npg) return;
-    const int kb = blockIdx.x, j = pg * 16 + r;
+                                                        const int* __restrict__ pair_k, int npair, int npg, int NT, int shape, uint4* __restrict__ Zs) {
+    const int tid = threadIdx.x;
+    int r, sub, pgw, j;                                   // pair within its group, 16-row chunk of the k-block, group (of 16 / 32 pairs)
+    if (shape == 16) { r = tid & 15; sub = (tid >> 4) & 3; pgw = (int)blockIdx.y * 4 + (tid >> 6); j = pgw * 16 + r; if (pgw >= npg) return; }
+    else { r = tid & 31; sub = (tid >> 5) & 3; pgw = (int)blockIdx.y * 2 + (tid >> 7); j = pgw * 32 + r; if (2 * pgw >= npg) return; }
+    const int kb = blockIdx.x;
     unsigned char dig[S][16];
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -92,7 +98,7 @@ __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict_
         for (int t = 0; t < 16; ++t) dig[s][t] = 0;
     if (j < npair) {
         const int p = pair_p[j], q = pair_q[j], k = pair_k[j];
-        const long i0 = (long)kb * 64 + g * 16;
+        const long i0 = (long)kb * 64 + sub * 16;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const long i = i0 + t;
@@ -114,7 +120,8 @@ __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) u[c] = (unsigned)dig[s][4 * c] | ((unsigned)dig[s][4 * c + 1] << 8) | ((unsigned)dig[s][4 * c + 2] << 16) | ((unsigned)dig[s][4 * c + 3] << 24);
         w.x = u[0]; w.y = u[1]; w.z = u[2]; w.w = u[3];
-        Zs[((long)kb * NT + (long)pg * S + s) * 64 + g * 16 + r] = w;
+        if (shape == 16) Zs[((long)kb * NT + (long)pgw * S + s) * 64 + sub * 16 + r] = w;
+        else Zs[((long)kb * NT + ((long)pgw * S + s) * 2 + (sub >> 1)) * 64 + (sub & 1) * 32 + r] = w;
     }
 }
 
@@ -122,7 +129,7 @@ __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict_
 // One workgroup per replicate, the same Philox draws / explicit indices and the same 16-bit LDS histogram as resample_kernel; the
 // histogram leaves as bytes in fragment-major layout (16 consecutive rows = one 16-byte piece).  err bit 0: index out of range,
 // bit 1: a multiplicity above 127 (only possible with explicit indices; the host then falls back to the fp64 Gram).
-__global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
+__global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT, int shape, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
                                                            int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KB * 32 words: rows 2w, 2w+1 in the halves of word w (zero beyond N)
@@ -165,7 +172,8 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
         uint4 out;
         out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
         const int kb = c >> 2, g = c & 3;
-        Cd[((long)kb * MT + mt) * 64 + g * 16 + r] = out;
+        if (shape == 16) Cd[((long)kb * MT + mt) * 64 + g * 16 + r] = out;
+        else Cd[((long)kb * MT + (b >> 5) * 2 + (g >> 1)) * 64 + (g & 1) * 32 + (int)(b & 31)] = out;       // block (tile of 32, half g / 2), piece (g % 2) 32 + row
     }
     if (over) atomicOr(err, 2);
 }
@@ -193,10 +201,18 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
 // hide behind its own MFMAs: with two, the partner's MFMAs run meanwhile).
 // VAR (experiments, tools/i8_bench.py): ring depth NS = 3 + VAR % 3, a fragment read after every (1 + VAR / 3 % 3)-th MFMA, DMA issue
 // spread over the step (VAR / 9 == 0) or at its head (1).
-template <int S, int WM, int VAR = I8_DEFAULT_VAR>
+// SH: MFMA shape.  16: v_mfma_i32_16x16x64_i8, blocks of 16 rows x 64 k, waves 2 (pair groups of 16) x WM.  32: v_mfma_i32_32x32x32_i8 (a 12 %
+// higher measured ceiling, and 7 instead of 3 free issue slots behind every MFMA), blocks of 32 rows x 32 k (two per k-block: halves
+// h = 0, 1), every wave spans the workgroup's 32 pairs x S planes and 256 / NW replicates.  The 1 KB blocks a workgroup needs per
+// k-step are the same contiguous 16 + 2 S KB in both layouts; only the inside of a block differs (lane l's 16 bytes at 16 l in both).
+template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16>
 struct GramI8 {
     static constexpr int NW = 2 * WM;               // waves per workgroup
-    static constexpr int MTW = 16 / WM;             // count tiles (16 replicates) per wave
+    static constexpr int MTW = 16 / WM;             // SH 16: count tiles (16 replicates) per wave
+    static constexpr int T32W = 8 / NW;             // SH 32: count tiles (32 replicates) per wave
+    static constexpr int NA = SH == 16 ? MTW : 2 * T32W;      // operand fragments (16 B per lane) per wave and k-step: counts ...
+    static constexpr int NB = SH == 16 ? S : 2 * S;           // ... and digit planes
+    static constexpr int NMFMA = SH == 16 ? MTW * S : 2 * T32W * S;
     static constexpr int NBLK = 16 + 2 * S;         // 1 KB blocks per k-step: 16 count tiles + 2 pair groups x S planes
     static constexpr int PER = (NBLK + NW - 1) / NW;   // DMA instructions per wave and k-step
     static constexpr int STAGE_BYTES = NBLK * 1024;
@@ -219,16 +235,18 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ub), "s"(lds_dst) : "memory");
 }
 
-template <int S, int WM, int VAR = I8_DEFAULT_VAR>
+template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16>
 __global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2)))
 gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
                const int* __restrict__ pair_dst2, const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
-    using G = GramI8<S, WM, VAR>;
-    constexpr int MTW = G::MTW;
+    using G = GramI8<S, WM, VAR, SH>;
+    constexpr int MTW = G::MTW, NA = G::NA, NB = G::NB;
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    using AccT = typename std::conditional<SH == 16, i32x4, i32x16>::type;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = SH == 16 ? wave >> 1 : wave, wn = SH == 16 ? wave & 1 : 0;
     // XCD-aware tile enumeration
     const int total = ntx * nty, per = (total + 7) >> 3;
     const int w = blockIdx.x, slot = w >> 3;
@@ -272,64 +290,76 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     //    front of the next barrier (~900 cycles later), which names the registers "+v" so that nothing the compiler does with them
     //    can move above it -- compiler-issued LDS loads got an s_waitcnt lgkmcnt(0) in front of the first MFMA of every step;
     //  * an accumulator is touched once per k-step, so no MFMA depends on a neighbour; the epilogue reads them after the nops below.
-    i32x4 acc[MTW][S];
+    constexpr int NACC0 = SH == 16 ? MTW : G::T32W;
+    AccT acc[NACC0][S];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+    for (int mt = 0; mt < NACC0; ++mt)
 #pragma unroll
-        for (int s = 0; s < S; ++s) acc[mt][s] = (i32x4){0, 0, 0, 0};
-    const unsigned fbaseA = voff + (unsigned)wm * (unsigned)(MTW * 1024), fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
+        for (int s = 0; s < S; ++s) acc[mt][s] = AccT{};
+    // fragment a of the counts: SH 16 tile wm MTW + a; SH 32 (tile wm T32W + a / 2, half a % 2) -- consecutive blocks either way;
+    // fragment b of the digits: SH 16 plane b of pair group wn; SH 32 (plane b / 2, half b % 2)
+    const unsigned fbaseA = voff + (unsigned)wm * (unsigned)(NA * 1024), fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
 #define GI8_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(off))
-#define GI8_MFMA(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define GI8_MFMA16(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define GI8_MFMA32(c, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
     // one k-step: MFMAs on (fc, fd); in their shadow the fragment reads of the following k-step from LDS stage R into (fna, fnb)
-    // and this wave's DMA instructions of the k-step three ahead into stage W (an LDS-DMA instruction occupies the wave's issue for
+    // and this wave's DMA instructions of the k-step AHEAD into stage W (an LDS-DMA instruction occupies the wave's issue for
     // ~60 cycles: eight of them back to back in front of the barrier left the matrix pipe idle a third of every step)
-    auto step = [&](i32x4 (&fc)[MTW], i32x4 (&fd)[S], i32x4 (&fna)[MTW], i32x4 (&fnb)[S], unsigned Roff, unsigned Woff) {
+    auto step = [&](i32x4 (&fc)[NA], i32x4 (&fd)[NB], i32x4 (&fna)[NA], i32x4 (&fnb)[NB], unsigned Roff, unsigned Woff) {
         const unsigned ra = fbaseA + Roff, rb = fbaseB + Roff;
-        constexpr int RSTEP = (MTW * S) / (MTW + S) >= G::RSTEP ? G::RSTEP : 1;          // a fragment read after every RSTEP-th MFMA
+        constexpr int RSTEP = G::NMFMA / (NA + NB) >= G::RSTEP ? G::RSTEP : 1;          // a fragment read after every RSTEP-th MFMA
         int nread = 0, ndma = 0;
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int m = mt * S + s;
-                GI8_MFMA(acc[mt][s], fc[mt], fd[s]);
-                if (m % RSTEP == 0 && nread < MTW + S) {
-                    if (nread < MTW) GI8_DSREAD(fna[nread], ra, nread * 1024);
-                    else GI8_DSREAD(fnb[nread - MTW], rb, (nread - MTW) * 1024);
-                    ++nread;
-                }
-                if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * MTW * S) / G::PER + 1)) { issue_one(ndma, Woff); ++ndma; }
+        auto fill = [&](int m) {                              // what rides behind MFMA number m of the step
+            if (m % RSTEP == 0 && nread < NA + NB) {
+                if (nread < NA) GI8_DSREAD(fna[nread], ra, nread * 1024);
+                else GI8_DSREAD(fnb[nread - NA], rb, (nread - NA) * 1024);
+                ++nread;
             }
+            if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * G::NMFMA) / G::PER + 1)) { issue_one(ndma, Woff); ++ndma; }
+        };
+        if constexpr (SH == 16) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int s = 0; s < S; ++s) { GI8_MFMA16(acc[mt][s], fc[mt], fd[s]); fill(mt * S + s); }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < G::T32W; ++i)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) { GI8_MFMA32(acc[i][s], fc[2 * i + h], fd[2 * s + h]); fill((h * G::T32W + i) * S + s); }
+        }
+        // stragglers (more fragments than RSTEP-spaced slots)
+#pragma unroll
+        for (int r = 0; r < NA + NB; ++r)
+            if (r >= nread) { if (r < NA) GI8_DSREAD(fna[r], ra, r * 1024); else GI8_DSREAD(fnb[r - NA], rb, (r - NA) * 1024); }
         advance();
     };
     // wait until this wave's DMAs of the k-step after next are the only ones in flight and the fragment reads of the set consumed
     // next have returned (the registers are named so that nothing the compiler does with them moves above the wait); then the
     // workgroup barrier: every wave's share of the next k-step has landed
-    auto wait_barrier = [&](i32x4 (&fa)[MTW], i32x4 (&fb)[S]) {
+    auto wait_frags = [&](i32x4 (&fa)[NA], i32x4 (&fb)[NB]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(fb[i]));
+    };
+    auto wait_barrier = [&](i32x4 (&fa)[NA], i32x4 (&fb)[NB]) {
         // (the count differs between waves; the branch holds no register operands -- with the pins inside it hipcc merged the two
         // variants through copies of all the fragment registers every step)
         if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * G::PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * (G::PER - 1)) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(fa[i]));
-#pragma unroll
-        for (int i = 0; i < S; ++i) asm volatile("" : "+v"(fb[i]));
+        wait_frags(fa, fb);
         asm volatile("s_barrier" ::: "memory");
     };
-    auto wait_frags = [&](i32x4 (&fa)[MTW], i32x4 (&fb)[S]) {       // second k-step of a pair: only this wave's fragment reads
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(fa[i]));
-#pragma unroll
-        for (int i = 0; i < S; ++i) asm volatile("" : "+v"(fb[i]));
-    };
 
-    i32x4 fa0[MTW], fb0[S], fa1[MTW], fb1[S];
+    i32x4 fa0[NA], fb0[NB], fa1[NA], fb1[NB];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
+    for (int i = 0; i < NA; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
 #pragma unroll
-    for (int i = 0; i < S; ++i) { fb0[i] = (i32x4){0, 0, 0, 0}; fb1[i] = fb0[i]; }
+    for (int i = 0; i < NB; ++i) { fb0[i] = (i32x4){0, 0, 0, 0}; fb1[i] = fb0[i]; }
     const auto issue_all = [&](unsigned stage_off) {
 #pragma unroll
         for (int i = 0; i < G::PER; ++i) issue_one(i, stage_off);
@@ -338,9 +368,9 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     issue_all(0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // k-step 0 has landed
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
+    for (int i = 0; i < NA; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
 #pragma unroll
-    for (int i = 0; i < S; ++i) GI8_DSREAD(fb0[i], fbaseB, i * 1024);
+    for (int i = 0; i < NB; ++i) GI8_DSREAD(fb0[i], fbaseB, i * 1024);
     constexpr int AHEAD = G::PAIRB ? G::NS - 1 : G::NS;        // the DMA issued during k-step kb carries k-step kb + AHEAD
 #pragma unroll
     for (int st = 1; st < AHEAD; ++st) issue_all(st * G::STAGE_BYTES);
@@ -359,32 +389,52 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> readable
 #undef GI8_DSREAD
-#undef GI8_MFMA
+#undef GI8_MFMA16
+#undef GI8_MFMA32
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // no DMA may land after the workgroup has gone
 
-    const int j = (tx * 2 + wn) * 16 + (lane & 15);
+    // Epilogue: the lane's pair and replicates from the MFMA's C/D map -- 16x16: column lane & 15, rows 4 (lane >> 4) + reg;
+    // 32x32: column lane & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    const int j = SH == 16 ? (tx * 2 + wn) * 16 + (lane & 15) : tx * 32 + (lane & 31);
     if (j >= npair) return;
     const long dstj = pair_dst[j];
     const long dstj2 = pair_dst2 ? (long)pair_dst2[j] : -1;       // dense layout: the mirrored slot (q, p); -1 on the diagonal / packed layout
     const double sc = pair_scale[j];
-    const long rep0 = (long)ty * 256 + wm * (MTW * 16) + (lane >> 4) * 4;
-    double* gp = gram + rep0 * psize + dstj;           // walks the replicates of this lane; opaque to the compiler so that it does not
-#pragma unroll                                         // precompute (and spill) 32 addresses
-    for (int mt = 0; mt < MTW; ++mt) {
+    auto emit = [&](double* gp, bool live, auto pick) {            // pick(s): the element's accumulator of plane s
+        if (live) {
+            // sum_s acc_s 256^s from the low planes up: every term is exact in fp64, the partial sums round only once they
+            // pass 2^53 (relative 2^-53 each): the recombination costs about one ulp
+            double v = (double)pick(0);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            if (rep0 + mt * 16 + reg < nrep) {
-                // sum_s acc_s 256^s from the low planes up: every term is exact in fp64, the partial sums round only once they
-                // pass 2^53 (relative 2^-53 each): the recombination costs about one ulp
-                double v = (double)acc[mt][0][reg];
-#pragma unroll
-                for (int s = 1; s < S; ++s) v = fma((double)acc[mt][s][reg], (double)(1ll << (8 * s)), v);
-                *gp = v * sc;
-                if (dstj2 >= 0) gp[dstj2 - dstj] = v * sc;
-            }
-            gp += psize;
-            asm volatile("" : "+v"(gp)::"memory");
+            for (int s = 1; s < S; ++s) v = fma((double)pick(s), (double)(1ll << (8 * s)), v);
+            *gp = v * sc;
+            if (dstj2 >= 0) gp[dstj2 - dstj] = v * sc;
         }
-        gp += 12 * psize;
+    };
+    if constexpr (SH == 16) {
+        const long rep0 = (long)ty * 256 + wm * (MTW * 16) + (lane >> 4) * 4;
+        double* gp = gram + rep0 * psize + dstj;       // walks the replicates of this lane; opaque to the compiler so that it does not
+#pragma unroll                                         // precompute (and spill) 32 addresses
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                emit(gp, rep0 + mt * 16 + reg < nrep, [&](int s) { return acc[mt][s][reg]; });
+                gp += psize;
+                asm volatile("" : "+v"(gp)::"memory");
+            }
+            gp += 12 * psize;
+        }
+    } else {
+        const long rep0 = (long)ty * 256 + wm * (G::T32W * 32) + (lane >> 5) * 4;
+        double* gp = gram + rep0 * psize + dstj;
+#pragma unroll
+        for (int i = 0; i < G::T32W; ++i) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {                   // row (reg & 3) + 8 (reg >> 2) of the tile (+ 4 for the upper lanes)
+                emit(gp, rep0 + i * 32 + (reg & 3) + 8 * (reg >> 2) < nrep, [&](int s) { return acc[i][s][reg]; });
+                gp += ((reg & 3) == 3 ? 5 : 1) * psize;            // rows 0..3, 8..11, 16..19, 24..27
+                asm volatile("" : "+v"(gp)::"memory");
+            }
+        }
     }
 }

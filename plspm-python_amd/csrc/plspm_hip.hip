@@ -662,6 +662,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
+    else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 35) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
@@ -684,6 +685,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
+    else if (k == "i8_shape") *value = m->tune.i8_shape;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else return PLSPM_E_ARG;
     return 0;
@@ -985,7 +987,7 @@ static int prepare_zs(plspm_model* m) {
         hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
     }
     const dim3 grid((unsigned)KB, (unsigned)((npg + 3) / 4));
-#define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, (uint4*)m->zs.p)
+#define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, m->tune.i8_shape, (uint4*)m->zs.p)
     switch (S) { case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }
 #undef ZSB
     HIPCHK(m, hipGetLastError());
@@ -1006,7 +1008,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     if ((rc = allow_lds(m, (const void*)resample_i8_kernel, hist_bytes))) return rc;
     {
         ProfScope ps(m, PLSPM_K_RESAMPLE);
-        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, d_idx, seed, rep0, (uint4*)m->cd.p, (int*)m->err.p);
+        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)m->cd.p, (int*)m->err.p);
     }
     if (d_idx) {
         int* h_err = (int*)m->h_flag + 9;
@@ -1026,22 +1028,27 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const int* d_dst2 = nullptr;          // (a mirrored second store per element cost 0.08 ms per 5,000 replicates: the rows solver reads the triangle instead)
     const long out_stride = dense ? cov_doubles(m->Pg) : packed_size(m->T);
     ProfScope ps(m, PLSPM_K_GRAM);
-#define GI8V(SS, WW, VV)                                                                                                                     \
+#define GI8VS(SS, WW, VV, SH)                                                                                                                \
     {                                                                                                                                        \
-        const size_t lds_bytes = GramI8<SS, WW, VV>::LDS_BYTES;                                                                              \
-        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS, WW, VV>, lds_bytes))) return rc;                                              \
-        hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)m->cd.p, \
+        const size_t lds_bytes = GramI8<SS, WW, VV, SH>::LDS_BYTES;                                                                          \
+        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS, WW, VV, SH>, lds_bytes))) return rc;                                          \
+        hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV, SH>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)m->cd.p, \
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
     }
+#define GI8V(SS, WW, VV) GI8VS(SS, WW, VV, 16)
 #define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
 #ifdef PLSPM_I8_EXPERIMENTS       // every schedule variant of the 7-plane kernel (tools/i8_bench.py --variants; not in the release library)
 #define GI8X(WW) switch (m->tune.i8_variant) { case 0: GI8V(7, WW, 0) break; case 3: GI8V(7, WW, 3) break; case 6: GI8V(7, WW, 6) break; case 4: GI8V(7, WW, 4) break; \
         case 12: GI8V(7, WW, 12) break; case 18: GI8V(7, WW, 18) break; case 21: GI8V(7, WW, 21) break; case 24: GI8V(7, WW, 24) break; case 30: GI8V(7, WW, 30) break; default: GI8V(7, WW, 33) break; }
     if (S == 7 && m->tune.i8_variant >= 0) { if (m->tune.i8_waves == 4) GI8X(2) else GI8X(4) } else
 #endif
+    if (m->tune.i8_shape == 32) {              // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
+        switch (S) { case 5: GI8VS(5, 2, I8_DEFAULT_VAR, 32) break; case 6: GI8VS(6, 2, I8_DEFAULT_VAR, 32) break; case 7: GI8VS(7, 2, I8_DEFAULT_VAR, 32) break; default: GI8VS(8, 2, I8_DEFAULT_VAR, 32) break; }
+    } else
     if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8(5, 2) break; case 6: GI8(6, 2) break; case 7: GI8(7, 2) break; default: GI8(8, 2) break; } }
     else { switch (S) { case 5: GI8(5, 4) break; case 6: GI8(6, 4) break; case 7: GI8(7, 4) break; default: GI8(8, 4) break; } }
 #undef GI8V
+#undef GI8VS
 #undef GI8
     HIPCHK(m, hipGetLastError());
     return 0;

@@ -192,3 +192,22 @@ def test_rows_solver_equals_lds_solver_on_the_same_moments(modes, scheme):
         mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(3, r, 3000), corr)
         assert its == iters[r]
         assert_close(rows[r], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("slices", [5, 7, 8])
+def test_mfma_32x32x32_layout_gives_identical_matrices(slices):
+    """i8_shape 32: v_mfma_i32_32x32x32_i8 on 32-row fragment blocks.  Exact integer sums + the same recombination: the moment matrices
+    (hence the rows) are bit-identical to the 16x16x64 layout's."""
+    C = orc.chain_C(7)
+    X, blocks = orc.synth(777, C, 5, seed=2)
+    model = orc.Model(blocks, C, "ABABABA", "factorial", True)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.set_option("i8_slices", slices)
+    M16 = nm.bootstrap_moments(300, seed=7)
+    rows16 = nm.bootstrap(300, seed=7)[0]
+    nm.set_option("i8_shape", 32)
+    M32 = nm.bootstrap_moments(300, seed=7)
+    rows32 = nm.bootstrap(300, seed=7)[0]
+    assert nm.get_option("last_gram_path") == 2
+    assert np.array_equal(M16, M32) and np.array_equal(rows16, rows32)
