@@ -13,7 +13,7 @@ only spawns the ranks (RANK / LOCAL_RANK / WORLD_SIZE); without a launcher `--gp
 
 Extra objects on the line:
   roofline      dominant kernel, duration measured with HIP events on the library's own stream during the timed steps.  Default path:
-                gram_i8_kernel<7, 4, 3> (7 digit planes, 8 waves per workgroup) -- the batch's moment matrices as ONE exact int8 MFMA product of the dense resample
+                gram_i8_kernel<7, 2, 3, 16> (7 digit planes, 4 waves per workgroup, 16x16x64 MFMA) -- the batch's moment matrices as ONE exact int8 MFMA product of the dense resample
                 multiplicities with the 7 base-256 digit planes of the pair products x_p x_q (csrc/kernels_gram_i8.h); its
                 algorithmic work is 2 N (P+1)(P+2)/2 7 int8 ops per replicate.  --gram-path 1: the fp64 MFMA Gram of round 1
                 (gram_rows_kernel<4,false>, SURVEY.md 8(d) flops).  `fp64_mfma_path` on the line = the same workload on that path.
@@ -298,7 +298,7 @@ def main():
             traffic, traffic_src = static_traffic(("r02_gram_i8_traffic.json",))
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "gram_i8_kernel<%d, %d, 3>" % (slices, model.get_option("i8_waves") // 2), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
+                        "kernel": "gram_i8_kernel<%d, %d, 3, %d>" % (slices, model.get_option("i8_waves") // 2, model.get_option("i8_shape")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",
                         "algorithmic_ops_per_replicate": ops_rep,
                         "algorithmic_ops_derivation": "2 x N rows x %d pair columns x %d digit planes (SURVEY 8(d)'s N P (P+1) fp64 flops = %.4g per replicate, "
