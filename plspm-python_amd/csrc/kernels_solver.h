@@ -23,11 +23,37 @@ struct DevExecT {
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = __hiloint2double(__builtin_amdgcn_readlane(hi, first + j), __builtin_amdgcn_readlane(lo, first + j));
     }
+    // Broadcast operand of the rows solver's P x L products (one wave per problem): W[a] = w[16 a + lane % 16], i.e. every row of 16 lanes
+    // holds a copy of the whole vector in four register pairs; column q then reaches all 64 lanes as the DPP operand `row_newbcast:q % 16`
+    // of W[q / 16] INSIDE the multiply-add -- one v_fmac_f64_dpp per column, against two v_readlane + the v_fmac before (the wave
+    // issues one instruction per 4 cycles: instruction count is the cost).  Entries past n repeat w[n - 1] (finite; their partners are 0).
+    __device__ __forceinline__ void bcast_load(const double* w, int n, double (&W)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) W[a] = w[min(16 * a + (tid & 15), n - 1)];
+    }
+    // r0 += s[0] w[Q0] + s[2] w[Q0 + 2],  r1 += s[1] w[Q0 + 1] + s[3] w[Q0 + 3]   (Q0 % 4 == 0: the four columns share W[Q0 / 16]).
+    // The leading s_nop covers the two wait states between a VALU write of W (a register copy the compiler may have placed) and its DPP read.
+    template <int Q0> __device__ __forceinline__ void fma4_bcast(double& r0, double& r1, const double (&W)[4], const double*, const double* s) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+            : "+v"(r0), "+v"(r1)
+            : "v"(W[Q0 >> 4]), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "n"(Q0 & 15), "n"((Q0 + 1) & 15), "n"((Q0 + 2) & 15), "n"((Q0 + 3) & 15));
+    }
+    template <int Q> __device__ __forceinline__ void fma1_bcast(double& r, const double (&W)[4], const double*, double s) {
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(W[Q >> 4]), "v"(s), "n"(Q & 15));
+    }
+    // where threads without an item of their own may store (a shared dead array: every lane then runs the same store instruction)
+    __device__ __forceinline__ double* sink(double* dead) { return dead; }
     // a value every thread of the group holds identically, made provably uniform (scalar registers, scalar branches)
     __device__ __forceinline__ unsigned long long uniform(unsigned long long v) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return ((unsigned long long)hi << 32) | lo;
     }
+    // a uniform value the compiler may not hoist, expand or re-derive across this point (stays in one scalar register pair)
+    __device__ __forceinline__ unsigned long long opaque(unsigned long long v) { asm volatile("" : "+s"(v)); return v; }
     // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
     template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
         int i0 = tid, i1 = 0;

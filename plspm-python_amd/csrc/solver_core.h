@@ -470,33 +470,48 @@ template <int PMAX>
 struct CovRows {
     double s[PMAX];             // s[q] = S[q][p] of the calling thread's column p = ex.tid (symmetric: its row as well)
     unsigned long long ends;    // bit q set: column q is the last one of its LV block (wave-uniform; PMAX <= 64)
-    // s[q] is 0 for q >= P, so the products run unguarded over whole chunks of 8 columns: the 8 broadcast reads of w are issued
-    // together (a per-column guard made every column its own basic block -- one exposed LDS round trip each, 11k cycles per call),
-    // only the block-boundary bookkeeping is conditional (uniform).
+    // V[p, m] = sum over the columns q of block m of s[q] w[q].  s[q] is 0 for q >= P, so whole groups run unguarded.  w reaches the threads
+    // as a broadcast operand of the multiply-add itself (ex.bcast_load / fma4_bcast: device v_fmac_f64_dpp); columns go in groups of four:
+    // a group whose first three columns close no block (scalar test on the boundary mask, the usual case) is four multiply-adds back to
+    // back and one more scalar test, the others take the column-wise path that sits out of line.
+    // History (cycles per call at P = 60, L = 6, one wave): per-thread boundary tests + w from LDS 7.3k; selects instead of a branch 6.5k;
+    // uniform test per column, w by v_readlane 5.4k -- there hipcc had expanded the loop-invariant mask into 64 lane masks spilled to VGPR
+    // lanes (two v_readlane per column to get them back) and laid the common case out as a TAKEN branch (~60 cycles of instruction
+    // fetch each).  The mask is now re-materialised per call (ex.opaque) and the closing side is marked unlikely.
+    template <int Q0, class Ex, class Close>
+    PLSPM_HD void column_groups(Ex& ex, const double (&W)[4], const double* w, unsigned long long e, int P, double& r0, double& r1, Close& close) const {
+        if constexpr (Q0 < PMAX) {
+            if ((Q0 & ~15) < P) {                             // (uniform; one test per 16 columns)
+                const unsigned b = (unsigned)(e >> Q0) & 15u;
+                if (__builtin_expect((b & 7u) == 0u, 1)) {
+                    ex.template fma4_bcast<Q0>(r0, r1, W, w, s + Q0);
+                    if (__builtin_expect(b != 0u, 0)) close();
+                } else {
+                    ex.template fma1_bcast<Q0>(r0, W, w, s[Q0]);
+                    if (b & 1u) close();
+                    ex.template fma1_bcast<Q0 + 1>(r1, W, w, s[Q0 + 1]);
+                    if (b & 2u) close();
+                    ex.template fma1_bcast<Q0 + 2>(r0, W, w, s[Q0 + 2]);
+                    if (b & 4u) close();
+                    ex.template fma1_bcast<Q0 + 3>(r1, W, w, s[Q0 + 3]);
+                    if (b & 8u) close();
+                }
+            }
+            column_groups<Q0 + 4>(ex, W, w, e, P, r0, r1, close);
+        }
+    }
     template <class Ex>
     PLSPM_HD void block_products(Ex& ex, const ModelDesc& md, Workspace& ws) const {
         const int P = md.P, L = md.L, p = ex.tid;
-        // thread q holds w[q] in a register; a chunk of 8 reaches every thread through the executor (device: v_readlane -> scalar
-        // operands of the FMAs, no LDS round trip per chunk; every thread of the group takes part)
-        const double wreg = ws.w[(p < P) ? p : P - 1];
-        // (a wave issues one instruction per 4 cycles whatever the number of busy lanes: what counts is instructions per column.  A
-        // uniform test + conditional store per column measured 5.4k cycles per call; storing the running sum after EVERY column with
-        // selects instead of the branch 6.5k; per-thread boundary tests with w read from LDS 7.3k)
-        int m = 0;
+        double W[4];
+        ex.bcast_load(ws.w, P, W);
+        const unsigned long long e = ex.opaque(ends);
+        // every thread stores (idle ones into a sink -- ws.wn is dead while V is formed and holds P >= L doubles): closing a block is
+        // straight-line code with a scalar block counter; under `if (p < P)` it was a divergent region per column group
+        double* vrow = (p < P) ? ws.V + p * L : ex.sink(ws.wn);
         double r0 = 0.0, r1 = 0.0;                           // two chains per block (even / odd column): half the dependent latency
-#pragma unroll
-        for (int q0 = 0; q0 < PMAX; q0 += 8) {
-            if (q0 < P) {                                     // (uniform across the threads)
-                double wq[8];
-                ex.template gather8<PMAX>(wreg, q0, wq);      // w of columns q0 .. q0+7, the same on every thread
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = q0 + j;
-                    if (j & 1) r1 += s[q] * wq[j]; else r0 += s[q] * wq[j];
-                    if ((ends >> q) & 1ull) { if (p < P) ws.V[p * L + m] = r0 + r1; r0 = 0.0; r1 = 0.0; ++m; }     // column q closes block m (uniform test)
-                }
-            }
-        }
+        auto close = [&]() { *vrow++ = r0 + r1; r0 = 0.0; r1 = 0.0; };      // the column just added closes its block
+        column_groups<0>(ex, W, ws.w, e, P, r0, r1, close);
         ex.sync();
     }
     PLSPM_HD void cov_row(const Workspace&, int, int P, double* dst) const {
@@ -754,15 +769,11 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
             }
         });
     }
-    // init (weights.py:28-39): w_p = 1 / sqrt(sum(S_bb)) of the MV's own block
-    if (mine) {
-        const int l = md.lvof[p], b0 = md.boff[l], b1 = md.boff[l + 1];
-        double r = 0.0;
-#pragma unroll
-        for (int q = 0; q < PMAX; ++q) if (q >= b0 && q < b1) r += cov.s[q];
-        ws.dv[p] = r;
-    }
-    ex.sync();
+    // init (weights.py:28-39): w_p = 1 / sqrt(sum(S_bb)) of the MV's own block -- the block row sums are the products with w = 1
+    // (a per-thread `q in [b0, b1)` select chain over the 64 registers cost three instructions per column)
+    ex.par(P, [&](int i) { ws.w[i] = 1.0; });
+    cov.block_products(ex, md, ws);
+    ex.par(P, [&](int i) { ws.dv[i] = ws.V[i * L + md.lvof[i]]; });
     ex.par(L, [&](int l) {
         double s = 0.0;
         for (int q = md.boff[l]; q < md.boff[l + 1]; ++q) s += ws.dv[q];

@@ -25,6 +25,15 @@ struct HostExec {
     void mark(int) {}
     void sync() { bar->arrive_and_wait(); }
     unsigned long long uniform(unsigned long long v) { return v; }
+    unsigned long long opaque(unsigned long long v) { return v; }
+    double* sink(double*) { static thread_local double mine[64]; return mine; }       // (no shared writes: ThreadSanitizer runs this code)
+    // (device: the vector replicated per row of 16 lanes and consumed as a DPP broadcast operand; here: read in place)
+    void bcast_load(const double*, int n, double (&W)[4]) { W[0] = (double)n; W[1] = W[2] = W[3] = 0.0; }
+    template <int Q0> void fma4_bcast(double& r0, double& r1, const double (&W)[4], const double* w, const double* s) {
+        const int n = (int)W[0];
+        for (int j = 0; j < 4; ++j) { const double t = s[j] * ((Q0 + j < n) ? w[Q0 + j] : 0.0); if (j & 1) r1 += t; else r0 += t; }
+    }
+    template <int Q> void fma1_bcast(double& r, const double (&W)[4], const double* w, double s) { r += s * ((Q < (int)W[0]) ? w[Q] : 0.0); }
     template <int N> void gather8(double v, int first, double (&out)[8]) {      // `red` holds nt slots wherever this is used (rows variant)
         red[tid] = v;
         bar->arrive_and_wait();
