@@ -23,28 +23,61 @@ struct DevExecT {
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = __hiloint2double(__builtin_amdgcn_readlane(hi, first + j), __builtin_amdgcn_readlane(lo, first + j));
     }
-    // Broadcast operand of the rows solver's P x L products (one wave per problem): W[a] = w[16 a + lane % 16], i.e. every row of 16 lanes
-    // holds a copy of the whole vector in four register pairs; column q then reaches all 64 lanes as the DPP operand `row_newbcast:q % 16`
-    // of W[q / 16] INSIDE the multiply-add -- one v_fmac_f64_dpp per column, against two v_readlane + the v_fmac before (the wave
-    // issues one instruction per 4 cycles: instruction count is the cost).  Entries past n repeat w[n - 1] (finite; their partners are 0).
-    __device__ __forceinline__ void bcast_load(const double* w, int n, double (&W)[4]) {
+    // Segmented products of the rows solver (one wave per problem, solver_core.h CovRows::block_products): thread p holds s[q] = S[q][p];
+    //     vrow[m] = sum over the columns q of block m of s[q] w[q],     `ends` bit q = column q closes its block (wave-uniform).
+    // w reaches the lanes as the DPP operand of the multiply-add itself: W[a] = w[16 a + lane % 16] (every row of 16 lanes holds a copy of
+    // the vector in four register pairs), column q = `row_newbcast:q % 16` of W[q / 16] -- ONE v_fmac_f64_dpp per column, then a scalar bit
+    // test whose taken side (add the two chains, store, advance, clear: six instructions) sits out of line behind the block.  A wave issues
+    // one instruction per ~4 cycles whatever it is, so the count per column is the cost: 3 here; 7 + a TAKEN branch (an instruction-fetch
+    // bubble of ~60 cycles) in the compiled form with v_readlane broadcasts, where hipcc had also expanded the loop-invariant mask into
+    // 64 lane masks spilled to VGPR lanes (5.2k cycles per call at P = 60 against 2.6k for compiled DPP groups of four and this form's
+    // ~1k).  Columns >= P hold s = 0 and W repeats w[P - 1] (finite).  Sixteen columns per asm statement (operand count); the leading
+    // s_nop covers the two wait states between a VALU write of W (a copy the compiler may place in front) and its DPP read.
+#define PLSPM_SEG_COL(J, ACC, SOP)                                                                                  \
+    "v_fmac_f64_dpp " ACC ", %4, " SOP " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"                        \
+    "s_bitcmp1_b32 %21, " #J "\n\t"                                                                                 \
+    "s_cbranch_scc1 .Lc" #J "_%=\n"                                                                                 \
+    ".Lb" #J "_%=:\n\t"
+#define PLSPM_SEG_CLOSE(J)                                                                                          \
+    ".Lc" #J "_%=:\n\t"                                                                                             \
+    "v_add_f64 %3, %0, %1\n\t"                                                                                      \
+    "ds_write_b64 %2, %3\n\t"                                                                                       \
+    "v_add_u32 %2, 8, %2\n\t"                                                                                       \
+    "v_mov_b64 %0, 0\n\t"                                                                                           \
+    "v_mov_b64 %1, 0\n\t"                                                                                           \
+    "s_branch .Lb" #J "_%=\n"
+    template <int PMAX> __device__ __forceinline__ void seg_products(const double (&s)[PMAX], const double* w, int P, unsigned long long ends, double* vrow) {
+        static_assert(PMAX % 16 == 0, "sixteen columns per statement");
+        double W[PMAX / 16];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) W[a] = w[min(16 * a + (tid & 15), n - 1)];
+        for (int a = 0; a < PMAX / 16; ++a) W[a] = w[min(16 * a + (tid & 15), P - 1)];
+        unsigned va = (unsigned)(size_t)vrow;                     // LDS byte address (generic -> local is a truncation)
+        double r0 = 0.0, r1 = 0.0, t;                             // two chains per block (even / odd column): half the dependent latency
+#pragma unroll
+        for (int a = 0; a < PMAX / 16; ++a) {
+            if (16 * a < P) {                                     // (uniform)
+                const unsigned eh = (unsigned)(ends >> (16 * a)) & 0xffffu;
+                const double* c = s + 16 * a;
+                asm volatile("s_nop 1\n\t"
+                             PLSPM_SEG_COL(0, "%0", "%5") PLSPM_SEG_COL(1, "%1", "%6") PLSPM_SEG_COL(2, "%0", "%7") PLSPM_SEG_COL(3, "%1", "%8")
+                             PLSPM_SEG_COL(4, "%0", "%9") PLSPM_SEG_COL(5, "%1", "%10") PLSPM_SEG_COL(6, "%0", "%11") PLSPM_SEG_COL(7, "%1", "%12")
+                             PLSPM_SEG_COL(8, "%0", "%13") PLSPM_SEG_COL(9, "%1", "%14") PLSPM_SEG_COL(10, "%0", "%15") PLSPM_SEG_COL(11, "%1", "%16")
+                             PLSPM_SEG_COL(12, "%0", "%17") PLSPM_SEG_COL(13, "%1", "%18") PLSPM_SEG_COL(14, "%0", "%19") PLSPM_SEG_COL(15, "%1", "%20")
+                             "s_branch .Lend_%=\n"
+                             PLSPM_SEG_CLOSE(0) PLSPM_SEG_CLOSE(1) PLSPM_SEG_CLOSE(2) PLSPM_SEG_CLOSE(3) PLSPM_SEG_CLOSE(4) PLSPM_SEG_CLOSE(5)
+                             PLSPM_SEG_CLOSE(6) PLSPM_SEG_CLOSE(7) PLSPM_SEG_CLOSE(8) PLSPM_SEG_CLOSE(9) PLSPM_SEG_CLOSE(10) PLSPM_SEG_CLOSE(11)
+                             PLSPM_SEG_CLOSE(12) PLSPM_SEG_CLOSE(13) PLSPM_SEG_CLOSE(14) PLSPM_SEG_CLOSE(15)
+                             ".Lend_%=:"
+                             : "+v"(r0), "+v"(r1), "+v"(va), "=&v"(t)
+                             : "v"(W[a]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
+                               "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]), "s"(eh)
+                             : "memory", "scc");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the stores above are not on the compiler's counters
     }
-    // r0 += s[0] w[Q0] + s[2] w[Q0 + 2],  r1 += s[1] w[Q0 + 1] + s[3] w[Q0 + 3]   (Q0 % 4 == 0: the four columns share W[Q0 / 16]).
-    // The leading s_nop covers the two wait states between a VALU write of W (a register copy the compiler may have placed) and its DPP read.
-    template <int Q0> __device__ __forceinline__ void fma4_bcast(double& r0, double& r1, const double (&W)[4], const double*, const double* s) {
-        asm("s_nop 1\n\t"
-            "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
-            : "+v"(r0), "+v"(r1)
-            : "v"(W[Q0 >> 4]), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "n"(Q0 & 15), "n"((Q0 + 1) & 15), "n"((Q0 + 2) & 15), "n"((Q0 + 3) & 15));
-    }
-    template <int Q> __device__ __forceinline__ void fma1_bcast(double& r, const double (&W)[4], const double*, double s) {
-        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(W[Q >> 4]), "v"(s), "n"(Q & 15));
-    }
+#undef PLSPM_SEG_COL
+#undef PLSPM_SEG_CLOSE
     // where threads without an item of their own may store (a shared dead array: every lane then runs the same store instruction)
     __device__ __forceinline__ double* sink(double* dead) { return dead; }
     // a value every thread of the group holds identically, made provably uniform (scalar registers, scalar branches)
@@ -52,8 +85,6 @@ struct DevExecT {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return ((unsigned long long)hi << 32) | lo;
     }
-    // a uniform value the compiler may not hoist, expand or re-derive across this point (stays in one scalar register pair)
-    __device__ __forceinline__ unsigned long long opaque(unsigned long long v) { asm volatile("" : "+s"(v)); return v; }
     // par over an n0 x n1 grid, first index fastest across threads; (i0, i1) advance incrementally (no integer division per item)
     template <class F> __device__ __forceinline__ void par2(int n0, int n1, F f) {
         int i0 = tid, i1 = 0;

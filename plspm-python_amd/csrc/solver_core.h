@@ -470,48 +470,13 @@ template <int PMAX>
 struct CovRows {
     double s[PMAX];             // s[q] = S[q][p] of the calling thread's column p = ex.tid (symmetric: its row as well)
     unsigned long long ends;    // bit q set: column q is the last one of its LV block (wave-uniform; PMAX <= 64)
-    // V[p, m] = sum over the columns q of block m of s[q] w[q].  s[q] is 0 for q >= P, so whole groups run unguarded.  w reaches the threads
-    // as a broadcast operand of the multiply-add itself (ex.bcast_load / fma4_bcast: device v_fmac_f64_dpp); columns go in groups of four:
-    // a group whose first three columns close no block (scalar test on the boundary mask, the usual case) is four multiply-adds back to
-    // back and one more scalar test, the others take the column-wise path that sits out of line.
-    // History (cycles per call at P = 60, L = 6, one wave): per-thread boundary tests + w from LDS 7.3k; selects instead of a branch 6.5k;
-    // uniform test per column, w by v_readlane 5.4k -- there hipcc had expanded the loop-invariant mask into 64 lane masks spilled to VGPR
-    // lanes (two v_readlane per column to get them back) and laid the common case out as a TAKEN branch (~60 cycles of instruction
-    // fetch each).  The mask is now re-materialised per call (ex.opaque) and the closing side is marked unlikely.
-    template <int Q0, class Ex, class Close>
-    PLSPM_HD void column_groups(Ex& ex, const double (&W)[4], const double* w, unsigned long long e, int P, double& r0, double& r1, Close& close) const {
-        if constexpr (Q0 < PMAX) {
-            if ((Q0 & ~15) < P) {                             // (uniform; one test per 16 columns)
-                const unsigned b = (unsigned)(e >> Q0) & 15u;
-                if (__builtin_expect((b & 7u) == 0u, 1)) {
-                    ex.template fma4_bcast<Q0>(r0, r1, W, w, s + Q0);
-                    if (__builtin_expect(b != 0u, 0)) close();
-                } else {
-                    ex.template fma1_bcast<Q0>(r0, W, w, s[Q0]);
-                    if (b & 1u) close();
-                    ex.template fma1_bcast<Q0 + 1>(r1, W, w, s[Q0 + 1]);
-                    if (b & 2u) close();
-                    ex.template fma1_bcast<Q0 + 2>(r0, W, w, s[Q0 + 2]);
-                    if (b & 4u) close();
-                    ex.template fma1_bcast<Q0 + 3>(r1, W, w, s[Q0 + 3]);
-                    if (b & 8u) close();
-                }
-            }
-            column_groups<Q0 + 4>(ex, W, w, e, P, r0, r1, close);
-        }
-    }
+    // V[p, m] = sum over the columns q of block m of s[q] w[q]: the executor's segmented product (device: kernels_solver.h seg_products).
+    // Every thread stores (idle ones into a sink -- ws.wn is dead while V is formed and holds P >= L doubles), so closing a block is
+    // the same straight-line code on all lanes.
     template <class Ex>
     PLSPM_HD void block_products(Ex& ex, const ModelDesc& md, Workspace& ws) const {
         const int P = md.P, L = md.L, p = ex.tid;
-        double W[4];
-        ex.bcast_load(ws.w, P, W);
-        const unsigned long long e = ex.opaque(ends);
-        // every thread stores (idle ones into a sink -- ws.wn is dead while V is formed and holds P >= L doubles): closing a block is
-        // straight-line code with a scalar block counter; under `if (p < P)` it was a divergent region per column group
-        double* vrow = (p < P) ? ws.V + p * L : ex.sink(ws.wn);
-        double r0 = 0.0, r1 = 0.0;                           // two chains per block (even / odd column): half the dependent latency
-        auto close = [&]() { *vrow++ = r0 + r1; r0 = 0.0; r1 = 0.0; };      // the column just added closes its block
-        column_groups<0>(ex, W, ws.w, e, P, r0, r1, close);
+        ex.template seg_products<PMAX>(s, ws.w, P, ends, (p < P) ? ws.V + p * L : ex.sink(ws.wn));
         ex.sync();
     }
     PLSPM_HD void cov_row(const Workspace&, int, int P, double* dst) const {

@@ -25,20 +25,14 @@ struct HostExec {
     void mark(int) {}
     void sync() { bar->arrive_and_wait(); }
     unsigned long long uniform(unsigned long long v) { return v; }
-    unsigned long long opaque(unsigned long long v) { return v; }
     double* sink(double*) { static thread_local double mine[64]; return mine; }       // (no shared writes: ThreadSanitizer runs this code)
-    // (device: the vector replicated per row of 16 lanes and consumed as a DPP broadcast operand; here: read in place)
-    void bcast_load(const double*, int n, double (&W)[4]) { W[0] = (double)n; W[1] = W[2] = W[3] = 0.0; }
-    template <int Q0> void fma4_bcast(double& r0, double& r1, const double (&W)[4], const double* w, const double* s) {
-        const int n = (int)W[0];
-        for (int j = 0; j < 4; ++j) { const double t = s[j] * ((Q0 + j < n) ? w[Q0 + j] : 0.0); if (j & 1) r1 += t; else r0 += t; }
-    }
-    template <int Q> void fma1_bcast(double& r, const double (&W)[4], const double* w, double s) { r += s * ((Q < (int)W[0]) ? w[Q] : 0.0); }
-    template <int N> void gather8(double v, int first, double (&out)[8]) {      // `red` holds nt slots wherever this is used (rows variant)
-        red[tid] = v;
-        bar->arrive_and_wait();
-        for (int j = 0; j < 8; ++j) out[j] = (first + j < nt) ? red[first + j] : 0.0;
-        bar->arrive_and_wait();
+    // (device: w as a DPP broadcast operand of the multiply-adds, block ends by scalar bit tests; same order of additions)
+    template <int PMAX> void seg_products(const double (&s)[PMAX], const double* w, int P, unsigned long long ends, double* vrow) {
+        double r0 = 0.0, r1 = 0.0;
+        for (int q = 0; q < PMAX && q < P; ++q) {
+            if (q & 1) r1 += s[q] * w[q]; else r0 += s[q] * w[q];
+            if ((ends >> q) & 1ull) { *vrow++ = r0 + r1; r0 = 0.0; r1 = 0.0; }
+        }
     }
     template <class F> void par2(int n0, int n1, F f) {
         for (int e = tid; e < n0 * n1; e += nt) f(e % n0, e / n0);
