@@ -83,10 +83,20 @@ struct plspm_model {
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 7, i8_min_batch = 1, i8_waves = 4, i8_variant = -1, solver_rows = 1, i8_shape = 16; } tune;
+                  int gram_path = 0, i8_slices = 7, i8_min_batch = 1, i8_waves = 4, i8_variant = -1, solver_rows = 1, i8_shape = 16, resample_aux = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
-    Buf zs, cd, pair_tab, pair_scale;
+    Buf zs, cd, cd1, err2, pair_tab, pair_scale;
+    // set_option("resample_aux", 1..3): the int8 counts are drawn on a second stream (1 lowest / 2 default / 3 highest priority) into
+    // alternating buffers, so that the draws of call k+1 -- enqueued while the Gram / solver of call k still run -- take the CUs those
+    // leave idle (the Gram's last, partial round of workgroups first of all); the Gram waits for its counts by event.  Measured
+    // (tools/aux_ab.py, 5,000 replicates per step): 0.647 ms off, 0.635 lowest, 0.654 default, 0.634 highest priority.  OFF by default:
+    // 2 % is inside the box-to-box spread, and with it every Gram launch shares the chip with another kernel (0.455 -> 0.49 ms per
+    // launch), so per-kernel timings would no longer describe the kernel alone.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_counts[2] = {nullptr, nullptr}, ev_cdfree[2] = {nullptr, nullptr};
+    bool cdfree_set[2] = {false, false};
+    int cd_slot = 0;
     bool zs_valid = false;
     int zs_S = 0, zs_KB = 0, zs_NT = 0, zs_npair = 0, zs_npg = 0;
     double* moments_out = nullptr; // plspm_bootstrap_moments: dense moment matrices go here and the solver is skipped
@@ -141,17 +151,17 @@ inline int allow_lds(plspm_model* m, const void* fn, size_t bytes) {
 }
 
 struct ProfScope {
-    plspm_model* m; int id; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(plspm_model* m_, int id_) : m(m_), id(id_) {
+    plspm_model* m; int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(plspm_model* m_, int id_, hipStream_t stream = nullptr) : m(m_), id(id_), s(stream ? stream : m_->stream) {
         if (m->profiling) {
             auto& pool = m->prof[id].pool;
             if (pool.empty()) { hipEventCreate(&a); hipEventCreate(&b); }
             else { a = pool.back().first; b = pool.back().second; pool.pop_back(); }
-            hipEventRecord(a, m->stream);
+            hipEventRecord(a, s);
         }
     }
     ~ProfScope() {
-        if (m->profiling) { hipEventRecord(b, m->stream); m->prof[id].ev.emplace_back(a, b); }
+        if (m->profiling) { hipEventRecord(b, s); m->prof[id].ev.emplace_back(a, b); }
     }
 };
 inline void prof_collect(plspm_model* m) {

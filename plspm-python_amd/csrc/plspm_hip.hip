@@ -293,13 +293,14 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stage2) { m->stage2->stage1 = nullptr; m->stage2->stream = nullptr; }      // the pair is dissolved; the survivor is inert
     if (m->stage1) m->stage1->stage2 = nullptr;
     hipSetDevice(m->device);
+    if (m->aux) hipStreamSynchronize(m->aux);
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p,
-                    m->zs.p, m->cd.p, m->pair_tab.p, m->pair_scale.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->pair_tab.p, m->pair_scale.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -307,6 +308,8 @@ void plspm_model_destroy(plspm_model_t* m) {
     for (int k = 0; k < PLSPM_K_COUNT; ++k) for (auto& pr : m->prof[k].pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (m->h_flag) plspm_hfree(m->h_flag);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
+    for (int k = 0; k < 2; ++k) { if (m->ev_counts[k]) hipEventDestroy(m->ev_counts[k]); if (m->ev_cdfree[k]) hipEventDestroy(m->ev_cdfree[k]); }
+    if (m->aux) hipStreamDestroy(m->aux);                                   // (synchronised above; a low-priority stream of its own, not from the cache)
     if (m->stream && m->owns_stream) plspm_stream_release(m->stream);       // (synchronised above)
     delete m;
 }
@@ -334,6 +337,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
         if (ci[p] < 0 || ci[p] >= src_cols) return fail(m, PLSPM_E_ARG, "plspm_upload: col_index out of range");
     }
     HIPCHK(m, hipSetDevice(m->device));
+    if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
     m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
@@ -662,6 +666,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
+    else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 35) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
@@ -685,6 +690,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
+    else if (k == "resample_aux") *value = m->tune.resample_aux;
     else if (k == "i8_shape") *value = m->tune.i8_shape;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else return PLSPM_E_ARG;
@@ -1006,9 +1012,37 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const size_t hist_bytes = (size_t)KB * 32 * sizeof(unsigned);
     int rc;
     if ((rc = allow_lds(m, (const void*)resample_i8_kernel, hist_bytes))) return rc;
-    {
+    if (m->tune.resample_aux && !m->aux) {
+        int lo = 0, hi = 0;
+        HIPCHK(m, hipDeviceGetStreamPriorityRange(&lo, &hi));                // (numerically: lowest priority first)
+        HIPCHK(m, hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, m->tune.resample_aux == 2 ? 0 : (m->tune.resample_aux == 3 ? hi : lo)));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(m, hipEventCreateWithFlags(&m->ev_counts[k], hipEventDisableTiming));
+            HIPCHK(m, hipEventCreateWithFlags(&m->ev_cdfree[k], hipEventDisableTiming));
+        }
+        if ((rc = ensure(m, m->err2, sizeof(int)))) return rc;
+        HIPCHK(m, hipMemsetAsync(m->err2.p, 0, sizeof(int), m->aux));
+    }
+    // counts of this chunk: the buffer the Gram before last read; grown only with both streams idle
+    const int slot = m->aux ? (m->cd_slot ^= 1) : 0;
+    plspm_model::Buf& cd = slot ? m->cd1 : m->cd;
+    const size_t cd_bytes = (size_t)nty * 256 * ((size_t)KB + I8_SLACK_KB) * 64;
+    if (cd_bytes > cd.cap) { if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux)); if ((rc = ensure(m, cd, cd_bytes))) return rc; m->cdfree_set[slot] = false; }
+    if (!d_idx && m->aux) {
+        // Philox draws: on the low-priority stream, as soon as the Gram that last read this buffer is done -- i.e. beside the Gram and the
+        // solver of the PREVIOUS call when the host runs ahead; this call's Gram waits for the counts by event
+        if (m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->aux, m->ev_cdfree[slot], 0));
+        {
+            ProfScope ps(m, PLSPM_K_RESAMPLE, m->aux);
+            hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
+        }
+        HIPCHK(m, hipEventRecord(m->ev_counts[slot], m->aux));
+        HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_counts[slot], 0));
+    } else {
+        // explicit index lists (test / parity seam) arrive on the main stream: drawn there, and the host looks at the flag
+        if (m->aux && m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_cdfree[slot], 0));
         ProfScope ps(m, PLSPM_K_RESAMPLE);
-        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)m->cd.p, (int*)m->err.p);
+        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
     }
     if (d_idx) {
         int* h_err = (int*)m->h_flag + 9;
@@ -1032,7 +1066,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     {                                                                                                                                        \
         const size_t lds_bytes = GramI8<SS, WW, VV, SH>::LDS_BYTES;                                                                          \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS, WW, VV, SH>, lds_bytes))) return rc;                                          \
-        hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV, SH>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)m->cd.p, \
+        hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV, SH>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
     }
 #define GI8V(SS, WW, VV) GI8VS(SS, WW, VV, 16)
@@ -1051,6 +1085,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
 #undef GI8VS
 #undef GI8
     HIPCHK(m, hipGetLastError());
+    if (m->aux) { HIPCHK(m, hipEventRecord(m->ev_cdfree[slot], m->stream)); m->cdfree_set[slot] = true; }     // the counts buffer is free once this Gram has run
     return 0;
 }
 
@@ -1081,7 +1116,6 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     int rc;
     if (gpath == 2) {
         if ((rc = prepare_zs(m))) return rc;
-        if ((rc = ensure(m, m->cd, (size_t)((chunk + 255) / 256) * 256 * (kpad + 64 * I8_SLACK_KB)))) return rc;
     }
     if (need_lists) {
         if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
@@ -1224,6 +1258,11 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (*h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    if (m->err2.p) {                       // Philox draws on the int8 path: a multiplicity above 127 (P < 1e-200) would have wrapped
+        HIPCHK(m, hipMemcpyAsync(h_err, m->err2.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (*h_err) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: a resample multiplicity exceeded 127 on the int8 Gram path (set_option gram_path 1)");
+    }
     return 0;
 }
 
@@ -1455,6 +1494,7 @@ int plspm_profile_enable(plspm_model_t* m, int32_t on) {
 int plspm_profile_reset(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
     hipSetDevice(m->device);
+    if (m->aux) hipStreamSynchronize(m->aux);
     hipStreamSynchronize(m->stream);
     prof_collect(m);
     for (int k = 0; k < PLSPM_K_COUNT; ++k) { m->prof[k].total_ms = 0.0; m->prof[k].launches = 0; }
@@ -1463,6 +1503,7 @@ int plspm_profile_reset(plspm_model_t* m) {
 int plspm_profile_read(plspm_model_t* m, int32_t kernel_id, double* total_ms, int64_t* launches) {
     if (!m || kernel_id < 0 || kernel_id >= PLSPM_K_COUNT) return PLSPM_E_ARG;
     hipSetDevice(m->device);
+    if (m->aux) hipStreamSynchronize(m->aux);
     hipStreamSynchronize(m->stream);
     prof_collect(m);
     if (total_ms) *total_ms = m->prof[kernel_id].total_ms;
