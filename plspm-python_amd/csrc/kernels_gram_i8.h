@@ -438,3 +438,238 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------- the GEMM, persistent ("stream-K") form
+// The tiled launch above runs 1,200 tiles on 256 CUs at the headline size: 4.69 rounds of one workgroup per CU, i.e. a fifth round in
+// which 80 CUs idle (6 % of the kernel).  Here ONE workgroup per CU stays for the whole product.  With W workgroups per XCD and n tiles
+// in an XCD's range of the same XCD-aware enumeration, workgroup j takes the tiles j, j + W, ... of the first floor(n / W) rounds whole
+// -- the same tiles at the same time as the tiled launch, so the L2 sharing is unchanged -- and an equal share of the k-steps of the
+// n mod W tiles left over: its share is a contiguous range of (tile, pair of k-steps) units, at most the END of one tile and the START of
+// the next.  int32 partial sums are exact in any order, so splitting k costs no determinism: a workgroup that does not hold a tile's
+// last k-steps ("contributor") writes its 8 S accumulator tiles per wave to a scratch slot and raises a per-wave flag; the one that does
+// ("owner") adds the contributors' slots to its own accumulators and runs the epilogue.  Every workgroup does its contributor piece
+// BEFORE its owner piece, so a flag an owner waits for was raised long before unless the hardware has not started that workgroup yet
+// (it will: nothing it needs depends on the waiting one) -- the wait is bounded all the same, an expired wait poisons the tile with NaN
+// (status 3 on its replicates) instead of hanging the device.  Slots and flags are written with agent-scope stores (sc1: written through the XCD's L2) and
+// read behind an agent-scope acquire, so nothing depends on which XCD a workgroup landed on; `epoch` distinguishes launches (flags are
+// never reset).  Default schedule of GramI8 (three LDS stages), 16x16x64 instruction.
+// (the s_nop: a store of more than 8 bytes reads its data registers late -- a VALU write of them in the next slot corrupts the first
+// dword; hipcc's hazard recognizer inserts the wait state for its own stores, not behind an asm statement)
+__device__ __forceinline__ void st_sys_b128(void* p, i32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_sys_b32(void* p, unsigned v) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned ld_sys_b32(const void* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int S, int WM>
+__global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2)))
+gram_i8_sk_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
+                  const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize, i32x4* partial, unsigned* flags, unsigned epoch, int* err) {
+    using G = GramI8<S, WM, I8_DEFAULT_VAR, 16>;
+    static_assert(!G::PAIRB && G::NS == 3, "default schedule");
+    constexpr int MTW = G::MTW, NA = G::NA, NB = G::NB, NW = G::NW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // this workgroup's share: XCD x = id mod 8 walks the tiles [x per, (x + 1) per) of the enumeration; W workgroups per XCD
+    const int total = ntx * nty, per = (total + 7) >> 3;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const int nx = max(0, min(per, total - x * per));
+    const int R = nx / W, mrem = nx - R * W, KB2 = KB >> 1;
+    const long units = (long)mrem * KB2;
+    const long ra = units * j / W, rb = units * (j + 1) / W;
+    // pieces of the left-over tiles: A = [ra, end of its tile or rb), B = the start of the next tile (if the range crosses a tile end)
+    const int i0 = (int)(ra / KB2), i1 = rb > ra ? (int)((rb - 1) / KB2) : i0;
+    const int a0 = (int)(ra - (long)i0 * KB2), a1 = (int)(min(rb, (long)(i0 + 1) * KB2) - (long)i0 * KB2);
+    const int b1 = (int)(rb - (long)i1 * KB2);
+    const bool hasA = rb > ra, hasB = hasA && i1 > i0;
+    const bool ownA = hasA && a1 == KB2, ownB = hasB && b1 == KB2;
+    const int nitems = R + (hasA ? 1 : 0) + (hasB ? 1 : 0);
+
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_raw);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int myper = (G::NBLK - wave + NW - 1) / NW;
+    const bool full = myper == G::PER;
+    const unsigned fbaseA = voff + (unsigned)wm * (unsigned)(NA * 1024), fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
+    i32x4* const myslot = partial + ((size_t)blockIdx.x * NW + wave) * (size_t)(MTW * S) * 64 + lane;
+#define GI8_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(off))
+#define GI8_MFMA16(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+
+    for (int it = 0; it < nitems; ++it) {
+        // item: (tile of the XCD's list, pairs of k-steps [p0, p1), owner?) -- whole tiles first, then the contributor piece, then the owner piece
+        int tl, p0, p1; bool owner;
+        if (it < R) { tl = it * W + j; p0 = 0; p1 = KB2; owner = true; }
+        else {
+            const bool second = it > R;
+            // both pieces present: the contributor goes first (B is one unless it is a whole tile)
+            const bool firstIsB = hasB && !ownB;
+            const bool useB = hasB && (second ? !firstIsB : firstIsB);
+            if (useB) { tl = R * W + i1; p0 = 0; p1 = b1; owner = ownB; }
+            else { tl = R * W + i0; p0 = a0; p1 = a1; owner = ownA; }
+        }
+        const int gidx = x * per + tl;
+        const int srow = 4 * ntx;
+        const int sr = gidx / srow, rem = gidx - sr * srow;
+        const int nr = min(4, nty - 4 * sr);
+        const int tx = rem / nr, ty = 4 * sr + (rem - tx * nr);
+
+        const char* src[G::PER];
+        long inc[G::PER];
+        unsigned dst[G::PER];
+#pragma unroll
+        for (int i = 0; i < G::PER; ++i) {
+            const int b = min(wave + NW * i, G::NBLK - 1);
+            const bool isA = b < 16;
+            inc[i] = (isA ? (long)MT : (long)NT) * 1024;
+            src[i] = (isA ? (const char*)(Cd + ((long)ty * 16 + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - 16)) * 64)) + (long)(2 * p0) * inc[i];
+            dst[i] = lds0 + (unsigned)b * 1024u;
+        }
+        auto advance = [&]() {
+#pragma unroll
+            for (int i = 0; i < G::PER; ++i) src[i] += inc[i];
+        };
+        auto issue_one = [&](int i, unsigned stage_off) {
+            if (i < G::PER - 1 || full) glds_block(src[i], voff, dst[i] + stage_off);
+        };
+        i32x4 acc[MTW][S];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc[mt][s] = i32x4{};
+        auto step = [&](i32x4 (&fc)[NA], i32x4 (&fd)[NB], i32x4 (&fna)[NA], i32x4 (&fnb)[NB], unsigned Roff, unsigned Woff) {
+            const unsigned ra_ = fbaseA + Roff, rb_ = fbaseB + Roff;
+            constexpr int RSTEP = G::NMFMA / (NA + NB) >= G::RSTEP ? G::RSTEP : 1;
+            int nread = 0, ndma = 0;
+            auto fill = [&](int m) {
+                if (m % RSTEP == 0 && nread < NA + NB) {
+                    if (nread < NA) GI8_DSREAD(fna[nread], ra_, nread * 1024);
+                    else GI8_DSREAD(fnb[nread - NA], rb_, (nread - NA) * 1024);
+                    ++nread;
+                }
+                if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * G::NMFMA) / G::PER + 1)) { issue_one(ndma, Woff); ++ndma; }
+            };
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int s = 0; s < S; ++s) { GI8_MFMA16(acc[mt][s], fc[mt], fd[s]); fill(mt * S + s); }
+#pragma unroll
+            for (int r = 0; r < NA + NB; ++r)
+                if (r >= nread) { if (r < NA) GI8_DSREAD(fna[r], ra_, r * 1024); else GI8_DSREAD(fnb[r - NA], rb_, (r - NA) * 1024); }
+            advance();
+        };
+        auto wait_barrier = [&](i32x4 (&fa)[NA], i32x4 (&fb)[NB]) {
+            if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * G::PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * (G::PER - 1)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(fb[i]));
+            asm volatile("s_barrier" ::: "memory");
+        };
+        i32x4 fa0[NA], fb0[NB], fa1[NA], fb1[NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { fb0[i] = (i32x4){0, 0, 0, 0}; fb1[i] = fb0[i]; }
+        const auto issue_all = [&](unsigned stage_off) {
+#pragma unroll
+            for (int i = 0; i < G::PER; ++i) issue_one(i, stage_off);
+            advance();
+        };
+        issue_all(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NA; ++i) GI8_DSREAD(fa0[i], fbaseA, i * 1024);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) GI8_DSREAD(fb0[i], fbaseB, i * 1024);
+#pragma unroll
+        for (int st = 1; st < G::NS; ++st) issue_all(st * G::STAGE_BYTES);
+        unsigned Wst = 0, Rst = G::STAGE_BYTES;
+        auto next = [](unsigned st) { return (st == (G::NS - 1) * G::STAGE_BYTES) ? 0u : st + G::STAGE_BYTES; };
+        for (int pp = p0; pp < p1; ++pp) {
+            wait_barrier(fa0, fb0);
+            step(fa0, fb0, fa1, fb1, Rst, Wst);
+            Wst = next(Wst); Rst = next(Rst);
+            wait_barrier(fa1, fb1);
+            step(fa1, fb1, fa0, fb0, Rst, Wst);
+            Wst = next(Wst); Rst = next(Rst);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the LDS ring: the next item may overwrite it
+
+        if (!owner) {
+            // contributor: the accumulators to this workgroup's slot (system scope), then the wave's flag
+            i32x4* sp = myslot;                               // a running pointer, opaque per store: hipcc otherwise keeps (and spills) 8 S addresses
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int s = 0; s < S; ++s) { st_sys_b128(sp, acc[mt][s]); sp += 64; asm volatile("" : "+v"(sp)); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_sys_b32(flags + (size_t)blockIdx.x * NW + wave, epoch);
+            continue;
+        }
+        // owner: add the slots of the workgroups that hold the earlier k-steps of this tile (left-over tiles only: j' < j whose range
+        // reaches into the tile)
+        bool poisoned = false;
+        if (it >= R) {
+            const long tile_u0 = (long)(tl - R * W) * KB2;
+            for (int jc = j - 1; jc >= 0 && units * (jc + 1) / W > tile_u0; --jc) {
+                if (units * (jc + 1) / W == units * jc / W) continue;                   // (an empty share)
+                const unsigned wc = (unsigned)(jc * 8 + x);
+                const unsigned* fl = flags + (size_t)wc * NW + wave;
+                int spins = 0;
+                while (ld_sys_b32(fl) != epoch) {
+                    if (++spins > (1 << 20)) { poisoned = true; if (lane == 0) atomicOr(err, 4); break; }      // (~1 s)
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const i32x4* slot = partial + ((size_t)wc * NW + wave) * (size_t)(MTW * S) * 64 + lane;
+                // half of the slot in flight at a time (4 S loads = 16 S registers; the fragment registers are dead here): one memory
+                // round trip per half -- S loads per batch made it 2 MTW / ... round trips of ~2 us each in front of every split tile's epilogue
+                constexpr int HB = (MTW + 1) / 2;
+#pragma unroll
+                for (int h = 0; h < MTW; h += HB) {
+                    i32x4 t[HB][S];
+#pragma unroll
+                    for (int mt = 0; mt < HB; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) if (h + mt < MTW) t[mt][s] = __builtin_nontemporal_load(slot + (size_t)(mt * S + s) * 64);
+#pragma unroll
+                    for (int mt = 0; mt < HB; ++mt)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) if (h + mt < MTW) acc[h + mt][s] += t[mt][s];
+                    slot += (size_t)HB * S * 64;
+                    asm volatile("" : "+v"(slot) : : "memory");
+                }
+            }
+        }
+        const int jp = (tx * 2 + wn) * 16 + (lane & 15);
+        if (jp < npair) {
+            const long dstj = pair_dst[jp];
+            const double sc = poisoned ? __builtin_nan("") : pair_scale[jp];
+            const long rep0 = (long)ty * 256 + wm * (MTW * 16) + (lane >> 4) * 4;
+            double* gp = gram + rep0 * psize + dstj;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (rep0 + mt * 16 + reg < nrep) {
+                        double v = (double)acc[mt][0][reg];
+#pragma unroll
+                        for (int s = 1; s < S; ++s) v = fma((double)acc[mt][s][reg], (double)(1ll << (8 * s)), v);
+                        *gp = v * sc;
+                    }
+                    gp += psize;
+                    asm volatile("" : "+v"(gp)::"memory");
+                }
+                gp += 12 * psize;
+            }
+        }
+    }
+#undef GI8_DSREAD
+#undef GI8_MFMA16
+}

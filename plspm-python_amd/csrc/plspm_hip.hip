@@ -300,7 +300,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->pair_tab.p, m->pair_scale.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -667,6 +667,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
+    else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 35) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
@@ -691,6 +692,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
     else if (k == "resample_aux") *value = m->tune.resample_aux;
+    else if (k == "i8_sched") *value = m->tune.i8_sched;
     else if (k == "i8_shape") *value = m->tune.i8_shape;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else return PLSPM_E_ARG;
@@ -1061,7 +1063,33 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
     const int* d_dst2 = nullptr;          // (a mirrored second store per element cost 0.08 ms per 5,000 replicates: the rows solver reads the triangle instead)
     const long out_stride = dense ? cov_doubles(m->Pg) : packed_size(m->T);
+    // persistent stream-K schedule (kernels_gram_i8.h gram_i8_sk_kernel): one workgroup per CU, whole CUs per XCD
+    const bool sk = m->tune.i8_sched == 1 && m->tune.i8_shape == 16 && m->tune.i8_variant < 0 && S <= 7;      // (S = 8 spills in the persistent kernel)
+    int sk_grid = 0;
+    if (sk) {
+        if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
+        sk_grid = std::max(8, (m->cu_count / 8) * 8);
+        const size_t slot_bytes = (size_t)32 * S * 1024;                    // 16 count tiles x 2 pair groups x S planes x 1 KB of int32 per workgroup
+        if ((size_t)sk_grid * slot_bytes > m->sk_partial.cap && (rc = ensure(m, m->sk_partial, (size_t)sk_grid * slot_bytes))) return rc;
+        if (!m->sk_flags.p) {
+            if ((rc = ensure(m, m->sk_flags, (size_t)2048 * 8 * sizeof(unsigned)))) return rc;
+            HIPCHK(m, hipMemsetAsync(m->sk_flags.p, 0, (size_t)2048 * 8 * sizeof(unsigned), m->stream));
+            m->sk_epoch = 0;
+        }
+    }
     ProfScope ps(m, PLSPM_K_GRAM);
+#define GI8SK(SS, WW)                                                                                                                        \
+    {                                                                                                                                        \
+        const size_t lds_bytes = GramI8<SS, WW, I8_DEFAULT_VAR, 16>::LDS_BYTES;                                                              \
+        if ((rc = allow_lds(m, (const void*)gram_i8_sk_kernel<SS, WW>, lds_bytes))) return rc;                                               \
+        hipLaunchKernelGGL((gram_i8_sk_kernel<SS, WW>), dim3((unsigned)sk_grid), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p,    \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, \
+                           (i32x4*)m->sk_partial.p, (unsigned*)m->sk_flags.p, ++m->sk_epoch, (int*)m->err.p);                                \
+    }
+    if (sk) {
+        if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8SK(5, 2) break; case 6: GI8SK(6, 2) break; default: GI8SK(7, 2) break; } }
+        else { switch (S) { case 5: GI8SK(5, 4) break; case 6: GI8SK(6, 4) break; default: GI8SK(7, 4) break; } }
+    } else
 #define GI8VS(SS, WW, VV, SH)                                                                                                                \
     {                                                                                                                                        \
         const size_t lds_bytes = GramI8<SS, WW, VV, SH>::LDS_BYTES;                                                                          \
@@ -1257,6 +1285,7 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     int* h_err = (int*)m->h_flag + 8;
     HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (*h_err & 4) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the persistent Gram gave up waiting for a partial tile (device shared with a long-running kernel?); set_option i8_sched 0");
     if (*h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
     if (m->err2.p) {                       // Philox draws on the int8 path: a multiplicity above 127 (P < 1e-200) would have wrapped
         HIPCHK(m, hipMemcpyAsync(h_err, m->err2.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -1272,7 +1301,15 @@ int plspm_bootstrap_fetch(plspm_model_t* m, int64_t first, int64_t count, double
     if (first + count > m->rows_B) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_fetch: range exceeds the last bootstrap's replicates");
     HIPCHK(m, hipSetDevice(m->device));
     const int RS = plspm_row_stride(m);
-    return plspm_detail_fetch_records(m, (const double*)m->rows.p + first * RS, count, RS, out, status, iters);
+    int rc = plspm_detail_fetch_records(m, (const double*)m->rows.p + first * RS, count, RS, out, status, iters);
+    if (rc) return rc;
+    if (m->sk_epoch && m->err.p) {          // the persistent Gram's bounded wait (its tiles are NaN / status 3 then; say why)
+        int* h_err = (int*)m->h_flag + 8;
+        HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (*h_err & 4) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_fetch: the persistent Gram gave up waiting for a partial tile (device shared with a long-running kernel?); set_option i8_sched 0");
+    }
+    return 0;
 }
 
 int plspm_bootstrap_store(plspm_model_t* m, const double* records, int64_t B) {

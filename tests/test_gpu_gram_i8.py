@@ -211,3 +211,26 @@ def test_mfma_32x32x32_layout_gives_identical_matrices(slices):
     rows32 = nm.bootstrap(300, seed=7)[0]
     assert nm.get_option("last_gram_path") == 2
     assert np.array_equal(M16, M32) and np.array_equal(rows16, rows32)
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("B", [1, 300, 2100, 9000])
+def test_persistent_stream_k_schedule_gives_identical_matrices(B, waves):
+    """i8_sched 1: one workgroup per CU for the whole product, the left-over tiles split along k between workgroups (contributors hand
+    their int32 partial sums to the tile's owner through a flagged scratch slot).  Integer sums are exact in any order: moment matrices
+    and rows are bit-identical to the tiled launch -- with every tile split (B = 1 .. 300), with whole rounds + a split remainder
+    (2,100: 9 x 42 = 378 tiles, 9,000: 36 x 42 tiles) and over repeated launches (the flags carry a launch serial)."""
+    C = orc.chain_C(7)
+    X, blocks = orc.synth(777, C, 5, seed=2)
+    model = orc.Model(blocks, C, "ABABABA", "factorial", True)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.set_option("i8_waves", waves)
+    Mt = nm.bootstrap_moments(min(B, 600), seed=7)
+    rows_t, st_t, it_t = nm.bootstrap(B, seed=7)
+    nm.set_option("i8_sched", 1)
+    for _ in range(3):
+        rows_k, st_k, it_k = nm.bootstrap(B, seed=7)
+        assert nm.get_option("last_gram_path") == 2
+        assert np.array_equal(rows_t, rows_k) and np.array_equal(st_t, st_k) and np.array_equal(it_t, it_k)
+    assert np.array_equal(Mt, nm.bootstrap_moments(min(B, 600), seed=7))
