@@ -303,7 +303,7 @@ def main():
             npair = 61 * 62 // 2                               # unordered pairs of the 60 columns + the ones column
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = static_traffic(("r02_gram_i8_traffic.json",))
+            traffic, traffic_src = static_traffic(("r02c_gram_i8_traffic.json", "r02_gram_i8_traffic.json"))
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "gram_i8_kernel<%d, %d, 3, %d>" % (slices, model.get_option("i8_waves") // 2, model.get_option("i8_shape")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,

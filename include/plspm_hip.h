@@ -81,6 +81,11 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
  *   "i8_waves"        4 | 8   waves per workgroup of the int8 Gram (default 4: one per SIMD, 128 replicates x 16 pairs each; 8: two per SIMD)
  *   "i8_shape"        16 (default) | 32   MFMA shape / fragment-block layout of the int8 Gram (32: v_mfma_i32_32x32x32_i8, measured 16 % slower)
+ *   "i8_sched"        0 (default) | 1   int8 Gram as a persistent "stream-K" launch: one workgroup per CU, the tiles of the whole rounds
+ *                     + an equal share of the left-over tiles' k-steps each, exact int32 partial sums handed to the tile's owner through
+ *                     flagged scratch slots (bit-identical results; the kernel is ~3 % faster, the step is not: measured neutral)
+ *   "resample_aux"    0 (default) | 1 | 2 | 3   int8 resample counts on a second stream of lowest / default / highest priority, so that
+ *                     the draws of the next call fill CUs the Gram / solver of this one leave idle (+-2 %: measured neutral)
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
  * plspm_model_get_option reads a value back; the read-only key "last_gram_path" tells which Gram the last bootstrap call took.

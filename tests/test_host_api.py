@@ -291,10 +291,10 @@ def test_bench_guard_fixture_is_current():
 
 
 def test_committed_bench_line_follows_the_driver_contract():
-    """profiles/r02_bench_n1.json is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions
+    """profiles/r02c_bench_n1.json (the latest committed line) is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions
     (dtype = arithmetic type, vs_baseline null without a published number, config names the workload, roofline + cpu_baseline)."""
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02c_bench_n1.json")))
     for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                       ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(line[key], kind), key

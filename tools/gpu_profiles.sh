@@ -21,7 +21,16 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 -d $O/prof_c5_pmc1 -o pmc1 -- python $R/tools/fit_bench.py c5 > $O/prof_c5_pmc1.log 2>&1
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/prof_c5_pmc2 -o pmc2 -- python $R/tools/fit_bench.py c5 > $O/prof_c5_pmc2.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/prof_c5_fetch -o fetch -- python $R/tools/fit_bench.py c5 > $O/prof_c5_fetch.log 2>&1
+# the int8 digit-plane Gram and the rows solver of the headline step (interleaved A/B tool: every Gram variant runs full-size launches)
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_I8 -d $O/prof_i8_pmc1 -o pmc1 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH -d $O/prof_i8_pmc2 -o pmc2 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc2.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum SQC_ICACHE_REQ SQC_ICACHE_MISSES -d $O/prof_i8_pmc3 -o pmc3 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc3.log 2>&1
 cd $R
+timeout 300 python tools/i8_bench.py 5000 4 2>&1 | grep "^{" > $O/i8_bench.jsonl
+timeout 300 python tools/aux_ab.py i8_sched=0,1 2>&1 | grep "^{" > $O/ab_stream_k.jsonl
+timeout 300 python tools/aux_ab.py resample_aux=0,1,2,3 2>&1 | grep "^{" > $O/ab_resample_aux.jsonl
+timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench.json
+./tools/ubench/valu_issue > $O/ubench_valu_issue.txt 2>&1
 python - "$O" <<'PY'
 import sqlite3, glob, sys, json
 O = sys.argv[1]
@@ -31,7 +40,7 @@ for db in sorted(glob.glob(O + "/prof_*pmc*/*.db") + glob.glob(O + "/prof_c5_fet
     q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection c where grid_size = "
          "(select max(grid_size) from counters_collection c2 where c2.kernel_name = c.kernel_name) group by kernel_name, counter_name")
     for r in cur.execute(q):
-        if any(k in r[0] for k in ("gram", "solver_kernel", "resample", "scores_kernel", "summary")):
+        if any(k in r[0] for k in ("gram", "solver_kernel", "solver_rows", "resample", "scores_kernel", "summary")):
             out.append({"run": db.split("/")[-2], "kernel": r[0].split("(")[0].replace("void ", ""), "counter": r[1], "dispatches": r[2], "avg": round(r[3], 1), "avg_duration_ns": round(r[4], 1)})
 json.dump(out, open(O + "/pmc_rows.json", "w"), indent=0)
 for r in out: print(r["run"], r["kernel"][:36], r["counter"], r["dispatches"], r["avg"], r["avg_duration_ns"])
