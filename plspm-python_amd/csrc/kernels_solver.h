@@ -203,10 +203,13 @@ __global__ void __launch_bounds__(256) solver_kernel(ModelDesc md, const double*
 }
 
 
+#ifndef PLSPM_ROWS_WAVES
+#define PLSPM_ROWS_WAVES 2
+#endif
 // Rows variant (solver_core.h solve_problem_rows): ONE wave per problem, column p of the covariance in the registers of lane p,
 // the small workspace + descriptors in LDS (~11 KB at P = 60, L = 6).  Bootstrap batches of metric models with P <= 64 whose
 // moment matrices arrive dense from the int8 digit-plane Gram.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_rows_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PLSPM_ROWS_WAVES, PLSPM_ROWS_WAVES))) solver_rows_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
