@@ -1133,7 +1133,10 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const int gpath = choose_gram_path(m, B);
     m->last_gram_path = gpath;
     // one wave per problem on dense moment matrices (solver_rows_kernel): metric models of at most 64 MVs behind the int8 Gram
-    const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && m->P <= 64 && !m->n_ind && !m->nonmetric && !m->moments_out;
+    // rows solver: one wave per problem, its small workspace + descriptors in LDS -- eight problems per CU at the headline size
+    // (at least four problems per CU; wide inner models, L >~ 20, take the LDS solver, which can move its workspace to global scratch)
+    const size_t rows_lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
+    const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && m->P <= 64 && !m->n_ind && !m->nonmetric && !m->moments_out && rows_lds <= kMaxLds / 4;
     // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers
     const bool need_lists = gpath == 1 || d_idx != nullptr || m->nonmetric;
     const size_t kpad = (size_t)i8_kblocks(N) * 64;

@@ -234,3 +234,31 @@ def test_persistent_stream_k_schedule_gives_identical_matrices(B, waves):
         assert nm.get_option("last_gram_path") == 2
         assert np.array_equal(rows_t, rows_k) and np.array_equal(st_t, st_k) and np.array_equal(it_t, it_k)
     assert np.array_equal(Mt, nm.bootstrap_moments(min(B, 600), seed=7))
+
+
+@pytest.mark.parametrize("sizes", [[1] * 64, [2] * 32, [4] * 16, [3] * 20 + [4], [16, 16, 16, 16], [15, 1, 17, 31], [63, 1], [32, 32], [1, 62, 1], [7, 9, 5, 11, 3, 13, 1, 15]])
+def test_rows_solver_block_boundaries_at_every_position(sizes):
+    """The rows solver's segmented product walks the columns in asm blocks of sixteen with a scalar test for a block end behind every
+    column: LV blocks that end on, next to and across the sixteen-column seams, one MV per LV (every column closes a block, L = 64),
+    one block of all 64 columns.  Against the LDS solver (plain loops over the same moments) and the oracle."""
+    from plspm import _native
+    from test_gpu_parity import _ragged
+    L = len(sizes)
+    C = orc.chain_C(L)
+    X, blocks = _ragged(900, C, sizes, seed=4)
+    model = orc.Model(blocks, C, "A" * L, "factorial", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(130, seed=11)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("solver_rows") == 1
+    nm.set_option("solver_rows", 0)
+    rows0, status0, iters0 = nm.bootstrap(130, seed=11)
+    assert np.array_equal(status, status0) and np.array_equal(iters, iters0)
+    ok = status == 0
+    assert ok.sum() >= 100
+    assert_close(rows[ok], rows0[ok], 1e-10, 1e-12)
+    corr = orc.correction(900)
+    r = int(np.flatnonzero(ok)[0])
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(11, r, 900), corr)
+    assert its == iters[r]
+    assert_close(rows[r], mine, RTOL, ATOL)
