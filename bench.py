@@ -92,6 +92,41 @@ def cpu_baseline(budget_s=20.0):
                       % (count, cores, 1.0 / per_rep, wall)}
 
 
+def live_traffic(kernel_prefix, gram_path):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, counters only -- no trace domain), read back from the rocpd databases.  FETCH_SIZE is doubled
+    (gfx950 reports half the bytes of wide coalesced reads: MI355X_MICROARCH.md, HBM section; checked in tools/rocprof_summary.py on a
+    kernel of known traffic).  None when rocprofv3 is missing or a pass fails -- the caller then falls back to the committed figure."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    kib = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="plspm_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-api", "--no-traffic", "--gram-path", str(gram_path)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            dbs = glob.glob(os.path.join(d, "*.db")) + glob.glob(os.path.join(d, "*", "*.db"))
+            cur = sqlite3.connect(dbs[0]).cursor()
+            q = ("select kernel_name, count(*), avg(value) from counters_collection c where counter_name=? and grid_size = "
+                 "(select max(grid_size) from counters_collection c2 where c2.kernel_name = c.kernel_name) group by kernel_name")
+            hit = [(n, avg) for name, n, avg in cur.execute(q, (ctr,)) if kernel_prefix in name]
+            if not hit:
+                return None
+            kib[ctr] = hit[0][1]
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
+
+
 def api_inclusive(X, reps, pairs=7):
     """Replicates/s through the drop-in API: Plspm(..., bootstrap=True) minus the same call with bootstrap=False (median of paired
     runs).  The summaries are computed (on the device) inside the call; the reference-shaped frames are built on access."""
@@ -160,6 +195,7 @@ def main():
     ap.add_argument("--reps-per-gpu", type=int, default=REPS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
     ap.add_argument("--gram-path", type=int, default=0, choices=[0, 1, 2], help="0 library default (int8 digit planes), 1 fp64 MFMA Gram, 2 int8 digit planes")
     args = ap.parse_args()
@@ -298,12 +334,17 @@ def main():
             return None, None
         timing_note = ("HIP events around the kernel's launches in every %d-th step of the timed region (single stream: the kernel alone)" % prof_every if profiled else
                        "HIP events on the handle's stream over a calibration pass of the same launches without the overlapping collective")
+        live = None
+        if world == 1 and group is None and not launched and not args.no_traffic:
+            live = live_traffic("gram_i8_kernel" if used_path == 2 else "gram_rows_kernel", used_path)
+        live_src = ("live: two child runs of this script (3 steps) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters "
+                    "only), average over the kernel's full-size launches, FETCH_SIZE x 2 (gfx950)")
         if used_path == 2:
             slices = model.get_option("i8_slices")
             npair = 61 * 62 // 2                               # unordered pairs of the 60 columns + the ones column
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = static_traffic(("r02c_gram_i8_traffic.json", "r02_gram_i8_traffic.json"))
+            traffic, traffic_src = (live, live_src) if live else static_traffic(("r02c_gram_i8_traffic.json", "r02_gram_i8_traffic.json"))
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "gram_i8_kernel<%d, %d, 3, %d>" % (slices, model.get_option("i8_waves") // 2, model.get_option("i8_shape")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
@@ -316,7 +357,7 @@ def main():
                         "algorithmic_bytes_per_replicate": a_rep,
                         "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}}
         else:
-            traffic, traffic_src = static_traffic(("r02_gram_traffic.json", "r01_gram_traffic.json"))
+            traffic, traffic_src = (live, live_src) if live else static_traffic(("r02_gram_traffic.json", "r01_gram_traffic.json"))
             roofline = {"bound": "mfma", "achieved": round(f64_equiv, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(f64_equiv / FP64_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
