@@ -360,6 +360,8 @@ int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx)
 /* Kernel timing with HIP events on the handle's own stream (for the roofline figures in bench.py).
  * kernel ids: 0 resample/compact, 1 gram (MFMA), 2 solver, 3 scores, 4 upload/pack, 5 gram reduce. */
 enum { PLSPM_K_RESAMPLE = 0, PLSPM_K_GRAM = 1, PLSPM_K_SOLVER = 2, PLSPM_K_SCORES = 3, PLSPM_K_PACK = 4, PLSPM_K_REDUCE = 5, PLSPM_K_COUNT = 6 };
+/* on: 0 off, 1 every kernel, 2 + id only kernel `id` (an event pair costs dispatch latency on both sides: bracketing one kernel of a
+ * step perturbs the step less than bracketing all of them). */
 int plspm_profile_enable(plspm_model_t* m, int32_t on);
 int plspm_profile_read(plspm_model_t* m, int32_t kernel_id, double* total_ms, int64_t* launches);
 int plspm_profile_reset(plspm_model_t* m);

@@ -111,6 +111,7 @@ struct plspm_model {
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
     void* group = nullptr;        // the plspm_group this handle currently belongs to (plspm_group.cpp)
     bool profiling = false;
+    int prof_only = -1;          // >= 0: only this kernel id is bracketed by events (plspm_profile_enable(m, 2 + id))
     ProfSlot prof[PLSPM_K_COUNT];
     std::string error;
 };
@@ -156,8 +157,9 @@ inline int allow_lds(plspm_model* m, const void* fn, size_t bytes) {
 
 struct ProfScope {
     plspm_model* m; int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(plspm_model* m_, int id_, hipStream_t stream = nullptr) : m(m_), id(id_), s(stream ? stream : m_->stream) {
-        if (m->profiling) {
+    bool on;
+    ProfScope(plspm_model* m_, int id_, hipStream_t stream = nullptr) : m(m_), id(id_), s(stream ? stream : m_->stream), on(m_->profiling && (m_->prof_only < 0 || m_->prof_only == id_)) {
+        if (on) {
             auto& pool = m->prof[id].pool;
             if (pool.empty()) { hipEventCreate(&a); hipEventCreate(&b); }
             else { a = pool.back().first; b = pool.back().second; pool.pop_back(); }
@@ -165,7 +167,7 @@ struct ProfScope {
         }
     }
     ~ProfScope() {
-        if (m->profiling) { hipEventRecord(b, s); m->prof[id].ev.emplace_back(a, b); }
+        if (on) { hipEventRecord(b, s); m->prof[id].ev.emplace_back(a, b); }
     }
 };
 inline void prof_collect(plspm_model* m) {

@@ -1529,6 +1529,7 @@ int plspm_profile_enable(plspm_model_t* m, int32_t on) {
             while (m->prof[k].pool.size() < 128) { hipEvent_t a = nullptr, b = nullptr; hipEventCreate(&a); hipEventCreate(&b); m->prof[k].pool.emplace_back(a, b); }
     }
     m->profiling = on != 0;
+    m->prof_only = (on >= 2 && on < 2 + PLSPM_K_COUNT) ? on - 2 : -1;
     return 0;
 }
 int plspm_profile_reset(plspm_model_t* m) {

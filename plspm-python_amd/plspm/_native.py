@@ -337,8 +337,9 @@ class NativeModel:
     def sync(self):
         self._check(self._lib.plspm_sync(self._h), "plspm_sync")
 
-    def profile(self, on=True):
-        self._lib.plspm_profile_enable(self._h, int(on))
+    def profile(self, on=True, only=None):
+        """HIP-event timing of the handle's kernels: every kernel, or (``only="gram"`` ...) just one of them."""
+        self._lib.plspm_profile_enable(self._h, (2 + KERNELS[only]) if (on and only is not None) else int(bool(on)))
 
     def profile_reset(self):
         self._lib.plspm_profile_reset(self._h)
