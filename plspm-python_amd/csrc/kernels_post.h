@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(256) scores_kernel(const double* __restrict__ 
 //   3. the four order statistics the two quantiles interpolate between, WITHOUT sorting: an 8-bit-digit radix select on the
 //      order-preserving integer image of the doubles, both quantiles in the same eight passes over the values (a 256-bin LDS
 //      histogram per quantile and pass, block-wide scan of the bins), then one pass for the successor of each selected value.
-//      (The first version bitonic-sorted the padded column: 91 block-wide steps for 5,000 replicates, 0.37 ms; this one 0.06 ms.)
+//      (The first version bitonic-sorted the padded column: 91 block-wide steps for 5,000 replicates, 0.37 ms per call; radix select
+//      with one chunk of 256 replicates per barrier pair in the compaction and one LDS atomic per value 0.14 ms per call, the kernel
+//      itself 117 us; batched loads, run-length aggregated atomics, shared scans and the early exit: 68 us, 0.106 ms per call.)
 // out[c*6 + {0..5}] = original, mean, std.error, perc.025, perc.975, t stat.
 __device__ __forceinline__ unsigned long long order_key(double x) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -126,107 +128,175 @@ __device__ __forceinline__ double lerp_numpy(double a, double b, double t) {
     const double d = b - a;
     return (t >= 0.5) ? b - d * (1.0 - t) : a + d * t;             // numpy's _lerp (monotone form)
 }
+// block-wide reductions of the summary kernel: 64-lane shuffle tree, then the four wave results through LDS in wave order (one fixed
+// order -> bit-reproducible; two barriers instead of the eight of a 256-slot LDS tree)
+__device__ __forceinline__ double sum256(double v, double* red4, int lane, int wave) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red4[wave] = v;
+    __syncthreads();
+    const double t = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+    __syncthreads();
+    return t;
+}
 template <bool IN_LDS>
 __global__ void __launch_bounds__(256) summary_kernel(const double* __restrict__ rows, long B, int stride, int R, const double* __restrict__ original,
                                                        double* __restrict__ gbuf, int npad, double* __restrict__ out, int* __restrict__ n_used) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ double red[256];
+    constexpr int NB = 16;                        // chunks of 256 replicates whose loads are in flight together
+    __shared__ double red4[4];
     __shared__ unsigned hist[2][256];
-    __shared__ int wcount[4];
+    __shared__ int wcount[NB][4];
+    __shared__ unsigned wscan[2][4];
     __shared__ unsigned long long sel_prefix[2];
-    __shared__ unsigned sel_rank[2];
-    __shared__ unsigned long long red_key[256];
-    __shared__ unsigned red_cnt[256];
+    __shared__ unsigned sel_rank[2], sel_cnt[2];
+    __shared__ unsigned long long red_key[2][4];
+    __shared__ unsigned red_cnt[2][4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* buf = IN_LDS ? reinterpret_cast<double*>(smem_raw) : gbuf + (long)c * npad;
-    // 1. compaction in replicate order
+    // 1. compaction in replicate order.  The status and the value of NB x 256 replicates are loaded before anything is consumed
+    //    (both are strided reads; one chunk of 256 per barrier pair made the pass a chain of 20 memory round trips at B = 5,000)
     int m = 0;
-    for (long b0 = 0; b0 < B; b0 += 256) {
-        const long b = b0 + tid;
-        const bool ok = (b < B) && rows[b * stride + R] == 0.0;
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) wcount[wave] = __popcll(bal);
+    for (long s0 = 0; s0 < B; s0 += 256L * NB) {
+        double val[NB], st[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const long b = s0 + 256L * k + tid;
+            const long bc = (b < B) ? b : B - 1;
+            st[k] = rows[bc * stride + R];
+            val[k] = rows[bc * stride + c];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const bool ok = (s0 + 256L * k + tid < B) && st[k] == 0.0;
+            const unsigned long long bal = __ballot(ok);
+            if (lane == 0) wcount[k][wave] = __popcll(bal);
+        }
         __syncthreads();
-        int base = m;
-        for (int w = 0; w < wave; ++w) base += wcount[w];
-        if (ok) buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = rows[b * stride + c];
-        m += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const bool ok = (s0 + 256L * k + tid < B) && st[k] == 0.0;
+            const unsigned long long bal = __ballot(ok);
+            int base = m;
+            for (int w = 0; w < wave; ++w) base += wcount[k][w];
+            if (ok) buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = val[k];
+            m += wcount[k][0] + wcount[k][1] + wcount[k][2] + wcount[k][3];
+        }
         __syncthreads();
     }
     if (tid == 0 && c == 0) *n_used = m;
-    // 2. mean, variance (fixed order: thread t takes elements t, t + 256, ...; binary tree over the threads)
+    // 2. mean, variance (fixed order: thread t takes elements t, t + 256, ...; shuffle tree + wave order)
     double s = 0.0;
     for (int i = tid; i < m; i += 256) s += buf[i];
-    red[tid] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
-    const double mean = (m > 0) ? red[0] / (double)m : 0.0;
-    __syncthreads();
+    const double tot = sum256(s, red4, lane, wave);
+    const double mean = (m > 0) ? tot / (double)m : 0.0;
     double v = 0.0;
     for (int i = tid; i < m; i += 256) { const double d = buf[i] - mean; v += d * d; }
-    red[tid] = v;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if (tid < h) red[tid] += red[tid + h]; __syncthreads(); }
-    const double ssq = red[0];
-    __syncthreads();
-    // 3. order statistics lo_q = floor(q (m-1)) for q = 0.025, 0.975 (and their successors) by radix select
+    const double ssq = sum256(v, red4, lane, wave);
+    // 3. order statistics lo_q = floor(q (m-1)) for q = 0.025, 0.975 (and their successors) by radix select: both quantiles in the same
+    //    passes, the two bin scans share their barriers, and the passes stop as soon as both selected bins hold a single value (5,000
+    //    distinct doubles separate after about four of the eight digits)
     double q_out[2] = {0.0, 0.0};
     if (m > 0) {
         const double pos[2] = {0.025 * (double)(m - 1), 0.975 * (double)(m - 1)};
         const int lo[2] = {(int)floor(pos[0]), (int)floor(pos[1])};
-        if (tid < 2) { sel_prefix[tid] = 0ull; sel_rank[tid] = (unsigned)lo[tid]; }
+        if (tid < 2) { sel_prefix[tid] = 0ull; sel_rank[tid] = (unsigned)lo[tid]; sel_cnt[tid] = (unsigned)m; }
         unsigned long long mask = 0ull;
         for (int shift = 56; shift >= 0; shift -= 8) {
             hist[0][tid] = 0u; hist[1][tid] = 0u;
             __syncthreads();
+            if (sel_cnt[0] <= 1u && sel_cnt[1] <= 1u) break;       // (uniform: read behind the barrier)
             const unsigned long long p0 = sel_prefix[0], p1 = sel_prefix[1];
+            // run-length aggregation per thread: in the leading passes every value of a column has the same digit (sign, exponent) --
+            // 2 x 5,000 increments of ONE bin are 64-way same-address LDS atomics, 12 k clocks per pass; a thread now adds a run of
+            // equal digits with one atomic
+            unsigned run_d[2] = {0u, 0u}, run_n[2] = {0u, 0u};
             for (int i = tid; i < m; i += 256) {
                 const unsigned long long k = order_key(buf[i]);
                 const unsigned d = (unsigned)(k >> shift) & 255u;
-                if ((k & mask) == p0) atomicAdd(&hist[0][d], 1u);
-                if ((k & mask) == p1) atomicAdd(&hist[1][d], 1u);
+                const bool hit[2] = {(k & mask) == p0, (k & mask) == p1};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (hit[j]) {
+                        if (run_n[j] && run_d[j] != d) { atomicAdd(&hist[j][run_d[j]], run_n[j]); run_n[j] = 0u; }
+                        run_d[j] = d; ++run_n[j];
+                    }
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (run_n[j]) atomicAdd(&hist[j][run_d[j]], run_n[j]);
             __syncthreads();
-            // block-wide inclusive scan of the 256 bins of each histogram: bin tid is owned by thread tid
+            // inclusive scan of the 256 bins of both histograms: bin tid is owned by thread tid
+            unsigned mine[2], incl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned mine = hist[j][tid];
-                unsigned incl = mine;
+                mine[j] = hist[j][tid];
+                incl[j] = mine[j];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const unsigned up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
-                if (lane == 63) wcount[wave] = (int)incl;
-                __syncthreads();
-                unsigned before = 0;
-                for (int w = 0; w < wave; ++w) before += (unsigned)wcount[w];
-                incl += before;
-                const unsigned excl = incl - mine, rank = sel_rank[j];
-                __syncthreads();                                   // everyone has read wcount / sel_rank
-                if (rank >= excl && rank < incl) { sel_prefix[j] |= (unsigned long long)tid << shift; sel_rank[j] = rank - excl; }
-                __syncthreads();
+                for (int off = 1; off < 64; off <<= 1) { const unsigned up = __shfl_up(incl[j], off, 64); if (lane >= off) incl[j] += up; }
+                if (lane == 63) wscan[j][wave] = incl[j];
+            }
+            __syncthreads();
+            unsigned rank[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                for (int w = 0; w < wave; ++w) incl[j] += wscan[j][w];
+                rank[j] = sel_rank[j];
+            }
+            __syncthreads();                                       // everyone has read wscan / sel_rank
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned excl = incl[j] - mine[j];
+                if (rank[j] >= excl && rank[j] < incl[j]) { sel_prefix[j] |= (unsigned long long)tid << shift; sel_rank[j] = rank[j] - excl; sel_cnt[j] = mine[j]; }
             }
             mask |= 0xffull << shift;
+            __syncthreads();
         }
-        // successor of each selected value: the value itself when it is repeated past the rank, else the smallest larger one
+        // a bin with a single value: the remaining digits are that value's (found by the prefix); then the successor of each selected
+        // value: the value itself when it is repeated past the rank, else the smallest larger one
+        __syncthreads();
+        if (mask != ~0ull) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned long long pj = sel_prefix[j];
+                for (int i = tid; i < m; i += 256) {
+                    const unsigned long long k = order_key(buf[i]);
+                    if ((k & mask) == pj) red_key[j][0] = k;       // (one writer, or equal values)
+                }
+            }
+            __syncthreads();
+            if (tid < 2) sel_prefix[tid] = red_key[tid][0];
+            __syncthreads();
+        }
+        unsigned cnt[2] = {0u, 0u};
+        unsigned long long nxt[2] = {~0ull, ~0ull};
+        const unsigned long long vk[2] = {sel_prefix[0], sel_prefix[1]};
+        for (int i = tid; i < m; i += 256) {
+            const unsigned long long k = order_key(buf[i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { if (k <= vk[j]) ++cnt[j]; else nxt[j] = (k < nxt[j]) ? k : nxt[j]; }
+        }
+        __syncthreads();                                           // (red_key was read above)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned long long vk = sel_prefix[j];
-            unsigned cnt = 0;
-            unsigned long long nxt = ~0ull;
-            for (int i = tid; i < m; i += 256) {
-                const unsigned long long k = order_key(buf[i]);
-                if (k <= vk) ++cnt; else nxt = (k < nxt) ? k : nxt;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                cnt[j] += __shfl_down(cnt[j], off, 64);
+                const unsigned long long o = __shfl_down(nxt[j], off, 64);
+                nxt[j] = (o < nxt[j]) ? o : nxt[j];
             }
-            red_cnt[tid] = cnt; red_key[tid] = nxt;
-            __syncthreads();
-            for (int h = 128; h > 0; h >>= 1) {
-                if (tid < h) { red_cnt[tid] += red_cnt[tid + h]; red_key[tid] = (red_key[tid + h] < red_key[tid]) ? red_key[tid + h] : red_key[tid]; }
-                __syncthreads();
-            }
-            const double a = key_value(vk);
+            if (lane == 0) { red_cnt[j][wave] = cnt[j]; red_key[j][wave] = nxt[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned total = red_cnt[j][0] + red_cnt[j][1] + red_cnt[j][2] + red_cnt[j][3];
+            unsigned long long nk = red_key[j][0];
+            for (int w = 1; w < 4; ++w) nk = (red_key[j][w] < nk) ? red_key[j][w] : nk;
+            const double a = key_value(vk[j]);
             const bool has_next = lo[j] + 1 < m;
-            const double b2 = !has_next ? a : (((int)red_cnt[0] >= lo[j] + 2) ? a : key_value(red_key[0]));
+            const double b2 = !has_next ? a : (((int)total >= lo[j] + 2) ? a : key_value(nk));
             q_out[j] = lerp_numpy(a, b2, pos[j] - (double)lo[j]);
-            __syncthreads();
         }
     }
     if (tid == 0) {
