@@ -998,6 +998,25 @@ PLSPM_HD bool nm_step(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, c
     ex.par(P, [&](int p) { st.a_new[p] = ws.wn[p] * ws.wf[md.lvof[p]]; });
     nm_score_map(ex, md, st, st.a_new, st.c_new, st.k_new);
     ex.one([&]() { st.scal[2] = (double)(iteration + 1); if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3]; });
+    // The stop-rule value of THIS step, sum_il c_i (|y_old| - |y_new|)^2 (weights.py:120), needs a pass over the observations -- but
+    // ||a| - |b|| <= |a - b|, so it is bounded from above by  sum_il c_i (y_old - y_new)^2 = n sum_l d_l' R_bb d_l,  d = a_new - a_old,
+    // which lives on the correlation matrix.  The two differ only in the observations whose score changes sign between the steps
+    // (both scores near zero there), so when the iteration has converged the bound says so too: the problem stops HERE, with the same
+    // iteration count as the reference, and the pass of the last iteration -- a third of the stop-rule work at three iterations -- is
+    // not needed (its replicate groups find themselves inactive).  Never for the first step: the launch that prepares a problem does
+    // not finish it.  The margin covers the rounding of the bound itself.
+    if (iteration >= 1) {
+        ex.par(P, [&](int p) { ws.cv[p] = st.a_new[p] - st.a_old[p]; });
+        ex.par(P, [&](int p) { const int l = md.lvof[p]; ws.dv[p] = ws.cv[p] * dot_col(ws.S, PS, p, ws.cv, md.boff[l], md.boff[l + 1]); });
+        const double ub = n * ex.sum(P, [&](int p) { return ws.dv[p]; });
+        if (ub < md.tol * (1.0 - 1e-9)) {
+            ex.one([&]() {
+                st.scal[4] = ub; st.scal[3] = 0.0;
+                if (iteration + 1 > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED;      // (weights.py:183-186)
+            });
+            return false;
+        }
+    }
     return true;
 }
 
