@@ -277,6 +277,33 @@ PLSPM_HD bool nmx_step(Ex& ex, const ModelDesc& md, const MissDesc& xd, Workspac
     nmx_new_scores(ex, md, xd, ws, st, x, ws.wn, ws.wn, true);
     nmx_score_map(ex, md, x, st.c_new, st.k_new);
     ex.one([&]() { st.scal[2] = (double)(iteration + 1); if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3]; });
+    // The stop-rule value of THIS step bounded without a pass over the observations (solver_core.h nm_step has the argument): the
+    // complete rows contribute at most  sum_i c_i (y_old - y_new)^2 = n sum_l [d_g' Rn_bb d_g + 2 d_h (Rn_1b . d_g) + d_h^2 Rn_11]  with
+    // (d_g, d_h) the change of the score map on the standardised columns (the old map recovered from c_old / k_old), the incomplete
+    // rows their exact term.  Below the tolerance the problem stops here, with the reference's iteration count.
+    if (iteration >= 1) {
+        const int PS = ws.PS;
+        ex.par(P, [&](int p) { ws.cv[p] = x.g[p] - st.c_old[p] / x.alpha[p]; });
+        ex.par(L, [&](int l) {
+            double h_old = st.k_old[l];
+            for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) h_old -= x.beta[p] * (st.c_old[p] / x.alpha[p]);
+            ws.a[l] = x.h[l] - h_old;
+        });
+        ex.par(P, [&](int p) {
+            const int l = md.lvof[p];
+            ws.dv[p] = ws.cv[p] * (dot_col(ws.S, PS, p, ws.cv, md.boff[l], md.boff[l + 1]) + 2.0 * ws.a[l] * ws.S[P * PS + p]);
+        });
+        const double quad = ex.sum(P, [&](int p) { return ws.dv[p]; }) + ex.sum(L, [&](int l) { return ws.a[l] * ws.a[l] * ws.S[P * PS + P]; });
+        const double explicit_rows = ex.sum(K * L, [&](int e) { const double d = fabs(x.Yo[e]) - fabs(x.Yn[e]); return x.ck[e / L] * d * d; });
+        const double ub = n * quad + explicit_rows;
+        if (ub < md.tol * (1.0 - 1e-9)) {
+            ex.one([&]() {
+                st.scal[4] = ub; st.scal[3] = 0.0;
+                if (iteration + 1 > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED;
+            });
+            return false;
+        }
+    }
     return true;
 }
 
