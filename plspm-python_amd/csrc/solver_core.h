@@ -494,9 +494,17 @@ PLSPM_HD void apply_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const Cov& c
     ex.mark(17);
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;
-        double s = 0.0;
-        for (int p = md.boff[l]; p < md.boff[l + 1]; ++p) s += ws.w[p] * ws.V[p * L + m];
-        ws.Q[e] = s;
+        // four columns per trip, two chains: the LDS reads of a trip are in flight together and a trip pays one loop branch
+        // (~20 clocks on the device, taken or not) instead of four
+        double s0 = 0.0, s1 = 0.0;
+        int p = md.boff[l];
+        const int pe = md.boff[l + 1];
+        for (; p + 3 < pe; p += 4) {
+            s0 += ws.w[p] * ws.V[p * L + m]; s1 += ws.w[p + 1] * ws.V[(p + 1) * L + m];
+            s0 += ws.w[p + 2] * ws.V[(p + 2) * L + m]; s1 += ws.w[p + 3] * ws.V[(p + 3) * L + m];
+        }
+        for (; p < pe; ++p) s0 += ws.w[p] * ws.V[p * L + m];
+        ws.Q[e] = s0 + s1;
     });
     ex.mark(18);
 }
