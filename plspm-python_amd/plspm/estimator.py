@@ -95,7 +95,9 @@ class Estimator:
         config = calculator.config()
         hocs = config.hoc()
         if config.metric() or calculator._nonmetric() != 1 or data.isnull().values.any():
-            raise NotImplementedError("bootstrapping higher order constructs needs complete Scale.NUM / Scale.RAW data")
+            # (Scale.ORD / NOM: Plspm runs bootstrap.launch_replicatewise instead; NaNs: the reference cannot estimate a HOC model on
+            #  incomplete data either -- its Config.filter raises KeyError for the HOC, config.py:279)
+            raise NotImplementedError("the batched two-stage bootstrap needs complete Scale.NUM / Scale.RAW data")
         path1 = self.expanded_first_stage_path(config)
         compiled1 = compile_model(config, path1, list(data.columns))
         values = data.values

@@ -17,6 +17,7 @@ import plspm.outer_model as om
 import plspm.weights as w
 from plspm.bootstrap import Bootstrap
 from plspm.bootstrap import launch as launch_bootstrap
+from plspm.bootstrap import launch_replicatewise
 from plspm.estimator import Estimator
 from plspm.scheme import Scheme
 from plspm.unidimensionality import Unidimensionality
@@ -79,8 +80,12 @@ class Plspm:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
             # the handle of the fit already holds the data in HBM: the replicates are enqueued on it NOW (HOC models: on a two-stage
             # handle pair), so that the GPU resamples and solves while the host does whatever is left to do
-            boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
-            pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed)
+            if config.hoc() and calculator._nonmetric() == 2:
+                # higher order construct on Scale.ORD / NOM data: one two-stage device estimate per replicate (bootstrap.launch_replicatewise)
+                pending = launch_replicatewise(self._replicate_runner(config, calculator, observations), n_obs, fit, bootstrap_iterations, seed)
+            else:
+                boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
+                pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed)
         self._result = fit
         # The report frames only re-label / post-process the device outputs already on the host (fit.raw); they are built on first
         # access (the reference builds them eagerly, plspm.py:69-77 -- same objects, same values, ~4 ms of pandas work per call that a
@@ -138,6 +143,18 @@ class Plspm:
     def unidimensionality(self) -> pd.DataFrame:
         """Per block: mode, mvs, cronbach_alpha, dillon_goldstein_rho, eig_1st, eig_2nd."""
         return self._unidimensionality.summary()
+
+    @staticmethod
+    def _replicate_runner(config, calculator, observations):
+        """run_one(idx) of ``bootstrap.launch_replicatewise``: the estimate of the resampled observations in the device row layout
+        (weights | r2 | total | direct | loadings) -- what a reference worker computes per replicate (bootstrap.py:56-64)."""
+        def run_one(idx):
+            result = Estimator(config).run(calculator, observations.iloc[idx, :], want_scores=False)
+            raw = result.raw
+            row = np.concatenate((raw["weights"], raw["r2"], raw["total"], raw["direct"], raw["loadings"])).astype(np.float64)
+            result.native.close()
+            return row, int(raw["iterations"])
+        return run_one
 
     def bootstrap(self) -> Bootstrap:
         """The :class:`plspm.bootstrap.Bootstrap` results; raises when bootstrap=True was not requested."""

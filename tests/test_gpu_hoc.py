@@ -116,3 +116,75 @@ def test_api_bootstrap_of_a_hoc_model():
     mine = boot.replicates()                                             # noqa: SLF001 (rows in device order, failed ones dropped)
     assert boot.status()[:4].tolist() == [0, 0, 0, 0]
     assert_close(mine[3][16:16 + 5 + 16], np.concatenate((o["r2"], o["total"], o["direct"])), RTOL, ATOL)
+
+
+def _ordinal_hoc(scheme_name):
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    mobi = pd.read_csv(os.path.join(GOLDEN, "ref_data", "mobi.csv"), index_col=0).astype(float)
+    structure = c.Structure()
+    structure.add_path(["Expectation", "Quality"], ["Satisfaction"])
+    structure.add_path(["Satisfaction"], ["Complaints", "Loyalty"])
+    config = c.Config(structure.path(), default_scale=Scale.ORD)
+    config.add_higher_order("Satisfaction", Mode.A, ["Image", "Value"])
+    config.add_lv_with_columns_named("Expectation", Mode.A, mobi, "CUEX")
+    config.add_lv_with_columns_named("Quality", Mode.A, mobi, "PERQ")
+    config.add_lv_with_columns_named("Loyalty", Mode.A, mobi, "CUSL")
+    config.add_lv_with_columns_named("Image", Mode.A, mobi, "IMAG")
+    config.add_lv_with_columns_named("Complaints", Mode.A, mobi, "CUSCO")
+    config.add_lv_with_columns_named("Value", Mode.A, mobi, "PERV")
+    return mobi, config, {"path": Scheme.PATH, "centroid": Scheme.CENTROID}[scheme_name]
+
+
+@pytest.mark.parametrize("tag", ["path", "centroid"])
+def test_hoc_on_ordinal_data_fit_and_replicates_vs_reference_golden(tag):
+    """Higher order construct on Scale.ORD data (golden g15 from the real reference: full sample + five resamples on explicit indices).
+    The bootstrap of such a model is one two-stage device estimate per replicate (bootstrap.launch_replicatewise): the rows of the
+    explicit index lists must be the reference's, the records land in HBM and feed the device summaries like any other bootstrap."""
+    from plspm.bootstrap import launch_replicatewise
+    from plspm.plspm import Plspm
+    g = load("g15_hoc_ordinal")
+    mobi, config, scheme = _ordinal_hoc(tag)
+    pls = Plspm(mobi, config, scheme, 100, 1e-7)
+    fit = pls._result
+    cm = fit.compiled
+    assert list(cm.dev_mvs) == list(g[tag + "/mvs2"]) and list(cm.lvs) == list(g[tag + "/lvs2"])
+    gold = g[tag + "/rows"]
+    full = np.concatenate((fit.raw["weights"], fit.raw["r2"], fit.raw["total"], fit.raw["direct"], fit.raw["loadings"]))
+    assert_close(full, gold[0], RTOL, ATOL)
+    import plspm.weights as w
+    observations = config.filter(mobi)
+    calculator = w.WeightsCalculatorFactory(config, 100, 1e-7, np.sqrt(250 / 249), scheme, 0)
+    run_one = Plspm._replicate_runner(config, calculator, observations)
+    pending = launch_replicatewise(run_one, 250, fit, 5, seed=3, indices=g["idx"])
+    rows, status, iters = fit.native.fetch(0, 5)
+    assert np.all(status == 0) and np.all(iters > 0)
+    assert_close(rows, gold[1:], RTOL, ATOL)
+    table, used = fit.native.summary(5, full)
+    assert used == 5
+    assert_close(table[:, 1], gold[1:].mean(axis=0), 1e-6, 1e-9)
+
+
+def test_api_bootstrap_of_a_hoc_model_on_ordinal_data():
+    """Plspm(..., bootstrap=True) no longer refuses a higher order construct on Scale.ORD data: device RNG index stream, one
+    two-stage estimate per replicate, the reference's frames."""
+    from plspm import _native
+    from plspm.plspm import Plspm
+    mobi, config, scheme = _ordinal_hoc("path")
+    pls = Plspm(mobi, config, scheme, 100, 1e-7, bootstrap=True, bootstrap_iterations=40, seed=11)
+    boot = pls.bootstrap()
+    assert boot.used() >= 38
+    w = boot.weights()
+    assert np.all(np.isfinite(w[["mean", "std.error", "perc.025", "perc.975"]].values))
+    om = pls.outer_model()
+    assert_close(w.loc[om.index, "original"].values, om["weight"].values, 1e-12)
+    assert np.all(np.abs(w["mean"] - w["original"]) < 6 * w["std.error"] + 1e-3)
+    # replicate 0 is the estimate of the device stream's indices (seed, 0)
+    observations = config.filter(mobi)
+    import plspm.weights as wm
+    calculator = wm.WeightsCalculatorFactory(config, 100, 1e-7, np.sqrt(250 / 249), scheme, 0)
+    row, _ = Plspm._replicate_runner(config, calculator, observations)(_native.bootstrap_indices(11, 0, 250))
+    assert_close(boot.replicates()[0], row, 1e-12, 1e-14)
+    assert boot.r_squared().shape[0] == 3 and boot.total_effects().shape[0] == 8
