@@ -86,7 +86,7 @@ def launch_replicatewise(run_one, n_obs: int, result, iterations: int, seed=None
     """Replicates of a model the batched kernels do not cover -- a higher order construct on Scale.ORD / NOM data, where every
     replicate re-quantifies its MVs and the second stage is not a function of first-stage moments: every replicate is a
     complete two-stage DEVICE estimate of the resampled observations (``run_one(idx) -> (row, iterations)``: the kernels of the
-    full-sample fit, one replicate at a time, ~100 replicates/s), drawn with the device RNG's index stream (seed, replicate id) or the
+    full-sample fit, one replicate at a time, ~70 replicates/s on the mobi model), drawn with the device RNG's index stream (seed, replicate id) or the
     explicit ``indices``.  A replicate that raises is dropped like the reference's (bootstrap.py:65-66).  The records go back to HBM
     (``plspm_bootstrap_store``) so that summaries, fetches and frames are the ones of every other bootstrap."""
     from plspm import _native
