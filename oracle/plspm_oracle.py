@@ -457,7 +457,11 @@ def fit_two_stage(X, model1: Model, stage2, C2, modes2, corr: Optional[float] = 
             cols.extend(r1["scores"][:, j] for j in ref)
         blocks2.append(np.arange(start, len(cols)))
     X2 = np.column_stack(cols)
-    model2 = Model(blocks2, np.asarray(C2), modes2, model1.scheme, model1.scaled, max_iter=model1.max_iter, tol=model1.tol, scales=["NUM"] * X2.shape[1])
+    # stage-2 scales: a plain MV keeps its own (an ordinal MV is quantified again in stage 2), a HOC's score columns are Scale.NUM
+    scales2 = []
+    for kind, ref in stage2:
+        scales2.extend([model1.scales[p] for p in model1.blocks[ref]] if (kind == "lv" and model1.scales is not None) else ["NUM"] * (len(model1.blocks[ref]) if kind == "lv" else len(ref)))
+    model2 = Model(blocks2, np.asarray(C2), modes2, model1.scheme, model1.scaled, max_iter=model1.max_iter, tol=model1.tol, scales=scales2)
     r2 = fit(X2, model2, corr)
     r2["iterations1"] = r1["iterations"]
     return r2
