@@ -1377,7 +1377,10 @@ int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t 
     const int R = stride - 2;
     int rc = pin_ready(m);
     if (rc) return rc;
-    const int64_t per = std::max<int64_t>(1, (int64_t)(kPinHalf / ((size_t)stride * sizeof(double))));
+    // chunks of at most half the staging area -- and of at most a quarter of the records, so that the host's unpacking of one chunk runs
+    // beside the DMA of the next even when everything would fit a single chunk (5,000 x 158 records = 6.3 MB)
+    int64_t per = std::max<int64_t>(1, (int64_t)(kPinHalf / ((size_t)stride * sizeof(double))));
+    per = std::min<int64_t>(per, std::max<int64_t>(256, (B + 3) / 4));
     auto unpack = [&](int h, int64_t b0, int64_t nb) {
         const double* rec = (const double*)((const char*)m->h_pin + h * kPinHalf);
         for (int64_t b = 0; b < nb; ++b, rec += stride) {

@@ -256,15 +256,19 @@ class NativeModel:
         out["status"] = int(out["status"][0])
         return out
 
-    def bootstrap(self, B, seed=0, rep_offset=0, idx=None):
+    def bootstrap(self, B, seed=0, rep_offset=0, idx=None, out=None):
         """Returns (rows [B, R], status [B], iters [B]) on the host."""
         if idx is not None:
             idx = np.ascontiguousarray(idx, dtype=np.int32)
             if idx.shape != (B, self.N):
                 raise ValueError("idx must have shape (B, N)")
-        rows = np.empty((B, self.row_width))
-        status = np.empty(B, dtype=np.int32)
-        iters = np.empty(B, dtype=np.int32)
+        if out is None:
+            rows, status, iters = np.empty((B, self.row_width)), np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        else:                                      # caller-owned buffers (the C-ABI's contract): nothing is allocated -- or first touched -- per call
+            rows, status, iters = out
+            if rows.shape != (B, self.row_width) or rows.dtype != np.float64 or not rows.flags.c_contiguous or status.shape != (B,) or iters.shape != (B,) \
+                    or status.dtype != np.int32 or iters.dtype != np.int32:
+                raise ValueError("out = (rows [B, row_width] float64, status [B] int32, iters [B] int32), C-contiguous")
         self._check(self._lib.plspm_bootstrap(self._h, B, seed, rep_offset, _ptr(idx), _ptr(rows), _ptr(status), _ptr(iters)), "plspm_bootstrap")
         self.last_B = B
         return rows, status, iters
