@@ -32,7 +32,7 @@ struct DevExecT {
     // bubble of ~60 cycles) in the compiled form with v_readlane broadcasts, where hipcc had also expanded the loop-invariant mask into
     // 64 lane masks spilled to VGPR lanes (5.2k cycles per call at P = 60 against 2.6k for compiled DPP groups of four and this form's
     // ~1k).  Columns >= P hold s = 0 and W repeats w[P - 1] (finite).  Sixteen columns per asm statement (operand count); the leading
-    // s_nop covers the two wait states between a VALU write of W (a copy the compiler may place in front) and its DPP read.
+    // s_nop 4 covers the wait states a DPP read needs behind a VALU write of W (2: a copy the compiler may place in front) or of EXEC (5).
 #define PLSPM_SEG_COL(J, ACC, SOP)                                                                                  \
     "v_fmac_f64_dpp " ACC ", %4, " SOP " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"                        \
     "s_bitcmp1_b32 %21, " #J "\n\t"                                                                                 \
@@ -58,7 +58,7 @@ struct DevExecT {
             if (16 * a < P) {                                     // (uniform)
                 const unsigned eh = (unsigned)(ends >> (16 * a)) & 0xffffu;
                 const double* c = s + 16 * a;
-                asm volatile("s_nop 1\n\t"
+                asm volatile("s_nop 4\n\t"
                              PLSPM_SEG_COL(0, "%0", "%5") PLSPM_SEG_COL(1, "%1", "%6") PLSPM_SEG_COL(2, "%0", "%7") PLSPM_SEG_COL(3, "%1", "%8")
                              PLSPM_SEG_COL(4, "%0", "%9") PLSPM_SEG_COL(5, "%1", "%10") PLSPM_SEG_COL(6, "%0", "%11") PLSPM_SEG_COL(7, "%1", "%12")
                              PLSPM_SEG_COL(8, "%0", "%13") PLSPM_SEG_COL(9, "%1", "%14") PLSPM_SEG_COL(10, "%0", "%15") PLSPM_SEG_COL(11, "%1", "%16")
