@@ -83,7 +83,10 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "i8_shape"        16 (default) | 32   MFMA shape / fragment-block layout of the int8 Gram (32: v_mfma_i32_32x32x32_i8, measured 16 % slower)
  *   "i8_sched"        0 (default) | 1   int8 Gram as a persistent "stream-K" launch: one workgroup per CU, the tiles of the whole rounds
  *                     + an equal share of the left-over tiles' k-steps each, exact int32 partial sums handed to the tile's owner through
- *                     flagged scratch slots (bit-identical results; the kernel is ~3 % faster, the step is not: measured neutral)
+ *                     flagged scratch slots (bit-identical results; the kernel is ~3 % faster, the step is not: measured neutral).  Its
+ *                     workgroups wait for each other's partial sums: two such launches sharing one device at the same time can starve each
+ *                     other -- the wait is bounded (~1 s; the tile is then NaN, its replicates get status 3, plspm_bootstrap / _fetch
+ *                     return PLSPM_E_STATE), so leave it off on handles that run concurrently on one device
  *   "resample_aux"    0 (default) | 1 | 2 | 3   int8 resample counts on a second stream of lowest / default / highest priority, so that
  *                     the draws of the next call fill CUs the Gram / solver of this one leave idle (+-2 %: measured neutral)
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
