@@ -826,3 +826,50 @@ def test_large_p_block_gram(L, per, n):
     mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(4, 2, n), orc.correction(n))
     assert its == iters[2]
     assert_close(rows[2], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 256, 257, 4097, 9000])
+def test_device_summary_on_crafted_records(B):
+    """summary_kernel on records written by the host (plspm_bootstrap_store): heavy ties around both quantiles, constant columns,
+    negative values and signed zeros, values that differ only in their last bits, dropped replicates (status != 0 and the NaN status
+    of a ragged shard's padding) -- the radix select stops early on single-value bins and must not on tied ones; the compaction
+    loads 4,096 replicates per round.  Against the NumPy definition (orc.summary) on the rows that count."""
+    X, blocks, _ = satisfaction_oracle_inputs()
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=100)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    R = nm.row_width
+    rng = np.random.default_rng(B)
+    rows = rng.standard_normal((B, R))
+    rows[:, 0] = 3.25                                              # constant column
+    rows[:, 1] = rng.integers(0, 3, B).astype(float)               # three distinct values: ties at every rank
+    rows[:, 2] = np.where(rng.random(B) < 0.5, 0.0, -0.0)          # signed zeros
+    rows[:, 3] = -np.abs(rows[:, 3])                               # all negative
+    rows[:, 4] = 1.0 + rng.integers(0, 4, B) * 2.0 ** -52          # neighbours in the last bit
+    rows[:, 5] = np.round(rows[:, 5], 1)                           # many repeats
+    status = np.zeros(B, dtype=np.int32)
+    if B > 3:
+        status[rng.random(B) < 0.1] = 1
+        status[1] = 3
+    iters = np.full(B, 4, dtype=np.int32)
+    from plspm import parallel
+    records = parallel.join_records(rows, status, iters)
+    if B > 7:
+        records[-2:, R] = np.nan                                   # padding records of a ragged shard
+        status[-2:] = -1
+    nm.store(records)
+    original = np.linspace(-2.0, 2.0, R)
+    table, used = nm.summary(B, original)
+    ok = rows[status == 0]
+    assert used == ok.shape[0]
+    want = orc.summary(ok, original)
+    if ok.shape[0] < 2:
+        assert np.all(np.isnan(table[:, 2])) and np.all(np.isnan(table[:, 5]))
+        assert_close(table[:, [0, 1, 3, 4]], want[:, [0, 1, 3, 4]], 1e-12, 1e-14)
+    else:
+        finite = np.isfinite(want)
+        finite[4, 2] = finite[4, 5] = False        # std of values that differ in their last bit is rounding noise in NumPy and here alike
+        finite[0, 2] = finite[0, 5] = False        # (constant column: std 0 or an ulp of cancellation, t = +-inf or huge)
+        assert np.all(np.isfinite(table[finite]))
+        assert_close(table[finite], want[finite], 1e-11, 1e-13)
+        assert table[4, 2] < 1e-15 and table[0, 2] < 1e-15
