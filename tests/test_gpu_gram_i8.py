@@ -262,3 +262,23 @@ def test_rows_solver_block_boundaries_at_every_position(sizes):
     mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(11, r, 900), corr)
     assert its == iters[r]
     assert_close(rows[r], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("sizes,B", [([2, 2], 1), ([2, 2], 700), ([3, 1, 2], 4096), ([8, 8, 8, 8, 8, 8, 8, 8], 513)])
+def test_persistent_schedule_on_small_and_wide_tile_grids(sizes, B):
+    """The stream-K launch when the tile grid is smaller than the machine (a 4-MV model has ONE pair tile: most XCDs and workgroups
+    get nothing, the rest share single tiles along k) and when whole rounds and left-over tiles mix; against the tiled launch."""
+    from test_gpu_parity import _ragged
+    L = len(sizes)
+    C = orc.chain_C(L)
+    X, blocks = _ragged(640, C, sizes, seed=7)
+    model = orc.Model(blocks, C, "A" * L, "centroid", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows_t, st_t, it_t = nm.bootstrap(B, seed=2)
+    M_t = nm.bootstrap_moments(min(B, 300), seed=2)
+    assert nm.get_option("last_gram_path") == 2
+    nm.set_option("i8_sched", 1)
+    rows_k, st_k, it_k = nm.bootstrap(B, seed=2)
+    assert np.array_equal(rows_t, rows_k) and np.array_equal(st_t, st_k) and np.array_equal(it_t, it_k)
+    assert np.array_equal(M_t, nm.bootstrap_moments(min(B, 300), seed=2))
