@@ -58,14 +58,27 @@ def run_nm_emu(lib, X, model, counts=None, shift=None, nthreads=4, nparts=5):
     lv_of = np.repeat(np.arange(L), np.diff(boff))
     onehot = (lv_of[:, None] == np.arange(L)[None, :]).astype(float)
     partial = np.zeros(nparts)
+
+    def stop_rule_terms():
+        y_old = (Xs * state[sl["c_old"]]) @ onehot + state[sl["k_old"]]
+        y_new = (Xs * state[sl["c_new"]]) @ onehot + state[sl["k_new"]]
+        return ((np.abs(y_old) - np.abs(y_new)) ** 2).sum(axis=1) * cw                 # what the nm_conv kernel accumulates
+    early = False
     for _ in range(model.max_iter + 5):
         active = lib.hostemu_nm_step(*args, nthreads, _ptr(S), _ptr(state), _ptr(partial), nparts)
         if not active:
+            # the step either decided on the exact value of the previous pass or stopped on its own upper bound (nm_step: the
+            # quadratic form on the correlation matrix): whichever it was, state[4] must not be below the exact value of the step
+            # the score maps now describe
+            exact = float(stop_rule_terms().sum())
+            assert exact <= state[4] * (1.0 + 1e-9) + 1e-18, (exact, state[4])
+            early = abs(state[4] - partial.sum()) > 1e-15 * max(1.0, abs(state[4])) and state[1] == 0.0 and state[4] < model.tol
+            if early:
+                assert state[4] <= 50.0 * max(exact, 1e-300) + 1e-12                    # ... and the bound is tight where it is used
             break
-        y_old = (Xs * state[sl["c_old"]]) @ onehot + state[sl["k_old"]]
-        y_new = (Xs * state[sl["c_new"]]) @ onehot + state[sl["k_new"]]
-        d = ((np.abs(y_old) - np.abs(y_new)) ** 2).sum(axis=1) * cw                 # what the nm_conv kernel accumulates
+        d = stop_rule_terms()
         partial = np.array([chunk.sum() for chunk in np.array_split(d, nparts)])
+    run_nm_emu.early_stops = getattr(run_nm_emu, "early_stops", 0) + int(early)
     pairs = effect_pairs(model.C)
     ef = np.array([p[0] for p in pairs], dtype=np.int32); et = np.array([p[1] for p in pairs], dtype=np.int32)
     ne = len(pairs)
@@ -129,3 +142,14 @@ def test_nonmetric_not_converged(emu):
     model = orc.Model(RUSSA_BLOCKS, RUSSA_C, "AAA", "centroid", True, max_iter=2, tol=1e-30, scales=["NUM"] * 9)
     e = run_nm_emu(emu, X, model)
     assert e["status"] == 1 and e["iterations"] == 3
+
+
+def test_the_stop_rule_bound_is_exercised(emu):
+    """nm_step's upper bound on the stop-rule value (no pass over the observations in the converged iteration) must actually end
+    problems in this suite -- with the reference's iteration counts, which every test above asserts."""
+    X, blocks = orc.synth(2000, orc.satisfaction_C(), 4, seed=21)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True, tol=1e-6, scales=["NUM"] * 24)
+    before = getattr(run_nm_emu, "early_stops", 0)
+    e = run_nm_emu(emu, X, model)
+    check_nm(e, orc.fit(X, model), "bound")
+    assert getattr(run_nm_emu, "early_stops", 0) == before + 1
