@@ -306,7 +306,8 @@ typedef struct plspm_group plspm_group_t;
 int plspm_rccl_unique_id(uint8_t* id /* [PLSPM_UNIQUE_ID_BYTES] */);
 /* device_ids [n_local]: HIP device of every local rank; local rank i is global rank first_rank + i.  NULL on failure. */
 plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id);
-void plspm_comm_destroy(plspm_comm_t* c);                  /* also destroys the group still bound to it */
+void plspm_comm_destroy(plspm_comm_t* c);                  /* a group still bound to it is released (streams, buffers, its hold on the handles): later
+                                                              calls on that group return PLSPM_E_STATE; its owner still calls plspm_group_destroy */
 int32_t plspm_comm_size(const plspm_comm_t* c);            /* nranks */
 int32_t plspm_comm_uses_rccl(const plspm_comm_t* c);       /* 1: records travel through RCCL; 0: the same-device copy route */
 /* models [n_local of the communicator]: handle i lives on the communicator's device i, data uploaded.  NULL on failure. */
@@ -331,6 +332,11 @@ int plspm_group_records(plspm_group_t* g, int32_t local, void** d_records, int64
 int plspm_group_summary(plspm_group_t* g, const double* original, double* summary, int64_t* n_used);
 /* Host copy of the last plspm_group_bootstrap's replicates in replicate-id order: out [B*R], status / iters [B] (may be NULL). */
 int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* iters);
+/* Hand the last plspm_group_bootstrap's records to local handle 0 (device-to-device, replicate-id order): the handle then answers
+ * plspm_bootstrap_fetch / plspm_bootstrap_summary(d_rows = NULL) for them like for its own plspm_bootstrap_device, and the group --
+ * and with it the communicator's one group slot -- can be destroyed (the merge of Bootstrap.__init__, bootstrap.py:96-111, keeps
+ * nothing of the workers alive either). */
+int plspm_group_adopt(plspm_group_t* g);
 /* Collective helpers for a caller's timing protocol (bench.py): barrier = all-reduce of one word on the gather stream + host
  * wait; max = all-reduce(max) of one double over the ranks. */
 int plspm_group_barrier(plspm_group_t* g);

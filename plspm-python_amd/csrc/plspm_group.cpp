@@ -209,7 +209,9 @@ void plspm_group_destroy(plspm_group_t* g) {
 
 void plspm_comm_destroy(plspm_comm_t* c) {
     if (!c) return;
-    if (c->bound) plspm_group_destroy(c->bound);
+    // A group still bound lets go of its handles, streams and buffers here, but the struct stays with its owner: a later call on it
+    // reports PLSPM_E_STATE instead of touching freed memory, and the owner's plspm_group_destroy frees it.
+    if (c->bound) group_release(c->bound);
     for (size_t i = 0; i < c->comms.size(); ++i)
         if (c->comms[i] && g_rccl.so) { hipSetDevice(c->devices[i]); g_rccl.CommDestroy(c->comms[i]); }
     delete c;
@@ -354,27 +356,58 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
     } else {
         for (int i = 0; i < nl; ++i) run_shard(i);
     }
-    for (int i = 0; i < nl; ++i) if (shard_rc[i]) return gfail(g, shard_rc[i], "shard of rank " + std::to_string(g->first_rank + i) + ": " + g->loc[i].m->error);
+    // A failed shard (out of memory, an LDS limit, a read-back error of a non-metric model) must not keep this rank out of the
+    // collective: the other ranks of the job are already inside it and would wait forever.  Its send buffer becomes NaN-status
+    // records (never counted as replicates), the all-gather runs as planned, and the error is reported afterwards.
+    int first_bad = -1;
+    for (int i = 0; i < nl; ++i) {
+        if (!shard_rc[i]) continue;
+        if (first_bad < 0) first_bad = i;
+        Local& l = g->loc[i];
+        hipSetDevice(l.m->device);
+        (void)hipGetLastError();
+        hipMemsetAsync(l.send[s].p, 0xFF, send_bytes, l.m->stream);
+        hipEventRecord(l.computed[s], l.m->stream);
+    }
     // 2. the ONE collective, on the gather streams behind the shard kernels
+    int crc = 0;
+    std::string cwhy;
     if (g->use_rccl) {
         const Rccl* r = &g_rccl;
-        for (auto& l : g->loc) { GHIP(g, hipSetDevice(l.m->device)); GHIP(g, hipStreamWaitEvent(l.cstream, l.computed[s], 0)); }
-        GNCCL(g, r, r->GroupStart());
         for (auto& l : g->loc) {
-            GHIP(g, hipSetDevice(l.m->device));
-            GNCCL(g, r, r->AllGather(l.send[s].p, l.recv[s].p, (size_t)cap * RS, ncclDouble, l.comm, l.cstream));
+            hipError_t e = hipSetDevice(l.m->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(l.cstream, l.computed[s], 0);
+            if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e); }
         }
-        GNCCL(g, r, r->GroupEnd());
-        for (auto& l : g->loc) { GHIP(g, hipSetDevice(l.m->device)); GHIP(g, hipEventRecord(l.gathered[s], l.cstream)); }
+        ncclResult_t n = r->GroupStart();
+        if (n != ncclSuccess) { if (!crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupStart: ") + r->GetErrorString(n); } }
+        else {
+            // between GroupStart and GroupEnd nothing returns early: an open group call would poison every later RCCL call of the process
+            for (auto& l : g->loc) {
+                hipSetDevice(l.m->device);
+                n = r->AllGather(l.send[s].p, l.recv[s].p, (size_t)cap * RS, ncclDouble, l.comm, l.cstream);
+                if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclAllGather: ") + r->GetErrorString(n); }
+            }
+            n = r->GroupEnd();
+            if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupEnd: ") + r->GetErrorString(n); }
+        }
+        for (auto& l : g->loc) { hipSetDevice(l.m->device); hipEventRecord(l.gathered[s], l.cstream); }
     } else {
         for (auto& dst : g->loc) {
-            GHIP(g, hipSetDevice(dst.m->device));
+            hipSetDevice(dst.m->device);
             for (int i = 0; i < nl; ++i) {
-                GHIP(g, hipStreamWaitEvent(dst.cstream, g->loc[i].computed[s], 0));
-                GHIP(g, hipMemcpyAsync((char*)dst.recv[s].p + (size_t)i * send_bytes, g->loc[i].send[s].p, send_bytes, hipMemcpyDeviceToDevice, dst.cstream));
+                hipError_t e = hipStreamWaitEvent(dst.cstream, g->loc[i].computed[s], 0);
+                if (e == hipSuccess) e = hipMemcpyAsync((char*)dst.recv[s].p + (size_t)i * send_bytes, g->loc[i].send[s].p, send_bytes, hipMemcpyDeviceToDevice, dst.cstream);
+                if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
             }
-            GHIP(g, hipEventRecord(dst.gathered[s], dst.cstream));
+            hipEventRecord(dst.gathered[s], dst.cstream);
         }
+    }
+    if (first_bad >= 0 || crc) {
+        // the slot's buffers were handed to the collective: they count as in flight, but the call has no result
+        g->pending[s] = true; g->next_slot = s ^ 1; g->last_slot = -1;
+        if (first_bad >= 0) return gfail(g, shard_rc[first_bad], "shard of rank " + std::to_string(g->first_rank + first_bad) + ": " + g->loc[first_bad].m->error);
+        return gfail(g, crc, cwhy);
     }
     g->pending[s] = true; g->last_slot = s; g->next_slot = s ^ 1; g->last_B = B; g->last_cap = cap;
     return 0;
@@ -419,6 +452,29 @@ int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* it
                                             iters ? iters + first : nullptr);
         if (rc) return gfail(g, rc, l.m->error);
     }
+    return 0;
+}
+
+// The records of the last bootstrap move into local handle 0's own record buffer, compacted to replicate-id order: afterwards
+// plspm_bootstrap_fetch / plspm_bootstrap_summary on that handle serve them and the group (with its communicator slot) is free.
+int plspm_group_adopt(plspm_group_t* g) {
+    if (!g) return PLSPM_E_ARG;
+    if (g->last_slot < 0 || g->loc.empty()) return gfail(g, PLSPM_E_STATE, "plspm_group_adopt: no bootstrap result on this group");
+    Local& l = g->loc[0];
+    plspm_model* m = l.m;
+    const int RS = plspm_row_stride(m);
+    GHIP(g, hipSetDevice(m->device));
+    m->rows_B = 0;
+    int rc = ensure(m, m->rows, (size_t)g->last_B * RS * sizeof(double));
+    if (rc) return gfail(g, rc, m->error);
+    GHIP(g, hipStreamWaitEvent(m->stream, l.gathered[g->last_slot], 0));
+    const double* rec = (const double*)l.recv[g->last_slot].p;
+    for (int r = 0; r < g->nranks; ++r) {
+        int64_t first = 0, count = 0;
+        shard_of(g->last_B, g->nranks, r, &first, &count);
+        if (count) GHIP(g, hipMemcpyAsync((double*)m->rows.p + first * RS, rec + (size_t)r * g->last_cap * RS, (size_t)count * RS * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
+    }
+    m->rows_B = g->last_B;
     return 0;
 }
 

@@ -22,7 +22,7 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset",
            "plspm_model_set_option", "plspm_model_get_option", "plspm_bootstrap_moments", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
-           "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows",
+           "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt",
            "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
            "plspm_op_inner_weights", "plspm_op_outer_weights"]
 UNIQUE_ID_BYTES = 128
@@ -125,6 +125,7 @@ def load():
     lib.plspm_group_records.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32)]
     lib.plspm_group_summary.argtypes = [vp, vp, vp, ctypes.POINTER(i64)]
     lib.plspm_group_rows.argtypes = [vp, vp, vp, vp]
+    lib.plspm_group_adopt.argtypes = [vp]
     lib.plspm_group_barrier.argtypes = [vp]
     lib.plspm_group_max.argtypes = [vp, ctypes.POINTER(dbl)]
     lib.plspm_op_inner_weights.argtypes = [i32, i32, i32, vp, vp, i64, vp]
@@ -464,7 +465,9 @@ class NativeGroup:
             raise NativeBackendError("%s failed (%d): %s" % (what, rc, self._lib.plspm_group_last_error(self._h).decode()))
 
     def close(self):
-        if getattr(self, "_h", None) and getattr(self.comm, "_h", None):
+        # (a communicator that was destroyed first only RELEASED this group -- streams, buffers, its hold on the handles --; the
+        # struct is still ours to free, and calls on it in between report PLSPM_E_STATE)
+        if getattr(self, "_h", None):
             self._lib.plspm_group_destroy(self._h)
         self._h = None
 
@@ -509,6 +512,10 @@ class NativeGroup:
         used = ctypes.c_int64(0)
         self._check(self._lib.plspm_group_summary(self._h, _ptr(original), _ptr(out), ctypes.byref(used)), "plspm_group_summary")
         return out, used.value
+
+    def adopt(self):
+        """Move the last bootstrap's records into ``models[0]`` (device-to-device); the group may be closed afterwards."""
+        self._check(self._lib.plspm_group_adopt(self._h), "plspm_group_adopt")
 
     def rows(self):
         """(rows [B, R], status, iters) of the last bootstrap in replicate-id order, on the host."""

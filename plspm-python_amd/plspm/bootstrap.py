@@ -2,12 +2,13 @@
 
 The reference forks ``processes`` workers that each loop over resample -> estimate -> inner model -> loadings
 (bootstrap.py:54-66) and merges five DataFrames through a Queue.  Here all replicates of this process run as
-three batched kernels on the data already resident in HBM (resample/compact, fp64-MFMA Gram, LDS solver);
+three batched kernels on the data already resident in HBM (resample to int8 multiplicities, the batch's moment matrices as one
+exact int8 MFMA product on the digit planes of the pair products, one-wave-per-replicate solver; DESIGN.md 3b, 5);
 ``processes`` maps to GPUs: the replicate range is sharded over them and merged by ONE RCCL all-gather inside
 libplspm_hip.so (``plspm_group_*``), in one process or with one process per GPU (``plspm.parallel``).
 Replicates whose status is not OK are dropped, as the reference's bare ``except`` drops them
 (bootstrap.py:65-66).  The summaries of ``_create_summary`` (bootstrap.py:24-32) are computed on the device as well
-(``plspm_bootstrap_summary``: one workgroup per result column, LDS bitonic sort for the quantiles); the host
+(``plspm_bootstrap_summary``: one workgroup per result column, radix select for the quantiles); the host
 ``_create_summary`` below is the same statistic in NumPy, kept for API parity and as the checker of the kernel.
 """
 import os
@@ -46,7 +47,7 @@ class _Pending:
         self.t_launch = time.perf_counter()
 
 
-def launch(result, iterations: int, num_processes: int, seed=None, comm=None) -> _Pending:
+def launch(result, iterations: int, num_processes: int, seed=None, comm=None, devices=None) -> _Pending:
     """Enqueue the bootstrap replicates of a fitted model (``result``: the SolverResult whose handle holds the data) and return at
     once -- for metric models nothing here waits for the device, so the caller's host work (``Plspm`` builds its result frames)
     runs while the GPU resamples and solves.  Where the replicates run: see :class:`Bootstrap`."""
@@ -69,7 +70,7 @@ def launch(result, iterations: int, num_processes: int, seed=None, comm=None) ->
         group.bootstrap(iterations, seed, 0)
         source = group
     else:
-        devices = parallel.devices_for(num_processes, iterations, native.device_id)
+        devices = parallel.devices_for(num_processes, iterations, native.device_id, devices)
         if len(devices) > 1 and result.builder is not None:
             from plspm import _native
             helpers = [result.builder(dev) for dev in devices[1:]]                  # the same model + data on the other GPUs
@@ -120,29 +121,40 @@ class Bootstrap:
     Where the replicates run (results are bit-identical for every choice -- Philox stream keyed by (seed, replicate id)):
       * ``comm`` given (any object with rank / world / all_gather): the caller's host-side transport (``parallel.sharded_bootstrap``);
       * a one-process-per-GPU job (``parallel.init_process_group()`` was called): this rank's shard + ONE RCCL all-gather;
-      * otherwise ``num_processes`` (the reference's worker count) GPUs of this process, capped by the visible devices and by
-        ``parallel.MIN_REPLICATES_PER_GPU``: one handle per GPU + ONE RCCL all-gather; a single GPU needs no collective.
+      * otherwise the handle's own GPU -- or, when the caller names GPUs (``Plspm(devices=[...])`` / ``PLSPM_DEVICES``), up to
+        ``num_processes`` (the reference's worker count) of them, capped by ``parallel.MIN_REPLICATES_PER_GPU``: one handle per GPU
+        + ONE RCCL all-gather; a single GPU needs no collective.
     """
 
     def __init__(self, config, data: pd.DataFrame, inner_model, outer_model, calculator, iterations: int, num_processes: int,
-                 result=None, seed=None, comm=None, pending=None):
+                 result=None, seed=None, comm=None, pending=None, devices=None):
         if pending is None:
             if result is None:
                 from plspm.estimator import Estimator
                 result = Estimator(config).run(calculator, data, want_scores=False)
-            pending = launch(result, iterations, num_processes, seed, comm)
+            pending = launch(result, iterations, num_processes, seed, comm, devices)
         result = pending.result
         native, cm = result.native, result.compiled
         self._seed = pending.seed
         self._cm, self._native, self._iterations_requested = cm, native, pending.iterations
         self._inner_model = inner_model
         self._group, self._helpers, self._source = pending.group, pending.helpers, pending.source
+        self._ranks = pending.group.nranks if pending.group is not None else 1
+        self._via_group = pending.group is not None              # the records came through plspm_group_* (RCCL or the same-device route)
         original = self._original(result, inner_model, outer_model)
         # _create_summary (bootstrap.py:24-32) on the records still in HBM (this is where the host waits for the replicates)
         if self._source is native:
             self._table, self._used = native.summary(pending.iterations, original)
         else:
             self._table, self._used = self._group.summary(original)
+            # The gathered records move into this fit's own handle and the group goes away: a communicator serves ONE group at a
+            # time, so a second live Plspm(bootstrap=True) of the job (or a rebinding loop) must not find it taken; the lazy
+            # rows() / status() accessors then read the handle like after a single-GPU bootstrap.
+            self._group.adopt()
+            self._group.close()
+            for helper in (self._helpers or ()):
+                helper.close()
+            self._group, self._helpers, self._source = None, None, native
         self._rows = None
         self._frames = None
         self.latency_s = time.perf_counter() - pending.t_launch      # enqueue -> summaries on the host (host work in between overlaps)
@@ -179,7 +191,7 @@ class Bootstrap:
 
     def _fetch(self):
         if self._rows is None:
-            self._rows = self._source.rows() if self._source is self._group else self._native.fetch(0, self._iterations_requested)
+            self._rows = self._native.fetch(0, self._iterations_requested)
         return self._rows
 
     def weights(self) -> pd.DataFrame:
@@ -204,6 +216,10 @@ class Bootstrap:
     # --- extensions (not in the reference) -----------------------------------------------------------
     def seed(self):
         return self._seed
+
+    def ranks(self):
+        """Number of ranks (GPUs) the replicates were sharded over (1: no collective)."""
+        return self._ranks
 
     def used(self):
         """Number of replicates that entered the summaries (the others failed and were dropped, bootstrap.py:65-66)."""

@@ -58,13 +58,34 @@ def local_comm(devices):
     return comm
 
 
-def devices_for(processes, replicates, first_device=0):
-    """GPUs a single-process bootstrap uses: ``processes`` (the reference's worker count, plspm.py:35-37) capped by the visible
-    devices and by MIN_REPLICATES_PER_GPU.  Purely a performance decision -- the rows are the same for every answer."""
+def allowed_devices():
+    """The GPUs this process may shard a bootstrap over, from ``PLSPM_DEVICES`` (comma-separated HIP device ids), or None when the
+    variable is unset -- sharding over several GPUs of one process is OPT-IN: a caller that pinned ``device_id`` on a shared node
+    must not find its replicates (and 570 MB of librccl) on a neighbouring GPU that belongs to another job."""
+    spec = os.environ.get("PLSPM_DEVICES", "").strip()
+    if not spec:
+        return None
+    return [int(tok) for tok in spec.replace(";", ",").split(",") if tok.strip() != ""]
+
+
+def devices_for(processes, replicates, first_device=0, devices=None):
+    """GPUs a single-process bootstrap uses.  ``devices`` (the ``Plspm(devices=[...])`` argument) or, without it, the
+    ``PLSPM_DEVICES`` allow-list names the candidates; ``processes`` (the reference's worker count, plspm.py:35-37) and
+    MIN_REPLICATES_PER_GPU cap how many of them are taken, in the order given, ``first_device`` always first.  With neither the
+    answer is ``[first_device]``: the reference's default ``processes=2`` alone never reaches for a second GPU.  Purely a
+    performance decision -- the rows are the same for every answer."""
     from plspm import _native
+    first = int(first_device)
+    candidates = list(devices) if devices is not None else allowed_devices()
+    if not candidates:
+        return [first]
     available = _native.device_count()
-    n = max(1, min(int(processes), available - int(first_device), int(replicates) // MIN_REPLICATES_PER_GPU))
-    return [int(first_device) + g for g in range(n)]
+    ordered = [first] + [int(d) for d in candidates if int(d) != first]
+    for d in ordered:
+        if not (0 <= d < available):
+            raise ValueError("device %d is not among the %d visible HIP devices" % (d, available))
+    n = max(1, min(int(processes), len(ordered), int(replicates) // MIN_REPLICATES_PER_GPU))
+    return ordered[:n]
 
 
 # ------------------------------------------------------------------------------------------------ one process per GPU
@@ -77,31 +98,53 @@ _context = None
 _rendezvous_seq = 0
 
 
+def _rendezvous_dir(directory):
+    """Directory of the id exchange: the caller's, ``PLSPM_RDZV_DIR``, or a per-user one under the temp dir created with mode 0700
+    (the id is a bearer token of the job's RCCL bootstrap: other local users must neither read it nor plant one)."""
+    directory = directory or os.environ.get("PLSPM_RDZV_DIR")
+    if directory:
+        return directory
+    directory = os.path.join(tempfile.gettempdir(), "plspm-rdzv-%d" % os.geteuid())
+    os.makedirs(directory, mode=0o700, exist_ok=True)
+    st = os.stat(directory)
+    if st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+        from plspm import _native
+        raise _native.NativeBackendError("rendezvous directory %s is not private to this user (owner %d, mode %o): set PLSPM_RDZV_DIR"
+                                         % (directory, st.st_uid, st.st_mode & 0o777))
+    return directory
+
+
 def _rendezvous_path(directory):
     global _rendezvous_seq
     _rendezvous_seq += 1
     tag = "%s-%s-%d-%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"), os.getppid(), _rendezvous_seq)
-    return os.path.join(directory or os.environ.get("PLSPM_RDZV_DIR") or tempfile.gettempdir(), "plspm-rdzv-" + tag)
+    return os.path.join(_rendezvous_dir(directory), "plspm-rdzv-" + tag)
 
 
 def exchange_unique_id(rank, world, directory=None, timeout=300.0, make_id=None):
     """Rank 0 draws the ncclUniqueId and publishes it through a file that the other ranks of the same launcher (same parent
-    process, same MASTER_ADDR/PORT) poll for: single-node rendezvous without a store service.  Every rank must call this the same
-    number of times (the file name carries a per-process sequence number).  ``make_id`` replaces ncclGetUniqueId (tests)."""
+    process, same MASTER_ADDR/PORT) poll for: single-node rendezvous without a store service.  The file lives in a directory private
+    to the user, is created exclusively with mode 0600, and a reader only accepts a file owned by its own user.  Every rank must call
+    this the same number of times (the file name carries a per-process sequence number).  ``make_id`` replaces ncclGetUniqueId (tests)."""
     from plspm import _native
     path = _rendezvous_path(directory)
     deadline = time.time() + timeout
     if rank == 0:
         uid = (make_id or _native.rccl_unique_id)()
         tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as fh:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)       # never through a name somebody else prepared
+        with os.fdopen(fd, "wb") as fh:
             fh.write(uid)
+        if os.path.lexists(path):
+            os.remove(tmp)
+            raise _native.NativeBackendError("rendezvous: %s already exists (a stale or foreign file): remove it or set PLSPM_RDZV_DIR" % path)
         os.replace(tmp, path)                      # atomic: a reader never sees a partial id
         acks = [path + ".ack%d" % r for r in range(1, world)]
         try:
             while not all(os.path.exists(a) for a in acks):          # every rank has the id: nothing of this exchange stays behind
                 if time.time() > deadline:
-                    raise _native.NativeBackendError("rendezvous: not every rank picked up %s within %.0f s" % (path, timeout))
+                    raise _native.NativeBackendError("rendezvous: not every rank picked up %s within %.0f s (ranks of one job must share "
+                                                     "the launcher's parent process and MASTER_ADDR / MASTER_PORT; single node only)" % (path, timeout))
                 time.sleep(0.002)
         finally:
             for name in [path] + acks:
@@ -113,6 +156,8 @@ def exchange_unique_id(rank, world, directory=None, timeout=300.0, make_id=None)
     while True:
         try:
             with open(path, "rb") as fh:
+                if os.fstat(fh.fileno()).st_uid != os.geteuid():
+                    raise _native.NativeBackendError("rendezvous: %s belongs to another user" % path)
                 uid = fh.read()
             if len(uid) == _native.UNIQUE_ID_BYTES:
                 open(path + ".ack%d" % rank, "wb").close()
@@ -120,7 +165,8 @@ def exchange_unique_id(rank, world, directory=None, timeout=300.0, make_id=None)
         except FileNotFoundError:
             pass
         if time.time() > deadline:
-            raise _native.NativeBackendError("rendezvous: rank 0 did not publish %s within %.0f s" % (path, timeout))
+            raise _native.NativeBackendError("rendezvous: rank 0 did not publish %s within %.0f s (ranks of one job must share the "
+                                             "launcher's parent process and MASTER_ADDR / MASTER_PORT; single node only)" % (path, timeout))
         time.sleep(0.002)
 
 
@@ -136,6 +182,11 @@ def init_process_group(rank=None, world_size=None, local_rank=None, rendezvous_d
     local = int(os.environ.get("LOCAL_RANK", str(rank)) if local_rank is None else local_rank)
     if not (0 <= rank < world):
         raise ValueError("rank %d outside world of %d" % (rank, world))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > local_world:
+        raise _native.NativeBackendError("WORLD_SIZE %d > LOCAL_WORLD_SIZE %d: the file rendezvous of plspm.parallel is single-node only "
+                                         "(north_star: the 8 GPUs of ONE node); hand every rank the ncclUniqueId yourself and build "
+                                         "NativeComm([local_rank], nranks, rank, unique_id) for a multi-node job" % (world, local_world))
     if local >= _native.device_count():
         raise _native.NativeBackendError("LOCAL_RANK %d but only %d HIP devices are visible" % (local, _native.device_count()))
     uid = exchange_unique_id(rank, world, rendezvous_dir, timeout)

@@ -1,9 +1,10 @@
 """``Plspm`` -- the user-facing estimator (reference plspm/plspm.py:26-169), MI355X backend.
 
 Same constructor arguments, clamps, assertions and accessors as the reference.  ``processes`` -- the reference's number of forked
-bootstrap workers (plspm.py:35-37, bootstrap.py:89-94) -- is the number of GPUs of this process the replicates are sharded
-over (capped by the visible devices and by ``parallel.MIN_REPLICATES_PER_GPU`` replicates per GPU; ONE RCCL all-gather merges
-the shards; the rows do not depend on it).  Two keyword extensions: ``seed`` (reproducible bootstrap) and ``device_id``.
+bootstrap workers (plspm.py:35-37, bootstrap.py:89-94) -- caps the number of GPUs of this process the replicates are sharded
+over once the caller NAMES GPUs (``devices=[...]`` or the ``PLSPM_DEVICES`` allow-list; also capped by
+``parallel.MIN_REPLICATES_PER_GPU`` replicates per GPU; ONE RCCL all-gather merges the shards; the rows do not depend on it).
+Without named GPUs everything runs on ``device_id``.  Keyword extensions: ``seed`` (reproducible bootstrap), ``device_id``, ``devices``.
 """
 import time
 
@@ -63,7 +64,7 @@ class Plspm:
 
     def __init__(self, data: pd.DataFrame, config: c.Config, scheme: Scheme = Scheme.CENTROID, iterations: int = 100,
                  tolerance: float = 0.000001, bootstrap: bool = False, bootstrap_iterations: int = 100, processes: int = 2,
-                 seed: int = None, device_id: int = 0):
+                 seed: int = None, device_id: int = 0, devices=None):
         iterations, bootstrap_iterations = _normalise_arguments(scheme, iterations, tolerance, bootstrap_iterations, processes)
         t_start = time.perf_counter()
         estimator = Estimator(config)
@@ -85,7 +86,7 @@ class Plspm:
                 pending = launch_replicatewise(self._replicate_runner(config, calculator, observations), n_obs, fit, bootstrap_iterations, seed)
             else:
                 boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
-                pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed)
+                pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed, devices=devices)
         self._result = fit
         # The report frames only re-label / post-process the device outputs already on the host (fit.raw); they are built on first
         # access (the reference builds them eagerly, plspm.py:69-77 -- same objects, same values, ~4 ms of pandas work per call that a

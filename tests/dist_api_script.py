@@ -28,7 +28,11 @@ m = Plspm(sat, cfg, Scheme.PATH, bootstrap=True, bootstrap_iterations=300, proce
           device_id=ctx.local_rank if ctx else 0)
 b = m.bootstrap()
 if ctx is not None:
-    assert b._group is not None and ctx.comm.uses_rccl, "the RCCL route was not taken"
+    assert b._via_group and b.ranks() == ctx.world and ctx.comm.uses_rccl, "the RCCL route was not taken"
+    # a SECOND live Plspm(bootstrap=True) of the same job while the first object is still referenced (the job's one
+    # communicator used to stay bound to the first object's group) -- same seed, same records
+    m2 = Plspm(sat, cfg, Scheme.PATH, bootstrap=True, bootstrap_iterations=300, processes=1, seed=11, device_id=ctx.local_rank)
+    assert m2.bootstrap()._via_group and (m2.bootstrap().replicates() == b.replicates()).all()
 if (ctx.rank if ctx else 0) == 0:
     print("RESULT " + json.dumps({"weights": b.weights().values.tolist(), "paths": b.paths().values.tolist(),
                                   "r2": b.r_squared().values.tolist(), "loading": b.loading().values.tolist(),
@@ -36,3 +40,5 @@ if (ctx.rank if ctx else 0) == 0:
                                   "rows_sum": float(b.replicates().sum())}))
 if ctx is not None:
     parallel.destroy_process_group()
+    # the lazy accessors outlive the process group: the records were adopted by the fit's handle (no use of a released group)
+    assert int(b.status().sum()) == 0 and b.replicate_iterations().shape == (300,)

@@ -199,16 +199,22 @@ def test_plspm_processes_shards_over_handles_with_identical_results(kind, monkey
             cfg.add_lv_with_columns_named(lv, Mode.A, sat, lv.lower())
         return Plspm(sat, cfg, Scheme.PATH, bootstrap=True, bootstrap_iterations=2400, processes=processes, seed=21).bootstrap()
     single = run(1)
-    assert single._group is None
-    monkeypatch.setattr(parallel, "devices_for", lambda processes, replicates, first_device=0: [0] * min(int(processes), 2))
+    assert single.ranks() == 1
+    assert run(2).ranks() == 1              # processes alone never reaches for a second GPU: sharding is opt-in (devices= / PLSPM_DEVICES)
+    monkeypatch.setattr(parallel, "devices_for", lambda processes, replicates, first_device=0, devices=None: [0] * min(int(processes), 2))
     double = run(2)
-    assert double._group is not None and len(double._helpers) == 1 and double._group.nranks == 2
+    # the gathered records were adopted by the fit's handle and the group is gone: the communicator is free for the next bootstrap
+    assert double.ranks() == 2 and double._group is None and double._helpers is None
+    comm = parallel.local_comm([0, 0])
+    assert not comm.busy()
     for name in ("weights", "r_squared", "total_effects", "paths", "loading"):
         a, b = getattr(single, name)(), getattr(double, name)()
         assert list(a.index) == list(b.index)
         np.testing.assert_array_equal(a.values, b.values, err_msg=name)
     assert np.array_equal(single.replicates(), double.replicates()) and single.used() == double.used() == 2400
-    # a second multi-GPU bootstrap while the first one's group still holds the cached communicator gets a communicator of its own
+    # a second multi-GPU bootstrap while the first object is alive re-uses the cached communicator (it used to be refused
+    # or to need a communicator of its own), and both objects still answer their lazy accessors
     again = run(2)
-    assert again._group is not None and again._group.comm is not double._group.comm and double._group.comm.busy()
+    assert again.ranks() == 2 and parallel.local_comm([0, 0]) is comm
     assert np.array_equal(again.replicates(), double.replicates())
+    assert np.array_equal(double.status(), single.status()) and np.array_equal(again.replicate_iterations(), single.replicate_iterations())

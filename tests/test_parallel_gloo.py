@@ -147,3 +147,54 @@ def test_unique_id_rendezvous_file_world3(tmp_path):
     mp.spawn(_rdzv_worker, args=(3, str(tmp_path), str(tmp_path)), nprocs=3, join=True)
     for rank in range(3):
         assert open(os.path.join(str(tmp_path), "uid_r%d" % rank), "rb").read() == b"\x01" * 128 + b"\x02" * 128
+
+
+def test_rendezvous_directory_is_private_and_id_file_exclusive(tmp_path, monkeypatch):
+    """the ncclUniqueId is a bearer token of the job's RCCL bootstrap.  Default directory: per user, mode 0700, refused when
+    somebody else could write into it; the id file is created exclusively (a planted / stale file is an error, not an id)."""
+    import stat
+    import tempfile
+    from plspm import _native
+    monkeypatch.delenv("PLSPM_RDZV_DIR", raising=False)
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    d = parallel._rendezvous_dir(None)
+    assert d.startswith(str(tmp_path)) and stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    os.chmod(d, 0o777)
+    with pytest.raises(_native.NativeBackendError, match="not private"):
+        parallel._rendezvous_dir(None)
+    os.chmod(d, 0o700)
+    # a file already sitting at rank 0's path: refused (O_EXCL semantics), and removed names do not linger
+    seq = parallel._rendezvous_seq
+    planted = parallel._rendezvous_path(None)
+    parallel._rendezvous_seq = seq
+    with open(planted, "wb") as fh:
+        fh.write(b"\x07" * 128)
+    with pytest.raises(_native.NativeBackendError, match="already exists"):
+        parallel.exchange_unique_id(0, 2, None, timeout=1.0, make_id=lambda: b"\x01" * 128)
+    assert open(planted, "rb").read() == b"\x07" * 128 and not [n for n in os.listdir(d) if ".tmp" in n]
+
+
+def test_multi_node_world_is_refused_with_a_clear_message(monkeypatch):
+    from plspm import _native
+    monkeypatch.setattr(parallel, "_context", None)
+    monkeypatch.setattr(_native, "device_count", lambda: 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    with pytest.raises(_native.NativeBackendError, match="single-node only"):
+        parallel.init_process_group(rank=3, world_size=16, local_rank=3)
+
+
+def test_multi_gpu_sharding_is_opt_in(monkeypatch):
+    """the reference's default processes=2 must not reach for device_id + 1.  GPUs are named by the caller (devices=) or by
+    PLSPM_DEVICES; processes and MIN_REPLICATES_PER_GPU cap how many are taken; the handle's own device always comes first."""
+    from plspm import _native
+    monkeypatch.setattr(_native, "device_count", lambda: 8)
+    monkeypatch.delenv("PLSPM_DEVICES", raising=False)
+    assert parallel.devices_for(2, 40000, 3) == [3]
+    assert parallel.devices_for(8, 40000, 0, devices=[4, 5, 0, 6]) == [0, 4, 5, 6]
+    assert parallel.devices_for(2, 40000, 5, devices=[4, 5, 6]) == [5, 4]
+    assert parallel.devices_for(8, 2500, 0, devices=range(8)) == [0, 1]            # 1,000 replicates per GPU at least
+    monkeypatch.setenv("PLSPM_DEVICES", "0,1,2,3,4,5,6,7")
+    assert parallel.devices_for(8, 40000, 0) == list(range(8))
+    assert parallel.devices_for(2, 40000, 6) == [6, 0]
+    with pytest.raises(ValueError, match="not among"):
+        parallel.devices_for(4, 40000, 0, devices=[0, 9])
