@@ -91,7 +91,10 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     the draws of the next call fill CUs the Gram / solver of this one leave idle (+-2 %: measured neutral)
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
- * plspm_model_get_option reads a value back; the read-only key "last_gram_path" tells which Gram the last bootstrap call took.
+ *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
+ *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
+ * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes) and "last_solver"
+ * (1 LDS solver, 2 rows solver, 3 wave solver) tell what the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value);

@@ -205,15 +205,20 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
 // higher measured ceiling, and 7 instead of 3 free issue slots behind every MFMA), blocks of 32 rows x 32 k (two per k-block: halves
 // h = 0, 1), every wave spans the workgroup's 32 pairs x S planes and 256 / NW replicates.  The 1 KB blocks a workgroup needs per
 // k-step are the same contiguous 16 + 2 S KB in both layouts; only the inside of a block differs (lane l's 16 bytes at 16 l in both).
-template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16>
+// RT: count tiles (16 replicates each) per workgroup -- 16 = 256 replicates (default); 12 / 8 = 192 / 128 replicates per workgroup, i.e. 6 / 4
+// accumulator rows per wave at four waves (168 / 112 accumulator registers instead of 224): the variants that leave half of a SIMD's
+// register file to a co-resident wave of another kernel (the solver of the previous batch on a second stream).
+template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16, int RT = 16>
 struct GramI8 {
+    static_assert(RT == 16 || SH == 16, "narrow workgroup tiles exist for the 16x16x64 layout only");
+    static_assert(RT % WM == 0, "whole count tiles per wave");
     static constexpr int NW = 2 * WM;               // waves per workgroup
-    static constexpr int MTW = 16 / WM;             // SH 16: count tiles (16 replicates) per wave
+    static constexpr int MTW = RT / WM;             // SH 16: count tiles (16 replicates) per wave
     static constexpr int T32W = 8 / NW;             // SH 32: count tiles (32 replicates) per wave
     static constexpr int NA = SH == 16 ? MTW : 2 * T32W;      // operand fragments (16 B per lane) per wave and k-step: counts ...
     static constexpr int NB = SH == 16 ? S : 2 * S;           // ... and digit planes
     static constexpr int NMFMA = SH == 16 ? MTW * S : 2 * T32W * S;
-    static constexpr int NBLK = 16 + 2 * S;         // 1 KB blocks per k-step: 16 count tiles + 2 pair groups x S planes
+    static constexpr int NBLK = RT + 2 * S;         // 1 KB blocks per k-step: RT count tiles + 2 pair groups x S planes
     static constexpr int PER = (NBLK + NW - 1) / NW;   // DMA instructions per wave and k-step
     static constexpr int STAGE_BYTES = NBLK * 1024;
     // VAR >= 18: ONE workgroup barrier per two k-steps on a ring of five stages (k-steps 2p+1 and 2p+2 have landed at the barrier of
@@ -235,11 +240,11 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ub), "s"(lds_dst) : "memory");
 }
 
-template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16>
-__global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2)))
+template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16, int RT = 16>
+__global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(RT < 16 ? 2 : WM / 2, RT < 16 ? 2 : WM / 2)))
 gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
                const int* __restrict__ pair_dst2, const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
-    using G = GramI8<S, WM, VAR, SH>;
+    using G = GramI8<S, WM, VAR, SH, RT>;
     constexpr int MTW = G::MTW, NA = G::NA, NB = G::NB;
     typedef int i32x16 __attribute__((ext_vector_type(16)));
     using AccT = typename std::conditional<SH == 16, i32x4, i32x16>::type;
@@ -269,8 +274,8 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
 #pragma unroll
     for (int i = 0; i < G::PER; ++i) {
         const int b = min(wave + G::NW * i, G::NBLK - 1);
-        const bool isA = b < 16;
-        src[i] = isA ? (const char*)(Cd + ((long)ty * 16 + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - 16)) * 64);
+        const bool isA = b < RT;
+        src[i] = isA ? (const char*)(Cd + ((long)ty * RT + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - RT)) * 64);
         inc[i] = (isA ? (long)MT : (long)NT) * 1024;
         dst[i] = lds0 + (unsigned)b * 1024u;
     }
@@ -298,7 +303,7 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
         for (int s = 0; s < S; ++s) acc[mt][s] = AccT{};
     // fragment a of the counts: SH 16 tile wm MTW + a; SH 32 (tile wm T32W + a / 2, half a % 2) -- consecutive blocks either way;
     // fragment b of the digits: SH 16 plane b of pair group wn; SH 32 (plane b / 2, half b % 2)
-    const unsigned fbaseA = voff + (unsigned)wm * (unsigned)(NA * 1024), fbaseB = voff + (unsigned)(16 + wn * S) * 1024u;
+    const unsigned fbaseA = voff + (unsigned)wm * (unsigned)(NA * 1024), fbaseB = voff + (unsigned)(RT + wn * S) * 1024u;
 #define GI8_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(off))
 #define GI8_MFMA16(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 #define GI8_MFMA32(c, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
@@ -412,7 +417,7 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
         }
     };
     if constexpr (SH == 16) {
-        const long rep0 = (long)ty * 256 + wm * (MTW * 16) + (lane >> 4) * 4;
+        const long rep0 = (long)ty * (16 * RT) + wm * (MTW * 16) + (lane >> 4) * 4;
         double* gp = gram + rep0 * psize + dstj;       // walks the replicates of this lane; opaque to the compiler so that it does not
 #pragma unroll                                         // precompute (and spill) 32 addresses
         for (int mt = 0; mt < MTW; ++mt) {

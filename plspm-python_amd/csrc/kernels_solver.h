@@ -228,6 +228,75 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PLSPM_R
 }
 
 
+// Wave variant (solver_wave.h solve_problem_wave): ONE wave per problem with fixed lane roles -- the bootstrap solver of metric Mode-A
+// models with at most 64 MVs and 8 LVs.  Executor = the rows executor + the wave primitives.
+struct DevWaveExec : DevExecT<4> {
+    // butterfly sum: every lane ends with bitwise the same value (a + b == b + a at every level)
+    __device__ __forceinline__ double allsum(double v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    }
+    __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }       // nothing that touches memory moves across
+    __device__ __forceinline__ void opaque(int& x) { asm volatile("" : "+v"(x)); }
+    __device__ __forceinline__ void opaque(unsigned& x) { asm volatile("" : "+v"(x)); }      // the optimiser may not look through x (no hoisting of what derives from it)
+    // ... and these eight values are complete at this point (a fence the arithmetic cannot sink below)
+    __device__ __forceinline__ void pin8(double& a, double& b, double& c, double& d, double& e, double& f, double& g, double& h) {
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
+    }
+    __device__ __forceinline__ int vote_count(bool b) { return __popcll(__ballot(b)); }
+    __device__ __forceinline__ bool vote_any(bool b) { return __ballot(b) != 0ull; }
+    // Column `lane` of the symmetric moment matrix out of its upper triangle (entry (r, c >= r) at r * PS + c), into s[0 .. 63].
+    //   A. row r across the lanes, r = 0 .. 63: lane c >= r reads M[r][c] -- coalesced 512-byte rows; lanes c < r re-read the diagonal
+    //      element (same line): register r of lane c is column c's entry r wherever r <= c.  (The rows solver read the other half as
+    //      a strided run per lane: 134 MB fetched for 75 MB of triangles, the load phase of 2,048 resident waves bound by the address
+    //      units -- 29 k clocks in the first round, profiles/r02c_pmc.md.)
+    //   B. the other half is the transpose, s_p[q] = s_q[p] for q > p: four passes of 16 registers through a [16][66]-double LDS tile
+    //      (written row-wise, one row per register; lane p of the pass's 16 lanes reads row p - 16 j: pitch 66 = conflict-free 8-byte
+    //      reads, 16-byte aligned rows).
+    // Rows / lanes >= P repeat valid entries (finite; the caller zeroes them).
+    template <int PMAX> __device__ __forceinline__ void load_cov(const double* __restrict__ Md, int PS, int P, double (&s)[PMAX], double* stage) {
+        static_assert(PMAX == 64, "one register per lane of the wave");
+        const int lane = tid, cl = min(lane, P - 1);
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const int rc = min(r, P - 1);
+            const unsigned off = (unsigned)(rc * PS + max(cl, rc)) * 8u;
+            s[r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[r * 66 + lane] = s[16 * j + r];
+            __syncthreads();
+            if ((lane >> 4) == j) {
+                const double* row = stage + (lane - 16 * j) * 66;
+#pragma unroll
+                for (int q = 16 * j + 1; q < 16 * (j + 1); ++q) s[q] = (q > lane) ? row[q] : s[q];
+#pragma unroll
+                for (int q = 16 * (j + 1); q < 64; ++q) s[q] = row[q];
+            }
+            __syncthreads();
+        }
+    }
+};
+
+template <int LMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_wave_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const long b = blockIdx.x;
+    WaveWs<LMAX> ws;
+    wave_carve(ws, reinterpret_cast<double*>(smem_raw));
+    FitOutputs out{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevWaveExec ex;
+    ex.tid = (int)threadIdx.x; ex.nt = 64; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
+    solve_problem_wave<LMAX>(ex, md, ws, Md + b * md_stride, out);
+}
+
+
 // Metric data with missing values: per problem, the Gram of [data | missing indicators | 1] -> mean-imputed moments of the P
 // data columns (solver_core.h impute_collapse).  One workgroup per problem.
 __global__ void __launch_bounds__(256) impute_kernel(int P, int Qa, int Ta, int Ts, const int* __restrict__ ind_of, const double* __restrict__ Min, long in_stride,

@@ -26,6 +26,7 @@
 #include "solver_hoc.h"
 #include "solver_nmx.h"
 #include "solver_ops.h"
+#include "solver_wave.h"
 
 using namespace plspm;
 
@@ -294,13 +295,14 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stage1) m->stage1->stage2 = nullptr;
     hipSetDevice(m->device);
     if (m->aux) hipStreamSynchronize(m->aux);
+    if (m->aux2) hipStreamSynchronize(m->aux2);
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->gramB.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -309,7 +311,9 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->h_flag) plspm_hfree(m->h_flag);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
     for (int k = 0; k < 2; ++k) { if (m->ev_counts[k]) hipEventDestroy(m->ev_counts[k]); if (m->ev_cdfree[k]) hipEventDestroy(m->ev_cdfree[k]); }
+    for (int k = 0; k < 2; ++k) { if (m->ev_gram[k]) hipEventDestroy(m->ev_gram[k]); if (m->ev_solved[k]) hipEventDestroy(m->ev_solved[k]); }
     if (m->aux) hipStreamDestroy(m->aux);                                   // (synchronised above; a low-priority stream of its own, not from the cache)
+    if (m->aux2) hipStreamDestroy(m->aux2);
     if (m->stream && m->owns_stream) plspm_stream_release(m->stream);       // (synchronised above)
     delete m;
 }
@@ -665,7 +669,10 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_slices") { if (value < 5 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
+    else if (k == "i8_rt") { if (value != 16 && value != 12 && value != 8) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
+    else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
+    else if (k == "solver_aux") { if (value < 0 || value > 3) return bad(); m->tune.solver_aux = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
@@ -690,7 +697,11 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_slices") *value = m->tune.i8_slices;
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
+    else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
+    else if (k == "solver_wave") *value = m->tune.solver_wave;
+    else if (k == "solver_aux") *value = m->tune.solver_aux;
+    else if (k == "last_solver") *value = m->last_solver;
     else if (k == "resample_aux") *value = m->tune.resample_aux;
     else if (k == "i8_sched") *value = m->tune.i8_sched;
     else if (k == "i8_shape") *value = m->tune.i8_shape;
@@ -833,6 +844,8 @@ int plspm_sync(plspm_model_t* m) {
     if (!m) return PLSPM_E_ARG;
     HIPCHK(m, hipSetDevice(m->device));
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
+    if (m->aux2) HIPCHK(m, hipStreamSynchronize(m->aux2));
     return 0;
 }
 
@@ -1010,7 +1023,10 @@ static int prepare_zs(plspm_model* m) {
 static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback) {
     *fallback = false;
     const int S = m->zs_S, KB = m->zs_KB, NT = m->zs_NT;
-    const int nty = (int)((nb + 255) / 256), MT = nty * 16, ntx = m->zs_npg / 2;
+    // workgroup tile of the product: 16 RT replicates x 32 pairs; narrow tiles (RT 12 / 8) only in the plain four-wave 16x16x64 launch
+    const bool narrow = m->tune.i8_rt != 16 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7;
+    const int RTg = narrow ? m->tune.i8_rt : 16;
+    const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = m->zs_npg / 2;
     const size_t hist_bytes = (size_t)KB * 32 * sizeof(unsigned);
     int rc;
     if ((rc = allow_lds(m, (const void*)resample_i8_kernel, hist_bytes))) return rc;
@@ -1028,7 +1044,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     // counts of this chunk: the buffer the Gram before last read; grown only with both streams idle
     const int slot = m->aux ? (m->cd_slot ^= 1) : 0;
     plspm_model::Buf& cd = slot ? m->cd1 : m->cd;
-    const size_t cd_bytes = (size_t)nty * 256 * ((size_t)KB + I8_SLACK_KB) * 64;
+    const size_t cd_bytes = (size_t)nty * 16 * RTg * ((size_t)KB + I8_SLACK_KB) * 64;
     if (cd_bytes > cd.cap) { if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux)); if ((rc = ensure(m, cd, cd_bytes))) return rc; m->cdfree_set[slot] = false; }
     if (!d_idx && m->aux) {
         // Philox draws: on the low-priority stream, as soon as the Gram that last read this buffer is done -- i.e. beside the Gram and the
@@ -1104,6 +1120,15 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         case 12: GI8V(7, WW, 12) break; case 18: GI8V(7, WW, 18) break; case 21: GI8V(7, WW, 21) break; case 24: GI8V(7, WW, 24) break; case 30: GI8V(7, WW, 30) break; default: GI8V(7, WW, 33) break; }
     if (S == 7 && m->tune.i8_variant >= 0) { if (m->tune.i8_waves == 4) GI8X(2) else GI8X(4) } else
 #endif
+#define GI8RT(RR)                                                                                                                            \
+    {                                                                                                                                        \
+        const size_t lds_bytes = GramI8<7, 2, I8_DEFAULT_VAR, 16, RR>::LDS_BYTES;                                                            \
+        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<7, 2, I8_DEFAULT_VAR, 16, RR>, lds_bytes))) return rc;                             \
+        hipLaunchKernelGGL((gram_i8_kernel<7, 2, I8_DEFAULT_VAR, 16, RR>), dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p, \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+    }
+    if (narrow) { if (RTg == 12) GI8RT(12) else GI8RT(8) } else
+#undef GI8RT_DUMMY
     if (m->tune.i8_shape == 32) {              // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
         switch (S) { case 5: GI8VS(5, 2, I8_DEFAULT_VAR, 32) break; case 6: GI8VS(6, 2, I8_DEFAULT_VAR, 32) break; case 7: GI8VS(7, 2, I8_DEFAULT_VAR, 32) break; default: GI8VS(8, 2, I8_DEFAULT_VAR, 32) break; }
     } else
@@ -1165,12 +1190,31 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if (want_dcnt && (rc = ensure(m, m->dcnt, (size_t)chunk * dcnt_stride * sizeof(unsigned short)))) return rc;
     m->dcnt_stride = dcnt_stride; m->dcnt_ready = want_dcnt;
     HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
+    // solver_aux: the solver of this call on a second stream, moment matrices double-buffered -- it runs beside the resample / Gram of the
+    // NEXT call (enqueued while it is still running)
+    const bool pipe = m->tune.solver_aux != 0 && rows_solver && !d_idx && chunk >= B && wave_solver_covers<8>(m->P, m->L, m->n_chol) && m->tune.solver_wave != 0;
+    int gslot = 0;
+    if (pipe) {
+        if (!m->aux2) {
+            int lo = 0, hi = 0;
+            HIPCHK(m, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(m, hipStreamCreateWithPriority(&m->aux2, hipStreamNonBlocking, m->tune.solver_aux == 2 ? 0 : (m->tune.solver_aux == 3 ? hi : lo)));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(m, hipEventCreateWithFlags(&m->ev_gram[k], hipEventDisableTiming));
+                HIPCHK(m, hipEventCreateWithFlags(&m->ev_solved[k], hipEventDisableTiming));
+            }
+        }
+        gslot = (m->gram_slot ^= 1);
+        if (gslot && (rc = ensure(m, m->gramB, (size_t)chunk * cov_doubles(m->Pg) * sizeof(double)))) return rc;
+        if (m->solved_set[gslot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_solved[gslot], 0));      // the solver of two calls ago has read this buffer
+    }
+    double* const gram_buf = (pipe && gslot) ? (double*)m->gramB.p : (double*)m->gram.p;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
         bool f64_gram = gpath == 1;
         if (gpath == 2) {
             bool fallback = false;
-            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, (double*)m->gram.p, rows_solver, &fallback))) return rc;
+            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback))) return rc;
             f64_gram = fallback;
         }
         if (f64_gram || m->nonmetric) {            // (row,count) lists (+ dense uint16 histograms): the same draws as the int8 counts
@@ -1228,7 +1272,23 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         long long* d_marks = nullptr;
         HIPCHK(m, plspm_dmalloc((void**)&d_marks, 32 * sizeof(long long))); so.marks = d_marks;
 #endif
-        if (rows_solver && !f64_gram) {
+        if (rows_solver && !f64_gram && m->tune.solver_wave != 0 && wave_solver_covers<8>(m->P, m->L, m->n_chol)) {
+            // one wave per problem with fixed lane roles (solver_wave.h): Mode-A models of at most 64 MVs and 8 LVs
+            const size_t lds = (size_t)wave_ws_doubles<8>() * sizeof(double);
+            hipStream_t ss = m->stream;
+            if (pipe) {
+                HIPCHK(m, hipEventRecord(m->ev_gram[gslot], m->stream));
+                HIPCHK(m, hipStreamWaitEvent(m->aux2, m->ev_gram[gslot], 0));
+                ss = m->aux2;
+            }
+            {
+                ProfScope ps(m, PLSPM_K_SOLVER, ss);
+                hipLaunchKernelGGL(solver_wave_kernel<8>, dim3((unsigned)nb), dim3(64), lds, ss, make_desc(m), (const double*)gram_buf, (long)cov_doubles(m->Pg), so);
+            }
+            if (pipe) { HIPCHK(m, hipEventRecord(m->ev_solved[gslot], m->aux2)); m->solved_set[gslot] = true; }
+            m->last_solver = 3;
+        } else if (rows_solver && !f64_gram) {
+            m->last_solver = 2;
             const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
             if ((rc = allow_lds(m, (const void*)solver_rows_kernel, lds))) return rc;
             ProfScope ps(m, PLSPM_K_SOLVER);
@@ -1237,6 +1297,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             const double* Mp; long mp_stride;
             if ((rc = run_impute(m, nb, (const double*)m->gram.p, &Mp, &mp_stride))) return rc;
             ProfScope ps(m, PLSPM_K_SOLVER);
+            m->last_solver = 1;
             if ((rc = launch_solver(m, nb, Mp, mp_stride, so, m->tune.solver_threads))) return rc;
         }
 #ifdef PLSPM_DEBUG_MARKS
@@ -1244,12 +1305,19 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             long long h[32];
             HIPCHK(m, hipStreamSynchronize(m->stream));
             HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
+            if (m->last_solver == 3) {
+                fprintf(stderr, "[plspm wave clocks] load %lld  treat %lld  init %lld  iterations %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
+                        h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[13] - h[7], h[13] - h[0]);
+                fprintf(stderr, "[plspm wave last iterate] apply_cov %lld  a/G/E %lld  regress %lld  outer+conv %lld\n", h[9] - h[8], h[10] - h[9], h[11] - h[10], h[12] - h[11]);
+                fprintf(stderr, "[plspm wave last apply_cov] seg_products+T %lld  sync %lld  Q %lld\n", h[17] - h[16], h[18] - h[17], h[19] - h[18]);
+            } else {
             fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
             fprintf(stderr, "[plspm cov] sweep %lld  scale-factor %lld  centre+sd %lld\n", h[14] - h[0], h[15] - h[14], h[1] - h[15]);
             fprintf(stderr, "[plspm last iterate] apply_cov %lld  a+G %lld  inner_weights %lld  outer %lld  conv+copy %lld\n", h[9] - h[8], h[10] - h[9],
                     h[11] - h[10], h[12] - h[11], h[13] - h[12]);
             fprintf(stderr, "[plspm last apply_cov] block products %lld  Q %lld\n", h[17] - h[16], h[18] - h[17]);
+            }
             plspm_dfree(d_marks);
         }
 #endif

@@ -13,6 +13,7 @@
 #include "../../plspm-python_amd/csrc/solver_hoc.h"
 #include "../../plspm-python_amd/csrc/solver_nmx.h"
 #include "../../plspm-python_amd/csrc/solver_ops.h"
+#include "../../plspm-python_amd/csrc/solver_wave.h"
 
 using namespace plspm;
 
@@ -52,6 +53,35 @@ struct HostExec {
         for (int k = 0; k < nt; ++k) t += red[k];
         bar->arrive_and_wait();
         return t;
+    }
+    // ---- wave executor of solver_wave.h (nt == 64: one emulated thread per lane) ----
+    // butterfly sum in the device's order (v += shfl_xor(v, 32), 16, ... 1): bitwise the same value on every lane
+    double allsum(double v) {
+        for (int off = 32; off > 0; off >>= 1) {
+            red[tid] = v;
+            bar->arrive_and_wait();
+            const double t = red[tid ^ off];
+            bar->arrive_and_wait();
+            v += t;
+        }
+        return v;
+    }
+    int vote_count(bool b) {
+        red[tid] = b ? 1.0 : 0.0;
+        bar->arrive_and_wait();
+        int c = 0;
+        for (int k = 0; k < nt; ++k) c += red[k] != 0.0 ? 1 : 0;
+        bar->arrive_and_wait();
+        return c;
+    }
+    bool vote_any(bool b) { return vote_count(b) > 0; }
+    void fence() {}
+    void opaque(unsigned&) {}
+    void opaque(int&) {}
+    void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
+    // column `tid` of the symmetric moment matrix out of its upper triangle (device: coalesced rows + an LDS transpose)
+    template <int PMAX> void load_cov(const double* Md, int PS, int P, double (&s)[PMAX], double*) {
+        for (int q = 0; q < PMAX; ++q) s[q] = (q < P && tid < P) ? Md[(long)(q < tid ? q : tid) * PS + (q < tid ? tid : q)] : 0.0;
     }
     template <class F> bool any(int n, F f) {
         double s = 0.0;
@@ -295,6 +325,29 @@ int hostemu_solve_rows(int P, int L, int PA, int scheme, int scaled, int max_ite
             carve_small(ws, small.data(), P, L, em.md.kmax, em.md.n_chol);
             HostExec ex{t, nthreads, &bar, red.data()};
             solve_problem_rows<64>(ex, em.md, ws, Md, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+// Wave solver (solver_wave.h solve_problem_wave<8>): same inputs as the rows variant, 64 emulated lanes; returns 1 for a model it does not cover.
+int hostemu_solve_wave(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                       const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                       double* row, int* iters, int* status) {
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    if (!wave_solver_covers<8>(P, L, em.md.n_chol)) return 1;
+    const int nthreads = 64;
+    std::vector<double> lds(wave_ws_doubles<8>(), 0.0), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            WaveWs<8> ws{};
+            wave_carve(ws, lds.data());
+            HostExec ex{t, nthreads, &bar, red.data()};
+            solve_problem_wave<8>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;
