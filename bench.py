@@ -37,6 +37,7 @@ N_OBS, MVS_PER_LV, N_LV = 10000, 10, 6
 REPS_PER_GPU = 5000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet fp64 matrix; 77.9 TF measured with v_mfma_f64_16x16x4_f64 (tools/ubench)
+I8_MFMA_MEASURED_CEILING_TOPS = 3944.0   # MI355X_MICROARCH.md, matrix-core table: a pure v_mfma_i32_16x16x64_i8 stream on this chip (power-limited clock)
 I8_MFMA_PEAK_TOPS = 5033.0     # dense int8 matrix peak: 1,024 SIMDs x 2,048 ops/clk x 2.4 GHz = 2 x the ~2.5 PF bf16 dense peak of
                                # MI355X_MICROARCH.md (its table has no int8 spec entry; measured ceilings there: 3,944 TOP/s with
                                # 16x16x64, 4,404 with 32x32x32)
@@ -168,6 +169,7 @@ def api_inclusive(X, reps, pairs=7):
     for k in range(pairs + 2):
         h = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(N_LV, dtype=np.int32), 2, True, 100, 1e-6, 0)
         h.upload(X)
+        h.prepare_bootstrap()                        # as Plspm(bootstrap=True) does behind its upload: the digit planes are built beside the fit
         h.fit(want_scores=True, want_cov=True)
         t0 = time.perf_counter()
         h.bootstrap_device(reps, seed=1)
@@ -184,8 +186,8 @@ def api_inclusive(X, reps, pairs=7):
             "replicates_used": int(used),
             "note": "paired_difference_ms = median over %d pairs of [wall of Plspm(bootstrap=True, bootstrap_iterations=%d)] - [wall of Plspm()] (the replicates "
                     "are enqueued right after the fit; the pandas report frames are built on access); bootstrap_tail_ms / bootstrap_latency_ms = Plspm.timings(); "
-                    "standalone_ms = the same bootstrap on a fresh handle, nothing overlapped (enqueue -> kernels -> device summaries -> %d x 6 table on "
-                    "the host); value = replicates / max(paired_difference_ms, standalone_ms); rows stay in HBM" % (pairs, reps, 156)}
+                    "standalone_ms = the same bootstrap on a fresh handle behind upload + plspm_bootstrap_prepare + fit, nothing overlapped (enqueue -> "
+                    "kernels -> device summaries -> %d x 6 table on the host); value = replicates / max(paired_difference_ms, standalone_ms); rows stay in HBM" % (pairs, reps, 156)}
 
 
 def main():
@@ -229,6 +231,17 @@ def main():
     models = [make_model(d) for d in devices]
     model = models[0]
     group = _native.NativeGroup(comm, models) if comm is not None else None
+    # a multi-GPU run validates itself: the communicator really spans --gpus ranks, on distinct devices the records travel through
+    # RCCL (never the same-device copy route of the 1-GPU test box), and the shards partition the replicate range
+    transport, ranks_seen, shards = "none", 1, [[0, args.reps_per_gpu * world]]
+    if group is not None:
+        ranks_seen = int(comm.nranks)
+        assert ranks_seen == world == group.nranks, "communicator spans %d ranks, group %d, --gpus %d" % (ranks_seen, group.nranks, world)
+        transport = "rccl" if comm.uses_rccl else "device-copies"
+        if world > 1 and not comm.uses_rccl:
+            raise SystemExit("bench: %d ranks but the records would travel by device-to-device copies (ranks share a device): not a multi-GPU run" % world)
+        shards = [list(group.shard(args.reps_per_gpu * world, r)) for r in range(world)]
+        assert shards[0][0] == 0 and all(shards[r][0] + shards[r][1] == (shards[r + 1][0] if r + 1 < world else args.reps_per_gpu * world) for r in range(world)), shards
     B_total = args.reps_per_gpu * world
     width = model.row_width
     state = {"k": 0}
@@ -250,6 +263,18 @@ def main():
             group.sync()                                       # this process's kernel and gather streams
             group.barrier()                                    # every rank of the job (all-reduce of one word over RCCL)
 
+    # cold figure: the W warm-up steps and K timed steps straight after the upload, BEFORE the spin-up below -- what the driver's
+    # --warmup alone buys (reported beside `value`; every rank makes the same calls)
+    for _ in range(args.warmup):
+        step()
+    fence()
+    cold_t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    cold_elapsed = time.perf_counter() - cold_t0
+    if group is not None:
+        cold_elapsed = group.max(cold_elapsed)
     # spin-up: the first ~30 steps after an idle period run 4-5 % slower (0.666 against 0.637 ms per step with 5 against 50 warm-up
     # steps: clocks / power state), and W is the driver's choice -- so the device is brought to its working state with SPINUP_STEPS
     # of the same launches before the W warm-up steps; nothing of it is reused by the timed steps (fresh replicate ids)
@@ -366,8 +391,17 @@ def main():
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
             traffic, traffic_src = (live, live_src) if live else static_traffic(("r02c_gram_i8_traffic.json", "r02_gram_i8_traffic.json"))
+            # what the launch executes: whole tiles of 256 replicates x 64 rows x 32 pairs (= SQ_INSTS_VALU_MFMA_MOPS_I8 x 512 of the PMC passes
+            # in profiles/)
+            k_rows = ((N_OBS + 127) // 128) * 128
+            executed = 2.0 * (((reps_per_launch + 255) // 256) * 256) * k_rows * (((npair + 31) // 32) * 32) * slices
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4),
+                        "frac_of_measured_ceiling": round(achieved / I8_MFMA_MEASURED_CEILING_TOPS, 4),
+                        "measured_ceiling": {"value": I8_MFMA_MEASURED_CEILING_TOPS, "unit": "TOP/s",
+                                             "source": "MI355X_MICROARCH.md matrix-core table (I8, 16x16x64 micro-benchmark); the nominal peak is 2 x the bf16 dense spec"},
+                        "executed_ops": executed, "executed_over_algorithmic": round(executed / (ops_rep * reps_per_launch), 4),
+                        "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "gram_i8_kernel<%d, %d, 3, %d>" % (slices, model.get_option("i8_waves") // 2, model.get_option("i8_shape")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",
                         "algorithmic_ops_per_replicate": ops_rep,
@@ -422,9 +456,12 @@ def main():
                                    "(BASELINE.json configs[2]; %d GPUs x %d = configs[3] at 8); on-device Philox resampling, a fresh replicate-id "
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
-                       "parallelism": parallelism, "transport": ("rccl" if (comm is not None and comm.uses_rccl) else "none")},
+                       "parallelism": parallelism, "transport": transport, "ranks_seen_by_rccl": ranks_seen if transport == "rccl" else 0,
+                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>"}.get(model.get_option("last_solver"), "?")},
             "roofline": roofline,
             "spinup": "%d untimed steps (%.2f s) of the same launches before the %d warm-up steps: brings the device to its working clocks" % (spin_steps, spin_s, args.warmup),
+            "cold": {"value": round(B_total * args.steps / cold_elapsed, 1), "unit": "replicates/s", "ms_per_step": round(cold_elapsed / args.steps * 1e3, 4),
+                     "note": "the same %d timed steps behind %d warm-up steps only, measured before the spin-up (device coming out of idle)" % (args.steps, args.warmup)},
             "kernels_ms_per_step": {"resample": round(res_ms / max(res_n, 1), 4), "gram": round(gram_avg_ms, 4),
                                     "solver": round(sol_ms / max(sol_n, 1), 4)},
         }

@@ -50,7 +50,7 @@ enum {
 enum { PLSPM_E_ARG = 100, PLSPM_E_STATE = 101, PLSPM_E_LIMIT = 102 };
 
 /* ABI version of this header; plspm_abi_version() of the loaded library must match. */
-#define PLSPM_ABI_VERSION 2
+#define PLSPM_ABI_VERSION 3
 int plspm_abi_version(void);
 
 /* Number of HIP devices visible to the process (0 when there is none; never negative). */
@@ -74,8 +74,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
  *   "scores_tile"     0 (by LDS footprint) | 16 | 32   rows per tile of the scores kernel
  *   "gram_path"       0 auto | 1 fp64 MFMA Gram over (row,count) lists | 2 int8 digit-plane Gram (exact integer product of the dense
- *                     multiplicities with the base-256 digit planes of the pair products x_p x_q; bootstrap of metric models whose
- *                     planes fit the memory budget, N <= 65,535; other models always take path 1)
+ *                     multiplicities with the base-256 digit planes of the pair products x_p x_q; every bootstrap whose planes fit
+ *                     the memory budget: N < 2^24 rows (int32 sums), non-metric models N <= 65,535; second stages of HOC pairs take path 1)
  *   "i8_slices"       5 .. 8   digit planes per pair product (default 7: >= 53 significant bits of the column maximum)
  *   "i8_min_batch"    auto mode takes the int8 path from this many replicates per call (default 1: always -- the path must not
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
@@ -91,6 +91,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     the draws of the next call fill CUs the Gram / solver of this one leave idle (+-2 %: measured neutral)
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
+ *   "i8_rt"           16 (default) | 8   count tiles (16 replicates each) per workgroup of the int8 Gram: 256 or 128 replicates x 32 pairs
+ *                     (128: half the accumulator registers, two workgroups per CU; measured 2.6 % slower -- kept for co-scheduling experiments)
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes) and "last_solver"
@@ -250,6 +252,10 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
 int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out,
                            void** d_status, void** d_iters);
 int plspm_sync(plspm_model_t* m);
+/* Enqueue now what the first bootstrap call on the uploaded data would have to build before its first replicate (the int8 digit planes
+ * of the pair products, ~0.1 ms at 10k x 60): a host that knows a bootstrap follows the fit (Plspm(bootstrap=True): plspm.py:78-82 calls
+ * Bootstrap right behind the estimate) calls this after plspm_upload, so that the planes are built beside the fit.  Optional. */
+int plspm_bootstrap_prepare(plspm_model_t* m);
 /* Host copy of replicates [first, first + count) of the LAST plspm_bootstrap(_device) call on this handle, whose records are still
  * in HBM: out [count*R], status / iters [count] (each may be NULL).  Lets a caller keep the rows on the device (summaries:
  * plspm_bootstrap_summary) and pay for the PCIe transfer only when individual replicates are asked for.  PLSPM_E_STATE when the

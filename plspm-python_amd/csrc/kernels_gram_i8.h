@@ -126,24 +126,31 @@ __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- resample -> dense int8 counts
-// One workgroup per replicate, the same Philox draws / explicit indices and the same 16-bit LDS histogram as resample_kernel; the
-// histogram leaves as bytes in fragment-major layout (16 consecutive rows = one 16-byte piece).  err bit 0: index out of range,
-// bit 1: a multiplicity above 127 (only possible with explicit indices; the host then falls back to the fp64 Gram).
+// One workgroup per (replicate, window of I8_HIST_KB k-blocks = 65,536 rows), the same Philox draws / explicit indices and the same
+// 16-bit LDS histogram as resample_kernel; the histogram leaves as bytes in fragment-major layout (16 consecutive rows = one 16-byte
+// piece).  Data sets of more than 65,536 rows take several windows per replicate (blockIdx.y): every window's workgroup walks ALL N draws
+// of the replicate and counts the ones that fall into its rows -- the draws are regenerated from the counter-based stream, nothing is
+// exchanged between the windows (N = 100,000: two windows, the Philox work of the kernel doubles; the product behind it is 10 x larger
+// than at N = 10,000 anyway).  err bit 0: index out of range, bit 1: a multiplicity above 127 (only possible with explicit indices; the
+// host then falls back to the fp64 Gram).
+#define I8_HIST_KB 1024
 __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT, int shape, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
                                                            int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KB * 32 words: rows 2w, 2w+1 in the halves of word w (zero beyond N)
+    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KBw * 32 words: rows 2w, 2w+1 of the window in the halves of word w (zero beyond N)
     const int tid = threadIdx.x;
     const long b = blockIdx.x;
-    const int nwords = KB * 32;
+    const int kb0 = (int)blockIdx.y * I8_HIST_KB, KBw = min(I8_HIST_KB, KB - kb0);
+    const unsigned r0 = (unsigned)kb0 * 64u, rspan = (unsigned)KBw * 64u;      // this window's rows [r0, r0 + rspan)
+    const int nwords = KBw * 32;
     for (int i = tid; i < nwords; i += 256) hist[i] = 0u;
     __syncthreads();
     if (idx) {
         const int* my = idx + b * (long)N;
         for (int i = tid; i < N; i += 256) {
             const int r = my[i];
-            if ((unsigned)r < (unsigned)N) atomicAdd(&hist[r >> 1], (r & 1) ? 0x10000u : 1u);
-            else atomicOr(err, 1);
+            if ((unsigned)r < (unsigned)N) { const unsigned w = (unsigned)r - r0; if (w < rspan) atomicAdd(&hist[w >> 1], (w & 1u) ? 0x10000u : 1u); }
+            else if (blockIdx.y == 0) atomicOr(err, 1);
         }
     } else {
         const uint64_t rep = (uint64_t)(rep0 + b);
@@ -152,14 +159,14 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
             const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * q + j < N) { const unsigned r = to_index(u.v[j], (uint32_t)N); atomicAdd(&hist[r >> 1], (r & 1u) ? 0x10000u : 1u); }
+                if (4 * q + j < N) { const unsigned w = to_index(u.v[j], (uint32_t)N) - r0; if (w < rspan) atomicAdd(&hist[w >> 1], (w & 1u) ? 0x10000u : 1u); }
         }
     }
     __syncthreads();
     const int mt = (int)(b >> 4), r = (int)(b & 15);
     const uint4* h4 = reinterpret_cast<const uint4*>(hist);
     bool over = false;
-    for (int c = tid; c < KB * 4; c += 256) {                      // piece c: rows 16c .. 16c+15 = hist words 8c .. 8c+7
+    for (int c = tid; c < KBw * 4; c += 256) {                     // piece c: rows 16c .. 16c+15 of the window = hist words 8c .. 8c+7
         const uint4 lo = h4[2 * c], hi = h4[2 * c + 1];
         const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         unsigned o[4];
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
         }
         uint4 out;
         out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
-        const int kb = c >> 2, g = c & 3;
+        const int kb = kb0 + (c >> 2), g = c & 3;
         if (shape == 16) Cd[((long)kb * MT + mt) * 64 + g * 16 + r] = out;
         else Cd[((long)kb * MT + (b >> 5) * 2 + (g >> 1)) * 64 + (g & 1) * 32 + (int)(b & 31)] = out;       // block (tile of 32, half g / 2), piece (g % 2) 32 + row
     }

@@ -295,14 +295,13 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stage1) m->stage1->stage2 = nullptr;
     hipSetDevice(m->device);
     if (m->aux) hipStreamSynchronize(m->aux);
-    if (m->aux2) hipStreamSynchronize(m->aux2);
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->gramB.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -311,9 +310,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->h_flag) plspm_hfree(m->h_flag);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
     for (int k = 0; k < 2; ++k) { if (m->ev_counts[k]) hipEventDestroy(m->ev_counts[k]); if (m->ev_cdfree[k]) hipEventDestroy(m->ev_cdfree[k]); }
-    for (int k = 0; k < 2; ++k) { if (m->ev_gram[k]) hipEventDestroy(m->ev_gram[k]); if (m->ev_solved[k]) hipEventDestroy(m->ev_solved[k]); }
     if (m->aux) hipStreamDestroy(m->aux);                                   // (synchronised above; a low-priority stream of its own, not from the cache)
-    if (m->aux2) hipStreamDestroy(m->aux2);
     if (m->stream && m->owns_stream) plspm_stream_release(m->stream);       // (synchronised above)
     delete m;
 }
@@ -669,10 +666,9 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_slices") { if (value < 5 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
-    else if (k == "i8_rt") { if (value != 16 && value != 12 && value != 8) return bad(); m->tune.i8_rt = value; }
+    else if (k == "i8_rt") { if (value != 16 && value != 8) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
-    else if (k == "solver_aux") { if (value < 0 || value > 3) return bad(); m->tune.solver_aux = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
@@ -700,7 +696,6 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
     else if (k == "solver_wave") *value = m->tune.solver_wave;
-    else if (k == "solver_aux") *value = m->tune.solver_aux;
     else if (k == "last_solver") *value = m->last_solver;
     else if (k == "resample_aux") *value = m->tune.resample_aux;
     else if (k == "i8_sched") *value = m->tune.i8_sched;
@@ -845,7 +840,6 @@ int plspm_sync(plspm_model_t* m) {
     HIPCHK(m, hipSetDevice(m->device));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
-    if (m->aux2) HIPCHK(m, hipStreamSynchronize(m->aux2));
     return 0;
 }
 
@@ -966,7 +960,10 @@ static int choose_gram_path(const plspm_model* m, int64_t B) {
     // every model's replicates start from the moment matrix of the uploaded columns (metric, mean-imputed, non-metric, categorical
     // indicator columns, incomplete rows zeroed, first stage of a HOC pair).  The LDS histogram bounds N; int32 accumulators need
     // 128 N < 2^31.
-    if (m->stage1 || m->N > 65535 || m->N < 2) return 1;
+    // (int32 accumulators: |sum_i c_bi d_is| <= 128 sum_i c_bi = 128 N < 2^31, i.e. N < 2^24; the resample counts come from an LDS
+    // histogram of 65,536 rows per workgroup, larger data sets take several windows per replicate)
+    if (m->stage1 || m->N >= (1 << 24) || m->N < 2) return 1;
+    if (m->nonmetric && m->N > 65535) return 1;             // (their stop-rule passes want the dense uint16 histograms of the LDS-histogram resample)
     const size_t zs_bytes = (size_t)(i8_kblocks(m->N) + I8_SLACK_KB) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * m->tune.i8_slices) * 1024;
     if (zs_bytes > kZsBudget) return 1;
     if (m->tune.gram_path == 2) return 2;
@@ -1027,7 +1024,8 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const bool narrow = m->tune.i8_rt != 16 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7;
     const int RTg = narrow ? m->tune.i8_rt : 16;
     const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = m->zs_npg / 2;
-    const size_t hist_bytes = (size_t)KB * 32 * sizeof(unsigned);
+    const size_t hist_bytes = (size_t)std::min(KB, I8_HIST_KB) * 32 * sizeof(unsigned);
+    const unsigned hist_windows = (unsigned)((KB + I8_HIST_KB - 1) / I8_HIST_KB);      // 65,536 rows of 16-bit counters per workgroup
     int rc;
     if ((rc = allow_lds(m, (const void*)resample_i8_kernel, hist_bytes))) return rc;
     if (m->tune.resample_aux && !m->aux) {
@@ -1052,7 +1050,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         if (m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->aux, m->ev_cdfree[slot], 0));
         {
             ProfScope ps(m, PLSPM_K_RESAMPLE, m->aux);
-            hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
+            hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
         }
         HIPCHK(m, hipEventRecord(m->ev_counts[slot], m->aux));
         HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_counts[slot], 0));
@@ -1060,7 +1058,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         // explicit index lists (test / parity seam) arrive on the main stream: drawn there, and the host looks at the flag
         if (m->aux && m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_cdfree[slot], 0));
         ProfScope ps(m, PLSPM_K_RESAMPLE);
-        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
+        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
     }
     if (d_idx) {
         int* h_err = (int*)m->h_flag + 9;
@@ -1127,7 +1125,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         hipLaunchKernelGGL((gram_i8_kernel<7, 2, I8_DEFAULT_VAR, 16, RR>), dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p, \
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
     }
-    if (narrow) { if (RTg == 12) GI8RT(12) else GI8RT(8) } else
+    if (narrow) GI8RT(8) else
 #undef GI8RT_DUMMY
     if (m->tune.i8_shape == 32) {              // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
         switch (S) { case 5: GI8VS(5, 2, I8_DEFAULT_VAR, 32) break; case 6: GI8VS(6, 2, I8_DEFAULT_VAR, 32) break; case 7: GI8VS(7, 2, I8_DEFAULT_VAR, 32) break; default: GI8VS(8, 2, I8_DEFAULT_VAR, 32) break; }
@@ -1190,25 +1188,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if (want_dcnt && (rc = ensure(m, m->dcnt, (size_t)chunk * dcnt_stride * sizeof(unsigned short)))) return rc;
     m->dcnt_stride = dcnt_stride; m->dcnt_ready = want_dcnt;
     HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
-    // solver_aux: the solver of this call on a second stream, moment matrices double-buffered -- it runs beside the resample / Gram of the
-    // NEXT call (enqueued while it is still running)
-    const bool pipe = m->tune.solver_aux != 0 && rows_solver && !d_idx && chunk >= B && wave_solver_covers<8>(m->P, m->L, m->n_chol) && m->tune.solver_wave != 0;
-    int gslot = 0;
-    if (pipe) {
-        if (!m->aux2) {
-            int lo = 0, hi = 0;
-            HIPCHK(m, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPCHK(m, hipStreamCreateWithPriority(&m->aux2, hipStreamNonBlocking, m->tune.solver_aux == 2 ? 0 : (m->tune.solver_aux == 3 ? hi : lo)));
-            for (int k = 0; k < 2; ++k) {
-                HIPCHK(m, hipEventCreateWithFlags(&m->ev_gram[k], hipEventDisableTiming));
-                HIPCHK(m, hipEventCreateWithFlags(&m->ev_solved[k], hipEventDisableTiming));
-            }
-        }
-        gslot = (m->gram_slot ^= 1);
-        if (gslot && (rc = ensure(m, m->gramB, (size_t)chunk * cov_doubles(m->Pg) * sizeof(double)))) return rc;
-        if (m->solved_set[gslot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_solved[gslot], 0));      // the solver of two calls ago has read this buffer
-    }
-    double* const gram_buf = (pipe && gslot) ? (double*)m->gramB.p : (double*)m->gram.p;
+    double* const gram_buf = (double*)m->gram.p;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
         bool f64_gram = gpath == 1;
@@ -1275,17 +1255,8 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         if (rows_solver && !f64_gram && m->tune.solver_wave != 0 && wave_solver_covers<8>(m->P, m->L, m->n_chol)) {
             // one wave per problem with fixed lane roles (solver_wave.h): Mode-A models of at most 64 MVs and 8 LVs
             const size_t lds = (size_t)wave_ws_doubles<8>() * sizeof(double);
-            hipStream_t ss = m->stream;
-            if (pipe) {
-                HIPCHK(m, hipEventRecord(m->ev_gram[gslot], m->stream));
-                HIPCHK(m, hipStreamWaitEvent(m->aux2, m->ev_gram[gslot], 0));
-                ss = m->aux2;
-            }
-            {
-                ProfScope ps(m, PLSPM_K_SOLVER, ss);
-                hipLaunchKernelGGL(solver_wave_kernel<8>, dim3((unsigned)nb), dim3(64), lds, ss, make_desc(m), (const double*)gram_buf, (long)cov_doubles(m->Pg), so);
-            }
-            if (pipe) { HIPCHK(m, hipEventRecord(m->ev_solved[gslot], m->aux2)); m->solved_set[gslot] = true; }
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipLaunchKernelGGL(solver_wave_kernel<8>, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), (const double*)gram_buf, (long)cov_doubles(m->Pg), so);
             m->last_solver = 3;
         } else if (rows_solver && !f64_gram) {
             m->last_solver = 2;
@@ -1328,6 +1299,16 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
 }
 
 extern "C" {
+
+int plspm_bootstrap_prepare(plspm_model_t* m) {
+    if (!m) return PLSPM_E_ARG;
+    if (!m->d_Xa || m->N < 2) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_prepare: no data uploaded");
+    HIPCHK(m, hipSetDevice(m->device));
+    // what the first bootstrap call on this data would build before its first replicate: the digit planes of the pair products
+    // (enqueue only; a model that takes the fp64 Gram has nothing to prepare)
+    if (choose_gram_path(m, (int64_t)1 << 20) == 2) return prepare_zs(m);
+    return 0;
+}
 
 int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out, void** d_status,
                            void** d_iters) {

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLSPM_HIP_LIB", os.path.join(_HERE, "_lib", "libplspm_hip.so"))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
@@ -22,7 +22,7 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset",
            "plspm_model_set_option", "plspm_model_get_option", "plspm_bootstrap_moments", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
-           "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt",
+           "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt", "plspm_bootstrap_prepare",
            "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
            "plspm_op_inner_weights", "plspm_op_outer_weights"]
 UNIQUE_ID_BYTES = 128
@@ -102,6 +102,7 @@ def load():
     lib.plspm_bootstrap_fetch.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.plspm_bootstrap_moments.argtypes = [vp, i64, u64, i64, vp, vp]
     lib.plspm_bootstrap_store.argtypes = [vp, vp, i64]
+    lib.plspm_bootstrap_prepare.argtypes = [vp]
     lib.plspm_rccl_unique_id.argtypes = [vp]
     lib.plspm_comm_create.restype = vp
     lib.plspm_comm_create.argtypes = [vp, i32, i32, i32, vp]
@@ -285,6 +286,10 @@ class NativeModel:
         out = np.empty((B, C, C))
         self._check(self._lib.plspm_bootstrap_moments(self._h, B, seed, rep_offset, _ptr(idx), _ptr(out)), "plspm_bootstrap_moments")
         return out
+
+    def prepare_bootstrap(self):
+        """Enqueue the per-data-set preparation of a later bootstrap (digit planes of the int8 Gram) beside whatever runs next."""
+        self._check(self._lib.plspm_bootstrap_prepare(self._h), "plspm_bootstrap_prepare")
 
     def bootstrap_device(self, B, seed=0, rep_offset=0):
         """Enqueue B replicates; returns raw device pointers (rows, status, iters) owned by the handle."""

@@ -47,7 +47,7 @@ class Estimator:
             path = structure.path().drop(hoc).drop(hoc, axis=1)
         return path
 
-    def run(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame, want_scores=True, want_cov=False) -> SolverResult:
+    def run(self, calculator: WeightsCalculatorFactory, data: pd.DataFrame, want_scores=True, want_cov=False, prepare_bootstrap=False) -> SolverResult:
         calculator = calculator.clone()
         config = calculator.config()
         if config.missing() and not config.metric() and calculator._nonmetric() == 2:
@@ -57,7 +57,7 @@ class Estimator:
         hocs = config.hoc()
         if not hocs:
             self._config = config
-            return calculator.run(data, config.path(), scaled=config.scaled(), want_scores=want_scores, want_cov=want_cov)
+            return calculator.run(data, config.path(), scaled=config.scaled(), want_scores=want_scores, want_cov=want_cov, prepare_bootstrap=prepare_bootstrap)
         if config.metric():
             raise NotImplementedError("higher order constructs need Scale.NUM / Scale.RAW data (the reference's metric solver cannot run them either)")
         first = calculator.run(data, self._first_stage_path, scaled=config.scaled(), want_scores=True)

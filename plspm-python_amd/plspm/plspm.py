@@ -73,7 +73,7 @@ class Plspm:
         calculator = w.WeightsCalculatorFactory(config, iterations, tolerance, np.sqrt(n_obs / (n_obs - 1)), scheme, device_id)
 
         # one device fit: Gram -> LDS solver -> scores; everything below only re-labels / post-processes its outputs
-        fit = estimator.run(calculator, observations, want_scores=True, want_cov=True)
+        fit = estimator.run(calculator, observations, want_scores=True, want_cov=True, prepare_bootstrap=bool(bootstrap) and n_obs >= 10)
         model_spec = estimator.config()
         pending = None
         if bootstrap:

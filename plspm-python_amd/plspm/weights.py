@@ -93,9 +93,10 @@ class WeightsCalculatorFactory:
         filled = np.where(np.isnan(values), np.where(np.isnan(means), 0.0, means), values)
         return np.ascontiguousarray(filled), (rows, ~missing[rows], set(self._config.all_scales()) == {Scale.RAW})
 
-    def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False) -> SolverResult:
+    def run(self, data: pd.DataFrame, path: pd.DataFrame, scaled: bool, want_scores=True, want_cov=False, prepare_bootstrap=False) -> SolverResult:
         """Compile, upload ``data`` (raw or treated) and run one device fit.  Raises the reference's
-        ``Exception("Could not converge ...")`` (weights.py:185-186) on non-convergence."""
+        ``Exception("Could not converge ...")`` (weights.py:185-186) on non-convergence.  ``prepare_bootstrap``: a bootstrap on this
+        handle follows (plspm.py:78-82) -- its per-data-set preparation is enqueued beside the fit."""
         nonmetric = self._nonmetric()
         n = data.shape[0]
         expected = np.sqrt(n / (n - 1))
@@ -130,6 +131,8 @@ class WeightsCalculatorFactory:
             return handle
 
         native = build(self._device_id)
+        if prepare_bootstrap:
+            native.prepare_bootstrap()
         raw = native.fit(want_scores=want_scores, want_cov=want_cov)
         if raw["status"] == _native.STATUS_NOT_CONVERGED:
             raise ConvergenceError("Could not converge after " + str(raw["iterations"]) + " iterations")

@@ -218,3 +218,37 @@ def test_plspm_processes_shards_over_handles_with_identical_results(kind, monkey
     assert again.ranks() == 2 and parallel.local_comm([0, 0]) is comm
     assert np.array_equal(again.replicates(), double.replicates())
     assert np.array_equal(double.status(), single.status()) and np.array_equal(again.replicate_iterations(), single.replicate_iterations())
+
+
+def test_real_multi_gpu_rccl_all_gather_when_the_box_has_two_gpus():
+    """Skipped on the one-GPU test box.  With >= 2 MI355X: ncclCommInitAll over DISTINCT devices, one handle per GPU, ONE ncclAllGather
+    over xGMI -- the records are bit-identical to the single-handle stream (even, ragged and multi-call splits), the transport is RCCL
+    on every rank, and the one-process-per-GPU launcher route gives the same frames (reference fan-out: bootstrap.py:89-111)."""
+    from plspm import _native
+    G = min(_native.device_count(), 8)
+    if G < 2:
+        pytest.skip("needs at least two GPUs (the driver's multi-GPU box)")
+    models = [_model(device=d) for d in range(G)]
+    ref = models[0].bootstrap(1003, seed=5, rep_offset=7)
+    comm = _native.NativeComm(list(range(G)))
+    assert comm.uses_rccl and comm.nranks == G
+    group = _native.NativeGroup(comm, models)
+    for call in range(3):                                       # the double-buffered slots: three calls in a row, then the last one's records
+        group.bootstrap(1003, seed=5, rep_offset=7)
+    rows, status, iters = group.rows()
+    assert np.array_equal(rows, ref[0]) and np.array_equal(status, ref[1]) and np.array_equal(iters, ref[2])
+    covered = [group.shard(1003, r) for r in range(G)]
+    assert covered[0][0] == 0 and sum(c for _, c in covered) == 1003
+    original = np.linspace(-1.0, 1.0, models[0].row_width)
+    table, used = group.summary(original)
+    ref_table, ref_used = models[0].summary(1003, original)
+    assert used == ref_used == 1003 and np.array_equal(table, ref_table)
+    group.barrier()
+    assert group.max(3.5) == 3.5
+    group.close(); comm.close()
+    script = os.path.join(HERE, "dist_api_script.py")
+    plain = _run([sys.executable, script])
+    dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(min(G, 2)), "--master-addr", "127.0.0.1",
+                 "--master-port", "29537", script])
+    for key in plain:
+        np.testing.assert_allclose(np.array(dist[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)

@@ -282,3 +282,55 @@ def test_persistent_schedule_on_small_and_wide_tile_grids(sizes, B):
     rows_k, st_k, it_k = nm.bootstrap(B, seed=2)
     assert np.array_equal(rows_t, rows_k) and np.array_equal(st_t, st_k) and np.array_equal(it_t, it_k)
     assert np.array_equal(M_t, nm.bootstrap_moments(min(B, 300), seed=2))
+
+
+def test_int8_route_beyond_65535_rows():
+    """the reference has no N limit (bootstrap.py:56-57); the int8 route's resample counts now come from windows of
+    65,536 rows (two per replicate at N = 100,000; every window regenerates the replicate's Philox draws).  Rows vs the oracle on the
+    resampled DATA at the suite's 1e-8, the fp64 route at 1e-10, explicit index lists through the same windows."""
+    from plspm import _native
+    N = 100000
+    X, blocks = orc.synth(N, orc.satisfaction_C(), 10, seed=21)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(300, seed=4)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 3 and np.all(status == 0)
+    corr = orc.correction(N)
+    for r in (0, 299):
+        idx = _native.bootstrap_indices(4, r, N)
+        assert idx.max() > 65535 and idx.min() < 65535
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+    nm.set_option("gram_path", 1)
+    rows64, status64, iters64 = nm.bootstrap(300, seed=4)
+    assert nm.get_option("last_gram_path") == 1 and np.array_equal(iters, iters64)
+    assert_close(rows, rows64, 1e-10, 1e-13)
+    nm.set_option("gram_path", 0)
+    idx = np.stack([_native.bootstrap_indices(4, r, N) for r in (0, 299)]).astype(np.int32)
+    r2, s2, i2 = nm.bootstrap(2, idx=idx)
+    assert nm.get_option("last_gram_path") == 2 and np.array_equal(r2, rows[[0, 299]]) and np.array_equal(i2, iters[[0, 299]])
+
+
+def test_int8_route_with_120_mvs_and_12_lvs():
+    """P = 120 > 64: the digit-plane Gram (7,381 pair columns) feeds the LDS solver through the tile-packed layout (the one-wave solvers
+    hold a covariance column of at most 64 entries per lane).  Rows vs the oracle and vs the fp64 route."""
+    from plspm import _native
+    C = orc.chain_C(12)
+    X, blocks = orc.synth(2500, C, 10, seed=8)
+    for modes, scheme in (("A" * 12, "path"), ("AB" * 6, "factorial")):
+        model = orc.Model(blocks, C, modes, scheme, True)
+        nm = native_model(model)
+        nm.upload(X)
+        rows, status, iters = nm.bootstrap(260, seed=6)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 1 and np.all(status == 0)
+        corr = orc.correction(2500)
+        for r in (0, 259):
+            mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(6, r, 2500), corr)
+            assert its == iters[r]
+            assert_close(rows[r], mine, RTOL, ATOL)
+        nm.set_option("gram_path", 1)
+        rows64, _, iters64 = nm.bootstrap(260, seed=6)
+        assert np.array_equal(iters, iters64)
+        assert_close(rows, rows64, 1e-10, 1e-13)

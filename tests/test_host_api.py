@@ -189,7 +189,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libplspm_hip.so does not export " + name
     assert sorted(_native.EXPORTS) == declared
-    assert lib.plspm_abi_version() == 2
+    assert lib.plspm_abi_version() == 3
 
 
 def test_host_rng_mirror_properties():
