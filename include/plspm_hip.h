@@ -362,9 +362,16 @@ int plspm_group_max(plspm_group_t* g, double* value);
  *   plspm_op_outer_weights  Mode.X.value.outer_weights_metric(data, Z, lv, mvs)   plspm/mode.py:28-29, 50-52
  *       Xk [N*k] row-major: the block's (treated) MVs; z [N]: the LV's inner estimate; w [k]:
  *       Mode A  X_k' z / N;  Mode B  least squares of z on X_k (minimum norm when X_k is rank deficient, as scipy.linalg.lstsq)
+ *   plspm_op_outer_weights_nonmetric  Mode.X.value.outer_weights_nonmetric(mv_grouped_by_lv, mv_grouped_by_lv_missing, Z, lv, correction)
+ *       plspm/mode.py:31-42, 54-61.  Xk [N*k] row-major: the block's quantified MVs (NaN where missing); present [N*k] 0/1 or NULL when
+ *       the block has no missing cell (the reference's mv_grouped_by_lv_missing[lv]); z [N]; returns w [k] and the LV's new scores Y [N]:
+ *       Mode A  w = X'z / sum z^2 (NaN-aware ratios with a mask), Mode B least squares of z on X (no mask allowed); Y = X w (row-wise
+ *       normalised with a mask), then (Y - mean) / std1 * correction (util.py:43-53)
  */
 int plspm_op_inner_weights(int32_t device_id, int32_t scheme, int32_t L, const uint8_t* path, const double* y, int64_t N, double* E);
 int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, const double* z, int64_t N, int32_t k, double* w);
+int plspm_op_outer_weights_nonmetric(int32_t device_id, int32_t mode, const double* Xk, const uint8_t* present, const double* z, int64_t N, int32_t k,
+                                     double correction, double* w, double* Y);
 
 /* Test seam: only the resample + Gram stages of plspm_bootstrap (on the Gram path the handle's "gram_path" option selects).
  *   idx   NULL (on-device Philox draws) or [B*N] explicit row indices;   out [B * C * C], C = device columns + 1 (after the data

@@ -357,3 +357,67 @@ __global__ void __launch_bounds__(256) op_outer_kernel(int mode, int k, int T, c
     const long kk = (long)k * k;
     op_outer_weights(ex, mode, k, T, Mp, shift, scratch, scratch + kk, scratch + 2 * kk, w_out, scratch + 3 * kk);
 }
+
+// Mode.X.value.outer_weights_nonmetric (reference plspm/mode.py:31-42, 54-61) on the block's quantified MVs: one workgroup of 1,024 threads,
+// three passes over the N x k block.  Every sum runs over a fixed thread-to-row map and a fixed LDS tree: bit-reproducible.
+//   Mode A, complete block   w = X' z / sum z^2 (mode.py:38-39);      Y = X w
+//   Mode A, NaN cells        w_p = nansum_i(x_ip z_i) / sum_i (m_ip z_i)^2,  Y_i = nansum_p(x_ip w_p) / sum_p (m_ip w_p)^2 (mode.py:33-37; m = presence mask)
+//   Mode B                   w arrives (least squares of z on X, plspm_op_outer_weights);  Y = X w (mode.py:58-59)
+//   then Y <- treat_numpy(Y) * correction = (Y - nanmean) / nanstd1 * correction (util.py:43-53, mode.py:41,60)
+// red: LDS [1024] doubles.
+__device__ __forceinline__ double op_block_sum(double v, double* red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    const double s = red[0];
+    __syncthreads();
+    return s;
+}
+__global__ void __launch_bounds__(1024) op_nm_outer_kernel(int have_w, long N, int k, const double* __restrict__ X, const unsigned char* __restrict__ present,
+                                                           const double* __restrict__ z, double correction, double* __restrict__ w, double* __restrict__ Y) {
+    __shared__ double red[1024];
+    const int t = threadIdx.x;
+    if (!have_w) {
+        double zz = 0.0;
+        if (!present) { for (long i = t; i < N; i += 1024) zz += z[i] * z[i]; zz = op_block_sum(zz, red); }
+        for (int p = 0; p < k; ++p) {
+            double num = 0.0, den = 0.0;
+            for (long i = t; i < N; i += 1024) {
+                const double x = X[i * k + p], zi = z[i];
+                if (x == x) num += x * zi;
+                if (present) { const double mz = present[i * k + p] ? zi : 0.0; den += mz * mz; }
+            }
+            num = op_block_sum(num, red);
+            if (present) den = op_block_sum(den, red); else den = zz;
+            if (t == 0) w[p] = num / den;
+            __syncthreads();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    double sum = 0.0, cnt = 0.0;
+    for (long i = t; i < N; i += 1024) {
+        double y = 0.0, den = 0.0;
+        for (int p = 0; p < k; ++p) {
+            const double x = X[i * k + p], wp = w[p];
+            if (x == x) y += x * wp;
+            if (present) { const double mw = present[i * k + p] ? wp : 0.0; den += mw * mw; }
+        }
+        if (present) y = y / den;
+        Y[i] = y;
+        if (y == y) { sum += y; cnt += 1.0; }
+    }
+    sum = op_block_sum(sum, red);
+    cnt = op_block_sum(cnt, red);
+    const double mean = sum / cnt;
+    double ss = 0.0;
+    for (long i = t; i < N; i += 1024) { const double d = Y[i] - mean; if (d == d) ss += d * d; }
+    ss = op_block_sum(ss, red);
+    const double sd = sqrt(ss / (cnt - 1.0));
+    for (long i = t; i < N; i += 1024) Y[i] = (Y[i] - mean) / sd * correction;
+}
+

@@ -1535,6 +1535,40 @@ int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, co
     return done(0);
 }
 
+int plspm_op_outer_weights_nonmetric(int32_t device_id, int32_t mode, const double* Xk, const uint8_t* present, const double* z, int64_t N, int32_t k,
+                                     double correction, double* w, double* Y) {
+    g_create_error.clear();
+    if (!Xk || !z || !w || !Y || k < 1 || k > 1020 || N < 2 || (mode != PLSPM_MODE_A && mode != PLSPM_MODE_B))
+        return fail(nullptr, PLSPM_E_ARG, "plspm_op_outer_weights_nonmetric: bad arguments (1 <= k <= 1020, N >= 2)");
+    if (mode == PLSPM_MODE_B && present) return fail(nullptr, PLSPM_E_ARG, "plspm_op_outer_weights_nonmetric: Mode B takes no missing values (mode.py:55-56)");
+    int rc;
+    // Mode B: the least-squares weights of z on the block (minimum norm when rank deficient), as the metric operator computes them
+    if (mode == PLSPM_MODE_B && (rc = plspm_op_outer_weights(device_id, PLSPM_MODE_B, Xk, z, N, k, w))) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return fail(nullptr, PLSPM_E_STATE, "plspm_op_outer_weights_nonmetric: no such HIP device");
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, PLSPM_E_STATE, "hipSetDevice failed");
+    const size_t nx = (size_t)N * k;
+    const size_t bytes = sizeof(double) * (nx + 2 * (size_t)N + k) + (present ? nx : 0);
+    void* base = nullptr;
+    hipStream_t st = nullptr;
+    if (plspm_dmalloc(&base, bytes) != hipSuccess) return fail(nullptr, PLSPM_E_STATE, "plspm_op_outer_weights_nonmetric: out of device memory");
+    auto done = [&](int code, const char* why) { if (st) { hipStreamSynchronize(st); plspm_stream_release(st); } plspm_dfree(base); return code ? fail(nullptr, code, why) : 0; };
+    if (plspm_stream_acquire(&st) != hipSuccess) return done(PLSPM_E_STATE, "plspm_op_outer_weights_nonmetric: no stream");
+    double* d_X = (double*)base; double* d_z = d_X + nx; double* d_Y = d_z + N; double* d_w = d_Y + N;
+    unsigned char* d_m = present ? (unsigned char*)(d_w + k) : nullptr;
+    bool ok = hipMemcpyAsync(d_X, Xk, sizeof(double) * nx, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(d_z, z, sizeof(double) * N, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && present) ok = hipMemcpyAsync(d_m, present, nx, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && mode == PLSPM_MODE_B) ok = hipMemcpyAsync(d_w, w, sizeof(double) * k, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (!ok) return done(PLSPM_E_STATE, "plspm_op_outer_weights_nonmetric: upload failed");
+    hipLaunchKernelGGL(op_nm_outer_kernel, dim3(1), dim3(1024), 0, st, mode == PLSPM_MODE_B ? 1 : 0, (long)N, (int)k, (const double*)d_X, (const unsigned char*)d_m, (const double*)d_z,
+                       correction, d_w, d_Y);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(w, d_w, sizeof(double) * k, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(Y, d_Y, sizeof(double) * N, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return done(PLSPM_E_STATE, "plspm_op_outer_weights_nonmetric: launch / copy failed");
+    return done(0, "");
+}
+
 int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out) {
     if (!m || !out || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_moments: bad arguments");
     if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_bootstrap_moments: no data uploaded");

@@ -24,7 +24,7 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt", "plspm_bootstrap_prepare",
            "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
-           "plspm_op_inner_weights", "plspm_op_outer_weights"]
+           "plspm_op_inner_weights", "plspm_op_outer_weights", "plspm_op_outer_weights_nonmetric"]
 UNIQUE_ID_BYTES = 128
 
 
@@ -131,6 +131,7 @@ def load():
     lib.plspm_group_max.argtypes = [vp, ctypes.POINTER(dbl)]
     lib.plspm_op_inner_weights.argtypes = [i32, i32, i32, vp, vp, i64, vp]
     lib.plspm_op_outer_weights.argtypes = [i32, i32, vp, vp, i64, i32, vp]
+    lib.plspm_op_outer_weights_nonmetric.argtypes = [i32, i32, vp, vp, vp, i64, i32, dbl, vp, vp]
     if lib.plspm_abi_version() != ABI_VERSION:
         raise NativeBackendError("libplspm_hip.so ABI %d != expected %d" % (lib.plspm_abi_version(), ABI_VERSION))
     _lib = lib
@@ -387,6 +388,26 @@ def op_outer_weights(mode_code, Xk, z, device_id=0):
     if rc:
         raise NativeBackendError("plspm_op_outer_weights failed (%d): %s" % (rc, lib.plspm_last_error(None).decode()))
     return w
+
+
+def op_outer_weights_nonmetric(mode_code, Xk, present, z, correction, device_id=0):
+    """Non-metric Mode operator on the device (plspm_op_outer_weights_nonmetric): Xk [N, k] (NaN = missing), present [N, k] 0/1 or None,
+    z [N] -> (w [k], Y [N])."""
+    lib = load()
+    Xk = np.ascontiguousarray(Xk, dtype=np.float64)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    if Xk.ndim != 2 or z.shape != (Xk.shape[0],):
+        raise ValueError("Xk must be [N, k] and z [N]")
+    mask = None
+    if present is not None:
+        mask = np.ascontiguousarray(np.asarray(present) != 0, dtype=np.uint8)
+        if mask.shape != Xk.shape:
+            raise ValueError("present must have the shape of Xk")
+    w, Y = np.empty(Xk.shape[1]), np.empty(Xk.shape[0])
+    rc = lib.plspm_op_outer_weights_nonmetric(int(device_id), int(mode_code), _ptr(Xk), _ptr(mask), _ptr(z), Xk.shape[0], Xk.shape[1], float(correction), _ptr(w), _ptr(Y))
+    if rc:
+        raise NativeBackendError("plspm_op_outer_weights_nonmetric failed (%d): %s" % (rc, lib.plspm_last_error(None).decode()))
+    return w, Y
 
 
 def release_cached_memory():

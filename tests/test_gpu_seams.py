@@ -152,6 +152,48 @@ def test_mode_operator_outer_weights_metric(mode):
     assert_close(got["SAT"].values, want, 1e-9, 1e-12, what="mode " + mode)
 
 
+def _reference_outer_weights_nonmetric(mode, X, present, z, correction):
+    """NumPy restatement of reference mode.py:31-42 / 54-61 + util.treat_numpy (util.py:43-53) (test-side checker)."""
+    if mode == "A" and present is not None:
+        w = np.nansum(X * z[:, None], axis=0) / np.sum(np.power(present * z[:, None], 2), axis=0)
+        Y = np.nansum(X.T * w[:, None], axis=0) / np.sum(np.power(present.T * w[:, None], 2), axis=0)
+    elif mode == "A":
+        w = X.T @ z / np.power(z, 2).sum()
+        Y = X @ w
+    else:
+        w = np.linalg.lstsq(X, z, rcond=None)[0]
+        Y = X @ w
+    Y = Y - np.nanmean(Y)
+    return w, Y / np.nanstd(Y, axis=0, ddof=1) * correction
+
+
+@pytest.mark.parametrize("mode,missing", [("A", False), ("A", True), ("B", False)])
+def test_mode_operator_outer_weights_nonmetric(mode, missing):
+    """Mode.X.value.outer_weights_nonmetric(mv_grouped_by_lv, mv_grouped_by_lv_missing, Z, lv, correction) (reference mode.py:31-42,
+    54-61) as one device call: (weights, Y) with Y = treat_numpy(X w) * correction; NaN-aware ratios when the LV's block has missing
+    cells (the reference keeps the LV's presence mask only then); Mode B refuses missing data with the reference's message."""
+    rs = np.random.RandomState(12)
+    N, k = 777, 5
+    z = rs.standard_normal(N)
+    X = 0.6 * z[:, None] * np.linspace(0.5, 1.0, k) + rs.standard_normal((N, k))
+    X = (X - X.mean(axis=0)) / X.std(axis=0)
+    groups, masks = {"SAT": X.copy()}, {}
+    if missing:
+        holes = rs.rand(N, k) < 0.04
+        holes[holes.all(axis=1)] = False
+        groups["SAT"][holes] = np.nan
+        masks["SAT"] = 1 - np.isnan(groups["SAT"])
+    corr = np.sqrt(N / (N - 1))
+    w, Y = (Mode.A if mode == "A" else Mode.B).value.outer_weights_nonmetric(groups, masks, z, "SAT", corr)
+    want_w, want_Y = _reference_outer_weights_nonmetric(mode, groups["SAT"], masks.get("SAT"), z, corr)
+    assert isinstance(w, np.ndarray) and w.shape == (k,) and Y.shape == (N,)
+    assert_close(w, want_w, 1e-10, 1e-13, what="weights " + mode)
+    assert_close(Y, want_Y, 1e-9, 1e-12, what="scores " + mode)
+    if missing:
+        with pytest.raises(Exception, match="not supported in mode B"):
+            Mode.B.value.outer_weights_nonmetric(groups, masks, z, "SAT", corr)
+
+
 def test_mode_b_operator_minimum_norm_on_a_collinear_block():
     sat, cfg = sat_config("AAAAAA", 0)
     data = cfg.treat(cfg.filter(sat))
