@@ -231,9 +231,12 @@ struct GramI8 {
     // VAR >= 18: ONE workgroup barrier per two k-steps on a ring of five stages (k-steps 2p+1 and 2p+2 have landed at the barrier of
     // pair p, 2p+3 is in flight, 2p+4 / 2p+5 are issued during the pair into the stages of 2p-1 / 2p, whose fragments every wave
     // read before that barrier) -- when five stages fit the 160 KB
-    static constexpr bool PAIRB = VAR >= 18 && 5 * STAGE_BYTES <= 160 * 1024;
-    static constexpr int NS_WANT = PAIRB ? 5 : 3 + VAR % 3, NS = NS_WANT * STAGE_BYTES <= 160 * 1024 ? NS_WANT : (160 * 1024) / STAGE_BYTES;      // LDS stages of the DMA ring
-    static constexpr int RSTEP = 1 + (VAR / 3) % 3, DMA_HEAD = (VAR % 18) / 9;
+    // VAR >= 100 (experiments build only): ABLATIONS of the default schedule V = VAR % 100 -- timing probes whose results are garbage:
+    // bit 0 of VAR / 100: no LDS-DMA issue in the steady state, bit 1: no workgroup barrier, bit 2: no fragment reads
+    static constexpr int ABL = (VAR / 100) & 7, V = VAR % 100;
+    static constexpr bool PAIRB = V >= 18 && 5 * STAGE_BYTES <= 160 * 1024;
+    static constexpr int NS_WANT = PAIRB ? 5 : 3 + V % 3, NS = NS_WANT * STAGE_BYTES <= 160 * 1024 ? NS_WANT : (160 * 1024) / STAGE_BYTES;      // LDS stages of the DMA ring
+    static constexpr int RSTEP = 1 + (V / 3) % 3, DMA_HEAD = (V % 18) / 9;
     static constexpr int FLIGHT = PAIRB ? 1 : NS - 2;      // k-steps whose DMAs may still be in flight behind the barrier's wait
     static constexpr size_t LDS_BYTES = (size_t)NS * STAGE_BYTES;
 };
@@ -317,17 +320,22 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     // one k-step: MFMAs on (fc, fd); in their shadow the fragment reads of the following k-step from LDS stage R into (fna, fnb)
     // and this wave's DMA instructions of the k-step AHEAD into stage W (an LDS-DMA instruction occupies the wave's issue for
     // ~60 cycles: eight of them back to back in front of the barrier left the matrix pipe idle a third of every step)
+    // (tools/i8_ablate.py: without the DMA issue the kernel takes 0.39 instead of 0.46 ms -- and the second wave of a SIMD in the
+    // eight-wave form does not cover for it: with its DMA slots placed half an interval behind its partner's the kernel measured
+    // 0.466-0.474 ms against 0.456-0.458 with both waves on the same schedule)
     auto step = [&](i32x4 (&fc)[NA], i32x4 (&fd)[NB], i32x4 (&fna)[NA], i32x4 (&fnb)[NB], unsigned Roff, unsigned Woff) {
         const unsigned ra = fbaseA + Roff, rb = fbaseB + Roff;
         constexpr int RSTEP = G::NMFMA / (NA + NB) >= G::RSTEP ? G::RSTEP : 1;          // a fragment read after every RSTEP-th MFMA
         int nread = 0, ndma = 0;
         auto fill = [&](int m) {                              // what rides behind MFMA number m of the step
             if (m % RSTEP == 0 && nread < NA + NB) {
-                if (nread < NA) GI8_DSREAD(fna[nread], ra, nread * 1024);
-                else GI8_DSREAD(fnb[nread - NA], rb, (nread - NA) * 1024);
+                if (!(G::ABL & 4)) {
+                    if (nread < NA) GI8_DSREAD(fna[nread], ra, nread * 1024);
+                    else GI8_DSREAD(fnb[nread - NA], rb, (nread - NA) * 1024);
+                }
                 ++nread;
             }
-            if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * G::NMFMA) / G::PER + 1)) { issue_one(ndma, Woff); ++ndma; }
+            if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * G::NMFMA) / G::PER + 1)) { if (!(G::ABL & 1)) issue_one(ndma, Woff); ++ndma; }
         };
         if constexpr (SH == 16) {
 #pragma unroll
@@ -364,7 +372,7 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
         if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * G::PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::FLIGHT * (G::PER - 1)) : "memory");
         wait_frags(fa, fb);
-        asm volatile("s_barrier" ::: "memory");
+        if (!(G::ABL & 2)) asm volatile("s_barrier" ::: "memory");
     };
 
     i32x4 fa0[NA], fb0[NB], fa1[NA], fb1[NB];

@@ -672,7 +672,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
-    else if (k == "i8_variant") { if (value < -1 || value > 35) return bad(); m->tune.i8_variant = value; }
+    else if (k == "i8_variant") { if (value < -1 || value > 799) return bad(); m->tune.i8_variant = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
@@ -1115,6 +1115,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
 #define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
 #ifdef PLSPM_I8_EXPERIMENTS       // every schedule variant of the 7-plane kernel (tools/i8_bench.py --variants; not in the release library)
 #define GI8X(WW) switch (m->tune.i8_variant) { case 0: GI8V(7, WW, 0) break; case 3: GI8V(7, WW, 3) break; case 6: GI8V(7, WW, 6) break; case 4: GI8V(7, WW, 4) break; \
+        case 103: GI8V(7, WW, 103) break; case 203: GI8V(7, WW, 203) break; case 303: GI8V(7, WW, 303) break; case 403: GI8V(7, WW, 403) break; case 503: GI8V(7, WW, 503) break; case 703: GI8V(7, WW, 703) break; \
         case 12: GI8V(7, WW, 12) break; case 18: GI8V(7, WW, 18) break; case 21: GI8V(7, WW, 21) break; case 24: GI8V(7, WW, 24) break; case 30: GI8V(7, WW, 30) break; default: GI8V(7, WW, 33) break; }
     if (S == 7 && m->tune.i8_variant >= 0) { if (m->tune.i8_waves == 4) GI8X(2) else GI8X(4) } else
 #endif
