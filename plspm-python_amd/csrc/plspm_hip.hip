@@ -515,6 +515,12 @@ static int dense_moments(plspm_model* m) {
 
 // Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
 // finish.  The host only reads one counter per iteration (how many problems are still active).
+// doubles of per-problem solver state of a non-metric handle (NmState head + what its solver keeps behind it)
+static size_t nm_state_doubles_of(const plspm_model* m) {
+    return m->categorical ? (size_t)nmg_state_doubles(m->P, m->Pm, m->L, m->cmax, m->kmv)
+                          : m->nmx_K > 0 ? (size_t)nmx_state_doubles(m->P, m->L, m->n_chol, m->nmx_K) : (size_t)nm_state_doubles(m->P, m->L, m->n_chol);
+}
+
 static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, const int2* ent, const int* nent,
                          long ent_stride, int threads, bool finish = true) {
     const int P = m->P, L = m->L;
@@ -523,8 +529,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     const bool cat = m->categorical != 0, nmx = m->nmx_K > 0;
     int rc;
     const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
-    const size_t st_doubles = cat ? (size_t)nmg_state_doubles(P, m->Pm, L, m->cmax, m->kmv)
-                                  : nmx ? (size_t)nmx_state_doubles(P, L, m->n_chol, m->nmx_K) : (size_t)nm_state_doubles(P, L, m->n_chol);
+    const size_t st_doubles = nm_state_doubles_of(m);
     // bootstrap: dense stop-rule pass (nm_conv_dense_kernel) when the replicates' uint16 histograms are at hand and the coefficient
     // tile of 64 replicates fits LDS; otherwise (and for a single fit) the gathering pass
     const long ntiles16 = (N + 15) / 16;
@@ -614,7 +619,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             const int* conv_boff = m->d_boff;
             if (m->stage1) {
                 hipLaunchKernelGGL(hoc_compose_kernel, grid, dim3(64), 0, m->stream, make_hoc_desc(m), (const double*)m->stage1->nmstate.p,
-                                   (long)nm_state_doubles(src->P, src->L, src->n_chol), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride);
+                                   (long)nm_state_doubles_of(src), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride);
                 conv_state = (const double*)m->pseudo.p; conv_stride = ps_stride; conv_boff = m->d_lv_cols;
             }
             if (dense) {
@@ -766,8 +771,11 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     if (!first || !second || !lv_first || first == second) return fail(first, PLSPM_E_ARG, "plspm_model_attach_second_stage: bad arguments");
     plspm_model* m1 = first; plspm_model* m2 = second;
     if (m1->stage1 || m1->stage2 || m2->stage1 || m2->stage2) return fail(m1, PLSPM_E_STATE, "a handle takes part in one two-stage pair only");
-    if (!m1->nonmetric || !m2->nonmetric || m1->categorical || m2->categorical || m1->n_ind || m2->n_ind || m1->nmx_K)
-        return fail(m1, PLSPM_E_STATE, "two-stage estimation needs Scale.NUM / RAW handles (the reference's metric solver cannot run HOCs)");
+    if (!m1->nonmetric || !m2->nonmetric || m1->n_ind || m2->n_ind || m1->nmx_K)
+        return fail(m1, PLSPM_E_STATE, "two-stage estimation needs non-metric handles on complete data (the reference's metric solver cannot run HOCs)");
+    // Scale.ORD / NOM data: both stages work on aug columns (solver_nmg.h); "column" below then means aug column -- a plain LV keeps its
+    // indicator / data columns, a HOC's MVs are the constituents' stage-1 scores (one NUM column each), affine in the stage-1 aug columns
+    if (m1->categorical != m2->categorical) return fail(m1, PLSPM_E_STATE, "both stages are categorical handles (plspm_model_set_categorical) or neither is");
     if (m2->d_Xa) return fail(m1, PLSPM_E_STATE, "the second stage takes no data of its own");
     if (m1->device != m2->device) return fail(m1, PLSPM_E_ARG, "both stages must live on one device");
     const int L1 = m1->L, L2 = m2->L;
@@ -1236,7 +1244,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             {
                 ProfScope ps(m, PLSPM_K_REDUCE);
                 hipLaunchKernelGGL(hoc_moments_kernel, dim3((unsigned)nb), dim3(256), vlds, m->stream, hd, (const double*)m->gram.p, psize, (const double*)m->nmstate.p,
-                                   (long)nm_state_doubles(m->P, m->L, m->n_chol), (double*)m2->gram.p, psize2);
+                                   (long)nm_state_doubles_of(m), (double*)m2->gram.p, psize2);
             }
             rc = run_nonmetric(m2, nb, (const double*)m2->gram.p, psize2, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128);
             if (rc) return fail(m, rc, "second stage: " + m2->error);

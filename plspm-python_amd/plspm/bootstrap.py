@@ -83,34 +83,6 @@ def launch(result, iterations: int, num_processes: int, seed=None, comm=None, de
     return _Pending(result, iterations, seed, source, group, helpers)
 
 
-def launch_replicatewise(run_one, n_obs: int, result, iterations: int, seed=None, indices=None) -> _Pending:
-    """Replicates of a model the batched kernels do not cover -- a higher order construct on Scale.ORD / NOM data, where every
-    replicate re-quantifies its MVs and the second stage is not a function of first-stage moments: every replicate is a
-    complete two-stage DEVICE estimate of the resampled observations (``run_one(idx) -> (row, iterations)``: the kernels of the
-    full-sample fit, one replicate at a time, ~70 replicates/s on the mobi model), drawn with the device RNG's index stream (seed, replicate id) or the
-    explicit ``indices``.  A replicate that raises is dropped like the reference's (bootstrap.py:65-66).  The records go back to HBM
-    (``plspm_bootstrap_store``) so that summaries, fetches and frames are the ones of every other bootstrap."""
-    from plspm import _native
-    native = result.native
-    if seed is None:
-        seed = int.from_bytes(os.urandom(8), "little")
-    R = native.row_width
-    rows = np.zeros((iterations, R))
-    status = np.zeros(iterations, dtype=np.int32)
-    iters = np.zeros(iterations, dtype=np.int32)
-    for r in range(iterations):
-        idx = np.asarray(indices[r]) if indices is not None else _native.bootstrap_indices(seed, r, n_obs)
-        try:
-            row, its = run_one(idx)
-            if row.shape != (R,) or not np.all(np.isfinite(row)):
-                raise FloatingPointError("non-finite estimate")
-            rows[r], iters[r] = row, its
-        except Exception as error:
-            status[r] = _native.STATUS_NOT_CONVERGED if "converge" in str(error).lower() else _native.STATUS_NONFINITE
-    native.store(parallel.join_records(rows, status, iters))
-    return _Pending(result, iterations, seed, native, None, None)
-
-
 class Bootstrap:
     """Bootstrap results; constructed by :class:`plspm.plspm.Plspm` when ``bootstrap=True``.
 

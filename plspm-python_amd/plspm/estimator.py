@@ -94,10 +94,11 @@ class Estimator:
         calculator = calculator.clone()
         config = calculator.config()
         hocs = config.hoc()
-        if config.metric() or calculator._nonmetric() != 1 or data.isnull().values.any():
-            # (Scale.ORD / NOM: Plspm runs bootstrap.launch_replicatewise instead; NaNs: the reference cannot estimate a HOC model on
-            #  incomplete data either -- its Config.filter raises KeyError for the HOC, config.py:279)
-            raise NotImplementedError("the batched two-stage bootstrap needs complete Scale.NUM / Scale.RAW data")
+        nonmetric = calculator._nonmetric()
+        if config.metric() or not nonmetric or data.isnull().values.any():
+            # (NaNs: the reference cannot estimate a HOC model on incomplete data either -- its Config.filter raises KeyError for the
+            #  HOC, config.py:279)
+            raise NotImplementedError("the batched two-stage bootstrap needs complete non-metric data")
         path1 = self.expanded_first_stage_path(config)
         compiled1 = compile_model(config, path1, list(data.columns))
         values = data.values
@@ -110,14 +111,36 @@ class Estimator:
             config.add_lv(hoc, config.mode(hoc), *[c.MV(lv, Scale.NUM) for lv in parts])
         compiled2 = compile_model(config, config.path(), list(data.columns) + [lv for parts in hocs.values() for lv in parts])
         scheme_code = calculator.scheme().value.code
+        categorical1 = categorical2 = None
+        offsets1, offsets2 = compiled1.block_offset, compiled2.block_offset
+        if nonmetric == 2:
+            # Scale.ORD / NOM: both stages live on aug columns (one indicator column per category; _compile.augment).  A plain LV of
+            # stage 2 keeps the aug columns of its stage-1 twin, a HOC's MVs -- the constituents' stage-1 scores -- are one NUM column each.
+            from plspm._compile import augment
+            xaug, offsets1, mv_off1, mv_kind1 = augment(compiled1, config, values)
+            categorical1 = (mv_off1, mv_kind1)
+            widths2, kinds2, offsets2 = [], [], [0]
+            for l, lv in enumerate(compiled2.lvs):
+                if lv in hocs:
+                    widths2 += [1] * len(hocs[lv]); kinds2 += [0] * len(hocs[lv])
+                else:
+                    j = lv_first[l]
+                    for p in range(compiled1.block_offset[j], compiled1.block_offset[j + 1]):
+                        widths2.append(int(mv_off1[p + 1] - mv_off1[p])); kinds2.append(int(mv_kind1[p]))
+                offsets2.append(int(sum(widths2)))
+            categorical2 = (np.concatenate(([0], np.cumsum(widths2))).astype(np.int32), np.array(kinds2, dtype=np.int32))
+            offsets2 = np.array(offsets2, dtype=np.int32)
 
         def build(device_id):
             """The handle pair on ``device_id``: the data-holding first stage with the second stage attached."""
-            first = _native.NativeModel(compiled1.block_offset, compiled1.path, compiled1.modes, scheme_code, config.scaled(),
-                                        calculator._iterations, calculator._tolerance, device_id, nonmetric=True)
-            first.upload(values, compiled1.col_index)
-            second = _native.NativeModel(compiled2.block_offset, compiled2.path, compiled2.modes, scheme_code, config.scaled(),
-                                         calculator._iterations, calculator._tolerance, device_id, nonmetric=True)
+            first = _native.NativeModel(offsets1, compiled1.path, compiled1.modes, scheme_code, config.scaled(),
+                                        calculator._iterations, calculator._tolerance, device_id, nonmetric=True, categorical=categorical1)
+            if categorical1 is not None:
+                first.upload(xaug)
+            else:
+                first.upload(values, compiled1.col_index)
+            second = _native.NativeModel(offsets2, compiled2.path, compiled2.modes, scheme_code, config.scaled(),
+                                         calculator._iterations, calculator._tolerance, device_id, nonmetric=True, categorical=categorical2)
             first.attach_second_stage(second, lv_first)
             return first
 

@@ -18,7 +18,6 @@ import plspm.outer_model as om
 import plspm.weights as w
 from plspm.bootstrap import Bootstrap
 from plspm.bootstrap import launch as launch_bootstrap
-from plspm.bootstrap import launch_replicatewise
 from plspm.estimator import Estimator
 from plspm.scheme import Scheme
 from plspm.unidimensionality import Unidimensionality
@@ -81,12 +80,10 @@ class Plspm:
                 raise Exception("Bootstrapping could not be performed, at least 10 observations are required.")
             # the handle of the fit already holds the data in HBM: the replicates are enqueued on it NOW (HOC models: on a two-stage
             # handle pair), so that the GPU resamples and solves while the host does whatever is left to do
-            if config.hoc() and calculator._nonmetric() == 2:
-                # higher order construct on Scale.ORD / NOM data: one two-stage device estimate per replicate (bootstrap.launch_replicatewise)
-                pending = launch_replicatewise(self._replicate_runner(config, calculator, observations), n_obs, fit, bootstrap_iterations, seed)
-            else:
-                boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
-                pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed, devices=devices)
+            # (HOC models: on a two-stage handle pair -- Scale.NUM / RAW and, since round 3, Scale.ORD / NOM data alike: both stages of
+            #  every replicate run on the device, estimator.two_stage_bootstrap_handles)
+            boot_on = estimator.two_stage_bootstrap_handles(calculator, observations) if config.hoc() else fit
+            pending = launch_bootstrap(boot_on, bootstrap_iterations, processes, seed, devices=devices)
         self._result = fit
         # The report frames only re-label / post-process the device outputs already on the host (fit.raw); they are built on first
         # access (the reference builds them eagerly, plspm.py:69-77 -- same objects, same values, ~4 ms of pandas work per call that a
@@ -147,8 +144,9 @@ class Plspm:
 
     @staticmethod
     def _replicate_runner(config, calculator, observations):
-        """run_one(idx) of ``bootstrap.launch_replicatewise``: the estimate of the resampled observations in the device row layout
-        (weights | r2 | total | direct | loadings) -- what a reference worker computes per replicate (bootstrap.py:56-64)."""
+        """run_one(idx): ONE complete device estimate (two stages for a HOC model) of the resampled observations in the device row
+        layout (weights | r2 | total | direct | loadings) -- what a reference worker computes per replicate (bootstrap.py:56-64).  The
+        bootstrap itself is batched; this is the per-replicate cross-check the tests use."""
         def run_one(idx):
             result = Estimator(config).run(calculator, observations.iloc[idx, :], want_scores=False)
             raw = result.raw

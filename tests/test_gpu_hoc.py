@@ -141,9 +141,12 @@ def _ordinal_hoc(scheme_name):
 @pytest.mark.parametrize("tag", ["path", "centroid"])
 def test_hoc_on_ordinal_data_fit_and_replicates_vs_reference_golden(tag):
     """Higher order construct on Scale.ORD data (golden g15 from the real reference: full sample + five resamples on explicit indices).
-    The bootstrap of such a model is one two-stage device estimate per replicate (bootstrap.launch_replicatewise): the rows of the
-    explicit index lists must be the reference's, the records land in HBM and feed the device summaries like any other bootstrap."""
-    from plspm.bootstrap import launch_replicatewise
+    Round 3: the bootstrap of such a model is batched like every other one -- both stages of every replicate on the device (stage-1
+    categorical solver -> stage-2 moments by congruence with the stage-1 score maps over the indicator columns -> stage-2 categorical
+    solver; estimator.two_stage_bootstrap_handles) -- and the rows of the explicit index lists must be the reference's
+    (estimator.py:43-52 inside bootstrap.py:54-66)."""
+    import plspm.weights as w
+    from plspm.estimator import Estimator
     from plspm.plspm import Plspm
     g = load("g15_hoc_ordinal")
     mobi, config, scheme = _ordinal_hoc(tag)
@@ -154,22 +157,29 @@ def test_hoc_on_ordinal_data_fit_and_replicates_vs_reference_golden(tag):
     gold = g[tag + "/rows"]
     full = np.concatenate((fit.raw["weights"], fit.raw["r2"], fit.raw["total"], fit.raw["direct"], fit.raw["loadings"]))
     assert_close(full, gold[0], RTOL, ATOL)
-    import plspm.weights as w
     observations = config.filter(mobi)
     calculator = w.WeightsCalculatorFactory(config, 100, 1e-7, np.sqrt(250 / 249), scheme, 0)
-    run_one = Plspm._replicate_runner(config, calculator, observations)
-    pending = launch_replicatewise(run_one, 250, fit, 5, seed=3, indices=g["idx"])
-    rows, status, iters = fit.native.fetch(0, 5)
+    pair = Estimator(config).two_stage_bootstrap_handles(calculator, observations)
+    assert list(pair.compiled.dev_mvs) == list(cm.dev_mvs)
+    rows, status, iters = pair.native.bootstrap(5, idx=np.ascontiguousarray(g["idx"], dtype=np.int32))
     assert np.all(status == 0) and np.all(iters > 0)
     assert_close(rows, gold[1:], RTOL, ATOL)
-    table, used = fit.native.summary(5, full)
+    table, used = pair.native.summary(5, full)
     assert used == 5
     assert_close(table[:, 1], gold[1:].mean(axis=0), 1e-6, 1e-9)
+    # ... and the device RNG's replicates equal one two-stage device ESTIMATE of the resampled observations each
+    from plspm import _native
+    rows_d, status_d, _ = pair.native.bootstrap(6, seed=3)
+    for r in (0, 5):
+        res = Estimator(config).run(calculator, observations.iloc[_native.bootstrap_indices(3, r, 250), :], want_scores=False)
+        one = np.concatenate((res.raw["weights"], res.raw["r2"], res.raw["total"], res.raw["direct"], res.raw["loadings"]))
+        assert status_d[r] == 0
+        assert_close(rows_d[r], one, 1e-7, 1e-10)
 
 
 def test_api_bootstrap_of_a_hoc_model_on_ordinal_data():
-    """Plspm(..., bootstrap=True) no longer refuses a higher order construct on Scale.ORD data: device RNG index stream, one
-    two-stage estimate per replicate, the reference's frames."""
+    """Plspm(..., bootstrap=True) on a higher order construct with Scale.ORD data: device RNG index stream, both stages of every
+    replicate batched on the device, the reference's frames."""
     from plspm import _native
     from plspm.plspm import Plspm
     mobi, config, scheme = _ordinal_hoc("path")
@@ -186,5 +196,5 @@ def test_api_bootstrap_of_a_hoc_model_on_ordinal_data():
     import plspm.weights as wm
     calculator = wm.WeightsCalculatorFactory(config, 100, 1e-7, np.sqrt(250 / 249), scheme, 0)
     row, _ = Plspm._replicate_runner(config, calculator, observations)(_native.bootstrap_indices(11, 0, 250))
-    assert_close(boot.replicates()[0], row, 1e-12, 1e-14)
+    assert_close(boot.replicates()[0], row, 1e-7, 1e-10)          # (the batched second stage works on moments, the single estimate on the scores)
     assert boot.r_squared().shape[0] == 3 and boot.total_effects().shape[0] == 8

@@ -2,7 +2,7 @@
 # GPU-box script: everything that goes into profiles/ for one round.  usage: bash tools/gpu_profiles.sh r02
 # bench lines (plain, in-library group/RCCL, launcher), fit bench, non-metric bench, rocprofv3 kernel stats of the headline command,
 # HBM counters (separate --pmc passes, no trace domains), SQ counters of the headline Gram and of the configs[4] Gram.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
@@ -27,6 +27,18 @@ timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INS
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum SQC_ICACHE_REQ SQC_ICACHE_MISSES -d $O/prof_i8_pmc3 -o pmc3 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc3.log 2>&1
 cd $R
 timeout 300 python tools/i8_bench.py 5000 4 2>&1 | grep "^{" > $O/i8_bench.jsonl
+# round 3: the wave solver (A/B against the rows solver, kernel time against the batch size, SQ counters of both), sizes next to the headline,
+# co-scheduling experiments (narrow Gram tiles + two pipelines), ablation probes of the Gram (experiments build, if present)
+timeout 300 python tools/aux_ab.py solver_wave=0,1 2>&1 | grep "^{" > $O/ab_solver_wave.jsonl
+timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
+timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
+timeout 300 python tools/rt_check.py 2>&1 | grep "^{" > $O/i8_rt.jsonl
+timeout 300 python tools/two_pipelines.py 2>&1 | grep "^{" > $O/two_pipelines.jsonl
+timeout 300 python tools/two_pipelines.py i8_rt=8 2>&1 | grep "^{" >> $O/two_pipelines.jsonl
+[ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so timeout 300 python tools/i8_ablate.py 2>&1 | grep "^{" > $O/i8_ablate.jsonl
+[ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks.py > $O/solver_marks.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $O/prof_solver_pmc1 -o p1 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC -d $O/prof_solver_pmc2 -o p2 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_solver_fetch -o f -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/prof_solver_write -o w -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1)
+python tools/pmc_rows.py $O solver > $O/solver_pmc.txt 2>&1
 timeout 300 python tools/aux_ab.py i8_sched=0,1 2>&1 | grep "^{" > $O/ab_stream_k.jsonl
 timeout 300 python tools/aux_ab.py resample_aux=0,1,2,3 2>&1 | grep "^{" > $O/ab_resample_aux.jsonl
 timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench.json
