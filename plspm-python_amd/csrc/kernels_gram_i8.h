@@ -133,23 +133,34 @@ __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict_
 // exchanged between the windows (N = 100,000: two windows, the Philox work of the kernel doubles; the product behind it is 10 x larger
 // than at N = 10,000 anyway).  err bit 0: index out of range, bit 1: a multiplicity above 127 (only possible with explicit indices; the
 // host then falls back to the fp64 Gram).
+// BYTES (Philox draws of data sets beyond one 16-bit window only): 8-bit counters, four rows per LDS word, 131,072 rows per window -- N =
+// 100,000 takes ONE window again (one pass of Philox instead of two) and the histogram already is the output layout.  A Philox count
+// cannot reach 128, let alone carry into its neighbour at 256 (N draws over N >= 65,536 rows: P < 1e-200); explicit index lists CAN carry
+// any multiplicity, so they keep the 16-bit counters (where the overflow bit is reliable).
 #define I8_HIST_KB 1024
+#define I8_HIST_KB_BYTES 2048
+template <bool BYTES>
 __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT, int shape, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
                                                            int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KBw * 32 words: rows 2w, 2w+1 of the window in the halves of word w (zero beyond N)
     const int tid = threadIdx.x;
     const long b = blockIdx.x;
-    const int kb0 = (int)blockIdx.y * I8_HIST_KB, KBw = min(I8_HIST_KB, KB - kb0);
+    constexpr int WKB = BYTES ? I8_HIST_KB_BYTES : I8_HIST_KB;
+    const int kb0 = (int)blockIdx.y * WKB, KBw = min(WKB, KB - kb0);
     const unsigned r0 = (unsigned)kb0 * 64u, rspan = (unsigned)KBw * 64u;      // this window's rows [r0, r0 + rspan)
-    const int nwords = KBw * 32;
+    const int nwords = KBw * (BYTES ? 16 : 32);
+    auto count = [&](unsigned w) {                                               // row r0 + w of the window was drawn
+        if (BYTES) atomicAdd(&hist[w >> 2], 1u << (8u * (w & 3u)));
+        else atomicAdd(&hist[w >> 1], (w & 1u) ? 0x10000u : 1u);
+    };
     for (int i = tid; i < nwords; i += 256) hist[i] = 0u;
     __syncthreads();
     if (idx) {
         const int* my = idx + b * (long)N;
         for (int i = tid; i < N; i += 256) {
             const int r = my[i];
-            if ((unsigned)r < (unsigned)N) { const unsigned w = (unsigned)r - r0; if (w < rspan) atomicAdd(&hist[w >> 1], (w & 1u) ? 0x10000u : 1u); }
+            if ((unsigned)r < (unsigned)N) { const unsigned w = (unsigned)r - r0; if (w < rspan) count(w); }
             else if (blockIdx.y == 0) atomicOr(err, 1);
         }
     } else {
@@ -159,25 +170,30 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
             const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * q + j < N) { const unsigned w = to_index(u.v[j], (uint32_t)N) - r0; if (w < rspan) atomicAdd(&hist[w >> 1], (w & 1u) ? 0x10000u : 1u); }
+                if (4 * q + j < N) { const unsigned w = to_index(u.v[j], (uint32_t)N) - r0; if (w < rspan) count(w); }
         }
     }
     __syncthreads();
     const int mt = (int)(b >> 4), r = (int)(b & 15);
     const uint4* h4 = reinterpret_cast<const uint4*>(hist);
     bool over = false;
-    for (int c = tid; c < KBw * 4; c += 256) {                     // piece c: rows 16c .. 16c+15 of the window = hist words 8c .. 8c+7
-        const uint4 lo = h4[2 * c], hi = h4[2 * c + 1];
-        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        unsigned o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned a = w[2 * k], bb = w[2 * k + 1];
-            over |= ((a | bb) & 0xff80ff80u) != 0u;
-            o[k] = (a & 0xffu) | ((a >> 8) & 0xff00u) | ((bb & 0xffu) << 16) | ((bb << 8) & 0xff000000u);
-        }
+    for (int c = tid; c < KBw * 4; c += 256) {                     // piece c: rows 16c .. 16c+15 of the window = hist words 8c .. 8c+7 (bytes: 4c .. 4c+3)
         uint4 out;
-        out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
+        if (BYTES) {
+            out = h4[c];
+            over |= ((out.x | out.y | out.z | out.w) & 0x80808080u) != 0u;
+        } else {
+            const uint4 lo = h4[2 * c], hi = h4[2 * c + 1];
+            const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned a = w[2 * k], bb = w[2 * k + 1];
+                over |= ((a | bb) & 0xff80ff80u) != 0u;
+                o[k] = (a & 0xffu) | ((a >> 8) & 0xff00u) | ((bb & 0xffu) << 16) | ((bb << 8) & 0xff000000u);
+            }
+            out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
+        }
         const int kb = kb0 + (c >> 2), g = c & 3;
         if (shape == 16) Cd[((long)kb * MT + mt) * 64 + g * 16 + r] = out;
         else Cd[((long)kb * MT + (b >> 5) * 2 + (g >> 1)) * 64 + (g & 1) * 32 + (int)(b & 31)] = out;       // block (tile of 32, half g / 2), piece (g % 2) 32 + row

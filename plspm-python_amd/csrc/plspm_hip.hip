@@ -1032,10 +1032,15 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const bool narrow = m->tune.i8_rt != 16 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7;
     const int RTg = narrow ? m->tune.i8_rt : 16;
     const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = m->zs_npg / 2;
-    const size_t hist_bytes = (size_t)std::min(KB, I8_HIST_KB) * 32 * sizeof(unsigned);
-    const unsigned hist_windows = (unsigned)((KB + I8_HIST_KB - 1) / I8_HIST_KB);      // 65,536 rows of 16-bit counters per workgroup
+    // resample counts from an LDS histogram per (replicate, window of rows): 65,536 rows of 16-bit counters, or -- Philox draws of a data
+    // set that would need more than one such window -- 131,072 rows of 8-bit counters (kernels_gram_i8.h resample_i8_kernel)
+    const bool hist_byte = KB > I8_HIST_KB && !d_idx;
+    const int hist_kb = hist_byte ? I8_HIST_KB_BYTES : I8_HIST_KB;
+    const size_t hist_bytes = (size_t)std::min(KB, hist_kb) * (hist_byte ? 16 : 32) * sizeof(unsigned);
+    const unsigned hist_windows = (unsigned)((KB + hist_kb - 1) / hist_kb);
     int rc;
-    if ((rc = allow_lds(m, (const void*)resample_i8_kernel, hist_bytes))) return rc;
+    if ((rc = allow_lds(m, hist_byte ? (const void*)resample_i8_kernel<true> : (const void*)resample_i8_kernel<false>, hist_bytes))) return rc;
+    const auto resample_k = hist_byte ? resample_i8_kernel<true> : resample_i8_kernel<false>;
     if (m->tune.resample_aux && !m->aux) {
         int lo = 0, hi = 0;
         HIPCHK(m, hipDeviceGetStreamPriorityRange(&lo, &hi));                // (numerically: lowest priority first)
@@ -1058,7 +1063,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         if (m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->aux, m->ev_cdfree[slot], 0));
         {
             ProfScope ps(m, PLSPM_K_RESAMPLE, m->aux);
-            hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
+            hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
         }
         HIPCHK(m, hipEventRecord(m->ev_counts[slot], m->aux));
         HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_counts[slot], 0));
@@ -1066,7 +1071,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         // explicit index lists (test / parity seam) arrive on the main stream: drawn there, and the host looks at the flag
         if (m->aux && m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_cdfree[slot], 0));
         ProfScope ps(m, PLSPM_K_RESAMPLE);
-        hipLaunchKernelGGL(resample_i8_kernel, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
+        hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
     }
     if (d_idx) {
         int* h_err = (int*)m->h_flag + 9;
@@ -1172,7 +1177,9 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers
     const bool need_lists = gpath == 1 || d_idx != nullptr || m->nonmetric;
     const size_t kpad = (size_t)i8_kblocks(N) * 64;
-    const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)std::max<long>(psize, cov_doubles(m->Pg)) * sizeof(double) + (lds_hist ? 0 : (size_t)N * sizeof(unsigned)) +
+    // (the global-scratch histogram serves the (row,count) lists only: the int8 route on Philox draws never builds them)
+    const bool need_ghist = !lds_hist && need_lists;
+    const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)std::max<long>(psize, cov_doubles(m->Pg)) * sizeof(double) + (need_ghist ? (size_t)N * sizeof(unsigned) : 0) +
                            (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0);
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
     if (gpath == 2 && chunk < B) chunk = std::max<int64_t>(256, chunk & ~(int64_t)255);      // whole 256-replicate tiles per pass
@@ -1193,7 +1200,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if ((rc = ensure(m, m->status, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->iters, (size_t)B * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->err, sizeof(int)))) return rc;
-    if (!lds_hist && (rc = ensure(m, m->ghist, (size_t)chunk * N * sizeof(unsigned)))) return rc;
+    if (need_ghist && (rc = ensure(m, m->ghist, (size_t)chunk * N * sizeof(unsigned)))) return rc;
     if (want_dcnt && (rc = ensure(m, m->dcnt, (size_t)chunk * dcnt_stride * sizeof(unsigned short)))) return rc;
     m->dcnt_stride = dcnt_stride; m->dcnt_ready = want_dcnt;
     HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));

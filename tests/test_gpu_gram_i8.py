@@ -284,12 +284,13 @@ def test_persistent_schedule_on_small_and_wide_tile_grids(sizes, B):
     assert np.array_equal(M_t, nm.bootstrap_moments(min(B, 300), seed=2))
 
 
-def test_int8_route_beyond_65535_rows():
-    """the reference has no N limit (bootstrap.py:56-57); the int8 route's resample counts now come from windows of
-    65,536 rows (two per replicate at N = 100,000; every window regenerates the replicate's Philox draws).  Rows vs the oracle on the
-    resampled DATA at the suite's 1e-8, the fp64 route at 1e-10, explicit index lists through the same windows."""
+@pytest.mark.parametrize("N", [100000, 140000])
+def test_int8_route_beyond_65535_rows(N):
+    """the reference has no N limit (bootstrap.py:56-57); the int8 route's resample counts come from LDS histograms
+    over windows of rows -- Philox draws: 8-bit counters, 131,072 rows per window (one window at N = 100,000, two at 140,000; every
+    window regenerates the replicate's draws); explicit index lists: 16-bit counters, 65,536 rows per window.  Rows vs the oracle on
+    the resampled DATA at the suite's 1e-8, the fp64 route at 1e-10, explicit index lists through their windows bit-identical."""
     from plspm import _native
-    N = 100000
     X, blocks = orc.synth(N, orc.satisfaction_C(), 10, seed=21)
     model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
     nm = native_model(model)
@@ -299,7 +300,7 @@ def test_int8_route_beyond_65535_rows():
     corr = orc.correction(N)
     for r in (0, 299):
         idx = _native.bootstrap_indices(4, r, N)
-        assert idx.max() > 65535 and idx.min() < 65535
+        assert idx.max() > max(65535, N - 2000) and idx.min() < 1000
         mine, its = orc.bootstrap_replicate(X, model, idx, corr)
         assert its == iters[r]
         assert_close(rows[r], mine, RTOL, ATOL)
