@@ -237,6 +237,13 @@ struct DevWaveExec : DevExecT<4> {
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         return v;
     }
+    // value of `v` on lane q (q wave-uniform): two v_readlane into scalar registers -- no LDS round trip; `published` serves the CPU emulation
+    __device__ __forceinline__ double bcast(double v, int q, const double*) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), q), __builtin_amdgcn_readlane(__double2loint(v), q));
+    }
+    __device__ __forceinline__ double uniform_d(double v) {                           // a value every lane holds identically -> scalar registers
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
     __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }       // nothing that touches memory moves across
     __device__ __forceinline__ void opaque(int& x) { asm volatile("" : "+v"(x)); }
     __device__ __forceinline__ void opaque(unsigned& x) { asm volatile("" : "+v"(x)); }      // the optimiser may not look through x (no hoisting of what derives from it)

@@ -195,20 +195,22 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
         const double g2 = ss / (np_ - 1.0) * ((n - 1.0) / n);
         fac = 1.0 / (n * g2);
     }
-    // (eight columns per trip, a scheduling fence in front of the loop and between trips: left alone the compiler hoists all 64 LDS
-    // reads of mu above the reductions that produce `fac` -- 128 registers on top of the 128 of s[] -- and spills them to scratch)
+    // mu_q = the column sum lane q holds: a lane broadcast (v_readlane into scalar registers; the CPU emulation reads the published copy).
+    // (eight columns per trip, a scheduling fence in front of the loop and between trips: left alone the compiler hoists the 64
+    // broadcasts above the reductions that produce `fac` and spills them)
     ex.fence();
 #pragma unroll
     for (int q0 = 0; q0 < PMAX; q0 += 8) {
 #pragma unroll
         for (int q = q0; q < q0 + 8; ++q) {
-            const double v = (s[q] - (mup * ws.mu[(q < P) ? q : P - 1]) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q)
+            const double v = (s[q] - (mup * ex.bcast(mup, (q < P) ? q : P - 1, ws.mu)) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q)
             s[q] = (q < P) ? v : 0.0;
         }
         ex.pin8(s[q0], s[q0 + 1], s[q0 + 2], s[q0 + 3], s[q0 + 4], s[q0 + 5], s[q0 + 6], s[q0 + 7]);     // results final before the next loads issue
     }
     const double sdp = sqrt((dpp - (mup * mup) * inv_n) * fac);
-    const double corr2 = n / (n - 1.0);
+    // (loop constants in SCALAR registers: every lane holds the same value; as vector registers they were spilled around the loop)
+    const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);
 
     // LV role: normal equations M[f, f] x = M[f, p] over my predecessors f -- up to four in registers (wave_ldl4: every LV lane runs the
@@ -242,7 +244,7 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     //   phase 0  init (weights.py:28-39): w_p = corr / std1(sum of the block's MVs) = 1 / sqrt(sum(S_bb)) = 1 / sqrt(Q_ll) at w = 1
     //   phase 1  iterations (weights.py:41-54, stop rule weights.py:179-186)
     //   phase 2  the product of the final weights (weights.py:56-70), then out of the loop
-    const double icorr2 = (n - 1.0) / n;
+    const double icorr2 = ex.uniform_d((n - 1.0) / n);
     double Vp[LMAX], Qe = 0.0, wp = mine ? 1.0 : 0.0;
     int iteration = 0, phase = 0;
     while (true) {

@@ -76,6 +76,8 @@ struct HostExec {
     }
     bool vote_any(bool b) { return vote_count(b) > 0; }
     void fence() {}
+    double uniform_d(double v) { return v; }
+    double bcast(double, int q, const double* published) { return published[q]; }
     void opaque(unsigned&) {}
     void opaque(int&) {}
     void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
