@@ -1354,7 +1354,9 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (*h_err & 4) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the persistent Gram gave up waiting for a partial tile (device shared with a long-running kernel?); set_option i8_sched 0");
-    if (*h_err) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    if (*h_err & 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    if (*h_err & 2) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: a resample multiplicity exceeded 127 on the int8 Gram path (set_option gram_path 1)");
+    if (*h_err) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the device reported error bits " + std::to_string(*h_err));
     if (m->err2.p) {                       // Philox draws on the int8 path: a multiplicity above 127 (P < 1e-200) would have wrapped
         HIPCHK(m, hipMemcpyAsync(h_err, m->err2.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
         HIPCHK(m, hipStreamSynchronize(m->stream));

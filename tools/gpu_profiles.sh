@@ -42,6 +42,7 @@ python tools/pmc_rows.py $O solver > $O/solver_pmc.txt 2>&1
 timeout 300 python tools/aux_ab.py i8_sched=0,1 2>&1 | grep "^{" > $O/ab_stream_k.jsonl
 timeout 300 python tools/aux_ab.py resample_aux=0,1,2,3 2>&1 | grep "^{" > $O/ab_resample_aux.jsonl
 timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench.json
+timeout 600 python tools/hoc_bench.py 2>&1 | tail -1 > $O/hoc_bench.json
 ./tools/ubench/valu_issue > $O/ubench_valu_issue.txt 2>&1
 python - "$O" <<'PY'
 import sqlite3, glob, sys, json
