@@ -262,15 +262,18 @@ struct DevWaveExec : DevExecT<4> {
     //      (written row-wise, one row per register; lane p of the pass's 16 lanes reads row p - 16 j: pitch 66 = conflict-free 8-byte
     //      reads, 16-byte aligned rows).
     // Rows / lanes >= P repeat valid entries (finite; the caller zeroes them).
-    template <int PMAX> __device__ __forceinline__ void load_cov(const double* __restrict__ Md, int PS, int P, double (&s)[PMAX], double* stage) {
+    template <int PMAX> __device__ __forceinline__ void load_cov(const double* __restrict__ Md, int PS, int P, double (&s)[PMAX], double* stage, double& mu, double& diag) {
         static_assert(PMAX == 64, "one register per lane of the wave");
-        const int lane = tid, cl = min(lane, P - 1);
+        // (lane P -- when there is one -- takes the ones column: row r of the staging tile then carries the column sum M[r][P] as well, and
+        //  lane p picks its column sum and its diagonal entry out of its own row: no strided loads of 2 x P cache lines per problem)
+        const int lane = tid, cl = min(lane, P);
 #pragma unroll
         for (int r = 0; r < 64; ++r) {
             const int rc = min(r, P - 1);
             const unsigned off = (unsigned)(rc * PS + max(cl, rc)) * 8u;
             s[r] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off);
         }
+        const bool ones_lane = P < 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -278,6 +281,8 @@ struct DevWaveExec : DevExecT<4> {
             __syncthreads();
             if ((lane >> 4) == j) {
                 const double* row = stage + (lane - 16 * j) * 66;
+                diag = row[lane];
+                mu = ones_lane ? row[min(P, 63)] : Md[(long)min(lane, P - 1) * PS + P];
 #pragma unroll
                 for (int q = 16 * j + 1; q < 16 * (j + 1); ++q) s[q] = (q > lane) ? row[q] : s[q];
 #pragma unroll

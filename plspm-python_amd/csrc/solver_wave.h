@@ -176,10 +176,10 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     // 1. moments -> treated covariance (config.py:299-305, util.py:33-39): column p in registers
     ex.mark(0);
     double s[PMAX];
-    double dpp = 0.0, mup = 0.0;
-    if (mine) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; }     // column sums (ones column) and the diagonal
+    double dpp = 0.0, mup = 0.0;                                              // raw M[p][p] and the column sum M[p][P] (ones column)
     const double n = Md[(long)P * PS + P];
-    ex.template load_cov<PMAX>(Md, PS, P, s, ws.stage);
+    ex.template load_cov<PMAX>(Md, PS, P, s, ws.stage, mup, dpp);
+    if (!mine) { mup = 0.0; dpp = 0.0; }
     ex.mark(1);
     ws.mu[p] = mup;
     ws.w[p] = 1.0;                                               // init: block products with w = 1

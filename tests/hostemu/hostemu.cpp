@@ -82,8 +82,10 @@ struct HostExec {
     void opaque(int&) {}
     void pin8(double&, double&, double&, double&, double&, double&, double&, double&) {}
     // column `tid` of the symmetric moment matrix out of its upper triangle (device: coalesced rows + an LDS transpose)
-    template <int PMAX> void load_cov(const double* Md, int PS, int P, double (&s)[PMAX], double*) {
+    template <int PMAX> void load_cov(const double* Md, int PS, int P, double (&s)[PMAX], double*, double& mu, double& diag) {
         for (int q = 0; q < PMAX; ++q) s[q] = (q < P && tid < P) ? Md[(long)(q < tid ? q : tid) * PS + (q < tid ? tid : q)] : 0.0;
+        mu = tid < P ? Md[(long)tid * PS + P] : 0.0;
+        diag = tid < P ? Md[(long)tid * PS + tid] : 0.0;
     }
     template <class F> bool any(int n, F f) {
         double s = 0.0;
