@@ -291,10 +291,10 @@ def test_bench_guard_fixture_is_current():
 
 
 def test_committed_bench_line_follows_the_driver_contract():
-    """profiles/r02c_bench_n1.json (the latest committed line) is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions
+    """profiles/r03_bench_n1.json (the latest committed line) is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions
     (dtype = arithmetic type, vs_baseline null without a published number, config names the workload, roofline + cpu_baseline)."""
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02c_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))
     for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                       ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(line[key], kind), key
@@ -305,6 +305,10 @@ def test_committed_bench_line_follows_the_driver_contract():
     roof = line["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and (roof["traffic"] is None or roof["traffic"] > 0)
+    assert abs(roof["frac_of_measured_ceiling"] - roof["achieved"] / roof["measured_ceiling"]["value"]) < 1e-3 and roof["executed_ops"] >= roof["algorithmic_ops_per_replicate"] * 5000
+    assert line["cold"]["value"] > 0 and line["cold"]["ms_per_step"] >= 0.9 * line["ms_per_step"]
+    cfg = line["config"]
+    assert cfg["transport"] in ("none", "rccl") and cfg["replicate_ranges"][0][0] == 0 and cfg["replicate_ranges"][-1][1] == cfg["replicates_per_step"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert abs(line["value"] - line["config"]["replicates_per_step"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
