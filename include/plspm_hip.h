@@ -95,6 +95,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     (128: half the accumulator registers, two workgroups per CU; measured 2.6 % slower -- kept for co-scheduling experiments)
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
+ *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
+ *                     multiplicities from the int8 counts of the Gram (no second resample kernel / uint16 histograms / (row,count) lists)
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes) and "last_solver"
  * (1 LDS solver, 2 rows solver, 3 wave solver) tell what the last bootstrap call took.
  */

@@ -277,10 +277,34 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 // 16-double columns, not four): 16 rows x 8 waves (used) beat 32 rows x 4 waves by 30 % and 8 rows x 16 waves by 45 %.
 // BLOCKED: the coefficient tile of a 64-replicate group does not fit LDS as a whole (wide models, e.g. 300 indicator columns):
 // it is staged one LV block at a time ((2 kb + 2) x 64 doubles, kb = widest block), with two barriers per block.
-template <int RW, int NW, bool BLOCKED>
+// CNT8 (round 3): the row multiplicities come from the int8 counts the digit-plane Gram already consumed (`Cd`, fragment-major:
+// k-block of 64 rows x replicate tile of 16 -> [g 0..3][r 0..15][16 B]; the 16 rows of Xt tile t are piece g = t % 4 of k-block t / 4) --
+// 16 bytes per (replicate, tile), lanes of 16 consecutive replicates read 256 contiguous bytes -- instead of a second, uint16 histogram
+// that a second resample kernel had to write (20 KB per replicate).  dcnt_stride then carries MT (replicate tiles of the counts).
+template <int RW, int NW, bool BLOCKED, bool CNT8 = false>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
                                                                  const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
                                                                  long nproblems, double* __restrict__ partial, int nparts, int rbx, int gy, int kb) {
+    static_assert(!CNT8 || RW == 16, "the int8 counts come in pieces of 16 rows");
+    // multiplicities of this wave's RW rows in replicate b: packed words (uint16 pairs, or bytes of the int8 counts)
+    auto load_counts = [&](unsigned (&wq)[RW / 2], bool on, long b, long part) {
+        if (CNT8) {
+            const uint4* cd = reinterpret_cast<const uint4*>(dcnt);
+            const uint4 c = on ? cd[((part >> 2) * dcnt_stride + (b >> 4)) * 64 + (part & 3) * 16 + (b & 15)] : make_uint4(0, 0, 0, 0);
+            wq[0] = c.x; wq[1] = c.y; wq[2] = c.z; wq[3] = c.w;
+        } else {
+            const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (on ? b : 0) * dcnt_stride + (on ? part : 0) * RW);
+#pragma unroll
+            for (int h = 0; h < RW / 8; ++h) {
+                const uint4 c = on ? cp[h] : make_uint4(0, 0, 0, 0);
+                wq[4 * h] = c.x; wq[4 * h + 1] = c.y; wq[4 * h + 2] = c.z; wq[4 * h + 3] = c.w;
+            }
+        }
+    };
+    auto count_of = [&](const unsigned (&wq)[RW / 2], int r) -> double {
+        if (CNT8) return (double)((wq[r >> 2] >> (8 * (r & 3))) & 0xffu);
+        return (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* co = reinterpret_cast<double*>(smem_raw);           // [2P + 2L + 1][64]   (BLOCKED: [2 kb + 2][64])
     constexpr int PER_TILE = 16 / RW;                           // row parts per 16-row tile of Xt
@@ -309,14 +333,7 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
             const long b = (long)g * 64 + lane;
             const bool live = b < nproblems;
             unsigned wq[RW / 2];
-            {
-                const uint4* cp = reinterpret_cast<const uint4*>(dcnt + ((live && have) ? b : 0) * dcnt_stride + (have ? part : 0) * RW);
-#pragma unroll
-                for (int h = 0; h < RW / 8; ++h) {
-                    const uint4 c = (live && have) ? cp[h] : make_uint4(0, 0, 0, 0);
-                    wq[4 * h] = c.x; wq[4 * h + 1] = c.y; wq[4 * h + 2] = c.z; wq[4 * h + 3] = c.w;
-                }
-            }
+            load_counts(wq, live && have, b, part);
             const double* tg = table + (long)g * rows * 64;
             double* bcn = co + (long)kb * 64;                   // [kb][64] new coefficients, then k_old[64], k_new[64]
             double* bk = bcn + (long)kb * 64;
@@ -361,7 +378,7 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
                     const double d = fabs(ao[r]) - fabs(an[r]);
-                    const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
+                    const double w = count_of(wq, r);
                     acc = fma(w * d, d, acc);
                 }
             }
@@ -376,15 +393,8 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
         const long b = (long)g * 64 + lane;
         if (!have) continue;
         const bool live = b < nproblems;
-        unsigned wq[RW / 2];                                    // two uint16 counts per word
-        {
-            const uint4* cp = reinterpret_cast<const uint4*>(dcnt + (live ? b : 0) * dcnt_stride + part * RW);
-#pragma unroll
-            for (int h = 0; h < RW / 8; ++h) {
-                const uint4 c = live ? cp[h] : make_uint4(0, 0, 0, 0);
-                wq[4 * h] = c.x; wq[4 * h + 1] = c.y; wq[4 * h + 2] = c.z; wq[4 * h + 3] = c.w;
-            }
-        }
+        unsigned wq[RW / 2];                                    // two uint16 counts (or four int8 counts) per word
+        load_counts(wq, live, b, part);
         double acc = 0.0;
         // Column loop, software-pipelined by hand (hipcc sinks a C++ prefetch below the FMAs and waits right after issuing it):
         // the loads of column p + 1 -- one or two s_load_dwordx16 for the x values, two ds_read_b64 for the lane's coefficients --
@@ -426,7 +436,7 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 const double d = fabs(ao[r]) - fabs(an[r]);
-                const double w = (double)((r & 1) ? (wq[r >> 1] >> 16) : (wq[r >> 1] & 0xffffu));
+                const double w = count_of(wq, r);
                 acc = fma(w * d, d, acc);
             }
         }

@@ -521,8 +521,25 @@ static size_t nm_state_doubles_of(const plspm_model* m) {
                           : m->nmx_K > 0 ? (size_t)nmx_state_doubles(m->P, m->L, m->n_chol, m->nmx_K) : (size_t)nm_state_doubles(m->P, m->L, m->n_chol);
 }
 
+// LDS footprint of the dense stop-rule pass (nm_conv_dense_kernel) for this handle: the coefficient tile of 64 replicates whole, or one LV
+// block at a time; 0 when neither fits or the option forbids the pass
+static size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out) {
+    const plspm_model* src = m->stage1 ? m->stage1 : m;
+    const int table_rows = 2 * src->P + 2 * m->L + 1;
+    const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
+    const std::vector<int>& conv_blocks = m->stage1 ? m->lv_cols : m->boff;
+    int kb = 1;
+    for (int l = 0; l < m->L; ++l) kb = std::max(kb, conv_blocks[l + 1] - conv_blocks[l]);
+    const bool w = dense_lds <= kMaxLds && m->tune.conv_pass != 2;            // (option conv_pass = 2 forces the blocked variant: tests)
+    const size_t use = w ? dense_lds : (size_t)(2 * kb + 2) * 64 * sizeof(double);
+    if (whole) *whole = w;
+    if (kb_out) *kb_out = kb;
+    return (use <= kMaxLds && m->tune.conv_pass != 1) ? use : 0;
+}
+
+// cd8 / cd8_MT: the int8 row multiplicities of THESE problems (the counts the digit-plane Gram consumed; bootstrap only), or null
 static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, const int2* ent, const int* nent,
-                         long ent_stride, int threads, bool finish = true) {
+                         long ent_stride, int threads, bool finish = true, const void* cd8 = nullptr, int cd8_MT = 0) {
     const int P = m->P, L = m->L;
     plspm_model* src = m->stage1 ? m->stage1 : m;                // an attached second stage streams its first stage's data (solver_hoc.h)
     const long N = src->N;
@@ -534,22 +551,22 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     // tile of 64 replicates fits LDS; otherwise (and for a single fit) the gathering pass
     const long ntiles16 = (N + 15) / 16;
     const int table_rows = 2 * src->P + 2 * L + 1;
-    const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
     // coefficient tile of 64 replicates: whole in LDS when it fits, else one LV block at a time (kb = widest block of the map the pass uses)
-    const std::vector<int>& conv_blocks = m->stage1 ? m->lv_cols : m->boff;
+    bool dense_whole = false;
     int kb = 1;
-    for (int l = 0; l < L; ++l) kb = std::max(kb, conv_blocks[l + 1] - conv_blocks[l]);
-    const bool dense_whole = dense_lds <= kMaxLds && m->tune.conv_pass != 2;            // (option conv_pass = 2 forces the blocked variant: tests)
-    const size_t dense_blocked_lds = (size_t)(2 * kb + 2) * 64 * sizeof(double);
-    const size_t dense_use_lds = dense_whole ? dense_lds : dense_blocked_lds;
-    const bool dense = ent && src->dcnt_ready && dense_use_lds <= kMaxLds && m->tune.conv_pass != 1;
+    const size_t dense_use_lds = nm_dense_lds(m, &dense_whole, &kb);
+    // the replicates' row multiplicities: the int8 counts of the digit-plane Gram (round 3) or the uint16 histograms of resample_kernel
+    const bool counts8 = cd8 != nullptr;
+    const bool dense = dense_use_lds != 0 && (counts8 || (ent && src->dcnt_ready));
+    if (counts8 && !dense) return fail(m, PLSPM_E_STATE, "non-metric bootstrap: the dense stop-rule pass does not fit and no (row,count) lists were built");
     const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     const int ngroups = (int)((nproblems + 63) / 64);
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
         if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
-        if (dense_whole ? (rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8, false>, dense_use_lds)) : (rc = allow_lds(m, (const void*)nm_conv_dense_kernel<16, 8, true>, dense_use_lds)))
-            return rc;
+        const void* ck = counts8 ? (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, true> : (const void*)nm_conv_dense_kernel<16, 8, true, true>)
+                                 : (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, false> : (const void*)nm_conv_dense_kernel<16, 8, true, false>);
+        if ((rc = allow_lds(m, ck, dense_use_lds))) return rc;
         if (!src->Xt_valid) {
             hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, (double*)src->Xt.p);
             src->Xt_valid = true;
@@ -629,9 +646,11 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 // replicate slices: one group of 64 replicates per workgroup measured best (1.06 ms for three passes against 1.17 / 1.21 /
                 // 1.28 with 12 / 6 / 13 slices): many small workgroups let the dispatcher balance the CUs
                 const int gy = m->tune.conv_gy > 0 ? m->tune.conv_gy : ngroups;
-                auto conv_kernel = dense_whole ? nm_conv_dense_kernel<16, 8, false> : nm_conv_dense_kernel<16, 8, true>;
+                auto conv_kernel = counts8 ? (dense_whole ? nm_conv_dense_kernel<16, 8, false, true> : nm_conv_dense_kernel<16, 8, true, true>)
+                                           : (dense_whole ? nm_conv_dense_kernel<16, 8, false, false> : nm_conv_dense_kernel<16, 8, true, false>);
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
-                                   conv_boff, (const unsigned short*)src->dcnt.p, src->dcnt_stride, (const double*)m->ctable.p, ngroups, nproblems, part, nparts, rbx, gy, kb);
+                                   conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
+                                   (const double*)m->ctable.p, ngroups, nproblems, part, nparts, rbx, gy, kb);
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
                                    ent_stride, conv_state, conv_stride, part);
@@ -674,6 +693,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_rt") { if (value != 16 && value != 8) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
+    else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
@@ -701,6 +721,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
     else if (k == "solver_wave") *value = m->tune.solver_wave;
+    else if (k == "nm_counts8") *value = m->tune.nm_counts8;
     else if (k == "last_solver") *value = m->last_solver;
     else if (k == "resample_aux") *value = m->tune.resample_aux;
     else if (k == "i8_sched") *value = m->tune.i8_sched;
@@ -1025,8 +1046,10 @@ static int prepare_zs(plspm_model* m) {
 // Resample nb replicates into dense int8 counts and multiply with the digit planes: the nb moment matrices land at `out`.
 // Explicit indices can carry a multiplicity above 127 (Philox draws of N >= 128 rows cannot, P < 1e-200): the host looks at the
 // flag before the product and reports *fallback so that the caller takes the fp64 Gram for this chunk.
-static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback) {
+static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback,
+                       const void** counts = nullptr, int* counts_MT = nullptr) {
     *fallback = false;
+    if (counts) *counts = nullptr;
     const int S = m->zs_S, KB = m->zs_KB, NT = m->zs_NT;
     // workgroup tile of the product: 16 RT replicates x 32 pairs; narrow tiles (RT 12 / 8) only in the plain four-wave 16x16x64 launch
     const bool narrow = m->tune.i8_rt != 16 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7;
@@ -1085,6 +1108,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
             return 0;
         }
     }
+    if (counts && m->tune.i8_shape == 16) { *counts = cd.p; *counts_MT = MT; }       // (16-row pieces: what nm_conv_dense_kernel<.., CNT8> reads)
     const int total = ntx * nty, per = (total + 7) / 8;
     // packed: the tile-packed slots the LDS solver / impute kernel read; dense: [(Pg+1) x cov_ld(Pg)] row-major, upper triangle (rows solver)
     const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
@@ -1165,7 +1189,13 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const long ent_stride = ((N + 3) & ~3L) + 4;
     // replicates per pass: bound the (row,count) + Gram scratch to ~2 GiB
     // non-metric solvers: dense uint16 histograms for the dense stop-rule pass (LDS-histogram path only)
-    const bool want_dcnt = m->nonmetric && lds_hist;
+    // non-metric models on the int8 route with Philox draws (round 3): the dense stop-rule pass reads its row multiplicities from the int8
+    // counts the Gram consumed -- no second resample kernel, no (row,count) lists, no uint16 histograms (set_option "nm_counts8" 0: the
+    // round-2 path, kept for A/B and for the cases below)
+    const int gpath_plan = choose_gram_path(m, B);
+    const bool counts8_plan = m->nonmetric && gpath_plan == 2 && !d_idx && m->tune.nm_counts8 != 0 && m->tune.resample_aux == 0 && !m->aux && m->tune.i8_shape == 16 &&
+                              m->nmx_K == 0 && nm_dense_lds(m, nullptr, nullptr) != 0 && (!m->stage2 || nm_dense_lds(m->stage2, nullptr, nullptr) != 0);
+    const bool want_dcnt = m->nonmetric && lds_hist && !counts8_plan;
     const long dcnt_stride = ((N + 15) & ~15L);
     const int gpath = choose_gram_path(m, B);
     m->last_gram_path = gpath;
@@ -1175,7 +1205,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const size_t rows_lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
     const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && m->P <= 64 && !m->n_ind && !m->nonmetric && !m->moments_out && rows_lds <= kMaxLds / 4;
     // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers
-    const bool need_lists = gpath == 1 || d_idx != nullptr || m->nonmetric;
+    const bool need_lists = gpath == 1 || d_idx != nullptr || (m->nonmetric && !counts8_plan);
     const size_t kpad = (size_t)i8_kblocks(N) * 64;
     // (the global-scratch histogram serves the (row,count) lists only: the int8 route on Philox draws never builds them)
     const bool need_ghist = !lds_hist && need_lists;
@@ -1208,12 +1238,15 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
         bool f64_gram = gpath == 1;
+        const void* cd8 = nullptr;
+        int cd8_MT = 0;
         if (gpath == 2) {
             bool fallback = false;
-            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback))) return rc;
+            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback, &cd8, &cd8_MT))) return rc;
             f64_gram = fallback;
         }
-        if (f64_gram || m->nonmetric) {            // (row,count) lists (+ dense uint16 histograms): the same draws as the int8 counts
+        if (!counts8_plan) cd8 = nullptr;
+        if (f64_gram || (m->nonmetric && !counts8_plan)) {            // (row,count) lists (+ dense uint16 histograms): the same draws as the int8 counts
             if (lds_hist) {
                 const size_t hist_bytes = (size_t)((N + 1) / 2) * sizeof(unsigned);
                 if ((rc = allow_lds(m, (const void*)resample_kernel, hist_bytes))) return rc;
@@ -1243,7 +1276,9 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             // stage 2 on the second handle's descriptors with the convergence pass streaming THIS handle's data
             plspm_model* m2 = m->stage2;
             const long psize2 = packed_size(m2->Ts);
-            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, SolverOut{}, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128, false))) return rc;
+            const int2* ent_l = need_lists ? (const int2*)m->ent.p : nullptr;
+            const int* nent_l = need_lists ? (const int*)m->nent.p : nullptr;
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, SolverOut{}, ent_l, nent_l, ent_stride, 128, false, cd8, cd8_MT))) return rc;
             if ((rc = ensure(m, m2->gram, (size_t)nb * psize2 * sizeof(double)))) return rc;
             const HocDesc hd = make_hoc_desc(m2);
             const size_t vlds = std::max<size_t>(1, (size_t)hd.nh * (hd.P1 + 1)) * sizeof(double);
@@ -1253,7 +1288,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
                 hipLaunchKernelGGL(hoc_moments_kernel, dim3((unsigned)nb), dim3(256), vlds, m->stream, hd, (const double*)m->gram.p, psize, (const double*)m->nmstate.p,
                                    (long)nm_state_doubles_of(m), (double*)m2->gram.p, psize2);
             }
-            rc = run_nonmetric(m2, nb, (const double*)m2->gram.p, psize2, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, 128);
+            rc = run_nonmetric(m2, nb, (const double*)m2->gram.p, psize2, so, ent_l, nent_l, ent_stride, 128, true, cd8, cd8_MT);
             if (rc) return fail(m, rc, "second stage: " + m2->error);
             continue;
         }
@@ -1261,7 +1296,8 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             // threads per problem by model width (measured: 60 columns 0.60 / 0.64 / 0.81 ms with 64 / 128 / 256 threads; 300 indicator
             // columns 21.0 / 13.5 / 10.0 ms)
             const int nm_threads = m->tune.nm_threads > 0 ? m->tune.nm_threads : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));
-            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (const int2*)m->ent.p, (const int*)m->nent.p, ent_stride, nm_threads))) return rc;
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, need_lists ? (const int2*)m->ent.p : nullptr, need_lists ? (const int*)m->nent.p : nullptr, ent_stride,
+                                    nm_threads, true, cd8, cd8_MT))) return rc;
             continue;
         }
 #ifdef PLSPM_DEBUG_MARKS      // phase clocks of one solver problem (tools/gpu_marks.sh builds with -DPLSPM_DEBUG_MARKS); never in the release library

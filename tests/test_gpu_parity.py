@@ -655,6 +655,19 @@ def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
         assert np.array_equal(dense[1], other[1]) and np.array_equal(dense[2], other[2])
         assert_close(dense[0], other[0], 1e-12, 1e-14)
     assert np.all(dense[1] == 0) and dense[2].min() >= 2
+    # round 3: the dense pass reads the row multiplicities from the int8 counts of the digit-plane Gram (no second resample kernel, no
+    # uint16 histograms, no (row,count) lists); nm_counts8 = 0 is the round-2 route.  Same weights, same sums: bit-identical records,
+    # whole and block-staged coefficient tiles alike; and a FIT after a bootstrap must not pick up the last replicate's counts.
+    assert nm.get_option("nm_counts8") == 1 and nm.get_option("last_gram_path") == 2
+    nm.set_option("nm_counts8", 0)
+    old_route = nm.bootstrap(130, seed=2)
+    nm.set_option("conv_pass", 2)
+    old_blocked = nm.bootstrap(130, seed=2)
+    nm.set_option("conv_pass", 0); nm.set_option("nm_counts8", 1)
+    for a, b in ((dense, old_route), (blocked, old_blocked)):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    again = nm.fit(want_scores=False)
+    assert again["status"] == 0 and again["iterations"] == _["iterations"] and np.array_equal(again["weights"], _["weights"])
 
 
 def test_nonmetric_bootstrap_10k_vs_oracle_spot_checks():
