@@ -79,7 +79,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "i8_slices"       5 .. 8   digit planes per pair product (default 7: >= 53 significant bits of the column maximum)
  *   "i8_min_batch"    auto mode takes the int8 path from this many replicates per call (default 1: always -- the path must not
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
- *   "i8_waves"        4 | 8   waves per workgroup of the int8 Gram (default 4: one per SIMD, 128 replicates x 16 pairs each; 8: two per SIMD)
+ *   "i8_waves"        4 | 8   waves per workgroup of the int8 Gram (4: one per SIMD, 128 replicates x 16 pairs each; default 8: two per SIMD, 64 x 16 each -- 1.5 % faster steps in alternating A/B runs)
  *   "i8_shape"        16 (default) | 32   MFMA shape / fragment-block layout of the int8 Gram (32: v_mfma_i32_32x32x32_i8, measured 16 % slower)
  *   "i8_sched"        0 (default) | 1   int8 Gram as a persistent "stream-K" launch: one workgroup per CU, the tiles of the whole rounds
  *                     + an equal share of the left-over tiles' k-steps each, exact int32 partial sums handed to the tile's owner through
@@ -91,13 +91,15 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     the draws of the next call fill CUs the Gram / solver of this one leave idle (+-2 %: measured neutral)
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
+ *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the int8 Gram: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
+ *                     ... lds (per-workgroup descriptors + 32-bit offsets: ~3 % faster; auto takes it whenever an operand's walk stays below 4 GiB)
  *   "i8_rt"           16 (default) | 8   count tiles (16 replicates each) per workgroup of the int8 Gram: 256 or 128 replicates x 32 pairs
  *                     (128: half the accumulator registers, two workgroups per CU; measured 2.6 % slower -- kept for co-scheduling experiments)
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
  *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
  *                     multiplicities from the int8 counts of the Gram (no second resample kernel / uint16 histograms / (row,count) lists)
- * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes) and "last_solver"
+ * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
  * (1 LDS solver, 2 rows solver, 3 wave solver) tell what the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);

@@ -250,6 +250,13 @@ struct GramI8 {
     // VAR >= 100 (experiments build only): ABLATIONS of the default schedule V = VAR % 100 -- timing probes whose results are garbage:
     // bit 0 of VAR / 100: no LDS-DMA issue in the steady state, bit 1: no workgroup barrier, bit 2: no fragment reads
     static constexpr int ABL = (VAR / 100) & 7, V = VAR % 100;
+    // VAR >= 800: the LDS-DMA as a MUBUF instruction, `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`, instead of the FLAT-global form
+    // `global_load_lds_dwordx4 v_off, s[base]`: one descriptor per operand whose base is the workgroup's first block, 32-bit byte offsets
+    // (the host takes this form whenever both operands' walks stay below 4 GiB).  Alternating A/B at working clocks: 0.4494 -> 0.4473 ms
+    // with eight waves (all three rounds in favour), within the noise with four (profiles/r03_i8_dma_form.jsonl) -- the descriptor
+    // form saves the 64-bit address VALU adds, not the issue slot.
+    static constexpr int BUFM = VAR / 800;
+    static_assert(BUFM == 0 || (SH == 16 && RT % NW == 0), "buffer form: 16x16x64 layout, count blocks dealt evenly to the waves");
     static constexpr bool PAIRB = V >= 18 && 5 * STAGE_BYTES <= 160 * 1024;
     static constexpr int NS_WANT = PAIRB ? 5 : 3 + V % 3, NS = NS_WANT * STAGE_BYTES <= 160 * 1024 ? NS_WANT : (160 * 1024) / STAGE_BYTES;      // LDS stages of the DMA ring
     static constexpr int RSTEP = 1 + (V / 3) % 3, DMA_HEAD = (V % 18) / 9;
@@ -311,8 +318,32 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
 #pragma unroll
         for (int i = 0; i < G::PER; ++i) src[i] += inc[i];
     };
+    // buffer form: rsA / rsB address the workgroup's count tiles / digit blocks of k-step 0; src[] then holds byte OFFSETS (< 4 GiB)
+    i32x4 rsA = {0, 0, 0, 0}, rsB = {0, 0, 0, 0};
+    if constexpr (G::BUFM != 0) {
+        const unsigned long long bA = (unsigned long long)(Cd + (long)ty * RT * 64), bB = (unsigned long long)(Zs + (long)tx * 2 * S * 64);
+        rsA[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bA); rsA[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(bA >> 32) & 0xffffu));
+        rsB[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bB); rsB[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(bB >> 32) & 0xffffu));
+        rsA[2] = rsB[2] = (int)0xffffffffu;                      // num_records (bytes, stride 0): the 32-bit offsets are always in range
+        rsA[3] = rsB[3] = 0x00027000;                            // dst_sel xyzw, 32-bit data format (raw buffer)
+#pragma unroll
+        for (int i = 0; i < G::PER; ++i) {
+            const int b = min(wave + G::NW * i, G::NBLK - 1);
+            src[i] = (const char*)(unsigned long long)((unsigned)(b < RT ? b : b - RT) * 1024u);
+        }
+    }
     auto issue_one = [&](int i, unsigned stage_off) {
-        if (i < G::PER - 1 || full) glds_block(src[i], voff, dst[i] + stage_off);
+        if (i < G::PER - 1 || full) {
+            if constexpr (G::BUFM == 0) glds_block(src[i], voff, dst[i] + stage_off);
+            else {
+                // (block wave + NW i of the k-step: a count tile for i < RT / NW, else a digit block -- except that the LAST slot of a wave
+                //  without a block of its own repeats block NBLK - 1, a digit block)
+                const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)src[i]);
+                const unsigned ld = dst[i] + stage_off;
+                if (i < RT / G::NW) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsA), "s"(so), "s"(ld) : "memory");
+                else asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsB), "s"(so), "s"(ld) : "memory");
+            }
+        }
     };
     // Fragment reads and MFMAs are asm statements (fixed order, nothing counted by the compiler):
     //  * accumulators constrained to AGPRs ("+a"): with the builtin hipcc kept a third of the 224 accumulator registers in VGPRs and

@@ -697,7 +697,8 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
-    else if (k == "i8_variant") { if (value < -1 || value > 799) return bad(); m->tune.i8_variant = value; }
+    else if (k == "i8_variant") { if (value < -1 || value > 899) return bad(); m->tune.i8_variant = value; }
+    else if (k == "i8_dma") { if (value < 0 || value > 2) return bad(); m->tune.i8_dma = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
@@ -719,6 +720,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
+    else if (k == "i8_dma") *value = m->tune.i8_dma;
+    else if (k == "last_i8_dma") *value = m->last_i8_dma;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
     else if (k == "solver_wave") *value = m->tune.solver_wave;
     else if (k == "nm_counts8") *value = m->tune.nm_counts8;
@@ -1128,6 +1131,10 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
             m->sk_epoch = 0;
         }
     }
+    // the buffer form of the LDS-DMA needs every byte offset of a workgroup's walk (incl. the slack k-blocks) below 4 GiB
+    const bool dma_fits = (uint64_t)(KB + I8_SLACK_KB) * (uint64_t)std::max(MT, NT) * 1024ull < (1ull << 32);
+    const bool dma_buffer = m->tune.i8_dma != 1 && dma_fits && m->tune.i8_shape == 16 && !sk && !narrow && m->tune.i8_variant < 0;
+    m->last_i8_dma = dma_buffer ? 2 : 1;
     ProfScope ps(m, PLSPM_K_GRAM);
 #define GI8SK(SS, WW)                                                                                                                        \
     {                                                                                                                                        \
@@ -1150,9 +1157,10 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     }
 #define GI8V(SS, WW, VV) GI8VS(SS, WW, VV, 16)
 #define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
+#define GI8B(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR + 800)
 #ifdef PLSPM_I8_EXPERIMENTS       // every schedule variant of the 7-plane kernel (tools/i8_bench.py --variants; not in the release library)
 #define GI8X(WW) switch (m->tune.i8_variant) { case 0: GI8V(7, WW, 0) break; case 3: GI8V(7, WW, 3) break; case 6: GI8V(7, WW, 6) break; case 4: GI8V(7, WW, 4) break; \
-        case 103: GI8V(7, WW, 103) break; case 203: GI8V(7, WW, 203) break; case 303: GI8V(7, WW, 303) break; case 403: GI8V(7, WW, 403) break; case 503: GI8V(7, WW, 503) break; case 703: GI8V(7, WW, 703) break; \
+        case 803: GI8V(7, WW, 803) break; case 103: GI8V(7, WW, 103) break; case 203: GI8V(7, WW, 203) break; case 303: GI8V(7, WW, 303) break; case 403: GI8V(7, WW, 403) break; case 503: GI8V(7, WW, 503) break; case 703: GI8V(7, WW, 703) break; \
         case 12: GI8V(7, WW, 12) break; case 18: GI8V(7, WW, 18) break; case 21: GI8V(7, WW, 21) break; case 24: GI8V(7, WW, 24) break; case 30: GI8V(7, WW, 30) break; default: GI8V(7, WW, 33) break; }
     if (S == 7 && m->tune.i8_variant >= 0) { if (m->tune.i8_waves == 4) GI8X(2) else GI8X(4) } else
 #endif
@@ -1168,11 +1176,16 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     if (m->tune.i8_shape == 32) {              // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
         switch (S) { case 5: GI8VS(5, 2, I8_DEFAULT_VAR, 32) break; case 6: GI8VS(6, 2, I8_DEFAULT_VAR, 32) break; case 7: GI8VS(7, 2, I8_DEFAULT_VAR, 32) break; default: GI8VS(8, 2, I8_DEFAULT_VAR, 32) break; }
     } else
+    if (dma_buffer) {            // LDS-DMA as buffer_load ... lds (32-bit offsets from per-workgroup descriptors)
+        if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8B(5, 2) break; case 6: GI8B(6, 2) break; case 7: GI8B(7, 2) break; default: GI8B(8, 2) break; } }
+        else { switch (S) { case 5: GI8B(5, 4) break; case 6: GI8B(6, 4) break; case 7: GI8B(7, 4) break; default: GI8B(8, 4) break; } }
+    } else
     if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8(5, 2) break; case 6: GI8(6, 2) break; case 7: GI8(7, 2) break; default: GI8(8, 2) break; } }
     else { switch (S) { case 5: GI8(5, 4) break; case 6: GI8(6, 4) break; case 7: GI8(7, 4) break; default: GI8(8, 4) break; } }
 #undef GI8V
 #undef GI8VS
 #undef GI8
+#undef GI8B
     HIPCHK(m, hipGetLastError());
     if (m->aux) { HIPCHK(m, hipEventRecord(m->ev_cdfree[slot], m->stream)); m->cdfree_set[slot] = true; }     // the counts buffer is free once this Gram has run
     return 0;

@@ -335,3 +335,28 @@ def test_int8_route_with_120_mvs_and_12_lvs():
         rows64, _, iters64 = nm.bootstrap(260, seed=6)
         assert np.array_equal(iters, iters64)
         assert_close(rows, rows64, 1e-10, 1e-13)
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_buffer_form_of_the_lds_dma_gives_identical_matrices(waves):
+    """i8_dma: the k-step blocks travel global -> LDS by `buffer_load_dwordx4 ... lds` (per-workgroup descriptors, 32-bit offsets;
+    the default whenever an operand's walk stays below 4 GiB) or by `global_load_lds_dwordx4` (64-bit base per block).  Same bytes to
+    the same LDS places: moment matrices and rows are bit-identical, ragged tile grids included."""
+    C = orc.chain_C(7)
+    X, blocks = orc.synth(777, C, 5, seed=2)
+    model = orc.Model(blocks, C, "ABABABA", "factorial", True)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.set_option("i8_waves", waves)
+    for B in (1, 300, 2100):
+        rows_b = nm.bootstrap(B, seed=7)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_dma") == 2
+        M_b = nm.bootstrap_moments(min(B, 300), seed=7)
+        nm.set_option("i8_dma", 1)
+        rows_g = nm.bootstrap(B, seed=7)
+        assert nm.get_option("last_i8_dma") == 1
+        M_g = nm.bootstrap_moments(min(B, 300), seed=7)
+        nm.set_option("i8_dma", 0)
+        assert np.array_equal(M_b, M_g)
+        for a, b in zip(rows_b, rows_g):
+            assert np.array_equal(a, b)
