@@ -178,7 +178,8 @@ def api_inclusive(X, reps, pairs=7):
         keep = h                                     # the previous handle stays alive while the next one is built, as in the loop above
     standalone = float(np.median(alone[2:]))
     diff = float(np.median(diffs))
-    bound = max(diff, standalone)
+    latency = float(np.median(inner))
+    bound = max(latency, standalone)
     return {"value": round(reps / bound, 1), "unit": "replicates/s",
             "standalone_ms": round(standalone * 1e3, 3), "paired_difference_ms": round(diff * 1e3, 3),
             "bootstrap_tail_ms": round(float(np.median(tails)) * 1e3, 3), "bootstrap_latency_ms": round(float(np.median(inner)) * 1e3, 3),
@@ -187,7 +188,11 @@ def api_inclusive(X, reps, pairs=7):
             "note": "paired_difference_ms = median over %d pairs of [wall of Plspm(bootstrap=True, bootstrap_iterations=%d)] - [wall of Plspm()] (the replicates "
                     "are enqueued right after the fit; the pandas report frames are built on access); bootstrap_tail_ms / bootstrap_latency_ms = Plspm.timings(); "
                     "standalone_ms = the same bootstrap on a fresh handle behind upload + plspm_bootstrap_prepare + fit, nothing overlapped (enqueue -> "
-                    "kernels -> device summaries -> %d x 6 table on the host); value = replicates / max(paired_difference_ms, standalone_ms); rows stay in HBM" % (pairs, reps, 156)}
+                    "kernels -> record transpose + device summaries -> %d x 6 table on the host, one stream synchronise); bootstrap_latency_ms = the same span "
+                    "measured inside Plspm(bootstrap=True) (enqueue of the replicates -> summaries on the host; Plspm.timings()); value = replicates / "
+                    "max(bootstrap_latency_ms, standalone_ms) -- the bootstrap's own critical path, nothing credited for what the host does meanwhile; "
+                    "paired_difference_ms is the wall-time difference of two ~8 ms calls and scatters by more than the 0.7 ms it tries to resolve "
+                    "(informational); rows stay in HBM" % (pairs, reps, 156)}
 
 
 def main():
@@ -472,6 +477,8 @@ def main():
                                       "note": "plspm_bootstrap(): the B x 158 records copied to the caller's (pageable, re-used) host buffers through pinned staging every step"}
         if world == 1 and group is None and not args.no_api:
             line["api_inclusive"] = api_inclusive(X, args.reps_per_gpu)
+            line["api_inclusive"]["frac_of_value"] = round(line["api_inclusive"]["value"] / line["value"], 3)
+            line["api_inclusive"]["frac_of_cold_value"] = round(line["api_inclusive"]["value"] / line["cold"]["value"], 3)      # (an API call starts on an idle device, as `cold` does)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

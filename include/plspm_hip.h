@@ -92,7 +92,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
  *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the int8 Gram: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
- *                     ... lds (per-workgroup descriptors + 32-bit offsets: ~3 % faster; auto takes it whenever an operand's walk stays below 4 GiB)
+ *                     ... lds (per-workgroup descriptors + 32-bit offsets: 0.4 % faster; auto takes it whenever an operand's walk stays below 4 GiB)
  *   "i8_rt"           16 (default) | 8   count tiles (16 replicates each) per workgroup of the int8 Gram: 256 or 128 replicates x 32 pairs
  *                     (128: half the accumulator registers, two workgroups per CU; measured 2.6 % slower -- kept for co-scheduling experiments)
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed

@@ -231,12 +231,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PLSPM_R
 // Wave variant (solver_wave.h solve_problem_wave): ONE wave per problem with fixed lane roles -- the bootstrap solver of metric Mode-A
 // models with at most 64 MVs and 8 LVs.  Executor = the rows executor + the wave primitives.
 struct DevWaveExec : DevExecT<4> {
-    // butterfly sum: every lane ends with bitwise the same value (a + b == b + a at every level)
-    __device__ __forceinline__ double allsum(double v) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        return v;
-    }
+    // butterfly sum (lane ^ 1, 2, ... 32; wave_ops.h: DPP + permlane swaps, no LDS crossbar): every lane ends with bitwise the same value
+    __device__ __forceinline__ double allsum(double v) { return wv::allsum(v); }
     // value of `v` on lane q (q wave-uniform): two v_readlane into scalar registers -- no LDS round trip; `published` serves the CPU emulation
     __device__ __forceinline__ double bcast(double v, int q, const double*) {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), q), __builtin_amdgcn_readlane(__double2loint(v), q));

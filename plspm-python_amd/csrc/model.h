@@ -45,7 +45,7 @@ struct plspm_model {
     double* d_Xa = nullptr;
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_io, sum_buf;
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_buf, cols;
     int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
     int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
     int Pm = 0, cmax = 1, kmv = 1;

@@ -33,6 +33,7 @@ using namespace plspm;
 typedef double d4 __attribute__((ext_vector_type(4)));
 __host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a : b; }
 
+#include "wave_ops.h"
 #include "kernels_input.h"
 #include "kernels_gram.h"
 #include "kernels_gram_i8.h"
@@ -75,10 +76,10 @@ hipError_t pool_get(int idx, size_t bytes, void** out) {
         }
     }
     void* p = nullptr;
-    hipError_t e = (idx == 16) ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    hipError_t e = (idx == 16) ? hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped) : hipMalloc(&p, want);
     if (e != hipSuccess) {                                  // give the cache back to the runtime and try once more
         plspm_release_cached_memory();
-        e = (idx == 16) ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        e = (idx == 16) ? hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped) : hipMalloc(&p, want);
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lock(P.mu);
@@ -300,7 +301,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
-                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_io.p, m->sum_buf.p,
+                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_buf.p, m->cols.p,
                     m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
@@ -1527,27 +1528,39 @@ int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t 
     const bool in_lds = (size_t)npad * sizeof(double) <= (size_t)128 * 1024;
     int rc;
     if ((rc = pin_ready(m))) return rc;
-    if ((rc = ensure(m, m->sum_io, ((size_t)R * 7 + 2) * sizeof(double)))) return rc;
+    if ((size_t)R * 7 * sizeof(double) + 64 > m->h_pin_cap) return fail(m, PLSPM_E_ARG, "plspm_bootstrap_summary: record too wide for the staging area");
     if (!in_lds && (rc = ensure(m, m->sum_buf, (size_t)R * npad * sizeof(double)))) return rc;
-    double* d_orig = (double*)m->sum_io.p;
-    double* d_out = d_orig + R;
-    int* d_used = (int*)(d_out + (size_t)R * 6);
-    double* h_io = (double*)m->h_pin;                                   // [original R | summary 6R | n_used]: one small copy each way
+    // [original R | summary 6R | n_used] in the handle's pinned staging area, read and written by the kernel itself (R + 6R + 1 words
+    // across the host link): no copy engine operation in front of or behind the kernel, whose scheduling gaps cost more than the bytes
+    double* h_io = (double*)m->h_pin;
     memcpy(h_io, original, sizeof(double) * R);
-    HIPCHK(m, hipMemcpyAsync(d_orig, h_io, sizeof(double) * R, hipMemcpyHostToDevice, m->stream));
+    // the records column-major first (values + status: R + 1 columns of B, one small tiled transpose): read in place, every value of a
+    // column costs the summary workgroup a 128-byte line of its own (2 x B L1 fills per column were 40 % of the kernel)
+    const long cols_ld = (long)((B + 63) & ~(int64_t)63);
+    if ((rc = ensure(m, m->cols, (size_t)(R + 1) * cols_ld * sizeof(double)))) return rc;
+    const double* cols = (const double*)m->cols.p;
+    hipLaunchKernelGGL(records_transpose_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)((R + 1 + 63) / 64)), dim3(256), 0, m->stream, rows, (long)B, (int)stride, R + 1, (double*)m->cols.p,
+                       cols_ld);
+    double* h_out = h_io + R;
+    int* h_used = (int*)(h_out + (size_t)R * 6);
     if (in_lds) {
         const size_t lds = (size_t)npad * sizeof(double);
         if ((rc = allow_lds(m, (const void*)summary_kernel<true>, lds))) return rc;
-        hipLaunchKernelGGL((summary_kernel<true>), dim3(R), dim3(256), lds, m->stream, rows, (long)B, (int)stride, R, (const double*)d_orig, (double*)nullptr, npad, d_out, d_used);
+        hipLaunchKernelGGL((summary_kernel<true>), dim3(R), dim3(SUM_NT), lds, m->stream, cols, cols_ld, (long)B, R, (const double*)h_io, (double*)nullptr, npad, h_out, h_used);
     } else {
-        hipLaunchKernelGGL((summary_kernel<false>), dim3(R), dim3(256), 0, m->stream, rows, (long)B, (int)stride, R, (const double*)d_orig, (double*)m->sum_buf.p, npad, d_out,
-                           d_used);
+        hipLaunchKernelGGL((summary_kernel<false>), dim3(R), dim3(SUM_NT), 0, m->stream, cols, cols_ld, (long)B, R, (const double*)h_io, (double*)m->sum_buf.p, npad, h_out, h_used);
     }
     HIPCHK(m, hipGetLastError());
-    HIPCHK(m, hipMemcpyAsync(h_io + R, d_out, sizeof(double) * ((size_t)R * 6 + 1), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     memcpy(summary, h_io + R, sizeof(double) * R * 6);
     if (n_used) *n_used = *(const int*)(h_io + R + (size_t)R * 6);
+#ifdef PLSPM_DEBUG_MARKS
+    {
+        long long h[16];
+        HIPCHK(m, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_summary_marks), sizeof(h)));
+        fprintf(stderr, "[plspm summary clocks] compaction %lld  mean+var %lld  select %lld  successors %lld  total %lld\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[4] - h[0]);
+    }
+#endif
     return 0;
 }
 

@@ -55,9 +55,9 @@ struct HostExec {
         return t;
     }
     // ---- wave executor of solver_wave.h (nt == 64: one emulated thread per lane) ----
-    // butterfly sum in the device's order (v += shfl_xor(v, 32), 16, ... 1): bitwise the same value on every lane
+    // butterfly sum in the device's order (v += value of lane ^ 1, 2, ... 32: wave_ops.h): bitwise the same value on every lane
     double allsum(double v) {
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = 1; off < 64; off <<= 1) {
             red[tid] = v;
             bar->arrive_and_wait();
             const double t = red[tid ^ off];

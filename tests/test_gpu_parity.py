@@ -787,6 +787,31 @@ def test_device_bootstrap_summary_matches_host_statistics(B):
     assert_close(table, orc.summary(ok, original), 1e-11, 1e-13)
 
 
+@pytest.mark.parametrize("B", [100, 5000, 9000])
+def test_summary_of_device_records_equals_summary_of_the_same_records_stored_from_the_host(B):
+    """plspm_bootstrap_summary on the records the bootstrap left on the handle, then on the same records fetched and stored back
+    (plspm_bootstrap_store): identical tables; other records of the same count afterwards give their own table."""
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(600, C, 4, seed=3)
+    model = orc.Model(blocks, C, "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.bootstrap_device(B, seed=5)
+    original = np.linspace(-1.0, 2.0, nm.row_width)
+    first, used = nm.summary(B, original)
+    rows, status, iters = nm.fetch(0, B)
+    from plspm import parallel
+    nm.store(parallel.join_records(rows, status, iters))
+    again, used2 = nm.summary(B, original)
+    assert used == used2 == int((status == 0).sum())
+    assert np.array_equal(first, again)
+    assert_close(first, orc.summary(rows[status == 0], original), 1e-11, 1e-13)
+    other = rows[::-1].copy()
+    nm.store(parallel.join_records(other, status[::-1].copy(), iters[::-1].copy()))
+    t3, _ = nm.summary(B, original)
+    assert_close(t3, orc.summary(other[status[::-1] == 0], original), 1e-11, 1e-13)
+
+
 def test_api_metric_missing_values_match_reference_golden():
     """Mean imputation + all-block-missing row drop (reference config.py:273-285,300) through the drop-in API."""
     import plspm.config as c

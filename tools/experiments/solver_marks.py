@@ -18,3 +18,6 @@ for B in (256, 256, 2048, 5000, 5000):
     sys.stderr.write("--- B = %d\n" % B); sys.stderr.flush()
     nm.bootstrap_device(B, seed=1, rep_offset=0)
     nm.sync()
+sys.stderr.write("--- summary of the 5,000 records\n"); sys.stderr.flush()
+for k in range(3):
+    nm.summary(5000, np.ones(nm.row_width))
