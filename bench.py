@@ -391,7 +391,7 @@ def main():
         live_src = ("live: two child runs of this script (3 steps) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters "
                     "only), average over the kernel's full-size launches, FETCH_SIZE x 2 (gfx950)")
         if used_path == 2:
-            slices = model.get_option("i8_slices")
+            slices = model.get_option("last_i8_slices")
             npair = 61 * 62 // 2                               # unordered pairs of the 60 columns + the ones column
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
@@ -443,6 +443,34 @@ def main():
             other = {"value": round(B_total / dt, 1), "unit": "replicates/s", "ms_per_step": round(dt * 1e3, 4), "kernel": "gram_rows_kernel<4,false>",
                      "gram_avg_launch_ms": round(g_ms / max(g_n, 1), 4), "roofline_frac": round(tf / FP64_MFMA_PEAK_TF, 4),
                      "note": "10 steps of the same batch with set_option('gram_path', 1): fp64 MFMA Gram over (row,count) lists; frac = SURVEY 8(d) flops / 78.6 TFLOP/s"}
+        planes = None
+        if world == 1 and group is None and used_path == 2:
+            # the same workload with seven digit planes (correctly rounded sums) beside the automatic plane count, and how far the records differ
+            alt7 = make_model(devices[0])
+            alt7.set_option("i8_slices", 7)
+            for k in range(100):
+                alt7.bootstrap_device(B_total, seed=1, rep_offset=k * B_total)
+            alt7.sync()
+            alt7.profile(True); alt7.profile_reset()
+            t1 = time.perf_counter()
+            for k in range(20):
+                alt7.bootstrap_device(B_total, seed=1, rep_offset=(3 + k) * B_total)
+            alt7.sync()
+            dt7 = (time.perf_counter() - t1) / 20
+            alt7.profile(False)
+            g7_ms, g7_n = alt7.profile_read("gram")
+            r_auto = model.bootstrap(256, seed=1, rep_offset=0)[0]
+            r_7 = alt7.bootstrap(256, seed=1, rep_offset=0)[0]
+            dev = float(np.max(np.abs(r_auto - r_7) / np.maximum(np.abs(r_7), 1e-3)))
+            planes = {"S": int(slices), "min_sum_over_max": int(model.get_option("last_i8_ratio")),
+                      "rule": "fewest planes whose worst-case error of a replicate's sum, N 2^-(8S-1) max|z|, stays below a quarter of the a-priori bound N 2^-53 sum|z| of an "
+                              "fp64 accumulation of the same terms, in every pair column of the uploaded data (S = 6 needs sum|z| >= 256 max|z|; else 7)",
+                      "seven_planes": {"value": round(B_total / dt7, 1), "unit": "replicates/s", "ms_per_step": round(dt7 * 1e3, 4),
+                                       "gram_avg_launch_ms": round(g7_ms / max(g7_n, 1), 4),
+                                       "note": "20 steps with set_option('i8_slices', 7): sums correctly rounded (>= 53 bits of every column maximum)"},
+                      "max_rel_record_difference_vs_seven_planes": dev,
+                      "note": "records of 256 replicates (same seed) on both plane counts, |a - b| / max(|b|, 1e-3); the parity bar is 1e-6 (BASELINE.json north_star), "
+                              "the tests hold both against the oracle at 1e-8 and the moment matrices against 80-bit sums (tests/test_gpu_gram_i8.py)"}
         parallelism = ("one process, one GPU, no collective" if group is None else
                        "replicate-sharded x%d (%s), ONE ncclAllGather per step issued by libplspm_hip.so on a gather stream "
                        "(overlaps the next step's kernels; records double-buffered)" % (world, "one process per GPU" if launched else "one process, %d GPUs" % world))
@@ -454,9 +482,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "dtype_note": ("fp64 data, moments and solver; the batch Gram is evaluated as an exact int8 x int8 -> int32 product on the base-256 digit "
-                           "planes of the fp64 products (>= 53 bits of each column's largest product): results agree with the fp64 MFMA path to "
-                           "1e-10 and sit closer to the exactly rounded sums than it does (tests/test_gpu_gram_i8.py)") if used_path == 2 else "fp64 throughout",
+            "dtype_note": ("fp64 data, moments and solver; the batch Gram is evaluated as an exact int8 x int8 -> int32 product on %d base-256 digit "
+                           "planes of the fp64 products (the integer sums are exact; the plane count is the fewest whose representation error stays "
+                           "below the rounding bound of an fp64 accumulation of the same terms -- `digit_planes`): results agree with the fp64 MFMA path to "
+                           "1e-10 and sit closer to the exactly rounded sums than it does (tests/test_gpu_gram_i8.py)" % slices) if used_path == 2 else "fp64 throughout",
             "config": {"workload": "synthetic 10,000 obs x 60 MVs x 6 LVs, Mode A, Scheme.PATH, scaled, %d bootstrap replicates per GPU "
                                    "(BASELINE.json configs[2]; %d GPUs x %d = configs[3] at 8); on-device Philox resampling, a fresh replicate-id "
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
@@ -470,6 +499,8 @@ def main():
             "kernels_ms_per_step": {"resample": round(res_ms / max(res_n, 1), 4), "gram": round(gram_avg_ms, 4),
                                     "solver": round(sol_ms / max(sol_n, 1), 4)},
         }
+        if planes is not None:
+            line["digit_planes"] = planes
         if other is not None:
             line["fp64_mfma_path"] = other
         if pcie is not None:

@@ -5,7 +5,7 @@
 // c_bi (how often row i was drawn).  Over a batch that is a matrix product  M[b, (p,q)] = C[b, i] . Z[i, (p,q)],  Z[i,(p,q)] =
 // x_ip x_iq (one column per unordered pair incl. the ones column, built once per data set).  C is EXACTLY int8.  Z is fp64 -- but
 // cut into S balanced base-256 digits relative to the largest |z| of its column,
-//     z_i 2^k = sum_s d_is 256^s,   d_is in [-128, 127],   k = 8S - 2 - exponent(max_i |z_i|),
+//     z_i 2^k = sum_s d_is 256^s,   d_is in [-128, 127],   k = 8S - 1 - exponent(max_i |z_i|)   (one less when the maximum fills its binade),
 // every digit plane is int8 too, and  sum_i c_bi d_is  is an exact int32 dot product (|.| <= 128 N, N <= 2^24).  The fp64 matrix
 // pipe of MI355X peaks at 78.6 TFLOP/s, the int8 one at ~5,000 TOP/s: S = 7 digit planes (>= 53 significant bits of the column
 // maximum; the sum itself is exact, only the final int -> fp64 conversion rounds) cost 7 int8 MACs per fp64 MAC and still run several
@@ -61,6 +61,33 @@ __global__ void __launch_bounds__(256) zs_max_kernel(const double* __restrict__ 
         if (bits) atomicMax(pair_max + j, bits);
     }
 }
+// Second pass for the automatic plane count (plspm_hip.hip choose_slices): sum_i |z_i| of every pair column in fixed point relative to the
+// binade of the column maximum, 2^40 per unit of 2^e_max -- a thread's partial sum over its rows has one fixed order and integer adds
+// commute, so the result is a deterministic function of the data.  Same staging as zs_max_kernel.
+__global__ void __launch_bounds__(256) zs_abssum_kernel(const double* __restrict__ Xa, long N, int PA, int C, const int* __restrict__ pair_p, const int* __restrict__ pair_q,
+                                                         int npair, int RB, const unsigned long long* __restrict__ pair_max, unsigned long long* __restrict__ pair_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);
+    const int pitch = C | 1;
+    const long r0 = (long)blockIdx.x * RB;
+    const int nr = (int)min((long)RB, N - r0);
+    for (int e = threadIdx.x; e < RB * C; e += 256) {
+        const int r = e / C, c = e - r * C;
+        tile[r * pitch + c] = (r < nr) ? Xa[(r0 + r) * PA + c] : 0.0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < npair; j += 256) {
+        const unsigned long long mb = pair_max[j];
+        const int ef = (int)((mb >> 52) & 0x7ffull);                     // biased exponent of the column maximum
+        if (ef < 64 || ef >= 0x7ff) continue;                            // zero / tiny / non-finite column: the host keeps the full plane count
+        const double sc = __longlong_as_double((long long)((unsigned long long)(1023 + 40 - (ef - 1022)) << 52));     // 2^(40 - e), zmax = f 2^e
+        const int p = pair_p[j], q = pair_q[j];
+        double s = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < RB; ++r) s += fabs(tile[r * pitch + p] * tile[r * pitch + q]) * sc;       // each term < 2^40
+        atomicAdd(pair_sum + j, (unsigned long long)s);
+    }
+}
 __global__ void __launch_bounds__(256) zs_scale_kernel(const unsigned long long* __restrict__ pair_max, int npair, int S, int* __restrict__ pair_k, double* __restrict__ pair_scale) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= npair) return;
@@ -70,8 +97,11 @@ __global__ void __launch_bounds__(256) zs_scale_kernel(const unsigned long long*
     if (!(zmax <= 1.7976931348623157e308)) sc = __builtin_nan("");       // non-finite data: the fp64 path would report NaN moments as well
     else if (zmax > 0.0) {
         int e;
-        (void)frexp(zmax, &e);                                           // zmax = f 2^e, f in [0.5, 1)
-        k = 8 * S - 2 - e;                                               // |z| 2^k < 2^(8S-2): the top digit stays inside int8
+        const double f = frexp(zmax, &e);                                // zmax = f 2^e, f in [0.5, 1)
+        // balanced digits reach +-127.5 x 256^(S-1): |z| 2^k = f 2^(8S-1) fits while f <= 0.996 (one bit more resolution than a blanket
+        // 2^(8S-2) bound); a maximum that close to the top of its binade gives that bit back
+        // (eight planes: 2^63 would leave the int64 the digits are cut from)
+        k = 8 * S - 1 - e - ((f >= 0.99 || S >= 8) ? 1 : 0);
         sc = ldexp(1.0, -k);
     }
     pair_k[j] = k;

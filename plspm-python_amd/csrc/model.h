@@ -83,7 +83,7 @@ struct plspm_model {
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 7, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
     Buf zs, cd, cd1, err2, pair_tab, pair_scale;
@@ -103,6 +103,7 @@ struct plspm_model {
     int cd_slot = 0;
     bool zs_valid = false;
     int zs_S = 0, zs_KB = 0, zs_NT = 0, zs_npair = 0, zs_npg = 0;
+    double zs_ratio = 0.0;      // smallest sum|z| / max|z| over the pair columns (automatic plane count; 0: not evaluated)
     double* moments_out = nullptr; // plspm_bootstrap_moments: dense moment matrices go here and the solver is skipped
     int last_gram_path = 0;       // 1 fp64 MFMA, 2 int8 digit planes: what the last bootstrap call used (plspm_model_get_info)
     int last_i8_dma = 0;          // 1 global_load_lds, 2 buffer_load ... lds: the LDS-DMA form of the last int8 Gram launch

@@ -688,7 +688,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "scores_tile") { if (value != 0 && value != 16 && value != 32) return bad(); m->tune.scores_tile = value; }
     else if (k == "gram_lds_kb") { if (value < 0 || value > 160) return bad(); m->tune.gram_lds_kb = value; }
     else if (k == "gram_path") { if (value < 0 || value > 2) return bad(); m->tune.gram_path = value; }
-    else if (k == "i8_slices") { if (value < 5 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
+    else if (k == "i8_slices") { if (value != 0 && (value < 5 || value > 8)) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "i8_rt") { if (value != 16 && value != 8) return bad(); m->tune.i8_rt = value; }
@@ -718,6 +718,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "conv_gy") *value = m->tune.conv_gy;
     else if (k == "gram_path") *value = m->tune.gram_path;
     else if (k == "i8_slices") *value = m->tune.i8_slices;
+    else if (k == "last_i8_slices") *value = m->zs_valid ? m->zs_S : 0;
+    else if (k == "last_i8_ratio") *value = (m->zs_valid && m->zs_ratio < 9e18) ? (int64_t)m->zs_ratio : 0;      // floor of the smallest sum|z| / max|z| (automatic plane count)
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
@@ -997,19 +999,51 @@ static int choose_gram_path(const plspm_model* m, int64_t B) {
     // histogram of 65,536 rows per workgroup, larger data sets take several windows per replicate)
     if (m->stage1 || m->N >= (1 << 24) || m->N < 2) return 1;
     if (m->nonmetric && m->N > 65535) return 1;             // (their stop-rule passes want the dense uint16 histograms of the LDS-histogram resample)
-    const size_t zs_bytes = (size_t)(i8_kblocks(m->N) + I8_SLACK_KB) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * m->tune.i8_slices) * 1024;
+    const size_t zs_bytes = (size_t)(i8_kblocks(m->N) + I8_SLACK_KB) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * (m->tune.i8_slices ? m->tune.i8_slices : 7)) * 1024;
     if (zs_bytes > kZsBudget) return 1;
     if (m->tune.gram_path == 2) return 2;
     return B >= m->tune.i8_min_batch ? 2 : 1;
 }
 
 // Digit planes + pair tables of the resident data (once per upload / digit count).
+// How many digit planes ("i8_slices" 0 = automatic).  S planes represent every product with an absolute error of at most
+// 2^-(8S-1) max|z| of its column (zs_scale_kernel), so a replicate's sum is off by at most N 2^-(8S-1) max|z| (the multiplicities add up
+// to N) -- the integer sum itself is exact.  A sequential fp64 accumulation of the same N terms carries the a-priori bound gamma_N sum|z|
+// ~ N 2^-53 sum|z|.  S planes are therefore within the error bound of fp64 arithmetic on the same data whenever
+//       sum_i |z_i|  >=  2^(54 - 8S) max_i |z_i|        in every pair column:      S = 7: always,   S = 6: sum >= 64 max.
+// Automatic = 6 planes if every column clears that bar with a factor 4 to spare (sum >= 256 max; a resample re-weights the terms:
+// sum_i c_i |z_i| scatters by a few percent around sum_i |z_i|), else 7.  Data sets of a few hundred rows stay at 7; 10,000 rows of
+// anything bell-shaped reach several hundred.  Measured against 80-bit sums on the 10k x 60 benchmark data (tests/test_gpu_gram_i8.py,
+// error relative to sqrt(M_pp M_qq)): seven planes 1e-16 (correctly rounded), six planes 3e-15, the blocked fp64 MFMA accumulation
+// 1.6e-15 -- all nine orders below the 1e-6 the records are held to.
+static int choose_slices(plspm_model* m, const unsigned long long* d_max, unsigned long long* d_sum, long npair, int* S_out) {
+    std::vector<unsigned long long> h(2 * (size_t)npair);
+    HIPCHK(m, hipMemcpyAsync(h.data(), d_max, (size_t)npair * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(h.data() + npair, d_sum, (size_t)npair * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    double worst = 1e300;
+    for (long j = 0; j < npair; ++j) {
+        const unsigned long long mb = h[j];
+        if (mb == 0) continue;                                            // an all-zero column has nothing to round
+        const int ef = (int)((mb >> 52) & 0x7ffull);
+        if (ef < 64 || ef >= 0x7ff) { worst = 0.0; break; }               // tiny or non-finite maximum: not evaluated, full plane count
+        double zmax;
+        memcpy(&zmax, &mb, sizeof(double));
+        const double sum = std::ldexp((double)h[npair + j], (ef - 1022) - 40);
+        worst = std::min(worst, sum / zmax);
+    }
+    m->zs_ratio = worst;
+    *S_out = worst >= 256.0 ? 6 : 7;
+    return 0;
+}
+
 static int prepare_zs(plspm_model* m) {
     if (m->zs_valid) return 0;
-    const int S = m->tune.i8_slices, C = m->Pg + 1;
+    int S = m->tune.i8_slices;
+    const int C = m->Pg + 1;
     const long npair = i8_pairs(m);
     const int npg = (int)((npair + 31) / 32) * 2;             // pair groups of 16, padded to whole workgroup tiles (two groups)
-    const int KB = i8_kblocks(m->N), NT = npg * S;
+    const int KB = i8_kblocks(m->N);
     std::vector<int> tab(6 * (size_t)npair);
     int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | packed slot | dense slot | mirrored dense slot]
     int* hd1 = hd + npair; int* hd2 = hd1 + npair;
@@ -1023,20 +1057,28 @@ static int prepare_zs(plspm_model* m) {
     int rc;
     if ((rc = ensure(m, m->pair_tab, tab.size() * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->pair_scale, (size_t)npair * sizeof(double)))) return rc;
-    if ((rc = ensure(m, m->zs, (size_t)(KB + I8_SLACK_KB) * NT * 1024))) return rc;
+    if ((rc = ensure(m, m->zs, (size_t)(KB + I8_SLACK_KB) * (size_t)(npg * (S ? S : 7)) * 1024))) return rc;      // (sized for the larger automatic choice)
     if ((rc = plspm_detail_h2d(m, m->pair_tab.p, tab.data(), tab.size() * sizeof(int)))) return rc;
     int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
     ProfScope ps(m, PLSPM_K_PACK);
     {
-        // column maxima of the pair products: the digit buffer's head doubles as the npair x 8 B scratch (overwritten by zs_build below)
+        // column maxima of the pair products: the digit buffer's head doubles as the 2 x npair x 8 B scratch (overwritten by zs_build below)
         unsigned long long* d_max = (unsigned long long*)m->zs.p;
-        HIPCHK(m, hipMemsetAsync(d_max, 0, (size_t)npair * sizeof(unsigned long long), m->stream));
+        HIPCHK(m, hipMemsetAsync(d_max, 0, 2 * (size_t)npair * sizeof(unsigned long long), m->stream));
         const int RB = (int)std::max<size_t>(1, std::min<size_t>(64, (kMaxLds - 1024) / ((size_t)(C | 1) * sizeof(double))));
         const size_t lds = (size_t)RB * (C | 1) * sizeof(double);
         if ((rc = allow_lds(m, (const void*)zs_max_kernel, lds))) return rc;
         hipLaunchKernelGGL(zs_max_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB, d_max);
+        if (S == 0) {
+            if ((rc = allow_lds(m, (const void*)zs_abssum_kernel, lds))) return rc;
+            hipLaunchKernelGGL(zs_abssum_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB,
+                               (const unsigned long long*)d_max, d_max + npair);
+            HIPCHK(m, hipGetLastError());
+            if ((rc = choose_slices(m, d_max, d_max + npair, npair, &S))) return rc;
+        }
         hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
     }
+    const int NT = npg * S;
     const dim3 grid((unsigned)KB, (unsigned)((npg + 3) / 4));
 #define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, m->tune.i8_shape, (uint4*)m->zs.p)
     switch (S) { case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }

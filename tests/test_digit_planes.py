@@ -12,10 +12,11 @@ import plspm_oracle as orc
 
 
 def digit_planes(z, S):
-    """zs_max_kernel / zs_scale_kernel / zs_build_kernel: k = 8S - 2 - exponent(max |z|); z 2^k = sum_s d_s 256^s, d_s in [-128, 127]."""
+    """zs_max_kernel / zs_scale_kernel / zs_build_kernel: k = 8S - 1 - exponent(max |z|) (one less when the maximum fills its binade);
+    z 2^k = sum_s d_s 256^s, d_s in [-128, 127]."""
     zmax = np.abs(z).max()
-    _, e = np.frexp(zmax)
-    k = 8 * S - 2 - int(e)
+    f, e = np.frexp(zmax)
+    k = 8 * S - 1 - int(e) - (1 if (f >= 0.99 or S >= 8) else 0)
     v = np.rint(np.ldexp(z, k)).astype(np.int64)
     planes = []
     for _ in range(S):

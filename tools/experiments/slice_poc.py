@@ -8,8 +8,8 @@ from fractions import Fraction
 
 def slices_of(z, S):
     zmax = np.abs(z).max()
-    _, E = np.frexp(zmax)                      # zmax = f * 2^E, f in [0.5, 1)
-    k = 8 * S - 2 - int(E)                      # |z| 2^k < 2^(8S-2)
+    f, E = np.frexp(zmax)                      # zmax = f * 2^E, f in [0.5, 1)
+    k = 8 * S - 1 - int(E) - (1 if (f >= 0.99 or S >= 8) else 0)      # |z| 2^k <= 127.5 x 256^(S-1)
     q = np.rint(np.ldexp(z, k)).astype(np.int64)
     digs = []
     for s in range(S):
