@@ -40,6 +40,10 @@ timeout 300 python tools/two_pipelines.py i8_rt=8 2>&1 | grep "^{" >> $O/two_pip
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $O/prof_solver_pmc1 -o p1 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC -d $O/prof_solver_pmc2 -o p2 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_solver_fetch -o f -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/prof_solver_write -o w -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1)
 python tools/pmc_rows.py $O solver > $O/solver_pmc.txt 2>&1
 timeout 300 python tools/aux_ab.py i8_sched=0,1 2>&1 | grep "^{" > $O/ab_stream_k.jsonl
+timeout 300 python tools/aux_ab.py i8_waves=4,8 2>&1 | grep "^{" > $O/ab_i8_waves.jsonl
+timeout 300 python tools/aux_ab.py i8_slices=0,7 2>&1 | grep "^{" > $O/ab_i8_slices.jsonl
+timeout 300 python tools/i8_dma_form.py 2>&1 | grep "^{" > $O/i8_dma_form.jsonl
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --hip-trace --memory-copy-trace --output-format csv -d /tmp/tl -o tl -- python $R/tools/api_timeline.py run > $O/api_timeline.txt 2>/dev/null; python $R/tools/api_timeline.py read /tmp/tl >> $O/api_timeline.txt 2>&1)
 timeout 300 python tools/aux_ab.py resample_aux=0,1,2,3 2>&1 | grep "^{" > $O/ab_resample_aux.jsonl
 timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench.json
 timeout 600 python tools/hoc_bench.py 2>&1 | tail -1 > $O/hoc_bench.json
@@ -59,6 +63,6 @@ json.dump(out, open(O + "/pmc_rows.json", "w"), indent=0)
 for r in out: print(r["run"], r["kernel"][:36], r["counter"], r["dispatches"], r["avg"], r["avg_duration_ns"])
 PY
 python tools/rocprof_summary.py ${TAG}_tmp $(ls $O/prof_stats/*/*.db $O/prof_stats/*.db 2>/dev/null | head -1) $(ls $O/prof_fetch/*/*.db $O/prof_fetch/*.db 2>/dev/null | head -1) $(ls $O/prof_write/*/*.db $O/prof_write/*.db 2>/dev/null | head -1) > $O/rocprof_summary_stdout.txt 2>&1
-mv profiles/${TAG}_tmp_rocprof_summary.md $O/rocprof_summary.md 2>/dev/null; mv profiles/${TAG}_tmp_rocprof_summary.json $O/rocprof_summary.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_traffic.json $O/gram_traffic.json 2>/dev/null
+mv profiles/${TAG}_tmp_rocprof_summary.md $O/rocprof_summary.md 2>/dev/null; mv profiles/${TAG}_tmp_rocprof_summary.json $O/rocprof_summary.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_traffic.json $O/gram_traffic.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_i8_traffic.json $O/gram_i8_traffic.json 2>/dev/null
 find $O -name "*.db" -size +20M -delete
 du -sh $O; ls $O
