@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256) zs_max_kernel(const double* __restrict__ 
 // binade of the column maximum, 2^40 per unit of 2^e_max -- a thread's partial sum over its rows has one fixed order and integer adds
 // commute, so the result is a deterministic function of the data.  Same staging as zs_max_kernel.
 __global__ void __launch_bounds__(256) zs_abssum_kernel(const double* __restrict__ Xa, long N, int PA, int C, const int* __restrict__ pair_p, const int* __restrict__ pair_q,
-                                                         int npair, int RB, const unsigned long long* __restrict__ pair_max, unsigned long long* __restrict__ pair_sum) {
+                                                         int npair, int RB, const unsigned long long* __restrict__ pair_max, unsigned long long* __restrict__ pair_sum,
+                                                         unsigned long long* __restrict__ pair_or) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* tile = reinterpret_cast<double*>(smem_raw);
     const int pitch = C | 1;
@@ -81,11 +82,23 @@ __global__ void __launch_bounds__(256) zs_abssum_kernel(const double* __restrict
         const int ef = (int)((mb >> 52) & 0x7ffull);                     // biased exponent of the column maximum
         if (ef < 64 || ef >= 0x7ff) continue;                            // zero / tiny / non-finite column: the host keeps the full plane count
         const double sc = __longlong_as_double((long long)((unsigned long long)(1023 + 40 - (ef - 1022)) << 52));     // 2^(40 - e), zmax = f 2^e
+        // the integers the seven-plane decomposition would cut (zs_scale_kernel / zs_build_kernel): their bitwise OR tells how many low
+        // planes are identically zero -- data whose products are short binary fractions of the column maximum (0/1 indicator columns:
+        // one plane) are represented EXACTLY by fewer planes
+        int e7;
+        const double f7 = frexp(__longlong_as_double((long long)mb), &e7);
+        const int k7 = 55 - e7 - (f7 >= 0.99 ? 1 : 0);
         const int p = pair_p[j], q = pair_q[j];
         double s = 0.0;
+        unsigned long long bits = 0ull;
 #pragma unroll 8
-        for (int r = 0; r < RB; ++r) s += fabs(tile[r * pitch + p] * tile[r * pitch + q]) * sc;       // each term < 2^40
+        for (int r = 0; r < RB; ++r) {
+            const double z = fabs(tile[r * pitch + p] * tile[r * pitch + q]);
+            s += z * sc;                                                 // each term < 2^40
+            bits |= (unsigned long long)__double2ll_rn(ldexp(z, k7));
+        }
         atomicAdd(pair_sum + j, (unsigned long long)s);
+        if (bits) atomicOr(pair_or + j, bits);
     }
 }
 __global__ void __launch_bounds__(256) zs_scale_kernel(const unsigned long long* __restrict__ pair_max, int npair, int S, int* __restrict__ pair_k, double* __restrict__ pair_scale) {

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __r
 template <int MODE>
 __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
                                                   double* gS, double* gSm, double* gstate, long state_stride,
-                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish) {
+                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish, int extra_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
@@ -59,8 +59,9 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     Workspace ws;
     ws.PS = cov_ld(Q);
     ws.S = gS + b * cov_doubles(Q);
-    carve_small(ws, lp, Q, L, md.kmax, 0);
-    lp += workspace_small_doubles(Q, L, md.kmax, 0);
+    // (the aug-level solver indexes its workspace vectors by MV and by LV only -- wn, a, G, E, the regression scratch: Pm-sized suffices)
+    carve_small(ws, lp, cd.Pm, L, md.kmax, 0);
+    lp += workspace_small_doubles(cd.Pm, L, md.kmax, 0);
     Workspace wsm;
     wsm.PS = cov_ld(cd.Pm);
     wsm.S = gSm + b * cov_doubles(cd.Pm);
@@ -69,11 +70,23 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     double* state = gstate + b * state_stride;
     NmState st;
     nm_carve(st, state, Q, L);
-    NmgExtra x;
-    nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, cd.Pm, L, cd.cmax, cd.kmv);
     if (MODE == 1 && st.scal[3] == 0.0) return;
+    // The small arrays of the iteration (quantifications, block moment matrices, pooling scratch, per-MV scratch) are touched by hundreds of
+    // short dependent phases: in global memory every one of them is a memory round trip (the per-LV loop and the quantification were 55 % of
+    // a step).  When they fit they live in LDS for the launch; the two (Q+1) x L products stay global (streamed), the persistent head
+    // (tq | tc | akk) is copied in and out.
+    NmgExtra x, xg;
+    if (extra_in_lds) {
+        nmg_carve_fast(x, xg, state + nm_state_doubles(Q, L, 0), lp, Q, cd.Pm, L, cd.cmax, cd.kmv);
+        lp += (nmg_fast_doubles(Q, cd.Pm, L, cd.cmax, cd.kmv) + 1) & ~1L;
+        if (MODE != 0) {
+            const long np = nmg_persistent_doubles(Q, cd.Pm, L);
+            for (long i = threadIdx.x; i < np; i += blockDim.x) x.tq[i] = xg.tq[i];
+            __syncthreads();
+        }
+    } else nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, cd.Pm, L, cd.cmax, cd.kmv);
     stage_descriptors(md, lp);
-    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, nullptr};
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
     bool finish_now = (MODE == 2);
     if (MODE == 0) {
         nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
@@ -91,6 +104,11 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
         out.status = so.status ? so.status + b : nullptr;
         out.iters = so.iters ? so.iters + b : nullptr;
         nmg_finish(ex, md, cd, mdm, ws, wsm, st, x, out);
+    }
+    if (extra_in_lds) {
+        __syncthreads();
+        const long np = nmg_persistent_doubles(Q, cd.Pm, L);
+        for (long i = threadIdx.x; i < np; i += blockDim.x) xg.tq[i] = x.tq[i];
     }
 }
 

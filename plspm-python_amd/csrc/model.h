@@ -83,10 +83,10 @@ struct plspm_model {
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
-    Buf zs, cd, cd1, err2, pair_tab, pair_scale;
+    Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat;
     // set_option("resample_aux", 1..3): the int8 counts are drawn on a second stream (1 lowest / 2 default / 3 highest priority) into
     // alternating buffers, so that the draws of call k+1 -- enqueued while the Gram / solver of call k still run -- take the CUs those
     // leave idle (the Gram's last, partial round of workgroups first of all); the Gram waits for its counts by event.  Measured

@@ -302,7 +302,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_buf.p, m->cols.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -539,8 +539,9 @@ static size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out) {
 }
 
 // cd8 / cd8_MT: the int8 row multiplicities of THESE problems (the counts the digit-plane Gram consumed; bootstrap only), or null
-static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, const int2* ent, const int* nent,
+static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so_in, const int2* ent, const int* nent,
                          long ent_stride, int threads, bool finish = true, const void* cd8 = nullptr, int cd8_MT = 0) {
+    SolverOut so = so_in;
     const int P = m->P, L = m->L;
     plspm_model* src = m->stage1 ? m->stage1 : m;                // an attached second stage streams its first stage's data (solver_hoc.h)
     const long N = src->N;
@@ -578,9 +579,13 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
-    size_t lds = (size_t)workspace_small_doubles(P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
+    size_t lds = (size_t)workspace_small_doubles(cat ? m->Pm : P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
     if (cat) lds += (size_t)workspace_small_doubles(m->Pm, L, m->kmax, 0) * sizeof(double);
     if (lds > kMaxLds) return fail(m, PLSPM_E_LIMIT, "non-metric solver: workspace exceeds LDS");
+    // categorical problems: the small arrays of the iteration in LDS when they fit beside the workspaces (kernels_nonmetric.h nmg_kernel)
+    const size_t cat_fast_bytes = cat ? (size_t)((nmg_fast_doubles(P, m->Pm, L, m->cmax, m->kmv) + 1) & ~1L) * sizeof(double) : 0;
+    const int cat_fast = (cat && m->tune.nm_fast_lds != 0 && lds + cat_fast_bytes <= kMaxLds) ? 1 : 0;
+    if (cat_fast) lds += cat_fast_bytes;
     if (cat) {
         if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)))
             return rc;
@@ -607,11 +612,15 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     int* nact = (int*)m->nmactive.p;
     const dim3 grid((unsigned)nproblems);
     const int fuse = finish ? 1 : 0;           // the finish of a problem runs inside the step launch that decides its stop
+#ifdef PLSPM_DEBUG_MARKS
+    long long* d_nm_marks = nullptr;
+    if (cat) { HIPCHK(m, plspm_dmalloc((void**)&d_nm_marks, 32 * sizeof(long long))); so.marks = d_nm_marks; }
+#endif
     auto launch = [&](int mode_op) {
         ProfScope ps(m, PLSPM_K_SOLVER);
         if (cat) {
             auto k = mode_op == 0 ? nmg_kernel<0> : mode_op == 1 ? nmg_kernel<1> : nmg_kernel<2>;
-            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact, fuse);
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact, fuse, cat_fast);
         } else if (nmx) {
             auto k = mode_op == 0 ? nmx_kernel<0> : mode_op == 1 ? nmx_kernel<1> : nmx_kernel<2>;
             const MissDesc xd{m->nmx_raw, m->nmx_K, m->d_Xk, m->d_Mk};
@@ -658,8 +667,20 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             }
         }
         HIPCHK(m, hipEventSynchronize(m->ev_flag));
+#ifdef PLSPM_DEBUG_MARKS
+        if (cat && it == 1) {
+            long long h[32];
+            HIPCHK(m, hipStreamSynchronize(m->stream));
+            HIPCHK(m, hipMemcpy(h, d_nm_marks, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[plspm nmg_step clocks] V=Mn.c %lld  YY+G %lld  inner weights %lld  MZ+a %lld  quantify(par) %lld  LV loop %lld  score map %lld  total %lld\n", h[21] - h[20],
+                    h[22] - h[21], h[23] - h[22], h[24] - h[23], h[25] - h[24], h[26] - h[25], h[27] - h[26], h[27] - h[20]);
+        }
+#endif
         if (*m->h_flag == 0) break;
     }
+#ifdef PLSPM_DEBUG_MARKS
+    if (d_nm_marks) plspm_dfree(d_nm_marks);
+#endif
     HIPCHK(m, hipGetLastError());
     return 0;
 }
@@ -688,9 +709,10 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "scores_tile") { if (value != 0 && value != 16 && value != 32) return bad(); m->tune.scores_tile = value; }
     else if (k == "gram_lds_kb") { if (value < 0 || value > 160) return bad(); m->tune.gram_lds_kb = value; }
     else if (k == "gram_path") { if (value < 0 || value > 2) return bad(); m->tune.gram_path = value; }
-    else if (k == "i8_slices") { if (value != 0 && (value < 5 || value > 8)) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
+    else if (k == "i8_slices") { if (value < 0 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
+    else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "i8_rt") { if (value != 16 && value != 8) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
@@ -722,6 +744,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "last_i8_ratio") *value = (m->zs_valid && m->zs_ratio < 9e18) ? (int64_t)m->zs_ratio : 0;      // floor of the smallest sum|z| / max|z| (automatic plane count)
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
+    else if (k == "nm_fast_lds") *value = m->tune.nm_fast_lds;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_dma") *value = m->tune.i8_dma;
     else if (k == "last_i8_dma") *value = m->last_i8_dma;
@@ -1016,12 +1039,13 @@ static int choose_gram_path(const plspm_model* m, int64_t B) {
 // anything bell-shaped reach several hundred.  Measured against 80-bit sums on the 10k x 60 benchmark data (tests/test_gpu_gram_i8.py,
 // error relative to sqrt(M_pp M_qq)): seven planes 1e-16 (correctly rounded), six planes 3e-15, the blocked fp64 MFMA accumulation
 // 1.6e-15 -- all nine orders below the 1e-6 the records are held to.
-static int choose_slices(plspm_model* m, const unsigned long long* d_max, unsigned long long* d_sum, long npair, int* S_out) {
-    std::vector<unsigned long long> h(2 * (size_t)npair);
-    HIPCHK(m, hipMemcpyAsync(h.data(), d_max, (size_t)npair * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipMemcpyAsync(h.data() + npair, d_sum, (size_t)npair * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+static int choose_slices(plspm_model* m, const unsigned long long* d_max, long npair, int* S_out) {
+    std::vector<unsigned long long> h(3 * (size_t)npair);                     // [max bits | fixed-point sums | OR of the scaled integers]
+    HIPCHK(m, hipMemcpyAsync(h.data(), d_max, 3 * (size_t)npair * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     double worst = 1e300;
+    unsigned long long any = 0ull;
+    for (long j = 0; j < npair; ++j) any |= h[2 * npair + j];
     for (long j = 0; j < npair; ++j) {
         const unsigned long long mb = h[j];
         if (mb == 0) continue;                                            // an all-zero column has nothing to round
@@ -1033,7 +1057,16 @@ static int choose_slices(plspm_model* m, const unsigned long long* d_max, unsign
         worst = std::min(worst, sum / zmax);
     }
     m->zs_ratio = worst;
-    *S_out = worst >= 256.0 ? 6 : 7;
+    int S = worst >= 256.0 ? 6 : 7;
+    // planes that would be identically zero in the seven-plane decomposition carry nothing: dropping them changes no sum
+    int zero_planes = 0;
+    if (worst > 0.0) {
+        zero_planes = 6;
+        if (any) { int tz = 0; while (!((any >> tz) & 1ull)) ++tz; zero_planes = std::min(6, tz / 8); }
+    }
+    S = std::min(S, 7 - zero_planes);
+    if (m->tune.i8_shape == 32) S = std::max(S, 5);                            // (the 32x32x32 layout is instantiated for 5 .. 8 planes)
+    *S_out = S;
     return 0;
 }
 
@@ -1057,14 +1090,14 @@ static int prepare_zs(plspm_model* m) {
     int rc;
     if ((rc = ensure(m, m->pair_tab, tab.size() * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->pair_scale, (size_t)npair * sizeof(double)))) return rc;
-    if ((rc = ensure(m, m->zs, (size_t)(KB + I8_SLACK_KB) * (size_t)(npg * (S ? S : 7)) * 1024))) return rc;      // (sized for the larger automatic choice)
+    if ((rc = ensure(m, m->zs_stat, 3 * (size_t)npair * sizeof(unsigned long long)))) return rc;
     if ((rc = plspm_detail_h2d(m, m->pair_tab.p, tab.data(), tab.size() * sizeof(int)))) return rc;
     int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
     ProfScope ps(m, PLSPM_K_PACK);
     {
-        // column maxima of the pair products: the digit buffer's head doubles as the 2 x npair x 8 B scratch (overwritten by zs_build below)
-        unsigned long long* d_max = (unsigned long long*)m->zs.p;
-        HIPCHK(m, hipMemsetAsync(d_max, 0, 2 * (size_t)npair * sizeof(unsigned long long), m->stream));
+        // column maxima of the pair products (+ the two statistics of the automatic plane count)
+        unsigned long long* d_max = (unsigned long long*)m->zs_stat.p;
+        HIPCHK(m, hipMemsetAsync(d_max, 0, 3 * (size_t)npair * sizeof(unsigned long long), m->stream));
         const int RB = (int)std::max<size_t>(1, std::min<size_t>(64, (kMaxLds - 1024) / ((size_t)(C | 1) * sizeof(double))));
         const size_t lds = (size_t)RB * (C | 1) * sizeof(double);
         if ((rc = allow_lds(m, (const void*)zs_max_kernel, lds))) return rc;
@@ -1072,16 +1105,17 @@ static int prepare_zs(plspm_model* m) {
         if (S == 0) {
             if ((rc = allow_lds(m, (const void*)zs_abssum_kernel, lds))) return rc;
             hipLaunchKernelGGL(zs_abssum_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB,
-                               (const unsigned long long*)d_max, d_max + npair);
+                               (const unsigned long long*)d_max, d_max + npair, d_max + 2 * npair);
             HIPCHK(m, hipGetLastError());
-            if ((rc = choose_slices(m, d_max, d_max + npair, npair, &S))) return rc;
+            if ((rc = choose_slices(m, d_max, npair, &S))) return rc;
         }
         hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
     }
     const int NT = npg * S;
+    if ((rc = ensure(m, m->zs, (size_t)(KB + I8_SLACK_KB) * (size_t)NT * 1024))) return rc;      // (sized once the plane count is known: 0/1 data take one plane)
     const dim3 grid((unsigned)KB, (unsigned)((npg + 3) / 4));
 #define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, m->tune.i8_shape, (uint4*)m->zs.p)
-    switch (S) { case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }
+    switch (S) { case 1: ZSB(1); break; case 2: ZSB(2); break; case 3: ZSB(3); break; case 4: ZSB(4); break; case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }
 #undef ZSB
     HIPCHK(m, hipGetLastError());
     m->zs_S = S; m->zs_KB = KB; m->zs_NT = NT; m->zs_npair = (int)npair; m->zs_npg = npg;
@@ -1161,7 +1195,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const int* d_dst2 = nullptr;          // (a mirrored second store per element cost 0.08 ms per 5,000 replicates: the rows solver reads the triangle instead)
     const long out_stride = dense ? cov_doubles(m->Pg) : packed_size(m->T);
     // persistent stream-K schedule (kernels_gram_i8.h gram_i8_sk_kernel): one workgroup per CU, whole CUs per XCD
-    const bool sk = m->tune.i8_sched == 1 && m->tune.i8_shape == 16 && m->tune.i8_variant < 0 && S <= 7;      // (S = 8 spills in the persistent kernel)
+    const bool sk = m->tune.i8_sched == 1 && m->tune.i8_shape == 16 && m->tune.i8_variant < 0 && S >= 5 && S <= 7;      // (S = 8 spills in the persistent kernel)
     int sk_grid = 0;
     if (sk) {
         if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
@@ -1216,15 +1250,15 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     }
     if (narrow) GI8RT(8) else
 #undef GI8RT_DUMMY
-    if (m->tune.i8_shape == 32) {              // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
+    if (m->tune.i8_shape == 32 && S >= 5) {    // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
         switch (S) { case 5: GI8VS(5, 2, I8_DEFAULT_VAR, 32) break; case 6: GI8VS(6, 2, I8_DEFAULT_VAR, 32) break; case 7: GI8VS(7, 2, I8_DEFAULT_VAR, 32) break; default: GI8VS(8, 2, I8_DEFAULT_VAR, 32) break; }
     } else
     if (dma_buffer) {            // LDS-DMA as buffer_load ... lds (32-bit offsets from per-workgroup descriptors)
-        if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8B(5, 2) break; case 6: GI8B(6, 2) break; case 7: GI8B(7, 2) break; default: GI8B(8, 2) break; } }
-        else { switch (S) { case 5: GI8B(5, 4) break; case 6: GI8B(6, 4) break; case 7: GI8B(7, 4) break; default: GI8B(8, 4) break; } }
+        if (m->tune.i8_waves == 4) { switch (S) { case 1: GI8B(1, 2) break; case 2: GI8B(2, 2) break; case 3: GI8B(3, 2) break; case 4: GI8B(4, 2) break; case 5: GI8B(5, 2) break; case 6: GI8B(6, 2) break; case 7: GI8B(7, 2) break; default: GI8B(8, 2) break; } }
+        else { switch (S) { case 1: GI8B(1, 4) break; case 2: GI8B(2, 4) break; case 3: GI8B(3, 4) break; case 4: GI8B(4, 4) break; case 5: GI8B(5, 4) break; case 6: GI8B(6, 4) break; case 7: GI8B(7, 4) break; default: GI8B(8, 4) break; } }
     } else
-    if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8(5, 2) break; case 6: GI8(6, 2) break; case 7: GI8(7, 2) break; default: GI8(8, 2) break; } }
-    else { switch (S) { case 5: GI8(5, 4) break; case 6: GI8(6, 4) break; case 7: GI8(7, 4) break; default: GI8(8, 4) break; } }
+    if (m->tune.i8_waves == 4) { switch (S) { case 1: GI8(1, 2) break; case 2: GI8(2, 2) break; case 3: GI8(3, 2) break; case 4: GI8(4, 2) break; case 5: GI8(5, 2) break; case 6: GI8(6, 2) break; case 7: GI8(7, 2) break; default: GI8(8, 2) break; } }
+    else { switch (S) { case 1: GI8(1, 4) break; case 2: GI8(2, 4) break; case 3: GI8(3, 4) break; case 4: GI8(4, 4) break; case 5: GI8(5, 4) break; case 6: GI8(6, 4) break; case 7: GI8(7, 4) break; default: GI8(8, 4) break; } }
 #undef GI8V
 #undef GI8VS
 #undef GI8

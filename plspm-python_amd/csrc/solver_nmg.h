@@ -56,6 +56,23 @@ PLSPM_HD void nmg_carve(NmgExtra& x, double* base, int Q, int Pm, int L, int cma
     x.pq = p;
 }
 PLSPM_HD long nmg_state_doubles(int Q, int Pm, int L, int cmax, int kmv) { return nm_state_doubles(Q, L, 0) + nmg_extra_doubles(Q, Pm, L, cmax, kmv); }
+// The same arrays with everything but the two (Q+1) x L products in a caller-supplied FAST area (the device kernel: LDS).  The quantifications
+// and score constants persist between launches: the caller copies them in from / out to their slots of the global layout (`g`).
+PLSPM_HD long nmg_fast_doubles(int Q, int Pm, int L, int cmax, int kmv) { return nmg_extra_doubles(Q, Pm, L, cmax, kmv) - 2L * (Q + 1) * L; }
+PLSPM_HD long nmg_persistent_doubles(int Q, int Pm, int L) { return (long)Q + Pm + L; }          // tq | tc | akk, contiguous at the head of both layouts
+PLSPM_HD void nmg_carve_fast(NmgExtra& x, NmgExtra& g, double* gbase, double* fast, int Q, int Pm, int L, int cmax, int kmv) {
+    nmg_carve(g, gbase, Q, Pm, L, cmax, kmv);
+    double* p = fast;
+    x.tq = p; p += Q; x.tc = p; p += Pm; x.akk = p; p += L;
+    x.V = g.V; x.MZ = g.MZ;
+    x.YY = p; p += (long)L * L;
+    x.mvm = p; p += (long)Pm * L + Pm;
+    x.cm = p; p += cmax; x.cf = p; p += cmax; x.cs = p; p += cmax;
+    x.inc = p; p += cmax; x.dec = p; p += cmax; x.gsum = p; p += cmax; x.gf = p; p += cmax;
+    x.Bm = p; p += (long)kmv * kmv; x.Fm = p; p += (long)kmv * kmv; x.Vm = p; p += (long)kmv * kmv; x.beta = p; p += kmv; x.rhs = p; p += kmv;
+    x.grp = reinterpret_cast<int*>(p); p += cmax + 8;
+    x.pq = p;
+}
 
 // score map over the aug columns of coefficient set (a, kk) with the current quantification: c_j = a_mv(j) tq_j, k_l = kk_l + sum a_p tc_p
 template <class Ex>
@@ -74,7 +91,15 @@ PLSPM_HD void nmg_apply(Ex& ex, const ModelDesc& md, const double* Mn, int LD, c
     const int Q = md.P, L = md.L;
     ex.par2(Q + 1, L, [&](int j, int m) {
         double s = Mn[Q * LD + j] * k[m];                               // <col_j, 1> k_m   (Mn[Q][Q] = 1)
-        for (int q = md.boff[m]; q < md.boff[m + 1]; ++q) s += Mn[q * LD + j] * c[q];
+        // (eight loads in flight per thread: the pass streams all of Mn once and is bound by memory latency x concurrency)
+        const int q1 = md.boff[m + 1];
+        int q = md.boff[m];
+        for (; q + 8 <= q1; q += 8) {
+            double v[8];
+            for (int u = 0; u < 8; ++u) v[u] = Mn[(q + u) * LD + j];
+            for (int u = 0; u < 8; ++u) s += v[u] * c[q + u];
+        }
+        for (; q < q1; ++q) s += Mn[q * LD + j] * c[q];
         V[j * L + m] = s;
     });
 }
@@ -82,17 +107,38 @@ PLSPM_HD void nmg_apply(Ex& ex, const ModelDesc& md, const double* Mn, int LD, c
 // raw moment <MV_p, u> for a variable u given by its column moments Mu[j] = <col_j, u> and its mean
 PLSPM_HD double nmg_mv_moment(const CatDesc& cd, const NmgExtra& x, int p, const double* Mu, int stride, double mean_u) {
     double s = x.tc[p] * mean_u;
-    for (int j = cd.mv_off[p]; j < cd.mv_off[p + 1]; ++j) s += x.tq[j] * Mu[j * stride];
+    const int j1 = cd.mv_off[p + 1];
+    int j = cd.mv_off[p];
+    while (j < j1) {                                                    // (up to eight moment loads in flight, see nmg_mv_mv)
+        double v[8];
+        for (int u = 0; u < 8; ++u) v[u] = (j + u < j1) ? Mu[(j + u) * stride] : 0.0;
+        for (int u = 0; u < 8 && j + u < j1; ++u) s += x.tq[j + u] * v[u];
+        j += 8;
+    }
     return s;
 }
 // raw moment <MV_p, MV_q>
+// (the moment loads of a row of the sub-block are issued together, up to eight at a time: the entries come from global memory and a
+//  dependent chain of single loads costs a memory round trip each; same terms in the same order)
 PLSPM_HD double nmg_mv_mv(const CatDesc& cd, const NmgExtra& x, const double* Mn, int LD, int Q, int p, int q) {
     double s = 0.0, mq = x.tc[q];
-    for (int j = cd.mv_off[q]; j < cd.mv_off[q + 1]; ++j) mq += x.tq[j] * Mn[Q * LD + j];          // mean of MV_q
+    const int j0 = cd.mv_off[q], j1 = cd.mv_off[q + 1];
+    for (int j = j0; j < j1; ++j) mq += x.tq[j] * Mn[Q * LD + j];          // mean of MV_q
     for (int i = cd.mv_off[p]; i < cd.mv_off[p + 1]; ++i) {
         double t = 0.0;
-        for (int j = cd.mv_off[q]; j < cd.mv_off[q + 1]; ++j) t += Mn[j * LD + i] * x.tq[j];
-        s += x.tq[i] * (t + Mn[Q * LD + i] * x.tc[q]);
+        const double mi = Mn[Q * LD + i];
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            double v[8];
+            for (int u = 0; u < 8; ++u) v[u] = Mn[(j + u) * LD + i];
+            for (int u = 0; u < 8; ++u) t += v[u] * x.tq[j + u];
+        }
+        if (j < j1) {
+            double v[8];
+            for (int u = 0; u < 8; ++u) v[u] = (j + u < j1) ? Mn[(j + u) * LD + i] : 0.0;
+            for (int u = 0; u < 8; ++u) if (j + u < j1) t += v[u] * x.tq[j + u];
+        }
+        s += x.tq[i] * (t + mi * x.tc[q]);
     }
     return s + x.tc[p] * mq;
 }
@@ -213,20 +259,35 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
     }
     const double n = st.scal[0], corr2 = n / (n - 1.0);
     ex.one([&]() { ws.scal[3] = (double)ST_OK; });                                // the small workspace does not survive between launches
+    ex.mark(20);
     // scores' moments: V = Mn . score maps, YY raw, means, covariance
     nmg_apply(ex, md, Mn, LD, st.c_old, st.k_old, x.V);
+    ex.mark(21);
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;
         double s = st.k_old[l] * x.V[Q * L + m];
-        for (int j = md.boff[l]; j < md.boff[l + 1]; ++j) s += st.c_old[j] * x.V[j * L + m];
+        const int j1 = md.boff[l + 1];
+        int j = md.boff[l];
+        for (; j + 8 <= j1; j += 8) {                                             // (eight independent loads per trip, see nmg_apply)
+            double v[8], c[8];
+            for (int u = 0; u < 8; ++u) { v[u] = x.V[(j + u) * L + m]; c[u] = st.c_old[j + u]; }
+            for (int u = 0; u < 8; ++u) s += c[u] * v[u];
+        }
+        for (; j < j1; ++j) s += st.c_old[j] * x.V[j * L + m];
         x.YY[e] = s;
     });
     ex.par(L * L, [&](int e) { const int l = e / L, m = e - l * L; ws.G[e] = x.YY[e] - x.V[Q * L + l] * x.V[Q * L + m]; });
+    ex.mark(22);
     inner_weights(ex, md, ws, corr2, x.YY);
+    ex.mark(23);
     // MZ[j,l] = <col_j, z_l>, row Q = mean(z_l);  ws.a[l] = <z_l, z_l> raw
     ex.par2(Q + 1, L, [&](int j, int l) {
         double s = 0.0;
-        for (int m = 0; m < L; ++m) s += x.V[j * L + m] * ws.E[m * L + l];
+        for (int m = 0; m < L; m += 8) {                                          // (the row of V in one go)
+            double v[8];
+            for (int u = 0; u < 8; ++u) v[u] = (m + u < L) ? x.V[j * L + m + u] : 0.0;
+            for (int u = 0; u < 8 && m + u < L; ++u) s += v[u] * ws.E[(m + u) * L + l];
+        }
         x.MZ[j * L + l] = s;
     });
     ex.par(L, [&](int l) {
@@ -240,6 +301,7 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
         }
         ws.a[l] = s;
     });
+    ex.mark(24);
     // Quantification (weights.py:112-115).  Without the Mode-B correction (Mode A blocks, single-MV blocks) the MVs of a block
     // only read z_l, so ALL of them are quantified at once, one thread per MV with its own scratch; Mode-B blocks go MV by MV
     // below (Gauss-Seidel: the correction of MV j uses the block's MVs as updated so far, weights.py:143-145).
@@ -253,14 +315,66 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
         double* w = x.pq + (long)p * 8 * cm_;
         double *cm = w, *cf = w + cm_, *cs = w + 2 * cm_, *inc = w + 3 * cm_, *dec = w + 4 * cm_, *gsum = w + 5 * cm_, *gf = w + 6 * cm_;
         int* grp = reinterpret_cast<int*>(w + 7 * cm_);
-        for (int c = 0; c < C; ++c) {
-            cf[c] = Mn[Q * LD + j0 + c];
-            cm[c] = (cf[c] > 0.0) ? x.MZ[(j0 + c) * L + l] / cf[c] : 0.0;
+        for (int c0 = 0; c0 < C; c0 += 8) {                                       // (category counts and sums: the loads first, then the divisions)
+            double f[8], z[8];
+            for (int u = 0; u < 8; ++u) { const bool in = c0 + u < C; f[u] = in ? Mn[Q * LD + j0 + c0 + u] : 0.0; z[u] = in ? x.MZ[(j0 + c0 + u) * L + l] : 0.0; }
+            for (int u = 0; u < 8 && c0 + u < C; ++u) { cf[c0 + u] = f[u]; cm[c0 + u] = (f[u] > 0.0) ? z[u] / f[u] : 0.0; }
         }
         nmg_quantify_mv(kind, C, Mn + Q * LD + j0, cm, cf, cs, inc, dec, gsum, gf, grp, x.tq + j0);
         x.tc[p] = 0.0;
     });
+    ex.mark(25);
+    // Outer weights and normalisation.  When every block is Mode A the LVs do not depend on each other inside the step:
+    // all of them go through the same four phases at once (the per-LV loop below costs four dependent memory round trips per LV).
+    // Same expressions, same summation order as the loop: bitwise the same a_new / akk.
+    bool fused = true;
+    long npairs = 0;
     for (int l = 0; l < L; ++l) {
+        const int k = cd.lmv_off[l + 1] - cd.lmv_off[l];
+        if (md.mode[l] == MODE_B) fused = false;                                  // (block solves and the Gauss-Seidel correction: the loop below)
+        npairs += (long)k * k;
+    }
+    if (npairs > 8L * Pm * cd.cmax) fused = false;                                // the pair products borrow the quantification scratch
+    if (fused) {
+        double* pairs = x.pq;                                                     // [sum_l k_l^2]: <MV_r, MV_c> of the block, row-major per LV
+        double* mv_mean = x.mvm + Pm;                                             // [Pm] means of the quantified MVs
+        ex.par(Pm, [&](int p) {
+            int l = 0;
+            while (p >= cd.lmv_off[l + 1]) ++l;
+            const double m = nmg_mv_moment(cd, x, p, x.MZ + l, L, x.MZ[Q * L + l]);
+            x.mvm[p] = m;
+            ws.wn[p] = m / ws.a[l];            // Mode A (mode.py:38)
+            double mr = x.tc[p];
+            for (int j = cd.mv_off[p]; j < cd.mv_off[p + 1]; ++j) mr += x.tq[j] * Mn[Q * LD + j];
+            mv_mean[p] = mr;
+        });
+        ex.par((int)npairs, [&](int e) {
+            int l = 0, base = 0;
+            for (;;) { const int k = cd.lmv_off[l + 1] - cd.lmv_off[l]; if (e < base + k * k) break; base += k * k; ++l; }
+            const int p0 = cd.lmv_off[l], k = cd.lmv_off[l + 1] - p0;
+            const int r = (e - base) / k, c = (e - base) - r * k;
+            if (r <= c) { const double v = nmg_mv_mv(cd, x, Mn, LD, Q, p0 + r, p0 + c); pairs[base + r * k + c] = v; pairs[base + c * k + r] = v; }
+        });
+        ex.par(L, [&](int l) {
+            const int p0 = cd.lmv_off[l], k = cd.lmv_off[l + 1] - p0;
+            int base = 0;
+            for (int m = 0; m < l; ++m) { const int km = cd.lmv_off[m + 1] - cd.lmv_off[m]; base += km * km; }
+            double q = 0.0, mw = 0.0;
+            for (int r = 0; r < k; ++r) {
+                mw += ws.wn[p0 + r] * mv_mean[p0 + r];
+                for (int c = 0; c < k; ++c) q += ws.wn[p0 + r] * pairs[base + r * k + c] * ws.wn[p0 + c];
+            }
+            const double sd = sqrt(q - mw * mw);
+            x.akk[l] = -mw / sd;
+            ws.wf[l] = sd;                     // (an L-vector of the workspace that only the finish uses)
+        });
+        ex.par(Pm, [&](int p) {
+            int l = 0;
+            while (p >= cd.lmv_off[l + 1]) ++l;
+            st.a_new[p] = ws.wn[p] / ws.wf[l];
+        });
+    }
+    for (int l = 0; l < L && !fused; ++l) {
         const int p0 = cd.lmv_off[l], p1 = cd.lmv_off[l + 1], k = p1 - p0;
         const double mean_z = x.MZ[Q * L + l];
         bool have_beta = false;
@@ -344,7 +458,9 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
             x.akk[l] = -mw / sd;                                                   // constant of the NEW score (zero for centred MVs)
         });
     }
+    ex.mark(26);
     nmg_score_map(ex, md, cd, x, st.a_new, x.akk, st.c_new, st.k_new);
+    ex.mark(27);
     ex.one([&]() { st.scal[2] = (double)(iteration + 1); if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3]; });
     return true;
 }

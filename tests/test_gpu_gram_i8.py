@@ -393,3 +393,39 @@ def test_automatic_plane_count_and_its_error_against_extended_precision():
     small.upload(Xs)
     small.bootstrap_device(16, seed=1)
     assert small.get_option("last_gram_path") == 2 and small.get_option("last_i8_slices") == 7 and 0 < small.get_option("last_i8_ratio") < 256
+
+
+@pytest.mark.parametrize("step,expect", [(1.0, 1), (1.0 / 16, 2), (1.0 / 4096, 4)])
+def test_planes_that_would_be_zero_are_dropped_without_changing_a_bit(step, expect):
+    """Automatic plane count, second rule: planes that are identically zero in the seven-plane decomposition carry nothing.  Data on a
+    coarse binary grid (0/1 indicator columns, small integers, short binary fractions) are represented EXACTLY by fewer planes: the
+    moment matrices and the rows are bit-identical to the seven-plane ones.  Columns with exactly zero mean, so that the device's
+    mean-shifted columns stay on the grid."""
+    rng = np.random.default_rng(17)
+    N, C = 1200, orc.chain_C(3)
+    half = rng.integers(-7 * 16, 7 * 16 + 1, size=(N // 2, 9)).astype(float) * step * (1.0 if step < 1 else 1.0 / 16)
+    if step == 1.0:
+        half = np.round(half)
+    half = np.round(half / step) * step
+    eta = rng.standard_normal((N // 2, 3))
+    base = np.round((eta[:, [0, 0, 0, 1, 1, 1, 2, 2, 2]] * 2.0 + 0.3 * half / max(np.abs(half).max(), 1e-300) * 7) / step) * step
+    X = np.concatenate((base, -base), axis=0)                      # every column sums to exactly zero
+    blocks = [np.arange(0, 3), np.arange(3, 6), np.arange(6, 9)]
+    model = orc.Model(blocks, C, "AAA", "centroid", False)
+    nm = native_model(model)
+    nm.upload(X)
+    rows_auto = nm.bootstrap(40, seed=3)[0]
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_slices") == expect, nm.get_option("last_i8_slices")
+    M_auto = nm.bootstrap_moments(8, seed=3)
+    nm.set_option("i8_slices", 7)
+    rows_7 = nm.bootstrap(40, seed=3)[0]
+    M_7 = nm.bootstrap_moments(8, seed=3)
+    assert nm.get_option("last_i8_slices") == 7
+    assert np.array_equal(M_auto, M_7)
+    assert np.array_equal(rows_auto, rows_7)
+    for S in (1, 2, 3, 4):                                         # every small plane count runs (coarser ones simply round more)
+        nm.set_option("i8_slices", S)
+        M_S = nm.bootstrap_moments(8, seed=3)
+        assert nm.get_option("last_i8_slices") == S
+        if S >= expect:
+            assert np.array_equal(M_S, M_7)
