@@ -316,7 +316,11 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ub), "s"(lds_dst) : "memory");
 }
 
-template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16, int RT = 16>
+// IND ("independent planes"): the digit buffer holds ONE plane per pair group (0/1 indicator data, plspm_hip.hip choose_slices) and the S
+// "planes" a wave walks are S consecutive pair groups of it -- the same main loop at its full accumulator tile (a one-plane
+// instantiation moves 16 KB of counts per 8 MFMAs of a wave and is bound by the loads); the epilogue stores S x 16 pairs per wave
+// instead of recombining S planes into 16.
+template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16, int RT = 16, bool IND = false>
 __global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(RT < 16 ? 2 : WM / 2, RT < 16 ? 2 : WM / 2)))
 gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
                const int* __restrict__ pair_dst2, const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
@@ -505,6 +509,33 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
 
     // Epilogue: the lane's pair and replicates from the MFMA's C/D map -- 16x16: column lane & 15, rows 4 (lane >> 4) + reg;
     // 32x32: column lane & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    if constexpr (IND) {
+        static_assert(!IND || SH == 16, "independent planes: 16x16x64 layout");
+        const long rep0 = (long)ty * (16 * RT) + wm * (MTW * 16) + (lane >> 4) * 4;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int js = ((tx * 2 + wn) * S + s) * 16 + (lane & 15);          // plane s of this wave = pair group (2 tx + wn) S + s of the buffer
+            if (js >= npair) continue;
+            const double scs = pair_scale[js];
+            double* gp = gram + rep0 * psize + pair_dst[js];
+            const long d2 = pair_dst2 ? (long)pair_dst2[js] - (long)pair_dst[js] : 0;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (rep0 + mt * 16 + reg < nrep) {
+                        const double v = (double)acc[mt][s][reg] * scs;
+                        *gp = v;
+                        if (pair_dst2 && pair_dst2[js] >= 0) gp[d2] = v;
+                    }
+                    gp += psize;
+                    asm volatile("" : "+v"(gp)::"memory");
+                }
+                gp += 12 * psize;
+            }
+        }
+        return;
+    }
     const int j = SH == 16 ? (tx * 2 + wn) * 16 + (lane & 15) : tx * 32 + (lane & 31);
     if (j >= npair) return;
     const long dstj = pair_dst[j];

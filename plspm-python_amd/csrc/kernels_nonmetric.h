@@ -266,17 +266,59 @@ __global__ void __launch_bounds__(256) tile_transpose_kernel(const double* __res
     }
 }
 
-// table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = 64 g + lane; row 2P + 2L: active flag
-__global__ void __launch_bounds__(256) coef_table_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, long nproblems, double* __restrict__ table) {
+// The problems still iterating, in problem order: list[0 .. count) = their ids, list[-1] ... the count itself goes to *count.  One
+// workgroup; ballot prefix per wave, running offset across the trips (a few thousand problems: a few microseconds).  The stop-rule
+// pass then walks ceil(count / 64) groups of LIVE problems -- in the late iterations of a batch most problems have stopped, and a
+// group of 64 consecutive ids almost never stops as a whole.
+__global__ void __launch_bounds__(1024) active_list_kernel(const double* __restrict__ gstate, long state_stride, long nproblems, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ int wcount[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (long b0 = 0; b0 < nproblems; b0 += 1024) {
+        const long b = b0 + tid;
+        const bool on = b < nproblems && gstate[b * state_stride + 3] != 0.0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wcount[w];
+        if (on) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)b;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+
+// table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = list[64 g + lane] (live problems only); row
+// 2P + 2L: 1 for a live slot, 0 for the padding of the last group.  Grid (groups, chunks of 64 coefficients): the 64 coefficients of a
+// problem are read as one 512-byte run and leave transposed through LDS (the first version read every coefficient as a cache line of
+// its own: 71 us per call at 1,000 problems x 613 coefficients).
+__global__ void __launch_bounds__(256) coef_table_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, const int* __restrict__ list,
+                                                          const int* __restrict__ count, double* __restrict__ table) {
+    __shared__ double tile[64][65];
+    const int n = *count;
     const long g = blockIdx.x;
-    const int rows = 2 * P + 2 * L + 1;
-    double* out = table + g * (long)rows * 64;
-    for (int e = threadIdx.x; e < rows * 64; e += 256) {
-        const int q = e >> 6, lane = e & 63;
-        const long b = g * 64 + lane;
+    if (g * 64 >= n) return;
+    const int rows = 2 * P + 2 * L + 1, q0 = (int)blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = w; r < 64; r += 4) {                            // replicate slot r of the group: coefficients q0 .. q0 + 63
+        const long slot = g * 64 + r;
         double v = 0.0;
-        if (b < nproblems) { const double* st = gstate + b * state_stride; v = (q < rows - 1) ? st[8 + 2 * P + q] : st[3]; }
-        out[e] = v;
+        if (slot < n) {
+            const double* st = gstate + (long)list[slot] * state_stride;
+            const int q = q0 + lane;
+            v = (q < rows - 1) ? st[8 + 2 * P + q] : (q == rows - 1 ? 1.0 : 0.0);
+        }
+        tile[r][lane] = v;
+    }
+    __syncthreads();
+    double* out = table + g * (long)rows * 64;
+    for (int qq = w; qq < 64; qq += 4) {
+        const int q = q0 + qq;
+        if (q < rows) out[(long)q * 64 + lane] = tile[lane][qq];
     }
 }
 
@@ -301,8 +343,9 @@ typedef double d8 __attribute__((ext_vector_type(8)));
 // that a second resample kernel had to write (20 KB per replicate).  dcnt_stride then carries MT (replicate tiles of the counts).
 template <int RW, int NW, bool BLOCKED, bool CNT8 = false>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
-                                                                 const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table, int ngroups,
-                                                                 long nproblems, double* __restrict__ partial, int nparts, int rbx, int gy, int kb) {
+                                                                 const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table,
+                                                                 const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial, int nparts, int rbx,
+                                                                 int gy, int kb) {
     static_assert(!CNT8 || RW == 16, "the int8 counts come in pieces of 16 rows");
     // multiplicities of this wave's RW rows in replicate b: packed words (uint16 pairs, or bytes of the int8 counts)
     auto load_counts = [&](unsigned (&wq)[RW / 2], bool on, long b, long part) {
@@ -343,13 +386,13 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
     const double* cn = co + (long)P * 64;
     const double* ko = co + 2L * P * 64;
     const double* kn = ko + (long)L * 64;
+    // groups of 64 LIVE problems (active_list_kernel / coef_table_kernel): slot 64 g + lane is problem list[slot]; nothing live (the
+    // speculative pass after the last iteration): no trip at all
+    const int nlive = *count, ngroups = (nlive + 63) / 64;
     for (int g = gy0; g < ngroups; g += gy) {
-        // nothing active in this group (e.g. the speculative pass after the last iteration): skip before staging; the decision is
-        // the same for every thread of the workgroup, so no barrier is skipped by part of it
-        if (__ballot(table[((long)g * rows + rows - 1) * 64 + lane] != 0.0) == 0ull) continue;
         if (BLOCKED) {
-            const long b = (long)g * 64 + lane;
-            const bool live = b < nproblems;
+            const bool live = (long)g * 64 + lane < nlive;
+            const long b = live ? (long)list[(long)g * 64 + lane] : 0;
             unsigned wq[RW / 2];
             load_counts(wq, live && have, b, part);
             const double* tg = table + (long)g * rows * 64;
@@ -408,9 +451,9 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
         double2* dst = reinterpret_cast<double2*>(co);
         for (int e = threadIdx.x; e < rows * 32; e += 64 * NW) dst[e] = src[e];
         __syncthreads();
-        const long b = (long)g * 64 + lane;
         if (!have) continue;
-        const bool live = b < nproblems;
+        const bool live = (long)g * 64 + lane < nlive;
+        const long b = live ? (long)list[(long)g * 64 + lane] : 0;
         unsigned wq[RW / 2];                                    // two uint16 counts (or four int8 counts) per word
         load_counts(wq, live, b, part);
         double acc = 0.0;

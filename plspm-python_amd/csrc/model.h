@@ -45,7 +45,7 @@ struct plspm_model {
     double* d_Xa = nullptr;
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, sum_buf, cols;
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, nmlist, sum_buf, cols;
     int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
     int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
     int Pm = 0, cmax = 1, kmv = 1;
@@ -83,7 +83,7 @@ struct plspm_model {
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
     Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat;
@@ -103,6 +103,7 @@ struct plspm_model {
     int cd_slot = 0;
     bool zs_valid = false;
     int zs_S = 0, zs_KB = 0, zs_NT = 0, zs_npair = 0, zs_npg = 0;
+    bool zs_ind = false;        // one plane per pair group, launched through the seven-plane main loop (gram_i8_kernel<.., IND>)
     double zs_ratio = 0.0;      // smallest sum|z| / max|z| over the pair columns (automatic plane count; 0: not evaluated)
     double* moments_out = nullptr; // plspm_bootstrap_moments: dense moment matrices go here and the solver is skipped
     int last_gram_path = 0;       // 1 fp64 MFMA, 2 int8 digit planes: what the last bootstrap call used (plspm_model_get_info)

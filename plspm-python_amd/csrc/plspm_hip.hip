@@ -301,7 +301,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
-                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->sum_buf.p, m->cols.p,
+                    m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->sum_buf.p, m->cols.p,
                     m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
@@ -566,6 +566,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
         if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->nmlist, ((size_t)nproblems + 1) * sizeof(int)))) return rc;
         const void* ck = counts8 ? (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, true> : (const void*)nm_conv_dense_kernel<16, 8, true, true>)
                                  : (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, false> : (const void*)nm_conv_dense_kernel<16, 8, true, false>);
         if ((rc = allow_lds(m, ck, dense_use_lds))) return rc;
@@ -650,7 +651,10 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 conv_state = (const double*)m->pseudo.p; conv_stride = ps_stride; conv_boff = m->d_lv_cols;
             }
             if (dense) {
-                hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L, nproblems, (double*)m->ctable.p);
+                int* live_list = (int*)m->nmlist.p;                            // [count | ids of the problems still iterating, in problem order]
+                hipLaunchKernelGGL(active_list_kernel, dim3(1), dim3(1024), 0, m->stream, conv_state, conv_stride, nproblems, live_list + 1, live_list);
+                hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups, (unsigned)((2 * src->P + 2 * L + 1 + 63) / 64)), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L,
+                                   (const int*)(live_list + 1), (const int*)live_list, (double*)m->ctable.p);
                 const int gx = (int)((ntiles16 + 7) / 8);                      // row blocks of 128 rows (8 tiles: 8 x 16-row or 16 x 8-row waves)
                 const int rbx = (gx + 7) / 8;                                  // row blocks per XCD
                 // replicate slices: one group of 64 replicates per workgroup measured best (1.06 ms for three passes against 1.17 / 1.21 /
@@ -660,7 +664,7 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                                            : (dense_whole ? nm_conv_dense_kernel<16, 8, false, false> : nm_conv_dense_kernel<16, 8, true, false>);
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
-                                   (const double*)m->ctable.p, ngroups, nproblems, part, nparts, rbx, gy, kb);
+                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
                                    ent_stride, conv_state, conv_stride, part);
@@ -713,6 +717,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
+    else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
     else if (k == "i8_rt") { if (value != 16 && value != 8) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
@@ -745,6 +750,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "nm_fast_lds") *value = m->tune.nm_fast_lds;
+    else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_dma") *value = m->tune.i8_dma;
     else if (k == "last_i8_dma") *value = m->last_i8_dma;
@@ -1111,14 +1117,18 @@ static int prepare_zs(plspm_model* m) {
         }
         hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
     }
-    const int NT = npg * S;
+    // one plane (0/1 data): the product runs through the seven-plane main loop with the planes of a wave standing for seven consecutive
+    // pair groups (gram_i8_kernel<.., IND>): the buffer is padded to whole tiles of 2 x 7 groups
+    const bool ind = S == 1 && m->tune.i8_shape == 16 && m->tune.i8_ind != 0;
+    const int npg_built = ind ? ((npg + 13) / 14) * 14 : npg;
+    const int NT = npg_built * S;
     if ((rc = ensure(m, m->zs, (size_t)(KB + I8_SLACK_KB) * (size_t)NT * 1024))) return rc;      // (sized once the plane count is known: 0/1 data take one plane)
-    const dim3 grid((unsigned)KB, (unsigned)((npg + 3) / 4));
-#define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg, NT, m->tune.i8_shape, (uint4*)m->zs.p)
+    const dim3 grid((unsigned)KB, (unsigned)((npg_built + 3) / 4));
+#define ZSB(SS) hipLaunchKernelGGL((zs_build_kernel<SS>), grid, dim3(256), 0, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, d_p, d_q, d_k, (int)npair, npg_built, NT, m->tune.i8_shape, (uint4*)m->zs.p)
     switch (S) { case 1: ZSB(1); break; case 2: ZSB(2); break; case 3: ZSB(3); break; case 4: ZSB(4); break; case 5: ZSB(5); break; case 6: ZSB(6); break; case 7: ZSB(7); break; default: ZSB(8); break; }
 #undef ZSB
     HIPCHK(m, hipGetLastError());
-    m->zs_S = S; m->zs_KB = KB; m->zs_NT = NT; m->zs_npair = (int)npair; m->zs_npg = npg;
+    m->zs_S = S; m->zs_KB = KB; m->zs_NT = NT; m->zs_npair = (int)npair; m->zs_npg = npg_built; m->zs_ind = ind;
     m->zs_valid = true;
     return 0;
 }
@@ -1134,7 +1144,8 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     // workgroup tile of the product: 16 RT replicates x 32 pairs; narrow tiles (RT 12 / 8) only in the plain four-wave 16x16x64 launch
     const bool narrow = m->tune.i8_rt != 16 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7;
     const int RTg = narrow ? m->tune.i8_rt : 16;
-    const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = m->zs_npg / 2;
+    const bool ind = m->zs_ind && m->tune.i8_sched == 0 && m->tune.i8_variant < 0;
+    const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
     // resample counts from an LDS histogram per (replicate, window of rows): 65,536 rows of 16-bit counters, or -- Philox draws of a data
     // set that would need more than one such window -- 131,072 rows of 8-bit counters (kernels_gram_i8.h resample_i8_kernel)
     const bool hist_byte = KB > I8_HIST_KB && !d_idx;
@@ -1192,7 +1203,10 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const int total = ntx * nty, per = (total + 7) / 8;
     // packed: the tile-packed slots the LDS solver / impute kernel read; dense: [(Pg+1) x cov_ld(Pg)] row-major, upper triangle (rows solver)
     const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
-    const int* d_dst2 = nullptr;          // (a mirrored second store per element cost 0.08 ms per 5,000 replicates: the rows solver reads the triangle instead)
+    // (a mirrored second store per element cost 0.08 ms per 5,000 replicates of the metric benchmark: the rows solver reads the triangle
+    //  instead.  Categorical problems, whose solver wants the full square: Gram 1.40 -> 2.07 ms per 1,000 problems with the mirrored
+    //  stores against 0.4 ms saved in nmg_prepare's scatter -- not taken either)
+    const int* d_dst2 = nullptr;
     const long out_stride = dense ? cov_doubles(m->Pg) : packed_size(m->T);
     // persistent stream-K schedule (kernels_gram_i8.h gram_i8_sk_kernel): one workgroup per CU, whole CUs per XCD
     const bool sk = m->tune.i8_sched == 1 && m->tune.i8_shape == 16 && m->tune.i8_variant < 0 && S >= 5 && S <= 7;      // (S = 8 spills in the persistent kernel)
@@ -1248,6 +1262,17 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         hipLaunchKernelGGL((gram_i8_kernel<7, 2, I8_DEFAULT_VAR, 16, RR>), dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p, \
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
     }
+#define GI8IND(WW, VV)                                                                                                                       \
+    {                                                                                                                                        \
+        const size_t lds_bytes = GramI8<7, WW, VV, 16, 16>::LDS_BYTES;                                                                       \
+        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<7, WW, VV, 16, 16, true>, lds_bytes))) return rc;                                 \
+        hipLaunchKernelGGL((gram_i8_kernel<7, WW, VV, 16, 16, true>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+    }
+    if (ind) {                   // one plane per pair group, seven groups per wave
+        if (dma_buffer) { if (m->tune.i8_waves == 4) GI8IND(2, I8_DEFAULT_VAR + 800) else GI8IND(4, I8_DEFAULT_VAR + 800) }
+        else { if (m->tune.i8_waves == 4) GI8IND(2, I8_DEFAULT_VAR) else GI8IND(4, I8_DEFAULT_VAR) }
+    } else
     if (narrow) GI8RT(8) else
 #undef GI8RT_DUMMY
     if (m->tune.i8_shape == 32 && S >= 5) {    // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)
