@@ -270,7 +270,10 @@ __global__ void __launch_bounds__(256) tile_transpose_kernel(const double* __res
 // workgroup; ballot prefix per wave, running offset across the trips (a few thousand problems: a few microseconds).  The stop-rule
 // pass then walks ceil(count / 64) groups of LIVE problems -- in the late iterations of a batch most problems have stopped, and a
 // group of 64 consecutive ids almost never stops as a whole.
-__global__ void __launch_bounds__(1024) active_list_kernel(const double* __restrict__ gstate, long state_stride, long nproblems, int* __restrict__ list, int* __restrict__ count) {
+// `host_count` (pinned host memory, may be null): the count once more, for the host's "anything left?" test -- written by the kernel, no copy
+// operation (and no counter to clear) per iteration.
+__global__ void __launch_bounds__(1024) active_list_kernel(const double* __restrict__ gstate, long state_stride, long nproblems, int* __restrict__ list, int* __restrict__ count,
+                                                            int* __restrict__ host_count) {
     __shared__ int wcount[16];
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(1024) active_list_kernel(const double* __restr
         if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
         __syncthreads();
     }
-    if (tid == 0) *count = base;
+    if (tid == 0) { *count = base; if (host_count) *host_count = base; }
 }
 
 // table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = list[64 g + lane] (live problems only); row

@@ -632,14 +632,19 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact, fuse);
         }
     };
+    // (dense stop-rule pass: the list kernel of the pass counts the live problems anyway and writes the count to the pinned flag itself -- no
+    //  counter to clear, no copy operation: two tiny launches and their gaps less per iteration, 35 of ~590 us at three iterations)
+    const bool flag_from_list = dense && !m->stage1;
     for (int it = 0; it <= m->max_iter + 1; ++it) {
-        HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
+        if (!flag_from_list) HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
         launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
         // problems / replicate groups return at once on the device, and the 4-byte read-back of the counter overlaps with the pass
         // instead of leaving the GPU idle for a host round trip per iteration.
-        HIPCHK(m, hipMemcpyAsync(m->h_flag, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+        if (!flag_from_list) {
+            HIPCHK(m, hipMemcpyAsync(m->h_flag, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+        }
         {
             ProfScope ps(m, PLSPM_K_SCORES);
             const double* conv_state = gst;
@@ -652,7 +657,9 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             }
             if (dense) {
                 int* live_list = (int*)m->nmlist.p;                            // [count | ids of the problems still iterating, in problem order]
-                hipLaunchKernelGGL(active_list_kernel, dim3(1), dim3(1024), 0, m->stream, conv_state, conv_stride, nproblems, live_list + 1, live_list);
+                hipLaunchKernelGGL(active_list_kernel, dim3(1), dim3(1024), 0, m->stream, conv_state, conv_stride, nproblems, live_list + 1, live_list,
+                                   flag_from_list ? (int*)m->h_flag : (int*)nullptr);
+                if (flag_from_list) HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
                 hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups, (unsigned)((2 * src->P + 2 * L + 1 + 63) / 64)), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L,
                                    (const int*)(live_list + 1), (const int*)live_list, (double*)m->ctable.p);
                 const int gx = (int)((ntiles16 + 7) / 8);                      // row blocks of 128 rows (8 tiles: 8 x 16-row or 16 x 8-row waves)
