@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __r
 template <int MODE>
 __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
                                                   double* gS, double* gSm, double* gstate, long state_stride,
-                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish, int extra_in_lds) {
+                                                  const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish, int extra_in_lds,
+                                                  unsigned short* gK16, int ld16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
     const long b = blockIdx.x;
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
             __syncthreads();
         }
     } else nmg_carve(x, state + nm_state_doubles(Q, L, 0), Q, cd.Pm, L, cd.cmax, cd.kmv);
+    if (gK16) { x.k16 = gK16 + b * (long)(Q + 1) * ld16; x.ld16 = ld16; }       // all-indicator model: uint16 copy of the count matrix (solver_nmg.h)
     stage_descriptors(md, lp);
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
     bool finish_now = (MODE == 2);

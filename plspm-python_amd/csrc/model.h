@@ -45,8 +45,9 @@ struct plspm_model {
     double* d_Xa = nullptr;
     // grow-only device scratch
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, nmlist, sum_buf, cols;
+    Buf ent, nent, gram, gram_partial, rows, status, iters, gS, gsmall, fitout, idx, err, ghist, nmstate, nmpartial, nmactive, nmlist, gK16, sum_buf, cols;
     int nonmetric = 0;           // Scale.NUM / Scale.RAW data: population-standardised MVs, score-based stop rule
+    bool cat_pure = false;       // every logical MV is ORD / NOM: all device columns are 0/1 indicators
     int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
     int Pm = 0, cmax = 1, kmv = 1;
     std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol;
@@ -83,7 +84,7 @@ struct plspm_model {
     int64_t rows_B = 0;           // number of valid records in `rows` (0: none)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 16, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
     Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat;

@@ -921,6 +921,15 @@ template <class Ex>
 PLSPM_HD void nm_prepare(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, const double* Mp) {
     const int P = md.P, L = md.L, PS = ws.PS, T = md.T;
     const int ntile = T * (T + 1) / 2;
+    // n, the column sums and the diagonal first (2 P + 1 loads straight from the packed matrix): the scatter then writes the CORRELATIONS in the
+    // same pass (a separate normalisation pass re-read and re-wrote the whole square).  Same expressions as before, entry by entry.
+    const double n = Mp[packed_index(T, P, P)], inv_n = 1.0 / n;
+    ex.par(P, [&](int p) {
+        const double mu = Mp[packed_index(T, p, P)];
+        st.mu[p] = mu;
+        st.sd[p] = sqrt(Mp[packed_index(T, p, p)] * inv_n - (mu * inv_n) * (mu * inv_n));       // population std (config.py:314)
+    });
+    ex.one([&]() { st.scal[0] = n; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
     ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
         const int tile = chunk >> 2, r = chunk & 3;
         int t, u;
@@ -928,18 +937,11 @@ PLSPM_HD void nm_prepare(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st
         else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
         const int p = packed_col_of(T, t, 4 * r + (lane >> 4));
         const int q = packed_col_of(T, u, lane & 15);
-        if ((t != u || p <= q) && p <= P && q <= P) { ws.S[q * PS + p] = m; ws.S[p * PS + q] = m; }
-    });
-    const double n = ws.S[P * PS + P], inv_n = 1.0 / n;
-    ex.par(P, [&](int p) {
-        const double mu = ws.S[P * PS + p];
-        st.mu[p] = mu;
-        st.sd[p] = sqrt(ws.S[p * PS + p] * inv_n - (mu * inv_n) * (mu * inv_n));       // population std (config.py:314)
-    });
-    ex.one([&]() { st.scal[0] = n; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
-    ex.par(P, [&](int p) {
-        const double mp = st.mu[p], sp = st.sd[p];
-        for (int q = 0; q < P; ++q) ws.S[q * PS + p] = ((ws.S[q * PS + p] - (mp * st.mu[q]) * inv_n) * inv_n) / (sp * st.sd[q]);
+        if ((t != u || p <= q) && p <= P && q <= P) {
+            double v = m;                                   // row / column P: raw column sums and n
+            if (p < P && q < P) v = ((m - (st.mu[p] * st.mu[q]) * inv_n) * inv_n) / (st.sd[p] * st.sd[q]);
+            ws.S[q * PS + p] = v; ws.S[p * PS + q] = v;
+        }
     });
     if (md.n_chol > 0) {
         ex.par(L, [&](int l) {

@@ -40,6 +40,12 @@ struct NmgExtra {
     double *Bm, *Fm, *Vm, *beta, *rhs;   // [kmv*kmv] block moment matrix, its factor copy, eigenvector scratch of the minimum-norm fallback; [kmv], [kmv]
     int* grp;                   // [cmax] (stored in a double-aligned slot)
     double* pq;                 // [Pm * 8 * cmax] per-MV scratch of the parallel quantification (Mode A blocks)
+    // Models whose device columns are ALL 0/1 indicators (every MV ORD / NOM): the moment matrix n Mn is a matrix of co-occurrence counts
+    // <= N.  With N <= 65,535 the caller may supply room for a uint16 copy (row pitch ld16, a multiple of 4): the product V = Mn c of every
+    // step -- the one pass that streams the whole matrix -- then moves a quarter of the bytes.  (double)count * (1/n) IS the entry of Mn
+    // (nmg_prepare forms it the same way), so the step is bitwise the same.  Not part of the carved state.
+    unsigned short* k16 = nullptr;
+    int ld16 = 0;
 };
 PLSPM_HD long nmg_extra_doubles(int Q, int Pm, int L, int cmax, int kmv) {
     return (long)Q + Pm + L + 2L * (Q + 1) * L + (long)L * L + ((long)Pm * L + Pm) + 7L * cmax + 3L * kmv * kmv + 2L * kmv + cmax + 8 + 8L * Pm * cmax;
@@ -87,8 +93,28 @@ PLSPM_HD void nmg_score_map(Ex& ex, const ModelDesc& md, const CatDesc& cd, cons
 
 // V[j,m] = <col_j, y_m> for j = 0..Q (row Q: mean of y_m), from the score map (c, k)
 template <class Ex>
-PLSPM_HD void nmg_apply(Ex& ex, const ModelDesc& md, const double* Mn, int LD, const double* c, const double* k, double* V) {
+PLSPM_HD void nmg_apply(Ex& ex, const ModelDesc& md, const double* Mn, int LD, const double* c, const double* k, double* V, const unsigned short* k16 = nullptr, int ld16 = 0,
+                        double inv_n = 0.0) {
     const int Q = md.P, L = md.L;
+    if (k16) {
+        // four columns per item (one 8-byte load per row of the block), eight rows in flight
+        ex.par2((Q + 4) / 4, L, [&](int j4, int m) {
+            const int j = 4 * j4;
+            double s[4];
+            for (int u = 0; u < 4; ++u) s[u] = (j + u <= Q) ? Mn[Q * LD + j + u] * k[m] : 0.0;
+            const int q1 = md.boff[m + 1];
+            for (int q = md.boff[m]; q < q1; q += 8) {
+                unsigned long long w[8];
+                for (int t = 0; t < 8; ++t) w[t] = (q + t < q1) ? *reinterpret_cast<const unsigned long long*>(k16 + (long)(q + t) * ld16 + j) : 0ull;
+                for (int t = 0; t < 8 && q + t < q1; ++t) {
+                    const double cq = c[q + t];
+                    for (int u = 0; u < 4; ++u) s[u] += ((double)(unsigned)((w[t] >> (16 * u)) & 0xffffull) * inv_n) * cq;
+                }
+            }
+            for (int u = 0; u < 4; ++u) if (j + u <= Q) V[(j + u) * L + m] = s[u];
+        });
+        return;
+    }
     ex.par2(Q + 1, L, [&](int j, int m) {
         double s = Mn[Q * LD + j] * k[m];                               // <col_j, 1> k_m   (Mn[Q][Q] = 1)
         // (eight loads in flight per thread: the pass streams all of Mn once and is bound by memory latency x concurrency)
@@ -200,6 +226,9 @@ template <class Ex>
 PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace& ws, NmState& st, NmgExtra& x, const double* Mp) {
     const int Q = md.P, L = md.L, LD = ws.PS, T = md.T;
     const int ntile = T * (T + 1) / 2;
+    // n = <1, 1> first (one uniform load): the scatter then writes the scaled entries -- and the uint16 copy of the counts -- in the same
+    // pass (a separate scaling pass re-read and re-wrote the whole square: 1.4 MB of traffic per problem)
+    const double n = Mp[packed_index(T, Q, Q)], inv_n = 1.0 / n;
     ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
         const int tile = chunk >> 2, r = chunk & 3;
         int t, u;
@@ -207,11 +236,17 @@ PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Worksp
         else { t = 0; int rem = tile; while (rem >= T - t) { rem -= T - t; ++t; } u = t + rem; }
         const int p = 32 * (t >> 1) + (t & 1) + 8 * r + 2 * (lane >> 4);
         const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
-        if ((t != u || p <= q) && p <= Q && q <= Q) { ws.S[q * LD + p] = m; ws.S[p * LD + q] = m; }
+        if ((t != u || p <= q) && p <= Q && q <= Q) {
+            const double v = m * inv_n;
+            ws.S[q * LD + p] = v; ws.S[p * LD + q] = v;
+            if (x.k16) { const unsigned short h = (unsigned short)(m + 0.5); x.k16[(long)q * x.ld16 + p] = h; x.k16[(long)p * x.ld16 + q] = h; }       // (integers: exact)
+        }
     });
-    ex.one([&]() { st.scal[0] = ws.S[Q * LD + Q]; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
-    const double n = st.scal[0], inv_n = 1.0 / n;          // read through the state: the scaling below rewrites S[Q][Q]
-    ex.par(Q + 1, [&](int p) { for (int q = 0; q <= Q; ++q) ws.S[q * LD + p] *= inv_n; });
+    if (x.k16 && x.ld16 > Q + 1) {                         // pitch padding zeroed: the product reads whole 8-byte groups
+        const int pad = x.ld16 - (Q + 1);
+        ex.par((Q + 1) * pad, [&](int e) { const int q = e / pad, c = e - q * pad; x.k16[(long)q * x.ld16 + Q + 1 + c] = (unsigned short)0; });
+    }
+    ex.one([&]() { st.scal[0] = n; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
     const double* Mn = ws.S;
     // initial "treated" values (config.py:314-318): NUM / RAW population-standardised, ORD / NOM rank codes 1..C
     ex.par(cd.Pm, [&](int p) {
@@ -261,7 +296,7 @@ PLSPM_HD bool nmg_step(Ex& ex, const ModelDesc& md, const CatDesc& cd, Workspace
     ex.one([&]() { ws.scal[3] = (double)ST_OK; });                                // the small workspace does not survive between launches
     ex.mark(20);
     // scores' moments: V = Mn . score maps, YY raw, means, covariance
-    nmg_apply(ex, md, Mn, LD, st.c_old, st.k_old, x.V);
+    nmg_apply(ex, md, Mn, LD, st.c_old, st.k_old, x.V, x.k16, x.ld16, 1.0 / n);
     ex.mark(21);
     ex.par(L * L, [&](int e) {
         const int l = e / L, m = e - l * L;

@@ -670,6 +670,26 @@ def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
     assert again["status"] == 0 and again["iterations"] == _["iterations"] and np.array_equal(again["weights"], _["weights"])
 
 
+def test_nonmetric_live_problem_list_across_batches():
+    """The stop-rule pass walks a compacted list of the problems still iterating (active_list_kernel: trips of 1,024 problems).  Replicates
+    stop after different numbers of iterations (tight tolerance, 600 rows), so the list shrinks from pass to pass; the records of a
+    replicate must not depend on who else is in its batch: 2,300 in one call == the same replicate ids in calls of 100 and of 1."""
+    X, blocks = orc.synth(600, orc.satisfaction_C(), 4, seed=23)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True, tol=1e-9, scales=["NUM"] * 24)
+    nm, _ = gpu_fit_nm(X, model)
+    rows, status, iters = nm.bootstrap(2300, seed=4)
+    assert np.all(status == 0) and iters.max() > iters.min()               # a spread of iteration counts: the list shrinks between passes
+    for first in (0, 1024, 2200):
+        r2, s2, i2 = nm.bootstrap(100, seed=4, rep_offset=first)
+        assert np.array_equal(r2, rows[first:first + 100]) and np.array_equal(i2, iters[first:first + 100])
+    r1, _, i1 = nm.bootstrap(1, seed=4, rep_offset=2299)
+    assert np.array_equal(r1[0], rows[2299]) and i1[0] == iters[2299]
+    from plspm import _native
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(4, 1500, 600), orc.correction(600))
+    assert its == iters[1500]
+    assert_close(rows[1500], mine, RTOL, ATOL)
+
+
 def test_nonmetric_bootstrap_10k_vs_oracle_spot_checks():
     from plspm import _native
     X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
