@@ -76,10 +76,13 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "gram_path"       0 auto | 1 fp64 MFMA Gram over (row,count) lists | 2 int8 digit-plane Gram (exact integer product of the dense
  *                     multiplicities with the base-256 digit planes of the pair products x_p x_q; every bootstrap whose planes fit
  *                     the memory budget: N < 2^24 rows (int32 sums), non-metric models N <= 65,535; second stages of HOC pairs take path 1)
- *   "i8_slices"       0 | 5 .. 8   digit planes per pair product.  0 (default) = automatic: 6 planes when every pair column of the uploaded data has
+ *   "i8_slices"       0 | 1 .. 8   digit planes per pair product.  0 (default) = automatic: 6 planes when every pair column of the uploaded data has
  *                     sum|z| >= 256 max|z| -- the worst-case error N 2^-47 max|z| of a replicate's sum is then below the a-priori bound N 2^-53 sum|z|
  *                     of an fp64 accumulation of the same terms, with a factor 4 to spare -- else 7 (>= 53 significant bits of the column
- *                     maximum: correctly rounded sums); read-only "last_i8_slices" / "last_i8_ratio" report the choice and floor(min sum / max)
+ *                     maximum: correctly rounded sums); and never more planes than carry anything: planes that are identically zero in the
+ *                     seven-plane decomposition are dropped (0/1 indicator columns: ONE plane, bit-identical sums).  Read-only "last_i8_slices" /
+ *                     "last_i8_ratio" report the choice and floor(min sum / max)
+ *   "i8_ind"          1 (default) | 0   one-plane data run through the seven-plane main loop, the planes of a wave standing for seven pair groups
  *   "i8_min_batch"    auto mode takes the int8 path from this many replicates per call (default 1: always -- the path must not
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
  *   "i8_waves"        4 | 8   waves per workgroup of the int8 Gram (4: one per SIMD, 128 replicates x 16 pairs each; default 8: two per SIMD, 64 x 16 each -- 1.5 % faster steps in alternating A/B runs)
@@ -102,6 +105,9 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
  *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
  *                     multiplicities from the int8 counts of the Gram (no second resample kernel / uint16 histograms / (row,count) lists)
+ *   "nm_fast_lds"     1 (default) | 0   categorical (ORD / NOM) solver: the small arrays of the iteration in LDS for the duration of a launch
+ *   "nm_k16"          1 (default) | 0   all-indicator categorical models of at most 65,535 rows: uint16 copy of the count matrix for the
+ *                     streaming product of every step (bit-identical steps, a quarter of the bytes)
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
  * (1 LDS solver, 2 rows solver, 3 wave solver) tell what the last bootstrap call took.
  */

@@ -13,6 +13,7 @@ X, blocks = synth(10000, C, 10, seed=0)
 boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0)
 nm.upload(X)
+nm.set_option("i8_slices", 7)                 # the probes are instantiated for the seven-plane kernel
 ref = nm.bootstrap(64, seed=1)[0]
 names = {3: "default", 803: "LDS-DMA as buffer_load ... offen lds", 103: "no DMA issue", 203: "no barrier", 303: "no DMA, no barrier", 403: "no fragment reads", 503: "no DMA, no reads", 703: "MFMA stream only"}
 for waves in (4, 8):

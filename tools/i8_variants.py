@@ -14,7 +14,7 @@ nm.upload(X)
 ref = None
 for waves in (4, 8):
     for var in (0, 3, 6, 4, 12, 18, 21, 24, 30, 33):
-        nm.set_option("i8_waves", waves); nm.set_option("i8_variant", var)
+        nm.set_option("i8_slices", 7); nm.set_option("i8_waves", waves); nm.set_option("i8_variant", var)
         rows = nm.bootstrap(64, seed=1)[0]
         if ref is None: ref = rows
         ok = bool(np.array_equal(rows, ref))

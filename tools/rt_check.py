@@ -12,7 +12,7 @@ boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int3
 ref = None
 for rt in (16, 12, 8):
     m = _native.NativeModel(boff, orc.satisfaction_C().astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0)
-    m.upload(X); m.set_option("i8_rt", rt)
+    m.upload(X); m.set_option("i8_slices", 7); m.set_option("i8_waves", 4); m.set_option("i8_rt", rt)
     rows, st, it = m.bootstrap(B, seed=1)
     if ref is None: ref = rows
     for w in range(20): m.bootstrap_device(B, seed=1, rep_offset=w * B)

@@ -25,7 +25,7 @@ for name, N, C, B in (("10k x 60 x 6 (headline)", 10000, orc.satisfaction_C(), 5
     m = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(L, dtype=np.int32), 2, True, 100, 1e-6, 0)
     m.upload(X)
     rows, st, it = m.bootstrap(64, seed=1)
-    for w in range(3): m.bootstrap_device(B, seed=1, rep_offset=w * B)
+    for w in range(40 if N <= 10000 else 6): m.bootstrap_device(B, seed=1, rep_offset=w * B)      # (brings the device to its working clocks)
     m.sync()
     t0 = time.perf_counter()
     for w in range(10): m.bootstrap_device(B, seed=1, rep_offset=(3 + w) * B)
@@ -36,8 +36,9 @@ for name, N, C, B in (("10k x 60 x 6 (headline)", 10000, orc.satisfaction_C(), 5
     m.sync(); m.profile(False)
     k = {n: round(m.profile_read(n)[0] / max(1, m.profile_read(n)[1]), 4) for n in ("resample", "gram", "solver")}
     npair = (X.shape[1] + 1) * (X.shape[1] + 2) // 2
-    ops = 2.0 * N * npair * 7 * B
-    print(json.dumps({"workload": name, "replicates_per_step": B, "replicates_per_s": round(B / wall, 1), "ms_per_step": round(wall * 1e3, 4), "kernels_ms": k,
+    S = m.get_option("last_i8_slices")
+    ops = 2.0 * N * npair * S * B
+    print(json.dumps({"workload": name, "replicates_per_step": B, "digit_planes": S, "replicates_per_s": round(B / wall, 1), "ms_per_step": round(wall * 1e3, 4), "kernels_ms": k,
                       "gram_path": m.get_option("last_gram_path"), "solver": m.get_option("last_solver"), "status_ok": bool(np.all(st == 0)),
                       "int8_TOPs_algorithmic": round(ops / (k["gram"] * 1e-3) / 1e12, 1)}), flush=True)
     m.close()
