@@ -429,3 +429,37 @@ def test_planes_that_would_be_zero_are_dropped_without_changing_a_bit(step, expe
         assert nm.get_option("last_i8_slices") == S
         if S >= expect:
             assert np.array_equal(M_S, M_7)
+
+
+def test_every_plane_count_wave_count_and_dma_form_on_exactly_representable_data():
+    """Small integers with zero column means: every product is an integer below 64, so ONE digit plane already represents the data
+    exactly and every instantiation of the product -- 1 .. 8 planes, four / eight waves, both LDS-DMA forms, the one-plane data through
+    the seven-plane main loop (i8_ind) or through its own instantiation, the stream-K schedule where it exists -- must give the same
+    bits.  Ragged sizes: 777 rows, 1,100 replicates (tile grid 5 x 3 with padding in both directions)."""
+    rng = np.random.default_rng(5)
+    half = rng.integers(-6, 7, size=(388, 14)).astype(float)
+    X = np.concatenate((half, -half, np.zeros((1, 14))), axis=0)
+    blocks = [np.arange(0, 5), np.arange(5, 9), np.arange(9, 14)]
+    model = orc.Model(blocks, orc.chain_C(3), "AAA", "factorial", False)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.set_option("gram_path", 1)
+    M64 = nm.bootstrap_moments(1100, seed=2)
+    nm.set_option("gram_path", 2)
+    seen = set()
+    for S in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        for waves in (4, 8):
+            for dma in (1, 2):
+                for ind in ((0, 1) if S in (0, 1) else (1,)):
+                    nm.set_option("i8_slices", S); nm.set_option("i8_waves", waves); nm.set_option("i8_dma", dma); nm.set_option("i8_ind", ind)
+                    M = nm.bootstrap_moments(1100, seed=2)
+                    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_dma") == dma
+                    seen.add(nm.get_option("last_i8_slices"))
+                    assert np.array_equal(M, M64), (S, waves, dma, ind)       # integers: the fp64 route is exact as well
+    assert seen == {1, 2, 3, 4, 5, 6, 7, 8}
+    nm.set_option("i8_dma", 0); nm.set_option("i8_ind", 1); nm.set_option("i8_waves", 8)
+    for S in (0, 5, 6, 7):
+        nm.set_option("i8_slices", S); nm.set_option("i8_sched", 1)
+        M = nm.bootstrap_moments(1100, seed=2)
+        nm.set_option("i8_sched", 0)
+        assert np.array_equal(M, M64), ("stream-K", S)
