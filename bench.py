@@ -407,7 +407,7 @@ def main():
                                              "source": "MI355X_MICROARCH.md matrix-core table (I8, 16x16x64 micro-benchmark); the nominal peak is 2 x the bf16 dense spec"},
                         "executed_ops": executed, "executed_over_algorithmic": round(executed / (ops_rep * reps_per_launch), 4),
                         "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if model.get_option("last_i8_dma") == 2 else 3, model.get_option("i8_shape"), model.get_option("i8_rt")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
+                        "kernel": "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if model.get_option("last_i8_dma") == 2 else 3, model.get_option("i8_shape"), model.get_option("last_i8_rt")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",
                         "algorithmic_ops_per_replicate": ops_rep,
                         "algorithmic_ops_derivation": "2 x N rows x %d pair columns x %d digit planes (SURVEY 8(d)'s N P (P+1) fp64 flops = %.4g per replicate, "

@@ -731,7 +731,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "nm_k16") { if (value < 0 || value > 1) return bad(); m->tune.nm_k16 = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
-    else if (k == "i8_rt") { if (value != 16 && value != 8) return bad(); m->tune.i8_rt = value; }
+    else if (k == "i8_rt") { if (value != 0 && value != 16 && value != 8 && value != 20) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
     else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }
@@ -759,6 +759,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "gram_path") *value = m->tune.gram_path;
     else if (k == "i8_slices") *value = m->tune.i8_slices;
     else if (k == "last_i8_slices") *value = m->zs_valid ? m->zs_S : 0;
+    else if (k == "last_i8_rt") *value = m->last_i8_rt;
     else if (k == "last_i8_ratio") *value = (m->zs_valid && m->zs_ratio < 9e18) ? (int64_t)m->zs_ratio : 0;      // floor of the smallest sum|z| / max|z| (automatic plane count)
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
@@ -1158,8 +1159,19 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     if (counts) *counts = nullptr;
     const int S = m->zs_S, KB = m->zs_KB, NT = m->zs_NT;
     // workgroup tile of the product: 16 RT replicates x 32 pairs; narrow tiles (RT 12 / 8) only in the plain four-wave 16x16x64 launch
-    const bool narrow = m->tune.i8_rt != 16 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7;
-    const int RTg = narrow ? m->tune.i8_rt : 16;
+    // Six planes leave registers for a taller workgroup tile: 320 replicates x 32 pairs (`RT` 20: 30 accumulator tiles per wave with eight
+    // waves) moves 9 % fewer LDS-DMA bytes and reads 12 % fewer fragments per MFMA than 256 x 32 -- 2.2 % on the step when the tile grid
+    // fills the machine equally well (5,000 replicates: 960 tiles = 3.75 rounds against 1,200 = 4.69, both five tile-units per CU).  "i8_rt"
+    // 0 (default) takes it when its rounds cost no more than those of the 256-replicate tile; the sums are exact either way.
+    bool wide20 = m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 6 && !m->zs_ind && (m->tune.i8_rt == 20 || m->tune.i8_rt == 0);
+    if (wide20 && m->tune.i8_rt == 0) {
+        if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
+        const long cus = std::max(1, m->cu_count), ntx0 = m->zs_npg / 2;
+        auto units = [&](long rt) { return ((((nb + 16 * rt - 1) / (16 * rt)) * ntx0 + cus - 1) / cus) * rt; };      // rounds x tile height
+        wide20 = units(20) <= units(16);
+    }
+    const bool narrow = wide20 || (m->tune.i8_rt == 8 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7);
+    const int RTg = wide20 ? 20 : narrow ? 8 : 16;
     const bool ind = m->zs_ind && m->tune.i8_sched == 0 && m->tune.i8_variant < 0;
     const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
     // resample counts from an LDS histogram per (replicate, window of rows): 65,536 rows of 16-bit counters, or -- Philox draws of a data
@@ -1240,8 +1252,9 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     }
     // the buffer form of the LDS-DMA needs every byte offset of a workgroup's walk (incl. the slack k-blocks) below 4 GiB
     const bool dma_fits = (uint64_t)(KB + I8_SLACK_KB) * (uint64_t)std::max(MT, NT) * 1024ull < (1ull << 32);
-    const bool dma_buffer = m->tune.i8_dma != 1 && dma_fits && m->tune.i8_shape == 16 && !sk && !narrow && m->tune.i8_variant < 0;
+    const bool dma_buffer = m->tune.i8_dma != 1 && dma_fits && m->tune.i8_shape == 16 && !sk && (!narrow || (wide20 && m->tune.i8_waves == 4)) && m->tune.i8_variant < 0;
     m->last_i8_dma = dma_buffer ? 2 : 1;
+    m->last_i8_rt = RTg;
     ProfScope ps(m, PLSPM_K_GRAM);
 #define GI8SK(SS, WW)                                                                                                                        \
     {                                                                                                                                        \
@@ -1289,6 +1302,14 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         if (dma_buffer) { if (m->tune.i8_waves == 4) GI8IND(2, I8_DEFAULT_VAR + 800) else GI8IND(4, I8_DEFAULT_VAR + 800) }
         else { if (m->tune.i8_waves == 4) GI8IND(2, I8_DEFAULT_VAR) else GI8IND(4, I8_DEFAULT_VAR) }
     } else
+#define GI8RT20(WW, VV)                                                                                                                      \
+    {                                                                                                                                        \
+        const size_t lds_bytes = GramI8<6, WW, VV, 16, 20>::LDS_BYTES;                                                                       \
+        if ((rc = allow_lds(m, (const void*)gram_i8_kernel<6, WW, VV, 16, 20>, lds_bytes))) return rc;                                       \
+        hipLaunchKernelGGL((gram_i8_kernel<6, WW, VV, 16, 20>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+    }
+    if (wide20) { if (m->tune.i8_waves == 4) { if (dma_buffer) GI8RT20(2, I8_DEFAULT_VAR + 800) else GI8RT20(2, I8_DEFAULT_VAR) } else GI8RT20(4, I8_DEFAULT_VAR) } else
     if (narrow) GI8RT(8) else
 #undef GI8RT_DUMMY
     if (m->tune.i8_shape == 32 && S >= 5) {    // v_mfma_i32_32x32x32_i8: four waves (64 replicates x 32 pairs x S planes each)

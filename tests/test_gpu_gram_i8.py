@@ -49,7 +49,6 @@ def test_moment_matrices_vs_extended_precision(data):
     model = orc.Model(blocks, C, "A" * 6, "path", True)
     nm = native_model(model)
     nm.upload(X, model.mv_order.astype(np.int32))
-    rng = np.random.default_rng(11)
     idx = rng.integers(0, X.shape[0], size=(5, X.shape[0])).astype(np.int32)
     e64, M64 = moment_errors(nm, X, model.mv_order, idx, 1)
     errs = {S: moment_errors(nm, X, model.mv_order, idx, 2, S)[0] for S in (5, 6, 7, 8)}
@@ -463,3 +462,51 @@ def test_every_plane_count_wave_count_and_dma_form_on_exactly_representable_data
         M = nm.bootstrap_moments(1100, seed=2)
         nm.set_option("i8_sched", 0)
         assert np.array_equal(M, M64), ("stream-K", S)
+
+
+def test_tall_workgroup_tile_with_six_planes_gives_identical_matrices():
+    """i8_rt: with six planes the product runs on a 320-replicate x 32-pair workgroup tile (30 accumulator tiles per wave) when its tile
+    grid costs no more rounds x height than the 256-replicate one ("i8_rt" 0, automatic) or when asked for (20).  Exact int32 sums
+    either way: moment matrices and rows are bit-identical for four / eight waves and both LDS-DMA forms (the buffer form exists for
+    four waves: 20 count blocks do not deal evenly to eight), ragged grids included (777 rows; 1,100 replicates = 4 tiles of 320 with
+    180 padded replicates, 5 of 256)."""
+    C = orc.chain_C(3)
+    X, blocks = orc.synth(777, C, 5, seed=4)
+    model = orc.Model(blocks, C, "AAA", "factorial", True)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.set_option("i8_slices", 6)
+    for B in (1, 321, 1100):
+        nm.set_option("i8_rt", 16); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
+        M16 = nm.bootstrap_moments(B, seed=2)
+        rows16 = nm.bootstrap(B, seed=2)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_rt") == 16 and nm.get_option("last_i8_slices") == 6
+        for waves in (4, 8):
+            for dma in (1, 2):
+                nm.set_option("i8_rt", 20); nm.set_option("i8_waves", waves); nm.set_option("i8_dma", dma)
+                M20 = nm.bootstrap_moments(B, seed=2)
+                assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_dma") == (dma if waves == 4 else 1)
+                assert np.array_equal(M20, M16), (B, waves, dma)
+                rows20 = nm.bootstrap(B, seed=2)
+                for a, b in zip(rows16, rows20):
+                    assert np.array_equal(a, b)
+    # seven planes keep the 256-replicate tile whatever is asked for
+    nm.set_option("i8_slices", 7); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
+    nm.bootstrap_device(1100, seed=2)
+    assert nm.get_option("last_i8_rt") == 16
+    # automatic choice on the headline shape: 5,000 replicates -> 16 tiles of 320 x 60 pair tiles = 3.75 rounds x 20 against 4.69 x 16
+    Xh, bh = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    mh = orc.Model(bh, orc.satisfaction_C(), "A" * 6, "path", True)
+    nh = native_model(mh)
+    nh.upload(Xh, mh.mv_order.astype(np.int32))
+    assert nh.get_option("i8_rt") == 0
+    rows_auto = nh.bootstrap(5000, seed=8)
+    assert nh.get_option("last_i8_slices") == 6 and nh.get_option("last_i8_rt") == 20
+    nh.set_option("i8_rt", 16)
+    rows_16 = nh.bootstrap(5000, seed=8)
+    assert nh.get_option("last_i8_rt") == 16
+    for a, b in zip(rows_auto, rows_16):
+        assert np.array_equal(a, b)
+    nh.set_option("i8_rt", 0)
+    nh.bootstrap_device(64, seed=8)
+    assert nh.get_option("last_i8_rt") == 16                       # one tile row either way: the lower tile wins
