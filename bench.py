@@ -396,16 +396,19 @@ def main():
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
             traffic, traffic_src = (live, live_src) if live else static_traffic(("r03_gram_i8_traffic.json", "r02c_gram_i8_traffic.json", "r02_gram_i8_traffic.json"))
-            # what the launch executes: whole tiles of 256 replicates x 64 rows x 32 pairs (= SQ_INSTS_VALU_MFMA_MOPS_I8 x 512 of the PMC passes
+            # what the launch executes: whole tiles of 320 / 256 replicates x 64 rows x 32 pairs (= SQ_INSTS_VALU_MFMA_MOPS_I8 x 512 of the PMC passes
             # in profiles/)
             k_rows = ((N_OBS + 127) // 128) * 128
-            executed = 2.0 * (((reps_per_launch + 255) // 256) * 256) * k_rows * (((npair + 31) // 32) * 32) * slices
+            # (replicate slots: the launch's tile rows -- 320-replicate and, cut by plspm_hip.hip i8_mix_plan, 256-replicate ones -- x their heights)
+            rep_slots = 16 * model.get_option("last_i8_mt")
+            executed = 2.0 * rep_slots * k_rows * (((npair + 31) // 32) * 32) * slices
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4),
                         "frac_of_measured_ceiling": round(achieved / I8_MFMA_MEASURED_CEILING_TOPS, 4),
                         "measured_ceiling": {"value": I8_MFMA_MEASURED_CEILING_TOPS, "unit": "TOP/s",
                                              "source": "MI355X_MICROARCH.md matrix-core table (I8, 16x16x64 micro-benchmark); the nominal peak is 2 x the bf16 dense spec"},
                         "executed_ops": executed, "executed_over_algorithmic": round(executed / (ops_rep * reps_per_launch), 4),
+                        "tile_rows": {"workgroup_tile_replicates": 16 * model.get_option("last_i8_rt"), "short_rows_of_256": model.get_option("last_i8_short"), "replicate_slots": rep_slots},
                         "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if model.get_option("last_i8_dma") == 2 else 3, model.get_option("i8_shape"), model.get_option("last_i8_rt")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",

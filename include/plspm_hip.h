@@ -100,10 +100,14 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the int8 Gram: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
  *                     ... lds (per-workgroup descriptors + 32-bit offsets: 0.4 % faster; auto takes it whenever an operand's walk stays below 4 GiB)
  *   "i8_rt"           0 (default) | 16 | 20 | 8   count tiles (16 replicates each) per workgroup of the int8 Gram: 256, 320 or 128 replicates x 32
- *                     pairs.  0 = automatic: 320 with six planes when its tile grid costs no more rounds x height than the 256-replicate one
- *                     (fewer LDS-DMA bytes and fragment reads per MFMA: 2 % on the step at 5,000 replicates), else 256; 128: half the accumulator
- *                     registers, two workgroups per CU, seven planes (measured 2.6 % slower -- kept for co-scheduling experiments).  Read-only
- *                     "last_i8_rt" tells what the last launch took
+ *                     pairs.  0 = automatic, six planes: the replicates are cut into tile rows of 320 and -- eight-wave kernel -- rows of 256 in
+ *                     ONE launch so that the machine's last round is as full as the others (list-scheduling model of the 8 XCDs; 5,000
+ *                     replicates x 60 pair tiles on 256 CUs: 12 + 5 rows, Gram 0.396 -> 0.373 ms), or the 256-replicate kernel when that is
+ *                     no slower (fewer LDS-DMA bytes and fragment reads per MFMA on the tall tile; the sums are exact int32 either way, no
+ *                     result depends on the cut).  20: tall rows only.  128 (value 8): half the accumulator registers, two workgroups per
+ *                     CU, seven planes (2.6 % slower -- kept for co-scheduling experiments).  Read-only "last_i8_rt" / "last_i8_short" /
+ *                     "last_i8_mt": tile height, short rows and padded count tiles of the last launch
+ *   "i8_short_rows"   -1 (default) | n   test seam, with "i8_rt" 20 and eight waves: n rows of 256 replicates behind the tall ones
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
  *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row

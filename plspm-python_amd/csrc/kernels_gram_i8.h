@@ -305,6 +305,13 @@ struct GramI8 {
     static constexpr int RSTEP = 1 + (V / 3) % 3, DMA_HEAD = (V % 18) / 9;
     static constexpr int FLIGHT = PAIRB ? 1 : NS - 2;      // k-steps whose DMAs may still be in flight behind the barrier's wait
     static constexpr size_t LDS_BYTES = (size_t)NS * STAGE_BYTES;
+    // MIX: the launch may hold tile rows of TWO heights -- RT count tiles ("tall") and RT - WM ("short": every wave drops its last count
+    // tile, i.e. its last S MFMAs, one fragment read and the tile's share of the DMA blocks of a k-step).  A tile grid that fills the
+    // last round of the machine only partly is then re-cut so that every CU carries about the same number of count-tile rows (host:
+    // plspm_hip.hip i8_mix_plan); sums are exact int32 either way, the results do not depend on the cut.  Eight-wave FLAT-global form of
+    // the 320-replicate tile only (the buffer form fixes the operand of a DMA slot at compile time).
+    static constexpr bool MIX = RT == 20 && WM == 4 && SH == 16 && BUFM == 0 && DMA_HEAD == 0 && ((PER - 1) * NMFMA) / PER + 1 < (MTW - 1) * S;
+    static constexpr int RTS = RT - WM, NBLKS = RTS + 2 * S;      // count tiles / DMA blocks per k-step of a short tile
 };
 
 // one LDS-DMA block: 64 lanes x 16 B from `base + voff` to LDS byte address `lds_dst` (wave-uniform) + 16 lane
@@ -323,7 +330,7 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
 template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16, int RT = 16, bool IND = false>
 __global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(RT < 16 ? 2 : WM / 2, RT < 16 ? 2 : WM / 2)))
 gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
-               const int* __restrict__ pair_dst2, const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize) {
+               const int* __restrict__ pair_dst2, const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize, int nty_short) {
     using G = GramI8<S, WM, VAR, SH, RT>;
     constexpr int MTW = G::MTW, NA = G::NA, NB = G::NB;
     typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -332,32 +339,45 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = SH == 16 ? wave >> 1 : wave, wn = SH == 16 ? wave & 1 : 0;
-    // XCD-aware tile enumeration
-    const int total = ntx * nty, per = (total + 7) >> 3;
-    const int w = blockIdx.x, slot = w >> 3;
+    // XCD-aware tile enumeration.  MIX: nty - nty_short tall rows (count tiles 0 ..), then nty_short short rows; each list is cut into
+    // eight contiguous ranges and an XCD walks its tall range first, then its short one (longest tiles first: the CUs that finish early
+    // pick up the short ones).  ct0 = the tile's first count tile, shortT (wave-uniform) = its height.
+    const int w = blockIdx.x;
+    int slot = w >> 3, rows = nty, rbase = 0;
+    bool shortT = false;
+    if constexpr (G::MIX) {
+        const int ntall = nty - nty_short, tper = (ntx * ntall + 7) >> 3;
+        if (slot >= tper) { slot -= tper; rows = nty_short; rbase = ntall; shortT = true; }
+        else rows = ntall;
+    }
+    const int total = ntx * rows, per = (total + 7) >> 3;
     const int gidx = (w & 7) * per + slot;
     if (slot >= per || gidx >= total) return;
     const int srow = 4 * ntx;
     const int sr = gidx / srow, rem = gidx - sr * srow;
-    const int nr = min(4, nty - 4 * sr);
-    const int tx = rem / nr, ty = 4 * sr + (rem - tx * nr);
+    const int nr = min(4, rows - 4 * sr);
+    const int tx = rem / nr, tyl = 4 * sr + (rem - tx * nr), ty = rbase + tyl;
+    const int ct0 = G::MIX ? (shortT ? rbase * RT + tyl * G::RTS : tyl * RT) : ty * RT;
+    const int RTr = (G::MIX && shortT) ? G::RTS : RT, NBLKr = (G::MIX && shortT) ? G::NBLKS : G::NBLK;
 
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_raw);
     const unsigned voff = (unsigned)lane * 16u;
     // this wave's blocks of a k-step, dealt round-robin (wave, wave + NW, ...): block b < 16 = count tile b of the workgroup's 16, else
     // digit block b - 16 of its 2 S.  NBLK is not always a multiple of NW: the last waves own one block less (`full` tells).
-    const int myper = (G::NBLK - wave + G::NW - 1) / G::NW;
+    const int myper = (NBLKr - wave + G::NW - 1) / G::NW;
     const bool full = myper == G::PER;
     const char* src[G::PER];
     long inc[G::PER];
     unsigned dst[G::PER];
 #pragma unroll
     for (int i = 0; i < G::PER; ++i) {
-        const int b = min(wave + G::NW * i, G::NBLK - 1);
-        const bool isA = b < RT;
-        src[i] = isA ? (const char*)(Cd + ((long)ty * RT + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - RT)) * 64);
+        const int b = min(wave + G::NW * i, NBLKr - 1);
+        const bool isA = b < RTr;
+        src[i] = isA ? (const char*)(Cd + ((long)ct0 + b) * 64) : (const char*)(Zs + ((long)tx * 2 * S + (b - RTr)) * 64);
         inc[i] = (isA ? (long)MT : (long)NT) * 1024;
-        dst[i] = lds0 + (unsigned)b * 1024u;
+        // LDS slot: count tile a of wave row wm at wm MTW + a (a short tile leaves the last slot of every wave row unused), digits behind
+        const int sl = isA ? ((G::MIX && shortT) ? (b / (MTW - 1)) * MTW + b % (MTW - 1) : b) : RT + (b - RTr);
+        dst[i] = lds0 + (unsigned)sl * 1024u;
     }
     // the source pointers simply run on: the DMAs of the k-steps past the end (never consumed) read the I8_SLACK_KB k-blocks of slack
     // the host keeps behind both operands (a clamp cost a branch + 16 scalar selects per k-step)
@@ -368,7 +388,7 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     // buffer form: rsA / rsB address the workgroup's count tiles / digit blocks of k-step 0; src[] then holds byte OFFSETS (< 4 GiB)
     i32x4 rsA = {0, 0, 0, 0}, rsB = {0, 0, 0, 0};
     if constexpr (G::BUFM != 0) {
-        const unsigned long long bA = (unsigned long long)(Cd + (long)ty * RT * 64), bB = (unsigned long long)(Zs + (long)tx * 2 * S * 64);
+        const unsigned long long bA = (unsigned long long)(Cd + (long)ct0 * 64), bB = (unsigned long long)(Zs + (long)tx * 2 * S * 64);
         rsA[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bA); rsA[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(bA >> 32) & 0xffffu));
         rsB[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bB); rsB[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(bB >> 32) & 0xffffu));
         rsA[2] = rsB[2] = (int)0xffffffffu;                      // num_records (bytes, stride 0): the 32-bit offsets are always in range
@@ -431,7 +451,19 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
             }
             if (ndma < G::PER && m == (G::DMA_HEAD ? ndma : (ndma * G::NMFMA) / G::PER + 1)) { if (!(G::ABL & 1)) issue_one(ndma, Woff); ++ndma; }
         };
-        if constexpr (SH == 16) {
+        if constexpr (G::MIX) {
+            // the last count tile of the wave runs only in a tall workgroup tile (one uniform branch per k-step); every DMA and fragment
+            // read of the step rides behind the MFMAs in front of it
+            static_assert(!G::MIX || (G::DMA_HEAD == 0 && ((G::PER - 1) * G::NMFMA) / G::PER + 1 < (MTW - 1) * S), "DMA slots in front of the optional MFMAs");
+#pragma unroll
+            for (int mt = 0; mt < MTW - 1; ++mt)
+#pragma unroll
+                for (int s = 0; s < S; ++s) { GI8_MFMA16(acc[mt][s], fc[mt], fd[s]); fill(mt * S + s); }
+            if (!shortT) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) GI8_MFMA16(acc[MTW - 1][s], fc[MTW - 1], fd[s]);
+            }
+        } else if constexpr (SH == 16) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -553,13 +585,14 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
         }
     };
     if constexpr (SH == 16) {
-        const long rep0 = (long)ty * (16 * RT) + wm * (MTW * 16) + (lane >> 4) * 4;
+        const int mtw = (G::MIX && shortT) ? MTW - 1 : MTW;          // count tiles of this wave in this tile
+        const long rep0 = (long)ct0 * 16 + wm * (mtw * 16) + (lane >> 4) * 4;
         double* gp = gram + rep0 * psize + dstj;       // walks the replicates of this lane; opaque to the compiler so that it does not
 #pragma unroll                                         // precompute (and spill) 32 addresses
         for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                emit(gp, rep0 + mt * 16 + reg < nrep, [&](int s) { return acc[mt][s][reg]; });
+                emit(gp, mt < mtw && rep0 + mt * 16 + reg < nrep, [&](int s) { return acc[mt][s][reg]; });
                 gp += psize;
                 asm volatile("" : "+v"(gp)::"memory");
             }

@@ -731,6 +731,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "nm_k16") { if (value < 0 || value > 1) return bad(); m->tune.nm_k16 = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
+    else if (k == "i8_short_rows") { if (value < -1 || value > 4096) return bad(); m->tune.i8_short = value; }
     else if (k == "i8_rt") { if (value != 0 && value != 16 && value != 8 && value != 20) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
@@ -760,6 +761,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_slices") *value = m->tune.i8_slices;
     else if (k == "last_i8_slices") *value = m->zs_valid ? m->zs_S : 0;
     else if (k == "last_i8_rt") *value = m->last_i8_rt;
+    else if (k == "last_i8_short") *value = m->last_i8_short;
+    else if (k == "last_i8_mt") *value = m->last_i8_mt;
     else if (k == "last_i8_ratio") *value = (m->zs_valid && m->zs_ratio < 9e18) ? (int64_t)m->zs_ratio : 0;      // floor of the smallest sum|z| / max|z| (automatic plane count)
     else if (k == "i8_min_batch") *value = m->tune.i8_min_batch;
     else if (k == "i8_waves") *value = m->tune.i8_waves;
@@ -767,6 +770,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "nm_k16") *value = m->tune.nm_k16;
     else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
+    else if (k == "i8_short_rows") *value = m->tune.i8_short;
     else if (k == "i8_dma") *value = m->tune.i8_dma;
     else if (k == "last_i8_dma") *value = m->last_i8_dma;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
@@ -1150,6 +1154,46 @@ static int prepare_zs(plspm_model* m) {
     return 0;
 }
 
+// Tile rows of the six-plane int8 Gram for `ct` count tiles (16 replicates each) x `ntx` pair tiles on `cus` CUs in 8 XCDs: `tall` rows of
+// 20 count tiles and -- `mix` -- `shrt` rows of 16 in one launch of gram_i8_kernel<6, 4, ., 16, 20>, or (return false) the 256-replicate
+// kernel.  Cost model = what the device does: an XCD's workgroups go in order to the CU that is free first (one workgroup per CU), so the
+// makespan of a cut is that of list scheduling its tall tiles first, then its short ones, per XCD.  Costs in count-tile rows: 20 per
+// tall tile, 16.6 per short one (the same DMA ring for 4/5 of the MFMAs), 16.35 per tile of the 256-replicate kernel (measured on 960 tiles
+// of each kind, tools/i8_mix_calib.py: 0.391 / 0.3245 / 0.3195 ms).  Deterministic in (ct, ntx, cus): every rank of a job cuts alike -- and the sums are exact
+// integers, so the cut never shows in a result.
+static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* shrt) {
+    const int per_xcd = std::max(1, cus / 8);
+    auto makespan = [&](long a, long b, double ca, double cb) {
+        double worst = 0.0;
+        const long ta = a * ntx, tb = b * ntx, pa = (ta + 7) / 8, pb = (tb + 7) / 8;
+        std::vector<double> load((size_t)per_xcd);
+        for (int x = 0; x < 8; ++x) {
+            const long na = std::max(0L, std::min(pa, ta - x * pa)), nb2 = std::max(0L, std::min(pb, tb - x * pb));
+            if (na + nb2 > 64L * per_xcd) {            // many rounds: the closed form is as good
+                worst = std::max(worst, (na * ca + nb2 * cb) / per_xcd + ca);
+                continue;
+            }
+            std::fill(load.begin(), load.end(), 0.0);
+            for (long t = 0; t < na + nb2; ++t) *std::min_element(load.begin(), load.end()) += (t < na) ? ca : cb;
+            worst = std::max(worst, *std::max_element(load.begin(), load.end()));
+        }
+        return worst;
+    };
+    const long rows16 = (ct + 15) / 16;
+    const double ref16 = makespan(rows16, 0, 16.35, 0.0);
+    double best = 1e300;
+    long ba = 0, bb = 0;
+    for (long b = 0; b <= (mix ? std::min(rows16, 48L) : 0L); ++b) {
+        const long a = std::max(0L, (ct - 16 * b + 19) / 20);
+        if (a == 0 && b * 16 < ct) continue;
+        const double t = makespan(a, b, 20.0, 16.6);
+        if (t < best - 1e-9) { best = t; ba = a; bb = b; }
+        if (a == 0) break;
+    }
+    *tall = (int)ba; *shrt = (int)bb;
+    return best <= ref16;
+}
+
 // Resample nb replicates into dense int8 counts and multiply with the digit planes: the nb moment matrices land at `out`.
 // Explicit indices can carry a multiplicity above 127 (Philox draws of N >= 128 rows cannot, P < 1e-200): the host looks at the
 // flag before the product and reports *fallback so that the caller takes the fp64 Gram for this chunk.
@@ -1163,17 +1207,35 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     // waves) moves 9 % fewer LDS-DMA bytes and reads 12 % fewer fragments per MFMA than 256 x 32 -- 2.2 % on the step when the tile grid
     // fills the machine equally well (5,000 replicates: 960 tiles = 3.75 rounds against 1,200 = 4.69, both five tile-units per CU).  "i8_rt"
     // 0 (default) takes it when its rounds cost no more than those of the 256-replicate tile; the sums are exact either way.
-    bool wide20 = m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 6 && !m->zs_ind && (m->tune.i8_rt == 20 || m->tune.i8_rt == 0);
+#ifdef PLSPM_I8_EXPERIMENTS
+    const bool var20 = m->tune.i8_variant < 0 || m->tune.i8_rt == 20;      // experiments build: the schedule variants exist for the 320-replicate tile too
+#else
+    const bool var20 = m->tune.i8_variant < 0;
+#endif
+    bool wide20 = m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && var20 && S == 6 && !m->zs_ind && (m->tune.i8_rt == 20 || m->tune.i8_rt == 0);
+    // "i8_rt" 0: the cut of the replicates into tile rows is planned (i8_mix_plan below): rows of 320 and -- eight-wave kernel -- rows of 256
+    // in ONE launch, so that the last round of the machine is as full as the others (5,000 replicates x 60 pair tiles: 11 + 6 rows = 1,020
+    // tiles, every CU three tall + one short = 76 count-tile rows, against 16 rows of 320 = 960 tiles, 80 on three CUs of four)
+    int nty_tall = 0, nty_short = 0;
     if (wide20 && m->tune.i8_rt == 0) {
         if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
-        const long cus = std::max(1, m->cu_count), ntx0 = m->zs_npg / 2;
-        auto units = [&](long rt) { return ((((nb + 16 * rt - 1) / (16 * rt)) * ntx0 + cus - 1) / cus) * rt; };      // rounds x tile height
-        wide20 = units(20) <= units(16);
+        // (the plan of the last shape is kept: a bootstrap calls with the same B again and again, and the search costs of the order of a millisecond)
+        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count), (long)(m->tune.i8_waves == 8 && m->tune.i8_variant < 0 && m->tune.i8_dma != 2)};
+        if (!(m->mix_valid && std::equal(key, key + 4, m->mix_key))) {
+            m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], key[3] != 0, &m->mix_tall, &m->mix_short);
+            std::copy(key, key + 4, m->mix_key); m->mix_valid = true;
+        }
+        wide20 = m->mix_wide; nty_tall = m->mix_tall; nty_short = m->mix_short;
+    } else if (wide20) {
+        // "i8_rt" 20: tall rows only, or -- "i8_short_rows" n >= 0, eight waves (test seam) -- n short rows behind as many tall ones as it takes
+        const long ct = (nb + 15) / 16;
+        if (m->tune.i8_short > 0 && m->tune.i8_waves == 8 && m->tune.i8_variant < 0 && m->tune.i8_dma != 2) nty_short = (int)std::min<long>(m->tune.i8_short, (ct + 15) / 16);
+        nty_tall = (int)std::max(0L, (ct - 16L * nty_short + 19) / 20);
     }
     const bool narrow = wide20 || (m->tune.i8_rt == 8 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7);
     const int RTg = wide20 ? 20 : narrow ? 8 : 16;
     const bool ind = m->zs_ind && m->tune.i8_sched == 0 && m->tune.i8_variant < 0;
-    const int nty = (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
+    const int nty = wide20 ? nty_tall + nty_short : (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = wide20 ? nty_tall * 20 + nty_short * 16 : nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
     // resample counts from an LDS histogram per (replicate, window of rows): 65,536 rows of 16-bit counters, or -- Philox draws of a data
     // set that would need more than one such window -- 131,072 rows of 8-bit counters (kernels_gram_i8.h resample_i8_kernel)
     const bool hist_byte = KB > I8_HIST_KB && !d_idx;
@@ -1197,7 +1259,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     // counts of this chunk: the buffer the Gram before last read; grown only with both streams idle
     const int slot = m->aux ? (m->cd_slot ^= 1) : 0;
     plspm_model::Buf& cd = slot ? m->cd1 : m->cd;
-    const size_t cd_bytes = (size_t)nty * 16 * RTg * ((size_t)KB + I8_SLACK_KB) * 64;
+    const size_t cd_bytes = (size_t)MT * 16 * ((size_t)KB + I8_SLACK_KB) * 64;
     if (cd_bytes > cd.cap) { if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux)); if ((rc = ensure(m, cd, cd_bytes))) return rc; m->cdfree_set[slot] = false; }
     if (!d_idx && m->aux) {
         // Philox draws: on the low-priority stream, as soon as the Gram that last read this buffer is done -- i.e. beside the Gram and the
@@ -1228,7 +1290,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         }
     }
     if (counts && m->tune.i8_shape == 16) { *counts = cd.p; *counts_MT = MT; }       // (16-row pieces: what nm_conv_dense_kernel<.., CNT8> reads)
-    const int total = ntx * nty, per = (total + 7) / 8;
+    const int total = ntx * nty, per = wide20 ? (ntx * nty_tall + 7) / 8 + (ntx * nty_short + 7) / 8 : (total + 7) / 8;      // workgroups per XCD
     // packed: the tile-packed slots the LDS solver / impute kernel read; dense: [(Pg+1) x cov_ld(Pg)] row-major, upper triangle (rows solver)
     const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
     // (a mirrored second store per element cost 0.08 ms per 5,000 replicates of the metric benchmark: the rows solver reads the triangle
@@ -1255,6 +1317,8 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     const bool dma_buffer = m->tune.i8_dma != 1 && dma_fits && m->tune.i8_shape == 16 && !sk && (!narrow || (wide20 && m->tune.i8_waves == 4)) && m->tune.i8_variant < 0;
     m->last_i8_dma = dma_buffer ? 2 : 1;
     m->last_i8_rt = RTg;
+    m->last_i8_short = wide20 ? nty_short : 0;
+    m->last_i8_mt = MT;
     ProfScope ps(m, PLSPM_K_GRAM);
 #define GI8SK(SS, WW)                                                                                                                        \
     {                                                                                                                                        \
@@ -1273,7 +1337,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         const size_t lds_bytes = GramI8<SS, WW, VV, SH>::LDS_BYTES;                                                                          \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<SS, WW, VV, SH>, lds_bytes))) return rc;                                          \
         hipLaunchKernelGGL((gram_i8_kernel<SS, WW, VV, SH>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, 0); \
     }
 #define GI8V(SS, WW, VV) GI8VS(SS, WW, VV, 16)
 #define GI8(SS, WW) GI8V(SS, WW, I8_DEFAULT_VAR)
@@ -1289,14 +1353,14 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         const size_t lds_bytes = GramI8<7, 2, I8_DEFAULT_VAR, 16, RR>::LDS_BYTES;                                                            \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<7, 2, I8_DEFAULT_VAR, 16, RR>, lds_bytes))) return rc;                             \
         hipLaunchKernelGGL((gram_i8_kernel<7, 2, I8_DEFAULT_VAR, 16, RR>), dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p, \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, 0); \
     }
 #define GI8IND(WW, VV)                                                                                                                       \
     {                                                                                                                                        \
         const size_t lds_bytes = GramI8<7, WW, VV, 16, 16>::LDS_BYTES;                                                                       \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<7, WW, VV, 16, 16, true>, lds_bytes))) return rc;                                 \
         hipLaunchKernelGGL((gram_i8_kernel<7, WW, VV, 16, 16, true>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, 0); \
     }
     if (ind) {                   // one plane per pair group, seven groups per wave
         if (dma_buffer) { if (m->tune.i8_waves == 4) GI8IND(2, I8_DEFAULT_VAR + 800) else GI8IND(4, I8_DEFAULT_VAR + 800) }
@@ -1306,9 +1370,16 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     {                                                                                                                                        \
         const size_t lds_bytes = GramI8<6, WW, VV, 16, 20>::LDS_BYTES;                                                                       \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<6, WW, VV, 16, 20>, lds_bytes))) return rc;                                       \
+        if (nty_short && !GramI8<6, WW, VV, 16, 20>::MIX) return fail(m, PLSPM_E_STATE, "int8 Gram: short tile rows planned for a kernel form without them"); \
         hipLaunchKernelGGL((gram_i8_kernel<6, WW, VV, 16, 20>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, nty_short); \
     }
+#ifdef PLSPM_I8_EXPERIMENTS
+#define GI8X20(VV) case VV: GI8RT20(4, VV) break;
+    if (wide20 && m->tune.i8_variant >= 0 && m->tune.i8_waves == 8) {
+        switch (m->tune.i8_variant) { GI8X20(0) GI8X20(1) GI8X20(3) GI8X20(4) GI8X20(5) GI8X20(6) GI8X20(7) GI8X20(12) GI8X20(13) GI8X20(18) GI8X20(21) GI8X20(103) GI8X20(203) GI8X20(403) GI8X20(703) default: return fail(m, PLSPM_E_ARG, "i8_variant: not built for the 320-replicate tile"); }
+    } else
+#endif
     if (wide20) { if (m->tune.i8_waves == 4) { if (dma_buffer) GI8RT20(2, I8_DEFAULT_VAR + 800) else GI8RT20(2, I8_DEFAULT_VAR) } else GI8RT20(4, I8_DEFAULT_VAR) } else
     if (narrow) GI8RT(8) else
 #undef GI8RT_DUMMY

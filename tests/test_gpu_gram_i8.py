@@ -49,6 +49,7 @@ def test_moment_matrices_vs_extended_precision(data):
     model = orc.Model(blocks, C, "A" * 6, "path", True)
     nm = native_model(model)
     nm.upload(X, model.mv_order.astype(np.int32))
+    rng = np.random.default_rng(11)
     idx = rng.integers(0, X.shape[0], size=(5, X.shape[0])).astype(np.int32)
     e64, M64 = moment_errors(nm, X, model.mv_order, idx, 1)
     errs = {S: moment_errors(nm, X, model.mv_order, idx, 2, S)[0] for S in (5, 6, 7, 8)}
@@ -490,18 +491,31 @@ def test_tall_workgroup_tile_with_six_planes_gives_identical_matrices():
                 rows20 = nm.bootstrap(B, seed=2)
                 for a, b in zip(rows16, rows20):
                     assert np.array_equal(a, b)
+        # tile rows of both heights in one launch (eight-wave kernel; "i8_short_rows" forces n short rows of 256 replicates behind the
+        # tall ones -- the automatic cut of "i8_rt" 0 takes them when they fill the machine's last round better): same bits, whatever the cut
+        nm.set_option("i8_rt", 20); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
+        for n_short in (1, 2, 5):
+            nm.set_option("i8_short_rows", n_short)
+            Mx = nm.bootstrap_moments(B, seed=2)
+            assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_short") == min(n_short, (B + 255) // 256), (B, n_short)
+            assert np.array_equal(Mx, M16), (B, n_short)
+            rowsx = nm.bootstrap(B, seed=2)
+            for a, b in zip(rows16, rowsx):
+                assert np.array_equal(a, b)
+        nm.set_option("i8_short_rows", -1)
     # seven planes keep the 256-replicate tile whatever is asked for
     nm.set_option("i8_slices", 7); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
     nm.bootstrap_device(1100, seed=2)
     assert nm.get_option("last_i8_rt") == 16
-    # automatic choice on the headline shape: 5,000 replicates -> 16 tiles of 320 x 60 pair tiles = 3.75 rounds x 20 against 4.69 x 16
+    # automatic cut on the headline shape: 5,000 replicates x 60 pair tiles -> tall and short rows in one launch (e.g. 11 + 6 on 256 CUs:
+    # three tall + one short tile per CU instead of 3.75 rounds of tall ones)
     Xh, bh = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
     mh = orc.Model(bh, orc.satisfaction_C(), "A" * 6, "path", True)
     nh = native_model(mh)
     nh.upload(Xh, mh.mv_order.astype(np.int32))
     assert nh.get_option("i8_rt") == 0
     rows_auto = nh.bootstrap(5000, seed=8)
-    assert nh.get_option("last_i8_slices") == 6 and nh.get_option("last_i8_rt") == 20
+    assert nh.get_option("last_i8_slices") == 6 and nh.get_option("last_i8_rt") == 20 and nh.get_option("last_i8_short") > 0
     nh.set_option("i8_rt", 16)
     rows_16 = nh.bootstrap(5000, seed=8)
     assert nh.get_option("last_i8_rt") == 16
