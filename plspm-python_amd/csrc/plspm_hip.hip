@@ -1163,19 +1163,36 @@ static int prepare_zs(plspm_model* m) {
 // integers, so the cut never shows in a result.
 static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* shrt) {
     const int per_xcd = std::max(1, cus / 8);
+    // (tiles of one kind are interchangeable: after the tall ones the CUs of an XCD sit on at most two load levels, and the short ones raise
+    //  the lowest level a whole group of CUs at a time -- a handful of steps per XCD instead of one per tile)
+    auto xcd_span = [&](long na, long nb2, double ca, double cb) {
+        const long c = per_xcd, q = na / c, r = na % c;
+        double lv[3] = {q * ca, (q + 1) * ca, 0.0};
+        long cnt[3] = {c - r, r, 0};
+        int n = r ? 2 : 1;
+        long left = nb2;
+        while (left > 0) {
+            int lo = 0;
+            for (int k = 1; k < n; ++k) if (lv[k] < lv[lo]) lo = k;
+            if (left >= cnt[lo]) { left -= cnt[lo]; lv[lo] += cb; }
+            else { lv[n] = lv[lo] + cb; cnt[n] = left; cnt[lo] -= left; left = 0; ++n; }
+            for (int k = 0; k < n; ++k)                      // merge equal levels (keeps n <= 2 before the last step)
+                for (int k2 = k + 1; k2 < n; ++k2)
+                    if (lv[k2] == lv[k]) { cnt[k] += cnt[k2]; lv[k2] = lv[n - 1]; cnt[k2] = cnt[n - 1]; --n; --k2; }
+        }
+        double worst = 0.0;
+        for (int k = 0; k < n; ++k) if (cnt[k] > 0) worst = std::max(worst, lv[k]);
+        return worst;
+    };
     auto makespan = [&](long a, long b, double ca, double cb) {
         double worst = 0.0;
         const long ta = a * ntx, tb = b * ntx, pa = (ta + 7) / 8, pb = (tb + 7) / 8;
-        std::vector<double> load((size_t)per_xcd);
+        long seen_a = -1, seen_b = -1;
         for (int x = 0; x < 8; ++x) {
             const long na = std::max(0L, std::min(pa, ta - x * pa)), nb2 = std::max(0L, std::min(pb, tb - x * pb));
-            if (na + nb2 > 64L * per_xcd) {            // many rounds: the closed form is as good
-                worst = std::max(worst, (na * ca + nb2 * cb) / per_xcd + ca);
-                continue;
-            }
-            std::fill(load.begin(), load.end(), 0.0);
-            for (long t = 0; t < na + nb2; ++t) *std::min_element(load.begin(), load.end()) += (t < na) ? ca : cb;
-            worst = std::max(worst, *std::max_element(load.begin(), load.end()));
+            if (na == seen_a && nb2 == seen_b) continue;
+            seen_a = na; seen_b = nb2;
+            worst = std::max(worst, xcd_span(na, nb2, ca, cb));
         }
         return worst;
     };
@@ -1220,7 +1237,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     if (wide20 && m->tune.i8_rt == 0) {
         if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
         // (the plan of the last shape is kept: a bootstrap calls with the same B again and again, and the search costs of the order of a millisecond)
-        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count), (long)(m->tune.i8_waves == 8 && m->tune.i8_variant < 0 && m->tune.i8_dma != 2)};
+        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count), (long)(m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2)};
         if (!(m->mix_valid && std::equal(key, key + 4, m->mix_key))) {
             m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], key[3] != 0, &m->mix_tall, &m->mix_short);
             std::copy(key, key + 4, m->mix_key); m->mix_valid = true;
@@ -1229,7 +1246,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     } else if (wide20) {
         // "i8_rt" 20: tall rows only, or -- "i8_short_rows" n >= 0, eight waves (test seam) -- n short rows behind as many tall ones as it takes
         const long ct = (nb + 15) / 16;
-        if (m->tune.i8_short > 0 && m->tune.i8_waves == 8 && m->tune.i8_variant < 0 && m->tune.i8_dma != 2) nty_short = (int)std::min<long>(m->tune.i8_short, (ct + 15) / 16);
+        if (m->tune.i8_short > 0 && m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2) nty_short = (int)std::min<long>(m->tune.i8_short, (ct + 15) / 16);
         nty_tall = (int)std::max(0L, (ct - 16L * nty_short + 19) / 20);
     }
     const bool narrow = wide20 || (m->tune.i8_rt == 8 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7);

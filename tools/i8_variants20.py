@@ -13,7 +13,7 @@ X, blocks = synth(10000, C, 10, seed=0)
 boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0)
 nm.upload(X)
-nm.set_option("i8_rt", 20); nm.set_option("i8_waves", 8)
+nm.set_option("i8_rt", 20); nm.set_option("i8_short_rows", int(os.environ.get("I8_SHORT", "-1"))); nm.set_option("i8_waves", 8)
 ref = nm.bootstrap(400, seed=1)[0]
 res, ok = {v: [] for v in variants}, {}
 for w in range(30): nm.bootstrap_device(B, seed=1, rep_offset=w * B)
