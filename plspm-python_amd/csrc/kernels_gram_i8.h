@@ -183,11 +183,11 @@ __global__ void __launch_bounds__(256) zs_build_kernel(const double* __restrict_
 #define I8_HIST_KB 1024
 #define I8_HIST_KB_BYTES 2048
 template <bool BYTES>
-__global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT, int shape, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
+__global__ void __launch_bounds__(1024) resample_i8_kernel(int N, int KB, int MT, int shape, const int* __restrict__ idx, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd,
                                                            int* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KBw * 32 words: rows 2w, 2w+1 of the window in the halves of word w (zero beyond N)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;      // 256 ... 1,024 threads: the host fills the CU's wave slots whatever the histogram leaves room for
     const long b = blockIdx.x;
     constexpr int WKB = BYTES ? I8_HIST_KB_BYTES : I8_HIST_KB;
     const int kb0 = (int)blockIdx.y * WKB, KBw = min(WKB, KB - kb0);
@@ -197,11 +197,11 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
         if (BYTES) atomicAdd(&hist[w >> 2], 1u << (8u * (w & 3u)));
         else atomicAdd(&hist[w >> 1], (w & 1u) ? 0x10000u : 1u);
     };
-    for (int i = tid; i < nwords; i += 256) hist[i] = 0u;
+    for (int i = tid; i < nwords; i += nthr) hist[i] = 0u;
     __syncthreads();
     if (idx) {
         const int* my = idx + b * (long)N;
-        for (int i = tid; i < N; i += 256) {
+        for (int i = tid; i < N; i += nthr) {
             const int r = my[i];
             if ((unsigned)r < (unsigned)N) { const unsigned w = (unsigned)r - r0; if (w < rspan) count(w); }
             else if (blockIdx.y == 0) atomicOr(err, 1);
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
     } else {
         const uint64_t rep = (uint64_t)(rep0 + b);
         const int nq = (N + 3) >> 2;
-        for (int q = tid; q < nq; q += 256) {
+        for (int q = tid; q < nq; q += nthr) {
             const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) resample_i8_kernel(int N, int KB, int MT,
     const int mt = (int)(b >> 4), r = (int)(b & 15);
     const uint4* h4 = reinterpret_cast<const uint4*>(hist);
     bool over = false;
-    for (int c = tid; c < KBw * 4; c += 256) {                     // piece c: rows 16c .. 16c+15 of the window = hist words 8c .. 8c+7 (bytes: 4c .. 4c+3)
+    for (int c = tid; c < KBw * 4; c += nthr) {                     // piece c: rows 16c .. 16c+15 of the window = hist words 8c .. 8c+7 (bytes: 4c .. 4c+3)
         uint4 out;
         if (BYTES) {
             out = h4[c];

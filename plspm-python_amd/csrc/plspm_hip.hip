@@ -1262,6 +1262,9 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     int rc;
     if ((rc = allow_lds(m, hist_byte ? (const void*)resample_i8_kernel<true> : (const void*)resample_i8_kernel<false>, hist_bytes))) return rc;
     const auto resample_k = hist_byte ? resample_i8_kernel<true> : resample_i8_kernel<false>;
+    // threads per workgroup: the histogram decides how many workgroups share a CU (160 KB of LDS); the VALU-bound Philox loop wants the
+    // CU's wave slots filled either way (N = 100,000: one 128 KB histogram per CU -- 256 threads left three quarters of the SIMD time idle)
+    const unsigned resample_threads = (unsigned)std::min(1024, std::max(256, 256 * (int)(8 / std::max<size_t>(1, (160 * 1024) / std::max<size_t>(1, hist_bytes)))));
     if (m->tune.resample_aux && !m->aux) {
         int lo = 0, hi = 0;
         HIPCHK(m, hipDeviceGetStreamPriorityRange(&lo, &hi));                // (numerically: lowest priority first)
@@ -1284,7 +1287,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         if (m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->aux, m->ev_cdfree[slot], 0));
         {
             ProfScope ps(m, PLSPM_K_RESAMPLE, m->aux);
-            hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
+            hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(resample_threads), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
         }
         HIPCHK(m, hipEventRecord(m->ev_counts[slot], m->aux));
         HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_counts[slot], 0));
@@ -1292,7 +1295,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         // explicit index lists (test / parity seam) arrive on the main stream: drawn there, and the host looks at the flag
         if (m->aux && m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_cdfree[slot], 0));
         ProfScope ps(m, PLSPM_K_RESAMPLE);
-        hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(256), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
+        hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(resample_threads), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
     }
     if (d_idx) {
         int* h_err = (int*)m->h_flag + 9;
