@@ -33,6 +33,8 @@ timeout 300 python tools/aux_ab.py solver_wave=0,1 2>&1 | grep "^{" > $O/ab_solv
 timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
 timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
 timeout 300 python tools/rt_check.py 2>&1 | grep "^{" > $O/i8_rt.jsonl
+timeout 300 python tools/i8_mix_calib.py 2>&1 | grep "^{" > $O/i8_mix_calib.jsonl
+[ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && I8_SHORT=5 PLSPM_HIP_LIB=plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so timeout 300 python tools/i8_variants20.py 3 0 1 4 5 103 203 403 703 2>&1 | grep "^{" > $O/i8_variants20.jsonl
 timeout 300 python tools/two_pipelines.py 2>&1 | grep "^{" > $O/two_pipelines.jsonl
 timeout 300 python tools/two_pipelines.py i8_rt=8 2>&1 | grep "^{" >> $O/two_pipelines.jsonl
 [ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so timeout 300 python tools/i8_ablate.py 2>&1 | grep "^{" > $O/i8_ablate.jsonl

@@ -12,7 +12,7 @@ ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 C = satisfaction_C()
 X, blocks = synth(10000, C, 10, seed=0)
 boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
-configs = [(1, 7, 4, 16, 0), (2, 7, 4, 16, 0), (2, 7, 4, 16, 1), (2, 7, 8, 16, 0), (2, 7, 8, 16, 1), (2, 7, 4, 32, 0), (2, 6, 4, 16, 1), (2, 8, 4, 16, 1), (2, 5, 4, 16, 1)]
+configs = [(2, 0, 8, 16, 0), (1, 7, 4, 16, 0), (2, 7, 4, 16, 0), (2, 7, 4, 16, 1), (2, 7, 8, 16, 0), (2, 7, 8, 16, 1), (2, 7, 4, 32, 0), (2, 6, 4, 16, 1), (2, 8, 4, 16, 1), (2, 5, 4, 16, 1)]
 models = {}
 for cfg in configs:
     path, slices, waves, shape, sched = cfg
