@@ -402,6 +402,11 @@ int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t 
 /* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);
 
+/* Test seam, host arithmetic only (no device is touched): how the six-plane int8 Gram cuts `count_tiles` (16 replicates each) x
+ * `pair_tiles` (32 pair columns each) into tile rows on `cus` CUs ("i8_rt" 0).  *tall rows of 20 count tiles and, with `mix` != 0, *shrt
+ * rows of 16 in one launch; returns 1 when that launch is taken, 0 when the 256-replicate kernel is no slower, PLSPM_E_ARG on bad sizes. */
+int plspm_gram_tile_plan(int64_t count_tiles, int64_t pair_tiles, int32_t cus, int32_t mix, int32_t* tall, int32_t* shrt);
+
 /* Kernel timing with HIP events on the handle's own stream (for the roofline figures in bench.py).
  * kernel ids: 0 resample/compact, 1 gram (MFMA), 2 solver, 3 scores, 4 upload/pack, 5 gram reduce. */
 enum { PLSPM_K_RESAMPLE = 0, PLSPM_K_GRAM = 1, PLSPM_K_SOLVER = 2, PLSPM_K_SCORES = 3, PLSPM_K_PACK = 4, PLSPM_K_REDUCE = 5, PLSPM_K_COUNT = 6 };

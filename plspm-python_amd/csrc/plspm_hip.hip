@@ -1914,6 +1914,14 @@ int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t 
     return rc;
 }
 
+int plspm_gram_tile_plan(int64_t count_tiles, int64_t pair_tiles, int32_t cus, int32_t mix, int32_t* tall, int32_t* shrt) {
+    if (!tall || !shrt || count_tiles < 1 || pair_tiles < 1 || cus < 1 || count_tiles > ((int64_t)1 << 26) || pair_tiles > ((int64_t)1 << 20)) return PLSPM_E_ARG;
+    int a = 0, b = 0;
+    const bool wide = i8_mix_plan((long)count_tiles, (long)pair_tiles, std::max(8, (int)cus), mix != 0, &a, &b);
+    *tall = a; *shrt = b;
+    return wide ? 1 : 0;
+}
+
 int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx) {
     if (!idx || N < 1 || N > 0x7fffffffLL || rep < 0) return PLSPM_E_ARG;
     for (int64_t q = 0; q < (N + 3) / 4; ++q) {

@@ -24,7 +24,7 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt", "plspm_bootstrap_prepare",
            "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
-           "plspm_op_inner_weights", "plspm_op_outer_weights", "plspm_op_outer_weights_nonmetric"]
+           "plspm_op_inner_weights", "plspm_op_outer_weights", "plspm_op_outer_weights_nonmetric", "plspm_gram_tile_plan"]
 UNIQUE_ID_BYTES = 128
 
 
@@ -153,6 +153,17 @@ def bootstrap_indices(seed, rep, n):
     if rc:
         raise NativeBackendError("plspm_bootstrap_indices failed (%d)" % rc)
     return idx
+
+
+def i8_tile_plan(count_tiles, pair_tiles, cus=256, mix=True):
+    """Host mirror of the int8 Gram's tile-row cut (plspm_gram_tile_plan): (launch of the 320-replicate kernel taken?, tall rows, short rows)."""
+    tall, shrt = ctypes.c_int32(0), ctypes.c_int32(0)
+    lib = load()
+    lib.plspm_gram_tile_plan.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    rc = lib.plspm_gram_tile_plan(count_tiles, pair_tiles, cus, 1 if mix else 0, ctypes.byref(tall), ctypes.byref(shrt))
+    if rc not in (0, 1):
+        raise NativeBackendError("plspm_gram_tile_plan failed (%d)" % rc)
+    return bool(rc), tall.value, shrt.value
 
 
 class NativeModel:

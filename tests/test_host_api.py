@@ -205,6 +205,38 @@ def test_host_rng_mirror_properties():
     assert abs(big.mean() / 200000.0 - 0.5) < 0.01
 
 
+def test_tile_row_cut_of_the_int8_gram_covers_the_batch_and_balances_the_last_round():
+    """plspm_gram_tile_plan (host arithmetic of the six-plane int8 Gram): rows of 20 and 16 count tiles cover the batch
+    with less than one row of padding, the headline shape (313 count tiles x 60 pair tiles, 256 CUs) takes three tall + one short
+    tile per CU, batches that fill whole rounds of the 256-replicate kernel keep that kernel, and a cut is never modelled slower than
+    tall rows alone.  The cut never shows in a result (GPU test: bit-identical matrices for every cut)."""
+    def span(a, b, ntx, cus=256):                       # the model restated: list scheduling per XCD, tall tiles first
+        worst = 0.0
+        ta, tb = a * ntx, b * ntx
+        pa, pb = (ta + 7) // 8, (tb + 7) // 8
+        for x in range(8):
+            na, nb = max(0, min(pa, ta - x * pa)), max(0, min(pb, tb - x * pb))
+            load = [0.0] * (cus // 8)
+            for t in range(na + nb):
+                load[load.index(min(load))] += 20.0 if t < na else 16.6
+            worst = max(worst, max(load))
+        return worst
+    wide, a, b = _native.i8_tile_plan(313, 60)
+    assert wide and (a, b) == (12, 5) and span(a, b, 60) == 3 * 20.0 + 16.6
+    for ct, ntx in ((313, 60), (157, 60), (625, 60), (219, 60), (1250, 60), (313, 231), (40, 4), (1000, 7)):
+        wide, a, b = _native.i8_tile_plan(ct, ntx)
+        if wide:
+            assert 20 * a + 16 * b >= ct and 20 * a + 16 * b - ct < 20 + 16 * (b > 0), (ct, ntx, a, b)
+            assert span(a, b, ntx) <= span((ct + 19) // 20, 0, ntx) + 1e-9, (ct, ntx, a, b)
+            assert abs(span(a, b, ntx) - min(span(max(0, (ct - 16 * k + 19) // 20), k, ntx) for k in range(0, min((ct + 15) // 16, 48) + 1)
+                                             if max(0, (ct - 16 * k + 19) // 20) or 16 * k >= ct)) < 1e-9
+        _, a0, b0 = _native.i8_tile_plan(ct, ntx, mix=False)
+        assert b0 == 0 and 20 * a0 >= ct
+    assert _native.i8_tile_plan(256, 60)[0] is False        # 4,096 replicates: 960 tiles of 256 = 3.75 rounds x 16.35 beat every cut
+    assert _native.i8_tile_plan(4, 60)[0] is False          # one tile row either way: the lower tile wins
+    assert _native.i8_tile_plan(313, 60) == _native.i8_tile_plan(313, 60)
+
+
 @pytest.mark.skipif(_native.device_count() > 0, reason="needs a box WITHOUT a GPU")
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
     assert _native.device_count() == 0
