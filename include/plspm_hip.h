@@ -107,6 +107,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     result depends on the cut).  20: tall rows only.  128 (value 8): half the accumulator registers, two workgroups per
  *                     CU, seven planes (2.6 % slower -- kept for co-scheduling experiments).  Read-only "last_i8_rt" / "last_i8_short" /
  *                     "last_i8_mt": tile height, short rows and padded count tiles of the last launch
+ *   "upload_direct"   0 (default) | 1   plspm_upload of more than 64 MB: 0 through the handle's pinned staging halves, filled by several host
+ *                     threads; 1 the runtime's pageable copy (one staging thread: 13-52 GB/s depending on the host)
  *   "i8_short_rows"   -1 (default) | n   test seam, with "i8_rt" 20 and eight waves: n rows of 256 replicates behind the tall ones
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel

@@ -19,6 +19,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "../../include/plspm_hip.h"
 #include "solver_core.h"
@@ -356,9 +358,10 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     int* d_ci = (int*)m->up_ci.p;
     double* d_partial = (double*)m->up_partial.p;
     double* d_Xa = (double*)m->xa.p;
-    // host -> device: small matrices go through the handle's pinned staging halves (no page pinning per call); large ones are
-    // handed to the runtime as they are (its pageable path pipelines page-locking and DMA: 52 GB/s measured on 1.6 GB)
-    if (raw_bytes <= ((size_t)64 << 20)) { if ((rc = plspm_detail_h2d(m, d_raw, X, raw_bytes))) return rc; }
+    // host -> device through the handle's pinned staging halves (no page pinning per call); from 64 MB on several host threads fill
+    // every half (plspm_detail_h2d).  The runtime's own pageable path ("upload_direct" 1) moved configs[4]'s 1.6 GB at 52 GB/s on one
+    // box and at 13-15 GB/s on two others (its staging copy is one thread's memcpy)
+    if (raw_bytes <= ((size_t)64 << 20) || !m->tune.upload_direct) { if ((rc = plspm_detail_h2d(m, d_raw, X, raw_bytes))) return rc; }
     else HIPCHK(m, hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
     if ((rc = plspm_detail_h2d(m, d_ci, ci.data(), sizeof(int) * (size_t)Pg))) return rc;
     {
@@ -731,6 +734,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "nm_k16") { if (value < 0 || value > 1) return bad(); m->tune.nm_k16 = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
+    else if (k == "upload_direct") { if (value < 0 || value > 1) return bad(); m->tune.upload_direct = value; }
     else if (k == "i8_short_rows") { if (value < -1 || value > 4096) return bad(); m->tune.i8_short = value; }
     else if (k == "i8_rt") { if (value != 0 && value != 16 && value != 8 && value != 20) return bad(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
@@ -771,6 +775,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_short_rows") *value = m->tune.i8_short;
+    else if (k == "upload_direct") *value = m->tune.upload_direct;
     else if (k == "i8_dma") *value = m->tune.i8_dma;
     else if (k == "last_i8_dma") *value = m->last_i8_dma;
     else if (k == "solver_rows") *value = m->tune.solver_rows;
@@ -1706,23 +1711,90 @@ static int pin_ready(plspm_model* m) {
     return 0;
 }
 
+// Copy-in of a large pageable source by several host threads: one thread's memcpy into the pinned half runs at 13-50 GB/s depending on the
+// host (profiles/r02c_fit_bench.jsonl / r03_fit_bench.jsonl: configs[4]'s 1.6 GB took 105 / 30 ms on two boxes), below what the DMA behind
+// it moves; kCopyThreads stripes of every 8 MB chunk keep the staging ahead of the link on either.  The helpers live for one call.
+static constexpr int kCopyThreads = 8;
+static constexpr size_t kPinHalfBig = (size_t)32 << 20;
+static constexpr size_t kCopyParallelFrom = (size_t)64 << 20;
+struct CopyCrew {
+    std::atomic<uint64_t> seq{0};
+    std::atomic<int> done{0};
+    std::atomic<bool> stop{false};
+    const char* src = nullptr;
+    char* dst = nullptr;
+    size_t n = 0;
+    int T = 1;
+    std::vector<std::thread> helpers;
+    static void stripe(const char* src, char* dst, size_t n, int t, int T) {
+        const size_t per = ((n / T) + 4095) & ~(size_t)4095, lo = std::min(n, per * t), hi = (t == T - 1) ? n : std::min(n, per * (t + 1));
+        if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
+    }
+    void start(int threads) {
+        T = threads;
+        for (int t = 1; t < T; ++t)
+            helpers.emplace_back([this, t]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    uint64_t s;
+                    int spins = 0;
+                    while ((s = seq.load(std::memory_order_acquire)) == seen && !stop.load(std::memory_order_acquire))
+                        if (++spins > 2000) std::this_thread::yield();
+                    if (s == seen) return;                       // stop without new work
+                    seen = s;
+                    stripe(src, dst, n, t, T);
+                    done.fetch_add(1, std::memory_order_release);
+                }
+            });
+    }
+    void copy(const char* s, char* d, size_t bytes) {
+        if (T <= 1) { memcpy(d, s, bytes); return; }
+        src = s; dst = d; n = bytes;
+        done.store(0, std::memory_order_relaxed);
+        seq.fetch_add(1, std::memory_order_release);
+        stripe(s, d, bytes, 0, T);
+        while (done.load(std::memory_order_acquire) < T - 1) std::this_thread::yield();
+    }
+    ~CopyCrew() {
+        stop.store(true, std::memory_order_release);
+        for (auto& h : helpers) h.join();
+    }
+};
+
 int plspm_detail_h2d(plspm_model* m, void* dst, const void* src, size_t bytes) {
     int rc = pin_ready(m);
     if (rc) return rc;
+    CopyCrew crew;
+    // large transfers: halves of 32 MB from the library's pinned cache for the duration of the call (a chunk's fixed costs -- event wait,
+    // copy enqueue, the crew's hand-shake -- are ~30 us against 0.15 ms of DMA per 8 MB)
+    struct Big { void* p = nullptr; ~Big() { if (p) plspm_hfree(p); } } big;
+    size_t half = kPinHalf;
+    char* base = (char*)m->h_pin;
+    // ... and on a stream of their own: behind a kernel on the handle's stream the runtime moves host -> device copies at about half the
+    // rate it reaches on a stream that only ever copied (configs[4]'s upload right after a fit: 54 ms against 29.5; tools/experiments/upload_seq.py)
+    struct Lane { hipStream_t s = nullptr; ~Lane() { if (s) { (void)hipStreamSynchronize(s); plspm_stream_release(s); } } } lane;      // (error paths: no copy may still read the halves freed below)
+    hipStream_t cs = m->stream;
+    if (bytes >= kCopyParallelFrom) {
+        crew.start((int)std::min<unsigned>(kCopyThreads, std::max(1u, std::thread::hardware_concurrency() / 2)));
+        if (plspm_hmalloc(&big.p, 2 * kPinHalfBig) == hipSuccess && big.p) { half = kPinHalfBig; base = (char*)big.p; }
+        else big.p = nullptr;
+        HIPCHK(m, hipStreamSynchronize(m->stream));                  // whatever still reads or writes `dst` there has finished
+        if (plspm_stream_acquire(&lane.s) == hipSuccess && lane.s) cs = lane.s; else lane.s = nullptr;
+    }
     size_t done = 0;
     for (int k = 0; done < bytes; ++k) {
         const int h = k & 1;
-        const size_t n = std::min(kPinHalf, bytes - done);
-        char* stage = (char*)m->h_pin + h * kPinHalf;
+        const size_t n = std::min(half, bytes - done);
+        char* stage = base + h * half;
         if (k >= 2) HIPCHK(m, hipEventSynchronize(m->ev_pin[h]));            // the DMA that last read this half has finished
-        memcpy(stage, (const char*)src + done, n);
-        HIPCHK(m, hipMemcpyAsync((char*)dst + done, stage, n, hipMemcpyHostToDevice, m->stream));
-        HIPCHK(m, hipEventRecord(m->ev_pin[h], m->stream));
+        crew.copy((const char*)src + done, stage, n);
+        HIPCHK(m, hipMemcpyAsync((char*)dst + done, stage, n, hipMemcpyHostToDevice, cs));
+        HIPCHK(m, hipEventRecord(m->ev_pin[h], cs));
         done += n;
     }
     // the staging halves are re-used by the next call: wait for the (at most two) copies still in flight
     HIPCHK(m, hipEventSynchronize(m->ev_pin[0]));
-    if (bytes > kPinHalf) HIPCHK(m, hipEventSynchronize(m->ev_pin[1]));
+    if (bytes > half) HIPCHK(m, hipEventSynchronize(m->ev_pin[1]));
     return 0;
 }
 
