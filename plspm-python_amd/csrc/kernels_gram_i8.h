@@ -271,9 +271,10 @@ __global__ void __launch_bounds__(1024) resample_i8_kernel(int N, int KB, int MT
 // higher measured ceiling, and 7 instead of 3 free issue slots behind every MFMA), blocks of 32 rows x 32 k (two per k-block: halves
 // h = 0, 1), every wave spans the workgroup's 32 pairs x S planes and 256 / NW replicates.  The 1 KB blocks a workgroup needs per
 // k-step are the same contiguous 16 + 2 S KB in both layouts; only the inside of a block differs (lane l's 16 bytes at 16 l in both).
-// RT: count tiles (16 replicates each) per workgroup -- 16 = 256 replicates (default); 12 / 8 = 192 / 128 replicates per workgroup, i.e. 6 / 4
-// accumulator rows per wave at four waves (168 / 112 accumulator registers instead of 224): the variants that leave half of a SIMD's
-// register file to a co-resident wave of another kernel (the solver of the previous batch on a second stream).
+// RT: count tiles (16 replicates each) per workgroup -- 16 = 256 replicates; 20 = 320 replicates with S = 6 (30 accumulator tiles per wave at
+// eight waves: the six-plane default where its tile grid pays, with tile rows of 320 and 256 replicates in one launch -- MIX below);
+// 12 / 8 = 192 / 128 replicates per workgroup, i.e. 6 / 4 accumulator rows per wave at four waves (168 / 112 accumulator registers instead
+// of 224): the variants that leave half of a SIMD's register file to a co-resident wave of another kernel (measured: DESIGN.md 7b).
 template <int S, int WM, int VAR = I8_DEFAULT_VAR, int SH = 16, int RT = 16>
 struct GramI8 {
     static_assert(RT == 16 || SH == 16, "narrow workgroup tiles exist for the 16x16x64 layout only");
