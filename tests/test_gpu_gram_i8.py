@@ -524,3 +524,34 @@ def test_tall_workgroup_tile_with_six_planes_gives_identical_matrices():
     nh.set_option("i8_rt", 0)
     nh.bootstrap_device(64, seed=8)
     assert nh.get_option("last_i8_rt") == 16                       # one tile row either way: the lower tile wins
+
+
+def test_random_tile_row_cuts_on_random_shapes():
+    """The tile enumeration of the two-height launch (tall list, then short list, each cut into eight XCD ranges of 4-row x 8-column
+    blocks) on shapes it was not tuned on: 24 seeded (model, N, B, short rows) cases -- 1 .. 3 pair tiles up to several dozen, tile
+    rows that do not fill a 4-row block, more XCD ranges than tiles, all-short launches -- moment matrices bit-identical to the
+    256-replicate kernel's."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        L = int(rng.integers(2, 7))
+        per = int(rng.integers(2, 11))
+        N = int(rng.integers(130, 1500))
+        B = int(rng.integers(1, 2600))
+        C = orc.chain_C(L)
+        X, blocks = orc.synth(N, C, per, seed=100 + case)
+        model = orc.Model(blocks, C, "A" * L, "centroid", True)
+        nm = native_model(model)
+        nm.upload(X)
+        nm.set_option("i8_slices", 6); nm.set_option("i8_waves", 8)
+        nm.set_option("i8_rt", 16)
+        M16 = nm.bootstrap_moments(B, seed=case)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_rt") == 16
+        rows256 = (B + 255) // 256
+        for n_short in sorted({0, 1, int(rng.integers(0, rows256 + 1)), rows256}):
+            nm.set_option("i8_rt", 20); nm.set_option("i8_short_rows", n_short)
+            M = nm.bootstrap_moments(B, seed=case)
+            assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_short") == min(n_short, rows256)
+            assert np.array_equal(M, M16), (case, L, per, N, B, n_short)
+        nm.set_option("i8_short_rows", -1); nm.set_option("i8_rt", 0)
+        assert np.array_equal(nm.bootstrap_moments(B, seed=case), M16), (case, "auto")
+        nm.close()
