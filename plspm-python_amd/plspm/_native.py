@@ -63,6 +63,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NativeBackendError("libplspm_hip.so not found at %s: build it with `make -C plspm-python_amd/csrc` "
                                  "(there is no CPU fallback)" % LIB_PATH)
+    # multi-process RCCL / device-memory sharing on this platform needs dmabuf IPC (the host driver has no legacy IPC: without it
+    # hipIpcGetMemHandle fails with "invalid argument" inside ncclCommInitRank); the HSA runtime reads the variable when it starts, i.e.
+    # at the first HIP call behind this load -- a launcher that scrubbed the environment must not cost the job its collective
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
     lib.plspm_abi_version.restype = ctypes.c_int
