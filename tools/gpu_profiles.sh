@@ -66,7 +66,7 @@ for db in sorted(glob.glob(O + "/prof_*pmc*/*.db") + glob.glob(O + "/prof_c5_fet
 json.dump(out, open(O + "/pmc_rows.json", "w"), indent=0)
 for r in out: print(r["run"], r["kernel"][:36], r["counter"], r["dispatches"], r["avg"], r["avg_duration_ns"])
 PY
-python tools/rocprof_summary.py ${TAG}_tmp $(ls $O/prof_stats/*/*.db $O/prof_stats/*.db 2>/dev/null | head -1) $(ls $O/prof_fetch/*/*.db $O/prof_fetch/*.db 2>/dev/null | head -1) $(ls $O/prof_write/*/*.db $O/prof_write/*.db 2>/dev/null | head -1) > $O/rocprof_summary_stdout.txt 2>&1
+python tools/rocprof_summary.py ${TAG}_tmp $(ls $O/prof_stats/*/*.db $O/prof_stats/*.db 2>/dev/null | head -1) $(ls $O/prof_fetch/*/*.db $O/prof_fetch/*.db 2>/dev/null | head -1) $(ls $O/prof_write/*/*.db $O/prof_write/*.db 2>/dev/null | head -1) $O/prof_stats.log > $O/rocprof_summary_stdout.txt 2>&1
 mv profiles/${TAG}_tmp_rocprof_summary.md $O/rocprof_summary.md 2>/dev/null; mv profiles/${TAG}_tmp_rocprof_summary.json $O/rocprof_summary.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_traffic.json $O/gram_traffic.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_i8_traffic.json $O/gram_i8_traffic.json 2>/dev/null
 find $O -name "*.db" -size +20M -delete
 du -sh $O; ls $O

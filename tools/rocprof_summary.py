@@ -5,7 +5,7 @@ HBM counters (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs).
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
 read, so fetched bytes = 2 * FETCH_SIZE KiB; checked here on colsum_rowmajor_kernel, which reads a known N*P*8 bytes once.
 WRITE_SIZE is used as reported.
-usage: rocprof_summary.py <round-tag> <stats.db> [<fetch.db> <write.db>]"""
+usage: rocprof_summary.py <round-tag> <stats.db> [<fetch.db> <write.db> [<log of the traced run>]]"""
 import json
 import os
 import sqlite3
@@ -32,6 +32,30 @@ def main():
         pct = 100.0 * total / tot_all
         out["kernels"].append({"kernel": short(name), "calls": calls, "total_us": round(total, 3), "avg_us": round(avg, 3), "pct": round(pct, 2)})
         lines.append("| %s | %d | %.1f | %.2f | %.2f |" % (short(name), calls, total, avg, pct))
+    # the dominant kernel by phase of the bench command (bench.py: W + K cold steps, 200 spin-up steps, W warm-up steps, the K TIMED
+    # steps, then the profiled / validation launches): the timed-region average is the one the bench line's roofline.avg_launch_ms --
+    # HIP events on every 10th timed step of its own run -- has to agree with; the log of the traced run (argv[5]) carries that line
+    W, K, SPIN = 5, 50, 200
+    dom = rows[0][0] if rows else None
+    if dom and rows[0][1] >= 2 * (W + K) + SPIN:
+        d = [r[0] / 1e3 for r in cur.execute("select duration from kernels k where name = ? and grid_x*grid_y*grid_z = (select max(grid_x*grid_y*grid_z) "
+                                             "from kernels k2 where k2.name = k.name) order by start", (dom,))]
+        cuts = [("cold: the first W + K = %d steps (device coming out of idle)" % (W + K), 0, W + K), ("spin-up (%d steps)" % SPIN, W + K, W + K + SPIN),
+                ("warm-up (W = %d)" % W, W + K + SPIN, 2 * W + K + SPIN), ("TIMED region (K = %d)" % K, 2 * W + K + SPIN, 2 * (W + K) + SPIN), ("behind the timed region", 2 * (W + K) + SPIN, len(d))]
+        lines += ["", "# %s by phase of the command (`bench.py --steps %d --warmup %d`)" % (short(dom), K, W), "", "| phase | launches | avg us |", "|---|---:|---:|"]
+        out["dominant_by_phase"] = []
+        for label, a, b in cuts:
+            if b > a:
+                avg = sum(d[a:b]) / (b - a)
+                lines.append("| %s | %d | %.2f |" % (label, b - a, avg))
+                out["dominant_by_phase"].append({"phase": label, "launches": b - a, "avg_us": round(avg, 3)})
+        if len(sys.argv) >= 6 and os.path.exists(sys.argv[5]):
+            bl = [x for x in open(sys.argv[5]) if x.startswith("{")]
+            if bl:
+                b = json.loads(bl[-1])
+                lines += ["", "Bench line of the same (traced) run: value %.4g %s, ms_per_step %.4f, roofline.avg_launch_ms %.4f over %d bracketed launches of the timed region (HIP events; "
+                          "an event pair around a launch reads ~2 %% longer than the trace's begin / end of the same kernel)." % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["avg_launch_ms"], b["roofline"]["launches"])]
+                out["traced_run_bench_line"] = {"value": b["value"], "ms_per_step": b["ms_per_step"], "avg_launch_ms": b["roofline"]["avg_launch_ms"]}
     if len(sys.argv) >= 5:
         for key, db in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
             c2 = sqlite3.connect(db).cursor()
