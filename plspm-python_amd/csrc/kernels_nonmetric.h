@@ -509,3 +509,94 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
         if (live) partial[b * nparts + part] = acc;
     }
 }
+
+// ---------------------------------------------------------------------------------------------- dense stop-rule pass on category codes
+// All-indicator categorical models (every device column a 0/1 indicator of one category of one MV: plspm_model::cat_pure): a row holds
+// exactly one 1 among the columns of an MV, and the rows of a tile are the same for every lane (= replicate).  So instead of 2 x 16
+// multiply-adds per COLUMN of the block (nm_conv_dense_kernel: ten per row and five-category MV, nine of them with x = 0), the wave reads
+// the 16 category codes of (tile, MV) through the scalar cache and ADDS the old and the new coefficient of that one column -- the same
+// additions in the same order (fma(1, c, a) = a + c; fma(0, c, a) = a), so the partial sums are bit for bit those of the dense pass.
+// Coefficients of a block in LDS interleaved [column][old | new][64 lanes] (one address per row and MV); slot kb stays zero: the code of
+// a row without a 1 in that MV (the pad rows of the last tile).
+// codes[(tile * Pm + mv) * 16 + r]: the block-relative column of MV mv's category in row 16 tile + r.
+__global__ void __launch_bounds__(256) cat_codes_kernel(const double* __restrict__ Xa, long N, int PA, int Pm, const int* __restrict__ mv_off, const int* __restrict__ mv_lv,
+                                                         const int* __restrict__ boff, int none, long ntiles, unsigned short* __restrict__ codes) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ntiles * Pm * 16) return;
+    const int r = (int)(e & 15);
+    const long tm = e >> 4;
+    const int mv = (int)(tm % Pm);
+    const long i = (tm / Pm) * 16 + r;
+    int code = none;
+    if (i < N) {
+        const int c0 = mv_off[mv], c1 = mv_off[mv + 1], b0 = boff[mv_lv[mv]];
+        for (int c = c0; c < c1; ++c)
+            if (Xa[i * PA + c] != 0.0) { code = c - b0; break; }
+    }
+    codes[e] = (unsigned short)code;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) nm_conv_codes_kernel(const unsigned short* __restrict__ codes, long ntiles, int Pm, int P, int L, const int* __restrict__ boff,
+                                                                 const int* __restrict__ lmv_off, const uint4* __restrict__ cd, long MT, const double* __restrict__ table,
+                                                                 const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial, int nparts, int rbx,
+                                                                 int gy, int kb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* co = reinterpret_cast<double*>(smem_raw);           // [kb + 1][2][64], then k_old[64], k_new[64]
+    double* bk = co + (long)(kb + 1) * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;       // the dense pass's XCD-aware decomposition: row blocks k, k + 8, ... on XCD k
+    const int rb = (jj % rbx) * 8 + xcd, gy0 = jj / rbx;
+    const long part = (long)rb * NW + wave;                     // this wave's 16-row tile
+    if ((long)rb * NW >= ntiles) return;
+    const bool have = part < ntiles;
+    const uint4* __restrict__ cq = reinterpret_cast<const uint4*>(codes + (have ? part : 0) * (long)Pm * 16);      // two uint4 per MV
+    const int rows = 2 * P + 2 * L + 1;
+    for (int e = threadIdx.x; e < 128; e += 64 * NW) co[(long)kb * 128 + e] = 0.0;
+    const int nlive = *count, ngroups = (nlive + 63) / 64;
+    for (int g = gy0; g < ngroups; g += gy) {
+        const bool live = (long)g * 64 + lane < nlive;
+        const long b = live ? (long)list[(long)g * 64 + lane] : 0;
+        const uint4 cw = (live && have) ? cd[((part >> 2) * MT + (b >> 4)) * 64 + (part & 3) * 16 + (b & 15)] : make_uint4(0, 0, 0, 0);
+        const unsigned wq[4] = {cw.x, cw.y, cw.z, cw.w};
+        const double* tg = table + (long)g * rows * 64;
+        double acc = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const int p0 = boff[l], nb = boff[l + 1] - p0;
+            __syncthreads();                                    // everybody is done with the previous block's coefficients
+            for (int e = threadIdx.x; e < nb * 64; e += 64 * NW) {
+                const int q = e >> 6, ln = e & 63;
+                co[q * 128 + ln] = tg[(long)p0 * 64 + e];
+                co[q * 128 + 64 + ln] = tg[((long)P + p0) * 64 + e];
+            }
+            if (threadIdx.x < 64) { bk[lane] = tg[(2L * P + l) * 64 + lane]; bk[64 + lane] = tg[(2L * P + L + l) * 64 + lane]; }
+            __syncthreads();
+            if (!have) continue;                                // (uniform per wave; the barriers above are reached by every wave)
+            double ao[16], an[16];
+            const double k0 = bk[lane], k1 = bk[64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
+            const double* cl = co + lane;
+            const int m1 = lmv_off[l + 1];
+            for (int mv = lmv_off[l]; mv < m1; ++mv) {
+                const uint4 ca = cq[2 * mv], cb = cq[2 * mv + 1];      // (wave-uniform address: scalar loads)
+                const unsigned c16[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned code = (c16[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+                    const double* pc = cl + code * 128u;
+                    ao[r] += pc[0];
+                    an[r] += pc[64];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double d = fabs(ao[r]) - fabs(an[r]);
+                const double w = (double)((wq[r >> 2] >> (8 * (r & 3))) & 0xffu);
+                acc = fma(w * d, d, acc);
+            }
+        }
+        if (live && have) partial[b * nparts + part] = acc;
+    }
+}

@@ -305,7 +305,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
@@ -345,7 +345,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
-    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
+    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
     drop_incomplete_rows(m);
     // persistent grow-only buffers: a repeated upload of the same shape allocates nothing
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
@@ -579,6 +579,21 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             src->Xt_valid = true;
         }
     }
+    // all-indicator categorical models on the blocked dense pass with the Gram's int8 counts: the pass on category codes
+    // (kernels_nonmetric.h nm_conv_codes_kernel; one table of 16 codes per (row tile, MV), built once per upload)
+    const bool use_codes = dense && counts8 && cat && m->cat_pure && !m->stage1 && !nmx && m->tune.nm_codes != 0 && kb < 65535;
+    const size_t codes_lds = (size_t)(2 * (kb + 1) + 2) * 64 * sizeof(double);
+    if (use_codes) {
+        if ((rc = allow_lds(m, (const void*)nm_conv_codes_kernel<8>, codes_lds))) return rc;
+        if (!m->codes_valid) {
+            if ((rc = ensure(m, m->codes, (size_t)ntiles16 * m->Pm * 16 * sizeof(unsigned short)))) return rc;
+            const long total = ntiles16 * m->Pm * 16;
+            hipLaunchKernelGGL(cat_codes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const double*)m->d_Xa, N, m->PA, m->Pm, (const int*)m->d_mv_off,
+                               (const int*)m->d_mv_lv, (const int*)m->d_boff, kb, ntiles16, (unsigned short*)m->codes.p);
+            m->codes_valid = true;
+        }
+    }
+    m->last_nm_codes = use_codes ? 1 : 0;
     if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
@@ -678,6 +693,11 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 const int gy = m->tune.conv_gy > 0 ? m->tune.conv_gy : ngroups;
                 auto conv_kernel = counts8 ? (dense_whole ? nm_conv_dense_kernel<16, 8, false, true> : nm_conv_dense_kernel<16, 8, true, true>)
                                            : (dense_whole ? nm_conv_dense_kernel<16, 8, false, false> : nm_conv_dense_kernel<16, 8, true, false>);
+                if (use_codes)
+                    hipLaunchKernelGGL(nm_conv_codes_kernel<8>, dim3((unsigned)(8 * rbx * gy)), dim3(512), codes_lds, m->stream, (const unsigned short*)m->codes.p, ntiles16, m->Pm, P, L,
+                                       (const int*)m->d_boff, (const int*)m->d_lmv_off, (const uint4*)cd8, (long)cd8_MT, (const double*)m->ctable.p,
+                                       (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
+                else
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
                                    (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
@@ -734,6 +754,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); m->tune.i8_waves = value; }
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "nm_k16") { if (value < 0 || value > 1) return bad(); m->tune.nm_k16 = value; }
+    else if (k == "nm_codes") { if (value < 0 || value > 1) return bad(); m->tune.nm_codes = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
     else if (k == "upload_direct") { if (value < 0 || value > 1) return bad(); m->tune.upload_direct = value; }
     else if (k == "i8_short_rows") { if (value < -1 || value > 4096) return bad(); m->tune.i8_short = value; }
@@ -773,6 +794,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_waves") *value = m->tune.i8_waves;
     else if (k == "nm_fast_lds") *value = m->tune.nm_fast_lds;
     else if (k == "nm_k16") *value = m->tune.nm_k16;
+    else if (k == "nm_codes") *value = m->tune.nm_codes;
+    else if (k == "last_nm_codes") *value = m->last_nm_codes;
     else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_short_rows") *value = m->tune.i8_short;

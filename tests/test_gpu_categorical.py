@@ -202,3 +202,34 @@ def test_wide_indicator_model_uses_the_block_staged_stop_rule_pass():
     mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(4, 69, 1500), orc.correction(1500))
     assert its == dense[2][69]
     assert_close(rows[69], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("scale", ["ORD", "NOM"])
+def test_stop_rule_pass_on_category_codes_gives_the_dense_pass_bits(scale):
+    """All-indicator models on the blocked dense pass: nm_conv_codes_kernel adds the coefficient of the ONE column a row has set per MV
+    (16 category codes per row tile and MV) instead of multiplying five 0/1 columns through -- the same additions in the same order, so
+    records and iteration counts are bit-identical to the dense pass ("nm_codes" 0), and both follow the oracle.  1,500 rows (the last
+    tile holds pad rows), 300 indicator columns, uneven category counts (3 .. 5 per item)."""
+    from plspm import _native
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(1500, C, 10, seed=37)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+    likert[:, ::3] = np.clip(likert[:, ::3], 2, 4)          # every third item has three categories
+    model = orc.Model(blocks, C, "AAAAAA", "centroid", True, tol=1e-6, scales=[scale] * 60)
+    nm, g = gpu_fit_cat(likert, model)
+    assert nm.get_option("nm_codes") == 1
+    on = nm.bootstrap(200, seed=6)
+    assert nm.get_option("last_nm_codes") == 1 and nm.get_option("last_gram_path") == 2
+    nm.set_option("nm_codes", 0)
+    off = nm.bootstrap(200, seed=6)
+    assert nm.get_option("last_nm_codes") == 0
+    nm.set_option("nm_codes", 1)
+    assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2])
+    assert np.array_equal(on[0], off[0])
+    rows = _rows_in_data_order(on[0], g["inv"], 60, 6, nm.n_eff)
+    ok = np.flatnonzero(on[1] == 0)
+    r = int(ok[-1])
+    mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(6, r, 1500), orc.correction(1500))
+    assert its == on[2][r]
+    assert_close(rows[r], mine, RTOL, ATOL)
