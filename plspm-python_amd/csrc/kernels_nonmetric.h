@@ -519,8 +519,10 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
 // Coefficients of a block in LDS interleaved [column][old | new][64 lanes] (one address per row and MV); slot kb stays zero: the code of
 // a row without a 1 in that MV (the pad rows of the last tile).
 // codes[(tile * Pm + mv) * 16 + r]: the block-relative column of MV mv's category in row 16 tile + r.
-__global__ void __launch_bounds__(256) cat_codes_kernel(const double* __restrict__ Xa, long N, int PA, int Pm, const int* __restrict__ mv_off, const int* __restrict__ mv_lv,
-                                                         const int* __restrict__ boff, int none, long ntiles, unsigned short* __restrict__ codes) {
+// mv_base[mv]: first column of the block the pass files MV mv under (its LV's block; a second HOC stage: the block of the second-stage LV
+// that stands for it).
+__global__ void __launch_bounds__(256) cat_codes_kernel(const double* __restrict__ Xa, long N, int PA, int Pm, const int* __restrict__ mv_off, const int* __restrict__ mv_base,
+                                                         int none, long ntiles, unsigned short* __restrict__ codes) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= ntiles * Pm * 16) return;
     const int r = (int)(e & 15);
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(256) cat_codes_kernel(const double* __restrict
     const long i = (tm / Pm) * 16 + r;
     int code = none;
     if (i < N) {
-        const int c0 = mv_off[mv], c1 = mv_off[mv + 1], b0 = boff[mv_lv[mv]];
+        const int c0 = mv_off[mv], c1 = mv_off[mv + 1], b0 = mv_base[mv];
         for (int c = c0; c < c1; ++c)
             if (Xa[i * PA + c] != 0.0) { code = c - b0; break; }
     }

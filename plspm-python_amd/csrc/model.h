@@ -52,8 +52,8 @@ struct plspm_model {
     bool cat_pure = false;       // every logical MV is ORD / NOM: all device columns are 0/1 indicators
     int categorical = 0;         // Scale.ORD / NOM present: device columns are aug columns (solver_nmg.h); Pm logical MVs
     int Pm = 0, cmax = 1, kmv = 1;
-    std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol;
-    int *d_mv_off = nullptr, *d_mv_kind = nullptr, *d_lmv_off = nullptr, *d_mv_lv = nullptr, *d_no_chol = nullptr;
+    std::vector<int> mv_off, mv_kind, lmv_off, mv_lv, no_chol, mv_base, mv_base2, lmv2_off;
+    int *d_mv_off = nullptr, *d_mv_kind = nullptr, *d_lmv_off = nullptr, *d_mv_lv = nullptr, *d_no_chol = nullptr, *d_mv_base = nullptr, *d_mv_base2 = nullptr, *d_lmv2_off = nullptr;
     Buf gSm;
     // metric data with missing values: Pg = P + n_ind device columns (data | missing indicators); PA / T describe the Gram of
     // those, PAs / Ts the P-column moment matrix the solver reads (impute_collapse maps one to the other).  Pg == P otherwise.

@@ -302,7 +302,7 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
     void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
+                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_mv_base, m->d_mv_base2, m->d_lmv2_off, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
                     m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
@@ -345,7 +345,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
-    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
+    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; if (m->stage2) m->stage2->codes_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
     drop_incomplete_rows(m);
     // persistent grow-only buffers: a repeated upload of the same shape allocates nothing
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
@@ -579,17 +579,20 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
             src->Xt_valid = true;
         }
     }
-    // all-indicator categorical models on the blocked dense pass with the Gram's int8 counts: the pass on category codes
-    // (kernels_nonmetric.h nm_conv_codes_kernel; one table of 16 codes per (row tile, MV), built once per upload)
-    const bool use_codes = dense && counts8 && cat && m->cat_pure && !m->stage1 && !nmx && m->tune.nm_codes != 0 && kb < 65535;
+    // all-indicator categorical data on the dense pass with the Gram's int8 counts: the pass on category codes (kernels_nonmetric.h
+    // nm_conv_codes_kernel; one table of 16 codes per (row tile, MV), built once per upload -- a second HOC stage streams its first
+    // stage's rows under its own blocks and keeps its own table)
+    const int* codes_base = m->stage1 ? m->d_mv_base2 : m->d_mv_base;
+    const int* codes_lmv = m->stage1 ? m->d_lmv2_off : m->d_lmv_off;
+    const bool use_codes = dense && counts8 && src->categorical && src->cat_pure && (m->stage1 || cat) && codes_base && codes_lmv && !nmx && m->tune.nm_codes != 0 && kb < 65535;
     const size_t codes_lds = (size_t)(2 * (kb + 1) + 2) * 64 * sizeof(double);
     if (use_codes) {
         if ((rc = allow_lds(m, (const void*)nm_conv_codes_kernel<8>, codes_lds))) return rc;
         if (!m->codes_valid) {
-            if ((rc = ensure(m, m->codes, (size_t)ntiles16 * m->Pm * 16 * sizeof(unsigned short)))) return rc;
-            const long total = ntiles16 * m->Pm * 16;
-            hipLaunchKernelGGL(cat_codes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const double*)m->d_Xa, N, m->PA, m->Pm, (const int*)m->d_mv_off,
-                               (const int*)m->d_mv_lv, (const int*)m->d_boff, kb, ntiles16, (unsigned short*)m->codes.p);
+            if ((rc = ensure(m, m->codes, (size_t)ntiles16 * src->Pm * 16 * sizeof(unsigned short)))) return rc;
+            const long total = ntiles16 * src->Pm * 16;
+            hipLaunchKernelGGL(cat_codes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, src->Pm, (const int*)src->d_mv_off,
+                               codes_base, kb, ntiles16, (unsigned short*)m->codes.p);
             m->codes_valid = true;
         }
     }
@@ -694,8 +697,8 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
                 auto conv_kernel = counts8 ? (dense_whole ? nm_conv_dense_kernel<16, 8, false, true> : nm_conv_dense_kernel<16, 8, true, true>)
                                            : (dense_whole ? nm_conv_dense_kernel<16, 8, false, false> : nm_conv_dense_kernel<16, 8, true, false>);
                 if (use_codes)
-                    hipLaunchKernelGGL(nm_conv_codes_kernel<8>, dim3((unsigned)(8 * rbx * gy)), dim3(512), codes_lds, m->stream, (const unsigned short*)m->codes.p, ntiles16, m->Pm, P, L,
-                                       (const int*)m->d_boff, (const int*)m->d_lmv_off, (const uint4*)cd8, (long)cd8_MT, (const double*)m->ctable.p,
+                    hipLaunchKernelGGL(nm_conv_codes_kernel<8>, dim3((unsigned)(8 * rbx * gy)), dim3(512), codes_lds, m->stream, (const unsigned short*)m->codes.p, ntiles16, src->Pm, src->P, L,
+                                       conv_boff, codes_lmv, (const uint4*)cd8, (long)cd8_MT, (const double*)m->ctable.p,
                                        (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
                 else
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
@@ -837,6 +840,9 @@ int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_
     for (int k = 0; k < m->L; ++k) if (m->lmv_off[k + 1] == m->lmv_off[k]) return fail(m, PLSPM_E_ARG, "every LV needs at least one MV");
     m->no_chol.assign(m->L, -1);
     HIPCHK(m, hipSetDevice(m->device));
+    m->mv_base.assign(Pm, 0);
+    for (int p = 0; p < Pm; ++p) m->mv_base[p] = m->boff[m->mv_lv[p]];          // (category codes are filed relative to the MV's LV block: nm_conv_codes_kernel)
+    if (upload_vec(m, &m->d_mv_base, m->mv_base)) return fail(m, PLSPM_E_STATE, "descriptor upload failed: " + m->error);
     if (upload_vec(m, &m->d_mv_off, m->mv_off) || upload_vec(m, &m->d_mv_kind, m->mv_kind) || upload_vec(m, &m->d_lmv_off, m->lmv_off) ||
         upload_vec(m, &m->d_mv_lv, m->mv_lv) || upload_vec(m, &m->d_no_chol, m->no_chol))
         return fail(m, PLSPM_E_STATE, "descriptor upload failed");
@@ -903,6 +909,19 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     if (upload_vec(m2, &m2->d_lv_first, m2->lv_first) || upload_vec(m2, &m2->d_col2_lv1, m2->col2_lv1) || upload_vec(m2, &m2->d_col2_p1, m2->col2_p1) ||
         upload_vec(m2, &m2->d_hidx, m2->hidx) || upload_vec(m2, &m2->d_hcol, m2->hcol) || upload_vec(m2, &m2->d_lv_cols, m2->lv_cols))
         return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
+    if (m1->categorical && (int)m1->mv_lv.size() == m1->Pm && (int)m1->lmv_off.size() == L1 + 1) {
+        // category codes of the first stage's rows under the SECOND stage's blocks (nm_conv_codes_kernel): per first-stage MV the first
+        // column of the second-stage LV that stands for its LV, per second-stage LV its range of first-stage MVs
+        std::vector<int> base2(m1->Pm, 0), lmv2(L2 + 1, 0);
+        for (int l = 0; l <= L2; ++l) lmv2[l] = m1->lmv_off[lv_first[l]];
+        for (int p = 0; p < m1->Pm; ++p) {
+            int l2 = 0;
+            while (l2 + 1 < L2 && m1->mv_lv[p] >= lv_first[l2 + 1]) ++l2;
+            base2[p] = lv_cols[l2];
+        }
+        m2->mv_base2 = base2; m2->lmv2_off = lmv2;
+        if (upload_vec(m2, &m2->d_mv_base2, m2->mv_base2) || upload_vec(m2, &m2->d_lmv2_off, m2->lmv2_off)) return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
+    }
     HIPCHK(m1, hipMemset(m2->d_shift, 0, sizeof(double) * m2->P));
     HIPCHK(m1, hipStreamSynchronize(m2->stream));
     plspm_stream_release(m2->stream);

@@ -175,6 +175,16 @@ def test_hoc_on_ordinal_data_fit_and_replicates_vs_reference_golden(tag):
         one = np.concatenate((res.raw["weights"], res.raw["r2"], res.raw["total"], res.raw["direct"], res.raw["loadings"]))
         assert status_d[r] == 0
         assert_close(rows_d[r], one, 1e-7, 1e-10)
+    # the stop-rule passes of both stages ran on category codes (the second stage files the first stage's rows under its own blocks);
+    # with the multiply-add pass instead ("nm_codes" 0 on both handles) the records are the same bits
+    assert pair.native.get_option("last_nm_codes") == 1 and pair.native._second.get_option("last_nm_codes") == 1
+    rows_c, status_c, iters_c = pair.native.bootstrap(150, seed=11)
+    pair.native.set_option("nm_codes", 0); pair.native._second.set_option("nm_codes", 0)
+    rows_m, status_m, iters_m = pair.native.bootstrap(150, seed=11)
+    assert pair.native.get_option("last_nm_codes") == 0 and pair.native._second.get_option("last_nm_codes") == 0
+    pair.native.set_option("nm_codes", 1); pair.native._second.set_option("nm_codes", 1)
+    assert np.array_equal(status_c, status_m) and np.array_equal(iters_c, iters_m)
+    assert np.array_equal(rows_c, rows_m, equal_nan=True)
 
 
 def test_api_bootstrap_of_a_hoc_model_on_ordinal_data():
