@@ -584,8 +584,9 @@ static int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long 
     // stage's rows under its own blocks and keeps its own table)
     const int* codes_base = m->stage1 ? m->d_mv_base2 : m->d_mv_base;
     const int* codes_lmv = m->stage1 ? m->d_lmv2_off : m->d_lmv_off;
-    const bool use_codes = dense && counts8 && src->categorical && src->cat_pure && (m->stage1 || cat) && codes_base && codes_lmv && !nmx && m->tune.nm_codes != 0 && kb < 65535;
-    const size_t codes_lds = (size_t)(2 * (kb + 1) + 2) * 64 * sizeof(double);
+    const size_t codes_lds = (size_t)(2 * (kb + 1) + 2) * 64 * sizeof(double);      // one block's coefficients + the zero slot + the two constants
+    const bool use_codes = dense && counts8 && src->categorical && src->cat_pure && (m->stage1 || cat) && codes_base && codes_lmv && !nmx && m->tune.nm_codes != 0 && kb < 65535 &&
+                           codes_lds <= kMaxLds;
     if (use_codes) {
         if ((rc = allow_lds(m, (const void*)nm_conv_codes_kernel<8>, codes_lds))) return rc;
         if (!m->codes_valid) {
