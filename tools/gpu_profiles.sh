@@ -48,6 +48,7 @@ timeout 300 python tools/i8_dma_form.py 2>&1 | grep "^{" > $O/i8_dma_form.jsonl
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --hip-trace --memory-copy-trace --output-format csv -d /tmp/tl -o tl -- python $R/tools/api_timeline.py run > $O/api_timeline.txt 2>/dev/null; python $R/tools/api_timeline.py read /tmp/tl >> $O/api_timeline.txt 2>&1)
 timeout 300 python tools/aux_ab.py resample_aux=0,1,2,3 2>&1 | grep "^{" > $O/ab_resample_aux.jsonl
 timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench.json
+(for v in 0 1 0 1; do CAT_NM_CODES=$v timeout 300 python tools/categorical_bench.py 2>&1 | tail -1; done) > $O/ab_nm_codes.jsonl
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && CAT_BENCH_STEPS=1 PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/categorical_bench.py 1000 2>&1 | grep clocks | tail -4 > $O/categorical_marks.txt
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/cp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/categorical_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/categorical_kernels.txt 2>&1; rm -rf /tmp/cp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/nonmetric_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/nonmetric_kernels.txt 2>&1)
 timeout 600 python tools/hoc_bench.py 2>&1 | tail -1 > $O/hoc_bench.json
