@@ -1089,7 +1089,13 @@ static constexpr size_t kZsBudget = (size_t)24 << 30;       // digit planes of o
 static inline int i8_kblocks(long N) { return (int)((N + 127) / 128) * 2; }      // k-blocks of 64 rows, an even number
 static inline long i8_pairs(const plspm_model* m) { const long C = m->Pg + 1; return C * (C + 1) / 2; }
 // Which Gram a bootstrap call of B replicates takes: 1 = fp64 MFMA on the (row,count) lists, 2 = int8 digit planes.
-static int choose_gram_path(const plspm_model* m, int64_t B) {
+// Can a non-metric bootstrap with on-device draws take its stop-rule passes' row multiplicities from the int8 counts of the digit-plane Gram
+// (plspm_detail_bootstrap counts8_plan)?
+static bool nm_counts8_possible(const plspm_model* m) {
+    return m->nonmetric && m->tune.nm_counts8 != 0 && m->tune.resample_aux == 0 && !m->aux && m->tune.i8_shape == 16 && m->nmx_K == 0 &&
+           nm_dense_lds(m, nullptr, nullptr) != 0 && (!m->stage2 || nm_dense_lds(m->stage2, nullptr, nullptr) != 0);
+}
+static int choose_gram_path(const plspm_model* m, int64_t B, bool explicit_idx = false) {
     if (m->tune.gram_path == 1) return 1;
     // every model's replicates start from the moment matrix of the uploaded columns (metric, mean-imputed, non-metric, categorical
     // indicator columns, incomplete rows zeroed, first stage of a HOC pair).  The LDS histogram bounds N; int32 accumulators need
@@ -1097,7 +1103,9 @@ static int choose_gram_path(const plspm_model* m, int64_t B) {
     // (int32 accumulators: |sum_i c_bi d_is| <= 128 sum_i c_bi = 128 N < 2^31, i.e. N < 2^24; the resample counts come from an LDS
     // histogram of 65,536 rows per workgroup, larger data sets take several windows per replicate)
     if (m->stage1 || m->N >= (1 << 24) || m->N < 2) return 1;
-    if (m->nonmetric && m->N > 65535) return 1;             // (their stop-rule passes want the dense uint16 histograms of the LDS-histogram resample)
+    // non-metric models beyond one 16-bit histogram window: the int8 route when their stop-rule passes can read the Gram's int8 counts
+    // (on-device draws); else the fp64 route with (row,count) lists from the global histogram and the gathering pass
+    if (m->nonmetric && m->N > 65535 && (explicit_idx || !nm_counts8_possible(m))) return 1;
     const size_t zs_bytes = (size_t)(i8_kblocks(m->N) + I8_SLACK_KB) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * (m->tune.i8_slices ? m->tune.i8_slices : 7)) * 1024;
     if (zs_bytes > kZsBudget) return 1;
     if (m->tune.gram_path == 2) return 2;
@@ -1484,12 +1492,11 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // non-metric models on the int8 route with Philox draws (round 3): the dense stop-rule pass reads its row multiplicities from the int8
     // counts the Gram consumed -- no second resample kernel, no (row,count) lists, no uint16 histograms (set_option "nm_counts8" 0: the
     // round-2 path, kept for A/B and for the cases below)
-    const int gpath_plan = choose_gram_path(m, B);
-    const bool counts8_plan = m->nonmetric && gpath_plan == 2 && !d_idx && m->tune.nm_counts8 != 0 && m->tune.resample_aux == 0 && !m->aux && m->tune.i8_shape == 16 &&
-                              m->nmx_K == 0 && nm_dense_lds(m, nullptr, nullptr) != 0 && (!m->stage2 || nm_dense_lds(m->stage2, nullptr, nullptr) != 0);
+    const int gpath_plan = choose_gram_path(m, B, d_idx != nullptr);
+    const bool counts8_plan = gpath_plan == 2 && !d_idx && nm_counts8_possible(m);
     const bool want_dcnt = m->nonmetric && lds_hist && !counts8_plan;
     const long dcnt_stride = ((N + 15) & ~15L);
-    const int gpath = choose_gram_path(m, B);
+    const int gpath = gpath_plan;
     m->last_gram_path = gpath;
     // one wave per problem on dense moment matrices (solver_rows_kernel): metric models of at most 64 MVs behind the int8 Gram
     // rows solver: one wave per problem, its small workspace + descriptors in LDS -- eight problems per CU at the headline size

@@ -233,3 +233,27 @@ def test_stop_rule_pass_on_category_codes_gives_the_dense_pass_bits(scale):
     mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(6, r, 1500), orc.correction(1500))
     assert its == on[2][r]
     assert_close(rows[r], mine, RTOL, ATOL)
+
+
+def test_categorical_bootstrap_beyond_one_histogram_window_takes_the_int8_route():
+    """70,000 rows: non-metric bootstraps with on-device draws now stay on the digit-plane Gram (counts from the 131,072-row byte
+    histogram) and take their stop-rule passes' row multiplicities from its int8 counts -- on category codes for all-indicator data.
+    Same bits as the multiply-add pass; the fp64 route (row lists from the global histogram, gathering pass) agrees to 1e-9 with
+    identical iteration counts."""
+    C = orc.chain_C(3)
+    X, blocks = orc.synth(70000, C, 4, seed=41)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    likert = np.clip(np.round(2.5 + 0.9 * Z), 1, 4)
+    model = orc.Model(blocks, C, "AAA", "factorial", True, tol=1e-6, scales=["ORD"] * 12)
+    nm, g = gpu_fit_cat(likert, model)
+    on = nm.bootstrap(48, seed=2)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_nm_codes") == 1 and np.all(on[1] == 0)
+    nm.set_option("nm_codes", 0)
+    off = nm.bootstrap(48, seed=2)
+    assert nm.get_option("last_nm_codes") == 0
+    assert np.array_equal(on[0], off[0]) and np.array_equal(on[2], off[2])
+    nm.set_option("gram_path", 1)
+    f64 = nm.bootstrap(48, seed=2)
+    assert nm.get_option("last_gram_path") == 1
+    assert np.array_equal(on[2], f64[2]) and np.all(f64[1] == 0)
+    assert_close(on[0], f64[0], 1e-9, 1e-12)

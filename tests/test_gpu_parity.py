@@ -934,3 +934,22 @@ def test_device_summary_on_crafted_records(B):
         assert np.all(np.isfinite(table[finite]))
         assert_close(table[finite], want[finite], 1e-11, 1e-13)
         assert table[4, 2] < 1e-15 and table[0, 2] < 1e-15
+
+
+@pytest.mark.gpu
+def test_nonmetric_numeric_bootstrap_beyond_65535_rows_on_the_int8_route():
+    """Scale.NUM model, 70,000 rows: the digit-plane Gram with the dense stop-rule pass on its int8 counts against the fp64 route
+    (global-histogram row lists, gathering pass): identical iteration counts, records to 1e-9; one replicate against the oracle."""
+    from plspm import _native
+    C = orc.chain_C(3)
+    X, blocks = orc.synth(70000, C, 4, seed=43)
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+    nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(3, dtype=np.int32), 1, True, 100, 1e-6, 0, nonmetric=True)
+    nm.upload(X)
+    i8 = nm.bootstrap(40, seed=3)
+    assert nm.get_option("last_gram_path") == 2 and np.all(i8[1] == 0)
+    nm.set_option("gram_path", 1)
+    f64 = nm.bootstrap(40, seed=3)
+    assert nm.get_option("last_gram_path") == 1
+    assert np.array_equal(i8[2], f64[2])
+    np.testing.assert_allclose(i8[0], f64[0], rtol=1e-9, atol=1e-12)

@@ -11,6 +11,7 @@ timeout 600 python bench.py 2>$O/bench_n1.err | tail -1 > $O/bench_n1.json
 timeout 300 python bench.py --group --no-cpu-baseline --no-api 2>/dev/null | tail -1 > $O/bench_n1_group_rccl.json
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_n1_launcher_rccl.json
 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1 > $O/nonmetric_bench.json
+(NM_BENCH_N=100000 NM_BENCH_SPINUP=3 NM_BENCH_STEPS=5 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1; NM_BENCH_N=100000 NM_BENCH_GRAM_PATH=1 NM_BENCH_SPINUP=1 NM_BENCH_STEPS=2 timeout 600 python tools/nonmetric_bench.py 1000 2>&1 | tail -1) > $O/nonmetric_100k.jsonl
 timeout 900 python tools/fit_bench.py c2 c5 2>&1 | grep "^{" > $O/fit_bench.jsonl
 timeout 300 python tools/api_phase_times.py 2>&1 | grep "^{" > $O/api_phase_times.jsonl
 cd /tmp && export TMPDIR=/tmp
