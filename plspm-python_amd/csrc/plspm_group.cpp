@@ -106,6 +106,8 @@ struct plspm_group {
     int next_slot = 0, last_slot = -1;
     bool pending[2] = {false, false};
     int64_t last_B = 0, last_cap = 0;
+    int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
+    int peers_rc = 0;
     std::string error;
 };
 
@@ -288,7 +290,7 @@ plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models)
         for (int s = 0; s < 2; ++s)
             if (hipEventCreateWithFlags(&l.computed[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.gathered[s], hipEventDisableTiming) != hipSuccess)
                 return bail("event creation failed");
-        if (plspm_dmalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || plspm_hmalloc((void**)&l.h_word, 64) != hipSuccess)
+        if (plspm_dmalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || plspm_hmalloc((void**)&l.h_word, 64 + 8 * (size_t)std::max(8, c->nranks)) != hipSuccess)
             return bail("scratch allocation failed");
     }
     c->bound = g;
@@ -409,7 +411,34 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         if (first_bad >= 0) return gfail(g, shard_rc[first_bad], "shard of rank " + std::to_string(g->first_rank + first_bad) + ": " + g->loc[first_bad].m->error);
         return gfail(g, crc, cwhy);
     }
-    g->pending[s] = true; g->last_slot = s; g->next_slot = s ^ 1; g->last_B = B; g->last_cap = cap;
+    g->pending[s] = true; g->last_slot = s; g->next_slot = s ^ 1; g->last_B = B; g->last_cap = cap; g->peers_checked = -1;
+    return 0;
+}
+
+
+// A rank whose shard failed still joins the all-gather (its records are NaN-status filler, so the other ranks never wait for it) and reports
+// the error from ITS plspm_group_bootstrap.  The other ranks learn of it here, before any result leaves the group: the status word of the
+// first record of every rank's shard is read back once per bootstrap; NaN where replicates were due = that rank had nothing to contribute.
+// Called with local handle 0's device current, by everything that hands out records or statistics of the last bootstrap.
+static int check_peer_shards(plspm_group* g) {
+    const int s = g->last_slot;
+    if (g->peers_checked == s) return g->peers_rc ? gfail(g, g->peers_rc, g->error) : 0;
+    Local& l = g->loc[0];
+    const int RS = plspm_row_stride(l.m);
+    double* h = l.h_word + 8;
+    GHIP(g, hipStreamWaitEvent(l.cstream, l.gathered[s], 0));
+    GHIP(g, hipMemcpy2DAsync(h, sizeof(double), (const double*)l.recv[s].p + (RS - 2), (size_t)g->last_cap * RS * sizeof(double), sizeof(double), (size_t)g->nranks,
+                             hipMemcpyDeviceToHost, l.cstream));
+    GHIP(g, hipStreamSynchronize(l.cstream));
+    g->peers_checked = s; g->peers_rc = 0;
+    for (int r = 0; r < g->nranks; ++r) {
+        int64_t first = 0, count = 0;
+        shard_of(g->last_B, g->nranks, r, &first, &count);
+        if (count > 0 && h[r] != h[r]) {
+            g->peers_rc = PLSPM_E_STATE;
+            return gfail(g, PLSPM_E_STATE, "the shard of rank " + std::to_string(r) + " failed on its rank (no replicates arrived from it): the bootstrap has no complete result");
+        }
+    }
     return 0;
 }
 
@@ -419,6 +448,7 @@ int plspm_group_records(plspm_group_t* g, int32_t local, void** d_records, int64
     Local& l = g->loc[local];
     GHIP(g, hipSetDevice(l.m->device));
     GHIP(g, hipEventSynchronize(l.gathered[g->last_slot]));
+    { int prc; GHIP(g, hipSetDevice(g->loc[0].m->device)); if ((prc = check_peer_shards(g))) return prc; GHIP(g, hipSetDevice(l.m->device)); }
     if (d_records) *d_records = l.recv[g->last_slot].p;
     if (n_records) *n_records = g->last_cap * g->nranks;
     if (stride) *stride = plspm_row_stride(l.m);
@@ -431,7 +461,9 @@ int plspm_group_summary(plspm_group_t* g, const double* original, double* summar
     Local& l = g->loc[0];
     GHIP(g, hipSetDevice(l.m->device));
     GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
-    int rc = plspm_detail_summary(l.m, (const double*)l.recv[g->last_slot].p, g->last_cap * g->nranks, plspm_row_stride(l.m), original, summary, n_used);
+    int rc = check_peer_shards(g);
+    if (rc) return rc;
+    rc = plspm_detail_summary(l.m, (const double*)l.recv[g->last_slot].p, g->last_cap * g->nranks, plspm_row_stride(l.m), original, summary, n_used);
     if (rc) return gfail(g, rc, l.m->error);
     return 0;
 }
@@ -443,6 +475,7 @@ int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* it
     const int RS = plspm_row_stride(l.m), R = RS - 2;
     GHIP(g, hipSetDevice(l.m->device));
     GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
+    { int prc = check_peer_shards(g); if (prc) return prc; }
     const double* rec = (const double*)l.recv[g->last_slot].p;
     for (int r = 0; r < g->nranks; ++r) {
         int64_t first = 0, count = 0;
@@ -465,7 +498,9 @@ int plspm_group_adopt(plspm_group_t* g) {
     const int RS = plspm_row_stride(m);
     GHIP(g, hipSetDevice(m->device));
     m->rows_B = 0;
-    int rc = ensure(m, m->rows, (size_t)g->last_B * RS * sizeof(double));
+    int rc = check_peer_shards(g);
+    if (rc) return rc;
+    rc = ensure(m, m->rows, (size_t)g->last_B * RS * sizeof(double));
     if (rc) return gfail(g, rc, m->error);
     GHIP(g, hipStreamWaitEvent(m->stream, l.gathered[g->last_slot], 0));
     const double* rec = (const double*)l.recv[g->last_slot].p;

@@ -40,6 +40,7 @@ __host__ __device__ __forceinline__ long lmin(long a, long b) { return a < b ? a
 #include "kernels_input.h"
 #include "kernels_gram.h"
 #include "kernels_gram_i8.h"
+#include "kernels_gram_i8p.h"
 #include "kernels_solver.h"
 #include "kernels_nonmetric.h"
 #include "kernels_post.h"
@@ -768,6 +769,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
+    else if (k == "i8_priv") { if (value < 0 || value > 6) return bad(); m->tune.i8_priv = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 899) return bad(); m->tune.i8_variant = value; }
     else if (k == "i8_dma") { if (value < 0 || value > 2) return bad(); m->tune.i8_dma = value; }
@@ -812,6 +814,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "last_solver") *value = m->last_solver;
     else if (k == "resample_aux") *value = m->tune.resample_aux;
     else if (k == "i8_sched") *value = m->tune.i8_sched;
+    else if (k == "i8_priv") *value = m->tune.i8_priv;
+    else if (k == "last_i8_priv") *value = m->last_i8_priv;
     else if (k == "i8_shape") *value = m->tune.i8_shape;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else return PLSPM_E_ARG;
@@ -965,7 +969,8 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
     NMXCHK(hipStreamSynchronize(m->stream));
 #undef NMXCHK
     plspm_dfree(d_mask);
-    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false;
+    // the rows of Xa were rewritten: everything derived from them is stale (a caller may have run plspm_bootstrap_prepare before this call)
+    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false; m->zs_valid = false; m->codes_valid = false; m->dcnt_ready = false;
     return 0;
 }
 
@@ -1218,7 +1223,7 @@ static int prepare_zs(plspm_model* m) {
 // tall tile, 16.6 per short one (the same DMA ring for 4/5 of the MFMAs), 16.35 per tile of the 256-replicate kernel (measured on 960 tiles
 // of each kind, tools/i8_mix_calib.py: 0.391 / 0.3245 / 0.3195 ms).  Deterministic in (ct, ntx, cus): every rank of a job cuts alike -- and the sums are exact
 // integers, so the cut never shows in a result.
-static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* shrt) {
+static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* shrt, bool priv = false) {
     const int per_xcd = std::max(1, cus / 8);
     // (tiles of one kind are interchangeable: after the tall ones the CUs of an XCD sit on at most two load levels, and the short ones raise
     //  the lowest level a whole group of CUs at a time -- a handful of steps per XCD instead of one per tile)
@@ -1286,30 +1291,42 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
 #else
     const bool var20 = m->tune.i8_variant < 0;
 #endif
-    bool wide20 = m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && var20 && S == 6 && !m->zs_ind && (m->tune.i8_rt == 20 || m->tune.i8_rt == 0);
+    // private count fragments (kernels_gram_i8p.h, "i8_priv"): four waves, the counts straight into registers, only the digit blocks through LDS;
+    // six planes: tile rows of 320 (tall) / 256 (short) replicates, seven planes: 256 / 192
+#ifdef PLSPM_I8_EXPERIMENTS
+    const bool priv_var = m->tune.i8_variant < 16;                          // ablation probes of the kernel (tools/i8p_bench.py)
+#else
+    const bool priv_var = m->tune.i8_variant < 0;
+#endif
+    const bool priv = m->tune.i8_priv != 0 && m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && priv_var && (S == 6 || S == 7) && !m->zs_ind;
+    bool wide20 = !priv && m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && var20 && S == 6 && !m->zs_ind && (m->tune.i8_rt == 20 || m->tune.i8_rt == 0);
+    const int RTtall = priv ? (S == 6 ? 20 : 16) : 20, RTshort = RTtall - 4;
     // "i8_rt" 0: the cut of the replicates into tile rows is planned (i8_mix_plan below): rows of 320 and -- eight-wave kernel -- rows of 256
     // in ONE launch, so that the last round of the machine is as full as the others (5,000 replicates x 60 pair tiles: 11 + 6 rows = 1,020
     // tiles, every CU three tall + one short = 76 count-tile rows, against 16 rows of 320 = 960 tiles, 80 on three CUs of four)
     int nty_tall = 0, nty_short = 0;
-    if (wide20 && m->tune.i8_rt == 0) {
+    if ((wide20 || (priv && RTtall == 20)) && m->tune.i8_rt == 0 && m->tune.i8_short < 0) {
         if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
         // (the plan of the last shape is kept: a bootstrap calls with the same B again and again, and the search costs of the order of a millisecond)
-        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count), (long)(m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2)};
+        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count),
+                             priv ? 2L : (long)(m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2)};
         if (!(m->mix_valid && std::equal(key, key + 4, m->mix_key))) {
-            m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], key[3] != 0, &m->mix_tall, &m->mix_short);
+            m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], key[3] != 0, &m->mix_tall, &m->mix_short, priv);
             std::copy(key, key + 4, m->mix_key); m->mix_valid = true;
         }
-        wide20 = m->mix_wide; nty_tall = m->mix_tall; nty_short = m->mix_short;
-    } else if (wide20) {
-        // "i8_rt" 20: tall rows only, or -- "i8_short_rows" n >= 0, eight waves (test seam) -- n short rows behind as many tall ones as it takes
+        if (!priv) wide20 = m->mix_wide;
+        nty_tall = m->mix_tall; nty_short = m->mix_short;
+    } else if (wide20 || priv) {
+        // tall rows only, or -- "i8_short_rows" n >= 0 (test seam) -- n short rows behind as many tall ones as it takes
         const long ct = (nb + 15) / 16;
-        if (m->tune.i8_short > 0 && m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2) nty_short = (int)std::min<long>(m->tune.i8_short, (ct + 15) / 16);
-        nty_tall = (int)std::max(0L, (ct - 16L * nty_short + 19) / 20);
+        if (m->tune.i8_short > 0 && (priv || (m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2))) nty_short = (int)std::min<long>(m->tune.i8_short, (ct + RTshort - 1) / RTshort);
+        nty_tall = (int)std::max(0L, (ct - (long)RTshort * nty_short + RTtall - 1) / RTtall);
     }
-    const bool narrow = wide20 || (m->tune.i8_rt == 8 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7);
-    const int RTg = wide20 ? 20 : narrow ? 8 : 16;
+    const bool rows2 = wide20 || priv;                 // launches whose grid holds tile rows of two heights
+    const bool narrow = wide20 || (!priv && m->tune.i8_rt == 8 && m->tune.i8_shape == 16 && m->tune.i8_waves == 4 && m->tune.i8_sched == 0 && m->tune.i8_variant < 0 && S == 7);
+    const int RTg = rows2 ? RTtall : narrow ? 8 : 16;
     const bool ind = m->zs_ind && m->tune.i8_sched == 0 && m->tune.i8_variant < 0;
-    const int nty = wide20 ? nty_tall + nty_short : (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = wide20 ? nty_tall * 20 + nty_short * 16 : nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
+    const int nty = rows2 ? nty_tall + nty_short : (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = rows2 ? nty_tall * RTtall + nty_short * RTshort : nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
     // resample counts from an LDS histogram per (replicate, window of rows): 65,536 rows of 16-bit counters, or -- Philox draws of a data
     // set that would need more than one such window -- 131,072 rows of 8-bit counters (kernels_gram_i8.h resample_i8_kernel)
     const bool hist_byte = KB > I8_HIST_KB && !d_idx;
@@ -1367,7 +1384,7 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         }
     }
     if (counts && m->tune.i8_shape == 16) { *counts = cd.p; *counts_MT = MT; }       // (16-row pieces: what nm_conv_dense_kernel<.., CNT8> reads)
-    const int total = ntx * nty, per = wide20 ? (ntx * nty_tall + 7) / 8 + (ntx * nty_short + 7) / 8 : (total + 7) / 8;      // workgroups per XCD
+    const int total = ntx * nty, per = rows2 ? (ntx * nty_tall + 7) / 8 + (ntx * nty_short + 7) / 8 : (total + 7) / 8;      // workgroups per XCD
     // packed: the tile-packed slots the LDS solver / impute kernel read; dense: [(Pg+1) x cov_ld(Pg)] row-major, upper triangle (rows solver)
     const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
     // (a mirrored second store per element cost 0.08 ms per 5,000 replicates of the metric benchmark: the rows solver reads the triangle
@@ -1391,10 +1408,11 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     }
     // the buffer form of the LDS-DMA needs every byte offset of a workgroup's walk (incl. the slack k-blocks) below 4 GiB
     const bool dma_fits = (uint64_t)(KB + I8_SLACK_KB) * (uint64_t)std::max(MT, NT) * 1024ull < (1ull << 32);
-    const bool dma_buffer = m->tune.i8_dma != 1 && dma_fits && m->tune.i8_shape == 16 && !sk && (!narrow || (wide20 && m->tune.i8_waves == 4)) && m->tune.i8_variant < 0;
+    const bool dma_buffer = !priv && m->tune.i8_dma != 1 && dma_fits && m->tune.i8_shape == 16 && !sk && (!narrow || (wide20 && m->tune.i8_waves == 4)) && m->tune.i8_variant < 0;
     m->last_i8_dma = dma_buffer ? 2 : 1;
     m->last_i8_rt = RTg;
-    m->last_i8_short = wide20 ? nty_short : 0;
+    m->last_i8_short = rows2 ? nty_short : 0;
+    m->last_i8_priv = priv ? 1 : 0;
     m->last_i8_mt = MT;
     ProfScope ps(m, PLSPM_K_GRAM);
 #define GI8SK(SS, WW)                                                                                                                        \
@@ -1405,6 +1423,27 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, \
                            (i32x4*)m->sk_partial.p, (unsigned*)m->sk_flags.p, ++m->sk_epoch, (int*)m->err.p);                                \
     }
+#define GI8P(SS, MM, VV)                                                                                                                     \
+    {                                                                                                                                        \
+        const size_t lds_bytes = GramI8P<SS, MM, VV>::LDS_BYTES;                                                                             \
+        auto kfn = nty_short ? gram_i8p_kernel<SS, MM, VV, true> : gram_i8p_kernel<SS, MM, VV, false>;                                       \
+        if ((rc = allow_lds(m, (const void*)kfn, lds_bytes))) return rc;                                                                     \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p,                               \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, nty_short); \
+    }
+    if (priv) {                  // "i8_priv" 1: digit blocks by LDS-DMA, 2: through staging registers, 3: LDS-DMA on the evenly spaced schedule
+        const int pvar = m->tune.i8_priv == 2 ? 16 : m->tune.i8_priv == 3 ? 32 : m->tune.i8_priv == 4 ? 64 : m->tune.i8_priv == 5 ? 64 + 128 : m->tune.i8_priv == 6 ? 128 : 0;
+#define GI8PX(VV) case VV: if (S == 6) GI8P(6, 5, VV) else GI8P(7, 4, VV) break;
+#ifdef PLSPM_I8_EXPERIMENTS
+        switch (std::max(0, m->tune.i8_variant) | pvar) {
+            GI8PX(0) GI8PX(1) GI8PX(2) GI8PX(4) GI8PX(8) GI8PX(5) GI8PX(13) GI8PX(15) GI8PX(16) GI8PX(17) GI8PX(18) GI8PX(20) GI8PX(24) GI8PX(21) GI8PX(29) GI8PX(31)
+            GI8PX(32) GI8PX(33) GI8PX(34) GI8PX(36) GI8PX(40) GI8PX(37) GI8PX(45) GI8PX(47)
+            GI8PX(64) GI8PX(65) GI8PX(66) GI8PX(68) GI8PX(72) GI8PX(69) GI8PX(77) GI8PX(79) GI8PX(192) GI8PX(128)
+            default: return fail(m, PLSPM_E_ARG, "i8_variant: not an ablation of the private-count kernel"); }
+#else
+        switch (pvar) { GI8PX(0) GI8PX(16) GI8PX(32) GI8PX(64) GI8PX(192) GI8PX(128) }
+#endif
+    } else
     if (sk) {
         if (m->tune.i8_waves == 4) { switch (S) { case 5: GI8SK(5, 2) break; case 6: GI8SK(6, 2) break; default: GI8SK(7, 2) break; } }
         else { switch (S) { case 5: GI8SK(5, 4) break; case 6: GI8SK(6, 4) break; default: GI8SK(7, 4) break; } }
