@@ -769,7 +769,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); m->tune.i8_sched = value; }
-    else if (k == "i8_priv") { if (value < 0 || value > 6) return bad(); m->tune.i8_priv = value; }
+    else if (k == "i8_priv") { if (value < 0 || value > 1) return bad(); m->tune.i8_priv = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 899) return bad(); m->tune.i8_variant = value; }
     else if (k == "i8_dma") { if (value < 0 || value > 2) return bad(); m->tune.i8_dma = value; }
@@ -1223,7 +1223,11 @@ static int prepare_zs(plspm_model* m) {
 // tall tile, 16.6 per short one (the same DMA ring for 4/5 of the MFMAs), 16.35 per tile of the 256-replicate kernel (measured on 960 tiles
 // of each kind, tools/i8_mix_calib.py: 0.391 / 0.3245 / 0.3195 ms).  Deterministic in (ct, ntx, cus): every rank of a job cuts alike -- and the sums are exact
 // integers, so the cut never shows in a result.
-static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* shrt, bool priv = false) {
+// (profiles/r04_i8_mix_calib.jsonl: 960 tiles of each height, 0.3628 / 0.2990 ms with six planes, 0.3435 / 0.2700 with seven)
+static constexpr double kI8pTall6 = 20.0, kI8pShort6 = 16.5, kI8pTall7 = 16.0, kI8pShort7 = 12.6;
+// Tile heights and their costs: `rt_tall` / `rt_short` count tiles per row, `ca` / `cb` what a tile of each costs (any common unit).  The
+// round-3 kernel: 20 / 16 at 20 / 16.6; gram_i8p_kernel: i8p_costs() below.
+static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* shrt, int rt_tall = 20, int rt_short = 16, double ca = 20.0, double cb = 16.6, bool vs_rt16 = true) {
     const int per_xcd = std::max(1, cus / 8);
     // (tiles of one kind are interchangeable: after the tall ones the CUs of an XCD sit on at most two load levels, and the short ones raise
     //  the lowest level a whole group of CUs at a time -- a handful of steps per XCD instead of one per tile)
@@ -1258,14 +1262,14 @@ static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* sh
         }
         return worst;
     };
-    const long rows16 = (ct + 15) / 16;
-    const double ref16 = makespan(rows16, 0, 16.35, 0.0);
+    const long rows16 = (ct + 15) / 16, rows_s = (ct + rt_short - 1) / rt_short;
+    const double ref16 = vs_rt16 ? makespan(rows16, 0, 16.35, 0.0) : 1e300;
     double best = 1e300;
     long ba = 0, bb = 0;
-    for (long b = 0; b <= (mix ? std::min(rows16, 48L) : 0L); ++b) {
-        const long a = std::max(0L, (ct - 16 * b + 19) / 20);
-        if (a == 0 && b * 16 < ct) continue;
-        const double t = makespan(a, b, 20.0, 16.6);
+    for (long b = 0; b <= (mix ? std::min(rows_s, 48L) : 0L); ++b) {
+        const long a = std::max(0L, (ct - (long)rt_short * b + rt_tall - 1) / rt_tall);
+        if (a == 0 && b * rt_short < ct) continue;
+        const double t = makespan(a, b, ca, cb);
         if (t < best - 1e-9) { best = t; ba = a; bb = b; }
         if (a == 0) break;
     }
@@ -1294,24 +1298,27 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
     // private count fragments (kernels_gram_i8p.h, "i8_priv"): four waves, the counts straight into registers, only the digit blocks through LDS;
     // six planes: tile rows of 320 (tall) / 256 (short) replicates, seven planes: 256 / 192
 #ifdef PLSPM_I8_EXPERIMENTS
-    const bool priv_var = m->tune.i8_variant < 16;                          // ablation probes of the kernel (tools/i8p_bench.py)
+    const bool priv_var = true;                                             // schedule variants / ablation probes of the kernel (tools/i8p_bench.py)
 #else
     const bool priv_var = m->tune.i8_variant < 0;
 #endif
-    const bool priv = m->tune.i8_priv != 0 && m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && priv_var && (S == 6 || S == 7) && !m->zs_ind;
+    const bool priv = m->tune.i8_priv != 0 && m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && priv_var && (S == 6 || S == 7) && !m->zs_ind &&
+                      (m->tune.i8_rt == 0 || m->tune.i8_rt == (S == 6 ? 20 : 16));      // (an explicit other tile height names a round-3 kernel)
     bool wide20 = !priv && m->tune.i8_shape == 16 && m->tune.i8_sched == 0 && var20 && S == 6 && !m->zs_ind && (m->tune.i8_rt == 20 || m->tune.i8_rt == 0);
     const int RTtall = priv ? (S == 6 ? 20 : 16) : 20, RTshort = RTtall - 4;
     // "i8_rt" 0: the cut of the replicates into tile rows is planned (i8_mix_plan below): rows of 320 and -- eight-wave kernel -- rows of 256
     // in ONE launch, so that the last round of the machine is as full as the others (5,000 replicates x 60 pair tiles: 11 + 6 rows = 1,020
     // tiles, every CU three tall + one short = 76 count-tile rows, against 16 rows of 320 = 960 tiles, 80 on three CUs of four)
     int nty_tall = 0, nty_short = 0;
-    if ((wide20 || (priv && RTtall == 20)) && m->tune.i8_rt == 0 && m->tune.i8_short < 0) {
+    if ((wide20 || priv) && m->tune.i8_rt == 0 && m->tune.i8_short < 0) {
         if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
         // (the plan of the last shape is kept: a bootstrap calls with the same B again and again, and the search costs of the order of a millisecond)
         const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count),
-                             priv ? 2L : (long)(m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2)};
+                             priv ? 2L + S : (long)(m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2)};
         if (!(m->mix_valid && std::equal(key, key + 4, m->mix_key))) {
-            m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], key[3] != 0, &m->mix_tall, &m->mix_short, priv);
+            // (tile costs of gram_i8p_kernel, tools/i8_mix_calib.py on 960 tiles of each height: six planes 320 / 256 replicates, seven planes 256 / 192)
+            if (priv) m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], true, &m->mix_tall, &m->mix_short, RTtall, RTshort, S == 6 ? kI8pTall6 : kI8pTall7, S == 6 ? kI8pShort6 : kI8pShort7, false);
+            else m->mix_wide = i8_mix_plan(key[0], key[1], (int)key[2], key[3] != 0, &m->mix_tall, &m->mix_short);
             std::copy(key, key + 4, m->mix_key); m->mix_valid = true;
         }
         if (!priv) wide20 = m->mix_wide;
@@ -1431,17 +1438,17 @@ static int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, 
         hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p,                               \
                            (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, nty_short); \
     }
-    if (priv) {                  // "i8_priv" 1: digit blocks by LDS-DMA, 2: through staging registers, 3: LDS-DMA on the evenly spaced schedule
-        const int pvar = m->tune.i8_priv == 2 ? 16 : m->tune.i8_priv == 3 ? 32 : m->tune.i8_priv == 4 ? 64 : m->tune.i8_priv == 5 ? 64 + 128 : m->tune.i8_priv == 6 ? 128 : 0;
+    if (priv) {
 #define GI8PX(VV) case VV: if (S == 6) GI8P(6, 5, VV) else GI8P(7, 4, VV) break;
 #ifdef PLSPM_I8_EXPERIMENTS
-        switch (std::max(0, m->tune.i8_variant) | pvar) {
-            GI8PX(0) GI8PX(1) GI8PX(2) GI8PX(4) GI8PX(8) GI8PX(5) GI8PX(13) GI8PX(15) GI8PX(16) GI8PX(17) GI8PX(18) GI8PX(20) GI8PX(24) GI8PX(21) GI8PX(29) GI8PX(31)
-            GI8PX(32) GI8PX(33) GI8PX(34) GI8PX(36) GI8PX(40) GI8PX(37) GI8PX(45) GI8PX(47)
-            GI8PX(64) GI8PX(65) GI8PX(66) GI8PX(68) GI8PX(72) GI8PX(69) GI8PX(77) GI8PX(79) GI8PX(192) GI8PX(128)
-            default: return fail(m, PLSPM_E_ARG, "i8_variant: not an ablation of the private-count kernel"); }
+        // "i8_variant" v >= 0: the template's VAR itself -- bits 0-3 ablations, bit 4 digit blocks through staging registers, bits 5-6 the filler
+        // schedule (0 strides / 1 one per gap, DMAs last / 2 VMEM evenly spaced = the release kernel), bit 7 one barrier per two k-steps
+        switch (m->tune.i8_variant < 0 ? 64 : m->tune.i8_variant) {
+            GI8PX(0) GI8PX(1) GI8PX(2) GI8PX(4) GI8PX(8) GI8PX(15) GI8PX(16) GI8PX(32) GI8PX(128) GI8PX(192)
+            GI8PX(64) GI8PX(65) GI8PX(66) GI8PX(68) GI8PX(72) GI8PX(69) GI8PX(77) GI8PX(79)
+            default: return fail(m, PLSPM_E_ARG, "i8_variant: not a built variant of the private-count kernel"); }
 #else
-        switch (pvar) { GI8PX(0) GI8PX(16) GI8PX(32) GI8PX(64) GI8PX(192) GI8PX(128) }
+        switch (64) { GI8PX(64) }
 #endif
     } else
     if (sk) {

@@ -347,7 +347,7 @@ def test_buffer_form_of_the_lds_dma_gives_identical_matrices(waves):
     model = orc.Model(blocks, C, "ABABABA", "factorial", True)
     nm = native_model(model)
     nm.upload(X)
-    nm.set_option("i8_waves", waves)
+    nm.set_option("i8_waves", waves); nm.set_option("i8_priv", 0)        # (the round-3 kernel: gram_i8p_kernel has one DMA form)
     for B in (1, 300, 2100):
         rows_b = nm.bootstrap(B, seed=7)
         assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_dma") == 2
@@ -446,6 +446,13 @@ def test_every_plane_count_wave_count_and_dma_form_on_exactly_representable_data
     nm.set_option("gram_path", 1)
     M64 = nm.bootstrap_moments(1100, seed=2)
     nm.set_option("gram_path", 2)
+    for S in (6, 7):                 # the private-count kernel (default for six / seven planes), the automatic cut and a forced one
+        for short in (-1, 2):
+            nm.set_option("i8_slices", S); nm.set_option("i8_short_rows", short)
+            M = nm.bootstrap_moments(1100, seed=2)
+            assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_priv") == 1 and (short < 0 or nm.get_option("last_i8_short") == short)
+            assert np.array_equal(M, M64), (S, "private counts", short)
+    nm.set_option("i8_short_rows", -1); nm.set_option("i8_priv", 0)
     seen = set()
     for S in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         for waves in (4, 8):
@@ -482,31 +489,41 @@ def test_tall_workgroup_tile_with_six_planes_gives_identical_matrices():
         M16 = nm.bootstrap_moments(B, seed=2)
         rows16 = nm.bootstrap(B, seed=2)
         assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_rt") == 16 and nm.get_option("last_i8_slices") == 6
+        nm.set_option("i8_priv", 0)                     # the round-3 kernel on the 320-replicate tile
         for waves in (4, 8):
             for dma in (1, 2):
                 nm.set_option("i8_rt", 20); nm.set_option("i8_waves", waves); nm.set_option("i8_dma", dma)
                 M20 = nm.bootstrap_moments(B, seed=2)
-                assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_dma") == (dma if waves == 4 else 1)
+                assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_dma") == (dma if waves == 4 else 1) and nm.get_option("last_i8_priv") == 0
                 assert np.array_equal(M20, M16), (B, waves, dma)
                 rows20 = nm.bootstrap(B, seed=2)
                 for a, b in zip(rows16, rows20):
                     assert np.array_equal(a, b)
-        # tile rows of both heights in one launch (eight-wave kernel; "i8_short_rows" forces n short rows of 256 replicates behind the
-        # tall ones -- the automatic cut of "i8_rt" 0 takes them when they fill the machine's last round better): same bits, whatever the cut
-        nm.set_option("i8_rt", 20); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
-        for n_short in (1, 2, 5):
-            nm.set_option("i8_short_rows", n_short)
-            Mx = nm.bootstrap_moments(B, seed=2)
-            assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_short") == min(n_short, (B + 255) // 256), (B, n_short)
-            assert np.array_equal(Mx, M16), (B, n_short)
-            rowsx = nm.bootstrap(B, seed=2)
-            for a, b in zip(rows16, rowsx):
-                assert np.array_equal(a, b)
-        nm.set_option("i8_short_rows", -1)
-    # seven planes keep the 256-replicate tile whatever is asked for
-    nm.set_option("i8_slices", 7); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
-    nm.bootstrap_device(1100, seed=2)
-    assert nm.get_option("last_i8_rt") == 16
+        # tile rows of both heights in one launch ("i8_short_rows" forces n short rows of 256 replicates behind the tall ones -- the
+        # automatic cut of "i8_rt" 0 takes them when they fill the machine's last round better): same bits, whatever the cut; the
+        # private-count kernel (round 4, the default) and the round-3 eight-wave kernel
+        for priv in (1, 0):
+            nm.set_option("i8_priv", priv); nm.set_option("i8_rt", 20); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0)
+            for n_short in (0, 1, 2, 5):
+                nm.set_option("i8_short_rows", n_short if n_short else -1)
+                Mx = nm.bootstrap_moments(B, seed=2)
+                assert nm.get_option("last_i8_rt") == 20 and nm.get_option("last_i8_short") == min(n_short, (B + 255) // 256), (B, n_short)
+                assert nm.get_option("last_i8_priv") == priv
+                assert np.array_equal(Mx, M16), (B, n_short, priv)
+                rowsx = nm.bootstrap(B, seed=2)
+                for a, b in zip(rows16, rowsx):
+                    assert np.array_equal(a, b)
+            nm.set_option("i8_short_rows", -1)
+    # seven planes: tile rows of 256 (tall) and 192 replicates on the private-count kernel, the 256-replicate tile on the round-3 one
+    nm.set_option("i8_slices", 7); nm.set_option("i8_waves", 8); nm.set_option("i8_dma", 0); nm.set_option("i8_rt", 0)
+    M7 = {}
+    for priv, short in ((0, -1), (1, -1), (1, 1), (1, 3)):
+        nm.set_option("i8_priv", priv); nm.set_option("i8_short_rows", short)
+        M7[(priv, short)] = nm.bootstrap_moments(1100, seed=2)
+        assert nm.get_option("last_i8_rt") == 16 and nm.get_option("last_i8_priv") == priv and nm.get_option("last_i8_slices") == 7
+        if short > 0: assert nm.get_option("last_i8_short") == short
+        assert np.array_equal(M7[(priv, short)], M7[(0, -1)]), (priv, short)
+    nm.set_option("i8_short_rows", -1); nm.set_option("i8_priv", 1)
     # automatic cut on the headline shape: 5,000 replicates x 60 pair tiles -> tall and short rows in one launch (e.g. 11 + 6 on 256 CUs:
     # three tall + one short tile per CU instead of 3.75 rounds of tall ones)
     Xh, bh = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
@@ -523,7 +540,7 @@ def test_tall_workgroup_tile_with_six_planes_gives_identical_matrices():
         assert np.array_equal(a, b)
     nh.set_option("i8_rt", 0)
     nh.bootstrap_device(64, seed=8)
-    assert nh.get_option("last_i8_rt") == 16                       # one tile row either way: the lower tile wins
+    assert nh.get_option("last_i8_priv") == 1 and nh.get_option("last_i8_short") == 1      # one tile row either way: the lower tile wins
 
 
 def test_random_tile_row_cuts_on_random_shapes():
