@@ -13,10 +13,12 @@ only spawns the ranks (RANK / LOCAL_RANK / WORLD_SIZE); without a launcher `--gp
 
 Extra objects on the line:
   roofline      dominant kernel, duration measured with HIP events on the library's own stream during the timed steps.  Default path:
-                gram_i8_kernel<7, 2, 3, 16> (7 digit planes, 4 waves per workgroup, 16x16x64 MFMA) -- the batch's moment matrices as ONE exact int8 MFMA product of the dense resample
-                multiplicities with the 7 base-256 digit planes of the pair products x_p x_q (csrc/kernels_gram_i8.h); its
-                algorithmic work is 2 N (P+1)(P+2)/2 7 int8 ops per replicate.  --gram-path 1: the fp64 MFMA Gram of round 1
-                (gram_rows_kernel<4,false>, SURVEY.md 8(d) flops).  `fp64_mfma_path` on the line = the same workload on that path.
+                gram_i8p_kernel<S, MTW, 64> (round 4: S digit planes -- 6 on this data, `digit_planes` -- four waves per workgroup, each
+                MTW count tiles x 32 pairs x S planes of 16x16x64 int8 MFMA accumulators, count fragments straight from global memory) --
+                the batch's moment matrices as ONE exact int8 MFMA product of the dense resample multiplicities with the S base-256 digit
+                planes of the pair products x_p x_q (csrc/kernels_gram_i8p.h); its algorithmic work is 2 N (P+1)(P+2)/2 S int8 ops per
+                replicate.  --gram-path 1: the fp64 MFMA Gram of round 1 (gram_rows_kernel<4,false>, SURVEY.md 8(d) flops).
+                `fp64_mfma_path` on the line = the same workload on that path; `round3_gram_kernel` = the same steps on the round-3 kernel.
   api_inclusive replicates/s a user of the drop-in API sees: wall of Plspm(data, config, Scheme.PATH, bootstrap=True,
                 bootstrap_iterations=5000) minus the wall of the same call without the bootstrap (N = 1 only)
   cpu_baseline  the NumPy oracle (oracle/plspm_oracle.py, a port of the reference arithmetic) timed on this box's
@@ -52,7 +54,7 @@ def synth_inputs():
 
 
 SPINUP_STEPS = 200      # untimed launches of the same step before the W warm-up steps (device clocks / power state; ~0.13 s)
-PROF_EVERY = 10         # HIP-event pairs around the kernels of every 10th timed step (every step when fewer than 20 are timed)
+PROF_EVERY = 4          # a HIP-event pair around the dominant kernel of every 4th timed step (every step when fewer than 8 are timed)
 
 
 def cpu_worker(args):
@@ -127,6 +129,32 @@ def live_traffic(kernel_prefix, gram_path):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
+
+
+def moment_errors_vs_80bit(auto_model, seven_model, f64_model, X, reps=3):
+    """Worst entry of the replicates' moment matrices against 80-bit (np.longdouble) sums over the same resampled rows, relative to
+    sqrt(M_pp M_qq): automatic plane count, seven planes, fp64 MFMA route -- on THIS run's data (explicit index lists, `reps` replicates)."""
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, N_OBS, size=(reps, N_OBS)).astype(np.int32)
+    f64_model.set_option("gram_path", 1)
+    shift = auto_model.fit(want_scores=False)["mean"]                       # the device's own column means (its mean-shifted columns are what is multiplied)
+    Xa = np.concatenate((X - shift[None, :], np.ones((N_OBS, 1))), axis=1).astype(np.longdouble)
+    refs = []
+    for b in range(reps):
+        c = np.bincount(idx[b], minlength=N_OBS).astype(np.longdouble)
+        refs.append((Xa * c[:, None]).T @ Xa)
+    out = {}
+    for name, mdl in (("automatic", auto_model), ("seven_planes", seven_model), ("fp64_mfma_route", f64_model)):
+        M = mdl.bootstrap_moments(reps, idx=idx)
+        worst = 0.0
+        for b in range(reps):
+            scale = np.sqrt(np.outer(np.diag(refs[b]), np.diag(refs[b])))
+            worst = max(worst, float(np.max(np.abs(M[b].astype(np.longdouble) - refs[b]) / scale)))
+        out[name] = worst
+        out[name + "_route"] = {"gram_path": mdl.get_option("last_gram_path"), "planes": mdl.get_option("last_i8_slices") if mdl.get_option("last_gram_path") == 2 else None}
+    out["definition"] = ("max over %d replicates (explicit index lists) and all 61 x 61 entries of |M - M_80bit| / sqrt(M_pp M_qq); M_80bit = the same "
+                         "mean-shifted fp64 columns multiplied and summed in np.longdouble" % reps)
+    return out
 
 
 def api_inclusive(X, reps, pairs=7):
@@ -280,9 +308,10 @@ def main():
     cold_elapsed = time.perf_counter() - cold_t0
     if group is not None:
         cold_elapsed = group.max(cold_elapsed)
-    # spin-up: the first ~30 steps after an idle period run 4-5 % slower (0.666 against 0.637 ms per step with 5 against 50 warm-up
-    # steps: clocks / power state), and W is the driver's choice -- so the device is brought to its working state with SPINUP_STEPS
-    # of the same launches before the W warm-up steps; nothing of it is reused by the timed steps (fresh replicate ids)
+    # spin-up: steps straight after an idle period run 10-16 % slower than steps in a stream (`cold` on the line against `value`: 0.55-0.59
+    # against 0.48-0.51 ms per step in the round-3 / round-4 driver runs: clocks / power state), and W is the driver's choice -- so the device
+    # is brought to its working state with SPINUP_STEPS of the same launches before the W warm-up steps; nothing of it is reused by the
+    # timed steps (fresh replicate ids)
     spin_t0, spin_steps = time.perf_counter(), SPINUP_STEPS          # (a fixed count: every rank of a job must make the same collective calls)
     for i in range(spin_steps):
         step()
@@ -297,8 +326,8 @@ def main():
     if profiled:
         model.profile(True)
         model.profile_reset()
-    # HIP events bracket every kernel of every PROF_EVERY-th step of the timed region (the event pairs around a step's three
-    # kernels cost ~0.15 ms of a 0.63 ms step: recorded on every step they would slow down the very thing they measure)
+    # HIP events bracket the dominant kernel of every PROF_EVERY-th step of the timed region (an event pair costs a few microseconds of
+    # stream time: on every step they would slow down the very thing they measure)
     prof_every = PROF_EVERY if args.steps >= 2 * PROF_EVERY else 1
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -387,7 +416,7 @@ def main():
                        "HIP events on the handle's stream over a calibration pass of the same launches without the overlapping collective")
         live = None
         if world == 1 and group is None and not launched and not args.no_traffic:
-            live = live_traffic("gram_i8_kernel" if used_path == 2 else "gram_rows_kernel", used_path)
+            live = live_traffic(("gram_i8p_kernel" if model.get_option("last_i8_priv") else "gram_i8_kernel") if used_path == 2 else "gram_rows_kernel", used_path)
         live_src = ("live: two child runs of this script (3 steps) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters "
                     "only), average over the kernel's full-size launches, FETCH_SIZE x 2 (gfx950)")
         if used_path == 2:
@@ -402,15 +431,19 @@ def main():
             # (replicate slots: the launch's tile rows -- 320-replicate and, cut by plspm_hip.hip i8_mix_plan, 256-replicate ones -- x their heights)
             rep_slots = 16 * model.get_option("last_i8_mt")
             executed = 2.0 * rep_slots * k_rows * (((npair + 31) // 32) * 32) * slices
-            roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
+            priv = model.get_option("last_i8_priv")
+            rt = model.get_option("last_i8_rt")
+            kname = ("gram_i8p_kernel<%d, %d, 64, %s>" % (slices, rt // 4, "true" if model.get_option("last_i8_short") else "false") if priv else
+                     "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if model.get_option("last_i8_dma") == 2 else 3, model.get_option("i8_shape"), rt))
+            roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                         "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4),
                         "frac_of_measured_ceiling": round(achieved / I8_MFMA_MEASURED_CEILING_TOPS, 4),
                         "measured_ceiling": {"value": I8_MFMA_MEASURED_CEILING_TOPS, "unit": "TOP/s",
                                              "source": "MI355X_MICROARCH.md matrix-core table (I8, 16x16x64 micro-benchmark); the nominal peak is 2 x the bf16 dense spec"},
                         "executed_ops": executed, "executed_over_algorithmic": round(executed / (ops_rep * reps_per_launch), 4),
-                        "tile_rows": {"workgroup_tile_replicates": 16 * model.get_option("last_i8_rt"), "short_rows_of_256": model.get_option("last_i8_short"), "replicate_slots": rep_slots},
+                        "tile_rows": {"workgroup_tile_replicates": 16 * rt, "short_rows": model.get_option("last_i8_short"), "short_row_replicates": 16 * (rt - 4), "replicate_slots": rep_slots},
                         "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if model.get_option("last_i8_dma") == 2 else 3, model.get_option("i8_shape"), model.get_option("last_i8_rt")), "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
+                        "kernel": kname, "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",
                         "algorithmic_ops_per_replicate": ops_rep,
                         "algorithmic_ops_derivation": "2 x N rows x %d pair columns x %d digit planes (SURVEY 8(d)'s N P (P+1) fp64 flops = %.4g per replicate, "
@@ -465,15 +498,38 @@ def main():
             r_auto = model.bootstrap(256, seed=1, rep_offset=0)[0]
             r_7 = alt7.bootstrap(256, seed=1, rep_offset=0)[0]
             dev = float(np.max(np.abs(r_auto - r_7) / np.maximum(np.abs(r_7), 1e-3)))
+            merr = moment_errors_vs_80bit(model, alt7, make_model(devices[0]), X)
             planes = {"S": int(slices), "min_sum_over_max": int(model.get_option("last_i8_ratio")),
                       "rule": "fewest planes whose worst-case error of a replicate's sum, N 2^-(8S-1) max|z|, stays below a quarter of the a-priori bound N 2^-53 sum|z| of an "
                               "fp64 accumulation of the same terms, in every pair column of the uploaded data (S = 6 needs sum|z| >= 256 max|z|; else 7)",
                       "seven_planes": {"value": round(B_total / dt7, 1), "unit": "replicates/s", "ms_per_step": round(dt7 * 1e3, 4),
                                        "gram_avg_launch_ms": round(g7_ms / max(g7_n, 1), 4),
                                        "note": "20 steps with set_option('i8_slices', 7): sums correctly rounded (>= 53 bits of every column maximum)"},
+                      "moment_error_vs_80bit": merr,
                       "max_rel_record_difference_vs_seven_planes": dev,
                       "note": "records of 256 replicates (same seed) on both plane counts, |a - b| / max(|b|, 1e-3); the parity bar is 1e-6 (BASELINE.json north_star), "
                               "the tests hold both against the oracle at 1e-8 and the moment matrices against 80-bit sums (tests/test_gpu_gram_i8.py)"}
+        round3 = None
+        if world == 1 and group is None and used_path == 2 and model.get_option("last_i8_priv"):
+            # the same steps on the round-3 Gram kernel (both operands through LDS), same box, same clocks regime: the A/B of round 4's kernel
+            alt3 = make_model(devices[0])
+            alt3.set_option("i8_priv", 0)
+            for k in range(100):
+                alt3.bootstrap_device(B_total, seed=1, rep_offset=k * B_total)
+            alt3.sync()
+            alt3.profile(True, only="gram"); alt3.profile_reset()
+            t1 = time.perf_counter()
+            for k in range(20):
+                alt3.bootstrap_device(B_total, seed=1, rep_offset=(3 + k) * B_total)
+            alt3.sync()
+            dt3 = (time.perf_counter() - t1) / 20
+            alt3.profile(False)
+            g3_ms, g3_n = alt3.profile_read("gram")
+            k3 = "gram_i8_kernel<%d, 4, 3, 16, %d, false>" % (alt3.get_option("last_i8_slices"), alt3.get_option("last_i8_rt"))
+            same = bool(np.array_equal(alt3.bootstrap(64, seed=1, rep_offset=0)[0], model.bootstrap(64, seed=1, rep_offset=0)[0]))
+            round3 = {"kernel": k3,
+                      "gram_avg_launch_ms": round(g3_ms / max(g3_n, 1), 4), "ms_per_step": round(dt3 * 1e3, 4), "records_bit_identical": same,
+                      "note": "20 steps with set_option('i8_priv', 0) behind 100 spin-up steps, every Gram launch between HIP events"}
         parallelism = ("one process, one GPU, no collective" if group is None else
                        "replicate-sharded x%d (%s), ONE ncclAllGather per step issued by libplspm_hip.so on a gather stream "
                        "(overlaps the next step's kernels; records double-buffered)" % (world, "one process per GPU" if launched else "one process, %d GPUs" % world))
@@ -487,8 +543,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "dtype_note": ("fp64 data, moments and solver; the batch Gram is evaluated as an exact int8 x int8 -> int32 product on %d base-256 digit "
                            "planes of the fp64 products (the integer sums are exact; the plane count is the fewest whose representation error stays "
-                           "below the rounding bound of an fp64 accumulation of the same terms -- `digit_planes`): results agree with the fp64 MFMA path to "
-                           "1e-10 and sit closer to the exactly rounded sums than it does (tests/test_gpu_gram_i8.py)" % slices) if used_path == 2 else "fp64 throughout",
+                           "below a quarter of the a-priori rounding bound of an fp64 accumulation of the same terms -- `digit_planes`).  Measured on this "
+                           "data against 80-bit sums (`digit_planes.moment_error_vs_80bit`): seven planes sit below the fp64 MFMA route's error, the "
+                           "automatic %d planes within a small multiple of it -- all nine orders below the 1e-6 the records are held to; the seven-plane "
+                           "rate is on the line beside `value`" % (slices, slices)) if used_path == 2 else "fp64 throughout",
             "config": {"workload": "synthetic 10,000 obs x 60 MVs x 6 LVs, Mode A, Scheme.PATH, scaled, %d bootstrap replicates per GPU "
                                    "(BASELINE.json configs[2]; %d GPUs x %d = configs[3] at 8); on-device Philox resampling, a fresh replicate-id "
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
@@ -504,6 +562,8 @@ def main():
         }
         if planes is not None:
             line["digit_planes"] = planes
+        if round3 is not None:
+            line["round3_gram_kernel"] = round3
         if other is not None:
             line["fp64_mfma_path"] = other
         if pcie is not None:
@@ -515,6 +575,25 @@ def main():
             line["api_inclusive"]["frac_of_cold_value"] = round(line["api_inclusive"]["value"] / line["cold"]["value"], 3)      # (an API call starts on an idle device, as `cold` does)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            # the real reference cannot travel to this box: its rate measured in the build container, and the factor between the oracle and
+            # the reference measured there back to back (oracle/time_calibration.py -> profiles/r04_cpu_calibration.json), convert this
+            # box's oracle figure into reference-equivalent replicates/s
+            try:
+                cal = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_calibration.json")))
+                ref8 = [r for r in cal["reference"]["runs"] if r["processes"] == 8][0]
+                ref1 = [r for r in cal["reference"]["runs"] if r["processes"] == 1][0]
+                ratio = cal["oracle_over_reference"]["all_cores"]
+                line["cpu_baseline"]["reference"] = {
+                    "replicates_per_s_8_processes": ref8["replicates_per_s"], "replicates_per_s_1_process": ref1["replicates_per_s"],
+                    "host": "%s, %d cpus (build container)" % (cal["host"]["model"], cal["host"]["cpus"]),
+                    "oracle_on_that_host": {"all_cores": cal["oracle"]["pool"]["value"], "single_process": cal["oracle"]["single_process_replicates_per_s"]},
+                    "oracle_over_reference": ratio,
+                    "reference_equivalent_on_this_box": round(line["cpu_baseline"]["value"] / ratio, 2),
+                    "gpu_over_reference_equivalent": round(line["value"] / (line["cpu_baseline"]["value"] / ratio), 0),
+                    "source": "profiles/r04_cpu_calibration.json (oracle/time_calibration.py: plspm 0.5.6 through its public API and the oracle "
+                              "pool of this bench, back to back on the same cores)"}
+            except Exception:
+                pass
         print(json.dumps(line), flush=True)
     if group is not None:
         group.barrier()

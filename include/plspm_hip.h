@@ -376,6 +376,10 @@ int plspm_group_adopt(plspm_group_t* g);
  * wait; max = all-reduce(max) of one double over the ranks. */
 int plspm_group_barrier(plspm_group_t* g);
 int plspm_group_max(plspm_group_t* g, double* value);
+/* Host time of the last plspm_group_bootstrap call on this process, in milliseconds: enqueue of the shard kernels of all local handles
+ * (resident threads, one per handle) and enqueue of the exchange (event waits + ONE ncclAllGather per handle inside a group call, or the
+ * device copies of ranks that share a GPU).  Diagnostics for tools/group_enqueue.py. */
+int plspm_group_enqueue_times(const plspm_group_t* g, double* shards_ms, double* exchange_ms);
 
 /*
  * ---- Operator seam ------------------------------------------------------------------------------------------------------------

@@ -7,10 +7,14 @@
 // cut into S balanced base-256 digits relative to the largest |z| of its column,
 //     z_i 2^k = sum_s d_is 256^s,   d_is in [-128, 127],   k = 8S - 1 - exponent(max_i |z_i|)   (one less when the maximum fills its binade),
 // every digit plane is int8 too, and  sum_i c_bi d_is  is an exact int32 dot product (|.| <= 128 N, N <= 2^24).  The fp64 matrix
-// pipe of MI355X peaks at 78.6 TFLOP/s, the int8 one at ~5,000 TOP/s: S = 7 digit planes (>= 53 significant bits of the column
-// maximum; the sum itself is exact, only the final int -> fp64 conversion rounds) cost 7 int8 MACs per fp64 MAC and still run several
-// times faster than v_mfma_f64.  The result is MORE accurate than the fp64 accumulation chain (which rounds after every one of
-// its ~6,300 additions); tools/experiments/slice_poc.py and tests/test_gpu_gram_i8.py compare both with exact rational sums.
+// pipe of MI355X peaks at 78.6 TFLOP/s, the int8 one at ~5,000 TOP/s: S digit planes cost S int8 MACs per fp64 MAC and still run several
+// times faster than v_mfma_f64.  Accuracy (measured against 80-bit sums, worst entry relative to sqrt(M_pp M_qq) on the 10k x 60 benchmark
+// data; bench.py prints the three figures of its own run as digit_planes.moment_error_vs_80bit): S = 7 (>= 53 significant bits of the
+// column maximum; the sum itself is exact, only the final int -> fp64 conversion rounds) 1e-16 -- below the fp64 MFMA accumulation chain's
+// 1.6e-15, which rounds after every one of its ~6,300 additions; S = 6, the automatic choice where every column satisfies
+// sum|z| >= 256 max|z| (plspm_hip.hip choose_slices), 3e-15 -- about twice the fp64 chain's figure, inside the a-priori bound of an fp64
+// accumulation of the same terms, nine orders below the 1e-6 the records are held to.  tools/experiments/slice_poc.py and
+// tests/test_gpu_gram_i8.py compare all three with exact rational / extended-precision sums.
 // This is the error-free-transformation (Ozaki-style) scheme with the simplification that one operand needs no splitting.
 //
 // Layout ("fragment-major", both operands).  v_mfma_i32_16x16x64_i8 takes, per lane l, 16 consecutive k of row (l & 15) for A and

@@ -106,6 +106,11 @@ struct plspm_model {
     bool cdfree_set[2] = {false, false};
     int cd_slot = 0;
     bool zs_valid = false;
+    bool zs_stats_ready = false;  // phase 1 of the digit planes is enqueued (pair tables, column statistics on their way to h_zstat): plspm_hip.hip prepare_zs_stats
+    int zs_stats_S = 0;           // ... for this value of the "i8_slices" option
+    void* h_zstat = nullptr;      // pinned copy of the column statistics (automatic plane count)
+    size_t h_zstat_cap = 0;
+    hipEvent_t ev_zstat = nullptr;
     int zs_S = 0, zs_KB = 0, zs_NT = 0, zs_npair = 0, zs_npg = 0;
     bool zs_ind = false;        // one plane per pair group, launched through the seven-plane main loop (gram_i8_kernel<.., IND>)
     double zs_ratio = 0.0;      // smallest sum|z| / max|z| over the pair columns (automatic plane count; 0: not evaluated)

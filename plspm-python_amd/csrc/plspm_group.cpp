@@ -17,6 +17,11 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 
 #include "model.h"
 
@@ -85,6 +90,58 @@ struct Local {
     double* h_word = nullptr;                      // pinned mirror
 };
 
+// Resident helper threads of a group with several local handles: every handle's shard is enqueued by its own thread (handle 0 by the
+// caller), so the host side of a step costs one handle's enqueue (~25 us: three launches + event) instead of their sum -- 8 handles driven
+// by one thread took 0.19 ms for the launches alone (tools/group_enqueue.py, profiles/r04_group_enqueue.jsonl) of a 0.48 ms step.  The
+// helpers spin for a few hundred microseconds after a job (a bootstrap loop's next call arrives within that window) and then sleep on a
+// condition variable.  Non-metric handles (host read-backs per iteration) run on the same crew.
+struct ShardCrew {
+    int n = 0;                                     // local handles; helpers = n - 1
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> seq{0};
+    std::atomic<int> done{0};
+    std::atomic<bool> stop{false};
+    std::function<void(int)> job;
+    void helper(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t s2 = seq.load(std::memory_order_acquire);
+            if (s2 == seen) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while ((s2 = seq.load(std::memory_order_acquire)) == seen && !stop.load(std::memory_order_acquire)) {
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return seq.load(std::memory_order_acquire) != seen || stop.load(std::memory_order_acquire); });
+                    }
+                }
+                if (s2 == seen) return;            // stop without new work
+            }
+            seen = s2;
+            job(i);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void start(int handles) {
+        n = handles;
+        for (int i = 1; i < n; ++i) th.emplace_back([this, i] { helper(i); });
+    }
+    void run(const std::function<void(int)>& f) {  // f(i) for every local handle i; returns when all are done
+        job = f;
+        done.store(0, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(mu); seq.fetch_add(1, std::memory_order_release); }
+        cv.notify_all();
+        f(0);
+        while (done.load(std::memory_order_acquire) < n - 1) std::this_thread::yield();
+    }
+    ~ShardCrew() {
+        { std::lock_guard<std::mutex> lk(mu); stop.store(true, std::memory_order_release); }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
 }  // namespace
 
 // The communicator set of this process: every rank of a single-process job, or one rank of a one-process-per-GPU job.  Creating
@@ -108,6 +165,8 @@ struct plspm_group {
     int64_t last_B = 0, last_cap = 0;
     int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
     int peers_rc = 0;
+    double t_shards_ms = 0.0, t_exchange_ms = 0.0;  // host time of the last plspm_group_bootstrap: shard enqueue / exchange enqueue
+    std::unique_ptr<ShardCrew> crew;               // one enqueuing thread per local handle (groups of several handles)
     std::string error;
 };
 
@@ -193,6 +252,7 @@ static void group_release(plspm_group* g) {
         if (l.cstream) plspm_stream_release(l.cstream);
         l.m->group = nullptr;
     }
+    g->crew.reset();                                // (joins the helpers: none of them may touch a handle after this)
     g->loc.clear();
     g->last_slot = -1;
     if (g->comm && g->comm->bound == g) g->comm->bound = nullptr;
@@ -293,6 +353,10 @@ plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models)
         if (plspm_dmalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || plspm_hmalloc((void**)&l.h_word, 64 + 8 * (size_t)std::max(8, c->nranks)) != hipSuccess)
             return bail("scratch allocation failed");
     }
+    if (n_local > 1) {
+        try { g->crew.reset(new ShardCrew()); g->crew->start(n_local); }
+        catch (...) { g->crew.reset(); }           // no threads: the caller's thread enqueues every shard
+    }
     c->bound = g;
     return g;
 }
@@ -330,8 +394,7 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
             for (int k = 0; k < 2; ++k) if ((rc = grow(g, l, l.send[k], send_bytes)) || (rc = grow(g, l, l.recv[k], recv_bytes))) return rc;
         }
     }
-    // 1. shard kernels, one handle after the other (enqueue only); non-metric models iterate with host read-backs, so their
-    //    handles are driven by one host thread each
+    // 1. shard kernels (enqueue only; non-metric models iterate with host read-backs): every local handle by its own resident thread
     std::vector<int> shard_rc(nl, 0);
     auto run_shard = [&](int i) {
         Local& l = g->loc[i];
@@ -351,13 +414,10 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         }
         if (hipEventRecord(l.computed[s], m->stream) != hipSuccess) shard_rc[i] = fail(m, PLSPM_E_STATE, "hipEventRecord failed");
     };
-    if (nl > 1 && g->loc[0].m->nonmetric) {
-        std::vector<std::thread> workers;
-        for (int i = 0; i < nl; ++i) workers.emplace_back(run_shard, i);
-        for (auto& w : workers) w.join();
-    } else {
-        for (int i = 0; i < nl; ++i) run_shard(i);
-    }
+    const auto t_a = std::chrono::steady_clock::now();
+    if (nl > 1 && g->crew) g->crew->run(run_shard);
+    else for (int i = 0; i < nl; ++i) run_shard(i);
+    const auto t_b = std::chrono::steady_clock::now();
     // A failed shard (out of memory, an LDS limit, a read-back error of a non-metric model) must not keep this rank out of the
     // collective: the other ranks of the job are already inside it and would wait forever.  Its send buffer becomes NaN-status
     // records (never counted as replicates), the all-gather runs as planned, and the error is reported afterwards.
@@ -405,6 +465,8 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
             hipEventRecord(dst.gathered[s], dst.cstream);
         }
     }
+    g->t_shards_ms = std::chrono::duration<double, std::milli>(t_b - t_a).count();
+    g->t_exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count();
     if (first_bad >= 0 || crc) {
         // the slot's buffers were handed to the collective: they count as in flight, but the call has no result
         g->pending[s] = true; g->next_slot = s ^ 1; g->last_slot = -1;
@@ -526,6 +588,13 @@ int plspm_group_barrier(plspm_group_t* g) {
     }
     GNCCL(g, r, r->GroupEnd());
     for (auto& l : g->loc) { GHIP(g, hipSetDevice(l.m->device)); GHIP(g, hipStreamSynchronize(l.cstream)); }
+    return 0;
+}
+
+int plspm_group_enqueue_times(const plspm_group_t* g, double* shards_ms, double* exchange_ms) {
+    if (!g) return PLSPM_E_ARG;
+    if (shards_ms) *shards_ms = g->t_shards_ms;
+    if (exchange_ms) *exchange_ms = g->t_exchange_ms;
     return 0;
 }
 

@@ -166,6 +166,8 @@ extern "C" int plspm_release_cached_memory(void) {
     return 0;
 }
 
+static int prepare_zs(plspm_model* m);      // digit planes of the resident data (below; plspm_fit cuts them in its tail when asked to)
+
 static ModelDesc make_desc(const plspm_model* m) {
     ModelDesc md{};
     md.P = m->P; md.L = m->L; md.PA = m->PAs; md.T = m->Ts; md.scheme = m->scheme; md.scaled = m->scaled; md.max_iter = m->max_iter;
@@ -313,6 +315,8 @@ void plspm_model_destroy(plspm_model_t* m) {
     for (int k = 0; k < 2; ++k) if (m->ev_pin[k]) hipEventDestroy(m->ev_pin[k]);
     for (int k = 0; k < PLSPM_K_COUNT; ++k) for (auto& pr : m->prof[k].pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (m->h_flag) plspm_hfree(m->h_flag);
+    if (m->h_zstat) plspm_hfree(m->h_zstat);
+    if (m->ev_zstat) hipEventDestroy(m->ev_zstat);
     if (m->ev_flag) hipEventDestroy(m->ev_flag);
     for (int k = 0; k < 2; ++k) { if (m->ev_counts[k]) hipEventDestroy(m->ev_counts[k]); if (m->ev_cdfree[k]) hipEventDestroy(m->ev_cdfree[k]); }
     if (m->aux) hipStreamDestroy(m->aux);                                   // (synchronised above; a low-priority stream of its own, not from the cache)
@@ -346,7 +350,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
-    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; if (m->stage2) m->stage2->codes_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false;
+    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; if (m->stage2) m->stage2->codes_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false; m->zs_stats_ready = false;
     drop_incomplete_rows(m);
     // persistent grow-only buffers: a repeated upload of the same shape allocates nothing
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
@@ -970,7 +974,7 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
 #undef NMXCHK
     plspm_dfree(d_mask);
     // the rows of Xa were rewritten: everything derived from them is stale (a caller may have run plspm_bootstrap_prepare before this call)
-    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false; m->zs_valid = false; m->codes_valid = false; m->dcnt_ready = false;
+    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false; m->zs_valid = false; m->zs_stats_ready = false; m->codes_valid = false; m->dcnt_ready = false;
     return 0;
 }
 
@@ -1057,6 +1061,9 @@ int plspm_fit(plspm_model_t* m, const plspm_fit_result_t* out) {
     if (stage_scores) HIPCHK(m, hipMemcpyAsync(hs + fit_bytes, m->scores.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
     else if (out->scores) HIPCHK(m, hipMemcpyAsync(out->scores, m->scores.p, score_bytes, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    // plspm_bootstrap_prepare ran before this fit: its column statistics are on the host now, so the digit planes are cut (enqueue only)
+    // while the caller unpacks the fit -- the first bootstrap call finds them ready.  (A failure here is reported by that call, which retries.)
+    if (m->zs_stats_ready && !m->zs_valid) { const std::string keep = m->error; if (prepare_zs(m)) { (void)hipGetLastError(); m->error = keep; } }
     if (stage_scores) memcpy(out->scores, hs + fit_bytes, score_bytes);
     const double* h = (const double*)hs;
     const int* h_int = (const int*)(h + o_end);
@@ -1128,10 +1135,7 @@ static int choose_gram_path(const plspm_model* m, int64_t B, bool explicit_idx =
 // anything bell-shaped reach several hundred.  Measured against 80-bit sums on the 10k x 60 benchmark data (tests/test_gpu_gram_i8.py,
 // error relative to sqrt(M_pp M_qq)): seven planes 1e-16 (correctly rounded), six planes 3e-15, the blocked fp64 MFMA accumulation
 // 1.6e-15 -- all nine orders below the 1e-6 the records are held to.
-static int choose_slices(plspm_model* m, const unsigned long long* d_max, long npair, int* S_out) {
-    std::vector<unsigned long long> h(3 * (size_t)npair);                     // [max bits | fixed-point sums | OR of the scaled integers]
-    HIPCHK(m, hipMemcpyAsync(h.data(), d_max, 3 * (size_t)npair * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipStreamSynchronize(m->stream));
+static int choose_slices(plspm_model* m, const unsigned long long* h, long npair, int* S_out) {      // h: [max bits | fixed-point sums | OR of the scaled integers], on the host
     double worst = 1e300;
     unsigned long long any = 0ull;
     for (long j = 0; j < npair; ++j) any |= h[2 * npair + j];
@@ -1159,13 +1163,13 @@ static int choose_slices(plspm_model* m, const unsigned long long* d_max, long n
     return 0;
 }
 
-static int prepare_zs(plspm_model* m) {
-    if (m->zs_valid) return 0;
-    int S = m->tune.i8_slices;
+// Phase 1 of the digit planes (enqueue only -- plspm_bootstrap_prepare): pair tables, column maxima of the pair products and, for the
+// automatic plane count, the two column statistics, copied to a pinned block behind an event.  Nothing here waits for the device: the
+// plane count is read in phase 2 (prepare_zs), by which time the fit that was enqueued behind this has long synchronised the stream.
+static int prepare_zs_stats(plspm_model* m) {
+    if (m->zs_valid || m->zs_stats_ready) return 0;
     const int C = m->Pg + 1;
     const long npair = i8_pairs(m);
-    const int npg = (int)((npair + 31) / 32) * 2;             // pair groups of 16, padded to whole workgroup tiles (two groups)
-    const int KB = i8_kblocks(m->N);
     std::vector<int> tab(6 * (size_t)npair);
     int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | packed slot | dense slot | mirrored dense slot]
     int* hd1 = hd + npair; int* hd2 = hd1 + npair;
@@ -1181,25 +1185,52 @@ static int prepare_zs(plspm_model* m) {
     if ((rc = ensure(m, m->pair_scale, (size_t)npair * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->zs_stat, 3 * (size_t)npair * sizeof(unsigned long long)))) return rc;
     if ((rc = plspm_detail_h2d(m, m->pair_tab.p, tab.data(), tab.size() * sizeof(int)))) return rc;
-    int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
+    int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair;
     ProfScope ps(m, PLSPM_K_PACK);
-    {
-        // column maxima of the pair products (+ the two statistics of the automatic plane count)
-        unsigned long long* d_max = (unsigned long long*)m->zs_stat.p;
-        HIPCHK(m, hipMemsetAsync(d_max, 0, 3 * (size_t)npair * sizeof(unsigned long long), m->stream));
-        const int RB = (int)std::max<size_t>(1, std::min<size_t>(64, (kMaxLds - 1024) / ((size_t)(C | 1) * sizeof(double))));
-        const size_t lds = (size_t)RB * (C | 1) * sizeof(double);
-        if ((rc = allow_lds(m, (const void*)zs_max_kernel, lds))) return rc;
-        hipLaunchKernelGGL(zs_max_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB, d_max);
-        if (S == 0) {
-            if ((rc = allow_lds(m, (const void*)zs_abssum_kernel, lds))) return rc;
-            hipLaunchKernelGGL(zs_abssum_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB,
-                               (const unsigned long long*)d_max, d_max + npair, d_max + 2 * npair);
-            HIPCHK(m, hipGetLastError());
-            if ((rc = choose_slices(m, d_max, npair, &S))) return rc;
+    unsigned long long* d_max = (unsigned long long*)m->zs_stat.p;
+    HIPCHK(m, hipMemsetAsync(d_max, 0, 3 * (size_t)npair * sizeof(unsigned long long), m->stream));
+    const int RB = (int)std::max<size_t>(1, std::min<size_t>(64, (kMaxLds - 1024) / ((size_t)(C | 1) * sizeof(double))));
+    const size_t lds = (size_t)RB * (C | 1) * sizeof(double);
+    if ((rc = allow_lds(m, (const void*)zs_max_kernel, lds))) return rc;
+    hipLaunchKernelGGL(zs_max_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB, d_max);
+    if (m->tune.i8_slices == 0) {
+        if ((rc = allow_lds(m, (const void*)zs_abssum_kernel, lds))) return rc;
+        hipLaunchKernelGGL(zs_abssum_kernel, dim3((unsigned)((m->N + RB - 1) / RB)), dim3(256), lds, m->stream, (const double*)m->d_Xa, (long)m->N, m->PA, C, d_p, d_q, (int)npair, RB,
+                           (const unsigned long long*)d_max, d_max + npair, d_max + 2 * npair);
+        HIPCHK(m, hipGetLastError());
+        const size_t bytes = 3 * (size_t)npair * sizeof(unsigned long long);
+        if (m->h_zstat_cap < bytes) {
+            if (m->h_zstat) plspm_hfree(m->h_zstat);
+            m->h_zstat = nullptr; m->h_zstat_cap = 0;
+            HIPCHK(m, plspm_hmalloc(&m->h_zstat, bytes));
+            m->h_zstat_cap = bytes;
         }
-        hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
+        if (!m->ev_zstat) HIPCHK(m, hipEventCreateWithFlags(&m->ev_zstat, hipEventDisableTiming));
+        HIPCHK(m, hipMemcpyAsync(m->h_zstat, d_max, bytes, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipEventRecord(m->ev_zstat, m->stream));
     }
+    HIPCHK(m, hipGetLastError());
+    m->zs_stats_ready = true; m->zs_stats_S = m->tune.i8_slices;
+    return 0;
+}
+
+static int prepare_zs(plspm_model* m) {
+    if (m->zs_valid) return 0;
+    int rc;
+    if (m->zs_stats_ready && m->zs_stats_S != m->tune.i8_slices) m->zs_stats_ready = false;      // the option changed in between
+    if ((rc = prepare_zs_stats(m))) return rc;
+    int S = m->tune.i8_slices;
+    const long npair = i8_pairs(m);
+    const int npg = (int)((npair + 31) / 32) * 2;             // pair groups of 16, padded to whole workgroup tiles (two groups)
+    const int KB = i8_kblocks(m->N);
+    int* d_p = (int*)m->pair_tab.p; int* d_q = d_p + npair; int* d_k = d_q + npair;
+    unsigned long long* d_max = (unsigned long long*)m->zs_stat.p;
+    ProfScope ps(m, PLSPM_K_PACK);
+    if (S == 0) {
+        HIPCHK(m, hipEventSynchronize(m->ev_zstat));          // (long done when a fit ran behind plspm_bootstrap_prepare)
+        if ((rc = choose_slices(m, (const unsigned long long*)m->h_zstat, npair, &S))) return rc;
+    }
+    hipLaunchKernelGGL(zs_scale_kernel, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, m->stream, d_max, (int)npair, S, d_k, (double*)m->pair_scale.p);
     // one plane (0/1 data): the product runs through the seven-plane main loop with the planes of a wave standing for seven consecutive
     // pair groups (gram_i8_kernel<.., IND>): the buffer is padded to whole tiles of 2 x 7 groups
     const bool ind = S == 1 && m->tune.i8_shape == 16 && m->tune.i8_ind != 0;
@@ -1212,7 +1243,7 @@ static int prepare_zs(plspm_model* m) {
 #undef ZSB
     HIPCHK(m, hipGetLastError());
     m->zs_S = S; m->zs_KB = KB; m->zs_NT = NT; m->zs_npair = (int)npair; m->zs_npg = npg_built; m->zs_ind = ind;
-    m->zs_valid = true;
+    m->zs_valid = true; m->zs_stats_ready = false;
     return 0;
 }
 
@@ -1710,7 +1741,10 @@ int plspm_bootstrap_prepare(plspm_model_t* m) {
     HIPCHK(m, hipSetDevice(m->device));
     // what the first bootstrap call on this data would build before its first replicate: the digit planes of the pair products
     // (enqueue only; a model that takes the fp64 Gram has nothing to prepare)
-    if (choose_gram_path(m, (int64_t)1 << 20) == 2) return prepare_zs(m);
+    // (automatic plane count: the column statistics are enqueued and copied to pinned memory behind an event -- no host wait here; the
+    //  planes are cut by the first bootstrap call, which finds the statistics on the host.  A fixed plane count has nothing to read back:
+    //  everything is enqueued now)
+    if (choose_gram_path(m, (int64_t)1 << 20) == 2) return m->tune.i8_slices == 0 ? prepare_zs_stats(m) : prepare_zs(m);
     return 0;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_model_set_option", "plspm_model_get_option", "plspm_bootstrap_moments", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt", "plspm_bootstrap_prepare",
-           "plspm_group_barrier", "plspm_group_max", "plspm_release_cached_memory",
+           "plspm_group_barrier", "plspm_group_max", "plspm_group_enqueue_times", "plspm_release_cached_memory",
            "plspm_op_inner_weights", "plspm_op_outer_weights", "plspm_op_outer_weights_nonmetric", "plspm_gram_tile_plan"]
 UNIQUE_ID_BYTES = 128
 
@@ -133,6 +133,7 @@ def load():
     lib.plspm_group_adopt.argtypes = [vp]
     lib.plspm_group_barrier.argtypes = [vp]
     lib.plspm_group_max.argtypes = [vp, ctypes.POINTER(dbl)]
+    lib.plspm_group_enqueue_times.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     lib.plspm_op_inner_weights.argtypes = [i32, i32, i32, vp, vp, i64, vp]
     lib.plspm_op_outer_weights.argtypes = [i32, i32, vp, vp, i64, i32, vp]
     lib.plspm_op_outer_weights_nonmetric.argtypes = [i32, i32, vp, vp, vp, i64, i32, dbl, vp, vp]
@@ -538,6 +539,12 @@ class NativeGroup:
         v = ctypes.c_double(float(value))
         self._check(self._lib.plspm_group_max(self._h, ctypes.byref(v)), "plspm_group_max")
         return v.value
+
+    def enqueue_times(self):
+        """(shards_ms, exchange_ms): host time of the last bootstrap call's two enqueue phases on this process."""
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self._lib.plspm_group_enqueue_times(self._h, ctypes.byref(a), ctypes.byref(b)), "plspm_group_enqueue_times")
+        return a.value, b.value
 
     def records(self, local=0):
         """(device pointer, n_records, stride) of the gathered records of the last bootstrap on local handle ``local``."""
