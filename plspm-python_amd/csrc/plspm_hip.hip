@@ -1107,7 +1107,7 @@ static bool nm_counts8_possible(const plspm_model* m) {
     return m->nonmetric && m->tune.nm_counts8 != 0 && m->tune.resample_aux == 0 && !m->aux && m->tune.i8_shape == 16 && m->nmx_K == 0 &&
            nm_dense_lds(m, nullptr, nullptr) != 0 && (!m->stage2 || nm_dense_lds(m->stage2, nullptr, nullptr) != 0);
 }
-static int choose_gram_path(const plspm_model* m, int64_t B, bool explicit_idx = false) {
+static int choose_gram_path(const plspm_model* m, int64_t B) {
     if (m->tune.gram_path == 1) return 1;
     // every model's replicates start from the moment matrix of the uploaded columns (metric, mean-imputed, non-metric, categorical
     // indicator columns, incomplete rows zeroed, first stage of a HOC pair).  The LDS histogram bounds N; int32 accumulators need
@@ -1116,8 +1116,10 @@ static int choose_gram_path(const plspm_model* m, int64_t B, bool explicit_idx =
     // histogram of 65,536 rows per workgroup, larger data sets take several windows per replicate)
     if (m->stage1 || m->N >= (1 << 24) || m->N < 2) return 1;
     // non-metric models beyond one 16-bit histogram window: the int8 route when their stop-rule passes can read the Gram's int8 counts
-    // (on-device draws); else the fp64 route with (row,count) lists from the global histogram and the gathering pass
-    if (m->nonmetric && m->N > 65535 && (explicit_idx || !nm_counts8_possible(m))) return 1;
+    // (on-device draws, and -- round 4 -- explicit index lists too: windowed 16-bit histograms, resample_i8_kernel; a chunk that carries a
+    // multiplicity above 127 falls back to row lists from the global histogram, the fp64 Gram and the gathering pass, as for metric models);
+    // else the fp64 route
+    if (m->nonmetric && m->N > 65535 && !nm_counts8_possible(m)) return 1;
     const size_t zs_bytes = (size_t)(i8_kblocks(m->N) + I8_SLACK_KB) * (size_t)(((i8_pairs(m) + 31) / 32) * 2 * (m->tune.i8_slices ? m->tune.i8_slices : 7)) * 1024;
     if (zs_bytes > kZsBudget) return 1;
     if (m->tune.gram_path == 2) return 2;
@@ -1569,8 +1571,10 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // non-metric models on the int8 route with Philox draws (round 3): the dense stop-rule pass reads its row multiplicities from the int8
     // counts the Gram consumed -- no second resample kernel, no (row,count) lists, no uint16 histograms (set_option "nm_counts8" 0: the
     // round-2 path, kept for A/B and for the cases below)
-    const int gpath_plan = choose_gram_path(m, B, d_idx != nullptr);
-    const bool counts8_plan = gpath_plan == 2 && !d_idx && nm_counts8_possible(m);
+    const int gpath_plan = choose_gram_path(m, B);
+    // (explicit index lists of at most 65,535 rows keep the round-3 arrangement -- uint16 histograms beside the lists they need anyway; beyond
+    //  one window the int8 counts are the only dense multiplicities there are)
+    const bool counts8_plan = gpath_plan == 2 && (!d_idx || !lds_hist) && nm_counts8_possible(m);
     const bool want_dcnt = m->nonmetric && lds_hist && !counts8_plan;
     const long dcnt_stride = ((N + 15) & ~15L);
     const int gpath = gpath_plan;
@@ -1628,8 +1632,8 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback, &cd8, &cd8_MT))) return rc;
             f64_gram = fallback;
         }
-        if (!counts8_plan) cd8 = nullptr;
-        if (f64_gram || (m->nonmetric && !counts8_plan)) {            // (row,count) lists (+ dense uint16 histograms): the same draws as the int8 counts
+        if (!counts8_plan || f64_gram) cd8 = nullptr;                  // (a chunk that fell back has no usable int8 counts)
+        if (f64_gram || (m->nonmetric && !cd8)) {                      // (row,count) lists (+ dense uint16 histograms): the same draws as the int8 counts
             if (lds_hist) {
                 const size_t hist_bytes = (size_t)((N + 1) / 2) * sizeof(unsigned);
                 if ((rc = allow_lds(m, (const void*)resample_kernel, hist_bytes))) return rc;
@@ -1659,8 +1663,8 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             // stage 2 on the second handle's descriptors with the convergence pass streaming THIS handle's data
             plspm_model* m2 = m->stage2;
             const long psize2 = packed_size(m2->Ts);
-            const int2* ent_l = need_lists ? (const int2*)m->ent.p : nullptr;
-            const int* nent_l = need_lists ? (const int*)m->nent.p : nullptr;
+            const int2* ent_l = (need_lists && !cd8) ? (const int2*)m->ent.p : nullptr;      // (built above only when the int8 counts are not used)
+            const int* nent_l = (need_lists && !cd8) ? (const int*)m->nent.p : nullptr;
             if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, SolverOut{}, ent_l, nent_l, ent_stride, 128, false, cd8, cd8_MT))) return rc;
             if ((rc = ensure(m, m2->gram, (size_t)nb * psize2 * sizeof(double)))) return rc;
             const HocDesc hd = make_hoc_desc(m2);
@@ -1679,7 +1683,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             // threads per problem by model width (measured: 60 columns 0.60 / 0.64 / 0.81 ms with 64 / 128 / 256 threads; 300 indicator
             // columns 21.0 / 13.5 / 10.0 ms)
             const int nm_threads = m->tune.nm_threads > 0 ? m->tune.nm_threads : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));
-            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, need_lists ? (const int2*)m->ent.p : nullptr, need_lists ? (const int*)m->nent.p : nullptr, ent_stride,
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (need_lists && !cd8) ? (const int2*)m->ent.p : nullptr, (need_lists && !cd8) ? (const int*)m->nent.p : nullptr, ent_stride,
                                     nm_threads, true, cd8, cd8_MT))) return rc;
             continue;
         }

@@ -953,3 +953,18 @@ def test_nonmetric_numeric_bootstrap_beyond_65535_rows_on_the_int8_route():
     assert nm.get_option("last_gram_path") == 1
     assert np.array_equal(i8[2], f64[2])
     np.testing.assert_allclose(i8[0], f64[0], rtol=1e-9, atol=1e-12)
+    # round 4: EXPLICIT index lists beyond 65,535 rows stay on the digit planes as well (windowed 16-bit histograms, the stop-rule passes on
+    # the int8 counts): fed the indices of the Philox stream, the records are the Philox route's bit for bit
+    nm.set_option("gram_path", 0)
+    idx = np.stack([_native.bootstrap_indices(3, r, 70000) for r in range(12)]).astype(np.int32)
+    by_idx = nm.bootstrap(12, idx=idx)
+    assert nm.get_option("last_gram_path") == 2
+    assert np.array_equal(by_idx[0], i8[0][:12]) and np.array_equal(by_idx[2], i8[2][:12]) and np.all(by_idx[1] == 0)
+    # ... and a list that carries a multiplicity above 127 falls back to the fp64 route for its chunk without changing a count
+    heavy = idx.copy()
+    heavy[0, :200] = 5
+    hv = nm.bootstrap(12, idx=heavy)
+    nm.set_option("gram_path", 1)
+    hv64 = nm.bootstrap(12, idx=heavy)
+    assert np.array_equal(hv[2], hv64[2]) and np.all(hv[1] == 0)
+    np.testing.assert_allclose(hv[0], hv64[0], rtol=1e-9, atol=1e-12)
