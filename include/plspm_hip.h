@@ -64,63 +64,68 @@ int plspm_release_cached_memory(void);
 const char* plspm_last_error(const plspm_model_t* m);
 
 /*
- * Launch-geometry options of a handle (defaults are the measured optima; tests use them to force a kernel variant).  The library
+ * Options of a handle.  The defaults are the measured optima; tests and benches use the rest to force a route or a kernel form.  The library
  * reads NO environment variables.  Unknown keys / out-of-range values return PLSPM_E_ARG.
- *   "solver_threads"  64 | 128 | 256      threads per problem of the batched metric solver (default 128)
- *   "nm_threads"      0 (by model width) | 64 | 128 | 256   threads per problem of the non-metric solvers
- *   "fit_chunks"      0 (auto) .. 65535   row chunks (workgroups) of the single-fit Gram
- *   "wide_nw"         4 | 8 | 16          waves sharing one row walk in gram_wide_kernel<14>
- *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
- *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
- *   "scores_tile"     0 (by LDS footprint) | 16 | 32   rows per tile of the scores kernel
- *   "gram_path"       0 auto | 1 fp64 MFMA Gram over (row,count) lists | 2 int8 digit-plane Gram (exact integer product of the dense
- *                     multiplicities with the base-256 digit planes of the pair products x_p x_q; every bootstrap whose planes fit
- *                     the memory budget: N < 2^24 rows (int32 sums), non-metric models N <= 65,535; second stages of HOC pairs take path 1)
+ *
+ * Routes and precision
+ *   "gram_path"       0 auto | 1 fp64 MFMA Gram over (row,count) lists | 2 int8 digit-plane Gram (exact integer product of the dense resample
+ *                     multiplicities with the base-256 digit planes of the pair products x_p x_q).  Auto = 2 for every bootstrap whose planes
+ *                     fit the memory budget and whose sums fit int32 (N < 2^24 rows): metric, mean-imputed, non-metric and categorical models,
+ *                     on-device draws and explicit index lists alike (a chunk of an index list that carries a multiplicity above 127 takes
+ *                     route 1); second stages of HOC pairs work on their first stage's matrices
  *   "i8_slices"       0 | 1 .. 8   digit planes per pair product.  0 (default) = automatic: 6 planes when every pair column of the uploaded data has
  *                     sum|z| >= 256 max|z| -- the worst-case error N 2^-47 max|z| of a replicate's sum is then below the a-priori bound N 2^-53 sum|z|
  *                     of an fp64 accumulation of the same terms, with a factor 4 to spare -- else 7 (>= 53 significant bits of the column
  *                     maximum: correctly rounded sums); and never more planes than carry anything: planes that are identically zero in the
  *                     seven-plane decomposition are dropped (0/1 indicator columns: ONE plane, bit-identical sums).  Read-only "last_i8_slices" /
  *                     "last_i8_ratio" report the choice and floor(min sum / max)
- *   "i8_ind"          1 (default) | 0   one-plane data run through the seven-plane main loop, the planes of a wave standing for seven pair groups
- *   "i8_min_batch"    auto mode takes the int8 path from this many replicates per call (default 1: always -- the path must not
+ *   "i8_min_batch"    auto mode takes the int8 route from this many replicates per call (default 1: always -- the route must not
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
- *   "i8_waves"        4 | 8   waves per workgroup of the int8 Gram (4: one per SIMD, 128 replicates x 16 pairs each; default 8: two per SIMD, 64 x 16 each -- 1.5 % faster steps in alternating A/B runs)
- *   "i8_shape"        16 (default) | 32   MFMA shape / fragment-block layout of the int8 Gram (32: v_mfma_i32_32x32x32_i8, measured 16 % slower)
- *   "i8_sched"        0 (default) | 1   int8 Gram as a persistent "stream-K" launch: one workgroup per CU, the tiles of the whole rounds
- *                     + an equal share of the left-over tiles' k-steps each, exact int32 partial sums handed to the tile's owner through
- *                     flagged scratch slots (bit-identical results; the kernel is ~3 % faster, the step is not: measured neutral).  Its
- *                     workgroups wait for each other's partial sums: two such launches sharing one device at the same time can starve each
- *                     other -- the wait is bounded (~1 s; the tile is then NaN, its replicates get status 3, plspm_bootstrap / _fetch
- *                     return PLSPM_E_STATE), so leave it off on handles that run concurrently on one device
- *   "resample_aux"    0 (default) | 1 | 2 | 3   int8 resample counts on a second stream of lowest / default / highest priority, so that
- *                     the draws of the next call fill CUs the Gram / solver of this one leave idle (+-2 %: measured neutral)
- *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 path: one wave per replicate with the
+ * Int8 Gram kernels (all forms give bit-identical matrices: exact int32 sums)
+ *   "i8_priv"         1 (default) | 0   six / seven planes: gram_i8p_kernel (round 4: four waves, count fragments straight from global memory into
+ *                     registers, only the digit blocks through the LDS ring; tile rows of 320 / 256 replicates with six planes, 256 / 192 with
+ *                     seven) or, 0, the round-3 gram_i8_kernel (eight waves, both operands through LDS: 9-10 % slower, kept as the A/B reference
+ *                     and for the other plane counts).  Read-only "last_i8_priv"
+ *   "i8_rt"           0 (default) | 16 | 20   count tiles (16 replicates each) per tall workgroup tile.  0 = automatic: the replicates are cut into
+ *                     tall and short tile rows in ONE launch so that the machine's last round is as full as the others (list-scheduling model of
+ *                     the 8 XCDs, tile costs measured per kernel: profiles/r04_i8_mix_calib.jsonl); 20 / 16 with six / seven planes: tall rows
+ *                     only; 16 with six planes: the 256-replicate round-3 kernel.  Read-only "last_i8_rt" / "last_i8_short" / "last_i8_mt": tall
+ *                     tile height, short rows and padded count tiles of the last launch
+ *   "i8_short_rows"   -1 (default) | n   test seam: n short tile rows behind as many tall ones as it takes
+ *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the round-3 kernel: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
+ *                     ... lds (per-workgroup descriptors + 32-bit offsets; auto takes it whenever an operand's walk stays below 4 GiB)
+ *   "i8_ind"          1 (default) | 0   one-plane data run through the seven-plane main loop, the planes of a wave standing for seven pair groups
+ * Solvers
+ *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 route: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
- *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the int8 Gram: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
- *                     ... lds (per-workgroup descriptors + 32-bit offsets: 0.4 % faster; auto takes it whenever an operand's walk stays below 4 GiB)
- *   "i8_rt"           0 (default) | 16 | 20 | 8   count tiles (16 replicates each) per workgroup of the int8 Gram: 256, 320 or 128 replicates x 32
- *                     pairs.  0 = automatic, six planes: the replicates are cut into tile rows of 320 and -- eight-wave kernel -- rows of 256 in
- *                     ONE launch so that the machine's last round is as full as the others (list-scheduling model of the 8 XCDs; 5,000
- *                     replicates x 60 pair tiles on 256 CUs: 12 + 5 rows, Gram 0.396 -> 0.373 ms), or the 256-replicate kernel when that is
- *                     no slower (fewer LDS-DMA bytes and fragment reads per MFMA on the tall tile; the sums are exact int32 either way, no
- *                     result depends on the cut).  20: tall rows only.  128 (value 8): half the accumulator registers, two workgroups per
- *                     CU, seven planes (2.6 % slower -- kept for co-scheduling experiments).  Read-only "last_i8_rt" / "last_i8_short" /
- *                     "last_i8_mt": tile height, short rows and padded count tiles of the last launch
+ *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
+ *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
+ *   "solver_threads"  64 | 128 | 256      threads per problem of the LDS solver (default 128)
+ *   "nm_threads"      0 (by model width) | 64 | 128 | 256   threads per problem of the non-metric solvers
+ *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
+ *                     multiplicities from the int8 counts of the Gram (no second resample kernel / uint16 histograms / (row,count) lists)
  *   "nm_codes"        1 (default) | 0   all-indicator categorical models (every MV ORD / NOM), bootstrap on the int8 route: the dense
  *                     stop-rule pass adds the coefficient of the one column a row has set per MV (16 category codes per row tile and MV,
  *                     nm_conv_codes_kernel) instead of multiplying every 0/1 column through -- bit-identical partial sums, 2.3 x faster
  *                     passes on 300 indicator columns.  Read-only "last_nm_codes"
- *   "upload_direct"   0 (default) | 1   plspm_upload of more than 64 MB: 0 through the handle's pinned staging halves, filled by several host
- *                     threads; 1 the runtime's pageable copy (one staging thread: 13-52 GB/s depending on the host)
- *   "i8_short_rows"   -1 (default) | n   test seam, with "i8_rt" 20 and eight waves: n rows of 256 replicates behind the tall ones
- *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
- *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
- *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
- *                     multiplicities from the int8 counts of the Gram (no second resample kernel / uint16 histograms / (row,count) lists)
  *   "nm_fast_lds"     1 (default) | 0   categorical (ORD / NOM) solver: the small arrays of the iteration in LDS for the duration of a launch
  *   "nm_k16"          1 (default) | 0   all-indicator categorical models of at most 65,535 rows: uint16 copy of the count matrix for the
  *                     streaming product of every step (bit-identical steps, a quarter of the bytes)
+ *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
+ *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
+ * Single fit / upload
+ *   "fit_chunks"      0 (auto) .. 65535   row chunks (workgroups) of the single-fit Gram
+ *   "wide_nw"         4 | 8 | 16          waves sharing one row walk in gram_wide_kernel<14>
+ *   "scores_tile"     0 (by LDS footprint) | 16 | 32   rows per tile of the scores kernel
+ *   "gram_lds_kb"     0 .. 160   pads the dynamic LDS of gram_rows_kernel (occupancy experiments)
+ *   "upload_direct"   0 (default) | 1   plspm_upload of more than 64 MB: 0 through the handle's pinned staging halves, filled by several host
+ *                     threads; 1 the runtime's pageable copy (one staging thread: 13-52 GB/s depending on the host)
+ * Experiments build only (make -C plspm-python_amd/csrc experiments, loaded through PLSPM_HIP_LIB; the release library answers PLSPM_E_ARG):
+ * "i8_waves" 4 (four-wave forms of the round-3 kernel: measured equal), "i8_shape" 32 (v_mfma_i32_32x32x32_i8 layout: 16 % slower), "i8_sched" 1
+ * (persistent stream-K launch: kernel -3 %, step unchanged, and two such launches sharing a device can starve each other), "i8_rt" 8 (128-replicate
+ * tile: 2.6 % slower), "resample_aux" 1 .. 3 (counts drawn on a second stream: inside the spread), "i8_variant" (schedule variants and ablation
+ * probes of both Gram kernels).  Read-only "build_experiments" tells which library is loaded.  DESIGN.md 7b has the measurements.
+ *
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
  * (1 LDS solver, 2 rows solver, 3 wave solver) tell what the last bootstrap call took.
  */
@@ -280,7 +285,10 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
 int plspm_sync(plspm_model_t* m);
 /* Enqueue now what the first bootstrap call on the uploaded data would have to build before its first replicate (the int8 digit planes
  * of the pair products, ~0.1 ms at 10k x 60): a host that knows a bootstrap follows the fit (Plspm(bootstrap=True): plspm.py:78-82 calls
- * Bootstrap right behind the estimate) calls this after plspm_upload, so that the planes are built beside the fit.  Optional. */
+ * Bootstrap right behind the estimate) calls this after plspm_upload.  Enqueue only -- the call never waits for the device: with the
+ * automatic plane count it starts the column statistics and their copy to pinned memory, the plspm_fit that follows finds them on the host
+ * when its own synchronisation returns and cuts the planes in its tail, beside the caller's unpacking of the fit.  Optional.  Anything that
+ * rewrites the resident rows afterwards (plspm_upload, plspm_model_set_incomplete_rows) discards what was prepared. */
 int plspm_bootstrap_prepare(plspm_model_t* m);
 /* Host copy of replicates [first, first + count) of the LAST plspm_bootstrap(_device) call on this handle, whose records are still
  * in HBM: out [count*R], status / iters [count] (each may be NULL).  Lets a caller keep the rows on the device (summaries:

@@ -170,26 +170,6 @@ __global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, con
     }
 }
 
-// plspm_model_set_incomplete_rows: copy the incomplete rows (masked) into the side tables and zero them in Xa (data + ones column)
-__global__ void __launch_bounds__(256) extract_rows_kernel(double* __restrict__ Xa, int PA, int P, const int* __restrict__ rowid, const unsigned char* __restrict__ mask,
-                                                           double* __restrict__ Xk, double* __restrict__ Mk) {
-    const long j = blockIdx.x;
-    double* row = Xa + (long)rowid[j] * PA;
-    for (int p = threadIdx.x; p < PA; p += blockDim.x) {
-        if (p < P) {
-            const double present = mask[j * P + p] ? 1.0 : 0.0;
-            Mk[j * P + p] = present;
-            Xk[j * P + p] = present * row[p];
-        }
-        row[p] = 0.0;
-    }
-}
-
-// scores of the incomplete rows come from the solver state, not from the score map (plspm_fit)
-__global__ void __launch_bounds__(64) patch_scores_kernel(double* __restrict__ scores, int L, const int* __restrict__ rowid, const double* __restrict__ Yn) {
-    const long j = blockIdx.x;
-    for (int l = threadIdx.x; l < L; l += blockDim.x) scores[(long)rowid[j] * L + l] = Yn[j * L + l];
-}
 
 // Streaming convergence pass (reference weights.py:120): for every still-active problem, sum over its observations (all rows,
 // or the (row,count) list of a bootstrap replicate) of count * sum_l (|y_old| - |y_new|)^2, with y = xa . c + k for the two
@@ -601,4 +581,15 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_codes_kernel(const unsigned s
         }
         if (live && have) partial[b * nparts + part] = acc;
     }
+}
+
+// second stage of a HOC pair: its score maps composed with the first stage's, in the layout the stop-rule passes read (solver_hoc.h)
+__global__ void __launch_bounds__(64) hoc_compose_kernel(HocDesc hd, const double* __restrict__ state1, long st1_stride, double* state2, long st2_stride, int n_chol2,
+                                                         double* pseudo, long ps_stride) {
+    const long b = blockIdx.x;
+    const double* st = state1 + b * st1_stride;
+    NmState st2;
+    nm_carve(st2, state2 + b * st2_stride, hd.P2, hd.L2);
+    DevExec ex{(int)threadIdx.x, (int)blockDim.x, nullptr, nullptr};
+    hoc_compose_score_maps(ex, hd, st + 8 + 3 * hd.P1, st + 8 + 4 * hd.P1 + hd.L1, st2, pseudo + b * ps_stride);
 }

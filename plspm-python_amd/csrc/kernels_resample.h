@@ -1,113 +1,6 @@
-// kernels_input.h -- Device kernels, part 1: Philox4x32-10 resampling streams, upload (column means, pack) and the resample + compaction kernels.
-// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+// kernels_resample.h -- Device kernels, part 1b: resample + ordered compaction into (row, count) lists (fp64 Gram route, stop-rule passes).
+// Included by plspm_bootstrap.hip only (philox.h in front); not a stand-alone header.
 #pragma once
-
-// ------------------------------------------------------------------------------------------------ Philox4x32-10
-struct u32x4 { uint32_t v[4]; };
-__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
-__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    u32x4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
-    return o;
-}
-// Resample index i (0 <= i < N) of replicate `rep`: word (i & 3) of Philox(counter = (i >> 2, 0, rep), key = seed),
-// mapped to [0, N) by the 32x32 -> high-word multiply (bias <= N / 2^32).
-__host__ __device__ __forceinline__ u32x4 resample_quad(uint64_t seed, uint64_t rep, uint32_t q) {
-    return philox4x32_10(q, 0u, (uint32_t)rep, (uint32_t)(rep >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-}
-__host__ __device__ __forceinline__ int32_t to_index(uint32_t u, uint32_t n) { return (int32_t)mulhi32(u, n); }
-
-// ------------------------------------------------------------------------------------------------ upload kernels
-// Column sums, row-major source: block = 64 columns x 4 row lanes; partial[blockIdx.x][p].
-__global__ void __launch_bounds__(256) colsum_rowmajor_kernel(const double* __restrict__ X, long N, int src_cols, const int* __restrict__ colidx,
-                                                               int P, double* __restrict__ partial) {
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = lmin(N, r0 + rows_per_block);
-    for (int pbase = 0; pbase < P; pbase += 64) {
-        const int p = pbase + tx;
-        double s = 0.0;
-        if (p < P) {
-            const int c = colidx[p];
-            for (long i = r0 + ty; i < r1; i += 4) s += X[i * src_cols + c];
-        }
-        red[ty][tx] = s;
-        __syncthreads();
-        if (ty == 0 && p < P) partial[(long)blockIdx.x * P + p] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-        __syncthreads();
-    }
-}
-// Column sums, column-major source: grid (chunks, P); threads run along the rows.
-__global__ void __launch_bounds__(256) colsum_colmajor_kernel(const double* __restrict__ X, long N, const int* __restrict__ colidx, int P,
-                                                               double* __restrict__ partial) {
-    __shared__ double red[256];
-    const int p = blockIdx.y;
-    const double* col = X + (long)colidx[p] * N;
-    const long rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = lmin(N, r0 + rows_per_block);
-    double s = 0.0;
-    for (long i = r0 + threadIdx.x; i < r1; i += 256) s += col[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h]; __syncthreads(); }
-    if (threadIdx.x == 0) partial[(long)blockIdx.x * P + p] = red[0];
-}
-__global__ void colmean_kernel(const double* __restrict__ partial, int nblk, int P, long N, double* __restrict__ shift) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * P + p];
-    shift[p] = s / (double)N;
-}
-// Xa[i][p] = X[i][colidx[p]] - shift[p] (p < P), 1 (p == P), 0 (p > P).  Row-major source: one thread per output element.
-__global__ void __launch_bounds__(256) pack_rowmajor_kernel(const double* __restrict__ X, long N, int src_cols, const int* __restrict__ colidx,
-                                                             int P, int PA, const double* __restrict__ shift, double* __restrict__ Xa) {
-    const long total = N * PA;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long i = e / PA;
-        const int p = (int)(e - i * PA);
-        double v = 0.0;
-        if (p < P) v = X[i * src_cols + colidx[p]] - shift[p];
-        else if (p == P) v = 1.0;
-        Xa[e] = v;
-    }
-}
-// Column-major source: 64-row x 32-column LDS transpose tile (reads run along rows, writes along columns).
-__global__ void __launch_bounds__(256) pack_colmajor_kernel(const double* __restrict__ X, long N, const int* __restrict__ colidx, int P, int PA,
-                                                             const double* __restrict__ shift, double* __restrict__ Xa) {
-    __shared__ double tile[32][65];
-    const long i0 = (long)blockIdx.x * 64;
-    const int p0 = blockIdx.y * 32;
-    {
-        const int r = threadIdx.x & 63;
-        for (int c = threadIdx.x >> 6; c < 32; c += 4) {
-            const int p = p0 + c;
-            const long i = i0 + r;
-            double v = 0.0;
-            if (i < N) {
-                if (p < P) v = X[(long)colidx[p] * N + i] - shift[p];
-                else if (p == P) v = 1.0;
-            }
-            tile[c][r] = v;
-        }
-    }
-    __syncthreads();
-    {
-        const int c = threadIdx.x & 31;
-        for (int r = threadIdx.x >> 5; r < 64; r += 8) {
-            const long i = i0 + r;
-            if (i < N && p0 + c < PA) Xa[i * PA + p0 + c] = tile[c][r];
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ resample + compact
 // One workgroup per replicate: LDS histogram of the N drawn row indices, then an ordered compaction into
@@ -233,3 +126,4 @@ __global__ void __launch_bounds__(256) resample_global_kernel(int N, const int* 
     if (tid < padded - total) my_ent[total + tid] = make_int2(0, 0);
     if (tid == 0) nent[b] = total;
 }
+

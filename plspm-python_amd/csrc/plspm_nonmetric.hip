@@ -1,0 +1,220 @@
+// plspm_nonmetric.hip -- host side, part 2b: the non-metric iteration (Scale.NUM / RAW, ORD / NOM, incomplete rows, HOC second stages):
+// prepare -> (step, stop-rule pass)* -> finish, the host reading one counter per iteration.  Kernels: kernels_nonmetric.h.
+#include "host_internal.h"
+
+#include "wave_ops.h"
+#include "device_exec.h"
+#include "kernels_nonmetric.h"
+
+// Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
+// finish.  The host only reads one counter per iteration (how many problems are still active).
+// doubles of per-problem solver state of a non-metric handle (NmState head + what its solver keeps behind it)
+size_t nm_state_doubles_of(const plspm_model* m) {
+    return m->categorical ? (size_t)nmg_state_doubles(m->P, m->Pm, m->L, m->cmax, m->kmv)
+                          : m->nmx_K > 0 ? (size_t)nmx_state_doubles(m->P, m->L, m->n_chol, m->nmx_K) : (size_t)nm_state_doubles(m->P, m->L, m->n_chol);
+}
+
+// LDS footprint of the dense stop-rule pass (nm_conv_dense_kernel) for this handle: the coefficient tile of 64 replicates whole, or one LV
+// block at a time; 0 when neither fits or the option forbids the pass
+size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out) {
+    const plspm_model* src = m->stage1 ? m->stage1 : m;
+    const int table_rows = 2 * src->P + 2 * m->L + 1;
+    const size_t dense_lds = (size_t)table_rows * 64 * sizeof(double);
+    const std::vector<int>& conv_blocks = m->stage1 ? m->lv_cols : m->boff;
+    int kb = 1;
+    for (int l = 0; l < m->L; ++l) kb = std::max(kb, conv_blocks[l + 1] - conv_blocks[l]);
+    const bool w = dense_lds <= kMaxLds && m->tune.conv_pass != 2;            // (option conv_pass = 2 forces the blocked variant: tests)
+    const size_t use = w ? dense_lds : (size_t)(2 * kb + 2) * 64 * sizeof(double);
+    if (whole) *whole = w;
+    if (kb_out) *kb_out = kb;
+    return (use <= kMaxLds && m->tune.conv_pass != 1) ? use : 0;
+}
+
+// cd8 / cd8_MT: the int8 row multiplicities of THESE problems (the counts the digit-plane Gram consumed; bootstrap only), or null
+int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so_in, const int2* ent, const int* nent,
+                         long ent_stride, int threads, bool finish, const void* cd8, int cd8_MT) {
+    SolverOut so = so_in;
+    const int P = m->P, L = m->L;
+    plspm_model* src = m->stage1 ? m->stage1 : m;                // an attached second stage streams its first stage's data (solver_hoc.h)
+    const long N = src->N;
+    const bool cat = m->categorical != 0, nmx = m->nmx_K > 0;
+    int rc;
+    const size_t s_bytes = (size_t)cov_doubles(P) * sizeof(double);
+    const size_t st_doubles = nm_state_doubles_of(m);
+    // bootstrap: dense stop-rule pass (nm_conv_dense_kernel) when the replicates' uint16 histograms are at hand and the coefficient
+    // tile of 64 replicates fits LDS; otherwise (and for a single fit) the gathering pass
+    const long ntiles16 = (N + 15) / 16;
+    const int table_rows = 2 * src->P + 2 * L + 1;
+    // coefficient tile of 64 replicates: whole in LDS when it fits, else one LV block at a time (kb = widest block of the map the pass uses)
+    bool dense_whole = false;
+    int kb = 1;
+    const size_t dense_use_lds = nm_dense_lds(m, &dense_whole, &kb);
+    // the replicates' row multiplicities: the int8 counts of the digit-plane Gram (round 3) or the uint16 histograms of resample_kernel
+    const bool counts8 = cd8 != nullptr;
+    const bool dense = dense_use_lds != 0 && (counts8 || (ent && src->dcnt_ready));
+    if (counts8 && !dense) return fail(m, PLSPM_E_STATE, "non-metric bootstrap: the dense stop-rule pass does not fit and no (row,count) lists were built");
+    const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
+    const int ngroups = (int)((nproblems + 63) / 64);
+    if (dense) {
+        if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->nmlist, ((size_t)nproblems + 1) * sizeof(int)))) return rc;
+        const void* ck = counts8 ? (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, true> : (const void*)nm_conv_dense_kernel<16, 8, true, true>)
+                                 : (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, false> : (const void*)nm_conv_dense_kernel<16, 8, true, false>);
+        if ((rc = allow_lds(m, ck, dense_use_lds))) return rc;
+        if (!src->Xt_valid) {
+            hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, (double*)src->Xt.p);
+            src->Xt_valid = true;
+        }
+    }
+    // all-indicator categorical data on the dense pass with the Gram's int8 counts: the pass on category codes (kernels_nonmetric.h
+    // nm_conv_codes_kernel; one table of 16 codes per (row tile, MV), built once per upload -- a second HOC stage streams its first
+    // stage's rows under its own blocks and keeps its own table)
+    const int* codes_base = m->stage1 ? m->d_mv_base2 : m->d_mv_base;
+    const int* codes_lmv = m->stage1 ? m->d_lmv2_off : m->d_lmv_off;
+    const size_t codes_lds = (size_t)(2 * (kb + 1) + 2) * 64 * sizeof(double);      // one block's coefficients + the zero slot + the two constants
+    const bool use_codes = dense && counts8 && src->categorical && src->cat_pure && (m->stage1 || cat) && codes_base && codes_lmv && !nmx && m->tune.nm_codes != 0 && kb < 65535 &&
+                           codes_lds <= kMaxLds;
+    if (use_codes) {
+        if ((rc = allow_lds(m, (const void*)nm_conv_codes_kernel<8>, codes_lds))) return rc;
+        if (!m->codes_valid) {
+            if ((rc = ensure(m, m->codes, (size_t)ntiles16 * src->Pm * 16 * sizeof(unsigned short)))) return rc;
+            const long total = ntiles16 * src->Pm * 16;
+            hipLaunchKernelGGL(cat_codes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const double*)src->d_Xa, N, src->PA, src->Pm, (const int*)src->d_mv_off,
+                               codes_base, kb, ntiles16, (unsigned short*)m->codes.p);
+            m->codes_valid = true;
+        }
+    }
+    m->last_nm_codes = use_codes ? 1 : 0;
+    if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
+    if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
+    // all-indicator categorical models of at most 65,535 rows: a uint16 copy of every problem's count matrix for the streaming product of the step
+    const int ld16 = (P + 1 + 3) & ~3;
+    const bool k16 = cat && m->cat_pure && N <= 65535 && m->tune.nm_k16 != 0;
+    if (k16 && (rc = ensure(m, m->gK16, (size_t)nproblems * (P + 1) * ld16 * sizeof(unsigned short)))) return rc;
+    if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
+    size_t lds = (size_t)workspace_small_doubles(cat ? m->Pm : P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
+    if (cat) lds += (size_t)workspace_small_doubles(m->Pm, L, m->kmax, 0) * sizeof(double);
+    if (lds > kMaxLds) return fail(m, PLSPM_E_LIMIT, "non-metric solver: workspace exceeds LDS");
+    // categorical problems: the small arrays of the iteration in LDS when they fit beside the workspaces (kernels_nonmetric.h nmg_kernel)
+    const size_t cat_fast_bytes = cat ? (size_t)((nmg_fast_doubles(P, m->Pm, L, m->cmax, m->kmv) + 1) & ~1L) * sizeof(double) : 0;
+    const int cat_fast = (cat && m->tune.nm_fast_lds != 0 && lds + cat_fast_bytes <= kMaxLds) ? 1 : 0;
+    if (cat_fast) lds += cat_fast_bytes;
+    if (cat) {
+        if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)))
+            return rc;
+    } else if (nmx) {
+        if ((rc = allow_lds(m, (const void*)nmx_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<2>, lds)))
+            return rc;
+    } else if ((rc = allow_lds(m, (const void*)nm_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nm_kernel<2>, lds)))
+        return rc;
+    const size_t conv_lds = ((size_t)SCORE_ROWS * (src->PA + 1) + 2 * (size_t)src->P + 2 * (size_t)L + SCORE_ROWS + 256) * sizeof(double) + (size_t)(L + 2) * sizeof(int);
+    const long ps_stride = 8 + 4L * src->P + 2L * L;
+    if (m->stage1 && (rc = ensure(m, m->pseudo, (size_t)nproblems * ps_stride * sizeof(double)))) return rc;
+    if ((rc = allow_lds(m, (const void*)nm_conv_kernel, conv_lds))) return rc;
+    const ModelDesc md = make_desc(m);
+    CatDesc cd{};
+    ModelDesc mdm = md;
+    if (cat) {
+        cd.Pm = m->Pm; cd.cmax = m->cmax; cd.kmv = m->kmv; cd.mv_off = m->d_mv_off; cd.mv_kind = m->d_mv_kind; cd.lmv_off = m->d_lmv_off;
+        mdm.P = m->Pm; mdm.boff = m->d_lmv_off; mdm.lvof = m->d_mv_lv; mdm.chol_off = m->d_no_chol; mdm.n_chol = 0;      // shift: zeros (upload)
+    }
+    double* gS = (double*)m->gS.p;
+    double* gSm = (double*)m->gSm.p;
+    double* gst = (double*)m->nmstate.p;
+    double* part = (double*)m->nmpartial.p;
+    int* nact = (int*)m->nmactive.p;
+    const dim3 grid((unsigned)nproblems);
+    const int fuse = finish ? 1 : 0;           // the finish of a problem runs inside the step launch that decides its stop
+#ifdef PLSPM_DEBUG_MARKS
+    long long* d_nm_marks = nullptr;
+    if (cat) { HIPCHK(m, plspm_dmalloc((void**)&d_nm_marks, 32 * sizeof(long long))); so.marks = d_nm_marks; }
+#endif
+    auto launch = [&](int mode_op) {
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        if (cat) {
+            auto k = mode_op == 0 ? nmg_kernel<0> : mode_op == 1 ? nmg_kernel<1> : nmg_kernel<2>;
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact, fuse, cat_fast,
+                               k16 ? (unsigned short*)m->gK16.p : (unsigned short*)nullptr, ld16);
+        } else if (nmx) {
+            auto k = mode_op == 0 ? nmx_kernel<0> : mode_op == 1 ? nmx_kernel<1> : nmx_kernel<2>;
+            const MissDesc xd{m->nmx_raw, m->nmx_K, m->d_Xk, m->d_Mk};
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, xd, (const int*)m->d_rowid, Mp, mp_stride, so, gS, gst, (long)st_doubles, (const double*)part, nparts,
+                               nact, ent, nent, ent_stride, fuse);
+        } else {
+            auto k = mode_op == 0 ? nm_kernel<0> : mode_op == 1 ? nm_kernel<1> : nm_kernel<2>;
+            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact, fuse);
+        }
+    };
+    // (dense stop-rule pass: the list kernel of the pass counts the live problems anyway and writes the count to the pinned flag itself -- no
+    //  counter to clear, no copy operation: two tiny launches and their gaps less per iteration, 35 of ~590 us at three iterations)
+    const bool flag_from_list = dense && !m->stage1;
+    for (int it = 0; it <= m->max_iter + 1; ++it) {
+        if (!flag_from_list) HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
+        launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
+        // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
+        // problems / replicate groups return at once on the device, and the 4-byte read-back of the counter overlaps with the pass
+        // instead of leaving the GPU idle for a host round trip per iteration.
+        if (!flag_from_list) {
+            HIPCHK(m, hipMemcpyAsync(m->h_flag, nact, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+        }
+        {
+            ProfScope ps(m, PLSPM_K_SCORES);
+            const double* conv_state = gst;
+            long conv_stride = (long)st_doubles;
+            const int* conv_boff = m->d_boff;
+            if (m->stage1) {
+                hipLaunchKernelGGL(hoc_compose_kernel, grid, dim3(64), 0, m->stream, make_hoc_desc(m), (const double*)m->stage1->nmstate.p,
+                                   (long)nm_state_doubles_of(src), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride);
+                conv_state = (const double*)m->pseudo.p; conv_stride = ps_stride; conv_boff = m->d_lv_cols;
+            }
+            if (dense) {
+                int* live_list = (int*)m->nmlist.p;                            // [count | ids of the problems still iterating, in problem order]
+                hipLaunchKernelGGL(active_list_kernel, dim3(1), dim3(1024), 0, m->stream, conv_state, conv_stride, nproblems, live_list + 1, live_list,
+                                   flag_from_list ? (int*)m->h_flag : (int*)nullptr);
+                if (flag_from_list) HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+                hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups, (unsigned)((2 * src->P + 2 * L + 1 + 63) / 64)), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L,
+                                   (const int*)(live_list + 1), (const int*)live_list, (double*)m->ctable.p);
+                const int gx = (int)((ntiles16 + 7) / 8);                      // row blocks of 128 rows (8 tiles: 8 x 16-row or 16 x 8-row waves)
+                const int rbx = (gx + 7) / 8;                                  // row blocks per XCD
+                // replicate slices: one group of 64 replicates per workgroup measured best (1.06 ms for three passes against 1.17 / 1.21 /
+                // 1.28 with 12 / 6 / 13 slices): many small workgroups let the dispatcher balance the CUs
+                const int gy = m->tune.conv_gy > 0 ? m->tune.conv_gy : ngroups;
+                auto conv_kernel = counts8 ? (dense_whole ? nm_conv_dense_kernel<16, 8, false, true> : nm_conv_dense_kernel<16, 8, true, true>)
+                                           : (dense_whole ? nm_conv_dense_kernel<16, 8, false, false> : nm_conv_dense_kernel<16, 8, true, false>);
+                if (use_codes)
+                    hipLaunchKernelGGL(nm_conv_codes_kernel<8>, dim3((unsigned)(8 * rbx * gy)), dim3(512), codes_lds, m->stream, (const unsigned short*)m->codes.p, ntiles16, src->Pm, src->P, L,
+                                       conv_boff, codes_lmv, (const uint4*)cd8, (long)cd8_MT, (const double*)m->ctable.p,
+                                       (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
+                else
+                hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
+                                   conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
+                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
+            } else {
+                hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
+                                   ent_stride, conv_state, conv_stride, part);
+            }
+        }
+        HIPCHK(m, hipEventSynchronize(m->ev_flag));
+#ifdef PLSPM_DEBUG_MARKS
+        if (cat && it == 1) {
+            long long h[32];
+            HIPCHK(m, hipStreamSynchronize(m->stream));
+            HIPCHK(m, hipMemcpy(h, d_nm_marks, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[plspm nmg_step clocks] V=Mn.c %lld  YY+G %lld  inner weights %lld  MZ+a %lld  quantify(par) %lld  LV loop %lld  score map %lld  total %lld\n", h[21] - h[20],
+                    h[22] - h[21], h[23] - h[22], h[24] - h[23], h[25] - h[24], h[26] - h[25], h[27] - h[26], h[27] - h[20]);
+        }
+#endif
+        if (*m->h_flag == 0) break;
+    }
+#ifdef PLSPM_DEBUG_MARKS
+    if (d_nm_marks) plspm_dfree(d_nm_marks);
+#endif
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
+
+
