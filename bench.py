@@ -424,7 +424,7 @@ def main():
             npair = 61 * 62 // 2                               # unordered pairs of the 60 columns + the ones column
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = (live, live_src) if live else static_traffic(("r03_gram_i8_traffic.json", "r02c_gram_i8_traffic.json", "r02_gram_i8_traffic.json"))
+            traffic, traffic_src = (live, live_src) if live else static_traffic(("r04_gram_i8_traffic.json", "r03_gram_i8_traffic.json", "r02c_gram_i8_traffic.json"))
             # what the launch executes: whole tiles of 320 / 256 replicates x 64 rows x 32 pairs (= SQ_INSTS_VALU_MFMA_MOPS_I8 x 512 of the PMC passes
             # in profiles/)
             k_rows = ((N_OBS + 127) // 128) * 128

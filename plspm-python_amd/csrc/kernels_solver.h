@@ -115,7 +115,7 @@ struct DevWaveExec : DevExecT<4> {
     }
 };
 
-template <int LMAX>
+template <int LMAX, bool MODEB = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_wave_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long b = blockIdx.x;
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     out.iters = so.iters ? so.iters + b : nullptr;
     DevWaveExec ex;
     ex.tid = (int)threadIdx.x; ex.nt = 64; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
-    solve_problem_wave<LMAX>(ex, md, ws, Md + b * md_stride, out);
+    solve_problem_wave<LMAX, MODEB>(ex, md, ws, Md + b * md_stride, out);
 }
 
 

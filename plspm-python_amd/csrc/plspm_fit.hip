@@ -155,10 +155,11 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
     HIPCHK(m, plspm_dmalloc((void**)&d_marks, 32 * sizeof(long long))); so.marks = d_marks;
 #endif
     if (dense && m->tune.solver_wave != 0 && wave_solver_covers<8>(m->P, m->L, m->n_chol)) {
-        // one wave per problem with fixed lane roles (solver_wave.h): Mode-A models of at most 64 MVs and 8 LVs
-        const size_t lds = (size_t)wave_ws_doubles<8>() * sizeof(double);
+        // one wave per problem with fixed lane roles (solver_wave.h): at most 64 MVs and 8 LVs; Mode-B blocks keep their inverses behind the workspace
+        const size_t lds = (size_t)wave_ws_doubles<8>(m->n_chol) * sizeof(double);
         ProfScope ps(m, PLSPM_K_SOLVER);
-        hipLaunchKernelGGL(solver_wave_kernel<8>, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        if (m->n_chol > 0) hipLaunchKernelGGL((solver_wave_kernel<8, true>), dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        else hipLaunchKernelGGL((solver_wave_kernel<8, false>), dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 3;
     } else if (dense) {
         m->last_solver = 2;

@@ -1,12 +1,15 @@
 // solver_wave.h -- the metric PLS-PM solver as ONE 64-lane wave per problem, written for the wave instead of for a generic
 // thread group: the batched solver of bootstrap replicates for the model class the reference's own
-// examples and BASELINE.json's headline live in -- at most 64 MVs, at most LMAX = 8 LVs, Mode A blocks.
+// examples and BASELINE.json's headline live in -- at most 64 MVs, at most LMAX = 8 LVs; Mode A blocks, and (round 4) Mode B blocks whose
+// k x k inverses fit the staging area together (sum k^2 <= 1,056: e.g. six blocks of 13, one of 32).
 // Everything else keeps solve_problem_rows / solve_problem (solver_core.h), whose arithmetic this restates:
 //   Config.treat              plspm/config.py:299-305, util.treat plspm/util.py:33-39   -> treat block
 //   _MetricWeights.__init__   plspm/weights.py:28-39                                     -> init (block products with w = 1)
 //   _MetricWeights.iterate    plspm/weights.py:41-54                                     -> iteration loop
 //   Scheme.*.calculate        plspm/scheme.py:27-28, 36-37, 45-54                        -> inner weights on the pair lanes / LV lanes
 //   _ModeA.outer_weights_metric plspm/mode.py:28-29                                      -> outer step
+//   _ModeB.outer_weights_metric plspm/mode.py:50-52 (lstsq of z on the block)            -> outer step: w_b = S_bb^-1 (S Wn E)_b with the inverse
+//                                                                                           of every Mode-B block formed ONCE per problem
 //   WeightsCalculatorFactory.calculate plspm/weights.py:172-187                          -> stop rule
 //   _MetricWeights.calculate  plspm/weights.py:56-70                                     -> finalize, sign rule
 //   InnerModel / _effects     plspm/inner_model.py:58-75, 33-53                          -> inner model, effects
@@ -41,8 +44,11 @@ struct WaveWs {
     double *Qm, *Gm, *Em, *Cs, *Bm, *Ind;      // [LMAX * LMAX], entry (l, m) at l * LMAX + m
     double *a, *r2;  // [LMAX]
     double* sink;    // [LMAX] where the idle lanes of seg_products store
+    double* inv;     // [sum over the Mode-B blocks of k^2] (S_bb)^-1 (or the pseudo-inverse of a rank-deficient block), full k x k, block l at chol_off[l] / 2
 };
+// (+ n_chol / 2 doubles behind it for the Mode-B inverses: ModelDesc::n_chol counts chol_block_doubles(k) = 2 k^2 per Mode-B block)
 template <int LMAX> PLSPM_HD constexpr long wave_ws_doubles() { return 16 * 66 + 64 + 64 + 6 * LMAX * LMAX + 2 * LMAX + LMAX; }
+template <int LMAX> PLSPM_HD constexpr long wave_ws_doubles(int n_chol) { return wave_ws_doubles<LMAX>() + n_chol / 2; }
 template <int LMAX> PLSPM_HD void wave_carve(WaveWs<LMAX>& ws, double* base) {
     static_assert(2 * 64 * LMAX <= 16 * 66, "V and T fit the staging area");
     static_assert(LMAX * (2 * (LMAX - 1) * (LMAX - 1) + (LMAX - 1)) <= 16 * 66, "so does the scratch of LMAX regressions on LMAX - 1 predecessors");
@@ -52,10 +58,12 @@ template <int LMAX> PLSPM_HD void wave_carve(WaveWs<LMAX>& ws, double* base) {
     ws.Qm = p; p += LMAX * LMAX; ws.Gm = p; p += LMAX * LMAX; ws.Em = p; p += LMAX * LMAX;
     ws.Cs = p; p += LMAX * LMAX; ws.Bm = p; p += LMAX * LMAX; ws.Ind = p; p += LMAX * LMAX;
     ws.a = p; p += LMAX; ws.r2 = p; p += LMAX;
-    ws.sink = p;
+    ws.sink = p; p += LMAX;
+    ws.inv = p;
 }
 // What the wave solver covers (the host asks before it launches; everything else takes solve_problem_rows / solve_problem).
-template <int LMAX> PLSPM_HD bool wave_solver_covers(int P, int L, int n_chol) { return P >= 1 && P <= 64 && L >= 1 && L <= LMAX && n_chol == 0; }
+// Mode-B blocks: their inverses are formed by an out-of-place Gauss-Jordan sweep that ping-pongs between ws.inv and the staging area.
+template <int LMAX> PLSPM_HD bool wave_solver_covers(int P, int L, int n_chol) { return P >= 1 && P <= 64 && L >= 1 && L <= LMAX && n_chol / 2 <= 16 * 66; }
 
 // 1 / sqrt(x) and 1 / x to the last bit or two (not correctly rounded): v_rsq_f64 / v_rcp_f64 seeds + Newton steps on the device -- a
 // fraction of the dependent instructions of the IEEE sqrt + divide sequences, which sit on the critical path of every small phase.
@@ -137,7 +145,8 @@ PLSPM_HD bool wave_ldl4(const double* M, int ld, unsigned fpack, int k, int col,
 
 // Md: the DENSE moment matrix [(P+1) x cov_ld(P)] of the mean-shifted columns + ones, upper triangle (entry (r, c >= r) at r * PS + c),
 // as the int8 digit-plane Gram writes it.  Outputs: out.row / out.status / out.iters (a bootstrap record).
-template <int LMAX, class Ex>
+// MODEB: the model has Mode-B blocks (an instantiation of its own: the all-Mode-A code -- the headline's -- stays as it was, register for register)
+template <int LMAX, bool MODEB = false, class Ex>
 PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>& ws, const double* Md, const FitOutputs& out) {
     constexpr int PMAX = 64, LL = LMAX * LMAX, WAVE_REG_SCRATCH = 2 * (LMAX - 1) * (LMAX - 1) + (LMAX - 1);
     static_assert(LL <= 64, "one pair lane per entry of an L x L matrix");
@@ -212,6 +221,75 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     // (loop constants in SCALAR registers: every lane holds the same value; as vector registers they were spilled around the loop)
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);
+
+
+    // Mode-B blocks (mode.py:50-52: w_b = argmin |X_b w - z| = S_bb^-1 (X_b' z / N)): S_bb does not change over the iterations, so its
+    // inverse is formed once.  Gauss-Jordan sweep without pivoting (S_bb is positive definite; pivot j is the same Schur complement the
+    // Cholesky factorisation of solver_core.h tests, so a rank-deficient block is recognised by the same rule), every MV lane of a Mode-B
+    // block owning ROW i of its k x k matrix, all blocks at once, out of place: step j reads A, writes A' -- no lane reads what another
+    // rewrites in the same step, ONE exchange per step -- ping-ponging between ws.inv and the staging area (free until the first S W).
+    //     i == j:  A'[j][c] = A[j][c] / piv  (c != j),  A'[j][j] = 1 / piv
+    //     i != j:  A'[i][c] = A[i][c] - A[i][j] A[j][c] / piv  (c != j),  A'[i][j] = -A[i][j] / piv
+    // A block whose sweep meets a pivot that is not safely positive takes the minimum-norm route of the reference's gelsd (jacobi_pinv, on
+    // its LV lane, one such block at a time in the staging area) -- the outer step multiplies with the full symmetric matrix either way.
+    const bool modeb = MODEB && mine && md.mode[lp] == MODE_B;
+    const int bb0 = md.boff[lp], bk = md.boff[lp + 1] - bb0, bi = p - bb0;
+    const long boffB = modeb ? md.chol_off[lp] / 2 : 0;
+    if constexpr (MODEB) {
+        int kbB = 0;
+        for (int l = 0; l < L; ++l) if (md.mode[l] == MODE_B) { const int k = md.boff[l + 1] - md.boff[l]; kbB = k > kbB ? k : kbB; }
+        ex.sync();                                              // (every lane is done with the column sums ws.mu held)
+        ws.mu[p] = sdp * sdp;                                   // the treated diagonal S_pp: the scale a pivot is measured against
+        double* A = (kbB & 1) ? ws.stage : ws.inv;              // an odd number of steps ends in ws.inv
+        double* An = (kbB & 1) ? ws.inv : ws.stage;
+        auto fill_block = [&](double* dst) {                    // row bi of S_bb out of the column registers (S is symmetric)
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q)
+                if (modeb && q >= bb0 && q < bb0 + bk) dst[boffB + bi * bk + (q - bb0)] = s[q];
+        };
+        fill_block(A);
+        ex.sync();
+        bool okrow = true;
+        for (int j = 0; j < kbB; ++j) {
+            if (modeb) {
+                const double* Ab = A + boffB;
+                double* Ob = An + boffB;
+                if (j < bk) {
+                    const double piv = Ab[j * bk + j];
+                    okrow = okrow && (piv > PLSPM_PIVOT_RTOL * ws.mu[bb0 + j]);
+                    const double ip = 1.0 / piv;
+                    const double f = Ab[bi * bk + j];
+                    for (int c = 0; c < bk; ++c) {
+                        const double rjc = Ab[j * bk + c] * ip;
+                        double v;
+                        if (bi == j) v = (c == j) ? ip : rjc;
+                        else v = (c == j) ? -f * ip : Ab[bi * bk + c] - f * rjc;
+                        Ob[bi * bk + c] = v;
+                    }
+                } else {
+                    for (int c = 0; c < bk; ++c) Ob[bi * bk + c] = Ab[bi * bk + c];      // a smaller block waits out the larger ones' steps
+                }
+            }
+            ex.sync();
+            double* t = A; A = An; An = t;
+        }
+        // rank-deficient blocks, one at a time: S_bb once more from the registers, pseudo-inverse on the block's LV lane (scratch: the staging area)
+        for (int l = 0; l < L; ++l) {
+            if (md.mode[l] != MODE_B) continue;
+            const int k = md.boff[l + 1] - md.boff[l];
+            const bool bad_here = ex.vote_any(modeb && lp == l && !okrow);
+            if (!bad_here) continue;
+            if (lp == l) fill_block(ws.inv);
+            ex.sync();
+            if (p == l) {
+                double* F = ws.inv + md.chol_off[l] / 2;
+                bool ok = k > 1 && jacobi_pinv(F, k, ws.stage);
+                if (!ok) singular = true;
+                for (int r = 0; r < k; ++r) for (int c = 0; c < r; ++c) F[r * k + c] = F[c * k + r];      // jacobi_pinv leaves the upper triangle
+            }
+            ex.sync();
+        }
+    }
 
     // LV role: normal equations M[f, f] x = M[f, p] over my predecessors f -- up to four in registers (wave_ldl4: every LV lane runs the
     // same straight-line code, identity-padded), five to LMAX - 1 by Cholesky in LDS scratch; a rank-deficient system takes the
@@ -326,7 +404,20 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
             if (m + 1 < L) c1 += ws.a[m + 1] * Vp[m + 1] * ws.Em[(m + 1) * LMAX + lpl];
         }
         if (LMAX & 1) { if (LMAX - 1 < L) c0 += ws.a[LMAX - 1] * Vp[LMAX - 1] * ws.Em[(LMAX - 1) * LMAX + lpl]; }
-        const double wn = mine ? c0 + c1 : 0.0;
+        double wn = mine ? c0 + c1 : 0.0;
+        if constexpr (MODEB) {                                   // Mode B: w_b = S_bb^-1 c_b  (mode.py:51)
+            ws.mu[pl] = wn;
+            ex.sync();
+            if (modeb) {
+                const double* Ib = ws.inv + boffB + bi * bk;
+                const double* cb = ws.mu + bb0;
+                double a0 = 0.0, a1 = 0.0;
+                int q = 0;
+                for (; q + 1 < bk; q += 2) { a0 += Ib[q] * cb[q]; a1 += Ib[q + 1] * cb[q + 1]; }
+                if (q < bk) a0 += Ib[q] * cb[q];
+                wn = a0 + a1;
+            }
+        }
         const double dd = fabs(wp) - fabs(wn);
         const double conv = ex.allsum(dd * dd);
         wp = wn;

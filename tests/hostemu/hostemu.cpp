@@ -341,7 +341,7 @@ int hostemu_solve_wave(int P, int L, int PA, int scheme, int scaled, int max_ite
     EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
     if (!wave_solver_covers<8>(P, L, em.md.n_chol)) return 1;
     const int nthreads = 64;
-    std::vector<double> lds(wave_ws_doubles<8>(), 0.0), red(nthreads);
+    std::vector<double> lds(wave_ws_doubles<8>(em.md.n_chol), 0.0), red(nthreads);
     FitOutputs out{};
     out.row = row; out.iters = iters; out.status = status;
     std::barrier<> bar(nthreads);
@@ -351,7 +351,8 @@ int hostemu_solve_wave(int P, int L, int PA, int scheme, int scaled, int max_ite
             WaveWs<8> ws{};
             wave_carve(ws, lds.data());
             HostExec ex{t, nthreads, &bar, red.data()};
-            solve_problem_wave<8>(ex, em.md, ws, Md, out);
+            if (em.md.n_chol > 0) solve_problem_wave<8, true>(ex, em.md, ws, Md, out);
+            else solve_problem_wave<8, false>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

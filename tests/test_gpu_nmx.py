@@ -185,3 +185,42 @@ def test_api_reproduces_reference_russa_missing_data_test():
     boot = Plspm(russa, build(), Scheme.CENTROID, 100, 0.0000001, bootstrap=True, bootstrap_iterations=200, seed=11).bootstrap()
     w = boot.weights()
     assert np.all(np.isfinite(w[["mean", "std.error"]].values)) and int((boot.status() == 0).sum()) >= 190
+
+
+def test_digit_planes_prepared_before_the_incomplete_rows_are_rebuilt():
+    """upload -> plspm_bootstrap_prepare -> plspm_model_set_incomplete_rows is a natural order for a C-ABI caller.  The set call
+    zeroes the incomplete rows of the resident matrix, so digit planes (or column statistics) prepared before it describe rows that no
+    longer exist: the library must discard them.  Same records as a handle that never prepared early, and as the fp64 route."""
+    from plspm import _native
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(3000, C, 4, seed=29)
+    rs = np.random.RandomState(5)
+    Xn = X.copy()
+    for row in rs.choice(3000, size=90, replace=False):
+        Xn[row, rs.choice(24, size=rs.randint(1, 3), replace=False)] = np.nan
+    model = orc.Model(blocks, C, "AAAAAA", "centroid", True, tol=1e-7, scales=["NUM"] * 24)
+    Xn = orc.filter_missing(Xn, model)
+    ref, _ = gpu_model(Xn, model)
+    want = ref.bootstrap(40, seed=11)
+    assert ref.get_option("last_gram_path") == 2
+    for fixed_planes in (0, 7):              # automatic plane count (statistics in flight) and a fixed one (planes cut by the prepare call itself)
+        order = model.mv_order
+        filled, rows, Mk = split_incomplete(np.ascontiguousarray(Xn[:, order]))
+        boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
+        nm = _native.NativeModel(boff, model.C.astype(np.uint8), np.zeros(6, dtype=np.int32), SCHEME_ID[model.scheme], True, model.max_iter, model.tol, 0, nonmetric=True)
+        nm.upload(filled)
+        if fixed_planes:
+            nm.set_option("i8_slices", fixed_planes)
+        nm.prepare_bootstrap()
+        nm.set_incomplete_rows(rows, Mk > 0, raw_scale=False)
+        got = nm.bootstrap(40, seed=11)
+        assert nm.get_option("last_gram_path") == 2 and np.all(got[1] == 0)
+        assert np.array_equal(got[2], want[2])
+        if fixed_planes:
+            assert_close(got[0], want[0], 1e-10, 1e-12)
+        else:
+            assert np.array_equal(got[0], want[0])
+        nm.set_option("gram_path", 1)
+        f64 = nm.bootstrap(40, seed=11)
+        assert np.array_equal(f64[2], want[2])
+        assert_close(f64[0], want[0], 1e-9, 1e-12)

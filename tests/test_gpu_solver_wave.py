@@ -118,7 +118,7 @@ def test_wave_solver_model_shapes(sizes, scheme):
 
 def test_wave_solver_status_codes_and_fallbacks():
     """Not-converged counter (weights.py:181-186), a constant MV, collinear predecessor scores (minimum-norm coefficients, golden g14);
-    Mode-B blocks and 9 LVs are outside the class and take the rows solver."""
+    9 LVs and Mode-B blocks whose inverses exceed the staging area are outside the class and take the rows solver."""
     from test_oracle_golden import g14_case
     X, blocks, _ = satisfaction_oracle_inputs()
     tight = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True, max_iter=2, tol=1e-12)
@@ -140,8 +140,9 @@ def test_wave_solver_status_codes_and_fallbacks():
     ok = out["wave"][1] == 0
     assert ok.sum() >= 30
     assert_close(out["wave"][0][ok], out["lds"][0][ok], 1e-9, 1e-11)
-    nm = native_model(orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "path", True))
-    nm.upload(X, tight.mv_order.astype(np.int32)); nm.set_option("gram_path", 2)
+    Xw, bw = orc.synth(300, orc.chain_C(2), 30, seed=2)                  # two Mode-B blocks of 30 MVs: 1,800 doubles of inverses > 1,056
+    nm = native_model(orc.Model(bw, orc.chain_C(2), "BB", "path", True))
+    nm.upload(Xw); nm.set_option("gram_path", 2)
     nm.bootstrap(16, seed=1)
     assert nm.get_option("last_solver") == 2
     C9 = orc.chain_C(9)
@@ -150,3 +151,47 @@ def test_wave_solver_status_codes_and_fallbacks():
     nm.upload(X9); nm.set_option("gram_path", 2)
     nm.bootstrap(16, seed=1)
     assert nm.get_option("last_solver") == 2
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("modes", ["BBBBBB", "ABABAB"])
+def test_wave_solver_mode_b_blocks(modes, scheme):
+    """Round 4: Mode-B blocks on the wave solver (inverse of every S_bb by a Gauss-Jordan sweep on the block's MV lanes, once per problem; the
+    reference solves lstsq(X_b, z) in every iteration, mode.py:50-52).  Same iteration counts as the rows and LDS solvers (Cholesky factor +
+    triangular solves), records to 1e-10; replicates against the oracle on the same indices; the reference's rows of golden g14 (a duplicated
+    and a linearly dependent MV inside Mode-B blocks: gelsd's minimum-norm weights) on explicit indices."""
+    from plspm import _native
+    from test_oracle_golden import g14_case
+    X, blocks = orc.synth(3000, orc.satisfaction_C(), 10, seed=9)
+    for scaled in (False, True):
+        model = orc.Model(blocks, orc.satisfaction_C(), modes, scheme, scaled)
+        nm = native_model(model)
+        nm.upload(X)
+        out = _three_solvers(nm, 300, 3)
+        rows, status, iters = out["wave"]
+        assert np.all(status == 0)
+        for other in ("rows", "lds"):
+            assert np.array_equal(out[other][1], status) and np.array_equal(out[other][2], iters), other
+            assert_close(out[other][0], rows, 1e-10, 1e-12)
+        corr = orc.correction(3000)
+        for r in (0, 299):
+            mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(3, r, 3000), corr)
+            assert its == iters[r]
+            assert_close(rows[r], mine, RTOL, ATOL)
+    g = load("g14_rank_deficient")
+    Xa, blocks_a, Ca = g14_case(g, "a")
+    key = "a_%s_%s_1" % ("B" if modes == "BBBBBB" else "M", scheme)
+    model = orc.Model(blocks_a, Ca, modes if modes == "BBBBBB" else "BABABA", scheme, True)
+    nm = native_model(model)
+    nm.upload(Xa, model.mv_order.astype(np.int32)); nm.set_option("gram_path", 2)
+    if key + "/boot_rows" in g.files:
+        rows, status, iters = nm.bootstrap(len(g["idx"]), idx=g["idx"].astype(np.int32))
+        assert nm.get_option("last_solver") == 3 and np.all(status == 0) and np.array_equal(iters, g[key + "/boot_iters"])
+        inv = np.empty(len(model.mv_order), dtype=np.int64); inv[model.mv_order] = np.arange(len(model.mv_order))
+        P, L = len(inv), model.L
+        ne = (rows.shape[1] - 2 * P - L) // 2
+        mine = np.concatenate((rows[:, :P][:, inv], rows[:, P:P + L + 2 * ne], rows[:, P + L + 2 * ne:][:, inv]), axis=1)
+        assert_close(mine, g[key + "/boot_rows"], RTOL, 1e-8)
+    out = _three_solvers(nm, 64, 5)
+    assert np.array_equal(out["wave"][1], out["lds"][1]) and np.array_equal(out["wave"][2], out["lds"][2])
+    assert_close(out["wave"][0], out["lds"][0], 1e-8, 1e-10)

@@ -157,9 +157,71 @@ def test_wave_status_codes_and_rank_deficient_predecessors(emu):
         assert_close(e["r2"], r["r2"], RTOL, 1e-12)
 
 
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("modes", ["BBBBBB", "ABABAB", "BAAAAB"])
+def test_wave_mode_b_blocks_vs_oracle_and_rows_variant(emu, scheme, modes):
+    """Round 4: Mode-B blocks in the wave formulation -- the inverse of every S_bb by an out-of-place Gauss-Jordan sweep on the block's MV
+    lanes, once per problem; the outer step is a k-term product per lane (mode.py:50-52).  Against the oracle (lstsq on the data) and the
+    rows variant (Cholesky factor + two triangular solves per iteration): same iteration counts."""
+    X, blocks, _ = satisfaction_oracle_inputs()
+    for scaled in (False, True):
+        model = orc.Model(blocks, orc.satisfaction_C(), modes, scheme, scaled)
+        e = run_wave(emu, X, model)
+        assert e is not None
+        check(e, orc.fit(X, model), "wave %s %s/%d" % (modes, scheme, scaled))
+        base = run_emu(emu, X, model, rows=True)
+        assert e["iterations"] == base["iterations"]
+        assert_close(e["row"], base["row"], 1e-10, 1e-12)
+    Xs, bs = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    model = orc.Model(bs, orc.satisfaction_C(), modes, scheme, True)
+    rng = np.random.default_rng(6)
+    idx = rng.integers(0, 2000, 2000)
+    e = run_wave(emu, Xs, model, counts=np.bincount(idx, minlength=2000), shift=Xs[:, model.mv_order].mean(axis=0))
+    mine, its = orc.bootstrap_replicate(Xs, model, idx, orc.correction(2000))
+    assert e["status"] == 0 and e["iterations"] == its
+    assert_close(np.concatenate((e["weights"], e["r2"], e["total"], e["direct"], e["loadings"])), mine, RTOL, 1e-12)
+
+
+def test_wave_mode_b_rank_deficient_blocks_take_the_minimum_norm_route(emu):
+    """A duplicated MV and an MV that is a linear combination of others inside Mode-B blocks (golden g14 from the real reference: gelsd's
+    minimum-norm weights), blocks of 1 MV, ragged sizes."""
+    from helpers import load
+    from test_oracle_golden import g14_case
+    g = load("g14_rank_deficient")
+    Xa, blocks_a, Ca = g14_case(g, "a")
+    from helpers import case_modes
+    for mtag in ("B", "M"):
+        for scheme in ("centroid", "factorial", "path"):
+            for scaled in (0, 1):
+                key = "a_%s_%s_%d" % (mtag, scheme, scaled)
+                model = orc.Model(blocks_a, Ca, case_modes(mtag, mixed="BABABA"), scheme, bool(scaled))
+                e = run_wave(emu, Xa, model)
+                assert e is not None and e["status"] == 0 and e["iterations"] == int(g[key + "/iters"]), key
+                assert_close(e["weights"], g[key + "/weights"], RTOL, what=key)
+    rs = np.random.RandomState(9)
+    C = orc.chain_C(4)
+    sizes = [1, 13, 2, 6]
+    N = 500
+    eta = np.zeros((N, 4))
+    for j in range(4):
+        eta[:, j] = 0.5 * eta[:, C[j] == 1].sum(axis=1) + rs.standard_normal(N)
+    cols, blocks, c0 = [], [], 0
+    for j, k in enumerate(sizes):
+        cols.append(eta[:, [j]] * np.linspace(0.5, 0.9, k) + 0.6 * rs.standard_normal((N, k)))
+        blocks.append(np.arange(c0, c0 + k)); c0 += k
+    X = np.column_stack(cols)
+    for modes in ("BBBB", "BABA"):
+        for scheme in ("centroid", "path"):
+            model = orc.Model(blocks, C, modes, scheme, True)
+            e = run_wave(emu, X, model)
+            assert e is not None
+            check(e, orc.fit(X, model), "%s %s" % (modes, scheme))
+
+
 def test_wave_declines_models_outside_its_class(emu):
     X, blocks, _ = satisfaction_oracle_inputs()
-    assert run_wave(emu, X, orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "path", True)) is None         # Mode B blocks
+    Xw, bw = orc.synth(300, orc.chain_C(2), 30, seed=2)
+    assert run_wave(emu, Xw, orc.Model(bw, orc.chain_C(2), "BB", "path", True)) is None                    # two Mode-B blocks of 30: their inverses exceed the staging area
     C = orc.chain_C(9)
     Xs, bs = orc.synth(300, C, 3, seed=1)
     assert run_wave(emu, Xs, orc.Model(bs, C, "A" * 9, "path", True)) is None                              # 9 LVs
@@ -180,7 +242,7 @@ def test_wave_thread_sanitizer_clean():
     code = ("import sys; sys.path[:0]=[%r,%r]; import ctypes, numpy as np; import plspm_oracle as orc; import test_solver_hostemu_wave as t;"
             "from helpers import satisfaction_oracle_inputs;"
             "lib=ctypes.CDLL(%r); X,b,_=satisfaction_oracle_inputs();"
-            "[t.run_wave(lib, X, orc.Model(b, orc.satisfaction_C(), 'AAAAAA', s, True)) for s in ('centroid','path')];"
+            "[t.run_wave(lib, X, orc.Model(b, orc.satisfaction_C(), m, s, True)) for s in ('centroid','path') for m in ('AAAAAA', 'BABABB')];"
             "print('tsan-run-done')") % (HERE, os.path.join(os.path.dirname(HERE), "oracle"), os.path.join(EMU, "libplspm_hostemu_tsan.so"))
     tsan = subprocess.run(["bash", "-c", "ls /usr/lib/gcc/x86_64-linux-gnu/*/libtsan.so | head -1"], capture_output=True, text=True).stdout.strip()
     env = dict(os.environ, LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")

@@ -2,7 +2,7 @@
 # GPU-box script: everything that goes into profiles/ for one round.  usage: bash tools/gpu_profiles.sh r02
 # bench lines (plain, in-library group/RCCL, launcher), fit bench, non-metric bench, rocprofv3 kernel stats of the headline command,
 # HBM counters (separate --pmc passes, no trace domains), SQ counters of the headline Gram and of the configs[4] Gram.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
@@ -23,37 +23,36 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/prof_c5_pmc2 -o pmc2 -- python $R/tools/fit_bench.py c5 > $O/prof_c5_pmc2.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/prof_c5_fetch -o fetch -- python $R/tools/fit_bench.py c5 > $O/prof_c5_fetch.log 2>&1
 # the int8 digit-plane Gram and the rows solver of the headline step (interleaved A/B tool: every Gram variant runs full-size launches)
-timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_I8 -d $O/prof_i8_pmc1 -o pmc1 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc1.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH -d $O/prof_i8_pmc2 -o pmc2 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc2.log 2>&1
-timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum SQC_ICACHE_REQ SQC_ICACHE_MISSES -d $O/prof_i8_pmc3 -o pmc3 -- python $R/tools/i8_bench.py 5000 1 > $O/prof_i8_pmc3.log 2>&1
+# (round 4: tools/i8p_counters.py runs full-size launches of BOTH Gram kernels -- gram_i8p_kernel, the default, and the round-3 gram_i8_kernel -- so
+#  that one counter pass yields the A/B table of profiles/<tag>_pmc.md)
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_I8 -d $O/prof_i8_pmc1 -o pmc1 -- python $R/tools/i8p_counters.py > $O/prof_i8_pmc1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH -d $O/prof_i8_pmc2 -o pmc2 -- python $R/tools/i8p_counters.py > $O/prof_i8_pmc2.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum SQC_ICACHE_REQ SQC_ICACHE_MISSES -d $O/prof_i8_pmc3 -o pmc3 -- python $R/tools/i8p_counters.py > $O/prof_i8_pmc3.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA -d $O/prof_i8_pmc4 -o pmc4 -- python $R/tools/i8p_counters.py > $O/prof_i8_pmc4.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_i8_fetch -o f -- python $R/tools/i8p_counters.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/prof_i8_write -o w -- python $R/tools/i8p_counters.py > /dev/null 2>&1
 cd $R
-timeout 300 python tools/i8_bench.py 5000 4 2>&1 | grep "^{" > $O/i8_bench.jsonl
+timeout 300 python tools/i8p_bench.py 5000 5120 2>&1 | grep "^{" > $O/i8p_bench.jsonl
+I8P_SLICES=7 timeout 300 python tools/i8p_bench.py 5000 2>&1 | grep "^{" > $O/i8p_bench_s7.jsonl
+[ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so I8P_ABLATE=1 timeout 300 python tools/i8p_bench.py 5120 2>&1 | grep "^{" > $O/i8p_ablate.jsonl
+timeout 120 python tools/group_enqueue.py 2>/dev/null | grep "^{" > $O/group_enqueue.jsonl
+./tools/ubench/mfma_i8_fillers > $O/ubench_mfma_i8_fillers.jsonl 2>&1
 # round 3: the wave solver (A/B against the rows solver, kernel time against the batch size, SQ counters of both), sizes next to the headline,
 # co-scheduling experiments (narrow Gram tiles + two pipelines), ablation probes of the Gram (experiments build, if present)
 timeout 300 python tools/aux_ab.py solver_wave=0,1 2>&1 | grep "^{" > $O/ab_solver_wave.jsonl
 timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
 timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
-timeout 300 python tools/rt_check.py 2>&1 | grep "^{" > $O/i8_rt.jsonl
 timeout 300 python tools/i8_mix_calib.py 2>&1 | grep "^{" > $O/i8_mix_calib.jsonl
-[ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && I8_SHORT=5 PLSPM_HIP_LIB=plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so timeout 300 python tools/i8_variants20.py 3 0 1 4 5 103 203 403 703 2>&1 | grep "^{" > $O/i8_variants20.jsonl
-timeout 300 python tools/two_pipelines.py 2>&1 | grep "^{" > $O/two_pipelines.jsonl
-timeout 300 python tools/two_pipelines.py i8_rt=8 2>&1 | grep "^{" >> $O/two_pipelines.jsonl
-[ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so timeout 300 python tools/i8_ablate.py 2>&1 | grep "^{" > $O/i8_ablate.jsonl
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks.py > $O/solver_marks.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $O/prof_solver_pmc1 -o p1 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC -d $O/prof_solver_pmc2 -o p2 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_solver_fetch -o f -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/prof_solver_write -o w -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1)
 python tools/pmc_rows.py $O solver > $O/solver_pmc.txt 2>&1
-timeout 300 python tools/aux_ab.py i8_sched=0,1 2>&1 | grep "^{" > $O/ab_stream_k.jsonl
-timeout 300 python tools/aux_ab.py i8_waves=4,8 2>&1 | grep "^{" > $O/ab_i8_waves.jsonl
+timeout 300 python tools/aux_ab.py i8_priv=0,1 2>&1 | grep "^{" > $O/ab_i8_priv.jsonl
 timeout 300 python tools/aux_ab.py i8_slices=0,7 2>&1 | grep "^{" > $O/ab_i8_slices.jsonl
-timeout 300 python tools/i8_dma_form.py 2>&1 | grep "^{" > $O/i8_dma_form.jsonl
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --hip-trace --memory-copy-trace --output-format csv -d /tmp/tl -o tl -- python $R/tools/api_timeline.py run > $O/api_timeline.txt 2>/dev/null; python $R/tools/api_timeline.py read /tmp/tl >> $O/api_timeline.txt 2>&1)
-timeout 300 python tools/aux_ab.py resample_aux=0,1,2,3 2>&1 | grep "^{" > $O/ab_resample_aux.jsonl
 timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench.json
-(for v in 0 1 0 1; do CAT_NM_CODES=$v timeout 300 python tools/categorical_bench.py 2>&1 | tail -1; done) > $O/ab_nm_codes.jsonl
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && CAT_BENCH_STEPS=1 PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/categorical_bench.py 1000 2>&1 | grep clocks | tail -4 > $O/categorical_marks.txt
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/cp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/categorical_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/categorical_kernels.txt 2>&1; rm -rf /tmp/cp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/nonmetric_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/nonmetric_kernels.txt 2>&1)
 timeout 600 python tools/hoc_bench.py 2>&1 | tail -1 > $O/hoc_bench.json
-./tools/ubench/valu_issue > $O/ubench_valu_issue.txt 2>&1
 python - "$O" <<'PY'
 import sqlite3, glob, sys, json
 O = sys.argv[1]

@@ -1,6 +1,6 @@
 """The int8 Gram with private count fragments (kernels_gram_i8p.h, set_option("i8_priv", 1)) against the round-3 kernel: Gram time from the
 library's HIP events over alternating rounds, step time of un-profiled steps, bit-identity of the records.
-usage: i8p_bench.py [B ...]            (PLSPM_HIP_LIB=.../libplspm_hip_exp.so I8P_ABLATE=1: the ablation probes of the new kernel as well)"""
+usage: i8p_bench.py [B ...]            (PLSPM_HIP_LIB=.../libplspm_hip_exp.so with I8P_ABLATE=1 / I8P_VARIANTS=1: ablation probes / schedule variants as well)"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,15 +17,19 @@ nm.upload(X)
 if slices: nm.set_option("i8_slices", slices)
 for w in range(60): nm.bootstrap_device(5000, seed=1, rep_offset=w * 5000)
 nm.sync()
-modes = [int(x) for x in os.environ.get("I8P_MODES", "1,3").split(",")]
-configs = [("r3", {"i8_priv": 0})]
-for pv in modes: configs += [("priv%d" % pv, {"i8_priv": pv}), ("priv%d_alltall" % pv, {"i8_priv": pv, "i8_rt": 20})]
-if os.environ.get("I8P_ABLATE"):
-    for pv in modes:
+configs = [("r3", {"i8_priv": 0}), ("priv", {"i8_priv": 1}), ("priv_alltall", {"i8_priv": 1, "i8_rt": 20})]
+if os.environ.get("I8P_ABLATE") or os.environ.get("I8P_VARIANTS"):
+    # experiments build: "i8_variant" is the kernel template's VAR -- bits 0-3 ablations (1 no LDS-DMA, 2 no barrier, 4 no fragment reads, 8 no count
+    # loads), 16 digit blocks through staging registers, 32 / 64 the filler schedules (64 = the release kernel), 128 one barrier per two k-steps
+    if os.environ.get("I8P_VARIANTS"):
+        for v in (0, 32, 64, 16, 128, 192):
+            configs.append(("var%d_alltall" % v, {"i8_priv": 1, "i8_variant": v, "i8_rt": 20}))
+    if os.environ.get("I8P_ABLATE"):
         for v, what in ((1, "no_dma"), (2, "no_barrier"), (4, "no_reads"), (8, "no_count_loads"), (5, "no_dma_no_reads"), (13, "no_dma_reads_loads"), (15, "mfma_only")):
-            configs.append(("priv%d_" % pv + what, {"i8_priv": pv, "i8_variant": v, "i8_rt": 20}))
+            configs.append(("priv_" + what, {"i8_priv": 1, "i8_variant": 64 + v, "i8_rt": 20}))
 def apply(opts):
-    nm.set_option("i8_priv", 0); nm.set_option("i8_variant", -1); nm.set_option("i8_rt", 0)
+    nm.set_option("i8_priv", 1); nm.set_option("i8_rt", 0)
+    if nm.get_option("build_experiments"): nm.set_option("i8_variant", -1)
     for k, v in opts.items(): nm.set_option(k, v)
 for B in Bs:
     apply({})

@@ -75,7 +75,7 @@ def main():
         fh.write("\n".join(lines) + "\n")
     with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.json" % tag), "w") as fh:
         json.dump(out, fh, indent=1)
-    for prefix, fname in (("gram_i8_kernel", "%s_gram_i8_traffic.json"), ("gram_rows_kernel", "%s_gram_traffic.json")):
+    for prefix, fname in (("gram_i8_kernel", "%s_gram_i8_traffic.json"), ("gram_i8p_kernel", "%s_gram_i8_traffic.json"), ("gram_rows_kernel", "%s_gram_traffic.json")):
         gram = [k for k in out["counters"] if k.startswith(prefix)]
         if gram:
             with open(os.path.join(ROOT, "profiles", fname % tag), "w") as fh:
