@@ -127,6 +127,9 @@ struct plspm_model {
     void* h_pin = nullptr;
     size_t h_pin_cap = 0;
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    hipEvent_t ev_pin_async = nullptr;   // behind copies that left the staging area without a host wait (plspm_hip.hip pin_leave_async)
+    bool pin_pending = false;
+    std::vector<void*> blobs;     // descriptor blocks (several small arrays uploaded as one: plspm_hip.hip upload_blob)
     void* group = nullptr;        // the plspm_group this handle currently belongs to (plspm_group.cpp)
     bool profiling = false;
     int prof_only = -1;          // >= 0: only this kernel id is bracketed by events (plspm_profile_enable(m, 2 + id))

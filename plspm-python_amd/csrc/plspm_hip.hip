@@ -169,11 +169,38 @@ static void drop_incomplete_rows(plspm_model* m) {
     m->d_Xk = m->d_Mk = nullptr; m->d_rowid = nullptr; m->nmx_K = 0;
 }
 
+// Several small descriptor arrays as ONE device block and ONE staged copy: a blocking hipMemcpy costs a host round trip each (~20 us on a busy
+// device, 50-90 us on one coming out of idle), and plspm_model_create made eleven of them -- most of what a Plspm() call waited for
+// besides its kernels (tools/api_pyprofile.py).  The block is freed with the handle (plspm_model::blobs).
+struct BlobPart { void** dst; const void* src; size_t bytes; };
+static int pin_leave_async(plspm_model* m);
+static int upload_blob(plspm_model* m, const std::vector<BlobPart>& parts) {
+    size_t total = 0;
+    std::vector<size_t> off(parts.size());
+    for (size_t i = 0; i < parts.size(); ++i) { off[i] = total; total += (std::max<size_t>(parts[i].bytes, 1) + 63) & ~(size_t)63; }
+    void* blob = nullptr;
+    HIPCHK(m, plspm_dmalloc(&blob, total));
+    m->blobs.push_back(blob);
+    if (total > kPinHalf) return fail(m, PLSPM_E_LIMIT, "descriptor block exceeds the staging area");
+    int rc = pin_ready(m);
+    if (rc) return rc;
+    char* host = (char*)m->h_pin;
+    memset(host, 0, total);
+    for (size_t i = 0; i < parts.size(); ++i) {
+        if (parts[i].bytes) memcpy(host + off[i], parts[i].src, parts[i].bytes);
+        *parts[i].dst = (char*)blob + off[i];
+    }
+    HIPCHK(m, hipMemcpyAsync(blob, host, total, hipMemcpyHostToDevice, m->stream));
+    return pin_leave_async(m);                                   // no host wait: whoever uses the staging area or the descriptors next is ordered behind the copy
+}
+template <class Tv> static BlobPart blob_part(Tv** dst, const std::vector<Tv>& v) { return BlobPart{(void**)dst, v.data(), v.size() * sizeof(Tv)}; }
+
 template <class Tv>
 static int upload_vec(plspm_model* m, Tv** dst, const std::vector<Tv>& v) {
     const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(Tv);
     HIPCHK(m, plspm_dmalloc((void**)dst, bytes));
-    if (!v.empty()) HIPCHK(m, hipMemcpy(*dst, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    // (on the handle's stream: its descriptor blocks travel there without a host wait, and a copy on the null stream is not ordered behind them)
+    if (!v.empty()) { HIPCHK(m, hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice, m->stream)); HIPCHK(m, hipStreamSynchronize(m->stream)); }
     return 0;
 }
 
@@ -241,10 +268,9 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
     auto bail = [&](const std::string& why) { g_create_error = why + (m->error.empty() ? "" : (": " + m->error)); plspm_model_destroy(m); return (plspm_model_t*)nullptr; };
     if (hipSetDevice(device_id) != hipSuccess) return bail("hipSetDevice failed");
     if (plspm_stream_acquire(&m->stream) != hipSuccess) return bail("hipStreamCreate failed");
-    if (upload_vec(m, &m->d_boff, m->boff) || upload_vec(m, &m->d_lvof, m->lvof) || upload_vec(m, &m->d_mode, m->mode) ||
-        upload_vec(m, &m->d_chol_off, m->chol_off) || upload_vec(m, &m->d_eff_from, m->eff_from) || upload_vec(m, &m->d_eff_to, m->eff_to) ||
-        upload_vec(m, &m->d_C, m->C) || upload_vec(m, &m->d_pred_off, m->pred_off) || upload_vec(m, &m->d_pred_idx, m->pred_idx) ||
-        upload_vec(m, &m->d_succ_off, m->succ_off) || upload_vec(m, &m->d_succ_idx, m->succ_idx))
+    if (upload_blob(m, {blob_part(&m->d_boff, m->boff), blob_part(&m->d_lvof, m->lvof), blob_part(&m->d_mode, m->mode), blob_part(&m->d_chol_off, m->chol_off),
+                        blob_part(&m->d_eff_from, m->eff_from), blob_part(&m->d_eff_to, m->eff_to), blob_part(&m->d_C, m->C), blob_part(&m->d_pred_off, m->pred_off),
+                        blob_part(&m->d_pred_idx, m->pred_idx), blob_part(&m->d_succ_off, m->succ_off), blob_part(&m->d_succ_idx, m->succ_idx)}))
         return bail("descriptor upload failed");
     if (plspm_dmalloc((void**)&m->d_shift, sizeof(double) * P) != hipSuccess) return bail("hipMalloc failed");
     if (plspm_hmalloc((void**)&m->h_flag, 64) != hipSuccess || hipEventCreateWithFlags(&m->ev_flag, hipEventDisableTiming) != hipSuccess)
@@ -266,10 +292,12 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
                     m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
-    for (void* p : ptrs) if (p) plspm_dfree(p);
+    for (void* p : ptrs) if (p) plspm_dfree(p);          // (pointers into a descriptor blob are not the allocator's: ignored there)
+    for (void* p : m->blobs) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
     for (int k = 0; k < 2; ++k) if (m->ev_pin[k]) hipEventDestroy(m->ev_pin[k]);
+    if (m->ev_pin_async) hipEventDestroy(m->ev_pin_async);
     for (int k = 0; k < PLSPM_K_COUNT; ++k) for (auto& pr : m->prof[k].pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (m->h_flag) plspm_hfree(m->h_flag);
     if (m->h_zstat) plspm_hfree(m->h_zstat);
@@ -324,9 +352,25 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     // host -> device through the handle's pinned staging halves (no page pinning per call); from 64 MB on several host threads fill
     // every half (plspm_detail_h2d).  The runtime's own pageable path ("upload_direct" 1) moved configs[4]'s 1.6 GB at 52 GB/s on one
     // box and at 13-15 GB/s on two others (its staging copy is one thread's memcpy)
-    if (raw_bytes <= ((size_t)64 << 20) || !m->tune.upload_direct) { if ((rc = plspm_detail_h2d(m, d_raw, X, raw_bytes))) return rc; }
-    else HIPCHK(m, hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
-    if ((rc = plspm_detail_h2d(m, d_ci, ci.data(), sizeof(int) * (size_t)Pg))) return rc;
+    const size_t ci_bytes = sizeof(int) * (size_t)Pg;
+    bool fast_upload = false;
+    if (raw_bytes + ci_bytes + 64 <= kPinHalf) {
+        // small data sets (the 4.8 MB of the 10k x 60 headline): matrix and column index through ONE staging half, both copies enqueued without a
+        // host wait -- the synchronise at the end of this call is the only round trip of the upload (it also covers the staging area's re-use)
+        if ((rc = pin_ready(m))) return rc;
+        char* stage = (char*)m->h_pin;
+        const size_t ci_off = (raw_bytes + 63) & ~(size_t)63;
+        memcpy(stage, X, raw_bytes);
+        memcpy(stage + ci_off, ci.data(), ci_bytes);
+        HIPCHK(m, hipMemcpyAsync(d_raw, stage, raw_bytes, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(m, hipMemcpyAsync(d_ci, stage + ci_off, ci_bytes, hipMemcpyHostToDevice, m->stream));
+        if ((rc = pin_leave_async(m))) return rc;                 // (the caller's X has been read: nothing below needs the host to wait)
+        fast_upload = true;
+    } else {
+        if (raw_bytes <= ((size_t)64 << 20) || !m->tune.upload_direct) { if ((rc = plspm_detail_h2d(m, d_raw, X, raw_bytes))) return rc; }
+        else HIPCHK(m, hipMemcpyAsync(d_raw, X, raw_bytes, hipMemcpyHostToDevice, m->stream));
+        if ((rc = plspm_detail_h2d(m, d_ci, ci.data(), ci_bytes))) return rc;
+    }
     {
         ProfScope ps(m, PLSPM_K_PACK);
         if (layout == 0) {
@@ -348,7 +392,9 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     }
     HIPCHK(m, hipMemsetAsync(d_Xa + (size_t)N * m->PA, 0, (size_t)m->PA * sizeof(double), m->stream));
     HIPCHK(m, hipGetLastError());
-    HIPCHK(m, hipStreamSynchronize(m->stream));          // X may be released by the caller on return
+    // X may be released by the caller on return: the small path has copied it into the staging area (the pack kernels run behind the copies
+    // on the handle's stream, like everything a later call enqueues); the chunked path waits for its last DMA
+    if (!fast_upload) HIPCHK(m, hipStreamSynchronize(m->stream));
     if (raw_bytes > ((size_t)1 << 30)) {                 // do not keep a multi-GB staging copy alive next to the resident matrix
         plspm_dfree(m->up_raw.p);
         m->up_raw.p = nullptr; m->up_raw.cap = 0;
@@ -491,16 +537,16 @@ int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_
     HIPCHK(m, hipSetDevice(m->device));
     m->mv_base.assign(Pm, 0);
     for (int p = 0; p < Pm; ++p) m->mv_base[p] = m->boff[m->mv_lv[p]];          // (category codes are filed relative to the MV's LV block: nm_conv_codes_kernel)
-    if (upload_vec(m, &m->d_mv_base, m->mv_base)) return fail(m, PLSPM_E_STATE, "descriptor upload failed: " + m->error);
-    if (upload_vec(m, &m->d_mv_off, m->mv_off) || upload_vec(m, &m->d_mv_kind, m->mv_kind) || upload_vec(m, &m->d_lmv_off, m->lmv_off) ||
-        upload_vec(m, &m->d_mv_lv, m->mv_lv) || upload_vec(m, &m->d_no_chol, m->no_chol))
-        return fail(m, PLSPM_E_STATE, "descriptor upload failed");
+    if (upload_blob(m, {blob_part(&m->d_mv_base, m->mv_base), blob_part(&m->d_mv_off, m->mv_off), blob_part(&m->d_mv_kind, m->mv_kind), blob_part(&m->d_lmv_off, m->lmv_off),
+                        blob_part(&m->d_mv_lv, m->mv_lv), blob_part(&m->d_no_chol, m->no_chol)}))
+        return fail(m, PLSPM_E_STATE, "descriptor upload failed: " + m->error);
     m->Pm = Pm; m->categorical = 1; m->nonmetric = 1; m->n_chol = 0;
     m->cat_pure = true;
     for (int p = 0; p < Pm; ++p) if (mv_kind[p] == 0) m->cat_pure = false;             // a NUM / RAW column: real-valued moments
     set_geometry(m);
     for (auto& c : m->chol_off) c = -1;
-    HIPCHK(m, hipMemcpy(m->d_chol_off, m->chol_off.data(), sizeof(int) * m->L, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemcpyAsync(m->d_chol_off, m->chol_off.data(), sizeof(int) * m->L, hipMemcpyHostToDevice, m->stream));      // (behind the descriptor block of plspm_model_create)
+    HIPCHK(m, hipStreamSynchronize(m->stream));
     return 0;
 }
 
@@ -555,8 +601,8 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     if (hcol.empty()) hcol.push_back(0), hcol.pop_back();
     HIPCHK(m1, hipSetDevice(m1->device));
     m2->lv_first.assign(lv_first, lv_first + L2 + 1); m2->col2_lv1 = col2_lv1; m2->col2_p1 = col2_p1; m2->hidx = hidx; m2->hcol = hcol; m2->lv_cols = lv_cols;
-    if (upload_vec(m2, &m2->d_lv_first, m2->lv_first) || upload_vec(m2, &m2->d_col2_lv1, m2->col2_lv1) || upload_vec(m2, &m2->d_col2_p1, m2->col2_p1) ||
-        upload_vec(m2, &m2->d_hidx, m2->hidx) || upload_vec(m2, &m2->d_hcol, m2->hcol) || upload_vec(m2, &m2->d_lv_cols, m2->lv_cols))
+    if (upload_blob(m2, {blob_part(&m2->d_lv_first, m2->lv_first), blob_part(&m2->d_col2_lv1, m2->col2_lv1), blob_part(&m2->d_col2_p1, m2->col2_p1),
+                         blob_part(&m2->d_hidx, m2->hidx), blob_part(&m2->d_hcol, m2->hcol), blob_part(&m2->d_lv_cols, m2->lv_cols)}))
         return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
     if (m1->categorical && (int)m1->mv_lv.size() == m1->Pm && (int)m1->lmv_off.size() == L1 + 1) {
         // category codes of the first stage's rows under the SECOND stage's blocks (nm_conv_codes_kernel): per first-stage MV the first
@@ -571,7 +617,7 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
         m2->mv_base2 = base2; m2->lmv2_off = lmv2;
         if (upload_vec(m2, &m2->d_mv_base2, m2->mv_base2) || upload_vec(m2, &m2->d_lmv2_off, m2->lmv2_off)) return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
     }
-    HIPCHK(m1, hipMemset(m2->d_shift, 0, sizeof(double) * m2->P));
+    HIPCHK(m1, hipMemsetAsync(m2->d_shift, 0, sizeof(double) * m2->P, m2->stream));
     HIPCHK(m1, hipStreamSynchronize(m2->stream));
     plspm_stream_release(m2->stream);
     m2->stream = m1->stream; m2->owns_stream = false;
@@ -630,10 +676,22 @@ int plspm_sync(plspm_model_t* m) {
 
 // ---- pinned staging: pageable host buffers never meet the DMA engines directly --------------------------------------------------
 int pin_ready(plspm_model* m) {
-    if (m->h_pin) return 0;
-    HIPCHK(m, plspm_hmalloc(&m->h_pin, 2 * kPinHalf));
-    m->h_pin_cap = 2 * kPinHalf;
-    for (int k = 0; k < 2; ++k) HIPCHK(m, hipEventCreateWithFlags(&m->ev_pin[k], hipEventDisableTiming));
+    if (!m->h_pin) {
+        HIPCHK(m, plspm_hmalloc(&m->h_pin, 2 * kPinHalf));
+        m->h_pin_cap = 2 * kPinHalf;
+        for (int k = 0; k < 2; ++k) HIPCHK(m, hipEventCreateWithFlags(&m->ev_pin[k], hipEventDisableTiming));
+        HIPCHK(m, hipEventCreateWithFlags(&m->ev_pin_async, hipEventDisableTiming));
+    }
+    // a copy that was enqueued out of the staging area WITHOUT a host wait (pin_leave_async: descriptor block of plspm_model_create, the small
+    // upload) must have read it before the next user writes there -- by now it has, as a rule, and the wait returns at once
+    if (m->pin_pending) { HIPCHK(m, hipEventSynchronize(m->ev_pin_async)); m->pin_pending = false; }
+    return 0;
+}
+
+// The caller enqueued copies out of the staging area on the handle's stream and returns without waiting for them: pin_ready() of the next user waits.
+static int pin_leave_async(plspm_model* m) {
+    HIPCHK(m, hipEventRecord(m->ev_pin_async, m->stream));
+    m->pin_pending = true;
     return 0;
 }
 

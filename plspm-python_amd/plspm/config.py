@@ -139,6 +139,7 @@ class Config:
         twin._mv_scales = dict(self._mv_scales)
         twin._metric = self._metric
         twin._missing = self._missing
+        twin._nan_seen = getattr(self, "_nan_seen", None)
         return twin
 
     # ------------------------------------------------------------------ queries
@@ -212,17 +213,38 @@ class Config:
         absent = set(wanted).difference(set(data))
         if absent:
             raise ValueError("The following manifest variables you configured are not present in the data set: " + ", ".join(absent))
-        data = data[wanted]
+        if list(data.columns) != wanted:                     # (the frame itself when it already holds exactly the configured columns in order: nothing
+            data = data[wanted]                              #  downstream writes to it, and the copy of a 10k x 60 frame is a third of a millisecond)
         if not all(np.issubdtype(dtype, np.number) for dtype in data.dtypes):
             raise ValueError("Data must only contain numeric values. Please convert any categorical data into numerical values.")
-        self._missing = bool(data.isnull().values.any())
+        # ONE pass over the values tells whether -- and in which columns -- cells are missing; plspm.py / weights.py ask nan_columns(data)
+        # instead of scanning the same matrix again (three scans were 0.6 ms of a 2.3 ms Plspm() call at 10k x 60)
+        nan_cols = self._scan_nan(data)
+        self._missing = bool(nan_cols.any())
         if self._missing:
             drop = np.zeros(len(data.index), dtype=bool)
             for lv in list(self.path()):
                 block = data[self.mvs(lv)].values.astype(np.float64)
                 drop |= np.isnan(block).all(axis=1)
-            data = data.loc[~drop]
+            if drop.any():
+                data = data.loc[~drop]
+                nan_cols = self._scan_nan(data)
+        self._nan_seen = (id(data), data.shape, nan_cols)
         return data
+
+    @staticmethod
+    def _scan_nan(data: pd.DataFrame) -> np.ndarray:
+        values = data.to_numpy()
+        if values.dtype.kind != "f":
+            values = values.astype(np.float64) if values.dtype == object else None
+        return np.isnan(values).any(axis=0) if values is not None else np.zeros(data.shape[1], dtype=bool)
+
+    def nan_columns(self, data: pd.DataFrame) -> np.ndarray:
+        """Per column of ``data``: does it hold a NaN?  Served from the scan ``filter`` made when ``data`` is the frame it returned."""
+        seen = getattr(self, "_nan_seen", None)
+        if seen is not None and seen[0] == id(data) and seen[1] == data.shape:
+            return seen[2]
+        return self._scan_nan(data)
 
     def treat(self, data: pd.DataFrame) -> pd.DataFrame:
         """Host-side restatement of the data pre-treatment (reference config.py:299-318).  Metric data: centre, and

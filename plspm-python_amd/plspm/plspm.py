@@ -89,13 +89,16 @@ class Plspm:
         # access (the reference builds them eagerly, plspm.py:69-77 -- same objects, same values, ~4 ms of pandas work per call that a
         # caller who wants two of the nine accessors does not pay).
         path = model_spec.path()
-        incomplete = list(observations.columns[observations.isnull().values.any(axis=0)])        # one vectorised pass, not one per column
-        self._scores = _Lazy(fit.scores)
-        self._inner_model = _Lazy(lambda: im.InnerModel.from_device(path, fit))
-        self._outer_model = _Lazy(lambda: om.OuterModel(fit, self._inner_model.r_squared()))
-        self._inner_summary = _Lazy(lambda: pis.InnerSummary(model_spec, self._inner_model.r_squared(), self._inner_model.r_squared_adj(),
-                                                             self._outer_model.model()))
-        self._unidimensionality = _Lazy(lambda: Unidimensionality(model_spec, fit, incomplete))
+        incomplete = list(observations.columns[config.nan_columns(observations)])                 # (the scan Config.filter made)
+        # (the builders close over LOCAL names, never over `self`: a Plspm object then holds no reference cycle, and dropping it releases its device
+        #  handle and frames at once instead of whenever the cycle collector next runs -- inside somebody else's timed Plspm() call, as a rule)
+        scores = _Lazy(fit.scores)
+        inner_model = _Lazy(lambda: im.InnerModel.from_device(path, fit))
+        outer_model = _Lazy(lambda: om.OuterModel(fit, inner_model.r_squared()))
+        inner_summary = _Lazy(lambda: pis.InnerSummary(model_spec, inner_model.r_squared(), inner_model.r_squared_adj(), outer_model.model()))
+        unidimensionality = _Lazy(lambda: Unidimensionality(model_spec, fit, incomplete))
+        self._scores, self._inner_model, self._outer_model = scores, inner_model, outer_model
+        self._inner_summary, self._unidimensionality = inner_summary, unidimensionality
         self._bootstrap = None
         t_fit = time.perf_counter()
         if bootstrap:

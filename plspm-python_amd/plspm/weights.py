@@ -110,7 +110,7 @@ class WeightsCalculatorFactory:
         else:
             values = values if values.dtype == np.float64 else values.astype(np.float64)
             col_index, ind_of = compiled.col_index, None
-            if np.isnan(values).any():
+            if self._config.nan_columns(data).any():          # (Config.filter's scan when `data` is the frame it returned)
                 if not nonmetric:
                     values, col_index, ind_of = with_missing_indicators(compiled, values)
                 else:

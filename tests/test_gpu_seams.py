@@ -204,3 +204,26 @@ def test_mode_b_operator_minimum_norm_on_a_collinear_block():
     want = np.linalg.lstsq(data.loc[:, mvs].values, Z["IMAG"].values, rcond=None)[0]       # gelsd: minimum norm
     assert_close(got.values, want, 1e-8, 1e-11)
     assert abs(got["imag1"] - got["imag1dup"]) < 1e-12
+
+
+def test_plspm_objects_hold_no_reference_cycle():
+    """A Plspm object (and its Bootstrap) must die with its last reference -- device handle, records in HBM and frames released at that moment, not
+    whenever Python's cycle collector next runs (which is inside some later, possibly timed, Plspm() call: the 3-8 ms a bootstrap call seemed to
+    cost over a plain one in the round-3 bench were the previous model's garbage being traversed).  Checked with the collector switched off."""
+    import gc
+    import weakref
+    from plspm.plspm import Plspm
+    sat, cfg = sat_config("AAAAAA", 1)
+    gc.collect()
+    gc.disable()
+    try:
+        for boot in (False, True):
+            m = Plspm(sat, cfg, Scheme.CENTROID, bootstrap=boot, bootstrap_iterations=200, processes=1, seed=3)
+            m.scores(); m.inner_summary(); m.outer_model(); m.unidimensionality()
+            if boot:
+                m.bootstrap().weights()
+            refs = [weakref.ref(m), weakref.ref(m._result.native)] + ([weakref.ref(m._bootstrap)] if boot else [])
+            del m
+            assert all(r() is None for r in refs), "a reference cycle keeps the model alive (bootstrap=%s)" % boot
+    finally:
+        gc.enable()
