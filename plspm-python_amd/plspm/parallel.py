@@ -103,6 +103,12 @@ def _rendezvous_dir(directory):
     (the id is a bearer token of the job's RCCL bootstrap: other local users must neither read it nor plant one)."""
     directory = directory or os.environ.get("PLSPM_RDZV_DIR")
     if directory:
+        # a caller-supplied directory: the user's own, or a sticky one (a shared /tmp-like place where nobody can replace another user's files);
+        # the files themselves are created exclusively with mode 0600 and readers accept their own user's files only
+        st = os.stat(directory)
+        if st.st_uid != os.geteuid() and not (st.st_mode & 0o1000):
+            from plspm import _native
+            raise _native.NativeBackendError("rendezvous directory %s belongs to user %d and is not sticky: another user could replace the id file" % (directory, st.st_uid))
         return directory
     directory = os.path.join(tempfile.gettempdir(), "plspm-rdzv-%d" % os.geteuid())
     os.makedirs(directory, mode=0o700, exist_ok=True)
@@ -126,19 +132,23 @@ def exchange_unique_id(rank, world, directory=None, timeout=300.0, make_id=None)
     process, same MASTER_ADDR/PORT) poll for: single-node rendezvous without a store service.  The file lives in a directory private
     to the user, is created exclusively with mode 0600, and a reader only accepts a file owned by its own user.  Every rank must call
     this the same number of times (the file name carries a per-process sequence number).  ``make_id`` replaces ncclGetUniqueId (tests)."""
+    import struct
     from plspm import _native
     path = _rendezvous_path(directory)
-    deadline = time.time() + timeout
+    entered = time.time()
+    deadline = entered + timeout
     if rank == 0:
         uid = (make_id or _native.rccl_unique_id)()
         tmp = path + ".tmp%d" % os.getpid()
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)       # never through a name somebody else prepared
         with os.fdopen(fd, "wb") as fh:
-            fh.write(uid)
-        if os.path.lexists(path):
+            fh.write(uid + struct.pack("<d", time.time()))                   # id + when it was published (readers reject a left-over of an earlier job)
+        try:
+            os.link(tmp, path)                     # atomic AND exclusive: fails when the name exists (no check-then-act window), a reader never sees a partial id
+        except FileExistsError:
+            raise _native.NativeBackendError("rendezvous: %s already exists (a stale or foreign file): remove it or set PLSPM_RDZV_DIR" % path) from None
+        finally:
             os.remove(tmp)
-            raise _native.NativeBackendError("rendezvous: %s already exists (a stale or foreign file): remove it or set PLSPM_RDZV_DIR" % path)
-        os.replace(tmp, path)                      # atomic: a reader never sees a partial id
         acks = [path + ".ack%d" % r for r in range(1, world)]
         try:
             while not all(os.path.exists(a) for a in acks):          # every rank has the id: nothing of this exchange stays behind
@@ -158,10 +168,14 @@ def exchange_unique_id(rank, world, directory=None, timeout=300.0, make_id=None)
             with open(path, "rb") as fh:
                 if os.fstat(fh.fileno()).st_uid != os.geteuid():
                     raise _native.NativeBackendError("rendezvous: %s belongs to another user" % path)
-                uid = fh.read()
-            if len(uid) == _native.UNIQUE_ID_BYTES:
-                open(path + ".ack%d" % rank, "wb").close()
-                return uid
+                blob = fh.read()
+            if len(blob) == _native.UNIQUE_ID_BYTES + 8:
+                published = struct.unpack("<d", blob[_native.UNIQUE_ID_BYTES:])[0]
+                # a file published long before this rank came here is the left-over of a job that died (same launcher tag): its id leads
+                # into a dead bootstrap -- ignore it, rank 0 of THIS job refuses the name and says so
+                if published >= entered - timeout:
+                    open(path + ".ack%d" % rank, "wb").close()
+                    return blob[:_native.UNIQUE_ID_BYTES]
         except FileNotFoundError:
             pass
         if time.time() > deadline:

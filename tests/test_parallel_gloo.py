@@ -172,6 +172,34 @@ def test_rendezvous_directory_is_private_and_id_file_exclusive(tmp_path, monkeyp
     with pytest.raises(_native.NativeBackendError, match="already exists"):
         parallel.exchange_unique_id(0, 2, None, timeout=1.0, make_id=lambda: b"\x01" * 128)
     assert open(planted, "rb").read() == b"\x07" * 128 and not [n for n in os.listdir(d) if ".tmp" in n]
+    os.remove(planted)
+    # a reader does not pick up the left-over of an earlier job with the same launcher tag -- an id file carries its publication
+    # time, and one published long before this rank arrived is ignored (rank 0 of the live job refuses the name and reports it)
+    import struct
+    import time
+    seq = parallel._rendezvous_seq
+    stale = parallel._rendezvous_path(None)
+    parallel._rendezvous_seq = seq
+    with open(stale, "wb") as fh:
+        fh.write(b"\x09" * 128 + struct.pack("<d", time.time() - 3600.0))
+    with pytest.raises(_native.NativeBackendError, match="did not publish"):
+        parallel.exchange_unique_id(1, 2, None, timeout=0.3)
+    os.remove(stale)
+    seq = parallel._rendezvous_seq
+    fresh = parallel._rendezvous_path(None)
+    parallel._rendezvous_seq = seq
+    with open(fresh, "wb") as fh:
+        fh.write(b"\x0a" * 128 + struct.pack("<d", time.time()))
+    assert parallel.exchange_unique_id(1, 2, None, timeout=5.0) == b"\x0a" * 128
+    # a caller-supplied directory that another user owns and that is not sticky is refused
+    foreign = tmp_path / "foreign"
+    foreign.mkdir()
+    real_stat = os.stat
+    class FakeStat:
+        def __init__(self, st): self.st_uid, self.st_mode = st.st_uid + 1, st.st_mode & ~0o1000
+    monkeypatch.setattr(os, "stat", lambda p, *a, **k: FakeStat(real_stat(p)) if str(p) == str(foreign) else real_stat(p, *a, **k))
+    with pytest.raises(_native.NativeBackendError, match="not sticky"):
+        parallel._rendezvous_dir(str(foreign))
 
 
 def test_multi_node_world_is_refused_with_a_clear_message(monkeypatch):
