@@ -433,7 +433,7 @@ def main():
             # what the launch executes: whole tiles of 320 / 256 replicates x 64 rows x 32 pairs (= SQ_INSTS_VALU_MFMA_MOPS_I8 x 512 of the PMC passes
             # in profiles/)
             k_rows = ((N_OBS + 127) // 128) * 128
-            # (replicate slots: the launch's tile rows -- 320-replicate and, cut by plspm_hip.hip i8_mix_plan, 256-replicate ones -- x their heights)
+            # (replicate slots: the launch's tile rows -- 320-replicate and, cut by plspm_gram_i8.hip i8_mix_plan, 256-replicate ones -- x their heights)
             rep_slots = 16 * model.get_option("last_i8_mt")
             executed = 2.0 * rep_slots * k_rows * (((npair + 31) // 32) * 32) * slices
             priv = model.get_option("last_i8_priv")

@@ -1,5 +1,5 @@
 // kernels_gram.h -- Device kernels, part 2: the fp64 MFMA weighted Gram kernels (rows / wide / block variants) and the fixed-order reduce.
-// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+// Device code shared by the translation units of libplspm_hip.so (host_internal.h lists them); not a stand-alone header.
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ Gram (fp64 MFMA)

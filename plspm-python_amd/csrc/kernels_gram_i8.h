@@ -1,5 +1,5 @@
 // kernels_gram_i8.h -- Device kernels, part 2b: the weighted Gram of a bootstrap BATCH as one exact int8 MFMA product.
-// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+// Device code shared by the translation units of libplspm_hip.so (host_internal.h lists them); not a stand-alone header.
 //
 // Why.  Every replicate's moment matrix is M_b[p,q] = sum_i c_bi x_ip x_iq with the SAME data and small integer multiplicities
 // c_bi (how often row i was drawn).  Over a batch that is a matrix product  M[b, (p,q)] = C[b, i] . Z[i, (p,q)],  Z[i,(p,q)] =
@@ -12,7 +12,7 @@
 // data; bench.py prints the three figures of its own run as digit_planes.moment_error_vs_80bit): S = 7 (>= 53 significant bits of the
 // column maximum; the sum itself is exact, only the final int -> fp64 conversion rounds) 1e-16 -- below the fp64 MFMA accumulation chain's
 // 1.6e-15, which rounds after every one of its ~6,300 additions; S = 6, the automatic choice where every column satisfies
-// sum|z| >= 256 max|z| (plspm_hip.hip choose_slices), 3e-15 -- about twice the fp64 chain's figure, inside the a-priori bound of an fp64
+// sum|z| >= 256 max|z| (plspm_gram_i8.hip choose_slices), 3e-15 -- about twice the fp64 chain's figure, inside the a-priori bound of an fp64
 // accumulation of the same terms, nine orders below the 1e-6 the records are held to.  tools/experiments/slice_poc.py and
 // tests/test_gpu_gram_i8.py compare all three with exact rational / extended-precision sums.
 // This is the error-free-transformation (Ozaki-style) scheme with the simplification that one operand needs no splitting.
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) zs_max_kernel(const double* __restrict__ 
         if (bits) atomicMax(pair_max + j, bits);
     }
 }
-// Second pass for the automatic plane count (plspm_hip.hip choose_slices): sum_i |z_i| of every pair column in fixed point relative to the
+// Second pass for the automatic plane count (plspm_gram_i8.hip choose_slices): sum_i |z_i| of every pair column in fixed point relative to the
 // binade of the column maximum, 2^40 per unit of 2^e_max -- a thread's partial sum over its rows has one fixed order and integer adds
 // commute, so the result is a deterministic function of the data.  Same staging as zs_max_kernel.
 __global__ void __launch_bounds__(256) zs_abssum_kernel(const double* __restrict__ Xa, long N, int PA, int C, const int* __restrict__ pair_p, const int* __restrict__ pair_q,
@@ -313,7 +313,7 @@ struct GramI8 {
     // MIX: the launch may hold tile rows of TWO heights -- RT count tiles ("tall") and RT - WM ("short": every wave drops its last count
     // tile, i.e. its last S MFMAs, one fragment read and the tile's share of the DMA blocks of a k-step).  A tile grid that fills the
     // last round of the machine only partly is then re-cut so that every CU carries about the same number of count-tile rows (host:
-    // plspm_hip.hip i8_mix_plan); sums are exact int32 either way, the results do not depend on the cut.  Eight-wave FLAT-global form of
+    // plspm_gram_i8.hip i8_mix_plan); sums are exact int32 either way, the results do not depend on the cut.  Eight-wave FLAT-global form of
     // the 320-replicate tile only (the buffer form fixes the operand of a DMA slot at compile time).
     static constexpr bool MIX = RT == 20 && WM == 4 && SH == 16 && BUFM == 0 && DMA_HEAD == 0 && ((PER - 1) * NMFMA) / PER + 1 < (MTW - 1) * S;
     static constexpr int RTS = RT - WM, NBLKS = RTS + 2 * S;      // count tiles / DMA blocks per k-step of a short tile
@@ -328,7 +328,7 @@ __device__ __forceinline__ void glds_block(const void* base, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(ub), "s"(lds_dst) : "memory");
 }
 
-// IND ("independent planes"): the digit buffer holds ONE plane per pair group (0/1 indicator data, plspm_hip.hip choose_slices) and the S
+// IND ("independent planes"): the digit buffer holds ONE plane per pair group (0/1 indicator data, plspm_gram_i8.hip choose_slices) and the S
 // "planes" a wave walks are S consecutive pair groups of it -- the same main loop at its full accumulator tile (a one-plane
 // instantiation moves 16 KB of counts per 8 MFMAs of a wave and is bound by the loads); the epilogue stores S x 16 pairs per wave
 // instead of recombining S planes into 16.

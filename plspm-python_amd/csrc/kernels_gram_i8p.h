@@ -1,5 +1,5 @@
 // kernels_gram_i8p.h -- Device kernels, part 2c: the int8 digit-plane Gram with PRIVATE count fragments (round 4).
-// Included by plspm_hip.hip behind kernels_gram_i8.h (same product, same operand layouts, same epilogue); not a stand-alone header.
+// Included by plspm_gram_i8.hip behind kernels_gram_i8.h (same product, same operand layouts, same epilogue); not a stand-alone header.
 //
 // gram_i8_kernel shares BOTH operands of a k-step through LDS: eight waves as 4 (replicate rows) x 2 (pair groups), 20 count blocks + 12
 // digit blocks by LDS-DMA, every wave reading 5 + 6 fragments back -- 32 DMA instructions and 88 KB of fragment reads per CU and k-step

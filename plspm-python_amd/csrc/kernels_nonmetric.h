@@ -1,5 +1,5 @@
 // kernels_nonmetric.h -- Device kernels, part 4: non-metric solvers (NUM/RAW, categorical, missing data) and the stop-rule passes (gathering and dense).
-// Included by plspm_hip.hip (one translation unit); not a stand-alone header.
+// Device code shared by the translation units of libplspm_hip.so (host_internal.h lists them); not a stand-alone header.
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ non-metric (NUM / RAW) kernels

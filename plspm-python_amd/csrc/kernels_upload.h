@@ -1,5 +1,5 @@
 // kernels_upload.h -- Device kernels, part 1a: upload (column means, pack into the resident layout) and the incomplete-row side tables.
-// Included by plspm_hip.hip only; not a stand-alone header.
+// Device code shared by the translation units of libplspm_hip.so (host_internal.h lists them); not a stand-alone header.
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ upload kernels

@@ -1,5 +1,5 @@
 // Host-side state of one libplspm_hip handle (include/plspm_hip.h), shared by the translation units of the library:
-// plspm_hip.hip (kernels + single-device entry points) and plspm_group.cpp (multi-GPU groups over RCCL).
+// the .hip translation units (kernels + single-device entry points; host_internal.h lists them) and plspm_group.cpp (multi-GPU groups over RCCL).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -106,7 +106,7 @@ struct plspm_model {
     bool cdfree_set[2] = {false, false};
     int cd_slot = 0;
     bool zs_valid = false;
-    bool zs_stats_ready = false;  // phase 1 of the digit planes is enqueued (pair tables, column statistics on their way to h_zstat): plspm_hip.hip prepare_zs_stats
+    bool zs_stats_ready = false;  // phase 1 of the digit planes is enqueued (pair tables, column statistics on their way to h_zstat): plspm_gram_i8.hip prepare_zs_stats
     int zs_stats_S = 0;           // ... for this value of the "i8_slices" option
     void* h_zstat = nullptr;      // pinned copy of the column statistics (automatic plane count)
     size_t h_zstat_cap = 0;
@@ -119,9 +119,9 @@ struct plspm_model {
     int last_i8_dma = 0;          // 1 global_load_lds, 2 buffer_load ... lds: the LDS-DMA form of the last int8 Gram launch
     int last_i8_priv = 0;         // 1: the last int8 Gram launch was gram_i8p_kernel (private count fragments)
     int last_i8_rt = 0;           // count tiles (16 replicates each) per workgroup of the last int8 Gram launch: 16, 20 or 8
-    bool mix_valid = false, mix_wide = false; long mix_key[4] = {0, 0, 0, 0}; int mix_tall = 0, mix_short = 0;      // plspm_hip.hip i8_mix_plan: the last tile-row cut
+    bool mix_valid = false, mix_wide = false; long mix_key[4] = {0, 0, 0, 0}; int mix_tall = 0, mix_short = 0;      // plspm_gram_i8.hip i8_mix_plan: the last tile-row cut
     int last_i8_mt = 0;           // count tiles (padded) of the last int8 Gram launch: 16 x this many replicate slots went through the matrix pipe
-    int last_i8_short = 0;        // ... and, with 20, how many of its tile rows were short ones (16 count tiles: plspm_hip.hip i8_mix_plan)
+    int last_i8_short = 0;        // ... and, with 20, how many of its tile rows were short ones (16 count tiles: plspm_gram_i8.hip i8_mix_plan)
     int last_solver = 0;          // 1 LDS solver (solver_kernel), 2 rows solver (solver_rows_kernel), 3 wave solver (solver_wave_kernel): the last metric bootstrap's
     // grow-only pinned host staging for uploads / row downloads (two halves: copy-in of chunk k+1 overlaps the DMA of chunk k)
     void* h_pin = nullptr;
@@ -137,7 +137,7 @@ struct plspm_model {
     std::string error;
 };
 
-// Core of plspm_bootstrap_device (plspm_hip.hip): enqueue B replicates on the handle's stream, records written at `rows_out`
+// Core of plspm_bootstrap_device (plspm_bootstrap.hip): enqueue B replicates on the handle's stream, records written at `rows_out`
 // (pitch plspm_row_stride) or into the handle's own `rows` buffer when rows_out is NULL.  No host synchronisation for metric models.
 int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, double* rows_out);
 // plspm_group.cpp: a handle that is destroyed while bound to a group takes the group's hold on every handle with it.

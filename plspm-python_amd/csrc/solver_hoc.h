@@ -1,6 +1,6 @@
 // solver_hoc.h -- second stage of the two-stage higher-order-construct estimation, on the moments.
 //
-// TEST NOTE: like solver_core.h this source is compiled twice -- for the GPU (plspm_hip.hip) and for the std::thread emulation
+// TEST NOTE: like solver_core.h this source is compiled twice -- for the GPU (plspm_nonmetric.hip / plspm_fit.hip) and for the std::thread emulation
 // build that the CPU tests drive (tests/hostemu).
 //
 // Reference: Estimator.estimate (plspm/estimator.py:29-55).  Stage 1 estimates the model in which every higher order

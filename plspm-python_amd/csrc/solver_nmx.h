@@ -1,6 +1,6 @@
 // solver_nmx.h -- non-metric (Scale.NUM) data with MISSING VALUES.
 //
-// TEST NOTE: like solver_core.h this source is compiled twice -- for the GPU (plspm_hip.hip) and for the std::thread emulation
+// TEST NOTE: like solver_core.h this source is compiled twice -- for the GPU (plspm_nonmetric.hip / plspm_fit.hip) and for the std::thread emulation
 // build that the CPU tests drive (tests/hostemu).
 //
 // Reference: _NonmetricWeights with NaNs (plspm/weights.py:88-98, 107-133), Mode A NaN-aware products (mode.py:35-41),

@@ -1,7 +1,7 @@
 // wave_ops.h -- 64-lane wave reductions and scans on the DPP and permlane-swap data paths of gfx950.  `__shfl_*` compiles to
 // ds_bpermute_b32: every step of a shuffle tree is an LDS-crossbar round trip (~100 clocks for a double); a DPP move costs one VALU
 // issue, v_permlane16_swap / v_permlane32_swap (new with gfx950) exchange rows / wave halves in one instruction.
-// Included by plspm_hip.hip (device code only).
+// Included by the .hip translation units (device code only).
 #pragma once
 
 namespace wv {

@@ -1,4 +1,4 @@
-"""Cost model of the tile-row cut (plspm_hip.hip i8_mix_plan) for gram_i8p_kernel: Gram kernel time of 960 tiles = 3.75 rounds of each height --
+"""Cost model of the tile-row cut (plspm_gram_i8.hip i8_mix_plan) for gram_i8p_kernel: Gram kernel time of 960 tiles = 3.75 rounds of each height --
 six planes: tall 320 replicates (B = 5,120) / short 256 (B = 4,096, "i8_short_rows" 16); seven planes: tall 256 (B = 4,096) / short 192 (B = 3,072) --
 then the automatic cut against all-tall rows for a few batch sizes.  usage: i8_mix_calib.py"""
 import json, os, sys
