@@ -333,7 +333,7 @@ int plspm_bootstrap_summary(plspm_model_t* m, const void* d_rows, int64_t B, int
  * cheap: a gather stream, four events and the record buffers per handle).  Two ways to form a communicator:
  *   single process   n_local == nranks ranks on DISTINCT devices (ncclCommInitAll); unique_id = NULL, first_rank = 0.
  *                    Ranks that share a device (testing on a 1-GPU box; RCCL refuses duplicate devices) exchange their records
- *                    with device-to-device copies instead of RCCL -- same buffers, same ordering, same results.
+ *                    with device-to-device copies (one copy launch when every handle shares a device) instead of RCCL -- same buffers, same ordering, same results.
  *   one process per GPU (torchrun / mpirun)   n_local == 1, first_rank = this process's rank, unique_id = the 128 bytes that
  *                    rank 0 obtained from plspm_rccl_unique_id() and handed to every rank (ncclCommInitRank: collective call).
  * A communicator serves one group at a time; a handle belongs to at most one group at a time and must outlive it.  Group calls

@@ -149,6 +149,10 @@ int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t 
 // Host copy of device records [B x stride] -> rows [B x R], status, iters (any may be NULL), through the pinned staging buffer.
 int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t B, int32_t stride, double* out, int32_t* status, int32_t* iters);
 
+// Same-device record exchange of a group (plspm_bootstrap.hip): send[i] -> recv[d] + i * doubles for all i, d < n, one launch on `stream`.
+#define PLSPM_GATHER_LOCAL_MAX 16
+int plspm_detail_gather_local(hipStream_t stream, int n, const double* const* send, double* const* recv, size_t doubles);
+
 inline int fail(plspm_model* m, int code, const std::string& msg) {
     if (m) m->error = msg; else g_create_error = msg;
     return code;

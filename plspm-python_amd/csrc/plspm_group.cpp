@@ -296,7 +296,7 @@ plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int3
     if (!c) return bad(PLSPM_E_STATE, "out of host memory");
     c->nranks = nranks; c->first_rank = first_rank;
     c->devices.assign(device_ids, device_ids + n_local);
-    // ranks that share a device (a 1-GPU test box; RCCL refuses duplicate devices) exchange records with device-to-device copies
+    // ranks that share a device (a 1-GPU test box; RCCL refuses duplicate devices) exchange records with device-to-device copies (all on one device: gather_local_kernel, one launch)
     c->use_rccl = distinct;
     if (!c->use_rccl) return c;
     std::string why;
@@ -394,6 +394,9 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
             for (int k = 0; k < 2; ++k) if ((rc = grow(g, l, l.send[k], send_bytes)) || (rc = grow(g, l, l.recv[k], recv_bytes))) return rc;
         }
     }
+    // handles sharing one device (tests, single-GPU runs of this path) exchange their records in ONE launch instead of G x G copies
+    bool one_device = !g->use_rccl && nl <= PLSPM_GATHER_LOCAL_MAX;
+    for (int i = 1; i < nl && one_device; ++i) one_device = g->loc[i].m->device == g->loc[0].m->device;
     // 1. shard kernels (enqueue only; non-metric models iterate with host read-backs): every local handle by its own resident thread
     std::vector<int> shard_rc(nl, 0);
     auto run_shard = [&](int i) {
@@ -402,7 +405,7 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         if (hipSetDevice(m->device) != hipSuccess) { shard_rc[i] = fail(m, PLSPM_E_STATE, "hipSetDevice failed"); return; }
         if (g->pending[s]) {
             // slot s was last read / written by the collective of two calls ago
-            if (g->use_rccl) hipStreamWaitEvent(m->stream, l.gathered[s], 0);
+            if (g->use_rccl || one_device) hipStreamWaitEvent(m->stream, l.gathered[s], 0);            // (one launch / one collective read every send buffer)
             else for (auto& peer : g->loc) hipStreamWaitEvent(m->stream, peer.gathered[s], 0);          // peers pull from this send buffer
         }
         int64_t first = 0, count = 0;
@@ -454,6 +457,18 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
             if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupEnd: ") + r->GetErrorString(n); }
         }
         for (auto& l : g->loc) { hipSetDevice(l.m->device); hipEventRecord(l.gathered[s], l.cstream); }
+    } else if (one_device) {
+        Local& l0 = g->loc[0];
+        hipError_t e = hipSetDevice(l0.m->device);
+        const double* send[PLSPM_GATHER_LOCAL_MAX];
+        double* recv[PLSPM_GATHER_LOCAL_MAX];
+        for (int i = 0; i < nl; ++i) {
+            if (e == hipSuccess) e = hipStreamWaitEvent(l0.cstream, g->loc[i].computed[s], 0);
+            send[i] = (const double*)g->loc[i].send[s].p; recv[i] = (double*)g->loc[i].recv[s].p;
+        }
+        if (e == hipSuccess && plspm_detail_gather_local(l0.cstream, nl, send, recv, (size_t)cap * RS)) e = hipErrorLaunchFailure;
+        for (int i = 0; i < nl && e == hipSuccess; ++i) e = hipEventRecord(g->loc[i].gathered[s], l0.cstream);
+        if (e != hipSuccess) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
     } else {
         for (auto& dst : g->loc) {
             hipSetDevice(dst.m->device);

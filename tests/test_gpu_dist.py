@@ -75,6 +75,28 @@ def test_group_records_bit_identical_to_single_handle(nranks, B):
     group.close(); comm.close()
 
 
+def test_group_exchange_of_odd_sized_record_blocks():
+    """Handles on one device exchange their records in ONE launch (16-byte pieces when a rank's block is a whole number of them, 8-byte
+    ones otherwise): a model whose record stride is odd, with an odd number of replicates per rank."""
+    from plspm import _native
+    C = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0]], dtype=float)      # record stride = 2 P + L + 2 effects + 2: odd with an odd number of LVs
+    X, blocks = orc.synth(500, C, 4, seed=11)
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
+    models = []
+    for _ in range(3):
+        nm = _native.NativeModel(boff, C.astype(np.uint8), np.zeros(3, dtype=np.int32), 2, True, 100, 1e-6, 0)
+        nm.upload(X); models.append(nm)
+    B = 21                                                   # 7 replicates per rank
+    assert models[0].row_stride % 2 == 1 and ((B + 2) // 3) % 2 == 1, models[0].row_stride
+    ref_rows, ref_status, ref_iters = models[0].bootstrap(B, seed=2, rep_offset=1)
+    comm = _native.NativeComm([0] * 3)
+    group = _native.NativeGroup(comm, models)
+    for _ in range(2): group.bootstrap(B, seed=2, rep_offset=1)
+    rows, status, iters = group.rows()
+    assert np.array_equal(rows, ref_rows) and np.array_equal(status, ref_status) and np.array_equal(iters, ref_iters)
+    group.close(); comm.close()
+
+
 def test_group_growing_and_shrinking_batches_and_a_second_group_on_the_same_comm():
     from plspm import _native
     models = [_model(800, 4, seed=8) for _ in range(2)]
