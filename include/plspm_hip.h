@@ -97,7 +97,9 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "i8_ind"          1 (default) | 0   one-plane data run through the seven-plane main loop, the planes of a wave standing for seven pair groups
  * Solvers
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 route: one wave per replicate with the
- *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS
+ *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS; models of
+ *                     65 ... 128 MVs whose blocks divide into two runs of at most 64 MVs: four waves per replicate, two threads per MV
+ *                     (solver_rows_split_kernel)
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
  *   "solver_threads"  64 | 128 | 256      threads per problem of the LDS solver (default 128)
@@ -127,7 +129,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  * probes of both Gram kernels).  Read-only "build_experiments" tells which library is loaded.  DESIGN.md 7b has the measurements.
  *
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
- * (1 LDS solver, 2 rows solver, 3 wave solver) tell what the last bootstrap call took.
+ * (1 LDS solver, 2 rows solver, 3 wave solver, 4 split rows solver) tell what the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value);

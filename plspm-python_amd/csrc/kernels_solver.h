@@ -54,6 +54,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PLSPM_R
 }
 
 
+// Split rows variant (round 4; solve_problem_rows<64, true>): 64 < P <= 128 MVs, FOUR waves per problem -- thread t serves MV t mod 128 with the
+// columns on side t / 128 of a block boundary, so the covariance of a 120-MV model lives in the registers of four waves (two problems per
+// CU, small workspace ~30 KB of LDS each) where solver_kernel keeps 115 KB of LDS per problem (one per CU).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_rows_split_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    const long b = blockIdx.x;
+    Workspace ws;
+    ws.PS = cov_ld(md.P);
+    ws.S = nullptr;
+    carve_small(ws, lp, md.P, md.L, md.kmax, md.n_chol);
+    lp += workspace_small_doubles(md.P, md.L, md.kmax, md.n_chol);
+    stage_descriptors(md, lp);
+    FitOutputs out{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevExecT<4> ex{(int)threadIdx.x, 256, ws.red, (b == 0) ? so.marks : nullptr};
+    solve_problem_rows<64, true>(ex, md, ws, Md + b * md_stride, out);
+}
+
+
 // Wave variant (solver_wave.h solve_problem_wave): ONE wave per problem with fixed lane roles -- the bootstrap solver of metric Mode-A
 // models with at most 64 MVs and 8 LVs.  Executor = the rows executor + the wave primitives.
 struct DevWaveExec : DevExecT<4> {

@@ -162,11 +162,18 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         else hipLaunchKernelGGL((solver_wave_kernel<8, false>), dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 3;
     } else if (dense) {
-        m->last_solver = 2;
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
-        if ((rc = allow_lds(m, (const void*)solver_rows_kernel, lds))) return rc;
-        ProfScope ps(m, PLSPM_K_SOLVER);
-        hipLaunchKernelGGL(solver_rows_kernel, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        if (m->P > 64) {                           // split form: two threads per MV (plspm_detail_bootstrap asked rows_split_block)
+            m->last_solver = 4;
+            if ((rc = allow_lds(m, (const void*)solver_rows_split_kernel, lds))) return rc;
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipLaunchKernelGGL(solver_rows_split_kernel, dim3((unsigned)nb), dim3(256), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        } else {
+            m->last_solver = 2;
+            if ((rc = allow_lds(m, (const void*)solver_rows_kernel, lds))) return rc;
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipLaunchKernelGGL(solver_rows_kernel, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        }
     } else {
         const double* Mp; long mp_stride;
         if ((rc = run_impute(m, nb, gram_buf, &Mp, &mp_stride))) return rc;

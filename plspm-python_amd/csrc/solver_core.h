@@ -468,22 +468,33 @@ struct CovLds {
 };
 template <int PMAX>
 struct CovRows {
-    double s[PMAX];             // s[q] = S[q][p] of the calling thread's column p = ex.tid (symmetric: its row as well)
-    unsigned long long ends;    // bit q set: column q is the last one of its LV block (wave-uniform; PMAX <= 64)
+    double s[PMAX];             // s[j] = S[q0 + j][p] of the calling thread's column p (symmetric: its row as well)
+    unsigned long long ends;    // bit j set: column q0 + j is the last one of its LV block (wave-uniform; PMAX <= 64)
+    // The thread's window of columns: the whole matrix (q0 = 0, nq = P, m0 = 0: one thread per MV, P <= PMAX), or -- split form, two threads
+    // per MV, P <= 2 PMAX -- the columns of the LV blocks [m0, ...) on one side of a block boundary (rows_split_block): no block is shared
+    // between the two windows, so each thread closes its own blocks and nothing has to be combined.
+    int p, q0, nq, m0;
     // V[p, m] = sum over the columns q of block m of s[q] w[q]: the executor's segmented product (device: kernels_solver.h seg_products).
     // Every thread stores (idle ones into a sink -- ws.wn is dead while V is formed and holds P >= L doubles), so closing a block is
     // the same straight-line code on all lanes.
     template <class Ex>
     PLSPM_HD void block_products(Ex& ex, const ModelDesc& md, Workspace& ws) const {
-        const int P = md.P, L = md.L, p = ex.tid;
-        ex.template seg_products<PMAX>(s, ws.w, P, ends, (p < P) ? ws.V + p * L : ex.sink(ws.wn));
+        const int P = md.P, L = md.L;
+        ex.template seg_products<PMAX>(s, ws.w + q0, nq, ends, (p < P) ? ws.V + p * L + m0 : ex.sink(ws.wn));
         ex.sync();
     }
-    PLSPM_HD void cov_row(const Workspace&, int, int P, double* dst) const {
+    PLSPM_HD void cov_row(const Workspace&, int, int, double* dst) const {
 #pragma unroll
-        for (int q = 0; q < PMAX; ++q) if (q < P) dst[q] = s[q];
+        for (int q = 0; q < PMAX; ++q) if (q < nq) dst[q0 + q] = s[q];
     }
 };
+// Split form of the rows solver: the block boundary that divides the MVs into two windows of at most PMAX columns each (the last
+// boundary at or below PMAX); 0 when there is none -- the host asks before it launches (rows_split_covers).
+PLSPM_HD int rows_split_block(const int* boff, int L, int PMAX) {
+    int ms = 0;
+    for (int l = 1; l < L; ++l) if (boff[l] <= PMAX) ms = l;
+    return (ms > 0 && boff[L] - boff[ms] <= PMAX) ? ms : 0;
+}
 
 // V[p,m] = sum_{q in block m} S[p,q] w[q];   Q[l,m] = sum_{p in block l} w[p] V[p,m]
 template <class Ex, class Cov>
@@ -669,31 +680,40 @@ PLSPM_HD void solve_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const do
 // UPPER triangle only (entry (r, c), r <= c, at r * PS + c), as the int8 digit-plane Gram writes it (kernels_gram_i8.h, dense
 // slots: one store per element, 16 consecutive columns of a row per store group).  Same arithmetic as moments_to_cov /
 // solve_problem; sums over a block run in a different (fixed) order, so results agree to rounding, not bitwise.
-template <int PMAX, class Ex>
+// SPLIT (64 < P <= 2 PMAX, 4 PMAX threads = two per MV; round 4): thread t serves MV p = t mod 2 PMAX with the columns on side t / (2 PMAX) of
+// the block boundary rows_split_block -- the covariance of a 128-MV model sits in the registers of four waves instead of 115 KB of LDS
+// (one problem per CU), and everything outside the three places that touch `cov` is the same code on more threads.
+template <int PMAX, bool SPLIT = false, class Ex>
 PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, const double* Md, const FitOutputs& out) {
-    const int P = md.P, L = md.L, PS = cov_ld(P), p = ex.tid;
-    const bool mine = p < P;
+    const int P = md.P, L = md.L, PS = cov_ld(P), p = SPLIT ? (ex.tid & (2 * PMAX - 1)) : ex.tid;
+    const int side = SPLIT ? ex.tid / (2 * PMAX) : 0;
+    const bool mine = p < P && side == 0;                 // the thread that owns MV p's entries of the per-MV arrays
     CovRows<PMAX> cov;
+    cov.p = p;
     {
+        const int ms = SPLIT ? rows_split_block(md.boff, L, PMAX) : 0, l0 = side ? ms : 0, l1 = (SPLIT && !side) ? ms : L;
+        cov.m0 = l0; cov.q0 = md.boff[l0]; cov.nq = md.boff[l1] - md.boff[l0];
         unsigned long long e = 0ull;
-        for (int l = 0; l < L; ++l) e |= 1ull << (md.boff[l + 1] - 1);
-        cov.ends = ex.uniform(e);                         // the same value on every thread: block boundaries become scalar tests
+        for (int l = l0; l < l1; ++l) e |= 1ull << (md.boff[l + 1] - 1 - cov.q0);
+        cov.ends = ex.uniform(e);                         // the same value on every thread of a wave: block boundaries become scalar tests
     }
+    const int q0 = cov.q0, nq = cov.nq;
     ex.mark(0);
     // 1. moments -> treated covariance (config.py:299-305, util.py:33-39).  Column p = entries (q, p) above the diagonal (one row of
     //    Md across the threads: coalesced) + the thread's own row (p, q) behind it (a contiguous run per thread).
     //    One load per column with a selected address (a select of two loads became two exec-masked branches per column); idle threads
     //    and columns past P re-read valid entries, zeroed below.
-    const int pc = mine ? p : P - 1;
+    const int pc = (p < P) ? p : P - 1;
 #pragma unroll
     for (int q = 0; q < PMAX; ++q) {
-        const int qc = (q < P) ? q : P - 1;
+        const int qc = q0 + ((q < nq) ? q : nq - 1);
         const unsigned off = (unsigned)((qc <= pc) ? qc * PS + pc : pc * PS + qc) * 8u;      // 32-bit byte offset from one base: one
         cov.s[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off); // address register per load, all in flight
     }
     double dpp = 0.0, mup = 0.0;
-    if (mine) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; ws.mu[p] = mup; ws.dv[p] = dpp; }
-    if (p == 0) ws.scal[1] = Md[(long)P * PS + P];
+    if (p < P) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; }
+    if (mine) { ws.mu[p] = mup; ws.dv[p] = dpp; }
+    if (ex.tid == 0) ws.scal[1] = Md[(long)P * PS + P];
     ex.sync();
     ex.mark(14);
     const double n = ws.scal[1], inv_n = 1.0 / n;
@@ -712,8 +732,8 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
     ex.mark(15);
 #pragma unroll
     for (int q = 0; q < PMAX; ++q) {
-        const double v = (cov.s[q] - (mup * ws.mu[(q < P) ? q : P - 1]) * inv_n) * fac;          // (mu_p mu_q) first: bitwise symmetric in (p, q)
-        cov.s[q] = (q < P) ? v : 0.0;
+        const double v = (cov.s[q] - (mup * ws.mu[q0 + ((q < nq) ? q : nq - 1)]) * inv_n) * fac;          // (mu_p mu_q) first: bitwise symmetric in (p, q)
+        cov.s[q] = (q < nq) ? v : 0.0;
     }
     if (mine) {
         ws.sd[p] = sqrt((dpp - (mup * mup) * inv_n) * fac);
@@ -726,14 +746,14 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
     if (md.n_chol > 0) {
         // every thread of a Mode-B block writes its row of S_bb into the block's factor slot and into the scratch half behind it
         // (psd_factor restores from there for the minimum-norm fallback)
-        if (mine) {
+        if (p < P) {                                      // (split form: the side whose window holds the block finds its columns)
             const int l = md.lvof[p];
             if (md.mode[l] == MODE_B) {
-                const int b0 = md.boff[l], b1 = md.boff[l + 1], k = b1 - b0;
+                const int b0 = md.boff[l] - q0, b1 = md.boff[l + 1] - q0, k = b1 - b0, pr = p - md.boff[l];
                 double* F = ws.chol + md.chol_off[l];
 #pragma unroll
                 for (int q = 0; q < PMAX; ++q)
-                    if (q >= b0 && q < b1) { F[(p - b0) * k + (q - b0)] = cov.s[q]; F[(long)k * k + (p - b0) * k + (q - b0)] = cov.s[q]; }
+                    if (q >= b0 && q < b1 && q < nq) { F[pr * k + (q - b0)] = cov.s[q]; F[(long)k * k + pr * k + (q - b0)] = cov.s[q]; }
             }
         }
         ex.sync();

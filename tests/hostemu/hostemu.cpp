@@ -314,7 +314,10 @@ int hostemu_solve_rows(int P, int L, int PA, int scheme, int scaled, int max_ite
                        const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
                        int nthreads, double* row, double* crossloadings, double* path_coef, double* lv_cov, double* indirect,
                        double* score_w, double* score_c, double* cov, double* mean, int8_t* sign, int* iters, int* status) {
-    if (P > 64 || nthreads < P || nthreads > 64) return 1;
+    // nthreads 256: the split form (solve_problem_rows<64, true>: 64 < P <= 128, two emulated threads per MV, no covariance output)
+    const bool split = nthreads == 256;
+    if (split ? (P <= 64 || P > 128 || rows_split_block(boff, L, 64) == 0) : (P > 64 || nthreads < P || nthreads > 64)) return 1;
+    if (split) cov = nullptr;
     EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
     std::vector<double> small(workspace_small_doubles(P, L, em.md.kmax, em.md.n_chol)), red(nthreads);
     FitOutputs out{};
@@ -328,7 +331,8 @@ int hostemu_solve_rows(int P, int L, int PA, int scheme, int scaled, int max_ite
             ws.S = nullptr; ws.PS = cov_ld(P);
             carve_small(ws, small.data(), P, L, em.md.kmax, em.md.n_chol);
             HostExec ex{t, nthreads, &bar, red.data()};
-            solve_problem_rows<64>(ex, em.md, ws, Md, out);
+            if (split) solve_problem_rows<64, true>(ex, em.md, ws, Md, out);
+            else solve_problem_rows<64>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

@@ -328,8 +328,9 @@ def test_int8_route_beyond_65535_rows(N):
 
 
 def test_int8_route_with_120_mvs_and_12_lvs():
-    """P = 120 > 64: the digit-plane Gram (7,381 pair columns) feeds the LDS solver through the tile-packed layout (the one-wave solvers
-    hold a covariance column of at most 64 entries per lane).  Rows vs the oracle and vs the fp64 route."""
+    """P = 120 > 64: the digit-plane Gram (7,381 pair columns) feeds the split rows solver (round 4: two threads per MV on either side of a
+    block boundary, dense layout) or -- set_option("solver_rows", 0) -- the LDS solver through the tile-packed layout.  Rows vs the oracle,
+    between the two solvers and vs the fp64 route."""
     from plspm import _native
     C = orc.chain_C(12)
     X, blocks = orc.synth(2500, C, 10, seed=8)
@@ -338,12 +339,17 @@ def test_int8_route_with_120_mvs_and_12_lvs():
         nm = native_model(model)
         nm.upload(X)
         rows, status, iters = nm.bootstrap(260, seed=6)
-        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 1 and np.all(status == 0)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 4 and np.all(status == 0)
         corr = orc.correction(2500)
         for r in (0, 259):
             mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(6, r, 2500), corr)
             assert its == iters[r]
             assert_close(rows[r], mine, RTOL, ATOL)
+        nm.set_option("solver_rows", 0)
+        rows_l, status_l, iters_l = nm.bootstrap(260, seed=6)
+        assert nm.get_option("last_solver") == 1 and np.array_equal(status, status_l) and np.array_equal(iters, iters_l)
+        assert_close(rows, rows_l, 1e-11, 1e-13)
+        nm.set_option("solver_rows", 1)
         nm.set_option("gram_path", 1)
         rows64, _, iters64 = nm.bootstrap(260, seed=6)
         assert np.array_equal(iters, iters64)

@@ -40,9 +40,10 @@ def dense_from_packed(Mp, PA, P):
     return Md
 
 
-def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None, rows=False):
+def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None, rows=False, split=False):
     """`packed`: precomputed (Mp, shift, PA) of the DEVICE-ordered columns instead of the scatter of X (X then only feeds the score check).
-    `rows`: the one-wave-per-problem variant (solve_problem_rows<64>) on the dense moment matrix, 64 emulated lanes."""
+    `rows`: the one-wave-per-problem variant (solve_problem_rows<64>) on the dense moment matrix, 64 emulated lanes; with `split` its
+    two-threads-per-MV form for 65 ... 128 MVs (solve_problem_rows<64, true>, 256 emulated threads)."""
     order = model.mv_order
     Xdev = np.ascontiguousarray(X[:, order])
     P, L = Xdev.shape[1], model.L
@@ -62,7 +63,7 @@ def run_emu(lib, X, model, counts=None, shift=None, nthreads=4, packed=None, row
         Md = np.ascontiguousarray(dense_from_packed(Mp, PA, P))
         rc = lib.hostemu_solve_rows(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
                                     _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte), _ptr(mode, ctypes.c_int), _ptr(shift), ne,
-                                    _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Md), 64, _ptr(row), _ptr(cl), _ptr(pc),
+                                    _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Md), 256 if split else 64, _ptr(row), _ptr(cl), _ptr(pc),
                                     _ptr(lc), _ptr(ind), _ptr(sw), _ptr(sc), _ptr(cov), _ptr(mean), _ptr(sign, ctypes.c_int8),
                                     ctypes.byref(iters), ctypes.byref(status))
         assert rc == 0
@@ -337,3 +338,46 @@ def test_operator_seam_outer_weights_on_moments(emu, mode):
     assert emu.hostemu_op_outer_weights(mode, 7, PA, _ptr(np.ascontiguousarray(shift)), _ptr(Mp), 3, _ptr(w)) == 0
     want = X.T @ z / 300 if mode == 0 else np.linalg.lstsq(X, z, rcond=None)[0]
     assert_close(w, want, 1e-9, 1e-12)
+
+
+def _wide_model(P_per, L, modes, scheme, seed):
+    """L LVs in a chain with a few extra paths, P_per MVs each."""
+    C = np.zeros((L, L))
+    for i in range(1, L):
+        C[i, i - 1] = 1
+        if i >= 3: C[i, i - 3] = 1
+    X, blocks = orc.synth(1500, C, P_per, seed=seed)
+    return X, orc.Model(blocks, C, case_modes(modes) if L == 6 else [("B" if (modes == "B" or (modes == "M" and l % 3 == 0)) else "A") for l in range(L)], scheme, True)
+
+
+@pytest.mark.parametrize("modes,scheme,P_per,L", [("A", "path", 10, 12), ("M", "factorial", 10, 12), ("B", "centroid", 9, 9), ("A", "centroid", 16, 8), ("M", "path", 13, 5)])
+def test_split_rows_variant_for_65_to_128_columns(emu, modes, scheme, P_per, L):
+    """solve_problem_rows<64, true>: two threads per MV on either side of a block boundary (round 4, models of 65 ... 128 MVs) against the oracle
+    and the LDS variant -- plain and with bootstrap counts."""
+    X, model = _wide_model(P_per, L, modes, scheme, seed=21)
+    assert 64 < X.shape[1] <= 128
+    e = run_emu(emu, X, model, rows=True, split=True)
+    check(e, orc.fit(X, model), "split rows %s/%s" % (modes, scheme))
+    base = run_emu(emu, X, model)
+    assert e["iterations"] == base["iterations"]
+    assert_close(e["row"], base["row"], 1e-10, 1e-13)
+    rng = np.random.default_rng(8)
+    idx = rng.integers(0, X.shape[0], X.shape[0])
+    counts = np.bincount(idx, minlength=X.shape[0])
+    shift = X[:, model.mv_order].mean(axis=0)
+    e = run_emu(emu, X, model, counts=counts, shift=shift, rows=True, split=True)
+    mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(X.shape[0]))
+    assert e["status"] == 0 and e["iterations"] == its
+    assert_close(np.concatenate((e["weights"], e["r2"], e["total"], e["direct"], e["loadings"])), mine, RTOL, 1e-12)
+
+
+def test_split_rows_variant_needs_a_block_boundary(emu):
+    """One block wider than 64 MVs on either side of every boundary: the emulation entry (like the host's rows_split_block test) declines."""
+    C = np.array([[0, 0], [1, 0]], dtype=float)
+    X, blocks = orc.synth(300, C, 35, seed=3)                     # 70 MVs in two blocks of 35: boundary at 35 -> 35 | 35 fits
+    model = orc.Model(blocks, C, ["A", "A"], "centroid", True)
+    check(run_emu(emu, X, model, rows=True, split=True), orc.fit(X, model))
+    blocks2 = [list(blocks[0]) + list(blocks[1][:31]), list(blocks[1][31:])]          # 66 | 4: no boundary leaves both sides <= 64
+    model2 = orc.Model(blocks2, C, ["A", "A"], "centroid", True)
+    with pytest.raises(AssertionError):
+        run_emu(emu, X, model2, rows=True, split=True)
