@@ -288,6 +288,8 @@ def test_thread_sanitizer_clean():
             "from helpers import satisfaction_oracle_inputs;"
             "lib=ctypes.CDLL(%r); X,b,_=satisfaction_oracle_inputs();"
             "[t.run_emu(lib, X, orc.Model(b, orc.satisfaction_C(), m, s, True), nthreads=6) for m in ('AAAAAA','BBBBBB') for s in ('centroid','path')];"
+            "[t.run_emu(lib, X, orc.Model(b, orc.satisfaction_C(), m, 'path', True), rows=True) for m in ('AAAAAA','BBBBBB')];"      # one thread per MV
+            "Xw,mw=t._wide_model(10, 12, 'M', 'path', 21); t.run_emu(lib, Xw, mw, rows=True, split=True);"                              # two threads per MV
             "print('tsan-run-done')") % (HERE, os.path.join(os.path.dirname(HERE), "oracle"), os.path.join(EMU, "libplspm_hostemu_tsan.so"))
     tsan = subprocess.run(["bash", "-c", "ls /usr/lib/gcc/x86_64-linux-gnu/*/libtsan.so | head -1"], capture_output=True, text=True).stdout.strip()
     env = dict(os.environ, LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
