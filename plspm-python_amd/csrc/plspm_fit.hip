@@ -192,6 +192,8 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[13] - h[7], h[13] - h[0]);
             fprintf(stderr, "[plspm wave last iterate] apply_cov %lld  a/G/E %lld  regress %lld  outer+conv %lld\n", h[9] - h[8], h[10] - h[9], h[11] - h[10], h[12] - h[11]);
             fprintf(stderr, "[plspm wave last apply_cov] seg_products+T %lld  sync %lld  Q %lld\n", h[17] - h[16], h[18] - h[17], h[19] - h[18]);
+            if (m->n_chol > 0) fprintf(stderr, "[plspm wave Mode-B inverses] setup %lld  fill %lld  rows %lld  sweep %lld  store %lld  fallback test %lld  rest of init %lld\n", h[20] - h[2], h[21] - h[20], h[22] - h[21],
+                                       h[23] - h[22], h[24] - h[23], h[25] - h[24], h[3] - h[25]);
         } else {
         fprintf(stderr, "[plspm solver clocks] cov %lld  chol+init %lld  iterate %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                 h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);

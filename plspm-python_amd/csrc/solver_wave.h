@@ -31,6 +31,7 @@
 // ex.load_cov = the column loader; ex.seg_products = the segmented multiply-add stream of solve_problem_rows.
 #pragma once
 #include "solver_core.h"
+#include <type_traits>
 
 namespace plspm {
 
@@ -172,11 +173,12 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     const int ne = md.n_eff;
     const int eidx = (p < ne) ? md.eff_to[p] * LMAX + md.eff_from[p] : 0;
     const double shp = md.scaled ? md.shift[pc] : 0.0;
-    int kbmax = 0;
+    int kbmax = 0, kbB = 0;                                      // widest block; widest Mode-B block
     unsigned long long ends = 0ull;
     for (int l = 0; l < L; ++l) {
         const int k = md.boff[l + 1] - md.boff[l];
         kbmax = k > kbmax ? k : kbmax;
+        if (MODEB && md.mode[l] == MODE_B) kbB = k > kbB ? k : kbB;
         ends |= 1ull << (md.boff[l + 1] - 1);
     }
     ends = ex.uniform(ends);
@@ -236,8 +238,6 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     const int bb0 = md.boff[lp], bk = md.boff[lp + 1] - bb0, bi = p - bb0;
     const long boffB = modeb ? md.chol_off[lp] / 2 : 0;
     if constexpr (MODEB) {
-        int kbB = 0;
-        for (int l = 0; l < L; ++l) if (md.mode[l] == MODE_B) { const int k = md.boff[l + 1] - md.boff[l]; kbB = k > kbB ? k : kbB; }
         ex.sync();                                              // (every lane is done with the column sums ws.mu held)
         ws.mu[p] = sdp * sdp;                                   // the treated diagonal S_pp: the scale a pivot is measured against
         double* A = (kbB & 1) ? ws.stage : ws.inv;              // an odd number of steps ends in ws.inv
@@ -247,9 +247,73 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
             for (int q = 0; q < PMAX; ++q)
                 if (modeb && q >= bb0 && q < bb0 + bk) dst[boffB + bi * bk + (q - bb0)] = s[q];
         };
+        // the same with every lane storing every column -- the ones outside its block into a slot of its own behind the pivot rows of the
+        // sweep below (an address select instead of an exec-masked branch per column: 7 k -> 2 k clocks)
+        auto fill_block_all = [&](double* dst) {
+            double* mine_row = dst + boffB + bi * bk - bb0;      // column q of my block lands at mine_row[q]
+            double* junk = ws.stage + 2 * LMAX * 16 + p;
+            const unsigned bkm = modeb ? (unsigned)bk : 0u;
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                double* d = ((unsigned)(q - bb0) < bkm) ? mine_row + q : junk;
+                *d = s[q];
+            }
+        };
+        bool okrow = true;
+        ex.mark(20);
+        // blocks of at most 16 MVs (round 4): every lane keeps ITS row of the block in registers; step j = the pivot lane publishes its row
+        // (double-buffered at the head of the staging area), one exchange, every lane updates its row with straight-line code (compile-time
+        // column index, `c == j` a scalar test) -- where the loop over LDS-resident matrices below pays two dependent LDS round trips per
+        // column and step (5 k clocks per step at k = 10 against ~1 k).  Same formulas, same pivot test.  KR = registers of a row: 8 / 12 / 16.
+        auto sweep_rows = [&](auto krc) {
+            constexpr int KR = decltype(krc)::value;
+            fill_block_all(ws.inv);
+            ex.sync();
+            ex.mark(21);
+            double row[KR];
+            {
+                const double* Ib0 = ws.inv + boffB + bi * bk;
+#pragma unroll
+                for (int c = 0; c < KR; ++c) row[c] = (modeb && c < bk) ? Ib0[c] : 0.0;
+            }
+            ex.mark(22);
+            for (int j = 0; j < kbB; ++j) {
+                double* Pj = ws.stage + ((j & 1) * LMAX + lp) * 16;
+                if (modeb && bi == j) {
+#pragma unroll
+                    for (int c = 0; c < KR; ++c) Pj[c] = row[c];
+                }
+                ex.sync();
+                if (modeb && j < bk) {
+                    double f = 0.0;
+#pragma unroll
+                    for (int c = 0; c < KR; ++c) f = (c == j) ? row[c] : f;
+                    const double piv = Pj[j];
+                    okrow = okrow && (piv > PLSPM_PIVOT_RTOL * ws.mu[bb0 + j]);
+                    const double ip = wave_rcp(piv);
+                    const bool pivlane = bi == j;
+                    const double fip = f * ip;
+#pragma unroll
+                    for (int c = 0; c < KR; ++c) {
+                        const double rjc = Pj[c] * ip;
+                        const double off = pivlane ? rjc : row[c] - f * rjc;
+                        const double dia = pivlane ? ip : -fip;
+                        row[c] = (c == j) ? dia : off;
+                    }
+                }
+            }
+            ex.mark(23);
+#pragma unroll
+            for (int c = 0; c < KR; ++c) if (modeb && c < bk) ws.inv[boffB + bi * bk + c] = row[c];
+            ex.sync();
+            ex.mark(24);
+        };
+        if (kbB <= 8) sweep_rows(std::integral_constant<int, 8>{});
+        else if (kbB <= 12) sweep_rows(std::integral_constant<int, 12>{});
+        else if (kbB <= 16) sweep_rows(std::integral_constant<int, 16>{});
+        else {
         fill_block(A);
         ex.sync();
-        bool okrow = true;
         for (int j = 0; j < kbB; ++j) {
             if (modeb) {
                 const double* Ab = A + boffB;
@@ -273,8 +337,10 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
             ex.sync();
             double* t = A; A = An; An = t;
         }
+        }
         // rank-deficient blocks, one at a time: S_bb once more from the registers, pseudo-inverse on the block's LV lane (scratch: the staging area)
-        for (int l = 0; l < L; ++l) {
+        const bool any_bad = ex.vote_any(modeb && !okrow);      // (one ballot instead of a descriptor walk when every sweep went through)
+        for (int l = 0; any_bad && l < L; ++l) {
             if (md.mode[l] != MODE_B) continue;
             const int k = md.boff[l + 1] - md.boff[l];
             const bool bad_here = ex.vote_any(modeb && lp == l && !okrow);
@@ -289,6 +355,7 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
             }
             ex.sync();
         }
+        ex.mark(25);
     }
 
     // LV role: normal equations M[f, f] x = M[f, p] over my predecessors f -- up to four in registers (wave_ldl4: every LV lane runs the
