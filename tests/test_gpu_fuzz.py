@@ -64,3 +64,59 @@ def test_random_model(seed):
             continue
         assert its == iters[b], tag + " replicate %d" % b
         assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+
+
+def make_wide_case(seed):
+    """65 ... 128 MVs in 3 ... 12 ragged blocks (metric): the split rows solver where a block boundary leaves at most 64 MVs on either
+    side, the LDS solver otherwise."""
+    rng = np.random.default_rng(5000 + seed)
+    L = int(rng.integers(3, 13))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.8)))
+    P = int(rng.integers(65, 129))
+    cuts = np.sort(rng.choice(np.arange(1, P), size=L - 1, replace=False))
+    sizes = np.diff(np.concatenate(([0], cuts, [P]))).tolist()
+    n = int(rng.integers(300, 900))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    modes = "".join("AB"[int(rng.integers(0, 2))] if 1 < sizes[l] <= 24 else "A" for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    return X, orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2))), sizes
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_wide_model_bootstrap(seed):
+    from plspm import _native
+    X, model, sizes = make_wide_case(seed)
+    n, P = X.shape
+    boff = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], model.scaled, model.max_iter, model.tol, 0)
+    nm.upload(X)
+    B = 40
+    rows, status, iters = nm.bootstrap(B, seed=seed)
+    if nm.get_option("last_gram_path") != 2:
+        pytest.skip("the fp64 route took this batch")
+    below = [int(b) for b in boff[1:-1] if b <= 64]
+    splittable = bool(below) and P - max(below) <= 64
+    assert nm.get_option("last_solver") == (4 if splittable else 1), (sizes, nm.get_option("last_solver"))
+    nm.set_option("solver_rows", 0)
+    rows_l, status_l, iters_l = nm.bootstrap(B, seed=seed)
+    assert nm.get_option("last_solver") == 1
+    tag = "seed %d P=%d sizes=%s %s %s" % (seed, P, sizes, model.modes, model.scheme)
+    assert np.array_equal(status, status_l), tag
+    ok = status == 0
+    assert np.array_equal(iters[ok], iters_l[ok]), tag
+    assert_close(rows[ok], rows_l[ok], 1e-9, 1e-12, what=tag)
+    corr = orc.correction(n)
+    checked = 0
+    for b in range(B):
+        if status[b] != 0 or checked == 2:
+            continue
+        try:
+            mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(seed, b, n), corr)
+        except Exception:
+            continue
+        if not np.all(np.isfinite(mine)):
+            continue
+        assert its == iters[b], tag + " replicate %d" % b
+        assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+        checked += 1
