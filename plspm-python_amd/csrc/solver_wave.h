@@ -68,26 +68,41 @@ template <int LMAX> PLSPM_HD bool wave_solver_covers(int P, int L, int n_chol) {
 
 // 1 / sqrt(x) and 1 / x to the last bit or two (not correctly rounded): v_rsq_f64 / v_rcp_f64 seeds + Newton steps on the device -- a
 // fraction of the dependent instructions of the IEEE sqrt + divide sequences, which sit on the critical path of every small phase.
+// The CPU emulation runs the SAME refinement on a seed of the hardware's accuracy (the exact value rounded to fp32's 24 bits, exponent kept
+// apart so that any double is in range): what the emulation tests then hold against the oracle is this arithmetic, not the IEEE divide.
 PLSPM_HD double wave_rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rsq(x);                           // ~2^-26 relative
+#else
+    double r;
+    if (!(x > 0.0) || x > 1.7976931348623157e308) r = 1.0 / sqrt(x);      // 0, negative, inf, NaN: what the instruction returns
+    else {
+        int e;
+        double m = frexp(x, &e);                                  // x = m 2^e, m in [1/2, 1)
+        if (e & 1) { m *= 2.0; --e; }                             // even exponent: sqrt(2^e) is a power of two
+        r = ldexp((double)(float)(1.0 / sqrt(m)), -e / 2);
+    }
+#endif
     const double hx = 0.5 * x;
     r = fma(r, fma(-hx * r, r, 0.5), r);                          // r (1 + (1/2 - x r^2 / 2))
     r = fma(r, fma(-hx * r, r, 0.5), r);
     return r;
-#else
-    return 1.0 / sqrt(x);
-#endif
 }
 PLSPM_HD double wave_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rcp(x);
+#else
+    double r;
+    if (!(fabs(x) > 0.0) || fabs(x) > 1.7976931348623157e308) r = 1.0 / x;
+    else {
+        int e;
+        const double m = frexp(x, &e);
+        r = ldexp((double)(float)(1.0 / m), -e);
+    }
+#endif
     r = fma(r, fma(-x, r, 1.0), r);
     r = fma(r, fma(-x, r, 1.0), r);
     return r;
-#else
-    return 1.0 / x;
-#endif
 }
 // Normal equations M[f, f] x = M[f, col], f = the k <= 4 indices packed one per byte in `fpack`, M an L x L matrix with pitch ld in the
 // workspace: square-root-free factorisation A = U' D U in registers (as solver_core.h spd_solve_fixed; identity padding beyond k),

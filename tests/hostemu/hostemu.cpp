@@ -338,6 +338,10 @@ int hostemu_solve_rows(int P, int L, int PA, int scheme, int scaled, int max_ite
     return 0;
 }
 
+// The wave solver's reciprocal forms (seed of the hardware's accuracy + two Newton steps): the emulation executes the same refinement.
+double hostemu_wave_rsqrt(double x) { return wave_rsqrt(x); }
+double hostemu_wave_rcp(double x) { return wave_rcp(x); }
+
 // Wave solver (solver_wave.h solve_problem_wave<8>): same inputs as the rows variant, 64 emulated lanes; returns 1 for a model it does not cover.
 int hostemu_solve_wave(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
                        const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,

@@ -249,3 +249,18 @@ def test_wave_thread_sanitizer_clean():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert "tsan-run-done" in r.stdout, r.stderr[-2000:]
     assert "data race" not in r.stderr, r.stderr[-4000:]
+
+
+def test_reciprocal_forms_reach_the_last_bits_from_a_24_bit_seed(emu):
+    """wave_rsqrt / wave_rcp: the device refines v_rsq_f64 / v_rcp_f64 (~2^-26) with two Newton steps; the emulation runs the same two steps
+    on the exact value rounded to 24 bits -- both must land within two units in the last place, whatever the exponent."""
+    emu.hostemu_wave_rsqrt.restype = ctypes.c_double; emu.hostemu_wave_rsqrt.argtypes = [ctypes.c_double]
+    emu.hostemu_wave_rcp.restype = ctypes.c_double; emu.hostemu_wave_rcp.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate((rng.uniform(0.5, 2.0, 400), 10.0 ** rng.uniform(-300, 300, 400), [1.0, 4.0, 2.0 ** -1000, 2.0 ** 1001, 3.0]))
+    worst_s = worst_r = 0.0
+    for x in xs:
+        worst_s = max(worst_s, abs(emu.hostemu_wave_rsqrt(float(x)) * np.sqrt(np.longdouble(x)) - 1))
+        worst_r = max(worst_r, abs(emu.hostemu_wave_rcp(float(x)) * np.longdouble(x) - 1), abs(emu.hostemu_wave_rcp(float(-x)) * np.longdouble(-x) - 1))
+    assert worst_s < 4.5e-16 and worst_r < 4.5e-16, (worst_s, worst_r)
+    assert not np.isfinite(emu.hostemu_wave_rcp(0.0)) and not np.isfinite(emu.hostemu_wave_rsqrt(0.0))      # (inf seed, NaN after the refinement -- as on the device; callers test the pivot first)
