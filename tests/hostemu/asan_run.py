@@ -18,6 +18,14 @@ X, b, _ = satisfaction_oracle_inputs()
 for m in ("AAAAAA", "BBBBBB", "ABABAB"):
     for s in ("centroid", "factorial", "path"):
         t0.run_emu(l, X, orc.Model(b, orc.satisfaction_C(), m, s, True), nthreads=5)
+for m in ("AAAAAA", "BBBBBB"):                                  # rows solver (one thread per MV), its split form (two per MV, 65-128 MVs) and the wave solver
+    t0.run_emu(l, X, orc.Model(b, orc.satisfaction_C(), m, "path", True), rows=True)
+Xw, mw = t0._wide_model(10, 12, "M", "path", 21)
+t0.run_emu(l, Xw, mw, rows=True, split=True)
+import test_solver_hostemu_wave as tw
+Xs, bs = orc.synth(500, orc.satisfaction_C(), 10, seed=4)
+for m in ("AAAAAA", "BBBBBB"):
+    tw.run_wave(l, Xs, orc.Model(bs, orc.satisfaction_C(), m, "path", True))
 print("metric ok")
 import test_solver_hostemu_nonmetric as t1
 from test_oracle_golden import RUSSA_BLOCKS, RUSSA_C, russa_inputs
