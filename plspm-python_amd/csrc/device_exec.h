@@ -79,6 +79,51 @@ struct DevExecT {
     }
 #undef PLSPM_SEG_COL
 #undef PLSPM_SEG_CLOSE
+    // Block loader of the split rows solver (solver_core.h solve_problem_rows<64, true>): lane of a wave <-> MV pc (consecutive over the wave's
+    // lanes: w0 .. w0 + 63, clamped to P - 1), registers <-> the nq <= 64 columns q0 .. of the thread's window; s[q] = S[q0 + q][pc] out of the
+    // upper triangle M[r][c >= r] (row pitch PS).  Entries on or above the diagonal (q0 + q <= pc) are row q0 + q read along the lanes; the ones
+    // below it are row pc of the matrix: read 16 rows at a time ALONG the lanes (lane <-> column q0 + lane) and turned through a 16 x 66 LDS
+    // tile of the wave's own (`xstage`), as solver_wave's loader does for its one diagonal block.  Waves whose block lies wholly on one side of
+    // the diagonal skip the other part (wave-uniform tests); every wave passes the same barriers.
+    template <int PMAX> __device__ __forceinline__ void load_cov_block(const double* __restrict__ Md, int PS, int P, int pc, int q0, int nq, double (&s)[PMAX]) {
+        static_assert(PMAX == 64, "one register per lane of the wave");
+        const int lane = tid & 63;
+        const int w0 = __builtin_amdgcn_readfirstlane((tid & ~63) & (2 * PMAX - 1));      // first MV of this wave
+        double* stage = xstage + (tid >> 6) * (16 * 66);
+        const bool direct = q0 <= min(w0 + 63, P - 1), turned = q0 + nq - 1 > w0;        // (uniform)
+        if (direct) {
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                const int qc = q0 + min(q, nq - 1);
+                const unsigned off = (unsigned)(qc * PS + max(pc, qc)) * 8u;
+                s[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off);
+            }
+        }
+        const int cq = q0 + min(lane, nq - 1);                                            // the column this lane reads in the turned part
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (turned) {
+                double t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rc = min(w0 + 16 * j + i, P - 1);
+                    const unsigned off = (unsigned)(rc * PS + max(cq, rc)) * 8u;
+                    t[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) stage[i * 66 + lane] = t[i];
+            }
+            __syncthreads();
+            if (turned && (lane >> 4) == j) {
+                const double* row = stage + (lane - 16 * j) * 66;
+                const int below = pc - q0;                                               // registers q > below hold entries under the diagonal
+#pragma unroll
+                for (int q = 0; q < PMAX; ++q) s[q] = (q > below) ? row[min(q, nq - 1)] : s[q];
+            }
+            __syncthreads();
+        }
+    }
+    double* xstage = nullptr;      // 16 x 66 doubles per wave (split rows solver only)
     // where threads without an item of their own may store (a shared dead array: every lane then runs the same store instruction)
     __device__ __forceinline__ double* sink(double* dead) { return dead; }
     // a value every thread of the group holds identically, made provably uniform (scalar registers, scalar branches)

@@ -54,12 +54,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PLSPM_R
 }
 
 
+#define PLSPM_ROWS_SPLIT_STAGE_DOUBLES (4 * 16 * 66)
 // Split rows variant (round 4; solve_problem_rows<64, true>): 64 < P <= 128 MVs, FOUR waves per problem -- thread t serves MV t mod 128 with the
 // columns on side t / 128 of a block boundary, so the covariance of a 120-MV model lives in the registers of four waves (two problems per
 // CU, small workspace ~30 KB of LDS each) where solver_kernel keeps 115 KB of LDS per problem (one per CU).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_rows_split_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
+    double* turn = lp;                              // four 16 x 66 tiles: the block loader's transposition staging (device_exec.h load_cov_block)
+    lp += PLSPM_ROWS_SPLIT_STAGE_DOUBLES;
     const long b = blockIdx.x;
     Workspace ws;
     ws.PS = cov_ld(md.P);
@@ -72,6 +75,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     out.status = so.status ? so.status + b : nullptr;
     out.iters = so.iters ? so.iters + b : nullptr;
     DevExecT<4> ex{(int)threadIdx.x, 256, ws.red, (b == 0) ? so.marks : nullptr};
+    ex.xstage = turn;
     solve_problem_rows<64, true>(ex, md, ws, Md + b * md_stride, out);
 }
 

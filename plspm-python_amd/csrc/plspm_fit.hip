@@ -165,9 +165,10 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
         if (m->P > 64) {                           // split form: two threads per MV (plspm_detail_bootstrap asked rows_split_block)
             m->last_solver = 4;
-            if ((rc = allow_lds(m, (const void*)solver_rows_split_kernel, lds))) return rc;
+            const size_t lds4 = lds + PLSPM_ROWS_SPLIT_STAGE_DOUBLES * sizeof(double);
+            if ((rc = allow_lds(m, (const void*)solver_rows_split_kernel, lds4))) return rc;
             ProfScope ps(m, PLSPM_K_SOLVER);
-            hipLaunchKernelGGL(solver_rows_split_kernel, dim3((unsigned)nb), dim3(256), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+            hipLaunchKernelGGL(solver_rows_split_kernel, dim3((unsigned)nb), dim3(256), lds4, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         } else {
             m->last_solver = 2;
             if ((rc = allow_lds(m, (const void*)solver_rows_kernel, lds))) return rc;

@@ -704,11 +704,17 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
     //    One load per column with a selected address (a select of two loads became two exec-masked branches per column); idle threads
     //    and columns past P re-read valid entries, zeroed below.
     const int pc = (p < P) ? p : P - 1;
+    if constexpr (SPLIT) {
+        // (the executor's block loader: on the device rows of the matrix are read along the lanes and turned through LDS -- the lane-per-row
+        //  walk below touches 64 cache lines per wave instruction: 42-48 k -> 34 k clocks of a problem's first-round load at 120 MVs)
+        ex.template load_cov_block<PMAX>(Md, PS, P, pc, q0, nq, cov.s);
+    } else {
 #pragma unroll
     for (int q = 0; q < PMAX; ++q) {
         const int qc = q0 + ((q < nq) ? q : nq - 1);
         const unsigned off = (unsigned)((qc <= pc) ? qc * PS + pc : pc * PS + qc) * 8u;      // 32-bit byte offset from one base: one
         cov.s[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off); // address register per load, all in flight
+    }
     }
     double dpp = 0.0, mup = 0.0;
     if (p < P) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; }

@@ -35,6 +35,13 @@ struct HostExec {
             if ((ends >> q) & 1ull) { *vrow++ = r0 + r1; r0 = 0.0; r1 = 0.0; }
         }
     }
+    // (device: rows read along the lanes + LDS transposition, device_exec.h; here the plain symmetric lookup)
+    template <int PMAX> void load_cov_block(const double* Md, int PS, int, int pc, int q0, int nq, double (&s)[PMAX]) {
+        for (int q = 0; q < PMAX; ++q) {
+            const int qc = q0 + ((q < nq) ? q : nq - 1);
+            s[q] = Md[(qc <= pc) ? qc * PS + pc : pc * PS + qc];
+        }
+    }
     template <class F> void par2(int n0, int n1, F f) {
         for (int e = tid; e < n0 * n1; e += nt) f(e % n0, e / n0);
         bar->arrive_and_wait();
