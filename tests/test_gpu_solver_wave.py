@@ -195,3 +195,30 @@ def test_wave_solver_mode_b_blocks(modes, scheme):
     out = _three_solvers(nm, 64, 5)
     assert np.array_equal(out["wave"][1], out["lds"][1]) and np.array_equal(out["wave"][2], out["lds"][2])
     assert_close(out["wave"][0], out["lds"][0], 1e-8, 1e-10)
+
+
+@pytest.mark.parametrize("sizes,modes", [([8, 8, 8, 8], "BBBB"), ([12, 3, 9], "BAB"), ([13, 16, 2, 7], "BBAB"), ([16, 16, 16, 16], "BBBB"),
+                                         ([17, 8, 5], "BBA"), ([32, 4, 4], "BAB"), ([20, 20, 20], "ABB")])
+def test_wave_solver_mode_b_block_widths(sizes, modes):
+    """Mode-B blocks at the widths where the inverse phase changes form (rows of 8 / 12 / 16 registers per lane; wider than 16 MVs the sweep over
+    LDS-resident matrices): wave solver against the rows and LDS solvers on the same moment matrices and against the oracle."""
+    from plspm import _native
+    from test_gpu_parity import _ragged
+    L = len(sizes)
+    C = orc.chain_C(L)
+    X, blocks = _ragged(900, C, sizes, seed=13)
+    for scheme, scaled in (("centroid", True), ("path", False)):
+        model = orc.Model(blocks, C, modes, scheme, scaled)
+        nm = native_model(model)
+        nm.upload(X)
+        out = _three_solvers(nm, 200, 4)
+        rows, status, iters = out["wave"]
+        assert np.all(status == 0), (sizes, modes, scheme)
+        for other in ("rows", "lds"):
+            assert np.array_equal(out[other][1], status) and np.array_equal(out[other][2], iters), other
+            assert_close(out[other][0], rows, 1e-10, 1e-12, what="%s %s %s" % (sizes, modes, other))
+        corr = orc.correction(900)
+        for r in (0, 199):
+            mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(4, r, 900), corr)
+            assert its == iters[r]
+            assert_close(rows[r], mine, RTOL, ATOL)

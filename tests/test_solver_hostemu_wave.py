@@ -264,3 +264,30 @@ def test_reciprocal_forms_reach_the_last_bits_from_a_24_bit_seed(emu):
         worst_r = max(worst_r, abs(emu.hostemu_wave_rcp(float(x)) * np.longdouble(x) - 1), abs(emu.hostemu_wave_rcp(float(-x)) * np.longdouble(-x) - 1))
     assert worst_s < 4.5e-16 and worst_r < 4.5e-16, (worst_s, worst_r)
     assert not np.isfinite(emu.hostemu_wave_rcp(0.0)) and not np.isfinite(emu.hostemu_wave_rsqrt(0.0))      # (inf seed, NaN after the refinement -- as on the device; callers test the pivot first)
+
+
+@pytest.mark.parametrize("sizes,modes", [([8, 8, 8, 8], "BBBB"), ([12, 3, 9], "BAB"), ([13, 16, 2, 7], "BBAB"), ([16, 16, 16, 16], "BBBB"),
+                                         ([17, 8, 5], "BBA"), ([32, 4, 4], "BAB"), ([20, 20, 20], "ABB")])
+def test_wave_mode_b_block_widths(emu, sizes, modes):
+    """Mode-B blocks at the widths where the inverse phase changes form: rows of 8 / 12 / 16 registers per lane, and -- wider than 16 MVs -- the
+    sweep over LDS-resident matrices; mixed with Mode-A blocks and with narrower Mode-B blocks that wait out the widest one's steps."""
+    rs = np.random.RandomState(11)
+    L = len(sizes)
+    C = orc.chain_C(L)
+    N = 600
+    eta = np.zeros((N, L))
+    for j in range(L):
+        eta[:, j] = 0.5 * eta[:, C[j] == 1].sum(axis=1) + rs.standard_normal(N)
+    cols, blocks, c0 = [], [], 0
+    for j, k in enumerate(sizes):
+        cols.append(eta[:, [j]] * np.linspace(0.5, 0.9, k) + 0.6 * rs.standard_normal((N, k)))
+        blocks.append(np.arange(c0, c0 + k)); c0 += k
+    X = np.column_stack(cols) + rs.standard_normal(c0)
+    for scheme, scaled in (("centroid", True), ("path", False)):
+        model = orc.Model(blocks, C, modes, scheme, scaled)
+        e = run_wave(emu, X, model)
+        assert e is not None
+        check(e, orc.fit(X, model), "%s %s %s" % (sizes, modes, scheme))
+        base = run_emu(emu, X, model, rows=True)
+        assert e["iterations"] == base["iterations"]
+        assert_close(e["row"], base["row"], 1e-10, 1e-12)
