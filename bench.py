@@ -251,7 +251,10 @@ def main():
         comm = ctx.comm
     else:
         rank, world, devices = 0, args.gpus, list(range(args.gpus))
-        if args.gpus > _native.device_count():
+        shared_device_test = os.environ.get("PLSPM_BENCH_SHARED_DEVICE") == "1"      # test seam: the multi-rank code path with every rank on device 0
+        if shared_device_test:
+            devices = [0] * args.gpus
+        elif args.gpus > _native.device_count():
             raise SystemExit("--gpus %d but %d HIP devices are visible" % (args.gpus, _native.device_count()))
         comm = parallel.local_comm(devices) if (world > 1 or args.group) else None
 
@@ -276,7 +279,7 @@ def main():
         ranks_seen = int(comm.nranks)
         assert ranks_seen == world == group.nranks, "communicator spans %d ranks, group %d, --gpus %d" % (ranks_seen, group.nranks, world)
         transport = "rccl" if comm.uses_rccl else "device-copies"
-        if world > 1 and not comm.uses_rccl:
+        if world > 1 and not comm.uses_rccl and os.environ.get("PLSPM_BENCH_SHARED_DEVICE") != "1":
             raise SystemExit("bench: %d ranks but the records would travel by device-to-device copies (ranks share a device): not a multi-GPU run" % world)
         shards = [list(group.shard(args.reps_per_gpu * world, r)) for r in range(world)]
         assert shards[0][0] == 0 and all(shards[r][0] + shards[r][1] == (shards[r + 1][0] if r + 1 < world else args.reps_per_gpu * world) for r in range(world)), shards
@@ -324,6 +327,30 @@ def main():
             fence()
     fence()
     spin_s = time.perf_counter() - spin_t0
+    # More than one rank: the all-gather of step k runs beside the kernels of step k + 1, and a Gram workgroup needs a whole CU -- every CU an
+    # RCCL channel occupies is missing from the launch's last round.  The tile-row cut can be planned for fewer CUs ("i8_cus"; results do not
+    # depend on the cut): a few candidates are tried here, untimed, every rank making the same calls and deciding on the max-over-ranks time.
+    plan_cus = {"chosen": 0, "tried_ms_per_step": {}}
+    if group is not None and world > 1:
+        for rnd in range(3):                                   # (three passes over the candidates, the best of each kept: single passes scatter)
+            for cand in (0, 248, 240, 232, 224, 208):
+                for mdl in models:
+                    mdl.set_option("i8_cus", cand)
+                for _ in range(4):
+                    step()
+                fence()
+                c0 = time.perf_counter()
+                for _ in range(16):
+                    step()
+                fence()
+                ms = round(group.max(time.perf_counter() - c0) / 16 * 1e3, 4)
+                plan_cus["tried_ms_per_step"][str(cand)] = min(ms, plan_cus["tried_ms_per_step"].get(str(cand), ms))
+        tried = plan_cus["tried_ms_per_step"]
+        best = min(tried, key=lambda k: tried[k])
+        if tried[best] < 0.985 * tried["0"]:                   # (a default that is within 1.5 % stays)
+            plan_cus["chosen"] = int(best)
+        for mdl in models:
+            mdl.set_option("i8_cus", plan_cus["chosen"])
     for _ in range(args.warmup):
         step()
     fence()
@@ -557,7 +584,8 @@ def main():
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
                        "parallelism": parallelism, "transport": transport, "ranks_seen_by_rccl": ranks_seen if transport == "rccl" else 0,
-                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>"}.get(model.get_option("last_solver"), "?")},
+                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel"}.get(model.get_option("last_solver"), "?"),
+                       "gram_tile_plan_cus": plan_cus},
             "roofline": roofline,
             "spinup": "%d untimed steps (%.2f s) of the same launches before the %d warm-up steps: brings the device to its working clocks" % (spin_steps, spin_s, args.warmup),
             "cold": {"value": round(B_total * args.steps / cold_elapsed, 1), "unit": "replicates/s", "ms_per_step": round(cold_elapsed / args.steps * 1e3, 4),

@@ -92,6 +92,9 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     only; 16 with six planes: the 256-replicate round-3 kernel.  Read-only "last_i8_rt" / "last_i8_short" / "last_i8_mt": tall
  *                     tile height, short rows and padded count tiles of the last launch
  *   "i8_short_rows"   -1 (default) | n   test seam: n short tile rows behind as many tall ones as it takes
+ *   "i8_cus"          0 (default: every CU of the device) | 8 ... the device's count: the tile-row cut is planned for that many CUs -- for launches
+ *                     that share the chip with the kernels of a collective (a Gram workgroup needs a whole CU; bench.py tries a few values when it
+ *                     runs more than one rank).  Results do not depend on it
  *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the round-3 kernel: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
  *                     ... lds (per-workgroup descriptors + 32-bit offsets; auto takes it whenever an operand's walk stays below 4 GiB)
  *   "i8_ind"          1 (default) | 0   one-plane data run through the seven-plane main loop, the planes of a wave standing for seven pair groups

@@ -254,7 +254,8 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     if ((wide20 || priv) && m->tune.i8_rt == 0 && m->tune.i8_short < 0) {
         if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
         // (the plan of the last shape is kept: a bootstrap calls with the same B again and again, and the search costs of the order of a millisecond)
-        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->cu_count),
+        // ("i8_cus": the cut for fewer CUs than the device has -- a launch that shares the chip with a collective's kernels)
+        const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->tune.i8_cus > 0 ? std::min(m->tune.i8_cus, m->cu_count) : m->cu_count),
                              priv ? 2L + S : (long)(m->tune.i8_waves == 8 && var20 && m->tune.i8_dma != 2)};
         if (!(m->mix_valid && std::equal(key, key + 4, m->mix_key))) {
             // (tile costs of gram_i8p_kernel, tools/i8_mix_calib.py on 960 tiles of each height: six planes 320 / 256 replicates, seven planes 256 / 192)

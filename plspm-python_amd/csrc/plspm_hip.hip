@@ -446,6 +446,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
     else if (k == "upload_direct") { if (value < 0 || value > 1) return bad(); m->tune.upload_direct = value; }
     else if (k == "i8_short_rows") { if (value < -1 || value > 4096) return bad(); m->tune.i8_short = value; }
+    else if (k == "i8_cus") { if (value != 0 && (value < 8 || value > 4096)) return bad(); m->tune.i8_cus = value; }
     else if (k == "i8_rt") { if (value != 0 && value != 16 && value != 8 && value != 20) return bad(); if (value == 8 && !experiments) return exp_only(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
@@ -488,6 +489,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_short_rows") *value = m->tune.i8_short;
+    else if (k == "i8_cus") *value = m->tune.i8_cus;
     else if (k == "upload_direct") *value = m->tune.upload_direct;
     else if (k == "i8_dma") *value = m->tune.i8_dma;
     else if (k == "last_i8_dma") *value = m->last_i8_dma;

@@ -274,3 +274,18 @@ def test_real_multi_gpu_rccl_all_gather_when_the_box_has_two_gpus():
                  "--master-port", "29537", script])
     for key in plain:
         np.testing.assert_allclose(np.array(dist[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)
+
+
+def test_bench_multi_rank_path_on_one_device_calibrates_the_tile_plan(tmp_path):
+    """bench.py --gpus 2 with both ranks on device 0 (test seam PLSPM_BENCH_SHARED_DEVICE): the multi-rank branch of the bench -- group steps,
+    max-over-ranks timing, the tile-plan calibration ("gram_tile_plan_cus") -- runs and prints its one JSON line."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PLSPM_BENCH_SHARED_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--reps-per-gpu", "1000"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["config"]["replicates_per_step"] == 2000 and d["config"]["transport"] == "device-copies"
+    plan = d["config"]["gram_tile_plan_cus"]
+    assert set(plan["tried_ms_per_step"]) == {"0", "248", "240", "232", "224", "208"} and plan["chosen"] in (0, 248, 240, 232, 224, 208)

@@ -594,3 +594,28 @@ def test_random_tile_row_cuts_on_random_shapes():
         nm.set_option("i8_short_rows", -1); nm.set_option("i8_rt", 0)
         assert np.array_equal(nm.bootstrap_moments(B, seed=case), M16), (case, "auto")
         nm.close()
+
+
+def test_tile_row_cut_planned_for_fewer_cus_gives_the_same_records():
+    """set_option("i8_cus", n): the tile rows of the default kernel are cut for n CUs instead of the device's (a launch that shares the chip with
+    a collective's kernels, bench.py's multi-rank calibration).  The cut changes, the records do not."""
+    X, blocks = orc.synth(10000, orc.satisfaction_C(), 10, seed=0)
+    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    ref = nm.bootstrap(5000, seed=3)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_priv") == 1 and nm.get_option("i8_cus") == 0
+    cut0 = (nm.get_option("last_i8_short"), nm.get_option("last_i8_mt"))
+    cuts = {cut0}
+    for cus in (248, 224, 192, 64, 8):
+        nm.set_option("i8_cus", cus)
+        out = nm.bootstrap(5000, seed=3)
+        cuts.add((nm.get_option("last_i8_short"), nm.get_option("last_i8_mt")))
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b), cus
+    assert len(cuts) > 1, cuts                      # the plan reacted to the CU count
+    with pytest.raises(Exception):
+        nm.set_option("i8_cus", 3)
+    nm.set_option("i8_cus", 0)
+    assert (nm.get_option("last_i8_short"), nm.get_option("last_i8_mt")) != (None, None)
+    nm.close()
