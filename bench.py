@@ -331,7 +331,7 @@ def main():
     # RCCL channel occupies is missing from the launch's last round.  The tile-row cut can be planned for fewer CUs ("i8_cus"; results do not
     # depend on the cut): a few candidates are tried here, untimed, every rank making the same calls and deciding on the max-over-ranks time.
     plan_cus = {"chosen": 0, "tried_ms_per_step": {}}
-    if group is not None and world > 1:
+    if group is not None:                                      # (also the one-rank --group run: RCCL's kernel is there all the same)
         for rnd in range(3):                                   # (three passes over the candidates, the best of each kept: single passes scatter)
             for cand in (0, 248, 240, 232, 224, 208):
                 for mdl in models:
