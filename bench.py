@@ -23,6 +23,10 @@ Extra objects on the line:
                 bootstrap_iterations=5000) minus the wall of the same call without the bootstrap (N = 1 only)
   cpu_baseline  the NumPy oracle (oracle/plspm_oracle.py, a port of the reference arithmetic) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  config.gram_tile_plan_cus  (more than one rank, or --group) the all-gather of step k runs beside the kernels of step k + 1 and a Gram workgroup
+                needs a whole CU: before the warm-up steps a few CU counts are tried for the tile-row cut (set_option "i8_cus"; results do not
+                depend on it), every rank making the same calls; `chosen` 0 = the device's count stayed
+PLSPM_BENCH_SHARED_DEVICE=1 is a test seam: --gpus N with every rank on device 0 (tests/test_gpu_dist.py) -- such a line is not a multi-GPU figure.
 """
 import argparse
 import json
