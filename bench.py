@@ -242,13 +242,16 @@ def main():
     ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
+    ap.add_argument("--no-transport-calibration", action="store_true", help="keep RCCL as created (skip the untimed comparison with channel-capped RCCL / the copy-engine exchange)")
     ap.add_argument("--gram-path", type=int, default=0, choices=[0, 1, 2], help="0 library default (int8 digit planes), 1 fp64 MFMA Gram, 2 int8 digit planes")
     args = ap.parse_args()
 
     from plspm import _native, parallel
     launched = "RANK" in os.environ            # one process per GPU (a launcher set RANK / LOCAL_RANK / WORLD_SIZE)
     if launched:
+        t_init = time.perf_counter()
         ctx = parallel.init_process_group()    # file rendezvous of the ncclUniqueId + ncclCommInitRank, inside libplspm_hip.so
+        ctx.comm.create_s = time.perf_counter() - t_init
         rank, world, devices = ctx.rank, ctx.world, [ctx.local_rank]
         if world != args.gpus:
             raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
@@ -261,6 +264,7 @@ def main():
         elif args.gpus > _native.device_count():
             raise SystemExit("--gpus %d but %d HIP devices are visible" % (args.gpus, _native.device_count()))
         comm = parallel.local_comm(devices) if (world > 1 or args.group) else None
+    comm_create_s = round(getattr(comm, "create_s", 0.0), 3) if comm is not None else None      # librccl load + ncclCommInit* (+ the id rendezvous under a launcher): once per process
 
     synthetic, X, blocks = synth_inputs()
     C = synthetic.satisfaction_C()
@@ -273,16 +277,27 @@ def main():
             mdl.set_option("gram_path", args.gram_path)
         return mdl
 
-    models = [make_model(d) for d in devices]
+    upload_s = []
+    models = []
+    for d in devices:
+        t_up = time.perf_counter()
+        models.append(make_model(d))
+        models[-1].sync()
+        upload_s.append(round(time.perf_counter() - t_up, 4))      # handle + descriptors + X over PCIe + mean shift, per device (the first one also pays the HIP context)
     model = models[0]
-    group = _native.NativeGroup(comm, models) if comm is not None else None
+
+    def make_group(on_comm):
+        g = _native.NativeGroup(on_comm, models)
+        g.set_option("chunks", 1)      # the step loop issues calls back to back: the gather of call k overlaps the kernels of call k + 1 as it is (sub-batches are for ONE call: single_call below)
+        return g
+    group = make_group(comm) if comm is not None else None
     # a multi-GPU run validates itself: the communicator really spans --gpus ranks, on distinct devices the records travel through
     # RCCL (never the same-device copy route of the 1-GPU test box), and the shards partition the replicate range
     transport, ranks_seen, shards = "none", 1, [[0, args.reps_per_gpu * world]]
     if group is not None:
         ranks_seen = int(comm.nranks)
         assert ranks_seen == world == group.nranks, "communicator spans %d ranks, group %d, --gpus %d" % (ranks_seen, group.nranks, world)
-        transport = "rccl" if comm.uses_rccl else "device-copies"
+        transport = comm.transport
         if world > 1 and not comm.uses_rccl and os.environ.get("PLSPM_BENCH_SHARED_DEVICE") != "1":
             raise SystemExit("bench: %d ranks but the records would travel by device-to-device copies (ranks share a device): not a multi-GPU run" % world)
         shards = [list(group.shard(args.reps_per_gpu * world, r)) for r in range(world)]
@@ -290,6 +305,7 @@ def main():
     B_total = args.reps_per_gpu * world
     width = model.row_width
     state = {"k": 0}
+    live = {"group": group, "comm": comm}
 
     def step():
         """One batch: a fresh replicate-id range every step (ids k*B .. (k+1)*B of the seeded stream).  Enqueue only -- with a
@@ -299,14 +315,14 @@ def main():
         if group is None:
             model.bootstrap_device(B_total, seed=1, rep_offset=offset)
         else:
-            group.bootstrap(B_total, seed=1, rep_offset=offset)
+            live["group"].bootstrap(B_total, seed=1, rep_offset=offset)
 
     def fence():
         if group is None:
             model.sync()
         else:
-            group.sync()                                       # this process's kernel and gather streams
-            group.barrier()                                    # every rank of the job (all-reduce of one word over RCCL)
+            live["group"].sync()                               # this process's kernel and gather streams
+            live["group"].barrier()                            # every rank of the job (all-reduce of one word over RCCL)
 
     # cold figure: the W warm-up steps and K timed steps straight after the upload, BEFORE the spin-up below -- what the driver's
     # --warmup alone buys (reported beside `value`; every rank makes the same calls)
@@ -334,6 +350,53 @@ def main():
     # More than one rank: the all-gather of step k runs beside the kernels of step k + 1, and a Gram workgroup needs a whole CU -- every CU an
     # RCCL channel occupies is missing from the launch's last round.  The tile-row cut can be planned for fewer CUs ("i8_cus"; results do not
     # depend on the cut): a few candidates are tried here, untimed, every rank making the same calls and deciding on the max-over-ranks time.
+    # How the records travel (round 5): RCCL's default channel count is sized for large all-reduces, while this job issues ONE
+    # all-gather of a few MB per step beside a Gram that needs whole CUs.  Candidates, each timed untimed-region-style on a group of its own over the
+    # SAME handles (every rank makes the same calls, decisions on the max-over-ranks time): RCCL as created (the default -- it stays unless a
+    # candidate is 1.5 % faster), RCCL communicators split off it with at most 8 / 2 channels (ncclCommSplit + ncclConfig_t.maxCTAs), and -- one
+    # process driving distinct devices -- the copy-engine exchange on peer-mapped buffers (no kernel at all).
+    transport_cal = None
+    if group is not None and comm.uses_rccl and not args.no_transport_calibration:
+        def time_steps(n_warm=4, n_timed=16):
+            for _ in range(n_warm):
+                step()
+            fence()
+            c0 = time.perf_counter()
+            for _ in range(n_timed):
+                step()
+            fence()
+            return live["group"].max(time.perf_counter() - c0) / n_timed * 1e3
+        cands = {"rccl": comm}
+        errors = {}
+        for cap in (8, 2):
+            try:
+                cands["rccl(max_channels=%d)" % cap] = comm.split(cap)
+            except Exception as exc:                           # (an RCCL without ncclCommSplit: every rank fails alike, the default stays)
+                errors["rccl(max_channels=%d)" % cap] = str(exc)[:200]
+        if not launched and world > 1:
+            try:
+                cands["copy-engines"] = _native.NativeComm(devices, transport="copy")
+            except Exception as exc:
+                errors["copy-engines"] = str(exc)[:200]
+        tried = {}
+        for rnd in range(2):
+            for name, cc in cands.items():
+                live["group"].close()
+                live["group"] = make_group(cc)
+                ms = round(time_steps(), 4)
+                tried[name] = min(ms, tried.get(name, ms))
+        best = min(tried, key=lambda k: tried[k])
+        chosen = best if tried[best] < 0.985 * tried["rccl"] else "rccl"
+        live["group"].close()
+        live["group"] = make_group(cands[chosen])
+        live["comm"] = cands[chosen]
+        for name, cc in cands.items():
+            if name != chosen and cc is not comm:
+                cc.close()
+        group = live["group"]
+        transport = chosen
+        transport_cal = {"tried_ms_per_step": tried, "chosen": chosen, "errors": errors,
+                         "split_s": {name: round(getattr(cc, "create_s", 0.0), 3) for name, cc in cands.items() if cc is not comm}}
     plan_cus = {"chosen": 0, "tried_ms_per_step": {}}
     if group is not None:                                      # (also the one-rank --group run: RCCL's kernel is there all the same)
         for rnd in range(3):                                   # (three passes over the candidates, the best of each kept: single passes scatter)
@@ -347,7 +410,7 @@ def main():
                 for _ in range(16):
                     step()
                 fence()
-                ms = round(group.max(time.perf_counter() - c0) / 16 * 1e3, 4)
+                ms = round(live["group"].max(time.perf_counter() - c0) / 16 * 1e3, 4)
                 plan_cus["tried_ms_per_step"][str(cand)] = min(ms, plan_cus["tried_ms_per_step"].get(str(cand), ms))
         tried = plan_cus["tried_ms_per_step"]
         best = min(tried, key=lambda k: tried[k])
@@ -414,6 +477,29 @@ def main():
             model.bootstrap_device(args.reps_per_gpu, seed=1, rep_offset=k * args.reps_per_gpu)
         model.sync()
         model.profile(False)
+
+    single_call = None
+    if group is not None:
+        # ONE call of the whole job (configs[3] as a user issues it: Plspm(bootstrap_iterations = N x 5,000, devices = ...)): enqueue -> every rank's
+        # records gathered on every rank, nothing of a neighbouring call to hide under.  With one sub-batch the whole gather is exposed; with the
+        # automatic sub-batches (plspm_group_bootstrap, round 5) only the last, smallest one.  Median of 7 calls each, max over ranks.
+        def one_call(chunks):
+            group.set_option("chunks", chunks)
+            ts = []
+            for _ in range(8):
+                fence()
+                c0 = time.perf_counter()
+                step()
+                group.sync()
+                ts.append(time.perf_counter() - c0)
+            return group.max(float(np.median(ts[1:]))) * 1e3
+        single_call = {"one_sub_batch_ms": round(one_call(1), 4), "sub_batches_ms": round(one_call(0), 4),
+                       "sub_batch_plan": [[a, n] for a, n in group.plan(B_total)],
+                       "note": "wall of ONE plspm_group_bootstrap call of %d replicates + plspm_group_sync on an idle job (median of 7, max over ranks): one sub-batch "
+                               "(the whole gather exposed) / automatic sub-batches (the gather of sub-batch k beside the kernels of k + 1); the timed steps "
+                               "above run back to back with one sub-batch per call" % B_total}
+        group.set_option("chunks", 1)
+        fence()
 
     pcie = None
     if world == 1 and group is None:
@@ -589,7 +675,8 @@ def main():
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
                        "parallelism": parallelism, "transport": transport, "ranks_seen_by_rccl": ranks_seen if transport == "rccl" else 0,
                        "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel"}.get(model.get_option("last_solver"), "?"),
-                       "gram_tile_plan_cus": plan_cus},
+                       "gram_tile_plan_cus": plan_cus, "transport_calibration": transport_cal,
+                       "comm_create_s": comm_create_s, "upload_s_per_device": upload_s, "single_call_latency_ms": single_call},
             "roofline": roofline,
             "spinup": "%d untimed steps (%.2f s) of the same launches before the %d warm-up steps: brings the device to its working clocks" % (spin_steps, spin_s, args.warmup),
             "cold": {"value": round(B_total * args.steps / cold_elapsed, 1), "unit": "replicates/s", "ms_per_step": round(cold_elapsed / args.steps * 1e3, 4),
@@ -599,13 +686,20 @@ def main():
         }
         if planes is not None:
             line["digit_planes"] = planes
+            # the rate that is no worse than fp64 BY CONSTRUCTION (seven planes: correctly rounded sums; what Plspm(..., precision="strict") runs and
+            # what data below the six-plane bar -- heavy tails, a few hundred rows -- get anyway), as a top-level field beside `value`
+            line["value_strict"] = planes["seven_planes"]["value"]
+            line["value_strict_note"] = ("replicates/s of the same workload on seven digit planes (Plspm(precision='strict') / set_option i8_slices 7): moment sums correctly "
+                                         "rounded by construction; `value` runs the automatic %d planes, whose error on this data is measured on this line (digit_planes)" % slices)
         if round3 is not None:
             line["round3_gram_kernel"] = round3
         if other is not None:
             line["fp64_mfma_path"] = other
         if pcie is not None:
             line["pcie_inclusive"] = {"value": round(pcie, 1), "unit": "replicates/s",
-                                      "note": "plspm_bootstrap(): the B x 158 records copied to the caller's (pageable, re-used) host buffers through pinned staging every step"}
+                                      "sub_batches": _native.chunk_plan(B_total, 8 * model.row_stride, model.get_option("boot_chunks"), model.get_option("boot_ratio")),
+                                      "note": "plspm_bootstrap(): the B x 158 records copied to the caller's (pageable, re-used) host buffers through pinned staging every step; "
+                                              "round 5: the call runs as sub-batches, the download + unpacking of sub-batch k beside the kernels of k + 1"}
         if world == 1 and group is None and not args.no_api:
             line["api_inclusive"] = api_inclusive(X, args.reps_per_gpu)
             line["api_inclusive"]["frac_of_value"] = round(line["api_inclusive"]["value"] / line["value"], 3)

@@ -50,7 +50,7 @@ enum {
 enum { PLSPM_E_ARG = 100, PLSPM_E_STATE = 101, PLSPM_E_LIMIT = 102 };
 
 /* ABI version of this header; plspm_abi_version() of the loaded library must match. */
-#define PLSPM_ABI_VERSION 3
+#define PLSPM_ABI_VERSION 4
 int plspm_abi_version(void);
 
 /* Number of HIP devices visible to the process (0 when there is none; never negative). */
@@ -91,7 +91,6 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     the 8 XCDs, tile costs measured per kernel: profiles/r04_i8_mix_calib.jsonl); 20 / 16 with six / seven planes: tall rows
  *                     only; 16 with six planes: the 256-replicate round-3 kernel.  Read-only "last_i8_rt" / "last_i8_short" / "last_i8_mt": tall
  *                     tile height, short rows and padded count tiles of the last launch
- *   "i8_short_rows"   -1 (default) | n   test seam: n short tile rows behind as many tall ones as it takes
  *   "i8_cus"          0 (default: every CU of the device) | 8 ... the device's count: the tile-row cut is planned for that many CUs -- for launches
  *                     that share the chip with the kernels of a collective (a Gram workgroup needs a whole CU; bench.py tries a few values when it
  *                     runs more than one rank).  Results do not depend on it
@@ -118,18 +117,19 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     streaming product of every step (bit-identical steps, a quarter of the bytes)
  *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
  *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
+ * Host-buffer bootstrap (plspm_bootstrap)
+ *   "boot_chunks"     0 (default: automatic) | 1 .. 8   plspm_bootstrap() of a metric model on Philox draws runs as sub-batches: the records of
+ *                     sub-batch k cross PCIe on a copy stream -- and are unpacked into the caller's buffers -- while the kernels of sub-batch
+ *                     k + 1 run.  Automatic: one below 2 MiB of records, else three, sizes falling by "boot_ratio" percent (default 60: what
+ *                     moving a record costs relative to computing it on the headline model), every one but the last a multiple of 64
+ *                     replicates.  Records do not depend on it
  * Single fit / upload
  *   "fit_chunks"      0 (auto) .. 65535   row chunks (workgroups) of the single-fit Gram
  *   "wide_nw"         4 | 8 | 16          waves sharing one row walk in gram_wide_kernel<14>
  *   "scores_tile"     0 (by LDS footprint) | 16 | 32   rows per tile of the scores kernel
- *   "gram_lds_kb"     0 .. 160   pads the dynamic LDS of gram_rows_kernel (occupancy experiments)
  *   "upload_direct"   0 (default) | 1   plspm_upload of more than 64 MB: 0 through the handle's pinned staging halves, filled by several host
  *                     threads; 1 the runtime's pageable copy (one staging thread: 13-52 GB/s depending on the host)
- * Experiments build only (make -C plspm-python_amd/csrc experiments, loaded through PLSPM_HIP_LIB; the release library answers PLSPM_E_ARG):
- * "i8_waves" 4 (four-wave forms of the round-3 kernel: measured equal), "i8_shape" 32 (v_mfma_i32_32x32x32_i8 layout: 16 % slower), "i8_sched" 1
- * (persistent stream-K launch: kernel -3 %, step unchanged, and two such launches sharing a device can starve each other), "i8_rt" 8 (128-replicate
- * tile: 2.6 % slower), "resample_aux" 1 .. 3 (counts drawn on a second stream: inside the spread), "i8_variant" (schedule variants and ablation
- * probes of both Gram kernels).  Read-only "build_experiments" tells which library is loaded.  DESIGN.md 7b has the measurements.
+ * (Test seams and the option values of the experiments build: include/plspm_hip_test.h.)
  *
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
  * (1 LDS solver, 2 rows solver, 3 wave solver, 4 split rows solver) tell what the last bootstrap call took.
@@ -356,8 +356,26 @@ int plspm_rccl_unique_id(uint8_t* id /* [PLSPM_UNIQUE_ID_BYTES] */);
 plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id);
 void plspm_comm_destroy(plspm_comm_t* c);                  /* a group still bound to it is released (streams, buffers, its hold on the handles): later
                                                               calls on that group return PLSPM_E_STATE; its owner still calls plspm_group_destroy */
+/* The same with the transport and RCCL's footprint chosen (round 5):
+ *   transport     PLSPM_TRANSPORT_AUTO   RCCL between distinct devices, one copy launch among ranks that share a device (plspm_comm_create)
+ *                 PLSPM_TRANSPORT_RCCL   RCCL or failure
+ *                 PLSPM_TRANSPORT_COPY   single-process jobs only (n_local == nranks): no RCCL -- every rank pulls its peers' shards with
+ *                                        device-to-device copies on peer-mapped buffers (hipDeviceEnablePeerAccess): the SDMA engines move the
+ *                                        records over xGMI and no kernel of the exchange takes a CU from the next step's Gram
+ *   max_channels  0: RCCL's default; n > 0: the communicator's collectives run at most n workgroups (ncclConfig_t.maxCTAs) -- a Gram workgroup
+ *                 needs a whole CU, so every CU an RCCL channel occupies is missing from a launch cut for all of them; the one all-gather of
+ *                 44 MB per 0.48 ms step (eight ranks) does not need RCCL's default channel count.  The NCCL_* environment variables of the
+ *                 caller are not touched.
+ * plspm_comm_split: a second communicator over the same ranks with its own max_channels, split off an RCCL communicator (ncclCommSplit --
+ * collective over the parent, every rank calls it; no new unique id): lets a job time RCCL's default against a capped one (bench.py). */
+enum { PLSPM_TRANSPORT_AUTO = 0, PLSPM_TRANSPORT_RCCL = 1, PLSPM_TRANSPORT_COPY = 2 };
+plspm_comm_t* plspm_comm_create_ex(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id, int32_t transport,
+                                   int32_t max_channels);
+plspm_comm_t* plspm_comm_split(plspm_comm_t* parent, int32_t max_channels);
 int32_t plspm_comm_size(const plspm_comm_t* c);            /* nranks */
-int32_t plspm_comm_uses_rccl(const plspm_comm_t* c);       /* 1: records travel through RCCL; 0: the same-device copy route */
+int32_t plspm_comm_uses_rccl(const plspm_comm_t* c);       /* 1: records travel through RCCL; 0: device-to-device copies */
+int32_t plspm_comm_transport(const plspm_comm_t* c);       /* PLSPM_TRANSPORT_RCCL / PLSPM_TRANSPORT_COPY / 3: ranks share a device (one copy launch) */
+int32_t plspm_comm_max_channels(const plspm_comm_t* c);    /* the cap the communicator was created with (0: RCCL's default) */
 /* models [n_local of the communicator]: handle i lives on the communicator's device i, data uploaded.  NULL on failure. */
 plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models);
 void plspm_group_destroy(plspm_group_t* g);
@@ -367,13 +385,24 @@ const char* plspm_group_last_error(const plspm_group_t* g);
 int32_t plspm_group_size(const plspm_group_t* g);          /* nranks */
 /* Shard of rank `rank`: balanced contiguous ranges, the first B % nranks ranks hold one replicate more. */
 int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* first, int64_t* count);
-/* Enqueue B replicates split over the group + the all-gather.  Returns without host synchronisation for metric models. */
+/* Enqueue B replicates split over the group + the all-gather.  Returns without host synchronisation for metric models.
+ * ONE call hides its merge (round 5): the call runs as up to three SUB-BATCHES -- consecutive ranges of the replicate ids, each sharded over the
+ * ranks like a call of its own (plspm_group_plan) -- and the all-gather of sub-batch k runs on the gather streams beside the shard kernels of
+ * sub-batch k + 1; only the last, smallest gather is exposed.  Results do not depend on the cut (Philox stream keyed by (seed, replicate id)).
+ * Options (plspm_group_set_option): "chunks" 0 (default: automatic -- one sub-batch below 2 MiB of records per rank or on a one-rank group,
+ * else up to three, sizes falling by "chunk_ratio" percent) | 1 .. 8 sub-batches -- a caller that issues calls back to back (bench.py's
+ * step loop) sets 1: the gather of call k then overlaps the kernels of call k + 1 anyway; "chunk_ratio" 10 .. 100 (default 50). */
 int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset);
+int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value);
+/* The sub-batches a call of B replicates is cut into: *n_sub (<= 8) ranges [sub_first[k], sub_first[k] + sub_count[k]) (arrays of 8), in
+ * replicate-id order; rank r computes plspm_group_shard(sub_count[k], r) of each, offset by sub_first[k]. */
+int plspm_group_plan(const plspm_group_t* g, int64_t B, int32_t* n_sub, int64_t* sub_first, int64_t* sub_count);
 /* Wait for everything enqueued on the group's streams (every local handle). */
 int plspm_group_sync(plspm_group_t* g);
-/* Gathered records of the last plspm_group_bootstrap on local handle `local`: *d_records -> [*n_records * *stride] fp64 in HBM,
- * n_records = nranks * ceil(B / nranks); rank r's shard starts at record r * ceil(B / nranks); the unused tail records of a ragged
- * split carry NaN in the status column.  Valid until the next-but-one plspm_group_bootstrap. */
+/* Gathered records of the last plspm_group_bootstrap on local handle `local`: *d_records -> [*n_records * *stride] fp64 in HBM.  One sub-batch
+ * (plspm_group_plan): n_records = nranks * ceil(B / nranks); rank r's shard starts at record r * ceil(B / nranks); the unused tail records of
+ * a ragged split carry NaN in the status column.  Several sub-batches: one such block per sub-batch, one after the other (the replicates stay
+ * in id order; n_records = nranks * sum_k ceil(sub_count[k] / nranks)).  Valid until the next-but-one plspm_group_bootstrap. */
 int plspm_group_records(plspm_group_t* g, int32_t local, void** d_records, int64_t* n_records, int32_t* stride);
 /* _create_summary (bootstrap.py:24-32) of the last plspm_group_bootstrap, on local handle 0's copy of the gathered records:
  * same outputs as plspm_bootstrap_summary. */
@@ -415,20 +444,6 @@ int plspm_op_inner_weights(int32_t device_id, int32_t scheme, int32_t L, const u
 int plspm_op_outer_weights(int32_t device_id, int32_t mode, const double* Xk, const double* z, int64_t N, int32_t k, double* w);
 int plspm_op_outer_weights_nonmetric(int32_t device_id, int32_t mode, const double* Xk, const uint8_t* present, const double* z, int64_t N, int32_t k,
                                      double correction, double* w, double* Y);
-
-/* Test seam: only the resample + Gram stages of plspm_bootstrap (on the Gram path the handle's "gram_path" option selects).
- *   idx   NULL (on-device Philox draws) or [B*N] explicit row indices;   out [B * C * C], C = device columns + 1 (after the data
- *   columns the missing indicators of plspm_model_set_missing, last the ones column): the replicate's full symmetric matrix
- *   sum_i c_i [x_i - shift, 1][x_i - shift, 1]' of the uploaded (mean-shifted) columns.  Metric handles only. */
-int plspm_bootstrap_moments(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out);
-
-/* The resample indices the on-device RNG uses for replicate `rep` (host-side mirror, for tests). */
-int plspm_bootstrap_indices(uint64_t seed, int64_t rep, int64_t N, int32_t* idx);
-
-/* Test seam, host arithmetic only (no device is touched): how the six-plane int8 Gram cuts `count_tiles` (16 replicates each) x
- * `pair_tiles` (32 pair columns each) into tile rows on `cus` CUs ("i8_rt" 0).  *tall rows of 20 count tiles and, with `mix` != 0, *shrt
- * rows of 16 in one launch; returns 1 when that launch is taken, 0 when the 256-replicate kernel is no slower, PLSPM_E_ARG on bad sizes. */
-int plspm_gram_tile_plan(int64_t count_tiles, int64_t pair_tiles, int32_t cus, int32_t mix, int32_t* tall, int32_t* shrt);
 
 /* Kernel timing with HIP events on the handle's own stream (for the roofline figures in bench.py).
  * kernel ids: 0 resample/compact, 1 gram (MFMA), 2 solver, 3 scores, 4 upload/pack, 5 gram reduce. */

@@ -20,7 +20,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/plspm_hip.h"
+#include "../../include/plspm_hip_test.h"
 #include "solver_core.h"
 #include "solver_nmg.h"
 #include "solver_hoc.h"

@@ -8,7 +8,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/plspm_hip.h"
+#include "../../include/plspm_hip_test.h"
 
 inline thread_local std::string g_create_error;
 
@@ -87,7 +87,7 @@ struct plspm_model {
     bool err_clean = false;       // the device error word is zero and no call since could have raised it (plspm_detail_bootstrap)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
     Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat, codes;
@@ -129,8 +129,13 @@ struct plspm_model {
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
     hipEvent_t ev_pin_async = nullptr;   // behind copies that left the staging area without a host wait (plspm_hip.hip pin_leave_async)
     bool pin_pending = false;
-    std::vector<void*> blobs;     // descriptor blocks (several small arrays uploaded as one: plspm_hip.hip upload_blob)
+    enum { BLOB_MODEL = 0, BLOB_CATEGORICAL = 1, BLOB_HOC = 2, BLOB_COUNT = 3 };
+    void* blobs[BLOB_COUNT] = {nullptr, nullptr, nullptr};     // descriptor blocks, one per call site (several small arrays uploaded as one: plspm_hip.hip upload_blob)
     void* group = nullptr;        // the plspm_group this handle currently belongs to (plspm_group.cpp)
+    // plspm_bootstrap as sub-batches (plspm_bootstrap.hip): the copy stream the records of sub-batch k leave on while sub-batch k + 1 computes,
+    // one event per sub-batch
+    hipStream_t dl = nullptr;
+    hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool profiling = false;
     int prof_only = -1;          // >= 0: only this kernel id is bracketed by events (plspm_profile_enable(m, 2 + id))
     ProfSlot prof[PLSPM_K_COUNT];
@@ -141,13 +146,22 @@ struct plspm_model {
 // (pitch plspm_row_stride) or into the handle's own `rows` buffer when rows_out is NULL.  No host synchronisation for metric models.
 int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, double* rows_out);
 // plspm_group.cpp: a handle that is destroyed while bound to a group takes the group's hold on every handle with it.
-extern "C" void plspm_detail_group_orphan(void* group);
+void plspm_detail_group_orphan(void* group);
 // Host -> device copy through the handle's pinned staging halves (chunked; returns when the source may be re-used).
 int plspm_detail_h2d(plspm_model* m, void* dst, const void* src, size_t bytes);
 // Summary statistics of device records (plspm_bootstrap_summary without the argument checks on `rows`).
 int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t stride, const double* original, double* summary, int64_t* n_used);
 // Host copy of device records [B x stride] -> rows [B x R], status, iters (any may be NULL), through the pinned staging buffer.
 int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t B, int32_t stride, double* out, int32_t* status, int32_t* iters);
+
+// Sub-batches of ONE call of B units (replicates) whose results leave the device behind the kernels -- over PCIe (plspm_bootstrap) or through the
+// collective (plspm_group_bootstrap): sizes in a geometric progression (ratio_pct / 100: what moving a unit costs relative to computing it), so that
+// the transfer of sub-batch k hides under the kernels of sub-batch k + 1 and only the last, smallest transfer is exposed; every part but the last
+// a multiple of 64 units (whole count tiles of the int8 Gram).  chunks_opt 0: automatic (one part below 2 MiB of results, else up to three),
+// n >= 1: n parts.  Returns the number of parts (<= kBootChunksMax), sizes in parts[].  Host arithmetic only (plspm_group.cpp).
+static constexpr int kBootChunksMax = 8;
+int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts);
+struct FetchSeg { int64_t b0, nb; hipEvent_t ready; };
 
 // Same-device record exchange of a group (plspm_bootstrap.hip): send[i] -> recv[d] + i * doubles for all i, d < n, one launch on `stream`.
 #define PLSPM_GATHER_LOCAL_MAX 16

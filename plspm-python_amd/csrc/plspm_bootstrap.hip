@@ -145,6 +145,9 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     return 0;
 }
 
+static int fetch_segments(plspm_model* m, hipStream_t cs, const double* d_records, int32_t stride, const FetchSeg* segs, int nsegs, int64_t B_total, double* out, int32_t* status,
+                          int32_t* iters);
+
 extern "C" {
 
 int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* d_idx, void** d_out, void** d_status,
@@ -158,7 +161,7 @@ int plspm_bootstrap_device(plspm_model_t* m, int64_t B, uint64_t seed, int64_t r
 }
 
 int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offset, const int32_t* idx, double* out, int32_t* status, int32_t* iters) {
-    if (!m || !out || B < 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
+    if (!m || !out || B < 1 || B > ((int64_t)1 << 30)) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: bad arguments");
     if (!m->d_Xa) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: no data uploaded");
     HIPCHK(m, hipSetDevice(m->device));
     const int32_t* d_idx = nullptr;
@@ -169,20 +172,46 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
         if ((rc = plspm_detail_h2d(m, m->idx.p, idx, bytes))) return rc;
         d_idx = (const int32_t*)m->idx.p;
     }
-    if ((rc = plspm_detail_bootstrap(m, B, seed, rep_offset, d_idx, nullptr))) return rc;
-    if ((rc = plspm_detail_fetch_records(m, (const double*)m->rows.p, B, plspm_row_stride(m), out, status, iters))) return rc;
-    int* h_err = (int*)m->h_flag + 8;
-    HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipStreamSynchronize(m->stream));
-    if (*h_err & 4) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the persistent Gram gave up waiting for a partial tile (device shared with a long-running kernel?); set_option i8_sched 0");
-    if (*h_err & 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
-    if (*h_err & 2) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: a resample multiplicity exceeded 127 on the int8 Gram path (set_option gram_path 1)");
-    if (*h_err) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the device reported error bits " + std::to_string(*h_err));
-    if (m->err2.p) {                       // Philox draws on the int8 path: a multiplicity above 127 (P < 1e-200) would have wrapped
-        HIPCHK(m, hipMemcpyAsync(h_err, m->err2.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(m, hipStreamSynchronize(m->stream));
-        if (*h_err) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: a resample multiplicity exceeded 127 on the int8 Gram path (set_option gram_path 1)");
+    // The call as SUB-BATCHES (round 5): the records of sub-batch k cross PCIe on a copy stream of the handle's own
+    // -- and are unpacked into the caller's buffers -- while the kernels of sub-batch k + 1 run; only the last, smallest sub-batch's download is
+    // exposed.  Metric models on Philox draws (explicit index lists and the non-metric iteration make host round trips inside the call as
+    // it is).  The records of a replicate do not depend on the sub-batch it travels in (exact integer Gram, per-replicate solver).
+    const int RS = plspm_row_stride(m);
+    int64_t parts[kBootChunksMax];
+    int nparts = 1;
+    parts[0] = B;
+    if (!d_idx && !m->nonmetric && !m->moments_out) nparts = plspm_detail_chunk_plan(B, (int64_t)RS * (int64_t)sizeof(double), m->tune.boot_chunks, m->tune.boot_ratio, parts);
+    if (nparts > 1) {
+        if (!m->dl) HIPCHK(m, plspm_stream_acquire(&m->dl));
+        for (int k = 0; k < nparts; ++k)
+            if (!m->ev_part[k]) HIPCHK(m, hipEventCreateWithFlags(&m->ev_part[k], hipEventDisableTiming));
     }
+    m->rows_B = 0;
+    if ((rc = ensure(m, m->rows, (size_t)B * RS * sizeof(double)))) return rc;
+    double* const rows = (double*)m->rows.p;
+    int* h_err = (int*)m->h_flag + 8;
+    h_err[0] = h_err[1] = 0;
+    FetchSeg segs[kBootChunksMax];
+    int64_t b0 = 0;
+    for (int k = 0; k < nparts; ++k) {
+        if ((rc = plspm_detail_bootstrap(m, parts[k], seed, rep_offset + b0, d_idx ? d_idx + b0 * m->N : nullptr, rows + b0 * RS))) return rc;
+        if (k == nparts - 1) {
+            // ONE error word, read with the last sub-batch: copied behind the last kernel, in front of the event its download waits for
+            HIPCHK(m, hipMemcpyAsync(h_err, m->err.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            if (m->err2.p) HIPCHK(m, hipMemcpyAsync(h_err + 1, m->err2.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));      // (experiments build: counts drawn on a second stream)
+        }
+        segs[k].b0 = b0; segs[k].nb = parts[k]; segs[k].ready = nullptr;
+        if (nparts > 1) { HIPCHK(m, hipEventRecord(m->ev_part[k], m->stream)); segs[k].ready = m->ev_part[k]; }
+        b0 += parts[k];
+    }
+    rc = fetch_segments(m, nparts > 1 ? m->dl : m->stream, rows, RS, segs, nparts, B, out, status, iters);
+    if (nparts > 1) HIPCHK(m, hipStreamSynchronize(m->stream));      // (done already: the last download waited for the last kernel; keeps the handle's invariants simple)
+    if (rc) return rc;
+    m->rows_B = B;
+    if (h_err[0] & 4) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the persistent Gram gave up waiting for a partial tile (device shared with a long-running kernel?); set_option i8_sched 0");
+    if (h_err[0] & 1) return fail(m, PLSPM_E_ARG, "plspm_bootstrap: resample index outside [0, N)");
+    if ((h_err[0] & 2) || h_err[1]) return fail(m, PLSPM_E_LIMIT, "plspm_bootstrap: a resample multiplicity exceeded 127 on the int8 Gram path (set_option gram_path 1)");
+    if (h_err[0]) return fail(m, PLSPM_E_STATE, "plspm_bootstrap: the device reported error bits " + std::to_string(h_err[0]));
     return 0;
 }
 
@@ -310,14 +339,17 @@ int plspm_detail_gather_local(hipStream_t stream, int n, const double* const* se
     return hipGetLastError() == hipSuccess ? 0 : PLSPM_E_STATE;
 }
 
-int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t B, int32_t stride, double* out, int32_t* status, int32_t* iters) {
+// Host copy of device records, segment by segment: segment k = records [b0, b0 + nb) of `d_records`, downloaded on `cs` once its `ready` event
+// (may be null) has fired on the device side -- the copy stream waits, not the host.  Pieces of at most half the staging area -- and of at
+// most a quarter of all records, so that the host's unpacking of one piece runs beside the DMA of the next even when everything would fit a
+// single piece (5,000 x 158 records = 6.3 MB).
+static int fetch_segments(plspm_model* m, hipStream_t cs, const double* d_records, int32_t stride, const FetchSeg* segs, int nsegs, int64_t B_total, double* out, int32_t* status,
+                          int32_t* iters) {
     const int R = stride - 2;
     int rc = pin_ready(m);
     if (rc) return rc;
-    // chunks of at most half the staging area -- and of at most a quarter of the records, so that the host's unpacking of one chunk runs
-    // beside the DMA of the next even when everything would fit a single chunk (5,000 x 158 records = 6.3 MB)
     int64_t per = std::max<int64_t>(1, (int64_t)(kPinHalf / ((size_t)stride * sizeof(double))));
-    per = std::min<int64_t>(per, std::max<int64_t>(256, (B + 3) / 4));
+    per = std::min<int64_t>(per, std::max<int64_t>(256, (B_total + 3) / 4));
     struct Job { const double* rec; int64_t b0, nb; int32_t stride, R; double* out; int32_t* status; int32_t* iters; };
     auto unpack_part = [](void* a, int t, int T) {
         const Job& j = *(const Job*)a;
@@ -331,23 +363,32 @@ int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t 
     };
     // the crew from a megabyte of records on (smaller downloads are done before a helper has woken up)
     struct Session { bool on = false; ~Session() { if (on) unpack_crew().end(); } } crew;
-    if ((size_t)B * stride * sizeof(double) >= ((size_t)1 << 20)) crew.on = unpack_crew().begin();
+    if ((size_t)B_total * stride * sizeof(double) >= ((size_t)1 << 20)) crew.on = unpack_crew().begin();
     auto unpack = [&](int h, int64_t b0, int64_t nb) {
         Job j{(const double*)((const char*)m->h_pin + h * kPinHalf), b0, nb, stride, R, out, status, iters};
         if (crew.on) unpack_crew().run(unpack_part, &j); else unpack_part(&j, 0, 1);
     };
     int64_t prev_b0 = 0, prev_nb = 0;
     int k = 0;
-    for (int64_t b0 = 0; b0 < B; b0 += per, ++k) {
-        const int h = k & 1;
-        const int64_t nb = std::min<int64_t>(per, B - b0);
-        HIPCHK(m, hipMemcpyAsync((char*)m->h_pin + h * kPinHalf, d_records + b0 * stride, (size_t)nb * stride * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(m, hipEventRecord(m->ev_pin[h], m->stream));
-        if (prev_nb) { HIPCHK(m, hipEventSynchronize(m->ev_pin[h ^ 1])); unpack(h ^ 1, prev_b0, prev_nb); }
-        prev_b0 = b0; prev_nb = nb;
+    for (int sg = 0; sg < nsegs; ++sg) {
+        if (segs[sg].ready) HIPCHK(m, hipStreamWaitEvent(cs, segs[sg].ready, 0));
+        for (int64_t b0 = segs[sg].b0; b0 < segs[sg].b0 + segs[sg].nb; b0 += per, ++k) {
+            const int h = k & 1;
+            const int64_t nb = std::min<int64_t>(per, segs[sg].b0 + segs[sg].nb - b0);
+            // (half h was unpacked before the piece before this one was waited for: free)
+            HIPCHK(m, hipMemcpyAsync((char*)m->h_pin + h * kPinHalf, d_records + b0 * stride, (size_t)nb * stride * sizeof(double), hipMemcpyDeviceToHost, cs));
+            HIPCHK(m, hipEventRecord(m->ev_pin[h], cs));
+            if (prev_nb) { HIPCHK(m, hipEventSynchronize(m->ev_pin[h ^ 1])); unpack(h ^ 1, prev_b0, prev_nb); }
+            prev_b0 = b0; prev_nb = nb;
+        }
     }
     if (prev_nb) { HIPCHK(m, hipEventSynchronize(m->ev_pin[(k - 1) & 1])); unpack((k - 1) & 1, prev_b0, prev_nb); }
     return 0;
+}
+
+int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t B, int32_t stride, double* out, int32_t* status, int32_t* iters) {
+    const FetchSeg seg{0, B, nullptr};
+    return fetch_segments(m, m->stream, d_records, stride, &seg, 1, B, out, status, iters);
 }
 
 int plspm_detail_summary(plspm_model* m, const double* rows, int64_t B, int32_t stride, const double* original, double* summary, int64_t* n_used) {

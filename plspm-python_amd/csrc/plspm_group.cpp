@@ -32,6 +32,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;      // (optional symbols: channel-capped communicators)
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -67,6 +69,8 @@ const Rccl* rccl(std::string& why) {
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     if (!ok) { dlclose(so); return nullptr; }
+    r.CommInitRankConfig = (decltype(r.CommInitRankConfig))dlsym(so, "ncclCommInitRankConfig");
+    r.CommSplit = (decltype(r.CommSplit))dlsym(so, "ncclCommSplit");
     g_rccl = r;
     return &g_rccl;
 }
@@ -84,7 +88,7 @@ struct Local {
     ncclComm_t comm = nullptr;                     // borrowed from the group's plspm_comm
     hipStream_t cstream = nullptr;                 // the collective's stream: it runs beside the next call's kernels
     plspm_model::Buf send[2], recv[2];
-    hipEvent_t computed[2] = {nullptr, nullptr};   // shard kernels of slot s done (recorded on the handle's stream)
+    hipEvent_t computed[2][kBootChunksMax] = {};   // shard kernels of sub-batch k of slot s done (recorded on the handle's stream)
     hipEvent_t gathered[2] = {nullptr, nullptr};   // records of slot s complete in recv[s] (recorded on cstream)
     double* d_word = nullptr;                      // barrier / max scratch
     double* h_word = nullptr;                      // pinned mirror
@@ -152,6 +156,8 @@ struct plspm_comm {
     bool use_rccl = false;
     std::vector<int> devices;                      // one per local rank
     std::vector<ncclComm_t> comms;                 // empty when use_rccl is false
+    int transport = 0;                             // 1 RCCL, 2 device-to-device copies on peer-mapped buffers (copy engines), 3 ranks share a device (one copy launch)
+    int max_channels = 0;                          // > 0: the communicator was created with ncclConfig_t.maxCTAs = this
     plspm_group* bound = nullptr;                  // the live group using it, if any
 };
 
@@ -162,7 +168,12 @@ struct plspm_group {
     std::vector<Local> loc;
     int next_slot = 0, last_slot = -1;
     bool pending[2] = {false, false};
-    int64_t last_B = 0, last_cap = 0;
+    int64_t last_B = 0, last_cap = 0;              // last call: replicates, records per rank (all sub-batches)
+    // sub-batches of the last call ("chunks"): sub-batch k = the global replicate ids [sub_first[k], sub_first[k] + sub_B[k]), sharded over the ranks like
+    // a call of its own; its gathered records start at record nranks * sub_off[k] of the receive buffer, sub_cap[k] per rank
+    int last_K = 1;
+    int64_t sub_B[kBootChunksMax] = {}, sub_first[kBootChunksMax] = {}, sub_cap[kBootChunksMax] = {}, sub_off[kBootChunksMax] = {};
+    int opt_chunks = 0, opt_ratio = 50;            // plspm_group_set_option
     int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
     int peers_rc = 0;
     double t_shards_ms = 0.0, t_exchange_ms = 0.0;  // host time of the last plspm_group_bootstrap: shard enqueue / exchange enqueue
@@ -213,24 +224,6 @@ int sync_all(plspm_group* g) {
 
 }  // namespace
 
-extern "C" {
-
-const char* plspm_group_last_error(const plspm_group_t* g) { return g ? g->error.c_str() : g_group_create_error.c_str(); }
-
-int plspm_rccl_unique_id(uint8_t* id) {
-    g_group_create_error.clear();
-    if (!id) return gfail(nullptr, PLSPM_E_ARG, "plspm_rccl_unique_id: null argument");
-    static_assert(sizeof(ncclUniqueId) == PLSPM_UNIQUE_ID_BYTES, "unique id size");
-    std::string why;
-    const Rccl* r = rccl(why);
-    if (!r) return gfail(nullptr, PLSPM_E_STATE, why);
-    ncclUniqueId uid;
-    StdoutToStderr quiet;
-    GNCCL(nullptr, r, r->GetUniqueId(&uid));
-    memcpy(id, &uid, sizeof(uid));
-    return 0;
-}
-
 // Release everything the group holds on its handles (streams, events, buffers) and unbind it; the struct itself stays (an owner may
 // still call plspm_group_destroy on it).  Idempotent.
 static void group_release(plspm_group* g) {
@@ -244,7 +237,7 @@ static void group_release(plspm_group* g) {
         for (int s = 0; s < 2; ++s) {
             if (l.send[s].p) plspm_dfree(l.send[s].p);
             if (l.recv[s].p) plspm_dfree(l.recv[s].p);
-            if (l.computed[s]) hipEventDestroy(l.computed[s]);
+            for (auto& e : l.computed[s]) if (e) hipEventDestroy(e);
             if (l.gathered[s]) hipEventDestroy(l.gathered[s]);
         }
         if (l.d_word) plspm_dfree(l.d_word);
@@ -263,6 +256,48 @@ static void group_release(plspm_group* g) {
 // of ALL its handles first, so that nothing dangles; later calls on the group report PLSPM_E_STATE.
 void plspm_detail_group_orphan(void* group) { if (group) group_release((plspm_group*)group); }
 
+int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts) {
+    parts[0] = B;
+    if (B < 1) return 1;
+    int n = chunks_opt;
+    if (n <= 0) n = (B * bytes_per_unit < ((int64_t)2 << 20)) ? 1 : 3;           // automatic: nothing worth hiding below 2 MiB of results
+    n = std::min(n, kBootChunksMax);
+    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, B / 512));                 // no part below 512 units (a sub-batch's fixed costs: three launches + an event)
+    if (n <= 1) return 1;
+    const double q = std::min(100, std::max(10, ratio_pct)) / 100.0;
+    double wsum = 0.0, w = 1.0;
+    for (int k = 0; k < n; ++k, w *= q) wsum += w;
+    int64_t left = B;
+    w = 1.0;
+    int k = 0;
+    for (; k < n - 1; ++k, w *= q) {
+        int64_t c = (int64_t)((double)B * w / wsum + 0.5);
+        c = std::max<int64_t>(64, (c + 32) / 64 * 64);
+        if (left - c < 64) break;                                                  // the remainder would be no part of its own
+        parts[k] = c; left -= c;
+    }
+    parts[k] = left;
+    return k + 1;
+}
+
+extern "C" {
+
+const char* plspm_group_last_error(const plspm_group_t* g) { return g ? g->error.c_str() : g_group_create_error.c_str(); }
+
+int plspm_rccl_unique_id(uint8_t* id) {
+    g_group_create_error.clear();
+    if (!id) return gfail(nullptr, PLSPM_E_ARG, "plspm_rccl_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == PLSPM_UNIQUE_ID_BYTES, "unique id size");
+    std::string why;
+    const Rccl* r = rccl(why);
+    if (!r) return gfail(nullptr, PLSPM_E_STATE, why);
+    ncclUniqueId uid;
+    StdoutToStderr quiet;
+    GNCCL(nullptr, r, r->GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof(uid));
+    return 0;
+}
+
 void plspm_group_destroy(plspm_group_t* g) {
     if (!g) return;
     group_release(g);
@@ -279,12 +314,25 @@ void plspm_comm_destroy(plspm_comm_t* c) {
     delete c;
 }
 
-plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id) {
+// max_channels > 0: RCCL may run at most that many workgroups ("channels", ncclConfig_t.maxCTAs) for this communicator's collectives.  Why: the
+// all-gather of step k runs beside the Gram of step k + 1, a Gram workgroup needs a whole CU, and every CU an RCCL channel sits on is missing from a
+// launch that was cut for all of them; 44 MB per 0.48 ms (eight ranks, 5,000 replicates each) does not need RCCL's default channel count.
+static ncclConfig_t capped_config(int max_channels) {
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.minCTAs = 1;
+    cfg.maxCTAs = max_channels;
+    return cfg;
+}
+
+plspm_comm_t* plspm_comm_create_ex(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id, int32_t transport,
+                                   int32_t max_channels) {
     g_group_create_error.clear();
     auto bad = [&](int code, const std::string& why) { gfail(nullptr, code, why); return (plspm_comm_t*)nullptr; };
-    if (!device_ids || n_local < 1 || nranks < n_local || first_rank < 0 || first_rank + n_local > nranks) return bad(PLSPM_E_ARG, "plspm_comm_create: bad arguments");
+    if (!device_ids || n_local < 1 || nranks < n_local || first_rank < 0 || first_rank + n_local > nranks || transport < 0 || transport > 2 || max_channels < 0 || max_channels > 256)
+        return bad(PLSPM_E_ARG, "plspm_comm_create: bad arguments");
     if (n_local != nranks && (n_local != 1 || !unique_id))
         return bad(PLSPM_E_ARG, "plspm_comm_create: either all ranks in one process (unique_id NULL) or one rank per process with rank 0's unique id");
+    if (transport == PLSPM_TRANSPORT_COPY && n_local != nranks) return bad(PLSPM_E_ARG, "plspm_comm_create: the copy-engine exchange needs every rank in this process (peer-mapped buffers)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(PLSPM_E_STATE, "no HIP device visible");
     bool distinct = true;
@@ -292,34 +340,106 @@ plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int3
         if (device_ids[i] < 0 || device_ids[i] >= ndev) return bad(PLSPM_E_ARG, "plspm_comm_create: device id out of range");
         for (int j = 0; j < i; ++j) if (device_ids[i] == device_ids[j]) distinct = false;
     }
+    if (transport == PLSPM_TRANSPORT_RCCL && !distinct) return bad(PLSPM_E_ARG, "plspm_comm_create: RCCL refuses ranks that share a device");
     plspm_comm* c = new (std::nothrow) plspm_comm();
     if (!c) return bad(PLSPM_E_STATE, "out of host memory");
     c->nranks = nranks; c->first_rank = first_rank;
     c->devices.assign(device_ids, device_ids + n_local);
     // ranks that share a device (a 1-GPU test box; RCCL refuses duplicate devices) exchange records with device-to-device copies (all on one device: gather_local_kernel, one launch)
-    c->use_rccl = distinct;
-    if (!c->use_rccl) return c;
+    c->use_rccl = distinct && transport != PLSPM_TRANSPORT_COPY;
+    c->transport = c->use_rccl ? PLSPM_TRANSPORT_RCCL : (distinct ? PLSPM_TRANSPORT_COPY : 3);
+    if (!c->use_rccl) {
+        if (distinct && n_local > 1) {
+            // copy-engine exchange: every device maps every other device's memory (idempotent; "already enabled" is not an error)
+            for (int i = 0; i < n_local; ++i)
+                for (int j = 0; j < n_local; ++j) {
+                    if (i == j) continue;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) != hipSuccess || !can) { delete c; return bad(PLSPM_E_STATE, "plspm_comm_create: device " + std::to_string(device_ids[i]) + " cannot map the memory of device " + std::to_string(device_ids[j])); }
+                    if (hipSetDevice(device_ids[i]) != hipSuccess) { delete c; return bad(PLSPM_E_STATE, "hipSetDevice failed"); }
+                    const hipError_t e = hipDeviceEnablePeerAccess(device_ids[j], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { delete c; return bad(-(int)e, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e)); }
+                    (void)hipGetLastError();
+                }
+        }
+        return c;
+    }
     std::string why;
     const Rccl* r = rccl(why);
     if (!r) { delete c; return bad(PLSPM_E_STATE, why); }
+    if (max_channels > 0 && !r->CommInitRankConfig) { delete c; return bad(PLSPM_E_STATE, "this librccl has no ncclCommInitRankConfig: max_channels needs it"); }
     c->comms.assign(n_local, nullptr);
+    c->max_channels = max_channels;
     ncclResult_t rc;
     StdoutToStderr quiet;
-    if (n_local == nranks) {
+    if (n_local == nranks && max_channels == 0) {
         rc = r->CommInitAll(c->comms.data(), n_local, c->devices.data());
         if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclCommInitAll: ") + r->GetErrorString(rc)); }
+    } else if (n_local == nranks) {
+        // all ranks of this process with a configuration: what ncclCommInitAll does, by hand (one unique id, a group of ncclCommInitRankConfig)
+        ncclUniqueId uid;
+        rc = r->GetUniqueId(&uid);
+        if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclGetUniqueId: ") + r->GetErrorString(rc)); }
+        ncclResult_t first = ncclSuccess;
+        rc = r->GroupStart();
+        if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclGroupStart: ") + r->GetErrorString(rc)); }
+        std::vector<ncclConfig_t> cfg(n_local, capped_config(max_channels));
+        for (int i = 0; i < n_local; ++i) {
+            if (hipSetDevice(c->devices[i]) != hipSuccess) { if (first == ncclSuccess) first = ncclUnhandledCudaError; continue; }
+            rc = r->CommInitRankConfig(&c->comms[i], nranks, uid, i, &cfg[i]);
+            if (rc != ncclSuccess && first == ncclSuccess) first = rc;
+        }
+        rc = r->GroupEnd();
+        if (first == ncclSuccess) first = rc;
+        if (first != ncclSuccess) { c->comms.clear(); delete c; return bad(-(1000 + (int)first), std::string("ncclCommInitRankConfig: ") + r->GetErrorString(first)); }
     } else {
         ncclUniqueId uid;
         memcpy(&uid, unique_id, sizeof(uid));
         if (hipSetDevice(c->devices[0]) != hipSuccess) { delete c; return bad(PLSPM_E_STATE, "hipSetDevice failed"); }
-        rc = r->CommInitRank(&c->comms[0], nranks, uid, first_rank);
+        if (max_channels > 0) { ncclConfig_t cfg = capped_config(max_channels); rc = r->CommInitRankConfig(&c->comms[0], nranks, uid, first_rank, &cfg); }
+        else rc = r->CommInitRank(&c->comms[0], nranks, uid, first_rank);
         if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclCommInitRank: ") + r->GetErrorString(rc)); }
     }
     return c;
 }
 
+plspm_comm_t* plspm_comm_create(const int32_t* device_ids, int32_t n_local, int32_t nranks, int32_t first_rank, const uint8_t* unique_id) {
+    return plspm_comm_create_ex(device_ids, n_local, nranks, first_rank, unique_id, PLSPM_TRANSPORT_AUTO, 0);
+}
+
+// A second communicator over the same ranks and devices with its own channel cap, split off an RCCL communicator (ncclCommSplit: collective over
+// the parent, no new unique id to hand round) -- lets a job compare RCCL's default against a capped one without a second rendezvous.
+plspm_comm_t* plspm_comm_split(plspm_comm_t* parent, int32_t max_channels) {
+    g_group_create_error.clear();
+    auto bad = [&](int code, const std::string& why) { gfail(nullptr, code, why); return (plspm_comm_t*)nullptr; };
+    if (!parent || max_channels < 0 || max_channels > 256) return bad(PLSPM_E_ARG, "plspm_comm_split: bad arguments");
+    if (!parent->use_rccl) return bad(PLSPM_E_STATE, "plspm_comm_split: the parent does not use RCCL");
+    const Rccl* r = &g_rccl;
+    if (!r->CommSplit) return bad(PLSPM_E_STATE, "this librccl has no ncclCommSplit");
+    plspm_comm* c = new (std::nothrow) plspm_comm();
+    if (!c) return bad(PLSPM_E_STATE, "out of host memory");
+    c->nranks = parent->nranks; c->first_rank = parent->first_rank; c->devices = parent->devices; c->use_rccl = true; c->transport = PLSPM_TRANSPORT_RCCL; c->max_channels = max_channels;
+    const int n_local = (int)c->devices.size();
+    c->comms.assign(n_local, nullptr);
+    StdoutToStderr quiet;
+    std::vector<ncclConfig_t> cfg(n_local);
+    for (auto& f : cfg) { ncclConfig_t init = NCCL_CONFIG_INITIALIZER; f = init; if (max_channels > 0) { f.minCTAs = 1; f.maxCTAs = max_channels; } }
+    ncclResult_t first = ncclSuccess, rc = n_local > 1 ? r->GroupStart() : ncclSuccess;
+    if (rc != ncclSuccess) { delete c; return bad(-(1000 + (int)rc), std::string("ncclGroupStart: ") + r->GetErrorString(rc)); }
+    for (int i = 0; i < n_local; ++i) {
+        if (hipSetDevice(c->devices[i]) != hipSuccess) { if (first == ncclSuccess) first = ncclUnhandledCudaError; continue; }
+        rc = r->CommSplit(parent->comms[i], 0, parent->first_rank + i, &c->comms[i], &cfg[i]);
+        if (rc != ncclSuccess && first == ncclSuccess) first = rc;
+    }
+    if (n_local > 1) { rc = r->GroupEnd(); if (first == ncclSuccess) first = rc; }
+    if (first != ncclSuccess) { c->comms.clear(); delete c; return bad(-(1000 + (int)first), std::string("ncclCommSplit: ") + r->GetErrorString(first)); }
+    return c;
+}
+
 int32_t plspm_comm_size(const plspm_comm_t* c) { return c ? c->nranks : 0; }
 int32_t plspm_comm_uses_rccl(const plspm_comm_t* c) { return (c && c->use_rccl) ? 1 : 0; }
+int32_t plspm_comm_transport(const plspm_comm_t* c) { return c ? c->transport : 0; }
+int32_t plspm_comm_max_channels(const plspm_comm_t* c) { return c ? c->max_channels : 0; }
 
 plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models) {
     g_group_create_error.clear();
@@ -347,9 +467,10 @@ plspm_group_t* plspm_group_create(plspm_comm_t* c, plspm_model_t* const* models)
     for (auto& l : g->loc) {
         l.m->group = g;
         if (hipSetDevice(l.m->device) != hipSuccess || plspm_stream_acquire(&l.cstream) != hipSuccess) return bail("gather stream creation failed");
-        for (int s = 0; s < 2; ++s)
-            if (hipEventCreateWithFlags(&l.computed[s], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.gathered[s], hipEventDisableTiming) != hipSuccess)
-                return bail("event creation failed");
+        for (int s = 0; s < 2; ++s) {
+            if (hipEventCreateWithFlags(&l.gathered[s], hipEventDisableTiming) != hipSuccess) return bail("event creation failed");
+            for (auto& e : l.computed[s]) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail("event creation failed");
+        }
         if (plspm_dmalloc((void**)&l.d_word, 64) != hipSuccess || hipMemset(l.d_word, 0, 64) != hipSuccess || plspm_hmalloc((void**)&l.h_word, 64 + 8 * (size_t)std::max(8, c->nranks)) != hipSuccess)
             return bail("scratch allocation failed");
     }
@@ -375,12 +496,55 @@ int plspm_group_sync(plspm_group_t* g) {
     return sync_all(g);
 }
 
+// How a call of B replicates is cut into sub-batches on this group ("chunks" / "chunk_ratio"): K ranges of global replicate ids, each sharded
+// over the ranks like a call of its own.  Deterministic in (B, nranks, options, record width): every rank of a job plans alike.
+static int plan_sub_batches(const plspm_group* g, int64_t B, int RS, int64_t* sub_first, int64_t* sub_B) {
+    const int64_t per_rank = (B + g->nranks - 1) / g->nranks;
+    int64_t parts[kBootChunksMax];
+    // (one rank: nothing travels, nothing to hide -- unless sub-batches are asked for by number)
+    const int K = (g->nranks == 1 && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts);
+    int64_t at = 0;
+    int n = 0;
+    for (int k = 0; k < K && at < B; ++k) {
+        const int64_t take = (k == K - 1) ? B - at : std::min<int64_t>(B - at, parts[k] * g->nranks);
+        sub_first[n] = at; sub_B[n] = take; at += take; ++n;
+    }
+    if (at < B) sub_B[n - 1] += B - at;
+    return n;
+}
+
+int plspm_chunk_plan(int64_t B, int64_t bytes_per_unit, int32_t chunks, int32_t ratio_pct, int64_t* parts) {
+    if (!parts || B < 1 || bytes_per_unit < 1 || chunks < 0 || chunks > kBootChunksMax || ratio_pct < 10 || ratio_pct > 100) return PLSPM_E_ARG > 0 ? -PLSPM_E_ARG : PLSPM_E_ARG;
+    return plspm_detail_chunk_plan(B, bytes_per_unit, chunks, ratio_pct, parts);
+}
+
+int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value) {
+    if (!g || !key) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: bad arguments");
+    const std::string k(key);
+    if (k == "chunks") { if (value < 0 || value > kBootChunksMax) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunks in 0 .. 8"); g->opt_chunks = value; }
+    else if (k == "chunk_ratio") { if (value < 10 || value > 100) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunk_ratio in 10 .. 100"); g->opt_ratio = value; }
+    else return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: unknown option '" + k + "'");
+    return 0;
+}
+
+int plspm_group_plan(const plspm_group_t* g, int64_t B, int32_t* n_sub, int64_t* sub_first, int64_t* sub_count) {
+    if (!g || B < 1 || !n_sub || !sub_first || !sub_count || g->loc.empty()) return PLSPM_E_ARG;
+    *n_sub = plan_sub_batches(g, B, plspm_row_stride(g->loc[0].m), sub_first, sub_count);
+    return 0;
+}
+
 int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset) {
     if (!g || B < 1 || rep_offset < 0 || B > ((int64_t)1 << 30)) return gfail(g, PLSPM_E_ARG, "plspm_group_bootstrap: bad arguments (1 <= B <= 2^30, rep_offset >= 0)");
     if (g->loc.empty()) return gfail(g, PLSPM_E_STATE, "the group's handles were destroyed");
     const int nl = (int)g->loc.size();
     const int RS = plspm_row_stride(g->loc[0].m);
-    const int64_t cap = (B + g->nranks - 1) / g->nranks;
+    // sub-batches (round 5): the all-gather of sub-batch k runs on the gather streams beside the shard kernels of sub-batch k + 1, so that ONE
+    // call hides its merge the way a loop of calls does; the gathered buffer holds the sub-batches one after the other, each in the layout of a
+    // call of its own -- i.e. in replicate-id order throughout (what the device summaries' fixed-order sums rely on)
+    int64_t sub_first[kBootChunksMax], sub_B[kBootChunksMax], sub_cap[kBootChunksMax], sub_off[kBootChunksMax];
+    const int K = plan_sub_batches(g, B, RS, sub_first, sub_B);
+    int64_t cap = 0;
+    for (int k = 0; k < K; ++k) { sub_cap[k] = (sub_B[k] + g->nranks - 1) / g->nranks; sub_off[k] = cap; cap += sub_cap[k]; }
     const size_t send_bytes = (size_t)cap * RS * sizeof(double), recv_bytes = send_bytes * g->nranks;
     const int s = g->next_slot;
     int rc;
@@ -398,7 +562,7 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
     bool one_device = !g->use_rccl && nl <= PLSPM_GATHER_LOCAL_MAX;
     for (int i = 1; i < nl && one_device; ++i) one_device = g->loc[i].m->device == g->loc[0].m->device;
     // 1. shard kernels (enqueue only; non-metric models iterate with host read-backs): every local handle by its own resident thread
-    std::vector<int> shard_rc(nl, 0);
+    std::vector<int> shard_rc(nl, 0), shard_done(nl, 0);      // shard_done[i]: sub-batches of handle i whose `computed` event is recorded
     auto run_shard = [&](int i) {
         Local& l = g->loc[i];
         plspm_model* m = l.m;
@@ -408,22 +572,25 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
             if (g->use_rccl || one_device) hipStreamWaitEvent(m->stream, l.gathered[s], 0);            // (one launch / one collective read every send buffer)
             else for (auto& peer : g->loc) hipStreamWaitEvent(m->stream, peer.gathered[s], 0);          // peers pull from this send buffer
         }
-        int64_t first = 0, count = 0;
-        shard_of(B, g->nranks, g->first_rank + i, &first, &count);
-        double* send = (double*)l.send[s].p;
-        if (count > 0 && (shard_rc[i] = plspm_detail_bootstrap(m, count, seed, rep_offset + first, nullptr, send))) return;
-        if (count < cap && hipMemsetAsync(send + count * RS, 0xFF, (size_t)(cap - count) * RS * sizeof(double), m->stream) != hipSuccess) {   // NaN status: not a replicate
-            shard_rc[i] = fail(m, PLSPM_E_STATE, "hipMemsetAsync failed"); return;
+        for (int k = 0; k < K; ++k) {
+            int64_t first = 0, count = 0;
+            shard_of(sub_B[k], g->nranks, g->first_rank + i, &first, &count);
+            double* send = (double*)l.send[s].p + sub_off[k] * RS;
+            if (count > 0 && (shard_rc[i] = plspm_detail_bootstrap(m, count, seed, rep_offset + sub_first[k] + first, nullptr, send))) return;
+            if (count < sub_cap[k] && hipMemsetAsync(send + count * RS, 0xFF, (size_t)(sub_cap[k] - count) * RS * sizeof(double), m->stream) != hipSuccess) {   // NaN status: not a replicate
+                shard_rc[i] = fail(m, PLSPM_E_STATE, "hipMemsetAsync failed"); return;
+            }
+            if (hipEventRecord(l.computed[s][k], m->stream) != hipSuccess) { shard_rc[i] = fail(m, PLSPM_E_STATE, "hipEventRecord failed"); return; }
+            shard_done[i] = k + 1;
         }
-        if (hipEventRecord(l.computed[s], m->stream) != hipSuccess) shard_rc[i] = fail(m, PLSPM_E_STATE, "hipEventRecord failed");
     };
     const auto t_a = std::chrono::steady_clock::now();
     if (nl > 1 && g->crew) g->crew->run(run_shard);
     else for (int i = 0; i < nl; ++i) run_shard(i);
     const auto t_b = std::chrono::steady_clock::now();
     // A failed shard (out of memory, an LDS limit, a read-back error of a non-metric model) must not keep this rank out of the
-    // collective: the other ranks of the job are already inside it and would wait forever.  Its send buffer becomes NaN-status
-    // records (never counted as replicates), the all-gather runs as planned, and the error is reported afterwards.
+    // collectives: the other ranks of the job are already inside them and would wait forever.  Its send buffer becomes NaN-status
+    // records (never counted as replicates) from the failed sub-batch on, every all-gather runs as planned, and the error is reported afterwards.
     int first_bad = -1;
     for (int i = 0; i < nl; ++i) {
         if (!shard_rc[i]) continue;
@@ -431,55 +598,61 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         Local& l = g->loc[i];
         hipSetDevice(l.m->device);
         (void)hipGetLastError();
-        hipMemsetAsync(l.send[s].p, 0xFF, send_bytes, l.m->stream);
-        hipEventRecord(l.computed[s], l.m->stream);
+        const int k0 = shard_done[i];
+        hipMemsetAsync((double*)l.send[s].p + sub_off[k0] * RS, 0xFF, (size_t)(cap - sub_off[k0]) * RS * sizeof(double), l.m->stream);
+        for (int k = k0; k < K; ++k) hipEventRecord(l.computed[s][k], l.m->stream);
     }
-    // 2. the ONE collective, on the gather streams behind the shard kernels
+    // 2. the collective of every sub-batch, on the gather streams behind that sub-batch's shard kernels
     int crc = 0;
     std::string cwhy;
-    if (g->use_rccl) {
-        const Rccl* r = &g_rccl;
-        for (auto& l : g->loc) {
-            hipError_t e = hipSetDevice(l.m->device);
-            if (e == hipSuccess) e = hipStreamWaitEvent(l.cstream, l.computed[s], 0);
-            if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e); }
-        }
-        ncclResult_t n = r->GroupStart();
-        if (n != ncclSuccess) { if (!crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupStart: ") + r->GetErrorString(n); } }
-        else {
-            // between GroupStart and GroupEnd nothing returns early: an open group call would poison every later RCCL call of the process
+    for (int k = 0; k < K; ++k) {
+        const size_t sub_doubles = (size_t)sub_cap[k] * RS, sub_bytes = sub_doubles * sizeof(double);
+        const size_t soff = (size_t)sub_off[k] * RS, roff = soff * g->nranks;       // (in doubles)
+        if (g->use_rccl) {
+            const Rccl* r = &g_rccl;
             for (auto& l : g->loc) {
-                hipSetDevice(l.m->device);
-                n = r->AllGather(l.send[s].p, l.recv[s].p, (size_t)cap * RS, ncclDouble, l.comm, l.cstream);
-                if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclAllGather: ") + r->GetErrorString(n); }
+                hipError_t e = hipSetDevice(l.m->device);
+                if (e == hipSuccess) e = hipStreamWaitEvent(l.cstream, l.computed[s][k], 0);
+                if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e); }
             }
-            n = r->GroupEnd();
-            if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupEnd: ") + r->GetErrorString(n); }
-        }
-        for (auto& l : g->loc) { hipSetDevice(l.m->device); hipEventRecord(l.gathered[s], l.cstream); }
-    } else if (one_device) {
-        Local& l0 = g->loc[0];
-        hipError_t e = hipSetDevice(l0.m->device);
-        const double* send[PLSPM_GATHER_LOCAL_MAX];
-        double* recv[PLSPM_GATHER_LOCAL_MAX];
-        for (int i = 0; i < nl; ++i) {
-            if (e == hipSuccess) e = hipStreamWaitEvent(l0.cstream, g->loc[i].computed[s], 0);
-            send[i] = (const double*)g->loc[i].send[s].p; recv[i] = (double*)g->loc[i].recv[s].p;
-        }
-        if (e == hipSuccess && plspm_detail_gather_local(l0.cstream, nl, send, recv, (size_t)cap * RS)) e = hipErrorLaunchFailure;
-        for (int i = 0; i < nl && e == hipSuccess; ++i) e = hipEventRecord(g->loc[i].gathered[s], l0.cstream);
-        if (e != hipSuccess) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
-    } else {
-        for (auto& dst : g->loc) {
-            hipSetDevice(dst.m->device);
+            ncclResult_t n = r->GroupStart();
+            if (n != ncclSuccess) { if (!crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupStart: ") + r->GetErrorString(n); } }
+            else {
+                // between GroupStart and GroupEnd nothing returns early: an open group call would poison every later RCCL call of the process
+                for (auto& l : g->loc) {
+                    hipSetDevice(l.m->device);
+                    n = r->AllGather((const double*)l.send[s].p + soff, (double*)l.recv[s].p + roff, sub_doubles, ncclDouble, l.comm, l.cstream);
+                    if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclAllGather: ") + r->GetErrorString(n); }
+                }
+                n = r->GroupEnd();
+                if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupEnd: ") + r->GetErrorString(n); }
+            }
+        } else if (one_device) {
+            Local& l0 = g->loc[0];
+            hipError_t e = hipSetDevice(l0.m->device);
+            const double* send[PLSPM_GATHER_LOCAL_MAX];
+            double* recv[PLSPM_GATHER_LOCAL_MAX];
             for (int i = 0; i < nl; ++i) {
-                hipError_t e = hipStreamWaitEvent(dst.cstream, g->loc[i].computed[s], 0);
-                if (e == hipSuccess) e = hipMemcpyAsync((char*)dst.recv[s].p + (size_t)i * send_bytes, g->loc[i].send[s].p, send_bytes, hipMemcpyDeviceToDevice, dst.cstream);
-                if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
+                if (e == hipSuccess) e = hipStreamWaitEvent(l0.cstream, g->loc[i].computed[s][k], 0);
+                send[i] = (const double*)g->loc[i].send[s].p + soff; recv[i] = (double*)g->loc[i].recv[s].p + roff;
             }
-            hipEventRecord(dst.gathered[s], dst.cstream);
+            if (e == hipSuccess && plspm_detail_gather_local(l0.cstream, nl, send, recv, sub_doubles)) e = hipErrorLaunchFailure;
+            if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
+        } else {
+            // copy-engine exchange (single process, peer-mapped buffers; plspm_comm_create_ex transport 2): every rank PULLS the peers' shards with
+            // device-to-device copies on its own gather stream -- no kernel, no CU: the SDMA engines move the records over xGMI
+            for (auto& dst : g->loc) {
+                hipSetDevice(dst.m->device);
+                for (int i = 0; i < nl; ++i) {
+                    hipError_t e = hipStreamWaitEvent(dst.cstream, g->loc[i].computed[s][k], 0);
+                    if (e == hipSuccess) e = hipMemcpyAsync((double*)dst.recv[s].p + roff + (size_t)i * sub_doubles, (const double*)g->loc[i].send[s].p + soff, sub_bytes, hipMemcpyDeviceToDevice, dst.cstream);
+                    if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
+                }
+            }
         }
     }
+    if (one_device) { for (int i = 0; i < nl; ++i) { hipError_t e = hipEventRecord(g->loc[i].gathered[s], g->loc[0].cstream); if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = "hipEventRecord failed"; } } }
+    else for (auto& l : g->loc) { hipSetDevice(l.m->device); hipEventRecord(l.gathered[s], l.cstream); }
     g->t_shards_ms = std::chrono::duration<double, std::milli>(t_b - t_a).count();
     g->t_exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count();
     if (first_bad >= 0 || crc) {
@@ -489,28 +662,43 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         return gfail(g, crc, cwhy);
     }
     g->pending[s] = true; g->last_slot = s; g->next_slot = s ^ 1; g->last_B = B; g->last_cap = cap; g->peers_checked = -1;
+    g->last_K = K;
+    for (int k = 0; k < K; ++k) { g->sub_B[k] = sub_B[k]; g->sub_first[k] = sub_first[k]; g->sub_cap[k] = sub_cap[k]; g->sub_off[k] = sub_off[k]; }
     return 0;
 }
 
+// Segment (sub-batch k, rank r) of the gathered records of the last call: its first record in the receive buffer, the global id of its first
+// replicate within the call, and how many replicates it holds.
+static void segment_of(const plspm_group* g, int k, int r, int64_t* rec0, int64_t* first, int64_t* count) {
+    int64_t f = 0, c = 0;
+    shard_of(g->sub_B[k], g->nranks, r, &f, &c);
+    *rec0 = g->nranks * g->sub_off[k] + (int64_t)r * g->sub_cap[k];
+    *first = g->sub_first[k] + f; *count = c;
+}
 
-// A rank whose shard failed still joins the all-gather (its records are NaN-status filler, so the other ranks never wait for it) and reports
-// the error from ITS plspm_group_bootstrap.  The other ranks learn of it here, before any result leaves the group: the status word of the
-// first record of every rank's shard is read back once per bootstrap; NaN where replicates were due = that rank had nothing to contribute.
-// Called with local handle 0's device current, by everything that hands out records or statistics of the last bootstrap.
+// A rank whose shard failed still joins every all-gather (its records are NaN-status filler from the failed sub-batch on, so the other ranks never
+// wait for it) and reports the error from ITS plspm_group_bootstrap.  The other ranks learn of it here, before any result leaves the group: the
+// status word of the first record of every rank's shard of the LAST sub-batch is read back once per bootstrap (nranks 8-byte copies); NaN where
+// replicates were due = that rank had nothing to contribute.  Called with local handle 0's device current, by everything that hands out
+// records or statistics of the last bootstrap (all of which wait for the collective anyway).
 static int check_peer_shards(plspm_group* g) {
     const int s = g->last_slot;
     if (g->peers_checked == s) return g->peers_rc ? gfail(g, g->peers_rc, g->error) : 0;
     Local& l = g->loc[0];
     const int RS = plspm_row_stride(l.m);
     double* h = l.h_word + 8;
+    const int kl = g->last_K - 1;
     GHIP(g, hipStreamWaitEvent(l.cstream, l.gathered[s], 0));
-    GHIP(g, hipMemcpy2DAsync(h, sizeof(double), (const double*)l.recv[s].p + (RS - 2), (size_t)g->last_cap * RS * sizeof(double), sizeof(double), (size_t)g->nranks,
-                             hipMemcpyDeviceToHost, l.cstream));
+    for (int r = 0; r < g->nranks; ++r) {
+        int64_t rec0 = 0, first = 0, count = 0;
+        segment_of(g, kl, r, &rec0, &first, &count);
+        GHIP(g, hipMemcpyAsync(h + r, (const double*)l.recv[s].p + rec0 * RS + (RS - 2), sizeof(double), hipMemcpyDeviceToHost, l.cstream));
+    }
     GHIP(g, hipStreamSynchronize(l.cstream));
     g->peers_checked = s; g->peers_rc = 0;
     for (int r = 0; r < g->nranks; ++r) {
-        int64_t first = 0, count = 0;
-        shard_of(g->last_B, g->nranks, r, &first, &count);
+        int64_t rec0 = 0, first = 0, count = 0;
+        segment_of(g, kl, r, &rec0, &first, &count);
         if (count > 0 && h[r] != h[r]) {
             g->peers_rc = PLSPM_E_STATE;
             return gfail(g, PLSPM_E_STATE, "the shard of rank " + std::to_string(r) + " failed on its rank (no replicates arrived from it): the bootstrap has no complete result");
@@ -554,14 +742,15 @@ int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* it
     GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
     { int prc = check_peer_shards(g); if (prc) return prc; }
     const double* rec = (const double*)l.recv[g->last_slot].p;
-    for (int r = 0; r < g->nranks; ++r) {
-        int64_t first = 0, count = 0;
-        shard_of(g->last_B, g->nranks, r, &first, &count);
-        if (!count) continue;
-        int rc = plspm_detail_fetch_records(l.m, rec + (size_t)r * g->last_cap * RS, count, RS, out ? out + first * R : nullptr, status ? status + first : nullptr,
-                                            iters ? iters + first : nullptr);
-        if (rc) return gfail(g, rc, l.m->error);
-    }
+    for (int k = 0; k < g->last_K; ++k)
+        for (int r = 0; r < g->nranks; ++r) {
+            int64_t rec0 = 0, first = 0, count = 0;
+            segment_of(g, k, r, &rec0, &first, &count);
+            if (!count) continue;
+            int rc = plspm_detail_fetch_records(l.m, rec + (size_t)rec0 * RS, count, RS, out ? out + first * R : nullptr, status ? status + first : nullptr,
+                                                iters ? iters + first : nullptr);
+            if (rc) return gfail(g, rc, l.m->error);
+        }
     return 0;
 }
 
@@ -575,17 +764,18 @@ int plspm_group_adopt(plspm_group_t* g) {
     const int RS = plspm_row_stride(m);
     GHIP(g, hipSetDevice(m->device));
     m->rows_B = 0;
-    int rc = check_peer_shards(g);
+    int rc = check_peer_shards(g);             // (no extra round trip in the Plspm flow: plspm_group_summary ran -- and waited -- before)
     if (rc) return rc;
     rc = ensure(m, m->rows, (size_t)g->last_B * RS * sizeof(double));
     if (rc) return gfail(g, rc, m->error);
     GHIP(g, hipStreamWaitEvent(m->stream, l.gathered[g->last_slot], 0));
     const double* rec = (const double*)l.recv[g->last_slot].p;
-    for (int r = 0; r < g->nranks; ++r) {
-        int64_t first = 0, count = 0;
-        shard_of(g->last_B, g->nranks, r, &first, &count);
-        if (count) GHIP(g, hipMemcpyAsync((double*)m->rows.p + first * RS, rec + (size_t)r * g->last_cap * RS, (size_t)count * RS * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
-    }
+    for (int k = 0; k < g->last_K; ++k)
+        for (int r = 0; r < g->nranks; ++r) {
+            int64_t rec0 = 0, first = 0, count = 0;
+            segment_of(g, k, r, &rec0, &first, &count);
+            if (count) GHIP(g, hipMemcpyAsync((double*)m->rows.p + first * RS, rec + (size_t)rec0 * RS, (size_t)count * RS * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
+        }
     m->rows_B = g->last_B;
     return 0;
 }

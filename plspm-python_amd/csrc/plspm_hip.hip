@@ -171,33 +171,38 @@ static void drop_incomplete_rows(plspm_model* m) {
 
 // Several small descriptor arrays as ONE device block and ONE staged copy: a blocking hipMemcpy costs a host round trip each (~20 us on a busy
 // device, 50-90 us on one coming out of idle), and plspm_model_create made eleven of them -- most of what a Plspm() call waited for
-// besides its kernels (tools/api_pyprofile.py).  The block is freed with the handle (plspm_model::blobs).
+// besides its kernels (tools/api_pyprofile.py).  One block per call site (`slot`: plspm_model::BLOB_*): a repeated call on the same handle
+// (plspm_model_set_categorical, a second plspm_model_attach_second_stage) replaces its block instead of stacking another one; the part
+// pointers are only assigned once the copy is on the stream, so a failed upload leaves the previous descriptors in place.
 struct BlobPart { void** dst; const void* src; size_t bytes; };
 static int pin_leave_async(plspm_model* m);
-static int upload_blob(plspm_model* m, const std::vector<BlobPart>& parts) {
+static int upload_blob(plspm_model* m, int slot, const std::vector<BlobPart>& parts) {
     size_t total = 0;
     std::vector<size_t> off(parts.size());
     for (size_t i = 0; i < parts.size(); ++i) { off[i] = total; total += (std::max<size_t>(parts[i].bytes, 1) + 63) & ~(size_t)63; }
-    void* blob = nullptr;
-    HIPCHK(m, plspm_dmalloc(&blob, total));
-    m->blobs.push_back(blob);
     if (total > kPinHalf) return fail(m, PLSPM_E_LIMIT, "descriptor block exceeds the staging area");
     int rc = pin_ready(m);
     if (rc) return rc;
+    void* blob = nullptr;
+    HIPCHK(m, plspm_dmalloc(&blob, total));
     char* host = (char*)m->h_pin;
     memset(host, 0, total);
-    for (size_t i = 0; i < parts.size(); ++i) {
+    for (size_t i = 0; i < parts.size(); ++i)
         if (parts[i].bytes) memcpy(host + off[i], parts[i].src, parts[i].bytes);
-        *parts[i].dst = (char*)blob + off[i];
-    }
-    HIPCHK(m, hipMemcpyAsync(blob, host, total, hipMemcpyHostToDevice, m->stream));
-    return pin_leave_async(m);                                   // no host wait: whoever uses the staging area or the descriptors next is ordered behind the copy
+    hipError_t e = hipMemcpyAsync(blob, host, total, hipMemcpyHostToDevice, m->stream);
+    if (e != hipSuccess) { plspm_dfree(blob); return fail(m, -(int)e, std::string("descriptor upload: ") + hipGetErrorString(e)); }
+    if ((rc = pin_leave_async(m))) { hipStreamSynchronize(m->stream); plspm_dfree(blob); return rc; }      // no host wait otherwise: whoever uses the staging area or the descriptors next is ordered behind the copy
+    if (m->blobs[slot]) { hipStreamSynchronize(m->stream); plspm_dfree(m->blobs[slot]); }                   // (a kernel enqueued earlier may still read the old block)
+    m->blobs[slot] = blob;
+    for (size_t i = 0; i < parts.size(); ++i) *parts[i].dst = (char*)blob + off[i];
+    return 0;
 }
 template <class Tv> static BlobPart blob_part(Tv** dst, const std::vector<Tv>& v) { return BlobPart{(void**)dst, v.data(), v.size() * sizeof(Tv)}; }
 
 template <class Tv>
 static int upload_vec(plspm_model* m, Tv** dst, const std::vector<Tv>& v) {
     const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(Tv);
+    if (*dst) { HIPCHK(m, hipStreamSynchronize(m->stream)); plspm_dfree(*dst); *dst = nullptr; }      // a repeated call replaces its block
     HIPCHK(m, plspm_dmalloc((void**)dst, bytes));
     // (on the handle's stream: its descriptor blocks travel there without a host wait, and a copy on the null stream is not ordered behind them)
     if (!v.empty()) { HIPCHK(m, hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice, m->stream)); HIPCHK(m, hipStreamSynchronize(m->stream)); }
@@ -268,7 +273,7 @@ plspm_model_t* plspm_model_create(int32_t P, int32_t L, const int32_t* block_off
     auto bail = [&](const std::string& why) { g_create_error = why + (m->error.empty() ? "" : (": " + m->error)); plspm_model_destroy(m); return (plspm_model_t*)nullptr; };
     if (hipSetDevice(device_id) != hipSuccess) return bail("hipSetDevice failed");
     if (plspm_stream_acquire(&m->stream) != hipSuccess) return bail("hipStreamCreate failed");
-    if (upload_blob(m, {blob_part(&m->d_boff, m->boff), blob_part(&m->d_lvof, m->lvof), blob_part(&m->d_mode, m->mode), blob_part(&m->d_chol_off, m->chol_off),
+    if (upload_blob(m, plspm_model::BLOB_MODEL, {blob_part(&m->d_boff, m->boff), blob_part(&m->d_lvof, m->lvof), blob_part(&m->d_mode, m->mode), blob_part(&m->d_chol_off, m->chol_off),
                         blob_part(&m->d_eff_from, m->eff_from), blob_part(&m->d_eff_to, m->eff_to), blob_part(&m->d_C, m->C), blob_part(&m->d_pred_off, m->pred_off),
                         blob_part(&m->d_pred_idx, m->pred_idx), blob_part(&m->d_succ_off, m->succ_off), blob_part(&m->d_succ_idx, m->succ_idx)}))
         return bail("descriptor upload failed");
@@ -287,16 +292,19 @@ void plspm_model_destroy(plspm_model_t* m) {
     if (m->aux) hipStreamSynchronize(m->aux);
     if (m->stream) hipStreamSynchronize(m->stream);
     prof_collect(m);
-    void* ptrs[] = {m->d_boff, m->d_lvof, m->d_mode, m->d_chol_off, m->d_eff_from, m->d_eff_to, m->d_C, m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
-                    m->d_pred_off, m->d_pred_idx, m->d_succ_off, m->d_succ_idx, m->d_mv_off, m->d_mv_kind, m->d_lmv_off, m->d_mv_lv, m->d_mv_base, m->d_mv_base2, m->d_lmv2_off, m->d_no_chol, m->gSm.p, m->d_ind_of, m->gram2.p, m->d_lv_cols, m->d_lv_first, m->d_col2_lv1, m->d_col2_p1, m->d_hcol, m->d_hidx, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
+    // (the descriptor arrays d_boff ... d_lv_cols are parts of the blobs below, not blocks of their own)
+    void* ptrs[] = {m->d_shift, m->xa.p, m->up_raw.p, m->up_ci.p, m->up_partial.p, m->scores.p,
+                    m->d_mv_base2, m->d_lmv2_off, m->gSm.p, m->d_ind_of, m->gram2.p, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
                     m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
-    for (void* p : ptrs) if (p) plspm_dfree(p);          // (pointers into a descriptor blob are not the allocator's: ignored there)
-    for (void* p : m->blobs) plspm_dfree(p);
+    for (void* p : ptrs) if (p) plspm_dfree(p);
+    for (void* p : m->blobs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
     if (m->h_pin) plspm_hfree(m->h_pin);
     for (int k = 0; k < 2; ++k) if (m->ev_pin[k]) hipEventDestroy(m->ev_pin[k]);
+    for (auto& e : m->ev_part) if (e) hipEventDestroy(e);
+    if (m->dl) { hipStreamSynchronize(m->dl); plspm_stream_release(m->dl); }
     if (m->ev_pin_async) hipEventDestroy(m->ev_pin_async);
     for (int k = 0; k < PLSPM_K_COUNT; ++k) for (auto& pr : m->prof[k].pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (m->h_flag) plspm_hfree(m->h_flag);
@@ -458,6 +466,8 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_variant") { if (value < -1 || value > 899) return bad(); if (value >= 0 && !experiments) return exp_only(); m->tune.i8_variant = value; }
     else if (k == "i8_dma") { if (value < 0 || value > 2) return bad(); m->tune.i8_dma = value; }
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
+    else if (k == "boot_chunks") { if (value < 0 || value > kBootChunksMax) return bad(); m->tune.boot_chunks = value; }
+    else if (k == "boot_ratio") { if (value < 10 || value > 100) return bad(); m->tune.boot_ratio = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
 }
@@ -502,6 +512,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_priv") *value = m->tune.i8_priv;
     else if (k == "last_i8_priv") *value = m->last_i8_priv;
     else if (k == "i8_shape") *value = m->tune.i8_shape;
+    else if (k == "boot_chunks") *value = m->tune.boot_chunks;
+    else if (k == "boot_ratio") *value = m->tune.boot_ratio;
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else if (k == "build_experiments") {
 #ifdef PLSPM_I8_EXPERIMENTS
@@ -539,7 +551,7 @@ int plspm_model_set_categorical(plspm_model_t* m, int32_t Pm, const int32_t* mv_
     HIPCHK(m, hipSetDevice(m->device));
     m->mv_base.assign(Pm, 0);
     for (int p = 0; p < Pm; ++p) m->mv_base[p] = m->boff[m->mv_lv[p]];          // (category codes are filed relative to the MV's LV block: nm_conv_codes_kernel)
-    if (upload_blob(m, {blob_part(&m->d_mv_base, m->mv_base), blob_part(&m->d_mv_off, m->mv_off), blob_part(&m->d_mv_kind, m->mv_kind), blob_part(&m->d_lmv_off, m->lmv_off),
+    if (upload_blob(m, plspm_model::BLOB_CATEGORICAL, {blob_part(&m->d_mv_base, m->mv_base), blob_part(&m->d_mv_off, m->mv_off), blob_part(&m->d_mv_kind, m->mv_kind), blob_part(&m->d_lmv_off, m->lmv_off),
                         blob_part(&m->d_mv_lv, m->mv_lv), blob_part(&m->d_no_chol, m->no_chol)}))
         return fail(m, PLSPM_E_STATE, "descriptor upload failed: " + m->error);
     m->Pm = Pm; m->categorical = 1; m->nonmetric = 1; m->n_chol = 0;
@@ -603,7 +615,7 @@ int plspm_model_attach_second_stage(plspm_model_t* first, plspm_model_t* second,
     if (hcol.empty()) hcol.push_back(0), hcol.pop_back();
     HIPCHK(m1, hipSetDevice(m1->device));
     m2->lv_first.assign(lv_first, lv_first + L2 + 1); m2->col2_lv1 = col2_lv1; m2->col2_p1 = col2_p1; m2->hidx = hidx; m2->hcol = hcol; m2->lv_cols = lv_cols;
-    if (upload_blob(m2, {blob_part(&m2->d_lv_first, m2->lv_first), blob_part(&m2->d_col2_lv1, m2->col2_lv1), blob_part(&m2->d_col2_p1, m2->col2_p1),
+    if (upload_blob(m2, plspm_model::BLOB_HOC, {blob_part(&m2->d_lv_first, m2->lv_first), blob_part(&m2->d_col2_lv1, m2->col2_lv1), blob_part(&m2->d_col2_p1, m2->col2_p1),
                          blob_part(&m2->d_hidx, m2->hidx), blob_part(&m2->d_hcol, m2->hcol), blob_part(&m2->d_lv_cols, m2->lv_cols)}))
         return fail(m1, PLSPM_E_STATE, "descriptor upload failed: " + m2->error);
     if (m1->categorical && (int)m1->mv_lv.size() == m1->Pm && (int)m1->lmv_off.size() == L1 + 1) {

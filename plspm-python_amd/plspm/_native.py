@@ -7,13 +7,14 @@ The library is built in-tree by ``make -C plspm-python_amd/csrc`` (or ``__graft_
 import atexit
 import ctypes
 import os
+import time
 import weakref
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLSPM_HIP_LIB", os.path.join(_HERE, "_lib", "libplspm_hip.so"))
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_SINGULAR, STATUS_NONFINITE = 0, 1, 2, 3
 KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduce": 5}
@@ -24,7 +25,8 @@ EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt", "plspm_bootstrap_prepare",
            "plspm_group_barrier", "plspm_group_max", "plspm_group_enqueue_times", "plspm_release_cached_memory",
-           "plspm_op_inner_weights", "plspm_op_outer_weights", "plspm_op_outer_weights_nonmetric", "plspm_gram_tile_plan"]
+           "plspm_op_inner_weights", "plspm_op_outer_weights", "plspm_op_outer_weights_nonmetric", "plspm_gram_tile_plan",
+           "plspm_comm_create_ex", "plspm_comm_split", "plspm_comm_transport", "plspm_comm_max_channels", "plspm_group_set_option", "plspm_group_plan", "plspm_chunk_plan"]
 UNIQUE_ID_BYTES = 128
 
 
@@ -110,6 +112,17 @@ def load():
     lib.plspm_rccl_unique_id.argtypes = [vp]
     lib.plspm_comm_create.restype = vp
     lib.plspm_comm_create.argtypes = [vp, i32, i32, i32, vp]
+    lib.plspm_comm_create_ex.restype = vp
+    lib.plspm_comm_create_ex.argtypes = [vp, i32, i32, i32, vp, i32, i32]
+    lib.plspm_comm_split.restype = vp
+    lib.plspm_comm_split.argtypes = [vp, i32]
+    lib.plspm_comm_transport.restype = i32
+    lib.plspm_comm_transport.argtypes = [vp]
+    lib.plspm_comm_max_channels.restype = i32
+    lib.plspm_comm_max_channels.argtypes = [vp]
+    lib.plspm_group_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.plspm_group_plan.argtypes = [vp, i64, ctypes.POINTER(i32), vp, vp]
+    lib.plspm_chunk_plan.argtypes = [i64, i64, i32, i32, vp]
     lib.plspm_comm_destroy.restype = None
     lib.plspm_comm_destroy.argtypes = [vp]
     lib.plspm_comm_size.restype = i32
@@ -169,6 +182,16 @@ def i8_tile_plan(count_tiles, pair_tiles, cus=256, mix=True):
     if rc not in (0, 1):
         raise NativeBackendError("plspm_gram_tile_plan failed (%d)" % rc)
     return bool(rc), tall.value, shrt.value
+
+
+def chunk_plan(B, bytes_per_unit, chunks=0, ratio_pct=60):
+    """Host mirror of the sub-batch planner (plspm_chunk_plan): the sizes of the sub-batches ONE call of B units runs as."""
+    lib = load()
+    parts = np.zeros(8, dtype=np.int64)
+    n = lib.plspm_chunk_plan(B, bytes_per_unit, chunks, ratio_pct, _ptr(parts))
+    if n < 1:
+        raise NativeBackendError("plspm_chunk_plan failed (%d)" % n)
+    return [int(v) for v in parts[:n]]
 
 
 class NativeModel:
@@ -446,24 +469,46 @@ class NativeComm:
     (``NativeComm(devices)``) or one rank of a one-process-per-GPU job (``NativeComm([device], nranks, rank, unique_id)``).
     Expensive to create (librccl load + ncclCommInit*); create once, bind to groups one after the other."""
 
-    def __init__(self, devices, nranks=None, first_rank=0, unique_id=None):
+    TRANSPORTS = {"auto": 0, "rccl": 1, "copy": 2}
+
+    def __init__(self, devices, nranks=None, first_rank=0, unique_id=None, transport="auto", max_channels=0, _handle=None):
+        """``transport``: "auto" (RCCL between distinct devices), "rccl", or "copy" (single-process jobs: device-to-device copies on
+        peer-mapped buffers -- the SDMA engines move the records, no kernel of the exchange takes a CU).  ``max_channels`` > 0 caps the
+        workgroups RCCL runs for this communicator's collectives (ncclConfig_t.maxCTAs)."""
         lib = load()
         self._lib = lib
         self.devices = [int(d) for d in devices]
         self.nranks = len(self.devices) if nranks is None else int(nranks)
         self.first_rank = int(first_rank)
-        dev = np.ascontiguousarray(self.devices, dtype=np.int32)
-        uid = None
-        if unique_id is not None:
-            if len(unique_id) != UNIQUE_ID_BYTES:
-                raise ValueError("unique_id must have %d bytes" % UNIQUE_ID_BYTES)
-            uid = (ctypes.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
-        self._h = lib.plspm_comm_create(_ptr(dev), len(self.devices), self.nranks, self.first_rank, uid)
-        if not self._h:
-            raise NativeBackendError("plspm_comm_create: " + lib.plspm_group_last_error(None).decode())
+        if _handle is not None:
+            self._h = _handle
+        else:
+            dev = np.ascontiguousarray(self.devices, dtype=np.int32)
+            uid = None
+            if unique_id is not None:
+                if len(unique_id) != UNIQUE_ID_BYTES:
+                    raise ValueError("unique_id must have %d bytes" % UNIQUE_ID_BYTES)
+                uid = (ctypes.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+            t0 = time.perf_counter()
+            self._h = lib.plspm_comm_create_ex(_ptr(dev), len(self.devices), self.nranks, self.first_rank, uid, self.TRANSPORTS[transport], int(max_channels))
+            self.create_s = time.perf_counter() - t0
+            if not self._h:
+                raise NativeBackendError("plspm_comm_create: " + lib.plspm_group_last_error(None).decode())
         self.uses_rccl = bool(lib.plspm_comm_uses_rccl(self._h))
+        self.transport = {1: "rccl", 2: "copy-engines", 3: "device-copies"}.get(lib.plspm_comm_transport(self._h), "?")
+        self.max_channels = int(lib.plspm_comm_max_channels(self._h))
         self._bound = None              # weak reference to the group this communicator currently serves (one at a time)
         _live_comms.add(self)
+
+    def split(self, max_channels):
+        """A second communicator over the same ranks with its own channel cap (ncclCommSplit: collective over this one, every rank calls it)."""
+        t0 = time.perf_counter()
+        h = self._lib.plspm_comm_split(self._h, int(max_channels))
+        if not h:
+            raise NativeBackendError("plspm_comm_split: " + self._lib.plspm_group_last_error(None).decode())
+        twin = NativeComm(self.devices, self.nranks, self.first_rank, _handle=h)
+        twin.create_s = time.perf_counter() - t0
+        return twin
 
     def busy(self):
         """True while a live group is bound to this communicator (plspm_group_create refuses a second one)."""
@@ -523,6 +568,17 @@ class NativeGroup:
         first, count = ctypes.c_int64(0), ctypes.c_int64(0)
         self._check(self._lib.plspm_group_shard(self._h, B, rank, ctypes.byref(first), ctypes.byref(count)), "plspm_group_shard")
         return first.value, count.value
+
+    def set_option(self, key, value):
+        """"chunks" 0 automatic | 1 .. 8 sub-batches per call; "chunk_ratio" percent (include/plspm_hip.h, plspm_group_bootstrap)."""
+        self._check(self._lib.plspm_group_set_option(self._h, key.encode(), int(value)), "plspm_group_set_option")
+
+    def plan(self, B):
+        """The sub-batches a call of B replicates runs as: [(first, count), ...] in replicate-id order."""
+        n = ctypes.c_int32(0)
+        first, count = np.zeros(8, dtype=np.int64), np.zeros(8, dtype=np.int64)
+        self._check(self._lib.plspm_group_plan(self._h, B, ctypes.byref(n), _ptr(first), _ptr(count)), "plspm_group_plan")
+        return [(int(first[k]), int(count[k])) for k in range(n.value)]
 
     def bootstrap(self, B, seed=0, rep_offset=0):
         """Enqueue B replicates over the group + the all-gather (no host synchronisation for metric models)."""

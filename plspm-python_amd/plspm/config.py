@@ -6,6 +6,7 @@ specification: ``plspm._compile.compile_model`` lowers a Config + path matrix ON
 of the C-ABI (block offsets, path bitmap, mode ids) instead of being queried by label inside the iteration.
 """
 import itertools
+import weakref
 
 import numpy as np
 import pandas as pd
@@ -139,7 +140,7 @@ class Config:
         twin._mv_scales = dict(self._mv_scales)
         twin._metric = self._metric
         twin._missing = self._missing
-        twin._nan_seen = getattr(self, "_nan_seen", None)
+        twin._nan_seen = getattr(self, "_nan_seen", None)   # (keyed by a weak reference to the frame itself: valid for the twin as long as it is asked about that very object)
         return twin
 
     # ------------------------------------------------------------------ queries
@@ -229,8 +230,13 @@ class Config:
             if drop.any():
                 data = data.loc[~drop]
                 nan_cols = self._scan_nan(data)
-        self._nan_seen = (id(data), data.shape, nan_cols)
+        self._nan_seen = (weakref.ref(data), data.shape, nan_cols)      # (a weak reference: an id() could be recycled by another frame of the same shape)
         return data
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_nan_seen"] = None                            # never travels to another process: the frame it describes does not
+        return state
 
     @staticmethod
     def _scan_nan(data: pd.DataFrame) -> np.ndarray:
@@ -242,7 +248,7 @@ class Config:
     def nan_columns(self, data: pd.DataFrame) -> np.ndarray:
         """Per column of ``data``: does it hold a NaN?  Served from the scan ``filter`` made when ``data`` is the frame it returned."""
         seen = getattr(self, "_nan_seen", None)
-        if seen is not None and seen[0] == id(data) and seen[1] == data.shape:
+        if seen is not None and seen[0]() is data and seen[1] == data.shape:
             return seen[2]
         return self._scan_nan(data)
 

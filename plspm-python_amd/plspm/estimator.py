@@ -142,7 +142,7 @@ class Estimator:
             second = _native.NativeModel(offsets2, compiled2.path, compiled2.modes, scheme_code, config.scaled(),
                                          calculator._iterations, calculator._tolerance, device_id, nonmetric=True, categorical=categorical2)
             first.attach_second_stage(second, lv_first)
-            return first
+            return calculator.apply_precision(first)
 
         return SolverResult(compiled2, build(calculator._device_id), None, data.index, builder=build)
 

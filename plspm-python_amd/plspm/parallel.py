@@ -45,15 +45,19 @@ def join_records(rows, status, iters):
 _local_comms = {}
 
 
-def local_comm(devices):
+def local_comm(devices, transport=None, max_channels=None):
     """The process-wide communicator over ``devices`` (created on first use: librccl load + ncclCommInitAll take of the order
     of a second, every later bootstrap re-uses it).  A communicator serves one group at a time: while the bootstrap of an earlier
-    ``Plspm`` object is still alive on the cached one, the caller gets a communicator of its own (which becomes the cached one)."""
+    ``Plspm`` object is still alive on the cached one, the caller gets a communicator of its own (which becomes the cached one).
+    ``transport`` ("auto" / "rccl" / "copy": ``PLSPM_TRANSPORT``) and ``max_channels`` (``PLSPM_RCCL_MAX_CHANNELS``; 0 = RCCL's
+    default) pick how the records travel -- see ``_native.NativeComm``; the rows do not depend on either."""
     from plspm import _native
-    key = tuple(int(d) for d in devices)
+    transport = transport or os.environ.get("PLSPM_TRANSPORT", "auto")
+    max_channels = int(os.environ.get("PLSPM_RCCL_MAX_CHANNELS", "0")) if max_channels is None else int(max_channels)
+    key = (tuple(int(d) for d in devices), transport, max_channels)
     comm = _local_comms.get(key)
     if comm is None or not comm._h or comm.busy():
-        comm = _native.NativeComm(key)
+        comm = _native.NativeComm(key[0], transport=transport, max_channels=max_channels)
         _local_comms[key] = comm
     return comm
 
@@ -123,7 +127,11 @@ def _rendezvous_dir(directory):
 def _rendezvous_path(directory):
     global _rendezvous_seq
     _rendezvous_seq += 1
-    tag = "%s-%s-%d-%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"), os.getppid(), _rendezvous_seq)
+    # per-job nonce: launcher address / port, the launcher's pid, its run id and restart count (an elastic launcher that restarts its workers
+    # keeps pid and port: the ranks of the new incarnation must not pick up the dead one's id), this process's call count
+    tag = "%s-%s-%d-%s-%s-%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"), os.getppid(),
+                                 os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _rendezvous_seq)
+    tag = "".join(ch if (ch.isalnum() or ch in "-._") else "_" for ch in tag)
     return os.path.join(_rendezvous_dir(directory), "plspm-rdzv-" + tag)
 
 

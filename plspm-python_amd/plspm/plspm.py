@@ -4,7 +4,9 @@ Same constructor arguments, clamps, assertions and accessors as the reference.  
 bootstrap workers (plspm.py:35-37, bootstrap.py:89-94) -- caps the number of GPUs of this process the replicates are sharded
 over once the caller NAMES GPUs (``devices=[...]`` or the ``PLSPM_DEVICES`` allow-list; also capped by
 ``parallel.MIN_REPLICATES_PER_GPU`` replicates per GPU; ONE RCCL all-gather merges the shards; the rows do not depend on it).
-Without named GPUs everything runs on ``device_id``.  Keyword extensions: ``seed`` (reproducible bootstrap), ``device_id``, ``devices``.
+Without named GPUs everything runs on ``device_id``.  Keyword extensions: ``seed`` (reproducible bootstrap), ``device_id``, ``devices``,
+``precision`` ("auto": the bootstrap's moment sums on the fewest exact-integer digit planes that stay inside the error bound of the
+reference's own fp64 accumulation on the data at hand; "strict": always seven planes = correctly rounded sums, ~20 % slower).
 """
 import time
 
@@ -63,13 +65,13 @@ class Plspm:
 
     def __init__(self, data: pd.DataFrame, config: c.Config, scheme: Scheme = Scheme.CENTROID, iterations: int = 100,
                  tolerance: float = 0.000001, bootstrap: bool = False, bootstrap_iterations: int = 100, processes: int = 2,
-                 seed: int = None, device_id: int = 0, devices=None):
+                 seed: int = None, device_id: int = 0, devices=None, precision: str = "auto"):
         iterations, bootstrap_iterations = _normalise_arguments(scheme, iterations, tolerance, bootstrap_iterations, processes)
         t_start = time.perf_counter()
         estimator = Estimator(config)
         observations = config.filter(data)
         n_obs = observations.shape[0]
-        calculator = w.WeightsCalculatorFactory(config, iterations, tolerance, np.sqrt(n_obs / (n_obs - 1)), scheme, device_id)
+        calculator = w.WeightsCalculatorFactory(config, iterations, tolerance, np.sqrt(n_obs / (n_obs - 1)), scheme, device_id, precision)
 
         # one device fit: Gram -> LDS solver -> scores; everything below only re-labels / post-processes its outputs
         fit = estimator.run(calculator, observations, want_scores=True, want_cov=True, prepare_bootstrap=bool(bootstrap) and n_obs >= 10)

@@ -51,7 +51,10 @@ class SolverResult:
 class WeightsCalculatorFactory:
     """Calculates weights and scores from the data using the model, on the GPU."""
 
-    def __init__(self, config, iterations: int, tolerance: float, correction: float, scheme: Scheme, device_id: int = 0):
+    def __init__(self, config, iterations: int, tolerance: float, correction: float, scheme: Scheme, device_id: int = 0, precision: str = "auto"):
+        if precision not in ("auto", "strict"):
+            raise ValueError("precision must be 'auto' or 'strict'")
+        self._precision = precision
         self._config = config
         self._iterations = iterations
         self._tolerance = tolerance
@@ -61,7 +64,16 @@ class WeightsCalculatorFactory:
 
     def clone(self):
         return WeightsCalculatorFactory(self._config.clone(), self._iterations, self._tolerance, self._correction, self._scheme,
-                                        self._device_id)
+                                        self._device_id, self._precision)
+
+    def apply_precision(self, handle):
+        """``precision="strict"``: the bootstrap's moment sums are correctly rounded by construction -- SEVEN base-256 digit planes per pair
+        product (>= 53 significant bits of every column maximum, exact integer accumulation; include/plspm_hip.h "i8_slices") -- instead of
+        the automatic choice, which takes six planes when the uploaded data keep the representation error below a quarter of the a-priori
+        bound of the fp64 accumulation the reference performs (weights.py:43,60-61).  Costs ~20 % of the bootstrap rate."""
+        if self._precision == "strict":
+            handle.set_option("i8_slices", 7)
+        return handle
 
     def config(self):
         return self._config
@@ -122,13 +134,13 @@ class WeightsCalculatorFactory:
                 handle = _native.NativeModel(aug_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled, self._iterations,
                                              self._tolerance, device_id, nonmetric=True, categorical=(mv_off, mv_kind))
                 handle.upload(xaug)
-                return handle
+                return self.apply_precision(handle)
             handle = _native.NativeModel(compiled.block_offset, compiled.path, compiled.modes, self._scheme.value.code, scaled,
                                          self._iterations, self._tolerance, device_id, nonmetric=bool(nonmetric), missing=ind_of)
             handle.upload(values, col_index)
             if incomplete is not None:
                 handle.set_incomplete_rows(*incomplete)
-            return handle
+            return self.apply_precision(handle)
 
         native = build(self._device_id)
         if prepare_bootstrap:

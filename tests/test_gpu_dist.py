@@ -75,6 +75,76 @@ def test_group_records_bit_identical_to_single_handle(nranks, B):
     group.close(); comm.close()
 
 
+@pytest.mark.parametrize("nranks,B,chunks", [(2, 3000, 2), (2, 3001, 3), (3, 5003, 3), (1, 2600, 2), (2, 4500, 0), (4, 9000, 4)])
+def test_group_call_as_sub_batches_is_bit_identical(nranks, B, chunks):
+    """ONE plspm_group_bootstrap call as sub-batches (round 5: the gather of sub-batch k beside the kernels of sub-batch k + 1): consecutive ranges
+    of the replicate ids, each sharded over the ranks like a call of its own.  Rows, status, iteration counts and the device summary are bit
+    for bit those of the single-handle stream for even, ragged and automatic cuts; the plan covers the call; the gathered buffer holds one
+    block of nranks x ceil(count / nranks) records per sub-batch."""
+    from plspm import _native
+    models = [_model(1500, 5, seed=9) for _ in range(nranks)]
+    ref_rows, ref_status, ref_iters = models[0].bootstrap(B, seed=5, rep_offset=11)
+    original = np.linspace(-1.0, 1.0, models[0].row_width)
+    ref_table, ref_used = models[0].summary(B, original)
+    comm = _native.NativeComm([0] * nranks)
+    group = _native.NativeGroup(comm, models)
+    group.set_option("chunks", chunks)
+    plan = group.plan(B)
+    assert plan[0][0] == 0 and sum(c for _, c in plan) == B and all(plan[k][0] + plan[k][1] == plan[k + 1][0] for k in range(len(plan) - 1))
+    if chunks:
+        assert len(plan) == chunks, plan
+    elif nranks > 1:
+        assert len(plan) >= 2, plan                         # 2,250 records of 1 KB per rank: worth hiding
+    for _ in range(3):                                       # both buffer slots, and a slot re-used
+        group.bootstrap(B, seed=5, rep_offset=11)
+    rows, status, iters = group.rows()
+    assert np.array_equal(rows, ref_rows) and np.array_equal(status, ref_status) and np.array_equal(iters, ref_iters)
+    table, used = group.summary(original)
+    assert used == ref_used == B and np.array_equal(table, ref_table, equal_nan=True)
+    _, n_rec, _ = group.records(0)
+    assert n_rec == nranks * sum((c + nranks - 1) // nranks for _, c in plan)
+    group.adopt()                                            # replicate-id order in the handle's own buffer
+    got = models[0].fetch(0, B)
+    assert np.array_equal(got[0], ref_rows) and np.array_equal(got[2], ref_iters)
+    # a one-sub-batch call on the same group afterwards (the buffers are re-used with another layout)
+    group.set_option("chunks", 1)
+    group.bootstrap(B, seed=5, rep_offset=11)
+    assert np.array_equal(group.rows()[0], ref_rows) and len(group.plan(B)) == 1
+    with pytest.raises(_native.NativeBackendError):
+        group.set_option("chunks", 9)
+    group.close(); comm.close()
+
+
+@pytest.mark.parametrize("max_channels", [1, 4])
+def test_rccl_communicator_with_a_channel_cap_and_its_split(max_channels):
+    """plspm_comm_create_ex(max_channels) / plspm_comm_split: RCCL communicators whose collectives run at most that many workgroups
+    (ncclCommInitRankConfig / ncclCommSplit with ncclConfig_t.maxCTAs) -- one rank here (the box has one GPU): the all-gather, the barrier and
+    the max go through RCCL and the records are the single-handle stream."""
+    from plspm import _native
+    nm = _model(1200, 5, seed=6)
+    ref = nm.bootstrap(700, seed=3)
+    capped = _native.NativeComm([0], transport="rccl", max_channels=max_channels)
+    assert capped.uses_rccl and capped.transport == "rccl" and capped.max_channels == max_channels and capped.create_s > 0
+    group = _native.NativeGroup(capped, [nm])
+    for _ in range(3):
+        group.bootstrap(700, seed=3)
+    assert np.array_equal(group.rows()[0], ref[0])
+    group.barrier()
+    assert group.max(2.5) == 2.5
+    group.close()
+    twin = capped.split(0)                                   # RCCL's default channel count, split off the capped one
+    assert twin.uses_rccl and twin.max_channels == 0 and twin.nranks == 1
+    g2 = _native.NativeGroup(twin, [nm])
+    g2.bootstrap(700, seed=3)
+    assert np.array_equal(g2.rows()[0], ref[0])
+    g2.close(); twin.close(); capped.close()
+    with pytest.raises(_native.NativeBackendError):          # ranks sharing a device cannot be an RCCL communicator
+        _native.NativeComm([0, 0], transport="rccl")
+    shared = _native.NativeComm([0, 0], transport="copy")    # ... and the copy transport on one device is the one-launch exchange
+    assert not shared.uses_rccl and shared.transport == "device-copies"
+    shared.close()
+
+
 def test_group_exchange_of_odd_sized_record_blocks():
     """Handles on one device exchange their records in ONE launch (16-byte pieces when a rank's block is a whole number of them, 8-byte
     ones otherwise): a model whose record stride is odd, with an odd number of replicates per rank."""
@@ -268,6 +338,25 @@ def test_real_multi_gpu_rccl_all_gather_when_the_box_has_two_gpus():
     group.barrier()
     assert group.max(3.5) == 3.5
     group.close(); comm.close()
+    # every transport (round 5): RCCL with a channel cap, a capped communicator split off the default one, the copy-engine exchange on
+    # peer-mapped buffers -- each with one sub-batch and with three, against the same single-handle stream
+    for make in (lambda: _native.NativeComm(list(range(G)), transport="rccl", max_channels=4),
+                 lambda: _native.NativeComm(list(range(G)), transport="copy")):
+        comm = make()
+        assert comm.nranks == G and comm.transport == ("rccl" if comm.uses_rccl else "copy-engines")
+        comms = [comm] + ([comm.split(8)] if comm.uses_rccl else [])
+        for cc in comms:
+            group = _native.NativeGroup(cc, models)
+            for chunks in (1, 3):
+                group.set_option("chunks", chunks)
+                for call in range(3):
+                    group.bootstrap(8 * 1003, seed=5, rep_offset=7)
+                rows, status, iters = group.rows()
+                big = models[0].bootstrap(8 * 1003, seed=5, rep_offset=7)
+                assert np.array_equal(rows, big[0]) and np.array_equal(status, big[1]) and np.array_equal(iters, big[2]), (cc.transport, cc.max_channels, chunks)
+            group.close()
+        for cc in comms[::-1]:
+            cc.close()
     script = os.path.join(HERE, "dist_api_script.py")
     plain = _run([sys.executable, script])
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(min(G, 2)), "--master-addr", "127.0.0.1",

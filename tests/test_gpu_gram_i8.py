@@ -118,6 +118,37 @@ def test_ragged_batches_and_sharding_bit_identity(B):
         assert_close(rows[r], mine, RTOL, ATOL)
 
 
+@pytest.mark.parametrize("B,chunks", [(5000, 0), (5000, 2), (3333, 3), (1700, 3), (9000, 5)])
+def test_host_buffer_bootstrap_as_sub_batches_is_bit_identical(B, chunks):
+    """plspm_bootstrap() as sub-batches (round 5, "boot_chunks"): the records of sub-batch k are downloaded on a copy stream and unpacked while
+    the kernels of sub-batch k + 1 run.  Rows, status and iteration counts are those of the one-piece call, bit for bit; the device-resident
+    records afterwards serve fetch / summary like after any bootstrap; the error word still arrives (explicit indices take one piece)."""
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(3000, C, 10, seed=4)
+    model = orc.Model(blocks, C, "A" * 6, "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    nm.set_option("boot_chunks", 1)
+    ref = nm.bootstrap(B, seed=9, rep_offset=3)
+    nm.set_option("boot_chunks", chunks)
+    out = (np.full((B, nm.row_width), np.nan), np.full(B, -7, dtype=np.int32), np.full(B, -7, dtype=np.int32))
+    for _ in range(2):
+        got = nm.bootstrap(B, seed=9, rep_offset=3, out=out)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    again = nm.fetch(0, B)
+    assert np.array_equal(again[0], ref[0]) and np.array_equal(again[2], ref[2])
+    table, used = nm.summary(B, np.ones(nm.row_width))
+    nm.set_option("boot_chunks", 1)
+    nm.bootstrap(B, seed=9, rep_offset=3)
+    table1, used1 = nm.summary(B, np.ones(nm.row_width))
+    assert used == used1 == B and np.array_equal(table, table1, equal_nan=True)
+    nm.set_option("boot_chunks", chunks)
+    bad = np.zeros((2, 3000), dtype=np.int32); bad[1, 5] = 3000
+    from plspm import _native
+    with pytest.raises(_native.NativeBackendError):
+        nm.bootstrap(2, idx=bad)
+
+
 def test_multiplicity_above_127_falls_back_to_the_fp64_gram():
     X, blocks, _ = satisfaction_oracle_inputs()
     model = orc.Model(blocks, orc.satisfaction_C(), "A" * 6, "centroid", True)
@@ -414,6 +445,91 @@ def test_automatic_plane_count_and_its_error_against_extended_precision():
     small.upload(Xs)
     small.bootstrap_device(16, seed=1)
     assert small.get_option("last_gram_path") == 2 and small.get_option("last_i8_slices") == 7 and 0 < small.get_option("last_i8_ratio") < 256
+
+
+def numpy_fp64_error(X, order, shift, idx):
+    """Error of the REFERENCE'S OWN arithmetic on the same sums: NumPy fp64 products of the resampled (gathered) mean-shifted columns --
+    `X.T @ X` through BLAS, what weights.py:43,60-61 / mode.py:29 run on -- against the 80-bit sums, relative to sqrt(M_pp M_qq)."""
+    Xa = np.concatenate((X[:, order] - shift[None, :], np.ones((X.shape[0], 1))), axis=1)
+    worst = 0.0
+    for b in range(len(idx)):
+        ref = exact_moments(X[:, order], shift, idx[b])
+        Xg = Xa[idx[b]]
+        scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+        worst = max(worst, float(np.max(np.abs((Xg.T @ Xg).astype(np.longdouble) - ref) / scale)))
+    return worst
+
+
+def test_plane_count_error_against_the_reference_arithmetic_and_strict_precision():
+    """VERDICT r4 item 7 -- the precision claim, pinned.  On the headline data (10,000 bell-shaped rows) the automatic choice is SIX planes:
+    its worst moment entry against 80-bit sums stays below 2^-48 (3.6e-15) and within a single-digit multiple of what NumPy's own fp64
+    `X.T @ X` makes of the same resampled columns (measured 2.2e-15 against 3.5 ... 4.8e-16: ~5 x; asserted < 8 x) -- nine orders below the
+    1e-6 the records are held to, but NOT below fp64 by construction.  SEVEN planes are: `precision="strict"` (set_option i8_slices 7) sits
+    below NumPy's error.  On heavy-tailed data (Student t, 2.2 degrees of freedom, one gross outlier: sum|z| ~ max|z| in some pair column)
+    the automatic rule must pick seven planes by itself, and is then at or below NumPy's error as well."""
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(10000, C, 10, seed=0)
+    model = orc.Model(blocks, C, "A" * 6, "path", True)
+    nm = native_model(model)
+    nm.upload(X, model.mv_order.astype(np.int32))
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 10000, size=(3, 10000)).astype(np.int32)
+    e_auto, _ = moment_errors(nm, X, model.mv_order, idx, 2)
+    assert nm.get_option("last_i8_slices") == 6
+    shift = nm.fit(want_scores=False)["mean"]
+    e_np = numpy_fp64_error(X, model.mv_order, shift, idx)
+    e_strict, _ = moment_errors(nm, X, model.mv_order, idx, 2, 7)
+    assert 1e-17 < e_np < 2e-15, e_np
+    assert e_auto < 2.0 ** -48 and e_auto < 8 * e_np, (e_auto, e_np)
+    assert e_strict <= e_np, (e_strict, e_np)
+    # heavy tails: the rule itself takes seven planes
+    rng = np.random.default_rng(7)
+    Ch = orc.chain_C(3)
+    eta = rng.standard_t(2.2, size=(10000, 3))
+    Xh = np.repeat(eta, 4, axis=1) * 0.8 + 0.6 * rng.standard_t(2.2, size=(10000, 12))
+    Xh[17, 3] = 900.0
+    bh = [np.arange(0, 4), np.arange(4, 8), np.arange(8, 12)]
+    mh = orc.Model(bh, Ch, "AAA", "path", True)
+    nh = native_model(mh)
+    nh.upload(Xh, mh.mv_order.astype(np.int32))
+    e_h, _ = moment_errors(nh, Xh, mh.mv_order, idx, 2)
+    assert nh.get_option("last_i8_slices") == 7 and nh.get_option("last_i8_ratio") < 256
+    e_hnp = numpy_fp64_error(Xh, mh.mv_order, nh.fit(want_scores=False)["mean"], idx)
+    assert e_h <= max(e_hnp, 2.3e-16), (e_h, e_hnp)
+
+
+def test_plspm_precision_strict_takes_seven_planes_through_the_api():
+    """`Plspm(..., precision="strict")`: the bootstrap of the drop-in API runs on seven digit planes whatever the data; "auto" (default) keeps
+    the data-dependent choice.  Summaries of the two agree far inside the parity bar."""
+    import pandas as pd
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(10000, C, 10, seed=0)
+    lvs = ["IMAG", "EXPE", "QUAL", "VAL", "SAT", "LOY"]
+    cols = ["%s%d" % (lv.lower(), k) for lv in lvs for k in range(10)]
+    frame = pd.DataFrame(X, columns=cols)
+    structure = c.Structure()
+    for i in range(6):
+        for j in range(6):
+            if C[i, j]:
+                structure.add_path([lvs[j]], [lvs[i]])
+
+    def config():
+        cfg = c.Config(structure.path(), scaled=True)
+        for lv in lvs:
+            cfg.add_lv_with_columns_named(lv, Mode.A, frame, lv.lower())
+        return cfg
+    auto = Plspm(frame, config(), Scheme.PATH, bootstrap=True, bootstrap_iterations=512, processes=1, seed=4)
+    strict = Plspm(frame, config(), Scheme.PATH, bootstrap=True, bootstrap_iterations=512, processes=1, seed=4, precision="strict")
+    assert auto.bootstrap()._native.get_option("last_i8_slices") == 6
+    assert strict.bootstrap()._native.get_option("last_i8_slices") == 7
+    np.testing.assert_allclose(auto.bootstrap().weights().values, strict.bootstrap().weights().values, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(auto.bootstrap().paths().values, strict.bootstrap().paths().values, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        Plspm(frame, config(), Scheme.PATH, precision="sloppy")
 
 
 @pytest.mark.parametrize("step,expect", [(1.0, 1), (1.0 / 16, 2), (1.0 / 4096, 4)])

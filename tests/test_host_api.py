@@ -183,13 +183,46 @@ def test_create_summary_matches_reference_golden():
 # ------------------------------------------------------------------ C-ABI surface
 def test_library_exports_every_declared_symbol():
     lib = _native.load()
-    header = open(os.path.join(ROOT, "include", "plspm_hip.h")).read()
+    # production ABI + the test seams (include/plspm_hip_test.h); together they are exactly what the library exports
+    header = open(os.path.join(ROOT, "include", "plspm_hip.h")).read() + open(os.path.join(ROOT, "include", "plspm_hip_test.h")).read()
     declared = sorted(set(re.findall(r"\b(plspm_[a-z_]+)\s*\(", header)) - {"plspm_model", "plspm_fit_result"})
     assert len(declared) >= 17
     for name in declared:
         assert hasattr(lib, name), "libplspm_hip.so does not export " + name
     assert sorted(_native.EXPORTS) == declared
-    assert lib.plspm_abi_version() == 3
+    # ... and nothing else: `nm -D` of the library shows the headers' symbols only (csrc/exports.map; no internal seam leaks)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in nm.splitlines() if line.split()[-2] in "TDBWV")
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+    assert lib.plspm_abi_version() == 4
+
+
+def test_sub_batch_planner_covers_the_call_and_shrinks_geometrically():
+    """plspm_chunk_plan (host arithmetic; plspm_bootstrap "boot_chunks", plspm_group_bootstrap "chunks"): ONE call as sub-batches whose
+    transfer hides under the next sub-batch's kernels.  The parts cover B exactly, fall by about the ratio, are multiples of 64 (whole
+    count tiles of the int8 Gram) but for the last, never fall below 64, and small calls -- below 2 MiB of results -- stay in one piece."""
+    rec = 158 * 8
+    assert _native.chunk_plan(5000, rec) == [2560, 1536, 904]                   # the headline batch: 6.3 MB of records, three parts
+    assert _native.chunk_plan(5000, rec, chunks=1) == [5000]
+    assert _native.chunk_plan(1000, rec) == [1000]                               # 1.26 MB: nothing worth hiding
+    assert _native.chunk_plan(1024, rec, chunks=4) == [576, 448] or len(_native.chunk_plan(1024, rec, chunks=4)) <= 2      # no part below 512 units asked for
+    for B in (1, 63, 64, 65, 511, 1664, 1700, 4999, 5000, 40000, 123457, 1 << 20):
+        for chunks in (0, 1, 2, 3, 5, 8):
+            for ratio in (10, 50, 60, 100):
+                parts = _native.chunk_plan(B, rec, chunks, ratio)
+                assert sum(parts) == B and all(p >= 1 for p in parts), (B, chunks, ratio, parts)
+                assert 1 <= len(parts) <= max(1, chunks if chunks else 3)
+                assert all(p % 64 == 0 for p in parts[:-1])
+                if len(parts) > 1:
+                    assert min(parts) >= 64
+                    assert all(parts[k + 1] <= parts[k] + 64 for k in range(len(parts) - 2)), parts        # falling sizes (the last takes the remainder)
+    # 100 %: equal parts; a steeper ratio makes the first part larger
+    eq = _native.chunk_plan(6144, rec, 3, 100)
+    assert eq == [2048, 2048, 2048]
+    assert _native.chunk_plan(6144, rec, 3, 30)[0] > _native.chunk_plan(6144, rec, 3, 60)[0] > eq[0]
+    with pytest.raises(_native.NativeBackendError):
+        _native.chunk_plan(0, rec)
 
 
 def test_host_rng_mirror_properties():
