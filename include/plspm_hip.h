@@ -391,7 +391,9 @@ int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* 
  * sub-batch k + 1; only the last, smallest gather is exposed.  Results do not depend on the cut (Philox stream keyed by (seed, replicate id)).
  * Options (plspm_group_set_option): "chunks" 0 (default: automatic -- one sub-batch below 2 MiB of records per rank or on a one-rank group,
  * else up to three, sizes falling by "chunk_ratio" percent) | 1 .. 8 sub-batches -- a caller that issues calls back to back (bench.py's
- * step loop) sets 1: the gather of call k then overlaps the kernels of call k + 1 anyway; "chunk_ratio" 10 .. 100 (default 50). */
+ * step loop) sets 1: the gather of call k then overlaps the kernels of call k + 1 anyway; "chunk_ratio" 10 .. 100 (default 50); "chunk_align"
+ * 0 (default: every sub-batch but the last fills whole ROUNDS of the device per rank -- a part that ends inside a round of Gram tiles pays for
+ * the whole round; models whose round holds more replicates than the call has stay in one piece) | n: multiples of n replicates per rank. */
 int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset);
 int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value);
 /* The sub-batches a call of B replicates is cut into: *n_sub (<= 8) ranges [sub_first[k], sub_first[k] + sub_count[k]) (arrays of 8), in

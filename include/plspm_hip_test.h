@@ -42,8 +42,12 @@ int plspm_gram_tile_plan(int64_t count_tiles, int64_t pair_tiles, int32_t cus, i
 
 /* Test seam, host arithmetic only: the sub-batch sizes of ONE call of B units whose results leave the device behind the kernels (PCIe download of
  * plspm_bootstrap, "boot_chunks"; gather of plspm_group_bootstrap, "chunks", per rank): parts [8]; returns the number of parts.  chunks 0 =
- * automatic (one part below 2 MiB = B * bytes_per_unit of results, else up to three), ratio_pct: size of part k + 1 relative to part k. */
-int plspm_chunk_plan(int64_t B, int64_t bytes_per_unit, int32_t chunks, int32_t ratio_pct, int64_t* parts);
+ * automatic (one part below 2 MiB = B * bytes_per_unit of results, else up to three), ratio_pct: size of part k + 1 relative to part k; align: every part
+ * but the last a multiple of it (0: 64 -- whole count tiles; the library passes the replicates of one ROUND of the device, read-only option
+ * "boot_round_units" of a handle: 1,280 for the headline model on 256 CUs).  Handle option "boot_align" n > 0 overrides the alignment (A/B).
+ * Group options for diagnosis: "skip_exchange" 1 (the step's events and kernels without moving the records -- NOT a result), "events_device_scope" 1
+ * (the group's events release at device scope). */
+int plspm_chunk_plan(int64_t B, int64_t bytes_per_unit, int32_t chunks, int32_t ratio_pct, int64_t align, int64_t* parts);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ struct plspm_model {
     bool err_clean = false;       // the device error word is zero and no call since could have raised it (plspm_detail_bootstrap)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60, boot_align = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
     Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat, codes;
@@ -157,10 +157,15 @@ int plspm_detail_fetch_records(plspm_model* m, const double* d_records, int64_t 
 // Sub-batches of ONE call of B units (replicates) whose results leave the device behind the kernels -- over PCIe (plspm_bootstrap) or through the
 // collective (plspm_group_bootstrap): sizes in a geometric progression (ratio_pct / 100: what moving a unit costs relative to computing it), so that
 // the transfer of sub-batch k hides under the kernels of sub-batch k + 1 and only the last, smallest transfer is exposed; every part but the last
-// a multiple of 64 units (whole count tiles of the int8 Gram).  chunks_opt 0: automatic (one part below 2 MiB of results, else up to three),
+// a multiple of `align` units (64: whole count tiles of the int8 Gram; plspm_detail_round_units: whole rounds of the machine).  chunks_opt 0: automatic (one part below 2 MiB of results, else up to three),
 // n >= 1: n parts.  Returns the number of parts (<= kBootChunksMax), sizes in parts[].  Host arithmetic only (plspm_group.cpp).
 static constexpr int kBootChunksMax = 8;
-int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts);
+int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts, int64_t align = 64);
+// Replicates that fill ONE round of the device with tall tiles of the int8 Gram on this handle's model (whole tile rows: a row of tall tiles
+// is 320 / 256 replicates x every pair tile) -- the alignment of the sub-batches of a call: a part that ends inside a round pays for the
+// whole round (5,000 replicates of the headline model as 2,560 + 1,536 + 904: Gram 0.42 ms; as 2,560 + 1,280 + 1,160: 0.35; one batch 0.334).
+// 64 when the handle's bootstrap does not take that Gram.  plspm_gram_i8.hip.
+int64_t plspm_detail_round_units(plspm_model* m);
 struct FetchSeg { int64_t b0, nb; hipEvent_t ready; };
 
 // Same-device record exchange of a group (plspm_bootstrap.hip): send[i] -> recv[d] + i * doubles for all i, d < n, one launch on `stream`.

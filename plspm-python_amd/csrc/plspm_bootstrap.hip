@@ -180,7 +180,8 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     int64_t parts[kBootChunksMax];
     int nparts = 1;
     parts[0] = B;
-    if (!d_idx && !m->nonmetric && !m->moments_out) nparts = plspm_detail_chunk_plan(B, (int64_t)RS * (int64_t)sizeof(double), m->tune.boot_chunks, m->tune.boot_ratio, parts);
+    if (!d_idx && !m->nonmetric && !m->moments_out)
+        nparts = plspm_detail_chunk_plan(B, (int64_t)RS * (int64_t)sizeof(double), m->tune.boot_chunks, m->tune.boot_ratio, parts, m->tune.boot_align > 0 ? m->tune.boot_align : plspm_detail_round_units(m));
     if (nparts > 1) {
         if (!m->dl) HIPCHK(m, plspm_stream_acquire(&m->dl));
         for (int k = 0; k < nparts; ++k)

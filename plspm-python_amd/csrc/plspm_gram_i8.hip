@@ -482,6 +482,17 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     return 0;
 }
 
+int64_t plspm_detail_round_units(plspm_model* m) {
+    if (!m || !m->d_Xa || m->nonmetric || m->n_ind || choose_gram_path(m, (int64_t)1 << 20) != 2) return 64;
+    if (hipSetDevice(m->device) != hipSuccess || prepare_zs(m)) return 64;            // (the plane count decides the tile height; built once per upload anyway)
+    const int S = m->zs_S;
+    if ((S != 6 && S != 7) || m->zs_ind || m->tune.i8_priv == 0) return 64;
+    if (!m->cu_count) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, m->device) != hipSuccess) return 64; m->cu_count = pr.multiProcessorCount; }
+    const int cus = std::max(8, m->tune.i8_cus > 0 ? std::min(m->tune.i8_cus, m->cu_count) : m->cu_count);
+    const int ntx = std::max(1, m->zs_npg / 2), tall = (S == 6 ? 20 : 16) * 16;
+    return (int64_t)std::max(1, cus / ntx) * tall;
+}
+
 extern "C" {
 
 int plspm_bootstrap_prepare(plspm_model_t* m) {

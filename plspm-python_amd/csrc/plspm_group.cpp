@@ -174,6 +174,8 @@ struct plspm_group {
     int last_K = 1;
     int64_t sub_B[kBootChunksMax] = {}, sub_first[kBootChunksMax] = {}, sub_cap[kBootChunksMax] = {}, sub_off[kBootChunksMax] = {};
     int opt_chunks = 0, opt_ratio = 50;            // plspm_group_set_option
+    int opt_align = 0;                             // "chunk_align": 0 = whole rounds of the device (plspm_detail_round_units), n > 0 = multiples of n replicates per rank
+    int opt_skip_exchange = 0;                     // diagnostics (include/plspm_hip_test.h): the step without its exchange
     int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
     int peers_rc = 0;
     double t_shards_ms = 0.0, t_exchange_ms = 0.0;  // host time of the last plspm_group_bootstrap: shard enqueue / exchange enqueue
@@ -256,13 +258,15 @@ static void group_release(plspm_group* g) {
 // of ALL its handles first, so that nothing dangles; later calls on the group report PLSPM_E_STATE.
 void plspm_detail_group_orphan(void* group) { if (group) group_release((plspm_group*)group); }
 
-int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts) {
+int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts, int64_t align) {
     parts[0] = B;
     if (B < 1) return 1;
+    if (align < 1) align = 64;
     int n = chunks_opt;
     if (n <= 0) n = (B * bytes_per_unit < ((int64_t)2 << 20)) ? 1 : 3;           // automatic: nothing worth hiding below 2 MiB of results
     n = std::min(n, kBootChunksMax);
-    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, B / 512));                 // no part below 512 units (a sub-batch's fixed costs: three launches + an event)
+    // no part below 512 units (a sub-batch's fixed costs: three launches + an event) -- nor below one alignment unit (a round of the machine)
+    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, (B + align / 2) / std::max<int64_t>(512, align)));
     if (n <= 1) return 1;
     const double q = std::min(100, std::max(10, ratio_pct)) / 100.0;
     double wsum = 0.0, w = 1.0;
@@ -272,8 +276,8 @@ int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, i
     int k = 0;
     for (; k < n - 1; ++k, w *= q) {
         int64_t c = (int64_t)((double)B * w / wsum + 0.5);
-        c = std::max<int64_t>(64, (c + 32) / 64 * 64);
-        if (left - c < 64) break;                                                  // the remainder would be no part of its own
+        c = std::max<int64_t>(align, (c + align / 2) / align * align);
+        if (left - c < std::min<int64_t>(align, 64)) break;                        // the remainder would be no part of its own
         parts[k] = c; left -= c;
     }
     parts[k] = left;
@@ -502,7 +506,8 @@ static int plan_sub_batches(const plspm_group* g, int64_t B, int RS, int64_t* su
     const int64_t per_rank = (B + g->nranks - 1) / g->nranks;
     int64_t parts[kBootChunksMax];
     // (one rank: nothing travels, nothing to hide -- unless sub-batches are asked for by number)
-    const int K = (g->nranks == 1 && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts);
+    const int K = (g->nranks == 1 && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts,
+                                                                                       g->opt_align > 0 ? g->opt_align : plspm_detail_round_units(g->loc[0].m));
     int64_t at = 0;
     int n = 0;
     for (int k = 0; k < K && at < B; ++k) {
@@ -513,15 +518,32 @@ static int plan_sub_batches(const plspm_group* g, int64_t B, int RS, int64_t* su
     return n;
 }
 
-int plspm_chunk_plan(int64_t B, int64_t bytes_per_unit, int32_t chunks, int32_t ratio_pct, int64_t* parts) {
-    if (!parts || B < 1 || bytes_per_unit < 1 || chunks < 0 || chunks > kBootChunksMax || ratio_pct < 10 || ratio_pct > 100) return PLSPM_E_ARG > 0 ? -PLSPM_E_ARG : PLSPM_E_ARG;
-    return plspm_detail_chunk_plan(B, bytes_per_unit, chunks, ratio_pct, parts);
+int plspm_chunk_plan(int64_t B, int64_t bytes_per_unit, int32_t chunks, int32_t ratio_pct, int64_t align, int64_t* parts) {
+    if (!parts || B < 1 || bytes_per_unit < 1 || chunks < 0 || chunks > kBootChunksMax || ratio_pct < 10 || ratio_pct > 100 || align < 0) return -PLSPM_E_ARG;
+    return plspm_detail_chunk_plan(B, bytes_per_unit, chunks, ratio_pct, parts, align);
 }
 
 int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value) {
     if (!g || !key) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: bad arguments");
     const std::string k(key);
     if (k == "chunks") { if (value < 0 || value > kBootChunksMax) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunks in 0 .. 8"); g->opt_chunks = value; }
+    else if (k == "chunk_align") { if (value < 0 || value > (1 << 20)) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunk_align in 0 .. 2^20"); g->opt_align = value; }
+    else if (k == "skip_exchange") { if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: skip_exchange 0 | 1"); g->opt_skip_exchange = value; }
+    else if (k == "events_device_scope") {
+        if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: events_device_scope 0 | 1");
+        int rc = sync_all(g);
+        if (rc) return rc;
+        for (auto& l : g->loc) {
+            GHIP(g, hipSetDevice(l.m->device));
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned flags = hipEventDisableTiming | (value ? hipEventReleaseToDevice : 0u);
+                hipEventDestroy(l.gathered[s2]); l.gathered[s2] = nullptr;
+                GHIP(g, hipEventCreateWithFlags(&l.gathered[s2], flags));
+                for (auto& e : l.computed[s2]) { hipEventDestroy(e); e = nullptr; GHIP(g, hipEventCreateWithFlags(&e, flags)); }
+            }
+        }
+        g->pending[0] = g->pending[1] = false;
+    }
     else if (k == "chunk_ratio") { if (value < 10 || value > 100) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunk_ratio in 10 .. 100"); g->opt_ratio = value; }
     else return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: unknown option '" + k + "'");
     return 0;
@@ -608,7 +630,9 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
     for (int k = 0; k < K; ++k) {
         const size_t sub_doubles = (size_t)sub_cap[k] * RS, sub_bytes = sub_doubles * sizeof(double);
         const size_t soff = (size_t)sub_off[k] * RS, roff = soff * g->nranks;       // (in doubles)
-        if (g->use_rccl) {
+        if (g->opt_skip_exchange) {
+            for (auto& l : g->loc) { hipSetDevice(l.m->device); hipStreamWaitEvent(l.cstream, l.computed[s][k], 0); }
+        } else if (g->use_rccl) {
             const Rccl* r = &g_rccl;
             for (auto& l : g->loc) {
                 hipError_t e = hipSetDevice(l.m->device);

@@ -468,6 +468,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "conv_gy") { if (value < 0 || value > 65535) return bad(); m->tune.conv_gy = value; }
     else if (k == "boot_chunks") { if (value < 0 || value > kBootChunksMax) return bad(); m->tune.boot_chunks = value; }
     else if (k == "boot_ratio") { if (value < 10 || value > 100) return bad(); m->tune.boot_ratio = value; }
+    else if (k == "boot_align") { if (value < 0 || value > (1 << 20)) return bad(); m->tune.boot_align = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
     return 0;
 }
@@ -514,6 +515,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_shape") *value = m->tune.i8_shape;
     else if (k == "boot_chunks") *value = m->tune.boot_chunks;
     else if (k == "boot_ratio") *value = m->tune.boot_ratio;
+    else if (k == "boot_align") *value = m->tune.boot_align;
+    else if (k == "boot_round_units") *value = (int32_t)plspm_detail_round_units(const_cast<plspm_model*>(m));
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else if (k == "build_experiments") {
 #ifdef PLSPM_I8_EXPERIMENTS

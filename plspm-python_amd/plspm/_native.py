@@ -122,7 +122,7 @@ def load():
     lib.plspm_comm_max_channels.argtypes = [vp]
     lib.plspm_group_set_option.argtypes = [vp, ctypes.c_char_p, i32]
     lib.plspm_group_plan.argtypes = [vp, i64, ctypes.POINTER(i32), vp, vp]
-    lib.plspm_chunk_plan.argtypes = [i64, i64, i32, i32, vp]
+    lib.plspm_chunk_plan.argtypes = [i64, i64, i32, i32, i64, vp]
     lib.plspm_comm_destroy.restype = None
     lib.plspm_comm_destroy.argtypes = [vp]
     lib.plspm_comm_size.restype = i32
@@ -184,11 +184,11 @@ def i8_tile_plan(count_tiles, pair_tiles, cus=256, mix=True):
     return bool(rc), tall.value, shrt.value
 
 
-def chunk_plan(B, bytes_per_unit, chunks=0, ratio_pct=60):
+def chunk_plan(B, bytes_per_unit, chunks=0, ratio_pct=60, align=0):
     """Host mirror of the sub-batch planner (plspm_chunk_plan): the sizes of the sub-batches ONE call of B units runs as."""
     lib = load()
     parts = np.zeros(8, dtype=np.int64)
-    n = lib.plspm_chunk_plan(B, bytes_per_unit, chunks, ratio_pct, _ptr(parts))
+    n = lib.plspm_chunk_plan(B, bytes_per_unit, chunks, ratio_pct, align, _ptr(parts))
     if n < 1:
         raise NativeBackendError("plspm_chunk_plan failed (%d)" % n)
     return [int(v) for v in parts[:n]]

@@ -89,12 +89,16 @@ def test_group_call_as_sub_batches_is_bit_identical(nranks, B, chunks):
     comm = _native.NativeComm([0] * nranks)
     group = _native.NativeGroup(comm, models)
     group.set_option("chunks", chunks)
+    units = models[0].get_option("boot_round_units")        # replicates of one round of the device for this model (a small model: thousands)
+    assert units >= 64 and len(group.plan(B)) <= max(1, -(-B // (units * nranks)))      # never more sub-batches than (started) rounds per rank
+    group.set_option("chunk_align", 64)                      # ... so the cuts of this test are asked for in count tiles
     plan = group.plan(B)
     assert plan[0][0] == 0 and sum(c for _, c in plan) == B and all(plan[k][0] + plan[k][1] == plan[k + 1][0] for k in range(len(plan) - 1))
     if chunks:
-        assert len(plan) == chunks, plan
+        assert 2 <= len(plan) <= chunks, plan               # (never more sub-batches than whole rounds of the device per rank)
     elif nranks > 1:
         assert len(plan) >= 2, plan                         # 2,250 records of 1 KB per rank: worth hiding
+    assert all(c % (64 * nranks) == 0 for _, c in plan[:-1]), plan
     for _ in range(3):                                       # both buffer slots, and a slot re-used
         group.bootstrap(B, seed=5, rep_offset=11)
     rows, status, iters = group.rows()

@@ -131,6 +131,7 @@ def test_host_buffer_bootstrap_as_sub_batches_is_bit_identical(B, chunks):
     nm.set_option("boot_chunks", 1)
     ref = nm.bootstrap(B, seed=9, rep_offset=3)
     nm.set_option("boot_chunks", chunks)
+    nm.set_option("boot_align", 64 if chunks else 0)         # forced cuts in count tiles; the automatic one in whole rounds of the device
     out = (np.full((B, nm.row_width), np.nan), np.full(B, -7, dtype=np.int32), np.full(B, -7, dtype=np.int32))
     for _ in range(2):
         got = nm.bootstrap(B, seed=9, rep_offset=3, out=out)

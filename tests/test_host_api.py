@@ -200,23 +200,29 @@ def test_library_exports_every_declared_symbol():
 
 def test_sub_batch_planner_covers_the_call_and_shrinks_geometrically():
     """plspm_chunk_plan (host arithmetic; plspm_bootstrap "boot_chunks", plspm_group_bootstrap "chunks"): ONE call as sub-batches whose
-    transfer hides under the next sub-batch's kernels.  The parts cover B exactly, fall by about the ratio, are multiples of 64 (whole
-    count tiles of the int8 Gram) but for the last, never fall below 64, and small calls -- below 2 MiB of results -- stay in one piece."""
+    transfer hides under the next sub-batch's kernels.  The parts cover B exactly, fall by about the ratio, are multiples of the alignment
+    (64: whole count tiles of the int8 Gram; the library passes the replicates of one ROUND of the device -- 1,280 for the headline model:
+    a part that ends inside a round pays for the whole round) but for the last, and small calls -- below 2 MiB of results -- stay in one piece."""
     rec = 158 * 8
-    assert _native.chunk_plan(5000, rec) == [2560, 1536, 904]                   # the headline batch: 6.3 MB of records, three parts
+    assert _native.chunk_plan(5000, rec) == [2560, 1536, 904]                   # 6.3 MB of records, three parts of whole count tiles
+    assert _native.chunk_plan(5000, rec, align=1280) == [2560, 1280, 1160]      # ... of whole rounds: the headline batch as the library cuts it
+    assert _native.chunk_plan(40000, rec, align=1280) == [20480, 12800, 6720]
+    assert _native.chunk_plan(2500, rec, align=1280) == [1280, 1220]
     assert _native.chunk_plan(5000, rec, chunks=1) == [5000]
     assert _native.chunk_plan(1000, rec) == [1000]                               # 1.26 MB: nothing worth hiding
-    assert _native.chunk_plan(1024, rec, chunks=4) == [576, 448] or len(_native.chunk_plan(1024, rec, chunks=4)) <= 2      # no part below 512 units asked for
-    for B in (1, 63, 64, 65, 511, 1664, 1700, 4999, 5000, 40000, 123457, 1 << 20):
-        for chunks in (0, 1, 2, 3, 5, 8):
-            for ratio in (10, 50, 60, 100):
-                parts = _native.chunk_plan(B, rec, chunks, ratio)
-                assert sum(parts) == B and all(p >= 1 for p in parts), (B, chunks, ratio, parts)
-                assert 1 <= len(parts) <= max(1, chunks if chunks else 3)
-                assert all(p % 64 == 0 for p in parts[:-1])
-                if len(parts) > 1:
-                    assert min(parts) >= 64
-                    assert all(parts[k + 1] <= parts[k] + 64 for k in range(len(parts) - 2)), parts        # falling sizes (the last takes the remainder)
+    assert len(_native.chunk_plan(1024, rec, chunks=4)) <= 2                     # no part below 512 units asked for
+    for align in (0, 64, 320, 1280):
+        a = align or 64
+        for B in (1, 63, 64, 65, 511, 1664, 1700, 4999, 5000, 40000, 123457, 1 << 20):
+            for chunks in (0, 1, 2, 3, 5, 8):
+                for ratio in (10, 50, 60, 100):
+                    parts = _native.chunk_plan(B, rec, chunks, ratio, align)
+                    assert sum(parts) == B and all(p >= 1 for p in parts), (B, chunks, ratio, parts)
+                    assert 1 <= len(parts) <= max(1, chunks if chunks else 3)
+                    assert all(p % a == 0 for p in parts[:-1])
+                    if len(parts) > 1:
+                        assert min(parts) >= 64
+                        assert all(parts[k + 1] <= parts[k] + a for k in range(len(parts) - 2)), parts        # falling sizes (the last takes the remainder)
     # 100 %: equal parts; a steeper ratio makes the first part larger
     eq = _native.chunk_plan(6144, rec, 3, 100)
     assert eq == [2048, 2048, 2048]
