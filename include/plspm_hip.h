@@ -74,11 +74,15 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     on-device draws and explicit index lists alike (a chunk of an index list that carries a multiplicity above 127 takes
  *                     route 1); second stages of HOC pairs work on their first stage's matrices
  *   "i8_slices"       0 | 1 .. 8   digit planes per pair product.  0 (default) = automatic: 6 planes when every pair column of the uploaded data has
- *                     sum|z| >= 256 max|z| -- the worst-case error N 2^-47 max|z| of a replicate's sum is then below the a-priori bound N 2^-53 sum|z|
- *                     of an fp64 accumulation of the same terms, with a factor 4 to spare -- else 7 (>= 53 significant bits of the column
- *                     maximum: correctly rounded sums); and never more planes than carry anything: planes that are identically zero in the
+ *                     sum|z| >= 257 max|z| -- the worst-case error N 2^-47 max|z| of a replicate's sum is then below the a-priori bound N 2^-53 sum|z|
+ *                     of an fp64 accumulation of the same terms, with a factor 4 to spare, even for a replicate that misses the column's largest
+ *                     row -- else 7 (>= 54 significant bits of the column maximum), else -- sum|z| < 2 max|z|: one gross outlier row carries
+ *                     the column, and a replicate without it sums products that are tiny against the scale of the planes -- 8; and never more
+ *                     planes than carry anything: planes that are identically zero in the
  *                     seven-plane decomposition are dropped (0/1 indicator columns: ONE plane, bit-identical sums).  Read-only "last_i8_slices" /
  *                     "last_i8_ratio" report the choice and floor(min sum / max)
+ *   "i8_min_slices"   0 (default) | 6 .. 8   the automatic choice, but never fewer planes (Plspm(precision="strict"): 7 -- the rate bench.py reports
+ *                     as `value_strict`)
  *   "i8_min_batch"    auto mode takes the int8 route from this many replicates per call (default 1: always -- the route must not
  *                     depend on how a job is sharded, or shards of different size would differ in the last bits)
  * Int8 Gram kernels (all forms give bit-identical matrices: exact int32 sums)
@@ -389,8 +393,8 @@ int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* 
  * ONE call hides its merge (round 5): the call runs as up to three SUB-BATCHES -- consecutive ranges of the replicate ids, each sharded over the
  * ranks like a call of its own (plspm_group_plan) -- and the all-gather of sub-batch k runs on the gather streams beside the shard kernels of
  * sub-batch k + 1; only the last, smallest gather is exposed.  Results do not depend on the cut (Philox stream keyed by (seed, replicate id)).
- * Options (plspm_group_set_option): "chunks" 0 (default: automatic -- one sub-batch below 2 MiB of records per rank or on a one-rank group,
- * else up to three, sizes falling by "chunk_ratio" percent) | 1 .. 8 sub-batches -- a caller that issues calls back to back (bench.py's
+ * Options (plspm_group_set_option): "chunks" 0 (default: automatic -- one sub-batch below 2 MiB of records per rank, on a one-rank group and among
+ * ranks that share a device, else up to three, sizes falling by "chunk_ratio" percent) | 1 .. 8 sub-batches -- a caller that issues calls back to back (bench.py's
  * step loop) sets 1: the gather of call k then overlaps the kernels of call k + 1 anyway; "chunk_ratio" 10 .. 100 (default 50); "chunk_align"
  * 0 (default: every sub-batch but the last fills whole ROUNDS of the device per rank -- a part that ends inside a round of Gram tiles pays for
  * the whole round; models whose round holds more replicates than the call has stay in one piece) | n: multiples of n replicates per rank. */

@@ -325,3 +325,269 @@ gram_i8p_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int 
         else run(std::integral_constant<int, MTW>{});
     } else run(std::integral_constant<int, MTW>{});
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gram_i8pp_kernel (round 5): the same product, the same tiles, the same k-step -- as ONE PERSISTENT workgroup per CU.
+//
+// The tiled launch pays a fixed cost per tile that the MFMA-only probe prices at ~8 us (profiles/r04_pmc.md: 0.2965 ms for 0.253-0.266 ms of
+// pipe time, four rounds of tiles per CU): the dispatch of the next workgroup onto the CU, its cold first loads (two count fragments sets
+// + three LDS stages before the first MFMA), the epilogue.  Here a workgroup keeps its CU for the whole launch:
+//   * tiles come from the SAME per-XCD lists (tall rows first, then short ones; XCD = blockIdx & 7), handed out by one atomic counter per
+//     XCD: workgroup j starts with slot j and grabs the next free slot while it works -- exactly the order in which the dispatcher hands
+//     the tiled launch's workgroups to the CU that is free first (list scheduling), so a launch that shares the chip with another stream's
+//     kernels still balances itself; the last workgroup of an XCD to leave resets the counters (no host bookkeeping between launches);
+//   * the NEXT tile's prologue -- count fragments of k-blocks 0 / 1, digit blocks of k-blocks 0 .. 2 -- is issued IN FRONT of this tile's
+//     epilogue (the accumulators are the only live state; the fragment registers and the LDS ring are free once the k-loop's last wait and
+//     a workgroup barrier have passed), so its memory latency runs under the 40 stores + ~3,000 fp64 operations per lane of the epilogue;
+//   * tall and short tiles are two PHASES of a workgroup (two instantiations of loop + epilogue, as in the tiled kernel): a workgroup walks
+//     tall tiles until the counter hands it a short one, then short tiles; only the tile at the phase change starts cold.
+// Exact integer sums, same epilogue arithmetic: matrices and records are bit-identical to the tiled launch ("i8_persist" 0).
+struct GramI8PPCtl { unsigned next[8]; unsigned done[8]; };      // per XCD: slots handed out beyond the first of every workgroup / workgroups that left
+
+template <int S, int MTW, int VAR = 0, bool SHORTS = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gram_i8pp_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int KB, int MT, int NT, int ntx, int nty, const int* __restrict__ pair_dst,
+                 const double* __restrict__ pair_scale, int npair, long nrep, double* __restrict__ gram, long psize, int nty_short, GramI8PPCtl* __restrict__ ctl) {
+    using G = GramI8P<S, MTW, VAR>;
+    static_assert(!G::BREG && !G::PAIRB && G::SCHED != 0 && G::ABL == 0, "the persistent form exists for the release schedule");
+    constexpr int NB = G::NB, RT = G::RT;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, wpx = gridDim.x >> 3;          // workgroups per XCD
+    const int ntall = SHORTS ? nty - nty_short : nty;
+    const int tper = (ntx * ntall + 7) >> 3, sper = SHORTS ? (ntx * nty_short + 7) >> 3 : 0, per_all = tper + sper;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_raw);
+    const unsigned lds_word = lds0 + (unsigned)G::LDS_BYTES;       // the next slot of this workgroup, written by wave 0
+    const unsigned voff = (unsigned)lane * 16u;
+    const long binc = (long)NT * 1024, ainc = (long)MT * 1024;
+    auto sgpr64 = [](const void* p) {
+        const unsigned long long b = (unsigned long long)p;
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+    };
+    // slot -> tile of its list: pair tile tx, first count tile ct0 (the enumeration of gram_i8p_kernel); false: the slot holds no tile (padding of
+    // the eight ranges)
+    auto decode = [&](int slot, bool shortT, int& tx, int& ct0) -> bool {
+        const int rows = shortT ? nty_short : ntall, s = shortT ? slot - tper : slot;
+        const int total = ntx * rows, per = (total + 7) >> 3;
+        const int gidx = xcd * per + s;
+        if (s >= per || gidx >= total) return false;
+        const int srow = 4 * ntx;
+        const int sr = __builtin_amdgcn_readfirstlane(gidx / srow), rem = gidx - sr * srow;
+        const int nr = min(4, rows - 4 * sr);
+        tx = __builtin_amdgcn_readfirstlane(rem / nr);
+        const int tyl = 4 * sr + (rem - tx * nr);
+        ct0 = shortT ? ntall * RT + tyl * G::RTS : tyl * RT;
+        return true;
+    };
+
+    // One phase: tiles of one height, from `slot` on, while the counter hands out slots below `slot_end`.  Returns the first slot it was handed
+    // that is not its kind (>= slot_end).
+    auto phase = [&](auto mwc, int slot, const bool shortT, const int slot_end) -> int {
+        constexpr int MW = decltype(mwc)::value;
+        using K = GramI8PStep<S, MW, G::SCHED>;
+        int tx = 0, ct0 = 0;
+        // (slots of the padding hold no tile: skip them without touching the counter's order -- at most seven per list)
+        const char* abase;
+        const char* bsrc;
+#define GI8P_ALOAD(dst, t) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sgpr64(abase)), "i"(((t) - 2) * 1024) : "memory")
+#define GI8P_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(off))
+#define GI8P_MFMA(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define GI8P_MFMA0(c, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b))
+        const int b0 = min(wave * K::PERB, NB - K::PERB);      // the wave's consecutive digit blocks
+        const unsigned bdst0 = lds0 + (unsigned)b0 * 1024u;
+        auto dma_one = [&](int i, unsigned stage_off) {
+            const unsigned long long ub = sgpr64(bsrc);
+            if (i == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(bdst0 + stage_off) : "memory");
+#pragma unroll
+            for (int k = 0; k < K::PERB; ++k)
+                if (k == i) asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(ub), "i"(k * 1024) : "memory");
+        };
+        i32x4 acc[MW][NB];
+        i32x4 fa0[MW], fa1[MW], fb0[NB], fb1[NB];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) { fa0[i] = (i32x4){0, 0, 0, 0}; fa1[i] = fa0[i]; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { fb0[i] = (i32x4){0, 0, 0, 0}; fb1[i] = fb0[i]; }
+        // prologue of tile (ptx, pct0): counts of k-blocks 0 and 1 into the two sets, digit blocks of k-blocks 0 .. 2 into the three stages;
+        // leaves abase at k-block 1 and bsrc at k-block 3 (what the k-loop expects)
+        auto issue_prologue = [&](int ptx, int pct0) {
+            abase = (const char*)(Cd + ((long)(pct0 + wave * MW) + 2) * 64);
+            bsrc = (const char*)(Zs + ((long)ptx * NB + b0) * 64);
+#pragma unroll
+            for (int t = 0; t < MW; ++t) GI8P_ALOAD(fa0[t], t);
+            abase += ainc;
+#pragma unroll
+            for (int t = 0; t < MW; ++t) GI8P_ALOAD(fa1[t], t);
+#pragma unroll
+            for (int st = 0; st < G::AHEAD; ++st) {
+#pragma unroll
+                for (int i = 0; i < K::PERB; ++i) dma_one(i, st * G::STAGE_BYTES);
+                bsrc += binc;
+            }
+        };
+        const unsigned fbase = lds0 + voff;
+        // FIRST: the k-step that opens a tile -- its MFMAs take the constant 0 as the accumulator input ("=a": the accumulators are DEFINED here, so
+        // nothing of the previous tile's sums is carried round the tile loop and no zeroing pass is needed)
+        auto step = [&](auto first, i32x4 (&xa)[MW], i32x4 (&xb)[NB], i32x4 (&ya)[MW], i32x4 (&yb)[NB], unsigned Roff, unsigned Woff) {
+            constexpr bool FIRST = decltype(first)::value;
+            const unsigned rb = fbase + Roff;
+            auto fill = [&](int m) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+                    if (m == K::rslot(r)) GI8P_DSREAD(yb[r], rb, r * 1024);
+                if (m == K::aslot(0)) { GI8P_ALOAD(ya[MW - 1], MW - 1); abase += ainc; }
+#pragma unroll
+                for (int i = 1; i < MW; ++i)
+                    if (m == K::aslot(i)) GI8P_ALOAD(xa[i - 1], i - 1);
+#pragma unroll
+                for (int i = 0; i < K::PERB; ++i)
+                    if (m == K::dslot(i)) dma_one(i, Woff);
+            };
+            constexpr int M0 = NB * (MW - 1);
+#pragma unroll
+            for (int mt = 0; mt < MW - 1; ++mt)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if constexpr (FIRST) GI8P_MFMA0(acc[mt][j], xa[mt], xb[j]); else GI8P_MFMA(acc[mt][j], xa[mt], xb[j]);
+                    fill(mt * NB + j);
+                }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MW + K::PERB - 1 + K::vm_before(M0)) : "memory");
+            asm volatile("" : "+v"(xa[MW - 1]));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if constexpr (FIRST) GI8P_MFMA0(acc[MW - 1][j], xa[MW - 1], xb[j]); else GI8P_MFMA(acc[MW - 1][j], xa[MW - 1], xb[j]);
+                fill(M0 + j);
+            }
+            bsrc += binc;
+        };
+        auto wait_barrier = [&](i32x4 (&xa)[MW], i32x4 (&xb)[NB]) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MW + K::PERB) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < MW - 1; ++i) asm volatile("" : "+v"(xa[i]));
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(xb[i]));
+            asm volatile("s_barrier" ::: "memory");
+        };
+        auto next_stage = [](unsigned st) { return (st == (G::NS - 1) * G::STAGE_BYTES) ? 0u : st + G::STAGE_BYTES; };
+        // the epilogue of tile (etx, ect0): gram_i8p_kernel's, and the accumulators zeroed for the next tile on the way
+        // (the tile's output slots and scales arrive as arguments: they are loaded with the tile's prologue -- a load of the compiler's own in here
+        //  would make it wait for vmcnt(0), i.e. for the NEXT tile's prologue, at the head of the epilogue)
+        auto epilogue = [&](int etx, int ect0, const long (&dst)[2], const double (&scl)[2]) {
+            const long rep0 = (long)(ect0 + wave * MW) * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+                const int j = (etx * 2 + pg) * 16 + (lane & 15);
+                if (j >= npair) continue;
+                const long dstj = dst[pg];
+                const double sc = scl[pg];
+                double* gp = gram + rep0 * psize + dstj;
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (rep0 + mt * 16 + reg < nrep) {
+                            double v = (double)acc[mt][pg * S][reg];
+#pragma unroll
+                            for (int s = 1; s < S; ++s) v = fma((double)acc[mt][pg * S + s][reg], (double)(1ll << (8 * s)), v);
+                            *gp = v * sc;
+                        }
+                        gp += psize;
+                        asm volatile("" : "+v"(gp)::"memory");
+                    }
+                    gp += 12 * psize;
+                }
+            }
+        };
+
+        // the first tile of the phase starts cold
+        while (slot < slot_end && !decode(slot, shortT, tx, ct0)) slot = slot_end;      // (a padding slot can only be the list's tail: this workgroup has no tile of this kind)
+        if (slot >= slot_end) return slot;
+        issue_prologue(tx, ct0);
+        for (;;) {
+            // this tile's output slots / scales (clamped index instead of a branch: no control flow while the prologue's loads are in flight)
+            long dst[2];
+            double scl[2];
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+                const int jj = min((tx * 2 + pg) * 16 + (lane & 15), npair - 1);
+                dst[pg] = pair_dst[jj];
+                scl[pg] = pair_scale[jj];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(scl[0]), "+v"(scl[1]));      // (consumed here: the compiler's wait for them sits beside ours)
+            // the slot after this one: one atomic per workgroup and tile, from asm (the compiler must not wait for it: its round trip -- a microsecond
+            // or two at device scope -- runs under the first k-steps; wave 0's counted waits there only become conservative by one older operation).
+            // The result is complete at the second k-step's wait and is published to the other waves behind the peeled pair.
+            unsigned grabbed = 0u;
+            if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(grabbed) : "v"(0u), "v"(1u), "s"(&ctl->next[xcd]) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+            // (the digit fragment sets are DEFINED here ("=v"): their registers carry nothing from the previous tile, so they are free during its
+            //  epilogue -- with "+v" the compiler keeps 96 dead registers alive across it and spills accumulators instead)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb0[j]) : "v"(fbase), "i"(j * 1024));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) asm volatile("" : "=v"(fb1[j]));
+            unsigned W = (G::AHEAD % G::NS) * G::STAGE_BYTES, R = G::STAGE_BYTES;
+            // (KB is even and >= 2: the first pair of k-steps is peeled, its first step defines the accumulators)
+            wait_barrier(fa0, fb0);
+            step(std::true_type{}, fa0, fb0, fa1, fb1, R, W);
+            W = next_stage(W); R = next_stage(R);
+            wait_barrier(fa1, fb1);
+            step(std::false_type{}, fa1, fb1, fa0, fb0, R, W);
+            W = next_stage(W); R = next_stage(R);
+            if (tid == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(lds_word), "v"(grabbed + (unsigned)wpx) : "memory");
+            for (int kb = 2; kb < KB; kb += 2) {
+                wait_barrier(fa0, fb0);
+                step(std::false_type{}, fa0, fb0, fa1, fb1, R, W);
+                W = next_stage(W); R = next_stage(R);
+                wait_barrier(fa1, fb1);
+                step(std::false_type{}, fa1, fb1, fa0, fb0, R, W);
+                W = next_stage(W); R = next_stage(R);
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // (the accumulators are named here so that no read of them can be scheduled above the wait states of the last MFMAs)
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) asm volatile("" : "+a"(acc[mt][j]));
+            asm volatile("s_barrier" ::: "memory");            // every wave is done with the LDS ring; wave 0 has published the next slot
+            unsigned nxt_v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nxt_v) : "v"(lds_word) : "memory");
+            const int nxt = __builtin_amdgcn_readfirstlane((int)nxt_v);
+            int ntx2 = 0, nct0 = 0;
+            const bool more = nxt < slot_end && decode(nxt, shortT, ntx2, nct0);
+            if (more) {
+                issue_prologue(ntx2, nct0);                    // under the epilogue: loads into the fragment sets, LDS-DMA into the ring
+                epilogue(tx, ct0, dst, scl);
+                tx = ntx2; ct0 = nct0;
+            } else {
+                epilogue(tx, ct0, dst, scl);
+                return nxt;
+            }
+        }
+#undef GI8P_ALOAD
+#undef GI8P_DSREAD
+#undef GI8P_MFMA
+#undef GI8P_MFMA0
+    };
+
+    int slot = blockIdx.x >> 3;
+    if (slot < per_all) {
+        if (slot < tper) slot = phase(std::integral_constant<int, MTW>{}, slot, false, tper);
+        if constexpr (SHORTS) {
+            // (a slot of the tall list's padding sends the workgroup on to the short list: ask the counter for a fresh slot there)
+            if (slot < per_all) slot = phase(std::integral_constant<int, MTW - 1>{}, slot, true, per_all);
+        }
+    }
+    // the last workgroup of the XCD to leave resets its counters: the next launch on this handle starts from zero
+    if (tid == 0) {
+        const unsigned left = __hip_atomic_fetch_add(&ctl->done[xcd], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (unsigned)wpx - 1u) {
+            __hip_atomic_store(&ctl->next[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->done[xcd], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}

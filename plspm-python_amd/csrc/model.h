@@ -87,10 +87,10 @@ struct plspm_model {
     bool err_clean = false;       // the device error word is zero and no call since could have raised it (plspm_detail_bootstrap)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60, boot_align = 0; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60, boot_align = 0, i8_persist = 0, i8_min_slices = 0, i8_nostore = 0; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
-    Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat, codes;
+    Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat, codes, pp_ctl;      // pp_ctl: tile counters of the persistent Gram (kernels_gram_i8p.h GramI8PPCtl)
     // set_option("resample_aux", 1..3): the int8 counts are drawn on a second stream (1 lowest / 2 default / 3 highest priority) into
     // alternating buffers, so that the draws of call k+1 -- enqueued while the Gram / solver of call k still run -- take the CUs those
     // leave idle (the Gram's last, partial round of workgroups first of all); the Gram waits for its counts by event.  Measured
@@ -117,6 +117,7 @@ struct plspm_model {
     double* moments_out = nullptr; // plspm_bootstrap_moments: dense moment matrices go here and the solver is skipped
     int last_gram_path = 0;       // 1 fp64 MFMA, 2 int8 digit planes: what the last bootstrap call used (plspm_model_get_info)
     int last_i8_dma = 0;          // 1 global_load_lds, 2 buffer_load ... lds: the LDS-DMA form of the last int8 Gram launch
+    int last_i8_persist = 0;      // 1: ... as one persistent workgroup per CU (gram_i8pp_kernel)
     int last_i8_priv = 0;         // 1: the last int8 Gram launch was gram_i8p_kernel (private count fragments)
     int last_i8_rt = 0;           // count tiles (16 replicates each) per workgroup of the last int8 Gram launch: 16, 20 or 8
     bool mix_valid = false, mix_wide = false; long mix_key[4] = {0, 0, 0, 0}; int mix_tall = 0, mix_short = 0;      // plspm_gram_i8.hip i8_mix_plan: the last tile-row cut
@@ -132,6 +133,7 @@ struct plspm_model {
     enum { BLOB_MODEL = 0, BLOB_CATEGORICAL = 1, BLOB_HOC = 2, BLOB_COUNT = 3 };
     void* blobs[BLOB_COUNT] = {nullptr, nullptr, nullptr};     // descriptor blocks, one per call site (several small arrays uploaded as one: plspm_hip.hip upload_blob)
     void* group = nullptr;        // the plspm_group this handle currently belongs to (plspm_group.cpp)
+    hipEvent_t stop_event = nullptr;   // set by a caller of plspm_detail_bootstrap: the LAST kernel of a one-chunk metric batch signals it on completion (taken = reset to null)
     // plspm_bootstrap as sub-batches (plspm_bootstrap.hip): the copy stream the records of sub-batch k leave on while sub-batch k + 1 computes,
     // one event per sub-batch
     hipStream_t dl = nullptr;

@@ -81,8 +81,11 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if (!m->err_clean || may_raise) HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
     m->err_clean = !may_raise;
     double* const gram_buf = (double*)m->gram.p;
+    hipEvent_t parked_stop = m->stop_event;
+    m->stop_event = nullptr;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = std::min<int64_t>(chunk, B - b0);
+        if (b0 + nb >= B) m->stop_event = parked_stop;       // the last chunk's solver launch may signal the caller's event
         bool f64_gram = gpath == 1;
         const void* cd8 = nullptr;
         int cd8_MT = 0;
@@ -144,6 +147,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if (rows_out == (double*)m->rows.p) m->rows_B = B;
     return 0;
 }
+// (m->stop_event: only the last chunk's solver launch may take it -- plspm_detail_bootstrap parks it while earlier chunks run)
 
 static int fetch_segments(plspm_model* m, hipStream_t cs, const double* d_records, int32_t stride, const FetchSeg* segs, int nsegs, int64_t B_total, double* out, int32_t* status,
                           int32_t* iters);
@@ -190,7 +194,7 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     m->rows_B = 0;
     if ((rc = ensure(m, m->rows, (size_t)B * RS * sizeof(double)))) return rc;
     double* const rows = (double*)m->rows.p;
-    int* h_err = (int*)m->h_flag + 8;
+    int* h_err = (int*)m->h_flag + 10;                   // (+8: plspm_bootstrap_fetch, +9: run_gram_i8's look at the multiplicity flag of an explicit index list)
     h_err[0] = h_err[1] = 0;
     FetchSeg segs[kBootChunksMax];
     int64_t b0 = 0;

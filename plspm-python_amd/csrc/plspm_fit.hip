@@ -1,6 +1,7 @@
 // plspm_fit.hip -- host side, part 2: the fp64 MFMA Gram launches, the metric solvers, the single fit (plspm_fit) and the operator seam
 // (plspm_op_*).  Kernels: kernels_gram.h, kernels_solver.h, kernels_scores.h.  (The non-metric iteration: plspm_nonmetric.hip.)
 #include "host_internal.h"
+#include <hip/hip_ext.h>
 
 #include "wave_ops.h"
 #include "device_exec.h"
@@ -158,8 +159,12 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         // one wave per problem with fixed lane roles (solver_wave.h): at most 64 MVs and 8 LVs; Mode-B blocks keep their inverses behind the workspace
         const size_t lds = (size_t)wave_ws_doubles<8>(m->n_chol) * sizeof(double);
         ProfScope ps(m, PLSPM_K_SOLVER);
-        if (m->n_chol > 0) hipLaunchKernelGGL((solver_wave_kernel<8, true>), dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
-        else hipLaunchKernelGGL((solver_wave_kernel<8, false>), dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        // (a caller that wants an event behind this batch -- plspm_group.cpp: the `computed` event its collective waits for -- hands it over as the
+        //  launch's own completion signal: a separate hipEventRecord is one more packet the queue drains the device for, ~5 us of every step)
+        hipEvent_t stop = m->stop_event;
+        m->stop_event = nullptr;
+        if (m->n_chol > 0) hipExtLaunchKernelGGL((solver_wave_kernel<8, true>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        else hipExtLaunchKernelGGL((solver_wave_kernel<8, false>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 3;
     } else if (dense) {
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);

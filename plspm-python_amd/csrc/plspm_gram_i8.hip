@@ -60,14 +60,19 @@ static int choose_slices(plspm_model* m, const unsigned long long* h, long npair
         worst = std::min(worst, sum / zmax);
     }
     m->zs_ratio = worst;
-    int S = worst >= 256.0 ? 6 : 7;
+    // (round 5: EIGHT planes when some column's sum barely exceeds its largest product -- sum < 2 max: one gross outlier row carries the column.  A
+    //  replicate that does not draw that row sums products that are tiny against the column maximum the planes are scaled to; seven planes then
+    //  leave ~1e-14 of ITS moment (measured: tests/test_gpu_gram_i8.py, a 900-sigma cell), eight stay below fp64's own rounding.  Same a-priori
+    //  argument as for six / seven with the dominant row taken out of the sum: sum - max >= 2^(56 - 8S) max.)
+    int S = worst >= 257.0 ? 6 : (worst >= 2.0 ? 7 : 8);
+    if (m->tune.i8_min_slices > S) S = m->tune.i8_min_slices;              // "i8_min_slices": the automatic choice, but never fewer (Plspm(precision="strict"): 7)
     // planes that would be identically zero in the seven-plane decomposition carry nothing: dropping them changes no sum
     int zero_planes = 0;
     if (worst > 0.0) {
         zero_planes = 6;
         if (any) { int tz = 0; while (!((any >> tz) & 1ull)) ++tz; zero_planes = std::min(6, tz / 8); }
     }
-    S = std::min(S, 7 - zero_planes);
+    if (zero_planes > 0) S = std::min(S, 7 - zero_planes);                   // (data on a coarse binary grid are EXACT on fewer planes, whatever the rule above asked for)
     if (m->tune.i8_shape == 32) S = std::max(S, 5);                            // (the 32x32x32 layout is instantiated for 5 .. 8 planes)
     *S_out = S;
     return 0;
@@ -385,8 +390,41 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
         auto kfn = nty_short ? gram_i8p_kernel<SS, MM, VV, true> : gram_i8p_kernel<SS, MM, VV, false>;                                       \
         if ((rc = allow_lds(m, (const void*)kfn, lds_bytes))) return rc;                                                                     \
         hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * per)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p,                               \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, nty_short); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, nb_launch, out, out_stride, nty_short); \
     }
+    // round 5: the same tiles on ONE persistent workgroup per CU (gram_i8pp_kernel: tiles from a per-XCD counter, the next tile's prologue in front
+    // of this tile's epilogue; "i8_persist" 0: the tiled launch of round 4, kept as the A/B reference)
+#define GI8PP(SS, MM)                                                                                                                        \
+    {                                                                                                                                        \
+        const size_t lds_bytes = GramI8P<SS, MM, 64>::LDS_BYTES + 64;                                                                        \
+        auto kfn = nty_short ? gram_i8pp_kernel<SS, MM, 64, true> : gram_i8pp_kernel<SS, MM, 64, false>;                                     \
+        if ((rc = allow_lds(m, (const void*)kfn, lds_bytes))) return rc;                                                                     \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(8 * pp_wgs)), dim3(256), lds_bytes, m->stream, (const uint4*)cd.p,                            \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, (const double*)m->pair_scale.p, m->zs_npair, nb_launch, out, out_stride, nty_short, \
+                           (GramI8PPCtl*)m->pp_ctl.p);                                                                                       \
+    }
+#ifdef PLSPM_I8_EXPERIMENTS
+    // timing probe (results are garbage): "i8_nostore" 1 launches both forms of the private-count kernel with nrep = 0 -- every epilogue store (and the
+    // fp64 recombination in front of it) is skipped; tools/persist_ab.py prices the epilogue of the tiled and of the persistent form with it
+    const long nb_launch = m->tune.i8_nostore ? 0 : (long)nb;
+#else
+    const long nb_launch = (long)nb;
+#endif
+    const bool persist = priv && m->tune.i8_persist != 0 && (m->tune.i8_variant < 0 || m->tune.i8_variant == 64);
+    int pp_wgs = 0;
+    if (persist) {
+        if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
+        const int cus = std::max(8, m->tune.i8_cus > 0 ? std::min(m->tune.i8_cus, m->cu_count) : m->cu_count);
+        pp_wgs = std::max(1, std::min(cus / 8, per));                       // one workgroup per CU of an XCD, never more than the XCD has tiles
+        if (!m->pp_ctl.p) {
+            if ((rc = ensure(m, m->pp_ctl, sizeof(GramI8PPCtl)))) return rc;
+            HIPCHK(m, hipMemsetAsync(m->pp_ctl.p, 0, sizeof(GramI8PPCtl), m->stream));      // (once: the kernel leaves the counters at zero)
+        }
+    }
+    m->last_i8_persist = persist ? 1 : 0;
+    if (persist) {
+        if (S == 6) GI8PP(6, 5) else GI8PP(7, 4)
+    } else
     if (priv) {
 #define GI8PX(VV) case VV: if (S == 6) GI8P(6, 5, VV) else GI8P(7, 4, VV) break;
 #ifdef PLSPM_I8_EXPERIMENTS

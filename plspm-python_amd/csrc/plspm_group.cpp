@@ -175,6 +175,7 @@ struct plspm_group {
     int64_t sub_B[kBootChunksMax] = {}, sub_first[kBootChunksMax] = {}, sub_cap[kBootChunksMax] = {}, sub_off[kBootChunksMax] = {};
     int opt_chunks = 0, opt_ratio = 50;            // plspm_group_set_option
     int opt_align = 0;                             // "chunk_align": 0 = whole rounds of the device (plspm_detail_round_units), n > 0 = multiples of n replicates per rank
+    int opt_lean_events = 1;                       // "lean_events": no wait packet for an event that has fired, `computed` signalled by the shard's last kernel
     int opt_skip_exchange = 0;                     // diagnostics (include/plspm_hip_test.h): the step without its exchange
     int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
     int peers_rc = 0;
@@ -505,8 +506,9 @@ int plspm_group_sync(plspm_group_t* g) {
 static int plan_sub_batches(const plspm_group* g, int64_t B, int RS, int64_t* sub_first, int64_t* sub_B) {
     const int64_t per_rank = (B + g->nranks - 1) / g->nranks;
     int64_t parts[kBootChunksMax];
-    // (one rank: nothing travels, nothing to hide -- unless sub-batches are asked for by number)
-    const int K = (g->nranks == 1 && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts,
+    // (one rank, or ranks that share a device -- one copy launch of microseconds: nothing travels, nothing to hide; unless sub-batches are asked for by number)
+    const bool nothing_to_hide = g->nranks == 1 || (g->comm && g->comm->transport == 3);
+    const int K = (nothing_to_hide && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts,
                                                                                        g->opt_align > 0 ? g->opt_align : plspm_detail_round_units(g->loc[0].m));
     int64_t at = 0;
     int n = 0;
@@ -528,6 +530,7 @@ int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value) {
     const std::string k(key);
     if (k == "chunks") { if (value < 0 || value > kBootChunksMax) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunks in 0 .. 8"); g->opt_chunks = value; }
     else if (k == "chunk_align") { if (value < 0 || value > (1 << 20)) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunk_align in 0 .. 2^20"); g->opt_align = value; }
+    else if (k == "lean_events") { if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: lean_events 0 | 1"); g->opt_lean_events = value; }
     else if (k == "skip_exchange") { if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: skip_exchange 0 | 1"); g->opt_skip_exchange = value; }
     else if (k == "events_device_scope") {
         if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: events_device_scope 0 | 1");
@@ -590,15 +593,23 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         plspm_model* m = l.m;
         if (hipSetDevice(m->device) != hipSuccess) { shard_rc[i] = fail(m, PLSPM_E_STATE, "hipSetDevice failed"); return; }
         if (g->pending[s]) {
-            // slot s was last read / written by the collective of two calls ago
-            if (g->use_rccl || one_device) hipStreamWaitEvent(m->stream, l.gathered[s], 0);            // (one launch / one collective read every send buffer)
-            else for (auto& peer : g->loc) hipStreamWaitEvent(m->stream, peer.gathered[s], 0);          // peers pull from this send buffer
+            // slot s was last read / written by the collective of two calls ago -- long finished, as a rule: then no wait is enqueued at all (a wait
+            // is a barrier packet the queue drains the device for even when its event has fired: ~5 us of a 0.48 ms step)
+            auto wait_unless_done = [&](hipEvent_t e) { if (!g->opt_lean_events || hipEventQuery(e) != hipSuccess) { (void)hipGetLastError(); hipStreamWaitEvent(m->stream, e, 0); } };
+            if (g->use_rccl || one_device) wait_unless_done(l.gathered[s]);            // (one launch / one collective read every send buffer)
+            else for (auto& peer : g->loc) wait_unless_done(peer.gathered[s]);          // peers pull from this send buffer
         }
         for (int k = 0; k < K; ++k) {
             int64_t first = 0, count = 0;
             shard_of(sub_B[k], g->nranks, g->first_rank + i, &first, &count);
             double* send = (double*)l.send[s].p + sub_off[k] * RS;
-            if (count > 0 && (shard_rc[i] = plspm_detail_bootstrap(m, count, seed, rep_offset + sub_first[k] + first, nullptr, send))) return;
+            // (a full shard: its last kernel signals `computed` itself; a ragged one records the event behind the padding below)
+            const bool fused = g->opt_lean_events && count == sub_cap[k] && count > 0;
+            m->stop_event = fused ? l.computed[s][k] : nullptr;
+            if (count > 0 && (shard_rc[i] = plspm_detail_bootstrap(m, count, seed, rep_offset + sub_first[k] + first, nullptr, send))) { m->stop_event = nullptr; return; }
+            const bool signalled = fused && m->stop_event == nullptr;      // (taken by the solver launch; left in place by routes that do not end in it)
+            m->stop_event = nullptr;
+            if (signalled) { shard_done[i] = k + 1; continue; }
             if (count < sub_cap[k] && hipMemsetAsync(send + count * RS, 0xFF, (size_t)(sub_cap[k] - count) * RS * sizeof(double), m->stream) != hipSuccess) {   // NaN status: not a replicate
                 shard_rc[i] = fail(m, PLSPM_E_STATE, "hipMemsetAsync failed"); return;
             }

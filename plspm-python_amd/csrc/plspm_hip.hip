@@ -297,7 +297,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_mv_base2, m->d_lmv2_off, m->gSm.p, m->d_ind_of, m->gram2.p, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->pp_ctl.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     for (void* p : m->blobs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
@@ -446,6 +446,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "gram_lds_kb") { if (value < 0 || value > 160) return bad(); m->tune.gram_lds_kb = value; }
     else if (k == "gram_path") { if (value < 0 || value > 2) return bad(); m->tune.gram_path = value; }
     else if (k == "i8_slices") { if (value < 0 || value > 8) return bad(); if (value != m->tune.i8_slices) m->zs_valid = false; m->tune.i8_slices = value; }
+    else if (k == "i8_min_slices") { if (value != 0 && (value < 6 || value > 8)) return bad(); if (value != m->tune.i8_min_slices) { m->zs_valid = false; m->zs_stats_ready = false; } m->tune.i8_min_slices = value; }
     else if (k == "i8_min_batch") { if (value < 1) return bad(); m->tune.i8_min_batch = value; }
     else if (k == "i8_waves") { if (value != 4 && value != 8) return bad(); if (value != 8 && !experiments) return exp_only(); m->tune.i8_waves = value; }
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
@@ -462,6 +463,8 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); if (value && !experiments) return exp_only(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); if (value && !experiments) return exp_only(); m->tune.i8_sched = value; }
     else if (k == "i8_priv") { if (value < 0 || value > 1) return bad(); m->tune.i8_priv = value; }
+    else if (k == "i8_persist") { if (value < 0 || value > 1) return bad(); m->tune.i8_persist = value; }
+    else if (k == "i8_nostore") { if (value < 0 || value > 1) return bad(); if (value && !experiments) return exp_only(); m->tune.i8_nostore = value; }
     else if (k == "i8_shape") { if (value != 16 && value != 32) return bad(); if (value != 16 && !experiments) return exp_only(); if (value != m->tune.i8_shape) m->zs_valid = false; m->tune.i8_shape = value; }
     else if (k == "i8_variant") { if (value < -1 || value > 899) return bad(); if (value >= 0 && !experiments) return exp_only(); m->tune.i8_variant = value; }
     else if (k == "i8_dma") { if (value < 0 || value > 2) return bad(); m->tune.i8_dma = value; }
@@ -512,6 +515,9 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_sched") *value = m->tune.i8_sched;
     else if (k == "i8_priv") *value = m->tune.i8_priv;
     else if (k == "last_i8_priv") *value = m->last_i8_priv;
+    else if (k == "i8_persist") *value = m->tune.i8_persist;
+    else if (k == "i8_min_slices") *value = m->tune.i8_min_slices;
+    else if (k == "last_i8_persist") *value = m->last_i8_persist;
     else if (k == "i8_shape") *value = m->tune.i8_shape;
     else if (k == "boot_chunks") *value = m->tune.boot_chunks;
     else if (k == "boot_ratio") *value = m->tune.boot_ratio;

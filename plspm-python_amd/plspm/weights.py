@@ -67,12 +67,12 @@ class WeightsCalculatorFactory:
                                         self._device_id, self._precision)
 
     def apply_precision(self, handle):
-        """``precision="strict"``: the bootstrap's moment sums are correctly rounded by construction -- SEVEN base-256 digit planes per pair
-        product (>= 53 significant bits of every column maximum, exact integer accumulation; include/plspm_hip.h "i8_slices") -- instead of
-        the automatic choice, which takes six planes when the uploaded data keep the representation error below a quarter of the a-priori
-        bound of the fp64 accumulation the reference performs (weights.py:43,60-61).  Costs ~20 % of the bootstrap rate."""
+        """``precision="strict"``: never fewer than SEVEN base-256 digit planes per pair product (>= 54 significant bits of every column
+        maximum, exact integer accumulation; include/plspm_hip.h "i8_min_slices") -- the automatic choice takes six when the uploaded data
+        keep the representation error below a quarter of the a-priori bound of the fp64 accumulation the reference performs
+        (weights.py:43,60-61), and eight by itself when one gross outlier carries a pair column.  Costs ~20 % of the bootstrap rate."""
         if self._precision == "strict":
-            handle.set_option("i8_slices", 7)
+            handle.set_option("i8_min_slices", 7)
         return handle
 
     def config(self):

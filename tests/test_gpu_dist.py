@@ -97,7 +97,7 @@ def test_group_call_as_sub_batches_is_bit_identical(nranks, B, chunks):
     if chunks:
         assert 2 <= len(plan) <= chunks, plan               # (never more sub-batches than whole rounds of the device per rank)
     elif nranks > 1:
-        assert len(plan) >= 2, plan                         # 2,250 records of 1 KB per rank: worth hiding
+        assert len(plan) == 1, plan                         # ranks that share a device exchange with one copy launch: nothing worth hiding
     assert all(c % (64 * nranks) == 0 for _, c in plan[:-1]), plan
     for _ in range(3):                                       # both buffer slots, and a slot re-used
         group.bootstrap(B, seed=5, rep_offset=11)

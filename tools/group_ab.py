@@ -42,8 +42,8 @@ def run(kind, steps):
 
 run("plain", 200)
 for rnd in range(4):
-    for kind, opts in (("plain", {}), ("group", {"skip_exchange": 0, "events_device_scope": 0}), ("group-no-exchange", {"skip_exchange": 1, "events_device_scope": 0}),
-                       ("group-device-scope-events", {"skip_exchange": 0, "events_device_scope": 1}), ("group-no-exchange-device-scope", {"skip_exchange": 1, "events_device_scope": 1})):
+    for kind, opts in (("plain", {}), ("group", {"skip_exchange": 0, "lean_events": 1}), ("group-round4-events", {"skip_exchange": 0, "lean_events": 0}),
+                       ("group-no-exchange", {"skip_exchange": 1, "lean_events": 1}), ("group-no-exchange-round4-events", {"skip_exchange": 1, "lean_events": 0})):
         if kind != "plain":
             for k, v in opts.items():
                 group.set_option(k, v)
@@ -52,4 +52,4 @@ for rnd in range(4):
         run("plain" if kind == "plain" else "group", 40)
         ms = (time.perf_counter() - t0) / 40 * 1e3
         print(json.dumps({"kind": kind, "round": rnd, "ms_per_step": round(ms, 4), "transport": comm.transport}), flush=True)
-group.set_option("skip_exchange", 0); group.set_option("events_device_scope", 0)
+group.set_option("skip_exchange", 0); group.set_option("lean_events", 1)
