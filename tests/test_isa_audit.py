@@ -30,6 +30,9 @@ template __global__ void gram_i8p_kernel<6, 5, 64, false>(P_ARGS);
 template __global__ void gram_i8p_kernel<6, 5, 64, true>(P_ARGS);
 template __global__ void gram_i8p_kernel<7, 4, 64, false>(P_ARGS);
 template __global__ void gram_i8p_kernel<7, 4, 64, true>(P_ARGS);
+#define PP_ARGS const uint4*, const uint4*, int, int, int, int, int, const int*, const double*, int, long, double*, long, int, GramI8PPCtl*
+template __global__ void gram_i8pp_kernel<6, 5, 64, true>(PP_ARGS);
+template __global__ void gram_i8pp_kernel<7, 4, 64, true>(PP_ARGS);
 template __global__ void gram_i8_kernel<6, 4, 3, 16, 20, false>(R_ARGS);
 template __global__ void gram_i8_kernel<7, 4, 803, 16, 16, false>(R_ARGS);
 template __global__ void gram_i8_kernel<5, 4, 3, 16, 16, false>(R_ARGS);
@@ -51,7 +54,7 @@ def assembly():
 
 
 def kernels(asm):
-    for m in re.finditer(r"^(_Z\d+gram_i8p?_kernel\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
+    for m in re.finditer(r"^(_Z\d+gram_i8p{0,2}_kernel\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
         yield m.group(1), m.group(2).split("\n")
 
 
@@ -61,7 +64,12 @@ def mfma_loops(body):
         mm = re.match(r"\s*s_c?branch\w*\s+(\.LBB\w+)", l)
         if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
             seg = body[labels[mm.group(1)]:i + 1]
-            if any("v_mfma" in x for x in seg):
+            # (innermost loops only: the persistent kernel's tile loop holds the k-step loop AND the epilogue, which is the compiler's to schedule)
+            inner = any(re.match(r"\s*s_c?branch\w*\s+(\.LBB\w+)", x) and labels.get(re.match(r"\s*s_c?branch\w*\s+(\.LBB\w+)", x).group(1), 1 << 30) >= labels[mm.group(1)]
+                        and labels.get(re.match(r"\s*s_c?branch\w*\s+(\.LBB\w+)", x).group(1), 1 << 30) < i and k < len(seg) - 1
+                        and labels.get(re.match(r"\s*s_c?branch\w*\s+(\.LBB\w+)", x).group(1), 1 << 30) <= labels[mm.group(1)] + k
+                        for k, x in enumerate(seg[:-1]))
+            if any("v_mfma" in x for x in seg) and not inner:
                 yield seg
 
 
@@ -81,17 +89,69 @@ def test_no_compiler_instruction_touches_the_hand_counted_queues(assembly):
                     foreign.append(t.split(";")[0].strip())
             assert not foreign, "%s: the compiler emitted %s inside a k-step loop" % (name, Counter(x.split()[0] for x in foreign))
             seen += 1
-    assert seen >= 9            # 4 + 2 (two heights in the SHORTS instantiations) + 3 round-3 kernels
+    assert seen >= 13           # 4 + 2 (two heights in the SHORTS instantiations) + 3 round-3 kernels + 2 x 2 phases of the persistent kernel
 
 
 def test_no_spills_no_scratch_and_the_register_budget(assembly):
-    meta = re.findall(r"\.name:\s+(_Z\d+gram_i8p?_kernel\w+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", assembly, re.S)
-    assert len(meta) >= 7
+    meta = re.findall(r"\.name:\s+(_Z\d+gram_i8p{0,2}_kernel\w+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", assembly, re.S)
+    assert len(meta) >= 9
     for name, scratch, sspill, vgpr, vspill in meta:
         assert int(scratch) == 0 and int(vspill) == 0, (name, scratch, vspill)
         assert int(vgpr) <= 512, (name, vgpr)
         if "gram_i8p" in name:
             assert int(sspill) == 0, (name, sspill)
+
+
+def test_persistent_gram_keeps_its_prefetch_registers_and_waits_to_itself(assembly):
+    """gram_i8pp_kernel issues the NEXT tile's count fragments (asm `global_load_dwordx4`) in front of this tile's epilogue and waits for them at the
+    head of the next tile.  Sound only while the compiler (a) touches none of those fragment registers other than to zero them before the first
+    load, (b) emits no VMEM load of its own inside the epilogue -- a load of its own there makes it wait for vmcnt(0), i.e. for the prefetch, at
+    the head of the epilogue: the tile's output slots are therefore loaded with the tile's prologue, and every compiler-emitted `s_waitcnt vmcnt`
+    sits right behind those loads (or the exit's atomics) --, and (c) spills nothing.  (Block layout is the compiler's: the checks are per kernel.)"""
+    found = 0
+    for name, body in kernels(assembly):
+        if "gram_i8pp" not in name:
+            continue
+        found += 1
+        flags, inasm = [], False
+        for l in body:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"): inasm = True
+            flags.append(inasm)
+            if t.startswith(";;#ASMEND"): inasm = False
+        frag = set()
+        for i, l in enumerate(body):
+            mm = re.match(r"\s*global_load_dwordx4 v\[(\d+):(\d+)\]", l)
+            if mm and flags[i]:
+                frag.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        assert len(frag) >= 32, name
+        own_vmem = [i for i, l in enumerate(body) if not flags[i] and re.match(r"\s*(global|flat|buffer)_(load|atomic)", l)]
+        stores = [i for i, l in enumerate(body) if not flags[i] and re.match(r"\s*(global|flat)_store", l)]
+        assert stores and 4 <= len(own_vmem) <= 24, (name, len(own_vmem))       # output slots / scales of a tile (x 2 phases) + the exit's counters: nothing per store
+        for i, l in enumerate(body):
+            t = l.strip()
+            if flags[i] or not t or t.startswith(";") or t.startswith("."): continue
+            code = t.split(";")[0]
+            assert not code.startswith("scratch_"), (name, code)
+            if "s_waitcnt" in code and "vmcnt" in code:
+                # the wait for its own loads (or the release in front of the exit's counter update), not one in the middle of an epilogue
+                assert any(0 < i - k <= 48 for k in own_vmem) or i >= len(body) - 60, (name, i, code)
+            touched = set()
+            for mm in re.finditer(r"v\[(\d+):(\d+)\]", code): touched.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+            for mm in re.finditer(r"\bv(\d+)\b", code): touched.add(int(mm.group(1)))
+            if touched & frag:
+                # registers are shared between the phases (tall / short tiles) and with what precedes a phase: the only thing allowed on a register that
+                # is a prefetch target is the zeroing in front of its first load and address arithmetic / epilogue temporaries of the OTHER phase;
+                # what must never appear is a copy FROM such a register (a v_mov / v_accvgpr_write with it as the source)
+                srcs = code.split(",", 1)[1] if "," in code else ""
+                src_regs = set()
+                for mm in re.finditer(r"v\[(\d+):(\d+)\]", srcs): src_regs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+                for mm in re.finditer(r"\bv(\d+)\b", srcs): src_regs.add(int(mm.group(1)))
+                dst_regs = touched - src_regs
+                if code.startswith("v_mov") or code.startswith("v_accvgpr_write"):
+                    # (zeroing chains in front of a phase copy one fragment register into another: allowed; a fragment's content must never LEAVE the set)
+                    assert not (src_regs & frag) or (dst_regs and dst_regs <= frag), (name, code)
+    assert found == 2
 
 
 def test_filler_schedule_tables():
