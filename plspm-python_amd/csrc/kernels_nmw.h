@@ -1,0 +1,416 @@
+// kernels_nmw.h -- Device kernels, part 4b (round 5): one iteration of the categorical (Scale.ORD / NOM, optimal scaling) solver as ONE 64-lane WAVE per
+// problem.  Included by plspm_nonmetric.hip behind kernels_nonmetric.h; device code only.
+//
+// Reference: _NonmetricWeights.iterate (plspm/weights.py:107-120) with the Scale operators (plspm/scale.py:41-89: ORD with the two-direction monotone
+// pooling `_ordinalize`, NOM), the Mode-A non-metric outer step (plspm/mode.py:31-42) and the inner schemes (plspm/scheme.py) -- the arithmetic of
+// solver_nmg.h nmg_step, which this restates for the model class the categorical bootstrap lives in: every MV ORD / NOM (all device columns 0/1
+// indicators: the moment matrix is a matrix of co-occurrence counts, kept as uint16), every block Mode A, at most 64 MVs of at most CMAX = 8
+// categories, at most LMAX = 8 LVs, at most 511 indicator columns.  Everything else keeps nmg_kernel<1>.
+//
+// Why.  nmg_kernel<1> runs ~50 dependent small phases per step on a 256-thread workgroup whose LDS footprint (54 KB) leaves two workgroups per CU:
+// 78 % of its wave cycles are waits, its VALUs are 14 % busy (profiles/r04); the one phase that moves data -- V = Mn c, the whole
+// count matrix once per iteration -- reaches ~2 TB/s in aggregate.  Here the lanes of a wave take fixed roles and the state of a step lives in
+// registers and ~12 KB of LDS, so that eight and more problems share a CU and one problem's round trips hide under its neighbours' streaming:
+//   column lane g       aug columns 8 g .. 8 g + 7 of every matrix-vector product: V[., m] and MZ[., l] are 8 x LMAX registers of the lane; a row of
+//                       the count matrix reaches the wave as ONE 16-byte load per lane (rows are contiguous: coalesced)
+//   MV lane p           manifest variable p: its <= 8 category frequencies, category means, pooled quantification -- registers, fully unrolled
+//                       (the per-MV scratch of nmg_step: 19 KB of LDS at 60 five-point items)
+//   pair lane e         entry (l, m) of the L x L matrices (YY, G, E): through solver_core.h inner_weights, unchanged
+// A step is: V = Mn c (stream 1) -> YY (segmented wave sums) -> inner weights -> category sums of z (the own-LV column of V E) -> category means -> quantification
+// (pooling in registers) -> outer weights, where the block quadratic form w' <MV, MV'> w is ONE more matrix-vector product on the BLOCK DIAGONAL of
+// the count matrix (stream 2: U = Mn_ll d, d = w_p tq_j; q_l = d' U) instead of k^2 pair moments of C^2 scattered loads each -> score map.
+// The prepare (first launch) and the finish stay nmg_kernel<0> / <2>; the state between launches is the same NmState / NmgExtra layout.
+// Same expressions as nmg_step up to the order of the sums that cross lanes (segmented wave sums; the quadratic form): records agree to ~1e-13,
+// iteration counts are equal (tests/test_gpu_categorical.py).
+#pragma once
+
+namespace nmw {
+
+constexpr int LMAX_MAX = 8, CMAX = 8, CPL = 8;      // LVs (the kernel is instantiated for LMAX = 2, 4, 6, 8), categories per MV, columns per lane
+
+// LDS of one problem (doubles): c | tq | mean | mzown (each QP = Q + 1 rounded up to 8), then the small arrays
+__host__ __device__ inline long lds_doubles(int Q, int Pm, int L, int kmax) {
+    const long QP = (Q + 1 + 7) & ~7L;
+    return 4 * QP + 3L * L * L + 6L * L + 2L * Pm + (long)L * regression_scratch_doubles(kmax) + 8 + 16;
+}
+
+// value of a[i] for a run-time i < CMAX out of a register array (static indices only)
+__device__ __forceinline__ double pick(const double (&a)[CMAX], int i) {
+    double v = a[0];
+#pragma unroll
+    for (int d = 1; d < CMAX; ++d) v = (i == d) ? a[d] : v;
+    return v;
+}
+
+// scale.py:54-66 (solver_nmg.h nmg_ordinalize) on register arrays: pool adjacent categories -- first violation from the left, restart -- until the
+// category means are monotone for `sign`; out[c] = pooled value of (compacted) category c < C; returns the population variance of the result.
+// Every lane runs its own MV (C = 0: idle); the wave loops while any lane still merges.
+__device__ __forceinline__ double ordinalize(const double (&m)[CMAX], const double (&f)[CMAX], int C, double sign, double (&out)[CMAX]) {
+    double gs[CMAX], gw[CMAX];
+    unsigned grp = 0x76543210u;                                   // group of category c in nibble c
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { gs[c] = (c < C) ? m[c] * f[c] : 0.0; gw[c] = (c < C) ? f[c] : 1.0; }
+    int ng = C;
+    bool active = ng > 1;
+    while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+        double gm[CMAX];
+#pragma unroll
+        for (int g = 0; g < CMAX; ++g) gm[g] = gs[g] / gw[g];
+        int first = -1;
+#pragma unroll
+        for (int g = CMAX - 2; g >= 0; --g) {
+            const double d = gm[g] - gm[g + 1];
+            const double sg = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : 0.0);
+            if (g + 1 < ng && sg == sign) first = g;              // (descending: the smallest violating g wins)
+        }
+        const bool merge = active && first >= 0;
+        if (merge) {
+            double ns[CMAX], nw[CMAX];
+#pragma unroll
+            for (int h = 0; h < CMAX; ++h) {
+                const double s_next = (h + 1 < CMAX) ? gs[h + 1] : 0.0, w_next = (h + 1 < CMAX) ? gw[h + 1] : 1.0;
+                ns[h] = (h < first) ? gs[h] : ((h == first) ? s_next + gs[h] : s_next);
+                nw[h] = (h < first) ? gw[h] : ((h == first) ? w_next + gw[h] : w_next);
+            }
+#pragma unroll
+            for (int h = 0; h < CMAX; ++h) { gs[h] = ns[h]; gw[h] = nw[h]; }
+            unsigned ngrp = 0u;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) { const unsigned gc = (grp >> (4 * c)) & 15u; ngrp |= (((int)gc > first) ? gc - 1u : gc) << (4 * c); }
+            grp = ngrp;
+            --ng;
+        }
+        active = merge && ng > 1;
+    }
+    double gm[CMAX];
+#pragma unroll
+    for (int g = 0; g < CMAX; ++g) gm[g] = gs[g] / gw[g];
+    double mean = 0.0, ss = 0.0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        const double v = pick(gm, (int)((grp >> (4 * c)) & 15u));
+        out[c] = v;
+        if (c < C) { mean += f[c] * v; ss += f[c] * v * v; }
+    }
+    return ss - mean * mean;
+}
+
+// sum over the lanes whose key equals l, for l = 0 .. L-1, of v[l] -- every lane gets all L totals (bitwise the same on every lane)
+template <int N> __device__ __forceinline__ void allsum_each(double (&v)[N], int n) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (i < n) v[i] = wv::allsum(v[i]);
+}
+
+template <int LMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nmw_step_kernel(ModelDesc md, CatDesc cd, double* __restrict__ gstate, long state_stride, const double* __restrict__ partial, int nparts,
+                                                      int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int Q = md.P, L = md.L, Pm = cd.Pm;
+    double* state = gstate + b * state_stride;
+    NmState st;
+    nm_carve(st, state, Q, L);
+    if (st.scal[3] == 0.0) return;                               // finished problems cost nothing more
+    NmgExtra xg;
+    nmg_carve(xg, state + nm_state_doubles(Q, L, 0), Q, Pm, L, cd.cmax, cd.kmv);
+    const unsigned short* k16 = gK16 + b * (long)(Q + 1) * ld16;
+    // ---- LDS
+    const int QP = (Q + 1 + 7) & ~7;
+    double* lp = reinterpret_cast<double*>(smem_raw);
+    double* c_s = lp; lp += QP;          // score-map coefficients of the current scores (later: d = w_p tq_j)
+    double* tq_s = lp; lp += QP;         // quantification values
+    double* mean_s = lp; lp += QP;       // column means = category frequencies (row Q of Mn)
+    double* mz_s = lp; lp += QP;         // <col_j, z_l(j)>: the inner estimate of the column's own LV
+    Workspace ws{};
+    ws.G = lp; lp += L * L; ws.E = lp; lp += L * L;
+    double* YY = lp; lp += L * L;
+    ws.a = lp; lp += L;
+    double* kold = lp; lp += L;
+    double* zmean = lp; lp += L;
+    double* vmean = lp; lp += L;
+    double* akk = lp; lp += L;
+    double* sdl = lp; lp += L;
+    lp += 2 * Pm;                        // (spare)
+    ws.scr = lp; lp += (long)L * regression_scratch_doubles(md.kmax);
+    ws.scal = lp; lp += 8;
+    ws.red = lp;
+    DevExec ex{lane, 64, ws.red, nullptr};
+
+    // ---- decide on the previous convergence value (solver_nmg.h nmg_step: same protocol)
+    const int iteration = (int)st.scal[2];
+    if (iteration > 0) {
+        double s = 0.0;
+        for (int i = lane; i < nparts; i += 64) s += partial[b * nparts + i];
+        const double conv = wv::allsum(s);
+        const bool stop = (conv < md.tol) || (iteration > md.max_iter);
+        if (lane == 0) {
+            st.scal[4] = conv;
+            if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+        }
+        if (stop) return;
+    }
+    const double n = st.scal[0], inv_n = 1.0 / n, corr2 = n / (n - 1.0);
+    // new -> old (the stop-rule pass of this iteration compares them), and the step's inputs into LDS
+    for (int j = lane; j < QP; j += 64) {
+        double cj = 0.0, tqj = 0.0, mj = 0.0;
+        if (j < Q) {
+            cj = iteration > 0 ? st.c_new[j] : st.c_old[j];
+            if (iteration > 0) st.c_old[j] = cj;
+            tqj = xg.tq[j];
+        }
+        if (j <= Q) mj = (double)k16[(long)Q * ld16 + j] * inv_n;
+        c_s[j] = cj; tq_s[j] = tqj; mean_s[j] = mj; mz_s[j] = 0.0;
+    }
+    if (lane < Pm && iteration > 0) st.a_old[lane] = st.a_new[lane];
+    if (lane < L) { const double k = iteration > 0 ? st.k_new[lane] : st.k_old[lane]; if (iteration > 0) st.k_old[lane] = k; kold[lane] = k; }
+    if (lane == 0) ws.scal[3] = (double)ST_OK;
+    __syncthreads();
+
+    // ---- stream 1: V[j, m] = <col_j, y_m> = mean_j k_m + sum over the rows q of block m of Mn[q][j] c_q, for this lane's eight columns
+    const int j0 = CPL * lane;
+    const bool have_cols = j0 <= Q;
+    double V[CPL][LMAX];
+#pragma unroll
+    for (int m = 0; m < LMAX; ++m) {
+        double acc[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) acc[u] = 0.0;
+        if (m < L) {
+            const double km = kold[m];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) acc[u] = (j0 + u <= Q) ? mean_s[j0 + u] * km : 0.0;
+            const int q0 = md.boff[m], q1 = md.boff[m + 1];
+            const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)q0 * ld16 + (have_cols ? j0 : 0));
+            const long pitch = ld16 / 8;                          // uint4 per row
+            for (int q = q0; q < q1; q += 8) {
+                uint4 w[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) w[t] = (have_cols && q + t < q1) ? row[t * pitch] : uint4{0u, 0u, 0u, 0u};
+                row += 8 * pitch;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (q + t < q1) {
+                        const double cq = c_s[q + t];
+                        const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) acc[u] += ((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * cq;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) V[u][m] = acc[u];
+    }
+    // LV of this lane's columns (columns >= Q: none)
+    int lvc[CPL];
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) lvc[u] = (j0 + u < Q) ? md.lvof[j0 + u] : -1;
+    // mean of y_m = V[Q, m]: held by the lane that owns column Q
+    {
+        const int gq = Q / CPL, uq = Q % CPL;
+#pragma unroll
+        for (int m = 0; m < LMAX; ++m) {
+            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) v = (u == uq) ? V[u][m] : v;
+            if (lane == gq && m < L) vmean[m] = v;
+        }
+    }
+    // ---- YY[l][m] = k_l mean(y_m) + sum over the columns j of block l of c_j V[j, m]   (raw second moments of the scores)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        if (l < L) {                                              // (uniform)
+            double part[LMAX];
+#pragma unroll
+            for (int m = 0; m < LMAX; ++m) {
+                double s = 0.0;
+#pragma unroll
+                for (int u = 0; u < CPL; ++u) s += (lvc[u] == l) ? c_s[j0 + u] * V[u][m] : 0.0;
+                part[m] = s;
+            }
+            allsum_each(part, L);
+            if (lane < L) {
+                double v = 0.0;
+#pragma unroll
+                for (int m = 0; m < LMAX; ++m) v = (lane == m) ? part[m] : v;
+                YY[l * L + lane] = v;                             // (+ k_l mean(y_m) below, once vmean is visible)
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < L * L; e += 64) {
+        const int l = e / L, m = e - l * L;
+        const double yy = kold[l] * vmean[m] + YY[e];
+        YY[e] = yy;
+        ws.G[e] = yy - vmean[l] * vmean[m];
+    }
+    __syncthreads();
+    inner_weights(ex, md, ws, corr2, YY);
+    // ---- a_l = <z_l, z_l>;  of MZ = V E only the column of the own LV is needed per aug column (the category sums of z_l) and the row of means
+    if (lane < L) {
+        const int l = lane;
+        double s = 0.0;
+        for (int m = 0; m < L; ++m) {
+            const double em = ws.E[m * L + l];
+            if (em == 0.0) continue;
+            double t = 0.0;
+            for (int m2 = 0; m2 < L; ++m2) t += YY[m * L + m2] * ws.E[m2 * L + l];
+            s += em * t;
+        }
+        ws.a[l] = s;
+        double zm = 0.0;
+        for (int m = 0; m < L; ++m) zm += vmean[m] * ws.E[m * L + l];
+        zmean[l] = zm;
+    }
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) {
+        if (lvc[u] >= 0) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < LMAX; ++m) if (m < L) s += V[u][m] * ws.E[m * L + lvc[u]];
+            mz_s[j0 + u] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- quantification (weights.py:112-115, scale.py:42-89) and the Mode-A outer weights: MV lane p
+    const bool is_mv = lane < Pm;
+    const int p = lane;
+    int jm0 = 0, C = 0, kind = KIND_NOM, lv = 0;
+    if (is_mv) { jm0 = cd.mv_off[p]; C = cd.mv_off[p + 1] - jm0; kind = cd.mv_kind[p]; lv = md.lvof[jm0]; }
+    double tqn[CMAX];
+    {
+        double cf[CMAX], cm[CMAX], fall[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const double f = (c < C) ? mean_s[jm0 + c] : 0.0, z = (c < C) ? mz_s[jm0 + c] : 0.0;
+            fall[c] = f;
+            cf[c] = f;
+            cm[c] = (f > 0.0) ? z / f : 0.0;
+        }
+        // compact to the categories present in this problem (a replicate may miss some)
+        double m2[CMAX], f2[CMAX];
+#pragma unroll
+        for (int d = 0; d < CMAX; ++d) { m2[d] = 0.0; f2[d] = 0.0; }
+        int Cp = 0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C && cf[c] > 0.0) {
+#pragma unroll
+                for (int d = 0; d <= c; ++d) if (Cp == d) { m2[d] = cm[c]; f2[d] = cf[c]; }
+                ++Cp;
+            }
+        }
+        double cs[CMAX];
+        // (every lane runs the pooling loops: C = 0 on the idle ones; NOM lanes take the category means)
+        double inc[CMAX], dec[CMAX];
+        const int Cord = (is_mv && kind == KIND_ORD) ? Cp : 0;
+        const double v_inc = ordinalize(m2, f2, Cord, 1.0, inc);
+        const double v_dec = ordinalize(m2, f2, Cord, -1.0, dec);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) cs[c] = (kind == KIND_ORD) ? ((v_inc < v_dec) ? -dec[c] : inc[c]) : m2[c];
+        double mean = 0.0, ss = 0.0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < Cp) { mean += f2[c] * cs[c]; ss += f2[c] * cs[c] * cs[c]; }
+        const double sd = sqrt(ss - mean * mean);
+        int at = 0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            double v = 0.0;
+            if (c < C && fall[c] > 0.0) { v = (pick(cs, at) - mean) / sd; ++at; }
+            tqn[c] = v;
+        }
+    }
+    // <MV_p, z_l>, Mode-A weight, mean of the quantified MV; d_j = w_p tq_j for the block quadratic form
+    double wn = 0.0, mvmean = 0.0;
+    if (is_mv) {
+        double mvm = 0.0 * zmean[lv];                            // tc_p = 0: the constant term of nmg_mv_moment
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) mvm += tqn[c] * mz_s[jm0 + c];
+        wn = mvm / ws.a[lv];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) mvmean += tqn[c] * mean_s[jm0 + c];
+    }
+    __syncthreads();                                              // (every lane is done reading c_s as the OLD score map)
+    if (is_mv) {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) { tq_s[jm0 + c] = tqn[c]; c_s[jm0 + c] = wn * tqn[c]; }
+    }
+    __syncthreads();
+    // ---- stream 2: U_i = sum over the rows j of the block of column i of Mn[j][i] d_j;  q_l = sum_i d_i U_i  (= w' <MV, MV'> w of block l)
+    double qpart[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) qpart[l] = 0.0;
+    {
+        const int bA = (have_cols && j0 < Q) ? lvc[0] : 0;
+        int bB = bA;
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) if (lvc[u] >= 0) bB = lvc[u];
+        const bool lane_on = have_cols && j0 < Q;
+        double U[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) U[u] = 0.0;
+        // the lane's columns lie in the consecutive blocks bA .. bB: pass s walks the rows of block bA + s (wave-uniform trip counts)
+        for (int s = 0; s < CPL; ++s) {
+            const int blk = bA + s;
+            const bool on = lane_on && blk <= bB;
+            if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
+            const int r0 = on ? md.boff[blk] : 0, r1 = on ? md.boff[blk + 1] : 0;
+            const int trips = (int)wv::allmax((unsigned long long)(unsigned)(r1 - r0));
+            const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)r0 * ld16 + (lane_on ? j0 : 0));
+            const long pitch = ld16 / 8;
+            for (int t0 = 0; t0 < trips; t0 += 4) {
+                uint4 w[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[t] = (on && r0 + t0 + t < r1) ? row[(long)(t0 + t) * pitch] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = r0 + t0 + t;
+                    const double dj = (on && j < r1) ? c_s[j] : 0.0;
+                    const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u)
+                        if (lvc[u] == blk) U[u] += ((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * dj;
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) s += (lvc[u] == l) ? c_s[j0 + u] * U[u] : 0.0;
+            qpart[l] = s;
+        }
+    }
+    allsum_each(qpart, L);
+    double mwpart[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) mwpart[l] = (is_mv && lv == l) ? wn * mvmean : 0.0;
+    allsum_each(mwpart, L);
+    if (lane < L) {
+        double q = 0.0, mw = 0.0;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { q = (lane == l) ? qpart[l] : q; mw = (lane == l) ? mwpart[l] : mw; }
+        const double sd = sqrt(q - mw * mw);
+        sdl[lane] = sd;
+        akk[lane] = -mw / sd;
+    }
+    __syncthreads();
+    // ---- new coefficients, score map (tc = 0: k_new = akk), state back to global memory
+    if (is_mv) {
+        const double an = wn / sdl[lv];
+        st.a_new[p] = an;
+        xg.tc[p] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) { st.c_new[jm0 + c] = an * tqn[c]; xg.tq[jm0 + c] = tqn[c]; }
+    }
+    if (lane < L) { st.k_new[lane] = akk[lane]; xg.akk[lane] = akk[lane]; }
+    if (lane == 0) {
+        st.scal[2] = (double)(iteration + 1);
+        if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3];
+        atomicAdd(nactive, 1);
+    }
+}
+
+}  // namespace nmw

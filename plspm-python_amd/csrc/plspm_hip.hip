@@ -452,6 +452,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "nm_k16") { if (value < 0 || value > 1) return bad(); m->tune.nm_k16 = value; }
     else if (k == "nm_codes") { if (value < 0 || value > 1) return bad(); m->tune.nm_codes = value; }
+    else if (k == "nm_wave") { if (value < 0 || value > 1) return bad(); m->tune.nm_wave = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
     else if (k == "upload_direct") { if (value < 0 || value > 1) return bad(); m->tune.upload_direct = value; }
     else if (k == "i8_short_rows") { if (value < -1 || value > 4096) return bad(); m->tune.i8_short = value; }
@@ -516,6 +517,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "i8_priv") *value = m->tune.i8_priv;
     else if (k == "last_i8_priv") *value = m->last_i8_priv;
     else if (k == "i8_persist") *value = m->tune.i8_persist;
+    else if (k == "nm_wave") *value = m->tune.nm_wave;
+    else if (k == "last_nm_wave") *value = m->last_nm_wave;
     else if (k == "i8_min_slices") *value = m->tune.i8_min_slices;
     else if (k == "last_i8_persist") *value = m->last_i8_persist;
     else if (k == "i8_shape") *value = m->tune.i8_shape;

@@ -5,6 +5,7 @@
 #include "wave_ops.h"
 #include "device_exec.h"
 #include "kernels_nonmetric.h"
+#include "kernels_nmw.h"
 
 // Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
 // finish.  The host only reads one counter per iteration (how many problems are still active).
@@ -90,8 +91,15 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
     // all-indicator categorical models of at most 65,535 rows: a uint16 copy of every problem's count matrix for the streaming product of the step
-    const int ld16 = (P + 1 + 3) & ~3;
+    const int ld16 = (P + 1 + 7) & ~7;                           // (whole 16-byte groups: the wave step loads eight counts per lane and row)
     const bool k16 = cat && m->cat_pure && N <= 65535 && m->tune.nm_k16 != 0;
+    // round 5: the iteration as one WAVE per problem (kernels_nmw.h nmw_step_kernel) for all-indicator models whose blocks are all Mode A, of at most
+    // 64 MVs with at most 8 categories each, 8 LVs and 511 indicator columns; prepare (launch 0) and finish stay nmg_kernel<0> / <2>
+    bool all_mode_a = true;
+    for (int l = 0; l < L; ++l) if (m->mode[l] != PLSPM_MODE_A) all_mode_a = false;
+    const size_t wave_lds = (size_t)nmw::lds_doubles(P, m->Pm, L, m->kmax) * sizeof(double);
+    const bool wave_step = k16 && all_mode_a && !nmx && m->Pm <= 64 && L <= nmw::LMAX_MAX && m->cmax <= nmw::CMAX && P + 1 <= 512 && m->tune.nm_wave != 0 && wave_lds <= kMaxLds;
+    m->last_nm_wave = wave_step ? 1 : 0;
     if (k16 && (rc = ensure(m, m->gK16, (size_t)nproblems * (P + 1) * ld16 * sizeof(unsigned short)))) return rc;
     if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
@@ -151,8 +159,14 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     // (dense stop-rule pass: the list kernel of the pass counts the live problems anyway and writes the count to the pinned flag itself -- no
     //  counter to clear, no copy operation: two tiny launches and their gaps less per iteration, 35 of ~590 us at three iterations)
     const bool flag_from_list = dense && !m->stage1;
+    auto wave_kernel = L <= 2 ? nmw::nmw_step_kernel<2> : L <= 4 ? nmw::nmw_step_kernel<4> : L <= 6 ? nmw::nmw_step_kernel<6> : nmw::nmw_step_kernel<8>;
+    if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
     for (int it = 0; it <= m->max_iter + 1; ++it) {
         if (!flag_from_list) HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
+        if (wave_step && it > 0) {
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipLaunchKernelGGL(wave_kernel, grid, dim3(64), wave_lds, m->stream, md, cd, gst, (long)st_doubles, (const double*)part, nparts, nact, (const unsigned short*)m->gK16.p, ld16);
+        } else
         launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
         // problems / replicate groups return at once on the device, and the 4-byte read-back of the counter overlaps with the pass
@@ -210,6 +224,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
 #endif
         if (*m->h_flag == 0) break;
     }
+    // the wave step does not carry the finish of a problem it stops: one finish launch over all problems once none is left iterating
+    if (wave_step && finish) launch(2);
 #ifdef PLSPM_DEBUG_MARKS
     if (d_nm_marks) plspm_dfree(d_nm_marks);
 #endif

@@ -235,6 +235,68 @@ def test_stop_rule_pass_on_category_codes_gives_the_dense_pass_bits(scale):
     assert_close(rows[r], mine, RTOL, ATOL)
 
 
+@pytest.mark.parametrize("case", ["likert60_path", "likert60_nom_centroid", "chain8_factorial", "tiny_blocks", "eight_categories"])
+def test_wave_step_agrees_with_the_workgroup_step(case):
+    """kernels_nmw.h (round 5): the categorical iteration as ONE WAVE per problem -- count matrix streamed 16 bytes per lane and row, the pooling
+    of the ordinal quantification in registers, the block quadratic form as a second matrix-vector product on the block diagonal -- against the
+    workgroup step it restates (nmg_kernel<1>, "nm_wave" 0): same iteration counts, records equal to 1e-10 (the sums that cross lanes are wave
+    reductions: a different order of the same terms), for fits and bootstraps; every shape class of its instantiations: 2 .. 8 LVs, 2 .. 8
+    categories per item, several LV blocks inside one lane's eight columns, replicates that lose categories, ORD and NOM; and both against the oracle."""
+    from plspm import _native
+    rng = np.random.default_rng(5)
+    if case in ("likert60_path", "likert60_nom_centroid"):
+        C = orc.satisfaction_C()
+        X, blocks = orc.synth(1500, C, 10, seed=31)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+        data[:, ::3] = np.clip(data[:, ::3], 2, 4)
+        scale, scheme = ("ORD", "path") if case == "likert60_path" else ("NOM", "centroid")
+        model = orc.Model(blocks, C, "A" * 6, scheme, True, tol=1e-6, scales=[scale] * 60)
+    elif case == "chain8_factorial":
+        C = orc.chain_C(8)
+        X, blocks = orc.synth(900, C, 4, seed=3)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(2.5 + 1.0 * Z), 1, 4)
+        model = orc.Model(blocks, C, "A" * 8, "factorial", True, tol=1e-6, scales=["ORD", "NOM"] * 16)
+    elif case == "tiny_blocks":
+        C = orc.chain_C(5)
+        X, blocks = orc.synth(400, C, 1, seed=8)               # one two-category item per LV: five blocks of two columns inside ONE lane's eight columns
+        X2, _ = orc.synth(400, C, 1, seed=9)
+        data = (np.concatenate((X, X2), axis=1) > 0).astype(float) + 1.0
+        blocks = [np.array([l, 5 + l]) for l in range(5)]
+        model = orc.Model(blocks, C, "A" * 5, "path", True, tol=1e-6, scales=["ORD"] * 10)
+    else:
+        C = orc.chain_C(2)
+        X, blocks = orc.synth(2500, C, 6, seed=12)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(4.5 + 1.6 * Z), 1, 8)             # eight categories per item
+        model = orc.Model(blocks, C, "AA", "centroid", True, tol=1e-6, scales=["ORD"] * 12)
+    nm, g = gpu_fit_cat(data, model)
+    assert nm.get_option("nm_wave") == 1 and nm.get_option("last_nm_wave") == 1
+    check_fit(g, orc.fit(data, model), case)
+    B = 300
+    wave = nm.bootstrap(B, seed=6)
+    assert nm.get_option("last_nm_wave") == 1
+    nm.set_option("nm_wave", 0)
+    fit0 = nm.fit(want_scores=True)
+    group = nm.bootstrap(B, seed=6)
+    assert nm.get_option("last_nm_wave") == 0
+    nm.set_option("nm_wave", 1)
+    assert fit0["iterations"] == g["iterations"]
+    assert_close(g["weights"], fit0["weights"], 1e-10, 1e-13)
+    assert_close(g["scores"], fit0["scores"], 1e-10, 1e-12)
+    assert np.array_equal(wave[1], group[1]) and np.array_equal(wave[2], group[2]), (np.flatnonzero(wave[2] != group[2])[:8], wave[1].sum(), group[1].sum())
+    ok = wave[1] == 0
+    assert ok.sum() >= 10
+    assert_close(wave[0][ok], group[0][ok], 1e-10, 1e-12)
+    r = int(np.flatnonzero(ok)[-1])
+    mine, its = orc.bootstrap_replicate(data, model, _native.bootstrap_indices(6, r, data.shape[0]), orc.correction(data.shape[0]))
+    Pm = len(model.scales)
+    rows = _rows_in_data_order(wave[0], g["inv"], Pm, C.shape[0], nm.n_eff)
+    assert its == wave[2][r]
+    assert_close(rows[r], mine, RTOL, ATOL)
+
+
 def test_categorical_bootstrap_beyond_one_histogram_window_takes_the_int8_route():
     """70,000 rows: non-metric bootstraps with on-device draws now stay on the digit-plane Gram (counts from the 131,072-row byte
     histogram) and take their stop-rule passes' row multiplicities from its int8 counts -- on category codes for all-indicator data.
