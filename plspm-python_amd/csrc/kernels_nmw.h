@@ -31,7 +31,9 @@ constexpr int LMAX_MAX = 8, CMAX = 8, CPL = 8;      // LVs (the kernel is instan
 // LDS of one problem (doubles): c | tq | mean | mzown (each QP = Q + 1 rounded up to 8), then the small arrays
 __host__ __device__ inline long lds_doubles(int Q, int Pm, int L, int kmax) {
     const long QP = (Q + 1 + 7) & ~7L;
-    return 4 * QP + 3L * L * L + 6L * L + 2L * Pm + (long)L * regression_scratch_doubles(kmax) + 8 + 16;
+    const long step = 3L * L * L + 6L * L + 2L * Pm + (long)L * regression_scratch_doubles(kmax) + 8 + 16;
+    const long fin = workspace_small_doubles(Pm, L, kmax, 0) + Pm;           // the fused finish: MV-level workspace of finish_problem + one row of the MV moment matrix
+    return 4 * QP + (step > fin ? step : fin);
 }
 
 // value of a[i] for a run-time i < CMAX out of a register array (static indices only)
@@ -101,9 +103,114 @@ template <int N> __device__ __forceinline__ void allsum_each(double (&v)[N], int
     for (int i = 0; i < N; ++i) if (i < n) v[i] = wv::allsum(v[i]);
 }
 
+// The finish of a problem whose stop has just been decided (solver_nmg.h nmg_finish): the correlation matrix of the final quantified MVs --
+// <MV_r, MV_c> = tq_r' N_rc tq_c / n, one more pass over the count matrix: for every MV c the wave forms y = Mn[:, cols(c)] tq_c on its column lanes
+// (the rows of MV c: one 16-byte load per lane and row) and folds y with tq over the columns of every MV r <= c -- then the shared tail
+// (finish_problem: loadings, cross-loadings, path regressions, effects, the record).  `fast`: the problem's LDS; MV r's columns sit in at most
+// two neighbouring lanes (at most 8 categories, 8 columns per lane): the lane that holds its first column stores, the other one adds.
+__device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const ModelDesc& mdm, const SolverOut& so, double* gSm, NmState& st, NmgExtra& xg,
+                              const unsigned short* k16, int ld16, double* fast, long b) {
+    const int lane = threadIdx.x, Q = md.P, L = md.L, Pm = cd.Pm;
+    const int QP = (Q + 1 + 7) & ~7;
+    double* lp = fast;
+    double* mvm_s = lp; lp += QP;        // means of the quantified MVs [Pm]
+    double* tq_s = lp; lp += QP;
+    double* mean_s = lp; lp += QP;
+    int* mvcol = reinterpret_cast<int*>(lp); lp += QP;      // MV of every aug column
+    Workspace wsm{};
+    wsm.PS = cov_ld(Pm);
+    wsm.S = gSm + b * cov_doubles(Pm);
+    carve_small(wsm, lp, Pm, L, md.kmax, 0);
+    lp += workspace_small_doubles(Pm, L, md.kmax, 0);
+    double* srow = lp;                   // [Pm] <MV_r, MV_c> of the current c
+    DevExec ex{lane, 64, wsm.red, nullptr};
+    const double n = st.scal[0], inv_n = 1.0 / n;
+    for (int j = lane; j < QP; j += 64) {
+        tq_s[j] = (j < Q) ? xg.tq[j] : 0.0;
+        mean_s[j] = (j <= Q) ? (double)k16[(long)Q * ld16 + j] * inv_n : 0.0;
+    }
+    __syncthreads();
+    if (lane < Pm) {
+        const int j0 = cd.mv_off[lane], C = cd.mv_off[lane + 1] - j0;
+        double mv = xg.tc[lane];                                  // nmg_mv_moment(.., Mn + Q LD, 1, 1.0) with tc = 0
+        for (int c = 0; c < C; ++c) { mv += tq_s[j0 + c] * mean_s[j0 + c]; mvcol[j0 + c] = lane; }
+        mvm_s[lane] = mv;
+    }
+    __syncthreads();
+    const int i0 = CPL * lane;
+    const bool lane_on = i0 < Q;
+    int mvc[CPL];
+    double tqi[CPL];
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) { mvc[u] = (i0 + u < Q) ? mvcol[i0 + u] : -1; tqi[u] = (i0 + u < Q) ? tq_s[i0 + u] : 0.0; }
+    const long pitch = ld16 / 8;
+    for (int c = 0; c < Pm; ++c) {
+        const int jc0 = cd.mv_off[c], Cc = cd.mv_off[c + 1] - jc0;                       // (uniform)
+        double y[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) y[u] = 0.0;
+        {
+            const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)jc0 * ld16 + (lane_on ? i0 : 0));
+            uint4 w[CMAX];
+#pragma unroll
+            for (int t = 0; t < CMAX; ++t) w[t] = (lane_on && t < Cc) ? row[(long)t * pitch] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < CMAX; ++t) {
+                if (t < Cc) {
+                    const double tj = tq_s[jc0 + t];
+                    const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) y[u] += ((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * tj;
+                }
+            }
+        }
+        // fold with tq over the runs of equal MV among this lane's columns: a run whose MV starts in this lane is stored, the head of an MV that
+        // started in the previous lane is added behind the barrier
+        int head_r = -1;
+        double head_v = 0.0;
+        {
+            int cur = -1;
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                if (mvc[u] >= 0) {
+                    if (mvc[u] != cur) {
+                        if (cur >= 0) { if (cd.mv_off[cur] >= i0) srow[cur] = acc; else { head_r = cur; head_v = acc; } }
+                        cur = mvc[u]; acc = 0.0;
+                    }
+                    acc += tqi[u] * y[u];
+                }
+            }
+            if (cur >= 0) { if (cd.mv_off[cur] >= i0) srow[cur] = acc; else { head_r = cur; head_v = acc; } }
+        }
+        __syncthreads();
+        if (head_r >= 0) srow[head_r] += head_v;
+        __syncthreads();
+        if (lane <= c && lane < Pm) {
+            const double v = srow[lane] - mvm_s[lane] * mvm_s[c];
+            wsm.S[(long)c * wsm.PS + lane] = v; wsm.S[(long)lane * wsm.PS + c] = v;
+        }
+        __syncthreads();
+    }
+    if (lane < Pm) { wsm.w[lane] = st.a_new[lane]; wsm.mu[lane] = 0.0; wsm.cs[lane] = 1.0; wsm.sd[lane] = sqrt(wsm.S[(long)lane * wsm.PS + lane]); }
+    if (lane == 0) { wsm.scal[1] = st.scal[0]; wsm.scal[2] = 1.0 / st.scal[0]; wsm.scal[3] = st.scal[1]; }
+    __syncthreads();
+    FitOutputs out = so.fit;
+    if (b != 0) out = FitOutputs{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    FitOutputs o2 = out;
+    o2.score_w = nullptr; o2.score_c = nullptr; o2.mean = nullptr;          // the score map lives on the aug columns (below)
+    finish_problem(ex, mdm, wsm, o2, (int)st.scal[2], false);
+    if (out.score_w) for (int j = lane; j < Q; j += 64) out.score_w[j] = st.c_new[j];
+    if (out.score_c && lane < L) out.score_c[lane] = st.k_new[lane];
+}
+
 template <int LMAX>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nmw_step_kernel(ModelDesc md, CatDesc cd, double* __restrict__ gstate, long state_stride, const double* __restrict__ partial, int nparts,
-                                                      int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
+                                                      const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
+                                                      int fuse_finish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -118,6 +225,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
     // ---- LDS
     const int QP = (Q + 1 + 7) & ~7;
     double* lp = reinterpret_cast<double*>(smem_raw);
+    double* const lp0 = lp;
     double* c_s = lp; lp += QP;          // score-map coefficients of the current scores (later: d = w_p tq_j)
     double* tq_s = lp; lp += QP;         // quantification values
     double* mean_s = lp; lp += QP;       // column means = category frequencies (row Q of Mn)
@@ -148,7 +256,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
             st.scal[4] = conv;
             if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
         }
-        if (stop) return;
+        if (stop) {
+            if (fuse_finish) {
+                __syncthreads();
+                finish(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+            }
+            return;
+        }
     }
     const double n = st.scal[0], inv_n = 1.0 / n, corr2 = n / (n - 1.0);
     // new -> old (the stop-rule pass of this iteration compares them), and the step's inputs into LDS
@@ -183,13 +297,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
             const int q0 = md.boff[m], q1 = md.boff[m + 1];
             const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)q0 * ld16 + (have_cols ? j0 : 0));
             const long pitch = ld16 / 8;                          // uint4 per row
-            for (int q = q0; q < q1; q += 8) {
-                uint4 w[8];
+            constexpr int NR = 16;                                // rows in flight per lane: one problem's stream is latency-bound (a wave has its SIMD to itself at 1,000 problems)
+            for (int q = q0; q < q1; q += NR) {
+                uint4 w[NR];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) w[t] = (have_cols && q + t < q1) ? row[t * pitch] : uint4{0u, 0u, 0u, 0u};
-                row += 8 * pitch;
+                for (int t = 0; t < NR; ++t) w[t] = (have_cols && q + t < q1) ? row[t * pitch] : uint4{0u, 0u, 0u, 0u};
+                row += NR * pitch;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < NR; ++t) {
                     if (q + t < q1) {
                         const double cq = c_s[q + t];
                         const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
@@ -351,27 +466,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
         double U[CPL];
 #pragma unroll
         for (int u = 0; u < CPL; ++u) U[u] = 0.0;
-        // the lane's columns lie in the consecutive blocks bA .. bB: pass s walks the rows of block bA + s (wave-uniform trip counts)
-        for (int s = 0; s < CPL; ++s) {
-            const int blk = bA + s;
-            const bool on = lane_on && blk <= bB;
-            if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
-            const int r0 = on ? md.boff[blk] : 0, r1 = on ? md.boff[blk + 1] : 0;
-            const int trips = (int)wv::allmax((unsigned long long)(unsigned)(r1 - r0));
-            const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)r0 * ld16 + (lane_on ? j0 : 0));
+        // the lane's columns lie in the consecutive blocks bA .. bB.  Two blocks per trip -- block bA + 2 s and its right neighbour, rows of both
+        // in flight together: blocks of eight and more columns (the usual case) put at most two into a lane's eight columns, so ONE pass of
+        // max(block length) trips serves every lane (a wave has its SIMD to itself at 1,000 problems: the stream is a chain of round trips)
+        for (int s2 = 0; s2 < CPL; s2 += 2) {
+            const int blkA = bA + s2, blkB = blkA + 1;
+            const bool onA = lane_on && blkA <= bB, onB = lane_on && blkB <= bB;
+            if (__builtin_amdgcn_ballot_w64(onA) == 0ull) break;
+            const int a0 = onA ? md.boff[blkA] : 0, a1 = onA ? md.boff[blkA + 1] : 0;
+            const int b0 = onB ? md.boff[blkB] : 0, b1 = onB ? md.boff[blkB + 1] : 0;
+            const int len = max(a1 - a0, b1 - b0);
+            const int trips = (int)wv::allmax((unsigned long long)(unsigned)len);
             const long pitch = ld16 / 8;
-            for (int t0 = 0; t0 < trips; t0 += 4) {
-                uint4 w[4];
+            const uint4* rowA = reinterpret_cast<const uint4*>(k16 + (long)a0 * ld16 + (lane_on ? j0 : 0));
+            const uint4* rowB = reinterpret_cast<const uint4*>(k16 + (long)b0 * ld16 + (lane_on ? j0 : 0));
+            constexpr int NU = 8;
+            for (int t0 = 0; t0 < trips; t0 += NU) {
+                uint4 wa[NU], wb[NU];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) w[t] = (on && r0 + t0 + t < r1) ? row[(long)(t0 + t) * pitch] : uint4{0u, 0u, 0u, 0u};
+                for (int t = 0; t < NU; ++t) {
+                    wa[t] = (onA && a0 + t0 + t < a1) ? rowA[(long)(t0 + t) * pitch] : uint4{0u, 0u, 0u, 0u};
+                    wb[t] = (onB && b0 + t0 + t < b1) ? rowB[(long)(t0 + t) * pitch] : uint4{0u, 0u, 0u, 0u};
+                }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int j = r0 + t0 + t;
-                    const double dj = (on && j < r1) ? c_s[j] : 0.0;
-                    const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+                for (int t = 0; t < NU; ++t) {
+                    const int ja = a0 + t0 + t, jb = b0 + t0 + t;
+                    const double da = (onA && ja < a1) ? c_s[ja] : 0.0, db = (onB && jb < b1) ? c_s[jb] : 0.0;
+                    const unsigned wwa[4] = {wa[t].x, wa[t].y, wa[t].z, wa[t].w}, wwb[4] = {wb[t].x, wb[t].y, wb[t].z, wb[t].w};
 #pragma unroll
-                    for (int u = 0; u < CPL; ++u)
-                        if (lvc[u] == blk) U[u] += ((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * dj;
+                    for (int u = 0; u < CPL; ++u) {
+                        if (lvc[u] == blkA) U[u] += ((double)((wwa[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * da;
+                        if (lvc[u] == blkB) U[u] += ((double)((wwb[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * db;
+                    }
                 }
             }
         }

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     if (extra_in_lds) {
         nmg_carve_fast(x, xg, state + nm_state_doubles(Q, L, 0), lp, Q, cd.Pm, L, cd.cmax, cd.kmv);
         lp += (nmg_fast_doubles(Q, cd.Pm, L, cd.cmax, cd.kmv) + 1) & ~1L;
-        if (MODE != 0) {
+        if (MODE != 0 && MODE != 3) {
             const long np = nmg_persistent_doubles(Q, cd.Pm, L);
             for (long i = threadIdx.x; i < np; i += blockDim.x) x.tq[i] = xg.tq[i];
             __syncthreads();
@@ -90,7 +90,12 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     stage_descriptors(md, lp);
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
     bool finish_now = (MODE == 2);
-    if (MODE == 0) {
+    if (MODE == 3) {
+        // prepare alone, and only what the wave step reads (kernels_nmw.h): the uint16 counts + the initial state -- no fp64 copy of the matrix
+        // (730 KB written per problem at 300 indicator columns, which the wave step and its fused finish never open)
+        ws.S = nullptr;
+        nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
+    } else if (MODE == 0) {
         nmg_prepare(ex, md, cd, ws, st, x, Mp + b * mp_stride);
         const bool active = nmg_step(ex, md, cd, ws, st, x, partial + b * nparts, nparts);
         if (active && threadIdx.x == 0) atomicAdd(nactive, 1);

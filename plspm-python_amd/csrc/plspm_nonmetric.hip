@@ -87,7 +87,6 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
         }
     }
     m->last_nm_codes = use_codes ? 1 : 0;
-    if ((rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
     // all-indicator categorical models of at most 65,535 rows: a uint16 copy of every problem's count matrix for the streaming product of the step
@@ -100,6 +99,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const size_t wave_lds = (size_t)nmw::lds_doubles(P, m->Pm, L, m->kmax) * sizeof(double);
     const bool wave_step = k16 && all_mode_a && !nmx && m->Pm <= 64 && L <= nmw::LMAX_MAX && m->cmax <= nmw::CMAX && P + 1 <= 512 && m->tune.nm_wave != 0 && wave_lds <= kMaxLds;
     m->last_nm_wave = wave_step ? 1 : 0;
+    // the fp64 square of every problem (730 KB at 300 indicator columns): not for the wave step, which reads the uint16 counts only
+    if (!wave_step && (rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
     if (k16 && (rc = ensure(m, m->gK16, (size_t)nproblems * (P + 1) * ld16 * sizeof(unsigned short)))) return rc;
     if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
@@ -111,7 +112,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const int cat_fast = (cat && m->tune.nm_fast_lds != 0 && lds + cat_fast_bytes <= kMaxLds) ? 1 : 0;
     if (cat_fast) lds += cat_fast_bytes;
     if (cat) {
-        if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)))
+        if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)) ||
+            (rc = allow_lds(m, (const void*)nmg_kernel<3>, lds)))
             return rc;
     } else if (nmx) {
         if ((rc = allow_lds(m, (const void*)nmx_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<2>, lds)))
@@ -163,9 +165,14 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
     for (int it = 0; it <= m->max_iter + 1; ++it) {
         if (!flag_from_list) HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
-        if (wave_step && it > 0) {
+        if (wave_step) {
+            // prepare: the uint16 counts + the initial state only (nmg_kernel<3>); every step, the first one included, one wave per problem; the
+            // finish of a problem inside the launch that decides its stop
             ProfScope ps(m, PLSPM_K_SOLVER);
-            hipLaunchKernelGGL(wave_kernel, grid, dim3(64), wave_lds, m->stream, md, cd, gst, (long)st_doubles, (const double*)part, nparts, nact, (const unsigned short*)m->gK16.p, ld16);
+            if (it == 0) hipLaunchKernelGGL(nmg_kernel<3>, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                                            0, cat_fast, (unsigned short*)m->gK16.p, ld16);
+            hipLaunchKernelGGL(wave_kernel, grid, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                               (const unsigned short*)m->gK16.p, ld16, fuse);
         } else
         launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
@@ -224,8 +231,6 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
 #endif
         if (*m->h_flag == 0) break;
     }
-    // the wave step does not carry the finish of a problem it stops: one finish launch over all problems once none is left iterating
-    if (wave_step && finish) launch(2);
 #ifdef PLSPM_DEBUG_MARKS
     if (d_nm_marks) plspm_dfree(d_nm_marks);
 #endif

@@ -238,7 +238,7 @@ PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Worksp
         const int q = 32 * (u >> 1) + (u & 1) + 2 * (lane & 15);
         if ((t != u || p <= q) && p <= Q && q <= Q) {
             const double v = m * inv_n;
-            ws.S[q * LD + p] = v; ws.S[p * LD + q] = v;
+            if (ws.S) { ws.S[q * LD + p] = v; ws.S[p * LD + q] = v; }       // (null: the uint16 counts are all the caller's iteration reads -- the wave step, kernels_nmw.h)
             if (x.k16) { const unsigned short h = (unsigned short)(m + 0.5); x.k16[(long)q * x.ld16 + p] = h; x.k16[(long)p * x.ld16 + q] = h; }       // (integers: exact)
         }
     });
@@ -258,7 +258,11 @@ PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Worksp
             // rank codes 1..C' over the categories PRESENT in this problem (a bootstrap replicate may miss some: util.rank ranks
             // the values that occur, util.py:80-86); absent categories have an all-zero indicator column, any coefficient does
             int code = 0;
-            for (int c = 0; c < C; ++c) { if (Mn[Q * LD + j0 + c] > 0.0) ++code; x.tq[j0 + c] = (double)code; }
+            for (int c = 0; c < C; ++c) {
+                const bool present = Mn ? Mn[Q * LD + j0 + c] > 0.0 : x.k16[(long)Q * x.ld16 + j0 + c] != 0;      // (category count > 0)
+                if (present) ++code;
+                x.tq[j0 + c] = (double)code;
+            }
             x.tc[p] = 0.0;
         }
     });
