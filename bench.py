@@ -707,10 +707,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             # the real reference cannot travel to this box: its rate measured in the build container, and the factor between the oracle and
-            # the reference measured there back to back (oracle/time_calibration.py -> profiles/r04_cpu_calibration.json), convert this
+            # the reference measured there back to back (oracle/time_calibration.py -> profiles/r05_cpu_calibration.json), convert this
             # box's oracle figure into reference-equivalent replicates/s
             try:
-                cal = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_calibration.json")))
+                cal = json.load(open(os.path.join(ROOT, "profiles", "r05_cpu_calibration.json")))
                 ref8 = [r for r in cal["reference"]["runs"] if r["processes"] == 8][0]
                 ref1 = [r for r in cal["reference"]["runs"] if r["processes"] == 1][0]
                 ratio = cal["oracle_over_reference"]["all_cores"]
@@ -721,7 +721,7 @@ def main():
                     "oracle_over_reference": ratio,
                     "reference_equivalent_on_this_box": round(line["cpu_baseline"]["value"] / ratio, 2),
                     "gpu_over_reference_equivalent": round(line["value"] / (line["cpu_baseline"]["value"] / ratio), 0),
-                    "source": "profiles/r04_cpu_calibration.json (oracle/time_calibration.py: plspm 0.5.6 through its public API and the oracle "
+                    "source": "profiles/r05_cpu_calibration.json (oracle/time_calibration.py: plspm 0.5.6 through its public API and the oracle "
                               "pool of this bench, back to back on the same cores)"}
             except Exception:
                 pass

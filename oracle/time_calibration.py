@@ -3,7 +3,7 @@
 bench.py, kind "port") and the REAL reference timed back to back on THIS container's cores on BASELINE.json configs[2] (10k x 60 x 6,
 Mode A, Scheme.PATH, scaled), so that the oracle's replicates/s measured on a GPU box converts to reference-equivalent replicates/s.
 The reference runs under /opt/conda/bin/python3.9 (oracle/refshim.py), the oracle under the interpreter bench.py uses.
-Writes profiles/r04_cpu_calibration.json.   Run: python oracle/time_calibration.py [reference replicates, default 160]"""
+Writes profiles/<tag>_cpu_calibration.json.   Run: python oracle/time_calibration.py [reference replicates, default 400 -- SURVEY.md 8(d) asks for >= 400] [tag, default r05]"""
 import json
 import os
 import subprocess
@@ -32,7 +32,7 @@ df = pd.DataFrame(X, columns=names)
 lvs = orc.SAT_LVS
 path = pd.DataFrame(orc.satisfaction_C(), index=lvs, columns=lvs)
 runs = []
-for procs, n in ((8, reps), (1, max(10, reps // 4))):
+for procs, n in ((8, reps), (1, max(10, reps // 4 if reps < 400 else 100))):
     cfg = c.Config(path, scaled=True)
     for lv, b in zip(lvs, blocks): cfg.add_lv(lv, Mode.A, *[c.MV(names[i]) for i in b])
     t0 = time.time(); Plspm(df, cfg, Scheme.PATH); t_fit = time.time() - t0
@@ -51,7 +51,8 @@ def oracle_rates():
 
 
 def main():
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     t0 = time.time()
     out = subprocess.run(["/opt/conda/bin/python3.9", "-c", REF_CHILD % {"here": HERE}, str(reps)], env=env, capture_output=True, text=True, check=True)
@@ -67,7 +68,7 @@ def main():
                                      "note": "divide a GPU box's cpu_baseline.value (oracle, one worker per core) by `all_cores` for the reference's "
                                              "replicates/s on that box's cores (same arithmetic, pandas / statsmodels overheads included)"},
            "wall_s": round(time.time() - t0, 1)}
-    with open(os.path.join(ROOT, "profiles", "r04_cpu_calibration.json"), "w") as fh:
+    with open(os.path.join(ROOT, "profiles", tag + "_cpu_calibration.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
 

@@ -2,7 +2,7 @@
 # GPU-box script: everything that goes into profiles/ for one round.  usage: bash tools/gpu_profiles.sh r02
 # bench lines (plain, in-library group/RCCL, launcher), fit bench, non-metric bench, rocprofv3 kernel stats of the headline command,
 # HBM counters (separate --pmc passes, no trace domains), SQ counters of the headline Gram and of the configs[4] Gram.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
@@ -10,6 +10,15 @@ cd $R
 timeout 600 python bench.py 2>$O/bench_n1.err | tail -1 > $O/bench_n1.json
 timeout 300 python bench.py --group --no-cpu-baseline --no-api 2>/dev/null | tail -1 > $O/bench_n1_group_rccl.json
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_n1_launcher_rccl.json
+PLSPM_BENCH_SHARED_DEVICE=1 timeout 300 python bench.py --gpus 2 --no-cpu-baseline --no-api 2>/dev/null | tail -1 > $O/bench_seam_2ranks_one_device.json
+# round 5: the persistent Gram against the tiled launch (with the experiments build: the same launches without epilogue stores), what the group path
+# costs a one-rank step, the host-buffer entry point under the sub-batch options
+[ -f plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so ] && (for a in "5000" "2500" "5000 7"; do PLSPM_HIP_LIB=$R/plspm-python_amd/csrc/build/exp_i8/libplspm_hip_exp.so timeout 300 python tools/persist_ab.py $a; done) 2>/dev/null | grep "^{" > $O/persist_ab.jsonl
+timeout 300 python tools/group_ab.py 2>/dev/null | grep "^{" > $O/group_ab.jsonl
+timeout 300 python tools/pcie_chunks.py 5000 2>/dev/null | grep "^{" > $O/pcie_chunks.jsonl
+timeout 300 python tools/categorical_bench.py 5000 2>&1 | tail -1 > $O/categorical_bench_5000.json
+CAT_NM_WAVE=0 timeout 300 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench_workgroup_step.json
+(bash tools/cat_pmc.sh > $O/categorical_pmc.txt 2>&1; rm -rf $R/gpurun_out/cat_pmc)
 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1 > $O/nonmetric_bench.json
 (NM_BENCH_N=100000 NM_BENCH_SPINUP=3 NM_BENCH_STEPS=5 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1; NM_BENCH_N=100000 NM_BENCH_GRAM_PATH=1 NM_BENCH_SPINUP=1 NM_BENCH_STEPS=2 timeout 600 python tools/nonmetric_bench.py 1000 2>&1 | tail -1) > $O/nonmetric_100k.jsonl
 timeout 900 python tools/fit_bench.py c2 c5 2>&1 | grep "^{" > $O/fit_bench.jsonl

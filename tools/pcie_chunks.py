@@ -41,5 +41,5 @@ for rnd in range(2):
         for _ in range(15):
             m.bootstrap(B, seed=1, out=host)
         ms = (time.perf_counter() - t0) / 15 * 1e3
-        print(json.dumps({"B": B, "boot_chunks": chunks, "boot_ratio": ratio, "parts": _native.chunk_plan(B, 8 * m.row_stride, chunks, ratio), "ms_per_call": round(ms, 4),
+        print(json.dumps({"B": B, "boot_chunks": chunks, "boot_ratio": ratio, "parts": _native.chunk_plan(B, 8 * m.row_stride, chunks, ratio, m.get_option("boot_round_units")), "ms_per_call": round(ms, 4),
                           "replicates_per_s": round(B / ms * 1e3, 1), "device_only_ms": round(dev_ms, 4), "rows_identical": same, "round": rnd}), flush=True)
