@@ -49,6 +49,11 @@ int plspm_gram_tile_plan(int64_t count_tiles, int64_t pair_tiles, int32_t cus, i
  * (the group's events release at device scope). */
 int plspm_chunk_plan(int64_t B, int64_t bytes_per_unit, int32_t chunks, int32_t ratio_pct, int64_t align, int64_t* parts);
 
+/* Test seam: the stop-rule value (weights.py:120) each of the first B problems of the handle's LAST non-metric run was decided on -- the criterion of
+ * the iteration that stopped it (or of its last iteration) -- out[B].  For holding the three forms of the stop-rule pass ("nm_mfma", "nm_codes") against
+ * each other on the VALUE, not only on the iteration counts.  PLSPM_E_STATE when no such run has happened. */
+int plspm_nonmetric_criteria(plspm_model_t* m, int64_t B, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,7 +297,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_mv_base2, m->d_lmv2_off, m->gSm.p, m->d_ind_of, m->gram2.p, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->err2.p, m->pp_ctl.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
+                    m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->ind8.p, m->tab8.p, m->scl8.p, m->err2.p, m->pp_ctl.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     for (void* p : m->blobs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
@@ -343,7 +343,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
     if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
-    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; if (m->stage2) m->stage2->codes_valid = false; m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false; m->zs_stats_ready = false;
+    m->N = 0; m->d_Xa = nullptr; m->Xt_valid = false; m->codes_valid = false; m->ind8_valid = false; if (m->stage2) { m->stage2->codes_valid = false; m->stage2->ind8_valid = false; } m->rows_B = 0; m->dcnt_ready = false; m->zs_valid = false; m->zs_stats_ready = false;
     drop_incomplete_rows(m);
     // persistent grow-only buffers: a repeated upload of the same shape allocates nothing
     const size_t raw_bytes = (size_t)N * src_cols * sizeof(double);
@@ -452,6 +452,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_fast_lds") { if (value < 0 || value > 1) return bad(); m->tune.nm_fast_lds = value; }
     else if (k == "nm_k16") { if (value < 0 || value > 1) return bad(); m->tune.nm_k16 = value; }
     else if (k == "nm_codes") { if (value < 0 || value > 1) return bad(); m->tune.nm_codes = value; }
+    else if (k == "nm_mfma") { if (value < 0 || value > 1) return bad(); m->tune.nm_mfma = value; }
     else if (k == "nm_wave") { if (value < 0 || value > 1) return bad(); m->tune.nm_wave = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
     else if (k == "upload_direct") { if (value < 0 || value > 1) return bad(); m->tune.upload_direct = value; }
@@ -501,6 +502,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "nm_k16") *value = m->tune.nm_k16;
     else if (k == "nm_codes") *value = m->tune.nm_codes;
     else if (k == "last_nm_codes") *value = m->last_nm_codes;
+    else if (k == "nm_mfma") *value = m->tune.nm_mfma;
+    else if (k == "last_nm_mfma") *value = m->last_nm_mfma;
     else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_short_rows") *value = m->tune.i8_short;
@@ -686,7 +689,7 @@ int plspm_model_set_incomplete_rows(plspm_model_t* m, int32_t K, const int32_t* 
 #undef NMXCHK
     plspm_dfree(d_mask);
     // the rows of Xa were rewritten: everything derived from them is stale (a caller may have run plspm_bootstrap_prepare before this call)
-    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false; m->zs_valid = false; m->zs_stats_ready = false; m->codes_valid = false; m->dcnt_ready = false;
+    m->nmx_K = K; m->nmx_raw = raw_scale ? 1 : 0; m->Xt_valid = false; m->zs_valid = false; m->zs_stats_ready = false; m->codes_valid = false; m->ind8_valid = false; m->dcnt_ready = false;
     return 0;
 }
 

@@ -6,6 +6,7 @@
 #include "device_exec.h"
 #include "kernels_nonmetric.h"
 #include "kernels_nmw.h"
+#include "kernels_nmp.h"
 
 // Non-metric solve of `nproblems` problems whose packed scatter matrices are at Mp: prepare -> (step, convergence pass)* ->
 // finish.  The host only reads one counter per iteration (how many problems are still active).
@@ -54,7 +55,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const bool counts8 = cd8 != nullptr;
     const bool dense = dense_use_lds != 0 && (counts8 || (ent && src->dcnt_ready));
     if (counts8 && !dense) return fail(m, PLSPM_E_STATE, "non-metric bootstrap: the dense stop-rule pass does not fit and no (row,count) lists were built");
-    const int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
+    int nparts = dense ? (int)ntiles16 : (int)std::max<long>(1, std::min<long>(nproblems == 1 ? 1024 : 8, (N + 1023) / 1024));
     const int ngroups = (int)((nproblems + 63) / 64);
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
@@ -86,7 +87,28 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
             m->codes_valid = true;
         }
     }
+    // round 5: that pass as an exact int8 matrix product (kernels_nmp.h) -- indicator bytes x digit planes of the score maps, blocks of at most 64 columns
+    // (one k-step of the instruction).  Row chunks of `tpc` tiles: enough waves to fill the device at the batch's first passes, whole tiles of work each.
+    const bool use_mfma = use_codes && kb <= 64 && m->tune.nm_mfma != 0;
+    const long ng16 = (nproblems + 15) / 16;
+    int tpc = 0;
+    if (use_mfma) {
+        const long want = std::max<long>(1, std::min<long>((4096 + ng16 - 1) / ng16, (ntiles16 + 7) / 8));
+        tpc = (int)((ntiles16 + want - 1) / want);
+        nparts = (int)((ntiles16 + tpc - 1) / tpc);
+        if (!m->ind8_valid) {
+            if ((rc = ensure(m, m->ind8, (size_t)L * ntiles16 * 64 * sizeof(uint4)))) return rc;
+            const long total = (long)L * ntiles16 * 64;
+            hipLaunchKernelGGL(nmp::ind8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const unsigned short*)m->codes.p, ntiles16, src->Pm, L, codes_lmv,
+                               (uint4*)m->ind8.p);
+            m->ind8_valid = true;
+        }
+        if ((rc = ensure(m, m->tab8, (size_t)ng16 * L * 2 * nmp::S * 64 * sizeof(uint4)))) return rc;
+        if ((rc = ensure(m, m->scl8, (size_t)ng16 * L * 2 * 16 * sizeof(double2)))) return rc;
+    }
     m->last_nm_codes = use_codes ? 1 : 0;
+    m->last_nm_problems = nproblems;
+    m->last_nm_mfma = use_mfma ? 1 : 0;
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
     // all-indicator categorical models of at most 65,535 rows: a uint16 copy of every problem's count matrix for the streaming product of the step
@@ -197,6 +219,12 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 hipLaunchKernelGGL(active_list_kernel, dim3(1), dim3(1024), 0, m->stream, conv_state, conv_stride, nproblems, live_list + 1, live_list,
                                    flag_from_list ? (int*)m->h_flag : (int*)nullptr);
                 if (flag_from_list) HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+                if (use_mfma) {
+                    hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16 * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, conv_boff, (const int*)(live_list + 1),
+                                       (const int*)live_list, (uint4*)m->tab8.p, (double2*)m->scl8.p);
+                    hipLaunchKernelGGL(nmp::conv_mfma_kernel<4>, dim3((unsigned)(nparts * ((ng16 + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
+                                       (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(live_list + 1), (const int*)live_list, part, nparts, tpc);
+                } else {
                 hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups, (unsigned)((2 * src->P + 2 * L + 1 + 63) / 64)), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L,
                                    (const int*)(live_list + 1), (const int*)live_list, (double*)m->ctable.p);
                 const int gx = (int)((ntiles16 + 7) / 8);                      // row blocks of 128 rows (8 tiles: 8 x 16-row or 16 x 8-row waves)
@@ -214,6 +242,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
                                    (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
+                }
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
                                    ent_stride, conv_state, conv_stride, part);
@@ -238,4 +267,13 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     return 0;
 }
 
-
+// include/plspm_hip_test.h
+extern "C" int plspm_nonmetric_criteria(plspm_model_t* m, int64_t B, double* out) {
+    if (!m || !out || B < 0) return PLSPM_E_ARG;
+    const size_t st = nm_state_doubles_of(m);
+    if (!m->nmstate.p || m->nmstate.cap < (size_t)B * st * sizeof(double) || !m->last_nm_problems || B > m->last_nm_problems) return fail(m, PLSPM_E_STATE, "plspm_nonmetric_criteria: no non-metric run of that many problems");
+    hipSetDevice(m->device);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy2D(out, sizeof(double), (const double*)m->nmstate.p + 4, st * sizeof(double), sizeof(double), (size_t)B, hipMemcpyDeviceToHost));
+    return 0;
+}

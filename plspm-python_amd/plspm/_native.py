@@ -21,7 +21,7 @@ KERNELS = {"resample": 0, "gram": 1, "solver": 2, "scores": 3, "pack": 4, "reduc
 EXPORTS = ["plspm_abi_version", "plspm_device_count", "plspm_last_error", "plspm_model_create", "plspm_model_destroy", "plspm_model_set_nonmetric", "plspm_model_set_categorical", "plspm_model_set_missing", "plspm_model_attach_second_stage", "plspm_model_set_incomplete_rows",
            "plspm_upload", "plspm_effect_pairs", "plspm_row_width", "plspm_row_stride", "plspm_fit", "plspm_bootstrap", "plspm_bootstrap_device", "plspm_bootstrap_summary",
            "plspm_sync", "plspm_stream", "plspm_bootstrap_indices", "plspm_profile_enable", "plspm_profile_read", "plspm_profile_reset",
-           "plspm_model_set_option", "plspm_model_get_option", "plspm_bootstrap_moments", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
+           "plspm_model_set_option", "plspm_model_get_option", "plspm_bootstrap_moments", "plspm_nonmetric_criteria", "plspm_bootstrap_fetch", "plspm_bootstrap_store", "plspm_rccl_unique_id", "plspm_comm_create", "plspm_comm_destroy",
            "plspm_comm_size", "plspm_comm_uses_rccl", "plspm_group_create", "plspm_group_destroy", "plspm_group_last_error", "plspm_group_size",
            "plspm_group_shard", "plspm_group_bootstrap", "plspm_group_sync", "plspm_group_records", "plspm_group_summary", "plspm_group_rows", "plspm_group_adopt", "plspm_bootstrap_prepare",
            "plspm_group_barrier", "plspm_group_max", "plspm_group_enqueue_times", "plspm_release_cached_memory",
@@ -107,6 +107,7 @@ def load():
     lib.plspm_model_get_option.restype = ctypes.c_int
     lib.plspm_bootstrap_fetch.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.plspm_bootstrap_moments.argtypes = [vp, i64, u64, i64, vp, vp]
+    lib.plspm_nonmetric_criteria.argtypes = [vp, i64, vp]
     lib.plspm_bootstrap_store.argtypes = [vp, vp, i64]
     lib.plspm_bootstrap_prepare.argtypes = [vp]
     lib.plspm_rccl_unique_id.argtypes = [vp]
@@ -325,6 +326,12 @@ class NativeModel:
         C = self.n_upload_cols + 1
         out = np.empty((B, C, C))
         self._check(self._lib.plspm_bootstrap_moments(self._h, B, seed, rep_offset, _ptr(idx), _ptr(out)), "plspm_bootstrap_moments")
+        return out
+
+    def nonmetric_criteria(self, B):
+        """Test seam (plspm_nonmetric_criteria): the stop-rule value each of the first B problems of the last non-metric run was decided on."""
+        out = np.empty(B)
+        self._check(self._lib.plspm_nonmetric_criteria(self._h, B, _ptr(out)), "plspm_nonmetric_criteria")
         return out
 
     def prepare_bootstrap(self):

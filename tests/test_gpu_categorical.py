@@ -235,6 +235,42 @@ def test_stop_rule_pass_on_category_codes_gives_the_dense_pass_bits(scale):
     assert_close(rows[r], mine, RTOL, ATOL)
 
 
+@pytest.mark.parametrize("scale,scheme", [("ORD", "path"), ("NOM", "centroid"), ("ORD", "factorial")])
+def test_stop_rule_pass_as_int8_matrix_product(scale, scheme):
+    """kernels_nmp.h (round 5): the score-based stop rule (weights.py:120) of all-indicator models as an exact int8 MFMA product -- indicator bytes x
+    seven base-256 digit planes of the score maps, the digits put together again per (row, replicate).  Held against the pass on category codes
+    ("nm_mfma" 0) on the VALUE of the criterion every replicate was decided on (test seam plspm_nonmetric_criteria: agreement far below anything a
+    decision could see), on the iteration counts and -- the pass only decides when to stop -- on the bits of the records; and against the oracle.
+    1,500 rows (the last tile holds pad rows, 94 tiles cut into row chunks), uneven category counts, replicates that lose categories."""
+    from plspm import _native
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(1500, C, 10, seed=53)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+    likert[:, ::3] = np.clip(likert[:, ::3], 2, 4)
+    model = orc.Model(blocks, C, "AAAAAA", scheme, True, tol=1e-6, scales=[scale] * 60)
+    nm, g = gpu_fit_cat(likert, model)
+    assert nm.get_option("nm_mfma") == 1
+    on = nm.bootstrap(330, seed=8)
+    assert nm.get_option("last_nm_mfma") == 1 and nm.get_option("last_nm_codes") == 1 and nm.get_option("last_gram_path") == 2
+    crit_on = nm.nonmetric_criteria(330)
+    nm.set_option("nm_mfma", 0)
+    off = nm.bootstrap(330, seed=8)
+    assert nm.get_option("last_nm_mfma") == 0 and nm.get_option("last_nm_codes") == 1
+    crit_off = nm.nonmetric_criteria(330)
+    nm.set_option("nm_mfma", 1)
+    assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2])
+    assert np.array_equal(on[0], off[0])
+    assert np.all(np.isfinite(crit_off)) and np.all(crit_off > 0) and np.all(crit_off[on[1] == 0] < 1e-6)
+    assert_close(crit_on, crit_off, 1e-9, 1e-20)
+    rows = _rows_in_data_order(on[0], g["inv"], 60, 6, nm.n_eff)
+    ok = np.flatnonzero(on[1] == 0)
+    for r in (int(ok[0]), int(ok[-1])):
+        mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(8, r, 1500), orc.correction(1500))
+        assert its == on[2][r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+
+
 @pytest.mark.parametrize("case", ["likert60_path", "likert60_nom_centroid", "chain8_factorial", "tiny_blocks", "eight_categories"])
 def test_wave_step_agrees_with_the_workgroup_step(case):
     """kernels_nmw.h (round 5): the categorical iteration as ONE WAVE per problem -- count matrix streamed 16 bytes per lane and row, the pooling

@@ -31,6 +31,7 @@ m = _native.NativeModel(np.array(boff, dtype=np.int32), C.astype(np.uint8), np.z
                         categorical=(np.array(mv_off, dtype=np.int32), np.ones(60, dtype=np.int32)))
 m.upload(Xaug)
 if "CAT_NM_WAVE" in os.environ: m.set_option("nm_wave", int(os.environ["CAT_NM_WAVE"]))        # A/B: 0 = the workgroup step of rounds 2-4 (nmg_kernel<1>)
+if "CAT_NM_MFMA" in os.environ: m.set_option("nm_mfma", int(os.environ["CAT_NM_MFMA"]))      # A/B: 0 = the stop-rule pass on category codes (LDS lookups) instead of the int8 matrix product
 if "CAT_NM_CODES" in os.environ: m.set_option("nm_codes", int(os.environ["CAT_NM_CODES"]))      # A/B: 0 = the stop-rule pass as multiply-adds over the 0/1 columns
 t0 = time.perf_counter(); fit = m.fit(want_scores=False); t_fit = time.perf_counter() - t0
 m.bootstrap_device(B, seed=1); m.sync()
@@ -43,6 +44,6 @@ dt = (time.perf_counter() - t0) / steps
 rows, status, iters = m.bootstrap(32, seed=1)
 k = {n: m.profile_read(n) for n in ("resample", "gram", "solver", "scores")}
 print(json.dumps({"workload": "categorical (Scale.ORD, 5-point) 10k x 60 MVs (300 indicator columns) x 6, Mode A, PATH, %d replicates per step" % B,
-                  "replicates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "step_kernel": ("nmw_step_kernel (one wave per problem)" if m.get_option("last_nm_wave") else "nmg_kernel<1> (workgroup)"), "stop_rule_pass": ("category codes" if m.get_option("last_nm_codes") else "multiply-adds over the indicator columns"), "fit_iterations": fit["iterations"], "fit_status": fit["status"],
+                  "replicates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "step_kernel": ("nmw_step_kernel (one wave per problem)" if m.get_option("last_nm_wave") else "nmg_kernel<1> (workgroup)"), "stop_rule_pass": ("int8 matrix product (indicator bytes x digit planes of the score maps)" if m.get_option("last_nm_mfma") else "category codes" if m.get_option("last_nm_codes") else "multiply-adds over the indicator columns"), "fit_iterations": fit["iterations"], "fit_status": fit["status"],
                   "fit_wall_ms": round(t_fit * 1e3, 2), "replicate_iterations": [int(iters.min()), int(iters.max())], "all_ok": bool(np.all(status == 0)),
                   "kernel_ms_per_step": {n: round(v[0] / steps, 3) for n, v in k.items()}}))
