@@ -63,7 +63,7 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
 size_t nm_state_doubles_of(const plspm_model* m);
 size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out);
 int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so_in, const int2* ent, const int* nent, long ent_stride, int threads,
-                  bool finish = true, const void* cd8 = nullptr, int cd8_MT = 0);
+                  bool finish = true, const void* cd8 = nullptr, int cd8_MT = 0, bool counts16_ready = false);
 // second-stage moments of a HOC pair by congruence with the first stage's score maps: m->gram (stage 1) -> m2->gram
 int run_hoc_moments(plspm_model* m, plspm_model* m2, long nb);
 
@@ -75,4 +75,5 @@ int choose_gram_path(const plspm_model* m, int64_t B);      // 1 fp64 MFMA on (r
 int prepare_zs_stats(plspm_model* m);
 int prepare_zs(plspm_model* m);
 int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback, const void** counts = nullptr,
-                int* counts_MT = nullptr);
+                int* counts_MT = nullptr, unsigned short* out16 = nullptr, bool* wrote16 = nullptr);
+bool nm_wave_step_planned(const plspm_model* m);      // plspm_nonmetric.hip: the categorical iteration of this handle runs one wave per problem (kernels_nmw.h)

@@ -549,6 +549,31 @@ gram_i8_kernel(const uint4* __restrict__ Cd, const uint4* __restrict__ Zs, int K
     if constexpr (IND) {
         static_assert(!IND || SH == 16, "independent planes: 16x16x64 layout");
         const long rep0 = (long)ty * (16 * RT) + wm * (MTW * 16) + (lane >> 4) * 4;
+        if (nty_short < 0) {
+            // round 5 (IND launches only; they have no short tile rows): the sums ARE co-occurrence counts -- they leave as uint16, upper triangle of the
+            // replicate's [C x ld16] count matrix (pair_dst: p ld16 + q; `gram` / `psize` in uint16 units), the layout the categorical wave step streams
+            // (kernels_nmw.h): a quarter of the bytes of the fp64 slots, 16 consecutive pairs of a replicate = one 32-byte run, and no scatter pass
+            // behind the product (nmg_kernel<3>: 0.4-0.5 ms per 1,000 problems); the lower triangle is mirrored by nmg_kernel<4>
+            unsigned short* g16 = reinterpret_cast<unsigned short*>(gram);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int js = ((tx * 2 + wn) * S + s) * 16 + (lane & 15);
+                if (js >= npair) continue;
+                const double scs = pair_scale[js];
+                unsigned short* gp = g16 + rep0 * psize + pair_dst[js];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (rep0 + mt * 16 + reg < nrep) *gp = (unsigned short)__double2int_rn((double)acc[mt][s][reg] * scs);
+                        gp += psize;
+                        asm volatile("" : "+v"(gp)::"memory");
+                    }
+                    gp += 12 * psize;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int js = ((tx * 2 + wn) * S + s) * 16 + (lane & 15);          // plane s of this wave = pair group (2 tx + wn) S + s of the buffer

@@ -88,8 +88,13 @@ __global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ g
 
 // value of the S digit sums of one (row, replicate) in units of the last digit: three planes at a time in int32 (|sum of <= 64 digits| <= 2^13, so
 // ((d0 256) + d1) 256 + d2 stays below 2^30), then two fp64 multiply-adds -- the first exact (< 2^53), the second rounds once
+__device__ __forceinline__ int shl8_add(int hi, int lo) {      // 256 hi + lo as ONE v_lshl_add_u32: the empty statement keeps the compiler from re-associating three planes into two
+    int r = (int)(((unsigned)hi << 8) + (unsigned)lo);          // shifts + v_add3_u32.  (No instruction in the asm: the hazard recogniser does not see inline asm as a reader of
+    asm("" : "+v"(r));                                         // MFMA results -- a real v_lshl_add_u32 written as asm read the digit sums too early.)
+    return r;
+}
 __device__ __forceinline__ double digits_value(int d0, int d1, int d2, int d3, int d4, int d5, int d6) {
-    const int i0 = (d0 * 256 + d1) * 256 + d2, i1 = (d3 * 256 + d4) * 256 + d5;
+    const int i0 = shl8_add(shl8_add(d0, d1), d2), i1 = shl8_add(shl8_add(d3, d4), d5);
     return fma(fma((double)i0, 16777216.0, (double)i1), 256.0, (double)d6);
 }
 

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     if (extra_in_lds) {
         nmg_carve_fast(x, xg, state + nm_state_doubles(Q, L, 0), lp, Q, cd.Pm, L, cd.cmax, cd.kmv);
         lp += (nmg_fast_doubles(Q, cd.Pm, L, cd.cmax, cd.kmv) + 1) & ~1L;
-        if (MODE != 0 && MODE != 3) {
+        if (MODE != 0 && MODE != 3 && MODE != 4) {
             const long np = nmg_persistent_doubles(Q, cd.Pm, L);
             for (long i = threadIdx.x; i < np; i += blockDim.x) x.tq[i] = xg.tq[i];
             __syncthreads();
@@ -90,7 +90,42 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
     stage_descriptors(md, lp);
     DevExec ex{(int)threadIdx.x, (int)blockDim.x, ws.red, (b == 0) ? so.marks : nullptr};
     bool finish_now = (MODE == 2);
-    if (MODE == 3) {
+    if constexpr (MODE == 4) {
+        // round 5: the int8 product wrote the UPPER triangle of the uint16 count matrix itself (gram_i8_kernel<.., IND>, nty_short < 0): mirror it -- tiles of
+        // 64 x 64 counts through LDS, 16-byte loads and stores on both sides -- then the initial state; no packed fp64 matrix exists (Mp is null)
+        __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
+        const int C = Q + 1, nt = (C + 63) >> 6, tid = threadIdx.x;
+        unsigned short* K = x.k16;
+        for (int ti = 0; ti < nt; ++ti)
+            for (int tj = ti; tj < nt; ++tj) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                     // tile (ti, tj): 64 rows x 8 groups of 8 counts
+                    const int e = tid + 256 * h, r = e >> 3, cg = e & 7;
+                    const int row = ti * 64 + r, col = tj * 64 + cg * 8;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (row < C && col < ld16) v = *reinterpret_cast<const uint4*>(K + (long)row * ld16 + col);
+                    *reinterpret_cast<uint4*>(&tile[r][cg * 8]) = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                     // its transpose into tile (tj, ti); on the diagonal: below the diagonal only
+                    const int e = tid + 256 * h, r = e >> 3, cg = e & 7;
+                    const int row = tj * 64 + r, col = ti * 64 + cg * 8;
+                    if (row < C && col < ld16) {
+                        unsigned short w[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int c = cg * 8 + u; w[u] = (ti != tj || c < r) ? tile[c][r] : tile[r][c]; }
+                        uint4 v;
+                        v.x = (unsigned)w[0] | ((unsigned)w[1] << 16); v.y = (unsigned)w[2] | ((unsigned)w[3] << 16);
+                        v.z = (unsigned)w[4] | ((unsigned)w[5] << 16); v.w = (unsigned)w[6] | ((unsigned)w[7] << 16);
+                        *reinterpret_cast<uint4*>(K + (long)row * ld16 + col) = v;
+                    }
+                }
+                __syncthreads();
+            }
+        ws.S = nullptr;
+        nmg_prepare(ex, md, cd, ws, st, x, (const double*)nullptr);
+    } else if (MODE == 3) {
         // prepare alone, and only what the wave step reads (kernels_nmw.h): the uint16 counts + the initial state -- no fp64 copy of the matrix
         // (730 KB written per problem at 300 indicator columns, which the wave step and its fused finish never open)
         ws.S = nullptr;

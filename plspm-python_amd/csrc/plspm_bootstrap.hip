@@ -81,6 +81,10 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if (!m->err_clean || may_raise) HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
     m->err_clean = !may_raise;
     double* const gram_buf = (double*)m->gram.p;
+    // round 5: all-indicator categorical models on the wave step -- the int8 product writes the uint16 count matrices the step streams itself (no fp64 slots, no
+    // scatter pass: kernels_gram_i8.h IND epilogue, kernels_nonmetric.h nmg_kernel<4>); option "nm_direct16" 0: the packed fp64 matrices + nmg_kernel<3>
+    const bool want16 = gpath == 2 && m->nonmetric && !m->stage2 && !m->stage1 && !m->moments_out && m->tune.nm_direct16 != 0 && nm_wave_step_planned(m);
+    if (want16 && (rc = ensure(m, m->gK16, (size_t)chunk * (m->P + 1) * ((m->P + 1 + 7) & ~7) * sizeof(unsigned short)))) return rc;
     hipEvent_t parked_stop = m->stop_event;
     m->stop_event = nullptr;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
@@ -89,9 +93,11 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         bool f64_gram = gpath == 1;
         const void* cd8 = nullptr;
         int cd8_MT = 0;
+        bool wrote16 = false;
         if (gpath == 2) {
             bool fallback = false;
-            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback, &cd8, &cd8_MT))) return rc;
+            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback, &cd8, &cd8_MT,
+                                  want16 ? (unsigned short*)m->gK16.p : nullptr, &wrote16))) return rc;
             f64_gram = fallback;
         }
         if (!counts8_plan || f64_gram) cd8 = nullptr;                  // (a chunk that fell back has no usable int8 counts)
@@ -138,7 +144,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             // columns 21.0 / 13.5 / 10.0 ms)
             const int nm_threads = m->tune.nm_threads > 0 ? m->tune.nm_threads : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));
             if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, so, (need_lists && !cd8) ? (const int2*)m->ent.p : nullptr, (need_lists && !cd8) ? (const int*)m->nent.p : nullptr, ent_stride,
-                                    nm_threads, true, cd8, cd8_MT))) return rc;
+                                    nm_threads, true, cd8, cd8_MT, wrote16))) return rc;
             continue;
         }
         if ((rc = launch_batch_solver(m, nb, rows_solver && !f64_gram, so))) return rc;

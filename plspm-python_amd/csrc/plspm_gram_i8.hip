@@ -85,15 +85,16 @@ int prepare_zs_stats(plspm_model* m) {
     if (m->zs_valid || m->zs_stats_ready) return 0;
     const int C = m->Pg + 1;
     const long npair = i8_pairs(m);
-    std::vector<int> tab(6 * (size_t)npair);
-    int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | packed slot | dense slot | mirrored dense slot]
-    int* hd1 = hd + npair; int* hd2 = hd1 + npair;
-    const int PSd = cov_ld(m->Pg);
+    std::vector<int> tab(7 * (size_t)npair);
+    int* hp = tab.data(); int* hq = hp + npair; int* hd = hq + 2 * npair;       // [p | q | k (device) | packed slot | dense slot | mirrored dense slot | uint16 count-matrix slot]
+    int* hd1 = hd + npair; int* hd2 = hd1 + npair; int* hd16 = hd2 + npair;
+    const int PSd = cov_ld(m->Pg), ld16 = (C + 7) & ~7;                          // (ld16: the pitch of run_nonmetric's uint16 count matrices)
     long j = 0;
     for (int p = 0; p < C; ++p)
         for (int q = p; q < C; ++q, ++j) {
             hp[j] = p; hq[j] = q; hd[j] = (int)packed_index(m->T, p, q);
             hd1[j] = p * PSd + q; hd2[j] = (p == q) ? -1 : q * PSd + p;
+            hd16[j] = p * ld16 + q;
         }
     int rc;
     if ((rc = ensure(m, m->pair_tab, tab.size() * sizeof(int)))) return rc;
@@ -226,10 +227,13 @@ static bool i8_mix_plan(long ct, long ntx, int cus, bool mix, int* tall, int* sh
 // Resample nb replicates into dense int8 counts and multiply with the digit planes: the nb moment matrices land at `out`.
 // Explicit indices can carry a multiplicity above 127 (Philox draws of N >= 128 rows cannot, P < 1e-200): the host looks at the
 // flag before the product and reports *fallback so that the caller takes the fp64 Gram for this chunk.
+// out16 (round 5, may be null): where an all-indicator data set's products -- co-occurrence counts -- may leave as uint16 [nb][C][ld16], upper triangle, instead
+// of fp64 slots at `out`; *wrote16 tells whether this call did (the one-plane launch on 0/1 data; any other launch writes `out` as ever).
 int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback,
-                const void** counts, int* counts_MT) {
+                const void** counts, int* counts_MT, unsigned short* out16, bool* wrote16) {
     *fallback = false;
     if (counts) *counts = nullptr;
+    if (wrote16) *wrote16 = false;
     const int S = m->zs_S, KB = m->zs_KB, NT = m->zs_NT;
     // workgroup tile of the product: 16 RT replicates x 32 pairs; narrow tiles (RT 12 / 8) only in the plain four-wave 16x16x64 launch
     // Six planes leave registers for a taller workgroup tile: 320 replicates x 32 pairs (`RT` 20: 30 accumulator tiles per wave with eight
@@ -340,12 +344,14 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     if (counts && m->tune.i8_shape == 16) { *counts = cd.p; *counts_MT = MT; }       // (16-row pieces: what nm_conv_dense_kernel<.., CNT8> reads)
     const int total = ntx * nty, per = rows2 ? (ntx * nty_tall + 7) / 8 + (ntx * nty_short + 7) / 8 : (total + 7) / 8;      // workgroups per XCD
     // packed: the tile-packed slots the LDS solver / impute kernel read; dense: [(Pg+1) x cov_ld(Pg)] row-major, upper triangle (rows solver)
-    const int* d_dst = (const int*)m->pair_tab.p + (dense ? 4 : 3) * (size_t)m->zs_npair;
+    const bool to16 = out16 && wrote16 && ind && m->tune.i8_shape == 16;
+    const int* d_dst = (const int*)m->pair_tab.p + (to16 ? 6 : (dense ? 4 : 3)) * (size_t)m->zs_npair;
     // (a mirrored second store per element cost 0.08 ms per 5,000 replicates of the metric benchmark: the rows solver reads the triangle
     //  instead.  Categorical problems, whose solver wants the full square: Gram 1.40 -> 2.07 ms per 1,000 problems with the mirrored
     //  stores against 0.4 ms saved in nmg_prepare's scatter -- not taken either)
     const int* d_dst2 = nullptr;
-    const long out_stride = dense ? cov_doubles(m->Pg) : packed_size(m->T);
+    const long out_stride = to16 ? (long)(m->Pg + 1) * ((m->Pg + 1 + 7) & ~7) : (dense ? cov_doubles(m->Pg) : packed_size(m->T));
+    if (to16) { out = reinterpret_cast<double*>(out16); *wrote16 = true; }
     // persistent stream-K schedule (kernels_gram_i8.h gram_i8_sk_kernel): one workgroup per CU, whole CUs per XCD
     const bool sk = m->tune.i8_sched == 1 && m->tune.i8_shape == 16 && m->tune.i8_variant < 0 && S >= 5 && S <= 7;      // (S = 8 spills in the persistent kernel)
     int sk_grid = 0;
@@ -472,7 +478,7 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
         const size_t lds_bytes = GramI8<7, WW, VV, 16, 16>::LDS_BYTES;                                                                       \
         if ((rc = allow_lds(m, (const void*)gram_i8_kernel<7, WW, VV, 16, 16, true>, lds_bytes))) return rc;                                 \
         hipLaunchKernelGGL((gram_i8_kernel<7, WW, VV, 16, 16, true>), dim3((unsigned)(8 * per)), dim3(128 * WW), lds_bytes, m->stream, (const uint4*)cd.p, \
-                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, 0); \
+                           (const uint4*)m->zs.p, KB, MT, NT, ntx, nty, d_dst, d_dst2, (const double*)m->pair_scale.p, m->zs_npair, (long)nb, out, out_stride, to16 ? -1 : 0); \
     }
     if (ind) {                   // one plane per pair group, seven groups per wave
 #ifdef PLSPM_I8_EXPERIMENTS

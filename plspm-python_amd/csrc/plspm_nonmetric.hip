@@ -32,9 +32,19 @@ size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out) {
     return (use <= kMaxLds && m->tune.conv_pass != 1) ? use : 0;
 }
 
+// round 5: the iteration as one WAVE per problem (kernels_nmw.h nmw_step_kernel) for all-indicator models of at most 65,535 rows whose blocks are all Mode A,
+// of at most 64 MVs with at most 8 categories each, 8 LVs and 511 indicator columns
+bool nm_wave_step_planned(const plspm_model* m) {
+    if (!m->categorical || !m->cat_pure || m->nmx_K > 0 || m->N > 65535 || m->tune.nm_k16 == 0 || m->tune.nm_wave == 0) return false;
+    for (int l = 0; l < m->L; ++l) if (m->mode[l] != PLSPM_MODE_A) return false;
+    const size_t wave_lds = (size_t)nmw::lds_doubles(m->P, m->Pm, m->L, m->kmax) * sizeof(double);
+    return m->Pm <= 64 && m->L <= nmw::LMAX_MAX && m->cmax <= nmw::CMAX && m->P + 1 <= 512 && wave_lds <= kMaxLds;
+}
+
 // cd8 / cd8_MT: the int8 row multiplicities of THESE problems (the counts the digit-plane Gram consumed; bootstrap only), or null
+// counts16_ready: the upper triangles of the problems' uint16 count matrices are in m->gK16 already (run_gram_i8 wrote them: no packed matrices at Mp)
 int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so_in, const int2* ent, const int* nent,
-                         long ent_stride, int threads, bool finish, const void* cd8, int cd8_MT) {
+                         long ent_stride, int threads, bool finish, const void* cd8, int cd8_MT, bool counts16_ready) {
     SolverOut so = so_in;
     const int P = m->P, L = m->L;
     plspm_model* src = m->stage1 ? m->stage1 : m;                // an attached second stage streams its first stage's data (solver_hoc.h)
@@ -93,7 +103,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const long ng16 = (nproblems + 15) / 16;
     int tpc = 0;
     if (use_mfma) {
-        const long want = std::max<long>(1, std::min<long>((4096 + ng16 - 1) / ng16, (ntiles16 + 7) / 8));
+        const long waves = m->tune.conv_gy > 0 ? (long)m->tune.conv_gy * 256 : 8192;      // (option conv_gy n: n x 256 waves aimed at; 4,096 / 8,192 / 16,384 measured 4.45 / 3.90 / 3.88 ms of passes per 5,000-replicate step)
+        const long want = std::max<long>(1, std::min<long>((waves + ng16 - 1) / ng16, (ntiles16 + 7) / 8));
         tpc = (int)((ntiles16 + want - 1) / want);
         nparts = (int)((ntiles16 + tpc - 1) / tpc);
         if (!m->ind8_valid) {
@@ -114,13 +125,11 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     // all-indicator categorical models of at most 65,535 rows: a uint16 copy of every problem's count matrix for the streaming product of the step
     const int ld16 = (P + 1 + 7) & ~7;                           // (whole 16-byte groups: the wave step loads eight counts per lane and row)
     const bool k16 = cat && m->cat_pure && N <= 65535 && m->tune.nm_k16 != 0;
-    // round 5: the iteration as one WAVE per problem (kernels_nmw.h nmw_step_kernel) for all-indicator models whose blocks are all Mode A, of at most
-    // 64 MVs with at most 8 categories each, 8 LVs and 511 indicator columns; prepare (launch 0) and finish stay nmg_kernel<0> / <2>
-    bool all_mode_a = true;
-    for (int l = 0; l < L; ++l) if (m->mode[l] != PLSPM_MODE_A) all_mode_a = false;
     const size_t wave_lds = (size_t)nmw::lds_doubles(P, m->Pm, L, m->kmax) * sizeof(double);
-    const bool wave_step = k16 && all_mode_a && !nmx && m->Pm <= 64 && L <= nmw::LMAX_MAX && m->cmax <= nmw::CMAX && P + 1 <= 512 && m->tune.nm_wave != 0 && wave_lds <= kMaxLds;
+    const bool wave_step = k16 && nm_wave_step_planned(m);
+    if (counts16_ready && !wave_step) return fail(m, PLSPM_E_STATE, "non-metric solver: uint16 counts without the wave step");
     m->last_nm_wave = wave_step ? 1 : 0;
+    m->last_nm_direct16 = counts16_ready ? 1 : 0;
     // the fp64 square of every problem (730 KB at 300 indicator columns): not for the wave step, which reads the uint16 counts only
     if (!wave_step && (rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
     if (k16 && (rc = ensure(m, m->gK16, (size_t)nproblems * (P + 1) * ld16 * sizeof(unsigned short)))) return rc;
@@ -135,7 +144,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     if (cat_fast) lds += cat_fast_bytes;
     if (cat) {
         if ((rc = allow_lds(m, (const void*)nmg_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<2>, lds)) ||
-            (rc = allow_lds(m, (const void*)nmg_kernel<3>, lds)))
+            (rc = allow_lds(m, (const void*)nmg_kernel<3>, lds)) || (rc = allow_lds(m, (const void*)nmg_kernel<4>, lds)))
             return rc;
     } else if (nmx) {
         if ((rc = allow_lds(m, (const void*)nmx_kernel<0>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<1>, lds)) || (rc = allow_lds(m, (const void*)nmx_kernel<2>, lds)))
@@ -191,8 +200,14 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
             // prepare: the uint16 counts + the initial state only (nmg_kernel<3>); every step, the first one included, one wave per problem; the
             // finish of a problem inside the launch that decides its stop
             ProfScope ps(m, PLSPM_K_SOLVER);
-            if (it == 0) hipLaunchKernelGGL(nmg_kernel<3>, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
-                                            0, cat_fast, (unsigned short*)m->gK16.p, ld16);
+            if (it == 0) {
+                if (counts16_ready)       // the Gram wrote the upper triangles: mirror them, set the initial state (no packed fp64 matrix exists)
+                    hipLaunchKernelGGL(nmg_kernel<4>, grid, dim3(256), lds, m->stream, md, cd, mdm, (const double*)nullptr, 0L, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                                       0, cat_fast, (unsigned short*)m->gK16.p, ld16);
+                else
+                    hipLaunchKernelGGL(nmg_kernel<3>, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                                       0, cat_fast, (unsigned short*)m->gK16.p, ld16);
+            }
             hipLaunchKernelGGL(wave_kernel, grid, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
                                (const unsigned short*)m->gK16.p, ld16, fuse);
         } else

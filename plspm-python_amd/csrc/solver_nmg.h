@@ -228,8 +228,9 @@ PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Worksp
     const int ntile = T * (T + 1) / 2;
     // n = <1, 1> first (one uniform load): the scatter then writes the scaled entries -- and the uint16 copy of the counts -- in the same
     // pass (a separate scaling pass re-read and re-wrote the whole square: 1.4 MB of traffic per problem)
-    const double n = Mp[packed_index(T, Q, Q)], inv_n = 1.0 / n;
-    ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
+    // (Mp null: the uint16 count matrix is complete already -- the int8 product wrote it, nmg_kernel<4> mirrored it: only the pitch padding and the state are left)
+    const double n = Mp ? Mp[packed_index(T, Q, Q)] : (double)x.k16[(long)Q * x.ld16 + Q], inv_n = 1.0 / n;
+    if (Mp) ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {
         const int tile = chunk >> 2, r = chunk & 3;
         int t, u;
         if (md.tile_tu) { const int tu = md.tile_tu[tile]; t = tu & 255; u = tu >> 8; }

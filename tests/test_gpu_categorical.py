@@ -271,6 +271,40 @@ def test_stop_rule_pass_as_int8_matrix_product(scale, scheme):
         assert_close(rows[r], mine, RTOL, ATOL)
 
 
+@pytest.mark.parametrize("shape", ["likert60", "chain3"])
+def test_count_matrices_written_by_the_int8_product(shape):
+    """Round 5: on all-indicator data the int8 product's sums ARE the co-occurrence counts the wave step streams -- the one-plane launch writes them as uint16
+    (upper triangle; nmg_kernel<4> mirrors it through LDS) instead of fp64 slots that a scatter pass re-reads ("nm_direct16" 0: that path).  Same integers,
+    so the records are the same bits.  301 / 49 count columns: five tiles of 64 with a ragged last one / a single ragged tile."""
+    if shape == "likert60":
+        C = orc.satisfaction_C()
+        X, blocks = orc.synth(1500, C, 10, seed=59)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+        model = orc.Model(blocks, C, "AAAAAA", "path", True, tol=1e-6, scales=["ORD"] * 60)
+    else:
+        C = orc.chain_C(3)
+        X, blocks = orc.synth(900, C, 4, seed=61)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        likert = np.clip(np.round(2.5 + 0.9 * Z), 1, 4)
+        model = orc.Model(blocks, C, "AAA", "factorial", True, tol=1e-6, scales=["NOM"] * 12)
+    from plspm import _native
+    nm, g = gpu_fit_cat(likert, model)
+    assert nm.get_option("nm_direct16") == 1
+    on = nm.bootstrap(300, seed=10)
+    assert nm.get_option("last_nm_direct16") == 1 and nm.get_option("last_nm_wave") == 1 and nm.get_option("last_gram_path") == 2
+    nm.set_option("nm_direct16", 0)
+    off = nm.bootstrap(300, seed=10)
+    assert nm.get_option("last_nm_direct16") == 0 and nm.get_option("last_nm_wave") == 1
+    nm.set_option("nm_direct16", 1)
+    assert np.all(on[1] == 0)
+    assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2]) and np.array_equal(on[0], off[0])
+    # explicit index lists take the same route (a multiplicity above 127 would fall back to the fp64 Gram: not here)
+    idx = np.stack([_native.bootstrap_indices(10, r, likert.shape[0]) for r in range(40)])
+    ex = nm.bootstrap(40, idx=idx)
+    assert np.array_equal(ex[0], on[0][:40]) and np.array_equal(ex[2], on[2][:40])
+
+
 @pytest.mark.parametrize("case", ["likert60_path", "likert60_nom_centroid", "chain8_factorial", "tiny_blocks", "eight_categories"])
 def test_wave_step_agrees_with_the_workgroup_step(case):
     """kernels_nmw.h (round 5): the categorical iteration as ONE WAVE per problem -- count matrix streamed 16 bytes per lane and row, the pooling

@@ -32,6 +32,8 @@ m = _native.NativeModel(np.array(boff, dtype=np.int32), C.astype(np.uint8), np.z
 m.upload(Xaug)
 if "CAT_NM_WAVE" in os.environ: m.set_option("nm_wave", int(os.environ["CAT_NM_WAVE"]))        # A/B: 0 = the workgroup step of rounds 2-4 (nmg_kernel<1>)
 if "CAT_NM_MFMA" in os.environ: m.set_option("nm_mfma", int(os.environ["CAT_NM_MFMA"]))      # A/B: 0 = the stop-rule pass on category codes (LDS lookups) instead of the int8 matrix product
+if "CAT_NM_DIRECT16" in os.environ: m.set_option("nm_direct16", int(os.environ["CAT_NM_DIRECT16"]))      # A/B: 0 = packed fp64 moment matrices + the scatter pass (nmg_kernel<3>)
+if "CAT_CONV_GY" in os.environ: m.set_option("conv_gy", int(os.environ["CAT_CONV_GY"]))      # waves the matrix-product pass aims at, in units of 256
 if "CAT_NM_CODES" in os.environ: m.set_option("nm_codes", int(os.environ["CAT_NM_CODES"]))      # A/B: 0 = the stop-rule pass as multiply-adds over the 0/1 columns
 t0 = time.perf_counter(); fit = m.fit(want_scores=False); t_fit = time.perf_counter() - t0
 m.bootstrap_device(B, seed=1); m.sync()

@@ -1,5 +1,6 @@
 // Micro-benchmark: issue cost of the 32-bit integer multiplies Philox4x32 is made of, one wave, 64 independent instructions between two
-// s_memtime reads: v_mul_lo_u32, v_mul_hi_u32, v_mad_u64_u32 (both halves of the product in one instruction), v_xor_b32 for scale.
+// s_memtime reads: v_mul_lo_u32, v_mul_hi_u32, v_mad_u64_u32 (both halves of the product in one instruction), v_xor_b32 for scale; round 5: the conversions and integer
+// combines of the digit-plane epilogue (kernels_nmp.h): v_cvt_f64_i32 / _u32, v_lshl_add_u32, v_mad_i32_i24, v_add_f64, v_fma_f64.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/mul_issue.hip -o tools/ubench/mul_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,6 +20,15 @@ __global__ void __launch_bounds__(64) k(unsigned* out, long long* clk, unsigned 
             if (MODE == 0) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(r[j]) : "v"(a[j]), "v"(a[(j + 1) & 7]));
             else if (MODE == 1) asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(r[j]) : "v"(a[j]), "v"(a[(j + 1) & 7]));
             else if (MODE == 2) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w[j]) : "v"(a[j]), "v"(a[(j + 1) & 7]) : "vcc");
+            else if (MODE == 4) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(w[j]) : "v"(a[j]));
+            else if (MODE == 5) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(w[j]) : "v"(a[j]));
+            else if (MODE == 6) asm volatile("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(r[j]) : "v"(a[j]), "v"(a[(j + 1) & 7]));
+            else if (MODE == 7) asm volatile("v_add_f64 %0, %1, %1" : "=v"(w[j]) : "v"(w[(j + 1) & 7]));
+            else if (MODE == 8) asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(w[j]) : "v"(w[(j + 1) & 7]));
+            else if (MODE == 9) asm volatile("v_mad_i32_i24 %0, %1, %2, %1" : "=v"(r[j]) : "v"(a[j]), "v"(a[(j + 1) & 7]));
+            else if (MODE == 10) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(r[j]) : "v"(a[j]));
+            else if (MODE == 11) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(w[j]) : "v"(a[j]));
+            else if (MODE == 12) asm volatile("v_ldexp_f64 %0, %1, %2" : "=v"(w[j]) : "v"(w[(j + 1) & 7]), "v"(a[j]));
             else asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r[j]) : "v"(a[j]), "v"(a[(j + 1) & 7]));
         }
     asm volatile("s_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
@@ -38,4 +48,4 @@ template <int MODE> void run(const char* name) {
     printf("%-16s %5lld cycles per 64 instructions = %.1f each\n", name, best, best / 64.0);
     CK(hipFree(out)); CK(hipFree(clk));
 }
-int main() { run<3>("v_xor_b32"); run<0>("v_mul_lo_u32"); run<1>("v_mul_hi_u32"); run<2>("v_mad_u64_u32"); return 0; }
+int main() { run<4>("v_cvt_f64_i32"); run<5>("v_cvt_f64_u32"); run<6>("v_lshl_add_u32"); run<7>("v_add_f64"); run<8>("v_fma_f64"); run<9>("v_mad_i32_i24"); run<10>("v_cvt_f32_i32"); run<11>("v_cvt_f64_f32"); run<12>("v_ldexp_f64"); run<3>("v_xor_b32"); run<0>("v_mul_lo_u32"); run<1>("v_mul_hi_u32"); run<2>("v_mad_u64_u32"); return 0; }
