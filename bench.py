@@ -697,7 +697,8 @@ def main():
             line["fp64_mfma_path"] = other
         if pcie is not None:
             line["pcie_inclusive"] = {"value": round(pcie, 1), "unit": "replicates/s",
-                                      "sub_batches": _native.chunk_plan(B_total, 8 * model.row_stride, model.get_option("boot_chunks"), model.get_option("boot_ratio")),
+                                      "sub_batches": _native.chunk_plan(B_total, 8 * model.row_stride, model.get_option("boot_chunks"), model.get_option("boot_ratio"),
+                                                                           model.get_option("boot_align") or model.get_option("boot_round_units")),
                                       "note": "plspm_bootstrap(): the B x 158 records copied to the caller's (pageable, re-used) host buffers through pinned staging every step; "
                                               "round 5: the call runs as sub-batches, the download + unpacking of sub-batch k beside the kernels of k + 1"}
         if world == 1 and group is None and not args.no_api:

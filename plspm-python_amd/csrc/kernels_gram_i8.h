@@ -248,6 +248,86 @@ __global__ void __launch_bounds__(1024) resample_i8_kernel(int N, int KB, int MT
     if (over) atomicOr(err, 2);
 }
 
+// Round 5 -- FOUR-bit counters for Philox draws of data sets beyond one 16-bit window: N = 100,000 takes 50 KB of LDS instead of 100, so THREE workgroups
+// share a CU and one replicate's clear / read-out / 6,250 scattered stores run under its neighbours' draws (the byte histogram's single workgroup per CU
+// serialised them: 0.67-0.75 ms per 5,000 replicates, of which the generator is 0.11, tools/ubench/resample_rng.hip).  A count of 16 (P = 1.8e-14 per row
+// and replicate: once in ~10^5 calls of 5,000 x 100,000) carries into the neighbouring nibble -- and is FOUND: every carry lowers the sum of the nibbles by
+// 15 or 16, so "sum of the counts == draws that fell into the window" holds exactly when no counter overflowed.  The read-out accumulates that sum beside
+// its stores; a workgroup whose sum is short draws the replicate again with 8-bit counters, two half-windows in the same LDS, and overwrites its pieces
+// (`force_slow`: that path for every replicate -- tests).  Same draws, same layout, same bits as resample_i8_kernel.
+#define I8_HIST_KB_NIB 4096
+__device__ __forceinline__ unsigned nib_spread16(unsigned t) {      // four nibbles (bits 0 .. 15) -> four bytes
+    t = (t | (t << 8)) & 0x00ff00ffu;
+    return (t | (t << 4)) & 0x0f0f0f0fu;
+}
+__global__ void __launch_bounds__(1024) resample_i8_nib_kernel(int N, int KB, int MT, uint64_t seed, int64_t rep0, uint4* __restrict__ Cd, int* __restrict__ err, int force_slow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);      // KBw * 8 words: row 8 w + i of the window in nibble i of word w
+    __shared__ unsigned tot[2];                                   // [sum of the counts read out, draws that fell into the window]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const long b = blockIdx.x;
+    const int kb0 = (int)blockIdx.y * I8_HIST_KB_NIB, KBw = min(I8_HIST_KB_NIB, KB - kb0);
+    const unsigned r0 = (unsigned)kb0 * 64u, rspan = (unsigned)KBw * 64u;
+    const int nwords = KBw * 8;
+    const uint64_t rep = (uint64_t)(rep0 + b);
+    const int nq = (N + 3) >> 2;
+    const int mt = (int)(b >> 4), r = (int)(b & 15);
+    for (int i = tid; i < nwords; i += nthr) hist[i] = 0u;
+    if (tid < 2) tot[tid] = 0u;
+    __syncthreads();
+    unsigned inwin = 0u;
+    for (int q = tid; q < nq; q += nthr) {
+        const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * q + j < N) {
+                const unsigned w = to_index(u.v[j], (uint32_t)N) - r0;
+                if (w < rspan) { atomicAdd(&hist[w >> 3], 1u << (4u * (w & 7u))); ++inwin; }
+            }
+    }
+    __syncthreads();
+    unsigned seen = 0u;
+    const uint2* h2 = reinterpret_cast<const uint2*>(hist);
+    for (int c = tid; c < KBw * 4; c += nthr) {                     // piece c: rows 16 c .. 16 c + 15 of the window = words 2 c, 2 c + 1
+        const uint2 w = h2[c];
+        uint4 out;
+        out.x = nib_spread16(w.x & 0xffffu); out.y = nib_spread16(w.x >> 16); out.z = nib_spread16(w.y & 0xffffu); out.w = nib_spread16(w.y >> 16);
+        seen = __builtin_amdgcn_sad_u8(out.x, 0u, seen); seen = __builtin_amdgcn_sad_u8(out.y, 0u, seen);
+        seen = __builtin_amdgcn_sad_u8(out.z, 0u, seen); seen = __builtin_amdgcn_sad_u8(out.w, 0u, seen);
+        Cd[((long)(kb0 + (c >> 2)) * MT + mt) * 64 + (c & 3) * 16 + r] = out;
+    }
+    seen = wv::allsum(seen); inwin = wv::allsum(inwin);
+    if ((tid & 63) == 0) { atomicAdd(&tot[0], seen); atomicAdd(&tot[1], inwin); }
+    __syncthreads();
+    if (tot[0] == tot[1] && !force_slow) return;                    // (uniform over the workgroup)
+    // a counter overflowed: the replicate again, 8-bit counters, the window in two halves of KBw * 2 pieces (KBw * 32 rows) each
+    bool over = false;
+    for (int half = 0; half < 2; ++half) {
+        const unsigned h0 = (unsigned)half * (unsigned)KBw * 32u, hspan = min((unsigned)KBw * 32u, rspan - h0);
+        __syncthreads();
+        for (int i = tid; i < nwords; i += nthr) hist[i] = 0u;
+        __syncthreads();
+        for (int q = tid; q < nq; q += nthr) {
+            const u32x4 u = resample_quad(seed, rep, (uint32_t)q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < N) {
+                    const unsigned w = to_index(u.v[j], (uint32_t)N) - r0 - h0;
+                    if (w < hspan) atomicAdd(&hist[w >> 2], 1u << (8u * (w & 3u)));
+                }
+        }
+        __syncthreads();
+        const uint4* h4 = reinterpret_cast<const uint4*>(hist);
+        for (int c = tid; c < KBw * 2; c += nthr) {                 // piece KBw * 2 * half + c of the window
+            const uint4 out = h4[c];
+            over |= ((out.x | out.y | out.z | out.w) & 0x80808080u) != 0u;
+            const int cw = KBw * 2 * half + c;
+            Cd[((long)(kb0 + (cw >> 2)) * MT + mt) * 64 + (cw & 3) * 16 + r] = out;
+        }
+    }
+    if (over) atomicOr(err, 2);
+}
+
 // ---------------------------------------------------------------------------------------------- the GEMM
 // Workgroup tile: 256 replicates x 2 pair groups (32 pairs x S digit planes); 4 waves as 2 (replicate halves) x 2 (pair groups);
 // a wave keeps 8 x S accumulator tiles (S = 7: 224 AGPRs) -- one wave per SIMD, latency hidden inside the wave.

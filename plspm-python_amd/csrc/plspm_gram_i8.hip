@@ -3,6 +3,7 @@
 #include "host_internal.h"
 
 #include "philox.h"
+#include "wave_ops.h"
 #include "kernels_gram_i8.h"
 #include "kernels_gram_i8p.h"
 
@@ -287,13 +288,18 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     const int nty = rows2 ? nty_tall + nty_short : (int)((nb + 16 * RTg - 1) / (16 * RTg)), MT = rows2 ? nty_tall * RTtall + nty_short * RTshort : nty * RTg, ntx = ind ? m->zs_npg / 14 : m->zs_npg / 2;
     // resample counts from an LDS histogram per (replicate, window of rows): 65,536 rows of 16-bit counters, or -- Philox draws of a data
     // set that would need more than one such window -- 131,072 rows of 8-bit counters (kernels_gram_i8.h resample_i8_kernel)
+    // (round 5: 4-bit counters with an exact overflow test and an 8-bit second try, resample_i8_nib_kernel -- half the LDS again, three workgroups per CU at N = 100,000;
+    //  option "i8_nibbles" 0: the 8-bit histogram, 2: every replicate through the second try -- tests)
     const bool hist_byte = KB > I8_HIST_KB && !d_idx;
-    const int hist_kb = hist_byte ? I8_HIST_KB_BYTES : I8_HIST_KB;
-    const size_t hist_bytes = (size_t)std::min(KB, hist_kb) * (hist_byte ? 16 : 32) * sizeof(unsigned);
+    const bool hist_nib = hist_byte && m->tune.i8_nibbles != 0 && m->tune.i8_shape == 16;
+    const int hist_kb = hist_nib ? I8_HIST_KB_NIB : (hist_byte ? I8_HIST_KB_BYTES : I8_HIST_KB);
+    const size_t hist_bytes = (size_t)std::min(KB, hist_kb) * (hist_nib ? 8 : (hist_byte ? 16 : 32)) * sizeof(unsigned);
     const unsigned hist_windows = (unsigned)((KB + hist_kb - 1) / hist_kb);
     int rc;
-    if ((rc = allow_lds(m, hist_byte ? (const void*)resample_i8_kernel<true> : (const void*)resample_i8_kernel<false>, hist_bytes))) return rc;
+    if ((rc = allow_lds(m, hist_nib ? (const void*)resample_i8_nib_kernel : (hist_byte ? (const void*)resample_i8_kernel<true> : (const void*)resample_i8_kernel<false>), hist_bytes))) return rc;
     const auto resample_k = hist_byte ? resample_i8_kernel<true> : resample_i8_kernel<false>;
+    const int nib_slow = m->tune.i8_nibbles == 2 ? 1 : 0;
+    m->last_i8_nibbles = hist_nib ? 1 : 0;
     // threads per workgroup: the histogram decides how many workgroups share a CU (160 KB of LDS); the VALU-bound Philox loop wants the
     // CU's wave slots filled either way (N = 100,000: one 128 KB histogram per CU -- 256 threads left three quarters of the SIMD time idle)
     const unsigned resample_threads = (unsigned)std::min(1024, std::max(256, 256 * (int)(8 / std::max<size_t>(1, (160 * 1024) / std::max<size_t>(1, hist_bytes)))));
@@ -319,6 +325,8 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
         if (m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->aux, m->ev_cdfree[slot], 0));
         {
             ProfScope ps(m, PLSPM_K_RESAMPLE, m->aux);
+            if (hist_nib) hipLaunchKernelGGL(resample_i8_nib_kernel, dim3((unsigned)nb, hist_windows), dim3(resample_threads), hist_bytes, m->aux, (int)m->N, KB, MT, seed, rep0, (uint4*)cd.p, (int*)m->err2.p, nib_slow);
+            else
             hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(resample_threads), hist_bytes, m->aux, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err2.p);
         }
         HIPCHK(m, hipEventRecord(m->ev_counts[slot], m->aux));
@@ -327,6 +335,8 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
         // explicit index lists (test / parity seam) arrive on the main stream: drawn there, and the host looks at the flag
         if (m->aux && m->cdfree_set[slot]) HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_cdfree[slot], 0));
         ProfScope ps(m, PLSPM_K_RESAMPLE);
+        if (hist_nib) hipLaunchKernelGGL(resample_i8_nib_kernel, dim3((unsigned)nb, hist_windows), dim3(resample_threads), hist_bytes, m->stream, (int)m->N, KB, MT, seed, rep0, (uint4*)cd.p, (int*)m->err.p, nib_slow);
+        else
         hipLaunchKernelGGL(resample_k, dim3((unsigned)nb, hist_windows), dim3(resample_threads), hist_bytes, m->stream, (int)m->N, KB, MT, m->tune.i8_shape, d_idx, seed, rep0, (uint4*)cd.p, (int*)m->err.p);
     }
     if (d_idx) {

@@ -454,6 +454,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_codes") { if (value < 0 || value > 1) return bad(); m->tune.nm_codes = value; }
     else if (k == "nm_mfma") { if (value < 0 || value > 1) return bad(); m->tune.nm_mfma = value; }
     else if (k == "nm_direct16") { if (value < 0 || value > 1) return bad(); m->tune.nm_direct16 = value; }
+    else if (k == "i8_nibbles") { if (value < 0 || value > 2) return bad(); m->tune.i8_nibbles = value; }
     else if (k == "nm_wave") { if (value < 0 || value > 1) return bad(); m->tune.nm_wave = value; }
     else if (k == "i8_ind") { if (value < 0 || value > 1) return bad(); if (value != m->tune.i8_ind) m->zs_valid = false; m->tune.i8_ind = value; }
     else if (k == "upload_direct") { if (value < 0 || value > 1) return bad(); m->tune.upload_direct = value; }
@@ -507,6 +508,8 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "last_nm_mfma") *value = m->last_nm_mfma;
     else if (k == "nm_direct16") *value = m->tune.nm_direct16;
     else if (k == "last_nm_direct16") *value = m->last_nm_direct16;
+    else if (k == "i8_nibbles") *value = m->tune.i8_nibbles;
+    else if (k == "last_i8_nibbles") *value = m->last_i8_nibbles;
     else if (k == "i8_ind") *value = m->tune.i8_ind;
     else if (k == "i8_rt") *value = m->tune.i8_rt;
     else if (k == "i8_short_rows") *value = m->tune.i8_short;

@@ -342,6 +342,15 @@ def test_int8_route_beyond_65535_rows(N):
     nm.upload(X)
     rows, status, iters = nm.bootstrap(300, seed=4)
     assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 3 and np.all(status == 0)
+    # round 5: the draws land in 4-bit counters (three workgroups per CU) whose overflow is detected exactly (sum of the counts == draws); "i8_nibbles" 2 sends
+    # every replicate through the 8-bit second try a workgroup takes on an overflow, 0 is the 8-bit histogram of round 3: the same bits all three ways
+    assert nm.get_option("last_i8_nibbles") == 1
+    for v in (2, 0):
+        nm.set_option("i8_nibbles", v)
+        rows_v, status_v, iters_v = nm.bootstrap(300, seed=4)
+        assert nm.get_option("last_i8_nibbles") == (1 if v else 0)
+        assert np.array_equal(rows, rows_v) and np.array_equal(status, status_v) and np.array_equal(iters, iters_v)
+    nm.set_option("i8_nibbles", 1)
     corr = orc.correction(N)
     for r in (0, 299):
         idx = _native.bootstrap_indices(4, r, N)
@@ -357,6 +366,28 @@ def test_int8_route_beyond_65535_rows(N):
     idx = np.stack([_native.bootstrap_indices(4, r, N) for r in (0, 299)]).astype(np.int32)
     r2, s2, i2 = nm.bootstrap(2, idx=idx)
     assert nm.get_option("last_gram_path") == 2 and np.array_equal(r2, rows[[0, 299]]) and np.array_equal(i2, iters[[0, 299]])
+
+
+def test_four_bit_counters_over_two_windows_and_a_real_overflow():
+    """resample_i8_nib_kernel beyond one window of 4-bit counters (262,144 rows: N = 270,000 takes two, every window regenerates the replicate's draws) -- moment
+    matrices bit-identical to the 8-bit histograms' -- and with a counter that really overflows: N = 66,000 rows drawn 66,000 times cannot reach 16, but the
+    sum test must also hold when it does, so the second try is forced ("i8_nibbles" 2) on a shape where the halves of the window are ragged (N = 70,001)."""
+    C = orc.chain_C(2)
+    for N in (270000, 70001):
+        X, blocks = orc.synth(N, C, 3, seed=77)
+        model = orc.Model(blocks, C, "AA", "centroid", True)
+        nm = native_model(model)
+        nm.upload(X)
+        ref = None
+        for v in (0, 1, 2):
+            nm.set_option("i8_nibbles", v)
+            M = nm.bootstrap_moments(40, seed=9)
+            assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_i8_nibbles") == (1 if v else 0)
+            if ref is None:
+                ref = M
+                assert np.allclose(M[:, -1, -1], N)                 # every replicate drew N rows
+            else:
+                assert np.array_equal(ref, M)
 
 
 def test_int8_route_with_120_mvs_and_12_lvs():

@@ -27,6 +27,20 @@ __host__ __device__ __forceinline__ u32x4 philox(uint32_t c0, uint32_t c1, uint3
     }
     return u32x4{{c0, c1, c2, c3}};
 }
+// Philox4x32-10 with BOTH halves of a product from one v_mad_u64_u32 (the compiler's choice is v_mul_hi_u32 + v_mul_lo_u32) and the three-way xors as v_xor3_b32: the same bits
+__device__ __forceinline__ u32x4 philox10_mad(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0, p1;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "v"(c0), "v"(0xD2511F53u) : "vcc");
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(c2), "v"(0xCD9E8D57u) : "vcc");
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{{c0, c1, c2, c3}};
+}
 __host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 // Threefry4x32-R: key (k0..k3), counter (c0..c3); rotation constants and key schedule of the Random123 definition (Skein's 4x32 variant)
 template <int R>
@@ -57,6 +71,9 @@ __host__ __device__ __forceinline__ u32x4 quad(uint64_t seed, uint64_t rep, uint
     if (GEN == 2) return threefry<20>(q, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)rep, (uint32_t)(rep >> 32));
     if (GEN == 3) return threefry<16>(q, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)rep, (uint32_t)(rep >> 32));
     if (GEN == 4) return threefry<12>(q, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)rep, (uint32_t)(rep >> 32));
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (GEN == 6) return philox10_mad(q, 0u, (uint32_t)rep, (uint32_t)(rep >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+#endif
     return u32x4{{q * 0x9E3779B9u, q * 0x85EBCA6Bu + (uint32_t)rep, q * 0xC2B2AE35u, (q + (uint32_t)rep) * 0x27D4EB2Fu}};
 }
 
@@ -212,13 +229,22 @@ int main(int argc, char** argv) {
     // known-answer check of the Threefry restatement: Random123's kat_vectors entry "threefry4x32 20", counter = key = 0
     const u32x4 kat = threefry<20>(0, 0, 0, 0, 0, 0, 0, 0);
     printf("{\"threefry4x32_20_zero_kat\": \"%08x %08x %08x %08x\", \"expected\": \"9c6ca96a e17eae66 fc10ecd4 5256a7d8\"}\n", kat.v[0], kat.v[1], kat.v[2], kat.v[3]);
+    if (N <= 65536) {
     run<0>("philox4x32-10", N, B, threads, cd, err);
     run<1>("philox4x32-7", N, B, threads, cd, err);
     run<2>("threefry4x32-20", N, B, threads, cd, err);
     run<3>("threefry4x32-16", N, B, threads, cd, err);
     run<4>("threefry4x32-12", N, B, threads, cd, err);
     run<5>("none", N, B, threads, cd, err);
-    if (N > 20000) return 0;
+    run<6>("philox4x32-10 (v_mad_u64_u32)", N, B, threads, cd, err);
+    }
+    if (N > 20000) {      // round 5: data sets beyond one 16-bit window (byte histogram, one workgroup of 1,024 threads per CU): the generator's share there
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            run_multi<0, 1, true, 0>(N, B, 1024, cd, err); run_multi<6, 1, true, 0>(N, B, 1024, cd, err); run_multi<1, 1, true, 0>(N, B, 1024, cd, err); run_multi<5, 1, true, 0>(N, B, 1024, cd, err);
+            run_multi<0, 1, true, 2>(N, B, 1024, cd, err); run_multi<6, 1, true, 2>(N, B, 1024, cd, err); run_multi<5, 1, true, 2>(N, B, 1024, cd, err); run_multi<0, 1, true, 1>(N, B, 1024, cd, err);
+        }
+        return 0;
+    }
     for (int rnd = 0; rnd < 3; ++rnd) {
         run_multi<0, 1, false, 0>(N, B, 256, cd, err); run_multi<0, 1, false, 4>(N, B, 256, cd, err); run_multi<0, 1, false, 8>(N, B, 256, cd, err); run_multi<0, 1, false, 12>(N, B, 256, cd, err);
         run_multi<0, 1, true, 0>(N, B, 256, cd, err); run_multi<0, 1, true, 4>(N, B, 256, cd, err); run_multi<0, 1, true, 12>(N, B, 256, cd, err);
