@@ -23,10 +23,12 @@
 // Same expressions as nmg_step up to the order of the sums that cross lanes (segmented wave sums; the quadratic form): records agree to ~1e-13,
 // iteration counts are equal (tests/test_gpu_categorical.py).
 #pragma once
+#include <type_traits>
 
 namespace nmw {
 
-constexpr int LMAX_MAX = 8, CMAX = 8, CPL = 8;      // LVs (the kernel is instantiated for LMAX = 2, 4, 6, 8), categories per MV, columns per lane
+constexpr int LMAX_MAX = 8, CMAX_MAX = 16, CPL = 8;      // LVs (the kernel is instantiated for LMAX = 2, 4, 6, 8), categories per MV (CMAX = 8; 16: ten-point items -- the reference's own
+                                                         // mobi / ECSI example data -- at one wave per SIMD), columns per lane
 
 // LDS of one problem (doubles): c | tq | mean | mzown (each QP = Q + 1 rounded up to 8), then the small arrays
 __host__ __device__ inline long lds_doubles(int Q, int Pm, int L, int kmax) {
@@ -37,7 +39,7 @@ __host__ __device__ inline long lds_doubles(int Q, int Pm, int L, int kmax) {
 }
 
 // value of a[i] for a run-time i < CMAX out of a register array (static indices only)
-__device__ __forceinline__ double pick(const double (&a)[CMAX], int i) {
+template <int CMAX> __device__ __forceinline__ double pick(const double (&a)[CMAX], int i) {
     double v = a[0];
 #pragma unroll
     for (int d = 1; d < CMAX; ++d) v = (i == d) ? a[d] : v;
@@ -47,9 +49,10 @@ __device__ __forceinline__ double pick(const double (&a)[CMAX], int i) {
 // scale.py:54-66 (solver_nmg.h nmg_ordinalize) on register arrays: pool adjacent categories -- first violation from the left, restart -- until the
 // category means are monotone for `sign`; out[c] = pooled value of (compacted) category c < C; returns the population variance of the result.
 // Every lane runs its own MV (C = 0: idle); the wave loops while any lane still merges.
-__device__ __forceinline__ double ordinalize(const double (&m)[CMAX], const double (&f)[CMAX], int C, double sign, double (&out)[CMAX]) {
+template <int CMAX> __device__ __forceinline__ double ordinalize(const double (&m)[CMAX], const double (&f)[CMAX], int C, double sign, double (&out)[CMAX]) {
     double gs[CMAX], gw[CMAX];
-    unsigned grp = 0x76543210u;                                   // group of category c in nibble c
+    using GrpT = typename std::conditional<(CMAX > 8), unsigned long long, unsigned>::type;
+    GrpT grp = (GrpT)0xfedcba9876543210ull;                       // group of category c in nibble c
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) { gs[c] = (c < C) ? m[c] * f[c] : 0.0; gw[c] = (c < C) ? f[c] : 1.0; }
     int ng = C;
@@ -76,9 +79,9 @@ __device__ __forceinline__ double ordinalize(const double (&m)[CMAX], const doub
             }
 #pragma unroll
             for (int h = 0; h < CMAX; ++h) { gs[h] = ns[h]; gw[h] = nw[h]; }
-            unsigned ngrp = 0u;
+            GrpT ngrp = 0;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) { const unsigned gc = (grp >> (4 * c)) & 15u; ngrp |= (((int)gc > first) ? gc - 1u : gc) << (4 * c); }
+            for (int c = 0; c < CMAX; ++c) { const unsigned gc = (unsigned)(grp >> (4 * c)) & 15u; ngrp |= (GrpT)(((int)gc > first) ? gc - 1u : gc) << (4 * c); }
             grp = ngrp;
             --ng;
         }
@@ -90,7 +93,7 @@ __device__ __forceinline__ double ordinalize(const double (&m)[CMAX], const doub
     double mean = 0.0, ss = 0.0;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-        const double v = pick(gm, (int)((grp >> (4 * c)) & 15u));
+        const double v = pick<CMAX>(gm, (int)((unsigned)(grp >> (4 * c)) & 15u));
         out[c] = v;
         if (c < C) { mean += f[c] * v; ss += f[c] * v * v; }
     }
@@ -108,6 +111,7 @@ template <int N> __device__ __forceinline__ void allsum_each(double (&v)[N], int
 // (the rows of MV c: one 16-byte load per lane and row) and folds y with tq over the columns of every MV r <= c -- then the shared tail
 // (finish_problem: loadings, cross-loadings, path regressions, effects, the record).  `fast`: the problem's LDS; MV r's columns sit in at most
 // two neighbouring lanes (at most 8 categories, 8 columns per lane): the lane that holds its first column stores, the other one adds.
+template <int CMAX>
 __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const ModelDesc& mdm, const SolverOut& so, double* gSm, NmState& st, NmgExtra& xg,
                               const unsigned short* k16, int ld16, double* fast, long b) {
     const int lane = threadIdx.x, Q = md.P, L = md.L, Pm = cd.Pm;
@@ -184,7 +188,14 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
             if (cur >= 0) { if (cd.mv_off[cur] >= i0) srow[cur] = acc; else { head_r = cur; head_v = acc; } }
         }
         __syncthreads();
-        if (head_r >= 0) srow[head_r] += head_v;
+        if constexpr (CMAX <= CPL) { if (head_r >= 0) srow[head_r] += head_v; }
+        else {
+            // up to 16 categories: an MV may lie across THREE lanes -- the lane next to its first one adds first, the one after that behind a second barrier
+            const bool near = head_r >= 0 && cd.mv_off[head_r] >= i0 - CPL;
+            if (near) srow[head_r] += head_v;
+            __syncthreads();
+            if (head_r >= 0 && !near) srow[head_r] += head_v;
+        }
         __syncthreads();
         if (lane <= c && lane < Pm) {
             const double v = srow[lane] - mvm_s[lane] * mvm_s[c];
@@ -207,8 +218,8 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
     if (out.score_c && lane < L) out.score_c[lane] = st.k_new[lane];
 }
 
-template <int LMAX>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
+template <int LMAX, int CMAX = 8>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 8 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
                                                       const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
                                                       int fuse_finish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -259,7 +270,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
         if (stop) {
             if (fuse_finish) {
                 __syncthreads();
-                finish(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+                finish<CMAX>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
             }
             return;
         }
@@ -421,8 +432,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
         // (every lane runs the pooling loops: C = 0 on the idle ones; NOM lanes take the category means)
         double inc[CMAX], dec[CMAX];
         const int Cord = (is_mv && kind == KIND_ORD) ? Cp : 0;
-        const double v_inc = ordinalize(m2, f2, Cord, 1.0, inc);
-        const double v_dec = ordinalize(m2, f2, Cord, -1.0, dec);
+        const double v_inc = ordinalize<CMAX>(m2, f2, Cord, 1.0, inc);
+        const double v_dec = ordinalize<CMAX>(m2, f2, Cord, -1.0, dec);
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) cs[c] = (kind == KIND_ORD) ? ((v_inc < v_dec) ? -dec[c] : inc[c]) : m2[c];
         double mean = 0.0, ss = 0.0;
@@ -433,7 +444,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) nm
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
             double v = 0.0;
-            if (c < C && fall[c] > 0.0) { v = (pick(cs, at) - mean) / sd; ++at; }
+            if (c < C && fall[c] > 0.0) { v = (pick<CMAX>(cs, at) - mean) / sd; ++at; }
             tqn[c] = v;
         }
     }

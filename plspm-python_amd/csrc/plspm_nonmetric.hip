@@ -38,7 +38,7 @@ bool nm_wave_step_planned(const plspm_model* m) {
     if (!m->categorical || !m->cat_pure || m->nmx_K > 0 || m->N > 65535 || m->tune.nm_k16 == 0 || m->tune.nm_wave == 0) return false;
     for (int l = 0; l < m->L; ++l) if (m->mode[l] != PLSPM_MODE_A) return false;
     const size_t wave_lds = (size_t)nmw::lds_doubles(m->P, m->Pm, m->L, m->kmax) * sizeof(double);
-    return m->Pm <= 64 && m->L <= nmw::LMAX_MAX && m->cmax <= nmw::CMAX && m->P + 1 <= 512 && wave_lds <= kMaxLds;
+    return m->Pm <= 64 && m->L <= nmw::LMAX_MAX && m->cmax <= nmw::CMAX_MAX && m->P + 1 <= 512 && wave_lds <= kMaxLds;
 }
 
 // cd8 / cd8_MT: the int8 row multiplicities of THESE problems (the counts the digit-plane Gram consumed; bootstrap only), or null
@@ -192,7 +192,9 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     // (dense stop-rule pass: the list kernel of the pass counts the live problems anyway and writes the count to the pinned flag itself -- no
     //  counter to clear, no copy operation: two tiny launches and their gaps less per iteration, 35 of ~590 us at three iterations)
     const bool flag_from_list = dense && !m->stage1;
-    auto wave_kernel = L <= 2 ? nmw::nmw_step_kernel<2> : L <= 4 ? nmw::nmw_step_kernel<4> : L <= 6 ? nmw::nmw_step_kernel<6> : nmw::nmw_step_kernel<8>;
+    // (instantiations: LMAX 2 / 4 / 6 / 8 LVs x at most 8 categories per MV -- two waves per SIMD -- or at most 16 -- ten-point items; one wave per SIMD, 512 registers)
+    auto wave_kernel = m->cmax <= 8 ? (L <= 2 ? nmw::nmw_step_kernel<2, 8> : L <= 4 ? nmw::nmw_step_kernel<4, 8> : L <= 6 ? nmw::nmw_step_kernel<6, 8> : nmw::nmw_step_kernel<8, 8>)
+                                    : (L <= 2 ? nmw::nmw_step_kernel<2, 16> : L <= 4 ? nmw::nmw_step_kernel<4, 16> : L <= 6 ? nmw::nmw_step_kernel<6, 16> : nmw::nmw_step_kernel<8, 16>);
     if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
     for (int it = 0; it <= m->max_iter + 1; ++it) {
         if (!flag_from_list) HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));

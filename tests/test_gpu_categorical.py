@@ -305,13 +305,13 @@ def test_count_matrices_written_by_the_int8_product(shape):
     assert np.array_equal(ex[0], on[0][:40]) and np.array_equal(ex[2], on[2][:40])
 
 
-@pytest.mark.parametrize("case", ["likert60_path", "likert60_nom_centroid", "chain8_factorial", "tiny_blocks", "eight_categories"])
+@pytest.mark.parametrize("case", ["likert60_path", "likert60_nom_centroid", "chain8_factorial", "tiny_blocks", "eight_categories", "ten_point_items", "sixteen_categories"])
 def test_wave_step_agrees_with_the_workgroup_step(case):
     """kernels_nmw.h (round 5): the categorical iteration as ONE WAVE per problem -- count matrix streamed 16 bytes per lane and row, the pooling
     of the ordinal quantification in registers, the block quadratic form as a second matrix-vector product on the block diagonal -- against the
     workgroup step it restates (nmg_kernel<1>, "nm_wave" 0): same iteration counts, records equal to 1e-10 (the sums that cross lanes are wave
     reductions: a different order of the same terms), for fits and bootstraps; every shape class of its instantiations: 2 .. 8 LVs, 2 .. 8
-    categories per item, several LV blocks inside one lane's eight columns, replicates that lose categories, ORD and NOM; and both against the oracle."""
+    categories per item (and -- the second set of instantiations -- 9 .. 16), several LV blocks inside one lane's eight columns, replicates that lose categories, ORD and NOM; and both against the oracle."""
     from plspm import _native
     rng = np.random.default_rng(5)
     if case in ("likert60_path", "likert60_nom_centroid"):
@@ -335,6 +335,21 @@ def test_wave_step_agrees_with_the_workgroup_step(case):
         data = (np.concatenate((X, X2), axis=1) > 0).astype(float) + 1.0
         blocks = [np.array([l, 5 + l]) for l in range(5)]
         model = orc.Model(blocks, C, "A" * 5, "path", True, tol=1e-6, scales=["ORD"] * 10)
+    elif case == "ten_point_items":
+        # the reference's own example data (mobi / ECSI) are ten-point items: the CMAX = 16 instantiation (one wave per SIMD); an MV's ten columns lie across
+        # two or three lanes of the column role
+        C = orc.chain_C(3)
+        X, blocks = orc.synth(3000, C, 5, seed=14)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(5.5 + 2.0 * Z), 1, 10)
+        model = orc.Model(blocks, C, "AAA", "path", True, tol=1e-6, scales=["ORD"] * 15)
+    elif case == "sixteen_categories":
+        C = orc.chain_C(2)
+        X, blocks = orc.synth(4000, C, 4, seed=16)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(8.5 + 3.2 * Z), 1, 16)
+        data[:, 1] = np.clip(data[:, 1], 4, 12)                   # (one item with nine)
+        model = orc.Model(blocks, C, "AA", "factorial", True, tol=1e-6, scales=["ORD", "NOM"] * 4)
     else:
         C = orc.chain_C(2)
         X, blocks = orc.synth(2500, C, 6, seed=12)
