@@ -161,10 +161,10 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
 #pragma unroll
             for (int t = 0; t < CMAX; ++t) {
                 if (t < Cc) {
-                    const double tj = tq_s[jc0 + t];
+                    const double tj = tq_s[jc0 + t] * inv_n;
                     const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
 #pragma unroll
-                    for (int u = 0; u < CPL; ++u) y[u] += ((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * tj;
+                    for (int u = 0; u < CPL; ++u) y[u] = fma((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu), tj, y[u]);
                 }
             }
         }
@@ -317,10 +317,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #pragma unroll
                 for (int t = 0; t < NR; ++t) {
                     if (q + t < q1) {
-                        const double cq = c_s[q + t];
+                        const double cq = c_s[q + t] * inv_n;                 // (1 / n once per row, not once per count: a quarter of the stream's arithmetic)
                         const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
 #pragma unroll
-                        for (int u = 0; u < CPL; ++u) acc[u] += ((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * cq;
+                        for (int u = 0; u < CPL; ++u) acc[u] = fma((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu), cq, acc[u]);
                     }
                 }
             }
@@ -502,12 +502,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #pragma unroll
                 for (int t = 0; t < NU; ++t) {
                     const int ja = a0 + t0 + t, jb = b0 + t0 + t;
-                    const double da = (onA && ja < a1) ? c_s[ja] : 0.0, db = (onB && jb < b1) ? c_s[jb] : 0.0;
+                    const double da = (onA && ja < a1) ? c_s[ja] * inv_n : 0.0, db = (onB && jb < b1) ? c_s[jb] * inv_n : 0.0;
                     const unsigned wwa[4] = {wa[t].x, wa[t].y, wa[t].z, wa[t].w}, wwb[4] = {wb[t].x, wb[t].y, wb[t].z, wb[t].w};
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
-                        if (lvc[u] == blkA) U[u] += ((double)((wwa[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * da;
-                        if (lvc[u] == blkB) U[u] += ((double)((wwb[u >> 1] >> (16 * (u & 1))) & 0xffffu) * inv_n) * db;
+                        if (lvc[u] == blkA) U[u] = fma((double)((wwa[u >> 1] >> (16 * (u & 1))) & 0xffffu), da, U[u]);
+                        if (lvc[u] == blkB) U[u] = fma((double)((wwb[u >> 1] >> (16 * (u & 1))) & 0xffffu), db, U[u]);
                     }
                 }
             }
