@@ -117,7 +117,7 @@ def live_traffic(kernel_prefix, gram_path):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="plspm_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline", "--no-api", "--no-traffic", "--gram-path", str(gram_path)]
+               "--no-cpu-baseline", "--no-api", "--no-traffic", "--no-next-rows", "--gram-path", str(gram_path)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = glob.glob(os.path.join(d, "*.db")) + glob.glob(os.path.join(d, "*", "*.db"))
@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--reps-per-gpu", type=int, default=REPS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the categorical bootstrap beside the headline (two child runs of tools/categorical_bench.py)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
     ap.add_argument("--no-transport-calibration", action="store_true", help="keep RCCL as created (skip the untimed comparison with channel-capped RCCL / the copy-engine exchange)")
@@ -705,6 +706,20 @@ def main():
             line["api_inclusive"] = api_inclusive(X, args.reps_per_gpu)
             line["api_inclusive"]["frac_of_value"] = round(line["api_inclusive"]["value"] / line["value"], 3)
             line["api_inclusive"]["frac_of_cold_value"] = round(line["api_inclusive"]["value"] / line["cold"]["value"], 3)      # (an API call starts on an idle device, as `cold` does)
+        if world == 1 and group is None and not args.no_next_rows:
+            # SURVEY 8(f) "next" rows beside the headline, measured by this run (child processes: their handles, their clocks): the categorical
+            # (Scale.ORD, five-point) counterpart of the headline workload at 1,000 and 5,000 replicates per step -- tools/categorical_bench.py
+            import subprocess
+            cat = {}
+            for reps in (1000, 5000):
+                try:
+                    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "categorical_bench.py"), str(reps)], capture_output=True, text=True, timeout=240).stdout
+                    cat["replicates_per_step_%d" % reps] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+                except Exception as e:                                    # noqa: BLE001 -- an extra of the line, never its failure
+                    cat["replicates_per_step_%d" % reps] = {"error": repr(e)[:200]}
+            line["next_rows"] = {"categorical_bootstrap": cat,
+                                 "note": "not part of `value`: ORD / NOM optimal scaling on 300 indicator columns (10k x 60 five-point items x 6 LVs), one wave per problem, "
+                                         "count matrices written by the int8 product as uint16, stop rule as an int8 matrix product; DESIGN 5c"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             # the real reference cannot travel to this box: its rate measured in the build container, and the factor between the oracle and

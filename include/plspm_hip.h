@@ -101,6 +101,9 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "i8_dma"          0 (auto) | 1 | 2   LDS-DMA form of the round-3 kernel: 1 global_load_lds_dwordx4 (64-bit base per block), 2 buffer_load_dwordx4
  *                     ... lds (per-workgroup descriptors + 32-bit offsets; auto takes it whenever an operand's walk stays below 4 GiB)
  *   "i8_ind"          1 (default) | 0   one-plane data run through the seven-plane main loop, the planes of a wave standing for seven pair groups
+ *   "i8_nibbles"      1 (default) | 0 | 2   (round 5) Philox draws of data sets beyond 65,536 rows: 4-bit LDS counters (three workgroups per CU at 100,000
+ *                     rows) with an exact overflow test -- sum of the counts == draws -- and an 8-bit second try for a replicate that fails it; 0: the
+ *                     8-bit histogram of round 3; 2: every replicate through the second try (tests).  Same counts.  Read-only "last_i8_nibbles"
  * Solvers
  *   "solver_rows"     1 (default) | 0   bootstrap of metric models with at most 64 MVs on the int8 route: one wave per replicate with the
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS; models of
@@ -116,11 +119,22 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     stop-rule pass adds the coefficient of the one column a row has set per MV (16 category codes per row tile and MV,
  *                     nm_conv_codes_kernel) instead of multiplying every 0/1 column through -- bit-identical partial sums, 2.3 x faster
  *                     passes on 300 indicator columns.  Read-only "last_nm_codes"
+ *   "nm_mfma"         1 (default) | 0   (round 5) among those, LV blocks of at most 64 indicator columns: the stop-rule pass as an exact int8 matrix product --
+ *                     indicator bytes of the rows x seven base-256 digit planes of the replicates' score maps (nmp::conv_mfma_kernel), the digits put
+ *                     together again per (row, replicate); same decisions, criterion values equal to ~1e-12 relative, 2 x faster than the pass on
+ *                     category codes.  Read-only "last_nm_mfma"
+ *   "nm_wave"         1 (default) | 0   (round 5) all-indicator categorical models, every block Mode A, at most 64 MVs of at most 16 categories, 8 LVs,
+ *                     511 indicator columns, 65,535 rows: the iteration as one wave per problem (nmw::nmw_step_kernel) instead of one workgroup
+ *                     (nmg_kernel<1>); records equal to ~1e-13, equal iteration counts.  Read-only "last_nm_wave"
+ *   "nm_direct16"     1 (default) | 0   (round 5) bootstrap of such models on the int8 route: the product writes the replicates' co-occurrence counts
+ *                     as uint16 matrices itself (upper triangle; mirrored through LDS by nmg_kernel<4>) instead of fp64 moment matrices that a scatter
+ *                     pass turns into the same integers -- bit-identical records.  Read-only "last_nm_direct16"
  *   "nm_fast_lds"     1 (default) | 0   categorical (ORD / NOM) solver: the small arrays of the iteration in LDS for the duration of a launch
  *   "nm_k16"          1 (default) | 0   all-indicator categorical models of at most 65,535 rows: uint16 copy of the count matrix for the
  *                     streaming product of every step (bit-identical steps, a quarter of the bytes)
  *   "conv_pass"       0 auto | 1 gathering stop-rule pass | 2 dense pass with block-staged coefficients (non-metric bootstrap)
- *   "conv_gy"         0 (one replicate group per workgroup) .. 65535 replicate slices of the dense stop-rule pass
+ *   "conv_gy"         0 (default) .. 65535   replicate slices of the dense stop-rule pass (0: one replicate group per workgroup); matrix-product pass:
+ *                     the waves it aims at, in units of 256 (0: 8,192)
  * Host-buffer bootstrap (plspm_bootstrap)
  *   "boot_chunks"     0 (default: automatic) | 1 .. 8   plspm_bootstrap() of a metric model on Philox draws runs as sub-batches: the records of
  *                     sub-batch k cross PCIe on a copy stream -- and are unpacked into the caller's buffers -- while the kernels of sub-batch
