@@ -11,6 +11,6 @@ for db in sorted(glob.glob(O+"/p*/*.db")+glob.glob(O+"/p*/*/*.db")):
     cur=sqlite3.connect(db).cursor()
     q=("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection c where grid_size = (select max(grid_size) from counters_collection c2 where c2.kernel_name = c.kernel_name) group by kernel_name, counter_name")
     for r in cur.execute(q):
-        if any(k in r[0] for k in ("nmg_kernel","nm_conv_codes","nmw_step")):
-            print(r[0].split("(")[0].replace("void ","")[:28], r[1], r[2], "%.4g"%r[3], "%.0f ns"%r[4])
+        if any(k in r[0] for k in ("nmg_kernel","nm_conv_codes","nmw_step","conv_mfma","planes_kernel")):
+            print(r[0].split("(")[0].replace("void ","")[:32], r[1], r[2], "%.4g"%r[3], "%.0f ns"%r[4])
 PY

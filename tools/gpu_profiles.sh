@@ -18,6 +18,12 @@ timeout 300 python tools/group_ab.py 2>/dev/null | grep "^{" > $O/group_ab.jsonl
 timeout 300 python tools/pcie_chunks.py 5000 2>/dev/null | grep "^{" > $O/pcie_chunks.jsonl
 timeout 300 python tools/categorical_bench.py 5000 2>&1 | tail -1 > $O/categorical_bench_5000.json
 CAT_NM_WAVE=0 timeout 300 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_bench_workgroup_step.json
+# round 5, second half: A/B lines of the categorical path (stop rule on category codes instead of the int8 matrix product; packed fp64 matrices + scatter pass instead of
+# uint16 counts from the Gram), the stand-alone resample kernel with its generator variants at 10,000 and 100,000 rows, issue cost of the epilogue's instructions
+(for v in 0 1; do CAT_NM_MFMA=$v timeout 300 python tools/categorical_bench.py 2>&1 | tail -1; CAT_NM_MFMA=$v timeout 300 python tools/categorical_bench.py 5000 2>&1 | tail -1; done) > $O/categorical_ab_nm_mfma.jsonl
+(for v in 0 1; do CAT_NM_DIRECT16=$v timeout 300 python tools/categorical_bench.py 2>&1 | tail -1; CAT_NM_DIRECT16=$v timeout 300 python tools/categorical_bench.py 5000 2>&1 | tail -1; done) > $O/categorical_ab_nm_direct16.jsonl
+(./tools/ubench/resample_rng 10000 5000 256 x | head -9; ./tools/ubench/resample_rng 100000 5000 1024) 2>&1 | grep "^{" > $O/ubench_resample_rng.jsonl
+./tools/ubench/mul_issue > $O/ubench_mul_issue.txt 2>&1
 (bash tools/cat_pmc.sh > $O/categorical_pmc.txt 2>&1; rm -rf $R/gpurun_out/cat_pmc)
 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1 > $O/nonmetric_bench.json
 (NM_BENCH_N=100000 NM_BENCH_SPINUP=3 NM_BENCH_STEPS=5 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1; NM_BENCH_N=100000 NM_BENCH_GRAM_PATH=1 NM_BENCH_SPINUP=1 NM_BENCH_STEPS=2 timeout 600 python tools/nonmetric_bench.py 1000 2>&1 | tail -1) > $O/nonmetric_100k.jsonl
@@ -62,6 +68,7 @@ timeout 600 python tools/categorical_bench.py 2>&1 | tail -1 > $O/categorical_be
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && CAT_BENCH_STEPS=1 PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/categorical_bench.py 1000 2>&1 | grep clocks | tail -4 > $O/categorical_marks.txt
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/cp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/categorical_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/categorical_kernels.txt 2>&1; rm -rf /tmp/cp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/nonmetric_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/nonmetric_kernels.txt 2>&1)
 timeout 600 python tools/hoc_bench.py 2>&1 | tail -1 > $O/hoc_bench.json
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/cp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/cp -o cp -- python $R/tools/hoc_bench.py > /dev/null 2>&1; python $R/tools/kernel_table.py /tmp/cp > $O/hoc_kernels.txt 2>&1)
 python - "$O" <<'PY'
 import sqlite3, glob, sys, json
 O = sys.argv[1]
