@@ -255,6 +255,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     ws.scal = lp; lp += 8;
     ws.red = lp;
     DevExec ex{lane, 64, ws.red, nullptr};
+#ifdef PLSPM_DEBUG_MARKS
+#define NMW_MARK(i) do { if (b == 0 && lane == 0 && so.marks && (int)st.scal[2] == 1) so.marks[i] = clock64(); } while (0)      // (the second iteration of problem 0)
+#else
+#define NMW_MARK(i) do { } while (0)
+#endif
 
     // ---- decide on the previous convergence value (solver_nmg.h nmg_step: same protocol)
     const int iteration = (int)st.scal[2];
@@ -275,6 +280,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
             return;
         }
     }
+    NMW_MARK(20);
     const double n = st.scal[0], inv_n = 1.0 / n, corr2 = n / (n - 1.0);
     // new -> old (the stop-rule pass of this iteration compares them), and the step's inputs into LDS
     for (int j = lane; j < QP; j += 64) {
@@ -328,6 +334,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #pragma unroll
         for (int u = 0; u < CPL; ++u) V[u][m] = acc[u];
     }
+    NMW_MARK(21);
     // LV of this lane's columns (columns >= Q: none)
     int lvc[CPL];
 #pragma unroll
@@ -372,7 +379,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         ws.G[e] = yy - vmean[l] * vmean[m];
     }
     __syncthreads();
+    NMW_MARK(22);
     inner_weights(ex, md, ws, corr2, YY);
+    NMW_MARK(23);
     // ---- a_l = <z_l, z_l>;  of MZ = V E only the column of the own LV is needed per aug column (the category sums of z_l) and the row of means
     if (lane < L) {
         const int l = lane;
@@ -400,6 +409,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     }
     __syncthreads();
 
+    NMW_MARK(24);
     // ---- quantification (weights.py:112-115, scale.py:42-89) and the Mode-A outer weights: MV lane p
     const bool is_mv = lane < Pm;
     const int p = lane;
@@ -464,6 +474,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         for (int c = 0; c < CMAX; ++c) if (c < C) { tq_s[jm0 + c] = tqn[c]; c_s[jm0 + c] = wn * tqn[c]; }
     }
     __syncthreads();
+    NMW_MARK(25);
     // ---- stream 2: U_i = sum over the rows j of the block of column i of Mn[j][i] d_j;  q_l = sum_i d_i U_i  (= w' <MV, MV'> w of block l)
     double qpart[LMAX];
 #pragma unroll
@@ -534,6 +545,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         akk[lane] = -mw / sd;
     }
     __syncthreads();
+    NMW_MARK(26);
     // ---- new coefficients, score map (tc = 0: k_new = akk), state back to global memory
     if (is_mv) {
         const double an = wn / sdl[lv];
@@ -543,6 +555,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         for (int c = 0; c < CMAX; ++c) if (c < C) { st.c_new[jm0 + c] = an * tqn[c]; xg.tq[jm0 + c] = tqn[c]; }
     }
     if (lane < L) { st.k_new[lane] = akk[lane]; xg.akk[lane] = akk[lane]; }
+    NMW_MARK(27);
     if (lane == 0) {
         st.scal[2] = (double)(iteration + 1);
         if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3];
