@@ -354,16 +354,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         if (l < L) {                                              // (uniform)
+            // (the upper triangle only: <y_l, y_m> is symmetric, and a wave-wide sum per entry is what this phase costs -- 21 instead of 36 at six LVs)
             double part[LMAX];
 #pragma unroll
             for (int m = 0; m < LMAX; ++m) {
                 double s = 0.0;
+                if (m >= l) {
 #pragma unroll
-                for (int u = 0; u < CPL; ++u) s += (lvc[u] == l) ? c_s[j0 + u] * V[u][m] : 0.0;
+                    for (int u = 0; u < CPL; ++u) s += (lvc[u] == l) ? c_s[j0 + u] * V[u][m] : 0.0;
+                }
                 part[m] = s;
             }
-            allsum_each(part, L);
-            if (lane < L) {
+#pragma unroll
+            for (int m = 0; m < LMAX; ++m) if (m >= l && m < L) part[m] = wv::allsum(part[m]);
+            if (lane < L && lane >= l) {
                 double v = 0.0;
 #pragma unroll
                 for (int m = 0; m < LMAX; ++m) v = (lane == m) ? part[m] : v;
@@ -372,11 +376,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         }
     }
     __syncthreads();
+    double yy_up = 0.0;
+    for (int e = lane; e < L * L; e += 64) {                      // (L <= 8: one trip)
+        const int l = e / L, m = e - l * L;
+        const int lo = l < m ? l : m, hi = l < m ? m : l;
+        yy_up = kold[lo] * vmean[hi] + YY[lo * L + hi];
+    }
+    __syncthreads();
     for (int e = lane; e < L * L; e += 64) {
         const int l = e / L, m = e - l * L;
-        const double yy = kold[l] * vmean[m] + YY[e];
-        YY[e] = yy;
-        ws.G[e] = yy - vmean[l] * vmean[m];
+        YY[e] = yy_up;
+        ws.G[e] = yy_up - vmean[l] * vmean[m];
     }
     __syncthreads();
     NMW_MARK(22);
