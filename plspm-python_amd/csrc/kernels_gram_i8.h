@@ -26,6 +26,7 @@
 //   Zs: digits,  block index kb * NT + nt   (nt = pair_group * S + s, r = pair % 16)
 #pragma once
 #include <type_traits>
+#include "wave_ops.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define I8_SLACK_KB 6        // k-blocks of readable slack behind the counts and the digit planes (the DMA ring runs up to 5 k-steps ahead)
