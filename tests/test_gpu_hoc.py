@@ -187,6 +187,38 @@ def test_hoc_on_ordinal_data_fit_and_replicates_vs_reference_golden(tag):
     assert np.array_equal(rows_c, rows_m, equal_nan=True)
 
 
+@pytest.mark.parametrize("tag", ["path", "centroid"])
+def test_hoc_on_five_point_items_takes_the_matrix_product_pass_in_both_stages(tag):
+    """Round 5: with LV blocks of at most 64 indicator columns (mobi recoded to five-point items) the stop-rule passes of BOTH stages of a higher order
+    construct run as int8 matrix products (kernels_nmp.h: the second stage files the first stage's rows under its own blocks and reads the composed
+    score maps), and the first stage takes the wave step.  Held against the pass on category codes ("nm_mfma" 0 on both handles): same iteration
+    counts and statuses, same bits of the records; and a replicate against one two-stage device ESTIMATE of the resampled observations."""
+    import plspm.weights as w
+    from plspm import _native
+    from plspm.estimator import Estimator
+    mobi, config, scheme = _ordinal_hoc(tag)
+    mobi = np.ceil(mobi / 2.0)
+    observations = config.filter(mobi)
+    calculator = w.WeightsCalculatorFactory(config, 100, 1e-7, np.sqrt(250 / 249), scheme, 0)
+    pair = Estimator(config).two_stage_bootstrap_handles(calculator, observations)
+    rows_p, status_p, iters_p = pair.native.bootstrap(200, seed=21)
+    assert pair.native.get_option("last_nm_mfma") == 1 and pair.native._second.get_option("last_nm_mfma") == 1
+    assert pair.native.get_option("last_nm_wave") == 1
+    pair.native.set_option("nm_mfma", 0); pair.native._second.set_option("nm_mfma", 0)
+    rows_c, status_c, iters_c = pair.native.bootstrap(200, seed=21)
+    assert pair.native.get_option("last_nm_mfma") == 0 and pair.native._second.get_option("last_nm_mfma") == 0
+    assert pair.native.get_option("last_nm_codes") == 1 and pair.native._second.get_option("last_nm_codes") == 1
+    pair.native.set_option("nm_mfma", 1); pair.native._second.set_option("nm_mfma", 1)
+    assert np.array_equal(status_p, status_c) and np.array_equal(iters_p, iters_c)
+    assert np.array_equal(rows_p, rows_c, equal_nan=True)
+    ok = np.flatnonzero(status_p == 0)
+    assert ok.size >= 150
+    r = int(ok[-1])
+    res = Estimator(config).run(calculator, observations.iloc[_native.bootstrap_indices(21, r, 250), :], want_scores=False)
+    one = np.concatenate((res.raw["weights"], res.raw["r2"], res.raw["total"], res.raw["direct"], res.raw["loadings"]))
+    assert_close(rows_p[r], one, 1e-7, 1e-10)
+
+
 def test_api_bootstrap_of_a_hoc_model_on_ordinal_data():
     """Plspm(..., bootstrap=True) on a higher order construct with Scale.ORD data: device RNG index stream, both stages of every
     replicate batched on the device, the reference's frames."""
