@@ -382,6 +382,47 @@ def test_wave_step_agrees_with_the_workgroup_step(case):
     assert_close(rows[r], mine, RTOL, ATOL)
 
 
+def test_full_size_categorical_bootstrap_properties():
+    """The categorical counterpart of the headline workload at FULL size -- 10,000 rows x 60 five-point items (300 indicator columns) x 6 LVs, 2,000 replicates --
+    through size-independent properties: (i) every route of round 5 gives the same records (stop rule as int8 matrix product / on category codes; count matrices
+    from the int8 product / through the scatter pass; wave step / workgroup step to 1e-10 with equal iteration counts); (ii) sharding invariance: the replicates of
+    two calls with `rep_offset` are the bits of one call; (iii) a replicate against the oracle on the resampled DATA; (iv) the criterion every replicate stopped
+    on is below the tolerance and agrees between the two passes."""
+    from plspm import _native
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(10000, C, 10, seed=0)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+    model = orc.Model(blocks, C, "AAAAAA", "path", True, tol=1e-6, scales=["ORD"] * 60)
+    nm, g = gpu_fit_cat(likert, model)
+    B = 2000
+    base = nm.bootstrap(B, seed=1)
+    assert nm.get_option("last_nm_wave") == 1 and nm.get_option("last_nm_mfma") == 1 and nm.get_option("last_nm_direct16") == 1 and nm.get_option("last_gram_path") == 2
+    assert np.all(base[1] == 0) and base[2].min() >= 3
+    crit = nm.nonmetric_criteria(B)
+    assert np.all(crit < 1e-6) and np.all(crit > 0)
+    a = nm.bootstrap(1200, seed=1)
+    b = nm.bootstrap(800, seed=1, rep_offset=1200)
+    assert np.array_equal(np.concatenate((a[0], b[0])), base[0]) and np.array_equal(np.concatenate((a[2], b[2])), base[2])
+    for key in ("nm_mfma", "nm_direct16"):
+        nm.set_option(key, 0)
+        other = nm.bootstrap(B, seed=1)
+        assert nm.get_option("last_" + key) == 0
+        if key == "nm_mfma": assert_close(nm.nonmetric_criteria(B), crit, 1e-9, 1e-20)
+        nm.set_option(key, 1)
+        assert np.array_equal(other[0], base[0]) and np.array_equal(other[1], base[1]) and np.array_equal(other[2], base[2]), key
+    nm.set_option("nm_wave", 0)
+    group = nm.bootstrap(B, seed=1)
+    nm.set_option("nm_wave", 1)
+    assert nm.get_option("last_nm_wave") == 0 and np.array_equal(group[2], base[2])
+    assert_close(group[0], base[0], 1e-10, 1e-12)
+    rows = _rows_in_data_order(base[0], g["inv"], 60, 6, nm.n_eff)
+    r = B - 1
+    mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(1, r, 10000), orc.correction(10000))
+    assert its == base[2][r]
+    assert_close(rows[r], mine, RTOL, ATOL)
+
+
 def test_categorical_bootstrap_beyond_one_histogram_window_takes_the_int8_route():
     """70,000 rows: non-metric bootstraps with on-device draws now stay on the digit-plane Gram (counts from the 131,072-row byte
     histogram) and take their stop-rule passes' row multiplicities from its int8 counts -- on category codes for all-indicator data.
