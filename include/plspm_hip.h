@@ -119,7 +119,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     stop-rule pass adds the coefficient of the one column a row has set per MV (16 category codes per row tile and MV,
  *                     nm_conv_codes_kernel) instead of multiplying every 0/1 column through -- bit-identical partial sums, 2.3 x faster
  *                     passes on 300 indicator columns.  Read-only "last_nm_codes"
- *   "nm_mfma"         1 (default) | 0   (round 5) among those, LV blocks of at most 64 indicator columns: the stop-rule pass as an exact int8 matrix product --
+ *   "nm_mfma"         1 (default) | 0   (round 5) among those, LV blocks of at most 128 indicator columns: the stop-rule pass as an exact int8 matrix product --
  *                     indicator bytes of the rows x seven base-256 digit planes of the replicates' score maps (nmp::conv_mfma_kernel), the digits put
  *                     together again per (row, replicate); same decisions, criterion values equal to ~1e-12 relative, 2 x faster than the pass on
  *                     category codes.  Read-only "last_nm_mfma"

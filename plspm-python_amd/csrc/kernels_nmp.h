@@ -17,8 +17,9 @@
 //
 // Layouts (16 bytes per lane, lane = 16 kg + i: the k-bytes 16 kg .. 16 kg + 15 of row / replicate i; A and B use the same k order, whatever
 // order the instruction gives the 64 k inside):
-//   ind8[(l * ntiles + t) * 64 + lane]                     indicator bytes of rows 16 t + i under block l          (built once per upload)
-//   tab8[((((g * L + l) * 2 + m) * S + s) * 64 + lane]     digit s of map m (0 old, 1 new) of live slots 16 g + i   (built once per pass)
+//   ind8[((l * ntiles + t) * KS + ks) * 64 + lane]                     indicator bytes of rows 16 t + i under columns 64 ks .. of block l   (built once per upload)
+//   tab8[(((((g * L + l) * 2 + m) * S + s) * KS + ks) * 64 + lane]     digit s of map m (0 old, 1 new) of live slots 16 g + i               (built once per pass)
+//   KS = k-steps of a block: 1 for blocks of at most 64 indicator columns, 2 up to 128 (the two MFMAs of a plane chain through the accumulator)
 //   scl [(((g * L + l) * 2 + m) * 16 + i]                  {2^(e - 54), k_l}: value of one unit of the last digit, constant term
 #pragma once
 
@@ -29,13 +30,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 // indicator bytes from the category codes (cat_codes_kernel: codes[(t * Pm + mv) * 16 + r] = block-relative column of MV mv's category in row
 // 16 t + r, or `kb` for a row without one)
-__global__ void __launch_bounds__(256) ind8_kernel(const unsigned short* __restrict__ codes, long ntiles, int Pm, int L, const int* __restrict__ lmv_off, uint4* __restrict__ ind8) {
+__global__ void __launch_bounds__(256) ind8_kernel(const unsigned short* __restrict__ codes, long ntiles, int Pm, int L, int KS, const int* __restrict__ lmv_off, uint4* __restrict__ ind8) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)L * ntiles * 64) return;
-    const int lane = (int)(e & 63), r = lane & 15, kg = lane >> 4;
-    const long lt = e >> 6;
+    if (e >= (long)L * ntiles * KS * 64) return;
+    const int lane = (int)(e & 63), r = lane & 15;
+    const long ltk = e >> 6;
+    const int ks = (int)(ltk % KS);
+    const long lt = ltk / KS;
     const int l = (int)(lt / ntiles);
     const long t = lt - (long)l * ntiles;
+    const int kg = ks * 4 + (lane >> 4);                         // group of 16 block columns this lane's bytes stand for
     unsigned w[4] = {0u, 0u, 0u, 0u};
     for (int mv = lmv_off[l]; mv < lmv_off[l + 1]; ++mv) {
         const unsigned code = codes[(t * Pm + mv) * 16 + r];
@@ -46,7 +50,7 @@ __global__ void __launch_bounds__(256) ind8_kernel(const unsigned short* __restr
 
 // digit planes of the live problems' score maps.  One wave per live slot (grid: slots rounded up to whole groups of 16; the padding slots write
 // zeros: weight 0 in the pass).  state_b[8 + 2 P ..]: c_old[P] | c_new[P] | k_old[L] | k_new[L] (coef_table_kernel reads the same run).
-__global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, const int* __restrict__ boff, const int* __restrict__ list,
+__global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, int KS, const int* __restrict__ boff, const int* __restrict__ list,
                                                     const int* __restrict__ count, uint4* __restrict__ tab8, double2* __restrict__ scl) {
     __shared__ __attribute__((aligned(16))) unsigned char dig[S][64];
     const int n = *count;
@@ -59,29 +63,38 @@ __global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ g
     for (int l = 0; l < L; ++l) {
         const int p0 = boff[l], nb = boff[l + 1] - p0;
         for (int m = 0; m < 2; ++m) {
-            const double c = (live && lane < nb) ? st[(long)m * P + p0 + lane] : 0.0;
-            const double mx = __longlong_as_double((long long)wv::allmax((unsigned long long)__double_as_longlong(fabs(c))));      // (non-negative doubles order like their bit patterns; NaN sorts above inf)
+            double cks[2];                                        // this lane's coefficient of either k-step (KS <= 2)
+            double amax = 0.0;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 64 + lane;
+                cks[ks] = (live && k < nb) ? st[(long)m * P + p0 + k] : 0.0;
+                const double a = fabs(cks[ks]);
+                amax = (a > amax || a != a) ? a : amax;           // (NaN wins)
+            }
+            const double mx = __longlong_as_double((long long)wv::allmax((unsigned long long)__double_as_longlong(amax)));      // (non-negative doubles order like their bit patterns; NaN sorts above inf)
             int ex = 0;
             double unit = 0.0;
-            long long q = 0;
-            if (mx > 0.0 && mx <= 1.7976931348623157e308) {
+            const bool fin = mx > 0.0 && mx <= 1.7976931348623157e308;
+            if (fin) {
                 (void)frexp(mx, &ex);                             // mx = f 2^ex, 1/2 <= f < 1: every |c| < 2^ex
-                q = (long long)rint(ldexp(c, FBITS - ex));        // |q| <= 2^54
                 unit = ldexp(1.0, ex - FBITS);
             } else if (!(mx == 0.0)) unit = mx - mx;              // inf / NaN coefficients: NaN scores, a NaN criterion (what the fp64 pass returns)
+            for (int ks = 0; ks < KS; ++ks) {
+                long long q = fin ? (long long)rint(ldexp(cks[ks], FBITS - ex)) : 0;      // |q| <= 2^54
 #pragma unroll
-            for (int s = S - 1; s >= 0; --s) {
-                const long long d = ((q + 128) & 255) - 128;       // balanced digit in [-128, 127]
-                dig[s][lane] = (unsigned char)(signed char)d;
-                q = (q - d) >> 8;
-            }
-            __syncthreads();
-            if (lane < S * 4) {
-                const int s = lane >> 2, kg = lane & 3;
-                tab8[((((g * L + l) * 2 + m) * S + s) * 64) + kg * 16 + i] = *reinterpret_cast<const uint4*>(&dig[s][16 * kg]);
+                for (int s = S - 1; s >= 0; --s) {
+                    const long long d = ((q + 128) & 255) - 128;   // balanced digit in [-128, 127]
+                    dig[s][lane] = (unsigned char)(signed char)d;
+                    q = (q - d) >> 8;
+                }
+                __syncthreads();
+                if (lane < S * 4) {
+                    const int s = lane >> 2, kg = lane & 3;
+                    tab8[((((g * L + l) * 2 + m) * S + s) * KS + ks) * 64 + kg * 16 + i] = *reinterpret_cast<const uint4*>(&dig[s][16 * kg]);
+                }
+                __syncthreads();
             }
             if (lane == 0) scl[((g * L + l) * 2 + m) * 16 + i] = make_double2(unit, live ? st[2L * P + (long)m * L + l] : 0.0);
-            __syncthreads();
         }
     }
 }
@@ -101,7 +114,7 @@ __device__ __forceinline__ double digits_value(int d0, int d1, int d2, int d3, i
 // The pass.  Workgroup = NW waves; wave w of workgroup (chunk, gq) takes the live slots 16 (gq NW + w) .. + 15 and the row tiles
 // [chunk tpc, (chunk + 1) tpc): the waves of a workgroup walk the SAME indicator tiles (they meet in the CU's vector cache).  LV blocks outermost --
 // the 2 S digit fragments of a block stay in registers (56) over the chunk's tiles.  partial[b * nparts + chunk]: summed by the step kernel in a fixed order.
-template <int NW>
+template <int NW, int KS = 1>
 __global__ void __launch_bounds__(64 * NW) conv_mfma_kernel(const uint4* __restrict__ ind8, long ntiles, int L, const unsigned* __restrict__ cd, long MT, const uint4* __restrict__ tab8,
                                                              const double2* __restrict__ scl, const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial,
                                                              int nparts, int tpc) {
@@ -121,23 +134,29 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_kernel(const uint4* __restr
     double acc = 0.0;
     const v4i zero = {0, 0, 0, 0};
     for (int l = 0; l < L; ++l) {
-        v4i B[2][S];
-        const uint4* tb = tab8 + ((g * L + l) * 2 * S) * 64 + lane;
+        v4i B[2][S][KS];
+        const uint4* tb = tab8 + ((g * L + l) * 2 * S * KS) * 64 + lane;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int s = 0; s < S; ++s) { const uint4 v = tb[(m * S + s) * 64]; B[m][s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) { const uint4 v = tb[((m * S + s) * KS + ks) * 64]; B[m][s][ks] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
         const double2 so = scl[((g * L + l) * 2 + 0) * 16 + i], sn = scl[((g * L + l) * 2 + 1) * 16 + i];
-        const uint4* ia = ind8 + ((long)l * ntiles + t0) * 64 + lane;
-        for (long t = t0; t < t1; ++t, ia += 64) {
-            const uint4 av = *ia;
-            const v4i A = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+        const uint4* ia = ind8 + ((long)l * ntiles + t0) * KS * 64 + lane;
+        for (long t = t0; t < t1; ++t, ia += KS * 64) {
+            v4i A[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { const uint4 av = ia[ks * 64]; A[ks] = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w}; }
             const unsigned cw = live ? cdb[((t >> 2) * MT * 64 + (t & 3) * 16) * 4] : 0u;
             v4i D[2][S];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int s = 0; s < S; ++s) D[m][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[m][s], zero, 0, 0, 0);
+                for (int s = 0; s < S; ++s) {
+                    D[m][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], B[m][s][0], zero, 0, 0, 0);
+                    if constexpr (KS > 1) D[m][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], B[m][s][1], D[m][s], 0, 0, 0);      // (the second 64 columns of the block)
+                }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double a = fma(digits_value(D[0][0][r], D[0][1][r], D[0][2][r], D[0][3][r], D[0][4][r], D[0][5][r], D[0][6][r]), so.x, so.y);

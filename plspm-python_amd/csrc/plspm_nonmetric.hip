@@ -99,7 +99,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     }
     // round 5: that pass as an exact int8 matrix product (kernels_nmp.h) -- indicator bytes x digit planes of the score maps, blocks of at most 64 columns
     // (one k-step of the instruction).  Row chunks of `tpc` tiles: enough waves to fill the device at the batch's first passes, whole tiles of work each.
-    const bool use_mfma = use_codes && kb <= 64 && m->tune.nm_mfma != 0;
+    const bool use_mfma = use_codes && kb <= 128 && m->tune.nm_mfma != 0;
+    const int KS = kb > 64 ? 2 : 1;                              // k-steps of a block (64 columns per instruction)
     const long ng16 = (nproblems + 15) / 16;
     int tpc = 0;
     if (use_mfma) {
@@ -108,13 +109,13 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
         tpc = (int)((ntiles16 + want - 1) / want);
         nparts = (int)((ntiles16 + tpc - 1) / tpc);
         if (!m->ind8_valid) {
-            if ((rc = ensure(m, m->ind8, (size_t)L * ntiles16 * 64 * sizeof(uint4)))) return rc;
-            const long total = (long)L * ntiles16 * 64;
-            hipLaunchKernelGGL(nmp::ind8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const unsigned short*)m->codes.p, ntiles16, src->Pm, L, codes_lmv,
+            if ((rc = ensure(m, m->ind8, (size_t)L * ntiles16 * KS * 64 * sizeof(uint4)))) return rc;
+            const long total = (long)L * ntiles16 * KS * 64;
+            hipLaunchKernelGGL(nmp::ind8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->stream, (const unsigned short*)m->codes.p, ntiles16, src->Pm, L, KS, codes_lmv,
                                (uint4*)m->ind8.p);
             m->ind8_valid = true;
         }
-        if ((rc = ensure(m, m->tab8, (size_t)ng16 * L * 2 * nmp::S * 64 * sizeof(uint4)))) return rc;
+        if ((rc = ensure(m, m->tab8, (size_t)ng16 * L * 2 * nmp::S * KS * 64 * sizeof(uint4)))) return rc;
         if ((rc = ensure(m, m->scl8, (size_t)ng16 * L * 2 * 16 * sizeof(double2)))) return rc;
     }
     m->last_nm_codes = use_codes ? 1 : 0;
@@ -237,9 +238,10 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                                    flag_from_list ? (int*)m->h_flag : (int*)nullptr);
                 if (flag_from_list) HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
                 if (use_mfma) {
-                    hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16 * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, conv_boff, (const int*)(live_list + 1),
+                    hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16 * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, KS, conv_boff, (const int*)(live_list + 1),
                                        (const int*)live_list, (uint4*)m->tab8.p, (double2*)m->scl8.p);
-                    hipLaunchKernelGGL(nmp::conv_mfma_kernel<4>, dim3((unsigned)(nparts * ((ng16 + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
+                    auto pass_kernel = KS == 1 ? nmp::conv_mfma_kernel<4, 1> : nmp::conv_mfma_kernel<4, 2>;
+                    hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ng16 + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
                                        (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(live_list + 1), (const int*)live_list, part, nparts, tpc);
                 } else {
                 hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups, (unsigned)((2 * src->P + 2 * L + 1 + 63) / 64)), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L,

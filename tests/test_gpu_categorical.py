@@ -271,6 +271,43 @@ def test_stop_rule_pass_as_int8_matrix_product(scale, scheme):
         assert_close(rows[r], mine, RTOL, ATOL)
 
 
+@pytest.mark.parametrize("shape", ["fourteen_five_point_items", "eight_ten_point_items"])
+def test_matrix_product_pass_on_blocks_of_up_to_128_columns(shape):
+    """LV blocks of 65 .. 128 indicator columns take TWO k-steps of the instruction (nmp::conv_mfma_kernel<4, 2>: the second MFMA of a plane chains through the
+    accumulator): 14 five-point items per LV (70 columns) and 8 ten-point items (80 columns; the CMAX = 16 wave step).  Against the pass on category codes:
+    criterion values to 1e-9, identical iteration counts and records; a replicate against the oracle."""
+    from plspm import _native
+    C = orc.chain_C(2)
+    if shape == "fourteen_five_point_items":
+        X, blocks = orc.synth(2000, C, 14, seed=71)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+        model = orc.Model(blocks, C, "AA", "centroid", True, tol=1e-6, scales=["ORD"] * 28)
+    else:
+        X, blocks = orc.synth(3000, C, 8, seed=73)
+        Z = (X - X.mean(axis=0)) / X.std(axis=0)
+        data = np.clip(np.round(5.5 + 2.0 * Z), 1, 10)
+        model = orc.Model(blocks, C, "AA", "path", True, tol=1e-6, scales=["ORD", "NOM"] * 8)
+    nm, g = gpu_fit_cat(data, model)
+    on = nm.bootstrap(200, seed=12)
+    assert nm.get_option("last_nm_mfma") == 1 and nm.get_option("last_nm_wave") == 1 and nm.get_option("last_gram_path") == 2
+    crit_on = nm.nonmetric_criteria(200)
+    nm.set_option("nm_mfma", 0)
+    off = nm.bootstrap(200, seed=12)
+    assert nm.get_option("last_nm_mfma") == 0 and nm.get_option("last_nm_codes") == 1
+    crit_off = nm.nonmetric_criteria(200)
+    nm.set_option("nm_mfma", 1)
+    assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2]) and np.array_equal(on[0], off[0])
+    assert_close(crit_on, crit_off, 1e-9, 1e-20)
+    ok = np.flatnonzero(on[1] == 0)
+    assert ok.size >= 150
+    r = int(ok[-1])
+    mine, its = orc.bootstrap_replicate(data, model, _native.bootstrap_indices(12, r, data.shape[0]), orc.correction(data.shape[0]))
+    rows = _rows_in_data_order(on[0], g["inv"], len(model.scales), 2, nm.n_eff)
+    assert its == on[2][r]
+    assert_close(rows[r], mine, RTOL, ATOL)
+
+
 @pytest.mark.parametrize("shape", ["likert60", "chain3"])
 def test_count_matrices_written_by_the_int8_product(shape):
     """Round 5: on all-indicator data the int8 product's sums ARE the co-occurrence counts the wave step streams -- the one-plane launch writes them as uint16
