@@ -99,29 +99,57 @@ struct DevExecT {
                 s[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off);
             }
         }
-        const int cq = q0 + min(lane, nq - 1);                                            // the column this lane reads in the turned part
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (turned) {
-                double t[16];
+        // The turned part (round 5, second form): a tile belongs to ONE wave, so the hand-over between its lanes needs the wave's own LDS order, not a
+        // workgroup barrier (the four waves of a problem no longer wait for each other's memory round trips: eight barriers -> one); the rows of
+        // round j + 1 are requested as soon as round j's registers have gone to the tile, in front of the reads of round j; the 64 reads of a lane are 32
+        // 16-byte ones, taken unconditionally in groups of four and selected against the diagonal afterwards (the compiler had sunk every 8-byte
+        // read into an exec-masked block of its own: 266 of them per problem); lanes beyond the window hold its last column already, so the
+        // reads need no clamp; the rounds are a real loop (a quarter of the code).
+        if (turned) {
+            const int cq = q0 + min(lane, nq - 1);                                        // the column this lane reads in the turned part
+            auto fetch = [&](double (&t)[16], int j) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int rc = min(w0 + 16 * j + i, P - 1);
                     const unsigned off = (unsigned)(rc * PS + max(cq, rc)) * 8u;
                     t[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Md) + off);
                 }
+            };
+            auto put = [&](const double (&t)[16]) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) stage[i * 66 + lane] = t[i];
-            }
-            __syncthreads();
-            if (turned && (lane >> 4) == j) {
-                const double* row = stage + (lane - 16 * j) * 66;
-                const int below = pc - q0;                                               // registers q > below hold entries under the diagonal
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            const int below = pc - q0;                                                   // registers q > below hold entries under the diagonal
+            auto take = [&](int j) {
+                if ((lane >> 4) == j) {
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    const d2* row = reinterpret_cast<const d2*>(stage + (lane & 15) * 66);
 #pragma unroll
-                for (int q = 0; q < PMAX; ++q) s[q] = (q > below) ? row[min(q, nq - 1)] : s[q];
+                    for (int g = 0; g < PMAX; g += 8) {
+                        d2 r[4];
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) r[h] = row[(g >> 1) + h];
+                        asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            s[g + 2 * h] = (g + 2 * h > below) ? r[h].x : s[g + 2 * h];
+                            s[g + 2 * h + 1] = (g + 2 * h + 1 > below) ? r[h].y : s[g + 2 * h + 1];
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // (the tile is free for the next round's rows)
+            };
+            double ta[16];
+            fetch(ta, 0);
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                put(ta);
+                if (j < 3) fetch(ta, j + 1);
+                take(j);
             }
-            __syncthreads();
         }
+        __syncthreads();                                                                  // (callers re-use the tiles' memory)
     }
     double* xstage = nullptr;      // 16 x 66 doubles per wave (split rows solver only)
     // where threads without an item of their own may store (a shared dead array: every lane then runs the same store instruction)

@@ -27,6 +27,7 @@
 #include "solver_nmx.h"
 #include "solver_ops.h"
 #include "solver_wave.h"
+#include "solver_quad.h"
 
 using namespace plspm;
 

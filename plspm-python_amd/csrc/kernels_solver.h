@@ -89,6 +89,7 @@ struct DevWaveExec : DevExecT<4> {
     __device__ __forceinline__ double bcast(double v, int q, const double*) {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), q), __builtin_amdgcn_readlane(__double2loint(v), q));
     }
+    __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ double uniform_d(double v) {                           // a value every lane holds identically -> scalar registers
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
@@ -100,6 +101,7 @@ struct DevWaveExec : DevExecT<4> {
         asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
     }
     __device__ __forceinline__ int vote_count(bool b) { return __popcll(__ballot(b)); }
+    __device__ __forceinline__ int wave_vote_count(bool b) { return __popcll(__ballot(b)); }      // (solver_quad.h: four waves per problem, votes per wave)
     __device__ __forceinline__ bool vote_any(bool b) { return __ballot(b) != 0ull; }
     // Column `lane` of the symmetric moment matrix out of its upper triangle (entry (r, c >= r) at r * PS + c), into s[0 .. 63].
     //   A. row r across the lanes, r = 0 .. 63: lane c >= r reads M[r][c] -- coalesced 512-byte rows; lanes c < r re-read the diagonal
@@ -154,6 +156,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     DevWaveExec ex;
     ex.tid = (int)threadIdx.x; ex.nt = 64; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
     solve_problem_wave<LMAX, MODEB>(ex, md, ws, Md + b * md_stride, out);
+}
+
+
+// Quad variant (solver_quad.h solve_problem_quad; round 5): the wave solver's lane roles on FOUR waves per problem -- metric Mode-A models of
+// 65 .. 128 MVs and at most 16 LVs; two problems per CU (one wave of each per SIMD), ~52 KB of LDS per problem.
+template <int LMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_quad_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const long b = blockIdx.x;
+    QuadWs<LMAX> ws;
+    quad_carve(ws, reinterpret_cast<double*>(smem_raw));
+    FitOutputs out{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevWaveExec ex;
+    ex.tid = (int)threadIdx.x; ex.nt = 256; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
+    ex.xstage = ws.stage;
+    solve_problem_quad<LMAX>(ex, md, ws, Md + b * md_stride, out);
 }
 
 

@@ -41,7 +41,9 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // (at least four problems per CU; wide inner models, L >~ 20, take the LDS solver, which can move its workspace to global scratch)
     const size_t rows_lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
     // (round 4: 64 < P <= 128 in the split form -- two threads per MV on either side of a block boundary, four waves and ~30 KB of LDS per problem)
-    const bool rows_width = m->P <= 64 ? rows_lds <= kMaxLds / 4 : (m->P <= 128 && rows_split_block(m->boff.data(), m->L, 64) > 0 && rows_lds + 4 * 16 * 66 * sizeof(double) <= kMaxLds / 2);
+    // (round 5: the quad solver -- solver_quad.h, Mode-A models of 65 .. 128 MVs and at most 16 LVs -- has a workspace of its own, ~52 KB whatever the inner model)
+    const bool quad_width = m->tune.solver_quad != 0 && quad_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax, m->boff.data());
+    const bool rows_width = m->P <= 64 ? rows_lds <= kMaxLds / 4 : (quad_width || (m->P <= 128 && rows_split_block(m->boff.data(), m->L, 64) > 0 && rows_lds + 4 * 16 * 66 * sizeof(double) <= kMaxLds / 2));
     const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && rows_width && !m->n_ind && !m->nonmetric && !m->moments_out;
     // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers
     const bool need_lists = gpath == 1 || d_idx != nullptr || (m->nonmetric && !counts8_plan);

@@ -168,7 +168,16 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         m->last_solver = 3;
     } else if (dense) {
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
-        if (m->P > 64) {                           // split form: two threads per MV (plspm_detail_bootstrap asked rows_split_block)
+        if (m->P > 64 && m->tune.solver_quad != 0 && quad_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax, m->boff.data())) {
+            // four waves per problem with fixed lane roles (solver_quad.h; round 5): Mode-A models of 65 .. 128 MVs and at most 16 LVs
+            m->last_solver = 5;
+            const size_t ldsq = (size_t)quad_ws_doubles<16>(m->L, m->kmax) * sizeof(double);
+            if ((rc = allow_lds(m, (const void*)solver_quad_kernel<16>, ldsq))) return rc;
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            hipEvent_t stop = m->stop_event;
+            m->stop_event = nullptr;
+            hipExtLaunchKernelGGL((solver_quad_kernel<16>), dim3((unsigned)nb), dim3(256), ldsq, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        } else if (m->P > 64) {                    // split form: two threads per MV (plspm_detail_bootstrap asked rows_split_block)
             m->last_solver = 4;
             const size_t lds4 = lds + PLSPM_ROWS_SPLIT_STAGE_DOUBLES * sizeof(double);
             if ((rc = allow_lds(m, (const void*)solver_rows_split_kernel, lds4))) return rc;
@@ -193,7 +202,7 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         long long h[32];
         HIPCHK(m, hipStreamSynchronize(m->stream));
         HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
-        if (m->last_solver == 3) {
+        if (m->last_solver == 3 || m->last_solver == 5) {
             fprintf(stderr, "[plspm wave clocks] load %lld  treat %lld  init %lld  iterations %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[13] - h[7], h[13] - h[0]);
             fprintf(stderr, "[plspm wave last iterate] apply_cov %lld  a/G/E %lld  regress %lld  outer+conv %lld\n", h[9] - h[8], h[10] - h[9], h[11] - h[10], h[12] - h[11]);

@@ -14,6 +14,7 @@
 #include "../../plspm-python_amd/csrc/solver_nmx.h"
 #include "../../plspm-python_amd/csrc/solver_ops.h"
 #include "../../plspm-python_amd/csrc/solver_wave.h"
+#include "../../plspm-python_amd/csrc/solver_quad.h"
 
 using namespace plspm;
 
@@ -82,8 +83,18 @@ struct HostExec {
         return c;
     }
     bool vote_any(bool b) { return vote_count(b) > 0; }
+    // ballot over the caller's 64-lane wave (solver_quad.h: nt == 256, four emulated waves)
+    int wave_vote_count(bool b) {
+        red[tid] = b ? 1.0 : 0.0;
+        bar->arrive_and_wait();
+        int c = 0;
+        for (int k = tid & ~63; k < (tid & ~63) + 64 && k < nt; ++k) c += red[k] != 0.0 ? 1 : 0;
+        bar->arrive_and_wait();
+        return c;
+    }
     void fence() {}
     double uniform_d(double v) { return v; }
+    int uniform_i(int v) { return v; }
     double bcast(double, int q, const double* published) { return published[q]; }
     void opaque(unsigned&) {}
     void opaque(int&) {}
@@ -368,6 +379,29 @@ int hostemu_solve_wave(int P, int L, int PA, int scheme, int scaled, int max_ite
             HostExec ex{t, nthreads, &bar, red.data()};
             if (em.md.n_chol > 0) solve_problem_wave<8, true>(ex, em.md, ws, Md, out);
             else solve_problem_wave<8, false>(ex, em.md, ws, Md, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+// Quad solver (solver_quad.h solve_problem_quad<16>): 256 emulated threads = four waves; returns 1 for a model it does not cover.
+int hostemu_solve_quad(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                       const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                       double* row, int* iters, int* status) {
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    if (!quad_solver_covers<16>(P, L, em.md.n_chol, em.md.kmax, boff)) return 1;
+    const int nthreads = 256;
+    std::vector<double> lds(quad_ws_doubles<16>(L, em.md.kmax), 0.0), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            QuadWs<16> ws{};
+            quad_carve(ws, lds.data());
+            HostExec ex{t, nthreads, &bar, red.data()};
+            solve_problem_quad<16>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

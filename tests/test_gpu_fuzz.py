@@ -67,8 +67,8 @@ def test_random_model(seed):
 
 
 def make_wide_case(seed):
-    """65 ... 128 MVs in 3 ... 12 ragged blocks (metric): the split rows solver where a block boundary leaves at most 64 MVs on either
-    side, the LDS solver otherwise."""
+    """65 ... 128 MVs in 3 ... 12 ragged blocks (metric): the quad solver (all Mode A) or the split rows solver (Mode-B blocks) where a block
+    boundary leaves at most 64 MVs on either side, the LDS solver otherwise."""
     rng = np.random.default_rng(5000 + seed)
     L = int(rng.integers(3, 13))
     C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.8)))
@@ -97,7 +97,16 @@ def test_random_wide_model_bootstrap(seed):
         pytest.skip("the fp64 route took this batch")
     below = [int(b) for b in boff[1:-1] if b <= 64]
     splittable = bool(below) and P - max(below) <= 64
-    assert nm.get_option("last_solver") == (4 if splittable else 1), (sizes, nm.get_option("last_solver"))
+    # (round 5: all-Mode-A models of at most 16 LVs take the quad solver -- four waves per problem with fixed lane roles -- where they took the split rows solver)
+    quad = splittable and "B" not in model.modes
+    assert nm.get_option("last_solver") == ((5 if quad else 4) if splittable else 1), (sizes, nm.get_option("last_solver"))
+    if quad:
+        nm.set_option("solver_quad", 0)
+        rows_s, status_s, iters_s = nm.bootstrap(B, seed=seed)
+        assert nm.get_option("last_solver") == 4
+        assert np.array_equal(status, status_s) and np.array_equal(iters[status == 0], iters_s[status == 0]), (sizes, model.scheme)
+        assert_close(rows[status == 0], rows_s[status == 0], 1e-9, 1e-12, what="quad vs split rows %s" % sizes)
+        nm.set_option("solver_quad", 1)
     nm.set_option("solver_rows", 0)
     rows_l, status_l, iters_l = nm.bootstrap(B, seed=seed)
     assert nm.get_option("last_solver") == 1

@@ -391,8 +391,8 @@ def test_four_bit_counters_over_two_windows_and_a_real_overflow():
 
 
 def test_int8_route_with_120_mvs_and_12_lvs():
-    """P = 120 > 64: the digit-plane Gram (7,381 pair columns) feeds the split rows solver (round 4: two threads per MV on either side of a
-    block boundary, dense layout) or -- set_option("solver_rows", 0) -- the LDS solver through the tile-packed layout.  Rows vs the oracle,
+    """P = 120 > 64: the digit-plane Gram (7,381 pair columns) feeds the quad solver (round 5: all-Mode-A models, four waves per problem with fixed lane roles)
+    / the split rows solver (round 4: two threads per MV on either side of a block boundary, dense layout; Mode-B blocks) or -- set_option("solver_rows", 0) -- the LDS solver through the tile-packed layout.  Rows vs the oracle,
     between the two solvers and vs the fp64 route."""
     from plspm import _native
     C = orc.chain_C(12)
@@ -402,7 +402,7 @@ def test_int8_route_with_120_mvs_and_12_lvs():
         nm = native_model(model)
         nm.upload(X)
         rows, status, iters = nm.bootstrap(260, seed=6)
-        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 4 and np.all(status == 0)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == (5 if "B" not in modes else 4) and np.all(status == 0)
         corr = orc.correction(2500)
         for r in (0, 259):
             mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(6, r, 2500), corr)
