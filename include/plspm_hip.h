@@ -111,6 +111,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     (solver_rows_split_kernel)
  *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
  *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
+ *   "solver_quad"     1 (default) | 0   (round 5) Mode-A models of 65 ... 128 MVs and at most 16 LVs whose blocks divide into two runs of at most 64
+ *                     MVs: the wave solver's fixed lane roles on four waves per replicate (solver_quad_kernel) instead of solver_rows_split_kernel
  *   "solver_threads"  64 | 128 | 256      threads per problem of the LDS solver (default 128)
  *   "nm_threads"      0 (by model width) | 64 | 128 | 256   threads per problem of the non-metric solvers
  *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
@@ -150,7 +152,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  * (Test seams and the option values of the experiments build: include/plspm_hip_test.h.)
  *
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
- * (1 LDS solver, 2 rows solver, 3 wave solver, 4 split rows solver) tell what the last bootstrap call took.
+ * (1 LDS solver, 2 rows solver, 3 wave solver, 4 split rows solver, 5 quad solver) tell what the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value);

@@ -120,10 +120,12 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     // 1. moments -> treated covariance (config.py:299-305, util.py:33-39): my window of row p in registers
     ex.mark(0);
     double s[PMAX];
-    ex.template load_cov_block<PMAX>(Md, PS, P, pc, q0, nq, s);
+    // (the two strided entries of my row first: their round trip runs under the loader's)
     double dpp = 0.0, mup = 0.0;                                 // raw M[p][p] and the column sum M[p][P] (ones column)
     if (valid) { mup = Md[(long)p * PS + P]; dpp = Md[(long)p * PS + p]; }
-    const double n = ex.uniform_d(Md[(long)P * PS + P]);
+    const double n_raw = Md[(long)P * PS + P];
+    ex.template load_cov_block<PMAX>(Md, PS, P, pc, q0, nq, s);
+    const double n = ex.uniform_d(n_raw);
     ex.mark(1);
     if (side == 0) { ws.mu[p] = mup; ws.w[p] = 1.0; }            // init: block products with w = 1
     ex.sync();
@@ -198,20 +200,19 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
         const int ell = tl / LMAX, eml = tl % LMAX;
         ex.mark(16);
         ex.template seg_products<PMAX>(s, ws.w + q0, nq, ends, valid ? ws.V + pl * QUAD_VP + l0l : ex.sink(ws.sink));      // (own row: no exchange)
-#pragma unroll
-        for (int m = 0; m < LMAX; ++m)
-            if (m >= l0 && m < l1) ws.T[m * QUAD_TP + pl] = valid ? wp * ws.V[pl * QUAD_VP + m] : 0.0;      // (uniform tests; own row: no exchange)
         ex.mark(17);
         ex.sync();
         ex.mark(18);
         {
-            // Q[el, em] = sum over the MVs of block el of T[em, .]: eight loads in flight per trip
+            // Q[el, em] = sum over the MVs p of block el of w_p V[p, em]: eight terms (sixteen loads) in flight per trip.  (The wave solver stores
+            // T = w V transposed for this sum; here that pass -- an LDS round trip per LV on every MV thread -- cost more than the second load.)
             double s0 = 0.0, s1 = 0.0;
-            const double* tt = ws.T + eml * QUAD_TP + pb0l;
+            const double* vv = ws.V + pb0l * QUAD_VP + eml;
+            const double* ww = ws.w + pb0l;
             for (int i0 = 0; i0 < kbmax; i0 += 8) {
                 double v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pk) ? tt[i0 + j] : 0.0;
+                for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pk) ? ww[i0 + j] * vv[(i0 + j) * QUAD_VP] : 0.0;
                 s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
             }
             Qe = s0 + s1;
@@ -241,7 +242,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
             } else if (d_lm) {
                 Ee = (md.scheme == SCHEME_CENTROID) ? ((Ge > 0.0) ? 1.0 : ((Ge < 0.0) ? -1.0 : 0.0)) : Ge * corr2 * (double)d_lm;   // cov1 = cov0 N/(N-1)
             }
-            ws.Gm[tl] = Ge; ws.Em[tl] = Ee;
+            ws.Gm[tl] = Ge; ws.Em[tl] = al * Ee;                 // (row el of E carries a_el: the outer step multiplies V with a E)
             if (el == em) ws.a[ell] = al;
         }
         ex.sync();
@@ -250,8 +251,8 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
             if (lvlane && nk > 0) {                              // regression of Yhat_t on its predecessors, no intercept (scheme.py:48-50)
                 const double* x = regress(ws.Gm);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < nk) ws.Em[pred(r) * LMAX + tl] = x[r];
-                for (int r = 4; r < nk; ++r) ws.Em[pred(r) * LMAX + tl] = x[r];
+                for (int r = 0; r < 4; ++r) if (r < nk) ws.Em[pred(r) * LMAX + tl] = ws.a[pred(r)] * x[r];
+                for (int r = 4; r < nk; ++r) ws.Em[pred(r) * LMAX + tl] = ws.a[pred(r)] * x[r];
             }
             ex.sync();
         }
@@ -261,8 +262,8 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
         double c0 = 0.0, c1 = 0.0;
 #pragma unroll
         for (int m = 0; m + 1 < LMAX; m += 2) {
-            if (m < L) c0 += ws.a[m] * ws.V[pl * QUAD_VP + m] * ws.Em[m * LMAX + lpl];
-            if (m + 1 < L) c1 += ws.a[m + 1] * ws.V[pl * QUAD_VP + m + 1] * ws.Em[(m + 1) * LMAX + lpl];
+            if (m < L) c0 += ws.V[pl * QUAD_VP + m] * ws.Em[m * LMAX + lpl];
+            if (m + 1 < L) c1 += ws.V[pl * QUAD_VP + m + 1] * ws.Em[(m + 1) * LMAX + lpl];
         }
         const double wn = valid ? c0 + c1 : 0.0;
         const double dd = fabs(wp) - fabs(wn);
@@ -280,27 +281,29 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     wp *= wfp;
     // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]).  The owners sit in waves 0 and 1; every wave casts the same number of
     // ballots (the CPU emulation's ballot is a barrier).
+    {
+        double vr[LMAX];                                         // (my row of V in one batch of loads: a load inside every ballot's block waits out its own LDS round trip)
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l)
-        if (l < L) { const int neg = ex.wave_vote_count(owner && ws.V[p * QUAD_VP + l] < 0.0); if ((t & 63) == 0 && side == 0) ws.votes[wave * LMAX + l] = (double)neg; }
-    ex.sync();
-    unsigned negmask = 0u;
-    for (int l = 0; l < L; ++l) {
-        const int neg = (int)ws.votes[l] + (int)ws.votes[LMAX + l];
-        if (P - 2 * neg < 0) negmask |= 1u << l;
+        for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * QUAD_VP + (l < L ? l : 0)];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+            if (l < L) { const int neg = ex.wave_vote_count(owner && vr[l] < 0.0); if ((t & 63) == 0 && side == 0) ws.votes[wave * LMAX + l] = (double)neg; }
     }
+    ex.sync();
+    // (a thread looks up the three signs it needs -- its pair's two LVs, its MV's LV -- instead of walking all L tallies)
+    auto sign_of = [&](int l) { return ((double)P - 2.0 * (ws.votes[l] + ws.votes[LMAX + l]) < 0.0) ? -1.0 : 1.0; };
+    const double sgl = sign_of(lp);
     {
         const double wfl = wave_rsqrt(ws.Qm[el * LMAX + el]), wfm = wave_rsqrt(ws.Qm[em * LMAX + em]);
-        const double sl = ((negmask >> el) & 1u) ? -1.0 : 1.0, sm = ((negmask >> em) & 1u) ? -1.0 : 1.0;
+        const double sl = sign_of(pair ? el : 0), sm = sign_of(pair ? em : 0);
         if (pair) ws.Cs[t] = sl * sm * wfl * wfm * Qe;           // population covariance of the sign-corrected scores
+        ws.Bm[t] = 0.0;                                          // (all 256 entries: the effects below then run without a test per row)
     }
     ex.sync();
     ex.mark(5);
     // inner model (inner_model.py:58-75): OLS with intercept == centred normal equations on the score covariance
     double r2p = 0.0;
     if (lvlane) {
-#pragma unroll
-        for (int j = 0; j < LMAX; ++j) ws.Bm[t * LMAX + j] = 0.0;
         if (nk > 0) {
             const double* x = regress(ws.Cs);
             double expl = 0.0;
@@ -315,22 +318,20 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     ex.mark(6);
     // effects (inner_model.py:33-53): indirect = B^2 + B^3 + ... = (I - B)^-1 - I - B; B is strictly lower triangular in path order, so column t of
     // (I - B)^-1 follows by forward substitution in the registers of LV thread t.  colx = the column without its unit entry: rows above t are
-    // zero, so the sum over ALL k < i of B[i][k] colx[k] is the sum over the paths of length >= 2 -- no predicate per term, rows >= L skipped
-    // by a uniform branch (66 terms at L = 12, not 120).
+    // zero, so the sum over ALL k < i of B[i][k] colx[k] is the sum over the paths of length >= 2 -- no predicate per term.  Rows >= L of B are zero
+    // (cleared above), so all 120 terms run as one block: the loads of B do not depend on the arithmetic and go out in batches, where a branch per
+    // row held every row's loads back behind the previous row's chain (3.4 k -> ~1.5 k clocks).
     if (lvlane) {
         double colx[LMAX];
 #pragma unroll
         for (int i = 0; i < LMAX; ++i) {
-            colx[i] = 0.0;
-            if (i < L) {
-                double i0 = 0.0, i1 = 0.0;
+            double i0 = 0.0, i1 = 0.0;
 #pragma unroll
-                for (int k = 0; k + 1 < i; k += 2) { i0 += ws.Bm[i * LMAX + k] * colx[k]; i1 += ws.Bm[i * LMAX + k + 1] * colx[k + 1]; }
-                if (i & 1) i0 += ws.Bm[i * LMAX + i - 1] * colx[i - 1];
-                const double ind = (i > t) ? i0 + i1 : 0.0;
-                colx[i] = (i > t) ? ws.Bm[i * LMAX + t] + ind : 0.0;
-                ws.Ind[i * LMAX + t] = ind;
-            }
+            for (int k = 0; k + 1 < i; k += 2) { i0 += ws.Bm[i * LMAX + k] * colx[k]; i1 += ws.Bm[i * LMAX + k + 1] * colx[k + 1]; }
+            if (i & 1) i0 += ws.Bm[i * LMAX + i - 1] * colx[i - 1];
+            const double ind = (i > t) ? i0 + i1 : 0.0;
+            colx[i] = (i > t) ? ws.Bm[i * LMAX + t] + ind : 0.0;
+            ws.Ind[i * LMAX + t] = ind;
         }
     }
     ex.sync();
@@ -339,7 +340,6 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     if (out.row) {
         if (owner) {
             out.row[p] = wp;
-            const double sgl = ((negmask >> lp) & 1u) ? -1.0 : 1.0;
             out.row[P + L + 2 * ne + p] = sgl * ws.V[p * QUAD_VP + lp] * wfp / sdp;
         }
         if (lvlane) out.row[P + t] = r2p;

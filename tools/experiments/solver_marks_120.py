@@ -1,4 +1,4 @@
-"""Phase clocks of one split-rows solver problem (marks build) on the 10k x 120 x 12 model of tools/size_bench.py."""
+"""Phase clocks of one quad-solver problem (solver_quad.h; with nm.set_option("solver_quad", 0): of the split rows solver) (marks build) on the 10k x 120 x 12 model of tools/size_bench.py."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

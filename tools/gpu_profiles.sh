@@ -57,6 +57,8 @@ timeout 120 python tools/group_enqueue.py 2>/dev/null | grep "^{" > $O/group_enq
 timeout 300 python tools/aux_ab.py solver_wave=0,1 2>&1 | grep "^{" > $O/ab_solver_wave.jsonl
 timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
 timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
+timeout 600 python tools/solver_quad_ab.py 2>/dev/null | grep "^{" > $O/solver_quad_ab.jsonl
+[ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks_120.py > $O/solver_quad_marks.txt 2>&1
 timeout 300 python tools/i8_mix_calib.py 2>&1 | grep "^{" > $O/i8_mix_calib.jsonl
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks.py > $O/solver_marks.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $O/prof_solver_pmc1 -o p1 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC -d $O/prof_solver_pmc2 -o p2 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_solver_fetch -o f -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/prof_solver_write -o w -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1)

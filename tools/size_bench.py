@@ -1,5 +1,5 @@
 """Bootstrap throughput next to the headline size: N = 100,000 rows (the int8 route's resample counts from two
-65,536-row windows per replicate) and 120 MVs / 12 LVs (7,381 pair columns; the split rows solver behind the digit-plane Gram).  One JSON line
+65,536-row windows per replicate) and 120 MVs / 12 LVs (7,381 pair columns; the quad solver -- round 5 -- behind the digit-plane Gram).  One JSON line
 per workload: replicates/s, kernel times from the library's HIP events, the Gram route and solver taken."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
