@@ -221,9 +221,9 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
 template <int LMAX, int CMAX = 8>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 8 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
                                                       const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
-                                                      int fuse_finish) {
+                                                      int fuse_finish, const int* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const long b = blockIdx.x;
+    const long b = live ? live[blockIdx.x] : (long)blockIdx.x;      // (kernels_nonmetric.h nm_kernel: the live list of the previous step)
     const int lane = threadIdx.x;
     const int Q = md.P, L = md.L, Pm = cd.Pm;
     double* state = gstate + b * state_stride;

@@ -7,10 +7,12 @@
 // small workspace and the descriptors are LDS-resident.  MODE 0 prepare, 1 step, 2 finish (solver_core.h nm_*).
 template <int MODE>
 __global__ void __launch_bounds__(256) nm_kernel(ModelDesc md, const double* __restrict__ Mp, long mp_stride, SolverOut so, double* gS, double* gstate,
-                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish) {
+                                                 const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish, const int* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
+    // `live` (may be null): the problems still iterating after the previous step (active_list_kernel's list) -- the launch then has one workgroup per LIVE
+    // problem instead of one per problem of the batch that finds itself stopped (the late iterations of a batch are a handful of problems among thousands)
+    const long b = live ? live[blockIdx.x] : (long)blockIdx.x;
     Workspace ws;
     ws.PS = cov_ld(md.P);
     ws.S = gS + b * cov_doubles(md.P);
@@ -52,10 +54,10 @@ template <int MODE>
 __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, const double* __restrict__ Mp, long mp_stride, SolverOut so,
                                                   double* gS, double* gSm, double* gstate, long state_stride,
                                                   const double* __restrict__ partial, int nparts, int* __restrict__ nactive, int fuse_finish, int extra_in_lds,
-                                                  unsigned short* gK16, int ld16) {
+                                                  unsigned short* gK16, int ld16, const int* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
+    const long b = live ? live[blockIdx.x] : (long)blockIdx.x;      // (nm_kernel: the live list of the previous step)
     const int Q = md.P, L = md.L;
     Workspace ws;
     ws.PS = cov_ld(Q);
@@ -160,10 +162,11 @@ __global__ void __launch_bounds__(256) nmg_kernel(ModelDesc md, CatDesc cd, Mode
 template <int MODE>
 __global__ void __launch_bounds__(256) nmx_kernel(ModelDesc md, MissDesc xd, const int* __restrict__ rowid, const double* __restrict__ Mp, long mp_stride, SolverOut so,
                                                   double* gS, double* gstate, long state_stride, const double* __restrict__ partial, int nparts,
-                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride, int fuse_finish) {
+                                                  int* __restrict__ nactive, const int2* __restrict__ ent, const int* __restrict__ nent, long ent_stride, int fuse_finish,
+                                                  const int* __restrict__ live) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lp = reinterpret_cast<double*>(smem_raw);
-    const long b = blockIdx.x;
+    const long b = live ? live[blockIdx.x] : (long)blockIdx.x;      // (nm_kernel: the live list of the previous step)
     Workspace ws;
     ws.PS = cov_ld(md.P);
     ws.S = gS + b * cov_doubles(md.P);
@@ -625,8 +628,9 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_codes_kernel(const unsigned s
 
 // second stage of a HOC pair: its score maps composed with the first stage's, in the layout the stop-rule passes read (solver_hoc.h)
 __global__ void __launch_bounds__(64) hoc_compose_kernel(HocDesc hd, const double* __restrict__ state1, long st1_stride, double* state2, long st2_stride, int n_chol2,
-                                                         double* pseudo, long ps_stride) {
-    const long b = blockIdx.x;
+                                                         double* pseudo, long ps_stride, const int* __restrict__ live) {
+    const long b = live ? live[blockIdx.x] : (long)blockIdx.x;      // (nm_kernel: the live list of the previous step -- a problem that stopped in this step still
+                                                                    //  gets its flag copied; one that stopped earlier keeps the cleared flag it got then)
     const double* st = state1 + b * st1_stride;
     NmState st2;
     nm_carve(st2, state2 + b * st2_stride, hd.P2, hd.L2);

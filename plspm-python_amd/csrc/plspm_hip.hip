@@ -464,6 +464,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
     else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
     else if (k == "solver_quad") { if (value != 0 && value != 1) return bad(); m->tune.solver_quad = value; }
+    else if (k == "nm_live") { if (value != 0 && value != 1) return bad(); m->tune.nm_live = value; }
     else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); if (value && !experiments) return exp_only(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); if (value && !experiments) return exp_only(); m->tune.i8_sched = value; }
@@ -521,6 +522,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "solver_rows") *value = m->tune.solver_rows;
     else if (k == "solver_wave") *value = m->tune.solver_wave;
     else if (k == "solver_quad") *value = m->tune.solver_quad;
+    else if (k == "nm_live") *value = m->tune.nm_live;
     else if (k == "nm_counts8") *value = m->tune.nm_counts8;
     else if (k == "last_solver") *value = m->last_solver;
     else if (k == "resample_aux") *value = m->tune.resample_aux;

@@ -174,20 +174,26 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     long long* d_nm_marks = nullptr;
     if (cat) { HIPCHK(m, plspm_dmalloc((void**)&d_nm_marks, 32 * sizeof(long long))); so.marks = d_nm_marks; }
 #endif
+    // round 5 (second half): from the second step on, a launch of the dense route covers the problems that were still iterating after the previous step --
+    // the list the previous stop-rule pass built and the count the host has just read -- instead of every problem of the batch: the late iterations of
+    // a batch are a handful of stragglers (up to max_iter + 1 trips) among thousands of problems whose workgroups did nothing but find their flag cleared
+    // (HOC on ordinal items: ~90 of ~100 trips per stage; 31 us per step launch, 79 us per compose launch at 5,000 problems)
+    dim3 lgrid = grid;
+    const int* live = nullptr;
     auto launch = [&](int mode_op) {
         ProfScope ps(m, PLSPM_K_SOLVER);
         if (cat) {
             auto k = mode_op == 0 ? nmg_kernel<0> : mode_op == 1 ? nmg_kernel<1> : nmg_kernel<2>;
-            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact, fuse, cat_fast,
-                               k16 ? (unsigned short*)m->gK16.p : (unsigned short*)nullptr, ld16);
+            hipLaunchKernelGGL(k, lgrid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact, fuse, cat_fast,
+                               k16 ? (unsigned short*)m->gK16.p : (unsigned short*)nullptr, ld16, live);
         } else if (nmx) {
             auto k = mode_op == 0 ? nmx_kernel<0> : mode_op == 1 ? nmx_kernel<1> : nmx_kernel<2>;
             const MissDesc xd{m->nmx_raw, m->nmx_K, m->d_Xk, m->d_Mk};
-            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, xd, (const int*)m->d_rowid, Mp, mp_stride, so, gS, gst, (long)st_doubles, (const double*)part, nparts,
-                               nact, ent, nent, ent_stride, fuse);
+            hipLaunchKernelGGL(k, lgrid, dim3(threads), lds, m->stream, md, xd, (const int*)m->d_rowid, Mp, mp_stride, so, gS, gst, (long)st_doubles, (const double*)part, nparts,
+                               nact, ent, nent, ent_stride, fuse, live);
         } else {
             auto k = mode_op == 0 ? nm_kernel<0> : mode_op == 1 ? nm_kernel<1> : nm_kernel<2>;
-            hipLaunchKernelGGL(k, grid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact, fuse);
+            hipLaunchKernelGGL(k, lgrid, dim3(threads), lds, m->stream, md, Mp, mp_stride, so, gS, gst, (const double*)part, nparts, nact, fuse, live);
         }
     };
     // (dense stop-rule pass: the list kernel of the pass counts the live problems anyway and writes the count to the pinned flag itself -- no
@@ -198,6 +204,10 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                                     : (L <= 2 ? nmw::nmw_step_kernel<2, 16> : L <= 4 ? nmw::nmw_step_kernel<4, 16> : L <= 6 ? nmw::nmw_step_kernel<6, 16> : nmw::nmw_step_kernel<8, 16>);
     if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
     for (int it = 0; it <= m->max_iter + 1; ++it) {
+        if (it >= 1 && dense && m->tune.nm_live != 0) {            // (*h_flag: the count behind the previous step == the length of the list its pass built)
+            const long nlive = *m->h_flag;
+            if (nlive >= 1 && nlive < nproblems) { lgrid = dim3((unsigned)nlive); live = (const int*)m->nmlist.p + 1; }
+        }
         if (!flag_from_list) HIPCHK(m, hipMemsetAsync(nact, 0, sizeof(int), m->stream));
         if (wave_step) {
             // prepare: the uint16 counts + the initial state only (nmg_kernel<3>); every step, the first one included, one wave per problem; the
@@ -206,13 +216,13 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
             if (it == 0) {
                 if (counts16_ready)       // the Gram wrote the upper triangles: mirror them, set the initial state (no packed fp64 matrix exists)
                     hipLaunchKernelGGL(nmg_kernel<4>, grid, dim3(256), lds, m->stream, md, cd, mdm, (const double*)nullptr, 0L, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
-                                       0, cat_fast, (unsigned short*)m->gK16.p, ld16);
+                                       0, cat_fast, (unsigned short*)m->gK16.p, ld16, (const int*)nullptr);
                 else
                     hipLaunchKernelGGL(nmg_kernel<3>, grid, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
-                                       0, cat_fast, (unsigned short*)m->gK16.p, ld16);
+                                       0, cat_fast, (unsigned short*)m->gK16.p, ld16, (const int*)nullptr);
             }
-            hipLaunchKernelGGL(wave_kernel, grid, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
-                               (const unsigned short*)m->gK16.p, ld16, fuse);
+            hipLaunchKernelGGL(wave_kernel, lgrid, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                               (const unsigned short*)m->gK16.p, ld16, fuse, live);
         } else
         launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
@@ -228,8 +238,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
             long conv_stride = (long)st_doubles;
             const int* conv_boff = m->d_boff;
             if (m->stage1) {
-                hipLaunchKernelGGL(hoc_compose_kernel, grid, dim3(64), 0, m->stream, make_hoc_desc(m), (const double*)m->stage1->nmstate.p,
-                                   (long)nm_state_doubles_of(src), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride);
+                hipLaunchKernelGGL(hoc_compose_kernel, lgrid, dim3(64), 0, m->stream, make_hoc_desc(m), (const double*)m->stage1->nmstate.p,
+                                   (long)nm_state_doubles_of(src), gst, (long)st_doubles, m->n_chol, (double*)m->pseudo.p, ps_stride, live);
                 conv_state = (const double*)m->pseudo.p; conv_stride = ps_stride; conv_boff = m->d_lv_cols;
             }
             if (dense) {
