@@ -28,6 +28,7 @@
 #include "solver_ops.h"
 #include "solver_wave.h"
 #include "solver_quad.h"
+#include "solver_wave16.h"
 
 using namespace plspm;
 

@@ -159,6 +159,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 
+// Wave variant for 9 .. 16 LVs (solver_wave16.h solve_problem_wave16; round 5): one wave per problem, four matrix entries per pair lane, V in LDS.
+template <int LMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_wave16_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const long b = blockIdx.x;
+    Wave16Ws<LMAX> ws;
+    wave16_carve(ws, reinterpret_cast<double*>(smem_raw));
+    FitOutputs out{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    DevWaveExec ex;
+    ex.tid = (int)threadIdx.x; ex.nt = 64; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
+    solve_problem_wave16<LMAX>(ex, md, ws, Md + b * md_stride, out);
+}
+
+
 // Quad variant (solver_quad.h solve_problem_quad; round 5): the wave solver's lane roles on FOUR waves per problem -- metric Mode-A models of
 // 65 .. 128 MVs and at most 16 LVs; two problems per CU (one wave of each per SIMD), ~52 KB of LDS per problem.
 template <int LMAX>

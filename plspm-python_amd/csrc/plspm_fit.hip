@@ -166,6 +166,15 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         if (m->n_chol > 0) hipExtLaunchKernelGGL((solver_wave_kernel<8, true>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         else hipExtLaunchKernelGGL((solver_wave_kernel<8, false>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 3;
+    } else if (dense && m->tune.solver_wave != 0 && wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax)) {
+        // the same for 9 .. 16 LVs (solver_wave16.h; round 5): four matrix entries per pair lane, V in LDS
+        const size_t lds = (size_t)wave16_ws_doubles<16>(m->L, m->kmax) * sizeof(double);
+        if ((rc = allow_lds(m, (const void*)solver_wave16_kernel<16>, lds))) return rc;
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        hipEvent_t stop = m->stop_event;
+        m->stop_event = nullptr;
+        hipExtLaunchKernelGGL((solver_wave16_kernel<16>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        m->last_solver = 6;
     } else if (dense) {
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
         if (m->P > 64 && m->tune.solver_quad != 0 && quad_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax, m->boff.data())) {
@@ -202,7 +211,7 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         long long h[32];
         HIPCHK(m, hipStreamSynchronize(m->stream));
         HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
-        if (m->last_solver == 3 || m->last_solver == 5) {
+        if (m->last_solver == 3 || m->last_solver == 5 || m->last_solver == 6) {
             fprintf(stderr, "[plspm wave clocks] load %lld  treat %lld  init %lld  iterations %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[13] - h[7], h[13] - h[0]);
             fprintf(stderr, "[plspm wave last iterate] apply_cov %lld  a/G/E %lld  regress %lld  outer+conv %lld\n", h[9] - h[8], h[10] - h[9], h[11] - h[10], h[12] - h[11]);

@@ -1,0 +1,347 @@
+// solver_wave16.h -- the wave solver (solver_wave.h: ONE 64-lane wave per problem, fixed lane roles) for inner models of 9 .. 16 LVs: metric Mode-A
+// models with at most 64 MVs -- "many LVs, few indicators each" (twelve LVs of three to five items) -- which the rows solver's generic thread-group
+// code served until round 5 (0.16 / 0.18 / 0.32 ms per 5,000 replicates at 10 / 12 / 16 LVs beside the wave solver's 0.10 at 8).
+// Same arithmetic, same reference lines as solver_wave.h / solver_quad.h:
+//   Config.treat plspm/config.py:299-305 + util.treat plspm/util.py:33-39; _MetricWeights.__init__ plspm/weights.py:28-39; .iterate
+//   plspm/weights.py:41-54; Scheme.*.calculate plspm/scheme.py:27-28, 36-37, 45-54; _ModeA.outer_weights_metric plspm/mode.py:28-29;
+//   WeightsCalculatorFactory.calculate plspm/weights.py:172-187 (stop rule); _MetricWeights.calculate plspm/weights.py:56-70 (sign rule);
+//   InnerModel / _effects plspm/inner_model.py:58-75, 33-53; bootstrap row plspm/bootstrap.py:58-64.
+// Roles:
+//   MV lane p < P          column p of the treated covariance in 64 register pairs, its weight
+//   pair lane t            FOUR entries of every L x L matrix: column m = t mod 16, rows l = t / 16 + 4 u, u = 0 .. 3 (the wave solver: one entry per lane,
+//                          L <= 8) -- a quarter of the lanes' work per phase is still a few dozen flops
+//   LV lane i < L          the small regressions of LV i and column i of (I - B)^-1
+// and the quad solver's arrangement of the small arrays: V = S W stays in LDS (pitch 17: conflict-free) and is read there by the Q sums (w_p V[p, m]
+// directly, no transposed T pass), the outer step (a folded into E), the sign rule and the loadings; the regressions have a scratch area of their
+// own.  LDS per problem ~16 KB + the regression scratch: eight problems per CU, like the wave solver.
+#pragma once
+#include "solver_wave.h"
+
+namespace plspm {
+
+constexpr int W16_VP = 17;                   // pitch of a row of V (doubles)
+
+template <int LMAX>
+struct Wave16Ws {
+    double* stage;   // [64 * W16_VP]  the column loader's 16 x 66 transposition tile; then V[p * W16_VP + m]
+    double* V;
+    double* w;       // [64]
+    double* mu;      // [64]
+    double *Qm, *Gm, *Em;      // [LMAX * LMAX], entry (l, m) at l * LMAX + m;  after the loop: Ind (= Qm), Cs (= Gm), Bm (= Em)
+    double *a, *r2;  // [LMAX]
+    double* sink;    // [LMAX]
+    double* scr;     // [L * regression_scratch_doubles(kmax)]
+};
+template <int LMAX> PLSPM_HD constexpr long wave16_ws_doubles(int L, int kmax) { return 64 * W16_VP + 64 + 64 + 3 * LMAX * LMAX + 3 * LMAX + (long)L * regression_scratch_doubles(kmax); }
+template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base) {
+    static_assert(64 * W16_VP >= 16 * 66, "the loader's tile fits the V area");
+    static_assert(LMAX == 16, "pair lane: column t mod 16, rows t / 16 + 4 u");
+    double* p = base;
+    ws.stage = p; ws.V = p; p += 64 * W16_VP;
+    ws.w = p; p += 64; ws.mu = p; p += 64;
+    ws.Qm = p; p += LMAX * LMAX; ws.Gm = p; p += LMAX * LMAX; ws.Em = p; p += LMAX * LMAX;
+    ws.a = p; p += LMAX; ws.r2 = p; p += LMAX; ws.sink = p; p += LMAX;
+    ws.scr = p;
+}
+// What this solver covers (the host asks before it launches): at least four problems per CU.
+template <int LMAX> PLSPM_HD bool wave16_solver_covers(int P, int L, int n_chol, int kmax) {
+    return P >= 1 && P <= 64 && L > 8 && L <= LMAX && n_chol == 0 && wave16_ws_doubles<LMAX>(L, kmax) * (long)sizeof(double) <= 40 * 1024;
+}
+
+// Md: the DENSE moment matrix [(P+1) x cov_ld(P)] of the mean-shifted columns + ones, upper triangle.  Outputs: out.row / out.status / out.iters.
+template <int LMAX, class Ex>
+PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<LMAX>& ws, const double* Md, const FitOutputs& out) {
+    constexpr int PMAX = 64, NE = LMAX * LMAX / 64;
+    const int P = md.P, L = md.L, PS = cov_ld(P), t = ex.tid, p = t;
+    const bool valid = p < P;
+    const int pc = valid ? p : P - 1;
+    const int lp = md.lvof[pc];                                  // MV role: my LV
+    const int em = t % LMAX, er0 = t / LMAX;                     // pair role: column em, rows er0 + 4 u
+    const bool lvlane = t < L;                                   // LV role
+    int pb0[NE], pk[NE], dlm[NE];                                // pair role, entry u: the block of its row; C[el, em] + 2 C[em, el]
+    bool pairu[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int el = er0 + (64 / LMAX) * u;
+        pairu[u] = el < L && em < L;
+        const int elc = pairu[u] ? el : 0, emc = pairu[u] ? em : 0;
+        pb0[u] = md.boff[elc];
+        pk[u] = pairu[u] ? md.boff[elc + 1] - pb0[u] : 0;
+        dlm[u] = pairu[u] ? (int)md.C[elc * L + emc] + 2 * (int)md.C[emc * L + elc] : 0;      // bit 0: LV em -> LV el
+    }
+    int nk = 0;                                                  // LV role: my predecessors, the first four one byte each
+    unsigned fpack = 0u;
+    if (lvlane) {
+        const int o = md.pred_off[t];
+        nk = md.pred_off[t + 1] - o;
+        for (int r = 0; r < 4; ++r) if (r < nk) fpack |= (unsigned)md.pred_idx[o + r] << (8 * r);
+    }
+    const int ne = md.n_eff;
+    const double shp = md.scaled ? md.shift[pc] : 0.0;
+    int kbmax = 0;
+    unsigned long long ends = 0ull;
+    for (int l = 0; l < L; ++l) {
+        const int k = md.boff[l + 1] - md.boff[l];
+        kbmax = k > kbmax ? k : kbmax;
+        ends |= 1ull << (md.boff[l + 1] - 1);
+    }
+    ends = ex.uniform(ends);
+    bool singular = false;
+
+    // 1. moments -> treated covariance (config.py:299-305, util.py:33-39): column p in registers
+    ex.mark(0);
+    double s[PMAX];
+    double dpp = 0.0, mup = 0.0;                                 // raw M[p][p] and the column sum M[p][P] (ones column)
+    const double n = ex.uniform_d(Md[(long)P * PS + P]);
+    ex.template load_cov<PMAX>(Md, PS, P, s, ws.stage, mup, dpp);
+    if (!valid) { mup = 0.0; dpp = 0.0; }
+    ex.mark(1);
+    ws.mu[p] = mup;
+    ws.w[p] = 1.0;                                               // init: block products with w = 1
+    ex.sync();
+    const double inv_n = ex.uniform_d(1.0 / n);
+    double fac = inv_n;
+    if (md.scaled) {
+        // g = std1(all N*P raw values) * sqrt((N-1)/N)   (config.py:302), evaluated around the grand mean
+        const double tot = ex.allsum(valid ? mup + n * shp : 0.0);
+        const double np_ = n * (double)P, grand = tot / np_;
+        const double d = shp - grand;
+        const double ss = ex.allsum(valid ? dpp + 2.0 * d * mup + n * d * d : 0.0);
+        const double g2 = ss / (np_ - 1.0) * ((n - 1.0) / n);
+        fac = ex.uniform_d(1.0 / (n * g2));
+    }
+    ex.fence();
+#pragma unroll
+    for (int qb = 0; qb < PMAX; qb += 8) {
+#pragma unroll
+        for (int q = qb; q < qb + 8; ++q) {
+            const double v = (s[q] - (mup * ws.mu[(q < P) ? q : P - 1]) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q)
+            s[q] = (q < P) ? v : 0.0;
+        }
+        ex.pin8(s[qb], s[qb + 1], s[qb + 2], s[qb + 3], s[qb + 4], s[qb + 5], s[qb + 6], s[qb + 7]);
+    }
+    if (!valid) {
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) s[q] = 0.0;
+    }
+    const double sdp = sqrt((dpp - (mup * mup) * inv_n) * fac);
+    const double corr2 = ex.uniform_d(n / (n - 1.0));
+    ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: V takes the tile's place)
+
+    // LV role: normal equations M[f, f] x = M[f, t] over my predecessors f (solver_quad.h: the same lambda)
+    const int* fglob = md.pred_idx + (lvlane ? md.pred_off[t] : 0);
+    const long rscr = regression_scratch_doubles(md.kmax);
+    const int km = md.kmax;
+    auto pred = [&](int r) { return r < 4 ? (int)((fpack >> (8 * r)) & 255u) : fglob[r]; };
+    auto regress = [&](const double* M) {
+        double* scratch = ws.scr + t * rscr;
+        double* x = scratch + 2 * km * km;
+        bool ok;
+        if (nk <= 4) {
+            unsigned fp = fpack;
+            ex.opaque(fp);
+            ok = wave_ldl4(M, LMAX, fp, nk, t, x);
+        } else {
+            for (int r = 0; r < nk; ++r) {
+                for (int c = 0; c < nk; ++c) scratch[r * nk + c] = M[fglob[r] * LMAX + fglob[c]];
+                x[r] = M[fglob[r] * LMAX + t];
+            }
+            ok = chol_factor(scratch, nk);
+            if (ok) chol_solve(scratch, nk, x);
+        }
+        if (!ok && !(nk > 1 && pinv_solve(M, LMAX, fglob, nk, t, x, scratch))) singular = true;
+        return x;
+    };
+
+    // ONE loop carries init, the iterations and the finalisation (as solve_problem_wave)
+    const double icorr2 = ex.uniform_d((n - 1.0) / n);
+    double Qe[NE], wp = valid ? 1.0 : 0.0;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) Qe[u] = 0.0;
+    int iteration = 0, phase = 0;
+    while (true) {
+        int pl = p, lpl = lp;                                    // opaque copies: LDS addresses recomputed per trip instead of hoisted and spilled
+        ex.opaque(pl); ex.opaque(lpl);
+        const int eml = pl % LMAX, er0l = pl / LMAX;
+        ex.mark(16);
+        ex.template seg_products<PMAX>(s, ws.w, P, ends, valid ? ws.V + pl * W16_VP : ex.sink(ws.sink));
+        ex.mark(17);
+        ex.sync();
+        ex.mark(18);
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if ((64 / LMAX) * u < L) {                           // (uniform: rows 4 u .. 4 u + 3 exist)
+                // Q[el, em] = sum over the MVs p of block el of w_p V[p, em]: eight terms in flight per trip
+                double s0 = 0.0, s1 = 0.0;
+                int pb = pb0[u];
+                ex.opaque(pb);
+                const double* vv = ws.V + pb * W16_VP + eml;
+                const double* ww = ws.w + pb;
+                for (int i0 = 0; i0 < kbmax; i0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pk[u]) ? ww[i0 + j] * vv[(i0 + j) * W16_VP] : 0.0;
+                    s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
+                }
+                Qe[u] = s0 + s1;
+                ws.Qm[pl + 64 * u] = pairu[u] ? Qe[u] : 1.0;
+            }
+        }
+        ex.sync();
+        ex.mark(19);
+        if (phase == 2) break;
+        if (phase == 0) {
+            wp = valid ? wave_rsqrt(ws.Qm[lpl * LMAX + lpl]) : 0.0;
+            ws.w[pl] = valid ? wp : 1.0;
+            ex.sync();
+            ex.mark(3);
+            phase = 1;
+            continue;
+        }
+        ++iteration;
+        ex.mark(9);
+        // Yhat_l = Y_l / std1 / corr:  a_l = 1 / (corr2 sqrt(Q_ll)),  G = cov0(Yhat) = a a' o Q   (weights.py:43-44)
+        const double rm = wave_rsqrt(ws.Qm[eml * LMAX + eml]), am = rm * icorr2;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if ((64 / LMAX) * u < L) {
+                const int ell = er0l + (64 / LMAX) * u;
+                const double rl = wave_rsqrt(ws.Qm[ell * LMAX + ell]), al = rl * icorr2;
+                const double Ge = al * am * Qe[u];
+                double Ee = 0.0;
+                if (pairu[u]) {
+                    if (md.scheme == SCHEME_PATH) {
+                        if (dlm[u] & 1) Ee = Qe[u] * rl * rm;    // column em of E: correlations with the successors of em (scheme.py:51-53)
+                    } else if (dlm[u]) {
+                        const int d = (dlm[u] & 1) + (dlm[u] >> 1);
+                        Ee = (md.scheme == SCHEME_CENTROID) ? ((Ge > 0.0) ? 1.0 : ((Ge < 0.0) ? -1.0 : 0.0)) : Ge * corr2 * (double)d;   // cov1 = cov0 N/(N-1)
+                    }
+                    ws.Gm[pl + 64 * u] = Ge; ws.Em[pl + 64 * u] = al * Ee;      // (row el of E carries a_el: the outer step multiplies V with a E)
+                    if (ell == eml) ws.a[ell] = al;
+                }
+            }
+        }
+        ex.sync();
+        ex.mark(10);
+        if (md.scheme == SCHEME_PATH) {
+            if (lvlane && nk > 0) {                              // regression of Yhat_t on its predecessors, no intercept (scheme.py:48-50)
+                const double* x = regress(ws.Gm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r < nk) ws.Em[pred(r) * LMAX + pl] = ws.a[pred(r)] * x[r];
+                for (int r = 4; r < nk; ++r) ws.Em[pred(r) * LMAX + pl] = ws.a[pred(r)] * x[r];
+            }
+            ex.sync();
+        }
+        ex.mark(11);
+        // outer step, Mode A: w = (S Wn E)[p, lv(p)] == X'Z/N  (mode.py:29): row p of V out of LDS
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int m = 0; m + 1 < LMAX; m += 2) {
+            if (m < L) c0 += ws.V[pl * W16_VP + m] * ws.Em[m * LMAX + lpl];
+            if (m + 1 < L) c1 += ws.V[pl * W16_VP + m + 1] * ws.Em[(m + 1) * LMAX + lpl];
+        }
+        const double wn = valid ? c0 + c1 : 0.0;
+        const double dd = fabs(wp) - fabs(wn);
+        const double conv = ex.allsum(dd * dd);
+        wp = wn;
+        ws.w[pl] = valid ? wp : 1.0;
+        ex.sync();
+        ex.mark(12);
+        if (conv < md.tol || iteration > md.max_iter) phase = 2;
+    }
+    const bool not_converged = iteration > md.max_iter;
+    ex.mark(4);
+
+    // finalize (weights.py:56-70): wf_l = 1 / sqrt(Q_ll); returned weights never sign-flipped
+    const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
+    wp *= wfp;
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l])
+    unsigned negmask = 0u;
+    {
+        double vr[LMAX];                                         // (my row of V in one batch of loads)
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * W16_VP + (l < L ? l : 0)];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+            if (l < L) { const int neg = ex.vote_count(valid && vr[l] < 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }
+    }
+    const double sgl = ((negmask >> lp) & 1u) ? -1.0 : 1.0;
+    const double vlp = ws.V[p * W16_VP + lp];                    // V[p, lv(p)] for the loading
+    double* const Cs = ws.Gm;                                    // (the iteration's G and E are dead: the score covariance and the path matrix take their places,
+    double* const Bm = ws.Em;                                    //  the indirect effects the place of Q once the covariance is formed)
+    double* const Ind = ws.Qm;
+    {
+        const double wfm = wave_rsqrt(ws.Qm[em * LMAX + em]), sm = ((negmask >> em) & 1u) ? -1.0 : 1.0;
+        double cs[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int el = er0 + (64 / LMAX) * u;
+            const double wfl = wave_rsqrt(ws.Qm[el * LMAX + el]), sl = ((negmask >> el) & 1u) ? -1.0 : 1.0;
+            cs[u] = sl * sm * wfl * wfm * Qe[u];                 // population covariance of the sign-corrected scores
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if (pairu[u]) Cs[t + 64 * u] = cs[u];
+            Bm[t + 64 * u] = 0.0;                                // (all 256 entries: the effects below run without a test per row)
+        }
+    }
+    ex.sync();
+    ex.mark(5);
+    // inner model (inner_model.py:58-75): OLS with intercept == centred normal equations on the score covariance
+    double r2p = 0.0;
+    if (lvlane) {
+        if (nk > 0) {
+            const double* x = regress(Cs);
+            double expl = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) { const int fr = pred(r); Bm[t * LMAX + fr] = x[r]; expl += x[r] * Cs[fr * LMAX + t]; }
+            for (int r = 4; r < nk; ++r) { const int fr = pred(r); Bm[t * LMAX + fr] = x[r]; expl += x[r] * Cs[fr * LMAX + t]; }
+            r2p = expl / Cs[t * LMAX + t];
+        }
+    }
+    ex.sync();
+    ex.mark(6);
+    // effects (inner_model.py:33-53): column t of (I - B)^-1 by forward substitution in the registers of LV lane t (solver_quad.h: colx = the column
+    // without its unit entry; rows >= L of B are zero)
+    if (lvlane) {
+        double colx[LMAX];
+#pragma unroll
+        for (int i = 0; i < LMAX; ++i) {
+            double i0 = 0.0, i1 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < i; k += 2) { i0 += Bm[i * LMAX + k] * colx[k]; i1 += Bm[i * LMAX + k + 1] * colx[k + 1]; }
+            if (i & 1) i0 += Bm[i * LMAX + i - 1] * colx[i - 1];
+            const double ind = (i > t) ? i0 + i1 : 0.0;
+            colx[i] = (i > t) ? Bm[i * LMAX + t] + ind : 0.0;
+            Ind[i * LMAX + t] = ind;
+        }
+    }
+    ex.sync();
+    ex.mark(7);
+    // outputs: the bootstrap record  weights | r2 | total | direct | loadings | status | iterations  (bootstrap.py:58-64)
+    if (out.row) {
+        if (valid) {
+            out.row[p] = wp;
+            out.row[P + L + 2 * ne + p] = sgl * vlp * wfp / sdp;
+        }
+        if (lvlane) out.row[P + t] = r2p;
+        for (int e = t; e < ne; e += 64) {                       // (up to 120 effects at 16 LVs)
+            const int idx = md.eff_to[e] * LMAX + md.eff_from[e];
+            out.row[P + L + e] = Bm[idx] + Ind[idx];
+            out.row[P + L + ne + e] = Bm[idx];
+        }
+    }
+    const bool bad = ex.vote_any((valid && !(isfinite(wp) && isfinite(sdp) && sdp > 0.0)) || (lvlane && !isfinite(r2p)));
+    const bool sing = ex.vote_any(singular);
+    if (t == 0) {
+        int st = sing ? ST_SINGULAR : (not_converged ? ST_NOT_CONVERGED : ST_OK);
+        if (st == ST_OK && bad) st = ST_NONFINITE;
+        if (out.status) *out.status = st;
+        if (out.iters) *out.iters = iteration;
+        if (out.row) { out.row[2 * P + L + 2 * ne] = (double)st; out.row[2 * P + L + 2 * ne + 1] = (double)iteration; }
+    }
+    ex.mark(13);
+}
+
+}  // namespace plspm

@@ -15,6 +15,7 @@
 #include "../../plspm-python_amd/csrc/solver_ops.h"
 #include "../../plspm-python_amd/csrc/solver_wave.h"
 #include "../../plspm-python_amd/csrc/solver_quad.h"
+#include "../../plspm-python_amd/csrc/solver_wave16.h"
 
 using namespace plspm;
 
@@ -379,6 +380,29 @@ int hostemu_solve_wave(int P, int L, int PA, int scheme, int scaled, int max_ite
             HostExec ex{t, nthreads, &bar, red.data()};
             if (em.md.n_chol > 0) solve_problem_wave<8, true>(ex, em.md, ws, Md, out);
             else solve_problem_wave<8, false>(ex, em.md, ws, Md, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+// Wave solver for 9 .. 16 LVs (solver_wave16.h solve_problem_wave16<16>): 64 emulated lanes; returns 1 for a model it does not cover.
+int hostemu_solve_wave16(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                         const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                         double* row, int* iters, int* status) {
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    if (!wave16_solver_covers<16>(P, L, em.md.n_chol, em.md.kmax)) return 1;
+    const int nthreads = 64;
+    std::vector<double> lds(wave16_ws_doubles<16>(L, em.md.kmax), 0.0), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            Wave16Ws<16> ws{};
+            wave16_carve(ws, lds.data());
+            HostExec ex{t, nthreads, &bar, red.data()};
+            solve_problem_wave16<16>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

@@ -150,6 +150,12 @@ def test_wave_solver_status_codes_and_fallbacks():
     nm = native_model(orc.Model(b9, C9, "A" * 9, "path", True))
     nm.upload(X9); nm.set_option("gram_path", 2)
     nm.bootstrap(16, seed=1)
+    assert nm.get_option("last_solver") == 6                   # nine LVs: the wave solver for 9 ... 16 LVs (round 5, solver_wave16.h; tests/test_gpu_solver_wave16.py)
+    C17 = orc.chain_C(17)
+    X17, b17 = orc.synth(300, C17, 3, seed=1)
+    nm = native_model(orc.Model(b17, C17, "A" * 17, "path", True))
+    nm.upload(X17); nm.set_option("gram_path", 2)
+    nm.bootstrap(16, seed=1)
     assert nm.get_option("last_solver") == 2
 
 

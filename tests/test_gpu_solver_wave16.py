@@ -1,0 +1,118 @@
+"""GPU parity of solver_wave16_kernel (csrc/solver_wave16.h: one wave per replicate, four matrix entries per pair lane) -- the bootstrap solver of metric
+Mode-A models with at most 64 MVs and 9 ... 16 LVs -- through the C-ABI: against the oracle (reference arithmetic on the resampled data) and the rows / LDS
+variants on the same moment matrices.  Tolerances: oracle 1e-8 (north_star asks 1e-6); between solver variants 1e-10; iteration counts and status words equal."""
+import numpy as np
+import pytest
+
+import plspm_oracle as orc
+from helpers import assert_close
+from test_gpu_parity import native_model
+from test_solver_hostemu_quad import _shaped
+from test_solver_hostemu_wave16 import _dag
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-8, 1e-11
+
+
+def _three_solvers(nm, B, seed, idx=None):
+    out = {}
+    for name, (rows_opt, wave_opt, codes) in {"wave16": (1, 1, (6,)), "rows": (1, 0, (2, 1)), "lds": (0, 0, (1,))}.items():
+        nm.set_option("solver_rows", rows_opt)
+        nm.set_option("solver_wave", wave_opt)
+        out[name] = nm.bootstrap(B, seed=seed, idx=idx)
+        # (a wide inner model's generic workspace may not fit the rows solver's LDS share: the LDS solver then)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in codes, name
+    nm.set_option("solver_rows", 1); nm.set_option("solver_wave", 1)
+    return out
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_wave16_solver_equals_rows_and_lds_solvers_and_the_oracle(scheme, scaled):
+    """5 MVs x 12 LVs."""
+    from plspm import _native
+    C = _dag(12, 2)
+    X, blocks = orc.synth(3000, C, 5, seed=9)
+    model = orc.Model(blocks, C, "A" * 12, scheme, scaled)
+    nm = native_model(model)
+    nm.upload(X)
+    out = _three_solvers(nm, 700, 3)
+    rows, status, iters = out["wave16"]
+    assert np.all(status == 0)
+    for other in ("rows", "lds"):
+        assert np.array_equal(status, out[other][1]) and np.array_equal(iters, out[other][2]), other
+        assert_close(rows, out[other][0], 1e-10, 1e-13, what=other)
+    corr = orc.correction(3000)
+    for r in (0, 347, 699):
+        mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(3, r, 3000), corr)
+        assert its == iters[r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("sizes,fan", [([4] * 16, 1), ([4] * 16, 5), ([1] * 8 + [7] * 8, 2), ([1, 17, 2, 9, 5, 3, 3, 3, 4, 1], 4), ([30, 1, 1, 1, 1, 1, 1, 1, 1], 2),
+                                       ([5, 4, 3, 6, 2, 5, 4, 3, 6, 2, 5, 4, 3], 6), ([2] * 11, 10), ([3] * 9, 1)])
+@pytest.mark.parametrize("scheme", ["factorial", "path"])
+def test_wave16_solver_model_shapes(sizes, fan, scheme):
+    """Ragged blocks, 64 MVs, 9 ... 16 LVs, one to ten predecessors (in-register LDL', Cholesky in the scratch area), partly filled row groups of the pair lanes."""
+    from plspm import _native
+    L = len(sizes)
+    C = _dag(L, fan)
+    X, blocks = _shaped(C, sizes, seed=4, N=700)
+    model = orc.Model(blocks, C, "A" * L, scheme, True)
+    nm = native_model(model)
+    nm.upload(X)
+    out = _three_solvers(nm, 130, 11)
+    rows, status, iters = out["wave16"]
+    assert np.array_equal(status, out["rows"][1]) and np.array_equal(status, out["lds"][1])
+    ok = status == 0
+    assert ok.sum() >= 120
+    assert np.array_equal(iters[ok], out["rows"][2][ok]) and np.array_equal(iters[ok], out["lds"][2][ok])
+    assert_close(rows[ok], out["rows"][0][ok], 1e-10, 1e-13, what="rows")
+    assert_close(rows[ok], out["lds"][0][ok], 1e-10, 1e-13, what="lds")
+    corr = orc.correction(700)
+    r = int(np.flatnonzero(ok)[-1])
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(11, r, 700), corr)
+    assert its == iters[r]
+    assert_close(rows[r], mine, RTOL, ATOL)
+
+
+def test_wave16_solver_status_codes_sign_rule_and_fallbacks():
+    sizes = [5, 6, 4, 7, 5, 4, 6, 5, 4, 5]
+    C = _dag(10, 2)
+    X, blocks = _shaped(C, sizes, seed=9)
+    tight = orc.Model(blocks, C, "A" * 10, "centroid", True, max_iter=2, tol=1e-14)
+    nm = native_model(tight)
+    nm.upload(X); nm.set_option("gram_path", 2)
+    rows, status, iters = nm.bootstrap(70, seed=2)
+    assert nm.get_option("last_solver") == 6 and np.all(status == 1) and np.all(iters == 3)
+    Xn = X.copy()
+    Xn[:, blocks[0][:4]] *= -1.0
+    Xn[:, blocks[9][:4]] *= -1.0
+    nm = native_model(orc.Model(blocks, C, "A" * 10, "path", True))
+    nm.upload(Xn); nm.set_option("gram_path", 2)
+    out = _three_solvers(nm, 70, 2)
+    assert np.all(out["wave16"][1] == 0)
+    assert_close(out["wave16"][0], out["rows"][0], 1e-10, 1e-13)
+    # a Mode-B block: not this solver's
+    nmo = native_model(orc.Model(blocks, C, "A" * 9 + "B", "centroid", True))
+    nmo.upload(X); nmo.set_option("gram_path", 2)
+    nmo.bootstrap(70, seed=1)
+    assert nmo.get_option("last_solver") in (1, 2)
+
+
+def test_wave16_solver_full_size_batch_properties():
+    """10k x 60 x 12, 5,000 replicates: every record converged, equal to the rows solver's, independent of the batch it travels in."""
+    C = _dag(12, 2)
+    X, blocks = orc.synth(10000, C, 5, seed=0)
+    model = orc.Model(blocks, C, "A" * 12, "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    rows, status, iters = nm.bootstrap(5000, seed=1)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 6 and np.all(status == 0)
+    nm.set_option("solver_wave", 0)
+    rows_s, status_s, iters_s = nm.bootstrap(5000, seed=1)
+    assert nm.get_option("last_solver") == 2 and np.array_equal(iters, iters_s)
+    assert_close(rows, rows_s, 1e-10, 1e-13)
+    nm.set_option("solver_wave", 1)
+    part, _, _ = nm.bootstrap(700, seed=1, rep_offset=4300)
+    assert np.array_equal(part, rows[4300:])

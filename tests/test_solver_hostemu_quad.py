@@ -22,7 +22,7 @@ def emu():
     return ctypes.CDLL(os.path.join(EMU, "libplspm_hostemu.so"))
 
 
-def run_quad(lib, X, model, counts=None, shift=None):
+def run_quad(lib, X, model, counts=None, shift=None, entry="hostemu_solve_quad"):
     """solve_problem_quad<16> on the dense upper-triangular moment matrix of the device-ordered columns; returns the record pieces in DATA
     column order, or None when the model is outside the quad solver's class."""
     order = model.mv_order
@@ -40,7 +40,7 @@ def run_quad(lib, X, model, counts=None, shift=None):
     iters, status = ctypes.c_int(0), ctypes.c_int(-1)
     Md = np.ascontiguousarray(dense_from_packed(Mp, PA, P))
     shift = np.ascontiguousarray(shift, dtype=np.float64)
-    rc = lib.hostemu_solve_quad(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
+    rc = getattr(lib, entry)(P, L, PA, SCHEME_ID[model.scheme], int(model.scaled), model.max_iter, ctypes.c_double(model.tol),
                                 _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte), _ptr(mode, ctypes.c_int), _ptr(shift), ne,
                                 _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Md), _ptr(row), ctypes.byref(iters), ctypes.byref(status))
     if rc:
