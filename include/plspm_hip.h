@@ -109,8 +109,10 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS; models of
  *                     65 ... 128 MVs whose blocks divide into two runs of at most 64 MVs: four waves per replicate, two threads per MV
  *                     (solver_rows_split_kernel)
- *   "solver_wave"     1 (default) | 0   among those, Mode-A models with at most 8 LVs: the wave-native formulation (solver_wave_kernel: fixed
- *                     lane roles, coalesced triangle load + LDS transpose) instead of solver_rows_kernel
+ *   "solver_wave"     1 (default) | 0 | 3   among those, models with at most 8 LVs (Mode-B blocks included) or -- round 5 -- all-Mode-A models with at most
+ *                     16 LVs: the wave-native formulations (one wave per replicate with fixed lane roles, coalesced triangle load + LDS transpose:
+ *                     solver_wave_kernel for Mode-B blocks, solver_wave16_kernel<8> / <16> for Mode A) instead of solver_rows_kernel; 3: Mode-A
+ *                     models of at most 8 LVs on the round-3 kernel (solver_wave_kernel<8, false>; A/B)
  *   "solver_quad"     1 (default) | 0   (round 5) Mode-A models of 65 ... 128 MVs and at most 16 LVs whose blocks divide into two runs of at most 64
  *                     MVs: the wave solver's fixed lane roles on four waves per replicate (solver_quad_kernel) instead of solver_rows_split_kernel
  *   "solver_threads"  64 | 128 | 256      threads per problem of the LDS solver (default 128)
@@ -152,7 +154,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  * (Test seams and the option values of the experiments build: include/plspm_hip_test.h.)
  *
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
- * (1 LDS solver, 2 rows solver, 3 wave solver, 4 split rows solver, 5 quad solver) tell what the last bootstrap call took.
+ * (1 LDS solver, 2 rows solver, 3 wave solver of round 3 / Mode-B blocks, 4 split rows solver, 5 quad solver, 6 / 7 wave solver for 9 ... 16 / at most 8 LVs) tell what the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value);

@@ -77,6 +77,55 @@ struct DevExecT {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the stores above are not on the compiler's counters
     }
+    // The same stream with a SECOND store per block: the block sum times `scale` (the thread's weight) at `OFF2` bytes behind the first -- solver_wave16.h
+    // reads Q = W' S W from that copy (one load per term) instead of multiplying w_p V[p, m] term by term or building a transposed copy in a pass of its own.
+#define PLSPM_SEG_COL2(J, ACC, SOP)                                                                                 \
+    "v_fmac_f64_dpp " ACC ", %5, " SOP " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"                        \
+    "s_bitcmp1_b32 %22, " #J "\n\t"                                                                                 \
+    "s_cbranch_scc1 .Lc" #J "_%=\n"                                                                                 \
+    ".Lb" #J "_%=:\n\t"
+#define PLSPM_SEG_CLOSE2(J)                                                                                         \
+    ".Lc" #J "_%=:\n\t"                                                                                             \
+    "v_add_f64 %3, %0, %1\n\t"                                                                                      \
+    "ds_write_b64 %2, %3\n\t"                                                                                       \
+    "v_mul_f64 %4, %3, %23\n\t"                                                                                     \
+    "ds_write_b64 %2, %4 offset:%24\n\t"                                                                            \
+    "v_add_u32 %2, 8, %2\n\t"                                                                                       \
+    "v_mov_b64 %0, 0\n\t"                                                                                           \
+    "v_mov_b64 %1, 0\n\t"                                                                                           \
+    "s_branch .Lb" #J "_%=\n"
+    template <int PMAX, int OFF2> __device__ __forceinline__ void seg_products2(const double (&s)[PMAX], const double* w, int P, unsigned long long ends, double* vrow, double scale) {
+        static_assert(PMAX % 16 == 0 && OFF2 > 0 && OFF2 < 65536 && OFF2 % 8 == 0, "sixteen columns per statement; the second copy within the instruction's offset field");
+        double W[PMAX / 16];
+#pragma unroll
+        for (int a = 0; a < PMAX / 16; ++a) W[a] = w[min(16 * a + (tid & 15), P - 1)];
+        unsigned va = (unsigned)(size_t)vrow;
+        double r0 = 0.0, r1 = 0.0, t, t2;
+#pragma unroll
+        for (int a = 0; a < PMAX / 16; ++a) {
+            if (16 * a < P) {                                     // (uniform)
+                const unsigned eh = (unsigned)(ends >> (16 * a)) & 0xffffu;
+                const double* c = s + 16 * a;
+                asm volatile("s_nop 4\n\t"
+                             PLSPM_SEG_COL2(0, "%0", "%6") PLSPM_SEG_COL2(1, "%1", "%7") PLSPM_SEG_COL2(2, "%0", "%8") PLSPM_SEG_COL2(3, "%1", "%9")
+                             PLSPM_SEG_COL2(4, "%0", "%10") PLSPM_SEG_COL2(5, "%1", "%11") PLSPM_SEG_COL2(6, "%0", "%12") PLSPM_SEG_COL2(7, "%1", "%13")
+                             PLSPM_SEG_COL2(8, "%0", "%14") PLSPM_SEG_COL2(9, "%1", "%15") PLSPM_SEG_COL2(10, "%0", "%16") PLSPM_SEG_COL2(11, "%1", "%17")
+                             PLSPM_SEG_COL2(12, "%0", "%18") PLSPM_SEG_COL2(13, "%1", "%19") PLSPM_SEG_COL2(14, "%0", "%20") PLSPM_SEG_COL2(15, "%1", "%21")
+                             "s_branch .Lend_%=\n"
+                             PLSPM_SEG_CLOSE2(0) PLSPM_SEG_CLOSE2(1) PLSPM_SEG_CLOSE2(2) PLSPM_SEG_CLOSE2(3) PLSPM_SEG_CLOSE2(4) PLSPM_SEG_CLOSE2(5)
+                             PLSPM_SEG_CLOSE2(6) PLSPM_SEG_CLOSE2(7) PLSPM_SEG_CLOSE2(8) PLSPM_SEG_CLOSE2(9) PLSPM_SEG_CLOSE2(10) PLSPM_SEG_CLOSE2(11)
+                             PLSPM_SEG_CLOSE2(12) PLSPM_SEG_CLOSE2(13) PLSPM_SEG_CLOSE2(14) PLSPM_SEG_CLOSE2(15)
+                             ".Lend_%=:"
+                             : "+v"(r0), "+v"(r1), "+v"(va), "=&v"(t), "=&v"(t2)
+                             : "v"(W[a]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]),
+                               "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]), "s"(eh), "v"(scale), "i"(OFF2)
+                             : "memory", "scc");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef PLSPM_SEG_COL2
+#undef PLSPM_SEG_CLOSE2
 #undef PLSPM_SEG_COL
 #undef PLSPM_SEG_CLOSE
     // Block loader of the split rows solver (solver_core.h solve_problem_rows<64, true>): lane of a wave <-> MV pc (consecutive over the wave's

@@ -155,7 +155,18 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
     long long* d_marks = nullptr;
     HIPCHK(m, plspm_dmalloc((void**)&d_marks, 32 * sizeof(long long))); so.marks = d_marks;
 #endif
-    if (dense && m->tune.solver_wave != 0 && wave_solver_covers<8>(m->P, m->L, m->n_chol)) {
+    if (dense && (m->tune.solver_wave == 1 || m->tune.solver_wave == 2) && m->n_chol == 0 && m->L <= 8 && wave_solver_covers<8>(m->P, m->L, m->n_chol) &&
+        wave16_ws_doubles<8>(m->L, m->kmax) * sizeof(double) <= 20 * 1024) {
+        // round 5 (second half): all-Mode-A models of at most 8 LVs -- the headline's class -- in the arrangement of solver_wave16.h at LMAX = 8: V in LDS, the product
+        // stream's second copy w V for the Q sums, a folded into E (0.095 -> 0.084 ms per 5,000 replicates; set_option("solver_wave", 3): the round-3 kernel)
+        const size_t lds = (size_t)wave16_ws_doubles<8>(m->L, m->kmax) * sizeof(double);
+        if ((rc = allow_lds(m, (const void*)solver_wave16_kernel<8>, lds))) return rc;
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        hipEvent_t stop = m->stop_event;
+        m->stop_event = nullptr;
+        hipExtLaunchKernelGGL((solver_wave16_kernel<8>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        m->last_solver = 7;
+    } else if (dense && m->tune.solver_wave != 0 && wave_solver_covers<8>(m->P, m->L, m->n_chol)) {
         // one wave per problem with fixed lane roles (solver_wave.h): at most 64 MVs and 8 LVs; Mode-B blocks keep their inverses behind the workspace
         const size_t lds = (size_t)wave_ws_doubles<8>(m->n_chol) * sizeof(double);
         ProfScope ps(m, PLSPM_K_SOLVER);
@@ -211,7 +222,7 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         long long h[32];
         HIPCHK(m, hipStreamSynchronize(m->stream));
         HIPCHK(m, hipMemcpy(h, d_marks, sizeof(h), hipMemcpyDeviceToHost));
-        if (m->last_solver == 3 || m->last_solver == 5 || m->last_solver == 6) {
+        if (m->last_solver == 3 || m->last_solver >= 5) {
             fprintf(stderr, "[plspm wave clocks] load %lld  treat %lld  init %lld  iterations %lld  finalize %lld  inner %lld  effects %lld  outputs %lld  total %lld\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[13] - h[7], h[13] - h[0]);
             fprintf(stderr, "[plspm wave last iterate] apply_cov %lld  a/G/E %lld  regress %lld  outer+conv %lld\n", h[9] - h[8], h[10] - h[9], h[11] - h[10], h[12] - h[11]);

@@ -462,7 +462,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "i8_cus") { if (value != 0 && (value < 8 || value > 4096)) return bad(); m->tune.i8_cus = value; }
     else if (k == "i8_rt") { if (value != 0 && value != 16 && value != 8 && value != 20) return bad(); if (value == 8 && !experiments) return exp_only(); m->tune.i8_rt = value; }
     else if (k == "solver_rows") { if (value != 0 && value != 1) return bad(); m->tune.solver_rows = value; }
-    else if (k == "solver_wave") { if (value != 0 && value != 1) return bad(); m->tune.solver_wave = value; }
+    else if (k == "solver_wave") { if (value < 0 || value > 3) return bad(); m->tune.solver_wave = value; }
     else if (k == "solver_quad") { if (value != 0 && value != 1) return bad(); m->tune.solver_quad = value; }
     else if (k == "nm_live") { if (value != 0 && value != 1) return bad(); m->tune.nm_live = value; }
     else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }

@@ -19,11 +19,14 @@
 
 namespace plspm {
 
-constexpr int W16_VP = 17;                   // pitch of a row of V (doubles)
+// VP: pitch of a row of V (doubles): odd -- conflict-free 8-byte accesses.  TCOPY (LMAX = 8): the product stream stores w_p V[p, m] as a second copy behind V
+// (device_exec.h seg_products2: one multiply + one store per block close) and the Q sums read that -- one load per term; at LMAX = 16 the copy would cost two of the
+// eight problems a CU holds, and the sums multiply w_p V[p, m] term by term.
+template <int LMAX> struct W16 { static constexpr int VP = LMAX + 1; static constexpr bool TCOPY = LMAX <= 8; };
 
 template <int LMAX>
 struct Wave16Ws {
-    double* stage;   // [64 * W16_VP]  the column loader's 16 x 66 transposition tile; then V[p * W16_VP + m]
+    double* stage;   // [64 * W16<LMAX>::VP]  the column loader's 16 x 66 transposition tile; then V[p * W16<LMAX>::VP + m]
     double* V;
     double* w;       // [64]
     double* mu;      // [64]
@@ -32,12 +35,14 @@ struct Wave16Ws {
     double* sink;    // [LMAX]
     double* scr;     // [L * regression_scratch_doubles(kmax)]
 };
-template <int LMAX> PLSPM_HD constexpr long wave16_ws_doubles(int L, int kmax) { return 64 * W16_VP + 64 + 64 + 3 * LMAX * LMAX + 3 * LMAX + (long)L * regression_scratch_doubles(kmax); }
+template <int LMAX> PLSPM_HD constexpr long wave16_v_doubles() {                                                                             // (the loader's tile fits the V area)
+    return (W16<LMAX>::TCOPY ? 2 : 1) * 64 * W16<LMAX>::VP > 16 * 66 ? (W16<LMAX>::TCOPY ? 2 : 1) * 64 * W16<LMAX>::VP : 16 * 66;
+}
+template <int LMAX> PLSPM_HD constexpr long wave16_ws_doubles(int L, int kmax) { return wave16_v_doubles<LMAX>() + 64 + 64 + 3 * LMAX * LMAX + 3 * LMAX + (long)L * regression_scratch_doubles(kmax); }
 template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base) {
-    static_assert(64 * W16_VP >= 16 * 66, "the loader's tile fits the V area");
-    static_assert(LMAX == 16, "pair lane: column t mod 16, rows t / 16 + 4 u");
+    static_assert(LMAX == 16 || LMAX == 8, "pair lane: column t mod LMAX, rows t / LMAX + (64 / LMAX) u");
     double* p = base;
-    ws.stage = p; ws.V = p; p += 64 * W16_VP;
+    ws.stage = p; ws.V = p; p += wave16_v_doubles<LMAX>();
     ws.w = p; p += 64; ws.mu = p; p += 64;
     ws.Qm = p; p += LMAX * LMAX; ws.Gm = p; p += LMAX * LMAX; ws.Em = p; p += LMAX * LMAX;
     ws.a = p; p += LMAX; ws.r2 = p; p += LMAX; ws.sink = p; p += LMAX;
@@ -45,13 +50,13 @@ template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base)
 }
 // What this solver covers (the host asks before it launches): at least four problems per CU.
 template <int LMAX> PLSPM_HD bool wave16_solver_covers(int P, int L, int n_chol, int kmax) {
-    return P >= 1 && P <= 64 && L > 8 && L <= LMAX && n_chol == 0 && wave16_ws_doubles<LMAX>(L, kmax) * (long)sizeof(double) <= 40 * 1024;
+    return P >= 1 && P <= 64 && L > LMAX / 2 && L <= LMAX && n_chol == 0 && wave16_ws_doubles<LMAX>(L, kmax) * (long)sizeof(double) <= 40 * 1024;
 }
 
 // Md: the DENSE moment matrix [(P+1) x cov_ld(P)] of the mean-shifted columns + ones, upper triangle.  Outputs: out.row / out.status / out.iters.
 template <int LMAX, class Ex>
 PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<LMAX>& ws, const double* Md, const FitOutputs& out) {
-    constexpr int PMAX = 64, NE = LMAX * LMAX / 64;
+    constexpr int PMAX = 64, NE = LMAX * LMAX / 64;              // (LMAX = 8: one entry per lane -- an A/B form of the wave solver's own class, option solver_wave 2)
     const int P = md.P, L = md.L, PS = cov_ld(P), t = ex.tid, p = t;
     const bool valid = p < P;
     const int pc = valid ? p : P - 1;
@@ -115,7 +120,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     for (int qb = 0; qb < PMAX; qb += 8) {
 #pragma unroll
         for (int q = qb; q < qb + 8; ++q) {
-            const double v = (s[q] - (mup * ws.mu[(q < P) ? q : P - 1]) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q)
+            const double v = (s[q] - (mup * ex.bcast(mup, (q < P) ? q : P - 1, ws.mu)) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q); mu_q: a lane broadcast
             s[q] = (q < P) ? v : 0.0;
         }
         ex.pin8(s[qb], s[qb + 1], s[qb + 2], s[qb + 3], s[qb + 4], s[qb + 5], s[qb + 6], s[qb + 7]);
@@ -164,7 +169,8 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         ex.opaque(pl); ex.opaque(lpl);
         const int eml = pl % LMAX, er0l = pl / LMAX;
         ex.mark(16);
-        ex.template seg_products<PMAX>(s, ws.w, P, ends, valid ? ws.V + pl * W16_VP : ex.sink(ws.sink));
+        if constexpr (W16<LMAX>::TCOPY) ex.template seg_products2<PMAX, 64 * W16<LMAX>::VP * 8>(s, ws.w, P, ends, ws.V + pl * W16<LMAX>::VP, wp);      // (idle lanes: zeros into rows >= P)
+        else ex.template seg_products<PMAX>(s, ws.w, P, ends, valid ? ws.V + pl * W16<LMAX>::VP : ex.sink(ws.sink));
         ex.mark(17);
         ex.sync();
         ex.mark(18);
@@ -175,12 +181,15 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
                 double s0 = 0.0, s1 = 0.0;
                 int pb = pb0[u];
                 ex.opaque(pb);
-                const double* vv = ws.V + pb * W16_VP + eml;
+                const double* vv = ws.V + pb * W16<LMAX>::VP + eml;
                 const double* ww = ws.w + pb;
                 for (int i0 = 0; i0 < kbmax; i0 += 8) {
                     double v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pk[u]) ? ww[i0 + j] * vv[(i0 + j) * W16_VP] : 0.0;
+                    for (int j = 0; j < 8; ++j) {
+                        if constexpr (W16<LMAX>::TCOPY) v[j] = (i0 + j < pk[u]) ? vv[(64 + i0 + j) * W16<LMAX>::VP] : 0.0;      // (the copy: 64 rows behind V)
+                        else v[j] = (i0 + j < pk[u]) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
+                    }
                     s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
                 }
                 Qe[u] = s0 + s1;
@@ -237,8 +246,8 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         double c0 = 0.0, c1 = 0.0;
 #pragma unroll
         for (int m = 0; m + 1 < LMAX; m += 2) {
-            if (m < L) c0 += ws.V[pl * W16_VP + m] * ws.Em[m * LMAX + lpl];
-            if (m + 1 < L) c1 += ws.V[pl * W16_VP + m + 1] * ws.Em[(m + 1) * LMAX + lpl];
+            if (m < L) c0 += ws.V[pl * W16<LMAX>::VP + m] * ws.Em[m * LMAX + lpl];
+            if (m + 1 < L) c1 += ws.V[pl * W16<LMAX>::VP + m + 1] * ws.Em[(m + 1) * LMAX + lpl];
         }
         const double wn = valid ? c0 + c1 : 0.0;
         const double dd = fabs(wp) - fabs(wn);
@@ -260,13 +269,13 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     {
         double vr[LMAX];                                         // (my row of V in one batch of loads)
 #pragma unroll
-        for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * W16_VP + (l < L ? l : 0)];
+        for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * W16<LMAX>::VP + (l < L ? l : 0)];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
             if (l < L) { const int neg = ex.vote_count(valid && vr[l] < 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }
     }
     const double sgl = ((negmask >> lp) & 1u) ? -1.0 : 1.0;
-    const double vlp = ws.V[p * W16_VP + lp];                    // V[p, lv(p)] for the loading
+    const double vlp = ws.V[p * W16<LMAX>::VP + lp];                    // V[p, lv(p)] for the loading
     double* const Cs = ws.Gm;                                    // (the iteration's G and E are dead: the score covariance and the path matrix take their places,
     double* const Bm = ws.Em;                                    //  the indirect effects the place of Q once the covariance is formed)
     double* const Ind = ws.Qm;

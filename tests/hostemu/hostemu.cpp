@@ -28,13 +28,21 @@ struct HostExec {
     void mark(int) {}
     void sync() { bar->arrive_and_wait(); }
     unsigned long long uniform(unsigned long long v) { return v; }
-    double* sink(double*) { static thread_local double mine[64]; return mine; }       // (no shared writes: ThreadSanitizer runs this code)
+    double* sink(double*) { static thread_local double mine[64 * 34]; return mine; }       // (no shared writes: ThreadSanitizer runs this code)
     // (device: w as a DPP broadcast operand of the multiply-adds, block ends by scalar bit tests; same order of additions)
     template <int PMAX> void seg_products(const double (&s)[PMAX], const double* w, int P, unsigned long long ends, double* vrow) {
         double r0 = 0.0, r1 = 0.0;
         for (int q = 0; q < PMAX && q < P; ++q) {
             if (q & 1) r1 += s[q] * w[q]; else r0 += s[q] * w[q];
             if ((ends >> q) & 1ull) { *vrow++ = r0 + r1; r0 = 0.0; r1 = 0.0; }
+        }
+    }
+    // (device_exec.h seg_products2: a second store per block, the sum times `scale`, OFF2 bytes behind the first)
+    template <int PMAX, int OFF2> void seg_products2(const double (&s)[PMAX], const double* w, int P, unsigned long long ends, double* vrow, double scale) {
+        double r0 = 0.0, r1 = 0.0;
+        for (int q = 0; q < PMAX && q < P; ++q) {
+            if (q & 1) r1 += s[q] * w[q]; else r0 += s[q] * w[q];
+            if ((ends >> q) & 1ull) { const double v = r0 + r1; *vrow = v; vrow[OFF2 / 8] = v * scale; ++vrow; r0 = 0.0; r1 = 0.0; }
         }
     }
     // (device: rows read along the lanes + LDS transposition, device_exec.h; here the plain symmetric lookup)
@@ -403,6 +411,30 @@ int hostemu_solve_wave16(int P, int L, int PA, int scheme, int scaled, int max_i
             wave16_carve(ws, lds.data());
             HostExec ex{t, nthreads, &bar, red.data()};
             solve_problem_wave16<16>(ex, em.md, ws, Md, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+// The same source at LMAX = 8 (one matrix entry per pair lane, the product stream's second copy w V: the A/B form of the wave solver's own class,
+// set_option("solver_wave", 2)); returns 1 for a model it does not cover.
+int hostemu_solve_wave16_l8(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                            const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                            double* row, int* iters, int* status) {
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    if (P < 1 || P > 64 || L < 1 || L > 8 || em.md.n_chol != 0) return 1;
+    const int nthreads = 64;
+    std::vector<double> lds(wave16_ws_doubles<8>(L, em.md.kmax), 0.0), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            Wave16Ws<8> ws{};
+            wave16_carve(ws, lds.data());
+            HostExec ex{t, nthreads, &bar, red.data()};
+            solve_problem_wave16<8>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

@@ -341,7 +341,7 @@ def test_int8_route_beyond_65535_rows(N):
     nm = native_model(model)
     nm.upload(X)
     rows, status, iters = nm.bootstrap(300, seed=4)
-    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 3 and np.all(status == 0)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in (3, 7) and np.all(status == 0)
     # round 5: the draws land in 4-bit counters (three workgroups per CU) whose overflow is detected exactly (sum of the counts == draws); "i8_nibbles" 2 sends
     # every replicate through the 8-bit second try a workgroup takes on an overflow, 0 is the 8-bit histogram of round 3: the same bits all three ways
     assert nm.get_option("last_i8_nibbles") == 1

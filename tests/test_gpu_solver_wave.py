@@ -13,13 +13,25 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-8, 1e-11
 
 
+WAVE = (3, 7)      # last_solver of the wave class: 3 = solver_wave_kernel (round 3; Mode-B blocks; option solver_wave 3), 7 = solver_wave16_kernel<8> (round 5: all-Mode-A models)
+
+
 def _three_solvers(nm, B, seed, idx=None):
+    """The default route (wave class), the rows and the LDS solver on the same batch -- and, where the default is the round-5 form, the round-3 wave kernel
+    (set_option("solver_wave", 3)): equal iteration counts and status words, records to 1e-11."""
     out = {}
-    for name, (rows_opt, wave_opt, code) in {"wave": (1, 1, 3), "rows": (1, 0, 2), "lds": (0, 0, 1)}.items():
+    for name, (rows_opt, wave_opt, codes) in {"wave": (1, 1, WAVE), "rows": (1, 0, (2,)), "lds": (0, 0, (1,))}.items():
         nm.set_option("solver_rows", rows_opt)
         nm.set_option("solver_wave", wave_opt)
         out[name] = nm.bootstrap(B, seed=seed, idx=idx)
-        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == code, name
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in codes, name
+        if name == "wave" and nm.get_option("last_solver") == 7:
+            nm.set_option("solver_wave", 3)
+            rows3, status3, iters3 = nm.bootstrap(B, seed=seed, idx=idx)
+            assert nm.get_option("last_solver") == 3 and np.array_equal(status3, out[name][1])
+            ok = status3 == 0
+            assert np.array_equal(iters3[ok], out[name][2][ok])
+            assert_close(rows3[ok], out[name][0][ok], 1e-11, 1e-13, what="round-3 wave kernel")
     nm.set_option("solver_rows", 1); nm.set_option("solver_wave", 1)
     return out
 
@@ -54,7 +66,7 @@ def test_wave_solver_headline_workload_and_reference_rows():
     nm = native_model(model)
     nm.upload(X)
     rows, status, iters = nm.bootstrap(5000, seed=1)
-    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 3 and np.all(status == 0)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in WAVE and np.all(status == 0)
     nm.set_option("solver_wave", 0)
     rows_r, status_r, iters_r = nm.bootstrap(5000, seed=1)
     assert nm.get_option("last_solver") == 2 and np.array_equal(iters, iters_r) and np.array_equal(status, status_r)
@@ -63,7 +75,7 @@ def test_wave_solver_headline_workload_and_reference_rows():
     gold = load("g3_synth10k_path")
     idx = np.stack([np.random.RandomState(int(s)).randint(10000, size=10000) for s in gold["boot_seeds"]]).astype(np.int32)
     r2, s2, i2 = nm.bootstrap(len(idx), idx=idx)
-    assert nm.get_option("last_solver") == 3 and np.all(s2 == 0) and np.array_equal(i2, gold["boot_iters"])
+    assert nm.get_option("last_solver") in WAVE and np.all(s2 == 0) and np.array_equal(i2, gold["boot_iters"])
     assert_close(r2, gold["boot_rows"], RTOL, ATOL)
     # ragged batches: a replicate's record does not depend on the batch it travels in
     a = nm.bootstrap(257, seed=1)[0]
@@ -79,7 +91,7 @@ def test_wave_solver_reference_rows_satisfaction():
     nm.upload(X, model.mv_order.astype(np.int32))
     nm.set_option("gram_path", 2)
     rows, status, iters = nm.bootstrap(8, idx=g["idx"])
-    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 3 and np.all(status == 0)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in WAVE and np.all(status == 0)
     assert np.array_equal(iters, g["A_centroid_0/iters"])
     P, L, ne = 27, 6, nm.n_eff
     inv = np.empty(P, dtype=np.int64); inv[model.mv_order] = np.arange(P)
@@ -101,7 +113,7 @@ def test_wave_solver_model_shapes(sizes, scheme):
     nm = native_model(model)
     nm.upload(X)
     rows, status, iters = nm.bootstrap(130, seed=11)
-    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") == 3
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in WAVE
     nm.set_option("solver_rows", 0)
     rows0, status0, iters0 = nm.bootstrap(130, seed=11)
     assert nm.get_option("last_solver") == 1
@@ -125,11 +137,11 @@ def test_wave_solver_status_codes_and_fallbacks():
     nm = native_model(tight)
     nm.upload(X, tight.mv_order.astype(np.int32)); nm.set_option("gram_path", 2)
     rows, status, iters = nm.bootstrap(64, seed=2)
-    assert nm.get_option("last_solver") == 3 and np.all(status == 1) and np.all(iters == 3)
+    assert nm.get_option("last_solver") in WAVE and np.all(status == 1) and np.all(iters == 3)
     Xc = X.copy(); Xc[:, blocks[2][1]] = 3.0
     nm = native_model(orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True))
     nm.upload(Xc, tight.mv_order.astype(np.int32)); nm.set_option("gram_path", 2)
-    assert np.all(np.isin(nm.bootstrap(32, seed=2)[1], (2, 3))) and nm.get_option("last_solver") == 3
+    assert np.all(np.isin(nm.bootstrap(32, seed=2)[1], (2, 3))) and nm.get_option("last_solver") in WAVE
     g = load("g14_rank_deficient")
     Xb, blocks_b, Cb = g14_case(g, "b")
     model = orc.Model(blocks_b, Cb, "AAAAAAA", "path", True)

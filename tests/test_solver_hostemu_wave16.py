@@ -119,3 +119,28 @@ def test_wave16_thread_sanitizer_clean():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert "tsan-run-done" in r.stdout, r.stderr[-2000:]
     assert "data race" not in r.stderr, r.stderr[-4000:]
+
+
+def test_wave16_source_at_eight_lvs_equals_the_wave_solver(emu):
+    """solve_problem_wave16<8> (set_option("solver_wave", 2): V in LDS, the product stream's second copy w V for the Q sums, a folded into E) on the wave solver's
+    own class: the oracle at 1e-9, the wave solver's record at 1e-11, equal iteration counts; the reference's bootstrap rows of golden g4."""
+    from helpers import load, satisfaction_oracle_inputs
+    from test_solver_hostemu_wave import run_wave
+    X, blocks, _ = satisfaction_oracle_inputs()
+    for scheme in ("centroid", "factorial", "path"):
+        for scaled in (False, True):
+            model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", scheme, scaled)
+            e = run_quad(emu, X, model, entry="hostemu_solve_wave16_l8")
+            check(e, orc.fit(X, model), "wave16<8> %s/%d" % (scheme, scaled))
+            base = run_wave(emu, X, model)
+            assert e["iterations"] == base["iterations"]
+            assert_close(e["row"], base["row"], 1e-11, 1e-13)
+    for sizes, fan in (([8] * 8, 1), ([3, 1], 1), ([1, 17, 2, 9, 5], 2), ([4, 3, 5, 2, 6, 7], 4), ([63, 1], 1), ([7, 9, 5, 11, 3, 13, 1, 15], 7)):
+        L = len(sizes)
+        C = _dag(L, fan)
+        Xs, bs = _shaped(C, sizes, seed=4)
+        for scheme in ("centroid", "path"):
+            model = orc.Model(bs, C, "A" * L, scheme, True)
+            e = run_quad(emu, Xs, model, entry="hostemu_solve_wave16_l8")
+            assert e is not None
+            check(e, orc.fit(Xs, model), "wave16<8> L=%d %s %s" % (L, sizes, scheme))

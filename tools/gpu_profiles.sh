@@ -54,7 +54,7 @@ timeout 120 python tools/group_enqueue.py 2>/dev/null | grep "^{" > $O/group_enq
 ./tools/ubench/mfma_i8_fillers > $O/ubench_mfma_i8_fillers.jsonl 2>&1
 # round 3: the wave solver (A/B against the rows solver, kernel time against the batch size, SQ counters of both), sizes next to the headline,
 # co-scheduling experiments (narrow Gram tiles + two pipelines), ablation probes of the Gram (experiments build, if present)
-timeout 300 python tools/aux_ab.py solver_wave=0,1 2>&1 | grep "^{" > $O/ab_solver_wave.jsonl
+timeout 300 python tools/aux_ab.py solver_wave=0,3,1 2>&1 | grep "^{" > $O/ab_solver_wave.jsonl
 timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
 timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
 timeout 600 python tools/solver_quad_ab.py 2>/dev/null | grep "^{" > $O/solver_quad_ab.jsonl
