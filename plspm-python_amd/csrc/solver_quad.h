@@ -27,14 +27,13 @@
 namespace plspm {
 
 constexpr int QUAD_VP = 17;                  // pitch of a row of V (doubles): 34 dwords -- the 64 lanes' 8-byte stores of one column spread over all banks
-constexpr int QUAD_TP = 130;                 // pitch of a row of T: the 16 pair threads that read one column offset (m = 0 .. 15) land on distinct banks
-constexpr int QUAD_STAGE = 128 * QUAD_VP + 16 * QUAD_TP;      // 4,256 doubles >= 4 x 16 x 66 (the loader's four transposition tiles)
+constexpr int QUAD_STAGE = 2 * 128 * QUAD_VP;                 // 4,352 doubles >= 4 x 16 x 66 (the loader's four transposition tiles): V and its copy w V
 
 template <int LMAX>
 struct QuadWs {
     double* stage;   // [QUAD_STAGE]  the loader's tiles; then V and T
     double* V;       // [128 * QUAD_VP]   V[p * QUAD_VP + m]
-    double* T;       // [LMAX * QUAD_TP]  T[m * QUAD_TP + p] = w_p V[p, m]
+    double* T;       // [128 * QUAD_VP]   w_p V[p, m], the product stream's second store (device_exec.h seg_products2): the Q sums read one value per term
     double* w;       // [128]
     double* mu;      // [128]  column sums
     double *Qm, *Gm, *Em, *Cs, *Bm, *Ind;      // [LMAX * LMAX], entry (l, m) at l * LMAX + m
@@ -199,20 +198,20 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
         const int l0l = l0;
         const int ell = tl / LMAX, eml = tl % LMAX;
         ex.mark(16);
-        ex.template seg_products<PMAX>(s, ws.w + q0, nq, ends, valid ? ws.V + pl * QUAD_VP + l0l : ex.sink(ws.sink));      // (own row: no exchange)
+        ex.template seg_products2<PMAX, 128 * QUAD_VP * 8>(s, ws.w + q0, nq, ends, ws.V + pl * QUAD_VP + l0l, wp);      // (own row: no exchange; a thread without an MV stores zeros in a row >= P)
         ex.mark(17);
         ex.sync();
         ex.mark(18);
         {
-            // Q[el, em] = sum over the MVs p of block el of w_p V[p, em]: eight terms (sixteen loads) in flight per trip.  (The wave solver stores
-            // T = w V transposed for this sum; here that pass -- an LDS round trip per LV on every MV thread -- cost more than the second load.)
+            // Q[el, em] = sum over the MVs p of block el of w_p V[p, em] -- out of the product stream's second copy: eight loads in flight per trip.  (The wave
+            // solver stores T = w V transposed in a pass of its own for this sum -- an LDS round trip per LV on every MV thread; reading w_p and V[p, m] here
+            // cost two loads per term: 2.0 k clocks per trip against 1.2 k.)
             double s0 = 0.0, s1 = 0.0;
-            const double* vv = ws.V + pb0l * QUAD_VP + eml;
-            const double* ww = ws.w + pb0l;
+            const double* vv = ws.T + pb0l * QUAD_VP + eml;
             for (int i0 = 0; i0 < kbmax; i0 += 8) {
                 double v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pk) ? ww[i0 + j] * vv[(i0 + j) * QUAD_VP] : 0.0;
+                for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pk) ? vv[(i0 + j) * QUAD_VP] : 0.0;
                 s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
             }
             Qe = s0 + s1;
