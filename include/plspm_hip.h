@@ -117,6 +117,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     MVs: the wave solver's fixed lane roles on four waves per replicate (solver_quad_kernel) instead of solver_rows_split_kernel
  *   "solver_threads"  64 | 128 | 256      threads per problem of the LDS solver (default 128)
  *   "nm_threads"      0 (by model width) | 64 | 128 | 256   threads per problem of the non-metric solvers
+ *   "nm_live"         1 (default) | 0   (round 5) non-metric iteration on the dense stop-rule route: from the second step on, the step / compose launches cover the
+ *                     problems still iterating after the previous step (the list that step's stop-rule pass built) instead of every problem of the batch
  *   "nm_counts8"      1 (default) | 0   non-metric bootstrap on the int8 route: the dense stop-rule pass takes the replicates' row
  *                     multiplicities from the int8 counts of the Gram (no second resample kernel / uint16 histograms / (row,count) lists)
  *   "nm_codes"        1 (default) | 0   all-indicator categorical models (every MV ORD / NOM), bootstrap on the int8 route: the dense

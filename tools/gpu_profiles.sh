@@ -58,6 +58,7 @@ timeout 300 python tools/aux_ab.py solver_wave=0,3,1 2>&1 | grep "^{" > $O/ab_so
 timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
 timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
 timeout 600 python tools/solver_quad_ab.py 2>/dev/null | grep "^{" > $O/solver_quad_ab.jsonl
+timeout 600 python tools/solver_lv_sweep.py 2>/dev/null | grep "^{" > $O/solver_lv_sweep.jsonl
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks_120.py > $O/solver_quad_marks.txt 2>&1
 timeout 300 python tools/i8_mix_calib.py 2>&1 | grep "^{" > $O/i8_mix_calib.jsonl
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks.py > $O/solver_marks.txt 2>&1
