@@ -109,10 +109,10 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS; models of
  *                     65 ... 128 MVs whose blocks divide into two runs of at most 64 MVs: four waves per replicate, two threads per MV
  *                     (solver_rows_split_kernel)
- *   "solver_wave"     1 (default) | 0 | 3   among those, models with at most 8 LVs (Mode-B blocks included) or -- round 5 -- all-Mode-A models with at most
- *                     16 LVs: the wave-native formulations (one wave per replicate with fixed lane roles, coalesced triangle load + LDS transpose:
- *                     solver_wave_kernel for Mode-B blocks, solver_wave16_kernel<8> / <16> for Mode A) instead of solver_rows_kernel; 3: Mode-A
- *                     models of at most 8 LVs on the round-3 kernel (solver_wave_kernel<8, false>; A/B)
+ *   "solver_wave"     1 (default) | 0 | 3   among those, models with at most 16 LVs (round 5; Mode-B blocks whose inverses fit 1,056 doubles): the
+ *                     wave-native formulation (one wave per replicate with fixed lane roles, coalesced triangle load + LDS transpose:
+ *                     solver_wave16_kernel<8> / <16>) instead of solver_rows_kernel; 3: models of at most 8 LVs on the round-3 / round-4
+ *                     kernel (solver_wave_kernel<8>; A/B)
  *   "solver_quad"     1 (default) | 0   (round 5) Mode-A models of 65 ... 128 MVs and at most 16 LVs whose blocks divide into two runs of at most 64
  *                     MVs: the wave solver's fixed lane roles on four waves per replicate (solver_quad_kernel) instead of solver_rows_split_kernel
  *   "solver_threads"  64 | 128 | 256      threads per problem of the LDS solver (default 128)

@@ -160,19 +160,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 
 // Wave variant for 9 .. 16 LVs (solver_wave16.h solve_problem_wave16; round 5): one wave per problem, four matrix entries per pair lane, V in LDS.
-template <int LMAX>
+template <int LMAX, bool MODEB = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_wave16_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long b = blockIdx.x;
     Wave16Ws<LMAX> ws;
-    wave16_carve(ws, reinterpret_cast<double*>(smem_raw));
+    wave16_carve(ws, reinterpret_cast<double*>(smem_raw), md.L, md.kmax);
     FitOutputs out{};
     out.row = so.row ? so.row + b * so.row_stride : nullptr;
     out.status = so.status ? so.status + b : nullptr;
     out.iters = so.iters ? so.iters + b : nullptr;
     DevWaveExec ex;
     ex.tid = (int)threadIdx.x; ex.nt = 64; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
-    solve_problem_wave16<LMAX>(ex, md, ws, Md + b * md_stride, out);
+    solve_problem_wave16<LMAX, MODEB>(ex, md, ws, Md + b * md_stride, out);
 }
 
 

@@ -155,16 +155,18 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
     long long* d_marks = nullptr;
     HIPCHK(m, plspm_dmalloc((void**)&d_marks, 32 * sizeof(long long))); so.marks = d_marks;
 #endif
-    if (dense && (m->tune.solver_wave == 1 || m->tune.solver_wave == 2) && m->n_chol == 0 && m->L <= 8 && wave_solver_covers<8>(m->P, m->L, m->n_chol) &&
-        wave16_ws_doubles<8>(m->L, m->kmax) * sizeof(double) <= 20 * 1024) {
-        // round 5 (second half): all-Mode-A models of at most 8 LVs -- the headline's class -- in the arrangement of solver_wave16.h at LMAX = 8: V in LDS, the product
-        // stream's second copy w V for the Q sums, a folded into E (0.095 -> 0.084 ms per 5,000 replicates; set_option("solver_wave", 3): the round-3 kernel)
-        const size_t lds = (size_t)wave16_ws_doubles<8>(m->L, m->kmax) * sizeof(double);
-        if ((rc = allow_lds(m, (const void*)solver_wave16_kernel<8>, lds))) return rc;
+    if (dense && (m->tune.solver_wave == 1 || m->tune.solver_wave == 2) && m->L <= 8 && wave_solver_covers<8>(m->P, m->L, m->n_chol) &&
+        wave16_ws_doubles<8>(m->L, m->kmax, m->n_chol) * sizeof(double) <= 20 * 1024) {
+        // round 5 (second half): models of at most 8 LVs -- the headline's class -- in the arrangement of solver_wave16.h at LMAX = 8: V in LDS, the product
+        // stream's second copy w V for the Q sums, a folded into E (0.095 -> 0.084 ms per 5,000 replicates; set_option("solver_wave", 3): the round-3 kernel);
+        // Mode-B blocks: the round-4 block inverses on this workspace, a second instantiation
+        const size_t lds = (size_t)wave16_ws_doubles<8>(m->L, m->kmax, m->n_chol) * sizeof(double);
+        auto k8 = m->n_chol > 0 ? solver_wave16_kernel<8, true> : solver_wave16_kernel<8, false>;
+        if ((rc = allow_lds(m, (const void*)k8, lds))) return rc;
         ProfScope ps(m, PLSPM_K_SOLVER);
         hipEvent_t stop = m->stop_event;
         m->stop_event = nullptr;
-        hipExtLaunchKernelGGL((solver_wave16_kernel<8>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        hipExtLaunchKernelGGL(k8, dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 7;
     } else if (dense && m->tune.solver_wave != 0 && wave_solver_covers<8>(m->P, m->L, m->n_chol)) {
         // one wave per problem with fixed lane roles (solver_wave.h): at most 64 MVs and 8 LVs; Mode-B blocks keep their inverses behind the workspace
@@ -179,12 +181,13 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         m->last_solver = 3;
     } else if (dense && m->tune.solver_wave != 0 && wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax)) {
         // the same for 9 .. 16 LVs (solver_wave16.h; round 5): four matrix entries per pair lane, V in LDS
-        const size_t lds = (size_t)wave16_ws_doubles<16>(m->L, m->kmax) * sizeof(double);
-        if ((rc = allow_lds(m, (const void*)solver_wave16_kernel<16>, lds))) return rc;
+        const size_t lds = (size_t)wave16_ws_doubles<16>(m->L, m->kmax, m->n_chol) * sizeof(double);
+        auto k16 = m->n_chol > 0 ? solver_wave16_kernel<16, true> : solver_wave16_kernel<16, false>;
+        if ((rc = allow_lds(m, (const void*)k16, lds))) return rc;
         ProfScope ps(m, PLSPM_K_SOLVER);
         hipEvent_t stop = m->stop_event;
         m->stop_event = nullptr;
-        hipExtLaunchKernelGGL((solver_wave16_kernel<16>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        hipExtLaunchKernelGGL(k16, dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 6;
     } else if (dense) {
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);

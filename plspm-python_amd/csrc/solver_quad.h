@@ -37,13 +37,12 @@ struct QuadWs {
     double* w;       // [128]
     double* mu;      // [128]  column sums
     double *Qm, *Gm, *Em, *Cs, *Bm, *Ind;      // [LMAX * LMAX], entry (l, m) at l * LMAX + m
-    double *a, *r2;  // [LMAX]
-    double* sink;    // [LMAX] where the idle lanes of seg_products store
+    double* a;       // [LMAX]
     double* red;     // [8]  two alternating sets of one slot per wave (group sums)
     double* votes;   // [2 * LMAX]  negative votes of the sign rule per wave of side 0 and LV
     double* scr;     // [L * regression_scratch_doubles(kmax)]  the LV threads' normal equations (five and more predecessors, minimum-norm fallback) and solutions
 };
-template <int LMAX> PLSPM_HD constexpr long quad_ws_doubles(int L, int kmax) { return QUAD_STAGE + 128 + 128 + 6 * LMAX * LMAX + 2 * LMAX + LMAX + 8 + 2 * LMAX + (long)L * regression_scratch_doubles(kmax); }
+template <int LMAX> PLSPM_HD constexpr long quad_ws_doubles(int L, int kmax) { return QUAD_STAGE + 128 + 128 + 6 * LMAX * LMAX + LMAX + 8 + 2 * LMAX + (long)L * regression_scratch_doubles(kmax); }
 template <int LMAX> PLSPM_HD void quad_carve(QuadWs<LMAX>& ws, double* base) {
     static_assert(QUAD_STAGE >= 4 * 16 * 66, "the loader's four tiles fit the staging area");
     static_assert(LMAX == 16, "pair thread e = 16 l + m; 256 threads");
@@ -52,8 +51,7 @@ template <int LMAX> PLSPM_HD void quad_carve(QuadWs<LMAX>& ws, double* base) {
     ws.w = p; p += 128; ws.mu = p; p += 128;
     ws.Qm = p; p += LMAX * LMAX; ws.Gm = p; p += LMAX * LMAX; ws.Em = p; p += LMAX * LMAX;
     ws.Cs = p; p += LMAX * LMAX; ws.Bm = p; p += LMAX * LMAX; ws.Ind = p; p += LMAX * LMAX;
-    ws.a = p; p += LMAX; ws.r2 = p; p += LMAX;
-    ws.sink = p; p += LMAX;
+    ws.a = p; p += LMAX;
     ws.red = p; p += 8;
     ws.votes = p; p += 2 * LMAX;
     ws.scr = p;

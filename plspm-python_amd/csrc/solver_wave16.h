@@ -31,30 +31,33 @@ struct Wave16Ws {
     double* w;       // [64]
     double* mu;      // [64]
     double *Qm, *Gm, *Em;      // [LMAX * LMAX], entry (l, m) at l * LMAX + m;  after the loop: Ind (= Qm), Cs (= Gm), Bm (= Em)
-    double *a, *r2;  // [LMAX]
-    double* sink;    // [LMAX]
+    double* a;       // [LMAX]
+    double* sink;    // [LMAX] where the idle lanes of seg_products store (LMAX = 16)
     double* scr;     // [L * regression_scratch_doubles(kmax)]
+    double* inv;     // [n_chol / 2]  Mode-B blocks: (S_bb)^-1 (or the pseudo-inverse of a rank-deficient block), full k x k, block l at chol_off[l] / 2
 };
 template <int LMAX> PLSPM_HD constexpr long wave16_v_doubles() {                                                                             // (the loader's tile fits the V area)
     return (W16<LMAX>::TCOPY ? 2 : 1) * 64 * W16<LMAX>::VP > 16 * 66 ? (W16<LMAX>::TCOPY ? 2 : 1) * 64 * W16<LMAX>::VP : 16 * 66;
 }
-template <int LMAX> PLSPM_HD constexpr long wave16_ws_doubles(int L, int kmax) { return wave16_v_doubles<LMAX>() + 64 + 64 + 3 * LMAX * LMAX + 3 * LMAX + (long)L * regression_scratch_doubles(kmax); }
-template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base) {
+template <int LMAX> PLSPM_HD constexpr long wave16_ws_doubles(int L, int kmax, int n_chol = 0) { return wave16_v_doubles<LMAX>() + 64 + 64 + 3 * LMAX * LMAX + 2 * LMAX + (long)L * regression_scratch_doubles(kmax) + n_chol / 2; }
+template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base, int L, int kmax) {
     static_assert(LMAX == 16 || LMAX == 8, "pair lane: column t mod LMAX, rows t / LMAX + (64 / LMAX) u");
     double* p = base;
     ws.stage = p; ws.V = p; p += wave16_v_doubles<LMAX>();
     ws.w = p; p += 64; ws.mu = p; p += 64;
     ws.Qm = p; p += LMAX * LMAX; ws.Gm = p; p += LMAX * LMAX; ws.Em = p; p += LMAX * LMAX;
-    ws.a = p; p += LMAX; ws.r2 = p; p += LMAX; ws.sink = p; p += LMAX;
-    ws.scr = p;
+    ws.a = p; p += LMAX; ws.sink = p; p += LMAX;
+    ws.scr = p; p += (long)L * regression_scratch_doubles(kmax);
+    ws.inv = p;
 }
 // What this solver covers (the host asks before it launches): at least four problems per CU.
+// Mode-B blocks (round 5, last part): their inverses are formed in the V area before the first S W (solver_wave.h: the sweep ping-pongs between ws.inv and the staging area).
 template <int LMAX> PLSPM_HD bool wave16_solver_covers(int P, int L, int n_chol, int kmax) {
-    return P >= 1 && P <= 64 && L > LMAX / 2 && L <= LMAX && n_chol == 0 && wave16_ws_doubles<LMAX>(L, kmax) * (long)sizeof(double) <= 40 * 1024;
+    return P >= 1 && P <= 64 && L > LMAX / 2 && L <= LMAX && n_chol / 2 <= 16 * 66 && wave16_ws_doubles<LMAX>(L, kmax, n_chol) * (long)sizeof(double) <= 40 * 1024;
 }
 
 // Md: the DENSE moment matrix [(P+1) x cov_ld(P)] of the mean-shifted columns + ones, upper triangle.  Outputs: out.row / out.status / out.iters.
-template <int LMAX, class Ex>
+template <int LMAX, bool MODEB = false, class Ex>
 PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<LMAX>& ws, const double* Md, const FitOutputs& out) {
     constexpr int PMAX = 64, NE = LMAX * LMAX / 64;              // (LMAX = 8: one entry per lane -- an A/B form of the wave solver's own class, option solver_wave 2)
     const int P = md.P, L = md.L, PS = cov_ld(P), t = ex.tid, p = t;
@@ -83,11 +86,12 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     }
     const int ne = md.n_eff;
     const double shp = md.scaled ? md.shift[pc] : 0.0;
-    int kbmax = 0;
+    int kbmax = 0, kbB = 0;                                      // widest block; widest Mode-B block
     unsigned long long ends = 0ull;
     for (int l = 0; l < L; ++l) {
         const int k = md.boff[l + 1] - md.boff[l];
         kbmax = k > kbmax ? k : kbmax;
+        if (MODEB && md.mode[l] == MODE_B) kbB = k > kbB ? k : kbB;
         ends |= 1ull << (md.boff[l + 1] - 1);
     }
     ends = ex.uniform(ends);
@@ -132,6 +136,140 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     const double sdp = sqrt((dpp - (mup * mup) * inv_n) * fac);
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: V takes the tile's place)
+
+    // Mode-B blocks (solver_wave.h, round 4: the same code on this workspace -- the staging area is the V area, free until the first S W) (mode.py:50-52: w_b = argmin |X_b w - z| = S_bb^-1 (X_b' z / N)): S_bb does not change over the iterations, so its
+    // inverse is formed once.  Gauss-Jordan sweep without pivoting (S_bb is positive definite; pivot j is the same Schur complement the
+    // Cholesky factorisation of solver_core.h tests, so a rank-deficient block is recognised by the same rule), every MV lane of a Mode-B
+    // block owning ROW i of its k x k matrix, all blocks at once, out of place: step j reads A, writes A' -- no lane reads what another
+    // rewrites in the same step, ONE exchange per step -- ping-ponging between ws.inv and the staging area (free until the first S W).
+    //     i == j:  A'[j][c] = A[j][c] / piv  (c != j),  A'[j][j] = 1 / piv
+    //     i != j:  A'[i][c] = A[i][c] - A[i][j] A[j][c] / piv  (c != j),  A'[i][j] = -A[i][j] / piv
+    // A block whose sweep meets a pivot that is not safely positive takes the minimum-norm route of the reference's gelsd (jacobi_pinv, on
+    // its LV lane, one such block at a time in the staging area) -- the outer step multiplies with the full symmetric matrix either way.
+    const bool modeb = MODEB && valid && md.mode[lp] == MODE_B;
+    const int bb0 = md.boff[lp], bk = md.boff[lp + 1] - bb0, bi = p - bb0;
+    const long boffB = modeb ? md.chol_off[lp] / 2 : 0;
+    if constexpr (MODEB) {
+        ex.sync();                                              // (every lane is done with the column sums ws.mu held)
+        ws.mu[p] = sdp * sdp;                                   // the treated diagonal S_pp: the scale a pivot is measured against
+        double* A = (kbB & 1) ? ws.stage : ws.inv;              // an odd number of steps ends in ws.inv
+        double* An = (kbB & 1) ? ws.inv : ws.stage;
+        auto fill_block = [&](double* dst) {                    // row bi of S_bb out of the column registers (S is symmetric)
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q)
+                if (modeb && q >= bb0 && q < bb0 + bk) dst[boffB + bi * bk + (q - bb0)] = s[q];
+        };
+        // the same with every lane storing every column -- the ones outside its block into a slot of its own behind the pivot rows of the
+        // sweep below (an address select instead of an exec-masked branch per column: 7 k -> 2 k clocks)
+        auto fill_block_all = [&](double* dst) {
+            double* mine_row = dst + boffB + bi * bk - bb0;      // column q of my block lands at mine_row[q]
+            double* junk = ws.stage + 2 * LMAX * 16 + p;
+            const unsigned bkm = modeb ? (unsigned)bk : 0u;
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                double* d = ((unsigned)(q - bb0) < bkm) ? mine_row + q : junk;
+                *d = s[q];
+            }
+        };
+        bool okrow = true;
+        ex.mark(20);
+        // blocks of at most 16 MVs (round 4): every lane keeps ITS row of the block in registers; step j = the pivot lane publishes its row
+        // (double-buffered at the head of the staging area), one exchange, every lane updates its row with straight-line code (compile-time
+        // column index, `c == j` a scalar test) -- where the loop over LDS-resident matrices below pays two dependent LDS round trips per
+        // column and step (5 k clocks per step at k = 10 against ~1 k).  Same formulas, same pivot test.  KR = registers of a row: 8 / 12 / 16.
+        auto sweep_rows = [&](auto krc) {
+            constexpr int KR = decltype(krc)::value;
+            fill_block_all(ws.inv);
+            ex.sync();
+            ex.mark(21);
+            double row[KR];
+            {
+                const double* Ib0 = ws.inv + boffB + bi * bk;
+#pragma unroll
+                for (int c = 0; c < KR; ++c) row[c] = (modeb && c < bk) ? Ib0[c] : 0.0;
+            }
+            ex.mark(22);
+            for (int j = 0; j < kbB; ++j) {
+                double* Pj = ws.stage + ((j & 1) * LMAX + lp) * 16;
+                if (modeb && bi == j) {
+#pragma unroll
+                    for (int c = 0; c < KR; ++c) Pj[c] = row[c];
+                }
+                ex.sync();
+                if (modeb && j < bk) {
+                    double f = 0.0;
+#pragma unroll
+                    for (int c = 0; c < KR; ++c) f = (c == j) ? row[c] : f;
+                    const double piv = Pj[j];
+                    okrow = okrow && (piv > PLSPM_PIVOT_RTOL * ws.mu[bb0 + j]);
+                    const double ip = wave_rcp(piv);
+                    const bool pivlane = bi == j;
+                    const double fip = f * ip;
+#pragma unroll
+                    for (int c = 0; c < KR; ++c) {
+                        const double rjc = Pj[c] * ip;
+                        const double off = pivlane ? rjc : row[c] - f * rjc;
+                        const double dia = pivlane ? ip : -fip;
+                        row[c] = (c == j) ? dia : off;
+                    }
+                }
+            }
+            ex.mark(23);
+#pragma unroll
+            for (int c = 0; c < KR; ++c) if (modeb && c < bk) ws.inv[boffB + bi * bk + c] = row[c];
+            ex.sync();
+            ex.mark(24);
+        };
+        if (kbB <= 8) sweep_rows(std::integral_constant<int, 8>{});
+        else if (kbB <= 12) sweep_rows(std::integral_constant<int, 12>{});
+        else if (kbB <= 16) sweep_rows(std::integral_constant<int, 16>{});
+        else {
+        fill_block(A);
+        ex.sync();
+        for (int j = 0; j < kbB; ++j) {
+            if (modeb) {
+                const double* Ab = A + boffB;
+                double* Ob = An + boffB;
+                if (j < bk) {
+                    const double piv = Ab[j * bk + j];
+                    okrow = okrow && (piv > PLSPM_PIVOT_RTOL * ws.mu[bb0 + j]);
+                    const double ip = 1.0 / piv;
+                    const double f = Ab[bi * bk + j];
+                    for (int c = 0; c < bk; ++c) {
+                        const double rjc = Ab[j * bk + c] * ip;
+                        double v;
+                        if (bi == j) v = (c == j) ? ip : rjc;
+                        else v = (c == j) ? -f * ip : Ab[bi * bk + c] - f * rjc;
+                        Ob[bi * bk + c] = v;
+                    }
+                } else {
+                    for (int c = 0; c < bk; ++c) Ob[bi * bk + c] = Ab[bi * bk + c];      // a smaller block waits out the larger ones' steps
+                }
+            }
+            ex.sync();
+            double* t = A; A = An; An = t;
+        }
+        }
+        // rank-deficient blocks, one at a time: S_bb once more from the registers, pseudo-inverse on the block's LV lane (scratch: the staging area)
+        const bool any_bad = ex.vote_any(modeb && !okrow);      // (one ballot instead of a descriptor walk when every sweep went through)
+        for (int l = 0; any_bad && l < L; ++l) {
+            if (md.mode[l] != MODE_B) continue;
+            const int k = md.boff[l + 1] - md.boff[l];
+            const bool bad_here = ex.vote_any(modeb && lp == l && !okrow);
+            if (!bad_here) continue;
+            if (lp == l) fill_block(ws.inv);
+            ex.sync();
+            if (p == l) {
+                double* F = ws.inv + md.chol_off[l] / 2;
+                bool ok = k > 1 && jacobi_pinv(F, k, ws.stage);
+                if (!ok) singular = true;
+                for (int r = 0; r < k; ++r) for (int c = 0; c < r; ++c) F[r * k + c] = F[c * k + r];      // jacobi_pinv leaves the upper triangle
+            }
+            ex.sync();
+        }
+        ex.mark(25);
+    }
+
 
     // LV role: normal equations M[f, f] x = M[f, t] over my predecessors f (solver_quad.h: the same lambda)
     const int* fglob = md.pred_idx + (lvlane ? md.pred_off[t] : 0);
@@ -249,7 +387,20 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
             if (m < L) c0 += ws.V[pl * W16<LMAX>::VP + m] * ws.Em[m * LMAX + lpl];
             if (m + 1 < L) c1 += ws.V[pl * W16<LMAX>::VP + m + 1] * ws.Em[(m + 1) * LMAX + lpl];
         }
-        const double wn = valid ? c0 + c1 : 0.0;
+        double wn = valid ? c0 + c1 : 0.0;
+        if constexpr (MODEB) {                                   // Mode B: w_b = S_bb^-1 c_b  (mode.py:51)
+            ws.mu[pl] = wn;
+            ex.sync();
+            if (modeb) {
+                const double* Ib = ws.inv + boffB + bi * bk;
+                const double* cb = ws.mu + bb0;
+                double a0 = 0.0, a1 = 0.0;
+                int q = 0;
+                for (; q + 1 < bk; q += 2) { a0 += Ib[q] * cb[q]; a1 += Ib[q + 1] * cb[q + 1]; }
+                if (q < bk) a0 += Ib[q] * cb[q];
+                wn = a0 + a1;
+            }
+        }
         const double dd = fabs(wp) - fabs(wn);
         const double conv = ex.allsum(dd * dd);
         wp = wn;

@@ -28,7 +28,7 @@ struct HostExec {
     void mark(int) {}
     void sync() { bar->arrive_and_wait(); }
     unsigned long long uniform(unsigned long long v) { return v; }
-    double* sink(double*) { static thread_local double mine[64 * 34]; return mine; }       // (no shared writes: ThreadSanitizer runs this code)
+    double* sink(double*) { static thread_local double mine[64]; return mine; }       // (no shared writes: ThreadSanitizer runs this code)
     // (device: w as a DPP broadcast operand of the multiply-adds, block ends by scalar bit tests; same order of additions)
     template <int PMAX> void seg_products(const double (&s)[PMAX], const double* w, int P, unsigned long long ends, double* vrow) {
         double r0 = 0.0, r1 = 0.0;
@@ -400,7 +400,7 @@ int hostemu_solve_wave16(int P, int L, int PA, int scheme, int scaled, int max_i
     EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
     if (!wave16_solver_covers<16>(P, L, em.md.n_chol, em.md.kmax)) return 1;
     const int nthreads = 64;
-    std::vector<double> lds(wave16_ws_doubles<16>(L, em.md.kmax), 0.0), red(nthreads);
+    std::vector<double> lds(wave16_ws_doubles<16>(L, em.md.kmax, em.md.n_chol), 0.0), red(nthreads);
     FitOutputs out{};
     out.row = row; out.iters = iters; out.status = status;
     std::barrier<> bar(nthreads);
@@ -408,9 +408,10 @@ int hostemu_solve_wave16(int P, int L, int PA, int scheme, int scaled, int max_i
     for (int t = 0; t < nthreads; ++t)
         th.emplace_back([&, t]() {
             Wave16Ws<16> ws{};
-            wave16_carve(ws, lds.data());
+            wave16_carve(ws, lds.data(), L, em.md.kmax);
             HostExec ex{t, nthreads, &bar, red.data()};
-            solve_problem_wave16<16>(ex, em.md, ws, Md, out);
+            if (em.md.n_chol > 0) solve_problem_wave16<16, true>(ex, em.md, ws, Md, out);
+            else solve_problem_wave16<16, false>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;
@@ -422,9 +423,9 @@ int hostemu_solve_wave16_l8(int P, int L, int PA, int scheme, int scaled, int ma
                             const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
                             double* row, int* iters, int* status) {
     EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
-    if (P < 1 || P > 64 || L < 1 || L > 8 || em.md.n_chol != 0) return 1;
+    if (!wave_solver_covers<8>(P, L, em.md.n_chol)) return 1;
     const int nthreads = 64;
-    std::vector<double> lds(wave16_ws_doubles<8>(L, em.md.kmax), 0.0), red(nthreads);
+    std::vector<double> lds(wave16_ws_doubles<8>(L, em.md.kmax, em.md.n_chol), 0.0), red(nthreads);
     FitOutputs out{};
     out.row = row; out.iters = iters; out.status = status;
     std::barrier<> bar(nthreads);
@@ -432,9 +433,10 @@ int hostemu_solve_wave16_l8(int P, int L, int PA, int scheme, int scaled, int ma
     for (int t = 0; t < nthreads; ++t)
         th.emplace_back([&, t]() {
             Wave16Ws<8> ws{};
-            wave16_carve(ws, lds.data());
+            wave16_carve(ws, lds.data(), L, em.md.kmax);
             HostExec ex{t, nthreads, &bar, red.data()};
-            solve_problem_wave16<8>(ex, em.md, ws, Md, out);
+            if (em.md.n_chol > 0) solve_problem_wave16<8, true>(ex, em.md, ws, Md, out);
+            else solve_problem_wave16<8, false>(ex, em.md, ws, Md, out);
         });
     for (auto& x : th) x.join();
     return 0;

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-8, 1e-11
 
 
-WAVE = (3, 7)      # last_solver of the wave class: 3 = solver_wave_kernel (round 3; Mode-B blocks; option solver_wave 3), 7 = solver_wave16_kernel<8> (round 5: all-Mode-A models)
+WAVE = (3, 7)      # last_solver of the wave class: 3 = solver_wave_kernel (rounds 3 / 4; option solver_wave 3), 7 = solver_wave16_kernel<8> (round 5: the default)
 
 
 def _three_solvers(nm, B, seed, idx=None):
@@ -204,7 +204,7 @@ def test_wave_solver_mode_b_blocks(modes, scheme):
     nm.upload(Xa, model.mv_order.astype(np.int32)); nm.set_option("gram_path", 2)
     if key + "/boot_rows" in g.files:
         rows, status, iters = nm.bootstrap(len(g["idx"]), idx=g["idx"].astype(np.int32))
-        assert nm.get_option("last_solver") == 3 and np.all(status == 0) and np.array_equal(iters, g[key + "/boot_iters"])
+        assert nm.get_option("last_solver") in WAVE and np.all(status == 0) and np.array_equal(iters, g[key + "/boot_iters"])
         inv = np.empty(len(model.mv_order), dtype=np.int64); inv[model.mv_order] = np.arange(len(model.mv_order))
         P, L = len(inv), model.L
         ne = (rows.shape[1] - 2 * P - L) // 2

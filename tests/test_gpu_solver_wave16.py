@@ -93,11 +93,19 @@ def test_wave16_solver_status_codes_sign_rule_and_fallbacks():
     out = _three_solvers(nm, 70, 2)
     assert np.all(out["wave16"][1] == 0)
     assert_close(out["wave16"][0], out["rows"][0], 1e-10, 1e-13)
-    # a Mode-B block: not this solver's
-    nmo = native_model(orc.Model(blocks, C, "A" * 9 + "B", "centroid", True))
+    # Mode-B blocks (round 5, last part): this solver's as well -- against the rows and LDS solvers
+    nmo = native_model(orc.Model(blocks, C, "BABABABABB", "factorial", True))
     nmo.upload(X); nmo.set_option("gram_path", 2)
-    nmo.bootstrap(70, seed=1)
-    assert nmo.get_option("last_solver") in (1, 2)
+    outb = _three_solvers(nmo, 70, 1)
+    assert np.all(outb["wave16"][1] == 0) and np.array_equal(outb["wave16"][2], outb["rows"][2])
+    assert_close(outb["wave16"][0], outb["rows"][0], 1e-10, 1e-12)
+    assert_close(outb["wave16"][0], outb["lds"][0], 1e-10, 1e-12)
+    # Mode-B blocks whose inverses exceed the staging area: not this solver's
+    Xw, bw = _shaped(_dag(9, 1), [25, 25, 2, 2, 2, 2, 2, 2, 2], seed=3)
+    nmw = native_model(orc.Model(bw, _dag(9, 1), "BB" + "A" * 7, "centroid", True))
+    nmw.upload(Xw); nmw.set_option("gram_path", 2)
+    nmw.bootstrap(70, seed=1)
+    assert nmw.get_option("last_solver") in (1, 2)
 
 
 def test_wave16_solver_full_size_batch_properties():
@@ -116,3 +124,28 @@ def test_wave16_solver_full_size_batch_properties():
     nm.set_option("solver_wave", 1)
     part, _, _ = nm.bootstrap(700, seed=1, rep_offset=4300)
     assert np.array_equal(part, rows[4300:])
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "path"])
+@pytest.mark.parametrize("sizes,modes", [([5] * 12, "BBBBBBBBBBBB"), ([5] * 12, "ABABABABABAB"), ([1, 13, 2, 6, 3, 3, 17, 4, 5, 2], "BBABBABBAB"), ([4] * 16, "B" * 16)])
+def test_wave16_solver_mode_b_blocks(sizes, modes, scheme):
+    """Mode-B blocks at 9 ... 16 LVs: oracle 1e-8 (lstsq on the resampled data), rows / LDS solvers 1e-10, equal iteration counts."""
+    from plspm import _native
+    L = len(sizes)
+    C = _dag(L, 2)
+    X, blocks = _shaped(C, sizes, seed=14, N=900)
+    model = orc.Model(blocks, C, modes, scheme, True)
+    nm = native_model(model)
+    nm.upload(X); nm.set_option("gram_path", 2)
+    out = _three_solvers(nm, 130, 5)
+    rows, status, iters = out["wave16"]
+    ok = status == 0
+    assert ok.sum() >= 120 and np.array_equal(status, out["rows"][1]) and np.array_equal(status, out["lds"][1])
+    assert np.array_equal(iters[ok], out["rows"][2][ok]) and np.array_equal(iters[ok], out["lds"][2][ok])
+    assert_close(rows[ok], out["rows"][0][ok], 1e-10, 1e-12, what="rows")
+    assert_close(rows[ok], out["lds"][0][ok], 1e-10, 1e-12, what="lds")
+    corr = orc.correction(900)
+    r = int(np.flatnonzero(ok)[0])
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(5, r, 900), corr)
+    assert its == iters[r]
+    assert_close(rows[r], mine, RTOL, ATOL)

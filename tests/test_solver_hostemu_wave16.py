@@ -73,7 +73,7 @@ def test_wave16_model_shapes(emu):
 
 
 def test_wave16_declines_models_outside_its_class(emu):
-    for sizes, modes in (([5] * 8, "A" * 8), ([3] * 17, "A" * 17), ([5] * 12, "A" * 11 + "B"), ([7] * 10, "A" * 10)):      # 8 LVs: the wave solver's; 17 LVs; Mode B; 70 MVs
+    for sizes, modes in (([5] * 8, "A" * 8), ([3] * 17, "A" * 17), ([30, 30, 1, 1, 1, 1, 1, 1, 1], "BB" + "A" * 7), ([7] * 10, "A" * 10)):      # 8 LVs: the wave solver's; 17 LVs; Mode-B inverses beyond the staging area; 70 MVs
         L = len(sizes)
         X, blocks = _shaped(orc.chain_C(L), sizes, seed=2)
         assert run_w16(emu, X, orc.Model(blocks, orc.chain_C(L), modes, "centroid", True)) is None, sizes
@@ -144,3 +144,56 @@ def test_wave16_source_at_eight_lvs_equals_the_wave_solver(emu):
             e = run_quad(emu, Xs, model, entry="hostemu_solve_wave16_l8")
             assert e is not None
             check(e, orc.fit(Xs, model), "wave16<8> L=%d %s %s" % (L, sizes, scheme))
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+@pytest.mark.parametrize("modes", ["BBBBBB", "ABABAB", "BAAAAB"])
+def test_wave16_source_with_mode_b_blocks(emu, scheme, modes):
+    """Mode-B blocks (round 5, last part: the wave solver's block inverses on this workspace).  LMAX = 8 on the satisfaction model against the oracle, the wave
+    solver (1e-11) and a bootstrap replicate; LMAX = 16 on ten / twelve LVs against the oracle and the rows variant."""
+    from helpers import satisfaction_oracle_inputs
+    from test_solver_hostemu_wave import run_wave
+    X, blocks, _ = satisfaction_oracle_inputs()
+    for scaled in (False, True):
+        model = orc.Model(blocks, orc.satisfaction_C(), modes, scheme, scaled)
+        e = run_quad(emu, X, model, entry="hostemu_solve_wave16_l8")
+        assert e is not None
+        check(e, orc.fit(X, model), "wave16<8> %s %s/%d" % (modes, scheme, scaled))
+        base = run_wave(emu, X, model)
+        assert e["iterations"] == base["iterations"]
+        assert_close(e["row"], base["row"], 1e-11, 1e-13)
+    Xs, bs = orc.synth(2000, orc.satisfaction_C(), 10, seed=7)
+    model = orc.Model(bs, orc.satisfaction_C(), modes, scheme, True)
+    rng = np.random.default_rng(6)
+    idx = rng.integers(0, 2000, 2000)
+    e = run_quad(emu, Xs, model, counts=np.bincount(idx, minlength=2000), shift=Xs[:, model.mv_order].mean(axis=0), entry="hostemu_solve_wave16_l8")
+    mine, its = orc.bootstrap_replicate(Xs, model, idx, orc.correction(2000))
+    assert e["status"] == 0 and e["iterations"] == its
+    assert_close(np.concatenate((e["weights"], e["r2"], e["total"], e["direct"], e["loadings"])), mine, RTOL, 1e-12)
+    for sizes in ([5] * 12, [1, 13, 2, 6, 3, 3, 17, 4, 5, 2]):
+        L = len(sizes)
+        C = _dag(L, 2)
+        X16, b16 = _shaped(C, sizes, seed=12, N=600)
+        m16 = (modes * 3)[:L]
+        model = orc.Model(b16, C, m16, scheme, True)
+        e = run_w16(emu, X16, model)
+        assert e is not None
+        check(e, orc.fit(X16, model), "wave16<16> %s %s %s" % (m16, sizes, scheme))
+        base = run_emu(emu, X16, model, rows=True)
+        assert e["iterations"] == base["iterations"]
+        assert_close(e["row"], base["row"], 1e-10, 1e-12)
+
+
+def test_wave16_source_mode_b_rank_deficient_blocks_take_the_minimum_norm_route(emu):
+    """Golden g14 from the real reference (a duplicated MV and a linearly dependent MV inside Mode-B blocks: gelsd's minimum-norm weights) on the LMAX = 8 form."""
+    from helpers import case_modes, load
+    from test_oracle_golden import g14_case
+    g = load("g14_rank_deficient")
+    Xa, blocks_a, Ca = g14_case(g, "a")
+    for mtag in ("B", "M"):
+        for scheme in ("centroid", "path"):
+            key = "a_%s_%s_1" % (mtag, scheme)
+            model = orc.Model(blocks_a, Ca, case_modes(mtag, mixed="BABABA"), scheme, True)
+            e = run_quad(emu, Xa, model, entry="hostemu_solve_wave16_l8")
+            assert e is not None and e["status"] == 0 and e["iterations"] == int(g[key + "/iters"]), key
+            assert_close(e["weights"], g[key + "/weights"], RTOL, what=key)
