@@ -55,6 +55,7 @@ timeout 120 python tools/group_enqueue.py 2>/dev/null | grep "^{" > $O/group_enq
 # round 3: the wave solver (A/B against the rows solver, kernel time against the batch size, SQ counters of both), sizes next to the headline,
 # co-scheduling experiments (narrow Gram tiles + two pipelines), ablation probes of the Gram (experiments build, if present)
 timeout 300 python tools/aux_ab.py solver_wave=0,3,1 2>&1 | grep "^{" > $O/ab_solver_wave.jsonl
+(AB_MODES=BBBBBB timeout 300 python tools/aux_ab.py solver_wave=0,3,1 2>&1 | grep "^{"; AB_MODES=ABABAB timeout 300 python tools/aux_ab.py solver_wave=0,3,1 2>&1 | grep "^{") > $O/ab_solver_wave_mode_b.jsonl
 timeout 300 python tools/solver_rounds.py 2>&1 | grep "^{" > $O/solver_rounds.jsonl
 timeout 600 python tools/size_bench.py 2>&1 | grep "^{" > $O/size_bench.jsonl
 timeout 600 python tools/solver_quad_ab.py 2>/dev/null | grep "^{" > $O/solver_quad_ab.jsonl
