@@ -39,4 +39,14 @@ for scale_name, scale in (("ORD", Scale.ORD), ("NUM", Scale.NUM)):
     api = time.perf_counter() - t1
     out[scale_name] = {"replicates_per_s": round(B / dt, 1), "ms_per_%d" % B: round(dt * 1e3, 2), "ok_replicates": int((status == 0).sum()),
                        "stage2_iterations": [int(iters.min()), int(iters.max())], "api_Plspm_bootstrap_wall_ms": round(api * 1e3, 1), "api_used": int(m.bootstrap().used())}
+    # the throughput regime: the late trips of a batch run at the latency of ONE problem's step whatever the batch holds, so a larger batch costs little more
+    # (BASELINE configs[3] asks for 40,000 replicates)
+    B2 = 40000
+    pair.native.bootstrap_device(B2, seed=1, rep_offset=10 * B)
+    pair.native.sync()
+    t0 = time.perf_counter()
+    pair.native.bootstrap_device(B2, seed=1, rep_offset=10 * B + B2)
+    pair.native.sync()
+    dt2 = time.perf_counter() - t0
+    out[scale_name].update({"replicates_per_s_at_%d_per_call" % B2: round(B2 / dt2, 1), "ms_per_%d" % B2: round(dt2 * 1e3, 2)})
 print(json.dumps({"workload": "mobi 250 x 24, 6 first-stage LVs, HOC Satisfaction = {Image, Value}, Mode A, PATH, 5000 replicates per call", **out}))
