@@ -194,3 +194,41 @@ int main() { show<6, 5>(); show<6, 4>(); show<7, 4>(); show<7, 3>(); return 0; }
         assert max(r) <= nmfma - 10, line                                                        # >= 160 clocks of MFMAs behind the last fragment read (an LDS round trip is ~130)
         vm = sorted(a + d_)
         assert max(y - x for x, y in zip(vm, vm[1:])) <= 2 * nmfma // len(vm) + 2, line          # VMEM evenly spread
+
+
+# ------------------------------------------------------------------------------------------------ the one-wave / four-wave solver kernels (round 5)
+# These kernels hold a 64-column window of the covariance in 128 registers and are latency-bound chains of small phases: a value the allocator sends
+# to scratch inside the treatment loop or the iteration costs a memory round trip per use (the first quad kernel reloaded the column sum, 1 / n and the
+# scale factor three times per column: 59 k of a problem's 169 k clocks).  The test compiles the solver unit as the release build does and holds the
+# spill counts of the register-resident kernels at what the committed source gives (+ a margin for compiler noise).
+SOLVER_LIMITS = {  # kernel substring -> (max spilled VGPRs, max scratch bytes per lane)
+    "solver_wave16_kernelILi8ELb0E": (8, 48),
+    "solver_wave16_kernelILi8ELb1E": (12, 64),
+    "solver_wave16_kernelILi16ELb0E": (28, 128),
+    "solver_wave16_kernelILi16ELb1E": (28, 128),
+    "solver_quad_kernelILi16E": (10, 64),
+}
+
+
+def test_solver_kernels_keep_their_windows_in_registers():
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc in this environment")
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "--cuda-device-only", "-c",
+                            "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, "plspm_fit.hip"), "-o", os.path.join(d, "fit.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1); usage[name] = {}
+        for key in ("VGPRs Spill", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "VGPRs"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name:
+                usage[name].setdefault(key, int(m.group(1)))
+    for sub, (max_spill, max_scratch) in SOLVER_LIMITS.items():
+        found = [k for k in usage if sub in k]
+        assert len(found) == 1, (sub, found)
+        u = usage[found[0]]
+        assert u["Occupancy [waves/SIMD]"] == 2, (sub, u)                   # eight one-wave problems / two four-wave problems per CU
+        assert u["VGPRs Spill"] <= max_spill and u["ScratchSize [bytes/lane]"] <= max_scratch, (sub, u)
