@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--reps-per-gpu", type=int, default=REPS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
-    ap.add_argument("--no-next-rows", action="store_true", help="skip the categorical bootstrap beside the headline (two child runs of tools/categorical_bench.py)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the categorical bootstrap and the metric models beside the headline (child runs of tools/categorical_bench.py, tools/size_rows.py)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
     ap.add_argument("--no-transport-calibration", action="store_true", help="keep RCCL as created (skip the untimed comparison with channel-capped RCCL / the copy-engine exchange)")
@@ -717,7 +717,12 @@ def main():
                     cat["replicates_per_step_%d" % reps] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
                 except Exception as e:                                    # noqa: BLE001 -- an extra of the line, never its failure
                     cat["replicates_per_step_%d" % reps] = {"error": repr(e)[:200]}
-            line["next_rows"] = {"categorical_bootstrap": cat,
+            try:                                                           # metric models next to the headline: the solvers of round 5 (tools/size_rows.py)
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "size_rows.py")], capture_output=True, text=True, timeout=240).stdout
+                sizes = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+            except Exception as e:                                        # noqa: BLE001
+                sizes = {"error": repr(e)[:200]}
+            line["next_rows"] = {"categorical_bootstrap": cat, "metric_models_next_to_the_headline": sizes,
                                  "note": "not part of `value`: ORD / NOM optimal scaling on 300 indicator columns (10k x 60 five-point items x 6 LVs), one wave per problem, "
                                          "count matrices written by the int8 product as uint16, stop rule as an int8 matrix product; DESIGN 5c"}
         if world == 1 and not args.no_cpu_baseline:

@@ -10,3 +10,6 @@ if "api_inclusive" in d: print("api_inclusive %.4g  frac_of_value %s" % (d["api_
 if "cpu_baseline" in d: print("cpu_baseline %s %s on %s cores" % (d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"], d["cpu_baseline"]["cores"]))
 for k, v in d.get("next_rows", {}).get("categorical_bootstrap", {}).items():
     print("categorical", k, v.get("replicates_per_s"), v.get("ms_per_step"), v.get("kernel_ms_per_step"), v.get("error", ""))
+
+for k, v in d.get("next_rows", {}).get("metric_models_next_to_the_headline", {}).items():
+    if isinstance(v, dict): print("metric", k, v.get("replicates_per_s"), v.get("ms_per_step"), v.get("kernels_ms"), v.get("solver_kernel"))
