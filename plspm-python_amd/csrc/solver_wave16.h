@@ -66,17 +66,25 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     const int lp = md.lvof[pc];                                  // MV role: my LV
     const int em = t % LMAX, er0 = t / LMAX;                     // pair role: column em, rows er0 + 4 u
     const bool lvlane = t < L;                                   // LV role
-    int pb0[NE], pk[NE], dlm[NE];                                // pair role, entry u: the block of its row; C[el, em] + 2 C[em, el]
-    bool pairu[NE];
+    // pair role, entry u, ONE register: first MV of its row's block | MVs of that block << 8 | (C[el, em] + 2 C[em, el]) << 16 | "the entry exists" << 24
+    // (four registers per field of the <16> form were the values the allocator sent to scratch: twelve reloads per trip)
+    unsigned dsc[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
         const int el = er0 + (64 / LMAX) * u;
-        pairu[u] = el < L && em < L;
-        const int elc = pairu[u] ? el : 0, emc = pairu[u] ? em : 0;
-        pb0[u] = md.boff[elc];
-        pk[u] = pairu[u] ? md.boff[elc + 1] - pb0[u] : 0;
-        dlm[u] = pairu[u] ? (int)md.C[elc * L + emc] + 2 * (int)md.C[emc * L + elc] : 0;      // bit 0: LV em -> LV el
+        const bool pr = el < L && em < L;
+        const int elc = pr ? el : 0, emc = pr ? em : 0;
+        const int b0 = md.boff[elc];
+        dsc[u] = (unsigned)b0 | (unsigned)(pr ? md.boff[elc + 1] - b0 : 0) << 8 | (unsigned)(pr ? (int)md.C[elc * L + emc] + 2 * (int)md.C[emc * L + elc] : 0) << 16 |
+                 (pr ? 1u : 0u) << 24;                                   // bit 16: LV em -> LV el
     }
+    unsigned dl[NE];                                             // (inside the loop: opaque copies, unpacked where they are used instead of hoisted and spilled)
+#pragma unroll
+    for (int u = 0; u < NE; ++u) dl[u] = dsc[u];
+    auto pb0 = [&](int u) { return (int)(dl[u] & 255u); };
+    auto pk = [&](int u) { return (int)((dl[u] >> 8) & 255u); };
+    auto dlm = [&](int u) { return (int)((dl[u] >> 16) & 3u); };
+    auto pairu = [&](int u) { return (dl[u] >> 24) != 0u; };
     int nk = 0;                                                  // LV role: my predecessors, the first four one byte each
     unsigned fpack = 0u;
     if (lvlane) {
@@ -305,6 +313,8 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     while (true) {
         int pl = p, lpl = lp;                                    // opaque copies: LDS addresses recomputed per trip instead of hoisted and spilled
         ex.opaque(pl); ex.opaque(lpl);
+#pragma unroll
+        for (int u = 0; u < NE; ++u) { dl[u] = dsc[u]; ex.opaque(dl[u]); }
         const int eml = pl % LMAX, er0l = pl / LMAX;
         ex.mark(16);
         if constexpr (W16<LMAX>::TCOPY) ex.template seg_products2<PMAX, 64 * W16<LMAX>::VP * 8>(s, ws.w, P, ends, ws.V + pl * W16<LMAX>::VP, wp);      // (idle lanes: zeros into rows >= P)
@@ -317,7 +327,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
             if ((64 / LMAX) * u < L) {                           // (uniform: rows 4 u .. 4 u + 3 exist)
                 // Q[el, em] = sum over the MVs p of block el of w_p V[p, em]: eight terms in flight per trip
                 double s0 = 0.0, s1 = 0.0;
-                int pb = pb0[u];
+                int pb = pb0(u);
                 ex.opaque(pb);
                 const double* vv = ws.V + pb * W16<LMAX>::VP + eml;
                 const double* ww = ws.w + pb;
@@ -325,13 +335,13 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
                     double v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if constexpr (W16<LMAX>::TCOPY) v[j] = (i0 + j < pk[u]) ? vv[(64 + i0 + j) * W16<LMAX>::VP] : 0.0;      // (the copy: 64 rows behind V)
-                        else v[j] = (i0 + j < pk[u]) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
+                        if constexpr (W16<LMAX>::TCOPY) v[j] = (i0 + j < pk(u)) ? vv[(64 + i0 + j) * W16<LMAX>::VP] : 0.0;      // (the copy: 64 rows behind V)
+                        else v[j] = (i0 + j < pk(u)) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
                     }
                     s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
                 }
                 Qe[u] = s0 + s1;
-                ws.Qm[pl + 64 * u] = pairu[u] ? Qe[u] : 1.0;
+                ws.Qm[pl + 64 * u] = pairu(u) ? Qe[u] : 1.0;
             }
         }
         ex.sync();
@@ -356,11 +366,11 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
                 const double rl = wave_rsqrt(ws.Qm[ell * LMAX + ell]), al = rl * icorr2;
                 const double Ge = al * am * Qe[u];
                 double Ee = 0.0;
-                if (pairu[u]) {
+                if (pairu(u)) {
                     if (md.scheme == SCHEME_PATH) {
-                        if (dlm[u] & 1) Ee = Qe[u] * rl * rm;    // column em of E: correlations with the successors of em (scheme.py:51-53)
-                    } else if (dlm[u]) {
-                        const int d = (dlm[u] & 1) + (dlm[u] >> 1);
+                        if (dlm(u) & 1) Ee = Qe[u] * rl * rm;    // column em of E: correlations with the successors of em (scheme.py:51-53)
+                    } else if (dlm(u)) {
+                        const int d = (dlm(u) & 1) + (dlm(u) >> 1);
                         Ee = (md.scheme == SCHEME_CENTROID) ? ((Ge > 0.0) ? 1.0 : ((Ge < 0.0) ? -1.0 : 0.0)) : Ge * corr2 * (double)d;   // cov1 = cov0 N/(N-1)
                     }
                     ws.Gm[pl + 64 * u] = Ge; ws.Em[pl + 64 * u] = al * Ee;      // (row el of E carries a_el: the outer step multiplies V with a E)
@@ -441,7 +451,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         }
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
-            if (pairu[u]) Cs[t + 64 * u] = cs[u];
+            if (pairu(u)) Cs[t + 64 * u] = cs[u];
             Bm[t + 64 * u] = 0.0;                                // (all 256 entries: the effects below run without a test per row)
         }
     }

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_gpu_solver_wave16.py tests/test_gpu_solver_wave.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 python tools/solver_lv_sweep.py 2>/dev/null | cut -c1-260
+python tools/aux_ab.py solver_wave=3,1 2>&1 | grep "^{" | cut -c1-260
