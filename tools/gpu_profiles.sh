@@ -65,6 +65,9 @@ timeout 300 python tools/i8_mix_calib.py 2>&1 | grep "^{" > $O/i8_mix_calib.json
 [ -f plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so ] && PLSPM_HIP_LIB=plspm-python_amd/csrc/build/marks/libplspm_hip_marks.so timeout 300 python tools/experiments/solver_marks.py > $O/solver_marks.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $O/prof_solver_pmc1 -o p1 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC -d $O/prof_solver_pmc2 -o p2 -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_solver_fetch -o f -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1; timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/prof_solver_write -o w -- python $R/tools/solver_pmc_run.py > /dev/null 2>&1)
 python tools/pmc_rows.py $O solver > $O/solver_pmc.txt 2>&1
+# round 5, second half: the same counters for the solvers of the models next to the headline (quad, wave16 <16>, wave16 <8, true>: tools/size_rows.py)
+(cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -d $O/prof_sizes_pmc1 -o p1 -- python $R/tools/size_rows.py > /dev/null 2>&1; timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $O/prof_sizes_pmc2 -o p2 -- python $R/tools/size_rows.py > /dev/null 2>&1; timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/prof_sizes_fetch -o p3 -- python $R/tools/size_rows.py > /dev/null 2>&1)
+python tools/pmc_rows.py $O solver_quad solver_wave16_kernel\<16 "solver_wave16_kernel<8, true" > $O/solver_sizes_pmc.txt 2>&1
 timeout 300 python tools/aux_ab.py i8_priv=0,1 2>&1 | grep "^{" > $O/ab_i8_priv.jsonl
 timeout 300 python tools/aux_ab.py i8_slices=0,7 2>&1 | grep "^{" > $O/ab_i8_slices.jsonl
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --hip-trace --memory-copy-trace --output-format csv -d /tmp/tl -o tl -- python $R/tools/api_timeline.py run > $O/api_timeline.txt 2>/dev/null; python $R/tools/api_timeline.py read /tmp/tl >> $O/api_timeline.txt 2>&1)
