@@ -675,7 +675,7 @@ def main():
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
                        "parallelism": parallelism, "transport": transport, "ranks_seen_by_rccl": ranks_seen if transport == "rccl" else 0,
-                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel", 5: "solver_quad_kernel<16>", 6: "solver_wave16_kernel<16>", 7: "solver_wave16_kernel<8>"}.get(model.get_option("last_solver"), "?"),
+                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel", 5: "solver_quad_kernel<16>", 6: "solver_wave16_kernel<16>", 7: "solver_wave16_kernel<8>", 8: "solver_wave16_kernel<32>"}.get(model.get_option("last_solver"), "?"),
                        "gram_tile_plan_cus": plan_cus, "transport_calibration": transport_cal,
                        "comm_create_s": comm_create_s, "upload_s_per_device": upload_s, "single_call_latency_ms": single_call},
             "roofline": roofline,

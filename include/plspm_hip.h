@@ -109,7 +109,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     covariance columns in registers (solver_rows_kernel) instead of one workgroup with the covariance in LDS; models of
  *                     65 ... 128 MVs whose blocks divide into two runs of at most 64 MVs: four waves per replicate, two threads per MV
  *                     (solver_rows_split_kernel)
- *   "solver_wave"     1 (default) | 0 | 3   among those, models with at most 16 LVs (round 5; Mode-B blocks whose inverses fit 1,056 doubles): the
+ *   "solver_wave"     1 (default) | 0 | 3   among those, models with at most 16 LVs (round 5; Mode-B blocks whose inverses fit 1,056 doubles) and all-Mode-A
+ *                     models with at most 32: the
  *                     wave-native formulation (one wave per replicate with fixed lane roles, coalesced triangle load + LDS transpose:
  *                     solver_wave16_kernel<8> / <16>) instead of solver_rows_kernel; 3: models of at most 8 LVs on the round-3 / round-4
  *                     kernel (solver_wave_kernel<8>; A/B)
@@ -156,7 +157,7 @@ const char* plspm_last_error(const plspm_model_t* m);
  * (Test seams and the option values of the experiments build: include/plspm_hip_test.h.)
  *
  * plspm_model_get_option reads a value back; the read-only keys "last_gram_path" (1 fp64 MFMA, 2 int8 digit planes), "last_i8_dma" (1 / 2) and "last_solver"
- * (1 LDS solver, 2 rows solver, 3 wave solver of round 3 / Mode-B blocks, 4 split rows solver, 5 quad solver, 6 / 7 wave solver for 9 ... 16 / at most 8 LVs) tell what the last bootstrap call took.
+ * (1 LDS solver, 2 rows solver, 3 wave solver of round 3 / Mode-B blocks, 4 split rows solver, 5 quad solver, 6 / 7 / 8 wave solver for 9 ... 16 / at most 8 / 17 ... 32 LVs) tell what the last bootstrap call took.
  */
 int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value);
 int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* value);

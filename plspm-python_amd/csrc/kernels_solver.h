@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 // Wave variant for 9 .. 16 LVs (solver_wave16.h solve_problem_wave16; round 5): one wave per problem, four matrix entries per pair lane, V in LDS.
 template <int LMAX, bool MODEB = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_wave16_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LMAX > 16 ? 1 : 2, LMAX > 16 ? 1 : 2))) solver_wave16_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long b = blockIdx.x;
     Wave16Ws<LMAX> ws;

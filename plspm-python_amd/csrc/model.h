@@ -129,7 +129,7 @@ struct plspm_model {
     bool mix_valid = false, mix_wide = false; long mix_key[4] = {0, 0, 0, 0}; int mix_tall = 0, mix_short = 0;      // plspm_gram_i8.hip i8_mix_plan: the last tile-row cut
     int last_i8_mt = 0;           // count tiles (padded) of the last int8 Gram launch: 16 x this many replicate slots went through the matrix pipe
     int last_i8_short = 0;        // ... and, with 20, how many of its tile rows were short ones (16 count tiles: plspm_gram_i8.hip i8_mix_plan)
-    int last_solver = 0;          // 1 LDS solver (solver_kernel), 2 rows solver (solver_rows_kernel), 3 wave solver (solver_wave_kernel), 4 split rows solver (solver_rows_split_kernel), 5 quad solver (solver_quad_kernel), 6 wave solver for 9 .. 16 LVs (solver_wave16_kernel<16>), 7 its LMAX = 8 form (solver_wave16_kernel<8>: Mode-A models of at most 8 LVs since round 5): the last metric bootstrap's
+    int last_solver = 0;          // 1 LDS solver (solver_kernel), 2 rows solver (solver_rows_kernel), 3 wave solver (solver_wave_kernel), 4 split rows solver (solver_rows_split_kernel), 5 quad solver (solver_quad_kernel), 6 wave solver for 9 .. 16 LVs (solver_wave16_kernel<16>), 7 its LMAX = 8 form (solver_wave16_kernel<8>: models of at most 8 LVs since round 5), 8 its LMAX = 32 form (17 .. 32 LVs, all Mode A): the last metric bootstrap's
     // grow-only pinned host staging for uploads / row downloads (two halves: copy-in of chunk k+1 overlaps the DMA of chunk k)
     void* h_pin = nullptr;
     size_t h_pin_cap = 0;

@@ -43,7 +43,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // (round 4: 64 < P <= 128 in the split form -- two threads per MV on either side of a block boundary, four waves and ~30 KB of LDS per problem)
     // (round 5: the quad solver -- solver_quad.h, Mode-A models of 65 .. 128 MVs and at most 16 LVs -- has a workspace of its own, ~52 KB whatever the inner model)
     const bool quad_width = m->tune.solver_quad != 0 && quad_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax, m->boff.data());
-    const bool w16_width = m->tune.solver_wave != 0 && wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax);      // (solver_wave16.h: 9 .. 16 LVs, its own ~16 KB workspace)
+    const bool w16_width = m->tune.solver_wave != 0 && (wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax) || (m->n_chol == 0 && wave16_solver_covers<32>(m->P, m->L, 0, m->kmax)));      // (solver_wave16.h: 9 .. 16 LVs, its own ~16 KB workspace)
     const bool rows_width = m->P <= 64 ? (rows_lds <= kMaxLds / 4 || w16_width) : (quad_width || (m->P <= 128 && rows_split_block(m->boff.data(), m->L, 64) > 0 && rows_lds + 4 * 16 * 66 * sizeof(double) <= kMaxLds / 2));
     const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && rows_width && !m->n_ind && !m->nonmetric && !m->moments_out;
     // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers

@@ -189,6 +189,15 @@ int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so
         m->stop_event = nullptr;
         hipExtLaunchKernelGGL(k16, dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
         m->last_solver = 6;
+    } else if (dense && m->tune.solver_wave != 0 && m->n_chol == 0 && wave16_solver_covers<32>(m->P, m->L, m->n_chol, m->kmax)) {
+        // ... and for 17 .. 32 LVs: sixteen matrix entries per pair lane, three problems per CU (all Mode A)
+        const size_t lds = (size_t)wave16_ws_doubles<32>(m->L, m->kmax, 0) * sizeof(double);
+        if ((rc = allow_lds(m, (const void*)solver_wave16_kernel<32, false>, lds))) return rc;
+        ProfScope ps(m, PLSPM_K_SOLVER);
+        hipEvent_t stop = m->stop_event;
+        m->stop_event = nullptr;
+        hipExtLaunchKernelGGL((solver_wave16_kernel<32, false>), dim3((unsigned)nb), dim3(64), lds, m->stream, nullptr, stop, 0, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so);
+        m->last_solver = 8;
     } else if (dense) {
         const size_t lds = desc_lds_bytes(m->P, m->L, m->n_eff, (int)m->pred_idx.size()) + (size_t)workspace_small_doubles(m->P, m->L, m->kmax, m->n_chol) * sizeof(double);
         if (m->P > 64 && m->tune.solver_quad != 0 && quad_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax, m->boff.data())) {

@@ -41,7 +41,7 @@ template <int LMAX> PLSPM_HD constexpr long wave16_v_doubles() {                
 }
 template <int LMAX> PLSPM_HD constexpr long wave16_ws_doubles(int L, int kmax, int n_chol = 0) { return wave16_v_doubles<LMAX>() + 64 + 64 + 3 * LMAX * LMAX + 2 * LMAX + (long)L * regression_scratch_doubles(kmax) + n_chol / 2; }
 template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base, int L, int kmax) {
-    static_assert(LMAX == 16 || LMAX == 8, "pair lane: column t mod LMAX, rows t / LMAX + (64 / LMAX) u");
+    static_assert(LMAX == 32 || LMAX == 16 || LMAX == 8, "pair lane: column t mod LMAX, rows t / LMAX + (64 / LMAX) u");
     double* p = base;
     ws.stage = p; ws.V = p; p += wave16_v_doubles<LMAX>();
     ws.w = p; p += 64; ws.mu = p; p += 64;
@@ -53,7 +53,7 @@ template <int LMAX> PLSPM_HD void wave16_carve(Wave16Ws<LMAX>& ws, double* base,
 // What this solver covers (the host asks before it launches): at least four problems per CU.
 // Mode-B blocks (round 5, last part): their inverses are formed in the V area before the first S W (solver_wave.h: the sweep ping-pongs between ws.inv and the staging area).
 template <int LMAX> PLSPM_HD bool wave16_solver_covers(int P, int L, int n_chol, int kmax) {
-    return P >= 1 && P <= 64 && L > LMAX / 2 && L <= LMAX && n_chol / 2 <= 16 * 66 && wave16_ws_doubles<LMAX>(L, kmax, n_chol) * (long)sizeof(double) <= 40 * 1024;
+    return P >= 1 && P <= 64 && L > LMAX / 2 && L <= LMAX && n_chol / 2 <= 16 * 66 && wave16_ws_doubles<LMAX>(L, kmax, n_chol) * (long)sizeof(double) <= (LMAX > 16 ? 53 : 40) * 1024;
 }
 
 // Md: the DENSE moment matrix [(P+1) x cov_ld(P)] of the mean-shifted columns + ones, upper triangle.  Outputs: out.row / out.status / out.iters.

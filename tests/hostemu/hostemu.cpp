@@ -442,6 +442,29 @@ int hostemu_solve_wave16_l8(int P, int L, int PA, int scheme, int scaled, int ma
     return 0;
 }
 
+// ... and at LMAX = 32 (sixteen matrix entries per pair lane: all-Mode-A models of 17 ... 32 LVs); returns 1 for a model it does not cover.
+int hostemu_solve_wave16_l32(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                             const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                             double* row, int* iters, int* status) {
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    if (em.md.n_chol != 0 || !wave16_solver_covers<32>(P, L, 0, em.md.kmax)) return 1;
+    const int nthreads = 64;
+    std::vector<double> lds(wave16_ws_doubles<32>(L, em.md.kmax, 0), 0.0), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.iters = iters; out.status = status;
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            Wave16Ws<32> ws{};
+            wave16_carve(ws, lds.data(), L, em.md.kmax);
+            HostExec ex{t, nthreads, &bar, red.data()};
+            solve_problem_wave16<32, false>(ex, em.md, ws, Md, out);
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
 // Quad solver (solver_quad.h solve_problem_quad<16>): 256 emulated threads = four waves; returns 1 for a model it does not cover.
 int hostemu_solve_quad(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
                        const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,

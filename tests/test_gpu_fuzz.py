@@ -163,7 +163,7 @@ def _narrow_case_check(seed, B=40):
         pytest.skip("the fp64 route took this batch")
     code = nm.get_option("last_solver")
     tag = "seed %d P=%d sizes=%s %s %s solver %d" % (seed, P, sizes, model.modes, model.scheme, code)
-    assert code in (1, 2, 6, 7), tag
+    assert code in (1, 2, 6, 7, 8), tag
     if code in (6, 7):
         assert code == (7 if model.L <= 8 else 6), tag
     nm.set_option("solver_rows", 0)

@@ -168,7 +168,11 @@ def test_wave_solver_status_codes_and_fallbacks():
     nm = native_model(orc.Model(b17, C17, "A" * 17, "path", True))
     nm.upload(X17); nm.set_option("gram_path", 2)
     nm.bootstrap(16, seed=1)
-    assert nm.get_option("last_solver") == 2
+    assert nm.get_option("last_solver") == 8                   # 17 ... 32 LVs, all Mode A: solver_wave16_kernel<32>
+    nm = native_model(orc.Model(b17, C17, "A" * 16 + "B", "path", True))
+    nm.upload(X17); nm.set_option("gram_path", 2)
+    nm.bootstrap(16, seed=1)
+    assert nm.get_option("last_solver") == 2                   # ... with a Mode-B block: the rows solver
 
 
 @pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])

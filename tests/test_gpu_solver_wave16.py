@@ -149,3 +149,32 @@ def test_wave16_solver_mode_b_blocks(sizes, modes, scheme):
     mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(5, r, 900), corr)
     assert its == iters[r]
     assert_close(rows[r], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "path"])
+@pytest.mark.parametrize("sizes,fan", [([3] * 20, 2), ([2] * 32, 1), ([1] * 10 + [4] * 7, 5), ([5, 1, 2, 3, 1, 4, 2, 1, 3, 2, 1, 1, 6, 2, 3, 1, 2, 4, 1, 2, 3, 1, 1, 2], 3)])
+def test_wave16_solver_for_17_to_32_lvs(sizes, fan, scheme):
+    """solver_wave16_kernel<32> (sixteen matrix entries per pair lane, one wave per SIMD: 324 registers, three problems per CU): all-Mode-A models of 17 ... 32 LVs
+    against the rows / LDS solvers (1e-10, equal iteration counts) and the oracle (1e-8)."""
+    from plspm import _native
+    L = len(sizes)
+    C = _dag(L, fan)
+    X, blocks = _shaped(C, sizes, seed=31, N=700)
+    model = orc.Model(blocks, C, "A" * L, scheme, True)
+    nm = native_model(model)
+    nm.upload(X); nm.set_option("gram_path", 2)
+    out = {}
+    for name, (rows_opt, wave_opt, codes) in {"wave32": (1, 1, (8,)), "rows": (1, 0, (2, 1)), "lds": (0, 0, (1,))}.items():
+        nm.set_option("solver_rows", rows_opt); nm.set_option("solver_wave", wave_opt)
+        out[name] = nm.bootstrap(130, seed=11)
+        assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_solver") in codes, (name, nm.get_option("last_solver"))
+    rows, status, iters = out["wave32"]
+    ok = status == 0
+    assert ok.sum() >= 120 and np.array_equal(status, out["lds"][1])
+    assert np.array_equal(iters[ok], out["lds"][2][ok]) and np.array_equal(iters[ok], out["rows"][2][ok])
+    assert_close(rows[ok], out["lds"][0][ok], 1e-10, 1e-13, what="lds")
+    assert_close(rows[ok], out["rows"][0][ok], 1e-10, 1e-13, what="rows")
+    r = int(np.flatnonzero(ok)[-1])
+    mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(11, r, 700), orc.correction(700))
+    assert its == iters[r]
+    assert_close(rows[r], mine, RTOL, ATOL)

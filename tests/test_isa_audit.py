@@ -208,6 +208,7 @@ SOLVER_LIMITS = {  # kernel substring -> (max spilled VGPRs, max scratch bytes p
     "solver_wave16_kernelILi16ELb1E": (28, 128),
     "solver_quad_kernelILi16E": (10, 64),
 }
+SOLVER_ONE_WAVE = {"solver_wave16_kernelILi32ELb0E": (0, 0)}      # one wave per SIMD (three problems per CU by LDS): 512 registers, nothing in scratch
 
 
 def test_solver_kernels_keep_their_windows_in_registers():
@@ -232,3 +233,8 @@ def test_solver_kernels_keep_their_windows_in_registers():
         u = usage[found[0]]
         assert u["Occupancy [waves/SIMD]"] == 2, (sub, u)                   # eight one-wave problems / two four-wave problems per CU
         assert u["VGPRs Spill"] <= max_spill and u["ScratchSize [bytes/lane]"] <= max_scratch, (sub, u)
+    for sub, (max_spill, max_scratch) in SOLVER_ONE_WAVE.items():
+        found = [k for k in usage if sub in k]
+        assert len(found) == 1, (sub, found)
+        u = usage[found[0]]
+        assert u["Occupancy [waves/SIMD]"] == 1 and u["VGPRs Spill"] <= max_spill and u["ScratchSize [bytes/lane]"] <= max_scratch, (sub, u)

@@ -197,3 +197,27 @@ def test_wave16_source_mode_b_rank_deficient_blocks_take_the_minimum_norm_route(
             e = run_quad(emu, Xa, model, entry="hostemu_solve_wave16_l8")
             assert e is not None and e["status"] == 0 and e["iterations"] == int(g[key + "/iters"]), key
             assert_close(e["weights"], g[key + "/weights"], RTOL, what=key)
+
+
+@pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
+def test_wave16_source_at_32_lvs(emu, scheme):
+    """solve_problem_wave16<32> (sixteen matrix entries per pair lane): all-Mode-A models of 17 ... 32 LVs against the oracle, the LDS variant and a bootstrap replicate."""
+    for sizes, fan in (([3] * 20, 2), ([2] * 32, 1), ([1] * 10 + [4] * 7, 5), ([5, 1, 2, 3, 1, 4, 2, 1, 3, 2, 1, 1, 6, 2, 3, 1, 2, 4, 1, 2, 3, 1, 1, 2], 3)):
+        L = len(sizes)
+        C = _dag(L, fan)
+        X, blocks = _shaped(C, sizes, seed=31, N=600)
+        model = orc.Model(blocks, C, "A" * L, scheme, True)
+        e = run_quad(emu, X, model, entry="hostemu_solve_wave16_l32")
+        assert e is not None, sizes
+        check(e, orc.fit(X, model), "wave16<32> L=%d %s" % (L, scheme))
+        base = run_emu(emu, X, model)
+        assert e["iterations"] == base["iterations"]
+        assert_close(e["row"], base["row"], 1e-10, 1e-13)
+    rng = np.random.default_rng(8)
+    idx = rng.integers(0, X.shape[0], X.shape[0])
+    e = run_quad(emu, X, model, counts=np.bincount(idx, minlength=X.shape[0]), shift=X[:, model.mv_order].mean(axis=0), entry="hostemu_solve_wave16_l32")
+    mine, its = orc.bootstrap_replicate(X, model, idx, orc.correction(X.shape[0]))
+    assert e["status"] == 0 and e["iterations"] == its
+    assert_close(np.concatenate((e["weights"], e["r2"], e["total"], e["direct"], e["loadings"])), mine, RTOL, 1e-12)
+    Xs, bs = _shaped(orc.chain_C(16), [4] * 16, seed=2)
+    assert run_quad(emu, Xs, orc.Model(bs, orc.chain_C(16), "A" * 16, scheme, True), entry="hostemu_solve_wave16_l32") is None      # 16 LVs: the <16> form's

@@ -9,7 +9,7 @@ from plspm import _native
 from size_bench_models import chain_C
 
 B = 5000
-NAMES = {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel", 5: "solver_quad_kernel<16>", 6: "solver_wave16_kernel<16>", 7: "solver_wave16_kernel<8>"}
+NAMES = {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel", 5: "solver_quad_kernel<16>", 6: "solver_wave16_kernel<16>", 7: "solver_wave16_kernel<8>", 8: "solver_wave16_kernel<32>"}
 out = {}
 for name, C, per, modes in (("10k x 120 x 12", chain_C(12), 10, None), ("10k x 64 x 16", chain_C(16), 4, None), ("10k x 60 x 12", chain_C(12), 5, None),
                             ("10k x 60 x 6 all Mode B", orc.satisfaction_C(), 10, "B")):
