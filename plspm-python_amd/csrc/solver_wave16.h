@@ -322,26 +322,77 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         ex.mark(17);
         ex.sync();
         ex.mark(18);
+        if constexpr (NE == 1) {
+            // Q[el, em] = sum over the MVs p of block el of w_p V[p, em]: eight terms in flight per trip
+            double s0 = 0.0, s1 = 0.0;
+            int pb = pb0(0);
+            ex.opaque(pb);
+            const double* vv = ws.V + pb * W16<LMAX>::VP + eml;
+            const double* ww = ws.w + pb;
+            for (int i0 = 0; i0 < kbmax; i0 += 8) {
+                double v[8];
 #pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            if ((64 / LMAX) * u < L) {                           // (uniform: rows 4 u .. 4 u + 3 exist)
-                // Q[el, em] = sum over the MVs p of block el of w_p V[p, em]: eight terms in flight per trip
-                double s0 = 0.0, s1 = 0.0;
-                int pb = pb0(u);
-                ex.opaque(pb);
-                const double* vv = ws.V + pb * W16<LMAX>::VP + eml;
-                const double* ww = ws.w + pb;
-                for (int i0 = 0; i0 < kbmax; i0 += 8) {
-                    double v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if constexpr (W16<LMAX>::TCOPY) v[j] = (i0 + j < pk(u)) ? vv[(64 + i0 + j) * W16<LMAX>::VP] : 0.0;      // (the copy: 64 rows behind V)
-                        else v[j] = (i0 + j < pk(u)) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
-                    }
-                    s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (W16<LMAX>::TCOPY) v[j] = (i0 + j < pk(0)) ? vv[(64 + i0 + j) * W16<LMAX>::VP] : 0.0;      // (the copy: 64 rows behind V)
+                    else v[j] = (i0 + j < pk(0)) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
                 }
-                Qe[u] = s0 + s1;
-                ws.Qm[pl + 64 * u] = pairu(u) ? Qe[u] : 1.0;
+                s0 += v[0]; s1 += v[1]; s0 += v[2]; s1 += v[3]; s0 += v[4]; s1 += v[5]; s0 += v[6]; s1 += v[7];
+            }
+            Qe[0] = s0 + s1;
+            ws.Qm[pl] = pairu(0) ? Qe[0] : 1.0;
+        } else {
+            // several entries per lane: the trips run over the TERMS, all of the lane's entries side by side -- TT terms of every entry in flight per trip (models of
+            // many LVs have small blocks: a trip of eight terms per entry issued 2 x 8 loads per entry for three live terms; 60 x 20: 9.8 k -> 3 k clocks per product).
+            // Even terms into one chain, odd terms into the other: the sums of the eight-term form, bit for bit.
+            double s0[NE], s1[NE];
+#pragma unroll
+            for (int u = 0; u < NE; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+            auto terms = [&](auto ttc) {                         // TT terms of every entry per trip
+                constexpr int TT = decltype(ttc)::value;
+                for (int i0 = 0; i0 < kbmax; i0 += TT) {
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) {
+                        if ((64 / LMAX) * u < L) {               // (uniform: the rows of this entry group exist)
+                            const int pb = pb0(u), pkk = pk(u);
+                            const double* vv = ws.V + pb * W16<LMAX>::VP + eml;
+                            const double* ww = ws.w + pb;
+                            double v[TT];
+#pragma unroll
+                            for (int j = 0; j < TT; ++j) v[j] = (i0 + j < pkk) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
+#pragma unroll
+                            for (int j = 0; j < TT; j += 2) { s0[u] += v[j]; s1[u] += v[j + 1]; }
+                        }
+                    }
+                }
+            };
+            // (by the widest block: a model whose blocks fit one short trip takes the short trip; four entries per lane with wider blocks: one entry after the other,
+            //  eight terms per trip -- measured best at 60 x 10 / 60 x 12: 0.115 / 0.117 ms against 0.118 / 0.120 with four and 0.121 / 0.122 with eight terms side by side)
+            if (kbmax <= (NE <= 4 ? 4 : 2)) terms(std::integral_constant<int, (NE <= 4 ? 4 : 2)>{});
+            else if (NE > 4) terms(std::integral_constant<int, 4>{});
+            else {
+#pragma unroll
+                for (int u = 0; u < NE; ++u) {
+                    if ((64 / LMAX) * u < L) {
+                        int pb = pb0(u);
+                        ex.opaque(pb);
+                        const int pkk = pk(u);
+                        const double* vv = ws.V + pb * W16<LMAX>::VP + eml;
+                        const double* ww = ws.w + pb;
+                        for (int i0 = 0; i0 < kbmax; i0 += 8) {
+                            double v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = (i0 + j < pkk) ? ww[i0 + j] * vv[(i0 + j) * W16<LMAX>::VP] : 0.0;
+                            s0[u] += v[0]; s1[u] += v[1]; s0[u] += v[2]; s1[u] += v[3]; s0[u] += v[4]; s1[u] += v[5]; s0[u] += v[6]; s1[u] += v[7];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                if ((64 / LMAX) * u < L) {
+                    Qe[u] = s0[u] + s1[u];
+                    ws.Qm[pl + 64 * u] = pairu(u) ? Qe[u] : 1.0;
+                }
             }
         }
         ex.sync();
