@@ -1,19 +1,23 @@
-// solver_wave16.h -- the wave solver (solver_wave.h: ONE 64-lane wave per problem, fixed lane roles) for inner models of 9 .. 16 LVs: metric Mode-A
-// models with at most 64 MVs -- "many LVs, few indicators each" (twelve LVs of three to five items) -- which the rows solver's generic thread-group
-// code served until round 5 (0.16 / 0.18 / 0.32 ms per 5,000 replicates at 10 / 12 / 16 LVs beside the wave solver's 0.10 at 8).
+// solver_wave16.h -- the wave solver (solver_wave.h: ONE 64-lane wave per problem, fixed lane roles) in the arrangement round 5 arrived at, as a template on the
+// largest number of LVs: metric models with at most 64 MVs behind the int8 Gram's dense moment matrices.
+//   LMAX = 8    the headline's class (at most 8 LVs; Mode A and -- second instantiation -- Mode-B blocks): the default since the second half of round 5
+//               (solver_wave_kernel<8> of rounds 3 / 4 stays behind set_option("solver_wave", 3))
+//   LMAX = 16   9 .. 16 LVs -- "many LVs, few indicators each" (twelve LVs of three to five items) -- which the rows solver's generic thread-group code served
+//               before (0.16 / 0.18 / 0.32 ms per 5,000 replicates at 10 / 12 / 16 LVs beside the wave solver's 0.10 at 8); Mode A and Mode-B blocks
+//   LMAX = 32   17 .. 32 LVs, all Mode A (the LDS solver's class before): three problems per CU by LDS, one wave per SIMD
 // Same arithmetic, same reference lines as solver_wave.h / solver_quad.h:
 //   Config.treat plspm/config.py:299-305 + util.treat plspm/util.py:33-39; _MetricWeights.__init__ plspm/weights.py:28-39; .iterate
-//   plspm/weights.py:41-54; Scheme.*.calculate plspm/scheme.py:27-28, 36-37, 45-54; _ModeA.outer_weights_metric plspm/mode.py:28-29;
-//   WeightsCalculatorFactory.calculate plspm/weights.py:172-187 (stop rule); _MetricWeights.calculate plspm/weights.py:56-70 (sign rule);
+//   plspm/weights.py:41-54; Scheme.*.calculate plspm/scheme.py:27-28, 36-37, 45-54; _ModeA.outer_weights_metric plspm/mode.py:28-29; _ModeB.outer_weights_metric
+//   plspm/mode.py:50-52; WeightsCalculatorFactory.calculate plspm/weights.py:172-187 (stop rule); _MetricWeights.calculate plspm/weights.py:56-70 (sign rule);
 //   InnerModel / _effects plspm/inner_model.py:58-75, 33-53; bootstrap row plspm/bootstrap.py:58-64.
 // Roles:
 //   MV lane p < P          column p of the treated covariance in 64 register pairs, its weight
-//   pair lane t            FOUR entries of every L x L matrix: column m = t mod 16, rows l = t / 16 + 4 u, u = 0 .. 3 (the wave solver: one entry per lane,
-//                          L <= 8) -- a quarter of the lanes' work per phase is still a few dozen flops
+//   pair lane t            NE = LMAX^2 / 64 entries of every L x L matrix: column m = t mod LMAX, rows l = t / LMAX + (64 / LMAX) u, u < NE (one entry at LMAX = 8,
+//                          four at 16, sixteen at 32)
 //   LV lane i < L          the small regressions of LV i and column i of (I - B)^-1
-// and the quad solver's arrangement of the small arrays: V = S W stays in LDS (pitch 17: conflict-free) and is read there by the Q sums (w_p V[p, m]
-// directly, no transposed T pass), the outer step (a folded into E), the sign rule and the loadings; the regressions have a scratch area of their
-// own.  LDS per problem ~16 KB + the regression scratch: eight problems per CU, like the wave solver.
+// and the quad solver's arrangement of the small arrays: V = S W stays in LDS (odd pitch: conflict-free) and is read there by the Q sums, the outer step (a folded
+// into E), the sign rule and the loadings; the regressions have a scratch area of their own; Q / G / E are re-used as indirect effects / score covariance / path
+// matrix after the loop.  LDS per problem 12 KB (LMAX = 8), 16 KB (16), 43 KB (32) + the regression scratch (+ the Mode-B inverses).
 #pragma once
 #include "solver_wave.h"
 
