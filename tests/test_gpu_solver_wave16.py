@@ -178,3 +178,34 @@ def test_wave16_solver_for_17_to_32_lvs(sizes, fan, scheme):
     mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(11, r, 700), orc.correction(700))
     assert its == iters[r]
     assert_close(rows[r], mine, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("L,per", [(12, 5), (12, 10), (20, 3)])
+def test_plspm_api_bootstrap_on_models_of_the_new_solver_classes(L, per):
+    """Plspm(bootstrap=True) through the host API on chain models of 12 x 5 (wave solver for 9 ... 16 LVs), 12 x 10 (quad solver) and 20 x 3 MVs (17 ... 32 LVs):
+    the fit against the oracle, every replicate used, the bootstrap means beside the original weights."""
+    import sys, os
+    import pandas as pd
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    C = orc.chain_C(L)
+    X, blocks = orc.synth(2000, C, per, seed=3)
+    cols = ["x%d" % i for i in range(X.shape[1])]
+    names = ["LV%02d" % l for l in range(L)]
+    s = c.Structure()
+    for l in range(1, L):                                      # (orc.chain_C: edges l - 1 -> l and l - 3 -> l)
+        s.add_path([names[l - 1]], [names[l]])
+        if l >= 3:
+            s.add_path([names[l - 3]], [names[l]])
+    cfg = c.Config(s.path(), scaled=True)
+    for l in range(L):
+        cfg.add_lv(names[l], Mode.A, *[c.MV(cols[i]) for i in blocks[l]])
+    m = Plspm(pd.DataFrame(X, columns=cols), cfg, Scheme.PATH, 100, 1e-6, bootstrap=True, bootstrap_iterations=600, seed=1)
+    ref = orc.fit(X, orc.Model(blocks, C, "A" * L, "path", True, tol=1e-6))
+    om = m.outer_model()
+    assert_close(om.loc[cols, "weight"].values, ref["weights"], 1e-8, 1e-11)
+    bw = m.bootstrap().weights()
+    assert m.bootstrap().used() == 600 and np.all(np.isfinite(bw[["mean", "std.error"]].values))
+    assert float(np.abs(bw["original"] - bw["mean"]).max()) < 0.01
