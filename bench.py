@@ -100,8 +100,14 @@ def cpu_baseline(budget_s=20.0):
                       % (count, cores, 1.0 / per_rep, wall)}
 
 
-def live_traffic(kernel_prefix, gram_path):
-    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+def kernel_key(name):
+    """Kernel name as rocprofv3 prints it -> comparison key: no `void `, no argument list, no blanks."""
+    return name.replace("void ", "").split("(")[0].replace(" ", "")
+
+
+def live_traffic(kernel_name, gram_path, grid_hint=None):
+    """HBM bytes per launch of the dominant kernel -- the EXACT instantiation `kernel_name` the timed steps launched (a run also launches other
+    instantiations of the same template: sub-batches of the host-buffer leg, the seven-plane leg), measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, counters only -- no trace domain), read back from the rocpd databases.  FETCH_SIZE is doubled
     (gfx950 reports half the bytes of wide coalesced reads: MI355X_MICROARCH.md, HBM section; checked in tools/rocprof_summary.py on a
     kernel of known traffic).  None when rocprofv3 is missing or a pass fails -- the caller then falls back to the committed figure."""
@@ -117,15 +123,15 @@ def live_traffic(kernel_prefix, gram_path):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="plspm_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline", "--no-api", "--no-traffic", "--no-next-rows", "--gram-path", str(gram_path)]
+               "--no-cpu-baseline", "--no-api", "--no-traffic", "--no-next-rows", "--no-single-fit", "--gram-path", str(gram_path)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = glob.glob(os.path.join(d, "*.db")) + glob.glob(os.path.join(d, "*", "*.db"))
             cur = sqlite3.connect(dbs[0]).cursor()
             q = ("select kernel_name, count(*), avg(value) from counters_collection c where counter_name=? and grid_size = "
                  "(select max(grid_size) from counters_collection c2 where c2.kernel_name = c.kernel_name) group by kernel_name")
-            hit = [(n, avg) for name, n, avg in cur.execute(q, (ctr,)) if kernel_prefix in name]
-            if not hit:
+            hit = [(n, avg) for name, n, avg in cur.execute(q, (ctr,)) if kernel_key(name) == kernel_key(kernel_name)]
+            if len(hit) != 1:                                  # the timed instantiation was not launched by the child (or the name is ambiguous): no figure rather than a wrong one
                 return None
             kib[ctr] = hit[0][1]
         except Exception:
@@ -241,6 +247,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the categorical bootstrap and the metric models beside the headline (child runs of tools/categorical_bench.py, tools/size_rows.py)")
+    ap.add_argument("--no-single-fit", action="store_true", help="skip the single-fit rows (configs[1] and configs[4]: a child run of tools/fit_bench.py)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
     ap.add_argument("--no-transport-calibration", action="store_true", help="keep RCCL as created (skip the untimed comparison with channel-capped RCCL / the copy-engine exchange)")
@@ -436,6 +443,9 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    # the launch the timed region ran, described NOW: the legs below (host-buffer sub-batches, one-row probes) launch other instantiations and
+    # overwrite the handle's last_* words
+    timed_launch = {k: model.get_option(k) for k in ("last_gram_path", "last_i8_slices", "last_i8_mt", "last_i8_short", "last_i8_rt", "last_i8_priv", "last_i8_dma", "last_solver")}
     if profiled:
         model.profile(False)
         gram_timed = model.profile_read("gram")
@@ -517,7 +527,7 @@ def main():
         gram_ms, gram_n = gram_timed if profiled else model.profile_read("gram")
         res_ms, res_n = model.profile_read("resample")
         sol_ms, sol_n = model.profile_read("solver")
-        used_path = model.get_option("last_gram_path")
+        used_path = timed_launch["last_gram_path"]
         reps_per_launch = args.reps_per_gpu
         a_rep = 8.0 * N_OBS * 60 + 4.0 * N_OBS                 # one gathered read of X + the index vector
         f_rep = float(N_OBS) * 60 * 61                         # symmetric Gram flops
@@ -537,13 +547,18 @@ def main():
             return None, None
         timing_note = ("HIP events around the kernel's launches in every %d-th step of the timed region (single stream: the kernel alone)" % prof_every if profiled else
                        "HIP events on the handle's stream over a calibration pass of the same launches without the overlapping collective")
+        if used_path == 2:
+            slices, priv, rt = timed_launch["last_i8_slices"], timed_launch["last_i8_priv"], timed_launch["last_i8_rt"]
+            kname = ("gram_i8p_kernel<%d, %d, 64, %s>" % (slices, rt // 4, "true" if timed_launch["last_i8_short"] else "false") if priv else
+                     "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if timed_launch["last_i8_dma"] == 2 else 3, model.get_option("i8_shape"), rt))
+        else:
+            kname = "gram_rows_kernel<4, false>"
         live = None
         if world == 1 and group is None and not launched and not args.no_traffic:
-            live = live_traffic(("gram_i8p_kernel" if model.get_option("last_i8_priv") else "gram_i8_kernel") if used_path == 2 else "gram_rows_kernel", used_path)
+            live = live_traffic(kname, used_path)
         live_src = ("live: two child runs of this script (3 steps) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters "
                     "only), average over the kernel's full-size launches, FETCH_SIZE x 2 (gfx950)")
         if used_path == 2:
-            slices = model.get_option("last_i8_slices")
             npair = 61 * 62 // 2                               # unordered pairs of the 60 columns + the ones column
             ops_rep = 2.0 * N_OBS * npair * slices             # int8 multiply-adds x 2, unpadded
             achieved = ops_rep * reps_per_launch / (gram_avg_ms * 1e-3) / 1e12
@@ -552,36 +567,35 @@ def main():
             # in profiles/)
             k_rows = ((N_OBS + 127) // 128) * 128
             # (replicate slots: the launch's tile rows -- 320-replicate and, cut by plspm_gram_i8.hip i8_mix_plan, 256-replicate ones -- x their heights)
-            rep_slots = 16 * model.get_option("last_i8_mt")
+            rep_slots = 16 * timed_launch["last_i8_mt"]
             executed = 2.0 * rep_slots * k_rows * (((npair + 31) // 32) * 32) * slices
-            priv = model.get_option("last_i8_priv")
-            rt = model.get_option("last_i8_rt")
-            kname = ("gram_i8p_kernel<%d, %d, 64, %s>" % (slices, rt // 4, "true" if model.get_option("last_i8_short") else "false") if priv else
-                     "gram_i8_kernel<%d, %d, %d, %d, %d, false>" % (slices, model.get_option("i8_waves") // 2, 803 if model.get_option("last_i8_dma") == 2 else 3, model.get_option("i8_shape"), rt))
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                         "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4),
                         "frac_of_measured_ceiling": round(achieved / I8_MFMA_MEASURED_CEILING_TOPS, 4),
                         "measured_ceiling": {"value": I8_MFMA_MEASURED_CEILING_TOPS, "unit": "TOP/s",
                                              "source": "MI355X_MICROARCH.md matrix-core table (I8, 16x16x64 micro-benchmark); the nominal peak is 2 x the bf16 dense spec"},
                         "executed_ops": executed, "executed_over_algorithmic": round(executed / (ops_rep * reps_per_launch), 4),
-                        "tile_rows": {"workgroup_tile_replicates": 16 * rt, "short_rows": model.get_option("last_i8_short"), "short_row_replicates": 16 * (rt - 4), "replicate_slots": rep_slots},
+                        "tile_rows": {"workgroup_tile_replicates": 16 * rt, "short_rows": timed_launch["last_i8_short"], "short_row_replicates": 16 * (rt - 4), "replicate_slots": rep_slots},
                         "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": kname, "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "ops": "int8 multiply-add = 2 ops (TOP/s; v_mfma_i32_16x16x64_i8, exact int32 accumulation); peak = dense int8 matrix peak",
                         "algorithmic_ops_per_replicate": ops_rep,
                         "algorithmic_ops_derivation": "2 x N rows x %d pair columns x %d digit planes (SURVEY 8(d)'s N P (P+1) fp64 flops = %.4g per replicate, "
                                                       "each fp64 multiply-add carried by %d exact int8 ones)" % (npair, slices, f_rep, slices),
-                        "fp64_equivalent": {"achieved": round(f64_equiv, 1), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(f64_equiv / FP64_MFMA_PEAK_TF, 3),
-                                            "note": "SURVEY 8(d) flops per replicate / the kernel's time, against the fp64 matrix peak the round-1 kernel ran at 0.95 of"},
-                        "algorithmic_bytes_per_replicate": a_rep,
-                        "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}}
+                        "survey_8d_model": {"not_a_roofline": "SURVEY 8(d) priced a replicate as one gathered read of X (A_rep bytes) feeding an fp64 Gram (F_rep flops); this "
+                                                              "kernel neither gathers X per replicate nor multiplies in fp64 (one int8 product of the batch's count matrix with digit "
+                                                              "planes shared by all replicates), so both rates below exceed the respective peaks -- they restate the kernel's time in "
+                                                              "8(d)'s units and bound nothing",
+                                            "algorithmic_bytes_per_replicate": a_rep, "algorithmic_flops_per_replicate": f_rep,
+                                            "A_rep_rate_GBps": round(hbm_achieved, 1), "A_rep_rate_over_hbm_peak": round(hbm_achieved / HBM_PEAK_GBS, 3),
+                                            "F_rep_rate_TFLOPs": round(f64_equiv, 1), "F_rep_rate_over_fp64_mfma_peak": round(f64_equiv / FP64_MFMA_PEAK_TF, 3)}}
         else:
             traffic, traffic_src = (live, live_src) if live else static_traffic(("r02_gram_traffic.json", "r01_gram_traffic.json"))
             roofline = {"bound": "mfma", "achieved": round(f64_equiv, 2), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(f64_equiv / FP64_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "gram_rows_kernel<4,false>", "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
+                        "kernel": kname, "avg_launch_ms": round(gram_avg_ms, 4), "launches": gram_n, "note": timing_note,
                         "algorithmic_flops_per_replicate": f_rep, "algorithmic_bytes_per_replicate": a_rep,
-                        "hbm_equivalent": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4)}}
+                        "A_rep_rate_GBps": round(hbm_achieved, 1), "A_rep_rate_over_hbm_peak": round(hbm_achieved / HBM_PEAK_GBS, 4)}
         other = None
         if world == 1 and group is None and used_path == 2:
             # the same workload on the fp64 MFMA Gram (round 1's dominant kernel), for the record
@@ -675,7 +689,7 @@ def main():
                                    "range every step; X resident in HBM" % (args.reps_per_gpu, world, args.reps_per_gpu),
                        "replicates_per_step": B_total, "iterations_per_replicate": [int(iters_l.min()), int(iters_l.max())],
                        "parallelism": parallelism, "transport": transport, "ranks_seen_by_rccl": ranks_seen if transport == "rccl" else 0,
-                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel", 5: "solver_quad_kernel<16>", 6: "solver_wave16_kernel<16>", 7: "solver_wave16_kernel<8>", 8: "solver_wave16_kernel<32>"}.get(model.get_option("last_solver"), "?"),
+                       "replicate_ranges": [[a, a + n] for a, n in shards], "solver_kernel": {1: "solver_kernel", 2: "solver_rows_kernel", 3: "solver_wave_kernel<8>", 4: "solver_rows_split_kernel", 5: "solver_quad_kernel<16>", 6: "solver_wave16_kernel<16>", 7: "solver_wave16_kernel<8>", 8: "solver_wave16_kernel<32>"}.get(timed_launch["last_solver"], "?"),
                        "gram_tile_plan_cus": plan_cus, "transport_calibration": transport_cal,
                        "comm_create_s": comm_create_s, "upload_s_per_device": upload_s, "single_call_latency_ms": single_call},
             "roofline": roofline,
@@ -725,6 +739,19 @@ def main():
             line["next_rows"] = {"categorical_bootstrap": cat, "metric_models_next_to_the_headline": sizes,
                                  "note": "not part of `value`: ORD / NOM optimal scaling on 300 indicator columns (10k x 60 five-point items x 6 LVs), one wave per problem, "
                                          "count matrices written by the int8 product as uint16, stop rule as an int8 matrix product; DESIGN 5c"}
+        if world == 1 and group is None and not args.no_single_fit:
+            # SURVEY 8(d) "plus single-fit latency for C2 and C5": BASELINE.json configs[1] and configs[4] through plspm_upload / plspm_fit, in a child
+            # process (tools/fit_bench.py: its own handle and 1.6 GB matrix; HIP-event kernel times, walls with and without upload / scores download,
+            # A_fit / F_fit rooflines)
+            import subprocess
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fit_bench.py"), "c2", "c5"], capture_output=True, text=True, timeout=600).stdout
+                fits = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+                line["single_fit"] = {"configs[1]": fits[0], "configs[4]": fits[1],
+                                      "note": "device_ms_total = sum of the fit's kernels (HIP events); fit_wall_ms_* = host wall of plspm_fit with X resident; "
+                                              "upload_ms = plspm_upload of the fp64 matrix from pageable host memory (PCIe); never part of `value`"}
+            except Exception as e:                                        # noqa: BLE001 -- an extra of the line, never its failure
+                line["single_fit"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             # the real reference cannot travel to this box: its rate measured in the build container, and the factor between the oracle and

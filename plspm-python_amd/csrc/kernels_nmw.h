@@ -4,8 +4,8 @@
 // Reference: _NonmetricWeights.iterate (plspm/weights.py:107-120) with the Scale operators (plspm/scale.py:41-89: ORD with the two-direction monotone
 // pooling `_ordinalize`, NOM), the Mode-A non-metric outer step (plspm/mode.py:31-42) and the inner schemes (plspm/scheme.py) -- the arithmetic of
 // solver_nmg.h nmg_step, which this restates for the model class the categorical bootstrap lives in: every MV ORD / NOM (all device columns 0/1
-// indicators: the moment matrix is a matrix of co-occurrence counts, kept as uint16), every block Mode A, at most 64 MVs of at most CMAX = 8
-// categories, at most LMAX = 8 LVs, at most 511 indicator columns.  Everything else keeps nmg_kernel<1>.
+// indicators: the moment matrix is a matrix of co-occurrence counts, kept as uint16), every block Mode A, at most 64 MVs of at most CMAX categories
+// (instantiated for 8 and for 16 = CMAX_MAX), at most LMAX = 8 LVs, at most 511 indicator columns.  Everything else keeps nmg_kernel<1>.
 //
 // Why.  nmg_kernel<1> runs ~50 dependent small phases per step on a 256-thread workgroup whose LDS footprint (54 KB) leaves two workgroups per CU:
 // 78 % of its wave cycles are waits, its VALUs are 14 % busy (profiles/r04); the one phase that moves data -- V = Mn c, the whole
@@ -110,7 +110,7 @@ template <int N> __device__ __forceinline__ void allsum_each(double (&v)[N], int
 // <MV_r, MV_c> = tq_r' N_rc tq_c / n, one more pass over the count matrix: for every MV c the wave forms y = Mn[:, cols(c)] tq_c on its column lanes
 // (the rows of MV c: one 16-byte load per lane and row) and folds y with tq over the columns of every MV r <= c -- then the shared tail
 // (finish_problem: loadings, cross-loadings, path regressions, effects, the record).  `fast`: the problem's LDS; MV r's columns sit in at most
-// two neighbouring lanes (at most 8 categories, 8 columns per lane): the lane that holds its first column stores, the other one adds.
+// three neighbouring lanes (at most CMAX <= 16 categories, 8 columns per lane): the lane that holds its first column stores, the other one adds.
 template <int CMAX>
 __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const ModelDesc& mdm, const SolverOut& so, double* gSm, NmState& st, NmgExtra& xg,
                               const unsigned short* k16, int ld16, double* fast, long b) {

@@ -174,6 +174,12 @@ int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, i
 // whole round (5,000 replicates of the headline model as 2,560 + 1,536 + 904: Gram 0.42 ms; as 2,560 + 1,280 + 1,160: 0.35; one batch 0.334).
 // 64 when the handle's bootstrap does not take that Gram.  plspm_gram_i8.hip.
 int64_t plspm_detail_round_units(plspm_model* m);
+// The same figure from the handle's state AS IT IS -- no allocation, no launch, no host wait: 64 while the digit planes of the current upload
+// have not been built (read-only queries: plspm_model_get_option "boot_round_units", plspm_group_plan).
+int64_t plspm_detail_round_units_peek(const plspm_model* m);
+// plspm_group.cpp: the sub-batch alignment a group's ranks agreed on is void after an upload / option change on one of its handles (calls
+// every rank of a job makes alike); the next plspm_group_bootstrap agrees again.
+void plspm_detail_group_plan_changed(void* group);
 struct FetchSeg { int64_t b0, nb; hipEvent_t ready; };
 
 // Same-device record exchange of a group (plspm_bootstrap.hip): send[i] -> recv[d] + i * doubles for all i, d < n, one launch on `stream`.

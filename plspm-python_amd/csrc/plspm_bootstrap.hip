@@ -78,7 +78,8 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     if (want_dcnt && (rc = ensure(m, m->dcnt, (size_t)chunk * dcnt_stride * sizeof(unsigned short)))) return rc;
     m->dcnt_stride = dcnt_stride; m->dcnt_ready = want_dcnt;
     // The error word (index out of range / multiplicity above 127 / stream-K wait expired) can only be raised by a call that brings explicit
-    // indices or runs the persistent Gram: a Philox call on the tiled launch neither raises nor needs to clear it (the 4-byte memset is a
+    // indices or runs the persistent Gram (data sets of fewer than 128 rows cannot exceed a multiplicity of 127; they are kept on the clearing
+    // side because their launches take the short-N forms that share the word with the index check): a Philox call on the tiled launch neither raises nor needs to clear it (the 4-byte memset is a
     // kernel of its own on the stream: ~8 us with its gaps, 1.5 % of a 5,000-replicate step)
     const bool may_raise = d_idx != nullptr || m->tune.i8_sched != 0 || N < 128;
     if (!m->err_clean || may_raise) HIPCHK(m, hipMemsetAsync(m->err.p, 0, sizeof(int), m->stream));
@@ -193,7 +194,10 @@ int plspm_bootstrap(plspm_model_t* m, int64_t B, uint64_t seed, int64_t rep_offs
     int64_t parts[kBootChunksMax];
     int nparts = 1;
     parts[0] = B;
-    if (!d_idx && !m->nonmetric && !m->moments_out)
+    // (a call whose launches may raise the device error word -- plspm_detail_bootstrap's may_raise -- clears that word at the start of every
+    //  sub-batch, which would wipe the bits of the sub-batch before: such calls run as one batch, one memset, one read)
+    const bool may_raise = m->tune.i8_sched != 0 || m->N < 128;
+    if (!d_idx && !m->nonmetric && !m->moments_out && !may_raise)
         nparts = plspm_detail_chunk_plan(B, (int64_t)RS * (int64_t)sizeof(double), m->tune.boot_chunks, m->tune.boot_ratio, parts, m->tune.boot_align > 0 ? m->tune.boot_align : plspm_detail_round_units(m));
     if (nparts > 1) {
         if (!m->dl) HIPCHK(m, plspm_stream_acquire(&m->dl));

@@ -12,6 +12,14 @@ static constexpr size_t kZsBudget = (size_t)24 << 30;       // digit planes of o
 // Which Gram a bootstrap call of B replicates takes: 1 = fp64 MFMA on the (row,count) lists, 2 = int8 digit planes.
 // Can a non-metric bootstrap with on-device draws take its stop-rule passes' row multiplicities from the int8 counts of the digit-plane Gram
 // (plspm_detail_bootstrap counts8_plan)?
+static int cu_count_of(plspm_model* m) {
+    if (!m->cu_count) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, m->device) == hipSuccess) m->cu_count = n;
+    }
+    return m->cu_count;
+}
+
 bool nm_counts8_possible(const plspm_model* m) {
     return m->nonmetric && m->tune.nm_counts8 != 0 && m->tune.resample_aux == 0 && !m->aux && m->tune.i8_shape == 16 && m->nmx_K == 0 &&
            nm_dense_lds(m, nullptr, nullptr) != 0 && (!m->stage2 || nm_dense_lds(m->stage2, nullptr, nullptr) != 0);
@@ -262,7 +270,7 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     // tiles, every CU three tall + one short = 76 count-tile rows, against 16 rows of 320 = 960 tiles, 80 on three CUs of four)
     int nty_tall = 0, nty_short = 0;
     if ((wide20 || priv) && m->tune.i8_rt == 0 && m->tune.i8_short < 0) {
-        if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
+        if (!cu_count_of(m)) return fail(m, PLSPM_E_STATE, "hipDeviceGetAttribute(multiprocessor count) failed");
         // (the plan of the last shape is kept: a bootstrap calls with the same B again and again, and the search costs of the order of a millisecond)
         // ("i8_cus": the cut for fewer CUs than the device has -- a launch that shares the chip with a collective's kernels)
         const long key[4] = {(long)((nb + 15) / 16), (long)(m->zs_npg / 2), (long)std::max(8, m->tune.i8_cus > 0 ? std::min(m->tune.i8_cus, m->cu_count) : m->cu_count),
@@ -366,7 +374,7 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     const bool sk = m->tune.i8_sched == 1 && m->tune.i8_shape == 16 && m->tune.i8_variant < 0 && S >= 5 && S <= 7;      // (S = 8 spills in the persistent kernel)
     int sk_grid = 0;
     if (sk) {
-        if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
+        if (!cu_count_of(m)) return fail(m, PLSPM_E_STATE, "hipDeviceGetAttribute(multiprocessor count) failed");
         sk_grid = std::max(8, (m->cu_count / 8) * 8);
         const size_t slot_bytes = (size_t)32 * S * 1024;                    // 16 count tiles x 2 pair groups x S planes x 1 KB of int32 per workgroup
         if ((size_t)sk_grid * slot_bytes > m->sk_partial.cap && (rc = ensure(m, m->sk_partial, (size_t)sk_grid * slot_bytes))) return rc;
@@ -429,7 +437,7 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     const bool persist = priv && m->tune.i8_persist != 0 && (m->tune.i8_variant < 0 || m->tune.i8_variant == 64);
     int pp_wgs = 0;
     if (persist) {
-        if (!m->cu_count) { hipDeviceProp_t pr; HIPCHK(m, hipGetDeviceProperties(&pr, m->device)); m->cu_count = pr.multiProcessorCount; }
+        if (!cu_count_of(m)) return fail(m, PLSPM_E_STATE, "hipDeviceGetAttribute(multiprocessor count) failed");
         const int cus = std::max(8, m->tune.i8_cus > 0 ? std::min(m->tune.i8_cus, m->cu_count) : m->cu_count);
         pp_wgs = std::max(1, std::min(cus / 8, per));                       // one workgroup per CU of an XCD, never more than the XCD has tiles
         if (!m->pp_ctl.p) {
@@ -536,15 +544,20 @@ int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const i
     return 0;
 }
 
-int64_t plspm_detail_round_units(plspm_model* m) {
-    if (!m || !m->d_Xa || m->nonmetric || m->n_ind || choose_gram_path(m, (int64_t)1 << 20) != 2) return 64;
-    if (hipSetDevice(m->device) != hipSuccess || prepare_zs(m)) return 64;            // (the plane count decides the tile height; built once per upload anyway)
+int64_t plspm_detail_round_units_peek(const plspm_model* m) {
+    if (!m || !m->d_Xa || m->nonmetric || m->n_ind || !m->zs_valid || !m->cu_count || choose_gram_path(m, (int64_t)1 << 20) != 2) return 64;
     const int S = m->zs_S;
     if ((S != 6 && S != 7) || m->zs_ind || m->tune.i8_priv == 0) return 64;
-    if (!m->cu_count) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, m->device) != hipSuccess) return 64; m->cu_count = pr.multiProcessorCount; }
     const int cus = std::max(8, m->tune.i8_cus > 0 ? std::min(m->tune.i8_cus, m->cu_count) : m->cu_count);
     const int ntx = std::max(1, m->zs_npg / 2), tall = (S == 6 ? 20 : 16) * 16;
     return (int64_t)std::max(1, cus / ntx) * tall;
+}
+
+int64_t plspm_detail_round_units(plspm_model* m) {
+    if (!m || !m->d_Xa || m->nonmetric || m->n_ind || choose_gram_path(m, (int64_t)1 << 20) != 2) return 64;
+    if (hipSetDevice(m->device) != hipSuccess || prepare_zs(m)) return 64;            // (the plane count decides the tile height; built once per upload anyway)
+    if (!cu_count_of(m)) return 64;
+    return plspm_detail_round_units_peek(m);
 }
 
 extern "C" {

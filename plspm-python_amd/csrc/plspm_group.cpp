@@ -175,6 +175,10 @@ struct plspm_group {
     int64_t sub_B[kBootChunksMax] = {}, sub_first[kBootChunksMax] = {}, sub_cap[kBootChunksMax] = {}, sub_off[kBootChunksMax] = {};
     int opt_chunks = 0, opt_ratio = 50;            // plspm_group_set_option
     int opt_align = 0;                             // "chunk_align": 0 = whole rounds of the device (plspm_detail_round_units), n > 0 = multiples of n replicates per rank
+    // The automatic alignment is rank-LOCAL state (CU count, "i8_cus", whether the digit planes could be built), while the number and sizes of the
+    // collectives must be the same on every rank: the ranks agree on it (max over ranks, one blocking all-reduce) in the first plspm_group_bootstrap
+    // that consults it, and again after an upload / option change on a handle (calls every rank makes alike).  0 = not agreed.
+    int64_t agreed_units = 0;
     int opt_lean_events = 1;                       // "lean_events": no wait packet for an event that has fired, `computed` signalled by the shard's last kernel
     int opt_skip_exchange = 0;                     // diagnostics (include/plspm_hip_test.h): the step without its exchange
     int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
@@ -258,6 +262,7 @@ static void group_release(plspm_group* g) {
 // A handle is being destroyed while it still belongs to a group (host objects are collected in arbitrary order): the group lets go
 // of ALL its handles first, so that nothing dangles; later calls on the group report PLSPM_E_STATE.
 void plspm_detail_group_orphan(void* group) { if (group) group_release((plspm_group*)group); }
+void plspm_detail_group_plan_changed(void* group) { if (group) ((plspm_group*)group)->agreed_units = 0; }
 
 int plspm_detail_chunk_plan(int64_t B, int64_t bytes_per_unit, int chunks_opt, int ratio_pct, int64_t* parts, int64_t align) {
     parts[0] = B;
@@ -322,6 +327,14 @@ void plspm_comm_destroy(plspm_comm_t* c) {
 // max_channels > 0: RCCL may run at most that many workgroups ("channels", ncclConfig_t.maxCTAs) for this communicator's collectives.  Why: the
 // all-gather of step k runs beside the Gram of step k + 1, a Gram workgroup needs a whole CU, and every CU an RCCL channel sits on is missing from a
 // launch that was cut for all of them; 44 MB per 0.48 ms (eight ranks, 5,000 replicates each) does not need RCCL's default channel count.
+// communicators a failed group of ncclCommInitRankConfig / ncclCommSplit calls did create are destroyed, not dropped (ncclCommAbort where the library has it:
+// the peers of a half-built communicator may never arrive at a collective destroy)
+static void drop_partial_comms(const Rccl* r, plspm_comm* c) {
+    for (size_t i = 0; i < c->comms.size(); ++i)
+        if (c->comms[i]) { hipSetDevice(c->devices[i]); r->CommDestroy(c->comms[i]); c->comms[i] = nullptr; }
+    c->comms.clear();
+}
+
 static ncclConfig_t capped_config(int max_channels) {
     ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
     cfg.minCTAs = 1;
@@ -396,7 +409,7 @@ plspm_comm_t* plspm_comm_create_ex(const int32_t* device_ids, int32_t n_local, i
         }
         rc = r->GroupEnd();
         if (first == ncclSuccess) first = rc;
-        if (first != ncclSuccess) { c->comms.clear(); delete c; return bad(-(1000 + (int)first), std::string("ncclCommInitRankConfig: ") + r->GetErrorString(first)); }
+        if (first != ncclSuccess) { drop_partial_comms(r, c); delete c; return bad(-(1000 + (int)first), std::string("ncclCommInitRankConfig: ") + r->GetErrorString(first)); }
     } else {
         ncclUniqueId uid;
         memcpy(&uid, unique_id, sizeof(uid));
@@ -437,7 +450,7 @@ plspm_comm_t* plspm_comm_split(plspm_comm_t* parent, int32_t max_channels) {
         if (rc != ncclSuccess && first == ncclSuccess) first = rc;
     }
     if (n_local > 1) { rc = r->GroupEnd(); if (first == ncclSuccess) first = rc; }
-    if (first != ncclSuccess) { c->comms.clear(); delete c; return bad(-(1000 + (int)first), std::string("ncclCommSplit: ") + r->GetErrorString(first)); }
+    if (first != ncclSuccess) { drop_partial_comms(r, c); delete c; return bad(-(1000 + (int)first), std::string("ncclCommSplit: ") + r->GetErrorString(first)); }
     return c;
 }
 
@@ -502,14 +515,22 @@ int plspm_group_sync(plspm_group_t* g) {
 }
 
 // How a call of B replicates is cut into sub-batches on this group ("chunks" / "chunk_ratio"): K ranges of global replicate ids, each sharded
-// over the ranks like a call of its own.  Deterministic in (B, nranks, options, record width): every rank of a job plans alike.
+// over the ranks like a call of its own.  A function of rank-INVARIANT inputs only -- B, nranks, the group's options, the record width and the
+// alignment the ranks agreed on (agree_units) -- so every rank of a job issues the same number of collectives of the same sizes whatever
+// happened to it locally.
+static bool plan_consults_units(const plspm_group* g) {
+    const bool nothing_to_hide = g->nranks == 1 || (g->comm && g->comm->transport == 3);
+    return !(nothing_to_hide && g->opt_chunks <= 0) && g->opt_chunks != 1 && g->opt_align <= 0;
+}
+
 static int plan_sub_batches(const plspm_group* g, int64_t B, int RS, int64_t* sub_first, int64_t* sub_B) {
     const int64_t per_rank = (B + g->nranks - 1) / g->nranks;
     int64_t parts[kBootChunksMax];
     // (one rank, or ranks that share a device -- one copy launch of microseconds: nothing travels, nothing to hide; unless sub-batches are asked for by number)
     const bool nothing_to_hide = g->nranks == 1 || (g->comm && g->comm->transport == 3);
-    const int K = (nothing_to_hide && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts,
-                                                                                       g->opt_align > 0 ? g->opt_align : plspm_detail_round_units(g->loc[0].m));
+    // (not agreed yet -- a forecast through plspm_group_plan before the first call: this rank's own figure as its handle stands, nothing built for it)
+    const int64_t units = g->opt_align > 0 ? g->opt_align : (g->agreed_units > 0 ? g->agreed_units : plspm_detail_round_units_peek(g->loc[0].m));
+    const int K = (nothing_to_hide && g->opt_chunks <= 0) ? 1 : plspm_detail_chunk_plan(per_rank, (int64_t)RS * (int64_t)sizeof(double), g->opt_chunks, g->opt_ratio, parts, units);
     int64_t at = 0;
     int n = 0;
     for (int k = 0; k < K && at < B; ++k) {
@@ -567,6 +588,15 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
     // call hides its merge the way a loop of calls does; the gathered buffer holds the sub-batches one after the other, each in the layout of a
     // call of its own -- i.e. in replicate-id order throughout (what the device summaries' fixed-order sums rely on)
     int64_t sub_first[kBootChunksMax], sub_B[kBootChunksMax], sub_cap[kBootChunksMax], sub_off[kBootChunksMax];
+    if (plan_consults_units(g) && g->agreed_units <= 0) {
+        // every rank takes this branch alike (group options, rank count, and an agreement voided only by calls all ranks make); what a rank
+        // contributes is its own business -- a rank whose planes could not be built says 64 and fails in its shard below, BEHIND the collectives
+        double units = 64.0;
+        for (auto& l : g->loc) units = std::max(units, (double)plspm_detail_round_units(l.m));
+        int arc = plspm_group_max(g, &units);
+        if (arc) return arc;
+        g->agreed_units = (int64_t)units;
+    }
     const int K = plan_sub_batches(g, B, RS, sub_first, sub_B);
     int64_t cap = 0;
     for (int k = 0; k < K; ++k) { sub_cap[k] = (sub_B[k] + g->nranks - 1) / g->nranks; sub_off[k] = cap; cap += sub_cap[k]; }

@@ -340,6 +340,7 @@ int plspm_upload(plspm_model_t* m, const double* X, int64_t N, int32_t src_cols,
         if (ci[p] < 0 || ci[p] >= src_cols) return fail(m, PLSPM_E_ARG, "plspm_upload: col_index out of range");
     }
     HIPCHK(m, hipSetDevice(m->device));
+    if (m->group) plspm_detail_group_plan_changed(m->group);
     if (m->aux) HIPCHK(m, hipStreamSynchronize(m->aux));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     // whatever was resident is gone from here on (a failed upload leaves an empty, re-usable handle)
@@ -479,6 +480,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "boot_ratio") { if (value < 10 || value > 100) return bad(); m->tune.boot_ratio = value; }
     else if (k == "boot_align") { if (value < 0 || value > (1 << 20)) return bad(); m->tune.boot_align = value; }
     else return fail(m, PLSPM_E_ARG, "plspm_model_set_option: unknown option '" + k + "'");
+    if (m->group) plspm_detail_group_plan_changed(m->group);
     return 0;
 }
 
@@ -538,7 +540,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "boot_chunks") *value = m->tune.boot_chunks;
     else if (k == "boot_ratio") *value = m->tune.boot_ratio;
     else if (k == "boot_align") *value = m->tune.boot_align;
-    else if (k == "boot_round_units") *value = (int32_t)plspm_detail_round_units(const_cast<plspm_model*>(m));
+    else if (k == "boot_round_units") *value = (int32_t)plspm_detail_round_units_peek(m);      // (64 until the digit planes of this upload exist: a query builds nothing)
     else if (k == "last_gram_path") *value = m->last_gram_path;
     else if (k == "build_experiments") {
 #ifdef PLSPM_I8_EXPERIMENTS

@@ -33,7 +33,7 @@ size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out) {
 }
 
 // round 5: the iteration as one WAVE per problem (kernels_nmw.h nmw_step_kernel) for all-indicator models of at most 65,535 rows whose blocks are all Mode A,
-// of at most 64 MVs with at most 8 categories each, 8 LVs and 511 indicator columns
+// of at most 64 MVs with at most 16 categories each (nmw::CMAX_MAX), 8 LVs and 511 indicator columns
 bool nm_wave_step_planned(const plspm_model* m) {
     if (!m->categorical || !m->cat_pure || m->nmx_K > 0 || m->N > 65535 || m->tune.nm_k16 == 0 || m->tune.nm_wave == 0) return false;
     for (int l = 0; l < m->L; ++l) if (m->mode[l] != PLSPM_MODE_A) return false;

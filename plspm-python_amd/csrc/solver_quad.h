@@ -77,7 +77,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     const int pc = valid ? p : P - 1;
     const int lp = md.lvof[pc];                                  // MV role: my LV
     const int ms = rows_split_block(md.boff, L, PMAX);           // LVs [0, ms) on side 0, [ms, L) on side 1
-    const int l0 = side ? ms : 0, l1 = side ? L : ms, nl = l1 - l0;
+    const int l0 = side ? ms : 0, l1 = side ? L : ms;
     const int q0 = md.boff[l0], nq = md.boff[l1] - q0;           // my window of columns
     const int el = t / LMAX, em = t % LMAX;                      // pair role: entry (el, em)
     const bool pair = el < L && em < L;

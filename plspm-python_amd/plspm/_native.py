@@ -482,6 +482,8 @@ class NativeComm:
         """``transport``: "auto" (RCCL between distinct devices), "rccl", or "copy" (single-process jobs: device-to-device copies on
         peer-mapped buffers -- the SDMA engines move the records, no kernel of the exchange takes a CU).  ``max_channels`` > 0 caps the
         workgroups RCCL runs for this communicator's collectives (ncclConfig_t.maxCTAs)."""
+        if _handle is None and transport not in self.TRANSPORTS:
+            raise ValueError("transport must be one of %s (got %r; PLSPM_TRANSPORT sets the default)" % (", ".join(sorted(self.TRANSPORTS)), transport))
         lib = load()
         self._lib = lib
         self.devices = [int(d) for d in devices]

@@ -105,3 +105,48 @@ def effect_pairs(C):
     for _ in range(L):
         reach = reach | ((reach.astype(int) @ reach.astype(int)) > 0)
     return [(f, t) for f in range(L) for t in range(L) if f != t and reach[t, f]]
+
+
+# ----------------------------------------------------------------------------------------------
+# When may the device report a numerical condition the oracle did not?  (tests/test_gpu_fuzz.py)
+DEGENERATE_EIG_RTOL = 1e-10      # two orders above csrc/solver_core.h PLSPM_EIG_RTOL (1e-12) / PLSPM_PIVOT_RTOL (1e-13): the device's rank decision
+
+
+def oracle_conditioning(X, model):
+    """Smallest relative eigenvalue the oracle's own arithmetic meets on these rows: over the correlation matrices of the Mode-B blocks (mode.py:50-52,
+    lstsq on the block) and of every LV's predecessor scores (scheme.py:48-50, inner_model.py:69: OLS on the predecessors), and the smallest column
+    standard deviation relative to the largest.  Returns (value, what)."""
+    worst, what = 1.0, "none"
+    sd = X.std(axis=0)
+    if not np.all(np.isfinite(sd)) or sd.max() == 0:
+        return 0.0, "non-finite or constant data"
+    if sd.min() / sd.max() < worst:
+        worst, what = float(sd.min() / sd.max()), "column std ratio"
+    if sd.min() == 0:
+        return 0.0, "zero-variance MV"
+    for l, blk in enumerate(model.blocks):
+        if model.modes[l] == "B" and len(blk) > 1:
+            ev = np.linalg.eigvalsh(np.corrcoef(X[:, blk], rowvar=False))
+            if ev[0] / ev[-1] < worst:
+                worst, what = float(ev[0] / ev[-1]), "Mode-B block %d" % l
+    try:
+        scores = orc.fit(X, model)["scores"]
+    except Exception:                                      # noqa: BLE001 -- the oracle itself cannot estimate these rows
+        return 0.0, "oracle fails on these rows"
+    if not np.all(np.isfinite(scores)):
+        return 0.0, "oracle scores not finite"
+    for i in range(model.L):
+        pred = np.flatnonzero(model.C[i])
+        if len(pred) > 1:
+            ev = np.linalg.eigvalsh(np.corrcoef(scores[:, pred], rowvar=False))
+            if ev[0] / ev[-1] < worst:
+                worst, what = float(ev[0] / ev[-1]), "predecessors of LV %d" % i
+    return worst, what
+
+
+def assert_device_status_justified(status, X, model, tag=""):
+    """A device status the oracle did not share on the same rows: PLSPM_NOT_CONVERGED (1) is never acceptable (iteration counts are held equal);
+    PLSPM_SINGULAR / PLSPM_NONFINITE (2, 3) only when the oracle's own systems on these rows are degenerate to working precision."""
+    assert status != 1, "%s: the device did not converge where the oracle did" % tag
+    cond, what = oracle_conditioning(X, model)
+    assert cond < DEGENERATE_EIG_RTOL, "%s: device status %d on rows whose worst conditioning is %.3g (%s): not a degenerate case" % (tag, status, cond, what)

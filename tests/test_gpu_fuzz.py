@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import plspm_oracle as orc
-from helpers import assert_close
+from helpers import assert_close, assert_device_status_justified
 from test_gpu_parity import SCHEME_ID, _ragged, _random_dag
 
 pytestmark = pytest.mark.gpu
@@ -42,9 +42,11 @@ def test_random_model(seed):
     except orc.NotConverged:
         assert g["status"] == 1
         return
-    if g["status"] != 0:
-        pytest.skip("device flags a numerical condition (status %d) on a random model" % g["status"])
     tag = "seed %d L=%d P=%d n=%d %s %s %s" % (seed, model.L, X.shape[1], X.shape[0], model.modes, model.scheme, "NUM" if nonmetric else "metric")
+    if g["status"] != 0:
+        # a device-only status must be explained by the oracle's own conditioning on these rows -- it can turn the suite red
+        assert_device_status_justified(g["status"], X, model, tag)
+        return
     assert g["iterations"] == r["iterations"], tag
     assert_close(g["weights"], r["weights"], RTOL, ATOL, what=tag)
     assert_close(g["path_coef"], r["path_coef"], RTOL, ATOL, what=tag)
@@ -56,14 +58,29 @@ def test_random_model(seed):
     corr = orc.correction(n)
     for b in range(3):
         idx = _native.bootstrap_indices(seed, b, n)
-        try:
-            mine, its = orc.bootstrap_replicate(X, model, idx, corr)
-        except Exception:
+        if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
             continue
-        if status[b] != 0 or not np.all(np.isfinite(mine)):
-            continue
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
         assert its == iters[b], tag + " replicate %d" % b
         assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+
+
+def _replicate_comparable(X, model, idx, corr, status, tag):
+    """True when the oracle and the device both estimated the replicate (the caller then compares the records).  Otherwise the two must AGREE that it
+    cannot be estimated: an oracle failure (the reference's bare `except`, bootstrap.py:65-66, drops the replicate) needs a device status != 0, and a
+    device status the oracle does not share needs degenerate rows (helpers.assert_device_status_justified) -- never a silent `continue`."""
+    try:
+        mine, _ = orc.bootstrap_replicate(X, model, idx, corr)
+        oracle_ok = bool(np.all(np.isfinite(mine)))
+    except Exception:                                      # noqa: BLE001
+        oracle_ok = False
+    if not oracle_ok:
+        assert status != 0, tag + ": the oracle cannot estimate this replicate, the device reports PLSPM_OK"
+        return False
+    if status != 0:
+        assert_device_status_justified(int(status), X[idx], model, tag)
+        return False
+    return True
 
 
 def make_wide_case(seed):
@@ -119,14 +136,12 @@ def test_random_wide_model_bootstrap(seed):
     corr = orc.correction(n)
     checked = 0
     for b in range(B):
-        if status[b] != 0 or checked == 2:
+        if checked == 2 and status[b] == 0:
             continue
-        try:
-            mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(seed, b, n), corr)
-        except Exception:
+        idx = _native.bootstrap_indices(seed, b, n)
+        if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
             continue
-        if not np.all(np.isfinite(mine)):
-            continue
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
         assert its == iters[b], tag + " replicate %d" % b
         assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
         checked += 1
@@ -176,14 +191,12 @@ def _narrow_case_check(seed, B=40):
     corr = orc.correction(n)
     checked = 0
     for b in range(B):
-        if status[b] != 0 or checked == 2:
+        if checked == 2 and status[b] == 0:
             continue
-        try:
-            mine, its = orc.bootstrap_replicate(X, model, _native.bootstrap_indices(seed, b, n), corr)
-        except Exception:
+        idx = _native.bootstrap_indices(seed, b, n)
+        if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
             continue
-        if not np.all(np.isfinite(mine)):
-            continue
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
         assert its == iters[b], tag + " replicate %d" % b
         assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
         checked += 1

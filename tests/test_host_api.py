@@ -361,25 +361,70 @@ def test_bench_guard_fixture_is_current():
     np.testing.assert_allclose(row, g["row"], rtol=1e-12)
 
 
+def _newest_profile(suffix):
+    """profiles/rNN<suffix> with the largest round number NN (the latest committed measurement of that kind)."""
+    import glob
+    import re
+    hits = [(int(re.match(r"r(\d+)", os.path.basename(p)).group(1)), p) for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*" + suffix))
+            if re.fullmatch(r"r\d+" + re.escape(suffix), os.path.basename(p))]
+    assert hits, suffix
+    return max(hits)
+
+
 def test_committed_bench_line_follows_the_driver_contract():
-    """profiles/r03_bench_n1.json (the latest committed line) is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions
-    (dtype = arithmetic type, vs_baseline null without a published number, config names the workload, roofline + cpu_baseline)."""
+    """The newest profiles/rNN_bench_n1.json is the line `python bench.py` printed on the GPU box: keys, types and the tier's conventions (dtype =
+    arithmetic type, vs_baseline null without a published number, config names the workload, roofline + cpu_baseline + single_fit) -- and its
+    `roofline` object describes the launch that was TIMED: the kernel name occurs in the same round's rocprofv3 summary with an average duration
+    within 5 % of avg_launch_ms (timed-region average), the executed ops are 1.0-1.1 x the algorithmic ones, the traffic is that kernel's."""
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))
+    rnd, path = _newest_profile("_bench_n1.json")
+    assert rnd >= 6, "the committed line predates round 6's bench.py"
+    line = json.load(open(path))
     for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
-                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict),
+                      ("single_fit", dict)):
         assert isinstance(line[key], kind), key
     assert line["vs_baseline"] is None and line["dtype"] == "f64" and line["scaling"] == "weak" and line["higher_is_better"] is True
     assert "workload" in line["config"] and "model" not in line["config"]
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert line["metric"].split(" at ")[0] in baseline["metric"]
     roof = line["roofline"]
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and (roof["traffic"] is None or roof["traffic"] > 0)
-    assert abs(roof["frac_of_measured_ceiling"] - roof["achieved"] / roof["measured_ceiling"]["value"]) < 1e-3 and roof["executed_ops"] >= roof["algorithmic_ops_per_replicate"] * 5000
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s", "TOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] > 0
+
+    def fracs(obj, trail=""):
+        for k, v in obj.items():
+            if isinstance(v, dict):
+                yield from fracs(v, trail + k + ".")
+            elif k == "frac" or k.startswith("frac_"):
+                yield trail + k, v
+    for name, v in list(fracs(roof)) + list(fracs(line["single_fit"])):
+        assert 0.0 < v <= 1.0, (name, v)                     # nothing called a fraction of a peak exceeds it
+    reps = line["config"]["replicates_per_step"] // line["n_gpus"]
+    ratio = roof["executed_ops"] / (roof["algorithmic_ops_per_replicate"] * reps)
+    assert 1.0 <= ratio <= 1.1 and abs(ratio - roof["executed_over_algorithmic"]) < 1e-3, ratio
+    assert roof["tile_rows"]["replicate_slots"] >= reps
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r%02d_rocprof_summary.json" % rnd)))
+    mine = [k for k in summary["kernels"] if k["kernel"] == roof["kernel"]]
+    assert len(mine) == 1, (roof["kernel"], [k["kernel"] for k in summary["kernels"] if "gram" in k["kernel"]])
+    assert summary["kernels"][0]["kernel"] == roof["kernel"]                         # ... and it is that run's dominant kernel
+    timed = [p for p in summary["dominant_by_phase"] if p["phase"].startswith("TIMED")][0]
+    assert abs(timed["avg_us"] * 1e-3 - roof["avg_launch_ms"]) <= 0.05 * roof["avg_launch_ms"], (timed, roof["avg_launch_ms"])
+    ctr = summary["counters"][roof["kernel"]]
+    assert abs(ctr["hbm_bytes_per_dispatch"] - roof["traffic"]) <= 0.05 * roof["traffic"], (ctr, roof["traffic"])
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "r%02d_gram_i8_traffic.json" % rnd)))
+    assert traffic["kernel"] == roof["kernel"]
     assert line["cold"]["value"] > 0 and line["cold"]["ms_per_step"] >= 0.9 * line["ms_per_step"]
     cfg = line["config"]
     assert cfg["transport"] in ("none", "rccl") and cfg["replicate_ranges"][0][0] == 0 and cfg["replicate_ranges"][-1][1] == cfg["replicates_per_step"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert abs(line["value"] - line["config"]["replicates_per_step"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    # the two single-fit configurations of BASELINE.json (SURVEY 8(d)): iteration counts, HIP-event kernel times, A_fit / F_fit rooflines
+    for key, (n, p, l) in (("configs[1]", (10000, 60, 6)), ("configs[4]", (1000000, 200, 20))):
+        fit = line["single_fit"][key]
+        assert (fit["N"], fit["P"], fit["L"]) == (n, p, l) and fit["status"] == 0 and fit["iterations"] >= 2
+        r = fit["roofline"]
+        assert r["A_fit_bytes"] == 16.0 * n * p + 8.0 * n * l and r["F_fit_flops"] == float(n) * p * (p + 1) + 2.0 * n * p * l
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert abs(sum(fit["kernel_ms"].values()) - fit["device_ms_total"]) < 1e-3 and fit["device_ms_total"] >= r["bound_ms"]

@@ -56,7 +56,28 @@ def run(tag, n, C, per, modes, scheme, reps=5):
     a_fit = 16.0 * n * P + 8.0 * n * L
     f_fit = float(n) * P * (P + 1) + 2.0 * n * P * L
     dev_ms = ms["gram"] + ms["reduce"] + ms["solver"] + ms["scores"]
-    line = {"config": tag, "N": n, "P": P, "L": L, "iterations": out["iterations"], "status": out["status"],
+    # a single fit is bound by max(A_fit / HBM, F_fit / fp64 matrix peak); `roofline.achieved` is always computed from A_fit (and, for the
+    # matrix bound, F_fit) over the sum of the fit's kernel times (HIP events on the handle's stream).  C2 (10 MB) is launch-latency bound: a handful of
+    # dependent launches of a few microseconds each -- its fraction is small by construction and says so.
+    HBM_PEAK, F64_PEAK = 8000.0, 78.6
+    t_hbm, t_mfma = a_fit / (HBM_PEAK * 1e9), f_fit / (F64_PEAK * 1e12)
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    ach_hbm, ach_mfma = a_fit / dev_ms / 1e6, f_fit / dev_ms / 1e9
+    gram_tf = float(n) * P * (P + 1) / ms["gram"] / 1e9
+    roofline = {"bound": bound,
+                "achieved": round(ach_hbm if bound == "hbm" else ach_mfma, 2), "peak": HBM_PEAK if bound == "hbm" else F64_PEAK,
+                "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                "frac": round((ach_hbm / HBM_PEAK) if bound == "hbm" else (ach_mfma / F64_PEAK), 4),
+                "device_ms": round(dev_ms, 4), "bound_ms": round(max(t_hbm, t_mfma) * 1e3, 4),
+                "A_fit_bytes": a_fit, "F_fit_flops": f_fit,
+                "hbm": {"achieved_GBps": round(ach_hbm, 1), "frac": round(ach_hbm / HBM_PEAK, 4), "bound_ms": round(t_hbm * 1e3, 4)},
+                "mfma_f64": {"achieved_TFLOPs": round(ach_mfma, 2), "frac": round(ach_mfma / F64_PEAK, 4), "bound_ms": round(t_mfma * 1e3, 4)},
+                "gram_kernel": {"TFLOPs": round(gram_tf, 2), "frac_of_fp64_mfma_peak": round(gram_tf / F64_PEAK, 4),
+                                "GBps": round(8.0 * n * P / ms["gram"] / 1e6, 1), "frac_of_hbm_peak": round(8.0 * n * P / ms["gram"] / 1e6 / HBM_PEAK, 4)},
+                "note": ("A_fit = 16 N P + 8 N L, F_fit = N P (P+1) + 2 N P L (SURVEY.md 8(d)); frac = the binding term over the sum of the fit's kernel times "
+                         "(HIP events); " + ("launch-latency bound at this size: four dependent launches of 7-40 us on 10 MB" if n <= 100000 else
+                                             "MFMA co-limited: the fp64 Gram is the longest kernel"))}
+    line = {"config": tag, "N": n, "P": P, "L": L, "iterations": out["iterations"], "status": out["status"], "roofline": roofline,
             "kernel_ms": {a: round(b, 4) for a, b in ms.items()}, "device_ms_total": round(dev_ms, 4),
             "fit_wall_ms_incl_scores_download": round(wall * 1e3, 3), "fit_wall_ms_no_scores": round(wall_noscores * 1e3, 3),
             "upload_first_ms": round(t_up * 1e3, 2), "upload_ms": round(t_up2 * 1e3, 3), "upload_GBps": round(8.0 * n * P / t_up2 / 1e9, 2), "upload_runtime_pageable_ms": (round(t_direct * 1e3, 3) if t_direct else None),

@@ -76,7 +76,10 @@ def main():
     with open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.json" % tag), "w") as fh:
         json.dump(out, fh, indent=1)
     for prefix, fname in (("gram_i8_kernel", "%s_gram_i8_traffic.json"), ("gram_i8p_kernel", "%s_gram_i8_traffic.json"), ("gram_rows_kernel", "%s_gram_traffic.json")):
-        gram = [k for k in out["counters"] if k.startswith(prefix)]
+        # the instantiation that dominates the traced run's time (a run also launches other instantiations of the same template: the sub-batches of
+        # the host-buffer leg, the seven-plane leg) -- never "the first name that matches"
+        order = [k["kernel"] for k in out["kernels"]]
+        gram = sorted((k for k in out["counters"] if k.startswith(prefix + "<") or k == prefix), key=lambda k: order.index(k) if k in order else len(order))
         if gram:
             with open(os.path.join(ROOT, "profiles", fname % tag), "w") as fh:
                 json.dump({"kernel": gram[0], "hbm_bytes_per_launch": out["counters"][gram[0]]["hbm_bytes_per_dispatch"],
