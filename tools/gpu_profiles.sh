@@ -7,7 +7,7 @@ R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 600 python bench.py 2>$O/bench_n1.err | tail -1 > $O/bench_n1.json
+bash tools/gpu_profiles_headline.sh $TAG      # bench line, kernel trace, HBM counters, summary (profiles/<tag>_bench_n1.json, _rocprof_summary.*, _gram_i8_traffic.json)
 timeout 300 python bench.py --group --no-cpu-baseline --no-api --no-next-rows --no-single-fit 2>/dev/null | tail -1 > $O/bench_n1_group_rccl.json
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_n1_launcher_rccl.json
 PLSPM_BENCH_SHARED_DEVICE=1 timeout 300 python bench.py --gpus 2 --no-cpu-baseline --no-api --no-next-rows --no-single-fit 2>/dev/null | tail -1 > $O/bench_seam_2ranks_one_device.json
@@ -30,9 +30,6 @@ timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1 > $O/nonmetric_bench.
 timeout 900 python tools/fit_bench.py c2 c5 2>&1 | grep "^{" > $O/fit_bench.jsonl
 timeout 300 python tools/api_phase_times.py 2>&1 | grep "^{" > $O/api_phase_times.jsonl
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats -- python $R/bench.py --no-cpu-baseline --no-api --no-next-rows --no-single-fit --steps 50 --warmup 5 > $O/prof_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch -o fetch -- python $R/bench.py --no-cpu-baseline --no-api --no-next-rows --no-single-fit --steps 3 --warmup 1 > $O/prof_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/prof_write -o write -- python $R/bench.py --no-cpu-baseline --no-api --no-next-rows --no-single-fit --steps 3 --warmup 1 > $O/prof_write.log 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 -d $O/prof_pmc1 -o pmc1 -- python $R/bench.py --no-cpu-baseline --no-api --no-next-rows --no-single-fit --steps 3 --warmup 1 > $O/prof_pmc1.log 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 -d $O/prof_c5_pmc1 -o pmc1 -- python $R/tools/fit_bench.py c5 > $O/prof_c5_pmc1.log 2>&1
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/prof_c5_pmc2 -o pmc2 -- python $R/tools/fit_bench.py c5 > $O/prof_c5_pmc2.log 2>&1
@@ -90,7 +87,5 @@ for db in sorted(glob.glob(O + "/prof_*pmc*/*.db") + glob.glob(O + "/prof_c5_fet
 json.dump(out, open(O + "/pmc_rows.json", "w"), indent=0)
 for r in out: print(r["run"], r["kernel"][:36], r["counter"], r["dispatches"], r["avg"], r["avg_duration_ns"])
 PY
-python tools/rocprof_summary.py ${TAG}_tmp $(ls $O/prof_stats/*/*.db $O/prof_stats/*.db 2>/dev/null | head -1) $(ls $O/prof_fetch/*/*.db $O/prof_fetch/*.db 2>/dev/null | head -1) $(ls $O/prof_write/*/*.db $O/prof_write/*.db 2>/dev/null | head -1) $O/prof_stats.log > $O/rocprof_summary_stdout.txt 2>&1
-mv profiles/${TAG}_tmp_rocprof_summary.md $O/rocprof_summary.md 2>/dev/null; mv profiles/${TAG}_tmp_rocprof_summary.json $O/rocprof_summary.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_traffic.json $O/gram_traffic.json 2>/dev/null; mv profiles/${TAG}_tmp_gram_i8_traffic.json $O/gram_i8_traffic.json 2>/dev/null
 find $O -name "*.db" -size +20M -delete
 du -sh $O; ls $O
