@@ -22,6 +22,7 @@ import pandas as pd
 
 import plspm.config as c
 from plspm.scale import Scale
+from plspm.util import MissingDataError
 from plspm.weights import SolverResult, WeightsCalculatorFactory
 
 
@@ -51,7 +52,14 @@ class Estimator:
         calculator = calculator.clone()
         config = calculator.config()
         if config.missing() and not config.metric() and calculator._nonmetric() == 2:
-            raise NotImplementedError("missing values together with Scale.ORD / NOM are not part of the MI355X hot path; see SURVEY.md 8(f)")
+            holes = [mv for mv in data.columns[data.isnull().any()] if mv in config._mv_scales and config.scale(mv) in (Scale.ORD, Scale.NOM)]
+            if holes:
+                # the reference's own (most frequent) failure on such data, by name and message -- it has no defined estimate there (util.MissingDataError)
+                raise MissingDataError("exog contains inf or nans (missing cells in Scale.ORD / Scale.NOM column(s) %s: the reference raises this from statsmodels, "
+                                       "fails to converge, or returns a row-order dependent estimate; impute or drop those rows)" % ", ".join(map(str, holes)))
+            # NaNs only in the NUM / RAW columns of a model that also has ORD / NOM columns: the reference estimates this (NaN-aware Mode A on the NUM
+            # columns, weights.py:88-98); the device's categorical solver has no incomplete-row form yet
+            raise NotImplementedError("missing values in the Scale.NUM / RAW columns of a model with Scale.ORD / NOM columns are not part of the MI355X hot path; see SURVEY.md 8(f)")
         # NaNs otherwise travel to WeightsCalculatorFactory.run: metric -> mean imputation on the moments (util.py:61-68, config.py:300),
         # Scale.NUM -> incomplete rows handled explicitly by the device solver (weights.py:88-98, mode.py:35-41)
         hocs = config.hoc()

@@ -2,6 +2,15 @@
 from collections import OrderedDict
 
 
+class MissingDataError(Exception):
+    """Raised for missing cells in a Scale.ORD / Scale.NOM column.  The reference has no defined behaviour there: depending on mode, scheme and on
+    WHERE the NaN sits it raises ``statsmodels.tools.sm_exceptions.MissingDataError("exog contains inf or nans")`` (every Mode-B block, the PATH
+    scheme: weights.py:141, scheme.py:50), "Could not converge", a shape error (two NaNs in one column, scale.py:88), returns all-zero weights
+    (ORD), or an estimate that changes when the rows of the data set are permuted (NOM: util.groupby_mean sorts one dict key per NaN cell in
+    between the category keys, scale.py:83-88) -- tests/golden/g16_ordnom_missing_probe.json records all of it.  This backend raises the reference's
+    most frequent failure, by name and message, for every such data set."""
+
+
 class Value:
     """Payload type of the Mode / Scheme / Scale enums: compares by its tag (reference util.py:115-124)."""
 

@@ -299,9 +299,16 @@ def test_unsupported_paths_raise_not_implemented():
     from plspm._native import NativeBackendError
     with pytest.raises(NativeBackendError):
         Plspm(sat, cfg)
-    miss = sat.copy(); miss.iloc[0, 0] = np.nan                       # NaN-aware non-metric products are not built
-    with pytest.raises(NotImplementedError):
+    from plspm.util import MissingDataError
+    miss = sat.copy(); miss.iloc[0, 0] = np.nan                       # a NaN in an ORD column: the reference's own failure, by name and message
+    with pytest.raises(MissingDataError, match="exog contains inf or nans"):
         Plspm(miss, cfg)
+    mixed = c.Config(s.path(), default_scale=Scale.NUM)               # NaN in a NUM column beside ORD columns: the reference estimates, this backend does not yet
+    mixed.add_lv("IMAG", Mode.A, *[c.MV(n, Scale.ORD) for n in sat.columns if n.startswith("imag")])
+    mixed.add_lv_with_columns_named("EXPE", Mode.A, sat, "expe")
+    miss2 = sat.copy(); miss2.loc[miss2.index[3], [n for n in sat.columns if n.startswith("expe")][0]] = np.nan
+    with pytest.raises(NotImplementedError):
+        Plspm(miss2, mixed)
     hoc = c.Config(s.path())                                          # metric HOC: the reference cannot run it either
     hoc.add_higher_order("EXPE", Mode.A, ["A", "B"])
     hoc.add_lv_with_columns_named("IMAG", Mode.A, sat, "imag"); hoc.add_lv_with_columns_named("A", Mode.A, sat, "expe")
@@ -428,3 +435,26 @@ def test_committed_bench_line_follows_the_driver_contract():
         assert r["A_fit_bytes"] == 16.0 * n * p + 8.0 * n * l and r["F_fit_flops"] == float(n) * p * (p + 1) + 2.0 * n * p * l
         assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         assert abs(sum(fit["kernel_ms"].values()) - fit["device_ms_total"]) < 1e-3 and fit["device_ms_total"] >= r["bound_ms"]
+
+
+def test_ordnom_missing_probe_pins_the_reference_behaviour_this_backend_mirrors():
+    """tests/golden/g16_ordnom_missing_probe.json (tests/golden/probe_ordnom_missing.py driving the real reference in the build container): with NaN cells in
+    a Scale.ORD / NOM column the reference never returns a usable estimate -- it raises (statsmodels MissingDataError "exog contains inf or nans" in the
+    majority of the cases: every Mode-B case among them), returns all-zero weights, or returns weights that move by more than 1e-2 when the rows of the data
+    set are permuted (complete data: 1e-15).  plspm.util.MissingDataError carries that majority failure's name and message."""
+    import json
+    from plspm.util import MissingDataError
+    probe = json.load(open(os.path.join(GOLDEN, "g16_ordnom_missing_probe.json")))
+    assert probe["control_complete_data_max_abs_weight_change_under_row_permutation"] < 1e-12
+    recs = probe["records"]
+    assert len(recs) == 30
+    raised = [r for r in recs if r["outcome"] == "raises"]
+    named = [r for r in raised if r["exception"].endswith("MissingDataError")]
+    assert len(named) > len(raised) / 2 and all(r["message"] == "exog contains inf or nans" for r in named)
+    assert all(r["outcome"] == "raises" for r in recs if r["modes"] == "BBB")
+    for r in recs:
+        if r["outcome"] == "estimates":                       # never a usable estimate: degenerate, or not a function of the data SET
+            zero = max(abs(w) for w in r["weights"]) == 0.0
+            moved = r.get("max_abs_weight_change_under_row_permutation", 0.0) > 1e-2 or r["rows_permuted"]["outcome"] == "raises"
+            assert zero or moved, r["case"]
+    assert issubclass(MissingDataError, Exception) and MissingDataError.__name__ == named[0]["exception"].rsplit(".", 1)[1]
