@@ -62,6 +62,10 @@ int run_impute(plspm_model* m, long nproblems, const double* Min, const double**
 int launch_solver(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so, int threads);
 // the metric solver of a bootstrap batch: wave / rows solver on dense matrices (`dense`: the int8 Gram wrote that layout) or the LDS solver
 int launch_batch_solver(plspm_model* m, long nb, bool dense, const SolverOut& so);
+// Scale.NUM / RAW non-metric bootstrap batches as ONE solver launch (round 6; solver_wave16.h NM): does this model have such a kernel, and the launch itself
+// (dense moment matrices at m->gram; maps / steps as kernels_solver.h solver_nmwave_kernel takes them; force + live: the replay of `nb` listed replicates)
+bool nm_wave_solver_covers(const plspm_model* m);
+int launch_nm_wave_solver(plspm_model* m, long nb, const SolverOut& so, double* maps, long maps_stride, int* steps, const int* force, const int* live);
 size_t nm_state_doubles_of(const plspm_model* m);
 size_t nm_dense_lds(const plspm_model* m, bool* whole, int* kb_out);
 int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stride, const SolverOut& so_in, const int2* ent, const int* nent, long ent_stride, int threads,
@@ -78,4 +82,6 @@ int prepare_zs_stats(plspm_model* m);
 int prepare_zs(plspm_model* m);
 int run_gram_i8(plspm_model* m, int64_t nb, uint64_t seed, int64_t rep0, const int32_t* d_idx, double* out, bool dense, bool* fallback, const void** counts = nullptr,
                 int* counts_MT = nullptr, unsigned short* out16 = nullptr, bool* wrote16 = nullptr);
+bool nm_wave_route_planned(const plspm_model* m);     // plspm_nonmetric.hip: Scale.NUM / RAW batches as one solver launch + verification (run_nonmetric_wave)
+int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void* cd8, int cd8_MT);
 bool nm_wave_step_planned(const plspm_model* m);      // plspm_nonmetric.hip: the categorical iteration of this handle runs one wave per problem (kernels_nmw.h)

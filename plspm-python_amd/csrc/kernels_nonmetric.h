@@ -373,7 +373,11 @@ template <int RW, int NW, bool BLOCKED, bool CNT8 = false>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
                                                                  const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table,
                                                                  const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial, int nparts, int rbx,
-                                                                 int gy, int kb) {
+                                                                 int gy, int kb, double* __restrict__ vsum = nullptr, int by_slot = 0) {
+    // by_slot (round 6: the verification pass of the one-launch NUM / RAW solver, plspm_nonmetric.hip run_nonmetric_wave): the list holds VIRTUAL problems --
+    // (replicate, step) pairs; list[slot] is the replicate whose counts weigh the rows, the result is filed under the slot.  vsum: the sums of the row parts
+    // this launch covers are added up atomically per slot (a lower bound of the criterion that only has to clear the tolerance: the order of the additions
+    // does not matter) instead of being stored part by part.
     static_assert(!CNT8 || RW == 16, "the int8 counts come in pieces of 16 rows");
     // multiplicities of this wave's RW rows in replicate b: packed words (uint16 pairs, or bytes of the int8 counts)
     auto load_counts = [&](unsigned (&wq)[RW / 2], bool on, long b, long part) {
@@ -471,7 +475,10 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
                     acc = fma(w * d, d, acc);
                 }
             }
-            if (live && have) partial[b * nparts + part] = acc;
+            if (live && have) {
+                const long ob = by_slot ? (long)g * 64 + lane : b;
+                if (vsum) unsafeAtomicAdd(&vsum[ob], acc); else partial[ob * nparts + part] = acc;
+            }
             continue;
         }
         __syncthreads();
@@ -529,8 +536,147 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
                 acc = fma(w * d, d, acc);
             }
         }
-        if (live) partial[b * nparts + part] = acc;
+        if (live) {
+            const long ob = by_slot ? (long)g * 64 + lane : b;
+            if (vsum) unsafeAtomicAdd(&vsum[ob], acc); else partial[ob * nparts + part] = acc;
+        }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- verification of the one-launch NUM / RAW solver (round 6)
+// solver_nmwave_kernel (kernels_solver.h; solver_wave16.h NM) runs prepare + all steps + finish of a replicate in ONE launch: a step stops on the quadratic
+// upper bound of the reference's score criterion and continues otherwise -- speculatively, since "the bound is not below the tolerance" does not say that the
+// criterion is not.  What was speculated is checked here, on the observations, for every step a problem continued behind: VIRTUAL problems (b, j), j = 1 ..
+// steps_b - 1, "step j of replicate b: sum_il c_i (|y_{j-1}| - |y_j|)^2 >= tol?".  All terms are non-negative, so any subset of the rows gives a lower bound:
+// pass A evaluates the first rows only (an eighth; step 2 of the headline's replicates sits at 1e-4 against 1e-6, step 1 at 1e5) and confirms nearly
+// everything; what it cannot confirm goes through pass B over all rows with fixed-order sums, and a (b, j) whose exact value IS below the tolerance moves
+// replicate b's stop to step j (force[b] = min j; the solver replays those replicates).  Maps: maps[b][j] = [c_p (P) | k_l (L)] of step j's scores.
+//
+// vlist: the virtual problems of steps j0 .. j0 + JR - 1, step-major (consecutive slots = consecutive replicates: coalesced count loads), vb / vj, *count;
+// also max steps -> *host_max (pinned), vsum cleared, force[] = INT_MAX on the first round.  One workgroup.
+__global__ void __launch_bounds__(1024) nm_vlist_kernel(const int* __restrict__ steps, long nproblems, int j0, int JR, int* __restrict__ vb, int* __restrict__ vj,
+                                                         int* __restrict__ count, double* __restrict__ vsum, int* __restrict__ force, int* __restrict__ host_max) {
+    __shared__ int wcount[16];
+    __shared__ int base, smax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { base = 0; smax = 0; }
+    __syncthreads();
+    int mx = 0;
+    for (int j = j0; j < j0 + JR; ++j) {
+        for (long b0 = 0; b0 < nproblems; b0 += 1024) {
+            const long b = b0 + tid;
+            const int st = b < nproblems ? steps[b] : 0;
+            mx = max(mx, st);
+            if (j == j0 && j0 == 1 && b < nproblems) force[b] = 0x7fffffff;
+            const bool on = st - 1 >= j;
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) wcount[wave] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wave; ++w) off += wcount[w];
+            if (on) { const int v = off + __popcll(bal & ((1ull << lane) - 1ull)); vb[v] = (int)b; vj[v] = j; vsum[v] = 0.0; }
+            __syncthreads();
+            if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
+            __syncthreads();
+        }
+    }
+    atomicMax(&smax, mx);
+    __syncthreads();
+    if (tid == 0) { *count = base; if (host_max) *host_max = smax; }
+}
+
+// table[g][q][lane] of the virtual problems: q < P old coefficients (step j - 1), q < 2P new (step j), then k_old[L], k_new[L], live flag -- the layout
+// coef_table_kernel writes for the pass.
+__global__ void __launch_bounds__(256) nm_vtable_kernel(const double* __restrict__ maps, long maps_stride, int P, int L, const int* __restrict__ vb, const int* __restrict__ vj,
+                                                         const int* __restrict__ count, double* __restrict__ table) {
+    __shared__ double tile[64][65];
+    const int n = *count;
+    const long g = blockIdx.x;
+    if (g * 64 >= n) return;
+    const int rows = 2 * P + 2 * L + 1, q0 = (int)blockIdx.y * 64, W = P + L;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = w; r < 64; r += 4) {
+        const long slot = g * 64 + r;
+        double v = 0.0;
+        if (slot < n) {
+            const double* mo = maps + (long)vb[slot] * maps_stride + (long)(vj[slot] - 1) * W;
+            const double* mn = mo + W;
+            const int q = q0 + lane;
+            if (q < P) v = mo[q];
+            else if (q < 2 * P) v = mn[q - P];
+            else if (q < 2 * P + L) v = mo[P + q - 2 * P];
+            else if (q < rows - 1) v = mn[P + q - 2 * P - L];
+            else if (q == rows - 1) v = 1.0;
+        }
+        tile[r][lane] = v;
+    }
+    __syncthreads();
+    double* out = table + g * (long)rows * 64;
+    for (int qq = w; qq < 64; qq += 4) {
+        const int q = q0 + qq;
+        if (q < rows) out[(long)q * 64 + lane] = tile[lane][qq];
+    }
+}
+
+// What pass A could not confirm: slots whose partial sum is not safely at or above the tolerance -> (fb, fj), *fcount (+ pinned copy).  One workgroup.
+__global__ void __launch_bounds__(1024) nm_vflag_kernel(const double* __restrict__ vsum, const int* __restrict__ vb, const int* __restrict__ vj, const int* __restrict__ count,
+                                                         double tol, int* __restrict__ fb, int* __restrict__ fj, int* __restrict__ fcount, int* __restrict__ host_count) {
+    __shared__ int wcount[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    const int n = *count;
+    for (int v0 = 0; v0 < n; v0 += 1024) {
+        const int v = v0 + tid;
+        const bool on = v < n && !(vsum[v] >= tol * (1.0 + 1e-6));      // (NaN: flagged; the exact pass leaves it alone)
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wcount[w];
+        if (on) { const int o = off + __popcll(bal & ((1ull << lane) - 1ull)); fb[o] = vb[v]; fj[o] = vj[v]; }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) { *fcount = base; if (host_count) *host_count = base; }
+}
+
+// Pass B's verdict: the exact criterion of flagged slot v (fixed-order sum of its row parts) below the tolerance -> the reference stops replicate fb[v] at step fj[v].
+__global__ void __launch_bounds__(64) nm_vcheck_kernel(const double* __restrict__ partial, int nparts, const int* __restrict__ fb, const int* __restrict__ fj,
+                                                        const int* __restrict__ fcount, double tol, int* __restrict__ force) {
+    const int v = blockIdx.x;
+    if (v >= *fcount) return;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < nparts; c += 64) s += partial[(long)v * nparts + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0 && s < tol) atomicMin(&force[fb[v]], fj[v]);
+}
+
+// Replicates whose stop moved: force[b] < steps[b] -> list (+ count, pinned copy).  One workgroup.
+__global__ void __launch_bounds__(1024) nm_vfix_kernel(const int* __restrict__ steps, const int* __restrict__ force, long nproblems, int* __restrict__ list, int* __restrict__ count,
+                                                        int* __restrict__ host_count) {
+    __shared__ int wcount[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (long b0 = 0; b0 < nproblems; b0 += 1024) {
+        const long b = b0 + tid;
+        const bool on = b < nproblems && force[b] < steps[b];
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wcount[w];
+        if (on) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)b;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) { *count = base; if (host_count) *host_count = base; }
 }
 
 // ---------------------------------------------------------------------------------------------- dense stop-rule pass on category codes

@@ -176,6 +176,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LMAX > 
 }
 
 
+// The same wave on Scale.NUM / RAW non-metric data (solver_wave16.h NM; round 6): prepare + every step + finish of a replicate in one launch, the steps it
+// continued behind left as score maps for the verification pass (kernels_nonmetric.h nm_vlist_kernel ...).  `live` / `force`: the replay of the replicates
+// whose stop the verification moved (no maps stored).  The per-block sums of the map constants take 64 doubles behind the metric workspace.
+template <int LMAX, bool MODEB = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_nmwave_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so,
+                                                                                                        double* __restrict__ maps, long maps_stride, int* __restrict__ steps,
+                                                                                                        const int* __restrict__ force, const int* __restrict__ live, double bound_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const long b = live ? (long)live[blockIdx.x] : (long)blockIdx.x;
+    Wave16Ws<LMAX> ws;
+    wave16_carve(ws, reinterpret_cast<double*>(smem_raw), md.L, md.kmax);
+    double* nmk = reinterpret_cast<double*>(smem_raw) + wave16_ws_doubles<LMAX>(md.L, md.kmax, md.n_chol);
+    FitOutputs out{};
+    out.row = so.row ? so.row + b * so.row_stride : nullptr;
+    out.status = so.status ? so.status + b : nullptr;
+    out.iters = so.iters ? so.iters + b : nullptr;
+    NmWaveIo io;
+    io.maps = force ? nullptr : maps + b * maps_stride;
+    io.force_T = force ? force[b] : 0;
+    io.steps = force ? nullptr : steps + b;
+    io.bound_scale = bound_scale;
+    DevWaveExec ex;
+    ex.tid = (int)threadIdx.x; ex.nt = 64; ex.red = nullptr; ex.marks = (b == 0) ? so.marks : nullptr;
+    solve_problem_wave16<LMAX, MODEB, true>(ex, md, ws, Md + b * md_stride, out, &io, nmk);
+}
+
+
 // Quad variant (solver_quad.h solve_problem_quad; round 5): the wave solver's lane roles on FOUR waves per problem -- metric Mode-A models of
 // 65 .. 128 MVs and at most 16 LVs; two problems per CU (one wave of each per SIMD), ~52 KB of LDS per problem.
 template <int LMAX>

@@ -46,13 +46,18 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const bool w16_width = m->tune.solver_wave != 0 && (wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax) || (m->n_chol == 0 && wave16_solver_covers<32>(m->P, m->L, 0, m->kmax)));      // (solver_wave16.h: 9 .. 16 LVs, its own ~16 KB workspace)
     const bool rows_width = m->P <= 64 ? (rows_lds <= kMaxLds / 4 || w16_width) : (quad_width || (m->P <= 128 && rows_split_block(m->boff.data(), m->L, 64) > 0 && rows_lds + 4 * 16 * 66 * sizeof(double) <= kMaxLds / 2));
     const bool rows_solver = gpath == 2 && m->tune.solver_rows != 0 && rows_width && !m->n_ind && !m->nonmetric && !m->moments_out;
+    // round 6: Scale.NUM / RAW batches on the int8 route as one solver launch on dense moment matrices + a verification pass (plspm_nonmetric.hip
+    // run_nonmetric_wave) -- needs the int8 counts the Gram consumed (explicit index lists of at most 65,535 rows keep the per-iteration launches and their
+    // uint16 histograms; so does a chunk whose explicit indices made the int8 Gram fall back to the fp64 one)
+    const bool nm_wave = gpath == 2 && counts8_plan && !m->moments_out && nm_wave_route_planned(m);
     // the fp64 Gram walks (row,count) lists (explicit indices may fall back to it); so do the stop-rule passes of the non-metric solvers
     const bool need_lists = gpath == 1 || d_idx != nullptr || (m->nonmetric && !counts8_plan);
     const size_t kpad = (size_t)i8_kblocks(N) * 64;
     // (the global-scratch histogram serves the (row,count) lists only: the int8 route on Philox draws never builds them)
     const bool need_ghist = !lds_hist && need_lists;
     const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)std::max<long>(psize, cov_doubles(m->Pg)) * sizeof(double) + (need_ghist ? (size_t)N * sizeof(unsigned) : 0) +
-                           (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0);
+                           (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0) +
+                           (nm_wave ? (size_t)(m->max_iter + 2) * (m->P + m->L) * sizeof(double) + 4 * ((size_t)(2 * m->P + 2 * m->L + 1) + 8) * sizeof(double) : 0);      // (score maps + verification tables)
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
     if (gpath == 2 && chunk < B) chunk = std::max<int64_t>(256, chunk & ~(int64_t)255);      // whole 256-replicate tiles per pass
     int rc;
@@ -63,7 +68,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         if ((rc = ensure(m, m->ent, (size_t)chunk * ent_stride * sizeof(int2)))) return rc;
         if ((rc = ensure(m, m->nent, (size_t)chunk * sizeof(int)))) return rc;
     }
-    if ((rc = ensure(m, m->gram, (size_t)chunk * std::max<long>(psize, rows_solver ? cov_doubles(m->Pg) : 0) * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->gram, (size_t)chunk * std::max<long>(psize, (rows_solver || nm_wave) ? cov_doubles(m->Pg) : 0) * sizeof(double)))) return rc;
     if (!rows_out) {
         m->rows_B = 0;
         if ((rc = ensure(m, m->rows, (size_t)B * R * sizeof(double)))) return rc;
@@ -100,7 +105,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
         bool wrote16 = false;
         if (gpath == 2) {
             bool fallback = false;
-            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver, &fallback, &cd8, &cd8_MT,
+            if ((rc = run_gram_i8(m, nb, seed, rep_offset + b0, d_idx ? d_idx + b0 * N : nullptr, gram_buf, rows_solver || nm_wave, &fallback, &cd8, &cd8_MT,
                                   want16 ? (unsigned short*)m->gK16.p : nullptr, &wrote16))) return rc;
             f64_gram = fallback;
         }
@@ -143,7 +148,12 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             if (rc) return fail(m, rc, "second stage: " + m2->error);
             continue;
         }
+        if (m->nonmetric && nm_wave && cd8 && !f64_gram) {
+            if ((rc = run_nonmetric_wave(m, nb, so, cd8, cd8_MT))) return rc;
+            continue;
+        }
         if (m->nonmetric) {
+            m->last_nm_wave16 = 0;
             // threads per problem by model width (measured: 60 columns 0.60 / 0.64 / 0.81 ms with 64 / 128 / 256 threads; 300 indicator
             // columns 21.0 / 13.5 / 10.0 ms)
             const int nm_threads = m->tune.nm_threads > 0 ? m->tune.nm_threads : (m->P > 128 ? 256 : (m->P > 64 ? 128 : 64));

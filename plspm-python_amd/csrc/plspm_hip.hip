@@ -297,7 +297,7 @@ void plspm_model_destroy(plspm_model_t* m) {
                     m->d_mv_base2, m->d_lmv2_off, m->gSm.p, m->d_ind_of, m->gram2.p, m->pseudo.p, m->d_Xk, m->d_Mk, m->d_rowid, m->dcnt.p, m->ctable.p, m->Xt.p,
                     m->ent.p, m->nent.p, m->gram.p, m->gram_partial.p, m->rows.p, m->status.p, m->iters.p, m->gS.p, m->gsmall.p,
                     m->fitout.p, m->idx.p, m->err.p, m->ghist.p, m->nmstate.p, m->nmpartial.p, m->nmactive.p, m->nmlist.p, m->gK16.p, m->sum_buf.p, m->cols.p,
-                    m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->ind8.p, m->tab8.p, m->scl8.p, m->err2.p, m->pp_ctl.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
+                    m->nmw_maps.p, m->nmw_ints.p, m->nmw_vsum.p, m->zs.p, m->cd.p, m->cd1.p, m->codes.p, m->ind8.p, m->tab8.p, m->scl8.p, m->err2.p, m->pp_ctl.p, m->sk_partial.p, m->sk_flags.p, m->pair_tab.p, m->pair_scale.p, m->zs_stat.p};
     for (void* p : ptrs) if (p) plspm_dfree(p);
     for (void* p : m->blobs) if (p) plspm_dfree(p);
     if (m->h_stage) plspm_hfree(m->h_stage);
@@ -466,6 +466,9 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "solver_wave") { if (value < 0 || value > 3) return bad(); m->tune.solver_wave = value; }
     else if (k == "solver_quad") { if (value != 0 && value != 1) return bad(); m->tune.solver_quad = value; }
     else if (k == "nm_live") { if (value != 0 && value != 1) return bad(); m->tune.nm_live = value; }
+    else if (k == "nm_wave16") { if (value != 0 && value != 1) return bad(); m->tune.nm_wave16 = value; }            // 0: Scale.NUM / RAW batches on the per-iteration launches of rounds 1-5
+    else if (k == "nm_bound_shift") { if (value < 0 || value > 200) return bad(); m->tune.nm_bound_shift = value; }     // test seam: the solver's stop bound times 2^value (solver_wave16.h NmWaveIo)
+    else if (k == "nm_verify_rows") { if (value < 0 || value > 100) return bad(); m->tune.nm_verify_rows = value; }  // percent of the rows the lower-bound pass reads (0: an eighth)
     else if (k == "nm_counts8") { if (value != 0 && value != 1) return bad(); m->tune.nm_counts8 = value; }
     else if (k == "resample_aux") { if (value < 0 || value > 3) return bad(); if (value && !experiments) return exp_only(); m->tune.resample_aux = value; }
     else if (k == "i8_sched") { if (value != 0 && value != 1) return bad(); if (value && !experiments) return exp_only(); m->tune.i8_sched = value; }
@@ -525,6 +528,12 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "solver_wave") *value = m->tune.solver_wave;
     else if (k == "solver_quad") *value = m->tune.solver_quad;
     else if (k == "nm_live") *value = m->tune.nm_live;
+    else if (k == "nm_wave16") *value = m->tune.nm_wave16;
+    else if (k == "nm_verify_rows") *value = m->tune.nm_verify_rows;
+    else if (k == "nm_bound_shift") *value = m->tune.nm_bound_shift;
+    else if (k == "last_nm_wave16") *value = m->last_nm_wave16;
+    else if (k == "last_nm_flagged") *value = m->last_nm_flagged;
+    else if (k == "last_nm_replayed") *value = m->last_nm_replayed;
     else if (k == "nm_counts8") *value = m->tune.nm_counts8;
     else if (k == "last_solver") *value = m->last_solver;
     else if (k == "resample_aux") *value = m->tune.resample_aux;

@@ -270,7 +270,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 else
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
-                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb);
+                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb, (double*)nullptr, 0);
                 }
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
@@ -292,6 +292,105 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
 #ifdef PLSPM_DEBUG_MARKS
     if (d_nm_marks) plspm_dfree(d_nm_marks);
 #endif
+    HIPCHK(m, hipGetLastError());
+    return 0;
+}
+
+// Round 6: a bootstrap batch of a Scale.NUM / RAW model (no missing cells, at most 64 MVs and 16 LVs) on the int8 Gram route as ONE solver launch + a
+// verification pass (kernels_solver.h solver_nmwave_kernel; kernels_nonmetric.h nm_vlist_kernel ...).  The legacy loop (run_nonmetric) launches one step
+// kernel + one stop-rule pass over all rows per iteration, with a host round trip each: 0.435 ms of solver launches and 0.61 ms of passes per 5,000
+// replicates of the headline's shape (profiles/r05_nonmetric_kernels.txt).  Here: 1 launch that iterates on the bound, then -- for the steps it continued
+// behind -- an eighth of the rows (a lower bound of the criterion that only has to clear the tolerance), ONE host read-back, and the exact pass + replay for
+// whatever the lower bound could not confirm (nothing, as a rule).  Dense moment matrices at m->gram; cd8 / cd8_MT: the int8 counts the Gram consumed.
+bool nm_wave_route_planned(const plspm_model* m) {
+    bool whole = false;
+    int kb = 1;
+    return m->tune.nm_wave16 != 0 && nm_wave_solver_covers(m) && m->N <= 0x7fffffffL && nm_dense_lds(m, &whole, &kb) != 0;
+}
+
+int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void* cd8, int cd8_MT) {
+    const int P = m->P, L = m->L, W = P + L;
+    const long N = m->N, ntiles16 = (N + 15) / 16;
+    int rc;
+    bool dense_whole = false;
+    int kb = 1;
+    const size_t dense_use_lds = nm_dense_lds(m, &dense_whole, &kb);
+    if (!dense_use_lds || !cd8) return fail(m, PLSPM_E_STATE, "non-metric wave route: no dense stop-rule pass / no int8 counts");
+    constexpr int JR = 4;                                        // steps verified per round (three iterations -- two continued steps -- is the rule)
+    const long capV = nb * JR;
+    const long maps_stride = (long)(m->max_iter + 2) * W;
+    const int table_rows = 2 * P + 2 * L + 1;
+    const long ngroupsV = (capV + 63) / 64;
+    if ((rc = ensure(m, m->nmw_maps, (size_t)nb * maps_stride * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->nmw_ints, (size_t)(3 * nb + 4 * capV + 16) * sizeof(int)))) return rc;
+    if ((rc = ensure(m, m->nmw_vsum, (size_t)capV * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->Xt, (size_t)ntiles16 * 16 * m->PA * sizeof(double)))) return rc;
+    if ((rc = ensure(m, m->ctable, (size_t)ngroupsV * table_rows * 64 * sizeof(double)))) return rc;
+    auto conv_kernel = dense_whole ? nm_conv_dense_kernel<16, 8, false, true> : nm_conv_dense_kernel<16, 8, true, true>;
+    if ((rc = allow_lds(m, (const void*)conv_kernel, dense_use_lds))) return rc;
+    if (!m->Xt_valid) {
+        hipLaunchKernelGGL(tile_transpose_kernel, dim3((unsigned)ntiles16), dim3(256), 0, m->stream, (const double*)m->d_Xa, N, m->PA, (double*)m->Xt.p);
+        m->Xt_valid = true;
+    }
+    double* maps = (double*)m->nmw_maps.p;
+    int* ip = (int*)m->nmw_ints.p;
+    int* steps = ip; ip += nb;
+    int* force = ip; ip += nb;
+    int* fixlist = ip; ip += nb;
+    int* vb = ip; ip += capV;
+    int* vj = ip; ip += capV;
+    int* fb = ip; ip += capV;
+    int* fj = ip; ip += capV;
+    int* cnt = ip;                                               // [0] virtual problems of the round, [1] flagged, [2] replicates to replay
+    double* vsum = (double*)m->nmw_vsum.p;
+    int* h = (int*)m->h_flag;                                    // pinned: [0] most steps of a replicate, [1] flagged, [2] to replay
+    m->last_nm_wave16 = 1; m->last_nm_problems = 0; m->last_nm_codes = 0; m->last_nm_mfma = 0; m->last_nm_wave = 0; m->last_nm_direct16 = 0;
+    m->last_nm_flagged = 0; m->last_nm_replayed = 0;
+    if ((rc = launch_nm_wave_solver(m, nb, so, maps, maps_stride, steps, nullptr, nullptr))) return rc;
+    // the rows pass A looks at: the first eighth of the tiles (at least one row block of 128 rows)
+    const long nsub = std::min<long>(ntiles16, std::max<long>(8, m->tune.nm_verify_rows > 0 ? (ntiles16 * m->tune.nm_verify_rows + 99) / 100 : (ntiles16 + 7) / 8));
+    const int gyV = (int)std::max<long>(1, (2 * nb + 63) / 64);
+    auto pass = [&](long tiles, const int* list, const int* count, double* partial, int nparts, double* sums) {
+        const int gx = (int)((tiles + 7) / 8), rbx = (gx + 7) / 8;
+        hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gyV)), dim3(512), dense_use_lds, m->stream, (const double*)m->Xt.p, tiles, m->PA, P, L, (const int*)m->d_boff,
+                           (const unsigned short*)cd8, (long)cd8_MT, (const double*)m->ctable.p, list, count, partial, nparts, rbx, gyV, kb, sums, 1);
+    };
+    bool any_flagged = false;
+    for (int j0 = 1;; j0 += JR) {
+        {
+            ProfScope ps(m, PLSPM_K_SCORES);
+            hipLaunchKernelGGL(nm_vlist_kernel, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, nb, j0, JR, vb, vj, cnt, vsum, force, h);
+            hipLaunchKernelGGL(nm_vtable_kernel, dim3((unsigned)ngroupsV, (unsigned)((table_rows + 63) / 64)), dim3(256), 0, m->stream, (const double*)maps, maps_stride, P, L, (const int*)vb,
+                               (const int*)vj, (const int*)cnt, (double*)m->ctable.p);
+            pass(nsub, vb, cnt, nullptr, 0, vsum);
+            hipLaunchKernelGGL(nm_vflag_kernel, dim3(1), dim3(1024), 0, m->stream, (const double*)vsum, (const int*)vb, (const int*)vj, (const int*)cnt, m->tol, fb, fj, cnt + 1, h + 1);
+        }
+        HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+        HIPCHK(m, hipEventSynchronize(m->ev_flag));
+        const int most = h[0], flagged = h[1];
+        if (flagged > 0) {
+            // the exact criterion of what the lower bound left open: all rows, fixed-order sums; a value below the tolerance moves that replicate's stop
+            ProfScope ps(m, PLSPM_K_SCORES);
+            any_flagged = true;
+            m->last_nm_flagged += flagged;
+            if ((rc = ensure(m, m->nmpartial, (size_t)flagged * ntiles16 * sizeof(double)))) return rc;
+            hipLaunchKernelGGL(nm_vtable_kernel, dim3((unsigned)((flagged + 63) / 64), (unsigned)((table_rows + 63) / 64)), dim3(256), 0, m->stream, (const double*)maps, maps_stride, P, L,
+                               (const int*)fb, (const int*)fj, (const int*)(cnt + 1), (double*)m->ctable.p);
+            pass(ntiles16, fb, cnt + 1, (double*)m->nmpartial.p, (int)ntiles16, nullptr);
+            hipLaunchKernelGGL(nm_vcheck_kernel, dim3((unsigned)flagged), dim3(64), 0, m->stream, (const double*)m->nmpartial.p, (int)ntiles16, (const int*)fb, (const int*)fj,
+                               (const int*)(cnt + 1), m->tol, force);
+        }
+        if (j0 + JR > most - 1) break;                           // every step a replicate continued behind has been looked at
+    }
+    if (any_flagged) {
+        hipLaunchKernelGGL(nm_vfix_kernel, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (const int*)force, nb, fixlist, cnt + 2, h + 2);
+        HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+        HIPCHK(m, hipEventSynchronize(m->ev_flag));
+        if (h[2] > 0) {
+            m->last_nm_replayed = h[2];
+            if ((rc = launch_nm_wave_solver(m, h[2], so, nullptr, 0, nullptr, force, fixlist))) return rc;
+        }
+    }
     HIPCHK(m, hipGetLastError());
     return 0;
 }

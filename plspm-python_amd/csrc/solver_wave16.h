@@ -60,9 +60,27 @@ template <int LMAX> PLSPM_HD bool wave16_solver_covers(int P, int L, int n_chol,
     return P >= 1 && P <= 64 && L > LMAX / 2 && L <= LMAX && n_chol / 2 <= 16 * 66 && wave16_ws_doubles<LMAX>(L, kmax, n_chol) * (long)sizeof(double) <= (LMAX > 16 ? 53 : 40) * 1024;
 }
 
+// NM (round 6): the non-metric iteration on Scale.NUM / RAW data (reference _NonmetricWeights, plspm/weights.py:73-133; mode.py:31-42, 54-61; scale.py:22-39;
+// Config.treat config.py:306-318) on the same lane roles -- solver_core.h nm_prepare / nm_step / nm_finish restated.  Every MV is population-standardised, so
+// the column registers hold the CORRELATION matrix R; the scores y_l = Xs a_l are population-standardised after every step (treat_numpy(.) * correction,
+// mode.py:41,60), which in this loop's terms is the metric iteration with a_l = 1 / sqrt(Q_ll) in place of 1 / (corr2 sqrt(Q_ll)) -- except in the first step,
+// whose scores X a_0, a_0 = 1 / sqrt(k_l), are used as they are (weights.py:82-98).  Mode A's division by sum z^2 (mode.py:38) is a positive factor the
+// normalisation removes again.  The reference's stop rule is on the SCORES, sum_il c_i (|y_old| - |y_new|)^2 < tol (weights.py:120): not a function of second
+// moments.  Here a step STOPS on the upper bound n sum_l d_l' R_bb d_l (d = a_new - a_old; ||a| - |b|| <= |a - b|: the problem stops exactly where the
+// reference stops whenever the bound says so) and CONTINUES speculatively otherwise, leaving the score map of every step it continued behind in `io.maps`:
+// the host's verification pass (plspm_nonmetric.hip run_nonmetric_wave) evaluates the exact criterion of those steps on the observations and replays a
+// problem whose exact value was below the tolerance although its bound was not, with `io.force_T` = the step the reference stops at.
+struct NmWaveIo {
+    double* maps;      // [max_iter + 2][P + L]: step j's score map (c_p per uploaded column | k_l per LV), j = 0 .. steps - 1; null: nothing stored (replay)
+    int force_T;       // > 0: stop behind exactly this many steps, whatever the bound says
+    int* steps;        // steps taken (== the record's iteration count)
+    double bound_scale = 1.0;      // test seam (set_option "nm_bound_shift"): the bound times 2^k, k >= 0 -- still an upper bound, only a worse one: the problem runs on behind
+                                   // the reference's stop and the verification has to move it back
+};
+
 // Md: the DENSE moment matrix [(P+1) x cov_ld(P)] of the mean-shifted columns + ones, upper triangle.  Outputs: out.row / out.status / out.iters.
-template <int LMAX, bool MODEB = false, class Ex>
-PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<LMAX>& ws, const double* Md, const FitOutputs& out) {
+template <int LMAX, bool MODEB = false, bool NM = false, class Ex>
+PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<LMAX>& ws, const double* Md, const FitOutputs& out, const NmWaveIo* io = nullptr, double* nmk = nullptr) {
     constexpr int PMAX = 64, NE = LMAX * LMAX / 64;              // (LMAX = 8: one entry per lane -- an A/B form of the wave solver's own class, option solver_wave 2)
     const int P = md.P, L = md.L, PS = cov_ld(P), t = ex.tid, p = t;
     const bool valid = p < P;
@@ -117,12 +135,14 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     ex.template load_cov<PMAX>(Md, PS, P, s, ws.stage, mup, dpp);
     if (!valid) { mup = 0.0; dpp = 0.0; }
     ex.mark(1);
-    ws.mu[p] = mup;
-    ws.w[p] = 1.0;                                               // init: block products with w = 1
-    ex.sync();
     const double inv_n = ex.uniform_d(1.0 / n);
+    // NM: population std of the uploaded column (config.py:314) -- the expression of solver_core.h nm_prepare
+    const double sdraw = NM ? sqrt(dpp * inv_n - (mup * inv_n) * (mup * inv_n)) : 1.0;
+    ws.mu[p] = mup;
+    ws.w[p] = NM ? (valid ? sdraw : 1.0) : 1.0;                  // init: block products with w = 1  (NM: sigma_q published for the loop below; the initial weights follow it)
+    ex.sync();
     double fac = inv_n;
-    if (md.scaled) {
+    if (!NM && md.scaled) {
         // g = std1(all N*P raw values) * sqrt((N-1)/N)   (config.py:302), evaluated around the grand mean
         const double tot = ex.allsum(valid ? mup + n * shp : 0.0);
         const double np_ = n * (double)P, grand = tot / np_;
@@ -136,7 +156,9 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     for (int qb = 0; qb < PMAX; qb += 8) {
 #pragma unroll
         for (int q = qb; q < qb + 8; ++q) {
-            const double v = (s[q] - (mup * ex.bcast(mup, (q < P) ? q : P - 1, ws.mu)) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q); mu_q: a lane broadcast
+            double v;
+            if constexpr (NM) v = ((s[q] - (mup * ex.bcast(mup, (q < P) ? q : P - 1, ws.mu)) * inv_n) * inv_n) / (sdraw * ex.bcast(sdraw, (q < P) ? q : P - 1, ws.w));      // R_pq (nm_prepare)
+            else v = (s[q] - (mup * ex.bcast(mup, (q < P) ? q : P - 1, ws.mu)) * inv_n) * fac;      // (mu_p mu_q) first: bitwise symmetric in (p, q); mu_q: a lane broadcast
             s[q] = (q < P) ? v : 0.0;
         }
         ex.pin8(s[qb], s[qb + 1], s[qb + 2], s[qb + 3], s[qb + 4], s[qb + 5], s[qb + 6], s[qb + 7]);
@@ -145,7 +167,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
 #pragma unroll
         for (int q = 0; q < PMAX; ++q) s[q] = 0.0;
     }
-    const double sdp = sqrt((dpp - (mup * mup) * inv_n) * fac);
+    const double sdp = NM ? sqrt(((dpp - (mup * mup) * inv_n) * inv_n) / (sdraw * sdraw)) : sqrt((dpp - (mup * mup) * inv_n) * fac);      // (NM: sqrt(R_pp), 1 to rounding)
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: V takes the tile's place)
 
@@ -314,6 +336,15 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
 #pragma unroll
     for (int u = 0; u < NE; ++u) Qe[u] = 0.0;
     int iteration = 0, phase = 0;
+    double a_prev = 0.0, Ra_prev = 0.0;                          // NM: my entry of the previous step's normalised weights a and of R a (own block)
+    if constexpr (NM) {
+        // initial weights 1 / sqrt(k_l), scores X a_0 used as they are (weights.py:82-98): no normalising trip
+        ex.sync();                                               // (every lane is done with the sigma published in ws.w)
+        wp = valid ? 1.0 / sqrt((double)(md.boff[lp + 1] - md.boff[lp])) : 0.0;
+        ws.w[p] = valid ? wp : 1.0;
+        ex.sync();
+        phase = 1;
+    }
     while (true) {
         int pl = p, lpl = lp;                                    // opaque copies: LDS addresses recomputed per trip instead of hoisted and spilled
         ex.opaque(pl); ex.opaque(lpl);
@@ -401,7 +432,27 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         }
         ex.sync();
         ex.mark(19);
-        if (phase == 2) break;
+        bool nm_first = false;
+        if constexpr (NM) {
+            // the products above belong to the weights of step `iteration` (unnormalised; step 0: a_0): normalise, bound the criterion of that step, stop or go on
+            nm_first = iteration == 0;
+            const double wfl = nm_first ? 1.0 : wave_rsqrt(ws.Qm[lpl * LMAX + lpl]);
+            const double a_cur = valid ? wp * wfl : 0.0, Ra_cur = valid ? ws.V[pl * W16<LMAX>::VP + lpl] * wfl : 0.0;
+            bool stop = false;
+            if (!nm_first) {
+                const double d = a_cur - a_prev, Rd = Ra_cur - Ra_prev;
+                const double ub = n * ex.allsum(d * Rd);         // n sum_l d_l' R_bb d_l >= sum_il c_i (|y_old| - |y_new|)^2
+                stop = (io && io->force_T > 0) ? (iteration >= io->force_T) : (ub * (io ? io->bound_scale : 1.0) < md.tol * (1.0 - 1e-9));
+                if (iteration > md.max_iter) stop = true;        // (weights.py:183)
+            }
+            if (stop) break;
+            a_prev = a_cur; Ra_prev = Ra_cur;
+            // the map of this step's scores on the uploaded columns: y = sum_p x'_p c_p + k_l,  c_p = a_p / sigma_p,  k_l = -sum_p (mu_p / n) c_p
+            const double cmap = a_cur / sdraw;
+            if (io && io->maps && valid) io->maps[(long)iteration * (P + L) + pl] = cmap;
+            nmk[pl] = valid ? (mup * inv_n) * cmap : 0.0;        // (summed per block by the LV lanes behind the next barrier)
+        }
+        if (!NM && phase == 2) break;
         if (phase == 0) {
             wp = valid ? wave_rsqrt(ws.Qm[lpl * LMAX + lpl]) : 0.0;
             ws.w[pl] = valid ? wp : 1.0;
@@ -413,12 +464,12 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         ++iteration;
         ex.mark(9);
         // Yhat_l = Y_l / std1 / corr:  a_l = 1 / (corr2 sqrt(Q_ll)),  G = cov0(Yhat) = a a' o Q   (weights.py:43-44)
-        const double rm = wave_rsqrt(ws.Qm[eml * LMAX + eml]), am = rm * icorr2;
+        const double rm = wave_rsqrt(ws.Qm[eml * LMAX + eml]), am = NM ? (nm_first ? 1.0 : rm) : rm * icorr2;
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
             if ((64 / LMAX) * u < L) {
                 const int ell = er0l + (64 / LMAX) * u;
-                const double rl = wave_rsqrt(ws.Qm[ell * LMAX + ell]), al = rl * icorr2;
+                const double rl = wave_rsqrt(ws.Qm[ell * LMAX + ell]), al = NM ? (nm_first ? 1.0 : rl) : rl * icorr2;
                 const double Ge = al * am * Qe[u];
                 double Ee = 0.0;
                 if (pairu(u)) {
@@ -435,6 +486,13 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         }
         ex.sync();
         ex.mark(10);
+        if constexpr (NM) {
+            if (io && io->maps && lvlane) {                      // k_l of the map stored above (iteration counts the steps taken: this map is index iteration - 1)
+                double k0 = 0.0;
+                for (int q = md.boff[pl]; q < md.boff[pl + 1]; ++q) k0 += nmk[q];
+                io->maps[(long)(iteration - 1) * (P + L) + P + pl] = -k0;
+            }
+        }
         if (md.scheme == SCHEME_PATH) {
             if (lvlane && nk > 0) {                              // regression of Yhat_t on its predecessors, no intercept (scheme.py:48-50)
                 const double* x = regress(ws.Gm);
@@ -466,6 +524,12 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
                 wn = a0 + a1;
             }
         }
+        if constexpr (NM) {
+            wp = wn;                                             // (the stop rule of this step: behind the next products, above)
+            ws.w[pl] = valid ? wp : 1.0;
+            ex.sync();
+            ex.mark(12);
+        } else {
         const double dd = fabs(wp) - fabs(wn);
         const double conv = ex.allsum(dd * dd);
         wp = wn;
@@ -473,6 +537,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         ex.sync();
         ex.mark(12);
         if (conv < md.tol || iteration > md.max_iter) phase = 2;
+        }
     }
     const bool not_converged = iteration > md.max_iter;
     ex.mark(4);
@@ -488,7 +553,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * W16<LMAX>::VP + (l < L ? l : 0)];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
-            if (l < L) { const int neg = ex.vote_count(valid && vr[l] < 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }
+            if (!NM && l < L) { const int neg = ex.vote_count(valid && vr[l] < 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }      // (non-metric: no sign rule, weights.py:122-133)
     }
     const double sgl = ((negmask >> lp) & 1u) ? -1.0 : 1.0;
     const double vlp = ws.V[p * W16<LMAX>::VP + lp];                    // V[p, lv(p)] for the loading
@@ -565,6 +630,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         if (out.status) *out.status = st;
         if (out.iters) *out.iters = iteration;
         if (out.row) { out.row[2 * P + L + 2 * ne] = (double)st; out.row[2 * P + L + 2 * ne + 1] = (double)iteration; }
+        if constexpr (NM) { if (io && io->steps) *io->steps = iteration; }
     }
     ex.mark(13);
 }

@@ -442,6 +442,41 @@ int hostemu_solve_wave16_l8(int P, int L, int PA, int scheme, int scaled, int ma
     return 0;
 }
 
+// The non-metric (Scale.NUM / RAW) instantiation of the same source (solver_wave16.h NM; round 6): LMAX = 8 for at most 8 LVs, else 16.  maps: [(max_iter + 2) x (P + L)]
+// score maps of the steps the problem continued behind (or null), force_T > 0: stop behind exactly that many steps.  Returns 1 for a model it does not cover.
+int hostemu_solve_nmwave16(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
+                           const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
+                           double* row, int* iters, int* status, double* maps, int force_T, int* steps) {
+    EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
+    const bool small = L <= 8;
+    if (small ? !(P <= 64 && em.md.n_chol / 2 <= 16 * 66) : !wave16_solver_covers<16>(P, L, em.md.n_chol, em.md.kmax)) return 1;
+    const int nthreads = 64;
+    const long wsd = small ? wave16_ws_doubles<8>(L, em.md.kmax, em.md.n_chol) : wave16_ws_doubles<16>(L, em.md.kmax, em.md.n_chol);
+    std::vector<double> lds(wsd + 64, 0.0), red(nthreads);
+    FitOutputs out{};
+    out.row = row; out.iters = iters; out.status = status;
+    NmWaveIo io{maps, force_T, steps, 1.0};
+    std::barrier<> bar(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            HostExec ex{t, nthreads, &bar, red.data()};
+            if (small) {
+                Wave16Ws<8> ws{};
+                wave16_carve(ws, lds.data(), L, em.md.kmax);
+                if (em.md.n_chol > 0) solve_problem_wave16<8, true, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
+                else solve_problem_wave16<8, false, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
+            } else {
+                Wave16Ws<16> ws{};
+                wave16_carve(ws, lds.data(), L, em.md.kmax);
+                if (em.md.n_chol > 0) solve_problem_wave16<16, true, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
+                else solve_problem_wave16<16, false, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
+            }
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
 // ... and at LMAX = 32 (sixteen matrix entries per pair lane: all-Mode-A models of 17 ... 32 LVs); returns 1 for a model it does not cover.
 int hostemu_solve_wave16_l32(int P, int L, int PA, int scheme, int scaled, int max_iter, double tol, const int* boff, const unsigned char* C,
                              const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,

@@ -645,7 +645,13 @@ def test_nonmetric_dense_and_gathering_stop_rule_passes_agree():
     X, blocks = orc.synth(3000, orc.satisfaction_C(), 5, seed=17)
     model = orc.Model(blocks, orc.satisfaction_C(), "ABABAB", "factorial", True, tol=1e-7, scales=["NUM"] * 30)
     nm, _ = gpu_fit_nm(X, model)
+    wave = nm.bootstrap(130, seed=2)                        # round 6: one solver launch + verification (tests/test_gpu_nmwave.py); everything below: the per-iteration launches
+    assert nm.get_option("last_nm_wave16") == 1
+    nm.set_option("nm_wave16", 0)
     dense = nm.bootstrap(130, seed=2)
+    assert nm.get_option("last_nm_wave16") == 0
+    assert np.array_equal(wave[1], dense[1]) and np.array_equal(wave[2], dense[2])
+    assert_close(wave[0], dense[0], 1e-9, 1e-12)
     nm.set_option("conv_pass", 1)                           # the gathering pass
     gathered = nm.bootstrap(130, seed=2)
     nm.set_option("conv_pass", 2)                           # coefficient tile staged one LV block at a time (wide models)

@@ -21,6 +21,7 @@ X, blocks = orc.synth(NROWS, orc.satisfaction_C(), 10, seed=0)
 boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
 m = _native.NativeModel(boff, orc.satisfaction_C().astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, nonmetric=True)
 m.upload(X)
+if "NM_BENCH_WAVE16" in os.environ: m.set_option("nm_wave16", int(os.environ["NM_BENCH_WAVE16"]))      # 0 = the per-iteration launches of rounds 1-5 (A/B)
 if "NM_BENCH_GRAM_PATH" in os.environ: m.set_option("gram_path", int(os.environ["NM_BENCH_GRAM_PATH"]))      # 1 = fp64 route (beyond 65,535 rows: row lists + gathering pass)
 fit = m.fit(want_scores=False)
 # as bench.py does for the headline: spin-up steps bring the device to its working clocks; the timed steps run un-profiled (a fresh
@@ -41,7 +42,7 @@ dt_prof = (time.perf_counter() - t0) / steps
 m.profile(False)
 k = {n: m.profile_read(n) for n in ("resample", "gram", "solver", "scores")}
 rows, status, iters = m.bootstrap(64, seed=1)
-print(json.dumps({"workload": "non-metric (Scale.NUM) %d x 60 x 6, Mode A, PATH, tol 1e-6, %d replicates per step" % (NROWS, B), "gram_path": m.get_option("last_gram_path"),
+print(json.dumps({"workload": "non-metric (Scale.NUM) %d x 60 x 6, Mode A, PATH, tol 1e-6, %d replicates per step" % (NROWS, B), "gram_path": m.get_option("last_gram_path"), "one_launch_solver": m.get_option("last_nm_wave16"), "flagged": m.get_option("last_nm_flagged"), "replayed": m.get_option("last_nm_replayed"),
                   "replicates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "ms_per_step_profiled": round(dt_prof * 1e3, 3), "spinup_steps": spin, "fit_iterations": fit["iterations"],
                   "replicate_iterations": [int(iters.min()), int(iters.max())], "all_ok": bool(np.all(status == 0)),
                   "kernel_ms_per_step": {n: round(v[0] / steps, 3) for n, v in k.items()},
