@@ -736,7 +736,12 @@ def main():
                 sizes = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             except Exception as e:                                        # noqa: BLE001
                 sizes = {"error": repr(e)[:200]}
-            line["next_rows"] = {"categorical_bootstrap": cat, "metric_models_next_to_the_headline": sizes,
+            try:                                                           # the Scale.NUM counterpart of the headline workload: tools/nonmetric_bench.py
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nonmetric_bench.py")], capture_output=True, text=True, timeout=240).stdout
+                num = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+            except Exception as e:                                        # noqa: BLE001
+                num = {"error": repr(e)[:200]}
+            line["next_rows"] = {"nonmetric_num_bootstrap": num, "categorical_bootstrap": cat, "metric_models_next_to_the_headline": sizes,
                                  "note": "not part of `value`: ORD / NOM optimal scaling on 300 indicator columns (10k x 60 five-point items x 6 LVs), one wave per problem, "
                                          "count matrices written by the int8 product as uint16, stop rule as an int8 matrix product; DESIGN 5c"}
         if world == 1 and group is None and not args.no_single_fit:

@@ -373,7 +373,7 @@ template <int RW, int NW, bool BLOCKED, bool CNT8 = false>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
                                                                  const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table,
                                                                  const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial, int nparts, int rbx,
-                                                                 int gy, int kb, double* __restrict__ vsum = nullptr, int by_slot = 0) {
+                                                                 int gy, int kb, double* __restrict__ vsum = nullptr, int by_slot = 0, const int* __restrict__ vneed = nullptr) {
     // by_slot (round 6: the verification pass of the one-launch NUM / RAW solver, plspm_nonmetric.hip run_nonmetric_wave): the list holds VIRTUAL problems --
     // (replicate, step) pairs; list[slot] is the replicate whose counts weigh the rows, the result is filed under the slot.  vsum: the sums of the row parts
     // this launch covers are added up atomically per slot (a lower bound of the criterion that only has to clear the tolerance: the order of the additions
@@ -422,6 +422,11 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
     // speculative pass after the last iteration): no trip at all
     const int nlive = *count, ngroups = (nlive + 63) / 64;
     for (int g = gy0; g < ngroups; g += gy) {
+        if (vneed) {
+            // (verification, pass A: this group's slots ask for the first `need` row blocks only -- nm_vlist_kernel; uniform over the workgroup)
+            const int mine = ((long)g * 64 + lane < nlive) ? vneed[(long)g * 64 + lane] : 0;
+            if (rb >= wv::allreduce(mine, [](int a, int b) { return a > b ? a : b; })) continue;
+        }
         if (BLOCKED) {
             const bool live = (long)g * 64 + lane < nlive;
             const long b = live ? (long)list[(long)g * 64 + lane] : 0;
@@ -553,47 +558,84 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
 // replicate b's stop to step j (force[b] = min j; the solver replays those replicates).  Maps: maps[b][j] = [c_p (P) | k_l (L)] of step j's scores.
 //
 // vlist: the virtual problems of steps j0 .. j0 + JR - 1, step-major (consecutive slots = consecutive replicates: coalesced count loads), vb / vj, *count;
-// also max steps -> *host_max (pinned), vsum cleared, force[] = INT_MAX on the first round.  One workgroup.
-__global__ void __launch_bounds__(1024) nm_vlist_kernel(const int* __restrict__ steps, long nproblems, int j0, int JR, int* __restrict__ vb, int* __restrict__ vj,
+// also max steps -> *host_max (pinned), vsum cleared, force[] = INT_MAX on the first round.
+// One workgroup, two sweeps: wave w owns a contiguous range of replicates, counts its virtual problems per step, then -- behind one barrier -- files them.
+template <int JR>
+__global__ void __launch_bounds__(1024) nm_vlist_kernel(const int* __restrict__ steps, long nproblems, int j0, int* __restrict__ vb, int* __restrict__ vj,
                                                          int* __restrict__ count, double* __restrict__ vsum, int* __restrict__ force, int* __restrict__ host_max) {
-    __shared__ int wcount[16];
-    __shared__ int base, smax;
+    __shared__ int wtot[16][JR];
+    __shared__ int smax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { base = 0; smax = 0; }
+    if (tid == 0) smax = 0;
+    const long per = (((nproblems + 15) / 16) + 63) & ~63L;      // replicates per wave, whole trips of 64
+    const long w0 = (long)wave * per, w1 = lmin(nproblems, w0 + per);
+    int tot[JR], mx = 0;
+#pragma unroll
+    for (int jj = 0; jj < JR; ++jj) tot[jj] = 0;
+    for (long b0 = w0; b0 < w1; b0 += 64) {
+        const long b = b0 + lane;
+        const int st = b < w1 ? steps[b] : 0;
+        mx = max(mx, st);
+        if (j0 == 1 && b < w1) force[b] = 0x7fffffff;
+#pragma unroll
+        for (int jj = 0; jj < JR; ++jj) tot[jj] += __popcll(__ballot(st - 1 >= j0 + jj));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int jj = 0; jj < JR; ++jj) wtot[wave][jj] = tot[jj];
+    }
     __syncthreads();
-    int mx = 0;
-    for (int j = j0; j < j0 + JR; ++j) {
-        for (long b0 = 0; b0 < nproblems; b0 += 1024) {
-            const long b = b0 + tid;
-            const int st = b < nproblems ? steps[b] : 0;
-            mx = max(mx, st);
-            if (j == j0 && j0 == 1 && b < nproblems) force[b] = 0x7fffffff;
-            const bool on = st - 1 >= j;
+    atomicMax(&smax, mx);
+    int base[JR], total = 0;                                     // first slot of (step j0 + jj, this wave)
+#pragma unroll
+    for (int jj = 0; jj < JR; ++jj) {
+        int before = 0, all = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wtot[w][jj]; all += c; if (w < wave) before += c; }
+        base[jj] = total + before;
+        total += all;
+    }
+    for (long b0 = w0; b0 < w1; b0 += 64) {
+        const long b = b0 + lane;
+        const int st = b < w1 ? steps[b] : 0;
+#pragma unroll
+        for (int jj = 0; jj < JR; ++jj) {
+            const bool on = st - 1 >= j0 + jj;
             const unsigned long long bal = __ballot(on);
-            if (lane == 0) wcount[wave] = __popcll(bal);
-            __syncthreads();
-            int off = base;
-            for (int w = 0; w < wave; ++w) off += wcount[w];
-            if (on) { const int v = off + __popcll(bal & ((1ull << lane) - 1ull)); vb[v] = (int)b; vj[v] = j; vsum[v] = 0.0; }
-            __syncthreads();
-            if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
-            __syncthreads();
+            if (on) {
+                const int v = base[jj] + __popcll(bal & ((1ull << lane) - 1ull));
+                vb[v] = (int)b; vj[v] = j0 + jj; vsum[v] = 0.0;
+            }
+            base[jj] += __popcll(bal);
         }
     }
-    atomicMax(&smax, mx);
     __syncthreads();
-    if (tid == 0) { *count = base; if (host_max) *host_max = smax; }
+    if (tid == 0) { *count = total; if (host_max) *host_max = smax; }
 }
 
 // table[g][q][lane] of the virtual problems: q < P old coefficients (step j - 1), q < 2P new (step j), then k_old[L], k_new[L], live flag -- the layout
 // coef_table_kernel writes for the pass.
+// vneed[v] (may be null): the row blocks (128 rows) pass A reads for slot v -- the solver left the quadratic bound ub_j of every step beside its map, and the
+// criterion it bounds is nearly always a few sign flips below it, so a fraction ~ 8 tol / ub_j of the rows carries the lower bound over the tolerance: one
+// block for a first step (ub ~ 1e5), a handful for a second (ub ~ 1e-4 against 1e-6), at most `cap_blocks`; `fixed_blocks` > 0 (option nm_verify_rows): that
+// many for every slot.
 __global__ void __launch_bounds__(256) nm_vtable_kernel(const double* __restrict__ maps, long maps_stride, int P, int L, const int* __restrict__ vb, const int* __restrict__ vj,
-                                                         const int* __restrict__ count, double* __restrict__ table) {
+                                                         const int* __restrict__ count, double* __restrict__ table, int* __restrict__ vneed, double tol, int nblocks_all,
+                                                         int cap_blocks, int fixed_blocks) {
     __shared__ double tile[64][65];
     const int n = *count;
     const long g = blockIdx.x;
     if (g * 64 >= n) return;
-    const int rows = 2 * P + 2 * L + 1, q0 = (int)blockIdx.y * 64, W = P + L;
+    if (vneed && blockIdx.y == 0 && threadIdx.x < 64 && g * 64 + threadIdx.x < n) {
+        const long v = g * 64 + threadIdx.x;
+        int need = fixed_blocks > 0 ? fixed_blocks : cap_blocks;
+        if (fixed_blocks <= 0) {
+            const double ub = maps[(long)vb[v] * maps_stride + (long)vj[v] * (P + L + 1) + P + L];
+            const double want = 8.0 * tol / ub * (double)nblocks_all;       // (ub <= 0 or NaN: the cap)
+            if (want >= 0.0 && want < (double)cap_blocks) need = max(1, (int)want + 1);
+        }
+        vneed[v] = need;
+    }
+    const int rows = 2 * P + 2 * L + 1, q0 = (int)blockIdx.y * 64, W = P + L + 1;      // (a map: c_p | k_l | the bound of its step)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int r = w; r < 64; r += 4) {
         const long slot = g * 64 + r;
@@ -615,6 +657,80 @@ __global__ void __launch_bounds__(256) nm_vtable_kernel(const double* __restrict
     for (int qq = w; qq < 64; qq += 4) {
         const int q = q0 + qq;
         if (q < rows) out[(long)q * 64 + lane] = tile[lane][qq];
+    }
+}
+
+// Pass A: the lower bound of the criterion of every virtual problem from its first `need` row blocks.  The work is small (a few hundred workgroup-sized units
+// per 5,000 replicates) and nm_conv_dense_kernel -- built for throughput: its x columns come one scalar load per column through the scalar cache, whose latency
+// the many resident waves of a full pass hide -- runs it as a chain of ~60 dependent memory round trips per workgroup (85 us whatever the row count,
+// tools/experiments/nm_verify_prof.sh).  Here a wave copies its 16-row tile of Xt into LDS once (coalesced) and the column loop reads x as LDS broadcasts
+// beside the lane's two coefficients: the chain is the FMAs'.  Workgroup = (row block of 8 tiles, group of 64 slots); lane = slot; one atomic add per lane.
+__global__ void __launch_bounds__(512) nm_verify_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff, const uint4* __restrict__ cd,
+                                                         long MT, const double* __restrict__ table, const int* __restrict__ vb, const int* __restrict__ count,
+                                                         const int* __restrict__ vneed, double* __restrict__ vsum, int nrb, int gy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int rows = 2 * P + 2 * L + 1;
+    double* co = reinterpret_cast<double*>(smem_raw);           // [rows][64]
+    double* xs = co + (long)rows * 64;                           // [8 waves][P][16]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rb = blockIdx.x % nrb, gy0 = blockIdx.x / nrb;
+    const long tile = (long)rb * 8 + wave;
+    const bool have = tile < ntiles;
+    double* xw = xs + (long)wave * P * 16;
+    const int nlive = *count, ngroups = (nlive + 63) / 64;
+    bool tile_loaded = false;
+    for (int g = gy0; g < ngroups; g += gy) {
+        const long slot = (long)g * 64 + lane;
+        const int mine = slot < nlive ? vneed[slot] : 0;
+        if (rb >= wv::allreduce(mine, [](int a, int b) { return a > b ? a : b; })) continue;      // (uniform over the workgroup)
+        __syncthreads();
+        {
+            const double2* src = reinterpret_cast<const double2*>(table + (long)g * rows * 64);
+            double2* dst = reinterpret_cast<double2*>(co);
+            for (int e = threadIdx.x; e < rows * 32; e += 512) dst[e] = src[e];
+        }
+        if (have && !tile_loaded) {
+            const double2* src = reinterpret_cast<const double2*>(Xt + tile * 16 * PA);
+            double2* dst = reinterpret_cast<double2*>(xw);
+            for (int e = lane; e < P * 8; e += 64) dst[e] = src[e];
+            tile_loaded = true;
+        }
+        __syncthreads();
+        if (!have) continue;                                     // (the barriers of the next trip are reached by every wave: `continue` above is workgroup-uniform)
+        const bool live = slot < nlive;
+        const long b = live ? (long)vb[slot] : 0;
+        const uint4 cw = live ? cd[((tile >> 2) * MT + (b >> 4)) * 64 + (tile & 3) * 16 + (b & 15)] : make_uint4(0, 0, 0, 0);
+        const unsigned wq[4] = {cw.x, cw.y, cw.z, cw.w};
+        const double* cn = co + (long)P * 64;
+        const double* ko = co + 2L * P * 64;
+        const double* kn = ko + (long)L * 64;
+        double acc = 0.0;
+        int p = 0;
+        for (int l = 0; l < L; ++l) {
+            double ao[16], an[16];
+            const double k0 = ko[l * 64 + lane], k1 = kn[l * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ao[r] = k0; an[r] = k1; }
+            const int pend = boff[l + 1];
+            for (; p < pend; ++p) {
+                const double c0 = co[p * 64 + lane], c1 = cn[p * 64 + lane];
+                const double2* xr = reinterpret_cast<const double2*>(xw + p * 16);
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const double2 x = xr[h];
+                    ao[2 * h] = fma(x.x, c0, ao[2 * h]); an[2 * h] = fma(x.x, c1, an[2 * h]);
+                    ao[2 * h + 1] = fma(x.y, c0, ao[2 * h + 1]); an[2 * h + 1] = fma(x.y, c1, an[2 * h + 1]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double d = fabs(ao[r]) - fabs(an[r]);
+                const double w = (double)((wq[r >> 2] >> (8 * (r & 3))) & 0xffu);
+                acc = fma(w * d, d, acc);
+            }
+        }
+        if (live) unsafeAtomicAdd(&vsum[slot], acc);
     }
 }
 

@@ -270,7 +270,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 else
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
-                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb, (double*)nullptr, 0);
+                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb, (double*)nullptr, 0, (const int*)nullptr);
                 }
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
@@ -309,7 +309,7 @@ bool nm_wave_route_planned(const plspm_model* m) {
 }
 
 int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void* cd8, int cd8_MT) {
-    const int P = m->P, L = m->L, W = P + L;
+    const int P = m->P, L = m->L, W = P + L + 1;                 // a map: c_p | k_l | the bound of its step
     const long N = m->N, ntiles16 = (N + 15) / 16;
     int rc;
     bool dense_whole = false;
@@ -322,7 +322,7 @@ int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void*
     const int table_rows = 2 * P + 2 * L + 1;
     const long ngroupsV = (capV + 63) / 64;
     if ((rc = ensure(m, m->nmw_maps, (size_t)nb * maps_stride * sizeof(double)))) return rc;
-    if ((rc = ensure(m, m->nmw_ints, (size_t)(3 * nb + 4 * capV + 16) * sizeof(int)))) return rc;
+    if ((rc = ensure(m, m->nmw_ints, (size_t)(3 * nb + 5 * capV + 16) * sizeof(int)))) return rc;
     if ((rc = ensure(m, m->nmw_vsum, (size_t)capV * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->Xt, (size_t)ntiles16 * 16 * m->PA * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->ctable, (size_t)ngroupsV * table_rows * 64 * sizeof(double)))) return rc;
@@ -341,28 +341,36 @@ int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void*
     int* vj = ip; ip += capV;
     int* fb = ip; ip += capV;
     int* fj = ip; ip += capV;
+    int* vneed = ip; ip += capV;
     int* cnt = ip;                                               // [0] virtual problems of the round, [1] flagged, [2] replicates to replay
     double* vsum = (double*)m->nmw_vsum.p;
     int* h = (int*)m->h_flag;                                    // pinned: [0] most steps of a replicate, [1] flagged, [2] to replay
     m->last_nm_wave16 = 1; m->last_nm_problems = 0; m->last_nm_codes = 0; m->last_nm_mfma = 0; m->last_nm_wave = 0; m->last_nm_direct16 = 0;
     m->last_nm_flagged = 0; m->last_nm_replayed = 0;
     if ((rc = launch_nm_wave_solver(m, nb, so, maps, maps_stride, steps, nullptr, nullptr))) return rc;
-    // the rows pass A looks at: the first eighth of the tiles (at least one row block of 128 rows)
-    const long nsub = std::min<long>(ntiles16, std::max<long>(8, m->tune.nm_verify_rows > 0 ? (ntiles16 * m->tune.nm_verify_rows + 99) / 100 : (ntiles16 + 7) / 8));
+    // the rows pass A looks at: per slot by the bound of its step (nm_vlist_kernel), at most the first eighth of the row blocks of 128 rows -- or, option
+    // nm_verify_rows, that percentage for every slot
+    const int nblocks_all = (int)((ntiles16 + 7) / 8);
+    const int fixed_blocks = m->tune.nm_verify_rows > 0 ? (int)std::min<long>(nblocks_all, std::max<long>(1, ((long)nblocks_all * m->tune.nm_verify_rows + 99) / 100)) : 0;
+    const int cap_blocks = fixed_blocks > 0 ? fixed_blocks : std::max(1, (nblocks_all + 7) / 8);
+    const long nsub = std::min<long>(ntiles16, 8L * cap_blocks);
     const int gyV = (int)std::max<long>(1, (2 * nb + 63) / 64);
-    auto pass = [&](long tiles, const int* list, const int* count, double* partial, int nparts, double* sums) {
+    const size_t verify_lds = ((size_t)table_rows * 64 + (size_t)8 * P * 16) * sizeof(double);
+    if ((rc = allow_lds(m, (const void*)nm_verify_kernel, verify_lds))) return rc;
+    auto pass = [&](long tiles, const int* list, const int* count, double* partial, int nparts, double* sums, const int* need) {
         const int gx = (int)((tiles + 7) / 8), rbx = (gx + 7) / 8;
         hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gyV)), dim3(512), dense_use_lds, m->stream, (const double*)m->Xt.p, tiles, m->PA, P, L, (const int*)m->d_boff,
-                           (const unsigned short*)cd8, (long)cd8_MT, (const double*)m->ctable.p, list, count, partial, nparts, rbx, gyV, kb, sums, 1);
+                           (const unsigned short*)cd8, (long)cd8_MT, (const double*)m->ctable.p, list, count, partial, nparts, rbx, gyV, kb, sums, 1, need);
     };
     bool any_flagged = false;
     for (int j0 = 1;; j0 += JR) {
         {
             ProfScope ps(m, PLSPM_K_SCORES);
-            hipLaunchKernelGGL(nm_vlist_kernel, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, nb, j0, JR, vb, vj, cnt, vsum, force, h);
+            hipLaunchKernelGGL(nm_vlist_kernel<JR>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, nb, j0, vb, vj, cnt, vsum, force, h);
             hipLaunchKernelGGL(nm_vtable_kernel, dim3((unsigned)ngroupsV, (unsigned)((table_rows + 63) / 64)), dim3(256), 0, m->stream, (const double*)maps, maps_stride, P, L, (const int*)vb,
-                               (const int*)vj, (const int*)cnt, (double*)m->ctable.p);
-            pass(nsub, vb, cnt, nullptr, 0, vsum);
+                               (const int*)vj, (const int*)cnt, (double*)m->ctable.p, vneed, m->tol, nblocks_all, cap_blocks, fixed_blocks);
+            hipLaunchKernelGGL(nm_verify_kernel, dim3((unsigned)(cap_blocks * gyV)), dim3(512), verify_lds, m->stream, (const double*)m->Xt.p, nsub, m->PA, P, L, (const int*)m->d_boff,
+                               (const uint4*)cd8, (long)cd8_MT, (const double*)m->ctable.p, (const int*)vb, (const int*)cnt, (const int*)vneed, vsum, cap_blocks, gyV);
             hipLaunchKernelGGL(nm_vflag_kernel, dim3(1), dim3(1024), 0, m->stream, (const double*)vsum, (const int*)vb, (const int*)vj, (const int*)cnt, m->tol, fb, fj, cnt + 1, h + 1);
         }
         HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
@@ -375,8 +383,8 @@ int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void*
             m->last_nm_flagged += flagged;
             if ((rc = ensure(m, m->nmpartial, (size_t)flagged * ntiles16 * sizeof(double)))) return rc;
             hipLaunchKernelGGL(nm_vtable_kernel, dim3((unsigned)((flagged + 63) / 64), (unsigned)((table_rows + 63) / 64)), dim3(256), 0, m->stream, (const double*)maps, maps_stride, P, L,
-                               (const int*)fb, (const int*)fj, (const int*)(cnt + 1), (double*)m->ctable.p);
-            pass(ntiles16, fb, cnt + 1, (double*)m->nmpartial.p, (int)ntiles16, nullptr);
+                               (const int*)fb, (const int*)fj, (const int*)(cnt + 1), (double*)m->ctable.p, (int*)nullptr, m->tol, 0, 0, 0);
+            pass(ntiles16, fb, cnt + 1, (double*)m->nmpartial.p, (int)ntiles16, nullptr, nullptr);
             hipLaunchKernelGGL(nm_vcheck_kernel, dim3((unsigned)flagged), dim3(64), 0, m->stream, (const double*)m->nmpartial.p, (int)ntiles16, (const int*)fb, (const int*)fj,
                                (const int*)(cnt + 1), m->tol, force);
         }

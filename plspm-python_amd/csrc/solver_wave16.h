@@ -71,7 +71,7 @@ template <int LMAX> PLSPM_HD bool wave16_solver_covers(int P, int L, int n_chol,
 // the host's verification pass (plspm_nonmetric.hip run_nonmetric_wave) evaluates the exact criterion of those steps on the observations and replays a
 // problem whose exact value was below the tolerance although its bound was not, with `io.force_T` = the step the reference stops at.
 struct NmWaveIo {
-    double* maps;      // [max_iter + 2][P + L]: step j's score map (c_p per uploaded column | k_l per LV), j = 0 .. steps - 1; null: nothing stored (replay)
+    double* maps;      // [max_iter + 2][P + L + 1]: step j's score map (c_p per uploaded column | k_l per LV | the bound of step j), j = 0 .. steps - 1; null: nothing stored (replay)
     int force_T;       // > 0: stop behind exactly this many steps, whatever the bound says
     int* steps;        // steps taken (== the record's iteration count)
     double bound_scale = 1.0;      // test seam (set_option "nm_bound_shift"): the bound times 2^k, k >= 0 -- still an upper bound, only a worse one: the problem runs on behind
@@ -439,9 +439,10 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
             const double wfl = nm_first ? 1.0 : wave_rsqrt(ws.Qm[lpl * LMAX + lpl]);
             const double a_cur = valid ? wp * wfl : 0.0, Ra_cur = valid ? ws.V[pl * W16<LMAX>::VP + lpl] * wfl : 0.0;
             bool stop = false;
+            double ub = 0.0;
             if (!nm_first) {
                 const double d = a_cur - a_prev, Rd = Ra_cur - Ra_prev;
-                const double ub = n * ex.allsum(d * Rd);         // n sum_l d_l' R_bb d_l >= sum_il c_i (|y_old| - |y_new|)^2
+                ub = n * ex.allsum(d * Rd);                      // n sum_l d_l' R_bb d_l >= sum_il c_i (|y_old| - |y_new|)^2
                 stop = (io && io->force_T > 0) ? (iteration >= io->force_T) : (ub * (io ? io->bound_scale : 1.0) < md.tol * (1.0 - 1e-9));
                 if (iteration > md.max_iter) stop = true;        // (weights.py:183)
             }
@@ -449,7 +450,8 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
             a_prev = a_cur; Ra_prev = Ra_cur;
             // the map of this step's scores on the uploaded columns: y = sum_p x'_p c_p + k_l,  c_p = a_p / sigma_p,  k_l = -sum_p (mu_p / n) c_p
             const double cmap = a_cur / sdraw;
-            if (io && io->maps && valid) io->maps[(long)iteration * (P + L) + pl] = cmap;
+            if (io && io->maps && valid) io->maps[(long)iteration * (P + L + 1) + pl] = cmap;
+            if (io && io->maps && pl == 0) io->maps[(long)iteration * (P + L + 1) + P + L] = ub;      // (how many rows the verification reads for this step)
             nmk[pl] = valid ? (mup * inv_n) * cmap : 0.0;        // (summed per block by the LV lanes behind the next barrier)
         }
         if (!NM && phase == 2) break;
@@ -490,7 +492,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
             if (io && io->maps && lvlane) {                      // k_l of the map stored above (iteration counts the steps taken: this map is index iteration - 1)
                 double k0 = 0.0;
                 for (int q = md.boff[pl]; q < md.boff[pl + 1]; ++q) k0 += nmk[q];
-                io->maps[(long)(iteration - 1) * (P + L) + P + pl] = -k0;
+                io->maps[(long)(iteration - 1) * (P + L + 1) + P + pl] = -k0;
             }
         }
         if (md.scheme == SCHEME_PATH) {

@@ -51,7 +51,7 @@ def run_nmwave(lib, X, model, counts=None, shift=None, force_T=0):
     row = np.full(2 * P + L + 2 * ne + 2, np.nan)
     iters, status, steps = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int(-1)
     Md = np.ascontiguousarray(dense_from_packed(Mp, PA, P))
-    maps = np.full((model.max_iter + 2, P + L), np.nan)
+    maps = np.full((model.max_iter + 2, P + L + 1), np.nan)       # per step: c_p | k_l | the quadratic bound of the step
     rc = lib.hostemu_solve_nmwave16(P, L, PA, SCHEME_ID[model.scheme], 1, model.max_iter, ctypes.c_double(model.tol), _ptr(boff, ctypes.c_int), _ptr(C, ctypes.c_ubyte),
                                     _ptr(mode, ctypes.c_int), _ptr(shift), ne, _ptr(ef, ctypes.c_int), _ptr(et, ctypes.c_int), _ptr(Md), _ptr(row), ctypes.byref(iters),
                                     ctypes.byref(status), _ptr(maps), int(force_T), ctypes.byref(steps))
@@ -66,8 +66,10 @@ def run_nmwave(lib, X, model, counts=None, shift=None, force_T=0):
     onehot = (lv_of[:, None] == np.arange(L)[None, :]).astype(float)
     T = iters.value
     assert not np.isnan(maps[:T]).any() and np.isnan(maps[T:]).all()          # maps of steps 0 .. T - 1, nothing else
-    ys = [(Xs * maps[j, :P]) @ onehot + maps[j, P:] for j in range(T)]
+    ys = [(Xs * maps[j, :P]) @ onehot + maps[j, P:P + L] for j in range(T)]
     conv = [float((((np.abs(ys[j - 1]) - np.abs(ys[j])) ** 2).sum(axis=1) * cw).sum()) for j in range(1, T)]
+    for j in range(1, T):                                                        # the value stored beside map j bounds the criterion of step j from above
+        assert conv[j - 1] <= maps[j, P + L] * (1 + 1e-9), (j, conv[j - 1], maps[j, P + L])
     return dict(weights=row[:P][inv], r2=row[P:P + L], total=row[P + L:P + L + ne], direct=row[P + L + ne:P + L + 2 * ne],
                 loadings=row[P + L + 2 * ne:2 * P + L + 2 * ne][inv], iterations=T, status=status.value, row=row, conv=conv, scores=ys)
 

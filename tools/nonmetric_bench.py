@@ -22,6 +22,8 @@ boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int3
 m = _native.NativeModel(boff, orc.satisfaction_C().astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, nonmetric=True)
 m.upload(X)
 if "NM_BENCH_WAVE16" in os.environ: m.set_option("nm_wave16", int(os.environ["NM_BENCH_WAVE16"]))      # 0 = the per-iteration launches of rounds 1-5 (A/B)
+for kv in filter(None, os.environ.get("NM_BENCH_OPTS", "").split(",")):      # any set_option key=value, e.g. NM_BENCH_OPTS=nm_verify_rows=1
+    m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if "NM_BENCH_GRAM_PATH" in os.environ: m.set_option("gram_path", int(os.environ["NM_BENCH_GRAM_PATH"]))      # 1 = fp64 route (beyond 65,535 rows: row lists + gathering pass)
 fit = m.fit(want_scores=False)
 # as bench.py does for the headline: spin-up steps bring the device to its working clocks; the timed steps run un-profiled (a fresh
