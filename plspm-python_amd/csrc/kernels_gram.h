@@ -1,6 +1,7 @@
 // kernels_gram.h -- Device kernels, part 2: the fp64 MFMA weighted Gram kernels (rows / wide / block variants) and the fixed-order reduce.
 // Device code shared by the translation units of libplspm_hip.so (host_internal.h lists them); not a stand-alone header.
 #pragma once
+#include <utility>
 
 // ------------------------------------------------------------------------------------------------ Gram (fp64 MFMA)
 // v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; for the
@@ -155,6 +156,73 @@ __device__ __forceinline__ void gram_walk(AccArr<T, NW, W>& acc, const double* _
     for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
 }
 
+// The dense walk on a ring of row buffers (round 6; single fits of wide models -- configs[4]: T = 13, four waves of 23 tiles, one wave per SIMD).  Counters of
+// the two-stage ping-pong above on that launch (profiles/r05_pmc_rows.json): 3.9 % of the wave cycles wait for memory, 81 % wait to ISSUE, the matrix pipe is 82 %
+// busy at 2.15 GHz -- what the pipe loses is not latency but the instructions between the MFMA blocks: 26 register copies per stage (x[] = the row buffer, so that
+// the next stage's loads may overwrite the buffer while the MFMAs read the copies) + the loads' address arithmetic, on a SIMD with nobody else to issue.
+// With D >= 4 buffers nothing needs a copy: stage s's MFMAs read buffer s % D in place, the loads issued in stage s go to the buffer of stage s + D - 2, last read
+// by the MFMAs of stage s - 2 -- two whole stages (~3,000 clocks) before the data can land; s_waitcnt vmcnt((D - 3) x loads-per-stage) leaves the younger
+// stages in flight.  Stages past the end read the all-zero pad row (plspm_upload keeps it behind the matrix).
+template <class F, int... Bs>
+__device__ __forceinline__ void ring_stages(F&& f, std::integer_sequence<int, Bs...>) { (f(std::integral_constant<int, Bs>{}), ...); }
+template <int T, int NW, int W, int D>
+__device__ __forceinline__ void gram_walk_dense_ring(AccArr<T, NW, W>& acc, const double* __restrict__ Xa, long N, int ng, int g0, int gs, int lane) {
+    constexpr int G = T / 2, PA = 16 * T;
+    constexpr bool ODD = (T & 1) != 0;
+    constexpr int LPS = G + (ODD ? 1 : 0);                      // loads per stage and lane
+    constexpr int PD = D - 2;                                   // prefetch distance in stages
+    static_assert(D >= 4 && (PD - 1) * LPS <= 63, "ring depth: a buffer rests two stages before it is reloaded; the wait counter has six bits");
+    const int k = lane >> 4, i = lane & 15;
+    const double* xbase = Xa + 2 * i;
+    const double* tbase = Xa + 32 * G + i;
+    const int niter = (g0 < ng) ? (ng - g0 + gs - 1) / gs : 0;
+    auto drow = [&](int it) { const long r = 4 * ((long)g0 + (long)it * gs) + k; return (it < niter && r < N) ? r : N; };
+#pragma unroll
+    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) { acc[t] = (d4){0.0, 0.0, 0.0, 0.0}; asm volatile("" : "+a"(acc[t])); }
+    dv2 V[D][G];
+    double Tt[D];
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+        Tt[b] = 0.0;
+#pragma unroll
+        for (int q = 0; q < G; ++q) V[b][q] = (dv2){0.0, 0.0};
+    }
+#pragma unroll
+    for (int b = 0; b < PD; ++b) {                              // prologue: stages 0 .. PD - 1 in flight
+        RowLoader<0, G>::issue(V[b], xbase + drow(b) * PA);
+        if (ODD) issue_tail(Tt[b], tbase + drow(b) * PA);
+    }
+    for (int it = 0; it < niter; it += D) {
+        ring_stages([&](auto bc) {                              // stage it + b on buffer b
+            constexpr int b = decltype(bc)::value;
+            constexpr int bn = (b + PD) % D;                    // the buffer of stage it + b + PD == that of stage it + b - 2
+#pragma unroll
+            for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPS) : "memory");
+            RowLoader<0, G>::pin(V[b]);
+            if (ODD) asm volatile("" : "+v"(Tt[b]));
+            const long rnext = drow(it + b + PD);
+            RowLoader<0, G>::issue(V[bn], xbase + rnext * PA);
+            if (ODD) issue_tail(Tt[bn], tbase + rnext * PA);
+            auto xv = [&](int t) -> double { return (ODD && t == T - 1) ? Tt[b] : ((t & 1) ? V[b][t >> 1].y : V[b][t >> 1].x); };
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int u = t; u < T; ++u) {
+                    const int li = TileIdx<T>::of(t, u);
+                    const int sl = Own<T, NW, W>::slot(li);
+                    if (Own<T, NW, W>::mine(li)) acc[sl] = MFMA_F64(xv(t), xv(u), acc[sl]);
+                }
+            }
+        }, std::make_integer_sequence<int, D>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < D; ++b) { RowLoader<0, G>::pin(V[b]); if (ODD) asm volatile("" : "+v"(Tt[b])); }
+#pragma unroll
+    for (int t = 0; t < Own<T, NW, W>::COUNT; ++t) asm volatile("" : "+a"(acc[t]));
+}
+
 // Rows-split variant (T <= 4): every wave of the 256-thread workgroup keeps ALL upper tiles and takes every 4th
 // k-group of the (row,count) list; a two-level LDS tree adds the four partial accumulators at the end.
 template <int T, bool DENSE>
@@ -219,11 +287,12 @@ __global__ void __launch_bounds__(256) gram_rows_kernel(const double* __restrict
 
 // Tile-split variant (6 <= T <= 16): the NW waves of a workgroup walk the SAME k-groups; wave W owns the upper tiles
 // whose linear index == W (mod NW), so no reduction is needed and the accumulators stay within the register file.
-template <int T, int NW, int W, bool DENSE>
+template <int T, int NW, int W, bool DENSE, int RING = 0>
 __device__ __forceinline__ void gram_wide_body(const double* __restrict__ Xa, long N, const int2* __restrict__ e, int ng, int chunk, int nchunks,
                                                 double* __restrict__ dst, int lane) {
     d4 acc[Own<T, NW, W>::COUNT];
-    gram_walk<T, NW, W, DENSE>(acc, Xa, N, e, ng, chunk, nchunks, lane);
+    if constexpr (DENSE && RING >= 4) gram_walk_dense_ring<T, NW, W, RING>(acc, Xa, N, ng, chunk, nchunks, lane);
+    else gram_walk<T, NW, W, DENSE>(acc, Xa, N, e, ng, chunk, nchunks, lane);
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -235,20 +304,20 @@ __device__ __forceinline__ void gram_wide_body(const double* __restrict__ Xa, lo
             }
         }
 }
-template <int T, int NW, int W, bool DENSE>
+template <int T, int NW, int W, bool DENSE, int RING = 0>
 struct WideDispatch {
     __device__ static __forceinline__ void run(int wave, const double* Xa, long N, const int2* e, int ng, int chunk, int nchunks, double* dst, int lane) {
-        if (wave == W) gram_wide_body<T, NW, W, DENSE>(Xa, N, e, ng, chunk, nchunks, dst, lane);
-        else WideDispatch<T, NW, W + 1, DENSE>::run(wave, Xa, N, e, ng, chunk, nchunks, dst, lane);
+        if (wave == W) gram_wide_body<T, NW, W, DENSE, RING>(Xa, N, e, ng, chunk, nchunks, dst, lane);
+        else WideDispatch<T, NW, W + 1, DENSE, RING>::run(wave, Xa, N, e, ng, chunk, nchunks, dst, lane);
     }
 };
-template <int T, int NW, bool DENSE>
-struct WideDispatch<T, NW, NW, DENSE> {
+template <int T, int NW, bool DENSE, int RING>
+struct WideDispatch<T, NW, NW, DENSE, RING> {
     __device__ static __forceinline__ void run(int, const double*, long, const int2*, int, int, int, double*, int) {}
 };
 // NWV "virtual" waves share the tiles; a workgroup carries NWP of them and blockIdx.z selects which slice
 // (NWV == NWP: one workgroup per k-group walk; NWV == 2*NWP: two workgroups walk the same rows, disjoint tiles).
-template <int T, int NWV, int NWP, bool DENSE>
+template <int T, int NWV, int NWP, bool DENSE, int RING = 0>
 __global__ void __launch_bounds__(NWP * 64) gram_wide_kernel(const double* __restrict__ Xa, long N, const int2* __restrict__ ent,
                                                               const int* __restrict__ nent, long ent_stride, double* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -257,7 +326,7 @@ __global__ void __launch_bounds__(NWP * 64) gram_wide_kernel(const double* __res
     const int2* e = DENSE ? nullptr : ent + problem * ent_stride;
     const int ng = DENSE ? (int)((N + 3) >> 2) : ((nent[problem] + 3) >> 2);
     double* dst = out + (problem * gridDim.x + blockIdx.x) * (long)(TileIdx<T>::NTILE * 256);
-    WideDispatch<T, NWV, 0, DENSE>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
+    WideDispatch<T, NWV, 0, DENSE, RING>::run(wave, Xa, N, e, ng, (int)blockIdx.x, (int)gridDim.x, dst, lane);
 }
 
 

@@ -32,7 +32,12 @@ static int launch_gram(plspm_model* m, long nproblems, int nchunks, const int2* 
         case 7: WIDE(7, 4, 4) break;
         case 9: WIDE(9, 4, 4) break;
         case 11: WIDE(11, 4, 4) break;
-        case 13: WIDE(13, 4, 4) break;
+        case 13:
+            // (configs[4]: the dense walk on a ring of row buffers -- kernels_gram.h gram_walk_dense_ring; option wide_ring 0: the two-stage ping-pong)
+            if (DENSE && m->tune.wide_ring == 4) { hipLaunchKernelGGL((gram_wide_kernel<13, 4, 4, DENSE, DENSE ? 4 : 0>), dim3(nchunks, (unsigned)nproblems, 1), dim3(256), 0, s, m->d_Xa, N, ent, nent, ent_stride, out); }
+            else if (DENSE && m->tune.wide_ring >= 5) { hipLaunchKernelGGL((gram_wide_kernel<13, 4, 4, DENSE, DENSE ? 6 : 0>), dim3(nchunks, (unsigned)nproblems, 1), dim3(256), 0, s, m->d_Xa, N, ent, nent, ent_stride, out); }
+            else WIDE(13, 4, 4)
+            break;
         case 15: WIDE(15, 4, 4) break;
         case 8: WIDE(8, 4, 4) break;
         case 10: WIDE(10, 4, 4) break;

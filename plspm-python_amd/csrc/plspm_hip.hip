@@ -441,6 +441,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     if (k == "solver_threads") { if (value != 64 && value != 128 && value != 256) return bad(); m->tune.solver_threads = value; }
     else if (k == "nm_threads") { if (value != 0 && value != 64 && value != 128 && value != 256) return bad(); m->tune.nm_threads = value; }
     else if (k == "fit_chunks") { if (value < 0 || value > 65535) return bad(); m->tune.fit_chunks = value; }
+    else if (k == "wide_ring") { if (value != 0 && value != 4 && value != 6) return bad(); m->tune.wide_ring = value; }      // row buffers of the dense wide Gram's ring (0: two-stage ping-pong)
     else if (k == "wide_nw") { if (value != 4 && value != 8 && value != 16) return bad(); m->tune.wide_nw = value; }
     else if (k == "conv_pass") { if (value < 0 || value > 2) return bad(); m->tune.conv_pass = value; }
     else if (k == "scores_tile") { if (value != 0 && value != 16 && value != 32) return bad(); m->tune.scores_tile = value; }
@@ -494,6 +495,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "nm_threads") *value = m->tune.nm_threads;
     else if (k == "fit_chunks") *value = m->tune.fit_chunks;
     else if (k == "wide_nw") *value = m->tune.wide_nw;
+    else if (k == "wide_ring") *value = m->tune.wide_ring;
     else if (k == "conv_pass") *value = m->tune.conv_pass;
     else if (k == "scores_tile") *value = m->tune.scores_tile;
     else if (k == "gram_lds_kb") *value = m->tune.gram_lds_kb;

@@ -23,6 +23,8 @@ def run(tag, n, C, per, modes, scheme, reps=5):
     P = X.shape[1]
     boff = np.concatenate(([0], np.cumsum([len(b) for b in blocks]))).astype(np.int32)
     m = _native.NativeModel(boff, C.astype(np.uint8), np.array(modes, dtype=np.int32), scheme, True, 100, 1e-6, 0)
+    for kv in filter(None, os.environ.get("FIT_BENCH_OPTS", "").split(",")):      # any set_option key=value (A/B runs), e.g. FIT_BENCH_OPTS=wide_ring=0
+        m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     t0 = time.time(); m.upload(X); t_up = time.time() - t0            # first upload of the process: allocations + code-object load
     ups = []
     for _ in range(3 if n > 100000 else 10):
