@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--no-single-fit", action="store_true", help="skip the single-fit rows (configs[1] and configs[4]: a child run of tools/fit_bench.py)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
+    ap.add_argument("--gather", choices=["all", "root"], default="all", help="all (default): ONE ncclAllGather per step -- every rank receives every shard; root: the gather to rank 0 "
+                                                                               "(group option gather_root: ncclSend / ncclRecv, 1 / N of the bytes; only rank 0 checks the merged records)")
     ap.add_argument("--no-transport-calibration", action="store_true", help="keep RCCL as created (skip the untimed comparison with channel-capped RCCL / the copy-engine exchange)")
     ap.add_argument("--gram-path", type=int, default=0, choices=[0, 1, 2], help="0 library default (int8 digit planes), 1 fp64 MFMA Gram, 2 int8 digit planes")
     args = ap.parse_args()
@@ -296,6 +298,8 @@ def main():
 
     def make_group(on_comm):
         g = _native.NativeGroup(on_comm, models)
+        if args.gather == "root":
+            g.set_option("gather_root", 1)
         g.set_option("chunks", 1)      # the step loop issues calls back to back: the gather of call k overlaps the kernels of call k + 1 as it is (sub-batches are for ONE call: single_call below)
         return g
     group = make_group(comm) if comm is not None else None
@@ -461,14 +465,16 @@ def main():
 
     # what was timed is correct: every replicate of the last step converged, the gathered records are complete and in order
     last_offset = (state["k"] - 1) * B_total
-    if group is not None:
+    holds_records = not (group is not None and args.gather == "root" and rank != 0)      # (--gather root: the merged records exist on rank 0 only)
+    if group is not None and holds_records:
         rows_l, status_l, iters_l = group.rows()
-    else:
+    elif group is None:
         rows_l, status_l, iters_l = model.fetch(0, B_total)
-    assert rows_l.shape == (B_total, width) and np.all(status_l == 0), "a replicate of the timed batch failed"
     probe = B_total - 3                                        # a row owned by the last rank
     one, _, _ = model.bootstrap(1, seed=1, rep_offset=last_offset + probe)
-    assert np.array_equal(rows_l[probe], one[0]), "sharded stream differs from the single-GPU stream"
+    if holds_records:
+        assert rows_l.shape == (B_total, width) and np.all(status_l == 0), "a replicate of the timed batch failed"
+        assert np.array_equal(rows_l[probe], one[0]), "sharded stream differs from the single-GPU stream"
     # ... and equals the reference arithmetic: replicate 0 of the seeded stream against the committed oracle row
     # (tests/golden/bench_guard.npz, made by tests/golden/make_bench_guard.py with the oracle)
     rows, status, iters = model.bootstrap(8, seed=1, rep_offset=0)

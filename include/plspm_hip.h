@@ -418,7 +418,12 @@ int plspm_group_shard(const plspm_group_t* g, int64_t B, int32_t rank, int64_t* 
  * ranks that share a device, else up to three, sizes falling by "chunk_ratio" percent) | 1 .. 8 sub-batches -- a caller that issues calls back to back (bench.py's
  * step loop) sets 1: the gather of call k then overlaps the kernels of call k + 1 anyway; "chunk_ratio" 10 .. 100 (default 50); "chunk_align"
  * 0 (default: every sub-batch but the last fills whole ROUNDS of the device per rank -- a part that ends inside a round of Gram tiles pays for
- * the whole round; models whose round holds more replicates than the call has stay in one piece) | n: multiples of n replicates per rank. */
+ * the whole round; models whose round holds more replicates than the call has stay in one piece) | n: multiples of n replicates per rank;
+ * "gather_root" 0 (default: every rank receives every shard -- ncclAllGather) | 1: only rank 0 -- the rank whose handle summarises, as only the
+ * reference's parent process merges (bootstrap.py:96-111) -- receives them: grouped ncclSend / ncclRecv to rank 0 (or its copy engines alone pulling, in a
+ * one-process job on the copy transport): 1 / nranks of the bytes on the links, nothing arriving at the other ranks.  plspm_group_summary then computes the
+ * table on rank 0 and hands it to every rank in one small ncclBroadcast (every rank calls it, as before); plspm_group_records / _rows / _adopt report
+ * PLSPM_E_STATE on the ranks that hold no records.  The automatic sub-batch alignment is agreed across the ranks (max) in the first call that needs it. */
 int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t rep_offset);
 int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value);
 /* The sub-batches a call of B replicates is cut into: *n_sub (<= 8) ranges [sub_first[k], sub_first[k] + sub_count[k]) (arrays of 8), in

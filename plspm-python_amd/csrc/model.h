@@ -187,7 +187,8 @@ struct FetchSeg { int64_t b0, nb; hipEvent_t ready; };
 
 // Same-device record exchange of a group (plspm_bootstrap.hip): send[i] -> recv[d] + i * doubles for all i, d < n, one launch on `stream`.
 #define PLSPM_GATHER_LOCAL_MAX 16
-int plspm_detail_gather_local(hipStream_t stream, int n, const double* const* send, double* const* recv, size_t doubles);
+// ndst: the first `ndst` receive buffers are filled (n: all-gather; 1: the gather to rank 0 of group option "gather_root").
+int plspm_detail_gather_local(hipStream_t stream, int n, const double* const* send, double* const* recv, size_t doubles, int ndst);
 
 inline int fail(plspm_model* m, int code, const std::string& msg) {
     if (m) m->error = msg; else g_create_error = msg;

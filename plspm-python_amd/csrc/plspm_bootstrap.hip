@@ -356,14 +356,14 @@ __global__ void __launch_bounds__(256) gather_local_kernel(GatherLocalArgs a, lo
     T* __restrict__ dst = reinterpret_cast<T*>(a.recv[blockIdx.z]) + (long)blockIdx.y * n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
-int plspm_detail_gather_local(hipStream_t stream, int n, const double* const* send, double* const* recv, size_t doubles) {
-    if (n < 1 || n > PLSPM_GATHER_LOCAL_MAX) return PLSPM_E_ARG;
+int plspm_detail_gather_local(hipStream_t stream, int n, const double* const* send, double* const* recv, size_t doubles, int ndst) {
+    if (n < 1 || n > PLSPM_GATHER_LOCAL_MAX || ndst < 1 || ndst > n) return PLSPM_E_ARG;
     GatherLocalArgs a;
     for (int i = 0; i < n; ++i) { a.send[i] = send[i]; a.recv[i] = recv[i]; }
     for (int i = n; i < PLSPM_GATHER_LOCAL_MAX; ++i) { a.send[i] = nullptr; a.recv[i] = nullptr; }
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((doubles + 2047) / 2048, 512));
-    if (doubles % 2 == 0) hipLaunchKernelGGL(gather_local_kernel<double2>, dim3(gx, (unsigned)n, (unsigned)n), dim3(256), 0, stream, a, (long)(doubles / 2));
-    else hipLaunchKernelGGL(gather_local_kernel<double>, dim3(gx, (unsigned)n, (unsigned)n), dim3(256), 0, stream, a, (long)doubles);
+    if (doubles % 2 == 0) hipLaunchKernelGGL(gather_local_kernel<double2>, dim3(gx, (unsigned)n, (unsigned)ndst), dim3(256), 0, stream, a, (long)(doubles / 2));
+    else hipLaunchKernelGGL(gather_local_kernel<double>, dim3(gx, (unsigned)n, (unsigned)ndst), dim3(256), 0, stream, a, (long)doubles);
     return hipGetLastError() == hipSuccess ? 0 : PLSPM_E_STATE;
 }
 

@@ -37,6 +37,9 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;      // (optional symbols: the gather to rank 0, group option "gather_root")
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -71,6 +74,9 @@ const Rccl* rccl(std::string& why) {
     if (!ok) { dlclose(so); return nullptr; }
     r.CommInitRankConfig = (decltype(r.CommInitRankConfig))dlsym(so, "ncclCommInitRankConfig");
     r.CommSplit = (decltype(r.CommSplit))dlsym(so, "ncclCommSplit");
+    r.Send = (decltype(r.Send))dlsym(so, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(so, "ncclRecv");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(so, "ncclBroadcast");
     g_rccl = r;
     return &g_rccl;
 }
@@ -92,6 +98,7 @@ struct Local {
     hipEvent_t gathered[2] = {nullptr, nullptr};   // records of slot s complete in recv[s] (recorded on cstream)
     double* d_word = nullptr;                      // barrier / max scratch
     double* h_word = nullptr;                      // pinned mirror
+    plspm_model::Buf bcast;                        // gather_root: the summary table on its way from rank 0 to the other ranks
 };
 
 // Resident helper threads of a group with several local handles: every handle's shard is enqueued by its own thread (handle 0 by the
@@ -181,6 +188,10 @@ struct plspm_group {
     int64_t agreed_units = 0;
     int opt_lean_events = 1;                       // "lean_events": no wait packet for an event that has fired, `computed` signalled by the shard's last kernel
     int opt_skip_exchange = 0;                     // diagnostics (include/plspm_hip_test.h): the step without its exchange
+    // "gather_root" 1: only rank 0 -- the rank whose handle summarises (bootstrap.py:96-111: only the parent merges) -- receives the shards: 1 / nranks of the
+    // all-gather's bytes on the links, nothing arriving at (or read by) the other ranks; the summary table travels back to them in one small broadcast.
+    int opt_gather_root = 0;
+    bool last_root_only = false;                   // the last plspm_group_bootstrap gathered to rank 0 only
     int peers_checked = -1;                        // slot whose gathered shards were inspected for a failed peer (check_peer_shards)
     int peers_rc = 0;
     double t_shards_ms = 0.0, t_exchange_ms = 0.0;  // host time of the last plspm_group_bootstrap: shard enqueue / exchange enqueue
@@ -247,6 +258,7 @@ static void group_release(plspm_group* g) {
             for (auto& e : l.computed[s]) if (e) hipEventDestroy(e);
             if (l.gathered[s]) hipEventDestroy(l.gathered[s]);
         }
+        if (l.bcast.p) { plspm_dfree(l.bcast.p); l.bcast.p = nullptr; l.bcast.cap = 0; }
         if (l.d_word) plspm_dfree(l.d_word);
         if (l.h_word) plspm_hfree(l.h_word);
         if (l.cstream) plspm_stream_release(l.cstream);
@@ -552,6 +564,11 @@ int plspm_group_set_option(plspm_group_t* g, const char* key, int32_t value) {
     if (k == "chunks") { if (value < 0 || value > kBootChunksMax) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunks in 0 .. 8"); g->opt_chunks = value; }
     else if (k == "chunk_align") { if (value < 0 || value > (1 << 20)) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: chunk_align in 0 .. 2^20"); g->opt_align = value; }
     else if (k == "lean_events") { if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: lean_events 0 | 1"); g->opt_lean_events = value; }
+    else if (k == "gather_root") {
+        if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: gather_root 0 | 1");
+        if (value && g->use_rccl && (!g_rccl.Send || !g_rccl.Recv || !g_rccl.Broadcast)) return gfail(g, PLSPM_E_STATE, "plspm_group_set_option: this librccl has no ncclSend / ncclRecv / ncclBroadcast");
+        g->opt_gather_root = value;
+    }
     else if (k == "skip_exchange") { if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: skip_exchange 0 | 1"); g->opt_skip_exchange = value; }
     else if (k == "events_device_scope") {
         if (value < 0 || value > 1) return gfail(g, PLSPM_E_ARG, "plspm_group_set_option: events_device_scope 0 | 1");
@@ -666,6 +683,7 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         for (int k = k0; k < K; ++k) hipEventRecord(l.computed[s][k], l.m->stream);
     }
     // 2. the collective of every sub-batch, on the gather streams behind that sub-batch's shard kernels
+    const bool root_only = g->opt_gather_root != 0 && g->nranks > 0;
     int crc = 0;
     std::string cwhy;
     for (int k = 0; k < K; ++k) {
@@ -684,8 +702,18 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
             if (n != ncclSuccess) { if (!crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclGroupStart: ") + r->GetErrorString(n); } }
             else {
                 // between GroupStart and GroupEnd nothing returns early: an open group call would poison every later RCCL call of the process
-                for (auto& l : g->loc) {
+                for (int i = 0; i < nl; ++i) {
+                    Local& l = g->loc[i];
                     hipSetDevice(l.m->device);
+                    if (root_only) {
+                        // the gather SURVEY 8(e) names: every rank sends its shard to rank 0, rank 0 posts one receive per rank (its own included) -- one group call
+                        n = r->Send((const double*)l.send[s].p + soff, sub_doubles, ncclDouble, 0, l.comm, l.cstream);
+                        if (n == ncclSuccess && g->first_rank + i == 0)
+                            for (int src = 0; src < g->nranks && n == ncclSuccess; ++src)
+                                n = r->Recv((double*)l.recv[s].p + roff + (size_t)src * sub_doubles, sub_doubles, ncclDouble, src, l.comm, l.cstream);
+                        if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclSend / ncclRecv: ") + r->GetErrorString(n); }
+                        continue;
+                    }
                     n = r->AllGather((const double*)l.send[s].p + soff, (double*)l.recv[s].p + roff, sub_doubles, ncclDouble, l.comm, l.cstream);
                     if (n != ncclSuccess && !crc) { crc = -(1000 + (int)n); cwhy = std::string("ncclAllGather: ") + r->GetErrorString(n); }
                 }
@@ -701,12 +729,13 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
                 if (e == hipSuccess) e = hipStreamWaitEvent(l0.cstream, g->loc[i].computed[s][k], 0);
                 send[i] = (const double*)g->loc[i].send[s].p + soff; recv[i] = (double*)g->loc[i].recv[s].p + roff;
             }
-            if (e == hipSuccess && plspm_detail_gather_local(l0.cstream, nl, send, recv, sub_doubles)) e = hipErrorLaunchFailure;
+            if (e == hipSuccess && plspm_detail_gather_local(l0.cstream, nl, send, recv, sub_doubles, root_only ? 1 : nl)) e = hipErrorLaunchFailure;
             if (e != hipSuccess && !crc) { crc = -(int)e; cwhy = std::string("record exchange: ") + hipGetErrorString(e); }
         } else {
             // copy-engine exchange (single process, peer-mapped buffers; plspm_comm_create_ex transport 2): every rank PULLS the peers' shards with
             // device-to-device copies on its own gather stream -- no kernel, no CU: the SDMA engines move the records over xGMI
-            for (auto& dst : g->loc) {
+            for (int d = 0; d < (root_only ? 1 : nl); ++d) {      // (gather_root: only rank 0's copy engines pull)
+                Local& dst = g->loc[d];
                 hipSetDevice(dst.m->device);
                 for (int i = 0; i < nl; ++i) {
                     hipError_t e = hipStreamWaitEvent(dst.cstream, g->loc[i].computed[s][k], 0);
@@ -727,6 +756,7 @@ int plspm_group_bootstrap(plspm_group_t* g, int64_t B, uint64_t seed, int64_t re
         return gfail(g, crc, cwhy);
     }
     g->pending[s] = true; g->last_slot = s; g->next_slot = s ^ 1; g->last_B = B; g->last_cap = cap; g->peers_checked = -1;
+    g->last_root_only = root_only;
     g->last_K = K;
     for (int k = 0; k < K; ++k) { g->sub_B[k] = sub_B[k]; g->sub_first[k] = sub_first[k]; g->sub_cap[k] = sub_cap[k]; g->sub_off[k] = sub_off[k]; }
     return 0;
@@ -775,6 +805,7 @@ static int check_peer_shards(plspm_group* g) {
 int plspm_group_records(plspm_group_t* g, int32_t local, void** d_records, int64_t* n_records, int32_t* stride) {
     if (!g || local < 0 || local >= (int)g->loc.size()) return gfail(g, PLSPM_E_ARG, "plspm_group_records: bad arguments");
     if (g->last_slot < 0) return gfail(g, PLSPM_E_STATE, "plspm_group_records: no bootstrap on this group yet");
+    if (g->last_root_only && g->first_rank + local != 0) return gfail(g, PLSPM_E_STATE, "plspm_group_records: the records of the last bootstrap were gathered to rank 0 only (gather_root)");
     Local& l = g->loc[local];
     GHIP(g, hipSetDevice(l.m->device));
     GHIP(g, hipEventSynchronize(l.gathered[g->last_slot]));
@@ -790,6 +821,33 @@ int plspm_group_summary(plspm_group_t* g, const double* original, double* summar
     if (g->last_slot < 0) return gfail(g, PLSPM_E_STATE, "plspm_group_summary: no bootstrap on this group yet");
     Local& l = g->loc[0];
     GHIP(g, hipSetDevice(l.m->device));
+    const bool other_processes = g->use_rccl && (int)g->loc.size() != g->nranks;
+    if (g->last_root_only && other_processes) {
+        // gather_root in a one-process-per-GPU job: rank 0 holds the records, computes the table and sends [rc | n_used | table] to every rank in one
+        // broadcast -- every rank makes this call (as with the all-gather, where every rank computed the same table from its own copy)
+        const int R = plspm_row_width(l.m);
+        const size_t words = 2 + (size_t)R * 6, bytes = words * sizeof(double);
+        if (l.bcast.cap < bytes) { GHIP(g, hipStreamSynchronize(l.cstream)); int grc = grow(g, l, l.bcast, bytes); if (grc) return grc; }
+        std::vector<double> host(words, 0.0);
+        int rc0 = 0;
+        if (g->first_rank == 0) {
+            GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
+            int64_t used = 0;
+            rc0 = check_peer_shards(g);
+            if (!rc0) { rc0 = plspm_detail_summary(l.m, (const double*)l.recv[g->last_slot].p, g->last_cap * g->nranks, plspm_row_stride(l.m), original, host.data() + 2, &used); if (rc0) g->error = l.m->error; }
+            host[0] = (double)rc0; host[1] = (double)used;
+            GHIP(g, hipMemcpyAsync(l.bcast.p, host.data(), bytes, hipMemcpyHostToDevice, l.cstream));
+        }
+        const Rccl* r = &g_rccl;
+        GNCCL(g, r, r->Broadcast(l.bcast.p, l.bcast.p, words, ncclDouble, 0, l.comm, l.cstream));
+        if (g->first_rank != 0) GHIP(g, hipMemcpyAsync(host.data(), l.bcast.p, bytes, hipMemcpyDeviceToHost, l.cstream));
+        GHIP(g, hipStreamSynchronize(l.cstream));
+        if (g->first_rank == 0 && rc0) return gfail(g, rc0, g->error);
+        if (host[0] != 0.0) return gfail(g, (int)host[0], "plspm_group_summary: rank 0 reports a failed bootstrap (see its error)");
+        memcpy(summary, host.data() + 2, (size_t)R * 6 * sizeof(double));
+        if (n_used) *n_used = (int64_t)host[1];
+        return 0;
+    }
     GHIP(g, hipStreamWaitEvent(l.m->stream, l.gathered[g->last_slot], 0));
     int rc = check_peer_shards(g);
     if (rc) return rc;
@@ -801,6 +859,7 @@ int plspm_group_summary(plspm_group_t* g, const double* original, double* summar
 int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* iters) {
     if (!g) return PLSPM_E_ARG;
     if (g->last_slot < 0) return gfail(g, PLSPM_E_STATE, "plspm_group_rows: no bootstrap on this group yet");
+    if (g->last_root_only && g->first_rank != 0) return gfail(g, PLSPM_E_STATE, "plspm_group_rows: the records of the last bootstrap were gathered to rank 0 only (gather_root)");
     Local& l = g->loc[0];
     const int RS = plspm_row_stride(l.m), R = RS - 2;
     GHIP(g, hipSetDevice(l.m->device));
@@ -824,6 +883,7 @@ int plspm_group_rows(plspm_group_t* g, double* out, int32_t* status, int32_t* it
 int plspm_group_adopt(plspm_group_t* g) {
     if (!g) return PLSPM_E_ARG;
     if (g->last_slot < 0 || g->loc.empty()) return gfail(g, PLSPM_E_STATE, "plspm_group_adopt: no bootstrap result on this group");
+    if (g->last_root_only && g->first_rank != 0) return gfail(g, PLSPM_E_STATE, "plspm_group_adopt: the records of the last bootstrap were gathered to rank 0 only (gather_root)");
     Local& l = g->loc[0];
     plspm_model* m = l.m;
     const int RS = plspm_row_stride(m);

@@ -551,6 +551,7 @@ class NativeGroup:
         if not self._h:
             raise NativeBackendError("plspm_group_create: " + lib.plspm_group_last_error(None).decode())
         self.nranks = lib.plspm_group_size(self._h)
+        self.first_rank = int(comm.first_rank)        # rank of local handle 0 (0: this process holds the rank that summarises)
         self.row_width, self.row_stride = self.models[0].row_width, self.models[0].row_stride
         self.last_B = 0
         comm._bound = weakref.ref(self)

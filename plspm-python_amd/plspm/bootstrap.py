@@ -67,6 +67,8 @@ def launch(result, iterations: int, num_processes: int, seed=None, comm=None, de
             raise _native.NativeBackendError("the handle lives on device %d but this rank's GPU is %d: pass device_id=LOCAL_RANK"
                                              % (native.device_id, ctx.local_rank))
         group = _native.NativeGroup(ctx.comm, [native])
+        if parallel.gather_to_root():
+            group.set_option("gather_root", 1)
         group.bootstrap(iterations, seed, 0)
         source = group
     else:
@@ -75,6 +77,8 @@ def launch(result, iterations: int, num_processes: int, seed=None, comm=None, de
             from plspm import _native
             helpers = [result.builder(dev) for dev in devices[1:]]                  # the same model + data on the other GPUs
             group = _native.NativeGroup(parallel.local_comm(devices), [native] + helpers)
+            if parallel.gather_to_root():
+                group.set_option("gather_root", 1)
             group.bootstrap(iterations, seed, 0)
             source = group
         else:
@@ -92,7 +96,9 @@ class Bootstrap:
 
     Where the replicates run (results are bit-identical for every choice -- Philox stream keyed by (seed, replicate id)):
       * ``comm`` given (any object with rank / world / all_gather): the caller's host-side transport (``parallel.sharded_bootstrap``);
-      * a one-process-per-GPU job (``parallel.init_process_group()`` was called): this rank's shard + ONE RCCL all-gather;
+      * a one-process-per-GPU job (``parallel.init_process_group()`` was called): this rank's shard + ONE RCCL all-gather (``PLSPM_GATHER=root``:
+        a gather to rank 0 -- the reference's own merge, bootstrap.py:96-111 -- and one small broadcast of the summary table; ``replicates()`` /
+        ``status()`` then exist on rank 0 only);
       * otherwise the handle's own GPU -- or, when the caller names GPUs (``Plspm(devices=[...])`` / ``PLSPM_DEVICES``), up to
         ``num_processes`` (the reference's worker count) of them, capped by ``parallel.MIN_REPLICATES_PER_GPU``: one handle per GPU
         + ONE RCCL all-gather; a single GPU needs no collective.
@@ -122,7 +128,9 @@ class Bootstrap:
             # The gathered records move into this fit's own handle and the group goes away: a communicator serves ONE group at a
             # time, so a second live Plspm(bootstrap=True) of the job (or a rebinding loop) must not find it taken; the lazy
             # rows() / status() accessors then read the handle like after a single-GPU bootstrap.
-            self._group.adopt()
+            self._records_here = not (parallel.gather_to_root() and self._group.first_rank != 0)
+            if self._records_here:                   # (gather_root: the records live on rank 0 only; the summary table came back to every rank)
+                self._group.adopt()
             self._group.close()
             for helper in (self._helpers or ()):
                 helper.close()
@@ -162,6 +170,8 @@ class Bootstrap:
         return self._frames
 
     def _fetch(self):
+        if not getattr(self, "_records_here", True):
+            raise RuntimeError("the replicate records of this bootstrap were gathered to rank 0 only (PLSPM_GATHER=root); the summaries are on every rank")
         if self._rows is None:
             self._rows = self._native.fetch(0, self._iterations_requested)
         return self._rows

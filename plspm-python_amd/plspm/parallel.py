@@ -45,6 +45,15 @@ def join_records(rows, status, iters):
 _local_comms = {}
 
 
+def gather_to_root() -> bool:
+    """``PLSPM_GATHER=root``: the shards travel to rank 0 only (group option "gather_root": 1 / nranks of the all-gather's bytes, the summary table
+    broadcast back); default ``all``: every rank receives every shard (ONE ncclAllGather per sub-batch).  Every rank of a job must see the same value."""
+    mode = os.environ.get("PLSPM_GATHER", "all").lower()
+    if mode not in ("all", "root"):
+        raise ValueError("PLSPM_GATHER must be 'all' or 'root' (got %r)" % mode)
+    return mode == "root"
+
+
 def local_comm(devices, transport=None, max_channels=None):
     """The process-wide communicator over ``devices`` (created on first use: librccl load + ncclCommInitAll take of the order
     of a second, every later bootstrap re-uses it).  A communicator serves one group at a time: while the bootstrap of an earlier

@@ -19,8 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-def _run(cmd):
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+def _run(cmd, env=None):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
     assert lines, out.stdout[-2000:] + out.stderr[-3000:]
     return json.loads(lines[-1][7:])
@@ -43,6 +43,11 @@ def test_api_bootstrap_one_process_per_gpu_rccl_equals_single_process():
     env_cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29533", script]
     dist = _run(env_cmd)
+    for key in plain:
+        np.testing.assert_allclose(np.array(dist[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)
+    # round 6: the gather to rank 0 (PLSPM_GATHER=root; with one rank: ncclSend / ncclRecv to itself) gives the same frames
+    env_cmd[env_cmd.index("29533")] = "29535"
+    dist = _run(env_cmd, env=dict(os.environ, PLSPM_GATHER="root"))
     for key in plain:
         np.testing.assert_allclose(np.array(dist[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)
 
@@ -73,6 +78,79 @@ def test_group_records_bit_identical_to_single_handle(nranks, B):
     group.barrier()
     assert group.max(1.25) == 1.25
     group.close(); comm.close()
+
+
+@pytest.mark.parametrize("nranks,B,chunks", [(1, 64, 1), (2, 65, 1), (3, 5003, 3), (4, 9000, 4), (4, 3, 1)])
+def test_group_gather_to_root_is_bit_identical_and_only_root_holds_records(nranks, B, chunks):
+    """Group option "gather_root" (round 6: only the rank whose handle summarises receives the shards -- the reference's own merge, bootstrap.py:96-111; 1 / nranks of
+    the all-gather's bytes): rows, status, iteration counts, summary and the adopted handle are bit for bit those of the all-gather and of the single-handle
+    stream, for every sub-batch cut; the other local handles hold no records and say so.  One rank = the real RCCL transport (ncclSend / ncclRecv to itself in
+    one group call); several ranks on this one GPU = the same-device copy launch with one destination."""
+    from plspm import _native
+    models = [_model(1500, 5, seed=9) for _ in range(nranks)]
+    ref_rows, ref_status, ref_iters = models[0].bootstrap(B, seed=5, rep_offset=11)
+    original = np.linspace(-1.0, 1.0, models[0].row_width)
+    ref_table, ref_used = models[0].summary(B, original)
+    comm = _native.NativeComm([0] * nranks)
+    group = _native.NativeGroup(comm, models)
+    assert group.first_rank == 0
+    group.set_option("chunks", chunks); group.set_option("chunk_align", 64)
+    group.set_option("gather_root", 1)
+    for _ in range(3):                                       # both buffer slots, and a slot re-used
+        group.bootstrap(B, seed=5, rep_offset=11)
+    rows, status, iters = group.rows()
+    assert np.array_equal(rows, ref_rows) and np.array_equal(status, ref_status) and np.array_equal(iters, ref_iters)
+    table, used = group.summary(original)
+    assert used == ref_used and np.array_equal(table, ref_table, equal_nan=True)
+    assert group.records(0)[0]
+    for local in range(1, nranks):
+        with pytest.raises(_native.NativeBackendError, match="gathered to rank 0 only"):
+            group.records(local)
+    group.set_option("gather_root", 0)                       # ... and back: the all-gather fills every handle's buffer again
+    group.bootstrap(B, seed=5, rep_offset=11)
+    assert all(group.records(local)[0] for local in range(nranks))
+    rows2, status2, iters2 = group.rows()
+    assert np.array_equal(rows2, ref_rows) and np.array_equal(iters2, ref_iters)
+    group.set_option("gather_root", 1)
+    group.bootstrap(B, seed=5, rep_offset=11)
+    group.adopt()
+    got = models[0].fetch(0, B)
+    assert np.array_equal(got[0], ref_rows) and np.array_equal(got[1], ref_status)
+    group.close(); comm.close()
+
+
+def test_plspm_api_gather_to_root_env(monkeypatch):
+    """PLSPM_GATHER=root through the public API (one process, two handles on this GPU): the frames of the default all-gather."""
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    import pandas as pd
+    X, blocks = orc.synth(1200, orc.satisfaction_C(), 4, seed=3)
+    cols = ["%s%d" % (lv.lower(), k) for lv in orc.SAT_LVS for k in range(4)]
+    frame = pd.DataFrame(X, columns=cols)
+    structure = c.Structure()
+    for frm, to in orc.SAT_EDGES:
+        structure.add_path([frm], [to])
+
+    def run():
+        cfg = c.Config(structure.path(), scaled=True)
+        for lv in orc.SAT_LVS:
+            cfg.add_lv_with_columns_named(lv, Mode.A, frame, lv.lower())
+        m = Plspm(frame, cfg, Scheme.PATH, bootstrap=True, bootstrap_iterations=1200, processes=2, seed=6)
+        return m.bootstrap().weights(), m.bootstrap().paths(), m.bootstrap().ranks(), m.bootstrap().replicates()
+    from plspm import parallel
+    monkeypatch.setattr(parallel, "devices_for", lambda processes, replicates, first_device=0, devices=None: [0] * min(int(processes), 2))
+    base = run()
+    monkeypatch.setenv("PLSPM_GATHER", "root")
+    root = run()
+    assert base[2] == root[2] == 2
+    pd.testing.assert_frame_equal(base[0], root[0], check_exact=True)
+    pd.testing.assert_frame_equal(base[1], root[1], check_exact=True)
+    assert np.array_equal(base[3], root[3])
+    monkeypatch.setenv("PLSPM_GATHER", "sideways")
+    with pytest.raises(ValueError, match="PLSPM_GATHER"):
+        run()
 
 
 @pytest.mark.parametrize("nranks,B,chunks", [(2, 3000, 2), (2, 3001, 3), (3, 5003, 3), (1, 2600, 2), (2, 4500, 0), (4, 9000, 4)])
@@ -351,13 +429,17 @@ def test_real_multi_gpu_rccl_all_gather_when_the_box_has_two_gpus():
         comms = [comm] + ([comm.split(8)] if comm.uses_rccl else [])
         for cc in comms:
             group = _native.NativeGroup(cc, models)
-            for chunks in (1, 3):
+            for chunks, root in ((1, 0), (3, 0), (1, 1), (3, 1)):      # (round 6: ... and the gather to rank 0 -- ncclSend / ncclRecv, or rank 0's copy engines alone)
                 group.set_option("chunks", chunks)
+                group.set_option("gather_root", root)
                 for call in range(3):
                     group.bootstrap(8 * 1003, seed=5, rep_offset=7)
                 rows, status, iters = group.rows()
                 big = models[0].bootstrap(8 * 1003, seed=5, rep_offset=7)
-                assert np.array_equal(rows, big[0]) and np.array_equal(status, big[1]) and np.array_equal(iters, big[2]), (cc.transport, cc.max_channels, chunks)
+                assert np.array_equal(rows, big[0]) and np.array_equal(status, big[1]) and np.array_equal(iters, big[2]), (cc.transport, cc.max_channels, chunks, root)
+                if root:
+                    with pytest.raises(_native.NativeBackendError, match="gathered to rank 0 only"):
+                        group.records(1)
             group.close()
         for cc in comms[::-1]:
             cc.close()
@@ -367,6 +449,12 @@ def test_real_multi_gpu_rccl_all_gather_when_the_box_has_two_gpus():
                  "--master-port", "29537", script])
     for key in plain:
         np.testing.assert_allclose(np.array(dist[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)
+
+    # ... and the launcher route with PLSPM_GATHER=root: every rank gets the summary table through the broadcast, rank 0 prints the frames
+    dist_root = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(min(G, 2)), "--master-addr", "127.0.0.1",
+                      "--master-port", "29539", script], env=dict(os.environ, PLSPM_GATHER="root"))
+    for key in plain:
+        np.testing.assert_allclose(np.array(dist_root[key], dtype=float), np.array(plain[key], dtype=float), rtol=1e-12, atol=1e-14, err_msg=key)
 
 
 def test_bench_multi_rank_path_on_one_device_calibrates_the_tile_plan(tmp_path):
