@@ -28,6 +28,12 @@ CAT_NM_WAVE=0 timeout 300 python tools/categorical_bench.py 2>&1 | tail -1 > $O/
 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1 > $O/nonmetric_bench.json
 (NM_BENCH_N=100000 NM_BENCH_SPINUP=3 NM_BENCH_STEPS=5 timeout 600 python tools/nonmetric_bench.py 2>&1 | tail -1; NM_BENCH_N=100000 NM_BENCH_GRAM_PATH=1 NM_BENCH_SPINUP=1 NM_BENCH_STEPS=2 timeout 600 python tools/nonmetric_bench.py 1000 2>&1 | tail -1) > $O/nonmetric_100k.jsonl
 timeout 900 python tools/fit_bench.py c2 c5 2>&1 | grep "^{" > $O/fit_bench.jsonl
+# round 6: the one-launch NUM / RAW solver against the per-iteration launches (A/B), its verification pass with the lower bound forced to fail / to one row block
+# (kernel tables), the dense wide Gram of configs[4] on the ring of row buffers against the two-stage ping-pong
+(for v in 1 0 1 0; do NM_BENCH_WAVE16=$v timeout 300 python tools/nonmetric_bench.py 2>&1 | tail -1; done) > $O/nonmetric_ab_wave16.jsonl
+bash tools/experiments/nm_verify_prof.sh > $O/nonmetric_verify_kernels.txt 2>&1
+(for o in wide_ring=0 wide_ring=4 wide_ring=6 wide_ring=0 wide_ring=4 wide_ring=6; do FIT_BENCH_OPTS=$o timeout 300 python tools/fit_bench.py c5 2>&1 | grep "^{" | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'option': '$o', 'kernel_ms': d['kernel_ms'], 'gram_kernel': d['roofline']['gram_kernel'], 'iterations': d['iterations']}))"; done) > $O/c5_ring_ab.jsonl
 timeout 300 python tools/api_phase_times.py 2>&1 | grep "^{" > $O/api_phase_times.jsonl
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 -d $O/prof_pmc1 -o pmc1 -- python $R/bench.py --no-cpu-baseline --no-api --no-next-rows --no-single-fit --steps 3 --warmup 1 > $O/prof_pmc1.log 2>&1
