@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LMAX > 
 // continued behind left as score maps for the verification pass (kernels_nonmetric.h nm_vlist_kernel ...).  `live` / `force`: the replay of the replicates
 // whose stop the verification moved (no maps stored).  The per-block sums of the map constants take 64 doubles behind the metric workspace.
 template <int LMAX, bool MODEB = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) solver_nmwave_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LMAX > 16 ? 1 : 2, LMAX > 16 ? 1 : 2))) solver_nmwave_kernel(ModelDesc md, const double* __restrict__ Md, long md_stride, SolverOut so,
                                                                                                         double* __restrict__ maps, long maps_stride, int* __restrict__ steps,
                                                                                                         const int* __restrict__ force, const int* __restrict__ live, double bound_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -155,7 +155,8 @@ int run_hoc_moments(plspm_model* m, plspm_model* m2, long nb) {
 bool nm_wave_solver_covers(const plspm_model* m) {
     if (!m->nonmetric || m->categorical || m->n_ind || m->nmx_K > 0 || m->stage1 || m->stage2 || m->P > 64) return false;
     if (m->L <= 8) return m->P >= 1 && (wave16_ws_doubles<8>(m->L, m->kmax, m->n_chol) + 64) * sizeof(double) <= 20 * 1024 && m->n_chol / 2 <= 16 * 66;
-    return wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax);
+    if (m->L <= 16) return wave16_solver_covers<16>(m->P, m->L, m->n_chol, m->kmax);
+    return m->n_chol == 0 && wave16_solver_covers<32>(m->P, m->L, 0, m->kmax);      // 17 .. 32 LVs: all Mode A, as the metric <32> form
 }
 
 int launch_nm_wave_solver(plspm_model* m, long nb, const SolverOut& so, double* maps, long maps_stride, int* steps, const int* force, const int* live) {
@@ -168,12 +169,18 @@ int launch_nm_wave_solver(plspm_model* m, long nb, const SolverOut& so, double* 
         if ((rc = allow_lds(m, (const void*)k, lds))) return rc;
         hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so, maps, maps_stride, steps, force, live, std::ldexp(1.0, m->tune.nm_bound_shift));
         m->last_solver = 9;
-    } else {
+    } else if (m->L <= 16) {
         const size_t lds = (size_t)(wave16_ws_doubles<16>(m->L, m->kmax, m->n_chol) + 64) * sizeof(double);
         auto k = m->n_chol > 0 ? solver_nmwave_kernel<16, true> : solver_nmwave_kernel<16, false>;
         if ((rc = allow_lds(m, (const void*)k, lds))) return rc;
         hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so, maps, maps_stride, steps, force, live, std::ldexp(1.0, m->tune.nm_bound_shift));
         m->last_solver = 10;
+    } else {
+        const size_t lds = (size_t)(wave16_ws_doubles<32>(m->L, m->kmax, 0) + 64) * sizeof(double);
+        auto k = solver_nmwave_kernel<32, false>;
+        if ((rc = allow_lds(m, (const void*)k, lds))) return rc;
+        hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(64), lds, m->stream, make_desc(m), gram_buf, (long)cov_doubles(m->Pg), so, maps, maps_stride, steps, force, live, std::ldexp(1.0, m->tune.nm_bound_shift));
+        m->last_solver = 11;
     }
     return 0;
 }

@@ -448,10 +448,10 @@ int hostemu_solve_nmwave16(int P, int L, int PA, int scheme, int scaled, int max
                            const int* mode, const double* shift, int n_eff, const int* eff_from, const int* eff_to, const double* Md,
                            double* row, int* iters, int* status, double* maps, int force_T, int* steps) {
     EmuModel em(P, L, PA, scheme, scaled, max_iter, tol, boff, C, mode, shift, n_eff, eff_from, eff_to);
-    const bool small = L <= 8;
-    if (small ? !(P <= 64 && em.md.n_chol / 2 <= 16 * 66) : !wave16_solver_covers<16>(P, L, em.md.n_chol, em.md.kmax)) return 1;
+    const bool small = L <= 8, big = L > 16;
+    if (small ? !(P <= 64 && em.md.n_chol / 2 <= 16 * 66) : (big ? !(em.md.n_chol == 0 && wave16_solver_covers<32>(P, L, 0, em.md.kmax)) : !wave16_solver_covers<16>(P, L, em.md.n_chol, em.md.kmax))) return 1;
     const int nthreads = 64;
-    const long wsd = small ? wave16_ws_doubles<8>(L, em.md.kmax, em.md.n_chol) : wave16_ws_doubles<16>(L, em.md.kmax, em.md.n_chol);
+    const long wsd = small ? wave16_ws_doubles<8>(L, em.md.kmax, em.md.n_chol) : (big ? wave16_ws_doubles<32>(L, em.md.kmax, 0) : wave16_ws_doubles<16>(L, em.md.kmax, em.md.n_chol));
     std::vector<double> lds(wsd + 64, 0.0), red(nthreads);
     FitOutputs out{};
     out.row = row; out.iters = iters; out.status = status;
@@ -466,6 +466,10 @@ int hostemu_solve_nmwave16(int P, int L, int PA, int scheme, int scaled, int max
                 wave16_carve(ws, lds.data(), L, em.md.kmax);
                 if (em.md.n_chol > 0) solve_problem_wave16<8, true, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
                 else solve_problem_wave16<8, false, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
+            } else if (big) {
+                Wave16Ws<32> ws{};
+                wave16_carve(ws, lds.data(), L, em.md.kmax);
+                solve_problem_wave16<32, false, true>(ex, em.md, ws, Md, out, &io, lds.data() + wsd);
             } else {
                 Wave16Ws<16> ws{};
                 wave16_carve(ws, lds.data(), L, em.md.kmax);

@@ -36,7 +36,7 @@ def _oracle_rows(nm, X, model, seed, reps, rows, status, iters):
 
 
 CASES = [("path", "AAAAAA", 6, 10, 4000), ("centroid", "AAAAAA", 6, 10, 1500), ("factorial", "ABABAB", 6, 6, 1500), ("path", "AAAAAAAAAAAA", 12, 5, 1500),
-         ("centroid", "ABBAABBAAB", 10, 6, 900), ("factorial", "AA", 2, 7, 700)]
+         ("centroid", "ABBAABBAAB", 10, 6, 900), ("factorial", "AA", 2, 7, 700), ("path", "A" * 20, 20, 3, 1200)]
 
 
 @pytest.mark.parametrize("scheme,modes,L,per,n", CASES)
@@ -47,7 +47,7 @@ def test_wave_route_vs_oracle_and_per_iteration_launches(scheme, modes, L, per, 
     nm = _handle(X, blocks, C, modes, scheme)
     B = 600
     rows, status, iters = nm.bootstrap(B, seed=17)
-    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_nm_wave16") == 1 and nm.get_option("last_solver") == (9 if L <= 8 else 10)
+    assert nm.get_option("last_gram_path") == 2 and nm.get_option("last_nm_wave16") == 1 and nm.get_option("last_solver") == (9 if L <= 8 else (10 if L <= 16 else 11))
     assert np.all(status == 0)
     _oracle_rows(nm, X, model, 17, (0, 1, B // 2, B - 1), rows, status, iters)
     nm.set_option("nm_wave16", 0)

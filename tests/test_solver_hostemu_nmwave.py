@@ -93,7 +93,8 @@ def test_nmwave_russa_vs_oracle(emu, modes, scheme):
     _check(e, orc.fit(X, model), "russa %s %s" % (modes, scheme))
 
 
-@pytest.mark.parametrize("scheme,modes,L,per", [("path", "AAAAAA", 6, 10), ("centroid", "ABABAB", 6, 5), ("factorial", "AAAAAAAAAAAA", 12, 5), ("path", "ABBAABBAAB", 10, 6)])
+@pytest.mark.parametrize("scheme,modes,L,per", [("path", "AAAAAA", 6, 10), ("centroid", "ABABAB", 6, 5), ("factorial", "AAAAAAAAAAAA", 12, 5), ("path", "ABBAABBAAB", 10, 6),
+                                                ("centroid", "A" * 20, 20, 3), ("path", "A" * 24, 24, 2)])
 def test_nmwave_synthetic_vs_oracle_maps_and_bootstrap_replicate(emu, scheme, modes, L, per):
     C = orc.satisfaction_C() if L == 6 else orc.chain_C(L)
     X, blocks = orc.synth(700, C, per, seed=31)
