@@ -427,6 +427,10 @@ def test_committed_bench_line_follows_the_driver_contract():
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert abs(line["value"] - line["config"]["replicates_per_step"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    # SURVEY 8(f) rank 1 beside the headline (round 6: one solver launch + verification): the Scale.NUM counterpart of the workload, measured by the same run
+    num = line["next_rows"]["nonmetric_num_bootstrap"]
+    assert num["one_launch_solver"] == 1 and num["all_ok"] and num["replicates_per_s"] >= 6.0e6 and num["kernel_ms_per_step"]["solver"] <= 0.12, num
+    assert num["replicate_iterations"][0] >= 2 and num["fit_iterations"] >= 2
     # the two single-fit configurations of BASELINE.json: iteration counts, HIP-event kernel times, A_fit / F_fit rooflines
     for key, (n, p, l) in (("configs[1]", (10000, 60, 6)), ("configs[4]", (1000000, 200, 20))):
         fit = line["single_fit"][key]
