@@ -117,17 +117,24 @@ __device__ __forceinline__ double digits_value(int d0, int d1, int d2, int d3, i
 template <int NW, int KS = 1>
 __global__ void __launch_bounds__(64 * NW) conv_mfma_kernel(const uint4* __restrict__ ind8, long ntiles, int L, const unsigned* __restrict__ cd, long MT, const uint4* __restrict__ tab8,
                                                              const double2* __restrict__ scl, const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial,
-                                                             int nparts, int tpc) {
+                                                             int nparts, int tpc, int nrun, const double* __restrict__ gstate, long state_stride) {
     const int lane = threadIdx.x & 63, i = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nlive = *count;
     const long ng = (nlive + 15) >> 4;
-    const int chunk = (int)(blockIdx.x % (unsigned)nparts);
-    const long g = (long)(blockIdx.x / (unsigned)nparts) * NW + wave;
+    // (nrun <= nparts: the row chunks this launch covers)
+    const int chunk = (int)(blockIdx.x % (unsigned)nrun);
+    const long g = (long)(blockIdx.x / (unsigned)nrun) * NW + wave;
     if (g >= ng) return;
     const long slot = g * 16 + i;
     const bool live = slot < nlive;
     const long b = live ? (long)list[slot] : 0;
+    if (gstate) {
+        // round 6: every problem names the row chunks it needs (state word 7, kernels_nmw.h: enough for the lower bound to clear the tolerance); a wave whose
+        // sixteen problems all need fewer than this chunk has nothing to do
+        const int need = live ? (int)gstate[b * state_stride + 7] : 0;
+        if (chunk >= wv::allreduce(need, [](int a, int c) { return a > c ? a : c; })) return;
+    }
     const long t0 = (long)chunk * tpc, t1 = min(ntiles, t0 + tpc);
     // the lane's four rows of tile t in replicate b: dword kg of the 16-byte piece (k-block t / 4, replicate tile b / 16, piece t % 4, replicate b % 16)
     const unsigned* cdb = cd + ((b >> 4) * 64 + (b & 15)) * 4 + kg;

@@ -30,12 +30,12 @@ namespace nmw {
 constexpr int LMAX_MAX = 8, CMAX_MAX = 16, CPL = 8;      // LVs (the kernel is instantiated for LMAX = 2, 4, 6, 8), categories per MV (CMAX = 8; 16: ten-point items -- the reference's own
                                                          // mobi / ECSI example data -- at one wave per SIMD), columns per lane
 
-// LDS of one problem (doubles): c | tq | mean | mzown (each QP = Q + 1 rounded up to 8), then the small arrays
+// LDS of one problem (doubles): c | tq | mean | mzown (each QP = Q + 1 rounded up to 8), then the small arrays, then c_old (QP)
 __host__ __device__ inline long lds_doubles(int Q, int Pm, int L, int kmax) {
     const long QP = (Q + 1 + 7) & ~7L;
     const long step = 3L * L * L + 6L * L + 2L * Pm + (long)L * regression_scratch_doubles(kmax) + 8 + 16;
     const long fin = workspace_small_doubles(Pm, L, kmax, 0) + Pm;           // the fused finish: MV-level workspace of finish_problem + one row of the MV moment matrix
-    return 4 * QP + (step > fin ? step : fin);
+    return 4 * QP + (step > fin ? step : fin) + QP;             // (+ QP, round 6: the old score map beside the new one for the step's own bound)
 }
 
 // value of a[i] for a run-time i < CMAX out of a register array (static indices only)
@@ -218,10 +218,12 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
     if (out.score_c && lane < L) out.score_c[lane] = st.k_new[lane];
 }
 
-template <int LMAX, int CMAX = 8>
+// SUB (round 6): the step bounds its own criterion and stops on it, the pass behind it reads the rows each problem asks for (nsub > 0) -- an instantiation of its
+// own so that the launches without it (data sets of a few hundred rows, the A/B option) keep the register allocation they had.
+template <int LMAX, int CMAX = 8, bool SUB = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 8 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
                                                       const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
-                                                      int fuse_finish, const int* __restrict__ live) {
+                                                      int fuse_finish, const int* __restrict__ live, int nsub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long b = live ? live[blockIdx.x] : (long)blockIdx.x;      // (kernels_nonmetric.h nm_kernel: the live list of the previous step)
     const int lane = threadIdx.x;
@@ -254,6 +256,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     ws.scr = lp; lp += (long)L * regression_scratch_doubles(md.kmax);
     ws.scal = lp; lp += 8;
     ws.red = lp;
+    double* cold_s = lp0 + (lds_doubles(Q, Pm, L, md.kmax) - QP);      // the old score map (c_s is overwritten with the new one's numerators before the bound needs both)
     DevExec ex{lane, 64, ws.red, nullptr};
 #ifdef PLSPM_DEBUG_MARKS
 #define NMW_MARK(i) do { if (b == 0 && lane == 0 && so.marks && (int)st.scal[2] == 1) so.marks[i] = clock64(); } while (0)      // (the second iteration of problem 0)
@@ -262,14 +265,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #endif
 
     // ---- decide on the previous convergence value (solver_nmg.h nmg_step: same protocol)
+    // Round 6 (nsub > 0): the pass behind a step reads only the first row chunks of a problem -- as many as its own upper bound says are needed to carry the
+    // sum over the tolerance (scal[7], below; nsub = the safety factor).  Every term of the criterion is non-negative, so that sum is a LOWER bound: at or above the tolerance it says "go on" as surely as the exact value would (the step itself
+    // stops on the UPPER bound, below); below the tolerance it decides nothing -- the problem asks for the remaining chunks (scal[5] = 1: the host runs the
+    // full pass for such problems), sits this launch out and decides on the exact value in the next one.
     const int iteration = (int)st.scal[2];
+    if (SUB && iteration > 0 && st.scal[5] == 2.0) {                    // (words 5 .. 7 of a freshly prepared problem are whatever the buffer held: the first step writes them)
+        // the previous launch stopped this problem on its own upper bound and left the finish to this one: behind the step in the same wave it lengthened the
+        // launch by its whole duration (the steppers of a launch hide the finishers' time, not the other way round: 1.58 -> 1.96 ms of step launches per 1,000)
+        if (lane == 0) { st.scal[3] = 0.0; st.scal[5] = 0.0; }
+        if (fuse_finish) {
+            __syncthreads();
+            finish<CMAX>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+        }
+        return;
+    }
     if (iteration > 0) {
+        const int need = (int)st.scal[7];                         // row chunks the pass behind the last step read for this problem (set at the end of that step)
+        const bool exact = !SUB || nsub <= 0 || need >= nparts || st.scal[5] != 0.0;
+        const int np = exact ? nparts : need;
         double s = 0.0;
-        for (int i = lane; i < nparts; i += 64) s += partial[b * nparts + i];
+        for (int i = lane; i < np; i += 64) s += partial[b * nparts + i];
         const double conv = wv::allsum(s);
-        const bool stop = (conv < md.tol) || (iteration > md.max_iter);
+        if (!exact && !(conv >= md.tol) && iteration <= md.max_iter) {      // (beyond max_iter the problem stops whatever the value: no exact pass needed)
+            if (lane == 0) { st.scal[5] = 1.0; atomicAdd(nactive, 1); }
+            return;
+        }
+        const bool stop = (exact && conv < md.tol) || (iteration > md.max_iter);
         if (lane == 0) {
-            st.scal[4] = conv;
+            st.scal[4] = conv; st.scal[5] = 0.0;
             if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
         }
         if (stop) {
@@ -292,6 +316,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         }
         if (j <= Q) mj = (double)k16[(long)Q * ld16 + j] * inv_n;
         c_s[j] = cj; tq_s[j] = tqj; mean_s[j] = mj; mz_s[j] = 0.0;
+        if (SUB) cold_s[j] = cj;
     }
     if (lane < Pm && iteration > 0) st.a_old[lane] = st.a_new[lane];
     if (lane < L) { const double k = iteration > 0 ? st.k_new[lane] : st.k_old[lane]; if (iteration > 0) st.k_old[lane] = k; kold[lane] = k; }
@@ -411,10 +436,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #pragma unroll
     for (int u = 0; u < CPL; ++u) {
         if (lvc[u] >= 0) {
-            double s = 0.0;
+            double s = 0.0, vown = 0.0;
 #pragma unroll
-            for (int m = 0; m < LMAX; ++m) if (m < L) s += V[u][m] * ws.E[m * L + lvc[u]];
+            for (int m = 0; m < LMAX; ++m) if (m < L) { s += V[u][m] * ws.E[m * L + lvc[u]]; if (SUB) vown = (lvc[u] == m) ? V[u][m] : vown; }
             mz_s[j0 + u] = s;
+            // (round 6, for the step's own bound below: M_ll c_old of this column = V[., own LV] - mean k_old -- filed while V is still in registers; tq_s is free:
+            //  the quantification works from the state's copy in registers)
+            if (SUB) tq_s[j0 + u] = vown - mean_s[j0 + u] * kold[lvc[u]];
         }
     }
     __syncthreads();
@@ -481,7 +509,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     __syncthreads();                                              // (every lane is done reading c_s as the OLD score map)
     if (is_mv) {
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) { tq_s[jm0 + c] = tqn[c]; c_s[jm0 + c] = wn * tqn[c]; }
+        for (int c = 0; c < CMAX; ++c) if (c < C) c_s[jm0 + c] = wn * tqn[c];
     }
     __syncthreads();
     NMW_MARK(25);
@@ -540,6 +568,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
             for (int u = 0; u < CPL; ++u) s += (lvc[u] == l) ? c_s[j0 + u] * U[u] : 0.0;
             qpart[l] = s;
         }
+        // for the upper bound of this step's criterion (below): U = M_ll d of the lane's columns (mz_s is dead from here on: the quantification read it)
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) if (SUB && lvc[u] >= 0) mz_s[j0 + u] = U[u];
     }
     allsum_each(qpart, L);
     double mwpart[LMAX];
@@ -566,10 +597,55 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     }
     if (lane < L) { st.k_new[lane] = akk[lane]; xg.akk[lane] = akk[lane]; }
     NMW_MARK(27);
+    // ---- the criterion of THIS step from above (round 6; solver_core.h nm_step does the same for Scale.NUM): sum_il c_i (|y_old| - |y_new|)^2 <= sum_il c_i (y_old - y_new)^2
+    //      = n sum_l [ delta' M_ll delta + 2 kappa_l mean' delta + kappa_l^2 ],  delta = c_new - c_old on the columns of block l, kappa = k_new - k_old, M = counts / n --
+    //      and M_ll c_new = U / sd_l (stream 2), M_ll c_old = V[., l] - mean k_old (stream 1): no third stream.  Below the tolerance the problem stops HERE, with the
+    //      reference's iteration count, and the pass of its last step is not needed.
+    bool bound_stop = false;
+    double need_chunks = (double)nparts;
+    if (SUB && nsub > 0) {
+        // mean' delta of block l = mean(new score) - k_new - (mean(old score) - k_old) = -2 akk_l ... in the step's own terms: mw_l / sd_l = -akk_l, and
+        // mean(old score) = vmean[l]: no per-column work for it
+        double t1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) {
+            if (lvc[u] >= 0) {
+                const int j = j0 + u;
+                const double isd = 1.0 / sdl[lvc[u]];
+                const double delta = c_s[j] * isd - cold_s[j];
+                t1 = fma(delta, mz_s[j] * isd - tq_s[j], t1);
+            }
+        }
+        double ub = wv::allsum(t1);
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) {
+                const double kap = akk[l] - kold[l];
+                const double t2 = -akk[l] - (vmean[l] - kold[l]);
+                ub += 2.0 * kap * t2 + kap * kap;
+            }
+        }
+        ub *= n;
+        bound_stop = ub < md.tol * (1.0 - 1e-9);
+        // rows the pass needs: the criterion is nearly always a few sign flips below its bound and the rows are exchangeable, so a fraction nsub tol / ub of them
+        // carries the lower bound over the tolerance (nsub = 4: four times what the expectation asks for); all of them when that is most of them anyway
+        const double want = (double)nsub * md.tol / ub * (double)nparts;
+        if (want >= 0.0 && want < 0.75 * (double)nparts) need_chunks = floor(want) + 1.0;
+        if (lane == 0) st.scal[6] = ub;
+    }
     if (lane == 0) {
         st.scal[2] = (double)(iteration + 1);
+        // (2: stopped; stays on the live list for the next launch, which finishes it -- its pass reads no rows.  Nothing to finish -- the first stage of a HOC
+        //  pair --: off the list at once)
+        st.scal[5] = (bound_stop && fuse_finish) ? 2.0 : 0.0;
+        st.scal[7] = bound_stop ? 0.0 : need_chunks;
         if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3];
-        atomicAdd(nactive, 1);
+        if (bound_stop) {
+            st.scal[4] = st.scal[6];
+            if (!fuse_finish) st.scal[3] = 0.0;
+            if (iteration + 1 > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED;      // (weights.py:183-186)
+        }
+        if (!bound_stop || fuse_finish) atomicAdd(nactive, 1);
     }
 }
 

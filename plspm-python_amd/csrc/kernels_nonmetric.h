@@ -297,27 +297,32 @@ __global__ void __launch_bounds__(256) tile_transpose_kernel(const double* __res
 // group of 64 consecutive ids almost never stops as a whole.
 // `host_count` (pinned host memory, may be null): the count once more, for the host's "anything left?" test -- written by the kernel, no copy
 // operation (and no counter to clear) per iteration.
+// `list2` / `count2` / `host_count2` (round 6, may be null): among them, the problems whose lower bound from the first row chunks did not decide and that ask for
+// the pass over all rows (state word 5: kernels_nmw.h nmw_step_kernel) -- the same sweep files them a second time.
 __global__ void __launch_bounds__(1024) active_list_kernel(const double* __restrict__ gstate, long state_stride, long nproblems, int* __restrict__ list, int* __restrict__ count,
-                                                            int* __restrict__ host_count) {
-    __shared__ int wcount[16];
-    __shared__ int base;
+                                                            int* __restrict__ host_count, int* __restrict__ list2 = nullptr, int* __restrict__ count2 = nullptr,
+                                                            int* __restrict__ host_count2 = nullptr) {
+    __shared__ int wcount[16], wcount2[16];
+    __shared__ int base, base2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base = 0;
+    if (tid == 0) { base = 0; base2 = 0; }
     __syncthreads();
     for (long b0 = 0; b0 < nproblems; b0 += 1024) {
         const long b = b0 + tid;
         const bool on = b < nproblems && gstate[b * state_stride + 3] != 0.0;
-        const unsigned long long bal = __ballot(on);
-        if (lane == 0) wcount[wave] = __popcll(bal);
+        const bool on2 = list2 && on && gstate[b * state_stride + 5] == 1.0;
+        const unsigned long long bal = __ballot(on), bal2 = __ballot(on2);
+        if (lane == 0) { wcount[wave] = __popcll(bal); wcount2[wave] = __popcll(bal2); }
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wcount[w];
+        int off = base, off2 = base2;
+        for (int w = 0; w < wave; ++w) { off += wcount[w]; off2 += wcount2[w]; }
         if (on) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)b;
+        if (on2) list2[off2 + __popcll(bal2 & ((1ull << lane) - 1ull))] = (int)b;
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wcount[w]; base += t; }
+        if (tid == 0) { int t = 0, t2 = 0; for (int w = 0; w < 16; ++w) { t += wcount[w]; t2 += wcount2[w]; } base += t; base2 += t2; }
         __syncthreads();
     }
-    if (tid == 0) { *count = base; if (host_count) *host_count = base; }
+    if (tid == 0) { *count = base; if (host_count) *host_count = base; if (count2) *count2 = base2; if (host_count2) *host_count2 = base2; }
 }
 
 // table[g][q][lane] = state_b[8 + 2P + q], q < 2P + 2L (c_old | c_new | k_old | k_new), b = list[64 g + lane] (live problems only); row

@@ -70,7 +70,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     if (dense) {
         if ((rc = ensure(m, src->Xt, (size_t)ntiles16 * 16 * src->PA * sizeof(double)))) return rc;
         if ((rc = ensure(m, m->ctable, (size_t)ngroups * table_rows * 64 * sizeof(double)))) return rc;
-        if ((rc = ensure(m, m->nmlist, ((size_t)nproblems + 1) * sizeof(int)))) return rc;
+        if ((rc = ensure(m, m->nmlist, 2 * ((size_t)nproblems + 1) * sizeof(int)))) return rc;      // [count | live problems] + [count | those that ask for the pass over all rows]
         const void* ck = counts8 ? (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, true> : (const void*)nm_conv_dense_kernel<16, 8, true, true>)
                                  : (dense_whole ? (const void*)nm_conv_dense_kernel<16, 8, false, false> : (const void*)nm_conv_dense_kernel<16, 8, true, false>);
         if ((rc = allow_lds(m, ck, dense_use_lds))) return rc;
@@ -120,6 +120,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     }
     m->last_nm_codes = use_codes ? 1 : 0;
     m->last_nm_problems = nproblems;
+    m->last_nm_exact = 0;
     m->last_nm_mfma = use_mfma ? 1 : 0;
     if (cat && (rc = ensure(m, m->gSm, (size_t)nproblems * cov_doubles(m->Pm) * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmstate, (size_t)nproblems * st_doubles * sizeof(double)))) return rc;
@@ -128,6 +129,11 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const bool k16 = cat && m->cat_pure && N <= 65535 && m->tune.nm_k16 != 0;
     const size_t wave_lds = (size_t)nmw::lds_doubles(P, m->Pm, L, m->kmax) * sizeof(double);
     const bool wave_step = k16 && nm_wave_step_planned(m);
+    // round 6: the wave step stops on its own upper bound and needs the pass only to hear "go on" -- a lower bound from the first row chunks says that as surely as the
+    // exact sum (kernels_nmw.h); what it leaves open gets the full pass in a launch of its own.  The int8-product pass of all-indicator models only.
+    // (data sets of a few hundred rows: a pass is a few row chunks and a launch floor either way -- nothing to save, one more list to file)
+    const bool sub_pass = use_mfma && !m->stage1 && m->tune.nm_subset != 0 && wave_step && N >= 1024;
+    const int nsub = sub_pass ? std::max(1, m->tune.nm_subset) : 0;      // the safety factor of the rows a problem asks for (kernels_nmw.h); 0: every pass over all rows
     if (counts16_ready && !wave_step) return fail(m, PLSPM_E_STATE, "non-metric solver: uint16 counts without the wave step");
     m->last_nm_wave = wave_step ? 1 : 0;
     m->last_nm_direct16 = counts16_ready ? 1 : 0;
@@ -200,10 +206,14 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     //  counter to clear, no copy operation: two tiny launches and their gaps less per iteration, 35 of ~590 us at three iterations)
     const bool flag_from_list = dense && !m->stage1;
     // (instantiations: LMAX 2 / 4 / 6 / 8 LVs x at most 8 categories per MV -- two waves per SIMD -- or at most 16 -- ten-point items; one wave per SIMD, 512 registers)
-    auto wave_kernel = m->cmax <= 8 ? (L <= 2 ? nmw::nmw_step_kernel<2, 8> : L <= 4 ? nmw::nmw_step_kernel<4, 8> : L <= 6 ? nmw::nmw_step_kernel<6, 8> : nmw::nmw_step_kernel<8, 8>)
-                                    : (L <= 2 ? nmw::nmw_step_kernel<2, 16> : L <= 4 ? nmw::nmw_step_kernel<4, 16> : L <= 6 ? nmw::nmw_step_kernel<6, 16> : nmw::nmw_step_kernel<8, 16>);
+    using nmw::nmw_step_kernel;
+    auto wave_kernel = sub_pass ? (m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, true> : L <= 4 ? nmw_step_kernel<4, 8, true> : L <= 6 ? nmw_step_kernel<6, 8, true> : nmw_step_kernel<8, 8, true>)
+                                                : (L <= 2 ? nmw_step_kernel<2, 16, true> : L <= 4 ? nmw_step_kernel<4, 16, true> : L <= 6 ? nmw_step_kernel<6, 16, true> : nmw_step_kernel<8, 16, true>))
+                                : (m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, false> : L <= 4 ? nmw_step_kernel<4, 8, false> : L <= 6 ? nmw_step_kernel<6, 8, false> : nmw_step_kernel<8, 8, false>)
+                                                : (L <= 2 ? nmw_step_kernel<2, 16, false> : L <= 4 ? nmw_step_kernel<4, 16, false> : L <= 6 ? nmw_step_kernel<6, 16, false> : nmw_step_kernel<8, 16, false>));
     if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
-    for (int it = 0; it <= m->max_iter + 1; ++it) {
+    // (round 6: a problem whose lower bound decided nothing sits one launch out while the pass over all rows runs for it -- at most once per step)
+    for (int it = 0; it <= (sub_pass ? 2 : 1) * (m->max_iter + 1); ++it) {
         if (it >= 1 && dense && m->tune.nm_live != 0) {            // (*h_flag: the count behind the previous step == the length of the list its pass built)
             const long nlive = *m->h_flag;
             if (nlive >= 1 && nlive < nproblems) { lgrid = dim3((unsigned)nlive); live = (const int*)m->nmlist.p + 1; }
@@ -222,7 +232,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                                        0, cat_fast, (unsigned short*)m->gK16.p, ld16, (const int*)nullptr);
             }
             hipLaunchKernelGGL(wave_kernel, lgrid, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
-                               (const unsigned short*)m->gK16.p, ld16, fuse, live);
+                               (const unsigned short*)m->gK16.p, ld16, fuse, live, nsub);
         } else
         launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
@@ -244,15 +254,34 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
             }
             if (dense) {
                 int* live_list = (int*)m->nmlist.p;                            // [count | ids of the problems still iterating, in problem order]
+                int* full_list = live_list + nproblems + 1;                    // [count | ids of the live problems that ask for the pass over all rows] (round 6)
+                int* h_full = (int*)m->h_flag + 1;
+                if (sub_pass) *h_full = 0;
                 hipLaunchKernelGGL(active_list_kernel, dim3(1), dim3(1024), 0, m->stream, conv_state, conv_stride, nproblems, live_list + 1, live_list,
-                                   flag_from_list ? (int*)m->h_flag : (int*)nullptr);
+                                   flag_from_list ? (int*)m->h_flag : (int*)nullptr, sub_pass ? full_list + 1 : (int*)nullptr, sub_pass ? full_list : (int*)nullptr,
+                                   (sub_pass && flag_from_list) ? h_full : (int*)nullptr);
                 if (flag_from_list) HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
                 if (use_mfma) {
+                    auto pass_kernel = KS == 1 ? nmp::conv_mfma_kernel<4, 1> : nmp::conv_mfma_kernel<4, 2>;
                     hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16 * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, KS, conv_boff, (const int*)(live_list + 1),
                                        (const int*)live_list, (uint4*)m->tab8.p, (double2*)m->scl8.p);
-                    auto pass_kernel = KS == 1 ? nmp::conv_mfma_kernel<4, 1> : nmp::conv_mfma_kernel<4, 2>;
                     hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ng16 + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
-                                       (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(live_list + 1), (const int*)live_list, part, nparts, tpc);
+                                       (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(live_list + 1), (const int*)live_list, part, nparts, tpc, nparts,
+                                       sub_pass ? conv_state : (const double*)nullptr, conv_stride);
+                    if (sub_pass && flag_from_list) {
+                        // the problems whose lower bound decided nothing (few, as a rule none): all row chunks, fixed-order sums -- the host knows their number
+                        // by now (the list kernel wrote it to pinned memory; the passes above run meanwhile)
+                        HIPCHK(m, hipEventSynchronize(m->ev_flag));
+                        const long nfull = *h_full;
+                        if (nfull > 0) {
+                            m->last_nm_exact += (int)nfull;
+                            const long ngf = (nfull + 15) / 16;
+                            hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ngf * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, KS, conv_boff, (const int*)(full_list + 1),
+                                               (const int*)full_list, (uint4*)m->tab8.p, (double2*)m->scl8.p);
+                            hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ngf + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
+                                               (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(full_list + 1), (const int*)full_list, part, nparts, tpc, nparts, (const double*)nullptr, 0L);
+                        }
+                    }
                 } else {
                 hipLaunchKernelGGL(coef_table_kernel, dim3((unsigned)ngroups, (unsigned)((2 * src->P + 2 * L + 1 + 63) / 64)), dim3(256), 0, m->stream, conv_state, conv_stride, src->P, L,
                                    (const int*)(live_list + 1), (const int*)live_list, (double*)m->ctable.p);

@@ -251,14 +251,20 @@ def test_stop_rule_pass_as_int8_matrix_product(scale, scheme):
     model = orc.Model(blocks, C, "AAAAAA", scheme, True, tol=1e-6, scales=[scale] * 60)
     nm, g = gpu_fit_cat(likert, model)
     assert nm.get_option("nm_mfma") == 1
+    sub = nm.bootstrap(330, seed=8)                       # round 6 default: the step's own upper bound stops, the pass over the first row chunks says "go on"
+    bound = nm.nonmetric_criteria(330)
+    nm.set_option("nm_subset", 0)                           # ... and every pass over all rows, as in round 5: what the two pass kernels are compared on
     on = nm.bootstrap(330, seed=8)
     assert nm.get_option("last_nm_mfma") == 1 and nm.get_option("last_nm_codes") == 1 and nm.get_option("last_gram_path") == 2
     crit_on = nm.nonmetric_criteria(330)
+    assert np.array_equal(sub[0], on[0]) and np.array_equal(sub[1], on[1]) and np.array_equal(sub[2], on[2])
+    okb = on[1] == 0
+    assert np.all(bound[okb] >= crit_on[okb] * (1 - 1e-9)) and np.all(bound[okb] < 1e-6)      # the value a replicate stopped on: the upper bound of the exact criterion
     nm.set_option("nm_mfma", 0)
     off = nm.bootstrap(330, seed=8)
     assert nm.get_option("last_nm_mfma") == 0 and nm.get_option("last_nm_codes") == 1
     crit_off = nm.nonmetric_criteria(330)
-    nm.set_option("nm_mfma", 1)
+    nm.set_option("nm_mfma", 1); nm.set_option("nm_subset", 4)
     assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2])
     assert np.array_equal(on[0], off[0])
     assert np.all(np.isfinite(crit_off)) and np.all(crit_off > 0) and np.all(crit_off[on[1] == 0] < 1e-6)
@@ -289,14 +295,17 @@ def test_matrix_product_pass_on_blocks_of_up_to_128_columns(shape):
         data = np.clip(np.round(5.5 + 2.0 * Z), 1, 10)
         model = orc.Model(blocks, C, "AA", "path", True, tol=1e-6, scales=["ORD", "NOM"] * 8)
     nm, g = gpu_fit_cat(data, model)
+    sub = nm.bootstrap(200, seed=12)                      # (round 6 default: upper bound + lower bound from the first row chunks)
+    nm.set_option("nm_subset", 0)
     on = nm.bootstrap(200, seed=12)
     assert nm.get_option("last_nm_mfma") == 1 and nm.get_option("last_nm_wave") == 1 and nm.get_option("last_gram_path") == 2
     crit_on = nm.nonmetric_criteria(200)
+    assert np.array_equal(sub[0], on[0]) and np.array_equal(sub[1], on[1]) and np.array_equal(sub[2], on[2])
     nm.set_option("nm_mfma", 0)
     off = nm.bootstrap(200, seed=12)
     assert nm.get_option("last_nm_mfma") == 0 and nm.get_option("last_nm_codes") == 1
     crit_off = nm.nonmetric_criteria(200)
-    nm.set_option("nm_mfma", 1)
+    nm.set_option("nm_mfma", 1); nm.set_option("nm_subset", 4)
     assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2]) and np.array_equal(on[0], off[0])
     assert_close(crit_on, crit_off, 1e-9, 1e-20)
     ok = np.flatnonzero(on[1] == 0)
@@ -433,7 +442,11 @@ def test_full_size_categorical_bootstrap_properties():
     model = orc.Model(blocks, C, "AAAAAA", "path", True, tol=1e-6, scales=["ORD"] * 60)
     nm, g = gpu_fit_cat(likert, model)
     B = 2000
+    sub = nm.bootstrap(B, seed=1)                           # round 6 default: the step's upper bound stops, a lower bound from the first row chunks says "go on"
+    assert nm.get_option("last_nm_exact") == 0              # ... and decides every step of this workload without the pass over all rows
+    nm.set_option("nm_subset", 0)                           # the comparisons below: every pass over all rows (round 5's protocol)
     base = nm.bootstrap(B, seed=1)
+    assert np.array_equal(sub[0], base[0]) and np.array_equal(sub[1], base[1]) and np.array_equal(sub[2], base[2])
     assert nm.get_option("last_nm_wave") == 1 and nm.get_option("last_nm_mfma") == 1 and nm.get_option("last_nm_direct16") == 1 and nm.get_option("last_gram_path") == 2
     assert np.all(base[1] == 0) and base[2].min() >= 3
     crit = nm.nonmetric_criteria(B)

@@ -30,6 +30,8 @@ Xaug = np.ascontiguousarray(np.concatenate(cols, axis=1))
 m = _native.NativeModel(np.array(boff, dtype=np.int32), C.astype(np.uint8), np.zeros(6, dtype=np.int32), 2, True, 100, 1e-6, 0, nonmetric=True,
                         categorical=(np.array(mv_off, dtype=np.int32), np.ones(60, dtype=np.int32)))
 m.upload(Xaug)
+for kv in filter(None, os.environ.get("CAT_BENCH_OPTS", "").split(",")):      # any set_option key=value (A/B runs), e.g. CAT_BENCH_OPTS=nm_subset=0
+    m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if "CAT_NM_WAVE" in os.environ: m.set_option("nm_wave", int(os.environ["CAT_NM_WAVE"]))        # A/B: 0 = the workgroup step of rounds 2-4 (nmg_kernel<1>)
 if "CAT_NM_MFMA" in os.environ: m.set_option("nm_mfma", int(os.environ["CAT_NM_MFMA"]))      # A/B: 0 = the stop-rule pass on category codes (LDS lookups) instead of the int8 matrix product
 if "CAT_NM_DIRECT16" in os.environ: m.set_option("nm_direct16", int(os.environ["CAT_NM_DIRECT16"]))      # A/B: 0 = packed fp64 moment matrices + the scatter pass (nmg_kernel<3>)
