@@ -50,8 +50,13 @@ __global__ void __launch_bounds__(256) ind8_kernel(const unsigned short* __restr
 
 // digit planes of the live problems' score maps.  One wave per live slot (grid: slots rounded up to whole groups of 16; the padding slots write
 // zeros: weight 0 in the pass).  state_b[8 + 2 P ..]: c_old[P] | c_new[P] | k_old[L] | k_new[L] (coef_table_kernel reads the same run).
+// Virtual problems (round 6, vj != null: the verification of the one-launch categorical solver, kernels_nmw.h ONE): slot = (replicate list[slot], step vj[slot]); its
+// old / new maps are the rows vj - 1 and vj of the replicate's map store -- gstate = the coefficient rows [steps][P] (adjacent rows ARE c_old | c_new), kmaps = the
+// constant rows [steps][L + 1] with the step's own bound behind them, from which the slot's row-chunk need is filed in vneed (nsub tol / bound of the chunks).
 __global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ gstate, long state_stride, int P, int L, int KS, const int* __restrict__ boff, const int* __restrict__ list,
-                                                    const int* __restrict__ count, uint4* __restrict__ tab8, double2* __restrict__ scl) {
+                                                    const int* __restrict__ count, uint4* __restrict__ tab8, double2* __restrict__ scl, const int* __restrict__ vj = nullptr,
+                                                    const double* __restrict__ kmaps = nullptr, long kstride = 0, int* __restrict__ vneed = nullptr, double tol = 0.0, int nsub = 0,
+                                                    int nparts = 0) {
     __shared__ __attribute__((aligned(16))) unsigned char dig[S][64];
     const int n = *count;
     const long slot = blockIdx.x;
@@ -59,7 +64,15 @@ __global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ g
     const long g = slot >> 4;
     const int i = (int)(slot & 15), lane = threadIdx.x;
     const bool live = slot < n;
-    const double* st = live ? gstate + (long)list[slot] * state_stride + 8 + 2 * P : nullptr;
+    const double* st = live ? (vj ? gstate + (long)list[slot] * state_stride + (long)(vj[slot] - 1) * P : gstate + (long)list[slot] * state_stride + 8 + 2 * P) : nullptr;
+    const double* kk = (live && vj) ? kmaps + (long)list[slot] * kstride + (long)(vj[slot] - 1) * (L + 1) : nullptr;
+    if (vneed && live && lane == 0) {
+        const double ub = kk[(L + 1) + L];                        // the bound of step vj
+        int need = nparts;
+        const double want = (double)nsub * tol / ub * (double)nparts;
+        if (want >= 0.0 && want < 0.75 * (double)nparts) need = (int)want + 1;
+        vneed[slot] = need;
+    }
     for (int l = 0; l < L; ++l) {
         const int p0 = boff[l], nb = boff[l + 1] - p0;
         for (int m = 0; m < 2; ++m) {
@@ -94,7 +107,7 @@ __global__ void __launch_bounds__(64) planes_kernel(const double* __restrict__ g
                 }
                 __syncthreads();
             }
-            if (lane == 0) scl[((g * L + l) * 2 + m) * 16 + i] = make_double2(unit, live ? st[2L * P + (long)m * L + l] : 0.0);
+            if (lane == 0) scl[((g * L + l) * 2 + m) * 16 + i] = make_double2(unit, live ? (vj ? kk[(long)m * (L + 1) + l] : st[2L * P + (long)m * L + l]) : 0.0);
         }
     }
 }
@@ -117,7 +130,8 @@ __device__ __forceinline__ double digits_value(int d0, int d1, int d2, int d3, i
 template <int NW, int KS = 1>
 __global__ void __launch_bounds__(64 * NW) conv_mfma_kernel(const uint4* __restrict__ ind8, long ntiles, int L, const unsigned* __restrict__ cd, long MT, const uint4* __restrict__ tab8,
                                                              const double2* __restrict__ scl, const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial,
-                                                             int nparts, int tpc, int nrun, const double* __restrict__ gstate, long state_stride) {
+                                                             int nparts, int tpc, int nrun, const double* __restrict__ gstate, long state_stride, const int* __restrict__ vneed = nullptr,
+                                                             double* __restrict__ vsum = nullptr, int by_slot = 0) {
     const int lane = threadIdx.x & 63, i = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nlive = *count;
@@ -133,6 +147,10 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_kernel(const uint4* __restr
         // round 6: every problem names the row chunks it needs (state word 7, kernels_nmw.h: enough for the lower bound to clear the tolerance); a wave whose
         // sixteen problems all need fewer than this chunk has nothing to do
         const int need = live ? (int)gstate[b * state_stride + 7] : 0;
+        if (chunk >= wv::allreduce(need, [](int a, int c) { return a > c ? a : c; })) return;
+    }
+    if (vneed) {                                                 // (virtual problems: the need filed by planes_kernel)
+        const int need = live ? vneed[slot] : 0;
         if (chunk >= wv::allreduce(need, [](int a, int c) { return a > c ? a : c; })) return;
     }
     const long t0 = (long)chunk * tpc, t1 = min(ntiles, t0 + tpc);
@@ -178,7 +196,11 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_kernel(const uint4* __restr
     double x, y;
     wv::swap16(acc, x, y); acc = x + y;
     wv::swap32(acc, x, y); acc = x + y;
-    if (live && kg == 0) partial[b * nparts + chunk] = acc;
+    if (live && kg == 0) {
+        // by_slot: filed under the (virtual) slot; vsum: the chunks a slot asked for added up atomically -- a lower bound that only has to clear the tolerance
+        if (vsum) { if (!vneed || chunk < vneed[slot]) unsafeAtomicAdd(&vsum[slot], acc); }
+        else partial[(by_slot ? slot : b) * nparts + chunk] = acc;
+    }
 }
 
 }  // namespace nmp

@@ -220,10 +220,17 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
 
 // SUB (round 6): the step bounds its own criterion and stops on it, the pass behind it reads the rows each problem asks for (nsub > 0) -- an instantiation of its
 // own so that the launches without it (data sets of a few hundred rows, the A/B option) keep the register allocation they had.
-template <int LMAX, int CMAX = 8, bool SUB = false>
+// ONE (round 6, needs SUB): prepare-to-finish of a problem in ONE launch -- the steps in a loop, each stopping on its own upper bound and going on speculatively
+// otherwise, the score map (and the bound) of every step left in cmaps / kmaps for the verification pass on the observations (plspm_nonmetric.hip
+// run_categorical_wave; the Scale.NUM solver of solver_wave16.h does the same); force[b] > 0: stop behind exactly that many steps (the replay of a problem
+// whose stop the verification moved).  The state still travels through the problem's block in global memory between steps (the same loads and stores as the
+// per-launch form, behind a device-scope fence): what goes away is the launch boundary -- and with it the passes over all rows and the host round trips.
+struct NmwMaps { double* c; long cstride; double* k; long kstride; int* steps; const int* force; double bound_scale = 1.0; };      // (bound_scale: test seam, option nm_bound_shift -- the bound times 2^k is still an upper bound)
+template <int LMAX, int CMAX = 8, bool SUB = false, bool ONE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 8 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
                                                       const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
-                                                      int fuse_finish, const int* __restrict__ live, int nsub) {
+                                                      int fuse_finish, const int* __restrict__ live, int nsub, NmwMaps mp = NmwMaps{}) {
+    static_assert(!ONE || SUB, "the one-launch form stops on the step's own bound");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long b = live ? live[blockIdx.x] : (long)blockIdx.x;      // (kernels_nonmetric.h nm_kernel: the live list of the previous step)
     const int lane = threadIdx.x;
@@ -269,8 +276,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     // sum over the tolerance (scal[7], below; nsub = the safety factor).  Every term of the criterion is non-negative, so that sum is a LOWER bound: at or above the tolerance it says "go on" as surely as the exact value would (the step itself
     // stops on the UPPER bound, below); below the tolerance it decides nothing -- the problem asks for the remaining chunks (scal[5] = 1: the host runs the
     // full pass for such problems), sits this launch out and decides on the exact value in the next one.
-    const int iteration = (int)st.scal[2];
-    if (SUB && iteration > 0 && st.scal[5] == 2.0) {                    // (words 5 .. 7 of a freshly prepared problem are whatever the buffer held: the first step writes them)
+    int iteration = (int)st.scal[2];
+    if (!ONE && SUB && iteration > 0 && st.scal[5] == 2.0) {                    // (words 5 .. 7 of a freshly prepared problem are whatever the buffer held: the first step writes them)
         // the previous launch stopped this problem on its own upper bound and left the finish to this one: behind the step in the same wave it lengthened the
         // launch by its whole duration (the steppers of a launch hide the finishers' time, not the other way round: 1.58 -> 1.96 ms of step launches per 1,000)
         if (lane == 0) { st.scal[3] = 0.0; st.scal[5] = 0.0; }
@@ -280,7 +287,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         }
         return;
     }
-    if (iteration > 0) {
+    if (!ONE && iteration > 0) {
         const int need = (int)st.scal[7];                         // row chunks the pass behind the last step read for this problem (set at the end of that step)
         const bool exact = !SUB || nsub <= 0 || need >= nparts || st.scal[5] != 0.0;
         const int np = exact ? nparts : need;
@@ -306,6 +313,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     }
     NMW_MARK(20);
     const double n = st.scal[0], inv_n = 1.0 / n, corr2 = n / (n - 1.0);
+    for (;;) {                                                    // (ONE: a trip per step; otherwise one trip)
     // new -> old (the stop-rule pass of this iteration compares them), and the step's inputs into LDS
     for (int j = lane; j < QP; j += 64) {
         double cj = 0.0, tqj = 0.0, mj = 0.0;
@@ -322,6 +330,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
     if (lane < L) { const double k = iteration > 0 ? st.k_new[lane] : st.k_old[lane]; if (iteration > 0) st.k_old[lane] = k; kold[lane] = k; }
     if (lane == 0) ws.scal[3] = (double)ST_OK;
     __syncthreads();
+    if (ONE && iteration == 0 && mp.c) {                         // the map of the initial scores: step 1 is verified against it
+        for (int j = lane; j < Q; j += 64) mp.c[b * mp.cstride + j] = c_s[j];
+        if (lane < L) mp.k[b * mp.kstride + lane] = kold[lane];
+        if (lane == 0) mp.k[b * mp.kstride + L] = 0.0;
+    }
 
     // ---- stream 1: V[j, m] = <col_j, y_m> = mean_j k_m + sum over the rows q of block m of Mn[q][j] c_q, for this lane's eight columns
     const int j0 = CPL * lane;
@@ -626,12 +639,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
             }
         }
         ub *= n;
-        bound_stop = ub < md.tol * (1.0 - 1e-9);
+        bound_stop = ub * (ONE ? mp.bound_scale : 1.0) < md.tol * (1.0 - 1e-9);
         // rows the pass needs: the criterion is nearly always a few sign flips below its bound and the rows are exchangeable, so a fraction nsub tol / ub of them
         // carries the lower bound over the tolerance (nsub = 4: four times what the expectation asks for); all of them when that is most of them anyway
         const double want = (double)nsub * md.tol / ub * (double)nparts;
         if (want >= 0.0 && want < 0.75 * (double)nparts) need_chunks = floor(want) + 1.0;
         if (lane == 0) st.scal[6] = ub;
+    }
+    if constexpr (ONE) {
+        // the map of this step beside the state (MV lanes: their columns' coefficients; LV lanes: the constants; lane 0: the bound), then stop or go on
+        const long mrow = (long)(iteration + 1);
+        if (mp.c) {
+            if (is_mv) {
+                const double an = wn / sdl[lv];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) mp.c[b * mp.cstride + mrow * Q + jm0 + c] = an * tqn[c];
+            }
+            if (lane < L) mp.k[b * mp.kstride + mrow * (L + 1) + lane] = akk[lane];
+            if (lane == 0) mp.k[b * mp.kstride + mrow * (L + 1) + L] = st.scal[6];
+        }
+        ++iteration;
+        const int forced = mp.force ? mp.force[b] : 0;
+        const bool stop = (forced > 0 ? iteration >= forced : bound_stop) || iteration > md.max_iter;
+        if (lane == 0) {
+            st.scal[2] = (double)iteration;
+            if (ws.scal[3] != (double)ST_OK && st.scal[1] == (double)ST_OK) st.scal[1] = ws.scal[3];
+            if (stop) {
+                st.scal[3] = 0.0; st.scal[4] = st.scal[6];
+                if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED;      // (weights.py:183-186)
+                if (mp.steps && !mp.force) mp.steps[b] = iteration;
+            }
+        }
+        __threadfence();                                         // the state written above is read back by other lanes: at the top of the next trip, or by the finish
+        __syncthreads();
+        if (stop) {
+            if (fuse_finish) finish<CMAX>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+            return;
+        }
+        continue;
     }
     if (lane == 0) {
         st.scal[2] = (double)(iteration + 1);
@@ -647,6 +692,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         }
         if (!bound_stop || fuse_finish) atomicAdd(nactive, 1);
     }
+    return;
+    }                                                             // (the step loop)
 }
 
 }  // namespace nmw

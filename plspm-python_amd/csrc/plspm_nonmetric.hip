@@ -212,6 +212,93 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                                 : (m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, false> : L <= 4 ? nmw_step_kernel<4, 8, false> : L <= 6 ? nmw_step_kernel<6, 8, false> : nmw_step_kernel<8, 8, false>)
                                                 : (L <= 2 ? nmw_step_kernel<2, 16, false> : L <= 4 ? nmw_step_kernel<4, 16, false> : L <= 6 ? nmw_step_kernel<6, 16, false> : nmw_step_kernel<8, 16, false>));
     if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
+    // ---- round 6: the whole batch in ONE solver launch + verification (kernels_nmw.h ONE; the categorical counterpart of run_nonmetric_wave) --------------------------------
+    // All-indicator, all-Mode-A models on the wave step with the int8 stop-rule product, not a stage of a HOC pair.  The solver iterates on its own upper bound and
+    // leaves every step's score map behind; the verification evaluates the criterion of every step a replicate continued behind on the row chunks that step asks for
+    // (a lower bound), the exact pass takes what that leaves open, a replicate whose exact criterion was below the tolerance is replayed with the reference's stop.
+    const bool one_launch = sub_pass && finish && !m->stage2 && !m->stage1 && counts8 && cd8 && m->tune.nm_cat_one != 0 && nproblems <= 0x7fffffffL;
+    m->last_nm_one = one_launch ? 1 : 0;
+    if (one_launch) {
+        constexpr int JR = 8;                                // steps verified per round (six to nine iterations is the rule: one round, one host read-back)
+        const long capV = nproblems * JR, ng16V = (capV + 15) / 16;
+        const long cstride = (long)(m->max_iter + 2) * P, kstride = (long)(m->max_iter + 2) * (L + 1);
+        if ((rc = ensure(m, m->nmw_maps, (size_t)nproblems * (cstride + kstride) * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->nmw_ints, (size_t)(3 * nproblems + 5 * capV + 16) * sizeof(int)))) return rc;
+        if ((rc = ensure(m, m->nmw_vsum, (size_t)capV * sizeof(double)))) return rc;
+        if ((rc = ensure(m, m->tab8, (size_t)ng16V * L * 2 * nmp::S * KS * 64 * sizeof(uint4)))) return rc;
+        if ((rc = ensure(m, m->scl8, (size_t)ng16V * L * 2 * 16 * sizeof(double2)))) return rc;
+        double* cmaps = (double*)m->nmw_maps.p;
+        double* kmaps = cmaps + nproblems * cstride;
+        int* ip = (int*)m->nmw_ints.p;
+        int* steps = ip; ip += nproblems;
+        int* force = ip; ip += nproblems;
+        int* fixlist = ip; ip += nproblems;
+        int* vb = ip; ip += capV;
+        int* vj = ip; ip += capV;
+        int* fb = ip; ip += capV;
+        int* fj = ip; ip += capV;
+        int* vneed = ip; ip += capV;
+        int* cnt = ip;
+        double* vsum = (double*)m->nmw_vsum.p;
+        int* h = (int*)m->h_flag;                                // pinned: [0] most steps of a replicate, [1] flagged, [2] to replay
+        m->last_nm_flagged = 0; m->last_nm_replayed = 0;
+        auto one_kernel = m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, true, true> : L <= 4 ? nmw_step_kernel<4, 8, true, true> : L <= 6 ? nmw_step_kernel<6, 8, true, true> : nmw_step_kernel<8, 8, true, true>)
+                                       : (L <= 2 ? nmw_step_kernel<2, 16, true, true> : L <= 4 ? nmw_step_kernel<4, 16, true, true> : L <= 6 ? nmw_step_kernel<6, 16, true, true> : nmw_step_kernel<8, 16, true, true>);
+        if ((rc = allow_lds(m, (const void*)one_kernel, wave_lds))) return rc;
+        auto pass_kernel = KS == 1 ? nmp::conv_mfma_kernel<4, 1> : nmp::conv_mfma_kernel<4, 2>;
+        auto solve = [&](long count, const int* list, const int* forced) {
+            ProfScope ps(m, PLSPM_K_SOLVER);
+            const dim3 g1((unsigned)count);
+            if (counts16_ready)
+                hipLaunchKernelGGL(nmg_kernel<4>, g1, dim3(256), lds, m->stream, md, cd, mdm, (const double*)nullptr, 0L, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                                   0, cat_fast, (unsigned short*)m->gK16.p, ld16, list);
+            else
+                hipLaunchKernelGGL(nmg_kernel<3>, g1, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
+                                   0, cat_fast, (unsigned short*)m->gK16.p, ld16, list);
+            hipLaunchKernelGGL(one_kernel, g1, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)nullptr, nparts, nact,
+                               (const unsigned short*)m->gK16.p, ld16, 1, list, nsub, nmw::NmwMaps{forced ? nullptr : cmaps, cstride, forced ? nullptr : kmaps, kstride, steps, forced, std::ldexp(1.0, m->tune.nm_bound_shift)});
+        };
+        solve(nproblems, nullptr, nullptr);
+        bool any_flagged = false;
+        for (int j0 = 1;; j0 += JR) {
+            {
+                ProfScope ps(m, PLSPM_K_SCORES);
+                hipLaunchKernelGGL(nm_vlist_kernel<JR>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (long)nproblems, j0, vb, vj, cnt, vsum, force, h);
+                hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16V * 16)), dim3(64), 0, m->stream, (const double*)cmaps, cstride, P, L, KS, (const int*)m->d_boff, (const int*)vb,
+                                   (const int*)cnt, (uint4*)m->tab8.p, (double2*)m->scl8.p, (const int*)vj, (const double*)kmaps, kstride, vneed, m->tol, nsub, nparts);
+                hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ng16V + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8, (long)cd8_MT,
+                                   (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)vb, (const int*)cnt, (double*)nullptr, nparts, tpc, nparts, (const double*)nullptr, 0L,
+                                   (const int*)vneed, vsum, 1);
+                hipLaunchKernelGGL(nm_vflag_kernel, dim3(1), dim3(1024), 0, m->stream, (const double*)vsum, (const int*)vb, (const int*)vj, (const int*)cnt, m->tol, fb, fj, cnt + 1, h + 1);
+            }
+            HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+            HIPCHK(m, hipEventSynchronize(m->ev_flag));
+            const int most = h[0], flagged = h[1];
+            if (flagged > 0) {
+                ProfScope ps(m, PLSPM_K_SCORES);
+                any_flagged = true;
+                m->last_nm_flagged += flagged;
+                const long ngf = ((long)flagged + 15) / 16;
+                if ((rc = ensure(m, m->nmpartial, (size_t)std::max<long>(flagged, nproblems) * nparts * sizeof(double)))) return rc;
+                hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ngf * 16)), dim3(64), 0, m->stream, (const double*)cmaps, cstride, P, L, KS, (const int*)m->d_boff, (const int*)fb,
+                                   (const int*)(cnt + 1), (uint4*)m->tab8.p, (double2*)m->scl8.p, (const int*)fj, (const double*)kmaps, kstride, (int*)nullptr, m->tol, 0, nparts);
+                hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ngf + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8, (long)cd8_MT,
+                                   (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)fb, (const int*)(cnt + 1), (double*)m->nmpartial.p, nparts, tpc, nparts, (const double*)nullptr, 0L,
+                                   (const int*)nullptr, (double*)nullptr, 1);
+                hipLaunchKernelGGL(nm_vcheck_kernel, dim3((unsigned)flagged), dim3(64), 0, m->stream, (const double*)m->nmpartial.p, nparts, (const int*)fb, (const int*)fj, (const int*)(cnt + 1),
+                                   m->tol, force);
+            }
+            if (j0 + JR > most - 1) break;
+        }
+        if (any_flagged) {
+            hipLaunchKernelGGL(nm_vfix_kernel, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (const int*)force, (long)nproblems, fixlist, cnt + 2, h + 2);
+            HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
+            HIPCHK(m, hipEventSynchronize(m->ev_flag));
+            if (h[2] > 0) { m->last_nm_replayed = h[2]; solve(h[2], fixlist, force); }
+        }
+        HIPCHK(m, hipGetLastError());
+        return 0;
+    }
     // (round 6: a problem whose lower bound decided nothing sits one launch out while the pass over all rows runs for it -- at most once per step)
     for (int it = 0; it <= (sub_pass ? 2 : 1) * (m->max_iter + 1); ++it) {
         if (it >= 1 && dense && m->tune.nm_live != 0) {            // (*h_flag: the count behind the previous step == the length of the list its pass built)
@@ -232,7 +319,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                                        0, cat_fast, (unsigned short*)m->gK16.p, ld16, (const int*)nullptr);
             }
             hipLaunchKernelGGL(wave_kernel, lgrid, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
-                               (const unsigned short*)m->gK16.p, ld16, fuse, live, nsub);
+                               (const unsigned short*)m->gK16.p, ld16, fuse, live, nsub, nmw::NmwMaps{});
         } else
         launch(it == 0 ? 0 : 1);                   // launch 0 = prepare + first step
         // The stop-rule pass is enqueued right behind the step, BEFORE the host knows whether any problem is still active: finished
@@ -264,10 +351,10 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 if (use_mfma) {
                     auto pass_kernel = KS == 1 ? nmp::conv_mfma_kernel<4, 1> : nmp::conv_mfma_kernel<4, 2>;
                     hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16 * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, KS, conv_boff, (const int*)(live_list + 1),
-                                       (const int*)live_list, (uint4*)m->tab8.p, (double2*)m->scl8.p);
+                                       (const int*)live_list, (uint4*)m->tab8.p, (double2*)m->scl8.p, (const int*)nullptr, (const double*)nullptr, 0L, (int*)nullptr, 0.0, 0, 0);
                     hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ng16 + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
                                        (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(live_list + 1), (const int*)live_list, part, nparts, tpc, nparts,
-                                       sub_pass ? conv_state : (const double*)nullptr, conv_stride);
+                                       sub_pass ? conv_state : (const double*)nullptr, conv_stride, (const int*)nullptr, (double*)nullptr, 0);
                     if (sub_pass && flag_from_list) {
                         // the problems whose lower bound decided nothing (few, as a rule none): all row chunks, fixed-order sums -- the host knows their number
                         // by now (the list kernel wrote it to pinned memory; the passes above run meanwhile)
@@ -277,9 +364,9 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                             m->last_nm_exact += (int)nfull;
                             const long ngf = (nfull + 15) / 16;
                             hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ngf * 16)), dim3(64), 0, m->stream, conv_state, conv_stride, src->P, L, KS, conv_boff, (const int*)(full_list + 1),
-                                               (const int*)full_list, (uint4*)m->tab8.p, (double2*)m->scl8.p);
+                                               (const int*)full_list, (uint4*)m->tab8.p, (double2*)m->scl8.p, (const int*)nullptr, (const double*)nullptr, 0L, (int*)nullptr, 0.0, 0, 0);
                             hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ngf + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8,
-                                               (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(full_list + 1), (const int*)full_list, part, nparts, tpc, nparts, (const double*)nullptr, 0L);
+                                               (long)cd8_MT, (const uint4*)m->tab8.p, (const double2*)m->scl8.p, (const int*)(full_list + 1), (const int*)full_list, part, nparts, tpc, nparts, (const double*)nullptr, 0L, (const int*)nullptr, (double*)nullptr, 0);
                         }
                     }
                 } else {

@@ -495,3 +495,70 @@ def test_categorical_bootstrap_beyond_one_histogram_window_takes_the_int8_route(
     assert nm.get_option("last_gram_path") == 1
     assert np.array_equal(on[2], f64[2]) and np.all(f64[1] == 0)
     assert_close(on[0], f64[0], 1e-9, 1e-12)
+
+
+def _likert_model(n, per, scheme, scale, seed, tol=1e-6):
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(n, C, per, seed=seed)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    likert = np.clip(np.round(3 + 1.1 * Z), 1, 5)
+    return likert, orc.Model(blocks, C, "AAAAAA", scheme, True, tol=tol, scales=[scale] * (6 * per))
+
+
+@pytest.mark.parametrize("scheme,scale", [("path", "ORD"), ("centroid", "NOM")])
+def test_one_launch_categorical_bootstrap_against_the_launch_by_launch_forms(scheme, scale):
+    """Round 6: a batch of an all-indicator, all-Mode-A model as ONE solver launch (kernels_nmw.h ONE: every step stops on its own upper bound of the reference's
+    score criterion, weights.py:120, or goes on speculatively, leaving its score map behind) + the verification on the observations (lower bound from the row
+    chunks a step asks for, exact pass, replay).  Bit-identical records, status and iteration counts to the launch-by-launch forms -- with the bound + row subsets
+    ("nm_cat_one" 0) and with every pass over all rows ("nm_subset" 0, round 5) --, a replicate against the oracle; then the seams: a safety factor of 1 (the lower
+    bound fails for some steps: exact pass, nothing replayed) and a bound scaled by 2^30 (every replicate overshoots: every one replayed)."""
+    from plspm import _native
+    likert, model = _likert_model(3000, 6, scheme, scale, seed=61)
+    nm, g = gpu_fit_cat(likert, model)
+    B = 400
+    one = nm.bootstrap(B, seed=4)
+    assert nm.get_option("last_nm_one") == 1 and nm.get_option("last_nm_wave") == 1 and nm.get_option("last_nm_replayed") == 0
+    nm.set_option("nm_cat_one", 0)
+    step = nm.bootstrap(B, seed=4)
+    assert nm.get_option("last_nm_one") == 0
+    nm.set_option("nm_subset", 0)
+    full = nm.bootstrap(B, seed=4)
+    nm.set_option("nm_subset", 4); nm.set_option("nm_cat_one", 1)
+    for other in (step, full):
+        assert np.array_equal(one[1], other[1]) and np.array_equal(one[2], other[2]) and np.array_equal(one[0], other[0])
+    assert np.all(one[1] == 0) and one[2].min() >= 3
+    rows = _rows_in_data_order(one[0], g["inv"], likert.shape[1], 6, nm.n_eff)
+    for r in (0, B - 1):
+        mine, its = orc.bootstrap_replicate(likert, model, _native.bootstrap_indices(4, r, likert.shape[0]), orc.correction(likert.shape[0]))
+        assert its == one[2][r]
+        assert_close(rows[r], mine, RTOL, ATOL)
+    nm.set_option("nm_subset", 1)                            # the lower bound with no safety margin: some steps are left to the exact pass, which confirms them
+    tight = nm.bootstrap(B, seed=4)
+    assert nm.get_option("last_nm_flagged") > 0 and nm.get_option("last_nm_replayed") == 0
+    assert np.array_equal(tight[0], one[0]) and np.array_equal(tight[2], one[2])
+    nm.set_option("nm_subset", 4)
+    nm.set_option("nm_bound_shift", 30)                      # a useless (but valid) bound: every replicate runs on behind the reference's stop and is moved back
+    over = nm.bootstrap(B, seed=4)
+    assert nm.get_option("last_nm_replayed") == B
+    assert np.array_equal(over[1], one[1]) and np.array_equal(over[2], one[2])
+    assert_close(over[0], one[0], 1e-12, 1e-14)
+    nm.set_option("nm_bound_shift", 0)
+
+
+def test_one_launch_categorical_not_converged_and_sharding():
+    """max_iter reached inside the one launch: PLSPM_NOT_CONVERGED at max_iter + 1 steps (weights.py:183-186), as the launch-by-launch form reports it; and a
+    replicate's record does not depend on the batch it travels in."""
+    likert, model = _likert_model(2000, 5, "factorial", "ORD", seed=67)
+    nm, g = gpu_fit_cat(likert, model)
+    base = nm.bootstrap(300, seed=2)
+    assert nm.get_option("last_nm_one") == 1
+    part = nm.bootstrap(120, seed=2, rep_offset=100)
+    assert np.array_equal(part[0], base[0][100:220]) and np.array_equal(part[2], base[2][100:220])
+    stubborn = orc.Model(model.blocks, model.C, "AAAAAA", "factorial", True, tol=1e-300, max_iter=6, scales=["ORD"] * 30)
+    nm2, _ = gpu_fit_cat(likert, stubborn)
+    one = nm2.bootstrap(200, seed=3)
+    assert nm2.get_option("last_nm_one") == 1
+    nm2.set_option("nm_cat_one", 0)
+    step = nm2.bootstrap(200, seed=3)
+    assert np.array_equal(one[1], step[1]) and np.array_equal(one[2], step[2])
+    assert np.all(one[1][one[2] == 7] == 1) and np.any(one[2] == 7)
