@@ -462,3 +462,18 @@ def test_ordnom_missing_probe_pins_the_reference_behaviour_this_backend_mirrors(
             moved = r.get("max_abs_weight_change_under_row_permutation", 0.0) > 1e-2 or r["rows_permuted"]["outcome"] == "raises"
             assert zero or moved, r["case"]
     assert issubclass(MissingDataError, Exception) and MissingDataError.__name__ == named[0]["exception"].rsplit(".", 1)[1]
+
+
+def test_gather_mode_env_is_validated(monkeypatch):
+    """PLSPM_GATHER picks the exchange of a multi-GPU bootstrap (plspm/parallel.py): all (ONE ncclAllGather per sub-batch) or root (the gather to rank 0 the reference's parent
+    process performs, bootstrap.py:96-111); anything else is a ValueError naming the choices -- no silent default."""
+    from plspm import parallel
+    monkeypatch.delenv("PLSPM_GATHER", raising=False)
+    assert parallel.gather_to_root() is False
+    monkeypatch.setenv("PLSPM_GATHER", "root")
+    assert parallel.gather_to_root() is True
+    monkeypatch.setenv("PLSPM_GATHER", "ALL")
+    assert parallel.gather_to_root() is False
+    monkeypatch.setenv("PLSPM_GATHER", "ring")
+    with pytest.raises(ValueError, match="'all' or 'root'"):
+        parallel.gather_to_root()

@@ -32,6 +32,11 @@ timeout 900 python tools/fit_bench.py c2 c5 2>&1 | grep "^{" > $O/fit_bench.json
 # (kernel tables), the dense wide Gram of configs[4] on the ring of row buffers against the two-stage ping-pong
 (for v in 1 0 1 0; do NM_BENCH_WAVE16=$v timeout 300 python tools/nonmetric_bench.py 2>&1 | tail -1; done) > $O/nonmetric_ab_wave16.jsonl
 bash tools/experiments/nm_verify_prof.sh > $O/nonmetric_verify_kernels.txt 2>&1
+# round 6: the categorical bootstrap launch by launch with every pass over all rows (round 5) / with the step's own bound + rows on request / as one launch + verification
+(for o in "nm_cat_one=0,nm_subset=0" "nm_cat_one=0" "nm_cat_one=1"; do for B in 1000 5000; do CAT_BENCH_OPTS=$o timeout 300 python tools/categorical_bench.py $B 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'options': '$o', 'replicates_per_step': $B, 'replicates_per_s': d['replicates_per_s'], 'ms_per_step': d['ms_per_step'], 'kernel_ms_per_step': d['kernel_ms_per_step'], 'replicate_iterations': d['replicate_iterations']}))"; done; done) > $O/categorical_ab_one_launch.jsonl
+bash tools/experiments/cat_one_prof.sh 1000 > $O/categorical_one_launch_kernels.txt 2>&1
+timeout 120 python tools/experiments/cat_bound_probe.py > $O/categorical_bound_probe.txt 2>&1
 (for o in wide_ring=0 wide_ring=4 wide_ring=6 wide_ring=0 wide_ring=4 wide_ring=6; do FIT_BENCH_OPTS=$o timeout 300 python tools/fit_bench.py c5 2>&1 | grep "^{" | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'option': '$o', 'kernel_ms': d['kernel_ms'], 'gram_kernel': d['roofline']['gram_kernel'], 'iterations': d['iterations']}))"; done) > $O/c5_ring_ab.jsonl
 timeout 300 python tools/api_phase_times.py 2>&1 | grep "^{" > $O/api_phase_times.jsonl
