@@ -131,8 +131,11 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const bool wave_step = k16 && nm_wave_step_planned(m);
     // round 6: the wave step stops on its own upper bound and needs the pass only to hear "go on" -- a lower bound from the first row chunks says that as surely as the
     // exact sum (kernels_nmw.h); what it leaves open gets the full pass in a launch of its own.  The int8-product pass of all-indicator models only.
-    // (data sets of a few hundred rows: a pass is a few row chunks and a launch floor either way -- nothing to save, one more list to file)
-    const bool sub_pass = use_mfma && !m->stage1 && m->tune.nm_subset != 0 && wave_step && N >= 1024;
+    // (launch by launch, data sets of a few hundred rows: a pass is a few row chunks and a launch floor either way -- nothing to save, one more list to file; the
+    //  one-launch form below has no pass per step and takes them as well)
+    const bool bound_ok = use_mfma && !m->stage1 && m->tune.nm_subset != 0 && wave_step;
+    const bool one_launch = bound_ok && counts8 && cd8 && m->tune.nm_cat_one != 0 && nproblems <= 0x7fffffffL;
+    const bool sub_pass = bound_ok && (N >= 1024 || one_launch);
     const int nsub = sub_pass ? std::max(1, m->tune.nm_subset) : 0;      // the safety factor of the rows a problem asks for (kernels_nmw.h); 0: every pass over all rows
     if (counts16_ready && !wave_step) return fail(m, PLSPM_E_STATE, "non-metric solver: uint16 counts without the wave step");
     m->last_nm_wave = wave_step ? 1 : 0;
@@ -216,7 +219,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     // All-indicator, all-Mode-A models on the wave step with the int8 stop-rule product, not a stage of a HOC pair.  The solver iterates on its own upper bound and
     // leaves every step's score map behind; the verification evaluates the criterion of every step a replicate continued behind on the row chunks that step asks for
     // (a lower bound), the exact pass takes what that leaves open, a replicate whose exact criterion was below the tolerance is replayed with the reference's stop.
-    const bool one_launch = sub_pass && finish && !m->stage2 && !m->stage1 && counts8 && cd8 && m->tune.nm_cat_one != 0 && nproblems <= 0x7fffffffL;
+    // (the first stage of a HOC pair too -- nothing to finish there: the final state is what the second stage's moments are composed from)
     m->last_nm_one = one_launch ? 1 : 0;
     if (one_launch) {
         constexpr int JR = 8;                                // steps verified per round (six to nine iterations is the rule: one round, one host read-back)
@@ -256,7 +259,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 hipLaunchKernelGGL(nmg_kernel<3>, g1, dim3(threads), lds, m->stream, md, cd, mdm, Mp, mp_stride, so, gS, gSm, gst, (long)st_doubles, (const double*)part, nparts, nact,
                                    0, cat_fast, (unsigned short*)m->gK16.p, ld16, list);
             hipLaunchKernelGGL(one_kernel, g1, dim3(64), wave_lds, m->stream, md, cd, mdm, so, gSm, gst, (long)st_doubles, (const double*)nullptr, nparts, nact,
-                               (const unsigned short*)m->gK16.p, ld16, 1, list, nsub, nmw::NmwMaps{forced ? nullptr : cmaps, cstride, forced ? nullptr : kmaps, kstride, steps, forced, std::ldexp(1.0, m->tune.nm_bound_shift)});
+                               (const unsigned short*)m->gK16.p, ld16, fuse, list, nsub, nmw::NmwMaps{forced ? nullptr : cmaps, cstride, forced ? nullptr : kmaps, kstride, steps, forced, std::ldexp(1.0, m->tune.nm_bound_shift)});
         };
         solve(nproblems, nullptr, nullptr);
         bool any_flagged = false;
