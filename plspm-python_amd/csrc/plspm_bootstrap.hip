@@ -55,13 +55,15 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     const size_t kpad = (size_t)i8_kblocks(N) * 64;
     // (the global-scratch histogram serves the (row,count) lists only: the int8 route on Philox draws never builds them)
     const bool need_ghist = !lds_hist && need_lists;
+    const bool cat_one = gpath_plan == 2 && counts8_plan && !m->stage1 && m->tune.nm_cat_one != 0 && m->tune.nm_subset != 0 && m->tune.nm_mfma != 0 && nm_wave_step_planned(m);
     const size_t per_rep = (need_lists ? (size_t)ent_stride * sizeof(int2) : 0) + (size_t)std::max<long>(psize, cov_doubles(m->Pg)) * sizeof(double) + (need_ghist ? (size_t)N * sizeof(unsigned) : 0) +
                            (want_dcnt ? (size_t)dcnt_stride * sizeof(unsigned short) : 0) + (gpath == 2 ? kpad : 0) +
                            (nm_wave ? (size_t)(m->max_iter + 2) * (m->P + m->L + 1) * sizeof(double) + 4 * ((size_t)(2 * m->P + 2 * m->L + 1) + 8) * sizeof(double) : 0) +      // (score maps + verification tables)
                            // (the categorical one-launch form, plspm_nonmetric.hip: a map per step and replicate, digit planes of eight (replicate, step) slots per replicate)
-                           ((gpath_plan == 2 && counts8_plan && !m->stage1 && m->tune.nm_cat_one != 0 && m->tune.nm_subset != 0 && m->tune.nm_mfma != 0 && nm_wave_step_planned(m))
-                                ? (size_t)(m->max_iter + 2) * (m->P + m->L + 1) * sizeof(double) + 8 * ((size_t)m->L * 2 * 7 * 2 * 64 + 64) : 0);
-    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)((2ull << 30) / per_rep)));
+                           (cat_one ? (size_t)(m->max_iter + 2) * (m->P + m->L + 1) * sizeof(double) + 8 * ((size_t)m->L * 2 * 7 * 2 * 64 + 64) : 0);
+    // (the one-launch categorical batch lasts as long as its slowest replicate -- the ones that never converge run max_iter + 1 steps in one wave --, so cutting a call
+    //  into passes multiplies that tail: 16 GiB of the 288 for it instead of 2)
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(((cat_one ? 16ull : 2ull) << 30) / per_rep)));
     if (gpath == 2 && chunk < B) chunk = std::max<int64_t>(256, chunk & ~(int64_t)255);      // whole 256-replicate tiles per pass
     int rc;
     if (gpath == 2) {
