@@ -206,3 +206,43 @@ def _narrow_case_check(seed, B=40):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_narrow_model_bootstrap(seed):
     _narrow_case_check(seed)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_num_model_on_the_one_launch_route(seed):
+    """Scale.NUM models of the narrow fuzz class (at most 64 MVs in 2 ... 16 ragged blocks, random Mode A / B blocks, random scheme) on the int8 route: the one-launch
+    solver + verification of round 6 (solver_wave16.h NM) against the per-iteration launches (equal status and iteration counts, records to 1e-9) and two replicates
+    against the oracle on the mirrored Philox draws."""
+    from plspm import _native
+    X, metric, sizes = make_narrow_case(seed)
+    model = orc.Model(metric.blocks, metric.C, metric.modes, metric.scheme, True, tol=1e-7, scales=["NUM"] * X.shape[1])
+    n, P = X.shape
+    boff = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], True, model.max_iter, model.tol, 0, nonmetric=True)
+    nm.upload(X)
+    nm.set_option("gram_path", 2)
+    B = 40
+    rows, status, iters = nm.bootstrap(B, seed=seed)
+    tag = "seed %d P=%d sizes=%s %s %s" % (seed, P, sizes, model.modes, model.scheme)
+    if nm.get_option("last_gram_path") != 2 or nm.get_option("last_nm_wave16") != 1:
+        pytest.skip("outside the one-launch class (%s)" % tag)
+    nm.set_option("nm_wave16", 0)
+    rows_l, status_l, iters_l = nm.bootstrap(B, seed=seed)
+    assert nm.get_option("last_nm_wave16") == 0
+    assert np.array_equal(status, status_l), tag
+    ok = status == 0
+    assert np.array_equal(iters[ok], iters_l[ok]), tag
+    assert_close(rows[ok], rows_l[ok], 1e-9, 1e-12, what=tag)
+    corr = orc.correction(n)
+    checked = 0
+    for b in range(B):
+        if checked == 2 and status[b] == 0:
+            continue
+        idx = _native.bootstrap_indices(seed, b, n)
+        if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
+            continue
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == iters[b], tag + " replicate %d" % b
+        assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+        checked += 1
