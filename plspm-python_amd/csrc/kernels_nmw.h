@@ -27,7 +27,7 @@
 
 namespace nmw {
 
-constexpr int LMAX_MAX = 8, CMAX_MAX = 16, CPL = 8;      // LVs (the kernel is instantiated for LMAX = 2, 4, 6, 8), categories per MV (CMAX = 8; 16: ten-point items -- the reference's own
+constexpr int LMAX_MAX = 8, CMAX_MAX = 16, CPL8 = 8;      // LVs (the kernel is instantiated for LMAX = 2, 4, 6, 8), categories per MV (CMAX = 8; 16: ten-point items -- the reference's own
                                                          // mobi / ECSI example data -- at one wave per SIMD), columns per lane
 
 // LDS of one problem (doubles): c | tq | mean | mzown (each QP = Q + 1 rounded up to 8), then the small arrays, then c_old (QP)
@@ -37,6 +37,22 @@ __host__ __device__ inline long lds_doubles(int Q, int Pm, int L, int kmax) {
     const long fin = workspace_small_doubles(Pm, L, kmax, 0) + Pm;           // the fused finish: MV-level workspace of finish_problem + one row of the MV moment matrix
     return 4 * QP + (step > fin ? step : fin) + QP;             // (+ QP, round 6: the old score map beside the new one for the step's own bound)
 }
+
+// CPL consecutive uint16 counts of a row as packed dwords: 8 columns per lane (one 16-byte load; up to 511 aug columns) or -- round 6 -- 6 (one 12-byte load; up to 383
+// columns): the count streams are VALU-bound and 300 columns at 8 per lane leave 26 of the 64 lanes without work; at 6 per lane 51 lanes share it.
+template <int CPL> struct CountRow;
+template <> struct CountRow<8> {
+    static constexpr int W = 4;
+    unsigned w[4];
+    __device__ __forceinline__ void load(const unsigned short* p) { const uint4 v = *reinterpret_cast<const uint4*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    __device__ __forceinline__ void zero() { w[0] = w[1] = w[2] = w[3] = 0u; }
+};
+template <> struct CountRow<6> {
+    static constexpr int W = 3;
+    unsigned w[3];
+    __device__ __forceinline__ void load(const unsigned short* p) { const uint3 v = *reinterpret_cast<const uint3*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; }
+    __device__ __forceinline__ void zero() { w[0] = w[1] = w[2] = 0u; }
+};
 
 // value of a[i] for a run-time i < CMAX out of a register array (static indices only)
 template <int CMAX> __device__ __forceinline__ double pick(const double (&a)[CMAX], int i) {
@@ -111,7 +127,7 @@ template <int N> __device__ __forceinline__ void allsum_each(double (&v)[N], int
 // (the rows of MV c: one 16-byte load per lane and row) and folds y with tq over the columns of every MV r <= c -- then the shared tail
 // (finish_problem: loadings, cross-loadings, path regressions, effects, the record).  `fast`: the problem's LDS; MV r's columns sit in at most
 // three neighbouring lanes (at most CMAX <= 16 categories, 8 columns per lane): the lane that holds its first column stores, the other one adds.
-template <int CMAX>
+template <int CMAX, int CPL = CPL8>
 __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const ModelDesc& mdm, const SolverOut& so, double* gSm, NmState& st, NmgExtra& xg,
                               const unsigned short* k16, int ld16, double* fast, long b) {
     const int lane = threadIdx.x, Q = md.P, L = md.L, Pm = cd.Pm;
@@ -147,22 +163,21 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
     double tqi[CPL];
 #pragma unroll
     for (int u = 0; u < CPL; ++u) { mvc[u] = (i0 + u < Q) ? mvcol[i0 + u] : -1; tqi[u] = (i0 + u < Q) ? tq_s[i0 + u] : 0.0; }
-    const long pitch = ld16 / 8;
     for (int c = 0; c < Pm; ++c) {
         const int jc0 = cd.mv_off[c], Cc = cd.mv_off[c + 1] - jc0;                       // (uniform)
         double y[CPL];
 #pragma unroll
         for (int u = 0; u < CPL; ++u) y[u] = 0.0;
         {
-            const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)jc0 * ld16 + (lane_on ? i0 : 0));
-            uint4 w[CMAX];
+            const unsigned short* row = k16 + (long)jc0 * ld16 + (lane_on ? i0 : 0);
+            CountRow<CPL> w[CMAX];
 #pragma unroll
-            for (int t = 0; t < CMAX; ++t) w[t] = (lane_on && t < Cc) ? row[(long)t * pitch] : uint4{0u, 0u, 0u, 0u};
+            for (int t = 0; t < CMAX; ++t) { if (lane_on && t < Cc) w[t].load(row + (long)t * ld16); else w[t].zero(); }
 #pragma unroll
             for (int t = 0; t < CMAX; ++t) {
                 if (t < Cc) {
                     const double tj = tq_s[jc0 + t] * inv_n;
-                    const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+                    const unsigned* ww = w[t].w;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) y[u] = fma((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu), tj, y[u]);
                 }
@@ -226,7 +241,7 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
 // whose stop the verification moved).  The state still travels through the problem's block in global memory between steps (the same loads and stores as the
 // per-launch form, behind a device-scope fence): what goes away is the launch boundary -- and with it the passes over all rows and the host round trips.
 struct NmwMaps { double* c; long cstride; double* k; long kstride; int* steps; const int* force; double bound_scale = 1.0; };      // (bound_scale: test seam, option nm_bound_shift -- the bound times 2^k is still an upper bound)
-template <int LMAX, int CMAX = 8, bool SUB = false, bool ONE = false>
+template <int LMAX, int CMAX = 8, bool SUB = false, bool ONE = false, int CPL = CPL8>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 8 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
                                                       const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
                                                       int fuse_finish, const int* __restrict__ live, int nsub, NmwMaps mp = NmwMaps{}) {
@@ -283,7 +298,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         if (lane == 0) { st.scal[3] = 0.0; st.scal[5] = 0.0; }
         if (fuse_finish) {
             __syncthreads();
-            finish<CMAX>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+            finish<CMAX, CPL>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
         }
         return;
     }
@@ -306,7 +321,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         if (stop) {
             if (fuse_finish) {
                 __syncthreads();
-                finish<CMAX>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+                finish<CMAX, CPL>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
             }
             return;
         }
@@ -350,19 +365,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
 #pragma unroll
             for (int u = 0; u < CPL; ++u) acc[u] = (j0 + u <= Q) ? mean_s[j0 + u] * km : 0.0;
             const int q0 = md.boff[m], q1 = md.boff[m + 1];
-            const uint4* row = reinterpret_cast<const uint4*>(k16 + (long)q0 * ld16 + (have_cols ? j0 : 0));
-            const long pitch = ld16 / 8;                          // uint4 per row
+            const unsigned short* row = k16 + (long)q0 * ld16 + (have_cols ? j0 : 0);
             constexpr int NR = 16;                                // rows in flight per lane: one problem's stream is latency-bound (a wave has its SIMD to itself at 1,000 problems)
             for (int q = q0; q < q1; q += NR) {
-                uint4 w[NR];
+                CountRow<CPL> w[NR];
 #pragma unroll
-                for (int t = 0; t < NR; ++t) w[t] = (have_cols && q + t < q1) ? row[t * pitch] : uint4{0u, 0u, 0u, 0u};
-                row += NR * pitch;
+                for (int t = 0; t < NR; ++t) { if (have_cols && q + t < q1) w[t].load(row + (long)t * ld16); else w[t].zero(); }
+                row += (long)NR * ld16;
 #pragma unroll
                 for (int t = 0; t < NR; ++t) {
                     if (q + t < q1) {
                         const double cq = c_s[q + t] * inv_n;                 // (1 / n once per row, not once per count: a quarter of the stream's arithmetic)
-                        const unsigned ww[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+                        const unsigned* ww = w[t].w;
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) acc[u] = fma((double)((ww[u >> 1] >> (16 * (u & 1))) & 0xffffu), cq, acc[u]);
                     }
@@ -550,22 +564,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
             const int b0 = onB ? md.boff[blkB] : 0, b1 = onB ? md.boff[blkB + 1] : 0;
             const int len = max(a1 - a0, b1 - b0);
             const int trips = (int)wv::allmax((unsigned long long)(unsigned)len);
-            const long pitch = ld16 / 8;
-            const uint4* rowA = reinterpret_cast<const uint4*>(k16 + (long)a0 * ld16 + (lane_on ? j0 : 0));
-            const uint4* rowB = reinterpret_cast<const uint4*>(k16 + (long)b0 * ld16 + (lane_on ? j0 : 0));
+            const unsigned short* rowA = k16 + (long)a0 * ld16 + (lane_on ? j0 : 0);
+            const unsigned short* rowB = k16 + (long)b0 * ld16 + (lane_on ? j0 : 0);
             constexpr int NU = 8;
             for (int t0 = 0; t0 < trips; t0 += NU) {
-                uint4 wa[NU], wb[NU];
+                CountRow<CPL> wa[NU], wb[NU];
 #pragma unroll
                 for (int t = 0; t < NU; ++t) {
-                    wa[t] = (onA && a0 + t0 + t < a1) ? rowA[(long)(t0 + t) * pitch] : uint4{0u, 0u, 0u, 0u};
-                    wb[t] = (onB && b0 + t0 + t < b1) ? rowB[(long)(t0 + t) * pitch] : uint4{0u, 0u, 0u, 0u};
+                    if (onA && a0 + t0 + t < a1) wa[t].load(rowA + (long)(t0 + t) * ld16); else wa[t].zero();
+                    if (onB && b0 + t0 + t < b1) wb[t].load(rowB + (long)(t0 + t) * ld16); else wb[t].zero();
                 }
 #pragma unroll
                 for (int t = 0; t < NU; ++t) {
                     const int ja = a0 + t0 + t, jb = b0 + t0 + t;
                     const double da = (onA && ja < a1) ? c_s[ja] * inv_n : 0.0, db = (onB && jb < b1) ? c_s[jb] * inv_n : 0.0;
-                    const unsigned wwa[4] = {wa[t].x, wa[t].y, wa[t].z, wa[t].w}, wwb[4] = {wb[t].x, wb[t].y, wb[t].z, wb[t].w};
+                    const unsigned* wwa = wa[t].w;
+                    const unsigned* wwb = wb[t].w;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
                         if (lvc[u] == blkA) U[u] = fma((double)((wwa[u >> 1] >> (16 * (u & 1))) & 0xffffu), da, U[u]);
@@ -673,7 +687,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         __threadfence();                                         // the state written above is read back by other lanes: at the top of the next trip, or by the finish
         __syncthreads();
         if (stop) {
-            if (fuse_finish) finish<CMAX>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
+            if (fuse_finish) finish<CMAX, CPL>(md, cd, mdm, so, gSm, st, xg, k16, ld16, lp0, b);
             return;
         }
         continue;

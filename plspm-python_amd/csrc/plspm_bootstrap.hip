@@ -98,7 +98,7 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
     // round 5: all-indicator categorical models on the wave step -- the int8 product writes the uint16 count matrices the step streams itself (no fp64 slots, no
     // scatter pass: kernels_gram_i8.h IND epilogue, kernels_nonmetric.h nmg_kernel<4>); option "nm_direct16" 0: the packed fp64 matrices + nmg_kernel<3>
     const bool want16 = gpath == 2 && m->nonmetric && !m->stage2 && !m->stage1 && !m->moments_out && m->tune.nm_direct16 != 0 && nm_wave_step_planned(m);
-    if (want16 && (rc = ensure(m, m->gK16, (size_t)chunk * (m->P + 1) * ((m->P + 1 + 7) & ~7) * sizeof(unsigned short)))) return rc;
+    if (want16 && (rc = ensure(m, m->gK16, (size_t)chunk * (m->P + 1) * ((m->P + 1 + 7) & ~7) * sizeof(unsigned short) + 64))) return rc;
     hipEvent_t parked_stop = m->stop_event;
     m->stop_event = nullptr;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {

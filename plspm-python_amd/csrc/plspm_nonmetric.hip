@@ -142,7 +142,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     m->last_nm_direct16 = counts16_ready ? 1 : 0;
     // the fp64 square of every problem (730 KB at 300 indicator columns): not for the wave step, which reads the uint16 counts only
     if (!wave_step && (rc = ensure(m, m->gS, (size_t)nproblems * s_bytes))) return rc;
-    if (k16 && (rc = ensure(m, m->gK16, (size_t)nproblems * (P + 1) * ld16 * sizeof(unsigned short)))) return rc;
+    if (k16 && (rc = ensure(m, m->gK16, (size_t)nproblems * (P + 1) * ld16 * sizeof(unsigned short) + 64))) return rc;      // (+ 64: the six-column lanes of the last row read a dword past it)
     if ((rc = ensure(m, m->nmpartial, (size_t)nproblems * nparts * sizeof(double)))) return rc;
     if ((rc = ensure(m, m->nmactive, sizeof(int)))) return rc;
     size_t lds = (size_t)workspace_small_doubles(cat ? m->Pm : P, L, m->kmax, m->n_chol) * sizeof(double) + desc_lds_bytes(P, L, m->n_eff, (int)m->pred_idx.size());
@@ -210,10 +210,16 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     const bool flag_from_list = dense && !m->stage1;
     // (instantiations: LMAX 2 / 4 / 6 / 8 LVs x at most 8 categories per MV -- two waves per SIMD -- or at most 16 -- ten-point items; one wave per SIMD, 512 registers)
     using nmw::nmw_step_kernel;
-    auto wave_kernel = sub_pass ? (m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, true> : L <= 4 ? nmw_step_kernel<4, 8, true> : L <= 6 ? nmw_step_kernel<6, 8, true> : nmw_step_kernel<8, 8, true>)
-                                                : (L <= 2 ? nmw_step_kernel<2, 16, true> : L <= 4 ? nmw_step_kernel<4, 16, true> : L <= 6 ? nmw_step_kernel<6, 16, true> : nmw_step_kernel<8, 16, true>))
-                                : (m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, false> : L <= 4 ? nmw_step_kernel<4, 8, false> : L <= 6 ? nmw_step_kernel<6, 8, false> : nmw_step_kernel<8, 8, false>)
-                                                : (L <= 2 ? nmw_step_kernel<2, 16, false> : L <= 4 ? nmw_step_kernel<4, 16, false> : L <= 6 ? nmw_step_kernel<6, 16, false> : nmw_step_kernel<8, 16, false>));
+    // (round 6: six columns per lane where they cover the model -- at most 383 aug columns of items with at most eight categories: 300 columns keep 51 lanes busy
+    //  instead of 38; option nm_cpl 8: eight per lane as before)
+    // (the finish files an MV's columns from at most three neighbouring lanes: 13 categories at six columns per lane)
+    const bool cpl6 = m->cmax <= 13 && P + 1 <= 6 * 64 && m->tune.nm_cpl != 8;
+#define NMW_PICK(SUBV, ONEV)                                                                                                                                            \
+    (m->cmax <= 8 ? (cpl6 ? (L <= 2 ? nmw_step_kernel<2, 8, SUBV, ONEV, 6> : L <= 4 ? nmw_step_kernel<4, 8, SUBV, ONEV, 6> : L <= 6 ? nmw_step_kernel<6, 8, SUBV, ONEV, 6> : nmw_step_kernel<8, 8, SUBV, ONEV, 6>) \
+                          : (L <= 2 ? nmw_step_kernel<2, 8, SUBV, ONEV, 8> : L <= 4 ? nmw_step_kernel<4, 8, SUBV, ONEV, 8> : L <= 6 ? nmw_step_kernel<6, 8, SUBV, ONEV, 8> : nmw_step_kernel<8, 8, SUBV, ONEV, 8>)) \
+                  : (cpl6 ? (L <= 2 ? nmw_step_kernel<2, 16, SUBV, ONEV, 6> : L <= 4 ? nmw_step_kernel<4, 16, SUBV, ONEV, 6> : L <= 6 ? nmw_step_kernel<6, 16, SUBV, ONEV, 6> : nmw_step_kernel<8, 16, SUBV, ONEV, 6>) \
+                          : (L <= 2 ? nmw_step_kernel<2, 16, SUBV, ONEV, 8> : L <= 4 ? nmw_step_kernel<4, 16, SUBV, ONEV, 8> : L <= 6 ? nmw_step_kernel<6, 16, SUBV, ONEV, 8> : nmw_step_kernel<8, 16, SUBV, ONEV, 8>)))
+    auto wave_kernel = sub_pass ? NMW_PICK(true, false) : NMW_PICK(false, false);
     if (wave_step && (rc = allow_lds(m, (const void*)wave_kernel, wave_lds))) return rc;
     // ---- round 6: the whole batch in ONE solver launch + verification (kernels_nmw.h ONE; the categorical counterpart of run_nonmetric_wave) --------------------------------
     // All-indicator, all-Mode-A models on the wave step with the int8 stop-rule product, not a stage of a HOC pair.  The solver iterates on its own upper bound and
@@ -245,8 +251,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
         double* vsum = (double*)m->nmw_vsum.p;
         int* h = (int*)m->h_flag;                                // pinned: [0] most steps of a replicate, [1] flagged, [2] to replay
         m->last_nm_flagged = 0; m->last_nm_replayed = 0;
-        auto one_kernel = m->cmax <= 8 ? (L <= 2 ? nmw_step_kernel<2, 8, true, true> : L <= 4 ? nmw_step_kernel<4, 8, true, true> : L <= 6 ? nmw_step_kernel<6, 8, true, true> : nmw_step_kernel<8, 8, true, true>)
-                                       : (L <= 2 ? nmw_step_kernel<2, 16, true, true> : L <= 4 ? nmw_step_kernel<4, 16, true, true> : L <= 6 ? nmw_step_kernel<6, 16, true, true> : nmw_step_kernel<8, 16, true, true>);
+        auto one_kernel = NMW_PICK(true, true);
         if ((rc = allow_lds(m, (const void*)one_kernel, wave_lds))) return rc;
         auto pass_kernel = KS == 1 ? nmp::conv_mfma_kernel<4, 1> : nmp::conv_mfma_kernel<4, 2>;
         auto solve = [&](long count, const int* list, const int* forced) {
