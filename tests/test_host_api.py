@@ -431,6 +431,10 @@ def test_committed_bench_line_follows_the_driver_contract():
     num = line["next_rows"]["nonmetric_num_bootstrap"]
     assert num["one_launch_solver"] == 1 and num["all_ok"] and num["replicates_per_s"] >= 6.0e6 and num["kernel_ms_per_step"]["solver"] <= 0.12, num
     assert num["replicate_iterations"][0] >= 2 and num["fit_iterations"] >= 2
+    # ... and the categorical (Scale.ORD) one (round 6: one launch + verification, six columns per lane)
+    cat = line["next_rows"]["categorical_bootstrap"]
+    assert cat["replicates_per_step_1000"]["replicates_per_s"] >= 4.0e5 and cat["replicates_per_step_5000"]["replicates_per_s"] >= 5.0e5, cat
+    assert cat["replicates_per_step_1000"]["all_ok"] and cat["replicates_per_step_5000"]["all_ok"]
     # the two single-fit configurations of BASELINE.json: iteration counts, HIP-event kernel times, A_fit / F_fit rooflines
     for key, (n, p, l) in (("configs[1]", (10000, 60, 6)), ("configs[4]", (1000000, 200, 20))):
         fit = line["single_fit"][key]
