@@ -378,11 +378,9 @@ template <int RW, int NW, bool BLOCKED, bool CNT8 = false>
 __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __restrict__ Xt, long ntiles, int PA, int P, int L, const int* __restrict__ boff,
                                                                  const unsigned short* __restrict__ dcnt, long dcnt_stride, const double* __restrict__ table,
                                                                  const int* __restrict__ list, const int* __restrict__ count, double* __restrict__ partial, int nparts, int rbx,
-                                                                 int gy, int kb, double* __restrict__ vsum = nullptr, int by_slot = 0, const int* __restrict__ vneed = nullptr) {
-    // by_slot (round 6: the verification pass of the one-launch NUM / RAW solver, plspm_nonmetric.hip run_nonmetric_wave): the list holds VIRTUAL problems --
-    // (replicate, step) pairs; list[slot] is the replicate whose counts weigh the rows, the result is filed under the slot.  vsum: the sums of the row parts
-    // this launch covers are added up atomically per slot (a lower bound of the criterion that only has to clear the tolerance: the order of the additions
-    // does not matter) instead of being stored part by part.
+                                                                 int gy, int kb, int by_slot = 0) {
+    // by_slot (round 6: the exact pass of the one-launch NUM / RAW solver's verification, plspm_nonmetric.hip run_nonmetric_wave): the list holds VIRTUAL problems --
+    // (replicate, step) pairs; list[slot] is the replicate whose counts weigh the rows, the result is filed under the slot.
     static_assert(!CNT8 || RW == 16, "the int8 counts come in pieces of 16 rows");
     // multiplicities of this wave's RW rows in replicate b: packed words (uint16 pairs, or bytes of the int8 counts)
     auto load_counts = [&](unsigned (&wq)[RW / 2], bool on, long b, long part) {
@@ -427,11 +425,6 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
     // speculative pass after the last iteration): no trip at all
     const int nlive = *count, ngroups = (nlive + 63) / 64;
     for (int g = gy0; g < ngroups; g += gy) {
-        if (vneed) {
-            // (verification, pass A: this group's slots ask for the first `need` row blocks only -- nm_vlist_kernel; uniform over the workgroup)
-            const int mine = ((long)g * 64 + lane < nlive) ? vneed[(long)g * 64 + lane] : 0;
-            if (rb >= wv::allreduce(mine, [](int a, int b) { return a > b ? a : b; })) continue;
-        }
         if (BLOCKED) {
             const bool live = (long)g * 64 + lane < nlive;
             const long b = live ? (long)list[(long)g * 64 + lane] : 0;
@@ -485,10 +478,7 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
                     acc = fma(w * d, d, acc);
                 }
             }
-            if (live && have) {
-                const long ob = by_slot ? (long)g * 64 + lane : b;
-                if (vsum) unsafeAtomicAdd(&vsum[ob], acc); else partial[ob * nparts + part] = acc;
-            }
+            if (live && have) partial[(by_slot ? (long)g * 64 + lane : b) * nparts + part] = acc;
             continue;
         }
         __syncthreads();
@@ -546,10 +536,7 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
                 acc = fma(w * d, d, acc);
             }
         }
-        if (live) {
-            const long ob = by_slot ? (long)g * 64 + lane : b;
-            if (vsum) unsafeAtomicAdd(&vsum[ob], acc); else partial[ob * nparts + part] = acc;
-        }
+        if (live) partial[(by_slot ? (long)g * 64 + lane : b) * nparts + part] = acc;
     }
 }
 

@@ -394,7 +394,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 else
                 hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gy)), dim3(512), dense_use_lds, m->stream, (const double*)src->Xt.p, ntiles16, src->PA, src->P, L,
                                    conv_boff, counts8 ? (const unsigned short*)cd8 : (const unsigned short*)src->dcnt.p, counts8 ? (long)cd8_MT : src->dcnt_stride,
-                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb, (double*)nullptr, 0, (const int*)nullptr);
+                                   (const double*)m->ctable.p, (const int*)((int*)m->nmlist.p + 1), (const int*)m->nmlist.p, part, nparts, rbx, gy, kb, 0);
                 }
             } else {
                 hipLaunchKernelGGL(nm_conv_kernel, dim3(nparts, (unsigned)nproblems), dim3(256), conv_lds, m->stream, src->d_Xa, N, src->PA, src->P, L, 0, conv_boff, ent, nent,
@@ -419,6 +419,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     HIPCHK(m, hipGetLastError());
     return 0;
 }
+#undef NMW_PICK
 
 // Round 6: a bootstrap batch of a Scale.NUM / RAW model (no missing cells, at most 64 MVs and 16 LVs) on the int8 Gram route as ONE solver launch + a
 // verification pass (kernels_solver.h solver_nmwave_kernel; kernels_nonmetric.h nm_vlist_kernel ...).  The legacy loop (run_nonmetric) launches one step
@@ -481,10 +482,10 @@ int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void*
     const int gyV = (int)std::max<long>(1, (2 * nb + 63) / 64);
     const size_t verify_lds = ((size_t)table_rows * 64 + (size_t)8 * P * 16) * sizeof(double);
     if ((rc = allow_lds(m, (const void*)nm_verify_kernel, verify_lds))) return rc;
-    auto pass = [&](long tiles, const int* list, const int* count, double* partial, int nparts, double* sums, const int* need) {
-        const int gx = (int)((tiles + 7) / 8), rbx = (gx + 7) / 8;
-        hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gyV)), dim3(512), dense_use_lds, m->stream, (const double*)m->Xt.p, tiles, m->PA, P, L, (const int*)m->d_boff,
-                           (const unsigned short*)cd8, (long)cd8_MT, (const double*)m->ctable.p, list, count, partial, nparts, rbx, gyV, kb, sums, 1, need);
+    auto exact_pass = [&](const int* list, const int* count, double* partial) {      // all rows, fixed-order partial sums filed under the (virtual) slot
+        const int gx = (int)((ntiles16 + 7) / 8), rbx = (gx + 7) / 8;
+        hipLaunchKernelGGL(conv_kernel, dim3((unsigned)(8 * rbx * gyV)), dim3(512), dense_use_lds, m->stream, (const double*)m->Xt.p, ntiles16, m->PA, P, L, (const int*)m->d_boff,
+                           (const unsigned short*)cd8, (long)cd8_MT, (const double*)m->ctable.p, list, count, partial, (int)ntiles16, rbx, gyV, kb, 1);
     };
     bool any_flagged = false;
     for (int j0 = 1;; j0 += JR) {
@@ -508,7 +509,7 @@ int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void*
             if ((rc = ensure(m, m->nmpartial, (size_t)flagged * ntiles16 * sizeof(double)))) return rc;
             hipLaunchKernelGGL(nm_vtable_kernel, dim3((unsigned)((flagged + 63) / 64), (unsigned)((table_rows + 63) / 64)), dim3(256), 0, m->stream, (const double*)maps, maps_stride, P, L,
                                (const int*)fb, (const int*)fj, (const int*)(cnt + 1), (double*)m->ctable.p, (int*)nullptr, m->tol, 0, 0, 0);
-            pass(ntiles16, fb, cnt + 1, (double*)m->nmpartial.p, (int)ntiles16, nullptr, nullptr);
+            exact_pass(fb, cnt + 1, (double*)m->nmpartial.p);
             hipLaunchKernelGGL(nm_vcheck_kernel, dim3((unsigned)flagged), dim3(64), 0, m->stream, (const double*)m->nmpartial.p, (int)ntiles16, (const int*)fb, (const int*)fj,
                                (const int*)(cnt + 1), m->tol, force);
         }
