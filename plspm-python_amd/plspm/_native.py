@@ -287,11 +287,15 @@ class NativeModel:
         self._check(self._lib.plspm_upload(self._h, _ptr(X), X.shape[0], X.shape[1], layout, _ptr(ci)), "plspm_upload")
         self.N = X.shape[0]
 
-    def fit(self, want_scores=True, want_cov=False):
+    def fit(self, want_scores=True, want_cov=False, scores_out=None):
+        """``scores_out``: a caller-owned [N, L] float64 C-contiguous buffer for the scores (as ``bootstrap(out=...)``: nothing is allocated -- or first
+        touched -- per call; a fresh 160 MB array costs more in page faults than its copy over the link)."""
         P, L, ne = self.P_out, self.L, self.n_eff
+        if scores_out is not None and (scores_out.shape != (self.N, L) or scores_out.dtype != np.float64 or not scores_out.flags.c_contiguous):
+            raise ValueError("scores_out = [N, L] float64, C-contiguous")
         out = dict(weights=np.empty(P), loadings=np.empty(P), crossloadings=np.empty((P, L)), path_coef=np.empty((L, L)), r2=np.empty(L),
                    lv_cov=np.empty((L, L)), total=np.empty(ne), direct=np.empty(ne), indirect=np.empty(ne),
-                   scores=np.empty((self.N, L)) if want_scores else None, cov=np.empty((P, P)) if want_cov else None, mean=np.empty(P),
+                   scores=(scores_out if scores_out is not None else np.empty((self.N, L))) if want_scores else None, cov=np.empty((P, P)) if want_cov else None, mean=np.empty(P),
                    sign=np.empty(L, dtype=np.int8), iterations=np.zeros(1, dtype=np.int32), status=np.full(1, -1, dtype=np.int32))
         res = _FitResult(**{k: (v.ctypes.data if v is not None and v.size else None) for k, v in out.items()})
         self._check(self._lib.plspm_fit(self._h, ctypes.byref(res)), "plspm_fit")

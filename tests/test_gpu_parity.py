@@ -78,6 +78,24 @@ def test_column_major_upload_gives_identical_results():
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("n", [250, 1500000 // 6])
+def test_scores_into_a_caller_owned_buffer(n):
+    """NativeModel.fit(scores_out=...): the C-ABI's contract (the caller owns the [N, L] buffer) without a fresh array per call -- the small block that rides the
+    pinned staging area and the large one (> 8 MB) that is copied straight into the buffer; the same bits as the allocating form, wrong shapes refused."""
+    C = orc.satisfaction_C()
+    X, blocks = orc.synth(n, C, 4, seed=11)
+    model = orc.Model(blocks, C, "AAAAAA", "path", True)
+    nm = native_model(model)
+    nm.upload(X)
+    ref = nm.fit(want_scores=True)
+    buf = np.full((n, 6), np.nan)
+    out = nm.fit(want_scores=True, scores_out=buf)
+    assert out["scores"] is buf and np.array_equal(buf, ref["scores"]) and np.array_equal(out["weights"], ref["weights"])
+    for bad in (np.empty((n, 5)), np.empty((n, 6), dtype=np.float32), np.empty((6, n)).T):
+        with pytest.raises(ValueError):
+            nm.fit(want_scores=True, scores_out=bad)
+
+
 @pytest.mark.parametrize("modes,scheme", [("A", "path"), ("B", "factorial"), ("M", "centroid")])
 def test_synth2000_vs_golden(modes, scheme):
     gold = load("g2_synth2000")

@@ -53,6 +53,14 @@ def run(tag, n, C, per, modes, scheme, reps=5):
     for _ in range(reps):
         m.fit(want_scores=False)
     wall_noscores = (time.time() - t0) / reps
+    # the same fit with the scores into a caller-owned, already touched buffer (NativeModel.fit(scores_out=...)): the fresh [N, L] array of the loop above pays
+    # first-touch page faults and the release of the previous result (160 MB at configs[4]: ~4 + ~5.5 ms of host memory management beside ~4 ms of copy,
+    # tools/experiments/host_alloc_decomp.py, tools/ubench/host_first_touch.cpp)
+    buf = np.empty((n, L)); buf.fill(0.0)
+    t0 = time.time()
+    for _ in range(reps):
+        m.fit(want_scores=True, scores_out=buf)
+    wall_reused = (time.time() - t0) / reps
     k = {name: m.profile_read(name) for name in ("gram", "reduce", "solver", "scores")}
     ms = {name: (v[0] / max(v[1], 1)) for name, v in k.items()}
     a_fit = 16.0 * n * P + 8.0 * n * L
@@ -82,6 +90,7 @@ def run(tag, n, C, per, modes, scheme, reps=5):
     line = {"config": tag, "N": n, "P": P, "L": L, "iterations": out["iterations"], "status": out["status"], "roofline": roofline,
             "kernel_ms": {a: round(b, 4) for a, b in ms.items()}, "device_ms_total": round(dev_ms, 4),
             "fit_wall_ms_incl_scores_download": round(wall * 1e3, 3), "fit_wall_ms_no_scores": round(wall_noscores * 1e3, 3),
+            "fit_wall_ms_scores_into_reused_buffer": round(wall_reused * 1e3, 3), "scores_download_GBps_reused_buffer": round(8.0 * n * L / max(wall_reused - wall_noscores, 1e-9) / 1e9, 1),
             "upload_first_ms": round(t_up * 1e3, 2), "upload_ms": round(t_up2 * 1e3, 3), "upload_GBps": round(8.0 * n * P / t_up2 / 1e9, 2), "upload_runtime_pageable_ms": (round(t_direct * 1e3, 3) if t_direct else None),
             "upload_plus_fit_plus_scores_wall_ms": round(t_e2e * 1e3, 3), "of_which_upload_ms": [round(x * 1e3, 2) for x in e2e_up], "synth_s": round(t_gen, 1),
             "algorithmic": {"bytes": a_fit, "flops": f_fit, "GBps_on_device_time": round(a_fit / dev_ms / 1e6, 1),
