@@ -133,6 +133,8 @@ const char* plspm_last_error(const plspm_model_t* m);
  *   "nm_wave"         1 (default) | 0   (round 5) all-indicator categorical models, every block Mode A, at most 64 MVs of at most 16 categories, 8 LVs,
  *                     511 indicator columns, 65,535 rows: the iteration as one wave per problem (nmw::nmw_step_kernel) instead of one workgroup
  *                     (nmg_kernel<1>); records equal to ~1e-13, equal iteration counts.  Read-only "last_nm_wave"
+ *   "nm_c10"          1 (default) | 0   (round 6) among those, items of nine or ten categories (the reference's mobi / ECSI data): the ten-category instantiation
+ *                     of the wave step, two waves per SIMD, instead of the sixteen-category one, which runs alone on its SIMD -- the same arithmetic, identical records
  *   "nm_direct16"     1 (default) | 0   (round 5) bootstrap of such models on the int8 route: the product writes the replicates' co-occurrence counts
  *                     as uint16 matrices itself (upper triangle; mirrored through LDS by nmg_kernel<4>) instead of fp64 moment matrices that a scatter
  *                     pass turns into the same integers -- bit-identical records.  Read-only "last_nm_direct16"

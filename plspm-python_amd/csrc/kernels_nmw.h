@@ -242,7 +242,7 @@ __device__ inline void finish(const ModelDesc& md, const CatDesc& cd, const Mode
 // per-launch form, behind a device-scope fence): what goes away is the launch boundary -- and with it the passes over all rows and the host round trips.
 struct NmwMaps { double* c; long cstride; double* k; long kstride; int* steps; const int* force; double bound_scale = 1.0; };      // (bound_scale: test seam, option nm_bound_shift -- the bound times 2^k is still an upper bound)
 template <int LMAX, int CMAX = 8, bool SUB = false, bool ONE = false, int CPL = CPL8>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 8 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 10 ? 1 : 2))) nmw_step_kernel(ModelDesc md, CatDesc cd, ModelDesc mdm, SolverOut so, double* __restrict__ gSm, double* __restrict__ gstate, long state_stride,
                                                       const double* __restrict__ partial, int nparts, int* __restrict__ nactive, const unsigned short* __restrict__ gK16, int ld16,
                                                       int fuse_finish, const int* __restrict__ live, int nsub, NmwMaps mp = NmwMaps{}) {
     static_assert(!ONE || SUB, "the one-launch form stops on the step's own bound");

@@ -214,8 +214,12 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     //  instead of 38; option nm_cpl 8: eight per lane as before)
     // (the finish files an MV's columns from at most three neighbouring lanes: 13 categories at six columns per lane)
     const bool cpl6 = m->cmax <= 13 && P + 1 <= 6 * 64 && m->tune.nm_cpl != 8;
+    // (round 6, last: items of nine or ten categories -- the reference's own mobi data -- on an instantiation of their own: its register arrays leave room for TWO waves
+    //  per SIMD like the eight-category form, where the sixteen-category one runs alone; six columns per lane only)
+    const bool c10 = m->cmax > 8 && m->cmax <= 10 && cpl6 && m->tune.nm_c10 != 0;
 #define NMW_PICK(SUBV, ONEV)                                                                                                                                            \
-    (m->cmax <= 8 ? (cpl6 ? (L <= 2 ? nmw_step_kernel<2, 8, SUBV, ONEV, 6> : L <= 4 ? nmw_step_kernel<4, 8, SUBV, ONEV, 6> : L <= 6 ? nmw_step_kernel<6, 8, SUBV, ONEV, 6> : nmw_step_kernel<8, 8, SUBV, ONEV, 6>) \
+    (c10 ? (L <= 2 ? nmw_step_kernel<2, 10, SUBV, ONEV, 6> : L <= 4 ? nmw_step_kernel<4, 10, SUBV, ONEV, 6> : L <= 6 ? nmw_step_kernel<6, 10, SUBV, ONEV, 6> : nmw_step_kernel<8, 10, SUBV, ONEV, 6>) : \
+     m->cmax <= 8 ? (cpl6 ? (L <= 2 ? nmw_step_kernel<2, 8, SUBV, ONEV, 6> : L <= 4 ? nmw_step_kernel<4, 8, SUBV, ONEV, 6> : L <= 6 ? nmw_step_kernel<6, 8, SUBV, ONEV, 6> : nmw_step_kernel<8, 8, SUBV, ONEV, 6>) \
                           : (L <= 2 ? nmw_step_kernel<2, 8, SUBV, ONEV, 8> : L <= 4 ? nmw_step_kernel<4, 8, SUBV, ONEV, 8> : L <= 6 ? nmw_step_kernel<6, 8, SUBV, ONEV, 8> : nmw_step_kernel<8, 8, SUBV, ONEV, 8>)) \
                   : (cpl6 ? (L <= 2 ? nmw_step_kernel<2, 16, SUBV, ONEV, 6> : L <= 4 ? nmw_step_kernel<4, 16, SUBV, ONEV, 6> : L <= 6 ? nmw_step_kernel<6, 16, SUBV, ONEV, 6> : nmw_step_kernel<8, 16, SUBV, ONEV, 6>) \
                           : (L <= 2 ? nmw_step_kernel<2, 16, SUBV, ONEV, 8> : L <= 4 ? nmw_step_kernel<4, 16, SUBV, ONEV, 8> : L <= 6 ? nmw_step_kernel<6, 16, SUBV, ONEV, 8> : nmw_step_kernel<8, 16, SUBV, ONEV, 8>)))

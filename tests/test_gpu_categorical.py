@@ -408,6 +408,12 @@ def test_wave_step_agrees_with_the_workgroup_step(case):
     B = 300
     wave = nm.bootstrap(B, seed=6)
     assert nm.get_option("last_nm_wave") == 1
+    if case == "ten_point_items":                               # round 6: the ten-category instantiation (two waves per SIMD) against the sixteen-category one
+        assert nm.get_option("nm_c10") == 1
+        nm.set_option("nm_c10", 0)
+        wide = nm.bootstrap(B, seed=6)
+        nm.set_option("nm_c10", 1)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(wave, wide))
     nm.set_option("nm_wave", 0)
     fit0 = nm.fit(want_scores=True)
     group = nm.bootstrap(B, seed=6)

@@ -23,3 +23,13 @@ print("--- totals")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-50s calls %5d total %10.1f us" % (n, c, t))
 P
+python - <<'P'
+import glob, sqlite3
+db = (glob.glob("/tmp/hp/*.db") + glob.glob("/tmp/hp/*/*.db"))[0]
+rows = list(sqlite3.connect(db).cursor().execute("select name, start, end from kernels order by start"))[-21:]
+t0 = rows[0][1]; prev = None
+print("--- the last three trips of the second stage")
+for name, s, e in rows:
+    print("%-44s start %8.1f us dur %7.1f us gap %6.1f us" % (name.split("(")[0].replace("void ", "")[:44], (s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev is None else (s - prev) / 1e3))
+    prev = e
+P
