@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--reps-per-gpu", type=int, default=REPS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
-    ap.add_argument("--no-next-rows", action="store_true", help="skip the categorical bootstrap and the metric models beside the headline (child runs of tools/categorical_bench.py, tools/size_rows.py)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the categorical / Scale.NUM / HOC bootstraps and the metric models beside the headline (child runs of tools/categorical_bench.py, nonmetric_bench.py, hoc_bench.py, size_rows.py)")
     ap.add_argument("--no-single-fit", action="store_true", help="skip the single-fit rows (configs[1] and configs[4]: a child run of tools/fit_bench.py)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the dominant kernel's HBM bytes")
     ap.add_argument("--group", action="store_true", help="N = 1 without a launcher: still go through the group / RCCL path")
@@ -747,7 +747,12 @@ def main():
                 num = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             except Exception as e:                                        # noqa: BLE001
                 num = {"error": repr(e)[:200]}
-            line["next_rows"] = {"nonmetric_num_bootstrap": num, "categorical_bootstrap": cat, "metric_models_next_to_the_headline": sizes,
+            try:                                                           # both stages of a higher order construct per replicate, on the reference's mobi data (tools/hoc_bench.py)
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hoc_bench.py")], capture_output=True, text=True, timeout=240).stdout
+                hoc = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+            except Exception as e:                                        # noqa: BLE001
+                hoc = {"error": repr(e)[:200]}
+            line["next_rows"] = {"nonmetric_num_bootstrap": num, "categorical_bootstrap": cat, "metric_models_next_to_the_headline": sizes, "hoc_two_stage_bootstrap": hoc,
                                  "note": "not part of `value`: ORD / NOM optimal scaling on 300 indicator columns (10k x 60 five-point items x 6 LVs), one wave per problem, "
                                          "count matrices written by the int8 product as uint16, stop rule as an int8 matrix product; DESIGN 5c"}
         if world == 1 and group is None and not args.no_single_fit:

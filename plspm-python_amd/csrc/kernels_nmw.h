@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CMAX > 
         double mean = 0.0, ss = 0.0;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < Cp) { mean += f2[c] * cs[c]; ss += f2[c] * cs[c] * cs[c]; }
-        const double sd = sqrt(ss - mean * mean);
+        const double sd = nmg_quant_sd(ss, mean);                // (a constant quantification is NaN as in the reference: solver_nmg.h)
         int at = 0;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {

@@ -195,6 +195,17 @@ PLSPM_HD double nmg_ordinalize(const double* m, const double* f, int C, double s
     return ss - mean * mean;
 }
 
+// Standard deviation of a quantified MV from its second moment and mean.  A quantification whose categories all carry the SAME value (every category mean of z
+// equal -- e.g. a two-category item whose category means tie exactly in the first trip of the centroid scheme; or ordinal pooling down to one group in both
+// directions) is a constant column in the reference: util.treat_numpy divides 0 by 0, the scores are NaN from there on, the stop rule never holds and the
+// estimate raises (weights.py:120-127) -- a bootstrap replicate is dropped.  On second moments the same variance is `ss - mean^2` of two equal numbers, i.e.
+// rounding noise of either sign: a negative one gave NaN as well, a positive one a standardisation of noise and a replicate that "converged".  A variance below
+// 1e-12 of the second moment (no quantification of real data comes near: the category means of a standardised z spread by percents) is that constant column.
+PLSPM_HD double nmg_quant_sd(double ss, double mean) {
+    const double var = ss - mean * mean;
+    return sqrt((var > 1e-12 * ss) ? var : -1.0);
+}
+
 // Quantification of one ORD / NOM manifest variable from the category means of (corrected) z (scale.py:42-89): compact to the
 // categories present in this problem (frequency > 0), pool monotonically (ORD, both directions) or keep the means (NOM),
 // population-standardise, scatter back into tq.  cm / cf: [C] category means and frequencies (overwritten); scratch: 5 arrays of C
@@ -213,7 +224,7 @@ PLSPM_HD void nmg_quantify_mv(int kind, int C, const double* freq_all, double* c
         for (int c = 0; c < Cp; ++c) cs[c] = cm[c];                                               // NOM (scale.py:87)
     }
     for (int c = 0; c < Cp; ++c) { mean += cf[c] * cs[c]; ss += cf[c] * cs[c] * cs[c]; }
-    const double sd = sqrt(ss - mean * mean);                          // treat_numpy(.) * correction == population standardisation
+    const double sd = nmg_quant_sd(ss, mean);                          // treat_numpy(.) * correction == population standardisation
     int at = 0;
     for (int c = 0; c < C; ++c) {
         if (freq_all[c] > 0.0) { tq_out[c] = (cs[at] - mean) / sd; ++at; }

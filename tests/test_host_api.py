@@ -435,6 +435,10 @@ def test_committed_bench_line_follows_the_driver_contract():
     cat = line["next_rows"]["categorical_bootstrap"]
     assert cat["replicates_per_step_1000"]["replicates_per_s"] >= 4.0e5 and cat["replicates_per_step_5000"]["replicates_per_s"] >= 5.0e5, cat
     assert cat["replicates_per_step_1000"]["all_ok"] and cat["replicates_per_step_5000"]["all_ok"]
+    # ... and both stages of a higher order construct per replicate on the reference's mobi data (round 6: ten-point items at two waves per SIMD)
+    hoc = line["next_rows"]["hoc_two_stage_bootstrap"]
+    assert hoc["ORD"]["replicates_per_s"] >= 1.0e5 and hoc["ORD"]["replicates_per_s_at_40000_per_call"] >= 1.5e5 and hoc["NUM"]["replicates_per_s"] >= 2.0e6, hoc
+    assert hoc["ORD"]["ok_replicates"] >= 4900 and hoc["NUM"]["ok_replicates"] == 5000
     # the two single-fit configurations of BASELINE.json: iteration counts, HIP-event kernel times, A_fit / F_fit rooflines
     for key, (n, p, l) in (("configs[1]", (10000, 60, 6)), ("configs[4]", (1000000, 200, 20))):
         fit = line["single_fit"][key]
