@@ -270,6 +270,13 @@ def nm_init_scores(X0, model: Model):
     return Y
 
 
+# Test diagnostics (tests/test_gpu_fuzz.py): a dict that solve_nonmetric fills when it is not None.  "min_direction_margin": the smallest relative gap
+# |var_incr - var_decr| / max(...) over all (trip, ordinal MV) decisions of scale.py:74.  The two variances are EQUAL in exact arithmetic whenever the category
+# means are mirror-symmetric (e.g. three categories with means a, b, a and equal outer counts -- coarse data, small samples, the first trips); the reference then takes the
+# direction np.var's rounding happens to favour, and two correct evaluations of the same formulas may walk different trajectories to the same fixed point.
+DIAG = None
+
+
 def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
     """WeightsCalculatorFactory.calculate, non-metric branch: _NonmetricWeights.__init__ / iterate / calculate
     (weights.py:73-154) with the four Scale operators (scale.py) and the Mode-B correction get_Z_for_mode_b (weights.py:135-145).
@@ -309,6 +316,10 @@ def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
                         x_inc, v_inc = _ordinalize(means, d.copy(), zc, 1)
                         x_dec, v_dec = _ordinalize(means, d.copy(), zc, -1)
                         xq = -x_dec if v_inc < v_dec else x_inc                         # scale.py:74
+                        if DIAG is not None:                                            # (test diagnostics: how close this run came to a coin toss)
+                            big = max(v_inc, v_dec)
+                            margin = abs(v_inc - v_dec) / big if big > 0 else 1.0
+                            DIAG["min_direction_margin"] = min(DIAG.get("min_direction_margin", 1.0), margin)
                     else:
                         xq = d @ means                                                  # scale.py:87
                     cur[:, p] = treat_numpy(xq) * corr
@@ -409,8 +420,10 @@ def loadings(Xt, scores, model: Model):
 
 
 # ----------------------------------------------------------------------------- whole fit / bootstrap
-def fit(X, model: Model, corr: Optional[float] = None):
+def fit(X, model: Model, corr: Optional[float] = None, _treated=None):
     """Estimator.estimate + the statistics the hot path feeds (estimator.py:29-55, plspm.py:63-72).
+    `_treated` (fit_two_stage only): (treated data, dummy matrices) of a non-metric model that Config.treat produced earlier -- the second stage of a HOC
+    estimate runs on the treatment of the FIRST (estimator.py:33,52: `treated_data` is treated once).
 
     `corr` defaults to sqrt(N/(N-1)) of X; the bootstrap passes the ORIGINAL fit's value
     (the calculator is built once, plspm.py:65-67, and cloned per replicate).
@@ -419,7 +432,7 @@ def fit(X, model: Model, corr: Optional[float] = None):
     if corr is None:
         corr = correction(n)
     if model.scales is not None:
-        X0, dummies = treat_nonmetric_full(X, model.scales)       # estimator.py:33 (config.py:306-318)
+        X0, dummies = _treated if _treated is not None else treat_nonmetric_full(X, model.scales)       # estimator.py:33 (config.py:306-318)
         s = solve_nonmetric(X0, model, corr, dummies)             # estimator.py:39 non-metric
         Xt = s["data"]
         s["sign"] = np.ones(model.L)
@@ -443,16 +456,25 @@ def fit_two_stage(X, model1: Model, stage2, C2, modes2, corr: Optional[float] = 
     """Estimator.estimate with higher order constructs (estimator.py:29-55): stage 1 = `model1` (every HOC replaced by its
     constituent LVs, estimator.py:60-74); stage 2 = the original path `C2` where LV l is `stage2[l]`: ("lv", j) -- stage-1
     LV j with its own MVs -- or ("hoc", [j, ...]) -- a HOC whose MVs are the stage-1 SCORES of those LVs, Scale.NUM
-    (estimator.py:43-52).  Non-metric (NUM / RAW) models only, as in the reference.  Returns the stage-2 fit (its MV order:
+    (estimator.py:43-52).  Non-metric models (NUM / RAW / ORD / NOM columns).  Returns the stage-2 fit (its MV order:
     stage-2 LV by LV) plus `iterations1`."""
     if corr is None:
         corr = correction(X.shape[0])
-    r1 = fit(X, model1, corr)
-    cols, blocks2 = [], []
+    # Config.treat runs ONCE per estimate (estimator.py:33); the second stage is calculate(treated_data, config.path()) on that same frame with one score
+    # column per constituent added (estimator.py:43-52): a plain MV enters stage 2 with its TREATED values -- rank codes for ORD / NOM, with the dummy
+    # matrices of the first treatment (config.dummies) -- not with the quantification stage 1 ended on.  (Ranking the quantified column instead merges every
+    # pair of categories that stage 1 had pooled: found by tests/golden/sweep_oracle_vs_reference.py `hocord`, round 6; NUM / RAW columns are standardised
+    # values either way.)
+    treated1 = treat_nonmetric_full(X, model1.scales) if model1.scales is not None else None
+    r1 = fit(X, model1, corr, _treated=treated1)
+    cols, blocks2, dummies2 = [], [], {}
     for kind, ref in stage2:
         start = len(cols)
         if kind == "lv":
-            cols.extend(r1["treated"][:, p] for p in model1.blocks[ref])      # treated_data keeps the stage-1 treatment (estimator.py:33,47)
+            for p in model1.blocks[ref]:
+                if treated1 is not None and p in treated1[1]:
+                    dummies2[len(cols)] = treated1[1][p]
+                cols.append(treated1[0][:, p] if treated1 is not None else r1["treated"][:, p])
         else:
             cols.extend(r1["scores"][:, j] for j in ref)
         blocks2.append(np.arange(start, len(cols)))
@@ -462,7 +484,7 @@ def fit_two_stage(X, model1: Model, stage2, C2, modes2, corr: Optional[float] = 
     for kind, ref in stage2:
         scales2.extend([model1.scales[p] for p in model1.blocks[ref]] if (kind == "lv" and model1.scales is not None) else ["NUM"] * (len(model1.blocks[ref]) if kind == "lv" else len(ref)))
     model2 = Model(blocks2, np.asarray(C2), modes2, model1.scheme, model1.scaled, max_iter=model1.max_iter, tol=model1.tol, scales=scales2)
-    r2 = fit(X2, model2, corr)
+    r2 = fit(X2, model2, corr, _treated=(X2, dummies2) if treated1 is not None else None)
     r2["iterations1"] = r1["iterations"]
     return r2
 

@@ -1,0 +1,161 @@
+"""Seeded random models for the differential fuzz tests (tests/test_gpu_fuzz.py, tools/experiments/*_fuzz_sweep.py) and for the oracle-against-the-real-reference sweep
+(tests/golden/sweep_oracle_vs_reference.py, build container only).  NumPy + the oracle's Model only: importable beside the reference's `plspm` package."""
+import numpy as np
+
+import plspm_oracle as orc
+
+
+def _random_dag(L, rng, density=0.5):
+    C = np.zeros((L, L), dtype=np.int64)
+    for i in range(1, L):
+        for j in range(i):
+            if rng.random() < density:
+                C[i, j] = 1
+        if C[i].sum() == 0 and C[:, i].sum() == 0:
+            C[i, rng.integers(0, i)] = 1
+    return C
+
+
+def _ragged(n, C, sizes, seed):
+    rng = np.random.default_rng(seed)
+    L = C.shape[0]
+    eta = np.zeros((n, L))
+    for j in range(L):
+        eta[:, j] = rng.standard_normal(n) + 0.4 * eta[:, C[j] == 1].sum(axis=1)
+    cols, blocks, at = [], [], 0
+    for j, k in enumerate(sizes):
+        lam = np.linspace(0.6, 0.9, k)
+        cols.append(eta[:, [j]] * lam[None, :] + 0.6 * rng.standard_normal((n, k)) + 3.0 * (j + 1))     # non-zero means on purpose
+        blocks.append(np.arange(at, at + k)); at += k
+    return np.column_stack(cols), blocks
+
+
+def make_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.integers(2, 9))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 9)) for _ in range(L)]
+    n = int(rng.integers(30, 700))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    modes = "".join("AB"[int(rng.integers(0, 2))] if sizes[l] > 1 else "A" for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    nonmetric = bool(rng.integers(0, 3) == 0)
+    scaled = bool(rng.integers(0, 2))
+    model = orc.Model(blocks, C, modes, scheme, scaled, tol=1e-6 if not nonmetric else 1e-7,
+                      scales=(["NUM"] * X.shape[1]) if nonmetric else None)
+    return X, model, nonmetric
+
+
+def make_cat_case(seed):
+    rng = np.random.default_rng(7000 + seed)
+    L = int(rng.integers(2, 7))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 6)) for _ in range(L)]
+    n = int(rng.integers(60, 900))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    P = X.shape[1]
+    kind = int(rng.integers(0, 3))            # 0 all ORD, 1 ORD / NOM mix, 2 with NUM columns
+    scales, data = [], X.copy()
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    for p in range(P):
+        s = "ORD" if kind == 0 else ("ORD", "NOM")[int(rng.integers(0, 2))] if kind == 1 else ("ORD", "NOM", "NUM")[int(rng.integers(0, 3))]
+        scales.append(s)
+        if s != "NUM":
+            c = int(rng.integers(2, 13))
+            data[:, p] = np.clip(np.round((c + 1) / 2.0 + float(rng.uniform(0.6, 1.4)) * c / 5.0 * Z[:, p]), 1, c)
+    all_a = bool(rng.integers(0, 2))
+    modes = "".join("A" if all_a or sizes[l] == 1 else "AB"[int(rng.integers(0, 2))] for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    model = orc.Model(blocks, C, modes, scheme, True, tol=1e-6, scales=scales)
+    return data, model
+
+
+def make_missing_case(seed):
+    rng = np.random.default_rng(9000 + seed)
+    L = int(rng.integers(2, 8))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 8)) for _ in range(L)]
+    n = int(rng.integers(50, 1200))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    P = X.shape[1]
+    Xn = X.copy()
+    ncols = int(rng.integers(1, P + 1))
+    for col in rng.choice(P, size=ncols, replace=False):
+        k = int(rng.integers(1, max(2, int(0.15 * n))))
+        Xn[rng.choice(n, size=k, replace=False), col] = np.nan
+    modes = "".join("AB"[int(rng.integers(0, 2))] if sizes[l] > 1 else "A" for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    model = orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2)))
+    return Xn, model
+
+
+def make_nmx_case(seed):
+    """Scale.NUM / RAW data with NaN cells: the NaN-aware Mode-A products of mode.py:35-41 (blocks with a missing cell must be Mode A: mode.py:55-56)."""
+    rng = np.random.default_rng(10000 + seed)
+    L = int(rng.integers(2, 7))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 7)) for _ in range(L)]
+    n = int(rng.integers(40, 800))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    Xn = X.copy()
+    nrows = int(rng.integers(1, max(2, int(0.1 * n))))
+    miss_blocks = set()
+    for r in rng.choice(n, size=nrows, replace=False):
+        l = int(rng.integers(0, L))
+        if sizes[l] == 1:
+            continue                                                       # (an LV whose only MV is missing in a row has no score there: the reference raises)
+        k = int(rng.integers(1, sizes[l]))
+        Xn[r, rng.choice(blocks[l], size=k, replace=False)] = np.nan
+        miss_blocks.add(l)
+    modes = "".join("A" if (l in miss_blocks or sizes[l] == 1) else "AB"[int(rng.integers(0, 2))] for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    raw = bool(rng.integers(0, 4) == 0)
+    model = orc.Model(blocks, C, modes, scheme, True, tol=1e-7, scales=["RAW" if raw else "NUM"] * X.shape[1])
+    return Xn, model
+
+
+def make_hoc_case(seed):
+    rng = np.random.default_rng(11000 + seed)
+    L2 = int(rng.integers(3, 7))
+    C2 = _random_dag(L2, rng, density=float(rng.uniform(0.4, 0.9)))
+    h = int(rng.integers(0, L2))                               # the HOC
+    k = int(rng.integers(2, 4))                                # its constituents
+    expand = [[l] for l in range(L2)]
+    first_of = []
+    at = 0
+    for l in range(L2):
+        first_of.append(at)
+        at += k if l == h else 1
+    L1 = at
+    first_of.append(L1)
+    owner = []                                                 # stage-1 LV -> stage-2 LV
+    for l in range(L2):
+        owner += [l] * (k if l == h else 1)
+    C1 = np.zeros((L1, L1), dtype=int)
+    for i in range(L1):
+        for j in range(L1):
+            if owner[i] != owner[j]:
+                C1[i, j] = C2[owner[i], owner[j]]
+    sizes = [int(rng.integers(1, 6)) for _ in range(L1)]
+    n = int(rng.integers(80, 700))
+    X, blocks = _ragged(n, C1, sizes, seed=seed)
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    modes1 = "".join("AB"[int(rng.integers(0, 2))] if sizes[i] > 1 else "A" for i in range(L1))
+    # stage 2: a plain LV keeps its mode, the HOC block (k score columns) takes a mode of its own
+    modes2 = "".join(("AB"[int(rng.integers(0, 2))] if l == h else modes1[first_of[l]]) for l in range(L2))
+    stage2 = [("hoc", list(range(first_of[l], first_of[l + 1]))) if l == h else ("lv", first_of[l]) for l in range(L2)]
+    model1 = orc.Model(blocks, C1, modes1, scheme, True, tol=1e-7, scales=["NUM"] * X.shape[1])
+    return X, model1, stage2, C2, modes2, first_of
+
+
+def make_hoc_ord_case(seed):
+    """The HOC model of make_hoc_case on ordinal items (3 .. 7 categories per MV, all Mode A: the reference's Mode-B correction of ordinal blocks is exercised by make_cat_case)."""
+    X, model1, stage2, C2, modes2, first_of = make_hoc_case(seed)
+    rng = np.random.default_rng(12000 + seed)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    data = X.copy()
+    for p in range(X.shape[1]):
+        c = int(rng.integers(3, 8))
+        data[:, p] = np.clip(np.round((c + 1) / 2.0 + float(rng.uniform(0.7, 1.3)) * c / 5.0 * Z[:, p]), 1, c)
+    model1 = orc.Model(model1.blocks, model1.C, "A" * model1.L, model1.scheme, True, tol=1e-6, scales=["ORD"] * X.shape[1])
+    return data, model1, stage2, C2, "A" * len(stage2), first_of

@@ -6,26 +6,11 @@ import pytest
 
 import plspm_oracle as orc
 from helpers import assert_close, assert_device_status_justified
+from fuzz_cases import make_case, make_cat_case, make_hoc_case, make_missing_case, make_nmx_case
 from test_gpu_parity import SCHEME_ID, _ragged, _random_dag
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-7, 1e-10
-
-
-def make_case(seed):
-    rng = np.random.default_rng(1000 + seed)
-    L = int(rng.integers(2, 9))
-    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
-    sizes = [int(rng.integers(1, 9)) for _ in range(L)]
-    n = int(rng.integers(30, 700))
-    X, blocks = _ragged(n, C, sizes, seed=seed)
-    modes = "".join("AB"[int(rng.integers(0, 2))] if sizes[l] > 1 else "A" for l in range(L))
-    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
-    nonmetric = bool(rng.integers(0, 3) == 0)
-    scaled = bool(rng.integers(0, 2))
-    model = orc.Model(blocks, C, modes, scheme, scaled, tol=1e-6 if not nonmetric else 1e-7,
-                      scales=(["NUM"] * X.shape[1]) if nonmetric else None)
-    return X, model, nonmetric
 
 
 @pytest.mark.parametrize("seed", range(60))
@@ -250,32 +235,9 @@ def test_random_num_model_on_the_one_launch_route(seed):
 
 # ---- categorical (Scale.ORD / NOM / NUM mixes): random path models, block sizes, category counts (2 .. 12), modes and schemes -- the fit and six bootstrap replicates on
 # explicit index lists against the oracle, through the wave step where it covers the model and the workgroup step elsewhere; where both exist, the same records from both
-def make_cat_case(seed):
-    rng = np.random.default_rng(7000 + seed)
-    L = int(rng.integers(2, 7))
-    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
-    sizes = [int(rng.integers(1, 6)) for _ in range(L)]
-    n = int(rng.integers(60, 900))
-    X, blocks = _ragged(n, C, sizes, seed=seed)
-    P = X.shape[1]
-    kind = int(rng.integers(0, 3))            # 0 all ORD, 1 ORD / NOM mix, 2 with NUM columns
-    scales, data = [], X.copy()
-    Z = (X - X.mean(axis=0)) / X.std(axis=0)
-    for p in range(P):
-        s = "ORD" if kind == 0 else ("ORD", "NOM")[int(rng.integers(0, 2))] if kind == 1 else ("ORD", "NOM", "NUM")[int(rng.integers(0, 3))]
-        scales.append(s)
-        if s != "NUM":
-            c = int(rng.integers(2, 13))
-            data[:, p] = np.clip(np.round((c + 1) / 2.0 + float(rng.uniform(0.6, 1.4)) * c / 5.0 * Z[:, p]), 1, c)
-    all_a = bool(rng.integers(0, 2))
-    modes = "".join("A" if all_a or sizes[l] == 1 else "AB"[int(rng.integers(0, 2))] for l in range(L))
-    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
-    model = orc.Model(blocks, C, modes, scheme, True, tol=1e-6, scales=scales)
-    return data, model
-
-
 def _cat_case_check(seed):
     import test_gpu_categorical as tc
+    from plspm import _native
     data, model = make_cat_case(seed)
     n = data.shape[0]
     tag = "seed %d L=%d P=%d n=%d %s %s %s" % (seed, model.L, data.shape[1], n, model.modes, model.scheme, "".join(s[0] for s in model.scales))
@@ -312,8 +274,17 @@ def _cat_case_check(seed):
             continue
         if not np.all(np.isfinite(mine)):
             continue
-        assert status[b] == 0 and its == iters[b], tag + " replicate %d: status %d iterations %d vs oracle %d" % (b, status[b], iters[b], its)
-        assert_close(rows[b], mine, 1e-6, 1e-8, what=tag + " replicate %d" % b)
+        try:
+            assert status[b] == 0 and its == iters[b], tag + " replicate %d: status %d iterations %d vs oracle %d" % (b, status[b], iters[b], its)
+            assert_close(rows[b], mine, 1e-6, 1e-8, what=tag + " replicate %d" % b)
+        except AssertionError:
+            orc.DIAG = {}                                   # (see below: a direction decision of scale.py:74 that is a tie in exact arithmetic)
+            with np.errstate(all="ignore"):
+                orc.bootstrap_replicate(data, model, idx[b], corr)
+            margin, orc.DIAG = orc.DIAG.get("min_direction_margin", 1.0), None
+            if margin >= 1e-9:
+                raise
+            continue
         compared += 1
     # the device's own resampling: the same records whatever the route (wave step / workgroup step), where both exist
     if route == "wave":
@@ -321,9 +292,19 @@ def _cat_case_check(seed):
         nm.set_option("nm_wave", 0)
         w = nm.bootstrap(40, seed=seed)
         nm.set_option("nm_wave", 1)
-        assert np.array_equal(a[1], w[1]) and np.array_equal(a[2], w[2]), tag + ": wave / workgroup step disagree on status or iterations"
-        ok = a[1] == 0
-        assert_close(a[0][ok], w[0][ok], 1e-9, 1e-11, what=tag + " wave vs workgroup step")
+        same = (a[1] == w[1]) & (a[2] == w[2]) & np.array([a[1][r] != 0 or np.allclose(a[0][r], w[0][r], rtol=1e-9, atol=1e-11) for r in range(40)])
+        for r in np.flatnonzero(~same):
+            # the two forms may part ways only where the REFERENCE's own answer is a coin toss: an ordinal MV whose increasing and decreasing poolings have the same
+            # variance in exact arithmetic (scale.py:74 `var_incr < var_decr`, decided by np.var's rounding) -- seed 1553, replicate 6: means (a, b, a), equal counts
+            orc.DIAG = {}
+            try:
+                with np.errstate(all="ignore"):
+                    orc.bootstrap_replicate(data, model, _native.bootstrap_indices(seed, int(r), n), corr)
+            except Exception:
+                pass
+            margin, orc.DIAG = orc.DIAG.get("min_direction_margin", 1.0), None
+            assert margin < 1e-9, tag + " replicate %d: wave / workgroup step disagree (status %d / %d, iterations %d / %d) with no tie in the oracle (margin %.3g)" % (
+                r, a[1][r], w[1][r], a[2][r], w[2][r], margin)
     return route + "/%d" % compared
 
 
@@ -350,3 +331,214 @@ def test_exact_tie_of_category_means_fails_like_the_reference():
         rows, status, iters = nm.bootstrap(6, idx=idx)
         assert nm.get_option("last_nm_wave") == wave
         assert status[4] != 0 and np.all(status[[0, 1, 2, 3, 5]] == 0), (wave, status.tolist(), iters.tolist())
+
+
+# ---- missing data: metric models with NaN cells (mean imputation on the moments, re-imputed per replicate) and Scale.NUM / RAW models with incomplete rows (the NaN-aware
+# Mode-A products of mode.py:35-41) -- random models, fit + five replicates on explicit index lists against the oracle
+def _missing_case_check(seed):
+    import test_gpu_missing as tm
+    Xn, model = make_missing_case(seed)
+    n, P = Xn.shape
+    tag = "seed %d L=%d P=%d n=%d %s %s scaled=%d nan=%d" % (seed, model.L, P, n, model.modes, model.scheme, model.scaled, int(np.isnan(Xn).sum()))
+    try:
+        ref = orc.fit(Xn, model)
+    except orc.NotConverged:
+        ref = None
+    nm, inv = tm.gpu_model(Xn, model)
+    out = nm.fit(want_scores=True)
+    if ref is None:
+        assert out["status"] == 1, tag
+        return "notconv"
+    if out["status"] != 0:
+        return "device-status-%d" % out["status"]
+    assert out["iterations"] == ref["iterations"], tag + ": iterations %d vs %d" % (out["iterations"], ref["iterations"])
+    assert_close(out["weights"][inv], ref["weights"], 1e-6, 1e-9, what=tag + " weights")
+    assert_close(out["loadings"][inv], ref["loadings"], 1e-6, 1e-9, what=tag + " loadings")
+    assert_close(out["path_coef"], ref["path_coef"], 1e-6, 1e-9, what=tag + " paths")
+    assert_close(out["scores"], ref["scores"], 1e-6, 1e-8, what=tag + " scores")
+    B = 5
+    idx = np.random.RandomState(seed).randint(n, size=(B, n)).astype(np.int32)
+    rows, status, iters = nm.bootstrap(B, idx=idx)
+    rows = tm.rows_in_data_order(rows, inv, P, model.L, nm.n_eff)
+    corr = orc.correction(n)
+    compared = 0
+    for b in range(B):
+        try:
+            with np.errstate(all="ignore"):
+                mine, its = orc.bootstrap_replicate(Xn, model, idx[b], corr)
+        except Exception:
+            assert status[b] != 0, tag + " replicate %d: the oracle cannot finish, device status 0" % b
+            continue
+        if not np.all(np.isfinite(mine)):
+            assert status[b] != 0, tag + " replicate %d: oracle row not finite, device status 0" % b
+            continue
+        if status[b] != 0:
+            continue                                                        # (device-only status: conditioning -- counted below)
+        assert its == iters[b], tag + " replicate %d: iterations %d vs %d" % (b, iters[b], its)
+        assert_close(rows[b], mine, 1e-6, 1e-8, what=tag + " replicate %d" % b)
+        compared += 1
+    return "ok/%d" % compared
+
+
+def _nmx_case_check(seed):
+    import test_gpu_nmx as tx
+    Xn, model = make_nmx_case(seed)
+    n, P = Xn.shape
+    tag = "nmx seed %d L=%d P=%d n=%d %s %s %s nan=%d" % (seed, model.L, P, n, model.modes, model.scheme, model.scales[0], int(np.isnan(Xn).sum()))
+    try:
+        with np.errstate(all="ignore"):
+            ref = orc.fit(Xn, model)
+    except orc.NotConverged:
+        ref = None
+    nm, inv = tx.gpu_model(Xn, model)
+    out = nm.fit(want_scores=True)
+    if ref is None:
+        assert out["status"] == 1, tag
+        return "nmx-notconv"
+    if out["status"] != 0:
+        return "nmx-device-status-%d" % out["status"]
+    tx.check_fit(out, ref, inv, tag)
+    B = 5
+    idx = np.random.RandomState(seed).randint(n, size=(B, n)).astype(np.int32)
+    rows, status, iters = nm.bootstrap(B, idx=idx)
+    rows = tx.rows_in_data_order(rows, inv, P, model.L, nm.n_eff)
+    corr = orc.correction(n)
+    compared = 0
+    for b in range(B):
+        try:
+            with np.errstate(all="ignore"):
+                mine, its = orc.bootstrap_replicate(Xn, model, idx[b], corr)
+        except Exception:
+            assert status[b] != 0, tag + " replicate %d: the oracle cannot finish, device status 0" % b
+            continue
+        if not np.all(np.isfinite(mine)):
+            assert status[b] != 0, tag + " replicate %d: oracle row not finite, device status 0" % b
+            continue
+        if status[b] != 0:
+            continue
+        assert its == iters[b], tag + " replicate %d: iterations %d vs %d" % (b, iters[b], its)
+        assert_close(rows[b], mine, 1e-6, 1e-8, what=tag + " replicate %d" % b)
+        compared += 1
+    return "nmx-ok/%d" % compared
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_model_with_missing_cells(seed):
+    _missing_case_check(seed)
+    _nmx_case_check(seed)
+
+
+# ---- higher order constructs (Scale.NUM): random stage-2 path models with one HOC of two or three first-stage constituents (stage 1 = the path with the HOC expanded in
+# place, estimator.py:60-74), both stages of five replicates on explicit index lists (the first: the data themselves) against the oracle's fit_two_stage
+def _hoc_case_check(seed):
+    from plspm import _native
+    X, model1, stage2, C2, modes2, first_of = make_hoc_case(seed)
+    n = X.shape[0]
+    L2 = len(stage2)
+    tag = "seed %d L1=%d L2=%d P=%d n=%d %s/%s %s" % (seed, model1.L, L2, X.shape[1], n, model1.modes, modes2, model1.scheme)
+    boff1 = np.concatenate(([0], np.cumsum([len(b) for b in model1.blocks]))).astype(np.int32)
+    m1 = np.array([0 if m == "A" else 1 for m in model1.modes], dtype=np.int32)
+    first = _native.NativeModel(boff1, model1.C.astype(np.uint8), m1, SCHEME_ID[model1.scheme], True, 100, 1e-7, 0, nonmetric=True)
+    first.upload(X[:, np.concatenate(model1.blocks)])
+    sizes2 = [(len(ref) if kind == "hoc" else len(model1.blocks[ref])) for kind, ref in stage2]
+    boff2 = np.concatenate(([0], np.cumsum(sizes2))).astype(np.int32)
+    m2 = np.array([0 if m == "A" else 1 for m in modes2], dtype=np.int32)
+    second = _native.NativeModel(boff2, np.asarray(C2).astype(np.uint8), m2, SCHEME_ID[model1.scheme], True, 100, 1e-7, 0, nonmetric=True)
+    first.attach_second_stage(second, list(first_of))
+    B = 5
+    idx = np.vstack([np.arange(n), np.random.RandomState(seed).randint(n, size=(B - 1, n))]).astype(np.int32)
+    rows, status, iters = first.bootstrap(B, idx=idx)
+    corr = orc.correction(n)
+    compared = 0
+    for b in range(B):
+        try:
+            with np.errstate(all="ignore"):
+                o = orc.fit_two_stage(X[idx[b]], model1, stage2, C2, modes2, corr)
+            mine = np.concatenate((o["weights"], o["r2"], o["total"], o["direct"], o["loadings"]))
+        except Exception:
+            assert status[b] != 0, tag + " replicate %d: the oracle cannot finish, device status 0" % b
+            continue
+        if not np.all(np.isfinite(mine)):
+            assert status[b] != 0, tag + " replicate %d: oracle row not finite, device status 0" % b
+            continue
+        if status[b] != 0:
+            continue
+        assert o["iterations"] == iters[b], tag + " replicate %d: stage-2 iterations %d vs %d" % (b, iters[b], o["iterations"])
+        assert_close(rows[b], mine, 1e-6, 1e-8, what=tag + " replicate %d" % b)
+        compared += 1
+    second.close(); first.close()
+    return "ok/%d" % compared
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_hoc_model_two_stage_bootstrap(seed):
+    _hoc_case_check(seed)
+
+
+# ---- higher order constructs on ORDINAL items through the host API (Estimator.two_stage_bootstrap_handles: both stages of every replicate on the device, the second stage on
+# the congruence of the first stage's count matrices): the rows of explicit index lists against the oracle's fit_two_stage -- whose second stage runs on the FIRST treatment's
+# rank codes and dummy matrices, as the reference's does (estimator.py:33,52; pinned by tests/golden/sweep_oracle_vs_reference.py `hocord`)
+def _hoc_ord_case_check(seed):
+    import pandas as pd
+    import plspm.config as c
+    import plspm.weights as w
+    from fuzz_cases import make_hoc_ord_case
+    from plspm.estimator import Estimator
+    from plspm.mode import Mode
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    data, model1, stage2, C2, modes2, first_of = make_hoc_ord_case(seed)
+    n = data.shape[0]
+    lvs1 = ["L%d" % l for l in range(model1.L)]
+    lv2 = ["H" if kind == "hoc" else lvs1[ref] for kind, ref in stage2]
+    tag = "seed %d L1=%d L2=%d P=%d n=%d %s" % (seed, model1.L, len(stage2), data.shape[1], n, model1.scheme)
+    df = pd.DataFrame(data, columns=["x%d" % p for p in range(data.shape[1])])
+    config = c.Config(pd.DataFrame(np.asarray(C2, dtype=int), index=lv2, columns=lv2), default_scale=Scale.ORD)
+    for (kind, ref), name in zip(stage2, lv2):
+        if kind == "hoc":
+            config.add_higher_order(name, Mode.A, [lvs1[j] for j in ref])
+    for l in range(model1.L):
+        config.add_lv(lvs1[l], Mode.A, *[c.MV("x%d" % p) for p in model1.blocks[l]])
+    scheme = {"centroid": Scheme.CENTROID, "factorial": Scheme.FACTORIAL, "path": Scheme.PATH}[model1.scheme]
+    observations = config.filter(df)
+    corr = orc.correction(n)
+    calculator = w.WeightsCalculatorFactory(config, 100, model1.tol, corr, scheme, 0)
+    pair = Estimator(config).two_stage_bootstrap_handles(calculator, observations)
+    names = []                                                 # the oracle's stage-2 MV order
+    for kind, ref in stage2:
+        names += [lvs1[j] for j in ref] if kind == "hoc" else ["x%d" % p for p in model1.blocks[ref]]
+    dev = list(pair.compiled.dev_mvs)
+    assert sorted(dev) == sorted(names), tag
+    perm = np.array([dev.index(x) for x in names])
+    B = 5
+    idx = np.vstack([np.arange(n), np.random.RandomState(seed).randint(n, size=(B - 1, n))]).astype(np.int32)
+    rows, status, iters = pair.native.bootstrap(B, idx=idx)
+    P2, L2 = len(names), len(stage2)
+    ne = (rows.shape[1] - 2 * P2 - L2) // 2
+    rows = np.concatenate((rows[:, :P2][:, perm], rows[:, P2:P2 + L2 + 2 * ne], rows[:, P2 + L2 + 2 * ne:][:, perm]), axis=1)
+    compared = 0
+    for b in range(B):
+        orc.DIAG = {}
+        try:
+            with np.errstate(all="ignore"):
+                o = orc.fit_two_stage(data[idx[b]], model1, stage2, C2, modes2, corr)
+            mine = np.concatenate((o["weights"], o["r2"], o["total"], o["direct"], o["loadings"]))
+        except Exception:
+            orc.DIAG = None
+            assert status[b] != 0, tag + " replicate %d: the oracle cannot finish, device status 0" % b
+            continue
+        margin, orc.DIAG = orc.DIAG.get("min_direction_margin", 1.0), None
+        if not np.all(np.isfinite(mine)):
+            assert status[b] != 0, tag + " replicate %d: oracle row not finite, device status 0" % b
+            continue
+        if status[b] != 0 or margin < 1e-9:                    # (a direction decision that is a tie in exact arithmetic: see _cat_case_check)
+            continue
+        assert o["iterations"] == iters[b], tag + " replicate %d: stage-2 iterations %d vs %d" % (b, iters[b], o["iterations"])
+        assert_close(rows[b], mine, 1e-6, 1e-8, what=tag + " replicate %d" % b)
+        compared += 1
+    return "ok/%d" % compared
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_hoc_model_on_ordinal_items(seed):
+    _hoc_ord_case_check(seed)

@@ -9,6 +9,7 @@ import pandas as pd
 import pytest
 
 import plspm_oracle as orc
+from fuzz_cases import _ragged, _random_dag
 from helpers import (GOLDEN, assert_close, case_modes, load, satisfaction_frame, satisfaction_oracle_inputs, SAT_ADD_ORDER,
                      SAT_PREFIX)
 
@@ -440,31 +441,6 @@ def test_bootstrap_large_n_histogram_paths(n):
 
 
 # ------------------------------------------------------------------ edge cases (ragged blocks, limits, tiny inputs)
-def _random_dag(L, rng, density=0.5):
-    C = np.zeros((L, L), dtype=np.int64)
-    for i in range(1, L):
-        for j in range(i):
-            if rng.random() < density:
-                C[i, j] = 1
-        if C[i].sum() == 0 and C[:, i].sum() == 0:
-            C[i, rng.integers(0, i)] = 1
-    return C
-
-
-def _ragged(n, C, sizes, seed):
-    rng = np.random.default_rng(seed)
-    L = C.shape[0]
-    eta = np.zeros((n, L))
-    for j in range(L):
-        eta[:, j] = rng.standard_normal(n) + 0.4 * eta[:, C[j] == 1].sum(axis=1)
-    cols, blocks, at = [], [], 0
-    for j, k in enumerate(sizes):
-        lam = np.linspace(0.6, 0.9, k)
-        cols.append(eta[:, [j]] * lam[None, :] + 0.6 * rng.standard_normal((n, k)) + 3.0 * (j + 1))     # non-zero means on purpose
-        blocks.append(np.arange(at, at + k)); at += k
-    return np.column_stack(cols), blocks
-
-
 @pytest.mark.parametrize("scheme", ["centroid", "factorial", "path"])
 def test_ragged_blocks_including_single_item_constructs(scheme):
     rng = np.random.default_rng(4)

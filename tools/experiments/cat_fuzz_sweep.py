@@ -1,7 +1,7 @@
 """Differential fuzz of the categorical (Scale.ORD / NOM / NUM mixes) path against the oracle: random path models, block sizes, category counts (2 .. 12), modes
 and schemes; the fit (iterations, weights, loadings, path coefficients, scores) and bootstrap replicates on explicit index lists -- through the wave step where it covers
-the model and the workgroup step elsewhere.  Seeds A .. B from the command line; prints the route histogram and the failures.  (A test-side tool: it drives the
-checker of tests/test_gpu_categorical.py.)"""
+the model and the workgroup step elsewhere.  Seeds A .. B from the command line; prints the route histogram and the failures.  (A test-side tool: generator and checker live in
+tests/test_gpu_fuzz.py.)"""
 import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("plspm-python_amd", "oracle", "tests"):
