@@ -159,3 +159,38 @@ def make_hoc_ord_case(seed):
         data[:, p] = np.clip(np.round((c + 1) / 2.0 + float(rng.uniform(0.7, 1.3)) * c / 5.0 * Z[:, p]), 1, c)
     model1 = orc.Model(model1.blocks, model1.C, "A" * model1.L, model1.scheme, True, tol=1e-6, scales=["ORD"] * X.shape[1])
     return data, model1, stage2, C2, "A" * len(stage2), first_of
+
+
+def make_hostile_case(seed):
+    """Metric models whose DATA are unkind to a fixed-point evaluation of the moments (the int8 digit-plane Gram): columns on scales from 1e-6 to 1e6,
+    offsets of up to 1e7 standard deviations, heavy tails, a handful of cells a thousand times their column's scale, five- / seven-point items read as numbers.
+    At most 40 MVs in 2 ... 8 blocks, 300 ... 3,000 rows."""
+    rng = np.random.default_rng(13000 + seed)
+    L = int(rng.integers(2, 9))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 6)) for _ in range(L)]
+    n = int(rng.integers(300, 3000))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    P = X.shape[1]
+    kind = int(rng.integers(0, 6))
+    allA = bool(rng.integers(0, 2))
+    modes = "".join("A" if allA or sizes[l] == 1 else "AB"[int(rng.integers(0, 2))] for l in range(L))
+    # (Mode-B weights are inverse to the data's scale and the stop rule is an ABSOLUTE tolerance on them (weights.py:179-186): with a block of columns twelve orders of magnitude
+    #  apart -- a covariance matrix of condition 1e24 -- or a global scale factor of 1e12 the reference's own trip count is rounding noise; such models keep three orders of magnitude)
+    span, off = (6.0, 7.0) if "B" not in modes else (1.5, 3.0)
+    X = X - X.mean(axis=0)
+    sd = X.std(axis=0)
+    if kind in (0, 5):                                         # scales
+        X = X * (10.0 ** rng.uniform(-span, span, size=P))[None, :]
+    if kind in (1, 5):                                         # offsets in units of the column's own spread
+        X = X + (X.std(axis=0) * 10.0 ** rng.uniform(0, off, size=P) * rng.choice([-1.0, 1.0], size=P))[None, :]
+    if kind == 2:                                              # heavy tails
+        X = X + sd[None, :] * rng.standard_t(1.5, size=(n, P)) * 0.3
+    if kind == 3:                                              # items read as numbers
+        c = int(rng.choice([5, 7]))
+        X = np.clip(np.round((c + 1) / 2.0 + c / 5.0 * X / sd[None, :]), 1, c)
+    if kind == 4:                                              # a few wild cells
+        k = max(1, int(0.004 * n * P))
+        X[rng.integers(0, n, size=k), rng.integers(0, P, size=k)] *= 1.0e3
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    return X, orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2))), sizes, kind

@@ -542,3 +542,62 @@ def _hoc_ord_case_check(seed):
 @pytest.mark.parametrize("seed", range(12))
 def test_random_hoc_model_on_ordinal_items(seed):
     _hoc_ord_case_check(seed)
+
+
+# ---- data that are unkind to a fixed-point evaluation of the moments (fuzz_cases.make_hostile_case): the int8 digit-plane route against the fp64 MFMA route on the same
+# Philox draws (equal status and iteration counts, records to 1e-7) and against the oracle (fit + two replicates)
+def _hostile_case_check(seed, B=48):
+    from fuzz_cases import make_hostile_case
+    from plspm import _native
+    X, model, sizes, kind = make_hostile_case(seed)
+    n, P = X.shape
+    boff = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], model.scaled, model.max_iter, model.tol, 0)
+    nm.upload(X)
+    tag = "seed %d kind %d P=%d n=%d %s %s scaled=%d" % (seed, kind, P, n, model.modes, model.scheme, model.scaled)
+    g = nm.fit(want_scores=True)
+    try:
+        with np.errstate(all="ignore"):
+            r = orc.fit(X, model)
+    except orc.NotConverged:
+        assert g["status"] == 1, tag
+        return "notconv"
+    if g["status"] != 0:
+        assert_device_status_justified(g["status"], X, model, tag)
+        return "device-status"
+    assert g["iterations"] == r["iterations"], tag
+    assert_close(g["weights"], r["weights"], 1e-6, 0.0, what=tag + " weights")
+    assert_close(g["path_coef"], r["path_coef"], 1e-6, 1e-9, what=tag + " paths")
+    assert_close(g["loadings"], r["loadings"], 1e-6, 1e-9, what=tag + " loadings")
+    nm.set_option("gram_path", 2)
+    rows, status, iters = nm.bootstrap(B, seed=seed)
+    planes = nm.get_option("last_i8_slices") if nm.get_option("last_gram_path") == 2 else 0
+    nm.set_option("gram_path", 1)
+    rows_f, status_f, iters_f = nm.bootstrap(B, seed=seed)
+    assert nm.get_option("last_gram_path") == 1
+    both = (status == 0) & (status_f == 0)
+    assert both.sum() >= B // 2 and np.array_equal(status == 0, status_f == 0), (tag, status.tolist(), status_f.tolist())
+    assert np.array_equal(iters[both], iters_f[both]), tag
+    scale = np.maximum(np.abs(rows_f[both]), 1e-3 * np.max(np.abs(rows_f[both]), axis=0, keepdims=True))       # (weights live on the data's scale: relative per column)
+    err = float(np.max(np.abs(rows[both] - rows_f[both]) / np.maximum(scale, 1e-300)))
+    assert err < 1e-7, tag + ": int8 route against the fp64 route %.3g (planes %d)" % (err, planes)
+    corr = orc.correction(n)
+    checked = 0
+    for b in range(B):
+        if checked == 2:
+            break
+        idx = _native.bootstrap_indices(seed, b, n)
+        if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
+            continue
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == iters[b], tag + " replicate %d" % b
+        sc = np.maximum(np.abs(mine), 1e-3 * np.max(np.abs(mine[:P])))
+        assert float(np.max(np.abs(rows[b] - mine) / sc)) < 1e-6, tag + " replicate %d" % b
+        checked += 1
+    return "kind%d/planes%d" % (kind, planes)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_model_on_hostile_data(seed):
+    _hostile_case_check(seed)
