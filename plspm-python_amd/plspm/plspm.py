@@ -21,6 +21,7 @@ import plspm.weights as w
 from plspm.bootstrap import Bootstrap
 from plspm.bootstrap import launch as launch_bootstrap
 from plspm.estimator import Estimator
+from plspm.scale import Scale
 from plspm.scheme import Scheme
 from plspm.unidimensionality import Unidimensionality
 
@@ -98,7 +99,11 @@ class Plspm:
         inner_model = _Lazy(lambda: im.InnerModel.from_device(path, fit))
         outer_model = _Lazy(lambda: om.OuterModel(fit, inner_model.r_squared()))
         inner_summary = _Lazy(lambda: pis.InnerSummary(model_spec, inner_model.r_squared(), inner_model.r_squared_adj(), outer_model.model()))
-        unidimensionality = _Lazy(lambda: Unidimensionality(model_spec, fit, incomplete))
+        # (the reference's block diagnostics standardise the filtered DATA, unidimensionality.py:40: for Scale.ORD / NOM columns those are the category codes, not the quantified
+        #  MVs whose covariance the device returns -- such models hand the observations in)
+        categorical = (not config.metric()) and any(config.scale(mv) in (Scale.ORD, Scale.NOM) for mv in observations.columns)
+        raw = observations if categorical else None
+        unidimensionality = _Lazy(lambda: Unidimensionality(model_spec, fit, incomplete, raw))
         self._scores, self._inner_model, self._outer_model = scores, inner_model, outer_model
         self._inner_summary, self._unidimensionality = inner_summary, unidimensionality
         self._bootstrap = None

@@ -3,7 +3,11 @@
 The reference runs sklearn PCA on every standardised block; the same numbers follow from the block's
 correlation matrix R_b, which is a sub-block of the treated covariance matrix the device already holds
 (``plspm_fit_result_t.cov``): eigenvalues of R_b, Cronbach's alpha = k/(k-1) * 2 sum_{i>j} R_ij / sum_ij R_ij,
-Dillon-Goldstein rho from the first principal component's loadings.  Host arithmetic on k x k matrices."""
+Dillon-Goldstein rho from the first principal component's loadings.  Host arithmetic on k x k matrices.
+
+Data with Scale.ORD / NOM columns are the exception: the reference standardises the FILTERED data of the block (unidimensionality.py:40: the raw category codes), not the
+quantified MVs the estimate ended on, so the device's covariance -- that of the quantified MVs -- is the wrong matrix there (1-2 % off on five- to ten-point items: golden g17);
+such models hand the observations in and the block's correlation matrix is taken from them."""
 import numpy as np
 import pandas as pd
 
@@ -11,10 +15,11 @@ from plspm.mode import Mode
 
 
 class Unidimensionality:
-    def __init__(self, config, result, incomplete_mvs=()):
+    def __init__(self, config, result, incomplete_mvs=(), raw=None):
         self._config = config
         self._result = result
         self._incomplete = set(incomplete_mvs)        # MVs with missing values: their blocks report NaN (unidimensionality.py:39)
+        self._raw = raw                               # the filtered observations of a model with Scale.ORD / NOM columns (else None: the device covariance serves)
 
     def summary(self) -> pd.DataFrame:
         cm = self._result.compiled
@@ -29,9 +34,13 @@ class Unidimensionality:
             out.loc[lv, "mvs"] = k
             if self._incomplete.intersection(self._config.mvs(lv)):
                 continue
-            block = cov[a:b, a:b]
-            d = np.sqrt(np.diag(block))
-            R = block / np.outer(d, d)
+            mvs = list(self._config.mvs(lv))
+            if self._raw is not None and all(mv in self._raw.columns for mv in mvs):
+                R = np.corrcoef(self._raw[mvs].values.astype(np.float64), rowvar=False).reshape(k, k) if k > 1 else np.ones((1, 1))
+            else:
+                block = cov[a:b, a:b]
+                d = np.sqrt(np.diag(block))
+                R = block / np.outer(d, d)
             evals, evecs = np.linalg.eigh(R)
             out.loc[lv, "eig_1st"] = evals[-1]
             out.loc[lv, "eig_2nd"] = evals[-2] if k > 1 else np.nan

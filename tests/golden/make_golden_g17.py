@@ -1,0 +1,88 @@
+#!/opt/conda/bin/python3.9
+"""Golden g17 (build container only): the reference's PUBLIC frames on seeded random models -- outer_model, inner_model (estimates, standard errors, t, p), inner_summary,
+path_coefficients, crossloadings, effects, unidimensionality, goodness_of_fit -- for the host-side statistics this backend computes from device outputs (plspm/inner_model.py,
+inner_summary.py, outer_model.py, unidimensionality.py).  The fixtures of the reference's own data sets pin those on four models; this one adds 12 metric / Scale.NUM models of
+tests/fuzz_cases.make_case and 6 categorical ones of make_cat_case.  Data + expected outputs only (arrays and label strings).
+
+Run:   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/make_golden_g17.py"""
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import make_golden as mg  # noqa: E402
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+import plspm.config as c  # noqa: E402
+from plspm.mode import Mode  # noqa: E402
+from plspm.plspm import Plspm  # noqa: E402
+from plspm.scale import Scale  # noqa: E402
+import fuzz_cases as fc  # noqa: E402
+
+warnings.filterwarnings("ignore")
+SCALE = {"NUM": Scale.NUM, "RAW": Scale.RAW, "ORD": Scale.ORD, "NOM": Scale.NOM}
+
+
+def frames(X, model):
+    L = model.L
+    lvs = ["L%d" % l for l in range(L)]
+    df = pd.DataFrame(X, columns=["x%d" % p for p in range(X.shape[1])])
+    scales = model.scales
+    cfg = c.Config(mg.path_frame(model.C, lvs), scaled=model.scaled, default_scale=(Scale.NUM if scales is not None else None))
+    for l in range(L):
+        cfg.add_lv(lvs[l], Mode.A if model.modes[l] == "A" else Mode.B, *[c.MV("x%d" % p, SCALE[scales[p]] if scales is not None else None) for p in model.blocks[l]])
+    m = Plspm(df, cfg, mg.SCHEMES[model.scheme], 100, model.tol)
+    out = {}
+    for name, fr in (("outer_model", m.outer_model()), ("inner_model", m.inner_model()), ("inner_summary", m.inner_summary()), ("path_coefficients", m.path_coefficients()),
+                     ("crossloadings", m.crossloadings()), ("unidimensionality", m.unidimensionality())):
+        num = fr.select_dtypes(include=[np.number])
+        out[name + "/values"] = num.values.astype(float)
+        out[name + "/index"] = np.array([str(i) for i in fr.index])
+        out[name + "/columns"] = np.array([str(x) for x in num.columns])
+    eff = m.effects()
+    out["effects/from"] = np.array([str(x) for x in eff["from"]]); out["effects/to"] = np.array([str(x) for x in eff["to"]])
+    out["effects/values"] = eff[["direct", "indirect", "total"]].values.astype(float)
+    out["gof"] = np.array(float(m.goodness_of_fit()))
+    return out
+
+
+def main():
+    store = {}
+    cases = []
+    for seed in range(40):
+        X, model, nonmetric = fc.make_case(seed)
+        if any(len(b) < 2 for b in model.blocks):
+            continue                                           # (goodness_of_fit / unidimensionality want blocks of two and more MVs)
+        cases.append(("metric", seed, X, model))
+        if sum(1 for k in cases if k[0] == "metric") == 12:
+            break
+    for seed in range(60):
+        X, model = fc.make_cat_case(seed)
+        if any(len(b) < 2 for b in model.blocks):
+            continue
+        cases.append(("cat", seed, X, model))
+        if sum(1 for k in cases if k[0] == "cat") == 6:
+            break
+    tags = []
+    for kind, seed, X, model in cases:
+        tag = "%s%d" % (kind, seed)
+        try:
+            out = frames(X, model)
+        except Exception as e:                                 # noqa: BLE001
+            print(tag, "reference raised", repr(e)[:120])
+            continue
+        tags.append(tag)
+        store[tag + "/x_sha"] = np.array(mg.sha(X))            # the matrix the generator must reproduce on the GPU box (NumPy's Generator streams are version-stable)
+        for k, v in out.items():
+            store[tag + "/" + k] = v
+        print(tag, X.shape, model.modes, model.scheme, "gof %.6f" % float(out["gof"]))
+    store["tags"] = np.array(tags)
+    np.savez_compressed(os.path.join(HERE, "g17_api_frames.npz"), **store)
+    print("wrote g17_api_frames.npz:", len(tags), "models,", os.path.getsize(os.path.join(HERE, "g17_api_frames.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

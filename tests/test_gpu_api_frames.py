@@ -1,0 +1,57 @@
+"""GPU: the host API's frames on seeded random models against golden g17 (tests/golden/make_golden_g17.py: the REAL reference's outer_model, inner_model with standard errors /
+t / p, inner_summary, path_coefficients, crossloadings, effects, unidimensionality and goodness_of_fit on 12 metric / Scale.NUM models of fuzz_cases.make_case and 6 categorical
+ones of make_cat_case).  The statistics behind them are host arithmetic on device outputs (plspm/inner_model.py from the device's L x L covariance instead of statsmodels,
+plspm/unidimensionality.py by eigh of the device covariance blocks instead of sklearn's PCA ...): the reference's own data sets pin them on four models, this on eighteen more."""
+import hashlib
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import fuzz_cases as fc
+from helpers import assert_close, load
+
+pytestmark = pytest.mark.gpu
+G = load("g17_api_frames")
+TAGS = [str(t) for t in G["tags"]]
+
+
+def _plspm(tag):
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    kind, seed = ("metric", int(tag[6:])) if tag.startswith("metric") else ("cat", int(tag[3:]))
+    if kind == "metric":
+        X, model, _ = fc.make_case(seed)
+    else:
+        X, model = fc.make_cat_case(seed)
+    assert hashlib.sha256(np.ascontiguousarray(X, dtype=np.float64).tobytes()).hexdigest() == str(G[tag + "/x_sha"]), "the generator no longer reproduces the matrix g17 was made from"
+    scale = {"NUM": Scale.NUM, "RAW": Scale.RAW, "ORD": Scale.ORD, "NOM": Scale.NOM}
+    lvs = ["L%d" % l for l in range(model.L)]
+    df = pd.DataFrame(X, columns=["x%d" % p for p in range(X.shape[1])])
+    cfg = c.Config(pd.DataFrame(np.asarray(model.C, dtype=int), index=lvs, columns=lvs), scaled=model.scaled, default_scale=(Scale.NUM if model.scales is not None else None))
+    for l in range(model.L):
+        cfg.add_lv(lvs[l], Mode.A if model.modes[l] == "A" else Mode.B, *[c.MV("x%d" % p, scale[model.scales[p]] if model.scales is not None else None) for p in model.blocks[l]])
+    scheme = {"centroid": Scheme.CENTROID, "factorial": Scheme.FACTORIAL, "path": Scheme.PATH}[model.scheme]
+    return Plspm(df, cfg, scheme, 100, model.tol)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_api_frames_vs_reference_on_random_models(tag):
+    m = _plspm(tag)
+    for name, frame in (("outer_model", m.outer_model()), ("inner_model", m.inner_model()), ("inner_summary", m.inner_summary()), ("path_coefficients", m.path_coefficients()),
+                        ("crossloadings", m.crossloadings()), ("unidimensionality", m.unidimensionality())):
+        num = frame.select_dtypes(include=[np.number])
+        index, columns = [str(i) for i in G[tag + "/" + name + "/index"]], [str(x) for x in G[tag + "/" + name + "/columns"]]
+        assert sorted(str(i) for i in frame.index) == sorted(index), (name, list(frame.index)[:6], index[:6])
+        assert [str(x) for x in num.columns] == columns, (name, list(num.columns), columns)
+        mine = num.loc[index].values.astype(float)
+        want = G[tag + "/" + name + "/values"]
+        # (p-values of strongly significant paths are 1e-30 and below: they pass on the absolute tolerance)
+        assert_close(mine, want, 1e-6, 1e-9, what="%s %s" % (tag, name))
+    eff = m.effects()
+    assert [str(x) for x in eff["from"]] == [str(x) for x in G[tag + "/effects/from"]] and [str(x) for x in eff["to"]] == [str(x) for x in G[tag + "/effects/to"]]
+    assert_close(eff[["direct", "indirect", "total"]].values.astype(float), G[tag + "/effects/values"], 1e-6, 1e-9, what=tag + " effects")
+    assert_close(float(m.goodness_of_fit()), float(G[tag + "/gof"]), 1e-6, what=tag + " goodness_of_fit")
