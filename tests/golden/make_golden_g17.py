@@ -2,7 +2,7 @@
 """Golden g17 (build container only): the reference's PUBLIC frames on seeded random models -- outer_model, inner_model (estimates, standard errors, t, p), inner_summary,
 path_coefficients, crossloadings, effects, unidimensionality, goodness_of_fit -- for the host-side statistics this backend computes from device outputs (plspm/inner_model.py,
 inner_summary.py, outer_model.py, unidimensionality.py).  The fixtures of the reference's own data sets pin those on four models; this one adds 12 metric / Scale.NUM models of
-tests/fuzz_cases.make_case and 6 categorical ones of make_cat_case.  Data + expected outputs only (arrays and label strings).
+tests/fuzz_cases.make_case, 6 categorical ones of make_cat_case and 3 + 3 with NaN cells (make_missing_case, make_nmx_case).  Data + expected outputs only (arrays and label strings).
 
 Run:   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/make_golden_g17.py"""
 import os
@@ -66,6 +66,14 @@ def main():
         cases.append(("cat", seed, X, model))
         if sum(1 for k in cases if k[0] == "cat") == 6:
             break
+    for kind, gen, want in (("missing", fc.make_missing_case, 3), ("nmx", fc.make_nmx_case, 3)):      # NaN cells: metric (mean imputation) / Scale.NUM (incomplete rows)
+        for seed in range(80):
+            X, model = gen(seed)
+            if any(len(b) < 2 for b in model.blocks):
+                continue
+            cases.append((kind, seed, X, model))
+            if sum(1 for k in cases if k[0] == kind) == want:
+                break
     tags = []
     for kind, seed, X, model in cases:
         tag = "%s%d" % (kind, seed)
