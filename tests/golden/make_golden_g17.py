@@ -26,18 +26,28 @@ warnings.filterwarnings("ignore")
 SCALE = {"NUM": Scale.NUM, "RAW": Scale.RAW, "ORD": Scale.ORD, "NOM": Scale.NOM}
 
 
-def frames(X, model):
+def frames(X, model, hoc=None):
+    """hoc = (stage2, C2, modes2) of fuzz_cases.make_hoc_case: the HOC is named H, its MVs after the constituents.  (The reference's unidimensionality() raises KeyError on a
+    HOC model -- it looks the HOC's score columns up in the filtered data, unidimensionality.py:39 --: not part of those models' fixtures.)"""
     L = model.L
     lvs = ["L%d" % l for l in range(L)]
     df = pd.DataFrame(X, columns=["x%d" % p for p in range(X.shape[1])])
     scales = model.scales
-    cfg = c.Config(mg.path_frame(model.C, lvs), scaled=model.scaled, default_scale=(Scale.NUM if scales is not None else None))
+    if hoc is None:
+        cfg = c.Config(mg.path_frame(model.C, lvs), scaled=model.scaled, default_scale=(Scale.NUM if scales is not None else None))
+    else:
+        stage2, C2, modes2 = hoc
+        lv2 = ["H" if kind == "hoc" else lvs[ref] for kind, ref in stage2]
+        cfg = c.Config(mg.path_frame(C2, lv2), scaled=True, default_scale=SCALE[scales[0]])
+        for (kind, ref), name, mode in zip(stage2, lv2, modes2):
+            if kind == "hoc":
+                cfg.add_higher_order(name, Mode.A if mode == "A" else Mode.B, [lvs[j] for j in ref])
     for l in range(L):
-        cfg.add_lv(lvs[l], Mode.A if model.modes[l] == "A" else Mode.B, *[c.MV("x%d" % p, SCALE[scales[p]] if scales is not None else None) for p in model.blocks[l]])
+        cfg.add_lv(lvs[l], Mode.A if model.modes[l] == "A" else Mode.B, *[c.MV("x%d" % p, SCALE[scales[p]] if (scales is not None and hoc is None) else None) for p in model.blocks[l]])
     m = Plspm(df, cfg, mg.SCHEMES[model.scheme], 100, model.tol)
     out = {}
     for name, fr in (("outer_model", m.outer_model()), ("inner_model", m.inner_model()), ("inner_summary", m.inner_summary()), ("path_coefficients", m.path_coefficients()),
-                     ("crossloadings", m.crossloadings()), ("unidimensionality", m.unidimensionality())):
+                     ("crossloadings", m.crossloadings())) + ((("unidimensionality", m.unidimensionality()),) if hoc is None else ()):
         num = fr.select_dtypes(include=[np.number])
         out[name + "/values"] = num.values.astype(float)
         out[name + "/index"] = np.array([str(i) for i in fr.index])
@@ -74,11 +84,22 @@ def main():
             cases.append((kind, seed, X, model))
             if sum(1 for k in cases if k[0] == kind) == want:
                 break
+    for kind, gen, want in (("hocnum", fc.make_hoc_case, 3), ("hocord", fc.make_hoc_ord_case, 3)):      # two-stage estimates (the HOC block has two or three score columns)
+        for seed in range(80):
+            X, model, stage2, C2, modes2, _ = gen(seed)
+            if any(len(b) < 2 for b in model.blocks):
+                continue
+            cases.append((kind, seed, X, (model, (stage2, C2, modes2))))
+            if sum(1 for k in cases if k[0] == kind) == want:
+                break
     tags = []
     for kind, seed, X, model in cases:
         tag = "%s%d" % (kind, seed)
+        hoc = None
+        if isinstance(model, tuple):
+            model, hoc = model
         try:
-            out = frames(X, model)
+            out = frames(X, model, hoc)
         except Exception as e:                                 # noqa: BLE001
             print(tag, "reference raised", repr(e)[:120])
             continue
@@ -86,7 +107,7 @@ def main():
         store[tag + "/x_sha"] = np.array(mg.sha(X))            # the matrix the generator must reproduce on the GPU box (NumPy's Generator streams are version-stable)
         for k, v in out.items():
             store[tag + "/" + k] = v
-        print(tag, X.shape, model.modes, model.scheme, "gof %.6f" % float(out["gof"]))
+        print(tag, X.shape, model.modes, model.scheme, "gof %.6f" % float(out["gof"]), "HOC" if hoc else "")
     store["tags"] = np.array(tags)
     np.savez_compressed(os.path.join(HERE, "g17_api_frames.npz"), **store)
     print("wrote g17_api_frames.npz:", len(tags), "models,", os.path.getsize(os.path.join(HERE, "g17_api_frames.npz")), "bytes")
