@@ -147,9 +147,11 @@ int plspm_detail_bootstrap(plspm_model* m, int64_t B, uint64_t seed, int64_t rep
             const long psize2 = packed_size(m2->Ts);
             const int2* ent_l = (need_lists && !cd8) ? (const int2*)m->ent.p : nullptr;      // (built above only when the int8 counts are not used)
             const int* nent_l = (need_lists && !cd8) ? (const int*)m->nent.p : nullptr;
-            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, SolverOut{}, ent_l, nent_l, ent_stride, 128, false, cd8, cd8_MT))) return rc;
+            // (threads per problem: 128 unless the handle's "nm_threads" option says otherwise -- each stage reads its own handle's)
+            const int t1 = m->tune.nm_threads > 0 ? m->tune.nm_threads : 128, t2 = m2->tune.nm_threads > 0 ? m2->tune.nm_threads : 128;
+            if ((rc = run_nonmetric(m, nb, (const double*)m->gram.p, psize, SolverOut{}, ent_l, nent_l, ent_stride, t1, false, cd8, cd8_MT))) return rc;
             if ((rc = run_hoc_moments(m, m2, nb))) return rc;
-            rc = run_nonmetric(m2, nb, (const double*)m2->gram.p, psize2, so, ent_l, nent_l, ent_stride, 128, true, cd8, cd8_MT);
+            rc = run_nonmetric(m2, nb, (const double*)m2->gram.p, psize2, so, ent_l, nent_l, ent_stride, t2, true, cd8, cd8_MT);
             if (rc) return fail(m, rc, "second stage: " + m2->error);
             continue;
         }

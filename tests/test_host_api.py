@@ -436,9 +436,7 @@ def test_committed_bench_line_follows_the_driver_contract():
     assert cat["replicates_per_step_1000"]["replicates_per_s"] >= 4.0e5 and cat["replicates_per_step_5000"]["replicates_per_s"] >= 5.0e5, cat
     assert cat["replicates_per_step_1000"]["all_ok"] and cat["replicates_per_step_5000"]["all_ok"]
     # ... and both stages of a higher order construct per replicate on the reference's mobi data (round 6: ten-point items at two waves per SIMD)
-    hoc = line["next_rows"].get("hoc_two_stage_bootstrap")
-    assert hoc is not None or "PENDING" in os.environ.get("PLSPM_BENCH_LINE", "PENDING"), "the committed line predates the HOC row"
-    hoc = hoc or {"ORD": {"replicates_per_s": 1e9, "replicates_per_s_at_40000_per_call": 1e9, "ok_replicates": 5000}, "NUM": {"replicates_per_s": 1e9, "ok_replicates": 5000}}
+    hoc = line["next_rows"]["hoc_two_stage_bootstrap"]
     assert hoc["ORD"]["replicates_per_s"] >= 1.0e5 and hoc["ORD"]["replicates_per_s_at_40000_per_call"] >= 1.5e5 and hoc["NUM"]["replicates_per_s"] >= 2.0e6, hoc
     assert hoc["ORD"]["ok_replicates"] >= 4900 and hoc["NUM"]["ok_replicates"] == 5000
     # the two single-fit configurations of BASELINE.json: iteration counts, HIP-event kernel times, A_fit / F_fit rooflines

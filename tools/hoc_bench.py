@@ -26,6 +26,8 @@ for scale_name, scale in (("ORD", Scale.ORD), ("NUM", Scale.NUM)):
     observations = config.filter(mobi)
     calculator = w.WeightsCalculatorFactory(config, 100, 1e-7, np.sqrt(250 / 249), Scheme.PATH, 0)
     pair = Estimator(config).two_stage_bootstrap_handles(calculator, observations)
+    for kv in filter(None, os.environ.get("HOC_BENCH_OPTS2", "").split(",")):      # set_option key=value on the SECOND stage's handle (A/B runs), e.g. HOC_BENCH_OPTS2=nm_threads=256
+        pair.native._second.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     B = 5000
     for k in range(2): pair.native.bootstrap_device(B, seed=1, rep_offset=k * B)
     pair.native.sync()
