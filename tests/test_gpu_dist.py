@@ -470,3 +470,35 @@ def test_bench_multi_rank_path_on_one_device_calibrates_the_tile_plan(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["replicates_per_step"] == 2000 and d["config"]["transport"] == "device-copies"
     plan = d["config"]["gram_tile_plan_cus"]
     assert set(plan["tried_ms_per_step"]) == {"0", "248", "240", "232", "224", "208"} and plan["chosen"] in (0, 248, 240, 232, 224, 208)
+
+
+@pytest.mark.parametrize("scale_name", ["NUM", "ORD"])
+def test_plspm_processes_shards_a_hoc_model_with_identical_results(scale_name, monkeypatch):
+    """Plspm(..., processes=2) on a higher order construct (both stages of every replicate on the device; on ordinal items the categorical solver with its host read-backs
+    inside a call): two handle PAIRS on one device form the group, and the replicates are the bits of the single-pair run."""
+    import pandas as pd
+    import plspm.config as c
+    from helpers import GOLDEN
+    from plspm import parallel
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    mobi = pd.read_csv(os.path.join(GOLDEN, "ref_data", "mobi.csv"), index_col=0).astype(float)
+
+    def run(processes):
+        structure = c.Structure()
+        structure.add_path(["Expectation", "Quality"], ["Satisfaction"])
+        structure.add_path(["Satisfaction"], ["Complaints", "Loyalty"])
+        config = c.Config(structure.path(), default_scale=getattr(Scale, scale_name))
+        config.add_higher_order("Satisfaction", Mode.A, ["Image", "Value"])
+        for lv, prefix in (("Expectation", "CUEX"), ("Quality", "PERQ"), ("Loyalty", "CUSL"), ("Image", "IMAG"), ("Complaints", "CUSCO"), ("Value", "PERV")):
+            config.add_lv_with_columns_named(lv, Mode.A, mobi, prefix)
+        return Plspm(mobi, config, Scheme.PATH, 100, 1e-7, bootstrap=True, bootstrap_iterations=600, processes=processes, seed=5).bootstrap()
+    single = run(1)
+    monkeypatch.setattr(parallel, "devices_for", lambda processes, replicates, first_device=0, devices=None: [0] * min(int(processes), 2))
+    double = run(2)
+    assert single.ranks() == 1 and double.ranks() == 2
+    assert single.used() == double.used() >= 590
+    assert np.array_equal(single.replicates(), double.replicates(), equal_nan=True)
+    assert np.array_equal(single.status(), double.status()) and np.array_equal(single.replicate_iterations(), double.replicate_iterations())
