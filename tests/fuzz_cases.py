@@ -194,3 +194,35 @@ def make_hostile_case(seed):
         X[rng.integers(0, n, size=k), rng.integers(0, P, size=k)] *= 1.0e3
     scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
     return X, orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2))), sizes, kind
+
+
+def make_degenerate_case(seed):
+    """Metric / Scale.NUM models at the edges the reference's own tests skirt: tiny samples (8 ... 40 rows: resamples with a handful of distinct rows), a column that is an
+    exact copy or an exact multiple of its neighbour (rank-deficient Mode-B blocks and path regressions take the minimum-norm answers), a constant column (zero variance: the
+    reference's loadings / Mode-B systems turn NaN or singular), iteration caps of 1 ... 4 and tolerances of 1e-2 / 1e-12."""
+    rng = np.random.default_rng(14000 + seed)
+    L = int(rng.integers(2, 6))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 5)) for _ in range(L)]
+    kind = int(rng.integers(0, 5))
+    n = int(rng.integers(8, 41)) if kind == 0 else int(rng.integers(60, 400))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    big = [l for l in range(L) if sizes[l] > 1]
+    nonmetric_first = bool(np.random.default_rng(15000 + seed).integers(0, 3) == 0)      # (drawn ahead of the data edits: the model kind decides which duplicate is fair)
+    if kind == 1 and big:                                      # an exact copy / multiple of a neighbouring column
+        b = blocks[big[int(rng.integers(0, len(big)))]]
+        # (a NEGATIVE multiple under Scale.NUM is left out: both columns are standardised, the initial score (x + x') / sqrt(2) is then zero in exact arithmetic, and the
+        #  reference iterates on from its rounding residue -- DESIGN 6, "what the sweeps found")
+        X[:, b[1]] = X[:, b[0]] * (1.0 if rng.integers(0, 2) else (2.5 if nonmetric_first else -2.5))
+    if kind == 2:                                              # a constant column
+        X[:, int(rng.integers(0, X.shape[1]))] = 3.25
+    modes = "".join("AB"[int(rng.integers(0, 2))] if sizes[l] > 1 else "A" for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    nonmetric = nonmetric_first
+    max_iter, tol = 100, (1e-6 if not nonmetric else 1e-7)
+    if kind == 3:
+        max_iter = int(rng.integers(1, 5))
+    if kind == 4:
+        tol = float(rng.choice([1e-2, 1e-12]))
+    model = orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2)) or nonmetric, max_iter=max_iter, tol=tol, scales=(["NUM"] * X.shape[1]) if nonmetric else None)
+    return X, model, nonmetric, kind
