@@ -213,7 +213,11 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     // (round 6: six columns per lane where they cover the model -- at most 383 aug columns of items with at most eight categories: 300 columns keep 51 lanes busy
     //  instead of 38; option nm_cpl 8: eight per lane as before)
     // (the finish files an MV's columns from at most three neighbouring lanes: 13 categories at six columns per lane)
-    const bool cpl6 = m->cmax <= 13 && P + 1 <= 6 * 64 && m->tune.nm_cpl != 8;
+    // (not for 7 / 8 LVs with items of 11 ... 13 categories: nmw_step_kernel<8, 16, false, false, 6> -- the launch-by-launch form without the step's own bound, i.e. every
+    //  single FIT of such a model -- returns NaN inner weights under the PATH scheme and faults on the fit's one-problem buffers, while the same source with SUB, with eight columns
+    //  per lane or with LMAX 6 is right (found by the large categorical fuzz, tests/fuzz_cases.make_cat_big_case seeds 34 / 124 / 133 / ...; centroid and factorial runs of the same
+    //  binary are right too: DESIGN 6).  That class keeps eight columns per lane in every form.)
+    const bool cpl6 = m->cmax <= 13 && P + 1 <= 6 * 64 && m->tune.nm_cpl != 8 && !(m->cmax > 10 && L > 6);
     // (round 6, last: items of nine or ten categories -- the reference's own mobi data -- on an instantiation of their own: its register arrays leave room for TWO waves
     //  per SIMD like the eight-category form, where the sixteen-category one runs alone; six columns per lane only)
     const bool c10 = m->cmax > 8 && m->cmax <= 10 && cpl6 && m->tune.nm_c10 != 0;

@@ -226,3 +226,27 @@ def make_degenerate_case(seed):
         tol = float(rng.choice([1e-2, 1e-12]))
     model = orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2)) or nonmetric, max_iter=max_iter, tol=tol, scales=(["NUM"] * X.shape[1]) if nonmetric else None)
     return X, model, nonmetric, kind
+
+
+def make_cat_big_case(seed):
+    """Categorical models beyond the wave step's class and at its limits: up to 10 LVs, blocks of up to 8 items (up to 80 MVs: more than 64 take the workgroup step), items of
+    up to 16 categories (the sixteen-category instantiation), 300 ... 2,500 rows; all Mode A in two of three cases."""
+    rng = np.random.default_rng(16000 + seed)
+    L = int(rng.integers(3, 11))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.8)))
+    sizes = [int(rng.integers(1, 9)) for _ in range(L)]
+    n = int(rng.integers(300, 2500))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    P = X.shape[1]
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    cmax = int(rng.choice([5, 8, 10, 13, 16]))
+    data, scales = X.copy(), []
+    for p in range(P):
+        s_ = ("ORD", "ORD", "NOM")[int(rng.integers(0, 3))]
+        scales.append(s_)
+        c = int(rng.integers(2, cmax + 1))
+        data[:, p] = np.clip(np.round((c + 1) / 2.0 + float(rng.uniform(0.6, 1.4)) * c / 5.0 * Z[:, p]), 1, c)
+    all_a = bool(rng.integers(0, 3) != 0)
+    modes = "".join("A" if all_a or sizes[l] == 1 else "AB"[int(rng.integers(0, 2))] for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    return data, orc.Model(blocks, C, modes, scheme, True, tol=1e-6, scales=scales)

@@ -260,10 +260,11 @@ def test_random_num_model_on_the_one_launch_route(seed):
 
 # ---- categorical (Scale.ORD / NOM / NUM mixes): random path models, block sizes, category counts (2 .. 12), modes and schemes -- the fit and six bootstrap replicates on
 # explicit index lists against the oracle, through the wave step where it covers the model and the workgroup step elsewhere; where both exist, the same records from both
-def _cat_case_check(seed):
+def _cat_case_check(seed, big=False):
     import test_gpu_categorical as tc
+    from fuzz_cases import make_cat_big_case
     from plspm import _native
-    data, model = make_cat_case(seed)
+    data, model = (make_cat_big_case if big else make_cat_case)(seed)
     n = data.shape[0]
     tag = "seed %d L=%d P=%d n=%d %s %s %s" % (seed, model.L, data.shape[1], n, model.modes, model.scheme, "".join(s[0] for s in model.scales))
     try:
@@ -336,6 +337,13 @@ def _cat_case_check(seed):
 @pytest.mark.parametrize("seed", range(30))
 def test_random_categorical_model(seed):
     _cat_case_check(seed)
+
+
+@pytest.mark.parametrize("seed", list(range(10)) + [34, 124])
+def test_random_large_categorical_model(seed):
+    """fuzz_cases.make_cat_big_case: up to 80 MVs in up to 10 blocks, items of up to 16 categories.  Seeds 34 / 124: seven / eight LVs, items of up to 13 categories, PATH scheme --
+    the class whose single fit returned NaN (and faulted) on the six-columns-per-lane form of the sixteen-category wave step (plspm_nonmetric.hip, `cpl6`)."""
+    _cat_case_check(seed, big=True)
 
 
 def test_exact_tie_of_category_means_fails_like_the_reference():

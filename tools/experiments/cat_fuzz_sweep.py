@@ -11,10 +11,11 @@ import test_gpu_fuzz as f
 
 if __name__ == "__main__":
     a, b = int(sys.argv[1]), int(sys.argv[2])
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"          # (fuzz_cases.make_cat_big_case: up to 80 MVs, items of up to 16 categories)
     hist, bad = collections.Counter(), []
     for seed in range(a, b):
         try:
-            hist[f._cat_case_check(seed)] += 1
+            hist[f._cat_case_check(seed, big)] += 1
         except Exception:
             tb = traceback.format_exc().splitlines()
             bad.append((seed, tb[-1][:400]))

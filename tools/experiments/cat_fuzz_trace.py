@@ -12,7 +12,10 @@ import test_gpu_categorical as tc
 from test_solver_hostemu_ordnom import build_aug
 from plspm import _native
 seed, r = int(sys.argv[1]), int(sys.argv[2])
-data, model = f.make_cat_case(seed)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+wave_opts = dict(kv.split("=") for kv in (sys.argv[4].split(",") if len(sys.argv) > 4 else []))      # options of the wave-step handle, e.g. nm_subset=0,nm_cpl=8
+import fuzz_cases as fc
+data, model = (fc.make_cat_big_case if big else f.make_cat_case)(seed)
 n = data.shape[0]
 idx = _native.bootstrap_indices(seed, r, n)[None, :].astype(np.int32)
 Xaug, mv_off, mv_kind, lmv_off, boff, mv_data_col = build_aug(data, model)
@@ -25,13 +28,16 @@ for p in range(Pm):
     vals = np.unique(data[:, col]); present = np.isin(vals, np.unique(Xr[:, col]))
     if not present.all():
         print("MV", p, "(data column", col, ") categories", len(vals), "absent:", [int(i) for i in np.flatnonzero(~present)], "counts present", [int((Xr[:, col] == v).sum()) for v in vals])
-for k in range(1, 22):
+for k in range(1, int(os.environ.get('TRACE_TRIPS', '21')) + 1):
     rows = {}
     for wave in (1, 0):
         nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, tc.SCHEME_ID[model.scheme], True, k, model.tol, 0, nonmetric=True, categorical=(mv_off, mv_kind))
         nm.upload(Xaug)
         nm.set_option("nm_wave", wave)
         nm.set_option("nm_cat_one", 0)
+        if wave:
+            for k_, v_ in wave_opts.items():
+                nm.set_option(k_, int(v_))
         out = nm.bootstrap(1, idx=idx)
         rows[wave] = (out[0][0].copy(), int(out[1][0]), int(out[2][0]))
         nm.close()
