@@ -217,7 +217,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
     //  single FIT of such a model -- returns NaN inner weights under the PATH scheme and faults on the fit's one-problem buffers, while the same source with SUB, with eight columns
     //  per lane or with LMAX 6 is right (found by the large categorical fuzz, tests/fuzz_cases.make_cat_big_case seeds 34 / 124 / 133 / ...; centroid and factorial runs of the same
     //  binary are right too: DESIGN 6).  That class keeps eight columns per lane in every form.)
-    const bool cpl6 = m->cmax <= 13 && P + 1 <= 6 * 64 && m->tune.nm_cpl != 8 && !(m->cmax > 10 && L > 6);
+    const bool cpl6 = m->cmax <= 13 && P + 1 <= 6 * 64 && m->tune.nm_cpl != 8 && (m->tune.nm_cpl == 6 || !(m->cmax > 10 && L > 6));      // (nm_cpl 6: six wherever the layout allows -- probes)
     // (round 6, last: items of nine or ten categories -- the reference's own mobi data -- on an instantiation of their own: its register arrays leave room for TWO waves
     //  per SIMD like the eight-category form, where the sixteen-category one runs alone; six columns per lane only)
     const bool c10 = m->cmax > 8 && m->cmax <= 10 && cpl6 && m->tune.nm_c10 != 0;
