@@ -199,7 +199,8 @@ inline int fail(plspm_model* m, int code, const std::string& msg) {
 #define HIPCHK(m, call)                                                                                         \
     do {                                                                                                        \
         hipError_t e__ = (call);                                                                                \
-        if (e__ != hipSuccess) return fail((m), -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); \
+        if (e__ != hipSuccess) { (void)hipGetLastError(); /* (the runtime's last-error word is per thread and sticky: a later hipGetLastError() check of ANOTHER handle must not inherit it) */ \
+            return fail((m), -(int)e__, std::string(#call) + ": " + hipGetErrorString(e__)); }                  \
     } while (0)
 
 inline int ensure(plspm_model* m, plspm_model::Buf& b, size_t bytes) {
@@ -215,7 +216,14 @@ static constexpr size_t kMaxLds = 160 * 1024;
 // Dynamic LDS beyond the 64 KiB default needs an explicit opt-in per kernel.
 inline int allow_lds(plspm_model* m, const void* fn, size_t bytes) {
     if (bytes > kMaxLds) return fail(m, PLSPM_E_LIMIT, "kernel needs more than 160 KiB of LDS");
-    if (bytes > 48 * 1024) HIPCHK(m, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 48 * 1024) {
+        // (a kernel with static LDS of its own can be refused below 160 KiB of dynamic LDS: the same limit, the same code -- found by the many-LV fuzz, a 34-LV / 179-MV model)
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(m, PLSPM_E_LIMIT, "kernel needs " + std::to_string(bytes) + " bytes of dynamic LDS beside its static share: more than the device grants (" + hipGetErrorString(e) + ")");
+        }
+    }
     return 0;
 }
 

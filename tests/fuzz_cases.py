@@ -250,3 +250,25 @@ def make_cat_big_case(seed):
     modes = "".join("A" if all_a or sizes[l] == 1 else "AB"[int(rng.integers(0, 2))] for l in range(L))
     scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
     return data, orc.Model(blocks, C, modes, scheme, True, tol=1e-6, scales=scales)
+
+
+def make_huge_case(seed):
+    """Metric / Scale.NUM models beyond the narrow and wide fuzz classes: 9 ... 48 LVs and up to 230 MVs (the 17 ... 32-LV wave solver, the rows solver of 33 ... 64 LVs, the LDS
+    solver beyond 128 MVs, Gram tile counts up to 15), sparse inner models (an LV has at most six predecessors), 400 ... 2,000 rows."""
+    rng = np.random.default_rng(17000 + seed)
+    L = int(rng.integers(9, 49))
+    C = np.zeros((L, L), dtype=np.int64)
+    for i in range(1, L):
+        k = int(rng.integers(1, min(i, 6) + 1))
+        C[i, rng.choice(i, size=k, replace=False)] = 1
+    P = int(rng.integers(L, min(230, 8 * L) + 1))
+    cuts = np.sort(rng.choice(np.arange(1, P), size=L - 1, replace=False))
+    sizes = np.diff(np.concatenate(([0], cuts, [P]))).tolist()
+    n = int(rng.integers(400, 2000))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    allA = bool(rng.integers(0, 2))
+    modes = "".join("A" if allA or sizes[l] == 1 or sizes[l] > 12 else "AB"[int(rng.integers(0, 2))] for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    nonmetric = bool(rng.integers(0, 4) == 0)
+    model = orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2)) or nonmetric, tol=(1e-7 if nonmetric else 1e-6), scales=(["NUM"] * P) if nonmetric else None)
+    return X, model, sizes, nonmetric

@@ -634,3 +634,66 @@ def _hostile_case_check(seed, B=48):
 @pytest.mark.parametrize("seed", range(24))
 def test_random_model_on_hostile_data(seed):
     _hostile_case_check(seed)
+
+
+# ---- many LVs / many MVs (fuzz_cases.make_huge_case): the fit against the oracle; a batch of replicates on the route the library picks against the LDS solver / the
+# per-iteration non-metric launches (equal status and iteration counts, records to 1e-9) and two of them against the oracle
+def _huge_case_check(seed, B=24):
+    from fuzz_cases import make_huge_case
+    from plspm import _native
+    X, model, sizes, nonmetric = make_huge_case(seed)
+    n, P = X.shape
+    boff = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], model.scaled, model.max_iter, model.tol, 0, nonmetric=nonmetric)
+    nm.upload(X)
+    tag = "seed %d L=%d P=%d n=%d %s %s" % (seed, model.L, P, n, model.scheme, "NUM" if nonmetric else "metric")
+    try:
+        g = nm.fit(want_scores=True)
+    except _native.NativeBackendError as e:                # the documented size limit of the LDS-resident solvers: PLSPM_E_LIMIT by name, nothing else
+        assert "(102)" in str(e) and "LDS" in str(e), tag + ": " + str(e)
+        return "E_LIMIT"
+    try:
+        with np.errstate(all="ignore"):
+            r = orc.fit(X, model)
+    except orc.NotConverged:
+        assert g["status"] == 1, tag
+        return "notconv"
+    if g["status"] != 0:
+        assert_device_status_justified(g["status"], X, model, tag)
+        return "device-status"
+    assert g["iterations"] == r["iterations"], tag
+    assert_close(g["weights"], r["weights"], 1e-6, 1e-9, what=tag + " weights")
+    assert_close(g["path_coef"], r["path_coef"], 1e-6, 1e-9, what=tag + " paths")
+    assert_close(g["loadings"], r["loadings"], 1e-6, 1e-9, what=tag + " loadings")
+    assert_close(g["scores"], r["scores"], 1e-6, 1e-8, what=tag + " scores")
+    rows, status, iters = nm.bootstrap(B, seed=seed)
+    route = "gram%d/solver%d/wave16-%d" % (nm.get_option("last_gram_path"), nm.get_option("last_solver"), nm.get_option("last_nm_wave16") if nonmetric else 0)
+    if nonmetric:
+        nm.set_option("nm_wave16", 0)
+    else:
+        nm.set_option("solver_rows", 0); nm.set_option("solver_wave", 0); nm.set_option("solver_quad", 0)
+    rows_l, status_l, iters_l = nm.bootstrap(B, seed=seed)
+    assert np.array_equal(status, status_l), tag + " " + route
+    ok = status == 0
+    assert ok.sum() >= B // 2, tag
+    assert np.array_equal(iters[ok], iters_l[ok]), tag + " " + route
+    assert_close(rows[ok], rows_l[ok], 1e-9, 1e-12, what=tag + " " + route)
+    corr = orc.correction(n)
+    checked = 0
+    for b in range(B):
+        if checked == 2:
+            break
+        idx = _native.bootstrap_indices(seed, b, n)
+        if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
+            continue
+        mine, its = orc.bootstrap_replicate(X, model, idx, corr)
+        assert its == iters[b], tag + " replicate %d" % b
+        assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+        checked += 1
+    return route
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_model_with_many_lvs(seed):
+    _huge_case_check(seed)
