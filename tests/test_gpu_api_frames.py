@@ -16,7 +16,7 @@ G = load("g17_api_frames")
 TAGS = [str(t) for t in G["tags"]]
 
 
-def _plspm(tag):
+def _plspm(tag, check_sha=True, **kwargs):
     import plspm.config as c
     from plspm.mode import Mode
     from plspm.plspm import Plspm
@@ -30,7 +30,8 @@ def _plspm(tag):
         hoc = (stage2, C2, modes2)
     else:
         X, model = {"metric": lambda s: fc.make_case(s)[:2], "cat": fc.make_cat_case, "missing": fc.make_missing_case, "nmx": fc.make_nmx_case}[kind](seed)
-    assert hashlib.sha256(np.ascontiguousarray(X, dtype=np.float64).tobytes()).hexdigest() == str(G[tag + "/x_sha"]), "the generator no longer reproduces the matrix g17 was made from"
+    if check_sha:
+        assert hashlib.sha256(np.ascontiguousarray(X, dtype=np.float64).tobytes()).hexdigest() == str(G[tag + "/x_sha"]), "the generator no longer reproduces the matrix g17 was made from"
     scale = {"NUM": Scale.NUM, "RAW": Scale.RAW, "ORD": Scale.ORD, "NOM": Scale.NOM}
     lvs = ["L%d" % l for l in range(model.L)]
     df = pd.DataFrame(X, columns=["x%d" % p for p in range(X.shape[1])])
@@ -46,7 +47,7 @@ def _plspm(tag):
         cfg.add_lv(lvs[l], Mode.A if model.modes[l] == "A" else Mode.B,
                    *[c.MV("x%d" % p, scale[model.scales[p]] if (model.scales is not None and hoc is None) else None) for p in model.blocks[l]])
     scheme = {"centroid": Scheme.CENTROID, "factorial": Scheme.FACTORIAL, "path": Scheme.PATH}[model.scheme]
-    return Plspm(df, cfg, scheme, 100, model.tol)
+    return Plspm(df, cfg, scheme, 100, model.tol, **kwargs)
 
 
 @pytest.mark.parametrize("tag", TAGS)
@@ -67,3 +68,39 @@ def test_api_frames_vs_reference_on_random_models(tag):
     assert [str(x) for x in eff["from"]] == [str(x) for x in G[tag + "/effects/from"]] and [str(x) for x in eff["to"]] == [str(x) for x in G[tag + "/effects/to"]]
     assert_close(eff[["direct", "indirect", "total"]].values.astype(float), G[tag + "/effects/values"], 1e-6, 1e-9, what=tag + " effects")
     assert_close(float(m.goodness_of_fit()), float(G[tag + "/gof"]), 1e-6, what=tag + " goodness_of_fit")
+
+
+# ---- Plspm(..., bootstrap=True) through the host API on random models of every kind (not in g17: any seed): the call returns, nearly every replicate is used, the frames carry the
+# fit's labels and its values in `original`, the replicate means sit near them, and the same seed gives the same table twice
+API_BOOT = [("metric", s) for s in range(8)] + [("cat", s) for s in range(6)] + [("missing", s) for s in range(4)] + [("nmx", s) for s in range(4)] + \
+           [("hocnum", s) for s in range(4)] + [("hocord", s) for s in range(4)]
+
+
+def _api_bootstrap_check(kind, seed, B=120):
+    m = _plspm("%s%d" % (kind, seed), check_sha=False, bootstrap=True, bootstrap_iterations=B, seed=seed + 1)
+    boot = m.bootstrap()
+    assert boot.used() >= int(0.8 * B), (kind, seed, boot.used())
+    om = m.outer_model()
+    w = boot.weights()
+    assert sorted(w.index) == sorted(om.index)
+    np.testing.assert_allclose(w.loc[om.index, "original"].values, om["weight"].values, rtol=1e-12, atol=1e-14)
+    ld = boot.loading()
+    np.testing.assert_allclose(ld.loc[om.index, "original"].values, om["loading"].values, rtol=1e-9, atol=1e-12)
+    paths = boot.paths()
+    pc = m.path_coefficients()
+    for label, row in paths.iterrows():
+        src, dst = [x.strip() for x in str(label).split("->")]
+        assert abs(row["original"] - pc.loc[dst, src]) <= 1e-9 * max(1.0, abs(row["original"])), (kind, seed, label)
+    for frame in (w, ld, paths, boot.r_squared(), boot.total_effects()):
+        vals = frame[["original", "mean", "std.error", "perc.025", "perc.975"]].values.astype(float)
+        assert np.all(np.isfinite(vals)), (kind, seed)
+        assert np.all(frame["perc.025"].values <= frame["perc.975"].values + 1e-12)
+    assert np.all(np.abs(w["mean"] - w["original"]) <= 8 * w["std.error"] + 1e-3 * np.abs(w["original"]).max()), (kind, seed)
+    again = _plspm("%s%d" % (kind, seed), check_sha=False, bootstrap=True, bootstrap_iterations=B, seed=seed + 1).bootstrap()
+    assert np.array_equal(again.weights().values, w.values, equal_nan=True)
+    return boot.used()
+
+
+@pytest.mark.parametrize("kind,seed", API_BOOT)
+def test_api_bootstrap_on_random_models(kind, seed):
+    _api_bootstrap_check(kind, seed)
