@@ -104,3 +104,60 @@ def _api_bootstrap_check(kind, seed, B=120):
 @pytest.mark.parametrize("kind,seed", API_BOOT)
 def test_api_bootstrap_on_random_models(kind, seed):
     _api_bootstrap_check(kind, seed)
+
+
+def test_api_is_indifferent_to_column_order_dtypes_index_and_unused_columns():
+    """Config.filter picks the configured MVs in add_lv order (config.py:262-270): shuffled columns, integer / float32 dtypes, a string index and columns the model never
+    names must not change a single frame (bootstrap included: same seed, same replicates)."""
+    import plspm.config as c
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scheme import Scheme
+    X, model = fc.make_case(3)[:2]
+    Xi = np.round(X * 4.0)                                    # integer-valued: int64 / float32 / float64 columns then hold the same numbers
+    lvs = ["L%d" % l for l in range(model.L)]
+    names = ["x%d" % p for p in range(X.shape[1])]
+
+    def run(df):
+        cfg = c.Config(pd.DataFrame(np.asarray(model.C, dtype=int), index=lvs, columns=lvs), scaled=model.scaled)
+        for l in range(model.L):
+            cfg.add_lv(lvs[l], Mode.A if model.modes[l] == "A" else Mode.B, *[c.MV(names[p]) for p in model.blocks[l]])
+        return Plspm(df, cfg, Scheme.PATH, 100, 1e-6, bootstrap=True, bootstrap_iterations=100, seed=9)
+    plain = run(pd.DataFrame(Xi, columns=names))
+    rs = np.random.RandomState(2)
+    odd = pd.DataFrame(Xi, columns=names)
+    odd["unused_a"] = rs.standard_normal(len(odd)); odd["unused_b"] = 7
+    odd = odd[list(rs.permutation(odd.columns))]
+    for k, col in enumerate(names):
+        odd[col] = odd[col].astype(["int64", "float32", "float64"][k % 3])
+    odd.index = ["row%05d" % i for i in range(len(odd))]
+    other = run(odd)
+    for name in ("outer_model", "inner_summary", "path_coefficients", "crossloadings", "effects"):
+        a, b = getattr(plain, name)(), getattr(other, name)()
+        assert list(a.index) == list(b.index) and list(a.columns) == list(b.columns), name
+        an, bn = a.select_dtypes(include=[np.number]).values, b.select_dtypes(include=[np.number]).values
+        assert np.array_equal(an, bn, equal_nan=True), name
+    assert np.array_equal(plain.scores().values, other.scores().values) and list(other.scores().index) == list(odd.index)
+    assert np.array_equal(plain.bootstrap().weights().values, other.bootstrap().weights().values)
+
+
+def test_categorical_model_beyond_65535_rows():
+    """All-indicator data sets of more than 65,535 rows leave the uint16 count matrices (a count may exceed 65,535): fit and two replicates of a 70,000-row ordinal model
+    against the oracle."""
+    import plspm_oracle as orc
+    import test_gpu_categorical as tc
+    from plspm import _native
+    C = orc.chain_C(3)
+    X, blocks = orc.synth(70000, C, 3, seed=23)
+    Z = (X - X.mean(axis=0)) / X.std(axis=0)
+    data = np.clip(np.round(3.0 + 1.1 * Z), 1, 5)
+    model = orc.Model(blocks, C, "AAA", "path", True, tol=1e-6, scales=["ORD"] * 9)
+    nm, g = tc.gpu_fit_cat(data, model)
+    tc.check_fit(g, orc.fit(data, model), "70,000 rows")
+    rows, status, iters = nm.bootstrap(8, seed=4)
+    assert np.all(status == 0)
+    rows = tc._rows_in_data_order(rows, g["inv"], 9, 3, nm.n_eff)
+    for r in (0, 7):
+        mine, its = orc.bootstrap_replicate(data, model, _native.bootstrap_indices(4, r, 70000), orc.correction(70000))
+        assert its == iters[r]
+        assert_close(rows[r], mine, 1e-6, 1e-9, what="replicate %d" % r)
