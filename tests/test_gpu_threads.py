@@ -147,3 +147,67 @@ def test_plspm_objects_from_two_threads():
         for res in got[i]:
             for a, b in zip(res, serial[i]):
                 pd.testing.assert_frame_equal(a, b, check_exact=True)
+
+
+def test_categorical_and_hoc_models_from_three_threads():
+    """The host-synchronising solvers under concurrency: an ordinal model (one-launch wave step + verification read-backs), a higher order construct on ordinal items (two
+    handle pairs' worth of launches and read-backs per call) and a metric model, each Plspm(..., bootstrap=True) on its own thread at the same time, three rounds -- every
+    thread gets the frames and replicates it gets alone."""
+    import os
+    import pandas as pd
+    import plspm.config as c
+    from helpers import GOLDEN
+    from plspm.mode import Mode
+    from plspm.plspm import Plspm
+    from plspm.scale import Scale
+    from plspm.scheme import Scheme
+    import fuzz_cases as fc
+    mobi = pd.read_csv(os.path.join(GOLDEN, "ref_data", "mobi.csv"), index_col=0).astype(float)
+
+    def hoc():
+        structure = c.Structure()
+        structure.add_path(["Expectation", "Quality"], ["Satisfaction"])
+        structure.add_path(["Satisfaction"], ["Complaints", "Loyalty"])
+        config = c.Config(structure.path(), default_scale=Scale.ORD)
+        config.add_higher_order("Satisfaction", Mode.A, ["Image", "Value"])
+        for lv, prefix in (("Expectation", "CUEX"), ("Quality", "PERQ"), ("Loyalty", "CUSL"), ("Image", "IMAG"), ("Complaints", "CUSCO"), ("Value", "PERV")):
+            config.add_lv_with_columns_named(lv, Mode.A, mobi, prefix)
+        return Plspm(mobi, config, Scheme.PATH, 100, 1e-7, bootstrap=True, bootstrap_iterations=400, seed=3)
+
+    def frame_model(X, model, scale):
+        lvs = ["L%d" % l for l in range(model.L)]
+        df = pd.DataFrame(X, columns=["x%d" % p for p in range(X.shape[1])])
+
+        def run():
+            cfg = c.Config(pd.DataFrame(np.asarray(model.C, dtype=int), index=lvs, columns=lvs), scaled=True, default_scale=scale)
+            for l in range(model.L):
+                cfg.add_lv(lvs[l], Mode.A, *[c.MV("x%d" % p) for p in model.blocks[l]])
+            return Plspm(df, cfg, Scheme.PATH, 100, 1e-6, bootstrap=True, bootstrap_iterations=600, seed=5)
+        return run
+    Xc, mc = fc.make_cat_big_case(12)                          # six LVs, 23 items of up to eight categories, all Mode A
+    Xm, mm, _ = fc.make_case(8)
+    runs = [hoc, frame_model(Xc, mc, Scale.ORD), frame_model(Xm, orc.Model(mm.blocks, mm.C, "A" * mm.L, "path", True), None)]
+
+    def digest(m):
+        b = m.bootstrap()
+        return [m.outer_model().select_dtypes(include=[np.number]).values, m.path_coefficients().values, b.replicates(), b.status(), b.weights().values]
+    serial = [digest(r()) for r in runs]
+    got, errors = {}, []
+    start = threading.Barrier(len(runs))
+
+    def runner(i):
+        try:
+            start.wait()
+            got[i] = [digest(runs[i]()) for _ in range(3)]
+        except Exception as exc:                               # noqa: BLE001
+            errors.append((i, repr(exc)))
+    threads = [threading.Thread(target=runner, args=(i,)) for i in range(len(runs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in got:
+        for r, res in enumerate(got[i]):
+            for a, b in zip(res, serial[i]):
+                assert np.array_equal(a, b, equal_nan=True), "thread %d round %d differs from the serial run" % (i, r)
