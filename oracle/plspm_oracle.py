@@ -415,7 +415,7 @@ def loadings(Xt, scores, model: Model):
     cl = crossloadings(Xt, scores)
     out = np.zeros(Xt.shape[1])
     for l, b in enumerate(model.blocks):
-        out[b] = cl[b, l]
+        out[b] = np.nan_to_num(cl[b, l], nan=0.0)        # (crossloadings * odm).sum(axis=1): pandas' sum skips the NaN a zero-variance column's corrwith gives -- loading 0
     return out
 
 
@@ -446,7 +446,7 @@ def fit(X, model: Model, corr: Optional[float] = None, _treated=None):
     cl = crossloadings(Xt, s["scores"])
     ld = np.zeros(X.shape[1])
     for l, b in enumerate(model.blocks):
-        ld[b] = cl[b, l]
+        ld[b] = np.nan_to_num(cl[b, l], nan=0.0)         # (as loadings(): pandas' sum skips NaN -- a zero-variance column has loading 0, outer_model.py:27 / bootstrap.py:62)
     return dict(treated=Xt, scores=s["scores"], weights=s["weights"], iterations=s["iterations"],
                 sign=s["sign"], path_coef=B, r2=r2, r2_adj=r2_adj, effect_pairs=pairs, direct=d,
                 indirect=ind, total=tot, crossloadings=cl, loadings=ld)

@@ -122,6 +122,18 @@ PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, i
 #define PLSPM_PIVOT_RTOL 1e-13
 #define PLSPM_EIG_RTOL 1e-12
 
+// Standard deviation of a treated (centred, scaled) metric column from its raw second moment about the upload's shift `dpp`, its sum `mup`, 1 / n and the scale factor.
+// A column that is CONSTANT in this data set -- in a bootstrap: an item whose resample holds one value only (a rare binary indicator, a small sample) -- is centred to exact
+// zeros by the reference: its Mode-A weight is 0, pandas' corrwith gives NaN for its cross-loadings and `(crossloadings * odm).sum(axis=1)` (plspm.py / bootstrap.py:62) skips
+// that NaN: LOADING 0, and the estimate -- or the replicate -- counts.  On second moments that variance is `dpp - mup^2 / n` of two equal numbers: rounding noise of either
+// sign.  Below 1e-12 of the second moment it is called zero here (no column of real data is constant to twelve digits without being constant); the outputs then follow the
+// reference (loading 0, cross-loadings NaN) and the status stays PLSPM_OK.  NaN / inf data keep their NaN / inf: PLSPM_NONFINITE as before.
+PLSPM_HD double treated_sd(double dpp, double mup, double inv_n, double fac) {
+    const double var = dpp - (mup * mup) * inv_n;
+    if (var > 1e-12 * dpp) return sqrt(var * fac);
+    return (var == var && dpp == dpp && fac == fac) ? 0.0 : var + dpp + fac;       // (NaN stays NaN)
+}
+
 // In-place Cholesky A = R^T R of a k x k SPD matrix (row-major, ld k, upper part used/overwritten).
 // Returns false at the first pivot that is not safely positive (rank deficient to working precision).
 PLSPM_HD bool chol_factor(double* A, int k) {
@@ -395,6 +407,7 @@ PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const d
     // 2. centre and scale in place: S <- (M - mu mu' / n) * fac   (thread p owns column p: conflict-free LDS walk)
     ex.par(P, [&](int p) {
         const double mp = ws.mu[p];
+        ws.sd[p] = treated_sd(ws.S[p * PS + p], mp, inv_n, fac);      // (from the RAW diagonal, before the walk below rewrites it)
         int q = 0;
         for (; q + 3 < P; q += 4) {
             const double a0 = ws.S[q * PS + p], a1 = ws.S[(q + 1) * PS + p], a2 = ws.S[(q + 2) * PS + p], a3 = ws.S[(q + 3) * PS + p];
@@ -406,7 +419,14 @@ PLSPM_HD void moments_to_cov(Ex& ex, const ModelDesc& md, Workspace& ws, const d
         }
         for (; q < P; ++q) ws.S[q * PS + p] = (ws.S[q * PS + p] - (mp * ws.mu[q]) * inv_n) * fac;
     });
-    ex.par(P, [&](int p) { ws.sd[p] = sqrt(ws.S[p * PS + p]); ws.cs[p] = sqrt(fac * n); });   // cs = 1/g (scaled) or 1
+    ex.par(P, [&](int p) { ws.cs[p] = sqrt(fac * n); });   // cs = 1/g (scaled) or 1
+    // a zero-variance column (treated_sd above): its row and column of S are rounding residue -- exact zeros instead, so that a Mode-B block that holds it is rank deficient by
+    // the pivot rule and takes the minimum-norm answer (weight 0 for that column, like the reference's gelsd) instead of dividing by the residue
+    if (ex.any(P, [&](int p) { return ws.sd[p] == 0.0; }))
+        ex.par(P, [&](int p) {
+            const bool mine0 = ws.sd[p] == 0.0;
+            for (int q = 0; q < P; ++q) if (mine0 || ws.sd[q] == 0.0) ws.S[q * PS + p] = 0.0;
+        });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -742,10 +762,15 @@ PLSPM_HD void solve_problem_rows(Ex& ex, const ModelDesc& md, Workspace& ws, con
         cov.s[q] = (q < nq) ? v : 0.0;
     }
     if (mine) {
-        ws.sd[p] = sqrt((dpp - (mup * mup) * inv_n) * fac);
+        ws.sd[p] = treated_sd(dpp, mup, inv_n, fac);
         ws.cs[p] = sqrt(fac * n);
     }
     ex.sync();
+    if (ex.any(P, [&](int e) { return ws.sd[e] == 0.0; })) {      // zero-variance columns: exact zeros in their rows and columns (moments_to_cov)
+        const bool mine0 = p < P && ws.sd[p] == 0.0;
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) if (q < nq && (mine0 || ws.sd[q0 + q] == 0.0)) cov.s[q] = 0.0;
+    }
     ex.mark(1);
     const double corr2 = n / (n - 1.0);
 
@@ -848,13 +873,16 @@ PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const F
     ex.par(L * NC, [&](int e) {
         const int l = e / NC, c = e - l * NC;
         const int p0 = (int)((long)P * c / NC), p1 = (int)((long)P * (c + 1) / NC);
+        // (a zero-variance column -- treated_sd -- votes -1 in EVERY LV: its correlations are 0 / 0 = the default NaN, whose sign bit is set, and copysign(1.0, NaN) of
+        //  weights.py:63 reads that bit; the oracle's NumPy does the same.  sd is exactly 0 for such a column and for no other.)
         int vote = 0;
         int p = p0;
         for (; p + 3 < p1; p += 4) {
             const double v0 = ws.V[p * L + l], v1 = ws.V[(p + 1) * L + l], v2 = ws.V[(p + 2) * L + l], v3 = ws.V[(p + 3) * L + l];
-            vote += ((v0 < 0.0) ? -1 : 1) + ((v1 < 0.0) ? -1 : 1) + ((v2 < 0.0) ? -1 : 1) + ((v3 < 0.0) ? -1 : 1);
+            const bool f0 = ws.sd[p] == 0.0, f1 = ws.sd[p + 1] == 0.0, f2 = ws.sd[p + 2] == 0.0, f3 = ws.sd[p + 3] == 0.0;
+            vote += ((v0 < 0.0 || f0) ? -1 : 1) + ((v1 < 0.0 || f1) ? -1 : 1) + ((v2 < 0.0 || f2) ? -1 : 1) + ((v3 < 0.0 || f3) ? -1 : 1);
         }
-        for (; p < p1; ++p) vote += (ws.V[p * L + l] < 0.0) ? -1 : 1;
+        for (; p < p1; ++p) vote += (ws.V[p * L + l] < 0.0 || ws.sd[p] == 0.0) ? -1 : 1;
         ws.Pw2[e] = (double)vote;
     });
     ex.par(L, [&](int l) {
@@ -871,11 +899,12 @@ PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const F
     // outputs
     ex.par(P, [&](int p) {
         const int l = md.lvof[p];
-        const double ld = ws.sgn[l] * ws.V[p * L + l] * ws.wf[l] / ws.sd[p];
+        const bool flat = ws.sd[p] == 0.0;                                 // a zero-variance column (treated_sd): loading 0, cross-loadings NaN, like the reference
+        const double ld = flat ? 0.0 : ws.sgn[l] * ws.V[p * L + l] * ws.wf[l] / ws.sd[p];
         if (out.row) { out.row[p] = ws.w[p]; out.row[P + L + 2 * md.n_eff + p] = ld; }
         if (out.weights) out.weights[p] = ws.w[p];
         if (out.loadings) out.loadings[p] = ld;
-        if (out.crossloadings) for (int m = 0; m < L; ++m) out.crossloadings[p * L + m] = ws.sgn[m] * ws.V[p * L + m] * ws.wf[m] / ws.sd[p];
+        if (out.crossloadings) for (int m = 0; m < L; ++m) out.crossloadings[p * L + m] = flat ? sqrt(-1.0) : ws.sgn[m] * ws.V[p * L + m] * ws.wf[m] / ws.sd[p];
         // scores_l = sgn_l * sum_p (x'_p - mu'_p) * cs_p * w_p
         const double n_ = ws.scal[1];
         if (out.score_w) out.score_w[p] = ws.sgn[l] * ws.w[p] * ws.cs[p];
@@ -903,7 +932,7 @@ PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const F
         if (out.indirect) out.indirect[e] = ws.Ind[idx];
     });
     const bool bad = ex.any(P + L, [&](int e) {
-        if (e < P) return !(isfinite(ws.w[e]) && isfinite(ws.sd[e]) && ws.sd[e] > 0.0);
+        if (e < P) return !(isfinite(ws.w[e]) && isfinite(ws.sd[e]) && ws.sd[e] >= 0.0);
         return !isfinite(ws.r2[e - P]);
     });
     ex.one([&]() {

@@ -153,7 +153,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
 #pragma unroll
         for (int q = 0; q < PMAX; ++q) s[q] = 0.0;
     }
-    const double sdp = sqrt((dpp - (mup * mup) * inv_n) * fac);
+    const double sdp = treated_sd(dpp, mup, inv_n, fac);           // (0: a column that is constant in this replicate -- solver_core.h)
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: the staging area is free)
 
@@ -276,7 +276,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     // finalize (weights.py:56-70): wf_l = 1 / sqrt(Q_ll); returned weights never sign-flipped
     const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
     wp *= wfp;
-    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]).  The owners sit in waves 0 and 1; every wave casts the same number of
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes -1 everywhere (the sign bit of its NaN correlations: solver_core.h).  The owners sit in waves 0 and 1; every wave casts the same number of
     // ballots (the CPU emulation's ballot is a barrier).
     {
         double vr[LMAX];                                         // (my row of V in one batch of loads: a load inside every ballot's block waits out its own LDS round trip)
@@ -284,7 +284,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
         for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * QUAD_VP + (l < L ? l : 0)];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
-            if (l < L) { const int neg = ex.wave_vote_count(owner && vr[l] < 0.0); if ((t & 63) == 0 && side == 0) ws.votes[wave * LMAX + l] = (double)neg; }
+            if (l < L) { const int neg = ex.wave_vote_count(owner && (vr[l] < 0.0 || sdp == 0.0)); if ((t & 63) == 0 && side == 0) ws.votes[wave * LMAX + l] = (double)neg; }
     }
     ex.sync();
     // (a thread looks up the three signs it needs -- its pair's two LVs, its MV's LV -- instead of walking all L tallies)
@@ -337,7 +337,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     if (out.row) {
         if (owner) {
             out.row[p] = wp;
-            out.row[P + L + 2 * ne + p] = sgl * ws.V[p * QUAD_VP + lp] * wfp / sdp;
+            out.row[P + L + 2 * ne + p] = (sdp > 0.0) ? sgl * ws.V[p * QUAD_VP + lp] * wfp / sdp : 0.0;      // (zero variance: loading 0, solver_core.h treated_sd)
         }
         if (lvlane) out.row[P + t] = r2p;
         if (t < ne) {
@@ -345,7 +345,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
             out.row[P + L + ne + t] = ws.Bm[eidx];
         }
     }
-    const int nbad = ex.wave_vote_count((owner && !(isfinite(wp) && isfinite(sdp) && sdp > 0.0)) || (lvlane && !isfinite(r2p)));
+    const int nbad = ex.wave_vote_count((owner && !(isfinite(wp) && isfinite(sdp) && sdp >= 0.0)) || (lvlane && !isfinite(r2p)));
     const bool sing = ex.wave_vote_count(singular) > 0;         // (the LV threads all sit in wave 0, with thread 0)
     if ((t & 63) == 0) ws.red[wave] = (double)nbad;
     ex.sync();

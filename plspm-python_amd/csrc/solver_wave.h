@@ -234,7 +234,7 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
         }
         ex.pin8(s[q0], s[q0 + 1], s[q0 + 2], s[q0 + 3], s[q0 + 4], s[q0 + 5], s[q0 + 6], s[q0 + 7]);     // results final before the next loads issue
     }
-    const double sdp = sqrt((dpp - (mup * mup) * inv_n) * fac);
+    const double sdp = treated_sd(dpp, mup, inv_n, fac);           // (0: a column that is constant in this replicate -- solver_core.h)
     // (loop constants in SCALAR registers: every lane holds the same value; as vector registers they were spilled around the loop)
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);
@@ -254,7 +254,7 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     const long boffB = modeb ? md.chol_off[lp] / 2 : 0;
     if constexpr (MODEB) {
         ex.sync();                                              // (every lane is done with the column sums ws.mu held)
-        ws.mu[p] = sdp * sdp;                                   // the treated diagonal S_pp: the scale a pivot is measured against
+        ws.mu[p] = (sdp > 0.0) ? sdp * sdp : 1e300;             // the treated diagonal S_pp: the scale a pivot is measured against (a zero-variance column: no pivot passes -- the block takes the minimum-norm route, weight 0 for it)
         double* A = (kbB & 1) ? ws.stage : ws.inv;              // an odd number of steps ends in ws.inv
         double* An = (kbB & 1) ? ws.inv : ws.stage;
         auto fill_block = [&](double* dst) {                    // row bi of S_bb out of the column registers (S is symmetric)
@@ -514,11 +514,11 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     // finalize (weights.py:56-70): wf_l = 1 / (std1(X w_l) / corr) = 1 / sqrt(Q_ll); returned weights never sign-flipped
     const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
     wp *= wfp;
-    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l])
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes -1 everywhere (the sign bit of its NaN correlations: solver_core.h)
     unsigned negmask = 0u;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
-        if (l < L) { const int neg = ex.vote_count(mine && Vp[l] < 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }
+        if (l < L) { const int neg = ex.vote_count(mine && (Vp[l] < 0.0 || sdp == 0.0)); if (P - 2 * neg < 0) negmask |= 1u << l; }
     {
         const double wfl = wave_rsqrt(ws.Qm[el * LMAX + el]), wfm = wave_rsqrt(ws.Qm[em * LMAX + em]);
         const double sl = ((negmask >> el) & 1u) ? -1.0 : 1.0, sm = ((negmask >> em) & 1u) ? -1.0 : 1.0;
@@ -567,7 +567,7 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
             double vl = 0.0;                                     // V[p, lv(p)]: the LDS copy may have served as regression scratch
 #pragma unroll
             for (int m = 0; m < LMAX; ++m) vl = (m == lp) ? Vp[m] : vl;
-            out.row[P + L + 2 * ne + p] = sgl * vl * wfp / sdp;
+            out.row[P + L + 2 * ne + p] = (sdp > 0.0) ? sgl * vl * wfp / sdp : 0.0;       // (a zero-variance column: the reference's loading is 0, solver_core.h treated_sd)
         }
         if (lvlane) out.row[P + p] = r2p;
         if (p < ne) {
@@ -575,7 +575,7 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
             out.row[P + L + ne + p] = ws.Bm[eidx];
         }
     }
-    const bool bad = ex.vote_any((mine && !(isfinite(wp) && isfinite(sdp) && sdp > 0.0)) || (lvlane && !isfinite(r2p)));
+    const bool bad = ex.vote_any((mine && !(isfinite(wp) && isfinite(sdp) && sdp >= 0.0)) || (lvlane && !isfinite(r2p)));
     const bool sing = ex.vote_any(singular);
     if (p == 0) {
         int st = sing ? ST_SINGULAR : (not_converged ? ST_NOT_CONVERGED : ST_OK);

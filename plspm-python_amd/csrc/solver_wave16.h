@@ -167,7 +167,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
 #pragma unroll
         for (int q = 0; q < PMAX; ++q) s[q] = 0.0;
     }
-    const double sdp = NM ? sqrt(((dpp - (mup * mup) * inv_n) * inv_n) / (sdraw * sdraw)) : sqrt((dpp - (mup * mup) * inv_n) * fac);      // (NM: sqrt(R_pp), 1 to rounding)
+    const double sdp = NM ? sqrt(((dpp - (mup * mup) * inv_n) * inv_n) / (sdraw * sdraw)) : treated_sd(dpp, mup, inv_n, fac);      // (NM: sqrt(R_pp), 1 to rounding)
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: V takes the tile's place)
 
@@ -185,7 +185,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     const long boffB = modeb ? md.chol_off[lp] / 2 : 0;
     if constexpr (MODEB) {
         ex.sync();                                              // (every lane is done with the column sums ws.mu held)
-        ws.mu[p] = sdp * sdp;                                   // the treated diagonal S_pp: the scale a pivot is measured against
+        ws.mu[p] = (sdp > 0.0) ? sdp * sdp : 1e300;             // the treated diagonal S_pp: the scale a pivot is measured against (a zero-variance column: no pivot passes -- the block takes the minimum-norm route, weight 0 for it)
         double* A = (kbB & 1) ? ws.stage : ws.inv;              // an odd number of steps ends in ws.inv
         double* An = (kbB & 1) ? ws.inv : ws.stage;
         auto fill_block = [&](double* dst) {                    // row bi of S_bb out of the column registers (S is symmetric)
@@ -547,7 +547,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     // finalize (weights.py:56-70): wf_l = 1 / sqrt(Q_ll); returned weights never sign-flipped
     const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
     wp *= wfp;
-    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l])
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes -1 everywhere (the sign bit of its NaN correlations: solver_core.h)
     unsigned negmask = 0u;
     {
         double vr[LMAX];                                         // (my row of V in one batch of loads)
@@ -555,7 +555,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * W16<LMAX>::VP + (l < L ? l : 0)];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
-            if (!NM && l < L) { const int neg = ex.vote_count(valid && vr[l] < 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }      // (non-metric: no sign rule, weights.py:122-133)
+            if (!NM && l < L) { const int neg = ex.vote_count(valid && (vr[l] < 0.0 || sdp == 0.0)); if (P - 2 * neg < 0) negmask |= 1u << l; }      // (non-metric: no sign rule, weights.py:122-133)
     }
     const double sgl = ((negmask >> lp) & 1u) ? -1.0 : 1.0;
     const double vlp = ws.V[p * W16<LMAX>::VP + lp];                    // V[p, lv(p)] for the loading
@@ -615,7 +615,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     if (out.row) {
         if (valid) {
             out.row[p] = wp;
-            out.row[P + L + 2 * ne + p] = sgl * vlp * wfp / sdp;
+            out.row[P + L + 2 * ne + p] = (sdp > 0.0) ? sgl * vlp * wfp / sdp : 0.0;      // (a zero-variance column: the reference's loading is 0, solver_core.h treated_sd)
         }
         if (lvlane) out.row[P + t] = r2p;
         for (int e = t; e < ne; e += 64) {                       // (up to 120 effects at 16 LVs)
@@ -624,7 +624,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
             out.row[P + L + ne + e] = Bm[idx];
         }
     }
-    const bool bad = ex.vote_any((valid && !(isfinite(wp) && isfinite(sdp) && sdp > 0.0)) || (lvlane && !isfinite(r2p)));
+    const bool bad = ex.vote_any((valid && !(isfinite(wp) && isfinite(sdp) && sdp >= 0.0)) || (lvlane && !isfinite(r2p)));
     const bool sing = ex.vote_any(singular);
     if (t == 0) {
         int st = sing ? ST_SINGULAR : (not_converged ? ST_NOT_CONVERGED : ST_OK);

@@ -26,7 +26,7 @@ warnings.filterwarnings("ignore")
 SCALE = {"NUM": Scale.NUM, "RAW": Scale.RAW, "ORD": Scale.ORD, "NOM": Scale.NOM}
 
 
-def frames(X, model, hoc=None):
+def frames(X, model, hoc=None, unidim=True):
     """hoc = (stage2, C2, modes2) of fuzz_cases.make_hoc_case: the HOC is named H, its MVs after the constituents.  (The reference's unidimensionality() raises KeyError on a
     HOC model -- it looks the HOC's score columns up in the filtered data, unidimensionality.py:39 --: not part of those models' fixtures.)"""
     L = model.L
@@ -47,7 +47,7 @@ def frames(X, model, hoc=None):
     m = Plspm(df, cfg, mg.SCHEMES[model.scheme], 100, model.tol)
     out = {}
     for name, fr in (("outer_model", m.outer_model()), ("inner_model", m.inner_model()), ("inner_summary", m.inner_summary()), ("path_coefficients", m.path_coefficients()),
-                     ("crossloadings", m.crossloadings())) + ((("unidimensionality", m.unidimensionality()),) if hoc is None else ()):
+                     ("crossloadings", m.crossloadings())) + ((("unidimensionality", m.unidimensionality()),) if (hoc is None and unidim) else ()):
         num = fr.select_dtypes(include=[np.number])
         out[name + "/values"] = num.values.astype(float)
         out[name + "/index"] = np.array([str(i) for i in fr.index])
@@ -92,6 +92,17 @@ def main():
             cases.append((kind, seed, X, (model, (stage2, C2, modes2))))
             if sum(1 for k in cases if k[0] == kind) == want:
                 break
+    # metric models with a CONSTANT column (fuzz_cases.make_degenerate_case kind 2): the reference centres it to zeros -- weight 0, loading 0 (pandas' sum skips the NaN of its
+    # correlations), NaN cross-loadings; its unidimensionality() raises ValueError there (PCA on NaN) and is left out
+    nflat = 0
+    for seed in range(400):
+        X, model, nonmetric, k2 = fc.make_degenerate_case(seed)
+        if k2 != 2 or nonmetric or any(len(b) < 2 for b in model.blocks):
+            continue
+        cases.append(("flat", seed, X, model))
+        nflat += 1
+        if nflat == 4:
+            break
     tags = []
     for kind, seed, X, model in cases:
         tag = "%s%d" % (kind, seed)
@@ -99,7 +110,7 @@ def main():
         if isinstance(model, tuple):
             model, hoc = model
         try:
-            out = frames(X, model, hoc)
+            out = frames(X, model, hoc, unidim=(kind != "flat"))
         except Exception as e:                                 # noqa: BLE001
             print(tag, "reference raised", repr(e)[:120])
             continue

@@ -1,7 +1,7 @@
 #!/opt/conda/bin/python3.9
 """Oracle against the REAL reference on seeded random models (build container only, like make_golden.py: the reference never travels).
 
-Run:   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/sweep_oracle_vs_reference.py KIND A B        KIND = cat | missing | nmx | hoc | hocord | metric
+Run:   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/sweep_oracle_vs_reference.py KIND A B        KIND = cat | catbig | missing | nmx | hoc | hocord | metric | edge | hostile | huge
 
 The fixtures g1-g16 pin the oracle on the reference's own data sets and a handful of synthetic ones; the GPU fuzz (tests/test_gpu_fuzz.py) then holds the device against the ORACLE on
 thousands of random models.  This sweep closes the triangle for the same generators (tests/fuzz_cases.py): the reference's public API (Plspm(...), fit only) on the model of seed s,
@@ -71,6 +71,7 @@ def reference_fit(X, model, tol, hoc=None):
 
 def check(kind, seed):
     hoc = None
+    erratic = False
     if kind == "cat":
         X, model = fc.make_cat_case(seed)
     elif kind == "missing":
@@ -79,6 +80,20 @@ def check(kind, seed):
         X, model = fc.make_nmx_case(seed)
     elif kind == "metric":
         X, model, nonmetric = fc.make_case(seed)
+    elif kind == "catbig":
+        X, model = fc.make_cat_big_case(seed)
+    elif kind == "edge":
+        X, model, _, edge_kind = fc.make_degenerate_case(seed)
+        if edge_kind == 3:                                     # Plspm() clamps `iterations` below 100 to 100 (plspm.py:54-55): the cap of 1 ... 4 exists at the C-ABI only
+            model = orc.Model(model.blocks, model.C, model.modes, model.scheme, model.scaled, max_iter=100, tol=model.tol, scales=model.scales)
+        # an exact copy / multiple of a column inside a Mode-B block: scipy.linalg.lstsq (mode.py:51) cuts singular values at machine epsilon, and the copy's sits AT that
+        # threshold -- the reference either returns the minimum-norm weights (what the oracle and the device always do: cut-off eps * max(M, N) / 1e-12) or keeps a singular
+        # value of 1e-16 and iterates on weights of 1e13 until "could not converge".  Such disagreements are the reference's coin toss, reported apart.
+        erratic = edge_kind == 1 and "B" in model.modes
+    elif kind == "hostile":
+        X, model = fc.make_hostile_case(seed)[:2]
+    elif kind == "huge":
+        X, model = fc.make_huge_case(seed)[:2]
     else:
         X, model, stage2, C2, modes2, _ = (fc.make_hoc_ord_case if kind == "hocord" else fc.make_hoc_case)(seed)
         hoc = (stage2, C2, modes2)
@@ -96,6 +111,8 @@ def check(kind, seed):
         orc_err = e
     if ref_err is not None or orc_err is not None:
         if (ref_err is None) != (orc_err is None):
+            if erratic and orc_err is None:
+                return "reference-erratic (gelsd at its rank threshold)"
             raise AssertionError("reference %r / oracle %r" % (ref_err, orc_err))
         return "both-raise"
     if not np.all(np.isfinite(ref["scores"])):
@@ -107,7 +124,12 @@ def check(kind, seed):
         names = []
         for kind2, ref2 in hoc[0]:
             names += ["L%d" % j for j in ref2] if kind2 == "hoc" else ["x%d" % p for p in model.blocks[ref2]]
-    close(ref["outer"].loc[names, "weight"].values, mine["weights"], "weights")
+    try:
+        close(ref["outer"].loc[names, "weight"].values, mine["weights"], "weights")
+    except AssertionError:
+        if erratic:
+            return "reference-erratic (gelsd at its rank threshold)"
+        raise
     close(ref["outer"].loc[names, "loading"].values, mine["loadings"], "loadings")
     close(ref["path_coef"], mine["path_coef"], "path coefficients")
     close(ref["r2"], mine["r2"], "r2")

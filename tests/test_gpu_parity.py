@@ -247,8 +247,15 @@ def test_sign_rule_and_status_codes():
     hard = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", False, max_iter=2, tol=1e-30)
     _, g = gpu_fit(X, hard)
     assert g["status"] == 1 and g["iterations"] == 3
-    Xd = X.copy(); Xd[:, blocks[2][1]] = 3.0                      # a constant MV: flagged, never silently returned
-    _, g = gpu_fit(Xd, orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True))
+    Xd = X.copy(); Xd[:, blocks[2][1]] = 3.0                      # a constant MV: weight 0, loading 0, cross-loadings NaN -- as the reference returns it (round 6)
+    flat = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True)
+    _, g = gpu_fit(Xd, flat)
+    r = orc.fit(Xd, flat)
+    assert g["status"] == 0 and g["iterations"] == r["iterations"]
+    assert_close(g["weights_d"], r["weights"], RTOL, 1e-12); assert_close(g["loadings_d"], r["loadings"], RTOL, 1e-12)
+    assert r["loadings"][blocks[2][1]] == 0.0 and g["loadings_d"][blocks[2][1]] == 0.0
+    Xn = X.copy(); Xn[7, 3] = np.nan                              # non-finite data stay flagged
+    _, g = gpu_fit(Xn, flat)
     assert g["status"] in (2, 3)
 
 

@@ -141,7 +141,16 @@ def test_wave_solver_status_codes_and_fallbacks():
     Xc = X.copy(); Xc[:, blocks[2][1]] = 3.0
     nm = native_model(orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True))
     nm.upload(Xc, tight.mv_order.astype(np.int32)); nm.set_option("gram_path", 2)
-    assert np.all(np.isin(nm.bootstrap(32, seed=2)[1], (2, 3))) and nm.get_option("last_solver") in WAVE
+    flat = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True)
+    rows, status, iters = nm.bootstrap(32, seed=2)              # a constant MV: weight 0, loading 0, the replicate counts -- as in the reference (solver_core.h treated_sd)
+    assert np.all(status == 0) and nm.get_option("last_solver") in WAVE
+    from plspm import _native
+    mine, its = orc.bootstrap_replicate(Xc, flat, _native.bootstrap_indices(2, 5, Xc.shape[0]), orc.correction(Xc.shape[0]))
+    P = Xc.shape[1]
+    inv = np.empty(P, dtype=np.int64); inv[flat.mv_order] = np.arange(P)
+    got = np.concatenate((rows[5, :P][inv], rows[5, P:P + 6 + 2 * nm.n_eff], rows[5, P + 6 + 2 * nm.n_eff:][inv]))
+    assert its == iters[5] and mine[P + 6 + 2 * nm.n_eff + blocks[2][1]] == 0.0
+    assert_close(got, mine, 1e-8, 1e-11)
     g = load("g14_rank_deficient")
     Xb, blocks_b, Cb = g14_case(g, "b")
     model = orc.Model(blocks_b, Cb, "AAAAAAA", "path", True)

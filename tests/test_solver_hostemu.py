@@ -275,11 +275,23 @@ def test_rank_deficient_least_squares_minimum_norm(emu, which, modes, scheme, sc
         assert_close(mine, g[key + "/boot_rows"][0], RTOL, 1e-11, what=key + " bootstrap row")
 
 
-def test_zero_variance_column_flagged(emu):
+@pytest.mark.parametrize("modes", ["AAAAAA", "ABBABA"])
+@pytest.mark.parametrize("rows", [False, True])
+def test_zero_variance_column_follows_the_reference(emu, modes, rows):
+    """A constant MV is centred to exact zeros by the reference: Mode-A weight 0 (Mode B: the minimum-norm answer gives it 0 as well), pandas' corrwith NaN for its
+    cross-loadings, which `(crossloadings * odm).sum(axis=1)` skips -- loading 0, and the estimate counts (round 6: found by tests/golden/sweep_oracle_vs_reference.py `edge`;
+    until then the device flagged PLSPM_NONFINITE, i.e. dropped every bootstrap replicate in which a rare binary item came out constant).  LDS and rows solver."""
     X, blocks, _ = satisfaction_oracle_inputs()
-    X = X.copy(); X[:, blocks[2][1]] = 3.0                            # a constant MV: nothing a least-squares solver can weigh
-    model = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True)
-    assert run_emu(emu, X, model)["status"] in (2, 3)
+    X = X.copy(); X[:, blocks[2][1]] = 3.0
+    model = orc.Model(blocks, orc.satisfaction_C(), modes, "centroid", True)
+    ref = orc.fit(X, model)
+    assert ref["loadings"][blocks[2][1]] == 0.0 and abs(ref["weights"][blocks[2][1]]) < 1e-15
+    got = run_emu(emu, X, model, rows=rows)
+    assert got["status"] == 0 and got["iterations"] == ref["iterations"]
+    assert got["loadings"][blocks[2][1]] == 0.0
+    assert_close(got["weights"], ref["weights"], RTOL, 1e-12, what="weights")
+    assert_close(got["loadings"], ref["loadings"], RTOL, 1e-12, what="loadings")
+    assert_close(got["r2"], ref["r2"], RTOL, 1e-12)
 
 
 def test_thread_sanitizer_clean():

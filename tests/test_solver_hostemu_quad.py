@@ -130,7 +130,10 @@ def test_quad_status_codes_sign_rule_and_rank_deficient_predecessors(emu):
     e = run_quad(emu, X, tight)
     assert e["status"] == 1 and e["iterations"] == 3           # counter runs to max_iter+1 before giving up (weights.py:181-186)
     Xc = X.copy(); Xc[:, blocks[2][1]] = 3.0                    # a constant MV
-    assert run_quad(emu, Xc, orc.Model(blocks, C, "AAAA", "centroid", True))["status"] in (2, 3)
+    cm = orc.Model(blocks, C, "AAAA", "centroid", True)                                     # a constant MV: the reference centres it to zeros -- weight 0, loading 0, the estimate counts (solver_core.h treated_sd)
+    e, r = run_quad(emu, Xc, cm), orc.fit(Xc, cm)
+    assert e["status"] == 0 and e["iterations"] == r["iterations"] and e["loadings"][blocks[2][1]] == 0.0
+    assert_close(e["weights"], r["weights"], 1e-9, 1e-12); assert_close(e["loadings"], r["loadings"], 1e-9, 1e-12)
     # sign rule: most MVs of the first side's blocks negated -> the votes of waves 0 / 1 flip those LVs (weights.py:62-64)
     Xn = X.copy()
     Xn[:, blocks[0][:15]] *= -1.0

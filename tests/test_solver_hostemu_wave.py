@@ -142,7 +142,10 @@ def test_wave_status_codes_and_rank_deficient_predecessors(emu):
     e = run_wave(emu, X, tight)
     assert e["status"] == 1 and e["iterations"] == 3           # counter runs to max_iter+1 before giving up (weights.py:181-186)
     Xc = X.copy(); Xc[:, blocks[2][1]] = 3.0                    # a constant MV
-    assert run_wave(emu, Xc, orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True))["status"] in (2, 3)
+    cm = orc.Model(blocks, orc.satisfaction_C(), "AAAAAA", "centroid", True)                                     # a constant MV: the reference centres it to zeros -- weight 0, loading 0, the estimate counts (solver_core.h treated_sd)
+    e, r = run_wave(emu, Xc, cm), orc.fit(Xc, cm)
+    assert e["status"] == 0 and e["iterations"] == r["iterations"] and e["loadings"][blocks[2][1]] == 0.0
+    assert_close(e["weights"], r["weights"], 1e-9, 1e-12); assert_close(e["loadings"], r["loadings"], 1e-9, 1e-12)
     # exactly collinear predecessor scores (a cloned LV): the minimum-norm coefficients of the reference's pinv (golden g14)
     g = load("g14_rank_deficient")
     Xb, blocks_b, Cb = g14_case(g, "b")
