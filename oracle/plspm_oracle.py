@@ -167,7 +167,8 @@ def finalize(Xt, W, model: Model, corr: float):
     cor = cov / np.outer(xs, ss)                                  # weights.py:61
     odm = (W != 0).astype(int)                                    # weights.py:62
     prod = cor * odm                                              # -0.0 where cor<0 and odm==0
-    sgn_mv = np.copysign(1.0, prod)
+    sgn_mv = np.where(np.isnan(prod), 1.0, np.copysign(1.0, prod))      # a zero-variance column: pandas' corr() returns np.nan -- sign bit CLEAR -- for it, so math.copysign
+                                                                  # (weights.py:63) makes its vote +1 in every LV (NumPy's own 0 / 0 would carry the sign bit: -1)
     sign = np.copysign(1.0, sgn_mv.sum(axis=0))                   # weights.py:64
     if -1 in sign:                                                # weights.py:65-68
         scores = scores * sign

@@ -873,16 +873,16 @@ PLSPM_HD void finish_problem(Ex& ex, const ModelDesc& md, Workspace& ws, const F
     ex.par(L * NC, [&](int e) {
         const int l = e / NC, c = e - l * NC;
         const int p0 = (int)((long)P * c / NC), p1 = (int)((long)P * (c + 1) / NC);
-        // (a zero-variance column -- treated_sd -- votes -1 in EVERY LV: its correlations are 0 / 0 = the default NaN, whose sign bit is set, and copysign(1.0, NaN) of
-        //  weights.py:63 reads that bit; the oracle's NumPy does the same.  sd is exactly 0 for such a column and for no other.)
+        // (a zero-variance column -- treated_sd -- votes +1 in EVERY LV: pandas' corr() returns np.nan for it, sign bit clear, and copysign(1.0, nan) of weights.py:63 is +1.
+        //  Its entries of V are rounding residue of either sign: sd, exactly 0 for such a column and for no other, keeps them out of the negative count.)
         int vote = 0;
         int p = p0;
         for (; p + 3 < p1; p += 4) {
             const double v0 = ws.V[p * L + l], v1 = ws.V[(p + 1) * L + l], v2 = ws.V[(p + 2) * L + l], v3 = ws.V[(p + 3) * L + l];
             const bool f0 = ws.sd[p] == 0.0, f1 = ws.sd[p + 1] == 0.0, f2 = ws.sd[p + 2] == 0.0, f3 = ws.sd[p + 3] == 0.0;
-            vote += ((v0 < 0.0 || f0) ? -1 : 1) + ((v1 < 0.0 || f1) ? -1 : 1) + ((v2 < 0.0 || f2) ? -1 : 1) + ((v3 < 0.0 || f3) ? -1 : 1);
+            vote += ((v0 < 0.0 && !f0) ? -1 : 1) + ((v1 < 0.0 && !f1) ? -1 : 1) + ((v2 < 0.0 && !f2) ? -1 : 1) + ((v3 < 0.0 && !f3) ? -1 : 1);
         }
-        for (; p < p1; ++p) vote += (ws.V[p * L + l] < 0.0 || ws.sd[p] == 0.0) ? -1 : 1;
+        for (; p < p1; ++p) vote += (ws.V[p * L + l] < 0.0 && ws.sd[p] != 0.0) ? -1 : 1;
         ws.Pw2[e] = (double)vote;
     });
     ex.par(L, [&](int l) {

@@ -276,7 +276,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
     // finalize (weights.py:56-70): wf_l = 1 / sqrt(Q_ll); returned weights never sign-flipped
     const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
     wp *= wfp;
-    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes -1 everywhere (the sign bit of its NaN correlations: solver_core.h).  The owners sit in waves 0 and 1; every wave casts the same number of
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes +1 everywhere (pandas' NaN correlation has its sign bit clear: solver_core.h).  The owners sit in waves 0 and 1; every wave casts the same number of
     // ballots (the CPU emulation's ballot is a barrier).
     {
         double vr[LMAX];                                         // (my row of V in one batch of loads: a load inside every ballot's block waits out its own LDS round trip)
@@ -284,7 +284,7 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
         for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * QUAD_VP + (l < L ? l : 0)];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
-            if (l < L) { const int neg = ex.wave_vote_count(owner && (vr[l] < 0.0 || sdp == 0.0)); if ((t & 63) == 0 && side == 0) ws.votes[wave * LMAX + l] = (double)neg; }
+            if (l < L) { const int neg = ex.wave_vote_count(owner && vr[l] < 0.0 && sdp != 0.0); if ((t & 63) == 0 && side == 0) ws.votes[wave * LMAX + l] = (double)neg; }
     }
     ex.sync();
     // (a thread looks up the three signs it needs -- its pair's two LVs, its MV's LV -- instead of walking all L tallies)

@@ -514,11 +514,11 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
     // finalize (weights.py:56-70): wf_l = 1 / (std1(X w_l) / corr) = 1 / sqrt(Q_ll); returned weights never sign-flipped
     const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
     wp *= wfp;
-    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes -1 everywhere (the sign bit of its NaN correlations: solver_core.h)
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes +1 everywhere (pandas' NaN correlation has its sign bit clear: solver_core.h)
     unsigned negmask = 0u;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l)
-        if (l < L) { const int neg = ex.vote_count(mine && (Vp[l] < 0.0 || sdp == 0.0)); if (P - 2 * neg < 0) negmask |= 1u << l; }
+        if (l < L) { const int neg = ex.vote_count(mine && Vp[l] < 0.0 && sdp != 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }
     {
         const double wfl = wave_rsqrt(ws.Qm[el * LMAX + el]), wfm = wave_rsqrt(ws.Qm[em * LMAX + em]);
         const double sl = ((negmask >> el) & 1u) ? -1.0 : 1.0, sm = ((negmask >> em) & 1u) ? -1.0 : 1.0;

@@ -547,7 +547,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     // finalize (weights.py:56-70): wf_l = 1 / sqrt(Q_ll); returned weights never sign-flipped
     const double wfp = wave_rsqrt(ws.Qm[lp * LMAX + lp]);
     wp *= wfp;
-    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes -1 everywhere (the sign bit of its NaN correlations: solver_core.h)
+    // sign rule: EVERY MV votes (weights.py:62-64); sign(cor[p,l]) == sign(V[p,l]); a zero-variance column votes +1 everywhere (pandas' NaN correlation has its sign bit clear: solver_core.h)
     unsigned negmask = 0u;
     {
         double vr[LMAX];                                         // (my row of V in one batch of loads)
@@ -555,7 +555,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         for (int l = 0; l < LMAX; ++l) vr[l] = ws.V[p * W16<LMAX>::VP + (l < L ? l : 0)];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
-            if (!NM && l < L) { const int neg = ex.vote_count(valid && (vr[l] < 0.0 || sdp == 0.0)); if (P - 2 * neg < 0) negmask |= 1u << l; }      // (non-metric: no sign rule, weights.py:122-133)
+            if (!NM && l < L) { const int neg = ex.vote_count(valid && vr[l] < 0.0 && sdp != 0.0); if (P - 2 * neg < 0) negmask |= 1u << l; }      // (non-metric: no sign rule, weights.py:122-133)
     }
     const double sgl = ((negmask >> lp) & 1u) ? -1.0 : 1.0;
     const double vlp = ws.V[p * W16<LMAX>::VP + lp];                    // V[p, lv(p)] for the loading
