@@ -126,11 +126,14 @@ PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, i
 // A column that is CONSTANT in this data set -- in a bootstrap: an item whose resample holds one value only (a rare binary indicator, a small sample) -- is centred to exact
 // zeros by the reference: its Mode-A weight is 0, pandas' corrwith gives NaN for its cross-loadings and `(crossloadings * odm).sum(axis=1)` (plspm.py / bootstrap.py:62) skips
 // that NaN: LOADING 0, and the estimate -- or the replicate -- counts.  On second moments that variance is `dpp - mup^2 / n` of two equal numbers: rounding noise of either
-// sign.  Below 1e-12 of the second moment it is called zero here (no column of real data is constant to twelve digits without being constant); the outputs then follow the
-// reference (loading 0, cross-loadings NaN) and the status stays PLSPM_OK.  NaN / inf data keep their NaN / inf: PLSPM_NONFINITE as before.
+// sign -- on the int8 digit-plane route up to N 2^-(8S-1) max|z_pp| of it, i.e. ~3e-17 (M / c)^2 of the second moment at seven planes for a column that sits at c in this
+// replicate and reaches M elsewhere (a rare indicator: M / c = n / k).  Below 1e-9 of the second moment it is called zero here: a real column's variance about the upload's
+// shift is ALL of its second moment up to (replicate mean - shift)^2, which resampling keeps within a few variances / n -- nothing real comes within nine orders of magnitude;
+// an indicator rarer than ~1 in 6,000 can fall short of the threshold on the int8 route and is then standardised like any column (as before this rule).  The outputs of a zero
+// follow the reference (loading 0, cross-loadings NaN), the status stays PLSPM_OK.  NaN / inf data keep their NaN / inf: PLSPM_NONFINITE as before.
 PLSPM_HD double treated_sd(double dpp, double mup, double inv_n, double fac) {
     const double var = dpp - (mup * mup) * inv_n;
-    if (var > 1e-12 * dpp) return sqrt(var * fac);
+    if (var > 1e-9 * dpp) return sqrt(var * fac);
     return (var == var && dpp == dpp && fac == fac) ? 0.0 : var + dpp + fac;       // (NaN stays NaN)
 }
 

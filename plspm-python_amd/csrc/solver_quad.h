@@ -154,6 +154,13 @@ PLSPM_HD void solve_problem_quad(Ex& ex, const ModelDesc& md, const QuadWs<LMAX>
         for (int q = 0; q < PMAX; ++q) s[q] = 0.0;
     }
     const double sdp = treated_sd(dpp, mup, inv_n, fac);           // (0: a column that is constant in this replicate -- solver_core.h)
+    // (its row of the covariance is rounding residue: exact zeros instead -- an LV whose only item is that column then has a score variance of exactly 0 and fails as the
+    //  reference's does, instead of normalising the residue; rare: one ballot, the loop runs for the waves that hold such a column)
+    if (ex.wave_vote_count(valid && sdp == 0.0) > 0) {
+        const double keep = (sdp == 0.0) ? 0.0 : 1.0;
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) s[q] *= keep;
+    }
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: the staging area is free)
 

@@ -235,6 +235,13 @@ PLSPM_HD void solve_problem_wave(Ex& ex, const ModelDesc& md, const WaveWs<LMAX>
         ex.pin8(s[q0], s[q0 + 1], s[q0 + 2], s[q0 + 3], s[q0 + 4], s[q0 + 5], s[q0 + 6], s[q0 + 7]);     // results final before the next loads issue
     }
     const double sdp = treated_sd(dpp, mup, inv_n, fac);           // (0: a column that is constant in this replicate -- solver_core.h)
+    // (its row of the covariance is rounding residue: exact zeros instead -- an LV whose only item is that column then has a score variance of exactly 0 and fails as the
+    //  reference's does, instead of normalising the residue; rare: one ballot, the loop runs for the waves that hold such a column)
+    if (ex.vote_any(mine && sdp == 0.0)) {
+        const double keep = (sdp == 0.0) ? 0.0 : 1.0;
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) s[q] *= keep;
+    }
     // (loop constants in SCALAR registers: every lane holds the same value; as vector registers they were spilled around the loop)
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);

@@ -168,6 +168,15 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
         for (int q = 0; q < PMAX; ++q) s[q] = 0.0;
     }
     const double sdp = NM ? sqrt(((dpp - (mup * mup) * inv_n) * inv_n) / (sdraw * sdraw)) : treated_sd(dpp, mup, inv_n, fac);      // (NM: sqrt(R_pp), 1 to rounding)
+    if constexpr (!NM) {
+        // (a zero-variance column's row of the covariance is rounding residue: exact zeros instead -- an LV whose only item is that column then has a score variance of exactly
+        //  0 and fails as the reference's does; rare: one ballot, the loop runs for the waves that hold such a column)
+        if (ex.vote_any(valid && sdp == 0.0)) {
+            const double keep = (sdp == 0.0) ? 0.0 : 1.0;
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) s[q] *= keep;
+        }
+    }
     const double corr2 = ex.uniform_d(n / (n - 1.0));
     ex.mark(2);                                                  // (the loader's last barrier stands behind its last tile read: V takes the tile's place)
 

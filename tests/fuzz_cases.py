@@ -272,3 +272,21 @@ def make_huge_case(seed):
     nonmetric = bool(rng.integers(0, 4) == 0)
     model = orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2)) or nonmetric, tol=(1e-7 if nonmetric else 1e-6), scales=(["NUM"] * P) if nonmetric else None)
     return X, model, sizes, nonmetric
+
+
+def make_rare_indicator_case(seed):
+    """A metric model of make_case with one column replaced by a rare 0/1 indicator (2 ... 6 ones) and six explicit index lists: the data themselves, two ordinary resamples
+    and three resamples that miss every one -- the indicator is CONSTANT there: the reference centres it to zeros (weight 0, loading 0) and counts the replicate.
+    Returns (X, model, idx [6, n]) or None for the Scale.NUM seeds."""
+    X, model, nonmetric = make_case(seed)
+    if nonmetric:
+        return None
+    rng = np.random.default_rng(18000 + seed)
+    n, P = X.shape
+    col = int(rng.integers(0, P))
+    ones = rng.choice(n, size=int(rng.integers(2, 7)), replace=False)
+    X = X.copy(); X[:, col] = 0.0; X[ones, col] = 1.0
+    idx = [np.arange(n), rng.integers(0, n, size=n), rng.integers(0, n, size=n)]
+    rest = np.setdiff1d(np.arange(n), ones)
+    idx += [rng.choice(rest, size=n, replace=True) for _ in range(3)]
+    return X, model, np.asarray(idx, dtype=np.int32)

@@ -697,3 +697,46 @@ def _huge_case_check(seed, B=24):
 @pytest.mark.parametrize("seed", range(12))
 def test_random_model_with_many_lvs(seed):
     _huge_case_check(seed)
+
+
+# ---- a rare 0/1 indicator that comes out CONSTANT in some replicates (fuzz_cases.make_rare_indicator_case; the oracle is pinned on the reference's own rows for the same
+# cases by tests/golden/sweep_bootstrap_rows_vs_reference.py): weight 0, loading 0, the replicate counts -- on both Gram routes
+def _rare_indicator_check(seed):
+    from fuzz_cases import make_rare_indicator_case
+    from plspm import _native
+    case = make_rare_indicator_case(seed)
+    if case is None:
+        return "skipped"
+    X, model, idx = case
+    n, P = X.shape
+    boff = np.concatenate(([0], np.cumsum([len(b) for b in model.blocks]))).astype(np.int32)
+    modes = np.array([0 if m == "A" else 1 for m in model.modes], dtype=np.int32)
+    nm = _native.NativeModel(boff, model.C.astype(np.uint8), modes, SCHEME_ID[model.scheme], model.scaled, model.max_iter, model.tol, 0)
+    nm.upload(X)
+    tag = "seed %d L=%d P=%d n=%d %s %s scaled=%d" % (seed, model.L, P, n, model.modes, model.scheme, model.scaled)
+    corr = orc.correction(n)
+    out = []
+    for path in (2, 1):
+        nm.set_option("gram_path", path)
+        rows, status, iters = nm.bootstrap(len(idx), idx=idx)
+        flat_ok = 0
+        for b in range(len(idx)):
+            try:
+                with np.errstate(all="ignore"):
+                    mine, its = orc.bootstrap_replicate(X, model, idx[b], corr)
+            except Exception:                              # noqa: BLE001  (e.g. the indicator is the only item of its LV: the reference fails too)
+                assert status[b] != 0, tag + " replicate %d (gram_path %d): the oracle cannot finish, device status 0" % (b, path)
+                continue
+            if status[b] != 0:
+                assert_device_status_justified(int(status[b]), np.delete(X[idx[b]], np.flatnonzero(X[idx[b]].std(axis=0) == 0), axis=1) if False else X[idx[b]], model, tag)
+                continue
+            assert its == iters[b], tag + " replicate %d (gram_path %d): iterations %d vs %d" % (b, path, iters[b], its)
+            assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d (gram_path %d)" % (b, path))
+            flat_ok += b >= 3
+        out.append(flat_ok)
+    return "flat replicates compared %d/%d" % tuple(out)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_rare_indicator_constant_in_some_replicates(seed):
+    _rare_indicator_check(seed)
