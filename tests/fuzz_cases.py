@@ -290,3 +290,15 @@ def make_rare_indicator_case(seed):
     rest = np.setdiff1d(np.arange(n), ones)
     idx += [rng.choice(rest, size=n, replace=True) for _ in range(3)]
     return X, model, np.asarray(idx, dtype=np.int32)
+
+
+def make_raw_case(seed):
+    """Non-metric models on Scale.RAW / Scale.NUM columns: all RAW (Config.treat switches scaling off: config.py:309-310) or a RAW / NUM mix (every column becomes NUM:
+    config.py:311-313) -- rules of the host-side Config, so these cases are for the API-level fixtures (golden g17)."""
+    X, model, _ = make_case(seed)
+    rng = np.random.default_rng(20000 + seed)
+    all_raw = bool(rng.integers(0, 2))
+    scales = ["RAW"] * X.shape[1] if all_raw else [("RAW", "NUM")[int(rng.integers(0, 2))] for _ in range(X.shape[1])]
+    if not all_raw and len(set(scales)) == 1:
+        scales[0] = "NUM" if scales[0] == "RAW" else "RAW"
+    return X, orc.Model(model.blocks, model.C, model.modes, model.scheme, True, tol=1e-7, scales=scales)

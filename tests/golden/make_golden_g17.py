@@ -103,6 +103,15 @@ def main():
         nflat += 1
         if nflat == 4:
             break
+    nraw = 0
+    for seed in range(60):                                     # Scale.RAW / RAW + NUM mixes: Config.treat's scale rules (config.py:309-313)
+        X, model = fc.make_raw_case(seed)
+        if any(len(b) < 2 for b in model.blocks):
+            continue
+        cases.append(("raw", seed, X, model))
+        nraw += 1
+        if nraw == 4:
+            break
     tags = []
     for kind, seed, X, model in cases:
         tag = "%s%d" % (kind, seed)

@@ -22,7 +22,7 @@ def _plspm(tag, check_sha=True, **kwargs):
     from plspm.plspm import Plspm
     from plspm.scale import Scale
     from plspm.scheme import Scheme
-    kind = [k for k in ("metric", "missing", "nmx", "cat", "hocnum", "hocord", "flat") if tag.startswith(k)][0]
+    kind = [k for k in ("metric", "missing", "nmx", "cat", "hocnum", "hocord", "flat", "raw") if tag.startswith(k)][0]
     seed = int(tag[len(kind):])
     hoc = None
     if kind.startswith("hoc"):
@@ -30,7 +30,7 @@ def _plspm(tag, check_sha=True, **kwargs):
         hoc = (stage2, C2, modes2)
     else:
         X, model = {"metric": lambda s: fc.make_case(s)[:2], "cat": fc.make_cat_case, "missing": fc.make_missing_case, "nmx": fc.make_nmx_case,
-                    "flat": lambda s: fc.make_degenerate_case(s)[:2]}[kind](seed)
+                    "flat": lambda s: fc.make_degenerate_case(s)[:2], "raw": fc.make_raw_case}[kind](seed)
     if check_sha:
         assert hashlib.sha256(np.ascontiguousarray(X, dtype=np.float64).tobytes()).hexdigest() == str(G[tag + "/x_sha"]), "the generator no longer reproduces the matrix g17 was made from"
     scale = {"NUM": Scale.NUM, "RAW": Scale.RAW, "ORD": Scale.ORD, "NOM": Scale.NOM}
