@@ -275,6 +275,11 @@ def nm_init_scores(X0, model: Model):
 # |var_incr - var_decr| / max(...) over all (trip, ordinal MV) decisions of scale.py:74.  The two variances are EQUAL in exact arithmetic whenever the category
 # means are mirror-symmetric (e.g. three categories with means a, b, a and equal outer counts -- coarse data, small samples, the first trips); the reference then takes the
 # direction np.var's rounding happens to favour, and two correct evaluations of the same formulas may walk different trajectories to the same fixed point.
+# "min_quant_var_over_z": the smallest var(quantified MV) / var(z) -- category means that tie leave a quantification of rounding residue (1e-34), which the reference
+# standardises into a +-1 pattern of that residue's signs (or, when the tie is exact in floating point too, into NaN: the estimate fails).  "min_z_scale": the smallest
+# std(z_l) / std(scores) -- an inner estimate that is residue itself (two initial scores whose covariance is exactly zero: z = -8e-18 y); "min_linked_score_corr": the smallest
+# |correlation| between the scores of two linked LVs (the same coincidence under the centroid scheme, which keeps only the residue's sign).  An evaluation on integer counts
+# meets these ties EXACTLY (0 / 0: the estimate fails); which of the two the reference does is decided by its own rounding.
 DIAG = None
 
 
@@ -293,6 +298,16 @@ def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
         E = _SCHEMES[model.scheme](model.C, Y)
         Z = Y @ E
         W = np.zeros((X0.shape[1], model.L))
+        if DIAG is not None:                                      # (an inner estimate that is rounding residue: e.g. two initial scores with a covariance of exactly zero)
+            with np.errstate(all="ignore"):
+                zs = float(np.min(np.std(Z, axis=0)) / max(float(np.max(np.std(Y, axis=0))), 1e-300))
+            DIAG["min_z_scale"] = min(DIAG.get("min_z_scale", 1.0), zs if zs == zs else 0.0)
+            with np.errstate(all="ignore"):                          # (linked LVs whose scores are uncorrelated to rounding: the centroid scheme takes the SIGN of that residue)
+                Rs = np.abs(np.corrcoef(Y, rowvar=False))
+            link = (np.asarray(model.C) + np.asarray(model.C).T) > 0
+            if link.any():
+                rmin = float(np.nanmin(np.where(link, Rs, np.nan)))
+                DIAG["min_linked_score_corr"] = min(DIAG.get("min_linked_score_corr", 1.0), rmin if rmin == rmin else 0.0)
         for l, b in enumerate(model.blocks):
             z = Z[:, l]
             betas = None
@@ -323,6 +338,10 @@ def solve_nonmetric(X0, model: Model, corr: float, dummies=None):
                             DIAG["min_direction_margin"] = min(DIAG.get("min_direction_margin", 1.0), margin)
                     else:
                         xq = d @ means                                                  # scale.py:87
+                    if DIAG is not None:                                                # (a quantification that is rounding residue: category means that tie)
+                        with np.errstate(all="ignore"):
+                            q = float(np.var(xq) / max(float(np.var(zc)), 1e-300))
+                        DIAG["min_quant_var_over_z"] = min(DIAG.get("min_quant_var_over_z", 1.0), q if q == q else 0.0)
                     cur[:, p] = treat_numpy(xq) * corr
             Xk = cur[:, b]
             if np.isnan(X0[:, b]).any():                                                # "lv in mv_grouped_by_lv_missing" (weights.py:88-89)

@@ -302,3 +302,12 @@ def make_raw_case(seed):
     if not all_raw and len(set(scales)) == 1:
         scales[0] = "NUM" if scales[0] == "RAW" else "RAW"
     return X, orc.Model(model.blocks, model.C, model.modes, model.scheme, True, tol=1e-7, scales=scales)
+
+
+def make_cat_small_case(seed):
+    """make_cat_case cut down to 30 ... 90 rows: nearly every resample loses categories (util.rank re-ranks the present ones), some items keep one category only (a constant
+    quantification: the estimate fails as the reference's does)."""
+    X, model = make_cat_case(seed)
+    rng = np.random.default_rng(21000 + seed)
+    n = min(X.shape[0], int(rng.integers(30, 91)))
+    return X[rng.choice(X.shape[0], size=n, replace=False)], model

@@ -10,7 +10,8 @@ import test_gpu_fuzz as f
 import test_gpu_categorical as tc
 from plspm import _native
 seed = int(sys.argv[1])
-data, model = f.make_cat_case(seed)
+import fuzz_cases as fc
+data, model = {"small": fc.make_cat_small_case, "big": fc.make_cat_big_case}.get(sys.argv[2] if len(sys.argv) > 2 else "", fc.make_cat_case)(seed)
 n = data.shape[0]
 nm, g = tc.gpu_fit_cat(data, model)
 a = nm.bootstrap(40, seed=seed)
@@ -21,6 +22,16 @@ Pm = len(model.scales)
 ra = tc._rows_in_data_order(a[0], g["inv"], Pm, model.L, nm.n_eff)
 rw = tc._rows_in_data_order(w[0], g["inv"], Pm, model.L, nm.n_eff)
 for r in range(40):
+    if a[1][r] != w[1][r] or a[2][r] != w[2][r]:
+        idx = _native.bootstrap_indices(seed, r, n)
+        try:
+            with np.errstate(all="ignore"):
+                mine, its = orc.bootstrap_replicate(data, model, idx, orc.correction(n)); o = "iterations %d" % its
+        except Exception as e:
+            o = "raises " + type(e).__name__
+        Xr = data[idx]
+        print("replicate", r, "status wave/group", a[1][r], w[1][r], "iterations", a[2][r], w[2][r], "oracle", o, "categories present per MV:", [len(np.unique(Xr[:, p])) for p in range(Pm)], "of", [len(np.unique(data[:, p])) for p in range(Pm)])
+        continue
     if a[1][r] != 0 or w[1][r] != 0:
         continue
     d = np.max(np.abs(ra[r] - rw[r]) / np.maximum(np.abs(rw[r]), 1e-3))

@@ -11,7 +11,7 @@ import test_gpu_fuzz as f
 
 if __name__ == "__main__":
     a, b = int(sys.argv[1]), int(sys.argv[2])
-    big = len(sys.argv) > 3 and sys.argv[3] == "big"          # (fuzz_cases.make_cat_big_case: up to 80 MVs, items of up to 16 categories)
+    big = (sys.argv[3] == "small" and "small") or (sys.argv[3] == "big") if len(sys.argv) > 3 else False      # big: make_cat_big_case (up to 80 MVs, 16 categories); small: make_cat_small_case (30 ... 90 rows)
     hist, bad = collections.Counter(), []
     for seed in range(a, b):
         try:

@@ -15,7 +15,8 @@ seed, r = int(sys.argv[1]), int(sys.argv[2])
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 wave_opts = dict(kv.split("=") for kv in (sys.argv[4].split(",") if len(sys.argv) > 4 else []))      # options of the wave-step handle, e.g. nm_subset=0,nm_cpl=8
 import fuzz_cases as fc
-data, model = (fc.make_cat_big_case if big else f.make_cat_case)(seed)
+small = len(sys.argv) > 3 and sys.argv[3] == "small"
+data, model = (fc.make_cat_small_case if small else fc.make_cat_big_case if big else f.make_cat_case)(seed)
 n = data.shape[0]
 idx = _native.bootstrap_indices(seed, r, n)[None, :].astype(np.int32)
 Xaug, mv_off, mv_kind, lmv_off, boff, mv_data_col = build_aug(data, model)
