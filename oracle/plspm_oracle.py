@@ -141,6 +141,15 @@ def iterate(Xt, W, model: Model, corr: float):
     Y = (Y - Y.mean(axis=0)) / np.std(Y, axis=0, ddof=1) / corr   # weights.py:44 (util.treat)
     E = _SCHEMES[model.scheme](model.C, Y)                        # weights.py:45
     Z = Y @ E                                                     # weights.py:46
+    if DIAG is not None:                                          # (test diagnostics, as in solve_nonmetric: scores of linked LVs that are uncorrelated to rounding)
+        with np.errstate(all="ignore"):
+            Rs = np.abs(np.corrcoef(Y, rowvar=False))
+            zs = float(np.min(np.std(Z, axis=0)) / max(float(np.max(np.std(Y, axis=0))), 1e-300))
+        link = (np.asarray(model.C) + np.asarray(model.C).T) > 0
+        if link.any():
+            rmin = float(np.nanmin(np.where(link, Rs, np.nan)))
+            DIAG["min_linked_score_corr"] = min(DIAG.get("min_linked_score_corr", 1.0), rmin if rmin == rmin else 0.0)
+        DIAG["min_z_scale"] = min(DIAG.get("min_z_scale", 1.0), zs if zs == zs else 0.0)
     Wn = W.copy()
     for l, b in enumerate(model.blocks):                          # weights.py:47-50
         Xk = Xt[:, b]
@@ -170,6 +179,13 @@ def finalize(Xt, W, model: Model, corr: float):
     sgn_mv = np.where(np.isnan(prod), 1.0, np.copysign(1.0, prod))      # a zero-variance column: pandas' corr() returns np.nan -- sign bit CLEAR -- for it, so math.copysign
                                                                   # (weights.py:63) makes its vote +1 in every LV (NumPy's own 0 / 0 would carry the sign bit: -1)
     sign = np.copysign(1.0, sgn_mv.sum(axis=0))                   # weights.py:64
+    if DIAG is not None:
+        # a vote is DECISIVE when turning it alone turns the LV: sums of 0 / +1 lean on their +1 votes, sums of -1 / -2 on their -1 votes.  The smallest |correlation| behind a
+        # decisive vote tells a sign rule settled by the sign bit of rounding residue (an off-block item that is exactly uncorrelated with the score in a sample of integers)
+        tot = sgn_mv.sum(axis=0)
+        decisive = ((tot >= 0) & (tot <= 1))[None, :] & (sgn_mv > 0) | ((tot < 0) & (tot >= -2))[None, :] & (sgn_mv < 0)
+        mag = np.where(decisive & ~np.isnan(cor), np.abs(cor), 1.0)
+        DIAG["min_decisive_vote_corr"] = min(DIAG.get("min_decisive_vote_corr", 1.0), float(mag.min()) if mag.size else 1.0)
     if -1 in sign:                                                # weights.py:65-68
         scores = scores * sign
     return scores, W.sum(axis=1), cor, sign

@@ -311,3 +311,20 @@ def make_cat_small_case(seed):
     rng = np.random.default_rng(21000 + seed)
     n = min(X.shape[0], int(rng.integers(30, 91)))
     return X[rng.choice(X.shape[0], size=n, replace=False)], model
+
+
+def make_small_int_case(seed):
+    """Metric / Scale.NUM models on five- / seven-point items read as numbers, 20 ... 80 rows: small samples of integers, where covariances can be EXACTLY zero."""
+    rng = np.random.default_rng(22000 + seed)
+    L = int(rng.integers(2, 6))
+    C = _random_dag(L, rng, density=float(rng.uniform(0.3, 0.9)))
+    sizes = [int(rng.integers(1, 5)) for _ in range(L)]
+    n = int(rng.integers(20, 81))
+    X, blocks = _ragged(n, C, sizes, seed=seed)
+    c = int(rng.choice([5, 7]))
+    X = np.clip(np.round((c + 1) / 2.0 + c / 5.0 * (X - X.mean(axis=0)) / X.std(axis=0)), 1, c)
+    modes = "".join("AB"[int(rng.integers(0, 2))] if sizes[l] > 1 else "A" for l in range(L))
+    scheme = ["centroid", "factorial", "path"][int(rng.integers(0, 3))]
+    nonmetric = bool(rng.integers(0, 3) == 0)
+    model = orc.Model(blocks, C, modes, scheme, bool(rng.integers(0, 2)) or nonmetric, tol=(1e-7 if nonmetric else 1e-6), scales=(["NUM"] * X.shape[1]) if nonmetric else None)
+    return X, model, nonmetric

@@ -80,6 +80,8 @@ def check(kind, seed):
         X, model = fc.make_nmx_case(seed)
     elif kind == "metric":
         X, model, nonmetric = fc.make_case(seed)
+    elif kind == "smallint":
+        X, model = fc.make_small_int_case(seed)[:2]
     elif kind == "catbig":
         X, model = fc.make_cat_big_case(seed)
     elif kind == "edge":

@@ -47,21 +47,32 @@ def _model_check(X, model, nonmetric, seed):
             assert cond < DEGENERATE_EIG_RTOL, tag + ": device status %d where the oracle runs out of iterations, conditioning %.3g (%s)" % (g["status"], cond, what)
         return "notconv"
     except Exception:                                      # noqa: BLE001  (a singular system: numpy raises LinAlgError where the reference's statsmodels / lstsq would)
-        assert g["status"] != 0, tag + ": the oracle cannot estimate this model, the device reports PLSPM_OK"
+        if g["status"] == 0:
+            # (an exactly collinear Mode-B block: the oracle's lstsq meets NaN where the reference's gelsd -- at its rank threshold -- went to 1e13, the device returns the
+            #  minimum-norm weights either way: DESIGN 6, "the reference's coin toss"; anything else is a failure)
+            cond, what = oracle_conditioning(X, model)
+            assert cond < DEGENERATE_EIG_RTOL, tag + ": the oracle cannot estimate this model (conditioning %.3g, %s), the device reports PLSPM_OK" % (cond, what)
         return "oracle-raised"
     if not all(np.all(np.isfinite(r[k])) for k in ("weights", "path_coef", "r2", "loadings", "scores")):
         assert g["status"] != 0 or not all(np.all(np.isfinite(g[k])) for k in ("weights", "path_coef", "r2", "loadings", "scores")), tag + ": oracle outputs not finite, device finite and PLSPM_OK"
         return "oracle-nonfinite"
     if g["status"] != 0:
         # a device-only status must be explained by the oracle's own conditioning on these rows -- it can turn the suite red
+        if _fit_is_a_coin_toss(X, model):                      # (two single-item LVs whose items are exactly uncorrelated: the reference normalises an inner estimate of 1e-18, the device meets 0 / 0)
+            return "coin-toss"
         assert_device_status_justified(g["status"], X, model, tag)
         return "device-status-%d" % g["status"]
-    assert g["iterations"] == r["iterations"], tag
-    assert_close(g["weights"], r["weights"], RTOL, ATOL, what=tag)
-    assert_close(g["path_coef"], r["path_coef"], RTOL, ATOL, what=tag)
-    assert_close(g["r2"], r["r2"], RTOL, ATOL, what=tag)
-    assert_close(g["loadings"], r["loadings"], RTOL, ATOL, what=tag)
-    assert_close(g["scores"], r["scores"], 1e-6, 1e-8, what=tag)
+    try:
+        assert g["iterations"] == r["iterations"], tag
+        assert_close(g["weights"], r["weights"], RTOL, ATOL, what=tag)
+        assert_close(g["path_coef"], r["path_coef"], RTOL, ATOL, what=tag)
+        assert_close(g["r2"], r["r2"], RTOL, ATOL, what=tag)
+        assert_close(g["loadings"], r["loadings"], RTOL, ATOL, what=tag)
+        assert_close(g["scores"], r["scores"], 1e-6, 1e-8, what=tag)
+    except AssertionError:
+        if not _fit_is_a_coin_toss(X, model):                  # (e.g. the centroid sign of a correlation that is exactly zero in a small sample of integers: _oracle_coin_toss)
+            raise
+        return "coin-toss"
     n = X.shape[0]
     rows, status, iters = nm.bootstrap(3, seed=seed)
     corr = orc.correction(n)
@@ -70,9 +81,25 @@ def _model_check(X, model, nonmetric, seed):
         if not _replicate_comparable(X, model, idx, corr, status[b], tag + " replicate %d" % b):
             continue
         mine, its = orc.bootstrap_replicate(X, model, idx, corr)
-        assert its == iters[b], tag + " replicate %d" % b
-        assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+        try:
+            assert its == iters[b], tag + " replicate %d" % b
+            assert_close(rows[b], mine, 1e-6, 1e-9, what=tag + " replicate %d" % b)
+        except AssertionError:
+            if not _fit_is_a_coin_toss(X[idx], model):
+                raise
     return "ok"
+
+
+def _fit_is_a_coin_toss(X, model):
+    """The oracle's own run on these rows passes through a decision the reference makes on rounding residue (plspm_oracle.DIAG)."""
+    orc.DIAG = {}
+    try:
+        with np.errstate(all="ignore"):
+            orc.fit(X, model)
+    except Exception:                                      # noqa: BLE001
+        pass
+    diag, orc.DIAG = orc.DIAG, None
+    return _oracle_coin_toss(diag)
 
 
 def _replicate_comparable(X, model, idx, corr, status, tag):
@@ -88,7 +115,8 @@ def _replicate_comparable(X, model, idx, corr, status, tag):
         assert status != 0, tag + ": the oracle cannot estimate this replicate, the device reports PLSPM_OK"
         return False
     if status != 0:
-        assert_device_status_justified(int(status), X[idx], model, tag)
+        if not _fit_is_a_coin_toss(X[idx], model):
+            assert_device_status_justified(int(status), X[idx], model, tag)
         return False
     return True
 
@@ -262,9 +290,9 @@ def test_random_num_model_on_the_one_launch_route(seed):
 # explicit index lists against the oracle, through the wave step where it covers the model and the workgroup step elsewhere; where both exist, the same records from both
 def _oracle_coin_toss(diag):
     """True when the oracle's run passed through a decision the reference itself makes on rounding residue (plspm_oracle.DIAG): a direction tie, category means that tie, an
-    inner estimate of residue, linked scores that are uncorrelated to rounding (small samples of integer codes meet these EXACTLY on the device's count arithmetic)."""
+    inner estimate of residue, linked scores that are uncorrelated to rounding, a sign rule settled by the sign bit of such a correlation (small samples of integer codes meet these EXACTLY on the device's count arithmetic)."""
     return (diag.get("min_direction_margin", 1.0) < 1e-9 or diag.get("min_quant_var_over_z", 1.0) < 1e-20 or diag.get("min_z_scale", 1.0) < 1e-12 or
-            diag.get("min_linked_score_corr", 1.0) < 1e-12)
+            diag.get("min_linked_score_corr", 1.0) < 1e-12 or diag.get("min_decisive_vote_corr", 1.0) < 1e-12)
 
 
 def _cat_case_check(seed, big=False):
@@ -753,3 +781,11 @@ def _rare_indicator_check(seed):
 @pytest.mark.parametrize("seed", range(24))
 def test_rare_indicator_constant_in_some_replicates(seed):
     _rare_indicator_check(seed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_model_on_a_small_sample_of_integers(seed):
+    """fuzz_cases.make_small_int_case: 20 ... 80 rows of five- / seven-point items read as numbers -- covariances that are exactly zero, blocks that are exactly collinear."""
+    from fuzz_cases import make_small_int_case
+    X, model, nonmetric = make_small_int_case(seed)
+    _model_check(X, model, nonmetric, seed)
