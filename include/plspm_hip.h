@@ -135,6 +135,9 @@ const char* plspm_last_error(const plspm_model_t* m);
  *                     (nmg_kernel<1>); records equal to ~1e-13, equal iteration counts.  Read-only "last_nm_wave"
  *   "nm_c10"          1 (default) | 0   (round 6) among those, items of nine or ten categories (the reference's mobi / ECSI data): the ten-category instantiation
  *                     of the wave step, two waves per SIMD, instead of the sixteen-category one, which runs alone on its SIMD -- the same arithmetic, identical records
+ *   "nm_vlong"        1 (default) | 0   (round 6) verification of the one-launch categorical batch: behind the fourth round of eight steps the replicates still
+ *                     iterating are the few that never converge; their remaining steps (up to 72) are verified in ONE round where the slots fit, instead of
+ *                     nine more rounds with a host read-back each -- the same slots, the same decisions
  *   "nm_direct16"     1 (default) | 0   (round 5) bootstrap of such models on the int8 route: the product writes the replicates' co-occurrence counts
  *                     as uint16 matrices itself (upper triangle; mirrored through LDS by nmg_kernel<4>) instead of fp64 moment matrices that a scatter
  *                     pass turns into the same integers -- bit-identical records.  Read-only "last_nm_direct16"

@@ -554,7 +554,9 @@ __global__ void __launch_bounds__(64 * NW) nm_conv_dense_kernel(const double* __
 // One workgroup, two sweeps: wave w owns a contiguous range of replicates, counts its virtual problems per step, then -- behind one barrier -- files them.
 template <int JR>
 __global__ void __launch_bounds__(1024) nm_vlist_kernel(const int* __restrict__ steps, long nproblems, int j0, int* __restrict__ vb, int* __restrict__ vj,
-                                                         int* __restrict__ count, double* __restrict__ vsum, int* __restrict__ force, int* __restrict__ host_max) {
+                                                         int* __restrict__ count, double* __restrict__ vsum, int* __restrict__ force, int* __restrict__ host_max, int cap) {
+    // `cap` > 0 (a long round behind the batch's main body: the few replicates that are still iterating, many steps each): more than `cap` slots would not fit the
+    // round's buffers -- nothing is filed then, host_max[3] = 1, and the host walks the same steps in short rounds
     __shared__ int wtot[16][JR];
     __shared__ int smax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -586,7 +588,8 @@ __global__ void __launch_bounds__(1024) nm_vlist_kernel(const int* __restrict__ 
         base[jj] = total + before;
         total += all;
     }
-    for (long b0 = w0; b0 < w1; b0 += 64) {
+    const bool over = cap > 0 && total > cap;
+    for (long b0 = w0; b0 < (over ? w0 : w1); b0 += 64) {
         const long b = b0 + lane;
         const int st = b < w1 ? steps[b] : 0;
 #pragma unroll
@@ -601,7 +604,7 @@ __global__ void __launch_bounds__(1024) nm_vlist_kernel(const int* __restrict__ 
         }
     }
     __syncthreads();
-    if (tid == 0) { *count = total; if (host_max) *host_max = smax; }
+    if (tid == 0) { *count = over ? 0 : total; if (host_max) { host_max[0] = smax; if (cap > 0) host_max[3] = over ? 1 : 0; } }
 }
 
 // table[g][q][lane] of the virtual problems: q < P old coefficients (step j - 1), q < 2P new (step j), then k_old[L], k_new[L], live flag -- the layout

@@ -98,7 +98,7 @@ struct plspm_model {
     bool err_clean = false;       // the device error word is zero and no call since could have raised it (plspm_detail_bootstrap)
     // launch-geometry options (plspm_model_set_option); validated there, never read from the environment
     struct Tune { int wide_nw = 4, fit_chunks = 0, conv_pass = 0, conv_gy = 0, nm_threads = 0, solver_threads = 128, scores_tile = 0, gram_lds_kb = 0;
-                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, solver_quad = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60, boot_align = 0, i8_persist = 0, i8_min_slices = 0, i8_nostore = 0, nm_wave = 1, nm_live = 1, nm_mfma = 1, nm_direct16 = 1, i8_nibbles = 1, nm_wave16 = 1, nm_verify_rows = 0, nm_bound_shift = 0, wide_ring = 4, nm_subset = 4, nm_cat_one = 1, nm_cpl = 0, nm_c10 = 1; } tune;
+                  int gram_path = 0, i8_slices = 0, i8_min_batch = 1, i8_waves = 8, i8_rt = 0, i8_short = -1, i8_cus = 0, upload_direct = 0, i8_dma = 0, i8_variant = -1, solver_rows = 1, solver_wave = 1, solver_quad = 1, nm_counts8 = 1, nm_fast_lds = 1, nm_k16 = 1, nm_codes = 1, i8_ind = 1, i8_shape = 16, resample_aux = 0, i8_sched = 0, i8_priv = 1, boot_chunks = 0, boot_ratio = 60, boot_align = 0, i8_persist = 0, i8_min_slices = 0, i8_nostore = 0, nm_wave = 1, nm_live = 1, nm_mfma = 1, nm_direct16 = 1, i8_nibbles = 1, nm_wave16 = 1, nm_verify_rows = 0, nm_bound_shift = 0, wide_ring = 4, nm_subset = 4, nm_cat_one = 1, nm_cpl = 0, nm_c10 = 1, nm_vlong = 1; } tune;
     // int8 digit-plane Gram of bootstrap batches (kernels_gram_i8.h): per data set the digit planes `zs` of all pair products and the
     // pair tables (p, q, k, slot in the packed matrix | 2^-k); per call the dense int8 multiplicities `cd`
     Buf zs, cd, cd1, err2, pair_tab, pair_scale, zs_stat, codes, ind8, tab8, scl8, pp_ctl;      // pp_ctl: tile counters of the persistent Gram (kernels_gram_i8p.h GramI8PPCtl)

@@ -471,6 +471,7 @@ int plspm_model_set_option(plspm_model_t* m, const char* key, int32_t value) {
     else if (k == "nm_subset") { if (value < 0 || value > 100) return bad(); m->tune.nm_subset = value; }      // categorical wave step: 0 every stop-rule pass over all rows (rounds 1-5) | n >= 1: the step stops on its own upper bound and its pass reads n tol / bound of the rows (lower bound; default 4)
     else if (k == "nm_cpl") { if (value != 0 && value != 8 && value != 6) return bad(); m->tune.nm_cpl = value; }      // categorical wave step: 0 automatic (six aug columns per lane where they cover the model) | 8 eight per lane (round 5) | 6 six wherever the layout allows (probes: plspm_nonmetric.hip `cpl6`)
     else if (k == "nm_c10") { if (value != 0 && value != 1) return bad(); m->tune.nm_c10 = value; }      // categorical wave step, items of nine / ten categories: 1 the ten-category instantiation (two waves per SIMD) | 0 the sixteen-category one
+    else if (k == "nm_vlong") { if (value != 0 && value != 1) return bad(); m->tune.nm_vlong = value; }      // one-launch categorical batch, verification: 1 one long round for the stragglers behind the fourth short one
     else if (k == "nm_cat_one") { if (value != 0 && value != 1) return bad(); m->tune.nm_cat_one = value; }      // 0: the categorical wave step launch by launch (round 5 / the bound + row-subset form of round 6)
     else if (k == "nm_bound_shift") { if (value < 0 || value > 200) return bad(); m->tune.nm_bound_shift = value; }     // test seam: the solver's stop bound times 2^value (solver_wave16.h NmWaveIo)
     else if (k == "nm_verify_rows") { if (value < 0 || value > 100) return bad(); m->tune.nm_verify_rows = value; }  // percent of the rows the lower-bound pass reads (0: an eighth)
@@ -541,6 +542,7 @@ int plspm_model_get_option(const plspm_model_t* m, const char* key, int32_t* val
     else if (k == "nm_cat_one") *value = m->tune.nm_cat_one;
     else if (k == "nm_cpl") *value = m->tune.nm_cpl;
     else if (k == "nm_c10") *value = m->tune.nm_c10;
+    else if (k == "nm_vlong") *value = m->tune.nm_vlong;
     else if (k == "last_nm_one") *value = m->last_nm_one;
     else if (k == "last_nm_exact") *value = m->last_nm_exact;
     else if (k == "last_nm_wave16") *value = m->last_nm_wave16;

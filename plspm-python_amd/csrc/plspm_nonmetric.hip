@@ -276,10 +276,20 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
         };
         solve(nproblems, nullptr, nullptr);
         bool any_flagged = false;
-        for (int j0 = 1;; j0 += JR) {
+        // (last session of round 6: behind the fourth round the replicates that are still iterating are the few that never converge -- 101 steps each, nine more rounds of four
+        //  launches and a host read-back for a handful of slots -- so the fifth round takes JRB steps at once where their slots fit the buffers of a short round: the list
+        //  kernel checks that itself and files nothing otherwise; option nm_vlong 0: short rounds only)
+        constexpr int JRB = 72;
+        bool long_ok = m->tune.nm_vlong != 0;
+        for (int j0 = 1;;) {
+            const bool long_round = long_ok && j0 > 4 * JR;
+            const int jr = long_round ? JRB : JR;
             {
                 ProfScope ps(m, PLSPM_K_SCORES);
-                hipLaunchKernelGGL(nm_vlist_kernel<JR>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (long)nproblems, j0, vb, vj, cnt, vsum, force, h);
+                if (long_round)
+                    hipLaunchKernelGGL(nm_vlist_kernel<JRB>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (long)nproblems, j0, vb, vj, cnt, vsum, force, h, (int)std::min<long>(capV, 0x7fffffffL));
+                else
+                    hipLaunchKernelGGL(nm_vlist_kernel<JR>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (long)nproblems, j0, vb, vj, cnt, vsum, force, h, 0);
                 hipLaunchKernelGGL(nmp::planes_kernel, dim3((unsigned)(ng16V * 16)), dim3(64), 0, m->stream, (const double*)cmaps, cstride, P, L, KS, (const int*)m->d_boff, (const int*)vb,
                                    (const int*)cnt, (uint4*)m->tab8.p, (double2*)m->scl8.p, (const int*)vj, (const double*)kmaps, kstride, vneed, m->tol, nsub, nparts);
                 hipLaunchKernelGGL(pass_kernel, dim3((unsigned)(nparts * ((ng16V + 3) / 4))), dim3(256), 0, m->stream, (const uint4*)m->ind8.p, ntiles16, L, (const unsigned*)cd8, (long)cd8_MT,
@@ -289,6 +299,7 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
             }
             HIPCHK(m, hipEventRecord(m->ev_flag, m->stream));
             HIPCHK(m, hipEventSynchronize(m->ev_flag));
+            if (long_round && h[3] == 1) { long_ok = false; continue; }      // (too many slots: nothing was filed; the same steps again, eight at a time)
             const int most = h[0], flagged = h[1];
             if (flagged > 0) {
                 ProfScope ps(m, PLSPM_K_SCORES);
@@ -304,7 +315,8 @@ int run_nonmetric(plspm_model* m, long nproblems, const double* Mp, long mp_stri
                 hipLaunchKernelGGL(nm_vcheck_kernel, dim3((unsigned)flagged), dim3(64), 0, m->stream, (const double*)m->nmpartial.p, nparts, (const int*)fb, (const int*)fj, (const int*)(cnt + 1),
                                    m->tol, force);
             }
-            if (j0 + JR > most - 1) break;
+            if (j0 + jr > most - 1) break;
+            j0 += jr;
         }
         if (any_flagged) {
             hipLaunchKernelGGL(nm_vfix_kernel, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, (const int*)force, (long)nproblems, fixlist, cnt + 2, h + 2);
@@ -499,7 +511,7 @@ int run_nonmetric_wave(plspm_model* m, long nb, const SolverOut& so, const void*
     for (int j0 = 1;; j0 += JR) {
         {
             ProfScope ps(m, PLSPM_K_SCORES);
-            hipLaunchKernelGGL(nm_vlist_kernel<JR>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, nb, j0, vb, vj, cnt, vsum, force, h);
+            hipLaunchKernelGGL(nm_vlist_kernel<JR>, dim3(1), dim3(1024), 0, m->stream, (const int*)steps, nb, j0, vb, vj, cnt, vsum, force, h, 0);
             hipLaunchKernelGGL(nm_vtable_kernel, dim3((unsigned)ngroupsV, (unsigned)((table_rows + 63) / 64)), dim3(256), 0, m->stream, (const double*)maps, maps_stride, P, L, (const int*)vb,
                                (const int*)vj, (const int*)cnt, (double*)m->ctable.p, vneed, m->tol, nblocks_all, cap_blocks, fixed_blocks);
             hipLaunchKernelGGL(nm_verify_kernel, dim3((unsigned)(cap_blocks * gyV)), dim3(512), verify_lds, m->stream, (const double*)m->Xt.p, nsub, m->PA, P, L, (const int*)m->d_boff,

@@ -240,3 +240,30 @@ def test_api_bootstrap_of_a_hoc_model_on_ordinal_data():
     row, _ = Plspm._replicate_runner(config, calculator, observations)(_native.bootstrap_indices(11, 0, 250))
     assert_close(boot.replicates()[0], row, 1e-7, 1e-10)          # (the batched second stage works on moments, the single estimate on the scores)
     assert boot.r_squared().shape[0] == 3 and boot.total_effects().shape[0] == 8
+
+
+@pytest.mark.parametrize("tol", [1e-7, 1e-30])
+def test_long_verification_round_for_the_stragglers_changes_nothing(tol):
+    """Round 6 (last session): behind the fourth round of eight steps the first stage's verification takes the stragglers' remaining steps in ONE round (option nm_vlong; the
+    list kernel files nothing and the host falls back to short rounds where the slots do not fit -- tol 1e-30: every replicate runs its 101 steps).  Same statuses, iteration
+    counts and bits of the records as the short rounds; at 1e-7 the call holds replicates that never converge (first stage: poisoned, PLSPM_NONFINITE after "101" trips of the
+    second stage, which a NaN criterion now ends at once)."""
+    import plspm.weights as w
+    from plspm.estimator import Estimator
+    mobi, config, scheme = _ordinal_hoc("path")
+    observations = config.filter(mobi)
+    calculator = w.WeightsCalculatorFactory(config, 100, tol, np.sqrt(250 / 249), scheme, 0)
+    pair = Estimator(config).two_stage_bootstrap_handles(calculator, observations)
+    B = 5000 if tol > 1e-10 else 600
+    assert pair.native.get_option("nm_vlong") == 1
+    a = pair.native.bootstrap(B, seed=1)
+    pair.native.set_option("nm_vlong", 0)
+    b = pair.native.bootstrap(B, seed=1)
+    pair.native.set_option("nm_vlong", 1)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[0], b[0], equal_nan=True)
+    bad = a[1] != 0
+    if tol > 1e-10:
+        assert 1 <= bad.sum() <= 20 and np.all(a[2][bad] == 101) and a[2][~bad].max() < 40
+    else:
+        assert bad.all()
