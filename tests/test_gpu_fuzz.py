@@ -335,7 +335,8 @@ def _cat_case_check(seed, big=False):
         try:
             mine, its = orc.bootstrap_replicate(data, model, idx[b], corr)
         except Exception:
-            assert status[b] != 0, tag + " replicate %d: the oracle cannot finish, device status 0" % b
+            # (device status 0 only behind one of the oracle's residue decisions: a direction tie taken the other way can converge where the oracle's run cycles -- seed 30224)
+            assert status[b] != 0 or _fit_is_a_coin_toss(data[idx[b]], model), tag + " replicate %d: the oracle cannot finish, device status 0" % b
             continue
         if not np.all(np.isfinite(mine)):
             continue
