@@ -1036,10 +1036,13 @@ PLSPM_HD bool nm_step(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st, c
     const int iteration = (int)st.scal[2];
     if (iteration > 0) {
         const double conv = ex.sum(nparts, [&](int c) { return partial[c]; });
-        const bool stop = (conv < md.tol) || (iteration > md.max_iter);            // weights.py:183
+        // (a NaN criterion is absorbing -- solver_nmg.h nmg_step --: the problem leaves with the record its max_iter + 1 trips would end in)
+        const bool never = conv != conv;
+        const bool stop = (conv < md.tol) || (iteration > md.max_iter) || never;            // weights.py:183
         ex.one([&]() {
             st.scal[4] = conv;
-            if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+            if (stop) { st.scal[3] = 0.0; if ((iteration > md.max_iter || never) && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+            if (never) st.scal[2] = (double)(md.max_iter + 1);
         });
         if (stop) return false;
         ex.par(P, [&](int p) { st.a_old[p] = st.a_new[p]; st.c_old[p] = st.c_new[p]; });

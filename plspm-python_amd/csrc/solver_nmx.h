@@ -223,10 +223,13 @@ PLSPM_HD bool nmx_step(Ex& ex, const ModelDesc& md, const MissDesc& xd, Workspac
         const double artefact = ex.sum(L, [&](int l) { const double d = fabs(st.k_old[l]) - fabs(st.k_new[l]); return d * d; });
         const double explicit_rows = ex.sum(K * L, [&](int e) { const double d = fabs(x.Yo[e]) - fabs(x.Yn[e]); return x.ck[e / L] * d * d; });
         const double conv = streamed - st.scal[6] * artefact + explicit_rows;
-        const bool stop = (conv < md.tol) || (iteration > md.max_iter);
+        // (a NaN criterion is absorbing -- solver_nmg.h nmg_step --: the problem leaves with the record its max_iter + 1 trips would end in)
+        const bool never = conv != conv;
+        const bool stop = (conv < md.tol) || (iteration > md.max_iter) || never;
         ex.one([&]() {
             st.scal[4] = conv;
-            if (stop) { st.scal[3] = 0.0; if (iteration > md.max_iter && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+            if (stop) { st.scal[3] = 0.0; if ((iteration > md.max_iter || never) && st.scal[1] == (double)ST_OK) st.scal[1] = (double)ST_NOT_CONVERGED; }
+            if (never) st.scal[2] = (double)(md.max_iter + 1);
         });
         if (stop) return false;
         ex.par(P, [&](int p) { st.c_old[p] = st.c_new[p]; st.a_old[p] = st.a_new[p]; });
