@@ -122,6 +122,15 @@ PLSPM_HD void carve_small(Workspace& ws, double* base, int P, int L, int kmax, i
 #define PLSPM_PIVOT_RTOL 1e-13
 #define PLSPM_EIG_RTOL 1e-12
 
+// Scale.NUM / RAW: population std of a column from its raw moments (a = mean of x^2, m = mean of x).  A column that is CONSTANT in this replicate is 0 / 0 in the reference's
+// standardisation (config.py:314): NaN scores, "could not converge" / a failed regression, and the bootstrap's bare except drops the replicate (bootstrap.py:65-66).  On the
+// moments its variance is rounding residue of either sign (a finite "standardised" column of noise with a weight of 1e-9, or NaN, by the luck of the rounding): NaN here
+// whatever the residue, with treated_sd's threshold (the int8 route's digit-plane residue is 1e-10 of the second moment).
+PLSPM_HD double nm_column_sd(double a, double m) {
+    const double var = a - m * m;
+    return sqrt((var > 1e-9 * a) ? var : -1.0);
+}
+
 // Standard deviation of a treated (centred, scaled) metric column from its raw second moment about the upload's shift `dpp`, its sum `mup`, 1 / n and the scale factor.
 // A column that is CONSTANT in this data set -- in a bootstrap: an item whose resample holds one value only (a rare binary indicator, a small sample) -- is centred to exact
 // zeros by the reference: its Mode-A weight is 0, pandas' corrwith gives NaN for its cross-loadings and `(crossloadings * odm).sum(axis=1)` (plspm.py / bootstrap.py:62) skips
@@ -995,7 +1004,7 @@ PLSPM_HD void nm_prepare(Ex& ex, const ModelDesc& md, Workspace& ws, NmState& st
     ex.par(P, [&](int p) {
         const double mu = Mp[packed_index(T, p, P)];
         st.mu[p] = mu;
-        st.sd[p] = sqrt(Mp[packed_index(T, p, p)] * inv_n - (mu * inv_n) * (mu * inv_n));       // population std (config.py:314)
+        st.sd[p] = nm_column_sd(Mp[packed_index(T, p, p)] * inv_n, mu * inv_n);                  // population std (config.py:314); NaN for a constant column
     });
     ex.one([&]() { st.scal[0] = n; st.scal[1] = (double)ST_OK; st.scal[2] = 0.0; st.scal[3] = 1.0; st.scal[4] = 0.0; });
     ex.par_chunks64(ntile * 4, Mp, [&](int chunk, int lane, double m) {

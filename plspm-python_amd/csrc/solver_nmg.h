@@ -264,7 +264,7 @@ PLSPM_HD void nmg_prepare(Ex& ex, const ModelDesc& md, const CatDesc& cd, Worksp
     ex.par(cd.Pm, [&](int p) {
         const int j0 = cd.mv_off[p], C = cd.mv_off[p + 1] - j0;
         if (cd.mv_kind[p] == KIND_NUM) {
-            const double mu = Mn[Q * LD + j0], sd = sqrt(Mn[j0 * LD + j0] - mu * mu);
+            const double mu = Mn[Q * LD + j0], sd = nm_column_sd(Mn[j0 * LD + j0], mu);      // (NaN for a column that is constant in this replicate: solver_core.h)
             x.tq[j0] = 1.0 / sd; x.tc[p] = -mu / sd;
         } else {
             // rank codes 1..C' over the categories PRESENT in this problem (a bootstrap replicate may miss some: util.rank ranks

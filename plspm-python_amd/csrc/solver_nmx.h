@@ -153,7 +153,7 @@ PLSPM_HD void nmx_prepare(Ex& ex, const ModelDesc& md, const MissDesc& xd, Works
             const double w = x.ck[j] * xd.Mk[j * P + p], v = xd.Xk[j * P + p];
             f += w; s1 += w * v; s2 += w * v * v;
         }
-        const double mu = s1 / f, sd = sqrt(s2 / f - mu * mu);
+        const double mu = s1 / f, sd = nm_column_sd(s2 / f, mu);                  // (NaN for a column that is constant in this replicate: solver_core.h)
         st.mu[p] = mu; st.sd[p] = sd;
         const double kappa = sqrt((f - 1.0) / f) / sqrt((n - 1.0) / n);   // treated column (config.py:314) / xh; 1 for a complete column
         const double unit = xd.raw ? kappa : 1.0;                       // Scale.RAW iterates on the treated values themselves

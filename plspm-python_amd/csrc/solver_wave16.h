@@ -137,7 +137,7 @@ PLSPM_HD void solve_problem_wave16(Ex& ex, const ModelDesc& md, const Wave16Ws<L
     ex.mark(1);
     const double inv_n = ex.uniform_d(1.0 / n);
     // NM: population std of the uploaded column (config.py:314) -- the expression of solver_core.h nm_prepare
-    const double sdraw = NM ? sqrt(dpp * inv_n - (mup * inv_n) * (mup * inv_n)) : 1.0;
+    const double sdraw = NM ? nm_column_sd(dpp * inv_n, mup * inv_n) : 1.0;      // (NaN for a column that is constant in this replicate: solver_core.h)
     ws.mu[p] = mup;
     ws.w[p] = NM ? (valid ? sdraw : 1.0) : 1.0;                  // init: block products with w = 1  (NM: sigma_q published for the loop below; the initial weights follow it)
     ex.sync();

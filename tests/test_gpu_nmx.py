@@ -224,3 +224,39 @@ def test_digit_planes_prepared_before_the_incomplete_rows_are_rebuilt():
         f64 = nm.bootstrap(40, seed=11)
         assert np.array_equal(f64[2], want[2])
         assert_close(f64[0], want[0], 1e-9, 1e-12)
+
+
+@pytest.mark.parametrize("route", ["one_launch", "launch_by_launch", "incomplete_rows"])
+def test_a_replicate_that_can_never_converge_keeps_the_record_of_max_iter_plus_one_trips(route):
+    """Scale.NUM: a column that is constant in a replicate standardises to NaN (the reference iterates its 101 trips on NaN scores and drops the replicate, weights.py:183-186 /
+    bootstrap.py:65-66).  The device ends such a problem at the first NaN stop criterion -- it is absorbing -- and must leave the record of the full run: a status != 0 and
+    max_iter + 1 iterations, on the one-launch form, the launch-by-launch step (nm_step) and the step for incomplete rows (nmx_step); its neighbours are untouched.
+    (Before the last session of round 6 the column's variance was rounding residue of either sign: a finite column of noise with a weight of 1e-9 and PLSPM_OK, or NaN -- solver_core.h
+    nm_column_sd.)"""
+    from plspm import _native
+    C = orc.chain_C(3)
+    X, blocks = orc.synth(120, C, 3, seed=44)
+    X[:, 0] = 0.0; X[:4, 0] = 1.0                               # a rare indicator: resamples of rows 4 ... 119 only see a constant
+    model = orc.Model(blocks, C, "AAA", "path", True, tol=1e-6, scales=["NUM"] * X.shape[1])
+    Xn = X.copy()
+    if route == "incomplete_rows":
+        Xn[7, 4] = np.nan; Xn[30, 8] = np.nan
+    nm, inv = gpu_model(Xn, model)
+    if route == "launch_by_launch":
+        nm.set_option("nm_wave16", 0)
+    rs = np.random.RandomState(3)
+    idx = np.vstack([np.arange(120), 4 + rs.randint(116, size=120), rs.randint(120, size=120), 4 + rs.randint(116, size=120)]).astype(np.int32)
+    rows, status, iters = nm.bootstrap(4, idx=idx)
+    assert status[0] == 0 and status[2] == 0 and status[1] != 0 and status[3] != 0, status
+    assert iters[1] == model.max_iter + 1 and iters[3] == model.max_iter + 1 and 1 <= iters[0] < 30 and 1 <= iters[2] < 30, iters
+    corr = orc.correction(120)
+    for b in (0, 2):
+        mine, its = orc.bootstrap_replicate(Xn, model, idx[b], corr)
+        assert its == iters[b]
+        P = X.shape[1]
+        ne = (rows.shape[1] - 2 * P - 3) // 2
+        got = np.concatenate((rows[b][:P][inv], rows[b][P:P + 3 + 2 * ne], rows[b][P + 3 + 2 * ne:][inv]))
+        assert_close(got, mine, RTOL, ATOL)
+    for b in (1, 3):
+        with pytest.raises((orc.NotConverged, np.linalg.LinAlgError)), np.errstate(all="ignore"):      # (the path scheme's regression meets the NaN scores first)
+            orc.bootstrap_replicate(Xn, model, idx[b], corr)
